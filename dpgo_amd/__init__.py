@@ -1,0 +1,19 @@
+"""dpgo_amd -- MI355X-native local solver for dpgo's per-agent RBCD step.
+
+Host-side mirror of the reference interface (PoseGraph, QuadraticProblem, QuadraticOptimizer,
+LiftedSEManifold, ROptParameters, ROPTResult) over the C ABI of libdpgo_hip.so
+(include/dpgo_hip.h).  Importing this package loads the shared library and fails loudly if it
+has not been built; there is no CPU fallback.
+"""
+from . import lib as _lib
+
+_lib.load()  # ImportError if libdpgo_hip.so is missing
+
+from .lib import DpgoError, device_count  # noqa: E402
+from .measurements import RelativeSEMeasurements, partition_contiguous, read_g2o_file  # noqa: E402
+from .solver import (LiftedSEManifold, PoseGraph, QuadraticOptimizer, QuadraticProblem,  # noqa: E402
+                     ROptParameters, ROPTResult)
+
+__all__ = ["DpgoError", "device_count", "RelativeSEMeasurements", "partition_contiguous", "read_g2o_file",
+           "LiftedSEManifold", "PoseGraph", "QuadraticOptimizer", "QuadraticProblem", "ROptParameters",
+           "ROPTResult"]

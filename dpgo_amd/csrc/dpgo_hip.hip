@@ -1,0 +1,833 @@
+// dpgo_hip.hip -- host driver + C ABI (include/dpgo_hip.h) of the MI355X-native RBCD local solver.
+//
+// Replaces, behind the reference's own interface, QuadraticProblem (src/QuadraticProblem.cpp),
+// QuadraticOptimizer (src/QuadraticOptimizer.cpp), the ROPTLIB RTRNewton / tCG_TR loop it drives and
+// the LiftedSEManifold operations (src/manifold/*.cpp).  All vectors stay in HBM for the whole solve;
+// the host only enqueues kernels and polls a 200-byte state record every few tCG iterations.
+#include "kernels.h"
+
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/dpgo_hip.h"
+
+using namespace dpgo;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg) {
+  g_err = msg;
+  return code;
+}
+
+#define HIPC(expr)                                                                              \
+  do {                                                                                          \
+    hipError_t e_ = (expr);                                                                     \
+    if (e_ != hipSuccess)                                                                       \
+      return fail(DPGO_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_) + " (" + __FILE__ + \
+                                    ":" + std::to_string(__LINE__) + ")");                      \
+  } while (0)
+
+#define CHK(expr)                \
+  do {                           \
+    int rc_ = (expr);            \
+    if (rc_ != DPGO_OK) return rc_; \
+  } while (0)
+
+// (d, r) pairs with compiled kernels
+#define DPGO_FOR_DR(M) M(2, 2) M(2, 3) M(2, 4) M(2, 5) M(3, 3) M(3, 4) M(3, 5) M(3, 6)
+
+bool supported(int d, int r) {
+#define M(dd, rr) \
+  if (d == dd && r == rr) return true;
+  DPGO_FOR_DR(M)
+#undef M
+  return false;
+}
+
+// DISPATCH(d, r, body): body sees constexpr int D, R
+#define DPGO_CASE(dd, rr, ...)   \
+  case (dd) * 16 + (rr): {       \
+    constexpr int D = dd, R = rr; \
+    __VA_ARGS__;                 \
+  } break;
+#define DISPATCH(d, r, ...)                                                                         \
+  switch ((d) * 16 + (r)) {                                                                         \
+    DPGO_CASE(2, 2, __VA_ARGS__) DPGO_CASE(2, 3, __VA_ARGS__) DPGO_CASE(2, 4, __VA_ARGS__)          \
+    DPGO_CASE(2, 5, __VA_ARGS__) DPGO_CASE(3, 3, __VA_ARGS__) DPGO_CASE(3, 4, __VA_ARGS__)          \
+    DPGO_CASE(3, 5, __VA_ARGS__) DPGO_CASE(3, 6, __VA_ARGS__)                                       \
+    default:                                                                                        \
+      return fail(DPGO_ERR_UNSUPPORTED, "unsupported (d, r)");                                      \
+  }
+
+struct Bsr {
+  int nrows = 0, ncols = 0, nnzb = 0;
+  int32_t* rowptr = nullptr;
+  int32_t* colidx = nullptr;
+  double* vals = nullptr;
+  BsrDev dev() const { return BsrDev{rowptr, colidx, vals}; }
+};
+
+int free_bsr(Bsr& m) {
+  if (m.rowptr) HIPC(hipFree(m.rowptr));
+  if (m.colidx) HIPC(hipFree(m.colidx));
+  if (m.vals) HIPC(hipFree(m.vals));
+  m = Bsr();
+  return DPGO_OK;
+}
+
+}  // namespace
+
+struct dpgo_problem_s {
+  int r = 0, d = 0, n = 0, b = 0, T = 0;
+  int device = 0;
+  hipStream_t own_stream = nullptr;
+  hipStream_t stream = nullptr;
+  Bsr Q;
+  Bsr C;  // inter-agent coupling (rectangular), for G
+  double* G0 = nullptr;
+  double* G = nullptr;
+  bool has_G = false;
+  double* dinv = nullptr;
+  double dinv_shift = -1.0;
+  // work vectors
+  double *x1 = nullptr, *x2 = nullptr, *g1 = nullptr, *g2 = nullptr, *eta = nullptr, *delta = nullptr,
+         *Hd = nullptr, *rr = nullptr, *z = nullptr, *S1 = nullptr, *S2 = nullptr;
+  double* partials = nullptr;  // 5 regions of kMaxGrid*kNP
+  DevState* dstate = nullptr;  // 2 slots
+  DevState* hstate = nullptr;  // pinned
+  int cur = 0;
+  size_t vec_bytes() const { return (size_t)n * T * sizeof(double); }
+  double* pE() const { return partials; }
+  double* pA() const { return partials + 1 * kMaxGrid * kNP; }
+  double* pB() const { return partials + 2 * kMaxGrid * kNP; }
+  double* pH() const { return partials + 3 * kMaxGrid * kNP; }
+  int grid() const {
+    const int P = (64 / b) * kWaves;
+    int tiles = (n + P - 1) / P;
+    if (tiles < 1) tiles = 1;
+    return tiles < kMaxGrid ? tiles : kMaxGrid;
+  }
+  int grid_flat() const {  // elementwise kernels
+    size_t total = (size_t)n * T;
+    size_t g = (total + kBlock - 1) / kBlock;
+    if (g < 1) g = 1;
+    return g < (size_t)kMaxGrid ? (int)g : kMaxGrid;
+  }
+};
+
+namespace {
+
+int set_device(dpgo_problem_s* p) {
+  HIPC(hipSetDevice(p->device));
+  return DPGO_OK;
+}
+
+int upload_bsr(Bsr& m, int nrows, int ncols, int nnzb, int b, const int32_t* rowptr, const int32_t* colidx,
+               const double* vals, hipStream_t s) {
+  CHK(free_bsr(m));
+  m.nrows = nrows;
+  m.ncols = ncols;
+  m.nnzb = nnzb;
+  HIPC(hipMalloc(&m.rowptr, sizeof(int32_t) * (nrows + 1)));
+  HIPC(hipMalloc(&m.colidx, sizeof(int32_t) * (nnzb > 0 ? nnzb : 1)));
+  HIPC(hipMalloc(&m.vals, sizeof(double) * (size_t)(nnzb > 0 ? nnzb : 1) * b * b));
+  HIPC(hipMemcpyAsync(m.rowptr, rowptr, sizeof(int32_t) * (nrows + 1), hipMemcpyHostToDevice, s));
+  if (nnzb > 0) {
+    HIPC(hipMemcpyAsync(m.colidx, colidx, sizeof(int32_t) * nnzb, hipMemcpyHostToDevice, s));
+    HIPC(hipMemcpyAsync(m.vals, vals, sizeof(double) * (size_t)nnzb * b * b, hipMemcpyHostToDevice, s));
+  }
+  HIPC(hipStreamSynchronize(s));
+  return DPGO_OK;
+}
+
+int validate_bsr(int nrows, int ncols, int nnzb, const int32_t* rowptr, const int32_t* colidx, bool need_diag) {
+  if (!rowptr || nnzb < 0 || (nnzb > 0 && !colidx)) return fail(DPGO_ERR_INVALID, "null BSR arrays");
+  if (rowptr[0] != 0 || rowptr[nrows] != nnzb) return fail(DPGO_ERR_INVALID, "BSR rowptr does not span nnzb");
+  for (int i = 0; i < nrows; ++i) {
+    if (rowptr[i + 1] < rowptr[i]) return fail(DPGO_ERR_INVALID, "BSR rowptr not monotone");
+    bool diag = false;
+    for (int t = rowptr[i]; t < rowptr[i + 1]; ++t) {
+      if (colidx[t] < 0 || colidx[t] >= ncols) return fail(DPGO_ERR_INVALID, "BSR column index out of range");
+      if (colidx[t] == i) diag = true;
+    }
+    if (need_diag && !diag) return fail(DPGO_ERR_INVALID, "BSR block row without diagonal block");
+  }
+  return DPGO_OK;
+}
+
+int build_dinv(dpgo_problem_s* p, double shift) {
+  if (!p->Q.vals) return fail(DPGO_ERR_STATE, "Q not set");
+  if (p->dinv_shift == shift) return DPGO_OK;
+  const int g = (p->n + kBlock - 1) / kBlock;
+  if (p->d == 2)
+    hipLaunchKernelGGL(k_build_dinv<2>, dim3(g), dim3(kBlock), 0, p->stream, p->Q.dev(), shift, p->dinv, p->n);
+  else
+    hipLaunchKernelGGL(k_build_dinv<3>, dim3(g), dim3(kBlock), 0, p->stream, p->Q.dev(), shift, p->dinv, p->n);
+  HIPC(hipGetLastError());
+  p->dinv_shift = shift;
+  return DPGO_OK;
+}
+
+int poll_state(dpgo_problem_s* p) {
+  HIPC(hipMemcpyAsync(p->hstate, p->dstate + p->cur, sizeof(DevState), hipMemcpyDeviceToHost, p->stream));
+  HIPC(hipStreamSynchronize(p->stream));
+  return DPGO_OK;
+}
+
+int push_state(dpgo_problem_s* p) {
+  HIPC(hipMemcpyAsync(p->dstate + 0, p->hstate, sizeof(DevState), hipMemcpyHostToDevice, p->stream));
+  HIPC(hipMemcpyAsync(p->dstate + 1, p->hstate, sizeof(DevState), hipMemcpyHostToDevice, p->stream));
+  HIPC(hipStreamSynchronize(p->stream));
+  return DPGO_OK;
+}
+
+// ---- kernel launch helpers (templated on D, R through DISPATCH) ----
+int launch_spmm(dpgo_problem_s* p, const Bsr& M, const double* V, const double* Gadd, double* OUT) {
+  DISPATCH(p->d, p->r, hipLaunchKernelGGL((k_spmm<D, R>), dim3(p->grid()), dim3(kBlock), 0, p->stream, M.dev(),
+                                          V, Gadd, OUT, p->n));
+  HIPC(hipGetLastError());
+  return DPGO_OK;
+}
+
+int launch_grad(dpgo_problem_s* p, const double* X, double* RG, double* S, double* EG) {
+  const double* Gm = p->has_G ? p->G : nullptr;
+  DISPATCH(p->d, p->r, hipLaunchKernelGGL((k_grad<D, R>), dim3(p->grid()), dim3(kBlock), 0, p->stream,
+                                          p->Q.dev(), X, Gm, RG, S, EG, p->pE(), p->n));
+  HIPC(hipGetLastError());
+  return DPGO_OK;
+}
+
+int launch_hess(dpgo_problem_s* p, const double* X, const double* S, const double* V, const double* Gdot,
+                double* HV, double* partials, const DevState* st, int check_tcg) {
+  DISPATCH(p->d, p->r, hipLaunchKernelGGL((k_hess<D, R>), dim3(p->grid()), dim3(kBlock), 0, p->stream,
+                                          p->Q.dev(), X, S, V, Gdot, HV, partials, st, check_tcg, p->n));
+  HIPC(hipGetLastError());
+  return DPGO_OK;
+}
+
+int launch_tcg_update(dpgo_problem_s* p, const double* dinv, int first) {
+  const int g = p->grid();
+  DISPATCH(p->d, p->r,
+           hipLaunchKernelGGL((k_tcg_update<D, R>), dim3(g), dim3(kBlock), 0, p->stream, p->x1, p->g1, dinv,
+                              p->delta, p->Hd, p->eta, p->rr, p->z, p->pA(), g, p->pB(), p->dstate + p->cur,
+                              p->dstate + (p->cur ^ 1), first, p->n));
+  HIPC(hipGetLastError());
+  p->cur ^= 1;
+  return DPGO_OK;
+}
+
+int launch_tcg_dir(dpgo_problem_s* p, int first) {
+  DISPATCH(p->d, p->r,
+           hipLaunchKernelGGL((k_tcg_dir<D, R>), dim3(p->grid_flat()), dim3(kBlock), 0, p->stream, p->z, p->delta,
+                              p->pB(), p->grid(), p->dstate + p->cur, p->dstate + (p->cur ^ 1), first, p->n));
+  HIPC(hipGetLastError());
+  p->cur ^= 1;
+  return DPGO_OK;
+}
+
+int launch_retract(dpgo_problem_s* p, const double* X, const double* eta, double scale, double* X2,
+                   const DevState* st) {
+  DISPATCH(p->d, p->r, hipLaunchKernelGGL((k_retract<D, R>), dim3(p->grid()), dim3(kBlock), 0, p->stream, X, eta,
+                                          scale, X2, st, p->n));
+  HIPC(hipGetLastError());
+  return DPGO_OK;
+}
+
+int launch_rtr_update(dpgo_problem_s* p) {
+  const int g = p->grid();
+  DISPATCH(p->d, p->r,
+           hipLaunchKernelGGL((k_rtr_update<D, R>), dim3(p->grid_flat()), dim3(kBlock), 0, p->stream, p->x1, p->x2,
+                              p->g1, p->g2, p->S1, p->S2, p->pE(), g, p->pH(), g, p->dstate + p->cur,
+                              p->dstate + (p->cur ^ 1), p->n));
+  HIPC(hipGetLastError());
+  p->cur ^= 1;
+  return DPGO_OK;
+}
+
+int launch_precond(dpgo_problem_s* p, const double* X, const double* V, const double* dinv, double* Z) {
+  DISPATCH(p->d, p->r, hipLaunchKernelGGL((k_precond<D, R>), dim3(p->grid()), dim3(kBlock), 0, p->stream, X, V,
+                                          dinv, Z, p->n));
+  HIPC(hipGetLastError());
+  return DPGO_OK;
+}
+
+int launch_rtr_begin(dpgo_problem_s* p, double tol, double Delta0, double Dmax, int max_inner, int tiny) {
+  hipLaunchKernelGGL(k_rtr_begin, dim3(1), dim3(kBlock), 0, p->stream, p->pE(), p->grid(), p->dstate, tol, Delta0,
+                     Dmax, max_inner, tiny);
+  HIPC(hipGetLastError());
+  p->cur = 0;
+  return DPGO_OK;
+}
+
+struct Counters {
+  int spmm = 0;
+};
+
+// One ROPTLIB SolversTR::Run outer iteration: tCG + retraction + rho test.  State stays on the
+// device; the host polls the tCG "done" flag every `poll` inner iterations.
+int rtr_outer_iteration(dpgo_problem_s* p, const dpgo_ropt_params* prm, const double* dinv, Counters& cnt) {
+  CHK(launch_tcg_update(p, dinv, 1));
+  CHK(launch_tcg_dir(p, 1));
+  const int max_inner = prm->RTR_tCG_iterations;
+  int poll = prm->tcg_poll_interval > 0 ? prm->tcg_poll_interval : 8;
+  int j = 0;
+  while (j < max_inner) {
+    const int chunk = (max_inner - j) < poll ? (max_inner - j) : poll;
+    for (int c = 0; c < chunk; ++c) {
+      CHK(launch_hess(p, p->x1, p->S1, p->delta, nullptr, p->Hd, p->pA(), p->dstate + p->cur, 1));
+      CHK(launch_tcg_update(p, dinv, 0));
+      CHK(launch_tcg_dir(p, 0));
+    }
+    j += chunk;
+    CHK(poll_state(p));
+    if (p->hstate->tcg_done) break;
+  }
+  CHK(launch_retract(p, p->x1, p->eta, 1.0, p->x2, p->dstate + p->cur));
+  CHK(launch_grad(p, p->x2, p->g2, p->S2, nullptr));
+  cnt.spmm += 1;
+  CHK(launch_hess(p, p->x1, p->S1, p->eta, p->g1, p->Hd, p->pH(), p->dstate + p->cur, 0));
+  cnt.spmm += 1;
+  CHK(launch_rtr_update(p));
+  CHK(poll_state(p));
+  return DPGO_OK;
+}
+
+int run_optimize(dpgo_problem_s* p, const dpgo_ropt_params* prm, dpgo_ropt_result* res) {
+  // X is in p->x1 on entry and on exit.  src/QuadraticOptimizer.cpp:26-48.
+  auto t0 = std::chrono::steady_clock::now();
+  Counters cnt;
+  std::memset(res, 0, sizeof(*res));
+  res->tCGStatus = DPGO_TCG_MAXITER;
+  const double* dinv = nullptr;
+  if (prm->precond == DPGO_PRECOND_BLOCK_JACOBI) {
+    CHK(build_dinv(p, prm->precond_shift));
+    dinv = p->dinv;
+  } else if (prm->precond != DPGO_PRECOND_NONE) {
+    return fail(DPGO_ERR_INVALID, "unknown preconditioner");
+  }
+  // statistics before optimisation (:28-29) -- one fused pass: f, rgrad, S
+  CHK(launch_grad(p, p->x1, p->g1, p->S1, nullptr));
+  cnt.spmm += 1;
+  CHK(launch_rtr_begin(p, prm->gradnorm_tol, prm->RTR_initial_radius, 5.0 * prm->RTR_initial_radius,
+                       prm->RTR_tCG_iterations, prm->accept_tiny_decrease));
+  CHK(poll_state(p));
+  res->fInit = p->hstate->fInit;
+  res->gradNormInit = p->hstate->gnInit;
+  int n_hess_total = 0;
+
+  if (prm->method == DPGO_METHOD_RTR) {
+    // trustRegion(): src/QuadraticOptimizer.cpp:50-108
+    if (!p->hstate->rtr_stop) {  // :57-59 early-out
+      if (prm->RTR_iterations == 1) {  // :80-99 shrink the radius until the step is accepted
+        double radius = prm->RTR_initial_radius;
+        int total_steps = 0;
+        while (true) {
+          p->hstate->Delta = radius;
+          p->hstate->Delta_max = radius;
+          p->hstate->outer_iter = 0;
+          CHK(push_state(p));
+          CHK(rtr_outer_iteration(p, prm, dinv, cnt));
+          res->rtr_iterations += 1;
+          if (p->hstate->accepted_last) break;
+          if (total_steps > 10) break;  // "Too many RTR rejections. Returning initial guess." (x1 untouched)
+          radius /= 4.0;
+          total_steps++;
+        }
+      } else {
+        for (int it = 0; it < prm->RTR_iterations; ++it) {
+          CHK(rtr_outer_iteration(p, prm, dinv, cnt));
+          res->rtr_iterations += 1;
+          if (p->hstate->rtr_stop) break;
+          const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+          if (prm->time_bound_s > 0 && el > prm->time_bound_s) break;  // Solver.TimeBound (:78)
+        }
+      }
+      res->tCGStatus = p->hstate->tcg_status;
+      res->rtr_accepted = p->hstate->n_accept;
+      res->latest_step_accepted = p->hstate->accepted_last;
+      n_hess_total = p->hstate->n_hess;
+    }
+    res->fOpt = p->hstate->f1;
+    res->gradNormOpt = p->hstate->ngf;
+  } else if (prm->method == DPGO_METHOD_RGD) {
+    // gradientDescent(): src/QuadraticOptimizer.cpp:110-137 (one fixed-step preconditioned step)
+    const double* step = p->g1;
+    if (prm->RGD_use_preconditioner) {
+      CHK(launch_precond(p, p->x1, p->g1, dinv, p->z));
+      step = p->z;
+    }
+    CHK(launch_retract(p, p->x1, step, -prm->RGD_stepsize, p->x2, nullptr));
+    HIPC(hipMemcpyAsync(p->x1, p->x2, p->vec_bytes(), hipMemcpyDeviceToDevice, p->stream));
+    CHK(launch_grad(p, p->x1, p->g1, p->S1, nullptr));
+    cnt.spmm += 1;
+    CHK(launch_rtr_begin(p, prm->gradnorm_tol, prm->RTR_initial_radius, 5.0 * prm->RTR_initial_radius,
+                         prm->RTR_tCG_iterations, prm->accept_tiny_decrease));
+    CHK(poll_state(p));
+    res->fOpt = p->hstate->f1;
+    res->gradNormOpt = p->hstate->ngf;
+  } else {
+    return fail(DPGO_ERR_INVALID, "unknown method");
+  }
+  res->tcg_iterations = n_hess_total;
+  res->spmm_count = cnt.spmm + n_hess_total;
+  res->success = 1;  // :44 (set unconditionally after a solve)
+  res->elapsedMs = 1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  return DPGO_OK;
+}
+
+int check_ready(dpgo_problem_s* p) {
+  if (!p) return fail(DPGO_ERR_INVALID, "null handle");
+  if (!p->Q.vals) return fail(DPGO_ERR_STATE, "quadratic matrix Q not set");
+  return set_device(p);
+}
+
+int h2d(dpgo_problem_s* p, double* dst, const double* src) {
+  HIPC(hipMemcpyAsync(dst, src, p->vec_bytes(), hipMemcpyHostToDevice, p->stream));
+  return DPGO_OK;
+}
+int d2h(dpgo_problem_s* p, double* dst, const double* src) {
+  HIPC(hipMemcpyAsync(dst, src, p->vec_bytes(), hipMemcpyDeviceToHost, p->stream));
+  HIPC(hipStreamSynchronize(p->stream));
+  return DPGO_OK;
+}
+
+}  // namespace
+
+// =====================================================================================
+extern "C" {
+
+const char* dpgo_version(void) { return "dpgo_hip 0.1 (gfx950)"; }
+const char* dpgo_last_error(void) { return g_err.c_str(); }
+
+int dpgo_device_count(int* count) {
+  if (!count) return fail(DPGO_ERR_INVALID, "null count");
+  int c = 0;
+  hipError_t e = hipGetDeviceCount(&c);
+  if (e != hipSuccess) {
+    *count = 0;
+    return fail(DPGO_ERR_HIP, std::string("hipGetDeviceCount: ") + hipGetErrorString(e));
+  }
+  *count = c;
+  return DPGO_OK;
+}
+
+void dpgo_ropt_params_default(dpgo_ropt_params* p) {
+  if (!p) return;
+  p->method = DPGO_METHOD_RTR;
+  p->verbose = 0;
+  p->gradnorm_tol = 1e-2;
+  p->RGD_stepsize = 1e-3;
+  p->RGD_use_preconditioner = 1;
+  p->RTR_iterations = 3;
+  p->RTR_tCG_iterations = 50;
+  p->RTR_initial_radius = 100.0;
+  p->precond = DPGO_PRECOND_BLOCK_JACOBI;
+  p->precond_shift = 1e-1;
+  p->accept_tiny_decrease = 1;
+  p->tcg_poll_interval = 8;
+  p->time_bound_s = 5.0;
+}
+
+int dpgo_supported(int d, int r) { return supported(d, r) ? 1 : 0; }
+
+int dpgo_problem_create(dpgo_problem_t* out, int r, int d, int n, int device) {
+  if (!out) return fail(DPGO_ERR_INVALID, "null out");
+  *out = nullptr;
+  if (n <= 0 || r < d || d < 2 || d > 3) return fail(DPGO_ERR_INVALID, "need n > 0, r >= d, d in {2,3}");
+  if (!supported(d, r)) return fail(DPGO_ERR_UNSUPPORTED, "(d, r) not compiled in");
+  int cnt = 0;
+  CHK(dpgo_device_count(&cnt));
+  if (cnt <= 0) return fail(DPGO_ERR_HIP, "no HIP device (this library has no CPU fallback)");
+  if (device < 0 || device >= cnt) return fail(DPGO_ERR_INVALID, "device index out of range");
+  auto* p = new dpgo_problem_s();
+  p->r = r;
+  p->d = d;
+  p->n = n;
+  p->b = d + 1;
+  p->T = p->b * r;
+  p->device = device;
+  int rc = [&]() -> int {
+    HIPC(hipSetDevice(device));
+    HIPC(hipStreamCreateWithFlags(&p->own_stream, hipStreamNonBlocking));
+    p->stream = p->own_stream;
+    const size_t vb = p->vec_bytes();
+    double** vecs[] = {&p->x1, &p->x2, &p->g1, &p->g2, &p->eta, &p->delta, &p->Hd, &p->rr, &p->z, &p->G, &p->G0};
+    for (auto v : vecs) {
+      HIPC(hipMalloc(v, vb));
+      HIPC(hipMemsetAsync(*v, 0, vb, p->stream));
+    }
+    HIPC(hipMalloc(&p->S1, sizeof(double) * (size_t)n * d * d));
+    HIPC(hipMalloc(&p->S2, sizeof(double) * (size_t)n * d * d));
+    HIPC(hipMalloc(&p->dinv, sizeof(double) * (size_t)n * p->b * p->b));
+    HIPC(hipMalloc(&p->partials, sizeof(double) * 5 * kMaxGrid * kNP));
+    HIPC(hipMemsetAsync(p->partials, 0, sizeof(double) * 5 * kMaxGrid * kNP, p->stream));
+    HIPC(hipMalloc(&p->dstate, sizeof(DevState) * 2));
+    HIPC(hipHostMalloc(&p->hstate, sizeof(DevState)));
+    HIPC(hipStreamSynchronize(p->stream));
+    return DPGO_OK;
+  }();
+  if (rc != DPGO_OK) {
+    dpgo_problem_destroy(p);
+    return rc;
+  }
+  *out = p;
+  return DPGO_OK;
+}
+
+int dpgo_problem_destroy(dpgo_problem_t p) {
+  if (!p) return DPGO_OK;
+  (void)hipSetDevice(p->device);
+  if (p->own_stream) (void)hipStreamSynchronize(p->own_stream);
+  free_bsr(p->Q);
+  free_bsr(p->C);
+  double* vecs[] = {p->x1, p->x2, p->g1, p->g2, p->eta, p->delta, p->Hd, p->rr, p->z, p->G, p->G0,
+                    p->S1, p->S2, p->dinv, p->partials};
+  for (auto v : vecs)
+    if (v) (void)hipFree(v);
+  if (p->dstate) (void)hipFree(p->dstate);
+  if (p->hstate) (void)hipHostFree(p->hstate);
+  if (p->own_stream) (void)hipStreamDestroy(p->own_stream);
+  delete p;
+  return DPGO_OK;
+}
+
+int dpgo_problem_set_stream(dpgo_problem_t p, void* hip_stream) {
+  if (!p) return fail(DPGO_ERR_INVALID, "null handle");
+  CHK(set_device(p));
+  HIPC(hipStreamSynchronize(p->stream));
+  p->stream = hip_stream ? (hipStream_t)hip_stream : p->own_stream;
+  return DPGO_OK;
+}
+
+int dpgo_problem_dims(dpgo_problem_t p, int* r, int* d, int* n, int* nnzb) {
+  if (!p) return fail(DPGO_ERR_INVALID, "null handle");
+  if (r) *r = p->r;
+  if (d) *d = p->d;
+  if (n) *n = p->n;
+  if (nnzb) *nnzb = p->Q.nnzb;
+  return DPGO_OK;
+}
+
+int dpgo_problem_set_Q_bsr(dpgo_problem_t p, int nnzb, const int32_t* rowptr, const int32_t* colidx,
+                           const double* vals) {
+  if (!p) return fail(DPGO_ERR_INVALID, "null handle");
+  if (!vals) return fail(DPGO_ERR_INVALID, "null vals");
+  CHK(validate_bsr(p->n, p->n, nnzb, rowptr, colidx, true));
+  CHK(set_device(p));
+  CHK(upload_bsr(p->Q, p->n, p->n, nnzb, p->b, rowptr, colidx, vals, p->stream));
+  p->dinv_shift = -1.0;
+  CHK(build_dinv(p, 1e-1));  // src/PoseGraph.cpp:603
+  HIPC(hipStreamSynchronize(p->stream));
+  return DPGO_OK;
+}
+
+int dpgo_problem_update_Q_values(dpgo_problem_t p, const double* vals) {
+  CHK(check_ready(p));
+  if (!vals) return fail(DPGO_ERR_INVALID, "null vals");
+  HIPC(hipMemcpyAsync(p->Q.vals, vals, sizeof(double) * (size_t)p->Q.nnzb * p->b * p->b, hipMemcpyHostToDevice,
+                      p->stream));
+  const double s = p->dinv_shift > 0 ? p->dinv_shift : 1e-1;
+  p->dinv_shift = -1.0;  // PoseGraph::clearQuadraticMatrix also drops the preconditioner (src/PoseGraph.cpp:352-355)
+  CHK(build_dinv(p, s));
+  HIPC(hipStreamSynchronize(p->stream));
+  return DPGO_OK;
+}
+
+int dpgo_problem_set_G(dpgo_problem_t p, const double* G_host) {
+  if (!p) return fail(DPGO_ERR_INVALID, "null handle");
+  CHK(set_device(p));
+  if (!G_host) {
+    p->has_G = false;
+    return DPGO_OK;
+  }
+  CHK(h2d(p, p->G, G_host));
+  HIPC(hipStreamSynchronize(p->stream));
+  p->has_G = true;
+  return DPGO_OK;
+}
+
+int dpgo_problem_set_G_device(dpgo_problem_t p, const double* G_dev) {
+  if (!p) return fail(DPGO_ERR_INVALID, "null handle");
+  CHK(set_device(p));
+  if (!G_dev) {
+    p->has_G = false;
+    return DPGO_OK;
+  }
+  HIPC(hipMemcpyAsync(p->G, G_dev, p->vec_bytes(), hipMemcpyDeviceToDevice, p->stream));
+  p->has_G = true;
+  return DPGO_OK;
+}
+
+int dpgo_problem_set_G_coupling(dpgo_problem_t p, int ncols, int nnzb, const int32_t* rowptr, const int32_t* colidx,
+                                const double* vals, const double* G0_host) {
+  if (!p) return fail(DPGO_ERR_INVALID, "null handle");
+  if (ncols < 0) return fail(DPGO_ERR_INVALID, "ncols < 0");
+  if (nnzb > 0 && !vals) return fail(DPGO_ERR_INVALID, "null vals");
+  CHK(validate_bsr(p->n, ncols, nnzb, rowptr, colidx, false));
+  CHK(set_device(p));
+  CHK(upload_bsr(p->C, p->n, ncols, nnzb, p->b, rowptr, colidx, vals, p->stream));
+  if (G0_host) {
+    CHK(h2d(p, p->G0, G0_host));
+  } else {
+    HIPC(hipMemsetAsync(p->G0, 0, p->vec_bytes(), p->stream));
+  }
+  HIPC(hipStreamSynchronize(p->stream));
+  return DPGO_OK;
+}
+
+int dpgo_problem_update_G_from_neighbors_device(dpgo_problem_t p, const double* nbr_tiles_dev) {
+  if (!p) return fail(DPGO_ERR_INVALID, "null handle");
+  if (!p->C.rowptr) return fail(DPGO_ERR_STATE, "G coupling not set");
+  if (!nbr_tiles_dev && p->C.nnzb > 0) return fail(DPGO_ERR_INVALID, "null neighbour tiles");
+  CHK(set_device(p));
+  CHK(launch_spmm(p, p->C, nbr_tiles_dev, p->G0, p->G));
+  p->has_G = true;
+  return DPGO_OK;
+}
+
+// ---- QuadraticProblem methods (host pointers) ----
+static int eval_common(dpgo_problem_t p, const double* X) {
+  CHK(check_ready(p));
+  if (!X) return fail(DPGO_ERR_INVALID, "null X");
+  CHK(h2d(p, p->x2, X));
+  return DPGO_OK;
+}
+
+int dpgo_problem_f(dpgo_problem_t p, const double* X, double* f) {
+  if (!f) return fail(DPGO_ERR_INVALID, "null out");
+  CHK(eval_common(p, X));
+  CHK(launch_grad(p, p->x2, nullptr, nullptr, nullptr));
+  CHK(launch_rtr_begin(p, 0.0, 1.0, 1.0, 0, 0));
+  CHK(poll_state(p));
+  *f = p->hstate->f1;
+  return DPGO_OK;
+}
+
+int dpgo_problem_euc_grad(dpgo_problem_t p, const double* X, double* EG) {
+  if (!EG) return fail(DPGO_ERR_INVALID, "null out");
+  CHK(eval_common(p, X));
+  CHK(launch_spmm(p, p->Q, p->x2, p->has_G ? p->G : nullptr, p->g2));
+  return d2h(p, EG, p->g2);
+}
+
+int dpgo_problem_euc_hess(dpgo_problem_t p, const double* V, double* HV) {
+  if (!HV) return fail(DPGO_ERR_INVALID, "null out");
+  CHK(eval_common(p, V));
+  CHK(launch_spmm(p, p->Q, p->x2, nullptr, p->g2));
+  return d2h(p, HV, p->g2);
+}
+
+int dpgo_problem_rie_grad(dpgo_problem_t p, const double* X, double* RG) {
+  if (!RG) return fail(DPGO_ERR_INVALID, "null out");
+  CHK(eval_common(p, X));
+  CHK(launch_grad(p, p->x2, p->g2, nullptr, nullptr));
+  return d2h(p, RG, p->g2);
+}
+
+int dpgo_problem_rie_grad_norm(dpgo_problem_t p, const double* X, double* gn) {
+  if (!gn) return fail(DPGO_ERR_INVALID, "null out");
+  CHK(eval_common(p, X));
+  CHK(launch_grad(p, p->x2, nullptr, nullptr, nullptr));
+  CHK(launch_rtr_begin(p, 0.0, 1.0, 1.0, 0, 0));
+  CHK(poll_state(p));
+  *gn = p->hstate->ngf;
+  return DPGO_OK;
+}
+
+int dpgo_problem_rie_hess(dpgo_problem_t p, const double* X, const double* V, double* HV) {
+  if (!HV || !V) return fail(DPGO_ERR_INVALID, "null pointer");
+  CHK(eval_common(p, X));
+  CHK(h2d(p, p->eta, V));
+  CHK(launch_grad(p, p->x2, nullptr, p->S2, nullptr));
+  CHK(launch_hess(p, p->x2, p->S2, p->eta, nullptr, p->g2, p->pH(), nullptr, 0));
+  return d2h(p, HV, p->g2);
+}
+
+int dpgo_problem_precondition(dpgo_problem_t p, int precond, double shift, const double* X, const double* V,
+                              double* Z) {
+  if (!Z || !V) return fail(DPGO_ERR_INVALID, "null pointer");
+  CHK(eval_common(p, X));
+  CHK(h2d(p, p->eta, V));
+  const double* dinv = nullptr;
+  if (precond == DPGO_PRECOND_BLOCK_JACOBI) {
+    CHK(build_dinv(p, shift));
+    dinv = p->dinv;
+  } else if (precond != DPGO_PRECOND_NONE) {
+    return fail(DPGO_ERR_INVALID, "unknown preconditioner");
+  }
+  CHK(launch_precond(p, p->x2, p->eta, dinv, p->g2));
+  return d2h(p, Z, p->g2);
+}
+
+int dpgo_optimize(dpgo_problem_t p, const dpgo_ropt_params* params, const double* X0, double* Xopt,
+                  dpgo_ropt_result* result) {
+  CHK(check_ready(p));
+  if (!params || !X0 || !Xopt || !result) return fail(DPGO_ERR_INVALID, "null pointer");
+  CHK(h2d(p, p->x1, X0));
+  CHK(run_optimize(p, params, result));
+  return d2h(p, Xopt, p->x1);
+}
+
+int dpgo_optimize_device(dpgo_problem_t p, const dpgo_ropt_params* params, double* X_dev, dpgo_ropt_result* result) {
+  CHK(check_ready(p));
+  if (!params || !X_dev || !result) return fail(DPGO_ERR_INVALID, "null pointer");
+  HIPC(hipMemcpyAsync(p->x1, X_dev, p->vec_bytes(), hipMemcpyDeviceToDevice, p->stream));
+  CHK(run_optimize(p, params, result));
+  HIPC(hipMemcpyAsync(X_dev, p->x1, p->vec_bytes(), hipMemcpyDeviceToDevice, p->stream));
+  HIPC(hipStreamSynchronize(p->stream));
+  return DPGO_OK;
+}
+
+int dpgo_spmm_device(dpgo_problem_t p, const double* V_dev, double* OUT_dev, int add_G) {
+  CHK(check_ready(p));
+  if (!V_dev || !OUT_dev) return fail(DPGO_ERR_INVALID, "null pointer");
+  return launch_spmm(p, p->Q, V_dev, (add_G && p->has_G) ? p->G : nullptr, OUT_dev);
+}
+
+int dpgo_problem_eval_device(dpgo_problem_t p, const double* X_dev, double* f, double* gradnorm) {
+  CHK(check_ready(p));
+  if (!X_dev) return fail(DPGO_ERR_INVALID, "null pointer");
+  CHK(launch_grad(p, X_dev, nullptr, nullptr, nullptr));
+  CHK(launch_rtr_begin(p, 0.0, 1.0, 1.0, 0, 0));
+  CHK(poll_state(p));
+  if (f) *f = p->hstate->f1;
+  if (gradnorm) *gradnorm = p->hstate->ngf;
+  return DPGO_OK;
+}
+
+int dpgo_bench_spmm(dpgo_problem_t p, int reps, int warmup, double* avg_ms) {
+  CHK(check_ready(p));
+  if (reps <= 0 || !avg_ms) return fail(DPGO_ERR_INVALID, "bad arguments");
+  hipEvent_t e0, e1;
+  HIPC(hipEventCreate(&e0));
+  HIPC(hipEventCreate(&e1));
+  for (int i = 0; i < warmup; ++i) CHK(launch_spmm(p, p->Q, p->x1, nullptr, p->x2));
+  HIPC(hipEventRecord(e0, p->stream));
+  for (int i = 0; i < reps; ++i) CHK(launch_spmm(p, p->Q, p->x1, nullptr, p->x2));
+  HIPC(hipEventRecord(e1, p->stream));
+  HIPC(hipEventSynchronize(e1));
+  float ms = 0.f;
+  HIPC(hipEventElapsedTime(&ms, e0, e1));
+  HIPC(hipEventDestroy(e0));
+  HIPC(hipEventDestroy(e1));
+  *avg_ms = (double)ms / reps;
+  return DPGO_OK;
+}
+
+// ---- manifold ----
+namespace {
+struct TmpDev {
+  std::vector<void*> ptrs;
+  ~TmpDev() {
+    for (auto q : ptrs) (void)hipFree(q);
+  }
+  int alloc(double** out, size_t bytes) {
+    HIPC(hipMalloc(out, bytes));
+    ptrs.push_back(*out);
+    return DPGO_OK;
+  }
+};
+int manifold_args(int r, int d, int n, int device) {
+  if (n <= 0 || r < d || d < 2 || d > 3) return fail(DPGO_ERR_INVALID, "need n > 0, r >= d, d in {2,3}");
+  if (!supported(d, r)) return fail(DPGO_ERR_UNSUPPORTED, "(d, r) not compiled in");
+  int cnt = 0;
+  CHK(dpgo_device_count(&cnt));
+  if (cnt <= 0) return fail(DPGO_ERR_HIP, "no HIP device (this library has no CPU fallback)");
+  if (device < 0 || device >= cnt) return fail(DPGO_ERR_INVALID, "device index out of range");
+  HIPC(hipSetDevice(device));
+  return DPGO_OK;
+}
+int tiles_grid(int d, int n) {
+  const int P = (64 / (d + 1)) * kWaves;
+  int t = (n + P - 1) / P;
+  if (t < 1) t = 1;
+  return t < kMaxGrid ? t : kMaxGrid;
+}
+}  // namespace
+
+int dpgo_manifold_project_device(int r, int d, int n, const double* M_dev, double* out_dev, void* stream) {
+  return dpgo_axpby_project_device(r, d, n, 1.0, M_dev, 0.0, nullptr, 0.0, nullptr, 1, out_dev, stream);
+}
+
+int dpgo_axpby_project_device(int r, int d, int n, double a, const double* A_dev, double b, const double* B_dev,
+                              double c, const double* C_dev, int project, double* out_dev, void* stream) {
+  if (!A_dev || !out_dev) return fail(DPGO_ERR_INVALID, "null pointer");
+  if (n <= 0) return fail(DPGO_ERR_INVALID, "n <= 0");
+  DISPATCH(d, r, hipLaunchKernelGGL((k_axpby_project<D, R>), dim3(tiles_grid(d, n)), dim3(kBlock), 0,
+                                    (hipStream_t)stream, a, A_dev, b, B_dev, c, C_dev, project, out_dev, n));
+  HIPC(hipGetLastError());
+  return DPGO_OK;
+}
+
+int dpgo_gather_tiles_device(int r, int d, const double* src_dev, const int32_t* idx_dev, int count, double* dst_dev,
+                             void* stream) {
+  if (count == 0) return DPGO_OK;
+  if (!src_dev || !idx_dev || !dst_dev || count < 0) return fail(DPGO_ERR_INVALID, "bad arguments");
+  size_t total = (size_t)count * (d + 1) * r;
+  int g = (int)((total + kBlock - 1) / kBlock);
+  if (g > kMaxGrid) g = kMaxGrid;
+  DISPATCH(d, r, hipLaunchKernelGGL((k_gather_tiles<D, R>), dim3(g), dim3(kBlock), 0, (hipStream_t)stream, src_dev,
+                                    idx_dev, count, dst_dev));
+  HIPC(hipGetLastError());
+  return DPGO_OK;
+}
+
+int dpgo_manifold_project(int r, int d, int n, const double* M, double* out, int device) {
+  if (!M || !out) return fail(DPGO_ERR_INVALID, "null pointer");
+  CHK(manifold_args(r, d, n, device));
+  TmpDev tmp;
+  const size_t vb = sizeof(double) * (size_t)n * (d + 1) * r;
+  double *a = nullptr, *o = nullptr;
+  CHK(tmp.alloc(&a, vb));
+  CHK(tmp.alloc(&o, vb));
+  HIPC(hipMemcpy(a, M, vb, hipMemcpyHostToDevice));
+  CHK(dpgo_manifold_project_device(r, d, n, a, o, nullptr));
+  HIPC(hipMemcpy(out, o, vb, hipMemcpyDeviceToHost));
+  return DPGO_OK;
+}
+
+int dpgo_manifold_tangent_project(int r, int d, int n, const double* X, const double* V, double* out, int device) {
+  if (!X || !V || !out) return fail(DPGO_ERR_INVALID, "null pointer");
+  CHK(manifold_args(r, d, n, device));
+  TmpDev tmp;
+  const size_t vb = sizeof(double) * (size_t)n * (d + 1) * r;
+  double *x = nullptr, *v = nullptr, *o = nullptr;
+  CHK(tmp.alloc(&x, vb));
+  CHK(tmp.alloc(&v, vb));
+  CHK(tmp.alloc(&o, vb));
+  HIPC(hipMemcpy(x, X, vb, hipMemcpyHostToDevice));
+  HIPC(hipMemcpy(v, V, vb, hipMemcpyHostToDevice));
+  DISPATCH(d, r, hipLaunchKernelGGL((k_precond<D, R>), dim3(tiles_grid(d, n)), dim3(kBlock), 0, (hipStream_t) nullptr,
+                                    x, v, (const double*)nullptr, o, n));
+  HIPC(hipGetLastError());
+  HIPC(hipMemcpy(out, o, vb, hipMemcpyDeviceToHost));
+  return DPGO_OK;
+}
+
+int dpgo_manifold_retract(int r, int d, int n, const double* X, const double* eta, double scale, double* out,
+                          int device) {
+  if (!X || !eta || !out) return fail(DPGO_ERR_INVALID, "null pointer");
+  CHK(manifold_args(r, d, n, device));
+  TmpDev tmp;
+  const size_t vb = sizeof(double) * (size_t)n * (d + 1) * r;
+  double *x = nullptr, *v = nullptr, *o = nullptr;
+  CHK(tmp.alloc(&x, vb));
+  CHK(tmp.alloc(&v, vb));
+  CHK(tmp.alloc(&o, vb));
+  HIPC(hipMemcpy(x, X, vb, hipMemcpyHostToDevice));
+  HIPC(hipMemcpy(v, eta, vb, hipMemcpyHostToDevice));
+  DISPATCH(d, r, hipLaunchKernelGGL((k_retract<D, R>), dim3(tiles_grid(d, n)), dim3(kBlock), 0, (hipStream_t) nullptr,
+                                    x, v, scale, o, (const DevState*)nullptr, n));
+  HIPC(hipGetLastError());
+  HIPC(hipMemcpy(out, o, vb, hipMemcpyDeviceToHost));
+  return DPGO_OK;
+}
+
+}  // extern "C"

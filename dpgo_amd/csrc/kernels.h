@@ -1,0 +1,923 @@
+// kernels.h -- hand-written HIP kernels (gfx950 / CDNA4) for the dpgo RBCD local solve.
+//
+// Thread mapping ("PC layout"): one lane owns one column c of one pose tile, i.e. the R
+// contiguous doubles X[i][c][0..R) of the reference layout (r x (d+1)n column-major,
+// include/DPGO/manifold/Poses.h:16-21).  A 64-wide wavefront holds G = 64/(D+1) poses
+// (16 for 3-D, 21 for 2-D), a 256-thread workgroup 4G poses.  A wave's loads and stores of
+// a dense vector are one contiguous span (G*(D+1)*R*8 bytes).  Operations that couple the
+// columns of one pose (tangent projection, Riemannian Hessian correction, block-Jacobi,
+// qf retraction) exchange the pose tile through a wave-private LDS slot.
+//
+// Scalars never leave the device inside a solve: every kernel that produces a dot product
+// writes one partial per workgroup; the NEXT kernel's prologue re-reduces those partials in
+// every workgroup in a fixed order (bit-identical in all workgroups, deterministic
+// run-to-run), advances the tCG / RTR scalar recurrences redundantly in registers, and
+// workgroup 0 publishes the new state to the other slot of a two-slot state buffer.
+// A kernel boundary (~1.5 us on MI355X) is the cheapest grid-wide barrier on this chip
+// (MI355X_MICROARCH.md, price list: barrier-xcd 4-7 us).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace dpgo {
+
+constexpr int kBlock = 256;
+constexpr int kWaves = kBlock / 64;
+constexpr int kMaxGrid = 1024;  // 4 workgroups per CU on 256 CUs
+constexpr int kNP = 4;          // partial sums per workgroup (max over kernels)
+
+enum : int { TCG_NEGCURV = 0, TCG_EXCREGION = 1, TCG_LCON = 2, TCG_SCON = 3, TCG_MAXITER = 4 };
+
+// Device-resident solver state (two slots; kernels read slot `in`, workgroup 0 writes `in^1`).
+struct DevState {
+  // --- RTR (ROPTLIB SolversTR::Run; reference configuration src/QuadraticOptimizer.cpp:64-78)
+  double f1, ngf, Delta, Delta_max, tol;
+  double f2, rho, fInit, gnInit;
+  int outer_iter, rtr_stop, accepted_last, n_accept;
+  int accept_tiny, pad0;
+  // --- tCG (ROPTLIB SolversTR::tCG_TR)
+  double z_r, d_Pd, e_Pd, e_Pe, norm_r0, alpha, theta, kappa;
+  int tcg_j, tcg_done, tcg_status, max_inner;
+  int n_hess, min_inner;
+};
+
+template <int D, int R>
+struct Geo {
+  static constexpr int B = D + 1;
+  static constexpr int T = B * R;       // doubles per pose tile
+  static constexpr int BB = B * B;      // doubles per Q block
+  static constexpr int G = 64 / B;      // poses per wavefront
+  static constexpr int P = G * kWaves;  // poses per workgroup tile
+};
+
+struct LaneId {
+  int wave, g, c;
+};
+template <int D>
+__device__ __forceinline__ LaneId lane_id() {
+  constexpr int B = D + 1;
+  LaneId id;
+  const int l = threadIdx.x & 63;
+  id.wave = threadIdx.x >> 6;
+  id.g = l / B;
+  id.c = l - id.g * B;
+  return id;
+}
+
+// ---------------------------------------------------------------- reductions
+__device__ __forceinline__ double wave_allreduce(double v) {
+  // xor butterfly: every lane ends with the same bits (each level adds a commutative pair)
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+template <int K>
+__device__ __forceinline__ void block_allreduce(double (&v)[K], double* red /* >= kWaves*K */) {
+#pragma unroll
+  for (int k = 0; k < K; ++k) v[k] = wave_allreduce(v[k]);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) red[(threadIdx.x >> 6) * K + k] = v[k];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    double s = red[k];
+#pragma unroll
+    for (int w = 1; w < kWaves; ++w) s += red[w * K + k];
+    v[k] = s;
+  }
+}
+
+// Sum the per-workgroup partials of the previous kernel; identical result in every thread
+// of every workgroup.
+template <int K>
+__device__ __forceinline__ void load_partials(const double* __restrict__ p, int nb, double (&out)[K],
+                                              double* red) {
+#pragma unroll
+  for (int k = 0; k < K; ++k) out[k] = 0.0;
+  for (int i = threadIdx.x; i < nb; i += kBlock) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) out[k] += p[i * kNP + k];
+  }
+  block_allreduce<K>(out, red);
+}
+
+template <int K>
+__device__ __forceinline__ void store_partials(double (&v)[K], double* __restrict__ p, double* red) {
+  block_allreduce<K>(v, red);
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) p[blockIdx.x * kNP + k] = v[k];
+  }
+}
+
+// ---------------------------------------------------------------- small dense pieces
+// Tangent projection of column c of W at Y (ROPTLIB Stiefel::ExtrProjection; the Euclidean
+// factor -- column D -- is untouched).  ys / ws: pose tiles in LDS ([col][R]).
+// Optionally returns s[a] = sym(Y^T W)[a][c].
+template <int D, int R>
+__device__ __forceinline__ void proj_col(const double* ys, const double* ws, int c, const double (&w)[R],
+                                         double (&out)[R], double (&s)[D]) {
+  if (c < D) {
+#pragma unroll
+    for (int a = 0; a < D; ++a) {
+      double p = 0.0, q = 0.0;
+#pragma unroll
+      for (int k = 0; k < R; ++k) {
+        p = fma(ys[a * R + k], ws[c * R + k], p);
+        q = fma(ws[a * R + k], ys[c * R + k], q);
+      }
+      s[a] = 0.5 * (p + q);
+    }
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+      double v = w[k];
+#pragma unroll
+      for (int a = 0; a < D; ++a) v = fma(-ys[a * R + k], s[a], v);
+      out[k] = v;
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < R; ++k) out[k] = w[k];
+#pragma unroll
+    for (int a = 0; a < D; ++a) s[a] = 0.0;
+  }
+}
+
+// Block-Jacobi: z[:,c] = sum_k v[:,k] * Dinv[k][c]   (Dinv symmetric; lane reads row c)
+template <int D, int R>
+__device__ __forceinline__ void jacobi_col(const double* vs /* LDS tile */, const double* __restrict__ dinv_row,
+                                           double (&z)[R]) {
+  constexpr int B = D + 1;
+#pragma unroll
+  for (int a = 0; a < R; ++a) z[a] = 0.0;
+#pragma unroll
+  for (int k = 0; k < B; ++k) {
+    const double dk = dinv_row[k];
+#pragma unroll
+    for (int a = 0; a < R; ++a) z[a] = fma(vs[k * R + a], dk, z[a]);
+  }
+}
+
+template <int R>
+__device__ __forceinline__ void load_col(const double* __restrict__ p, double (&v)[R]) {
+#pragma unroll
+  for (int a = 0; a < R; ++a) v[a] = p[a];
+}
+template <int R>
+__device__ __forceinline__ void store_col(double* __restrict__ p, const double (&v)[R]) {
+#pragma unroll
+  for (int a = 0; a < R; ++a) p[a] = v[a];
+}
+
+// ---------------------------------------------------------------- block-SpMM core
+// acc[:] = (V*Q)[i][c][:] = sum_j sum_k V_j[:,k] * Q[i,j][c][k]      (Q symmetric)
+// replaces Eigen's dense x RowMajor-sparse product in src/QuadraticProblem.cpp:33,39,46,53.
+template <int D, int R>
+__device__ __forceinline__ void spmm_col(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colidx,
+                                         const double* __restrict__ vals, const double* __restrict__ V,
+                                         int i, int c, double (&acc)[R]) {
+  constexpr int B = D + 1, T = B * R, BB = B * B;
+#pragma unroll
+  for (int a = 0; a < R; ++a) acc[a] = 0.0;
+  const int t0 = rowptr[i], t1 = rowptr[i + 1];
+  for (int t = t0; t < t1; ++t) {
+    const int j = colidx[t];
+    const double* __restrict__ q = vals + (size_t)t * BB + c * B;
+    const double* __restrict__ x = V + (size_t)j * T;
+    double qk[B];
+#pragma unroll
+    for (int k = 0; k < B; ++k) qk[k] = q[k];
+#pragma unroll
+    for (int k = 0; k < B; ++k) {
+#pragma unroll
+      for (int a = 0; a < R; ++a) acc[a] = fma(x[k * R + a], qk[k], acc[a]);
+    }
+  }
+}
+
+// ---------------------------------------------------------------- kernel arguments
+struct BsrDev {
+  const int32_t* rowptr;
+  const int32_t* colidx;
+  const double* vals;
+};
+
+// ================================================================ K1: plain SpMM
+// OUT = V*Q (+ Gadd).  QuadraticProblem::EucGrad / EucHessianEta
+// (src/QuadraticProblem.cpp:43-54) and, with a rectangular coupling matrix, PoseGraph::constructG
+// (src/PoseGraph.cpp:493-580).
+template <int D, int R>
+__global__ __launch_bounds__(kBlock) void k_spmm(BsrDev Q, const double* __restrict__ V,
+                                                 const double* __restrict__ Gadd, double* __restrict__ OUT,
+                                                 int n) {
+  using GEO = Geo<D, R>;
+  const LaneId L = lane_id<D>();
+  const int ntiles = (n + GEO::P - 1) / GEO::P;
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int i = tile * GEO::P + L.wave * GEO::G + L.g;
+    if (L.g < GEO::G && i < n) {
+      double acc[R];
+      spmm_col<D, R>(Q.rowptr, Q.colidx, Q.vals, V, i, L.c, acc);
+      const size_t off = (size_t)i * GEO::T + L.c * R;
+      if (Gadd) {
+#pragma unroll
+        for (int a = 0; a < R; ++a) acc[a] += Gadd[off + a];
+      }
+      store_col<R>(OUT + off, acc);
+    }
+  }
+}
+
+// ================================================================ K1+K2: cost + Riemannian gradient
+// One pass over Q gives f(X) = 0.5<XQ,X> + <X,G> (src/QuadraticProblem.cpp:29-41),
+// EG = XQ + G (:43-47), S = sym(Y^T EG_rot) (cached for the Hessian, ROPTLIB EucGradToGrad),
+// RG = proj_X(EG) (:71-79) and |RG|^2 (:81-83).
+// partials: [0] sum(XQ.X)  [1] sum(X.G)  [2] |RG|^2
+template <int D, int R>
+__global__ __launch_bounds__(kBlock) void k_grad(BsrDev Q, const double* __restrict__ X,
+                                                 const double* __restrict__ Gm, double* __restrict__ RG,
+                                                 double* __restrict__ S, double* __restrict__ EGout,
+                                                 double* __restrict__ partials, int n) {
+  using GEO = Geo<D, R>;
+  __shared__ double sm[kWaves][2][GEO::G][GEO::T];
+  __shared__ double red[kWaves * kNP];
+  const LaneId L = lane_id<D>();
+  const int ntiles = (n + GEO::P - 1) / GEO::P;
+  double part[3] = {0.0, 0.0, 0.0};
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int i = tile * GEO::P + L.wave * GEO::G + L.g;
+    const bool ok = (L.g < GEO::G) && (i < n);
+    double eg[R], x[R];
+    const size_t off = (size_t)i * GEO::T + L.c * R;
+    double* ys = ok ? &sm[L.wave][0][L.g][0] : nullptr;
+    double* ws = ok ? &sm[L.wave][1][L.g][0] : nullptr;
+    if (ok) {
+      spmm_col<D, R>(Q.rowptr, Q.colidx, Q.vals, X, i, L.c, eg);
+      load_col<R>(X + off, x);
+#pragma unroll
+      for (int a = 0; a < R; ++a) part[0] = fma(eg[a], x[a], part[0]);
+      if (Gm) {
+#pragma unroll
+        for (int a = 0; a < R; ++a) {
+          const double gv = Gm[off + a];
+          part[1] = fma(x[a], gv, part[1]);
+          eg[a] += gv;
+        }
+      }
+      store_col<R>(ys + L.c * R, x);
+      store_col<R>(ws + L.c * R, eg);
+    }
+    __syncthreads();
+    if (ok) {
+      double out[R], s[D];
+      proj_col<D, R>(ys, ws, L.c, eg, out, s);
+#pragma unroll
+      for (int a = 0; a < R; ++a) part[2] = fma(out[a], out[a], part[2]);
+      if (RG) store_col<R>(RG + off, out);
+      if (EGout) store_col<R>(EGout + off, eg);
+      if (S && L.c < D) {
+#pragma unroll
+        for (int a = 0; a < D; ++a) S[(size_t)i * D * D + L.c * D + a] = s[a];
+      }
+    }
+    __syncthreads();
+  }
+  store_partials<3>(part, partials, red);
+}
+
+// ================================================================ K1+K3+K2: Riemannian Hessian-vector product
+// HV = proj_X( V*Q - V_rot * S ),  S = sym(Y^T EG_rot)   (QuadraticProblem::EucHessianEta,
+// src/QuadraticProblem.cpp:49-54, + ROPTLIB Stiefel::EucHvToHv + ProductManifold::Projection).
+// partials: [0] <V,HV>   [1] <V,Gdot> (if Gdot != null; used for the RTR model decrease)
+// When `st` is given the kernel is a tCG step and exits early once tCG has finished.
+template <int D, int R>
+__global__ __launch_bounds__(kBlock) void k_hess(BsrDev Q, const double* __restrict__ X,
+                                                 const double* __restrict__ S, const double* __restrict__ V,
+                                                 const double* __restrict__ Gdot, double* __restrict__ HV,
+                                                 double* __restrict__ partials, const DevState* __restrict__ st,
+                                                 int check_tcg, int n) {
+  using GEO = Geo<D, R>;
+  __shared__ double sm[kWaves][3][GEO::G][GEO::T];
+  __shared__ double red[kWaves * kNP];
+  if (st) {
+    if (st->rtr_stop) return;
+    if (check_tcg && st->tcg_done) return;
+  }
+  const LaneId L = lane_id<D>();
+  const int ntiles = (n + GEO::P - 1) / GEO::P;
+  double part[2] = {0.0, 0.0};
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int i = tile * GEO::P + L.wave * GEO::G + L.g;
+    const bool ok = (L.g < GEO::G) && (i < n);
+    double h[R], v[R], x[R];
+    const size_t off = (size_t)i * GEO::T + L.c * R;
+    double* ys = ok ? &sm[L.wave][0][L.g][0] : nullptr;
+    double* vs = ok ? &sm[L.wave][1][L.g][0] : nullptr;
+    double* hs = ok ? &sm[L.wave][2][L.g][0] : nullptr;
+    if (ok) {
+      spmm_col<D, R>(Q.rowptr, Q.colidx, Q.vals, V, i, L.c, h);
+      load_col<R>(X + off, x);
+      load_col<R>(V + off, v);
+      store_col<R>(ys + L.c * R, x);
+      store_col<R>(vs + L.c * R, v);
+    }
+    __syncthreads();
+    if (ok) {
+      if (L.c < D) {
+        // h[:,c] -= sum_a V[:,a] * S[a][c]   (S symmetric: row c of S_i)
+#pragma unroll
+        for (int a = 0; a < D; ++a) {
+          const double sac = S[(size_t)i * D * D + L.c * D + a];
+#pragma unroll
+          for (int k = 0; k < R; ++k) h[k] = fma(-vs[a * R + k], sac, h[k]);
+        }
+      }
+      store_col<R>(hs + L.c * R, h);
+    }
+    __syncthreads();
+    if (ok) {
+      double out[R], s[D];
+      proj_col<D, R>(ys, hs, L.c, h, out, s);
+#pragma unroll
+      for (int a = 0; a < R; ++a) part[0] = fma(v[a], out[a], part[0]);
+      if (Gdot) {
+#pragma unroll
+        for (int a = 0; a < R; ++a) part[1] = fma(v[a], Gdot[off + a], part[1]);
+      }
+      store_col<R>(HV + off, out);
+    }
+    __syncthreads();
+  }
+  store_partials<2>(part, partials, red);
+}
+
+// ================================================================ K6: preconditioner (stand-alone)
+// Z = proj_X( V * Dinv )   (QuadraticProblem::PreConditioner, src/QuadraticProblem.cpp:56-69, with
+// the block-Jacobi factor in place of the CHOLMOD solve); dinv == nullptr -> Z = proj_X(V).
+template <int D, int R>
+__global__ __launch_bounds__(kBlock) void k_precond(const double* __restrict__ X, const double* __restrict__ V,
+                                                    const double* __restrict__ dinv, double* __restrict__ Z,
+                                                    int n) {
+  using GEO = Geo<D, R>;
+  __shared__ double sm[kWaves][3][GEO::G][GEO::T];
+  const LaneId L = lane_id<D>();
+  const int ntiles = (n + GEO::P - 1) / GEO::P;
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int i = tile * GEO::P + L.wave * GEO::G + L.g;
+    const bool ok = (L.g < GEO::G) && (i < n);
+    const size_t off = (size_t)i * GEO::T + L.c * R;
+    double* ys = ok ? &sm[L.wave][0][L.g][0] : nullptr;
+    double* vs = ok ? &sm[L.wave][1][L.g][0] : nullptr;
+    double* zs = ok ? &sm[L.wave][2][L.g][0] : nullptr;
+    double v[R], x[R], z[R];
+    if (ok) {
+      load_col<R>(X + off, x);
+      load_col<R>(V + off, v);
+      store_col<R>(ys + L.c * R, x);
+      store_col<R>(vs + L.c * R, v);
+    }
+    __syncthreads();
+    if (ok) {
+      if (dinv) {
+        jacobi_col<D, R>(vs, dinv + (size_t)i * GEO::BB + L.c * GEO::B, z);
+      } else {
+#pragma unroll
+        for (int a = 0; a < R; ++a) z[a] = v[a];
+      }
+      store_col<R>(zs + L.c * R, z);
+    }
+    __syncthreads();
+    if (ok) {
+      double out[R], s[D];
+      proj_col<D, R>(ys, zs, L.c, z, out, s);
+      store_col<R>(Z + off, out);
+    }
+    __syncthreads();
+  }
+}
+
+// ================================================================ K7a: tCG residual / iterate update
+// ROPTLIB SolversTR::tCG_TR, first half of one inner iteration (and, with first = 1, its
+// initialisation r = g, eta = 0, z = P(r)):
+//   d_Hd (from k_hess partials) -> alpha, e_Pe';  boundary / negative curvature -> eta += tau*delta, stop
+//   else eta += alpha*delta; r += alpha*Hd; z = P(r);  partials: [0] <r,r>  [1] <z,r>
+template <int D, int R>
+__global__ __launch_bounds__(kBlock) void k_tcg_update(const double* __restrict__ X, const double* __restrict__ g,
+                                                       const double* __restrict__ dinv,
+                                                       const double* __restrict__ delta,
+                                                       const double* __restrict__ Hd, double* __restrict__ eta,
+                                                       double* __restrict__ r, double* __restrict__ z,
+                                                       const double* __restrict__ pin, int nb_in,
+                                                       double* __restrict__ pout, const DevState* __restrict__ sin,
+                                                       DevState* __restrict__ sout, int first, int n) {
+  using GEO = Geo<D, R>;
+  __shared__ double sm[kWaves][3][GEO::G][GEO::T];
+  __shared__ double red[kWaves * kNP];
+  DevState st = *sin;
+  if (st.rtr_stop || (!first && st.tcg_done)) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) *sout = st;
+    return;
+  }
+  int mode = 0;  // 0: normal step, 1: boundary step (eta += tau*delta, stop), 2: init
+  double alpha = 0.0, tau = 0.0;
+  if (first) {
+    mode = 2;
+    st.tcg_done = 0;
+    st.tcg_j = 0;
+    st.tcg_status = TCG_MAXITER;
+    st.e_Pe = 0.0;
+    st.e_Pd = 0.0;
+  } else {
+    double dh[1];
+    load_partials<1>(pin, nb_in, dh, red);
+    const double d_Hd = dh[0];
+    alpha = st.z_r / d_Hd;
+    const double e_Pe_new = st.e_Pe + 2.0 * alpha * st.e_Pd + alpha * alpha * st.d_Pd;
+    st.n_hess += 1;
+    st.alpha = alpha;
+    const double D2 = st.Delta * st.Delta;
+    if (d_Hd <= 0.0 || e_Pe_new >= D2) {
+      tau = (-st.e_Pd + sqrt(st.e_Pd * st.e_Pd + st.d_Pd * (D2 - st.e_Pe))) / st.d_Pd;
+      mode = 1;
+      st.tcg_status = (d_Hd < 0.0) ? TCG_NEGCURV : TCG_EXCREGION;
+      st.tcg_done = 1;
+    } else {
+      st.e_Pe = e_Pe_new;
+    }
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) *sout = st;
+
+  const LaneId L = lane_id<D>();
+  const int ntiles = (n + GEO::P - 1) / GEO::P;
+  double part[2] = {0.0, 0.0};
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int i = tile * GEO::P + L.wave * GEO::G + L.g;
+    const bool ok = (L.g < GEO::G) && (i < n);
+    const size_t off = (size_t)i * GEO::T + L.c * R;
+    if (mode == 1) {  // workgroup-uniform
+      if (ok) {
+        double e[R], dl[R];
+        load_col<R>(eta + off, e);
+        load_col<R>(delta + off, dl);
+#pragma unroll
+        for (int a = 0; a < R; ++a) e[a] = fma(tau, dl[a], e[a]);
+        store_col<R>(eta + off, e);
+      }
+      continue;
+    }
+    double* ys = ok ? &sm[L.wave][0][L.g][0] : nullptr;
+    double* rs = ok ? &sm[L.wave][1][L.g][0] : nullptr;
+    double* zs = ok ? &sm[L.wave][2][L.g][0] : nullptr;
+    double rr[R], x[R], zz[R];
+    if (ok) {
+      if (mode == 2) {
+        load_col<R>(g + off, rr);
+        double e[R];
+#pragma unroll
+        for (int a = 0; a < R; ++a) e[a] = 0.0;
+        store_col<R>(eta + off, e);
+      } else {
+        double e[R], dl[R], hd[R];
+        load_col<R>(eta + off, e);
+        load_col<R>(delta + off, dl);
+        load_col<R>(Hd + off, hd);
+        load_col<R>(r + off, rr);
+#pragma unroll
+        for (int a = 0; a < R; ++a) {
+          e[a] = fma(alpha, dl[a], e[a]);
+          rr[a] = fma(alpha, hd[a], rr[a]);
+        }
+        store_col<R>(eta + off, e);
+      }
+      store_col<R>(r + off, rr);
+#pragma unroll
+      for (int a = 0; a < R; ++a) part[0] = fma(rr[a], rr[a], part[0]);
+      load_col<R>(X + off, x);
+      store_col<R>(ys + L.c * R, x);
+      store_col<R>(rs + L.c * R, rr);
+    }
+    __syncthreads();
+    if (ok) {
+      if (dinv) {
+        jacobi_col<D, R>(rs, dinv + (size_t)i * GEO::BB + L.c * GEO::B, zz);
+      } else {
+#pragma unroll
+        for (int a = 0; a < R; ++a) zz[a] = rr[a];
+      }
+      store_col<R>(zs + L.c * R, zz);
+    }
+    __syncthreads();
+    if (ok) {
+      double out[R], s[D];
+      proj_col<D, R>(ys, zs, L.c, zz, out, s);
+#pragma unroll
+      for (int a = 0; a < R; ++a) part[1] = fma(out[a], rr[a], part[1]);
+      store_col<R>(z + off, out);
+    }
+    __syncthreads();
+  }
+  if (mode != 1) store_partials<2>(part, pout, red);
+}
+
+// ================================================================ K7b: tCG search-direction update
+// Second half of the inner iteration: convergence test |r| <= |r0| min(|r0|^theta, kappa),
+// beta = z_r'/z_r, delta = beta*delta - z, e_Pd, d_Pd recurrences (first = 1: delta = -z and the
+// initial scalars norm_r0, z_r, d_Pd).
+template <int D, int R>
+__global__ __launch_bounds__(kBlock) void k_tcg_dir(const double* __restrict__ z, double* __restrict__ delta,
+                                                    const double* __restrict__ pin, int nb_in,
+                                                    const DevState* __restrict__ sin, DevState* __restrict__ sout,
+                                                    int first, int n) {
+  using GEO = Geo<D, R>;
+  __shared__ double red[kWaves * kNP];
+  DevState st = *sin;
+  if (st.rtr_stop || st.tcg_done) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) *sout = st;
+    return;
+  }
+  double pr[2];
+  load_partials<2>(pin, nb_in, pr, red);
+  const double r_r = pr[0], z_r_new = pr[1];
+  double beta = 0.0;
+  bool update = true;
+  if (first) {
+    st.norm_r0 = sqrt(r_r);
+    st.z_r = z_r_new;
+    st.d_Pd = z_r_new;
+    st.e_Pd = 0.0;
+    if (st.max_inner <= 0) st.tcg_done = 1;
+  } else {
+    const double norm_r = sqrt(r_r);
+    const double pw = pow(st.norm_r0, st.theta);
+    if (st.tcg_j >= st.min_inner && norm_r <= st.norm_r0 * (pw < st.kappa ? pw : st.kappa)) {
+      st.tcg_status = (st.kappa < pw) ? TCG_LCON : TCG_SCON;
+      st.tcg_done = 1;
+      update = false;
+    } else {
+      beta = z_r_new / st.z_r;
+      st.e_Pd = beta * (st.e_Pd + st.alpha * st.d_Pd);
+      st.d_Pd = z_r_new + beta * beta * st.d_Pd;
+      st.z_r = z_r_new;
+      st.tcg_j += 1;
+      if (st.tcg_j >= st.max_inner) {
+        st.tcg_done = 1;
+        st.tcg_status = TCG_MAXITER;
+      }
+    }
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) *sout = st;
+  if (!update) return;
+  const size_t total = (size_t)n * GEO::T;
+  for (size_t e = (size_t)blockIdx.x * kBlock + threadIdx.x; e < total; e += (size_t)gridDim.x * kBlock) {
+    const double zv = z[e];
+    delta[e] = first ? -zv : fma(beta, delta[e], -zv);
+  }
+}
+
+// ================================================================ K4: retraction
+// X2 = R_X(scale * eta): Stiefel factor = Q of the thin QR of Y + eta with diag(R) > 0 (modified
+// Gram-Schmidt; ROPTLIB Stiefel::qfRetraction), Euclidean factor p + eta.  Each lane c < D rebuilds
+// q_0..q_c from the LDS tile (identical arithmetic in all lanes of the pose).
+template <int D, int R>
+__global__ __launch_bounds__(kBlock) void k_retract(const double* __restrict__ X, const double* __restrict__ eta,
+                                                    double scale, double* __restrict__ X2,
+                                                    const DevState* __restrict__ st, int n) {
+  using GEO = Geo<D, R>;
+  __shared__ double sm[kWaves][GEO::G][GEO::T];
+  if (st && st->rtr_stop) return;
+  const LaneId L = lane_id<D>();
+  const int ntiles = (n + GEO::P - 1) / GEO::P;
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int i = tile * GEO::P + L.wave * GEO::G + L.g;
+    const bool ok = (L.g < GEO::G) && (i < n);
+    const size_t off = (size_t)i * GEO::T + L.c * R;
+    double* as = ok ? &sm[L.wave][L.g][0] : nullptr;
+    double a[R];
+    if (ok) {
+      double x[R], e[R];
+      load_col<R>(X + off, x);
+      load_col<R>(eta + off, e);
+#pragma unroll
+      for (int k = 0; k < R; ++k) a[k] = fma(scale, e[k], x[k]);
+      store_col<R>(as + L.c * R, a);
+    }
+    __syncthreads();
+    if (ok) {
+      if (L.c < D) {
+        double q[D][R];
+#pragma unroll
+        for (int k = 0; k < D; ++k) {
+          if (k <= L.c) {
+            double v[R];
+#pragma unroll
+            for (int t = 0; t < R; ++t) v[t] = as[k * R + t];
+#pragma unroll
+            for (int l = 0; l < D; ++l) {
+              if (l < k) {
+                double dp = 0.0;
+#pragma unroll
+                for (int t = 0; t < R; ++t) dp = fma(q[l][t], v[t], dp);
+#pragma unroll
+                for (int t = 0; t < R; ++t) v[t] = fma(-dp, q[l][t], v[t]);
+              }
+            }
+            double nn = 0.0;
+#pragma unroll
+            for (int t = 0; t < R; ++t) nn = fma(v[t], v[t], nn);
+            const double inv = 1.0 / sqrt(nn);
+#pragma unroll
+            for (int t = 0; t < R; ++t) q[k][t] = v[t] * inv;
+            if (k == L.c) {
+#pragma unroll
+              for (int t = 0; t < R; ++t) a[t] = q[k][t];
+            }
+          }
+        }
+      }
+      store_col<R>(X2 + off, a);
+    }
+    __syncthreads();
+  }
+}
+
+// ================================================================ K7c: RTR acceptance test
+// ROPTLIB SolversTR::Run, tail of one outer iteration: rho = (f1 - f2) / -(<eta,g> + 0.5 <eta,H eta>),
+// radius update, acceptance (rho > 0.1, or the tiny-decrease clause), and on acceptance
+// x1 <- x2, g1 <- g2, S1 <- S2.
+// pe: k_grad partials at x2;  ph: k_hess partials for V = eta, Gdot = g1.
+template <int D, int R>
+__global__ __launch_bounds__(kBlock) void k_rtr_update(double* __restrict__ x1, const double* __restrict__ x2,
+                                                       double* __restrict__ g1, const double* __restrict__ g2,
+                                                       double* __restrict__ S1, const double* __restrict__ S2,
+                                                       const double* __restrict__ pe, int nb_e,
+                                                       const double* __restrict__ ph, int nb_h,
+                                                       const DevState* __restrict__ sin, DevState* __restrict__ sout,
+                                                       int n) {
+  using GEO = Geo<D, R>;
+  __shared__ double red[kWaves * kNP];
+  DevState st = *sin;
+  if (st.rtr_stop) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) *sout = st;
+    return;
+  }
+  double e3[3], h2[2];
+  load_partials<3>(pe, nb_e, e3, red);
+  load_partials<2>(ph, nb_h, h2, red);
+  const double f2 = 0.5 * e3[0] + e3[1];
+  const double ngf2 = sqrt(e3[2]);
+  const double eta_Heta = h2[0], eta_g = h2[1];
+  const double rho = (st.f1 - f2) / (-(eta_g + 0.5 * eta_Heta));
+  if (rho > 0.75) {
+    if (st.tcg_status == TCG_EXCREGION || st.tcg_status == TCG_NEGCURV) st.Delta *= 2.0;
+    if (st.Delta > st.Delta_max) st.Delta = st.Delta_max;
+  } else if (rho < 0.25) {
+    st.Delta *= 0.25;
+  }
+  const double sqeps = 1.4901161193847656e-08;  // sqrt(DBL_EPSILON)
+  bool accept = rho > 0.1;
+  if (!accept && st.accept_tiny) accept = (fabs(st.f1 - f2) / (fabs(st.f1) + 1.0) < sqeps) && (f2 < st.f1);
+  st.f2 = f2;
+  st.rho = rho;
+  st.accepted_last = accept ? 1 : 0;
+  st.outer_iter += 1;
+  if (accept) {
+    st.f1 = f2;
+    st.ngf = ngf2;
+    st.n_accept += 1;
+    st.rtr_stop = (ngf2 < st.tol) ? 1 : 0;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) *sout = st;
+  if (!accept) return;
+  const size_t total = (size_t)n * GEO::T;
+  const size_t stride = (size_t)gridDim.x * kBlock;
+  for (size_t e = (size_t)blockIdx.x * kBlock + threadIdx.x; e < total; e += stride) {
+    x1[e] = x2[e];
+    g1[e] = g2[e];
+  }
+  const size_t totS = (size_t)n * D * D;
+  for (size_t e = (size_t)blockIdx.x * kBlock + threadIdx.x; e < totS; e += stride) S1[e] = S2[e];
+}
+
+// RTR start: f1, |g1| from k_grad partials at x1; initial radius; stop test.
+__global__ void k_rtr_begin(const double* __restrict__ pe, int nb_e, DevState* __restrict__ s0, double tol,
+                            double Delta0, double Delta_max, int max_inner, int accept_tiny) {
+  __shared__ double red[kWaves * kNP];
+  double e3[3];
+  load_partials<3>(pe, nb_e, e3, red);
+  if (threadIdx.x == 0) {
+    DevState st;
+    st.f1 = 0.5 * e3[0] + e3[1];
+    st.ngf = sqrt(e3[2]);
+    st.Delta = Delta0;
+    st.Delta_max = Delta_max;
+    st.tol = tol;
+    st.f2 = st.f1;
+    st.rho = 0.0;
+    st.fInit = st.f1;
+    st.gnInit = st.ngf;
+    st.outer_iter = 0;
+    st.rtr_stop = (st.ngf < tol) ? 1 : 0;
+    st.accepted_last = 0;
+    st.n_accept = 0;
+    st.accept_tiny = accept_tiny;
+    st.pad0 = 0;
+    st.z_r = st.d_Pd = st.e_Pd = st.e_Pe = st.norm_r0 = st.alpha = 0.0;
+    st.theta = 1.0;   // ROPTLIB RTRNewton default (SURVEY 8c' item 4)
+    st.kappa = 0.1;
+    st.tcg_j = 0;
+    st.tcg_done = 0;
+    st.tcg_status = TCG_MAXITER;
+    st.max_inner = max_inner;
+    st.n_hess = 0;
+    st.min_inner = 0;
+    s0[0] = st;
+    s0[1] = st;
+  }
+}
+
+// ================================================================ K5: polar projection
+// LiftedSEManifold::project (src/manifold/LiftedSEManifold.cpp:34-45; JacobiSVD U V^T,
+// src/DPGO_utils.cpp:480-486).  out = polar( a*A + b*Bm + c*Cm ) per pose when project != 0:
+// U V^T = M (M^T M)^{-1/2}; the D x D symmetric eigenproblem is solved by cyclic Jacobi sweeps
+// in registers.  One lane per pose column; every lane c < D of a pose repeats the small solve.
+template <int D, int R>
+__global__ __launch_bounds__(kBlock) void k_axpby_project(double a, const double* __restrict__ A, double b,
+                                                          const double* __restrict__ Bm, double c,
+                                                          const double* __restrict__ Cm, int project,
+                                                          double* __restrict__ out, int n) {
+  using GEO = Geo<D, R>;
+  __shared__ double sm[kWaves][GEO::G][GEO::T];
+  const LaneId L = lane_id<D>();
+  const int ntiles = (n + GEO::P - 1) / GEO::P;
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int i = tile * GEO::P + L.wave * GEO::G + L.g;
+    const bool ok = (L.g < GEO::G) && (i < n);
+    const size_t off = (size_t)i * GEO::T + L.c * R;
+    double* ms = ok ? &sm[L.wave][L.g][0] : nullptr;
+    double m[R];
+    if (ok) {
+#pragma unroll
+      for (int k = 0; k < R; ++k) {
+        double v = a * A[off + k];
+        if (Bm) v = fma(b, Bm[off + k], v);
+        if (Cm) v = fma(c, Cm[off + k], v);
+        m[k] = v;
+      }
+      store_col<R>(ms + L.c * R, m);
+    }
+    __syncthreads();
+    if (ok) {
+      if (project && L.c < D) {
+        // C = M^T M (D x D), eigen-decompose C = W diag(lam) W^T, out col c = sum_a M[:,a] * F[a][c],
+        // F = W diag(lam^-1/2) W^T.
+        double Cmat[D][D], W[D][D];
+#pragma unroll
+        for (int p = 0; p < D; ++p)
+#pragma unroll
+          for (int q = 0; q < D; ++q) {
+            double s = 0.0;
+#pragma unroll
+            for (int k = 0; k < R; ++k) s = fma(ms[p * R + k], ms[q * R + k], s);
+            Cmat[p][q] = s;
+            W[p][q] = (p == q) ? 1.0 : 0.0;
+          }
+        for (int sweep = 0; sweep < 12; ++sweep) {
+          double offn = 0.0;
+#pragma unroll
+          for (int p = 0; p < D; ++p)
+#pragma unroll
+            for (int q = p + 1; q < D; ++q) offn += Cmat[p][q] * Cmat[p][q];
+          double dn = 0.0;
+#pragma unroll
+          for (int p = 0; p < D; ++p) dn += Cmat[p][p] * Cmat[p][p];
+          if (offn <= 1e-32 * dn) break;
+#pragma unroll
+          for (int p = 0; p < D; ++p)
+#pragma unroll
+            for (int q = p + 1; q < D; ++q) {
+              const double apq = Cmat[p][q];
+              if (apq != 0.0) {
+                const double th = (Cmat[q][q] - Cmat[p][p]) / (2.0 * apq);
+                const double t = (th >= 0.0 ? 1.0 : -1.0) / (fabs(th) + sqrt(th * th + 1.0));
+                const double cs = 1.0 / sqrt(t * t + 1.0), sn = t * cs;
+#pragma unroll
+                for (int k = 0; k < D; ++k) {
+                  const double ckp = Cmat[k][p], ckq = Cmat[k][q];
+                  Cmat[k][p] = cs * ckp - sn * ckq;
+                  Cmat[k][q] = sn * ckp + cs * ckq;
+                }
+#pragma unroll
+                for (int k = 0; k < D; ++k) {
+                  const double cpk = Cmat[p][k], cqk = Cmat[q][k];
+                  Cmat[p][k] = cs * cpk - sn * cqk;
+                  Cmat[q][k] = sn * cpk + cs * cqk;
+                }
+#pragma unroll
+                for (int k = 0; k < D; ++k) {
+                  const double wkp = W[k][p], wkq = W[k][q];
+                  W[k][p] = cs * wkp - sn * wkq;
+                  W[k][q] = sn * wkp + cs * wkq;
+                }
+              }
+            }
+        }
+        double F[D];  // column c of F
+#pragma unroll
+        for (int p = 0; p < D; ++p) {
+          double s = 0.0;
+#pragma unroll
+          for (int k = 0; k < D; ++k) {
+            double wck = 0.0;
+#pragma unroll
+            for (int cc = 0; cc < D; ++cc) wck = (cc == L.c) ? W[cc][k] : wck;
+            s += W[p][k] * wck / sqrt(Cmat[k][k]);
+          }
+          F[p] = s;
+        }
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+          double s = 0.0;
+#pragma unroll
+          for (int p = 0; p < D; ++p) s = fma(ms[p * R + k], F[p], s);
+          m[k] = s;
+        }
+      }
+      store_col<R>(out + off, m);
+    }
+    __syncthreads();
+  }
+}
+
+// ================================================================ K11: pack public poses
+template <int D, int R>
+__global__ __launch_bounds__(kBlock) void k_gather_tiles(const double* __restrict__ src,
+                                                         const int32_t* __restrict__ idx, int count,
+                                                         double* __restrict__ dst) {
+  constexpr int T = (D + 1) * R;
+  const size_t total = (size_t)count * T;
+  for (size_t e = (size_t)blockIdx.x * kBlock + threadIdx.x; e < total; e += (size_t)gridDim.x * kBlock) {
+    const int k = (int)(e / T), w = (int)(e - (size_t)k * T);
+    dst[e] = src[(size_t)idx[k] * T + w];
+  }
+}
+
+// Block-Jacobi factors: Dinv_i = (Q_ii + shift I)^-1 by Gauss-Jordan on the SPD (D+1)x(D+1) block.
+template <int D>
+__global__ __launch_bounds__(kBlock) void k_build_dinv(BsrDev Q, double shift, double* __restrict__ dinv, int n) {
+  constexpr int B = D + 1;
+  for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+    double A[B][B], I[B][B];
+    bool found = false;
+    for (int t = Q.rowptr[i]; t < Q.rowptr[i + 1]; ++t) {
+      if (Q.colidx[t] == i) {
+#pragma unroll
+        for (int p = 0; p < B; ++p)
+#pragma unroll
+          for (int q = 0; q < B; ++q) A[p][q] = Q.vals[(size_t)t * B * B + p * B + q];
+        found = true;
+      }
+    }
+    if (!found) {
+#pragma unroll
+      for (int p = 0; p < B; ++p)
+#pragma unroll
+        for (int q = 0; q < B; ++q) A[p][q] = 0.0;
+    }
+#pragma unroll
+    for (int p = 0; p < B; ++p)
+#pragma unroll
+      for (int q = 0; q < B; ++q) I[p][q] = (p == q) ? 1.0 : 0.0;
+#pragma unroll
+    for (int p = 0; p < B; ++p) A[p][p] += shift;
+#pragma unroll
+    for (int p = 0; p < B; ++p) {
+      const double inv = 1.0 / A[p][p];
+#pragma unroll
+      for (int q = 0; q < B; ++q) {
+        A[p][q] *= inv;
+        I[p][q] *= inv;
+      }
+#pragma unroll
+      for (int k = 0; k < B; ++k) {
+        if (k != p) {
+          const double f = A[k][p];
+#pragma unroll
+          for (int q = 0; q < B; ++q) {
+            A[k][q] = fma(-f, A[p][q], A[k][q]);
+            I[k][q] = fma(-f, I[p][q], I[k][q]);
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int p = 0; p < B; ++p)
+#pragma unroll
+      for (int q = 0; q < B; ++q) dinv[(size_t)i * B * B + p * B + q] = 0.5 * (I[p][q] + I[q][p]);
+  }
+}
+
+}  // namespace dpgo

@@ -1,0 +1,474 @@
+"""Host-side mirror of the reference's local-solver interface, backed by libdpgo_hip.so.
+
+Same names, argument meaning and error behaviour as the reference classes so parity tests
+read like the reference's own tests:
+
+  PoseGraph (data-matrix part)   include/DPGO/PoseGraph.h:59-69,106-194 ; src/PoseGraph.cpp
+  QuadraticProblem               include/DPGO/QuadraticProblem.h:33-115
+  QuadraticOptimizer             include/DPGO/QuadraticOptimizer.h:20-104
+  LiftedSEManifold               include/DPGO/manifold/LiftedSEManifold.h:28-43
+  ROptParameters / ROPTResult    include/DPGO/DPGO_types.h:44-107
+
+"Matrix" arguments are numpy arrays of shape (r, (d+1)*n) -- the reference's
+Eigen::MatrixXd; they are passed to the device in column-major order (Fortran order), i.e.
+n consecutive pose tiles.  There is no CPU fallback anywhere in this module.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Dict, Optional, Tuple
+
+import numpy as np
+
+from . import lib as L
+from .measurements import RelativeSEMeasurements
+
+
+# --------------------------------------------------------------------------- parameters
+@dataclass
+class ROptParameters:
+    """DPGO::ROptParameters (include/DPGO/DPGO_types.h:44-86) + device-path extensions."""
+    method: str = "RTR"  # ROptMethod::RTR | "RGD"
+    verbose: bool = False
+    gradnorm_tol: float = 1e-2
+    RGD_stepsize: float = 1e-3
+    RGD_use_preconditioner: bool = True
+    RTR_iterations: int = 3
+    RTR_tCG_iterations: int = 50
+    RTR_initial_radius: float = 100.0
+    # extensions
+    precond: str = "jacobi"  # "jacobi" (block-Jacobi of Q + shift I) | "none"
+    precond_shift: float = 1e-1  # src/PoseGraph.cpp:603
+    accept_tiny_decrease: bool = True
+    tcg_poll_interval: int = 8
+    time_bound_s: float = 5.0  # Solver.TimeBound, src/QuadraticOptimizer.cpp:78
+
+    def to_c(self) -> L.RoptParamsC:
+        c = L.RoptParamsC()
+        c.method = {"RTR": L.METHOD_RTR, "RGD": L.METHOD_RGD}[self.method]
+        c.verbose = int(self.verbose)
+        c.gradnorm_tol = self.gradnorm_tol
+        c.RGD_stepsize = self.RGD_stepsize
+        c.RGD_use_preconditioner = int(self.RGD_use_preconditioner)
+        c.RTR_iterations = self.RTR_iterations
+        c.RTR_tCG_iterations = self.RTR_tCG_iterations
+        c.RTR_initial_radius = self.RTR_initial_radius
+        c.precond = {"jacobi": L.PRECOND_BLOCK_JACOBI, "none": L.PRECOND_NONE}[self.precond]
+        c.precond_shift = self.precond_shift
+        c.accept_tiny_decrease = int(self.accept_tiny_decrease)
+        c.tcg_poll_interval = self.tcg_poll_interval
+        c.time_bound_s = self.time_bound_s
+        return c
+
+
+@dataclass
+class ROPTResult:
+    """DPGO::ROPTResult (include/DPGO/DPGO_types.h:91-107) + counters."""
+    success: bool = False
+    fInit: float = 0.0
+    gradNormInit: float = 0.0
+    fOpt: float = 0.0
+    gradNormOpt: float = 0.0
+    elapsedMs: float = 0.0
+    tCGStatus: str = "MAXITER"
+    rtr_iterations: int = 0
+    rtr_accepted: int = 0
+    tcg_iterations: int = 0
+    spmm_count: int = 0
+    latest_step_accepted: bool = False
+
+    @staticmethod
+    def from_c(c: L.RoptResultC) -> "ROPTResult":
+        return ROPTResult(bool(c.success), c.fInit, c.gradNormInit, c.fOpt, c.gradNormOpt, c.elapsedMs,
+                          L.TCG_STATUS[c.tCGStatus], c.rtr_iterations, c.rtr_accepted, c.tcg_iterations,
+                          c.spmm_count, bool(c.latest_step_accepted))
+
+
+def _colmajor(X, r: int, N: int, what: str = "Matrix") -> np.ndarray:
+    X = np.asarray(X, dtype=np.float64)
+    if X.shape != (r, N):  # reference: CHECK_EQ on rows / cols (src/QuadraticProblem.cpp:30-31)
+        raise ValueError("%s has shape %s, expected (%d, %d)" % (what, X.shape, r, N))
+    return np.asfortranarray(X)
+
+
+# --------------------------------------------------------------------------- PoseGraph
+class PoseGraph:
+    """Data-matrix part of DPGO::PoseGraph: owns the measurements, neighbour poses and priors of
+    one agent and lazily builds Q (block-CSR) and G, with the reference's invalidation rules:
+    setNeighborPoses resets G only (src/PoseGraph.cpp:183-186); clearQuadraticMatrix also drops
+    the preconditioner (:352-355); setMeasurements empties everything (:61-66)."""
+
+    def __init__(self, id: int, r: int, d: int):
+        if r < d:
+            raise ValueError("CHECK(r >= d) failed")  # src/PoseGraph.cpp:19
+        self.id_, self.r_, self.d_, self.n_ = int(id), int(r), int(d), 0
+        self.prior_kappa_, self.prior_tau_ = 10000.0, 100.0  # :17-18
+        self._meas: Optional[RelativeSEMeasurements] = None
+        self.neighbor_poses_: Dict[Tuple[int, int], np.ndarray] = {}
+        self.priors_: Dict[int, np.ndarray] = {}
+        self._Q = None
+        self._G = None
+        self._coupling = None
+        self.q_version = 0
+
+    def id(self): return self.id_
+    def r(self): return self.r_
+    def d(self): return self.d_
+    def n(self): return self.n_
+
+    def setMeasurements(self, measurements: RelativeSEMeasurements) -> None:
+        """PoseGraph::setMeasurements (:61-66).  Irrelevant edges are dropped with a warning in
+        the reference (:68-71); duplicate (src, dst) edges are silently dropped (:83-88)."""
+        m = measurements
+        if m.d != self.d_:
+            raise ValueError("measurement dimension %d != %d" % (m.d, self.d_))
+        keep = (m.r1 == self.id_) | (m.r2 == self.id_)
+        m = m.select(keep)
+        seen, first = set(), []
+        for e in range(len(m)):
+            key = (int(m.r1[e]), int(m.p1[e]), int(m.r2[e]), int(m.p2[e]))
+            if key not in seen:
+                seen.add(key)
+                first.append(e)
+        m = m.select(np.array(first, dtype=np.int64))
+        self._meas = m
+        mine1 = m.r1 == self.id_
+        mine2 = m.r2 == self.id_
+        n = 0
+        if mine1.any():
+            n = max(n, int(m.p1[mine1].max()) + 1)
+        if mine2.any():
+            n = max(n, int(m.p2[mine2].max()) + 1)
+        self.n_ = n
+        self.neighbor_poses_ = {}
+        self.priors_ = {}
+        self.clearDataMatrices()
+
+    def measurements(self) -> RelativeSEMeasurements:
+        return self._meas
+
+    def sharedLoopClosures(self) -> RelativeSEMeasurements:
+        m = self._meas
+        return m.select(m.r1 != m.r2)
+
+    def neighborPoseIDs(self):
+        """Sorted (robot, frame) ids of the neighbour poses this agent needs (nbr_shared_pose_ids_)."""
+        m = self.sharedLoopClosures()
+        ids = set()
+        for e in range(len(m)):
+            if m.r1[e] == self.id_:
+                ids.add((int(m.r2[e]), int(m.p2[e])))
+            else:
+                ids.add((int(m.r1[e]), int(m.p1[e])))
+        return sorted(ids)
+
+    def localSharedPoseIDs(self):
+        m = self.sharedLoopClosures()
+        ids = set()
+        for e in range(len(m)):
+            ids.add(int(m.p1[e]) if m.r1[e] == self.id_ else int(m.p2[e]))
+        return sorted(ids)
+
+    def setPrior(self, index: int, Xi) -> None:  # :176-181
+        if not (0 <= index < self.n_):
+            raise ValueError("CHECK_LT(index, n()) failed")
+        Xi = np.asarray(Xi, dtype=np.float64)
+        if Xi.shape != (self.r_, self.d_ + 1):
+            raise ValueError("prior has shape %s, expected (%d, %d)" % (Xi.shape, self.r_, self.d_ + 1))
+        self.priors_[int(index)] = Xi.copy()
+        self.clearDataMatrices()
+
+    def setNeighborPoses(self, pose_dict: Dict[Tuple[int, int], np.ndarray]) -> None:  # :183-186
+        self.neighbor_poses_ = dict(pose_dict)
+        self._G = None
+
+    def clearDataMatrices(self) -> None:  # :376-379
+        self._Q = None
+        self._G = None
+        self._coupling = None
+        self.q_version += 1
+
+    def _edge_arrays(self):
+        m = self._meas
+        return (len(m), L.ptr(m.r1), L.ptr(m.p1), L.ptr(m.r2), L.ptr(m.p2), L.ptr(m.R), L.ptr(m.t),
+                L.ptr(m.kappa), L.ptr(m.tau), L.ptr(m.weight))
+
+    def quadraticMatrix(self):
+        """PoseGraph::quadraticMatrix (:345-350) -> (rowptr, colidx, vals[nnzb, b, b]) block-CSR,
+        built by dpgo_build_Q_bsr (constructQ, :381-491).  Every neighbour is treated as active;
+        the reference's missing-pose check (:418-424) is enforced where the poses are actually
+        consumed, in linearMatrix()."""
+        if self._Q is None:
+            if self._meas is None or self.n_ == 0:
+                raise RuntimeError("PoseGraph has no measurements")
+            lib = L.load()
+            b = self.d_ + 1
+            pidx = L.i32(sorted(self.priors_.keys()))
+            nnzb = C.c_int(0)
+            m, *arrs = self._edge_arrays()
+            L.check(lib.dpgo_build_Q_bsr(self.id_, self.d_, self.n_, m, *arrs, len(pidx), L.ptr(pidx),
+                                         self.prior_kappa_, self.prior_tau_, C.byref(nnzb), None, None, None))
+            rowptr = np.zeros(self.n_ + 1, dtype=np.int32)
+            colidx = np.zeros(nnzb.value, dtype=np.int32)
+            vals = np.zeros((nnzb.value, b, b))
+            L.check(lib.dpgo_build_Q_bsr(self.id_, self.d_, self.n_, m, *arrs, len(pidx), L.ptr(pidx),
+                                         self.prior_kappa_, self.prior_tau_, C.byref(nnzb), L.ptr(rowptr),
+                                         L.ptr(colidx), L.ptr(vals)))
+            self._Q = (rowptr, colidx, vals)
+        return self._Q
+
+    def couplingMatrix(self):
+        """Operator form of constructG (:493-580): returns (slots, rowptr, colidx, vals, G0) with
+        G = G0 + Xnbr * C; slots = sorted neighbour pose ids = column order of the tile buffer."""
+        if self._coupling is None:
+            lib = L.load()
+            m_all = self._meas
+            slots = self.neighborPoseIDs()
+            slot_index = {pid: k for k, pid in enumerate(slots)}
+            slot_of_edge = np.full(len(m_all), -1, dtype=np.int32)
+            for e in range(len(m_all)):
+                if m_all.r1[e] != m_all.r2[e]:
+                    pid = (int(m_all.r2[e]), int(m_all.p2[e])) if m_all.r1[e] == self.id_ else \
+                          (int(m_all.r1[e]), int(m_all.p1[e]))
+                    slot_of_edge[e] = slot_index[pid]
+            b = self.d_ + 1
+            nnzb = C.c_int(0)
+            m, *arrs = self._edge_arrays()
+            L.check(lib.dpgo_build_G_coupling(self.id_, self.d_, self.n_, m, *arrs, L.ptr(slot_of_edge),
+                                              C.byref(nnzb), None, None, None))
+            rowptr = np.zeros(self.n_ + 1, dtype=np.int32)
+            colidx = np.zeros(max(nnzb.value, 1), dtype=np.int32)[:nnzb.value]
+            vals = np.zeros((nnzb.value, b, b))
+            L.check(lib.dpgo_build_G_coupling(self.id_, self.d_, self.n_, m, *arrs, L.ptr(slot_of_edge),
+                                              C.byref(nnzb), L.ptr(rowptr), L.ptr(colidx) if nnzb.value else None,
+                                              L.ptr(vals) if nnzb.value else None))
+            G0 = np.zeros((self.r_, b * self.n_), order="F")
+            om = np.array([self.prior_kappa_] * self.d_ + [self.prior_tau_])
+            for idx, P in self.priors_.items():  # :565-574  L = -P Omega
+                G0[:, idx * b:(idx + 1) * b] += -(P * om[None, :])
+            self._coupling = (slots, rowptr, colidx, vals, G0)
+        return self._coupling
+
+    def linearMatrix(self) -> np.ndarray:
+        """PoseGraph::linearMatrix (:359-364): dense r x (d+1)n.  Host evaluation of
+        G = G0 + Xnbr * C (used by the host-pointer flavour; the device flavour is
+        QuadraticProblem.updateLinearMatrixFromNeighbors)."""
+        if self._G is None:
+            slots, rowptr, colidx, vals, G0 = self.couplingMatrix()
+            b, r = self.d_ + 1, self.r_
+            G = G0.copy(order="F")
+            for i in range(self.n_):
+                for t in range(rowptr[i], rowptr[i + 1]):
+                    pid = slots[colidx[t]]
+                    if pid not in self.neighbor_poses_:
+                        raise LookupError("Missing active neighbor pose %s" % (pid,))
+                    Xn = np.asarray(self.neighbor_poses_[pid], dtype=np.float64)  # r x b
+                    G[:, i * b:(i + 1) * b] += Xn @ vals[t].T  # out[a,c] = sum_k X[a,k] blk[c][k]
+            self._G = G
+        return self._G
+
+
+# --------------------------------------------------------------------------- QuadraticProblem
+class QuadraticProblem:
+    """DPGO::QuadraticProblem: f(X) = 0.5 <Q, X^T X> + <X, G> on (St(d,r) x R^r)^n.
+
+    Owns the device handle (Q in block-CSR, G, block-Jacobi factors, work vectors).  The
+    reference builds a new problem per iteration (src/PGOAgent.cpp:968); keep this object alive
+    across iterations instead and call refresh() after the pose graph changed."""
+
+    def __init__(self, pose_graph: PoseGraph, device: int = 0):
+        self.pose_graph_ = pose_graph
+        self._lib = L.load()
+        self._h = L._P()
+        r, d, n = pose_graph.r(), pose_graph.d(), pose_graph.n()
+        if n <= 0:
+            raise RuntimeError("pose graph must be initialised (n > 0)")
+        L.check(self._lib.dpgo_problem_create(C.byref(self._h), r, d, n, device))
+        self._q_version = -1
+        self._g_obj = None
+        self.refresh()
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None) is not None and self._h.value:
+                self._lib.dpgo_problem_destroy(self._h)
+                self._h = L._P()
+        except Exception:
+            pass
+
+    def num_poses(self) -> int: return self.pose_graph_.n()
+    def dimension(self) -> int: return self.pose_graph_.d()
+    def relaxation_rank(self) -> int: return self.pose_graph_.r()
+
+    @property
+    def handle(self):
+        return self._h
+
+    def _N(self):
+        return (self.dimension() + 1) * self.num_poses()
+
+    def refresh(self) -> None:
+        """Re-upload Q and/or G if the pose graph invalidated them (same rules as the reference's
+        lazy getters, src/PoseGraph.cpp:345-366)."""
+        pg = self.pose_graph_
+        if self._q_version != pg.q_version:
+            rowptr, colidx, vals = pg.quadraticMatrix()
+            L.check(self._lib.dpgo_problem_set_Q_bsr(self._h, len(colidx), L.ptr(rowptr), L.ptr(colidx), L.ptr(vals)))
+            self._q_version = pg.q_version
+            self._g_obj = None
+        has_shared = len(pg.sharedLoopClosures()) > 0 or len(pg.priors_) > 0
+        if not has_shared:
+            if self._g_obj is not False:
+                L.check(self._lib.dpgo_problem_set_G(self._h, None))
+                self._g_obj = False
+        else:
+            G = pg.linearMatrix()
+            if self._g_obj is not G:
+                L.check(self._lib.dpgo_problem_set_G(self._h, L.ptr(G)))
+                self._g_obj = G
+
+    def _in(self, X, what="Y"):
+        return _colmajor(X, self.relaxation_rank(), self._N(), what)
+
+    def _out(self):
+        return np.empty((self.relaxation_rank(), self._N()), order="F")
+
+    def f(self, Y) -> float:  # src/QuadraticProblem.cpp:29-35
+        Yc = self._in(Y)
+        out = C.c_double(0.0)
+        L.check(self._lib.dpgo_problem_f(self._h, L.ptr(Yc), C.byref(out)))
+        return out.value
+
+    def EucGrad(self, X) -> np.ndarray:  # :43-47
+        Xc, o = self._in(X), self._out()
+        L.check(self._lib.dpgo_problem_euc_grad(self._h, L.ptr(Xc), L.ptr(o)))
+        return o
+
+    def EucHessianEta(self, X, V) -> np.ndarray:  # :49-54  (x unused: the cost is quadratic)
+        Vc, o = self._in(V, "V"), self._out()
+        L.check(self._lib.dpgo_problem_euc_hess(self._h, L.ptr(Vc), L.ptr(o)))
+        return o
+
+    def RieHessianEta(self, X, V) -> np.ndarray:
+        """ROPTLIB Problem::HessianEta: EucHessianEta + Stiefel::EucHvToHv + tangent projection."""
+        Xc, Vc, o = self._in(X), self._in(V, "V"), self._out()
+        L.check(self._lib.dpgo_problem_rie_hess(self._h, L.ptr(Xc), L.ptr(Vc), L.ptr(o)))
+        return o
+
+    def PreConditioner(self, X, inVec, precond: str = "jacobi", shift: float = 1e-1) -> np.ndarray:  # :56-69
+        Xc, Vc, o = self._in(X), self._in(inVec, "inVec"), self._out()
+        pc = {"jacobi": L.PRECOND_BLOCK_JACOBI, "none": L.PRECOND_NONE}[precond]
+        L.check(self._lib.dpgo_problem_precondition(self._h, pc, shift, L.ptr(Xc), L.ptr(Vc), L.ptr(o)))
+        return o
+
+    def RieGrad(self, Y) -> np.ndarray:  # :71-79
+        Yc, o = self._in(Y), self._out()
+        L.check(self._lib.dpgo_problem_rie_grad(self._h, L.ptr(Yc), L.ptr(o)))
+        return o
+
+    def RieGradNorm(self, Y) -> float:  # :81-83
+        Yc = self._in(Y)
+        out = C.c_double(0.0)
+        L.check(self._lib.dpgo_problem_rie_grad_norm(self._h, L.ptr(Yc), C.byref(out)))
+        return out.value
+
+    # ---- device-resident flavour (torch tensors or raw device addresses) ----
+    def setStream(self, hip_stream: Optional[int]) -> None:
+        L.check(self._lib.dpgo_problem_set_stream(self._h, hip_stream))
+
+    def setCouplingFromPoseGraph(self) -> list:
+        """Upload the G operator once; returns the neighbour slot order (list of (robot, frame))."""
+        slots, rowptr, colidx, vals, G0 = self.pose_graph_.couplingMatrix()
+        L.check(self._lib.dpgo_problem_set_G_coupling(self._h, len(slots), len(colidx), L.ptr(rowptr),
+                                                      L.ptr(colidx) if len(colidx) else None,
+                                                      L.ptr(vals) if len(colidx) else None, L.ptr(G0)))
+        return slots
+
+    def updateLinearMatrixFromNeighbors(self, nbr_tiles_dev) -> None:
+        """constructG on the device from the neighbour tile buffer (src/PoseGraph.cpp:493-580)."""
+        L.check(self._lib.dpgo_problem_update_G_from_neighbors_device(self._h, L.ptr(nbr_tiles_dev)))
+        self._g_obj = None
+
+    def evalDevice(self, X_dev) -> Tuple[float, float]:
+        f, g = C.c_double(0.0), C.c_double(0.0)
+        L.check(self._lib.dpgo_problem_eval_device(self._h, L.ptr(X_dev), C.byref(f), C.byref(g)))
+        return f.value, g.value
+
+    def spmmDevice(self, V_dev, OUT_dev, add_G: bool = False) -> None:
+        L.check(self._lib.dpgo_spmm_device(self._h, L.ptr(V_dev), L.ptr(OUT_dev), int(add_G)))
+
+    def benchSpmm(self, reps: int, warmup: int = 5) -> float:
+        ms = C.c_double(0.0)
+        L.check(self._lib.dpgo_bench_spmm(self._h, reps, warmup, C.byref(ms)))
+        return ms.value
+
+
+# --------------------------------------------------------------------------- QuadraticOptimizer
+class QuadraticOptimizer:
+    """DPGO::QuadraticOptimizer (src/QuadraticOptimizer.cpp)."""
+
+    def __init__(self, p: QuadraticProblem, params: Optional[ROptParameters] = None):
+        self.problem_ = p
+        self.params_ = params or ROptParameters()
+        self.result_ = ROPTResult(success=False)  # :21-23
+
+    def setProblem(self, p): self.problem_ = p
+    def setVerbose(self, v): self.params_.verbose = bool(v)
+    def setAlgorithm(self, alg): self.params_.method = alg
+    def setRGDStepsize(self, s): self.params_.RGD_stepsize = float(s)
+    def setRTRIterations(self, it): self.params_.RTR_iterations = int(it)
+    def setGradientNormTolerance(self, tol): self.params_.gradnorm_tol = float(tol)
+    def setRTRInitialRadius(self, radius): self.params_.RTR_initial_radius = float(radius)
+    def setRTRtCGIterations(self, it): self.params_.RTR_tCG_iterations = int(it)
+    def getOptResult(self) -> ROPTResult: return self.result_
+
+    def optimize(self, Y) -> np.ndarray:
+        """Matrix optimize(const Matrix&) (:26-48): host matrix in, host matrix out."""
+        p = self.problem_
+        Yc = p._in(Y)
+        out = p._out()
+        cp, cr = self.params_.to_c(), L.RoptResultC()
+        L.check(p._lib.dpgo_optimize(p._h, C.byref(cp), L.ptr(Yc), L.ptr(out), C.byref(cr)))
+        self.result_ = ROPTResult.from_c(cr)
+        return out
+
+    def optimizeDevice(self, X_dev) -> ROPTResult:
+        """Device-resident flavour: X_dev (torch tensor / device address) is updated in place."""
+        p = self.problem_
+        cp, cr = self.params_.to_c(), L.RoptResultC()
+        L.check(p._lib.dpgo_optimize_device(p._h, C.byref(cp), L.ptr(X_dev), C.byref(cr)))
+        self.result_ = ROPTResult.from_c(cr)
+        return self.result_
+
+
+# --------------------------------------------------------------------------- LiftedSEManifold
+class LiftedSEManifold:
+    """DPGO::LiftedSEManifold (include/DPGO/manifold/LiftedSEManifold.h:28-43) =
+    (St(d,r) x R^r)^n with ROPTLIB's Stiefel parameter set 3 (Euclidean metric, qf retraction)."""
+
+    def __init__(self, r: int, d: int, n: int, device: int = 0):
+        self.r_, self.d_, self.n_, self.device = int(r), int(d), int(n), int(device)
+        self._lib = L.load()
+
+    def _N(self): return (self.d_ + 1) * self.n_
+
+    def project(self, M) -> np.ndarray:  # src/manifold/LiftedSEManifold.cpp:34-45
+        Mc = _colmajor(M, self.r_, self._N(), "M")
+        o = np.empty_like(Mc, order="F")
+        L.check(self._lib.dpgo_manifold_project(self.r_, self.d_, self.n_, L.ptr(Mc), L.ptr(o), self.device))
+        return o
+
+    def Projection(self, X, V) -> np.ndarray:  # ROPTLIB ProductManifold::Projection
+        Xc, Vc = _colmajor(X, self.r_, self._N(), "X"), _colmajor(V, self.r_, self._N(), "V")
+        o = np.empty_like(Xc, order="F")
+        L.check(self._lib.dpgo_manifold_tangent_project(self.r_, self.d_, self.n_, L.ptr(Xc), L.ptr(Vc), L.ptr(o),
+                                                        self.device))
+        return o
+
+    def Retraction(self, X, eta, scale: float = 1.0) -> np.ndarray:  # ROPTLIB ProductManifold::Retraction
+        Xc, Ec = _colmajor(X, self.r_, self._N(), "X"), _colmajor(eta, self.r_, self._N(), "eta")
+        o = np.empty_like(Xc, order="F")
+        L.check(self._lib.dpgo_manifold_retract(self.r_, self.d_, self.n_, L.ptr(Xc), L.ptr(Ec), float(scale),
+                                                L.ptr(o), self.device))
+        return o

@@ -1,0 +1,218 @@
+/* dpgo_hip.h -- C ABI of the MI355X-native RBCD local solver (libdpgo_hip.so).
+ *
+ * Drop-in boundary for the per-agent local solve of mit-acl/dpgo: what
+ * PGOAgent::updateX (reference src/PGOAgent.cpp:961-986) does through
+ * QuadraticProblem + QuadraticOptimizer + LiftedSEManifold.  Every entry point cites
+ * the reference interface it replaces.  Plain pointers and sizes only; no torch / Eigen
+ * types.  The reference-side binding a maintainer would add is in INTEGRATION.md.
+ *
+ * Matrix layout (all dense matrices): the reference's Eigen::MatrixXd r x (d+1)n,
+ * COLUMN-major (include/DPGO/manifold/Poses.h:16-21; pinned by tests/testEigenMap.cpp)
+ * = n consecutive pose tiles of (d+1)*r doubles; tile i = [Y_i (r x d) | p_i (r)].
+ *
+ * Q layout: block-CSR with (d+1)x(d+1) blocks; vals[t] is the dense block
+ * Q[i*b:(i+1)*b, j*b:(j+1)*b] stored ROW-major (scipy.sparse.bsr_matrix layout); Q is
+ * symmetric, so this is also the column-major block of Q's column i.  int32 indices, as
+ * Eigen::SparseMatrix<double,RowMajor> (include/DPGO/DPGO_types.h:26).
+ *
+ * Error convention: every function returns DPGO_OK (0) or a positive error code and
+ * never aborts (the reference's glog CHECKs become DPGO_ERR_INVALID);
+ * dpgo_last_error() returns a thread-local message.  There is NO CPU fallback: without
+ * a HIP device every compute entry point returns DPGO_ERR_HIP.
+ *
+ * Threading: one solve at a time per handle (as PGOAgent::updateX holds its mutexes for
+ * the whole call, src/PGOAgent.cpp:940-942); distinct handles are independent (one HIP
+ * stream each, no global mutable state).
+ */
+#ifndef DPGO_HIP_H
+#define DPGO_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DPGO_OK 0
+#define DPGO_ERR_INVALID 1     /* bad argument / shape mismatch (reference: glog CHECK) */
+#define DPGO_ERR_HIP 2         /* HIP runtime error or no device */
+#define DPGO_ERR_UNSUPPORTED 3 /* (d, r) combination not compiled in */
+#define DPGO_ERR_STATE 4       /* e.g. solve requested before Q was set */
+
+/* ROptParameters::ROptMethod (include/DPGO/DPGO_types.h:47-52) */
+#define DPGO_METHOD_RTR 0
+#define DPGO_METHOD_RGD 1
+
+/* Preconditioner applied by QuadraticProblem::PreConditioner's replacement.
+ * The reference factorises Q + 0.1 I with CHOLMOD (src/PoseGraph.cpp:598-613); the
+ * device path applies the inverse of the (d+1)x(d+1) diagonal blocks of Q + shift I
+ * (same fixed point, different tCG trajectory). */
+#define DPGO_PRECOND_NONE 0
+#define DPGO_PRECOND_BLOCK_JACOBI 1
+
+/* tCG termination status; replaces ROPTLIB::tCGstatusSet in ROPTResult
+ * (include/DPGO/DPGO_types.h:106). */
+#define DPGO_TCG_NEGCURVTURE 0
+#define DPGO_TCG_EXCREGION 1
+#define DPGO_TCG_LCON 2
+#define DPGO_TCG_SCON 3
+#define DPGO_TCG_MAXITER 4
+
+/* Mirrors DPGO::ROptParameters (include/DPGO/DPGO_types.h:44-86); the fields after
+ * RTR_initial_radius are extensions with reference-compatible defaults set by
+ * dpgo_ropt_params_default(). */
+typedef struct dpgo_ropt_params {
+  int method;                 /* DPGO_METHOD_*            default RTR  */
+  int verbose;                /*                          default 0    */
+  double gradnorm_tol;        /*                          default 1e-2 */
+  double RGD_stepsize;        /*                          default 1e-3 */
+  int RGD_use_preconditioner; /*                          default 1    */
+  int RTR_iterations;         /*                          default 3    */
+  int RTR_tCG_iterations;     /*                          default 50   */
+  double RTR_initial_radius;  /*                          default 100  */
+  /* --- extensions --- */
+  int precond;                /* DPGO_PRECOND_*           default BLOCK_JACOBI */
+  double precond_shift;       /* reference: 1e-1 (src/PoseGraph.cpp:603) */
+  int accept_tiny_decrease;   /* ROPTLIB's second acceptance clause (SURVEY 8c' item 5), default 1 */
+  int tcg_poll_interval;      /* tCG iterations enqueued between host polls of the device
+                                 "done" flag; default 8 */
+  double time_bound_s;        /* ROPTLIB Solver.TimeBound = 5.0 (src/QuadraticOptimizer.cpp:78) */
+} dpgo_ropt_params;
+
+/* Mirrors DPGO::ROPTResult (include/DPGO/DPGO_types.h:91-107) + counters. */
+typedef struct dpgo_ropt_result {
+  int success;
+  double fInit, gradNormInit, fOpt, gradNormOpt, elapsedMs;
+  int tCGStatus;          /* DPGO_TCG_* of the last tCG run */
+  int rtr_iterations;     /* outer iterations executed */
+  int rtr_accepted;       /* outer iterations accepted */
+  int tcg_iterations;     /* Hessian-vector products inside tCG (all outer iterations) */
+  int spmm_count;         /* Q*X block-SpMM launches in this call */
+  int latest_step_accepted;
+} dpgo_ropt_result;
+
+typedef struct dpgo_problem_s* dpgo_problem_t;
+
+/* ---- library ---- */
+const char* dpgo_version(void);
+const char* dpgo_last_error(void);
+int dpgo_device_count(int* count);
+void dpgo_ropt_params_default(dpgo_ropt_params* p);
+/* 1 if the (d, r) pair has compiled kernels */
+int dpgo_supported(int d, int r);
+
+/* ---- problem lifecycle: replaces QuadraticProblem(shared_ptr<PoseGraph>)
+ * (include/DPGO/QuadraticProblem.h:39) + the data PoseGraph caches for it
+ * (Q_, G_, precon_: include/DPGO/PoseGraph.h:324-331).  The handle owns device copies of
+ * Q (BSR), G, the block-Jacobi factors and all solver work vectors; create it once per
+ * PoseGraph and keep it across iterations (the reference rebuilds problem+optimizer per
+ * iteration, src/PGOAgent.cpp:968-969, which is free on the CPU but not on a device). */
+int dpgo_problem_create(dpgo_problem_t* out, int r, int d, int n, int device);
+int dpgo_problem_destroy(dpgo_problem_t h);
+/* use an external HIP stream (e.g. torch's current stream); NULL restores the handle's own */
+int dpgo_problem_set_stream(dpgo_problem_t h, void* hip_stream);
+int dpgo_problem_dims(dpgo_problem_t h, int* r, int* d, int* n, int* nnzb);
+
+/* PoseGraph::quadraticMatrix() (include/DPGO/PoseGraph.h:162).  Host arrays; rowptr has
+ * n+1 entries; every block row must contain its diagonal block (as the reference's QDiag
+ * guarantees, src/PoseGraph.cpp:470-485).  Also (re)builds the preconditioner, like
+ * PoseGraph::constructPreconditioner (src/PoseGraph.cpp:598-613). */
+int dpgo_problem_set_Q_bsr(dpgo_problem_t h, int nnzb, const int32_t* rowptr, const int32_t* colidx,
+                           const double* vals);
+/* same pattern, new values (GNC re-weighting: PGOAgent.cpp:1122 clearDataMatrices path) */
+int dpgo_problem_update_Q_values(dpgo_problem_t h, const double* vals);
+
+/* PoseGraph::linearMatrix() (include/DPGO/PoseGraph.h:171): dense r x (d+1)n; NULL = zero */
+int dpgo_problem_set_G(dpgo_problem_t h, const double* G_host);
+int dpgo_problem_set_G_device(dpgo_problem_t h, const double* G_dev);
+/* PoseGraph::constructG (src/PoseGraph.cpp:493-580) as a rectangular block-SpMM:
+ * G = G0 + Xnbr * C, C = the inter-agent off-diagonal blocks of the global connection
+ * Laplacian restricted to this agent's rows (n block rows, ncols neighbour-pose slots).
+ * Set the pattern once, then update G on the device from the neighbour tiles buffer
+ * (ncols tiles of (d+1)*r doubles, device pointer) every iteration. */
+int dpgo_problem_set_G_coupling(dpgo_problem_t h, int ncols, int nnzb, const int32_t* rowptr,
+                                const int32_t* colidx, const double* vals, const double* G0_host);
+int dpgo_problem_update_G_from_neighbors_device(dpgo_problem_t h, const double* nbr_tiles_dev);
+
+/* ---- QuadraticProblem methods, host-pointer flavour (drop-in) ----
+ * f           : QuadraticProblem::f            (src/QuadraticProblem.cpp:29-41)
+ * euc_grad    : QuadraticProblem::EucGrad      (:43-47)
+ * euc_hess    : QuadraticProblem::EucHessianEta(:49-54)
+ * precondition: QuadraticProblem::PreConditioner (:56-69)
+ * rie_grad    : QuadraticProblem::RieGrad      (:71-79)
+ * rie_grad_norm: QuadraticProblem::RieGradNorm (:81-83)
+ * rie_hess    : ROPTLIB Problem::HessianEta = EucHessianEta + Stiefel::EucHvToHv + projection
+ */
+int dpgo_problem_f(dpgo_problem_t h, const double* X, double* f);
+int dpgo_problem_euc_grad(dpgo_problem_t h, const double* X, double* EG);
+int dpgo_problem_euc_hess(dpgo_problem_t h, const double* V, double* HV);
+int dpgo_problem_rie_grad(dpgo_problem_t h, const double* X, double* RG);
+int dpgo_problem_rie_grad_norm(dpgo_problem_t h, const double* X, double* gn);
+int dpgo_problem_rie_hess(dpgo_problem_t h, const double* X, const double* V, double* HV);
+int dpgo_problem_precondition(dpgo_problem_t h, int precond, double shift, const double* X,
+                              const double* V, double* Z);
+
+/* ---- QuadraticOptimizer::optimize (src/QuadraticOptimizer.cpp:26-48) ----
+ * host flavour: X0 -> Xopt are host matrices (H2D + solve + D2H);
+ * device flavour: X is a device matrix updated in place (nothing but scalars crosses PCIe). */
+int dpgo_optimize(dpgo_problem_t h, const dpgo_ropt_params* params, const double* X0, double* Xopt,
+                  dpgo_ropt_result* result);
+int dpgo_optimize_device(dpgo_problem_t h, const dpgo_ropt_params* params, double* X_dev,
+                         dpgo_ropt_result* result);
+
+/* ---- device-pointer building blocks (bench / agent loop) ---- */
+/* OUT = V*Q (+G if add_G): the named north-star kernel */
+int dpgo_spmm_device(dpgo_problem_t h, const double* V_dev, double* OUT_dev, int add_G);
+/* f, |rgrad| at a device X without copying X back */
+int dpgo_problem_eval_device(dpgo_problem_t h, const double* X_dev, double* f, double* gradnorm);
+/* time `reps` back-to-back SpMM launches with HIP events on the handle's stream;
+ * n_buffers >= 1 rotates that many (V, OUT) buffer pairs; returns average ms per launch */
+int dpgo_bench_spmm(dpgo_problem_t h, int reps, int warmup, double* avg_ms);
+
+/* ---- manifold: LiftedSEManifold (include/DPGO/manifold/LiftedSEManifold.h:28-43) + the
+ * ROPTLIB Stiefel x Euclidean product-manifold operations it configures
+ * (src/manifold/LiftedSEManifold.cpp:16-24).  Host pointers; `device` selects the GPU. */
+/* LiftedSEManifold::project (polar factor per pose, src/manifold/LiftedSEManifold.cpp:34-45) */
+int dpgo_manifold_project(int r, int d, int n, const double* M, double* out, int device);
+/* ROPTLIB ProductManifold::Projection: tangent projection of V at X */
+int dpgo_manifold_tangent_project(int r, int d, int n, const double* X, const double* V, double* out,
+                                  int device);
+/* ROPTLIB ProductManifold::Retraction (qf on Stiefel, x+eta on Euclidean): out = R_X(scale*eta) */
+int dpgo_manifold_retract(int r, int d, int n, const double* X, const double* eta, double scale,
+                          double* out, int device);
+/* device-pointer versions on a caller-supplied stream (NULL = default stream) */
+int dpgo_manifold_project_device(int r, int d, int n, const double* M_dev, double* out_dev, void* stream);
+/* out[k] = src tile idx[k]  (K11 pack for the public-pose exchange:
+ * PGOAgent::getSharedPoseDict, src/PGOAgent.cpp:97-166) */
+int dpgo_gather_tiles_device(int r, int d, const double* src_dev, const int32_t* idx_dev, int count,
+                             double* dst_dev, void* stream);
+/* out = a*A + b*B (elementwise over n tiles), then optional polar projection: the Nesterov
+ * updates PGOAgent::updateY / updateV (src/PGOAgent.cpp:922-936) */
+int dpgo_axpby_project_device(int r, int d, int n, double a, const double* A_dev, double b,
+                              const double* B_dev, double c, const double* C_dev, int project,
+                              double* out_dev, void* stream);
+
+/* ---- host-side data-matrix construction (no GPU needed) ----
+ * PoseGraph::constructQ (src/PoseGraph.cpp:381-491) with constructConnectionLaplacianSE
+ * (src/DPGO_utils.cpp:272-344).  Measurements in SoA form (RelativeSEMeasurement.h:21-50):
+ * R is m x d x d with R[e][row][col] (row-major per edge), t is m x d.  Edges with
+ * r1 == r2 == my_id are private; others are shared (outgoing if r1 == my_id).
+ * Two-call pattern: call with rowptr/colidx/vals NULL to get *nnzb_out, then with buffers. */
+int dpgo_build_Q_bsr(int my_id, int d, int n, int m, const int32_t* r1, const int32_t* p1, const int32_t* r2,
+                     const int32_t* p2, const double* R, const double* t, const double* kappa,
+                     const double* tau, const double* weight, int n_priors, const int32_t* prior_idx,
+                     double prior_kappa, double prior_tau, int* nnzb_out, int32_t* rowptr,
+                     int32_t* colidx, double* vals);
+/* Inter-agent coupling blocks for dpgo_problem_set_G_coupling: slot_of_edge[e] (>= 0 for
+ * shared edges) is the column slot of the neighbour pose of edge e in the neighbour tile
+ * buffer.  Two-call pattern as above. */
+int dpgo_build_G_coupling(int my_id, int d, int n, int m, const int32_t* r1, const int32_t* p1,
+                          const int32_t* r2, const int32_t* p2, const double* R, const double* t,
+                          const double* kappa, const double* tau, const double* weight,
+                          const int32_t* slot_of_edge, int* nnzb_out, int32_t* rowptr, int32_t* colidx,
+                          double* vals);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DPGO_HIP_H */

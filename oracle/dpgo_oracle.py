@@ -1,0 +1,829 @@
+"""CPU oracle for the dpgo RBCD local solve -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import
+this module.  The product path (dpgo_amd/) never does; it fails loudly when the
+HIP extension is missing.
+
+This is a NumPy/SciPy restatement of the reference's per-agent Riemannian
+block-coordinate-descent local solve.  Every function cites the reference
+file:line (under /root/reference) whose arithmetic it follows.
+
+PARITY STATUS ("parity unpinned" at trajectory level).  The reference cannot be
+built in this image (Eigen3, SuiteSparse, glog, Boost and -- by git fetch at
+configure time -- ROPTLIB `yuluntian/ROPTLIB@feature/cmake` are absent;
+SURVEY.md section 8c).  RTR/tCG, the Stiefel projection / Hessian correction /
+qf retraction live in ROPTLIB, which is not in the tree; they are restated here
+from the published algorithm (Absil-Baker-Gallivan RTR; ROPTLIB SolversTR).
+What pins this oracle:
+  * the reference's own known-answer tests, restated in tests/test_oracle.py:
+    tests/testTriangleGraph.cpp:57 (1e-4), tests/testPGO.cpp:188-189 (1e-6),
+    tests/testUtils.cpp:28-54 (1e-5), tests/testEigenMap.cpp (layout);
+  * literature optima of sphere2500 / torus3D / smallGrid3D (SE-Sync, DPGO
+    papers) reproduced to 1e-9 relative.
+Per-iteration trajectories are NOT pinned against the reference binary.
+
+Memory layout.  The reference stores X as Eigen::MatrixXd r x (d+1)n,
+column-major (include/DPGO/manifold/Poses.h:16-21).  The same bytes are viewed
+here as a C-contiguous array X[n, d+1, r]: X[i, k, a] == X_ref(a, i*(d+1)+k).
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+import scipy.sparse as sp
+import scipy.sparse.linalg as spla
+
+# --------------------------------------------------------------------------
+# g2o reader -- src/DPGO_utils.cpp:113-257
+# --------------------------------------------------------------------------
+
+
+@dataclass
+class Measurements:
+    """SoA form of std::vector<RelativeSEMeasurement>
+    (include/DPGO/RelativeSEMeasurement.h:21-50)."""
+    d: int
+    r1: np.ndarray  # int64 [m]
+    p1: np.ndarray
+    r2: np.ndarray
+    p2: np.ndarray
+    R: np.ndarray  # [m, d, d] (R[e][row, col])
+    t: np.ndarray  # [m, d]
+    kappa: np.ndarray
+    tau: np.ndarray
+    weight: np.ndarray
+    fixed: np.ndarray  # bool
+
+    @property
+    def m(self) -> int:
+        return len(self.p1)
+
+    def subset(self, idx) -> "Measurements":
+        idx = np.asarray(idx, dtype=np.int64)
+        return Measurements(self.d, self.r1[idx], self.p1[idx], self.r2[idx], self.p2[idx],
+                            self.R[idx], self.t[idx], self.kappa[idx], self.tau[idx],
+                            self.weight[idx], self.fixed[idx])
+
+    @staticmethod
+    def empty(d: int) -> "Measurements":
+        z = np.zeros(0, dtype=np.int64)
+        f = np.zeros(0)
+        return Measurements(d, z, z.copy(), z.copy(), z.copy(), np.zeros((0, d, d)), np.zeros((0, d)),
+                            f, f.copy(), f.copy(), np.zeros(0, dtype=bool))
+
+    @staticmethod
+    def concat(parts: List["Measurements"]) -> "Measurements":
+        d = parts[0].d
+        cat = lambda name: np.concatenate([getattr(p, name) for p in parts], axis=0)
+        return Measurements(d, cat("r1"), cat("p1"), cat("r2"), cat("p2"), cat("R"), cat("t"),
+                            cat("kappa"), cat("tau"), cat("weight"), cat("fixed"))
+
+
+def quat_to_rot_unnormalised(w, x, y, z):
+    """Eigen::Quaterniond(w,x,y,z).toRotationMatrix() -- no normalisation
+    (src/DPGO_utils.cpp:215; SURVEY 8c')."""
+    tx, ty, tz = 2 * x, 2 * y, 2 * z
+    twx, twy, twz = tx * w, ty * w, tz * w
+    txx, txy, txz = tx * x, ty * x, tz * x
+    tyy, tyz, tzz = ty * y, tz * y, tz * z
+    return np.array([[1 - (tyy + tzz), txy - twz, txz + twy],
+                     [txy + twz, 1 - (txx + tzz), tyz - twx],
+                     [txz - twy, tyz + twx, 1 - (txx + tyy)]])
+
+
+def read_g2o(path: str) -> Tuple[Measurements, int]:
+    """src/DPGO_utils.cpp:113-257.  Returns (measurements, num_poses)."""
+    p1, p2, Rs, ts, kap, tau, fixed = [], [], [], [], [], [], []
+    d = None
+    with open(path) as fh:
+        for line in fh:
+            tok = line.split()
+            if not tok:
+                continue
+            if tok[0] == "EDGE_SE2":  # :144-182
+                i, j = int(tok[1]), int(tok[2])
+                dx, dy, dth = map(float, tok[3:6])
+                I11, I12, I13, I22, I23, I33 = map(float, tok[6:12])
+                d = 2
+                c, s = math.cos(dth), math.sin(dth)
+                R = np.array([[c, -s], [s, c]])
+                t = np.array([dx, dy])
+                TranCov = np.array([[I11, I12], [I12, I22]])
+                tau_e = 2.0 / np.trace(np.linalg.inv(TranCov))  # :174
+                kap_e = I33  # :176
+            elif tok[0] == "EDGE_SE3:QUAT":  # :184-236
+                i, j = int(tok[1]), int(tok[2])
+                dx, dy, dz, qx, qy, qz, qw = map(float, tok[3:10])
+                I = list(map(float, tok[10:31]))
+                (I11, I12, I13, I14, I15, I16, I22, I23, I24, I25, I26,
+                 I33, I34, I35, I36, I44, I45, I46, I55, I56, I66) = I
+                d = 3
+                R = quat_to_rot_unnormalised(qw, qx, qy, qz)
+                t = np.array([dx, dy, dz])
+                TranCov = np.array([[I11, I12, I13], [I12, I22, I23], [I13, I23, I33]])
+                tau_e = 3.0 / np.trace(np.linalg.inv(TranCov))  # :223
+                RotCov = np.array([[I44, I45, I46], [I45, I55, I56], [I46, I56, I66]])
+                kap_e = 3.0 / (2.0 * np.trace(np.linalg.inv(RotCov)))  # :230
+            elif tok[0] in ("VERTEX_SE2", "VERTEX_SE3:QUAT"):  # :238-240
+                continue
+            else:
+                raise ValueError("unrecognized g2o token %r" % tok[0])
+            p1.append(i); p2.append(j); Rs.append(R); ts.append(t)
+            kap.append(kap_e); tau.append(tau_e); fixed.append(i + 1 == j)
+    m = len(p1)
+    z = np.zeros(m, dtype=np.int64)
+    meas = Measurements(d, z, np.array(p1, dtype=np.int64), z.copy(), np.array(p2, dtype=np.int64),
+                        np.array(Rs), np.array(ts), np.array(kap), np.array(tau),
+                        np.ones(m), np.array(fixed, dtype=bool))
+    n = int(max(meas.p1.max(), meas.p2.max())) + 1  # :246-254
+    return meas, n
+
+
+# --------------------------------------------------------------------------
+# Partition -- examples/MultiRobotExample.cpp:71-119
+# --------------------------------------------------------------------------
+
+
+def partition_contiguous(meas: Measurements, n: int, num_robots: int):
+    """Contiguous index-range partition.  Returns (ranges, per_robot) where
+    per_robot[a] = dict(odometry, private, shared) in local pose indices; a shared
+    edge is pushed to BOTH endpoints' lists (MultiRobotExample.cpp:113-117)."""
+    per = n // num_robots
+    assert per > 0
+    starts = [a * per for a in range(num_robots)]
+    ends = [(a + 1) * per for a in range(num_robots)]
+    ends[-1] = n
+    robot_of = np.minimum(np.arange(n) // per, num_robots - 1)
+    local = np.arange(n) - np.array(starts)[robot_of]
+    g = Measurements(meas.d, robot_of[meas.p1], local[meas.p1], robot_of[meas.p2], local[meas.p2],
+                     meas.R, meas.t, meas.kappa, meas.tau, np.ones(meas.m), np.zeros(meas.m, dtype=bool))
+    out = []
+    for a in range(num_robots):
+        same = (g.r1 == a) & (g.r2 == a)
+        odo = same & (g.p1 + 1 == g.p2)
+        prv = same & ~odo
+        shr = ((g.r1 == a) | (g.r2 == a)) & ~same
+        out.append(dict(odometry=g.subset(np.nonzero(odo)[0]), private=g.subset(np.nonzero(prv)[0]),
+                        shared=g.subset(np.nonzero(shr)[0])))
+    return list(zip(starts, ends)), out
+
+
+# --------------------------------------------------------------------------
+# Connection Laplacian and the agent-local data matrices
+#   src/DPGO_utils.cpp:272-344, src/PoseGraph.cpp:381-491 (Q), :493-580 (G)
+# --------------------------------------------------------------------------
+
+
+def _T_Omega(meas: Measurements):
+    """T = [R t; 0 1], Omega = diag(w*kappa (x d), w*tau)  (DPGO_utils.cpp:307-329)."""
+    m, d = meas.m, meas.d
+    b = d + 1
+    T = np.zeros((m, b, b))
+    T[:, :d, :d] = meas.R
+    T[:, :d, d] = meas.t
+    T[:, d, d] = 1.0
+    om = np.empty((m, b))
+    om[:, :d] = (meas.weight * meas.kappa)[:, None]
+    om[:, d] = meas.weight * meas.tau
+    return T, om
+
+
+class BSR:
+    """Block-CSR of the symmetric (d+1)n x (d+1)n matrix Q.  vals[t] is the dense
+    b x b block Q[i*b:(i+1)*b, j*b:(j+1)*b] stored ROW-major (scipy.sparse.bsr_matrix
+    layout); colidx sorted within each block row."""
+
+    def __init__(self, n, b, rowptr, colidx, vals):
+        self.n, self.b = n, b
+        self.rowptr = np.ascontiguousarray(rowptr, dtype=np.int32)
+        self.colidx = np.ascontiguousarray(colidx, dtype=np.int32)
+        self.vals = np.ascontiguousarray(vals, dtype=np.float64)
+
+    @property
+    def nnzb(self):
+        return len(self.colidx)
+
+    def to_scipy(self):
+        N = self.n * self.b
+        return sp.bsr_matrix((self.vals, self.colidx, self.rowptr), shape=(N, N))
+
+    def diag_blocks(self):
+        rows = np.repeat(np.arange(self.n), np.diff(self.rowptr))
+        sel = np.nonzero(rows == self.colidx)[0]
+        out = np.zeros((self.n, self.b, self.b))
+        out[rows[sel]] = self.vals[sel]
+        return out
+
+
+def bsr_from_block_triplets(n, b, bi, bj, blocks) -> BSR:
+    """Sum duplicate (bi,bj) blocks, sort by (row, col)."""
+    bi = np.asarray(bi, dtype=np.int64); bj = np.asarray(bj, dtype=np.int64)
+    key = bi * n + bj
+    order = np.argsort(key, kind="stable")
+    key_s = key[order]
+    uniq, first = np.unique(key_s, return_index=True)
+    vals = np.add.reduceat(blocks[order], first, axis=0) if len(key_s) else np.zeros((0, b, b))
+    rows = uniq // n
+    cols = uniq % n
+    rowptr = np.zeros(n + 1, dtype=np.int64)
+    np.add.at(rowptr, rows + 1, 1)
+    rowptr = np.cumsum(rowptr)
+    return BSR(n, b, rowptr, cols, vals)
+
+
+def construct_Q(n: int, d: int, private: Measurements, shared: Optional[Measurements] = None,
+                my_id: int = 0, priors: Optional[Dict[int, np.ndarray]] = None,
+                prior_kappa: float = 10000.0, prior_tau: float = 100.0) -> BSR:
+    """PoseGraph::constructQ (src/PoseGraph.cpp:381-491) with
+    constructConnectionLaplacianSE (src/DPGO_utils.cpp:272-344).
+
+    Private edge (i->j): Q_ii += T Om T^T, Q_jj += Om, Q_ij = -T Om, Q_ji = Q_ij^T.
+    Shared edge, mine = source (outgoing): Q[p1,p1] += T Om T^T (:431-434);
+    mine = destination (incoming): Q[p2,p2] += Om (:455-457).
+    Prior on pose idx: Q[idx,idx] += diag(prior_kappa.., prior_tau) (:461-468).
+    Every pose gets an (explicit) diagonal block, as the reference's QDiag does (:470-485).
+    """
+    b = d + 1
+    bi, bj, blk = [np.arange(n)], [np.arange(n)], [np.zeros((n, b, b))]
+    if private is not None and private.m:
+        T, om = _T_Omega(private)
+        TO = T * om[:, None, :]  # T @ diag(om)
+        TOT = TO @ np.transpose(T, (0, 2, 1))
+        Om = np.zeros((private.m, b, b))
+        Om[:, np.arange(b), np.arange(b)] = om
+        i, j = private.p1, private.p2
+        bi += [i, j, i, j]
+        bj += [i, j, j, i]
+        blk += [TOT, Om, -TO, -np.transpose(TO, (0, 2, 1))]
+    if shared is not None and shared.m:
+        T, om = _T_Omega(shared)
+        TO = T * om[:, None, :]
+        TOT = TO @ np.transpose(T, (0, 2, 1))
+        Om = np.zeros((shared.m, b, b))
+        Om[:, np.arange(b), np.arange(b)] = om
+        out = shared.r1 == my_id
+        if out.any():
+            bi.append(shared.p1[out]); bj.append(shared.p1[out]); blk.append(TOT[out])
+        if (~out).any():
+            bi.append(shared.p2[~out]); bj.append(shared.p2[~out]); blk.append(Om[~out])
+    if priors:
+        idx = np.array(sorted(priors.keys()), dtype=np.int64)
+        P = np.zeros((len(idx), b, b))
+        P[:, np.arange(d), np.arange(d)] = prior_kappa
+        P[:, d, d] = prior_tau
+        bi.append(idx); bj.append(idx); blk.append(P)
+    return bsr_from_block_triplets(n, b, np.concatenate(bi), np.concatenate(bj), np.concatenate(blk, axis=0))
+
+
+def construct_G(n: int, d: int, r: int, shared: Optional[Measurements], my_id: int,
+                neighbor_poses: Dict[Tuple[int, int], np.ndarray],
+                priors: Optional[Dict[int, np.ndarray]] = None,
+                prior_kappa: float = 10000.0, prior_tau: float = 100.0) -> np.ndarray:
+    """PoseGraph::constructG (src/PoseGraph.cpp:493-580).  neighbor_poses maps
+    (robot, frame) -> tile [d+1, r] (the LiftedPose r x (d+1), column-major).
+    Outgoing: G[:,p1] += -X_j Om T^T (:533-537); incoming: G[:,p2] += -X_i T Om (:558-562);
+    prior: G[:,idx] += -P Om (:565-574).  Returns G in the [n, d+1, r] view."""
+    b = d + 1
+    G = np.zeros((n, b, r))
+    if shared is not None and shared.m:
+        T, om = _T_Omega(shared)
+        for e in range(shared.m):
+            if shared.r1[e] == my_id:
+                Xj = neighbor_poses[(int(shared.r2[e]), int(shared.p2[e]))]  # [b, r] == (r x b)^T
+                # L = -Xj Om T^T  ->  L^T = -T Om Xj^T
+                G[shared.p1[e]] += -(T[e] * om[e][None, :]) @ Xj
+            else:
+                Xi = neighbor_poses[(int(shared.r1[e]), int(shared.p1[e]))]
+                # L = -Xi T Om  ->  L^T = -Om T^T Xi^T
+                G[shared.p2[e]] += -(om[e][:, None] * T[e].T) @ Xi
+    if priors:
+        om = np.array([prior_kappa] * d + [prior_tau])
+        for idx, P in priors.items():
+            G[idx] += -(om[:, None] * P)
+    return G
+
+
+# --------------------------------------------------------------------------
+# Manifold (St(d,r) x R^r)^n -- ROPTLIB Stiefel (ChooseStieParamsSet3: Euclidean metric,
+# qf retraction, extrinsic representation) x Euclidean, configured at
+# src/manifold/LiftedSEManifold.cpp:16-24.  Restated from the published algorithm
+# (SURVEY.md 8c' items 1-3).
+# --------------------------------------------------------------------------
+
+
+def sym(A):
+    return 0.5 * (A + np.swapaxes(A, -1, -2))
+
+
+def tangent_project(X, W, d):
+    """ROPTLIB Stiefel::ExtrProjection per pose: W_rot - Y sym(Y^T W_rot); translation
+    column untouched (ProductManifold::Projection).  X, W: [n, d+1, r]."""
+    Y = X[:, :d, :]  # [n, d, r] == Y^T
+    Wr = W[:, :d, :]
+    S = sym(Y @ np.swapaxes(Wr, 1, 2))  # (Y^T W)[k,c] = sum_a Y[a,k] W[a,c]
+    out = W.copy()
+    out[:, :d, :] = Wr - np.swapaxes(S, 1, 2) @ Y  # (Y S)^T = S^T Y^T
+    return out
+
+
+def qf_retract(X, eta, d):
+    """ROPTLIB Stiefel::qfRetraction: Q-factor of the thin QR of Y+eta with diag(R) > 0;
+    Euclidean factor p + eta (SURVEY 8c' item 2).  Implemented as modified Gram-Schmidt,
+    which equals any positive-diagonal thin QR up to round-off."""
+    out = X + eta
+    A = out[:, :d, :]  # rows are the columns of Y+eta
+    Q = np.empty_like(A)
+    for k in range(d):
+        v = A[:, k, :].copy()
+        for l in range(k):
+            v -= np.sum(Q[:, l, :] * v, axis=1, keepdims=True) * Q[:, l, :]
+        Q[:, k, :] = v / np.linalg.norm(v, axis=1, keepdims=True)
+    out[:, :d, :] = Q
+    return out
+
+
+def polar_project(M, d):
+    """LiftedSEManifold::project (src/manifold/LiftedSEManifold.cpp:34-45) ->
+    projectToStiefelManifold (src/DPGO_utils.cpp:480-486): U V^T of the thin SVD of the
+    r x d block; translations copied."""
+    out = M.copy()
+    A = np.swapaxes(M[:, :d, :], 1, 2)  # [n, r, d]
+    U, _, Vt = np.linalg.svd(A, full_matrices=False)
+    out[:, :d, :] = np.swapaxes(U @ Vt, 1, 2)
+    return out
+
+
+def project_to_rotation_group(M):
+    """src/DPGO_utils.cpp:464-478."""
+    U, _, Vt = np.linalg.svd(M)
+    if np.linalg.det(U) * np.linalg.det(Vt) > 0:
+        return U @ Vt
+    U = U.copy(); U[:, -1] *= -1
+    return U @ Vt
+
+
+# --------------------------------------------------------------------------
+# QuadraticProblem -- src/QuadraticProblem.cpp
+# --------------------------------------------------------------------------
+
+
+class QuadraticProblem:
+    """f(X) = 0.5 <Q, X^T X> + <X, G>  (include/DPGO/QuadraticProblem.h:28-32).
+
+    precond: 'exact'  -> (Q + 0.1 I)^-1 via sparse LU of the SPD matrix, the reference's
+                         CHOLMOD path (src/PoseGraph.cpp:598-613, src/QuadraticProblem.cpp:56-69);
+             'jacobi' -> inverse of the (d+1)x(d+1) diagonal blocks of Q + 0.1 I (what the
+                         MI355X path runs; same fixed point, different trajectory);
+             'none'   -> identity.
+    All three are followed by the tangent projection (QuadraticProblem.cpp:68)."""
+
+    def __init__(self, Q: BSR, G: Optional[np.ndarray], r: int, d: int, precond: str = "exact",
+                 shift: float = 0.1):
+        self.Q, self.r, self.d, self.n = Q, r, d, Q.n
+        self.b = d + 1
+        self.N = self.n * self.b
+        self.Qs = Q.to_scipy().tocsr()
+        self.G = np.zeros((self.n, self.b, r)) if G is None else G
+        self.precond = precond
+        self.shift = shift
+        self._lu = None
+        self._dinv = None
+        self.n_spmm = 0
+
+    # --- SpMM: (X Q)^T = Q X^T (Q symmetric) ---
+    def XQ(self, X):
+        self.n_spmm += 1
+        return (self.Qs @ X.reshape(self.N, self.r)).reshape(X.shape)
+
+    def f(self, X):  # QuadraticProblem.cpp:29-41
+        return 0.5 * np.sum(self.XQ(X) * X) + np.sum(X * self.G)
+
+    def euc_grad(self, X):  # :43-47
+        return self.XQ(X) + self.G
+
+    def euc_hess(self, V):  # :49-54
+        return self.XQ(V)
+
+    def rie_grad(self, X):  # :71-79
+        return tangent_project(X, self.euc_grad(X), self.d)
+
+    def rie_grad_norm(self, X):  # :81-83
+        return float(np.linalg.norm(self.rie_grad(X)))
+
+    def rie_hess(self, X, S, V):
+        """ROPTLIB Stiefel::EucHvToHv, Euclidean metric (SURVEY 8c' item 3):
+        proj_X( V Q - V_rot sym(Y^T EG_rot) ),  S = sym(Y^T EG_rot) cached per outer iterate."""
+        H = self.XQ(V)
+        d = self.d
+        H[:, :d, :] -= np.swapaxes(S, 1, 2) @ V[:, :d, :]
+        return tangent_project(X, H, d)
+
+    def sym_ytg(self, X, EG):
+        d = self.d
+        return sym(X[:, :d, :] @ np.swapaxes(EG[:, :d, :], 1, 2))
+
+    def dinv_blocks(self):
+        if self._dinv is None:
+            D = self.Q.diag_blocks() + self.shift * np.eye(self.b)[None]
+            self._dinv = np.linalg.inv(D)
+        return self._dinv
+
+    def precondition(self, X, V):  # QuadraticProblem.cpp:56-69
+        if self.precond == "exact":
+            if self._lu is None:
+                P = (self.Qs + self.shift * sp.identity(self.N, format="csr")).tocsc()
+                self._lu = spla.splu(P)
+            Z = self._lu.solve(V.reshape(self.N, self.r)).reshape(V.shape)
+        elif self.precond == "jacobi":
+            # z_i (r x b) = v_i (r x b) Dinv_i ; in the [b, r] view: Z_i = Dinv_i^T V_i = Dinv_i V_i
+            Z = self.dinv_blocks() @ V
+        elif self.precond == "none":
+            Z = V.copy()
+        else:
+            raise ValueError(self.precond)
+        return tangent_project(X, Z, self.d)
+
+
+# --------------------------------------------------------------------------
+# QuadraticOptimizer -- src/QuadraticOptimizer.cpp  (+ ROPTLIB RTRNewton / tCG_TR)
+# --------------------------------------------------------------------------
+
+TCG_NEGCURV, TCG_EXCREGION, TCG_LCON, TCG_SCON, TCG_MAXITER = 0, 1, 2, 3, 4
+TCG_NAMES = ["NEGCURVTURE", "EXCREGION", "LCON", "SCON", "MAXITER"]
+
+
+@dataclass
+class ROptParameters:  # include/DPGO/DPGO_types.h:44-86
+    method: str = "RTR"
+    verbose: bool = False
+    gradnorm_tol: float = 1e-2
+    RGD_stepsize: float = 1e-3
+    RGD_use_preconditioner: bool = True
+    RTR_iterations: int = 3
+    RTR_tCG_iterations: int = 50
+    RTR_initial_radius: float = 100.0
+
+
+@dataclass
+class ROPTResult:  # include/DPGO/DPGO_types.h:91-107
+    success: bool = False
+    fInit: float = 0.0
+    gradNormInit: float = 0.0
+    fOpt: float = 0.0
+    gradNormOpt: float = 0.0
+    elapsedMs: float = 0.0
+    tCGStatus: int = TCG_MAXITER
+    # extras (not in the reference struct): bookkeeping used by parity tests
+    tcg_iters: int = 0
+    outer_iters: int = 0
+    trace: list = field(default_factory=list)
+
+
+def dot(A, B):
+    """ROPTLIB ProductManifold::Metric with Euclidean-metric factors = plain dot over all
+    r(d+1)n entries."""
+    return float(np.sum(A * B))
+
+
+def tcg(problem: QuadraticProblem, X, g, S, Delta, max_inner, theta=1.0, kappa=0.1, min_inner=0, trace=None):
+    """ROPTLIB SolversTR::tCG_TR restated, eta0 = 0 (useRand = false).
+    Returns (eta, status, inner_iters, n_hess)."""
+    r = g.copy()
+    e_Pe = 0.0
+    r_r = dot(r, r)
+    norm_r0 = math.sqrt(r_r)
+    z = problem.precondition(X, r)
+    z_r = dot(z, r)
+    d_Pd = z_r
+    delta = -z
+    e_Pd = 0.0
+    eta = np.zeros_like(g)
+    status = TCG_MAXITER
+    j = 0
+    n_hess = 0
+    while j < max_inner:
+        Hd = problem.rie_hess(X, S, delta)
+        n_hess += 1
+        d_Hd = dot(delta, Hd)
+        alpha = z_r / d_Hd if d_Hd != 0 else math.inf
+        e_Pe_new = e_Pe + 2.0 * alpha * e_Pd + alpha * alpha * d_Pd
+        if d_Hd <= 0 or e_Pe_new >= Delta * Delta:
+            tau = (-e_Pd + math.sqrt(e_Pd * e_Pd + d_Pd * (Delta * Delta - e_Pe))) / d_Pd
+            eta = eta + tau * delta
+            status = TCG_NEGCURV if d_Hd < 0 else TCG_EXCREGION
+            if trace is not None:
+                trace.append(dict(j=j, d_Hd=d_Hd, alpha=alpha, tau=tau, status=status))
+            break
+        e_Pe = e_Pe_new
+        eta = eta + alpha * delta
+        r = r + alpha * Hd
+        r_r = dot(r, r)
+        norm_r = math.sqrt(r_r)
+        if trace is not None:
+            trace.append(dict(j=j, d_Hd=d_Hd, alpha=alpha, norm_r=norm_r))
+        if j >= min_inner and norm_r <= norm_r0 * min(norm_r0 ** theta, kappa):
+            status = TCG_LCON if kappa < norm_r0 ** theta else TCG_SCON
+            break
+        z = problem.precondition(X, r)
+        zold_rold = z_r
+        z_r = dot(z, r)
+        beta = z_r / zold_rold
+        delta = beta * delta - z
+        e_Pd = beta * (e_Pd + alpha * d_Pd)
+        d_Pd = z_r + beta * beta * d_Pd
+        j += 1
+    return eta, status, j, n_hess
+
+
+class QuadraticOptimizer:
+    """src/QuadraticOptimizer.cpp.  `accept_tiny_decrease` is SURVEY 8c' item 5 (newer
+    ROPTLIB accepts a step whose relative decrease is positive but below sqrt(eps))."""
+
+    def __init__(self, problem: QuadraticProblem, params: Optional[ROptParameters] = None,
+                 accept_tiny_decrease: bool = True):
+        self.problem = problem
+        self.params = params or ROptParameters()
+        self.result = ROPTResult()
+        self.accept_tiny_decrease = accept_tiny_decrease
+
+    def optimize(self, Y):  # QuadraticOptimizer.cpp:26-48
+        import time
+        p = self.problem
+        self.result = ROPTResult()
+        self.result.fInit = p.f(Y)
+        self.result.gradNormInit = p.rie_grad_norm(Y)
+        t0 = time.perf_counter()
+        if self.params.method == "RTR":
+            Yopt = self.trust_region(Y)
+        else:
+            Yopt = self.gradient_descent(Y)
+        self.result.elapsedMs = 1e3 * (time.perf_counter() - t0)
+        self.result.fOpt = p.f(Yopt)
+        self.result.gradNormOpt = p.rie_grad_norm(Yopt)
+        self.result.success = True
+        return Yopt
+
+    def _run_rtr(self, x1, Delta0, Delta_max, max_iter):
+        """ROPTLIB SolversTR::Run restated (SURVEY 8a row a8 / 8c' item 4)."""
+        p, d = self.problem, self.problem.d
+        prm = self.params
+        sqeps = math.sqrt(np.finfo(float).eps)
+        EG = p.euc_grad(x1)
+        f1 = 0.5 * np.sum((EG - p.G) * x1) + np.sum(x1 * p.G)
+        S = p.sym_ytg(x1, EG)
+        g1 = tangent_project(x1, EG, d)
+        ngf = math.sqrt(dot(g1, g1))
+        Delta = Delta0
+        it = 0
+        accepted_last = False
+        status = TCG_MAXITER
+        isstop = ngf < prm.gradnorm_tol
+        while not isstop and it < max_iter:
+            tr = [] if prm.verbose else None
+            eta, status, inner, n_hess = tcg(p, x1, g1, S, Delta, prm.RTR_tCG_iterations, trace=tr)
+            self.result.tcg_iters += n_hess
+            x2 = qf_retract(x1, eta, d)
+            f2 = p.f(x2)
+            Heta = p.rie_hess(x1, S, eta)
+            rho = (f1 - f2) / (-dot(eta, g1 + 0.5 * Heta))
+            if rho > 0.75:
+                if status in (TCG_EXCREGION, TCG_NEGCURV):
+                    Delta *= 2.0
+                if Delta > Delta_max:
+                    Delta = Delta_max
+            elif rho < 0.25:
+                Delta *= 0.25
+            accept = rho > 0.1 or (self.accept_tiny_decrease and
+                                   abs(f1 - f2) / (abs(f1) + 1) < sqeps and f2 < f1)
+            self.result.trace.append(dict(it=it, f1=f1, f2=f2, rho=rho, Delta=Delta, inner=inner,
+                                          status=status, accept=accept, ngf=ngf))
+            if accept:
+                EG = p.euc_grad(x2)
+                S = p.sym_ytg(x2, EG)
+                g1 = tangent_project(x2, EG, d)
+                ngf = math.sqrt(dot(g1, g1))
+                x1, f1 = x2, f2
+                isstop = ngf < prm.gradnorm_tol
+            accepted_last = accept
+            it += 1
+        self.result.outer_iters += it
+        self.result.tCGStatus = status
+        return x1, accepted_last
+
+    def trust_region(self, Yinit):  # QuadraticOptimizer.cpp:50-108
+        prm = self.params
+        gn0 = self.problem.rie_grad_norm(Yinit)
+        if gn0 < prm.gradnorm_tol:  # :57-59
+            return Yinit
+        if prm.RTR_iterations == 1:  # :80-99
+            radius = prm.RTR_initial_radius
+            total = 0
+            while True:
+                x, accepted = self._run_rtr(Yinit.copy(), radius, radius, 1)
+                if accepted:
+                    return x
+                if total > 10:
+                    return Yinit
+                radius /= 4
+                total += 1
+        x, _ = self._run_rtr(Yinit.copy(), prm.RTR_initial_radius, 5 * prm.RTR_initial_radius,
+                             prm.RTR_iterations)  # :68-69,100
+        return x
+
+    def gradient_descent(self, Yinit):  # QuadraticOptimizer.cpp:110-137
+        p, prm = self.problem, self.params
+        g = p.rie_grad(Yinit)
+        if prm.RGD_use_preconditioner:
+            g = p.precondition(Yinit, g)
+        return qf_retract(Yinit, -prm.RGD_stepsize * g, p.d)
+
+
+# --------------------------------------------------------------------------
+# Initialisation helpers (host-side, "next" rows of SURVEY 8f; needed by the harness)
+# --------------------------------------------------------------------------
+
+
+def lift(T, r):
+    """X = YLift * T with YLift = [I_d; 0] (gauge note, SURVEY 8c: cost, gradnorm and the
+    whole RTR trajectory are invariant under X -> O X)."""
+    n, b, d = T.shape
+    X = np.zeros((n, b, r))
+    X[:, :, :d] = T
+    return X
+
+
+def odometry_initialization(odometry: Measurements, n: int):
+    """src/DPGO_solver.cpp:271-303.  Returns T in the [n, d+1, d] view."""
+    d = odometry.d
+    T = np.zeros((n, d + 1, d))
+    T[0, :d, :] = np.eye(d)
+    order = {int(odometry.p1[e]): e for e in range(odometry.m)}
+    for dst in range(1, n):
+        e = order[dst - 1]
+        assert odometry.p2[e] == dst
+        Rsrc = T[dst - 1, :d, :].T
+        tsrc = T[dst - 1, d, :]
+        T[dst, :d, :] = (Rsrc @ odometry.R[e]).T
+        T[dst, d, :] = tsrc + Rsrc @ odometry.t[e]
+    return T
+
+
+def chordal_initialization(meas: Measurements, n: int):
+    """src/DPGO_solver.cpp:220-269 with constructBMatrices / recoverTranslations
+    (src/DPGO_utils.cpp:346-462).  The reference solves the two least-squares problems by
+    SPQR; here by sparse normal equations (same minimiser; full column rank once pose 0 is
+    pinned)."""
+    d, m = meas.d, meas.m
+    d2 = d * d
+    rows, cols, vals = [], [], []
+    sk = np.sqrt(meas.kappa)
+    # B3: rows e*d2 + d*r + l ; cols i*d2 + d*c + l ; val -sqrt(kappa) R(c, r)   (:417-433)
+    for r_ in range(d):
+        for c in range(d):
+            for l in range(d):
+                rows.append(np.arange(m) * d2 + d * r_ + l)
+                cols.append(meas.p1 * d2 + d * c + l)
+                vals.append(-sk * meas.R[:, c, r_])
+    for l in range(d2):
+        rows.append(np.arange(m) * d2 + l)
+        cols.append(meas.p2 * d2 + l)
+        vals.append(sk)
+    B3 = sp.csr_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))), shape=(m * d2, n * d2))
+    Id_vec = np.eye(d).reshape(-1)
+    cR = B3[:, :d2] @ Id_vec
+    B3red = B3[:, d2:].tocsc()
+    A = (B3red.T @ B3red).tocsc()
+    rvec = -spla.splu(A).solve(B3red.T @ cR)
+    Rch = np.zeros((n, d, d))
+    Rch[0] = np.eye(d)
+    # column-major d x d blocks: rvec[(i-1)*d2 + d*c + l] = R_i(l, c)
+    Rm = rvec.reshape(n - 1, d, d)  # [i, c, l]
+    for i in range(1, n):
+        Rch[i] = project_to_rotation_group(Rm[i - 1].T)
+    # translations: B1 (:367-389), B2 (:394-407)
+    st = np.sqrt(meas.tau)
+    rows, cols, vals = [], [], []
+    for l in range(d):
+        rows += [np.arange(m) * d + l, np.arange(m) * d + l]
+        cols += [meas.p1 * d + l, meas.p2 * d + l]
+        vals += [-st, st]
+    B1 = sp.csr_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))), shape=(m * d, n * d))
+    rows, cols, vals = [], [], []
+    for k in range(d):
+        for r_ in range(d):
+            rows.append(np.arange(m) * d + r_)
+            cols.append(meas.p1 * d2 + d * k + r_)
+            vals.append(-st * meas.t[:, k])
+    B2 = sp.csr_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))), shape=(m * d, n * d2))
+    rv = np.swapaxes(Rch, 1, 2).reshape(-1)  # column-major vec of each R_i
+    c = B2 @ rv
+    B1red = B1[:, d:].tocsc()
+    A = (B1red.T @ B1red).tocsc()
+    tred = -spla.splu(A).solve(B1red.T @ c)
+    t = np.zeros((n, d))
+    t[1:] = tred.reshape(n - 1, d)
+    T = np.zeros((n, d + 1, d))
+    T[:, :d, :] = np.swapaxes(Rch, 1, 2)
+    T[:, d, :] = t
+    return T
+
+
+def measurement_error(meas: Measurements, X):
+    """computeMeasurementError (src/DPGO_utils.cpp:501-507) for every edge of a single-agent
+    graph; X in the [n, d+1, r] view."""
+    d = meas.d
+    Y1 = np.swapaxes(X[meas.p1, :d, :], 1, 2)  # [m, r, d]
+    Y2 = np.swapaxes(X[meas.p2, :d, :], 1, 2)
+    t1, t2 = X[meas.p1, d, :], X[meas.p2, d, :]
+    rot = np.sum((Y1 @ meas.R - Y2) ** 2, axis=(1, 2))
+    tr = np.sum((t2 - t1 - (Y1 @ meas.t[:, :, None])[:, :, 0]) ** 2, axis=1)
+    return meas.kappa * rot + meas.tau * tr
+
+
+# --------------------------------------------------------------------------
+# Synthetic 3-D grid (config C4 of SURVEY 8d)
+# --------------------------------------------------------------------------
+
+
+def _rotvec_to_R(v):
+    th = np.linalg.norm(v, axis=1)
+    k = v / np.maximum(th, 1e-300)[:, None]
+    K = np.zeros((len(v), 3, 3))
+    K[:, 0, 1], K[:, 0, 2] = -k[:, 2], k[:, 1]
+    K[:, 1, 0], K[:, 1, 2] = k[:, 2], -k[:, 0]
+    K[:, 2, 0], K[:, 2, 1] = -k[:, 1], k[:, 0]
+    s, c = np.sin(th)[:, None, None], np.cos(th)[:, None, None]
+    return np.eye(3)[None] + s * K + (1 - c) * (K @ K)
+
+
+def synthetic_grid(nx: int, ny: int, nz: int, seed: int = 0, sigma_t: float = 0.1, sigma_r: float = 0.2):
+    """Config C4: nx x ny x nz lattice, boustrophedon odometry path with x fastest,
+    then y, then z; a loop closure on every remaining lattice-adjacent pair; ground-truth
+    rotations uniform random; noise: translation N(0, sigma_t^2 I), rotation = axis-angle
+    N(0, sigma_r^2 I); information 1/sigma^2 I  => tau = 1/sigma_t^2, kappa = 1/(2 sigma_r^2)
+    by the g2o formulas (src/DPGO_utils.cpp:223,230).  RNG: numpy PCG64(seed).
+    Returns (measurements, n, T_true[n, 4, 3])."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    n = nx * ny * nz
+    idx = np.empty((nx, ny, nz), dtype=np.int64)
+    k = 0
+    for z in range(nz):
+        ys = range(ny) if z % 2 == 0 else range(ny - 1, -1, -1)
+        for yi, y in enumerate(ys):
+            fwd = ((yi + z * ny) % 2 == 0)
+            xs = range(nx) if fwd else range(nx - 1, -1, -1)
+            for x in xs:
+                idx[x, y, z] = k
+                k += 1
+    pos = np.zeros((n, 3))
+    gx, gy, gz = np.meshgrid(np.arange(nx), np.arange(ny), np.arange(nz), indexing="ij")
+    pos[idx.reshape(-1)] = np.stack([gx.reshape(-1), gy.reshape(-1), gz.reshape(-1)], axis=1)
+    q = rng.standard_normal((n, 4))
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    Rt = np.stack([quat_to_rot_unnormalised(*qq) for qq in q]) if n <= 4096 else _quat_batch(q)
+    pairs = []
+    a = idx[:-1, :, :].reshape(-1); b_ = idx[1:, :, :].reshape(-1); pairs.append(np.stack([a, b_], 1))
+    a = idx[:, :-1, :].reshape(-1); b_ = idx[:, 1:, :].reshape(-1); pairs.append(np.stack([a, b_], 1))
+    a = idx[:, :, :-1].reshape(-1); b_ = idx[:, :, 1:].reshape(-1); pairs.append(np.stack([a, b_], 1))
+    pairs = np.concatenate(pairs, 0)
+    lo = np.minimum(pairs[:, 0], pairs[:, 1]); hi = np.maximum(pairs[:, 0], pairs[:, 1])
+    order = np.lexsort((hi, lo))
+    lo, hi = lo[order], hi[order]
+    m = len(lo)
+    Ri, Rj = Rt[lo], Rt[hi]
+    Rij = np.swapaxes(Ri, 1, 2) @ Rj
+    tij = (np.swapaxes(Ri, 1, 2) @ (pos[hi] - pos[lo])[:, :, None])[:, :, 0]
+    Rn = _rotvec_to_R(sigma_r * rng.standard_normal((m, 3)))
+    Rmeas = Rij @ Rn
+    tmeas = tij + sigma_t * rng.standard_normal((m, 3))
+    z64 = np.zeros(m, dtype=np.int64)
+    meas = Measurements(3, z64, lo, z64.copy(), hi, Rmeas, tmeas,
+                        np.full(m, 1.0 / (2.0 * sigma_r ** 2)), np.full(m, 1.0 / sigma_t ** 2),
+                        np.ones(m), lo + 1 == hi)
+    Ttrue = np.zeros((n, 4, 3))
+    Ttrue[:, :3, :] = np.swapaxes(Rt, 1, 2)
+    Ttrue[:, 3, :] = pos
+    return meas, n, Ttrue
+
+
+def _quat_batch(q):
+    w, x, y, z = q[:, 0], q[:, 1], q[:, 2], q[:, 3]
+    R = np.empty((len(q), 3, 3))
+    R[:, 0, 0] = 1 - 2 * (y * y + z * z); R[:, 0, 1] = 2 * (x * y - w * z); R[:, 0, 2] = 2 * (x * z + w * y)
+    R[:, 1, 0] = 2 * (x * y + w * z); R[:, 1, 1] = 1 - 2 * (x * x + z * z); R[:, 1, 2] = 2 * (y * z - w * x)
+    R[:, 2, 0] = 2 * (x * z - w * y); R[:, 2, 1] = 2 * (y * z + w * x); R[:, 2, 2] = 1 - 2 * (x * x + y * y)
+    return R
+
+
+def perturbed_truth(Ttrue, seed: int = 2, sigma_t: float = 0.1, sigma_r: float = 0.2):
+    """Initial guess for C4: ground truth perturbed by the measurement-noise model."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    n = Ttrue.shape[0]
+    R = np.swapaxes(Ttrue[:, :3, :], 1, 2) @ _rotvec_to_R(sigma_r * rng.standard_normal((n, 3)))
+    T = Ttrue.copy()
+    T[:, :3, :] = np.swapaxes(R, 1, 2)
+    T[:, 3, :] += sigma_t * rng.standard_normal((n, 3))
+    return T

@@ -1,0 +1,149 @@
+"""CPU-side checks of the C-ABI library and the host logic (no GPU compute calls)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import DATA, ROOT, to_product_measurements
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    """Every function declared in include/dpgo_hip.h is exported by libdpgo_hip.so and bound in
+    dpgo_amd/lib.py."""
+    import dpgo_amd.lib as L
+    lib = L.load()
+    hdr = open(os.path.join(ROOT, "include", "dpgo_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(dpgo_[a-zA-Z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 30
+    for name in sorted(declared):
+        assert hasattr(lib, name), "libdpgo_hip.so does not export %s" % name
+        assert name in L.SIGNATURES, "%s not bound in dpgo_amd/lib.py" % name
+    assert set(L.SIGNATURES) == declared
+    assert lib.dpgo_version().startswith(b"dpgo_hip")
+
+
+def test_params_default_mirror_reference():
+    """ROptParameters defaults (include/DPGO/DPGO_types.h:53-61) and the preconditioner shift
+    (src/PoseGraph.cpp:603)."""
+    import dpgo_amd
+    import dpgo_amd.lib as L
+    c = L.RoptParamsC()
+    L.load().dpgo_ropt_params_default(C.byref(c))
+    assert (c.method, c.verbose, c.RGD_use_preconditioner, c.RTR_iterations, c.RTR_tCG_iterations) == (0, 0, 1, 3, 50)
+    assert (c.gradnorm_tol, c.RGD_stepsize, c.RTR_initial_radius, c.precond_shift) == (1e-2, 1e-3, 100.0, 1e-1)
+    assert c.time_bound_s == 5.0
+    p = dpgo_amd.ROptParameters().to_c()
+    for f, _ in L.RoptParamsC._fields_:
+        assert getattr(p, f) == getattr(c, f), f
+    assert L.load().dpgo_supported(3, 5) == 1 and L.load().dpgo_supported(2, 2) == 1
+    assert L.load().dpgo_supported(3, 2) == 0
+
+
+def test_no_cpu_fallback_without_device():
+    """Without a HIP device the product path fails loudly (DPGO_ERR_HIP); it never computes on the CPU."""
+    import dpgo_amd
+    import dpgo_amd.lib as L
+    if dpgo_amd.device_count() > 0:
+        pytest.skip("a GPU is present")
+    h = L._P()
+    rc = L.load().dpgo_problem_create(C.byref(h), 5, 3, 10, 0)
+    assert rc == L.ERR_HIP
+    assert b"device" in L.load().dpgo_last_error().lower()
+    M = np.zeros((5, 8), order="F")
+    with pytest.raises(dpgo_amd.DpgoError):
+        dpgo_amd.LiftedSEManifold(5, 3, 2).project(M)
+
+
+def test_invalid_arguments_are_reported_not_aborted():
+    """Reference: glog CHECK aborts (src/PoseGraph.cpp:19, QuadraticProblem.cpp:30-31); C ABI: codes."""
+    import dpgo_amd
+    import dpgo_amd.lib as L
+    h = L._P()
+    assert L.load().dpgo_problem_create(C.byref(h), 2, 3, 10, 0) == L.ERR_INVALID  # r < d
+    assert L.load().dpgo_problem_create(C.byref(h), 5, 3, 0, 0) == L.ERR_INVALID  # n = 0
+    assert L.load().dpgo_problem_create(C.byref(h), 9, 3, 4, 0) in (L.ERR_UNSUPPORTED, L.ERR_HIP)
+    with pytest.raises(ValueError):
+        dpgo_amd.PoseGraph(0, 2, 3)
+    nn = C.c_int(0)
+    assert L.load().dpgo_build_Q_bsr(0, 4, 3, 0, *([None] * 9), 0, None, 1.0, 1.0, C.byref(nn), None, None, None) \
+        == L.ERR_INVALID
+
+
+@pytest.mark.parametrize("name", ["tinyGrid3D", "smallGrid3D", "sphere2500", "kitti_00"])
+def test_g2o_reader_and_Q_builder_match_oracle(oracle, name):
+    """read_g2o_file (src/DPGO_utils.cpp:113-257) and constructQ (src/PoseGraph.cpp:381-491):
+    product host code vs oracle."""
+    import dpgo_amd
+    path = os.path.join(DATA, name + ".g2o")
+    om, n = oracle.read_g2o(path)
+    pm, n2 = dpgo_amd.read_g2o_file(path)
+    assert n == n2 and len(pm) == om.m and pm.d == om.d
+    assert np.array_equal(pm.p1, om.p1) and np.array_equal(pm.p2, om.p2)
+    assert np.array_equal(pm.R, om.R) and np.array_equal(pm.t, om.t)
+    assert np.allclose(pm.kappa, om.kappa, rtol=1e-15) and np.allclose(pm.tau, om.tau, rtol=1e-15)
+    assert np.array_equal(pm.fixedWeight, om.fixed)
+    pg = dpgo_amd.PoseGraph(0, 5, om.d)
+    pg.setMeasurements(pm)
+    rp, ci, v = pg.quadraticMatrix()
+    Q = oracle.construct_Q(n, om.d, om)
+    assert np.array_equal(rp, Q.rowptr) and np.array_equal(ci, Q.colidx)
+    assert np.abs(v - Q.vals).max() <= 1e-13 * np.abs(Q.vals).max()
+    # symmetric, every block row has its diagonal block
+    S = oracle.BSR(n, om.d + 1, rp, ci, v).to_scipy().tocsr()
+    assert abs(S - S.T).max() <= 1e-12 * abs(S).max()
+    rows = np.repeat(np.arange(n), np.diff(rp))
+    assert np.array_equal(np.unique(rows[rows == ci]), np.arange(n))
+
+
+def test_partition_and_coupling_match_oracle(oracle):
+    """examples/MultiRobotExample.cpp:71-119 partition; constructQ/constructG with shared edges and a prior."""
+    import dpgo_amd
+    path = os.path.join(DATA, "smallGrid3D.g2o")
+    om, n = oracle.read_g2o(path)
+    pm, _ = dpgo_amd.read_g2o_file(path)
+    ranges, per = oracle.partition_contiguous(om, n, 5)
+    ranges_p, per_p = dpgo_amd.partition_contiguous(pm, n, 5)
+    assert ranges == ranges_p
+    r, d = 5, 3
+    X = oracle.polar_project(np.random.default_rng(0).standard_normal((n, d + 1, r)), d)
+    for a in range(5):
+        s, e = ranges[a]
+        na = e - s
+        pg = dpgo_amd.PoseGraph(a, r, d)
+        pg.setMeasurements(per_p[a])
+        nshared = per[a]["shared"].m
+        assert len(pg.sharedLoopClosures()) == nshared and pg.n() == na
+        prior = {2: X[s + 2]}
+        pg.setPrior(2, X[s + 2].T)
+        priv = oracle.Measurements.concat([per[a]["odometry"], per[a]["private"]])
+        Qa = oracle.construct_Q(na, d, priv, per[a]["shared"], my_id=a, priors=prior)
+        rp, ci, v = pg.quadraticMatrix()
+        assert np.array_equal(rp, Qa.rowptr) and np.array_equal(ci, Qa.colidx)
+        assert np.abs(v - Qa.vals).max() <= 1e-12 * np.abs(Qa.vals).max()
+        nbr = {pid: X[ranges[pid[0]][0] + pid[1]] for pid in pg.neighborPoseIDs()}
+        with pytest.raises(LookupError):  # missing active neighbour pose (src/PoseGraph.cpp:515-520)
+            pg.linearMatrix()
+        pg.setNeighborPoses({k: t.T for k, t in nbr.items()})
+        G = pg.linearMatrix()
+        Ga = oracle.construct_G(na, d, r, per[a]["shared"], a, nbr, priors=prior)
+        Gt = np.ascontiguousarray(G.T).reshape(na, d + 1, r)
+        assert np.abs(Gt - Ga).max() <= 1e-12 * np.abs(Ga).max()
+
+
+def test_duplicate_and_irrelevant_edges(oracle):
+    """PoseGraph::addMeasurement drops irrelevant edges (src/PoseGraph.cpp:68-71) and duplicates (:83-88)."""
+    import dpgo_amd
+    pm, n = dpgo_amd.read_g2o_file(os.path.join(DATA, "tinyGrid3D.g2o"))
+    dup = dpgo_amd.RelativeSEMeasurements.concatenate([pm, pm.select(np.array([0, 1]))])
+    other = pm.select(np.array([0]))
+    other.r1[:] = 3
+    other.r2[:] = 4
+    pg = dpgo_amd.PoseGraph(0, 5, 3)
+    pg.setMeasurements(dpgo_amd.RelativeSEMeasurements.concatenate([dup, other]))
+    assert len(pg.measurements()) == len(pm)
+    pg2 = dpgo_amd.PoseGraph(0, 5, 3)
+    pg2.setMeasurements(pm)
+    assert np.array_equal(pg.quadraticMatrix()[2], pg2.quadraticMatrix()[2])

@@ -1,0 +1,280 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle on the same inputs.
+
+Tolerances: fp64 kernels vs fp64 oracle; element-wise results must agree to 1e-11 relative
+(different but equivalent summation orders), whole-solve results at matched settings to 1e-9,
+and the final cost against the reference-configuration oracle (exact preconditioner) to the
+1e-6 relative that BASELINE.json's north_star states.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import DATA, matrix_to_tiles, tiles_to_matrix, to_product_measurements
+
+pytestmark = pytest.mark.gpu
+
+RTOL_ELEM = 1e-11
+
+
+def relerr(a, b):
+    return float(np.linalg.norm(np.asarray(a) - np.asarray(b)) / max(np.linalg.norm(np.asarray(b)), 1e-300))
+
+
+def build_single_agent(oracle, name, r):
+    import dpgo_amd
+    om, n = oracle.read_g2o(os.path.join(DATA, name + ".g2o"))
+    d = om.d
+    Q = oracle.construct_Q(n, d, om)
+    pg = dpgo_amd.PoseGraph(0, r, d)
+    pg.setMeasurements(to_product_measurements(om))
+    assert pg.n() == n
+    prob = dpgo_amd.QuadraticProblem(pg)
+    return om, n, d, Q, pg, prob
+
+
+def random_point(oracle, n, d, r, seed):
+    rng = np.random.default_rng(seed)
+    M = rng.standard_normal((n, d + 1, r))
+    return oracle.polar_project(M, d)
+
+
+@pytest.mark.parametrize("name,r", [("tinyGrid3D", 5), ("smallGrid3D", 5), ("smallGrid3D", 3), ("sphere2500", 5),
+                                    ("kitti_00", 5), ("kitti_00", 2), ("smallGrid3D", 4), ("smallGrid3D", 6)])
+def test_problem_evaluations_match_oracle(oracle, name, r):
+    """f, EucGrad, EucHessianEta, RieGrad, RieGradNorm, Riemannian Hessian, PreConditioner."""
+    om, n, d, Q, pg, prob = build_single_agent(oracle, name, r)
+    op = oracle.QuadraticProblem(Q, None, r, d, precond="jacobi")
+    X = random_point(oracle, n, d, r, 1)
+    V = np.random.default_rng(2).standard_normal((n, d + 1, r))
+    Xm, Vm = tiles_to_matrix(X), tiles_to_matrix(V)
+    assert abs(prob.f(Xm) - op.f(X)) <= 1e-12 * abs(op.f(X))
+    assert relerr(matrix_to_tiles(prob.EucGrad(Xm), d), op.euc_grad(X)) < RTOL_ELEM
+    assert relerr(matrix_to_tiles(prob.EucHessianEta(Xm, Vm), d), op.euc_hess(V)) < RTOL_ELEM
+    assert relerr(matrix_to_tiles(prob.RieGrad(Xm), d), op.rie_grad(X)) < RTOL_ELEM
+    assert abs(prob.RieGradNorm(Xm) - op.rie_grad_norm(X)) <= 1e-11 * op.rie_grad_norm(X)
+    S = op.sym_ytg(X, op.euc_grad(X))
+    Vt = oracle.tangent_project(X, V, d)
+    assert relerr(matrix_to_tiles(prob.RieHessianEta(Xm, tiles_to_matrix(Vt)), d), op.rie_hess(X, S, Vt)) < RTOL_ELEM
+    for pc in ("jacobi", "none"):
+        op.precond = pc
+        assert relerr(matrix_to_tiles(prob.PreConditioner(Xm, Vm, pc), d), op.precondition(X, V)) < RTOL_ELEM
+
+
+@pytest.mark.parametrize("d,r,n", [(3, 5, 1000), (3, 3, 17), (2, 2, 64), (2, 5, 333), (3, 6, 129), (3, 5, 1)])
+def test_manifold_ops_match_oracle(oracle, d, r, n):
+    """LiftedSEManifold::project (tests/testUtils.cpp:40-54 tolerance 1e-5 on Y^T Y = I; here also
+    element-wise vs the SVD oracle), tangent projection, qf retraction."""
+    import dpgo_amd
+    rng = np.random.default_rng(5)
+    M = rng.uniform(-1, 1, (n, d + 1, r))  # Matrix::Random, testUtils.cpp:45
+    man = dpgo_amd.LiftedSEManifold(r, d, n)
+    Xp = matrix_to_tiles(man.project(tiles_to_matrix(M)), d)
+    Y = Xp[:, :d, :]
+    assert np.abs(Y @ np.swapaxes(Y, 1, 2) - np.eye(d)).max() <= 1e-12
+    assert relerr(Xp, oracle.polar_project(M, d)) < 1e-10
+    X = oracle.polar_project(M, d)
+    V = rng.standard_normal((n, d + 1, r))
+    assert relerr(matrix_to_tiles(man.Projection(tiles_to_matrix(X), tiles_to_matrix(V)), d),
+                  oracle.tangent_project(X, V, d)) < RTOL_ELEM
+    eta = 0.3 * oracle.tangent_project(X, V, d)
+    Xr = matrix_to_tiles(man.Retraction(tiles_to_matrix(X), tiles_to_matrix(eta)), d)
+    assert relerr(Xr, oracle.qf_retract(X, eta, d)) < RTOL_ELEM
+    Yr = Xr[:, :d, :]
+    assert np.abs(Yr @ np.swapaxes(Yr, 1, 2) - np.eye(d)).max() <= 1e-12
+
+
+@pytest.mark.parametrize("name,r,precond", [("smallGrid3D", 5, "jacobi"), ("smallGrid3D", 5, "none"),
+                                            ("sphere2500", 5, "jacobi"), ("tinyGrid3D", 3, "jacobi"),
+                                            ("kitti_00", 5, "jacobi")])
+def test_optimize_matches_oracle_at_matched_settings(oracle, name, r, precond):
+    """One QuadraticOptimizer::optimize call with the reference defaults (RTR 3 x <=50 tCG,
+    Delta0 = 100, tol 1e-2): same preconditioner on both sides => same trajectory."""
+    import dpgo_amd
+    om, n, d, Q, pg, prob = build_single_agent(oracle, name, r)
+    if name == "tinyGrid3D":
+        T = oracle.odometry_initialization(om.subset(np.nonzero(om.p1 + 1 == om.p2)[0]), n)
+    else:
+        T = oracle.chordal_initialization(om, n)
+    X0 = oracle.lift(T, r)
+    op = oracle.QuadraticProblem(Q, None, r, d, precond=precond)
+    oopt = oracle.QuadraticOptimizer(op, oracle.ROptParameters())
+    Xo = oopt.optimize(X0)
+    gopt = dpgo_amd.QuadraticOptimizer(prob, dpgo_amd.ROptParameters(precond=precond))
+    Xg = matrix_to_tiles(gopt.optimize(tiles_to_matrix(X0)), d)
+    ro, rg = oopt.result, gopt.getOptResult()
+    assert rg.success
+    assert abs(rg.fInit - ro.fInit) <= 1e-12 * abs(ro.fInit)
+    assert abs(rg.gradNormInit - ro.gradNormInit) <= 1e-10 * ro.gradNormInit
+    assert rg.rtr_iterations == ro.outer_iters
+    assert rg.tcg_iterations == ro.tcg_iters
+    assert rg.tCGStatus == oracle.TCG_NAMES[ro.tCGStatus]
+    assert abs(rg.fOpt - ro.fOpt) <= 1e-9 * abs(ro.fOpt)
+    assert relerr(Xg, Xo) < 1e-7
+    # and the problem object agrees with the optimizer's own statistics (QuadraticOptimizer.cpp:42-43)
+    assert abs(prob.f(tiles_to_matrix(Xg)) - rg.fOpt) <= 1e-12 * abs(rg.fOpt)
+
+
+@pytest.mark.parametrize("name,ref2f", [("smallGrid3D", 1025.3980556263), ("sphere2500", 1687.0058142808),
+                                        ("torus3D", 24227.0455583823)])
+def test_final_cost_matches_reference_configuration(oracle, name, ref2f):
+    """north_star: final cost matches the reference CPU solver's on the same .g2o to 1e-6 relative.
+    Both sides run RTR to a tight gradient norm from the chordal initialisation; the oracle uses the
+    reference's exact (Q + 0.1 I)^-1 preconditioner, the device path block-Jacobi."""
+    import dpgo_amd
+    r = 5
+    om, n, d, Q, pg, prob = build_single_agent(oracle, name, r)
+    X0 = oracle.lift(oracle.chordal_initialization(om, n), r)
+    prm_o = oracle.ROptParameters(gradnorm_tol=1e-4, RTR_iterations=60, RTR_tCG_iterations=500)
+    oopt = oracle.QuadraticOptimizer(oracle.QuadraticProblem(Q, None, r, d, precond="exact"), prm_o)
+    oopt.optimize(X0)
+    prm_g = dpgo_amd.ROptParameters(gradnorm_tol=1e-4, RTR_iterations=60, RTR_tCG_iterations=500,
+                                    time_bound_s=120.0)
+    gopt = dpgo_amd.QuadraticOptimizer(prob, prm_g)
+    gopt.optimize(tiles_to_matrix(X0))
+    fo, fg = oopt.result.fOpt, gopt.getOptResult().fOpt
+    assert abs(fg - fo) <= 1e-6 * abs(fo)
+    assert abs(2 * fg - ref2f) <= 1e-6 * ref2f  # literature optimum
+    assert gopt.getOptResult().gradNormOpt < 1e-3
+
+
+def test_triangle_graph_known_answer(oracle):
+    """tests/testTriangleGraph.cpp:57 restated: noise-free 3-pose triangle, r = d = 3, kappa = tau = 1;
+    chordal init + RTR returns Ttrue to 1e-4 (Frobenius)."""
+    import dpgo_amd
+    from test_oracle import triangle_graph
+    om, Ttrue = triangle_graph(oracle)
+    d = r = 3
+    pg = dpgo_amd.PoseGraph(0, r, d)
+    pg.setMeasurements(to_product_measurements(om))
+    prob = dpgo_amd.QuadraticProblem(pg)
+    T0 = oracle.chordal_initialization(om, 3)
+    opt = dpgo_amd.QuadraticOptimizer(prob, dpgo_amd.ROptParameters())
+    Topt = opt.optimize(tiles_to_matrix(oracle.lift(T0, r)))
+    # express in the frame of pose 0 (PGOAgent::getTrajectoryInLocalFrame)
+    Tt = matrix_to_tiles(Topt, d)
+    R0 = Tt[0, :d, :].T
+    t0 = Tt[0, d, :]
+    out = np.zeros((d, 3 * (d + 1)))
+    for i in range(3):
+        Ri = Tt[i, :d, :].T
+        out[:, i * (d + 1):i * (d + 1) + d] = R0.T @ Ri
+        out[:, i * (d + 1) + d] = R0.T @ (Tt[i, d, :] - t0)
+    assert np.linalg.norm(out - Ttrue) <= 1e-4
+
+
+def test_prior_known_answer(oracle):
+    """tests/testPGO.cpp:131-190 (testPrior): 2-pose graph + prior on pose 1; RTR 50 x 500,
+    tol 1e-5 => both poses equal the prior to 1e-6."""
+    import dpgo_amd
+    from test_oracle import prior_problem
+    om, prior_pose, T0 = prior_problem(oracle)
+    d = r = 3
+    pg = dpgo_amd.PoseGraph(0, r, d)
+    pg.setMeasurements(to_product_measurements(om))
+    pg.setPrior(1, prior_pose)
+    prob = dpgo_amd.QuadraticProblem(pg)
+    prm = dpgo_amd.ROptParameters(RTR_iterations=50, RTR_tCG_iterations=500, gradnorm_tol=1e-5)
+    opt = dpgo_amd.QuadraticOptimizer(prob, prm)
+    X0 = tiles_to_matrix(oracle.lift(T0, r))
+    assert np.linalg.norm(X0[:, 0:4] - prior_pose) > 1e-6
+    Topt = opt.optimize(X0)
+    assert np.linalg.norm(Topt[:, 0:4] - prior_pose) < 1e-6
+    assert np.linalg.norm(Topt[:, 4:8] - prior_pose) < 1e-6
+
+
+def test_rgd_step_matches_oracle(oracle):
+    """QuadraticOptimizer::gradientDescent (src/QuadraticOptimizer.cpp:110-137)."""
+    import dpgo_amd
+    om, n, d, Q, pg, prob = build_single_agent(oracle, "smallGrid3D", 5)
+    X0 = oracle.lift(oracle.chordal_initialization(om, n), 5)
+    for use_pc in (True, False):
+        op = oracle.QuadraticProblem(Q, None, 5, d, precond="jacobi")
+        oo = oracle.QuadraticOptimizer(op, oracle.ROptParameters(method="RGD", RGD_use_preconditioner=use_pc))
+        Xo = oo.optimize(X0)
+        go = dpgo_amd.QuadraticOptimizer(prob, dpgo_amd.ROptParameters(method="RGD", RGD_use_preconditioner=use_pc))
+        Xg = matrix_to_tiles(go.optimize(tiles_to_matrix(X0)), d)
+        assert relerr(Xg, Xo) < RTOL_ELEM
+        assert abs(go.getOptResult().fOpt - oo.result.fOpt) <= 1e-12 * abs(oo.result.fOpt)
+
+
+def test_multi_agent_G_and_local_problem(oracle):
+    """constructQ / constructG for an agent with shared edges (src/PoseGraph.cpp:381-580):
+    the agent-local cost gradient equals the agent's block of the central Riemannian gradient
+    (SURVEY 8c'), G built on the device from the neighbour tile buffer equals the oracle's."""
+    import torch
+    import dpgo_amd
+    r = 5
+    om, n = oracle.read_g2o(os.path.join(DATA, "smallGrid3D.g2o"))
+    d = om.d
+    ranges, per = oracle.partition_contiguous(om, n, 5)
+    dataset, _ = dpgo_amd.read_g2o_file(os.path.join(DATA, "smallGrid3D.g2o"))
+    ranges_p, per_p = dpgo_amd.partition_contiguous(dataset, n, 5)
+    assert ranges_p == ranges
+    X = random_point(oracle, n, d, r, 3)
+    central = oracle.QuadraticProblem(oracle.construct_Q(n, d, om), None, r, d)
+    RGc = central.rie_grad(X)
+    for a in range(5):
+        s, e = ranges[a]
+        na = e - s
+        priv = oracle.Measurements.concat([per[a]["odometry"], per[a]["private"]])
+        Qa = oracle.construct_Q(na, d, priv, per[a]["shared"], my_id=a)
+        pg = dpgo_amd.PoseGraph(a, r, d)
+        pg.setMeasurements(per_p[a])
+        assert pg.n() == na
+        rp, ci, v = pg.quadraticMatrix()
+        assert np.array_equal(rp, Qa.rowptr) and np.array_equal(ci, Qa.colidx)
+        assert np.abs(v - Qa.vals).max() <= 1e-12 * np.abs(Qa.vals).max()
+        nbr = {}
+        for (rob, fr) in pg.neighborPoseIDs():
+            nbr[(rob, fr)] = X[ranges[rob][0] + fr]  # tile [b, r]
+        Ga = oracle.construct_G(na, d, r, per[a]["shared"], a, nbr)
+        # host flavour: PoseGraph::setNeighborPoses + linearMatrix
+        pg.setNeighborPoses({k: v_.T for k, v_ in nbr.items()})  # LiftedPose r x (d+1)
+        assert relerr(matrix_to_tiles(pg.linearMatrix(), d), Ga) < 1e-13
+        prob = dpgo_amd.QuadraticProblem(pg)
+        Xa = X[s:e]
+        assert relerr(matrix_to_tiles(prob.RieGrad(tiles_to_matrix(Xa)), d), RGc[s:e]) < 1e-10
+        # device flavour: G = G0 + Xnbr * C from the tile buffer
+        slots = prob.setCouplingFromPoseGraph()
+        buf = torch.tensor(np.stack([nbr[sid] for sid in slots]), device="cuda", dtype=torch.float64).contiguous()
+        prob.setStream(torch.cuda.current_stream().cuda_stream)
+        prob.updateLinearMatrixFromNeighbors(buf)
+        Xd = torch.tensor(np.ascontiguousarray(Xa), device="cuda", dtype=torch.float64)
+        f_dev, gn_dev = prob.evalDevice(Xd)
+        torch.cuda.synchronize()
+        pa = oracle.QuadraticProblem(Qa, Ga, r, d)
+        assert abs(f_dev - pa.f(Xa)) <= 1e-12 * abs(pa.f(Xa))
+        assert abs(gn_dev - np.linalg.norm(RGc[s:e])) <= 1e-10 * np.linalg.norm(RGc[s:e])
+
+
+def test_spmm_properties_at_full_size(oracle):
+    """BASELINE.json config 4 size (100k-pose grid): size-independent properties of the Q*X kernel --
+    linearity, symmetry <X, YQ> = <Y, XQ>, and agreement with the oracle's CSR product."""
+    import torch
+    import dpgo_amd
+    meas, n, Ttrue = oracle.synthetic_grid(50, 50, 40, seed=0)
+    d, r = 3, 5
+    pg = dpgo_amd.PoseGraph(0, r, d)
+    pg.setMeasurements(to_product_measurements(meas))
+    assert pg.n() == 100000
+    rp, ci, v = pg.quadraticMatrix()
+    assert len(ci) == 687000  # nnzb = n + 2 * 293500
+    prob = dpgo_amd.QuadraticProblem(pg)
+    prob.setStream(torch.cuda.current_stream().cuda_stream)
+    g = torch.Generator(device="cuda").manual_seed(1)
+    X = torch.randn((n, d + 1, r), device="cuda", dtype=torch.float64, generator=g)
+    Y = torch.randn((n, d + 1, r), device="cuda", dtype=torch.float64, generator=g)
+    XQ, YQ, ZQ = torch.empty_like(X), torch.empty_like(X), torch.empty_like(X)
+    prob.spmmDevice(X, XQ)
+    prob.spmmDevice(Y, YQ)
+    Z = (2.5 * X - 0.75 * Y).contiguous()
+    prob.spmmDevice(Z, ZQ)
+    torch.cuda.synchronize()
+    lin = (ZQ - (2.5 * XQ - 0.75 * YQ)).norm() / ZQ.norm()
+    assert lin.item() < 1e-13
+    sym = abs((X * YQ).sum() - (Y * XQ).sum()) / abs((X * YQ).sum())
+    assert sym.item() < 1e-11
+    Qs = oracle.BSR(n, d + 1, rp, ci, v).to_scipy().tocsr()
+    ref = (Qs @ X.cpu().numpy().reshape(n * (d + 1), r)).reshape(n, d + 1, r)
+    assert relerr(XQ.cpu().numpy(), ref) < 1e-13
