@@ -1,0 +1,235 @@
+#!/usr/bin/env python
+"""bench.py -- RBCD iterations/sec of the MI355X-native local solver + Q*X roofline.
+
+    python bench.py --gpus N --steps K --warmup W [--workload grid100k|sphere2500|grid:NXxNYxNZ]
+
+One "step" = one RBCD iteration: every agent runs QuadraticOptimizer::optimize once (RTR, 3 outer
+iterations x <=50 tCG, Delta0 = 100, tol 1e-2: the reference defaults, include/DPGO/DPGO_types.h:53-61)
+on its block, with the block-Jacobi preconditioner.  N = 1: a single agent owns the whole graph.
+N > 1: the graph is cut into N contiguous blocks (examples/MultiRobotExample.cpp:71-88), one agent per
+GPU / process; agents of one colour update in parallel, then the other colour (two-colour RBCD),
+with the public-pose exchange over RCCL point-to-point.  Total work is fixed as N grows ("strong").
+
+Workload at N = 1: the synthetic 100k-pose 3-D grid of BASELINE.json (configs[3], the configuration the
+HBM-roofline target is quoted on; it fits one GPU).  Inputs are resident in HBM before the timed region.
+
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel, k_hess (the fused
+Q*X SpMM + Riemannian-Hessian epilogue launched once per tCG iteration); `cpu_baseline` times the CPU
+oracle ("port") on the same workload on the host cores (rank 0, N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="grid100k")
+    ap.add_argument("--rank", type=int, default=5, help="relaxation rank r")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget-s", type=float, default=25.0)
+    ap.add_argument("--spmm-reps", type=int, default=200)
+    return ap.parse_args()
+
+
+def make_workload(name, r):
+    """Returns (dataset, n, X0 tiles [n, d+1, r], description)."""
+    import dpgo_amd
+    from dpgo_amd import synthetic
+    if name == "grid100k":
+        name = "grid:50x50x40"
+    if name.startswith("grid:"):
+        nx, ny, nz = (int(v) for v in name[5:].split("x"))
+        meas, n, Ttrue = synthetic.synthetic_grid(nx, ny, nz, seed=0)
+        X0 = synthetic.lift_tiles(synthetic.perturbed_truth(Ttrue, seed=2), r)
+        return meas, n, X0, "synthetic 3-D grid %dx%dx%d (%d poses, %d edges), init = perturbed truth" % (
+            nx, ny, nz, n, len(meas))
+    if name == "sphere2500":
+        from dpgo_amd.initialization import chordal_initialization
+        meas, n = dpgo_amd.read_g2o_file(os.path.join(ROOT, "data", "sphere2500.g2o"))
+        X0 = synthetic.lift_tiles(chordal_initialization(meas, n), r)
+        return meas, n, X0, "sphere2500.g2o (2500 poses, 4949 edges), chordal init"
+    raise SystemExit("unknown workload %r" % name)
+
+
+def spmm_bytes(n, nnzb, d, r):
+    """Algorithmic bytes of one Q*X block-SpMM: BSR values + int32 column indices +
+    row pointers + one read of X + one write of OUT."""
+    b = d + 1
+    return nnzb * (8 * b * b + 4) + 4 * (n + 1) + 2 * 8 * r * b * n
+
+
+def hess_bytes(n, nnzb, d, r):
+    """k_hess = SpMM + fused epilogue: additionally reads the iterate X (8 r b n) and the cached
+    S = sym(Y^T EG) blocks (8 d^2 n)."""
+    b = d + 1
+    return spmm_bytes(n, nnzb, d, r) + 8 * r * b * n + 8 * d * d * n
+
+
+def cpu_baseline(meas_p, n, X0, r, budget_s):
+    """CPU oracle ("port": NumPy/SciPy restatement, 1 thread) timed on a bounded sample of the same
+    workload: whole RBCD iterations if one fits the budget, else tCG iterations extrapolated."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import dpgo_oracle as O
+    d = meas_p.d
+    om = O.Measurements(d, meas_p.r1.astype(np.int64), meas_p.p1.astype(np.int64), meas_p.r2.astype(np.int64),
+                        meas_p.p2.astype(np.int64), meas_p.R, meas_p.t, meas_p.kappa, meas_p.tau, meas_p.weight,
+                        meas_p.fixedWeight)
+    Q = O.construct_Q(n, d, om)
+    prob = O.QuadraticProblem(Q, None, r, d, precond="jacobi")
+    # time a few Hessian-vector products first to size the sample
+    X = X0.copy()
+    EG = prob.euc_grad(X)
+    S = prob.sym_ytg(X, EG)
+    g = O.tangent_project(X, EG, d)
+    t0 = time.perf_counter()
+    reps = 0
+    while reps < 3 or (time.perf_counter() - t0 < 1.0 and reps < 50):
+        prob.rie_hess(X, S, g)
+        prob.precondition(X, g)
+        reps += 1
+    per_tcg = (time.perf_counter() - t0) / reps
+    max_inner = 50
+    est_full = 3 * max_inner * per_tcg * 1.15
+    if est_full <= budget_s:
+        opt = O.QuadraticOptimizer(prob, O.ROptParameters())
+        t0 = time.perf_counter()
+        steps = 0
+        while True:
+            X = opt.optimize(X)
+            steps += 1
+            el = time.perf_counter() - t0
+            if el + el / steps > budget_s:
+                break
+        return dict(value=steps / el, unit="it/s", cores=1, kind="port",
+                    sample="%d full RBCD iteration(s) (RTR 3x<=50 tCG, block-Jacobi) of the same workload, "
+                           "NumPy/SciPy oracle, %.1f s" % (steps, el),
+                    spmm_ms=None)
+    inner = max(2, int(budget_s / 3 / per_tcg / 1.15))
+    opt = O.QuadraticOptimizer(prob, O.ROptParameters(RTR_tCG_iterations=inner))
+    t0 = time.perf_counter()
+    opt.optimize(X)
+    el = time.perf_counter() - t0
+    scaled = el * (max_inner / inner)
+    return dict(value=1.0 / scaled, unit="it/s", cores=1, kind="port",
+                sample="1 RBCD iteration with tCG capped at %d (of 50) inner iterations, %.1f s, time scaled by %.2f; "
+                       "NumPy/SciPy oracle, block-Jacobi" % (inner, el, max_inner / inner))
+
+
+def main():
+    args = parse_args()
+    import torch
+    import torch.distributed as dist
+    import dpgo_amd
+    from dpgo_amd.agent import DeviceAgent, RBCDCluster, build_pose_graphs
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("launch with torch.distributed.run for --gpus > 1")
+    if dpgo_amd.device_count() < 1:
+        raise SystemExit("bench.py needs a HIP device: the product path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    r = args.rank
+    meas, n, X0, desc = make_workload(args.workload, r)
+    d = meas.d
+    ranges, graphs = build_pose_graphs(meas, n, world, r)
+    s, e = ranges[rank]
+    params = dpgo_amd.ROptParameters()  # reference defaults + block-Jacobi
+    agent = DeviceAgent(graphs, rank, X0[s:e], params, device=local_rank)
+    cluster = RBCDCluster(agent, graphs, rank, world)
+    nnzb_local = len(graphs[rank].quadraticMatrix()[1])
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    f0, g0 = cluster.central_cost_and_gradnorm()
+    for _ in range(args.warmup):
+        cluster.sweep()
+    barrier()
+    t0 = time.perf_counter()
+    tcg_total = 0
+    for _ in range(args.steps):
+        cluster.sweep()
+        tcg_total += agent.last_result.tcg_iterations if agent.last_result else 0
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    f1, g1 = cluster.central_cost_and_gradnorm()
+
+    # ---- dominant-kernel roofline, measured live with HIP events on the solver's stream ----
+    lib = dpgo_amd.lib.load()
+    import ctypes as C
+    ms_hess, ms_spmm = C.c_double(0.0), C.c_double(0.0)
+    dpgo_amd.lib.check(lib.dpgo_bench_hess(agent.problem.handle, args.spmm_reps, 10, C.byref(ms_hess)))
+    dpgo_amd.lib.check(lib.dpgo_bench_spmm(agent.problem.handle, args.spmm_reps, 10, C.byref(ms_spmm)))
+    n_local = e - s
+    hb = hess_bytes(n_local, nnzb_local, d, r)
+    sb = spmm_bytes(n_local, nnzb_local, d, r)
+    ach = hb / (ms_hess.value * 1e-3) / 1e9
+    roofline = dict(bound="hbm", kernel="k_hess<%d,%d> (Q*X block-SpMM + Riemannian Hessian epilogue)" % (d, r),
+                    achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS, traffic=None,
+                    bytes_per_launch=hb, avg_launch_us=ms_hess.value * 1e3,
+                    spmm_only=dict(kernel="k_spmm<%d,%d>" % (d, r), bytes_per_launch=sb,
+                                   avg_launch_us=ms_spmm.value * 1e3,
+                                   achieved=sb / (ms_spmm.value * 1e-3) / 1e9,
+                                   frac=sb / (ms_spmm.value * 1e-3) / 1e9 / HBM_PEAK_GBS))
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(meas, n, X0, r, args.cpu_budget_s)
+
+    if rank == 0:
+        out = {
+            "metric": "rbcd_iterations_per_sec",
+            "value": args.steps / elapsed,
+            "unit": "it/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic" if args.workload.startswith("grid") else "g2o dataset shipped in data/",
+            "config": {"workload": desc, "agents": world, "r": r, "d": d,
+                       "local_solver": "RTR 3x<=50 tCG, Delta0=100, tol=1e-2 (reference defaults), block-Jacobi precond",
+                       "schedule": "single agent" if world == 1 else "two-colour parallel RBCD, RCCL p2p exchange",
+                       "poses_per_agent": n_local, "nnzb_per_agent": nnzb_local},
+            "roofline": roofline,
+            "cpu_baseline": cpu,
+            "quality": {"cost_2f_start": 2 * f0, "cost_2f_end": 2 * f1, "gradnorm_start": g0, "gradnorm_end": g1,
+                        "tcg_iterations_per_step_rank0": tcg_total / max(args.steps, 1)},
+        }
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -702,6 +702,18 @@ int dpgo_problem_eval_device(dpgo_problem_t p, const double* X_dev, double* f, d
   return DPGO_OK;
 }
 
+int dpgo_problem_eval_terms_device(dpgo_problem_t p, const double* X_dev, double* xqx, double* xg, double* g2) {
+  CHK(check_ready(p));
+  if (!X_dev) return fail(DPGO_ERR_INVALID, "null pointer");
+  CHK(launch_grad(p, X_dev, nullptr, nullptr, nullptr));
+  CHK(launch_rtr_begin(p, 0.0, 1.0, 1.0, 0, 0));
+  CHK(poll_state(p));
+  if (xqx) *xqx = p->hstate->xqx;
+  if (xg) *xg = p->hstate->xg;
+  if (g2) *g2 = p->hstate->ngf * p->hstate->ngf;
+  return DPGO_OK;
+}
+
 int dpgo_bench_spmm(dpgo_problem_t p, int reps, int warmup, double* avg_ms) {
   CHK(check_ready(p));
   if (reps <= 0 || !avg_ms) return fail(DPGO_ERR_INVALID, "bad arguments");
@@ -711,6 +723,25 @@ int dpgo_bench_spmm(dpgo_problem_t p, int reps, int warmup, double* avg_ms) {
   for (int i = 0; i < warmup; ++i) CHK(launch_spmm(p, p->Q, p->x1, nullptr, p->x2));
   HIPC(hipEventRecord(e0, p->stream));
   for (int i = 0; i < reps; ++i) CHK(launch_spmm(p, p->Q, p->x1, nullptr, p->x2));
+  HIPC(hipEventRecord(e1, p->stream));
+  HIPC(hipEventSynchronize(e1));
+  float ms = 0.f;
+  HIPC(hipEventElapsedTime(&ms, e0, e1));
+  HIPC(hipEventDestroy(e0));
+  HIPC(hipEventDestroy(e1));
+  *avg_ms = (double)ms / reps;
+  return DPGO_OK;
+}
+
+int dpgo_bench_hess(dpgo_problem_t p, int reps, int warmup, double* avg_ms) {
+  CHK(check_ready(p));
+  if (reps <= 0 || !avg_ms) return fail(DPGO_ERR_INVALID, "bad arguments");
+  hipEvent_t e0, e1;
+  HIPC(hipEventCreate(&e0));
+  HIPC(hipEventCreate(&e1));
+  for (int i = 0; i < warmup; ++i) CHK(launch_hess(p, p->x1, p->S1, p->delta, nullptr, p->Hd, p->pA(), nullptr, 0));
+  HIPC(hipEventRecord(e0, p->stream));
+  for (int i = 0; i < reps; ++i) CHK(launch_hess(p, p->x1, p->S1, p->delta, nullptr, p->Hd, p->pA(), nullptr, 0));
   HIPC(hipEventRecord(e1, p->stream));
   HIPC(hipEventSynchronize(e1));
   float ms = 0.f;

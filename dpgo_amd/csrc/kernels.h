@@ -33,6 +33,7 @@ struct DevState {
   // --- RTR (ROPTLIB SolversTR::Run; reference configuration src/QuadraticOptimizer.cpp:64-78)
   double f1, ngf, Delta, Delta_max, tol;
   double f2, rho, fInit, gnInit;
+  double xqx, xg;  // sum(XQ.X), sum(X.G) of the last k_rtr_begin evaluation
   int outer_iter, rtr_stop, accepted_last, n_accept;
   int accept_tiny, pad0;
   // --- tCG (ROPTLIB SolversTR::tCG_TR)
@@ -719,6 +720,8 @@ __global__ void k_rtr_begin(const double* __restrict__ pe, int nb_e, DevState* _
     st.rho = 0.0;
     st.fInit = st.f1;
     st.gnInit = st.ngf;
+    st.xqx = e3[0];
+    st.xg = e3[1];
     st.outer_iter = 0;
     st.rtr_stop = (st.ngf < tol) ? 1 : 0;
     st.accepted_last = 0;

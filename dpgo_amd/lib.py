@@ -7,6 +7,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import sys
 from typing import Optional
 
 import numpy as np
@@ -75,7 +76,9 @@ SIGNATURES = {
     "dpgo_optimize_device": ([_P, C.POINTER(RoptParamsC), _P, C.POINTER(RoptResultC)], _I),
     "dpgo_spmm_device": ([_P, _P, _P, _I], _I),
     "dpgo_problem_eval_device": ([_P, _P, C.POINTER(_D), C.POINTER(_D)], _I),
+    "dpgo_problem_eval_terms_device": ([_P, _P, C.POINTER(_D), C.POINTER(_D), C.POINTER(_D)], _I),
     "dpgo_bench_spmm": ([_P, _I, _I, C.POINTER(_D)], _I),
+    "dpgo_bench_hess": ([_P, _I, _I, C.POINTER(_D)], _I),
     "dpgo_manifold_project": ([_I, _I, _I, _P, _P, _I], _I),
     "dpgo_manifold_tangent_project": ([_I, _I, _I, _P, _P, _P, _I], _I),
     "dpgo_manifold_retract": ([_I, _I, _I, _P, _P, _D, _P, _I], _I),
@@ -100,6 +103,15 @@ def load() -> C.CDLL:
         raise ImportError(
             "dpgo_amd: %s not found -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "or `make -C dpgo_amd/csrc`.  There is no CPU fallback." % LIB_PATH)
+    # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64; if this library pulled in
+    # the system runtime first, torch would later fail with "No HIP GPUs are available".  Import torch
+    # first when it is installed so both bind to the same runtime (torch is plumbing here: device
+    # memory, streams, torch.distributed).
+    if "torch" not in sys.modules:
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
     lib = C.CDLL(LIB_PATH)
     for name, (argtypes, restype) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol

@@ -277,8 +277,12 @@ class QuadraticProblem:
     reference builds a new problem per iteration (src/PGOAgent.cpp:968); keep this object alive
     across iterations instead and call refresh() after the pose graph changed."""
 
-    def __init__(self, pose_graph: PoseGraph, device: int = 0):
+    def __init__(self, pose_graph: PoseGraph, device: int = 0, host_linear_term: bool = True):
+        """host_linear_term = False: G is not taken from PoseGraph::linearMatrix() on the host but
+        built on the device from the neighbour tile buffer (setCouplingFromPoseGraph +
+        updateLinearMatrixFromNeighbors)."""
         self.pose_graph_ = pose_graph
+        self._host_G = bool(host_linear_term)
         self._lib = L.load()
         self._h = L._P()
         r, d, n = pose_graph.r(), pose_graph.d(), pose_graph.n()
@@ -317,7 +321,9 @@ class QuadraticProblem:
             L.check(self._lib.dpgo_problem_set_Q_bsr(self._h, len(colidx), L.ptr(rowptr), L.ptr(colidx), L.ptr(vals)))
             self._q_version = pg.q_version
             self._g_obj = None
-        has_shared = len(pg.sharedLoopClosures()) > 0 or len(pg.priors_) > 0
+        has_shared = self._host_G and (len(pg.sharedLoopClosures()) > 0 or len(pg.priors_) > 0)
+        if not self._host_G:
+            return
         if not has_shared:
             if self._g_obj is not False:
                 L.check(self._lib.dpgo_problem_set_G(self._h, None))
@@ -394,6 +400,12 @@ class QuadraticProblem:
         f, g = C.c_double(0.0), C.c_double(0.0)
         L.check(self._lib.dpgo_problem_eval_device(self._h, L.ptr(X_dev), C.byref(f), C.byref(g)))
         return f.value, g.value
+
+    def evalTermsDevice(self, X_dev) -> Tuple[float, float, float]:
+        """(sum(XQ.X), sum(X.G), |rgrad|^2) at a device X; f = 0.5 xqx + xg."""
+        a, b, c = C.c_double(0.0), C.c_double(0.0), C.c_double(0.0)
+        L.check(self._lib.dpgo_problem_eval_terms_device(self._h, L.ptr(X_dev), C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
 
     def spmmDevice(self, V_dev, OUT_dev, add_G: bool = False) -> None:
         L.check(self._lib.dpgo_spmm_device(self._h, L.ptr(V_dev), L.ptr(OUT_dev), int(add_G)))

@@ -165,9 +165,16 @@ int dpgo_optimize_device(dpgo_problem_t h, const dpgo_ropt_params* params, doubl
 int dpgo_spmm_device(dpgo_problem_t h, const double* V_dev, double* OUT_dev, int add_G);
 /* f, |rgrad| at a device X without copying X back */
 int dpgo_problem_eval_device(dpgo_problem_t h, const double* X_dev, double* f, double* gradnorm);
+/* the three sums behind f and |rgrad|: xqx = sum(XQ.X), xg = sum(X.G), g2 = |rgrad|^2
+ * (f = 0.5 xqx + xg).  Lets a driver assemble the CENTRAL cost 0.5 sum_a (xqx_a + xg_a) from
+ * agent-local evaluations (examples/MultiRobotExample.cpp:220-225 does it on a central problem). */
+int dpgo_problem_eval_terms_device(dpgo_problem_t h, const double* X_dev, double* xqx, double* xg, double* g2);
 /* time `reps` back-to-back SpMM launches with HIP events on the handle's stream;
  * n_buffers >= 1 rotates that many (V, OUT) buffer pairs; returns average ms per launch */
 int dpgo_bench_spmm(dpgo_problem_t h, int reps, int warmup, double* avg_ms);
+/* same for the dominant kernel of a solve: the fused Q*X + Riemannian-Hessian kernel (one per tCG
+ * iteration), on the solver's own buffers (iterate, cached S, search direction) */
+int dpgo_bench_hess(dpgo_problem_t h, int reps, int warmup, double* avg_ms);
 
 /* ---- manifold: LiftedSEManifold (include/DPGO/manifold/LiftedSEManifold.h:28-43) + the
  * ROPTLIB Stiefel x Euclidean product-manifold operations it configures

@@ -104,15 +104,19 @@ def test_optimize_matches_oracle_at_matched_settings(oracle, name, r, precond):
     Xg = matrix_to_tiles(gopt.optimize(tiles_to_matrix(X0)), d)
     ro, rg = oopt.result, gopt.getOptResult()
     assert rg.success
-    assert abs(rg.fInit - ro.fInit) <= 1e-12 * abs(ro.fInit)
+    # f is a cancellation-heavy sum when kappa is large (kitti_00: kappa ~ 3e5, neighbouring poses
+    # nearly equal): the fp64 error of either side scales with |X|^T |Q| |X|, not with |f|
+    Xa = np.abs(X0).reshape(-1, r)
+    scale = float((Xa * (abs(op.Qs) @ Xa)).sum())
+    assert abs(rg.fInit - ro.fInit) <= 1e-14 * scale
     assert abs(rg.gradNormInit - ro.gradNormInit) <= 1e-10 * ro.gradNormInit
     assert rg.rtr_iterations == ro.outer_iters
     assert rg.tcg_iterations == ro.tcg_iters
     assert rg.tCGStatus == oracle.TCG_NAMES[ro.tCGStatus]
-    assert abs(rg.fOpt - ro.fOpt) <= 1e-9 * abs(ro.fOpt)
+    assert abs(rg.fOpt - ro.fOpt) <= 1e-9 * abs(ro.fOpt) + 1e-14 * scale
     assert relerr(Xg, Xo) < 1e-7
     # and the problem object agrees with the optimizer's own statistics (QuadraticOptimizer.cpp:42-43)
-    assert abs(prob.f(tiles_to_matrix(Xg)) - rg.fOpt) <= 1e-12 * abs(rg.fOpt)
+    assert abs(prob.f(tiles_to_matrix(Xg)) - rg.fOpt) <= 1e-12 * abs(rg.fOpt) + 1e-14 * scale
 
 
 @pytest.mark.parametrize("name,ref2f", [("smallGrid3D", 1025.3980556263), ("sphere2500", 1687.0058142808),
