@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/dpgo_hip.h"
@@ -98,10 +99,13 @@ struct dpgo_problem_s {
   double dinv_shift = -1.0;
   // work vectors
   double *x1 = nullptr, *x2 = nullptr, *g1 = nullptr, *g2 = nullptr, *eta = nullptr, *delta = nullptr,
-         *Hd = nullptr, *rr = nullptr, *z = nullptr, *S1 = nullptr, *S2 = nullptr;
+         *delta2 = nullptr, *Hd = nullptr, *rr = nullptr, *z = nullptr, *S1 = nullptr, *S2 = nullptr;
   double* partials = nullptr;  // 5 regions of kMaxGrid*kNP
   DevState* dstate = nullptr;  // 2 slots
   DevState* hstate = nullptr;  // pinned
+  unsigned long long* hflag = nullptr;  // pinned, host-coherent: device-published tCG progress word
+  unsigned gen = 0;
+  bool saw_rtr_stop = false;  // set from the progress word in just-in-time mode
   int cur = 0;
   size_t vec_bytes() const { return (size_t)n * T * sizeof(double); }
   double* pE() const { return partials; }
@@ -196,10 +200,11 @@ int launch_spmm(dpgo_problem_s* p, const Bsr& M, const double* V, const double* 
   return DPGO_OK;
 }
 
-int launch_grad(dpgo_problem_s* p, const double* X, double* RG, double* S, double* EG) {
+int launch_grad(dpgo_problem_s* p, const double* X, double* RG, double* S, double* EG,
+                const DevState* st = nullptr) {
   const double* Gm = p->has_G ? p->G : nullptr;
   DISPATCH(p->d, p->r, hipLaunchKernelGGL((k_grad<D, R>), dim3(p->grid()), dim3(kBlock), 0, p->stream,
-                                          p->Q.dev(), X, Gm, RG, S, EG, p->pE(), p->n));
+                                          p->Q.dev(), X, Gm, RG, S, EG, p->pE(), st, p->n));
   HIPC(hipGetLastError());
   return DPGO_OK;
 }
@@ -217,7 +222,19 @@ int launch_tcg_update(dpgo_problem_s* p, const double* dinv, int first) {
   DISPATCH(p->d, p->r,
            hipLaunchKernelGGL((k_tcg_update<D, R>), dim3(g), dim3(kBlock), 0, p->stream, p->x1, p->g1, dinv,
                               p->delta, p->Hd, p->eta, p->rr, p->z, p->pA(), g, p->pB(), p->dstate + p->cur,
-                              p->dstate + (p->cur ^ 1), first, p->n));
+                              p->dstate + (p->cur ^ 1), first, p->n, p->hflag, p->gen));
+  HIPC(hipGetLastError());
+  p->cur ^= 1;
+  return DPGO_OK;
+}
+
+// fused direction update + Riemannian Hessian-vector product (one tCG step)
+int launch_tcg_hess(dpgo_problem_s* p, int first) {
+  const int g = p->grid();
+  DISPATCH(p->d, p->r,
+           hipLaunchKernelGGL((k_tcg_hess<D, R>), dim3(g), dim3(kBlock), 0, p->stream, p->Q.dev(), p->x1, p->S1,
+                              p->z, p->delta, p->Hd, p->pB(), g, p->pA(), p->dstate + p->cur,
+                              p->dstate + (p->cur ^ 1), first, p->n, p->hflag, p->gen));
   HIPC(hipGetLastError());
   p->cur ^= 1;
   return DPGO_OK;
@@ -272,30 +289,72 @@ struct Counters {
 
 // One ROPTLIB SolversTR::Run outer iteration: tCG + retraction + rho test.  State stays on the
 // device; the host polls the tCG "done" flag every `poll` inner iterations.
-int rtr_outer_iteration(dpgo_problem_s* p, const dpgo_ropt_params* prm, const double* dinv, Counters& cnt) {
+int rtr_outer_iteration(dpgo_problem_s* p, const dpgo_ropt_params* prm, const double* dinv, Counters& cnt,
+                        bool poll_at_end) {
+  p->gen += 1;
   CHK(launch_tcg_update(p, dinv, 1));
-  CHK(launch_tcg_dir(p, 1));
   const int max_inner = prm->RTR_tCG_iterations;
-  int poll = prm->tcg_poll_interval > 0 ? prm->tcg_poll_interval : 8;
-  int j = 0;
-  while (j < max_inner) {
-    const int chunk = (max_inner - j) < poll ? (max_inner - j) : poll;
-    for (int c = 0; c < chunk; ++c) {
-      CHK(launch_hess(p, p->x1, p->S1, p->delta, nullptr, p->Hd, p->pA(), p->dstate + p->cur, 1));
-      CHK(launch_tcg_update(p, dinv, 0));
-      CHK(launch_tcg_dir(p, 0));
+  if (max_inner <= 0) CHK(launch_tcg_hess(p, 1));  // only finalises the tCG state (eta = 0)
+  bool done = false;
+  if (prm->tcg_poll_interval > 0) {
+    // polling mode: enqueue `poll` iterations, then synchronise and read the state back
+    const int poll = prm->tcg_poll_interval;
+    int j = 0;
+    while (j < max_inner) {
+      const int chunk = (max_inner - j) < poll ? (max_inner - j) : poll;
+      for (int c = 0; c < chunk; ++c) {
+        CHK(launch_tcg_hess(p, (j + c) == 0 ? 1 : 0));
+        CHK(launch_tcg_update(p, dinv, 0));
+      }
+      j += chunk;
+      CHK(poll_state(p));
+      if (p->hstate->tcg_done || p->hstate->rtr_stop) {
+        done = true;
+        break;
+      }
     }
-    j += chunk;
-    CHK(poll_state(p));
-    if (p->hstate->tcg_done) break;
+  } else {
+    // just-in-time feed: stay kAhead iterations ahead of the progress word the device publishes into
+    // host-coherent memory; no synchronisation, no copy, at most kAhead wasted (early-exit) iterations
+    constexpr int kAhead = 4;
+    int enq = 0;
+    const auto t_start = std::chrono::steady_clock::now();
+    while (true) {
+      const unsigned long long w = __atomic_load_n(p->hflag, __ATOMIC_ACQUIRE);
+      int dev_j = 0;
+      if ((unsigned)(w >> 32) == p->gen) {
+        dev_j = (int)((w >> 8) & 0xFFFFFFu);
+        if (w & 3ull) {
+          done = true;
+          if (w & 2ull) p->saw_rtr_stop = true;
+          break;
+        }
+      }
+      if (enq >= max_inner) break;
+      if (enq < dev_j + kAhead) {
+        CHK(launch_tcg_hess(p, enq == 0 ? 1 : 0));
+        CHK(launch_tcg_update(p, dinv, 0));
+        enq += 1;
+      } else {
+        __builtin_ia32_pause();
+        if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count() > 60.0) {
+          HIPC(hipStreamSynchronize(p->stream));  // surfaces a device fault instead of spinning forever
+          return fail(DPGO_ERR_HIP, "tCG progress word did not advance for 60 s");
+        }
+      }
+    }
   }
+  if (!done) {  // max_inner iterations enqueued and not (yet known to be) finished: one more prologue
+    CHK(launch_tcg_hess(p, 0));  // applies the last convergence test / marks MAXITER
+  }
+  if (p->saw_rtr_stop) return DPGO_OK;  // the previous outer iteration already met the stop test
   CHK(launch_retract(p, p->x1, p->eta, 1.0, p->x2, p->dstate + p->cur));
-  CHK(launch_grad(p, p->x2, p->g2, p->S2, nullptr));
+  CHK(launch_grad(p, p->x2, p->g2, p->S2, nullptr, p->dstate + p->cur));
   cnt.spmm += 1;
   CHK(launch_hess(p, p->x1, p->S1, p->eta, p->g1, p->Hd, p->pH(), p->dstate + p->cur, 0));
   cnt.spmm += 1;
   CHK(launch_rtr_update(p));
-  CHK(poll_state(p));
+  if (poll_at_end) CHK(poll_state(p));
   return DPGO_OK;
 }
 
@@ -321,6 +380,7 @@ int run_optimize(dpgo_problem_s* p, const dpgo_ropt_params* prm, dpgo_ropt_resul
   res->fInit = p->hstate->fInit;
   res->gradNormInit = p->hstate->gnInit;
   int n_hess_total = 0;
+  int shrink_tries = 0;
 
   if (prm->method == DPGO_METHOD_RTR) {
     // trustRegion(): src/QuadraticOptimizer.cpp:50-108
@@ -329,27 +389,31 @@ int run_optimize(dpgo_problem_s* p, const dpgo_ropt_params* prm, dpgo_ropt_resul
         double radius = prm->RTR_initial_radius;
         int total_steps = 0;
         while (true) {
+          shrink_tries += 1;
           p->hstate->Delta = radius;
           p->hstate->Delta_max = radius;
           p->hstate->outer_iter = 0;
           CHK(push_state(p));
-          CHK(rtr_outer_iteration(p, prm, dinv, cnt));
-          res->rtr_iterations += 1;
+          p->saw_rtr_stop = false;
+          CHK(rtr_outer_iteration(p, prm, dinv, cnt, true));
           if (p->hstate->accepted_last) break;
           if (total_steps > 10) break;  // "Too many RTR rejections. Returning initial guess." (x1 untouched)
           radius /= 4.0;
           total_steps++;
         }
       } else {
+        const bool polling = prm->tcg_poll_interval > 0;
+        p->saw_rtr_stop = false;
         for (int it = 0; it < prm->RTR_iterations; ++it) {
-          CHK(rtr_outer_iteration(p, prm, dinv, cnt));
-          res->rtr_iterations += 1;
-          if (p->hstate->rtr_stop) break;
+          CHK(rtr_outer_iteration(p, prm, dinv, cnt, polling));
+          if (polling ? (p->hstate->rtr_stop != 0) : p->saw_rtr_stop) break;
           const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
           if (prm->time_bound_s > 0 && el > prm->time_bound_s) break;  // Solver.TimeBound (:78)
         }
+        CHK(poll_state(p));
       }
       res->tCGStatus = p->hstate->tcg_status;
+      res->rtr_iterations = (prm->RTR_iterations == 1) ? shrink_tries : p->hstate->outer_iter;
       res->rtr_accepted = p->hstate->n_accept;
       res->latest_step_accepted = p->hstate->accepted_last;
       n_hess_total = p->hstate->n_hess;
@@ -431,7 +495,7 @@ void dpgo_ropt_params_default(dpgo_ropt_params* p) {
   p->precond = DPGO_PRECOND_BLOCK_JACOBI;
   p->precond_shift = 1e-1;
   p->accept_tiny_decrease = 1;
-  p->tcg_poll_interval = 8;
+  p->tcg_poll_interval = 0;
   p->time_bound_s = 5.0;
 }
 
@@ -458,7 +522,7 @@ int dpgo_problem_create(dpgo_problem_t* out, int r, int d, int n, int device) {
     HIPC(hipStreamCreateWithFlags(&p->own_stream, hipStreamNonBlocking));
     p->stream = p->own_stream;
     const size_t vb = p->vec_bytes();
-    double** vecs[] = {&p->x1, &p->x2, &p->g1, &p->g2, &p->eta, &p->delta, &p->Hd, &p->rr, &p->z, &p->G, &p->G0};
+    double** vecs[] = {&p->x1, &p->x2, &p->g1, &p->g2, &p->eta, &p->delta, &p->delta2, &p->Hd, &p->rr, &p->z, &p->G, &p->G0};
     for (auto v : vecs) {
       HIPC(hipMalloc(v, vb));
       HIPC(hipMemsetAsync(*v, 0, vb, p->stream));
@@ -470,6 +534,8 @@ int dpgo_problem_create(dpgo_problem_t* out, int r, int d, int n, int device) {
     HIPC(hipMemsetAsync(p->partials, 0, sizeof(double) * 5 * kMaxGrid * kNP, p->stream));
     HIPC(hipMalloc(&p->dstate, sizeof(DevState) * 2));
     HIPC(hipHostMalloc(&p->hstate, sizeof(DevState)));
+    HIPC(hipHostMalloc(&p->hflag, 64, hipHostMallocCoherent | hipHostMallocMapped));
+    *p->hflag = 0ull;
     HIPC(hipStreamSynchronize(p->stream));
     return DPGO_OK;
   }();
@@ -487,12 +553,13 @@ int dpgo_problem_destroy(dpgo_problem_t p) {
   if (p->own_stream) (void)hipStreamSynchronize(p->own_stream);
   free_bsr(p->Q);
   free_bsr(p->C);
-  double* vecs[] = {p->x1, p->x2, p->g1, p->g2, p->eta, p->delta, p->Hd, p->rr, p->z, p->G, p->G0,
+  double* vecs[] = {p->x1, p->x2, p->g1, p->g2, p->eta, p->delta, p->delta2, p->Hd, p->rr, p->z, p->G, p->G0,
                     p->S1, p->S2, p->dinv, p->partials};
   for (auto v : vecs)
     if (v) (void)hipFree(v);
   if (p->dstate) (void)hipFree(p->dstate);
   if (p->hstate) (void)hipHostFree(p->hstate);
+  if (p->hflag) (void)hipHostFree(p->hflag);
   if (p->own_stream) (void)hipStreamDestroy(p->own_stream);
   delete p;
   return DPGO_OK;
@@ -736,12 +803,28 @@ int dpgo_bench_spmm(dpgo_problem_t p, int reps, int warmup, double* avg_ms) {
 int dpgo_bench_hess(dpgo_problem_t p, int reps, int warmup, double* avg_ms) {
   CHK(check_ready(p));
   if (reps <= 0 || !avg_ms) return fail(DPGO_ERR_INVALID, "bad arguments");
+  // a state in which the tCG-step kernel never takes an early exit
+  std::memset(p->hstate, 0, sizeof(DevState));
+  p->hstate->z_r = 1.0;
+  p->hstate->theta = 1.0;
+  p->hstate->kappa = -1.0;  // convergence test can never fire
+  p->hstate->max_inner = 1 << 30;
+  CHK(push_state(p));
+  const int g = p->grid();
+  auto launch = [&]() -> int {
+    DISPATCH(p->d, p->r,
+             hipLaunchKernelGGL((k_tcg_hess<D, R>), dim3(g), dim3(kBlock), 0, p->stream, p->Q.dev(), p->x1, p->S1,
+                                p->z, p->delta, p->Hd, p->pB(), g, p->pA(), p->dstate, p->dstate + 1, 0, p->n,
+                                (unsigned long long*)nullptr, 0u));
+    HIPC(hipGetLastError());
+    return DPGO_OK;
+  };
   hipEvent_t e0, e1;
   HIPC(hipEventCreate(&e0));
   HIPC(hipEventCreate(&e1));
-  for (int i = 0; i < warmup; ++i) CHK(launch_hess(p, p->x1, p->S1, p->delta, nullptr, p->Hd, p->pA(), nullptr, 0));
+  for (int i = 0; i < warmup; ++i) CHK(launch());
   HIPC(hipEventRecord(e0, p->stream));
-  for (int i = 0; i < reps; ++i) CHK(launch_hess(p, p->x1, p->S1, p->delta, nullptr, p->Hd, p->pA(), nullptr, 0));
+  for (int i = 0; i < reps; ++i) CHK(launch());
   HIPC(hipEventRecord(e1, p->stream));
   HIPC(hipEventSynchronize(e1));
   float ms = 0.f;

@@ -42,6 +42,20 @@ struct DevState {
   int n_hess, min_inner;
 };
 
+// Progress word published by workgroup 0 into host-coherent pinned memory (system-scope relaxed
+// store).  The host feeds tCG-step kernels just-in-time, a few iterations ahead of `j`, instead of
+// synchronising every few iterations; it is a HINT only -- the device state above is the truth and
+// kernels enqueued after tCG finished exit in their prologue.
+//   [63:32] generation (one per tCG run)   [31:8] tcg_j   [1] rtr_stop   [0] tcg_done
+__device__ __forceinline__ void publish_progress(unsigned long long* hflag, unsigned gen, const DevState& st) {
+  if (hflag) {
+    const unsigned long long w = ((unsigned long long)gen << 32) |
+                                 ((unsigned long long)((unsigned)st.tcg_j & 0xFFFFFFu) << 8) |
+                                 (st.rtr_stop ? 2ull : 0ull) | (st.tcg_done ? 1ull : 0ull);
+    __hip_atomic_store(hflag, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
 template <int D, int R>
 struct Geo {
   static constexpr int B = D + 1;
@@ -63,6 +77,33 @@ __device__ __forceinline__ LaneId lane_id() {
   id.g = l / B;
   id.c = l - id.g * B;
   return id;
+}
+
+// ---------------------------------------------------------------- XCD-aware tile walk
+// MI355X has 8 XCDs with private 4 MiB L2s; workgroup b is observed to run on XCD b % 8
+// (MI355X_MICROARCH.md, "Workgroup dispatch"; used for SPEED only -- any placement is correct).
+// Give each XCD one contiguous eighth of the pose tiles so the X tiles gathered by the block-SpMM
+// (own rows + graph neighbours, mostly nearby indices) stay in that XCD's L2 instead of being
+// fetched by all eight.  Measured with FETCH_SIZE: 156 MB -> see profiles/ per launch at 100k poses.
+struct TileIter {
+  int first, last, step;
+};
+__device__ __forceinline__ TileIter tile_iter(int ntiles) {
+  TileIter it;
+  const int G = gridDim.x;
+  if (G < 16 || ntiles < 16) {
+    it.first = blockIdx.x;
+    it.last = ntiles;
+    it.step = G;
+    return it;
+  }
+  const int x = blockIdx.x & 7, lb = blockIdx.x >> 3;
+  const int nbx = (G - x + 7) >> 3;  // workgroups that land on this XCD
+  const int lo = (int)(((long long)ntiles * x) >> 3), hi = (int)(((long long)ntiles * (x + 1)) >> 3);
+  it.first = lo + lb;
+  it.last = hi;
+  it.step = nbx;
+  return it;
 }
 
 // ---------------------------------------------------------------- reductions
@@ -177,25 +218,56 @@ __device__ __forceinline__ void store_col(double* __restrict__ p, const double (
 // ---------------------------------------------------------------- block-SpMM core
 // acc[:] = (V*Q)[i][c][:] = sum_j sum_k V_j[:,k] * Q[i,j][c][k]      (Q symmetric)
 // replaces Eigen's dense x RowMajor-sparse product in src/QuadraticProblem.cpp:33,39,46,53.
+//
+// Wave-cooperative: must be called by ALL 64 lanes (lanes without a row pass ok = false).  The B
+// lanes of a pose preload the row's first 2B column indices (one coalesced load each) and broadcast
+// them with ds_bpermute, which removes the dependent colidx -> tile load from every iteration of the
+// gather loop (the kernel is bound by that latency chain, not by HBM: tools/spmm_lab.hip, 27.2 -> 24.6 us
+// at 100k poses).  Each lane streams row c of the Q block (32 B for D = 3: the quad reads the 128-B
+// block exactly once, coalesced) and the full gathered tile V_j (160 B, L2-resident).
 template <int D, int R>
 __device__ __forceinline__ void spmm_col(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colidx,
                                          const double* __restrict__ vals, const double* __restrict__ V,
-                                         int i, int c, double (&acc)[R]) {
+                                         int i, int c, bool ok, double (&acc)[R]) {
   constexpr int B = D + 1, T = B * R, BB = B * B;
 #pragma unroll
   for (int a = 0; a < R; ++a) acc[a] = 0.0;
-  const int t0 = rowptr[i], t1 = rowptr[i + 1];
-  for (int t = t0; t < t1; ++t) {
+  const int lane = threadIdx.x & 63;
+  const int gbase = lane - c;
+  const int t0 = ok ? rowptr[i] : 0, t1 = ok ? rowptr[i + 1] : 0;
+  const int deg = t1 - t0;
+  const int ja = (c < deg) ? colidx[t0 + c] : 0;
+  const int jb = (c + B < deg) ? colidx[t0 + c + B] : 0;
+  int maxdeg = deg;
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) maxdeg = max(maxdeg, __shfl_xor(maxdeg, o));
+  const int lim = maxdeg < 2 * B ? maxdeg : 2 * B;
+  for (int k = 0; k < lim; ++k) {
+    const int j = __shfl((k < B) ? ja : jb, gbase + (k < B ? k : k - B));
+    if (k < deg) {
+      const double* __restrict__ q = vals + (size_t)(t0 + k) * BB + c * B;
+      const double* __restrict__ x = V + (size_t)j * T;
+      double qk[B];
+#pragma unroll
+      for (int kk = 0; kk < B; ++kk) qk[kk] = q[kk];
+#pragma unroll
+      for (int kk = 0; kk < B; ++kk) {
+#pragma unroll
+        for (int a = 0; a < R; ++a) acc[a] = fma(x[kk * R + a], qk[kk], acc[a]);
+      }
+    }
+  }
+  for (int t = t0 + 2 * B; t < t1; ++t) {  // rows with more than 2B blocks
     const int j = colidx[t];
     const double* __restrict__ q = vals + (size_t)t * BB + c * B;
     const double* __restrict__ x = V + (size_t)j * T;
     double qk[B];
 #pragma unroll
-    for (int k = 0; k < B; ++k) qk[k] = q[k];
+    for (int kk = 0; kk < B; ++kk) qk[kk] = q[kk];
 #pragma unroll
-    for (int k = 0; k < B; ++k) {
+    for (int kk = 0; kk < B; ++kk) {
 #pragma unroll
-      for (int a = 0; a < R; ++a) acc[a] = fma(x[k * R + a], qk[k], acc[a]);
+      for (int a = 0; a < R; ++a) acc[a] = fma(x[kk * R + a], qk[kk], acc[a]);
     }
   }
 }
@@ -218,11 +290,13 @@ __global__ __launch_bounds__(kBlock) void k_spmm(BsrDev Q, const double* __restr
   using GEO = Geo<D, R>;
   const LaneId L = lane_id<D>();
   const int ntiles = (n + GEO::P - 1) / GEO::P;
-  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+  const TileIter ti_ = tile_iter(ntiles);
+  for (int tile = ti_.first; tile < ti_.last; tile += ti_.step) {
     const int i = tile * GEO::P + L.wave * GEO::G + L.g;
-    if (L.g < GEO::G && i < n) {
-      double acc[R];
-      spmm_col<D, R>(Q.rowptr, Q.colidx, Q.vals, V, i, L.c, acc);
+    const bool ok = (L.g < GEO::G) && (i < n);
+    double acc[R];
+    spmm_col<D, R>(Q.rowptr, Q.colidx, Q.vals, V, i, L.c, ok, acc);
+    if (ok) {
       const size_t off = (size_t)i * GEO::T + L.c * R;
       if (Gadd) {
 #pragma unroll
@@ -242,22 +316,25 @@ template <int D, int R>
 __global__ __launch_bounds__(kBlock) void k_grad(BsrDev Q, const double* __restrict__ X,
                                                  const double* __restrict__ Gm, double* __restrict__ RG,
                                                  double* __restrict__ S, double* __restrict__ EGout,
-                                                 double* __restrict__ partials, int n) {
+                                                 double* __restrict__ partials, const DevState* __restrict__ st,
+                                                 int n) {
   using GEO = Geo<D, R>;
   __shared__ double sm[kWaves][2][GEO::G][GEO::T];
   __shared__ double red[kWaves * kNP];
+  if (st && st->rtr_stop) return;
   const LaneId L = lane_id<D>();
   const int ntiles = (n + GEO::P - 1) / GEO::P;
   double part[3] = {0.0, 0.0, 0.0};
-  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+  const TileIter ti_ = tile_iter(ntiles);
+  for (int tile = ti_.first; tile < ti_.last; tile += ti_.step) {
     const int i = tile * GEO::P + L.wave * GEO::G + L.g;
     const bool ok = (L.g < GEO::G) && (i < n);
     double eg[R], x[R];
     const size_t off = (size_t)i * GEO::T + L.c * R;
     double* ys = ok ? &sm[L.wave][0][L.g][0] : nullptr;
     double* ws = ok ? &sm[L.wave][1][L.g][0] : nullptr;
+    spmm_col<D, R>(Q.rowptr, Q.colidx, Q.vals, X, i, L.c, ok, eg);
     if (ok) {
-      spmm_col<D, R>(Q.rowptr, Q.colidx, Q.vals, X, i, L.c, eg);
       load_col<R>(X + off, x);
 #pragma unroll
       for (int a = 0; a < R; ++a) part[0] = fma(eg[a], x[a], part[0]);
@@ -311,7 +388,8 @@ __global__ __launch_bounds__(kBlock) void k_hess(BsrDev Q, const double* __restr
   const LaneId L = lane_id<D>();
   const int ntiles = (n + GEO::P - 1) / GEO::P;
   double part[2] = {0.0, 0.0};
-  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+  const TileIter ti_ = tile_iter(ntiles);
+  for (int tile = ti_.first; tile < ti_.last; tile += ti_.step) {
     const int i = tile * GEO::P + L.wave * GEO::G + L.g;
     const bool ok = (L.g < GEO::G) && (i < n);
     double h[R], v[R], x[R];
@@ -319,8 +397,8 @@ __global__ __launch_bounds__(kBlock) void k_hess(BsrDev Q, const double* __restr
     double* ys = ok ? &sm[L.wave][0][L.g][0] : nullptr;
     double* vs = ok ? &sm[L.wave][1][L.g][0] : nullptr;
     double* hs = ok ? &sm[L.wave][2][L.g][0] : nullptr;
+    spmm_col<D, R>(Q.rowptr, Q.colidx, Q.vals, V, i, L.c, ok, h);
     if (ok) {
-      spmm_col<D, R>(Q.rowptr, Q.colidx, Q.vals, V, i, L.c, h);
       load_col<R>(X + off, x);
       load_col<R>(V + off, v);
       store_col<R>(ys + L.c * R, x);
@@ -356,6 +434,136 @@ __global__ __launch_bounds__(kBlock) void k_hess(BsrDev Q, const double* __restr
   store_partials<2>(part, partials, red);
 }
 
+// ================================================================ K7b + K1/K3/K2 fused: one tCG step
+// One launch per tCG iteration:
+//  (i)   prologue = the scalar half of the direction update (ROPTLIB tCG_TR): convergence test
+//        |r| <= |r0| min(|r0|^theta, kappa), beta = z_r'/z_r, e_Pd / d_Pd recurrences, from the
+//        <r,r>, <z,r> partials of k_tcg_update (first = 1: norm_r0, z_r, d_Pd initialisation);
+//  (ii)  Hz = proj_X( z Q - z_rot S ): the block-SpMM gathers the preconditioned residual z;
+//  (iii) row-local, in place:  delta <- beta*delta - z,   H delta <- beta*(H delta) - Hz
+//        (H is linear on the tangent space, so this equals H applied to the new delta; it lets the
+//        direction update ride in the SpMM epilogue instead of costing a second gather or a separate
+//        kernel: 3 -> 2 launches per tCG iteration), and the <delta, H delta> partial.
+// The oracle has the same option (hess_recurrence) for trajectory-level parity tests.
+template <int D, int R>
+__global__ __launch_bounds__(kBlock) void k_tcg_hess(BsrDev Q, const double* __restrict__ X,
+                                                     const double* __restrict__ S, const double* __restrict__ z,
+                                                     double* __restrict__ delta, double* __restrict__ Hd,
+                                                     const double* __restrict__ pin, int nb_in,
+                                                     double* __restrict__ pout, const DevState* __restrict__ sin,
+                                                     DevState* __restrict__ sout, int first, int n,
+                                                     unsigned long long* hflag, unsigned gen) {
+  using GEO = Geo<D, R>;
+  __shared__ double sm[kWaves][3][GEO::G][GEO::T];
+  __shared__ double red[kWaves * kNP];
+  DevState st = *sin;
+  if (st.rtr_stop || st.tcg_done) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+      *sout = st;
+      publish_progress(hflag, gen, st);
+    }
+    return;
+  }
+  double pr[2];
+  load_partials<2>(pin, nb_in, pr, red);
+  const double r_r = pr[0], z_r_new = pr[1];
+  double beta = 0.0;
+  bool go = true;
+  if (first) {
+    st.norm_r0 = sqrt(r_r);
+    st.z_r = z_r_new;
+    st.d_Pd = z_r_new;
+    st.e_Pd = 0.0;
+    if (st.max_inner <= 0) {
+      st.tcg_done = 1;
+      go = false;
+    }
+  } else {
+    const double norm_r = sqrt(r_r);
+    const double pw = pow(st.norm_r0, st.theta);
+    if (st.tcg_j >= st.min_inner && norm_r <= st.norm_r0 * (pw < st.kappa ? pw : st.kappa)) {
+      st.tcg_status = (st.kappa < pw) ? TCG_LCON : TCG_SCON;
+      st.tcg_done = 1;
+      go = false;
+    } else {
+      beta = z_r_new / st.z_r;
+      st.e_Pd = beta * (st.e_Pd + st.alpha * st.d_Pd);
+      st.d_Pd = z_r_new + beta * beta * st.d_Pd;
+      st.z_r = z_r_new;
+      st.tcg_j += 1;
+      if (st.tcg_j >= st.max_inner) {
+        st.tcg_done = 1;
+        st.tcg_status = TCG_MAXITER;
+        go = false;
+      }
+    }
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    *sout = st;
+    publish_progress(hflag, gen, st);
+  }
+  if (!go) return;
+
+  const LaneId L = lane_id<D>();
+  const int ntiles = (n + GEO::P - 1) / GEO::P;
+  double part[1] = {0.0};
+  const TileIter ti_ = tile_iter(ntiles);
+  for (int tile = ti_.first; tile < ti_.last; tile += ti_.step) {
+    const int i = tile * GEO::P + L.wave * GEO::G + L.g;
+    const bool ok = (L.g < GEO::G) && (i < n);
+    double h[R], zc[R], x[R];
+    const size_t off = (size_t)i * GEO::T + L.c * R;
+    double* ys = ok ? &sm[L.wave][0][L.g][0] : nullptr;
+    double* vs = ok ? &sm[L.wave][1][L.g][0] : nullptr;
+    double* hs = ok ? &sm[L.wave][2][L.g][0] : nullptr;
+    spmm_col<D, R>(Q.rowptr, Q.colidx, Q.vals, z, i, L.c, ok, h);
+    if (ok) {
+      load_col<R>(X + off, x);
+      load_col<R>(z + off, zc);
+      store_col<R>(ys + L.c * R, x);
+      store_col<R>(vs + L.c * R, zc);
+    }
+    __syncthreads();
+    if (ok) {
+      if (L.c < D) {
+#pragma unroll
+        for (int a = 0; a < D; ++a) {
+          const double sac = S[(size_t)i * D * D + L.c * D + a];
+#pragma unroll
+          for (int k = 0; k < R; ++k) h[k] = fma(-vs[a * R + k], sac, h[k]);
+        }
+      }
+      store_col<R>(hs + L.c * R, h);
+    }
+    __syncthreads();
+    if (ok) {
+      double hz[R], s[D], dl[R], hd[R];
+      proj_col<D, R>(ys, hs, L.c, h, hz, s);
+      if (first) {
+#pragma unroll
+        for (int a = 0; a < R; ++a) {
+          dl[a] = -zc[a];
+          hd[a] = -hz[a];
+        }
+      } else {
+        load_col<R>(delta + off, dl);
+        load_col<R>(Hd + off, hd);
+#pragma unroll
+        for (int a = 0; a < R; ++a) {
+          dl[a] = fma(beta, dl[a], -zc[a]);
+          hd[a] = fma(beta, hd[a], -hz[a]);
+        }
+      }
+#pragma unroll
+      for (int a = 0; a < R; ++a) part[0] = fma(dl[a], hd[a], part[0]);
+      store_col<R>(delta + off, dl);
+      store_col<R>(Hd + off, hd);
+    }
+    __syncthreads();
+  }
+  store_partials<1>(part, pout, red);
+}
+
 // ================================================================ K6: preconditioner (stand-alone)
 // Z = proj_X( V * Dinv )   (QuadraticProblem::PreConditioner, src/QuadraticProblem.cpp:56-69, with
 // the block-Jacobi factor in place of the CHOLMOD solve); dinv == nullptr -> Z = proj_X(V).
@@ -367,7 +575,8 @@ __global__ __launch_bounds__(kBlock) void k_precond(const double* __restrict__ X
   __shared__ double sm[kWaves][3][GEO::G][GEO::T];
   const LaneId L = lane_id<D>();
   const int ntiles = (n + GEO::P - 1) / GEO::P;
-  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+  const TileIter ti_ = tile_iter(ntiles);
+  for (int tile = ti_.first; tile < ti_.last; tile += ti_.step) {
     const int i = tile * GEO::P + L.wave * GEO::G + L.g;
     const bool ok = (L.g < GEO::G) && (i < n);
     const size_t off = (size_t)i * GEO::T + L.c * R;
@@ -414,13 +623,17 @@ __global__ __launch_bounds__(kBlock) void k_tcg_update(const double* __restrict_
                                                        double* __restrict__ r, double* __restrict__ z,
                                                        const double* __restrict__ pin, int nb_in,
                                                        double* __restrict__ pout, const DevState* __restrict__ sin,
-                                                       DevState* __restrict__ sout, int first, int n) {
+                                                       DevState* __restrict__ sout, int first, int n,
+                                                       unsigned long long* hflag, unsigned gen) {
   using GEO = Geo<D, R>;
   __shared__ double sm[kWaves][3][GEO::G][GEO::T];
   __shared__ double red[kWaves * kNP];
   DevState st = *sin;
   if (st.rtr_stop || (!first && st.tcg_done)) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) *sout = st;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+      *sout = st;
+      publish_progress(hflag, gen, st);
+    }
     return;
   }
   int mode = 0;  // 0: normal step, 1: boundary step (eta += tau*delta, stop), 2: init
@@ -450,12 +663,16 @@ __global__ __launch_bounds__(kBlock) void k_tcg_update(const double* __restrict_
       st.e_Pe = e_Pe_new;
     }
   }
-  if (blockIdx.x == 0 && threadIdx.x == 0) *sout = st;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    *sout = st;
+    publish_progress(hflag, gen, st);
+  }
 
   const LaneId L = lane_id<D>();
   const int ntiles = (n + GEO::P - 1) / GEO::P;
   double part[2] = {0.0, 0.0};
-  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+  const TileIter ti_ = tile_iter(ntiles);
+  for (int tile = ti_.first; tile < ti_.last; tile += ti_.step) {
     const int i = tile * GEO::P + L.wave * GEO::G + L.g;
     const bool ok = (L.g < GEO::G) && (i < n);
     const size_t off = (size_t)i * GEO::T + L.c * R;
@@ -592,7 +809,8 @@ __global__ __launch_bounds__(kBlock) void k_retract(const double* __restrict__ X
   if (st && st->rtr_stop) return;
   const LaneId L = lane_id<D>();
   const int ntiles = (n + GEO::P - 1) / GEO::P;
-  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+  const TileIter ti_ = tile_iter(ntiles);
+  for (int tile = ti_.first; tile < ti_.last; tile += ti_.step) {
     const int i = tile * GEO::P + L.wave * GEO::G + L.g;
     const bool ok = (L.g < GEO::G) && (i < n);
     const size_t off = (size_t)i * GEO::T + L.c * R;
@@ -756,7 +974,8 @@ __global__ __launch_bounds__(kBlock) void k_axpby_project(double a, const double
   __shared__ double sm[kWaves][GEO::G][GEO::T];
   const LaneId L = lane_id<D>();
   const int ntiles = (n + GEO::P - 1) / GEO::P;
-  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+  const TileIter ti_ = tile_iter(ntiles);
+  for (int tile = ti_.first; tile < ti_.last; tile += ti_.step) {
     const int i = tile * GEO::P + L.wave * GEO::G + L.g;
     const bool ok = (L.g < GEO::G) && (i < n);
     const size_t off = (size_t)i * GEO::T + L.c * R;

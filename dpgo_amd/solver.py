@@ -41,7 +41,7 @@ class ROptParameters:
     precond: str = "jacobi"  # "jacobi" (block-Jacobi of Q + shift I) | "none"
     precond_shift: float = 1e-1  # src/PoseGraph.cpp:603
     accept_tiny_decrease: bool = True
-    tcg_poll_interval: int = 8
+    tcg_poll_interval: int = 0  # 0 = just-in-time feed (default); k > 0 = poll every k tCG iterations
     time_bound_s: float = 5.0  # Solver.TimeBound, src/QuadraticOptimizer.cpp:78
 
     def to_c(self) -> L.RoptParamsC:

@@ -74,8 +74,9 @@ typedef struct dpgo_ropt_params {
   int precond;                /* DPGO_PRECOND_*           default BLOCK_JACOBI */
   double precond_shift;       /* reference: 1e-1 (src/PoseGraph.cpp:603) */
   int accept_tiny_decrease;   /* ROPTLIB's second acceptance clause (SURVEY 8c' item 5), default 1 */
-  int tcg_poll_interval;      /* tCG iterations enqueued between host polls of the device
-                                 "done" flag; default 8 */
+  int tcg_poll_interval;      /* 0 (default): just-in-time kernel feed driven by the progress word the
+                                 device publishes into host-coherent memory (no synchronisation);
+                                 k > 0: enqueue k tCG iterations, then synchronise and poll */
   double time_bound_s;        /* ROPTLIB Solver.TimeBound = 5.0 (src/QuadraticOptimizer.cpp:78) */
 } dpgo_ropt_params;
 

@@ -488,9 +488,15 @@ def dot(A, B):
     return float(np.sum(A * B))
 
 
-def tcg(problem: QuadraticProblem, X, g, S, Delta, max_inner, theta=1.0, kappa=0.1, min_inner=0, trace=None):
+def tcg(problem: QuadraticProblem, X, g, S, Delta, max_inner, theta=1.0, kappa=0.1, min_inner=0, trace=None,
+        hess_recurrence=False):
     """ROPTLIB SolversTR::tCG_TR restated (SURVEY 8a row a8), eta0 = 0 (useRand = false).
-    Returns (eta, status, inner_iters, n_hess)."""
+    Returns (eta, status, inner_iters, n_hess).
+
+    hess_recurrence = False is the reference's arithmetic (H applied to delta every iteration).
+    hess_recurrence = True is what the MI355X path computes: H is applied to the preconditioned
+    residual z and H delta follows the direction recurrence, H delta' = beta * H delta - H z (exact in
+    exact arithmetic because H is linear on the tangent space)."""
     r = g.copy()
     e_Pe = 0.0
     r_r = dot(r, r)
@@ -504,8 +510,14 @@ def tcg(problem: QuadraticProblem, X, g, S, Delta, max_inner, theta=1.0, kappa=0
     status = TCG_MAXITER
     j = 0
     n_hess = 0
+    beta = 0.0
+    Hd = None
     while j < max_inner:
-        Hd = problem.rie_hess(X, S, delta)
+        if hess_recurrence:
+            Hz = problem.rie_hess(X, S, z)
+            Hd = -Hz if j == 0 else beta * Hd - Hz
+        else:
+            Hd = problem.rie_hess(X, S, delta)
         n_hess += 1
         d_Hd = dot(delta, Hd)
         alpha = z_r / d_Hd if d_Hd != 0 else math.inf
@@ -543,11 +555,12 @@ class QuadraticOptimizer:
     ROPTLIB accepts a step whose relative decrease is positive but below sqrt(eps))."""
 
     def __init__(self, problem: QuadraticProblem, params: Optional[ROptParameters] = None,
-                 accept_tiny_decrease: bool = True):
+                 accept_tiny_decrease: bool = True, hess_recurrence: bool = False):
         self.problem = problem
         self.params = params or ROptParameters()
         self.result = ROPTResult()
         self.accept_tiny_decrease = accept_tiny_decrease
+        self.hess_recurrence = hess_recurrence
 
     def optimize(self, Y):  # QuadraticOptimizer.cpp:26-48
         import time
@@ -583,7 +596,8 @@ class QuadraticOptimizer:
         isstop = ngf < prm.gradnorm_tol
         while not isstop and it < max_iter:
             tr = [] if prm.verbose else None
-            eta, status, inner, n_hess = tcg(p, x1, g1, S, Delta, prm.RTR_tCG_iterations, trace=tr)
+            eta, status, inner, n_hess = tcg(p, x1, g1, S, Delta, prm.RTR_tCG_iterations, trace=tr,
+                                             hess_recurrence=self.hess_recurrence)
             self.result.tcg_iters += n_hess
             x2 = qf_retract(x1, eta, d)
             f2 = p.f(x2)

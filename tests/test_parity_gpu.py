@@ -86,10 +86,12 @@ def test_manifold_ops_match_oracle(oracle, d, r, n):
 
 @pytest.mark.parametrize("name,r,precond", [("smallGrid3D", 5, "jacobi"), ("smallGrid3D", 5, "none"),
                                             ("sphere2500", 5, "jacobi"), ("tinyGrid3D", 3, "jacobi"),
-                                            ("kitti_00", 5, "jacobi")])
+                                            ("kitti_00", 5, "jacobi"), ("torus3D", 5, "jacobi")])
 def test_optimize_matches_oracle_at_matched_settings(oracle, name, r, precond):
     """One QuadraticOptimizer::optimize call with the reference defaults (RTR 3 x <=50 tCG,
-    Delta0 = 100, tol 1e-2): same preconditioner on both sides => same trajectory."""
+    Delta0 = 100, tol 1e-2).  Same preconditioner and the same H-delta recurrence on both sides =>
+    same trajectory (iteration counts, tCG status, iterate to 1e-7).  Against the oracle in the
+    reference's own arithmetic (H applied to delta directly) the result must still agree closely."""
     import dpgo_amd
     om, n, d, Q, pg, prob = build_single_agent(oracle, name, r)
     if name == "tinyGrid3D":
@@ -98,7 +100,7 @@ def test_optimize_matches_oracle_at_matched_settings(oracle, name, r, precond):
         T = oracle.chordal_initialization(om, n)
     X0 = oracle.lift(T, r)
     op = oracle.QuadraticProblem(Q, None, r, d, precond=precond)
-    oopt = oracle.QuadraticOptimizer(op, oracle.ROptParameters())
+    oopt = oracle.QuadraticOptimizer(op, oracle.ROptParameters(), hess_recurrence=True)
     Xo = oopt.optimize(X0)
     gopt = dpgo_amd.QuadraticOptimizer(prob, dpgo_amd.ROptParameters(precond=precond))
     Xg = matrix_to_tiles(gopt.optimize(tiles_to_matrix(X0)), d)
@@ -117,6 +119,12 @@ def test_optimize_matches_oracle_at_matched_settings(oracle, name, r, precond):
     assert relerr(Xg, Xo) < 1e-7
     # and the problem object agrees with the optimizer's own statistics (QuadraticOptimizer.cpp:42-43)
     assert abs(prob.f(tiles_to_matrix(Xg)) - rg.fOpt) <= 1e-12 * abs(rg.fOpt) + 1e-14 * scale
+    # reference arithmetic (no recurrence): same decisions, same result up to round-off amplification
+    ref = oracle.QuadraticOptimizer(oracle.QuadraticProblem(Q, None, r, d, precond=precond), oracle.ROptParameters())
+    Xr = ref.optimize(X0)
+    assert ref.result.outer_iters == rg.rtr_iterations
+    assert abs(rg.fOpt - ref.result.fOpt) <= 1e-7 * abs(ref.result.fOpt) + 1e-14 * scale
+    assert relerr(Xg, Xr) < 1e-5
 
 
 @pytest.mark.parametrize("name,ref2f", [("smallGrid3D", 1025.3980556263), ("sphere2500", 1687.0058142808),
@@ -140,6 +148,31 @@ def test_final_cost_matches_reference_configuration(oracle, name, ref2f):
     assert abs(fg - fo) <= 1e-6 * abs(fo)
     assert abs(2 * fg - ref2f) <= 1e-6 * ref2f  # literature optimum
     assert gopt.getOptResult().gradNormOpt < 1e-3
+
+
+def test_feed_modes_and_single_iteration_radius_shrink(oracle):
+    """The just-in-time kernel feed (default) and the polling feed run the same device arithmetic;
+    RTR_iterations == 1 takes the radius-shrinking branch of trustRegion (src/QuadraticOptimizer.cpp:80-99)."""
+    import dpgo_amd
+    om, n, d, Q, pg, prob = build_single_agent(oracle, "sphere2500", 5)
+    X0 = tiles_to_matrix(oracle.lift(oracle.chordal_initialization(om, n), 5))
+    outs = []
+    for poll in (0, 1, 8):
+        opt = dpgo_amd.QuadraticOptimizer(prob, dpgo_amd.ROptParameters(tcg_poll_interval=poll))
+        outs.append((opt.optimize(X0), opt.getOptResult()))
+    for X, res in outs[1:]:
+        assert np.array_equal(X, outs[0][0])
+        assert (res.tcg_iterations, res.rtr_iterations, res.fOpt) == (outs[0][1].tcg_iterations,
+                                                                      outs[0][1].rtr_iterations, outs[0][1].fOpt)
+    # single-iteration mode: a tiny initial radius is accepted at once, result equals the oracle's
+    prm_o = oracle.ROptParameters(RTR_iterations=1, RTR_initial_radius=1.0)
+    oo = oracle.QuadraticOptimizer(oracle.QuadraticProblem(Q, None, 5, d, precond="jacobi"), prm_o, hess_recurrence=True)
+    Xo = oo.optimize(matrix_to_tiles(X0, d))
+    go = dpgo_amd.QuadraticOptimizer(prob, dpgo_amd.ROptParameters(RTR_iterations=1, RTR_initial_radius=1.0))
+    Xg = matrix_to_tiles(go.optimize(X0), d)
+    assert go.getOptResult().latest_step_accepted
+    assert go.getOptResult().tCGStatus == oracle.TCG_NAMES[oo.result.tCGStatus] == "EXCREGION"
+    assert relerr(Xg, Xo) < 1e-9
 
 
 def test_triangle_graph_known_answer(oracle):
