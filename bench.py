@@ -13,8 +13,8 @@ with the public-pose exchange over RCCL point-to-point.  Total work is fixed as 
 Workload at N = 1: the synthetic 100k-pose 3-D grid of BASELINE.json (configs[3], the configuration the
 HBM-roofline target is quoted on; it fits one GPU).  Inputs are resident in HBM before the timed region.
 
-Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel, k_hess (the fused
-Q*X SpMM + Riemannian-Hessian epilogue launched once per tCG iteration); `cpu_baseline` times the CPU
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel, k_tcg_hess (the fused
+Q*z SpMM + Riemannian-Hessian epilogue + direction recurrences, launched once per tCG iteration); `cpu_baseline` times the CPU
 oracle ("port") on the same workload on the host cores (rank 0, N = 1 only).
 """
 import argparse
@@ -41,6 +41,7 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget-s", type=float, default=25.0)
     ap.add_argument("--spmm-reps", type=int, default=200)
+    ap.add_argument("--agents-per-gpu", type=int, default=0, help="0 = auto (1 if one GPU, else 2)")
     return ap.parse_args()
 
 
@@ -72,10 +73,11 @@ def spmm_bytes(n, nnzb, d, r):
 
 
 def hess_bytes(n, nnzb, d, r):
-    """k_hess = SpMM + fused epilogue: additionally reads the iterate X (8 r b n) and the cached
-    S = sym(Y^T EG) blocks (8 d^2 n)."""
+    """k_tcg_hess = the SpMM (Q, indices, one read of z) + fused epilogue: reads the iterate X, the
+    cached S = sym(Y^T EG) blocks, delta and H delta; writes delta and H delta."""
     b = d + 1
-    return spmm_bytes(n, nnzb, d, r) + 8 * r * b * n + 8 * d * d * n
+    v = 8 * r * b * n
+    return nnzb * (8 * b * b + 4) + 4 * (n + 1) + v + (v + 8 * d * d * n) + 2 * v + 2 * v
 
 
 def cpu_baseline(meas_p, n, X0, r, budget_s):
@@ -133,7 +135,7 @@ def main():
     import torch
     import torch.distributed as dist
     import dpgo_amd
-    from dpgo_amd.agent import DeviceAgent, RBCDCluster, build_pose_graphs
+    from dpgo_amd.agent import DeviceAgent, ExchangePlan, RBCDCluster, build_pose_graphs
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -144,19 +146,36 @@ def main():
         raise SystemExit("launch with torch.distributed.run for --gpus > 1")
     if dpgo_amd.device_count() < 1:
         raise SystemExit("bench.py needs a HIP device: the product path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
+    dev_index = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        # "nccl" IS RCCL on ROCm; DPGO_DIST_BACKEND=gloo (host-staged) lets the N > 1 path be exercised
+        # on a single-GPU box with all ranks sharing device 0
+        backend = os.environ.get("DPGO_DIST_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend)
 
     r = args.rank
     meas, n, X0, desc = make_workload(args.workload, r)
     d = meas.d
-    ranges, graphs = build_pose_graphs(meas, n, world, r)
-    s, e = ranges[rank]
+    # agents: 1 for a single GPU (one agent owns the whole graph, BASELINE configs[1] style);
+    # for N > 1 GPUs two agents per GPU by default -- consecutive blocks of a chain / ring partition
+    # alternate colours, so every GPU hosts one agent of each colour and works in BOTH colour phases
+    apg = args.agents_per_gpu if args.agents_per_gpu > 0 else (1 if world == 1 else 2)
+    num_agents = world * apg
+    ranges, graphs = build_pose_graphs(meas, n, num_agents, r)
     params = dpgo_amd.ROptParameters()  # reference defaults + block-Jacobi
-    agent = DeviceAgent(graphs, rank, X0[s:e], params, device=local_rank)
-    cluster = RBCDCluster(agent, graphs, rank, world)
-    nnzb_local = len(graphs[rank].quadraticMatrix()[1])
+    plan = ExchangePlan(graphs)
+    my_ids = list(range(rank * apg, (rank + 1) * apg))
+    agents = {a: DeviceAgent(graphs, plan, a, X0[ranges[a][0]:ranges[a][1]], params, device=dev_index)
+              for a in my_ids}
+    cluster = RBCDCluster(plan, agents, rank, world, agents_per_rank=apg)
+    big = max(my_ids, key=lambda a: graphs[a].n())  # the agent whose kernels are profiled below
+    agent = agents[big]
+    nnzb_local = len(graphs[big].quadraticMatrix()[1])
+    n_local = graphs[big].n()
 
     def barrier():
         torch.cuda.synchronize()
@@ -172,11 +191,11 @@ def main():
     tcg_total = 0
     for _ in range(args.steps):
         cluster.sweep()
-        tcg_total += agent.last_result.tcg_iterations if agent.last_result else 0
+        tcg_total += sum(a.last_result.tcg_iterations for a in agents.values() if a.last_result)
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if cluster.stage else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     f1, g1 = cluster.central_cost_and_gradnorm()
@@ -187,14 +206,15 @@ def main():
     ms_hess, ms_spmm = C.c_double(0.0), C.c_double(0.0)
     dpgo_amd.lib.check(lib.dpgo_bench_hess(agent.problem.handle, args.spmm_reps, 10, C.byref(ms_hess)))
     dpgo_amd.lib.check(lib.dpgo_bench_spmm(agent.problem.handle, args.spmm_reps, 10, C.byref(ms_spmm)))
-    n_local = e - s
     hb = hess_bytes(n_local, nnzb_local, d, r)
     sb = spmm_bytes(n_local, nnzb_local, d, r)
     ach = hb / (ms_hess.value * 1e-3) / 1e9
-    roofline = dict(bound="hbm", kernel="k_hess<%d,%d> (Q*X block-SpMM + Riemannian Hessian epilogue)" % (d, r),
+    roofline = dict(bound="hbm",
+                    kernel="k_tcg_hess<%d,%d> (one tCG step: Q*z block-SpMM + Riemannian-Hessian epilogue + in-place "
+                           "direction / H-direction recurrences)" % (d, r),
                     achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS, traffic=None,
                     bytes_per_launch=hb, avg_launch_us=ms_hess.value * 1e3,
-                    spmm_only=dict(kernel="k_spmm<%d,%d>" % (d, r), bytes_per_launch=sb,
+                    spmm_only=dict(kernel="k_spmm<%d,%d> (plain Q*X)" % (d, r), bytes_per_launch=sb,
                                    avg_launch_us=ms_spmm.value * 1e3,
                                    achieved=sb / (ms_spmm.value * 1e-3) / 1e9,
                                    frac=sb / (ms_spmm.value * 1e-3) / 1e9 / HBM_PEAK_GBS))
@@ -217,9 +237,12 @@ def main():
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic" if args.workload.startswith("grid") else "g2o dataset shipped in data/",
-            "config": {"workload": desc, "agents": world, "r": r, "d": d,
+            "config": {"workload": desc, "agents": num_agents, "agents_per_gpu": apg, "r": r, "d": d,
                        "local_solver": "RTR 3x<=50 tCG, Delta0=100, tol=1e-2 (reference defaults), block-Jacobi precond",
-                       "schedule": "single agent" if world == 1 else "two-colour parallel RBCD, RCCL p2p exchange",
+                       "schedule": "single agent" if num_agents == 1 else
+                       "%d-colour parallel RBCD; 1 step = 1 sweep (every agent updates once); public-pose "
+                       "exchange over %s" % (plan.num_colours, "device copies" if world == 1 else
+                                             ("RCCL p2p" if not cluster.stage else "gloo (host-staged)")),
                        "poses_per_agent": n_local, "nnzb_per_agent": nnzb_local},
             "roofline": roofline,
             "cpu_baseline": cpu,

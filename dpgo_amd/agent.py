@@ -1,20 +1,24 @@
-"""Device-resident counterpart of the part of PGOAgent that calls the hot path.
+"""Device-resident counterpart of the part of PGOAgent that calls the hot path, and the
+public-pose exchange between agents.
 
 What the reference does per RBCD iteration (src/PGOAgent.cpp:376-432, 938-995):
   neighbours' public poses -> PoseGraph::setNeighborPoses -> constructG -> QuadraticProblem +
   QuadraticOptimizer::optimize(X0) -> X.
 Here X, the neighbour tile buffer, G and Q stay in HBM; one agent maps to one GPU / one process
 and the public-pose exchange (examples/MultiRobotExample.cpp:183-204 does it by pointer calls
-inside one process) is carried by RCCL point-to-point send/recv (torch.distributed, backend "nccl").
+inside one process; the wire unit is the LiftedPose, r x (d+1) doubles keyed by PoseID) is carried
+by RCCL point-to-point send/recv (torch.distributed, backend "nccl"), one grouped batch per
+exchange.  The same classes also run N agents inside one process on one GPU (device-to-device
+copies instead of RCCL) -- used by the single-GPU parity tests.
 
-The schedule for multi-GPU runs is the two-colour parallel RBCD of SURVEY 8e: agents of one colour
-update simultaneously (iterate(true)), the others keep their iterate -- expressible with the
-reference's unmodified iterate(bool) API.  "One RBCD iteration" = one sweep in which every agent
-has updated once.
+Schedule for parallel runs: the two-colour RBCD of SURVEY 8e -- agents of one colour update
+simultaneously (PGOAgent::iterate(true)), the others keep their iterate -- expressible with the
+reference's unmodified iterate(bool) API.  "One RBCD iteration" = one sweep in which every agent has
+updated once.
 """
 from __future__ import annotations
 
-from typing import Dict, List, Optional, Sequence
+from typing import Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
 
@@ -34,29 +38,61 @@ def build_pose_graphs(dataset: RelativeSEMeasurements, num_poses: int, num_robot
     return ranges, graphs
 
 
-def greedy_colouring(graphs: Sequence[PoseGraph]) -> List[int]:
-    """Colour the agent graph (agents adjacent iff they share a loop closure) greedily in id order;
-    chain / even-ring partitions get two colours."""
-    nbrs = [sorted({rob for rob, _ in g.neighborPoseIDs()}) for g in graphs]
-    colour = [-1] * len(graphs)
-    for a in range(len(graphs)):
-        used = {colour[q] for q in nbrs[a] if colour[q] >= 0}
-        c = 0
-        while c in used:
-            c += 1
-        colour[a] = c
-    return colour
+class ExchangePlan:
+    """Static description of the public-pose exchange, computed once from the pose graphs (host
+    only; the reference recomputes PoseDicts every iteration, src/PGOAgent.cpp:97-166).
+
+    slots[a]      : sorted (robot, frame) ids agent a needs = column order of its neighbour tile buffer
+    recv_range[a] : {q: (lo, hi)} -- the slots filled by neighbour q are one contiguous range
+    send_frames[a]: {q: [frames]} -- a's own poses that q needs, in q's slot order
+    colour[a]     : greedy colouring of the agent graph in id order (chain / even ring: 2 colours)
+    """
+
+    def __init__(self, graphs: Sequence[PoseGraph]):
+        self.num_agents = len(graphs)
+        self.slots: List[List[Tuple[int, int]]] = [g.neighborPoseIDs() for g in graphs]
+        self.recv_range: List[Dict[int, Tuple[int, int]]] = []
+        self.send_frames: List[Dict[int, List[int]]] = [dict() for _ in graphs]
+        for a, sl in enumerate(self.slots):
+            rr: Dict[int, Tuple[int, int]] = {}
+            for k, (rob, _fr) in enumerate(sl):
+                lo, _hi = rr.get(rob, (k, k))
+                rr[rob] = (lo, k + 1)
+            self.recv_range.append(rr)
+            for q in rr:
+                lo, hi = rr[q]
+                self.send_frames[q][a] = [fr for _rob, fr in sl[lo:hi]]
+        self.adj: List[List[int]] = [sorted(rr.keys()) for rr in self.recv_range]
+        self.colour = [-1] * self.num_agents
+        for a in range(self.num_agents):
+            used = {self.colour[q] for q in self.adj[a] if self.colour[q] >= 0}
+            c = 0
+            while c in used:
+                c += 1
+            self.colour[a] = c
+        self.num_colours = (max(self.colour) + 1) if self.num_agents else 0
+
+    def messages(self, receivers: Optional[int] = None) -> List[Tuple[int, int]]:
+        """(sender, receiver) pairs of one exchange; receivers = colour class that needs fresh
+        neighbour poses (None = everyone).  Deterministic order on every rank."""
+        out = []
+        for q in range(self.num_agents):
+            if receivers is None or self.colour[q] == receivers:
+                for a in self.adj[q]:
+                    out.append((a, q))
+        return out
 
 
 class DeviceAgent:
     """One agent on one GPU: device-resident X, neighbour tile buffer and problem handle."""
 
-    def __init__(self, graphs: Sequence[PoseGraph], my_id: int, X0_tiles: np.ndarray,
+    def __init__(self, graphs: Sequence[PoseGraph], plan: ExchangePlan, my_id: int, X0_tiles: np.ndarray,
                  params: Optional[ROptParameters] = None, device: int = 0):
         import torch
         self.torch = torch
         self.id = my_id
         self.pg = graphs[my_id]
+        self.plan = plan
         self.r, self.d, self.n = self.pg.r(), self.pg.d(), self.pg.n()
         self.b = self.d + 1
         self.device = torch.device("cuda", device)
@@ -67,32 +103,17 @@ class DeviceAgent:
         self.problem.setStream(torch.cuda.current_stream().cuda_stream)
         self.optimizer = QuadraticOptimizer(self.problem, params or ROptParameters())
         self.X = torch.tensor(np.ascontiguousarray(X0_tiles), dtype=torch.float64, device=self.device)
-        # neighbour slots: sorted (robot, frame) -> contiguous range per neighbour robot, frame order
-        self.slots = self.problem.setCouplingFromPoseGraph() if self.has_neighbours else []
-        self.nbr = torch.zeros((max(len(self.slots), 1), self.b, self.r), dtype=torch.float64, device=self.device)
-        self.recv_range: Dict[int, tuple] = {}
-        for k, (rob, _fr) in enumerate(self.slots):
-            lo, hi = self.recv_range.get(rob, (k, k))
-            self.recv_range[rob] = (min(lo, k), k + 1)
-        # what each neighbour needs from me, in ITS slot order
-        self.send_idx: Dict[int, "torch.Tensor"] = {}
-        for q, g in enumerate(graphs):
-            if q == my_id:
-                continue
-            frames = [fr for rob, fr in g.neighborPoseIDs() if rob == my_id]
-            if frames:
-                self.send_idx[q] = torch.tensor(frames, dtype=torch.int32, device=self.device)
+        self.has_neighbours = len(plan.slots[my_id]) > 0
+        if self.has_neighbours:
+            slots = self.problem.setCouplingFromPoseGraph()
+            assert slots == plan.slots[my_id]
+        self.nbr = torch.zeros((max(len(plan.slots[my_id]), 1), self.b, self.r), dtype=torch.float64,
+                               device=self.device)
+        self.send_idx = {q: torch.tensor(fr, dtype=torch.int32, device=self.device)
+                         for q, fr in plan.send_frames[my_id].items()}
         self.send_buf = {q: torch.empty((len(ix), self.b, self.r), dtype=torch.float64, device=self.device)
                          for q, ix in self.send_idx.items()}
         self.last_result: Optional[ROPTResult] = None
-
-    @property
-    def has_neighbours(self) -> bool:
-        return len(self.pg.sharedLoopClosures()) > 0
-
-    @property
-    def neighbours(self) -> List[int]:
-        return sorted(self.recv_range.keys())
 
     # ---- K11: pack / unpack of public poses (PGOAgent::getSharedPoseDict / updateNeighborPoses) ----
     def pack(self, q: int):
@@ -103,7 +124,7 @@ class DeviceAgent:
         return buf
 
     def recv_view(self, q: int):
-        lo, hi = self.recv_range[q]
+        lo, hi = self.plan.recv_range[self.id][q]
         return self.nbr[lo:hi]
 
     # ---- the hot path ----
@@ -124,44 +145,78 @@ class DeviceAgent:
 
 
 class RBCDCluster:
-    """N agents, one per rank, exchanging public poses over torch.distributed (RCCL)."""
+    """The agents hosted by THIS process plus the transport to the others.
 
-    def __init__(self, agent: DeviceAgent, graphs: Sequence[PoseGraph], rank: int, world: int):
-        self.agent, self.rank, self.world = agent, rank, world
-        self.colour = greedy_colouring(graphs)
-        self.num_colours = max(self.colour) + 1
-        self.adj = [sorted({rob for rob, _ in g.neighborPoseIDs()}) for g in graphs]
+    local_agents: {agent id: agent}; an "agent" only needs .id, .pack(q), .recv_view(q), .update(),
+    .local_terms().  owner(a) = rank hosting agent a: everything on rank 0 in single-process mode,
+    agents [k*apr, (k+1)*apr) on rank k under torch.distributed (one process per GPU)."""
+
+    def __init__(self, plan: ExchangePlan, local_agents: Dict[int, object], rank: int = 0, world: int = 1,
+                 stage_through_host: Optional[bool] = None, agents_per_rank: int = 1):
+        self.plan, self.agents, self.rank, self.world = plan, local_agents, rank, world
+        self.agents_per_rank = int(agents_per_rank)
+        if world > 1:
+            import torch.distributed as dist
+            if stage_through_host is None:
+                stage_through_host = dist.get_backend() == "gloo"
+        self.stage = bool(stage_through_host)
+
+    def owner(self, agent_id: int) -> int:
+        """Rank hosting an agent: consecutive ids share a rank (agents_per_rank = 2 puts one agent of
+        each colour of a chain / ring partition on every GPU, so no GPU idles during a colour phase)."""
+        return agent_id // self.agents_per_rank if self.world > 1 else 0
 
     def exchange(self, receivers: Optional[int] = None) -> None:
-        """Public-pose exchange.  receivers = colour whose agents need fresh neighbour poses
-        (None = everyone).  One grouped batch of isend/irecv per call (ncclGroupStart/End)."""
-        if self.world == 1:
-            return
-        import torch.distributed as dist
-        a = self.agent
-        ops = []
-        for q in self.adj[self.rank]:
-            if receivers is None or self.colour[q] == receivers:
-                ops.append(dist.P2POp(dist.isend, a.pack(q), q))
-            if receivers is None or self.colour[self.rank] == receivers:
-                ops.append(dist.P2POp(dist.irecv, a.recv_view(q), q))
+        """Public-pose exchange: every (sender a -> receiver q) message of ExchangePlan.messages.
+        Local pairs are device copies; remote pairs form ONE grouped batch of isend/irecv
+        (ncclGroupStart/End under RCCL), so no ordering between ranks can deadlock."""
+        ops, staged = [], []
+        dist = None
+        for a, q in self.plan.messages(receivers):
+            a_here, q_here = a in self.agents, q in self.agents
+            if a_here and q_here:
+                self.agents[q].recv_view(a).copy_(self.agents[a].pack(q))
+            elif a_here:
+                import torch.distributed as dist
+                buf = self.agents[a].pack(q)
+                ops.append(dist.P2POp(dist.isend, buf.cpu() if self.stage else buf, self.owner(q)))
+            elif q_here:
+                import torch.distributed as dist
+                view = self.agents[q].recv_view(a)
+                if self.stage:
+                    tmp = view.cpu()
+                    staged.append((view, tmp))
+                    ops.append(dist.P2POp(dist.irecv, tmp, self.owner(a)))
+                else:
+                    ops.append(dist.P2POp(dist.irecv, view, self.owner(a)))
         if ops:
             for w in dist.batch_isend_irecv(ops):
                 w.wait()
+            for view, tmp in staged:
+                view.copy_(tmp)
 
     def sweep(self) -> None:
         """One RBCD iteration: every colour class updates once (parallel within a class)."""
-        for c in range(self.num_colours):
+        for c in range(self.plan.num_colours):
             self.exchange(receivers=c)
-            if self.colour[self.rank] == c:
-                self.agent.update()
+            for a, agent in self.agents.items():
+                if self.plan.colour[a] == c:
+                    agent.update()
 
-    def central_cost_and_gradnorm(self):
-        import torch
-        import torch.distributed as dist
+    def central_cost_and_gradnorm(self) -> Tuple[float, float]:
+        """Central cost f(X) and Riemannian gradient norm (what examples/MultiRobotExample.cpp:220-225
+        evaluates on a central problem), assembled from agent-local terms + one tiny all-reduce."""
         self.exchange(None)
-        xqx, xg, g2 = self.agent.local_terms()
-        t = torch.tensor([0.5 * (xqx + xg), g2], dtype=torch.float64, device=self.agent.device)
+        acc = np.zeros(2)
+        for agent in self.agents.values():
+            xqx, xg, g2 = agent.local_terms()
+            acc += [0.5 * (xqx + xg), g2]
         if self.world > 1:
+            import torch
+            import torch.distributed as dist
+            any_agent = next(iter(self.agents.values()))
+            dev = getattr(any_agent, "device", "cpu")
+            t = torch.tensor(acc, dtype=torch.float64, device="cpu" if self.stage else dev)
             dist.all_reduce(t)
-        return float(t[0].item()), float(t[1].item()) ** 0.5
+            acc = t.cpu().numpy()
+        return float(acc[0]), float(acc[1]) ** 0.5

@@ -6,6 +6,7 @@
 // the host only enqueues kernels and polls a 200-byte state record every few tCG iterations.
 #include "kernels.h"
 
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -593,6 +594,46 @@ int dpgo_problem_set_Q_bsr(dpgo_problem_t p, int nnzb, const int32_t* rowptr, co
   CHK(build_dinv(p, 1e-1));  // src/PoseGraph.cpp:603
   HIPC(hipStreamSynchronize(p->stream));
   return DPGO_OK;
+}
+
+int dpgo_problem_set_Q_csr(dpgo_problem_t p, const int32_t* outer, const int32_t* inner, const double* values) {
+  if (!p) return fail(DPGO_ERR_INVALID, "null handle");
+  if (!outer || !inner || !values) return fail(DPGO_ERR_INVALID, "null CSR arrays");
+  const int b = p->b, n = p->n;
+  std::vector<int32_t> rowptr(n + 1, 0), colidx;
+  std::vector<double> vals;
+  std::vector<int> slot(n, -1);  // block column -> position in the current block row
+  for (int i = 0; i < n; ++i) {
+    const int first = (int)colidx.size();
+    std::vector<int> cols;
+    for (int rr = 0; rr < b; ++rr) {
+      const int row = i * b + rr;
+      if (outer[row + 1] < outer[row]) return fail(DPGO_ERR_INVALID, "CSR outer index not monotone");
+      for (int t = outer[row]; t < outer[row + 1]; ++t) {
+        const int c = inner[t];
+        if (c < 0 || c >= n * b) return fail(DPGO_ERR_INVALID, "CSR column index out of range");
+        const int j = c / b;
+        if (slot[j] < 0) {
+          slot[j] = 1;
+          cols.push_back(j);
+        }
+      }
+    }
+    std::sort(cols.begin(), cols.end());
+    for (size_t k = 0; k < cols.size(); ++k) slot[cols[k]] = first + (int)k;
+    colidx.insert(colidx.end(), cols.begin(), cols.end());
+    vals.resize(colidx.size() * (size_t)b * b, 0.0);
+    for (int rr = 0; rr < b; ++rr) {
+      const int row = i * b + rr;
+      for (int t = outer[row]; t < outer[row + 1]; ++t) {
+        const int c = inner[t];
+        vals[(size_t)slot[c / b] * b * b + rr * b + (c % b)] += values[t];
+      }
+    }
+    for (int j : cols) slot[j] = -1;
+    rowptr[i + 1] = (int32_t)colidx.size();
+  }
+  return dpgo_problem_set_Q_bsr(p, (int)colidx.size(), rowptr.data(), colidx.data(), vals.data());
 }
 
 int dpgo_problem_update_Q_values(dpgo_problem_t p, const double* vals) {

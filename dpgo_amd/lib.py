@@ -60,6 +60,7 @@ SIGNATURES = {
     "dpgo_problem_set_stream": ([_P, _P], _I),
     "dpgo_problem_dims": ([_P, C.POINTER(_I), C.POINTER(_I), C.POINTER(_I), C.POINTER(_I)], _I),
     "dpgo_problem_set_Q_bsr": ([_P, _I, _P, _P, _P], _I),
+    "dpgo_problem_set_Q_csr": ([_P, _P, _P, _P], _I),
     "dpgo_problem_update_Q_values": ([_P, _P], _I),
     "dpgo_problem_set_G": ([_P, _P], _I),
     "dpgo_problem_set_G_device": ([_P, _P], _I),

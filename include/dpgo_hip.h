@@ -120,6 +120,11 @@ int dpgo_problem_dims(dpgo_problem_t h, int* r, int* d, int* n, int* nnzb);
  * PoseGraph::constructPreconditioner (src/PoseGraph.cpp:598-613). */
 int dpgo_problem_set_Q_bsr(dpgo_problem_t h, int nnzb, const int32_t* rowptr, const int32_t* colidx,
                            const double* vals);
+/* The same from the reference's own storage: Eigen::SparseMatrix<double, RowMajor> Q is scalar CSR
+ * (outerIndexPtr / innerIndexPtr / valuePtr, int32; include/DPGO/DPGO_types.h:26) of size
+ * (d+1)n x (d+1)n.  Entries are binned into (d+1)x(d+1) blocks (structural zeros of the blocks,
+ * e.g. the last row of -T*Omega, are filled in); duplicates are summed. */
+int dpgo_problem_set_Q_csr(dpgo_problem_t h, const int32_t* outer, const int32_t* inner, const double* values);
 /* same pattern, new values (GNC re-weighting: PGOAgent.cpp:1122 clearDataMatrices path) */
 int dpgo_problem_update_Q_values(dpgo_problem_t h, const double* vals);
 

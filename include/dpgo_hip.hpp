@@ -1,0 +1,401 @@
+// dpgo_hip.hpp -- header-only C++17 mirror of the reference's local-solver classes over the C ABI
+// (dpgo_hip.h).  Same class / method names, argument meaning and error behaviour as
+//
+//   DPGO::QuadraticProblem    include/DPGO/QuadraticProblem.h:33-115
+//   DPGO::QuadraticOptimizer  include/DPGO/QuadraticOptimizer.h:20-104
+//   DPGO::LiftedSEManifold    include/DPGO/manifold/LiftedSEManifold.h:28-43
+//   DPGO::ROptParameters / ROPTResult   include/DPGO/DPGO_types.h:44-107
+//   DPGO::PoseGraph (data-matrix part)  include/DPGO/PoseGraph.h:59-69,106-194
+//
+// so that PGOAgent::updateX (src/PGOAgent.cpp:961-991) and solvePGO (src/DPGO_solver.cpp:322-331)
+// compile unchanged against it.  The reference's Matrix is Eigen::MatrixXd (column-major); this
+// header uses a minimal column-major Matrix with the same data layout so that it builds without
+// Eigen -- with Eigen present, Eigen::Map<const Eigen::MatrixXd>(m.data(), m.rows(), m.cols()) and
+// back are zero-copy views (INTEGRATION.md shows the Eigen-typed shim).
+//
+// Errors: the reference aborts through glog CHECK; here a dpgo_hip::Error (std::runtime_error) is
+// thrown with the C ABI's message.  Nothing in this header computes on the CPU: without a HIP
+// device every compute call throws.
+#pragma once
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <map>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "dpgo_hip.h"
+
+namespace dpgo_hip {
+
+struct Error : std::runtime_error {
+  int code;
+  Error(int c, const std::string& m) : std::runtime_error("dpgo_hip error " + std::to_string(c) + ": " + m), code(c) {}
+};
+inline void check(int rc) {
+  if (rc != DPGO_OK) throw Error(rc, dpgo_last_error());
+}
+
+// Column-major dense matrix with Eigen::MatrixXd's memory layout.
+class Matrix {
+ public:
+  Matrix() = default;
+  Matrix(size_t rows, size_t cols) : r_(rows), c_(cols), a_(rows * cols, 0.0) {}
+  static Matrix Zero(size_t rows, size_t cols) { return Matrix(rows, cols); }
+  static Matrix Identity(size_t rows, size_t cols) {
+    Matrix m(rows, cols);
+    for (size_t i = 0; i < rows && i < cols; ++i) m(i, i) = 1.0;
+    return m;
+  }
+  size_t rows() const { return r_; }
+  size_t cols() const { return c_; }
+  double* data() { return a_.data(); }
+  const double* data() const { return a_.data(); }
+  double& operator()(size_t i, size_t j) { return a_[j * r_ + i]; }
+  double operator()(size_t i, size_t j) const { return a_[j * r_ + i]; }
+  Matrix block(size_t i0, size_t j0, size_t nr, size_t nc) const {
+    Matrix m(nr, nc);
+    for (size_t j = 0; j < nc; ++j)
+      for (size_t i = 0; i < nr; ++i) m(i, j) = (*this)(i0 + i, j0 + j);
+    return m;
+  }
+  void setBlock(size_t i0, size_t j0, const Matrix& b) {
+    for (size_t j = 0; j < b.cols(); ++j)
+      for (size_t i = 0; i < b.rows(); ++i) (*this)(i0 + i, j0 + j) = b(i, j);
+  }
+  double norm() const {
+    double s = 0;
+    for (double v : a_) s += v * v;
+    return std::sqrt(s);
+  }
+
+ private:
+  size_t r_ = 0, c_ = 0;
+  std::vector<double> a_;
+};
+
+// DPGO::RelativeSEMeasurement (include/DPGO/RelativeSEMeasurement.h:21-50); R is d x d, t is d x 1.
+struct RelativeSEMeasurement {
+  size_t r1 = 0, r2 = 0, p1 = 0, p2 = 0;
+  Matrix R, t;
+  double kappa = 0, tau = 0;
+  bool fixedWeight = false;
+  double weight = 1.0;
+  RelativeSEMeasurement() = default;
+  RelativeSEMeasurement(size_t first_robot, size_t second_robot, size_t first_pose, size_t second_pose,
+                        const Matrix& relative_rotation, const Matrix& relative_translation,
+                        double rotational_precision, double translational_precision)
+      : r1(first_robot), r2(second_robot), p1(first_pose), p2(second_pose), R(relative_rotation),
+        t(relative_translation), kappa(rotational_precision), tau(translational_precision) {}
+};
+
+// DPGO::ROptParameters (include/DPGO/DPGO_types.h:44-86)
+class ROptParameters {
+ public:
+  enum class ROptMethod { RTR, RGD };
+  ROptMethod method = ROptMethod::RTR;
+  bool verbose = false;
+  double gradnorm_tol = 1e-2;
+  double RGD_stepsize = 1e-3;
+  bool RGD_use_preconditioner = true;
+  int RTR_iterations = 3;
+  int RTR_tCG_iterations = 50;
+  double RTR_initial_radius = 100;
+  dpgo_ropt_params to_c() const {
+    dpgo_ropt_params c;
+    dpgo_ropt_params_default(&c);
+    c.method = method == ROptMethod::RTR ? DPGO_METHOD_RTR : DPGO_METHOD_RGD;
+    c.verbose = verbose;
+    c.gradnorm_tol = gradnorm_tol;
+    c.RGD_stepsize = RGD_stepsize;
+    c.RGD_use_preconditioner = RGD_use_preconditioner;
+    c.RTR_iterations = RTR_iterations;
+    c.RTR_tCG_iterations = RTR_tCG_iterations;
+    c.RTR_initial_radius = RTR_initial_radius;
+    return c;
+  }
+};
+
+// DPGO::ROPTResult (include/DPGO/DPGO_types.h:91-107); tCGStatus is the DPGO_TCG_* code.
+struct ROPTResult {
+  ROPTResult(bool suc = false, double f0 = 0, double gn0 = 0, double fStar = 0, double gnStar = 0, double ms = 0)
+      : success(suc), fInit(f0), gradNormInit(gn0), fOpt(fStar), gradNormOpt(gnStar), elapsedMs(ms) {}
+  bool success;
+  double fInit, gradNormInit, fOpt, gradNormOpt, elapsedMs;
+  int tCGStatus = DPGO_TCG_MAXITER;
+  int tcgIterations = 0, rtrIterations = 0;
+};
+
+// Data-matrix part of DPGO::PoseGraph: measurements -> Q (block-CSR), G (dense), with the reference's
+// invalidation rules (src/PoseGraph.cpp:183-186, 345-379).
+class PoseGraph {
+ public:
+  using PoseID = std::pair<unsigned, unsigned>;  // (robot, frame); DPGO::PoseID, DPGO_types.h:110-120
+  PoseGraph(unsigned id, unsigned r, unsigned d) : id_(id), r_(r), d_(d) {
+    if (r < d) throw Error(DPGO_ERR_INVALID, "CHECK(r >= d) failed");  // src/PoseGraph.cpp:19
+  }
+  unsigned id() const { return id_; }
+  unsigned r() const { return r_; }
+  unsigned d() const { return d_; }
+  unsigned n() const { return n_; }
+
+  void setMeasurements(const std::vector<RelativeSEMeasurement>& ms) {  // src/PoseGraph.cpp:61-66
+    meas_.clear();
+    n_ = 0;
+    std::map<std::pair<PoseID, PoseID>, bool> seen;
+    for (const auto& m : ms) {
+      if (m.r1 != id_ && m.r2 != id_) continue;  // irrelevant edge (:68-71)
+      auto key = std::make_pair(PoseID(m.r1, m.p1), PoseID(m.r2, m.p2));
+      if (seen.count(key)) continue;  // duplicate (:83-88)
+      seen[key] = true;
+      meas_.push_back(m);
+      if (m.r1 == id_) n_ = std::max<unsigned>(n_, (unsigned)m.p1 + 1);
+      if (m.r2 == id_) n_ = std::max<unsigned>(n_, (unsigned)m.p2 + 1);
+    }
+    neighbor_poses_.clear();
+    priors_.clear();
+    clearDataMatrices();
+  }
+  void setPrior(unsigned index, const Matrix& Xi) {  // :176-181
+    if (index >= n_ || Xi.rows() != r_ || Xi.cols() != d_ + 1) throw Error(DPGO_ERR_INVALID, "bad prior");
+    priors_[index] = Xi;
+    clearDataMatrices();
+  }
+  void setNeighborPoses(const std::map<PoseID, Matrix>& pose_dict) {  // :183-186 (resets G only)
+    neighbor_poses_ = pose_dict;
+    has_G_ = false;
+  }
+  void clearDataMatrices() {  // :376-379
+    has_Q_ = has_G_ = false;
+    ++q_version_;
+  }
+  unsigned long qVersion() const { return q_version_; }
+  bool hasLinearTerm() const {
+    if (!priors_.empty()) return true;
+    for (const auto& m : meas_)
+      if (m.r1 != m.r2) return true;
+    return false;
+  }
+
+  struct Bsr {
+    std::vector<int32_t> rowptr, colidx;
+    std::vector<double> vals;
+  };
+  // PoseGraph::quadraticMatrix (:345-350) as block-CSR, built by dpgo_build_Q_bsr (constructQ :381-491)
+  const Bsr& quadraticMatrix() {
+    if (!has_Q_) {
+      Soa s = soa();
+      std::vector<int32_t> pidx;
+      for (const auto& kv : priors_) pidx.push_back((int32_t)kv.first);
+      int nnzb = 0;
+      check(dpgo_build_Q_bsr((int)id_, (int)d_, (int)n_, (int)meas_.size(), s.r1.data(), s.p1.data(), s.r2.data(),
+                             s.p2.data(), s.R.data(), s.t.data(), s.kappa.data(), s.tau.data(), s.w.data(),
+                             (int)pidx.size(), pidx.data(), 10000.0, 100.0, &nnzb, nullptr, nullptr, nullptr));
+      const unsigned b = d_ + 1;
+      Q_.rowptr.assign(n_ + 1, 0);
+      Q_.colidx.assign(nnzb, 0);
+      Q_.vals.assign((size_t)nnzb * b * b, 0.0);
+      check(dpgo_build_Q_bsr((int)id_, (int)d_, (int)n_, (int)meas_.size(), s.r1.data(), s.p1.data(), s.r2.data(),
+                             s.p2.data(), s.R.data(), s.t.data(), s.kappa.data(), s.tau.data(), s.w.data(),
+                             (int)pidx.size(), pidx.data(), 10000.0, 100.0, &nnzb, Q_.rowptr.data(),
+                             Q_.colidx.data(), Q_.vals.data()));
+      has_Q_ = true;
+    }
+    return Q_;
+  }
+  // PoseGraph::linearMatrix (:359-364), constructG (:493-580); throws if an active neighbour pose is missing
+  const Matrix& linearMatrix() {
+    if (!has_G_) {
+      const unsigned b = d_ + 1;
+      G_ = Matrix(r_, (size_t)b * n_);
+      for (const auto& m : meas_) {
+        if (m.r1 == m.r2) continue;
+        const bool outgoing = m.r1 == id_;
+        const PoseID nid = outgoing ? PoseID(m.r2, m.p2) : PoseID(m.r1, m.p1);
+        auto it = neighbor_poses_.find(nid);
+        if (it == neighbor_poses_.end()) throw Error(DPGO_ERR_STATE, "Missing active neighbor pose");
+        const Matrix& Xn = it->second;  // r x (d+1)
+        double T[4][4] = {}, om[4];
+        for (unsigned p = 0; p < d_; ++p) {
+          for (unsigned q = 0; q < d_; ++q) T[p][q] = m.R(p, q);
+          T[p][d_] = m.t(p, 0);
+          om[p] = m.weight * m.kappa;
+        }
+        T[d_][d_] = 1.0;
+        om[d_] = m.weight * m.tau;
+        const size_t col0 = (size_t)(outgoing ? m.p1 : m.p2) * b;
+        for (unsigned c = 0; c < b; ++c)
+          for (unsigned k = 0; k < b; ++k) {
+            // outgoing: L = -Xj Om T^T (:533-537);  incoming: L = -Xi T Om (:558-562)
+            const double coef = outgoing ? -om[k] * T[c][k] : -T[k][c] * om[c];
+            if (coef == 0.0) continue;
+            for (unsigned a = 0; a < r_; ++a) G_(a, col0 + c) += Xn(a, k) * coef;
+          }
+      }
+      for (const auto& kv : priors_) {  // :565-574
+        for (unsigned c = 0; c < b; ++c)
+          for (unsigned a = 0; a < r_; ++a)
+            G_(a, (size_t)kv.first * b + c) -= kv.second(a, c) * (c < d_ ? 10000.0 : 100.0);
+      }
+      has_G_ = true;
+    }
+    return G_;
+  }
+
+ private:
+  struct Soa {
+    std::vector<int32_t> r1, p1, r2, p2;
+    std::vector<double> R, t, kappa, tau, w;
+  };
+  Soa soa() const {
+    Soa s;
+    for (const auto& m : meas_) {
+      s.r1.push_back((int32_t)m.r1);
+      s.p1.push_back((int32_t)m.p1);
+      s.r2.push_back((int32_t)m.r2);
+      s.p2.push_back((int32_t)m.p2);
+      for (unsigned p = 0; p < d_; ++p)
+        for (unsigned q = 0; q < d_; ++q) s.R.push_back(m.R(p, q));
+      for (unsigned p = 0; p < d_; ++p) s.t.push_back(m.t(p, 0));
+      s.kappa.push_back(m.kappa);
+      s.tau.push_back(m.tau);
+      s.w.push_back(m.weight);
+    }
+    return s;
+  }
+  unsigned id_, r_, d_, n_ = 0;
+  std::vector<RelativeSEMeasurement> meas_;
+  std::map<PoseID, Matrix> neighbor_poses_;
+  std::map<unsigned, Matrix> priors_;
+  Bsr Q_;
+  Matrix G_;
+  bool has_Q_ = false, has_G_ = false;
+  unsigned long q_version_ = 0;
+};
+
+// DPGO::QuadraticProblem: f(X) = 0.5 <Q, X^T X> + <X, G>.  Owns the device handle; unlike the reference
+// (which rebuilds the problem every iteration, src/PGOAgent.cpp:968) keep it alive next to the PoseGraph.
+class QuadraticProblem {
+ public:
+  explicit QuadraticProblem(const std::shared_ptr<PoseGraph>& pose_graph, int device = 0) : pose_graph_(pose_graph) {
+    check(dpgo_problem_create(&h_, (int)pose_graph_->r(), (int)pose_graph_->d(), (int)pose_graph_->n(), device));
+    refresh();
+  }
+  ~QuadraticProblem() { dpgo_problem_destroy(h_); }
+  QuadraticProblem(const QuadraticProblem&) = delete;
+  QuadraticProblem& operator=(const QuadraticProblem&) = delete;
+
+  unsigned num_poses() const { return pose_graph_->n(); }
+  unsigned dimension() const { return pose_graph_->d(); }
+  unsigned relaxation_rank() const { return pose_graph_->r(); }
+  dpgo_problem_t handle() const { return h_; }
+
+  void refresh() {  // lazy-getter semantics of PoseGraph::quadraticMatrix / linearMatrix
+    if (q_version_ != pose_graph_->qVersion()) {
+      const auto& Q = pose_graph_->quadraticMatrix();
+      check(dpgo_problem_set_Q_bsr(h_, (int)Q.colidx.size(), Q.rowptr.data(), Q.colidx.data(), Q.vals.data()));
+      q_version_ = pose_graph_->qVersion();
+    }
+    if (pose_graph_->hasLinearTerm())
+      check(dpgo_problem_set_G(h_, pose_graph_->linearMatrix().data()));
+    else
+      check(dpgo_problem_set_G(h_, nullptr));
+  }
+  double f(const Matrix& Y) const {  // src/QuadraticProblem.cpp:29-35
+    shape(Y);
+    double out = 0;
+    check(dpgo_problem_f(h_, Y.data(), &out));
+    return out;
+  }
+  Matrix RieGrad(const Matrix& Y) const {  // :71-79
+    shape(Y);
+    Matrix out(Y.rows(), Y.cols());
+    check(dpgo_problem_rie_grad(h_, Y.data(), out.data()));
+    return out;
+  }
+  double RieGradNorm(const Matrix& Y) const {  // :81-83
+    shape(Y);
+    double out = 0;
+    check(dpgo_problem_rie_grad_norm(h_, Y.data(), &out));
+    return out;
+  }
+  // double*-based overloads of the ROPTLIB-typed virtuals (x->ObtainReadData() / ObtainWriteEntireData())
+  void EucGrad(const double* x, double* g) const { check(dpgo_problem_euc_grad(h_, x, g)); }            // :43-47
+  void EucHessianEta(const double*, const double* v, double* Hv) const { check(dpgo_problem_euc_hess(h_, v, Hv)); }  // :49-54
+  void PreConditioner(const double* x, const double* in, double* out) const {                            // :56-69
+    check(dpgo_problem_precondition(h_, DPGO_PRECOND_BLOCK_JACOBI, 1e-1, x, in, out));
+  }
+
+ private:
+  void shape(const Matrix& Y) const {  // CHECK_EQ (src/QuadraticProblem.cpp:30-31)
+    if (Y.rows() != relaxation_rank() || Y.cols() != (size_t)(dimension() + 1) * num_poses())
+      throw Error(DPGO_ERR_INVALID, "matrix shape mismatch");
+  }
+  std::shared_ptr<PoseGraph> pose_graph_;
+  dpgo_problem_t h_ = nullptr;
+  unsigned long q_version_ = (unsigned long)-1;
+};
+
+// DPGO::QuadraticOptimizer (src/QuadraticOptimizer.cpp)
+class QuadraticOptimizer {
+ public:
+  QuadraticOptimizer(QuadraticProblem* p, ROptParameters params = ROptParameters()) : problem_(p), params_(params) {
+    result_.success = false;
+  }
+  Matrix optimize(const Matrix& Y) {  // :26-48
+    Matrix out(Y.rows(), Y.cols());
+    dpgo_ropt_params c = params_.to_c();
+    dpgo_ropt_result res;
+    check(dpgo_optimize(problem_->handle(), &c, Y.data(), out.data(), &res));
+    result_ = ROPTResult(res.success != 0, res.fInit, res.gradNormInit, res.fOpt, res.gradNormOpt, res.elapsedMs);
+    result_.tCGStatus = res.tCGStatus;
+    result_.tcgIterations = res.tcg_iterations;
+    result_.rtrIterations = res.rtr_iterations;
+    return out;
+  }
+  void setProblem(QuadraticProblem* p) { problem_ = p; }
+  void setVerbose(bool v) { params_.verbose = v; }
+  void setAlgorithm(ROptParameters::ROptMethod alg) { params_.method = alg; }
+  void setRGDStepsize(double s) { params_.RGD_stepsize = s; }
+  void setRTRIterations(int iter) { params_.RTR_iterations = iter; }
+  void setGradientNormTolerance(double tol) { params_.gradnorm_tol = tol; }
+  void setRTRInitialRadius(double radius) { params_.RTR_initial_radius = radius; }
+  void setRTRtCGIterations(int iter) { params_.RTR_tCG_iterations = iter; }
+  ROPTResult getOptResult() const { return result_; }
+
+ private:
+  QuadraticProblem* problem_;
+  ROptParameters params_;
+  ROPTResult result_;
+};
+
+// DPGO::LiftedSEManifold (include/DPGO/manifold/LiftedSEManifold.h:28-43)
+class LiftedSEManifold {
+ public:
+  LiftedSEManifold(unsigned r, unsigned d, unsigned n, int device = 0) : r_(r), d_(d), n_(n), device_(device) {}
+  Matrix project(const Matrix& M) const {  // src/manifold/LiftedSEManifold.cpp:34-45
+    if (M.rows() != r_ || M.cols() != (size_t)(d_ + 1) * n_) throw Error(DPGO_ERR_INVALID, "matrix shape mismatch");
+    Matrix out(M.rows(), M.cols());
+    check(dpgo_manifold_project((int)r_, (int)d_, (int)n_, M.data(), out.data(), device_));
+    return out;
+  }
+  Matrix Projection(const Matrix& X, const Matrix& V) const {  // ROPTLIB ProductManifold::Projection
+    Matrix out(X.rows(), X.cols());
+    check(dpgo_manifold_tangent_project((int)r_, (int)d_, (int)n_, X.data(), V.data(), out.data(), device_));
+    return out;
+  }
+  Matrix Retraction(const Matrix& X, const Matrix& eta, double scale = 1.0) const {  // ProductManifold::Retraction
+    Matrix out(X.rows(), X.cols());
+    check(dpgo_manifold_retract((int)r_, (int)d_, (int)n_, X.data(), eta.data(), scale, out.data(), device_));
+    return out;
+  }
+
+ private:
+  unsigned r_, d_, n_;
+  int device_;
+};
+
+}  // namespace dpgo_hip

@@ -841,3 +841,54 @@ def perturbed_truth(Ttrue, seed: int = 2, sigma_t: float = 0.1, sigma_r: float =
     T[:, :3, :] = np.swapaxes(R, 1, 2)
     T[:, 3, :] += sigma_t * rng.standard_normal((n, 3))
     return T
+
+
+# --------------------------------------------------------------------------
+# Multi-agent RBCD driver (checker for dpgo_amd/agent.py)
+# --------------------------------------------------------------------------
+
+
+def rbcd_coloured(meas: Measurements, n: int, num_robots: int, r: int, X0, sweeps: int,
+                  params: Optional[ROptParameters] = None, precond: str = "jacobi", hess_recurrence: bool = False):
+    """Two-colour (greedy-coloured) parallel RBCD of SURVEY 8e on the contiguous partition of
+    examples/MultiRobotExample.cpp:71-119: in every sweep each colour class updates once; an agent's
+    update is PGOAgent::updateX (src/PGOAgent.cpp:938-995): G from the neighbours' current public poses
+    (constructG), then QuadraticOptimizer::optimize from its current block.  Agents of one colour are not
+    adjacent, so updating them one after the other equals updating them simultaneously.
+    Returns (X, [central 2f after each sweep], [central gradnorm after each sweep])."""
+    d = meas.d
+    ranges, per = partition_contiguous(meas, n, num_robots)
+    agents = []
+    for a in range(num_robots):
+        s, e = ranges[a]
+        priv = Measurements.concat([per[a]["odometry"], per[a]["private"]])
+        Qa = construct_Q(e - s, d, priv, per[a]["shared"], my_id=a)
+        sh = per[a]["shared"]
+        need = set()
+        for k in range(sh.m):
+            need.add((int(sh.r2[k]), int(sh.p2[k])) if sh.r1[k] == a else (int(sh.r1[k]), int(sh.p1[k])))
+        agents.append(dict(Q=Qa, shared=sh, need=sorted(need), adj=sorted({rob for rob, _ in need})))
+    colour = [-1] * num_robots
+    for a in range(num_robots):
+        used = {colour[q] for q in agents[a]["adj"] if colour[q] >= 0}
+        c = 0
+        while c in used:
+            c += 1
+        colour[a] = c
+    central = QuadraticProblem(construct_Q(n, d, meas), None, r, d)
+    X = X0.copy()
+    costs, gns = [], []
+    for _ in range(sweeps):
+        for c in range(max(colour) + 1):
+            for a in range(num_robots):
+                if colour[a] != c:
+                    continue
+                s, e = ranges[a]
+                nbr = {(rob, fr): X[ranges[rob][0] + fr] for rob, fr in agents[a]["need"]}
+                G = construct_G(e - s, d, r, agents[a]["shared"], a, nbr)
+                prob = QuadraticProblem(agents[a]["Q"], G, r, d, precond=precond)
+                opt = QuadraticOptimizer(prob, params or ROptParameters(), hess_recurrence=hess_recurrence)
+                X[s:e] = opt.optimize(X[s:e])
+        costs.append(2 * central.f(X))
+        gns.append(central.rie_grad_norm(X))
+    return X, costs, gns

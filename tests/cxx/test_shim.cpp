@@ -1,0 +1,208 @@
+// Reference known-answer tests re-stated against the C++ mirror (include/dpgo_hip.hpp):
+//   tests/testTriangleGraph.cpp:57   (noise-free triangle; 1e-4)
+//   tests/testPGO.cpp:131-190        (testPrior; 1e-6)
+//   tests/testUtils.cpp:40-54        (LiftedSEManifold::project; 1e-5)
+// plus the CSR hand-over (dpgo_problem_set_Q_csr) a reference-side PoseGraph would use.
+// Exit code 0 = pass, 77 = no HIP device (the library has no CPU fallback), 1 = failure.
+#include <cstdio>
+#include <cstdlib>
+
+#include "dpgo_hip.hpp"
+
+using namespace dpgo_hip;
+
+static Matrix mul(const Matrix& A, const Matrix& B) {
+  Matrix C(A.rows(), B.cols());
+  for (size_t i = 0; i < A.rows(); ++i)
+    for (size_t j = 0; j < B.cols(); ++j) {
+      double s = 0;
+      for (size_t k = 0; k < A.cols(); ++k) s += A(i, k) * B(k, j);
+      C(i, j) = s;
+    }
+  return C;
+}
+static Matrix transpose(const Matrix& A) {
+  Matrix C(A.cols(), A.rows());
+  for (size_t i = 0; i < A.rows(); ++i)
+    for (size_t j = 0; j < A.cols(); ++j) C(j, i) = A(i, j);
+  return C;
+}
+static Matrix se3(const double (&v)[12]) {  // row-major 3x4 literal -> 4x4
+  Matrix T = Matrix::Identity(4, 4);
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 4; ++j) T(i, j) = v[i * 4 + j];
+  return T;
+}
+static Matrix se3_inv(const Matrix& T) {
+  Matrix R = T.block(0, 0, 3, 3), t = T.block(0, 3, 3, 1);
+  Matrix Ti = Matrix::Identity(4, 4);
+  Ti.setBlock(0, 0, transpose(R));
+  Matrix mt = mul(transpose(R), t);
+  for (int i = 0; i < 3; ++i) Ti(i, 3) = -mt(i, 0);
+  return Ti;
+}
+static RelativeSEMeasurement between(size_t i, size_t j, const Matrix& Ti, const Matrix& Tj) {
+  Matrix dT = mul(se3_inv(Ti), Tj);
+  return RelativeSEMeasurement(0, 0, i, j, dT.block(0, 0, 3, 3), dT.block(0, 3, 3, 1), 1.0, 1.0);
+}
+#define REQUIRE(cond)                                              \
+  do {                                                             \
+    if (!(cond)) {                                                 \
+      std::printf("FAILED %s:%d: %s\n", __FILE__, __LINE__, #cond); \
+      return 1;                                                    \
+    }                                                              \
+  } while (0)
+
+static int run() {
+  const unsigned d = 3, r = 3;
+  // ---------------- triangle graph (testTriangleGraph.cpp:16-57)
+  const double w1[12] = {0.1436, 0.7406, 0.6564, 1, -0.8179, -0.2845, 0.5000, 1, 0.5571, -0.6087, 0.5649, 1};
+  const double w2[12] = {-0.4069, -0.4150, -0.8138, 2, 0.4049, 0.7166, -0.5679, 2, 0.8188, -0.5606, -0.1236, 2};
+  Matrix Tw0 = Matrix::Identity(4, 4), Tw1 = se3(w1), Tw2 = se3(w2);
+  std::vector<RelativeSEMeasurement> ms = {between(0, 1, Tw0, Tw1), between(1, 2, Tw1, Tw2), between(0, 2, Tw0, Tw2)};
+  auto pg = std::make_shared<PoseGraph>(0, r, d);
+  pg->setMeasurements(ms);
+  REQUIRE(pg->n() == 3);
+  QuadraticProblem problem(pg);
+  // odometryInitialization (src/DPGO_solver.cpp:271-303)
+  Matrix T0(d, 3 * (d + 1));
+  Matrix cur = Matrix::Identity(4, 4);
+  for (int i = 0; i < 3; ++i) {
+    if (i > 0) {
+      Matrix dT = Matrix::Identity(4, 4);
+      dT.setBlock(0, 0, ms[i - 1].R);
+      dT.setBlock(0, 3, ms[i - 1].t);
+      cur = mul(cur, dT);
+    }
+    T0.setBlock(0, i * 4, cur.block(0, 0, 3, 4));
+  }
+  QuadraticOptimizer optimizer(&problem);
+  Matrix Topt = optimizer.optimize(T0);
+  REQUIRE(optimizer.getOptResult().success);
+  // trajectory in the frame of pose 0 vs Ttrue
+  Matrix R0t = transpose(Topt.block(0, 0, 3, 3));
+  double err2 = 0;
+  const Matrix* Tw[3] = {&Tw0, &Tw1, &Tw2};
+  for (int i = 0; i < 3; ++i) {
+    Matrix Ri = mul(R0t, Topt.block(0, i * 4, 3, 3));
+    Matrix dt(3, 1);
+    for (int k = 0; k < 3; ++k) dt(k, 0) = Topt(k, i * 4 + 3) - Topt(k, 3);
+    Matrix ti = mul(R0t, dt);
+    for (int a = 0; a < 3; ++a) {
+      for (int b = 0; b < 3; ++b) err2 += std::pow(Ri(a, b) - (*Tw[i])(a, b), 2);
+      err2 += std::pow(ti(a, 0) - (*Tw[i])(a, 3), 2);
+    }
+  }
+  std::printf("triangle: |Ttrue - T| = %.3e, f %.3e -> %.3e\n", std::sqrt(err2), optimizer.getOptResult().fInit,
+              optimizer.getOptResult().fOpt);
+  REQUIRE(std::sqrt(err2) <= 1e-4);
+
+  // ---------------- CSR hand-over: scalar CSR of Q with the structural zeros dropped
+  {
+    const auto& Q = pg->quadraticMatrix();
+    const int b = d + 1, n = 3;
+    std::vector<int32_t> outer(n * b + 1, 0), inner;
+    std::vector<double> vals;
+    for (int i = 0; i < n; ++i)
+      for (int rr = 0; rr < b; ++rr) {
+        for (int t = Q.rowptr[i]; t < Q.rowptr[i + 1]; ++t)
+          for (int cc = 0; cc < b; ++cc) {
+            const double v = Q.vals[(size_t)t * b * b + rr * b + cc];
+            if (v != 0.0) {
+              inner.push_back(Q.colidx[t] * b + cc);
+              vals.push_back(v);
+            }
+          }
+        outer[i * b + rr + 1] = (int32_t)inner.size();
+      }
+    const double f_bsr = problem.f(T0);
+    check(dpgo_problem_set_Q_csr(problem.handle(), outer.data(), inner.data(), vals.data()));
+    const double f_csr = problem.f(T0);
+    std::printf("csr hand-over: f %.15g vs %.15g\n", f_csr, f_bsr);
+    REQUIRE(std::fabs(f_csr - f_bsr) <= 1e-13 * std::fabs(f_bsr) + 1e-15);
+  }
+
+  // ---------------- prior (testPGO.cpp:131-190)
+  {
+    RelativeSEMeasurement m(0, 0, 0, 1, Matrix::Identity(3, 3), Matrix::Zero(3, 1), 10000, 100);
+    m.fixedWeight = true;
+    auto pg2 = std::make_shared<PoseGraph>(0, 3, 3);
+    pg2->setMeasurements({m});
+    // prior rotation: the literal of testPGO.cpp:158-160 projected to SO(3) -- use the C ABI's polar projection
+    Matrix lit(3, 4);
+    const double pr[9] = {0.7236, 0.1817, 0.6658, -0.6100, 0.6198, 0.4938, -0.3230, -0.7634, 0.5594};
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 3; ++j) lit(i, j) = pr[i * 3 + j];
+    Matrix prior = LiftedSEManifold(3, 3, 1).project(lit);  // det > 0 for this literal: polar factor = SO(3) projection
+    pg2->setPrior(1, prior);
+    QuadraticProblem prob2(pg2);
+    ROptParameters params;
+    params.RTR_iterations = 50;
+    params.RTR_tCG_iterations = 500;
+    params.gradnorm_tol = 1e-5;
+    QuadraticOptimizer opt2(&prob2, params);
+    Matrix T = Matrix::Zero(3, 8);
+    T.setBlock(0, 0, Matrix::Identity(3, 3));
+    T.setBlock(0, 4, Matrix::Identity(3, 3));
+    Matrix Tq = opt2.optimize(T);
+    double e0 = 0, e1 = 0;
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 4; ++j) {
+        e0 += std::pow(Tq(i, j) - prior(i, j), 2);
+        e1 += std::pow(Tq(i, 4 + j) - prior(i, j), 2);
+      }
+    std::printf("prior: errors %.3e %.3e\n", std::sqrt(e0), std::sqrt(e1));
+    REQUIRE(std::sqrt(e0) < 1e-6 && std::sqrt(e1) < 1e-6);
+  }
+
+  // ---------------- LiftedSEManifold::project (testUtils.cpp:40-54)
+  {
+    const int dd = 3, rr = 5, nn = 100;
+    Matrix M(rr, (dd + 1) * nn);
+    unsigned s = 12345;
+    for (size_t k = 0; k < M.rows() * M.cols(); ++k) {
+      s = s * 1664525u + 1013904223u;
+      M.data()[k] = (double)(s >> 8) / (1u << 23) - 1.0;
+    }
+    Matrix X = LiftedSEManifold(rr, dd, nn).project(M);
+    for (int i = 0; i < nn; ++i) {
+      Matrix Y = X.block(0, i * (dd + 1), rr, dd);
+      Matrix D = mul(transpose(Y), Y);
+      for (int a = 0; a < dd; ++a) D(a, a) -= 1.0;
+      REQUIRE(D.norm() <= 1e-5);
+    }
+    std::printf("project: ok\n");
+  }
+  // ---------------- error behaviour: shape mismatch is reported, not aborted
+  try {
+    problem.f(Matrix(2, 5));
+    REQUIRE(false);
+  } catch (const Error& e) {
+    REQUIRE(e.code == DPGO_ERR_INVALID);
+  }
+  return 0;
+}
+
+int main() {
+  int count = 0;
+  if (dpgo_device_count(&count) != DPGO_OK || count < 1) {
+    // still exercise the failure path: creation must fail with DPGO_ERR_HIP, never fall back
+    try {
+      auto pg = std::make_shared<PoseGraph>(0, 3, 3);
+      Matrix I3 = Matrix::Identity(3, 3), z = Matrix::Zero(3, 1);
+      pg->setMeasurements({RelativeSEMeasurement(0, 0, 0, 1, I3, z, 1, 1)});
+      QuadraticProblem p(pg);
+      std::printf("unexpected: problem created without a device\n");
+      return 1;
+    } catch (const Error& e) {
+      std::printf("no HIP device: %s\n", e.what());
+      return e.code == DPGO_ERR_HIP ? 77 : 1;
+    }
+  }
+  try {
+    return run();
+  } catch (const std::exception& e) {
+    std::printf("exception: %s\n", e.what());
+    return 1;
+  }
+}

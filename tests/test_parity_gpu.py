@@ -315,3 +315,34 @@ def test_spmm_properties_at_full_size(oracle):
     Qs = oracle.BSR(n, d + 1, rp, ci, v).to_scipy().tocsr()
     ref = (Qs @ X.cpu().numpy().reshape(n * (d + 1), r)).reshape(n, d + 1, r)
     assert relerr(XQ.cpu().numpy(), ref) < 1e-13
+
+
+@pytest.mark.parametrize("name,robots,sweeps", [("smallGrid3D", 5, 4), ("torus3D", 8, 2)])
+def test_multi_agent_rbcd_on_one_gpu_matches_oracle(oracle, name, robots, sweeps):
+    """BASELINE configs[0] / configs[2] shape: N agents (one PGOAgent each in the reference's
+    MultiRobotExample), here N DeviceAgents on one GPU exchanging public poses by device copies;
+    coloured RBCD sweeps vs the oracle driver at matched settings (same preconditioner, same recurrence)."""
+    import dpgo_amd
+    from dpgo_amd.agent import DeviceAgent, ExchangePlan, RBCDCluster, build_pose_graphs
+    r = 5
+    om, n = oracle.read_g2o(os.path.join(DATA, name + ".g2o"))
+    d = om.d
+    X0 = oracle.lift(oracle.chordal_initialization(om, n), r)
+    Xref, costs, gns = oracle.rbcd_coloured(om, n, robots, r, X0, sweeps, hess_recurrence=True)
+    ranges, graphs = build_pose_graphs(to_product_measurements(om), n, robots, r)
+    plan = ExchangePlan(graphs)
+    agents = {a: DeviceAgent(graphs, plan, a, X0[ranges[a][0]:ranges[a][1]], dpgo_amd.ROptParameters())
+              for a in range(robots)}
+    cluster = RBCDCluster(plan, agents)
+    central = oracle.QuadraticProblem(oracle.construct_Q(n, d, om), None, r, d)
+    f0, g0 = cluster.central_cost_and_gradnorm()
+    assert abs(2 * f0 - 2 * central.f(X0)) <= 1e-10 * abs(2 * central.f(X0))
+    assert abs(g0 - central.rie_grad_norm(X0)) <= 1e-9 * g0
+    for k in range(sweeps):
+        cluster.sweep()
+        f, g = cluster.central_cost_and_gradnorm()
+        assert abs(2 * f - costs[k]) <= 1e-9 * abs(costs[k])
+        assert abs(g - gns[k]) <= 1e-6 * gns[k]
+    X = np.concatenate([agents[a].X.cpu().numpy() for a in range(robots)], axis=0)
+    assert relerr(X, Xref) < 1e-7
+    assert costs[-1] < costs[0]
