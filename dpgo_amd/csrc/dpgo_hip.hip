@@ -10,6 +10,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <utility>
@@ -68,6 +69,17 @@ bool supported(int d, int r) {
       return fail(DPGO_ERR_UNSUPPORTED, "unsupported (d, r)");                                      \
   }
 
+// launch a <D, R, SPLIT> kernel with the handle's split factor
+#define LAUNCH_SPLIT(p, KERNEL, GRID, ...)                                                            \
+  do {                                                                                                \
+    if ((p)->split == 4)                                                                              \
+      hipLaunchKernelGGL((KERNEL<D, R, 4>), dim3(GRID), dim3(kBlock), 0, (p)->stream, __VA_ARGS__);   \
+    else if ((p)->split == 2)                                                                         \
+      hipLaunchKernelGGL((KERNEL<D, R, 2>), dim3(GRID), dim3(kBlock), 0, (p)->stream, __VA_ARGS__);   \
+    else                                                                                              \
+      hipLaunchKernelGGL((KERNEL<D, R, 1>), dim3(GRID), dim3(kBlock), 0, (p)->stream, __VA_ARGS__);   \
+  } while (0)
+
 struct Bsr {
   int nrows = 0, ncols = 0, nnzb = 0;
   int32_t* rowptr = nullptr;
@@ -115,6 +127,13 @@ struct dpgo_problem_s {
   double* pH() const { return partials + 3 * kMaxGrid * kNP; }
   int grid() const {
     const int P = (64 / b) * kWaves;
+    int tiles = (n + P - 1) / P;
+    if (tiles < 1) tiles = 1;
+    return tiles < kMaxGrid ? tiles : kMaxGrid;
+  }
+  int split = 1;  // lane groups per pose in the SpMM kernels (latency layout for small blocks)
+  int grid_s() const {  // SpMM kernels (k_spmm, k_grad, k_hess, k_tcg_hess)
+    const int P = (64 / (b * split)) * kWaves;
     int tiles = (n + P - 1) / P;
     if (tiles < 1) tiles = 1;
     return tiles < kMaxGrid ? tiles : kMaxGrid;
@@ -195,8 +214,7 @@ int push_state(dpgo_problem_s* p) {
 
 // ---- kernel launch helpers (templated on D, R through DISPATCH) ----
 int launch_spmm(dpgo_problem_s* p, const Bsr& M, const double* V, const double* Gadd, double* OUT) {
-  DISPATCH(p->d, p->r, hipLaunchKernelGGL((k_spmm<D, R>), dim3(p->grid()), dim3(kBlock), 0, p->stream, M.dev(),
-                                          V, Gadd, OUT, p->n));
+  DISPATCH(p->d, p->r, LAUNCH_SPLIT(p, k_spmm, p->grid_s(), M.dev(), V, Gadd, OUT, p->n));
   HIPC(hipGetLastError());
   return DPGO_OK;
 }
@@ -204,16 +222,15 @@ int launch_spmm(dpgo_problem_s* p, const Bsr& M, const double* V, const double* 
 int launch_grad(dpgo_problem_s* p, const double* X, double* RG, double* S, double* EG,
                 const DevState* st = nullptr) {
   const double* Gm = p->has_G ? p->G : nullptr;
-  DISPATCH(p->d, p->r, hipLaunchKernelGGL((k_grad<D, R>), dim3(p->grid()), dim3(kBlock), 0, p->stream,
-                                          p->Q.dev(), X, Gm, RG, S, EG, p->pE(), st, p->n));
+  DISPATCH(p->d, p->r, LAUNCH_SPLIT(p, k_grad, p->grid_s(), p->Q.dev(), X, Gm, RG, S, EG, p->pE(), st, p->n));
   HIPC(hipGetLastError());
   return DPGO_OK;
 }
 
 int launch_hess(dpgo_problem_s* p, const double* X, const double* S, const double* V, const double* Gdot,
                 double* HV, double* partials, const DevState* st, int check_tcg) {
-  DISPATCH(p->d, p->r, hipLaunchKernelGGL((k_hess<D, R>), dim3(p->grid()), dim3(kBlock), 0, p->stream,
-                                          p->Q.dev(), X, S, V, Gdot, HV, partials, st, check_tcg, p->n));
+  DISPATCH(p->d, p->r,
+           LAUNCH_SPLIT(p, k_hess, p->grid_s(), p->Q.dev(), X, S, V, Gdot, HV, partials, st, check_tcg, p->n));
   HIPC(hipGetLastError());
   return DPGO_OK;
 }
@@ -222,7 +239,7 @@ int launch_tcg_update(dpgo_problem_s* p, const double* dinv, int first) {
   const int g = p->grid();
   DISPATCH(p->d, p->r,
            hipLaunchKernelGGL((k_tcg_update<D, R>), dim3(g), dim3(kBlock), 0, p->stream, p->x1, p->g1, dinv,
-                              p->delta, p->Hd, p->eta, p->rr, p->z, p->pA(), g, p->pB(), p->dstate + p->cur,
+                              p->delta, p->Hd, p->eta, p->rr, p->z, p->pA(), p->grid_s(), p->pB(), p->dstate + p->cur,
                               p->dstate + (p->cur ^ 1), first, p->n, p->hflag, p->gen));
   HIPC(hipGetLastError());
   p->cur ^= 1;
@@ -231,20 +248,9 @@ int launch_tcg_update(dpgo_problem_s* p, const double* dinv, int first) {
 
 // fused direction update + Riemannian Hessian-vector product (one tCG step)
 int launch_tcg_hess(dpgo_problem_s* p, int first) {
-  const int g = p->grid();
   DISPATCH(p->d, p->r,
-           hipLaunchKernelGGL((k_tcg_hess<D, R>), dim3(g), dim3(kBlock), 0, p->stream, p->Q.dev(), p->x1, p->S1,
-                              p->z, p->delta, p->Hd, p->pB(), g, p->pA(), p->dstate + p->cur,
-                              p->dstate + (p->cur ^ 1), first, p->n, p->hflag, p->gen));
-  HIPC(hipGetLastError());
-  p->cur ^= 1;
-  return DPGO_OK;
-}
-
-int launch_tcg_dir(dpgo_problem_s* p, int first) {
-  DISPATCH(p->d, p->r,
-           hipLaunchKernelGGL((k_tcg_dir<D, R>), dim3(p->grid_flat()), dim3(kBlock), 0, p->stream, p->z, p->delta,
-                              p->pB(), p->grid(), p->dstate + p->cur, p->dstate + (p->cur ^ 1), first, p->n));
+           LAUNCH_SPLIT(p, k_tcg_hess, p->grid_s(), p->Q.dev(), p->x1, p->S1, p->z, p->delta, p->Hd, p->pB(), p->grid(),
+                        p->pA(), p->dstate + p->cur, p->dstate + (p->cur ^ 1), first, p->n, p->hflag, p->gen));
   HIPC(hipGetLastError());
   p->cur ^= 1;
   return DPGO_OK;
@@ -259,7 +265,7 @@ int launch_retract(dpgo_problem_s* p, const double* X, const double* eta, double
 }
 
 int launch_rtr_update(dpgo_problem_s* p) {
-  const int g = p->grid();
+  const int g = p->grid_s();
   DISPATCH(p->d, p->r,
            hipLaunchKernelGGL((k_rtr_update<D, R>), dim3(p->grid_flat()), dim3(kBlock), 0, p->stream, p->x1, p->x2,
                               p->g1, p->g2, p->S1, p->S2, p->pE(), g, p->pH(), g, p->dstate + p->cur,
@@ -277,7 +283,7 @@ int launch_precond(dpgo_problem_s* p, const double* X, const double* V, const do
 }
 
 int launch_rtr_begin(dpgo_problem_s* p, double tol, double Delta0, double Dmax, int max_inner, int tiny) {
-  hipLaunchKernelGGL(k_rtr_begin, dim3(1), dim3(kBlock), 0, p->stream, p->pE(), p->grid(), p->dstate, tol, Delta0,
+  hipLaunchKernelGGL(k_rtr_begin, dim3(1), dim3(kBlock), 0, p->stream, p->pE(), p->grid_s(), p->dstate, tol, Delta0,
                      Dmax, max_inner, tiny);
   HIPC(hipGetLastError());
   p->cur = 0;
@@ -518,6 +524,12 @@ int dpgo_problem_create(dpgo_problem_t* out, int r, int d, int n, int device) {
   p->b = d + 1;
   p->T = p->b * r;
   p->device = device;
+  // small blocks are latency-bound: spread each row over 4 lane groups
+  p->split = (n < 40000) ? 4 : 1;
+  if (const char* e = std::getenv("DPGO_SPLIT")) {
+    const int v = std::atoi(e);
+    if (v == 1 || v == 2 || v == 4) p->split = v;
+  }
   int rc = [&]() -> int {
     HIPC(hipSetDevice(device));
     HIPC(hipStreamCreateWithFlags(&p->own_stream, hipStreamNonBlocking));
@@ -851,12 +863,10 @@ int dpgo_bench_hess(dpgo_problem_t p, int reps, int warmup, double* avg_ms) {
   p->hstate->kappa = -1.0;  // convergence test can never fire
   p->hstate->max_inner = 1 << 30;
   CHK(push_state(p));
-  const int g = p->grid();
   auto launch = [&]() -> int {
     DISPATCH(p->d, p->r,
-             hipLaunchKernelGGL((k_tcg_hess<D, R>), dim3(g), dim3(kBlock), 0, p->stream, p->Q.dev(), p->x1, p->S1,
-                                p->z, p->delta, p->Hd, p->pB(), g, p->pA(), p->dstate, p->dstate + 1, 0, p->n,
-                                (unsigned long long*)nullptr, 0u));
+             LAUNCH_SPLIT(p, k_tcg_hess, p->grid_s(), p->Q.dev(), p->x1, p->S1, p->z, p->delta, p->Hd, p->pB(),
+                          p->grid(), p->pA(), p->dstate, p->dstate + 1, 0, p->n, (unsigned long long*)nullptr, 0u));
     HIPC(hipGetLastError());
     return DPGO_OK;
   };

@@ -56,26 +56,51 @@ __device__ __forceinline__ void publish_progress(unsigned long long* hflag, unsi
   }
 }
 
-template <int D, int R>
+// Field-wise state copies: copying the whole struct by value (read, modify, write back) is lowered through
+// scratch memory (120 B/lane measured with -Rpass-analysis=kernel-resource-usage), i.e. extra memory
+// round trips on the critical path of every solver kernel.  Field by field it is scalar loads into SGPRs.
+#define DPGO_STATE_FIELDS(X)                                                                              \
+  X(f1) X(ngf) X(Delta) X(Delta_max) X(tol) X(f2) X(rho) X(fInit) X(gnInit) X(xqx) X(xg) X(outer_iter)      \
+  X(rtr_stop) X(accepted_last) X(n_accept) X(accept_tiny) X(pad0) X(z_r) X(d_Pd) X(e_Pd) X(e_Pe) X(norm_r0) \
+  X(alpha) X(theta) X(kappa) X(tcg_j) X(tcg_done) X(tcg_status) X(max_inner) X(n_hess) X(min_inner)
+__device__ __forceinline__ void load_state(DevState& st, const DevState* __restrict__ p) {
+#define X(f) st.f = p->f;
+  DPGO_STATE_FIELDS(X)
+#undef X
+}
+__device__ __forceinline__ void store_state(DevState* __restrict__ p, const DevState& st) {
+#define X(f) p->f = st.f;
+  DPGO_STATE_FIELDS(X)
+#undef X
+}
+
+// SPLIT > 1 (SpMM kernels only): SPLIT lane groups share one pose and take every SPLIT-th block of its
+// row; the partial columns are summed with log2(SPLIT) shuffles.  It shortens the dependent
+// index -> tile load chain per wave (latency-bound regime: small agents / many GPUs); SPLIT = 1 is the
+// throughput layout used for big blocks.
+template <int D, int R, int SPLIT = 1>
 struct Geo {
   static constexpr int B = D + 1;
-  static constexpr int T = B * R;       // doubles per pose tile
-  static constexpr int BB = B * B;      // doubles per Q block
-  static constexpr int G = 64 / B;      // poses per wavefront
-  static constexpr int P = G * kWaves;  // poses per workgroup tile
+  static constexpr int T = B * R;         // doubles per pose tile
+  static constexpr int BB = B * B;        // doubles per Q block
+  static constexpr int LPP = B * SPLIT;   // lanes per pose
+  static constexpr int G = 64 / LPP;      // poses per wavefront
+  static constexpr int P = G * kWaves;    // poses per workgroup tile
 };
 
 struct LaneId {
-  int wave, g, c;
+  int wave, g, s, c;
 };
-template <int D>
+template <int D, int SPLIT = 1>
 __device__ __forceinline__ LaneId lane_id() {
-  constexpr int B = D + 1;
+  constexpr int B = D + 1, LPP = B * SPLIT;
   LaneId id;
   const int l = threadIdx.x & 63;
   id.wave = threadIdx.x >> 6;
-  id.g = l / B;
-  id.c = l - id.g * B;
+  id.g = l / LPP;
+  const int lp = l - id.g * LPP;
+  id.s = lp / B;
+  id.c = lp - id.s * B;
   return id;
 }
 
@@ -104,6 +129,28 @@ __device__ __forceinline__ TileIter tile_iter(int ntiles) {
   it.last = hi;
   it.step = nbx;
   return it;
+}
+
+// The pose tiles exchanged through LDS are private to one wavefront, so a wave-level barrier (plus a
+// wavefront-scope fence that orders the DS operations) replaces __syncthreads(): no cross-wave stall.
+// occupancy hints (waves per SIMD) for the two kernels of the tCG loop; A/B-tuned on MI355X
+#ifndef DPGO_LB_HESS
+#define DPGO_LB_HESS 1
+#endif
+#ifndef DPGO_LB_UPDATE
+#define DPGO_LB_UPDATE 1
+#endif
+#ifndef DPGO_WAVE_SYNC
+#define DPGO_WAVE_SYNC 1
+#endif
+__device__ __forceinline__ void wave_sync() {
+#if DPGO_WAVE_SYNC
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#else
+  __syncthreads();
+#endif
 }
 
 // ---------------------------------------------------------------- reductions
@@ -225,26 +272,31 @@ __device__ __forceinline__ void store_col(double* __restrict__ p, const double (
 // gather loop (the kernel is bound by that latency chain, not by HBM: tools/spmm_lab.hip, 27.2 -> 24.6 us
 // at 100k poses).  Each lane streams row c of the Q block (32 B for D = 3: the quad reads the 128-B
 // block exactly once, coalesced) and the full gathered tile V_j (160 B, L2-resident).
-template <int D, int R>
+template <int D, int R, int SPLIT>
 __device__ __forceinline__ void spmm_col(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colidx,
                                          const double* __restrict__ vals, const double* __restrict__ V,
-                                         int i, int c, bool ok, double (&acc)[R]) {
-  constexpr int B = D + 1, T = B * R, BB = B * B;
+                                         int i, int s, int c, bool ok, double (&acc)[R]) {
+  constexpr int B = D + 1, T = B * R, BB = B * B, LPP = B * SPLIT;
+  constexpr int NJ = (SPLIT == 1) ? 2 : 1;   // preloaded indices per lane
+  constexpr int NPRE = NJ * LPP;             // preloaded indices per pose (2B for SPLIT = 1)
 #pragma unroll
   for (int a = 0; a < R; ++a) acc[a] = 0.0;
   const int lane = threadIdx.x & 63;
-  const int gbase = lane - c;
+  const int lp = s * B + c;
+  const int gbase = lane - lp;
   const int t0 = ok ? rowptr[i] : 0, t1 = ok ? rowptr[i + 1] : 0;
   const int deg = t1 - t0;
-  const int ja = (c < deg) ? colidx[t0 + c] : 0;
-  const int jb = (c + B < deg) ? colidx[t0 + c + B] : 0;
+  const int ja = (lp < deg) ? colidx[t0 + lp] : 0;
+  const int jb = (NJ == 2 && lp + LPP < deg) ? colidx[t0 + lp + LPP] : 0;
   int maxdeg = deg;
 #pragma unroll
   for (int o = 32; o >= 1; o >>= 1) maxdeg = max(maxdeg, __shfl_xor(maxdeg, o));
-  const int lim = maxdeg < 2 * B ? maxdeg : 2 * B;
-  for (int k = 0; k < lim; ++k) {
-    const int j = __shfl((k < B) ? ja : jb, gbase + (k < B ? k : k - B));
-    if (k < deg) {
+  const int kmax = maxdeg < NPRE ? maxdeg : NPRE;
+  for (int k0 = 0; k0 < kmax; k0 += SPLIT) {
+    const int k = k0 + s;  // this slice's block
+    const int src = (k < LPP) ? k : k - LPP;
+    const int j = __shfl((NJ == 2 && k >= LPP) ? jb : ja, gbase + (src < LPP ? src : 0));
+    if (k < deg && k < NPRE) {
       const double* __restrict__ q = vals + (size_t)(t0 + k) * BB + c * B;
       const double* __restrict__ x = V + (size_t)j * T;
       double qk[B];
@@ -257,7 +309,7 @@ __device__ __forceinline__ void spmm_col(const int32_t* __restrict__ rowptr, con
       }
     }
   }
-  for (int t = t0 + 2 * B; t < t1; ++t) {  // rows with more than 2B blocks
+  for (int t = t0 + NPRE + s; t < t1; t += SPLIT) {  // rows with more than NPRE blocks
     const int j = colidx[t];
     const double* __restrict__ q = vals + (size_t)t * BB + c * B;
     const double* __restrict__ x = V + (size_t)j * T;
@@ -268,6 +320,13 @@ __device__ __forceinline__ void spmm_col(const int32_t* __restrict__ rowptr, con
     for (int kk = 0; kk < B; ++kk) {
 #pragma unroll
       for (int a = 0; a < R; ++a) acc[a] = fma(x[kk * R + a], qk[kk], acc[a]);
+    }
+  }
+  if (SPLIT > 1) {  // fixed-order tree over the slices; the sum lands in slice 0
+#pragma unroll
+    for (int o = SPLIT / 2; o >= 1; o >>= 1) {
+#pragma unroll
+      for (int a = 0; a < R; ++a) acc[a] += __shfl_down(acc[a], o * B);
     }
   }
 }
@@ -283,19 +342,20 @@ struct BsrDev {
 // OUT = V*Q (+ Gadd).  QuadraticProblem::EucGrad / EucHessianEta
 // (src/QuadraticProblem.cpp:43-54) and, with a rectangular coupling matrix, PoseGraph::constructG
 // (src/PoseGraph.cpp:493-580).
-template <int D, int R>
+template <int D, int R, int SPLIT>
 __global__ __launch_bounds__(kBlock) void k_spmm(BsrDev Q, const double* __restrict__ V,
                                                  const double* __restrict__ Gadd, double* __restrict__ OUT,
                                                  int n) {
-  using GEO = Geo<D, R>;
-  const LaneId L = lane_id<D>();
+  using GEO = Geo<D, R, SPLIT>;
+  const LaneId L = lane_id<D, SPLIT>();
   const int ntiles = (n + GEO::P - 1) / GEO::P;
   const TileIter ti_ = tile_iter(ntiles);
   for (int tile = ti_.first; tile < ti_.last; tile += ti_.step) {
     const int i = tile * GEO::P + L.wave * GEO::G + L.g;
-    const bool ok = (L.g < GEO::G) && (i < n);
+    const bool okp = (L.g < GEO::G) && (i < n);
+    const bool ok = okp && (L.s == 0);
     double acc[R];
-    spmm_col<D, R>(Q.rowptr, Q.colidx, Q.vals, V, i, L.c, ok, acc);
+    spmm_col<D, R, SPLIT>(Q.rowptr, Q.colidx, Q.vals, V, i, L.s, L.c, okp, acc);
     if (ok) {
       const size_t off = (size_t)i * GEO::T + L.c * R;
       if (Gadd) {
@@ -312,28 +372,29 @@ __global__ __launch_bounds__(kBlock) void k_spmm(BsrDev Q, const double* __restr
 // EG = XQ + G (:43-47), S = sym(Y^T EG_rot) (cached for the Hessian, ROPTLIB EucGradToGrad),
 // RG = proj_X(EG) (:71-79) and |RG|^2 (:81-83).
 // partials: [0] sum(XQ.X)  [1] sum(X.G)  [2] |RG|^2
-template <int D, int R>
+template <int D, int R, int SPLIT>
 __global__ __launch_bounds__(kBlock) void k_grad(BsrDev Q, const double* __restrict__ X,
                                                  const double* __restrict__ Gm, double* __restrict__ RG,
                                                  double* __restrict__ S, double* __restrict__ EGout,
                                                  double* __restrict__ partials, const DevState* __restrict__ st,
                                                  int n) {
-  using GEO = Geo<D, R>;
+  using GEO = Geo<D, R, SPLIT>;
   __shared__ double sm[kWaves][2][GEO::G][GEO::T];
   __shared__ double red[kWaves * kNP];
   if (st && st->rtr_stop) return;
-  const LaneId L = lane_id<D>();
+  const LaneId L = lane_id<D, SPLIT>();
   const int ntiles = (n + GEO::P - 1) / GEO::P;
   double part[3] = {0.0, 0.0, 0.0};
   const TileIter ti_ = tile_iter(ntiles);
   for (int tile = ti_.first; tile < ti_.last; tile += ti_.step) {
     const int i = tile * GEO::P + L.wave * GEO::G + L.g;
-    const bool ok = (L.g < GEO::G) && (i < n);
+    const bool okp = (L.g < GEO::G) && (i < n);
+    const bool ok = okp && (L.s == 0);
     double eg[R], x[R];
     const size_t off = (size_t)i * GEO::T + L.c * R;
     double* ys = ok ? &sm[L.wave][0][L.g][0] : nullptr;
     double* ws = ok ? &sm[L.wave][1][L.g][0] : nullptr;
-    spmm_col<D, R>(Q.rowptr, Q.colidx, Q.vals, X, i, L.c, ok, eg);
+    spmm_col<D, R, SPLIT>(Q.rowptr, Q.colidx, Q.vals, X, i, L.s, L.c, okp, eg);
     if (ok) {
       load_col<R>(X + off, x);
 #pragma unroll
@@ -349,7 +410,7 @@ __global__ __launch_bounds__(kBlock) void k_grad(BsrDev Q, const double* __restr
       store_col<R>(ys + L.c * R, x);
       store_col<R>(ws + L.c * R, eg);
     }
-    __syncthreads();
+    wave_sync();
     if (ok) {
       double out[R], s[D];
       proj_col<D, R>(ys, ws, L.c, eg, out, s);
@@ -362,7 +423,7 @@ __global__ __launch_bounds__(kBlock) void k_grad(BsrDev Q, const double* __restr
         for (int a = 0; a < D; ++a) S[(size_t)i * D * D + L.c * D + a] = s[a];
       }
     }
-    __syncthreads();
+    wave_sync();
   }
   store_partials<3>(part, partials, red);
 }
@@ -372,39 +433,40 @@ __global__ __launch_bounds__(kBlock) void k_grad(BsrDev Q, const double* __restr
 // src/QuadraticProblem.cpp:49-54, + ROPTLIB Stiefel::EucHvToHv + ProductManifold::Projection).
 // partials: [0] <V,HV>   [1] <V,Gdot> (if Gdot != null; used for the RTR model decrease)
 // When `st` is given the kernel is a tCG step and exits early once tCG has finished.
-template <int D, int R>
+template <int D, int R, int SPLIT>
 __global__ __launch_bounds__(kBlock) void k_hess(BsrDev Q, const double* __restrict__ X,
                                                  const double* __restrict__ S, const double* __restrict__ V,
                                                  const double* __restrict__ Gdot, double* __restrict__ HV,
                                                  double* __restrict__ partials, const DevState* __restrict__ st,
                                                  int check_tcg, int n) {
-  using GEO = Geo<D, R>;
+  using GEO = Geo<D, R, SPLIT>;
   __shared__ double sm[kWaves][3][GEO::G][GEO::T];
   __shared__ double red[kWaves * kNP];
   if (st) {
     if (st->rtr_stop) return;
     if (check_tcg && st->tcg_done) return;
   }
-  const LaneId L = lane_id<D>();
+  const LaneId L = lane_id<D, SPLIT>();
   const int ntiles = (n + GEO::P - 1) / GEO::P;
   double part[2] = {0.0, 0.0};
   const TileIter ti_ = tile_iter(ntiles);
   for (int tile = ti_.first; tile < ti_.last; tile += ti_.step) {
     const int i = tile * GEO::P + L.wave * GEO::G + L.g;
-    const bool ok = (L.g < GEO::G) && (i < n);
+    const bool okp = (L.g < GEO::G) && (i < n);
+    const bool ok = okp && (L.s == 0);
     double h[R], v[R], x[R];
     const size_t off = (size_t)i * GEO::T + L.c * R;
     double* ys = ok ? &sm[L.wave][0][L.g][0] : nullptr;
     double* vs = ok ? &sm[L.wave][1][L.g][0] : nullptr;
     double* hs = ok ? &sm[L.wave][2][L.g][0] : nullptr;
-    spmm_col<D, R>(Q.rowptr, Q.colidx, Q.vals, V, i, L.c, ok, h);
+    spmm_col<D, R, SPLIT>(Q.rowptr, Q.colidx, Q.vals, V, i, L.s, L.c, okp, h);
     if (ok) {
       load_col<R>(X + off, x);
       load_col<R>(V + off, v);
       store_col<R>(ys + L.c * R, x);
       store_col<R>(vs + L.c * R, v);
     }
-    __syncthreads();
+    wave_sync();
     if (ok) {
       if (L.c < D) {
         // h[:,c] -= sum_a V[:,a] * S[a][c]   (S symmetric: row c of S_i)
@@ -417,7 +479,7 @@ __global__ __launch_bounds__(kBlock) void k_hess(BsrDev Q, const double* __restr
       }
       store_col<R>(hs + L.c * R, h);
     }
-    __syncthreads();
+    wave_sync();
     if (ok) {
       double out[R], s[D];
       proj_col<D, R>(ys, hs, L.c, h, out, s);
@@ -429,7 +491,7 @@ __global__ __launch_bounds__(kBlock) void k_hess(BsrDev Q, const double* __restr
       }
       store_col<R>(HV + off, out);
     }
-    __syncthreads();
+    wave_sync();
   }
   store_partials<2>(part, partials, red);
 }
@@ -445,21 +507,22 @@ __global__ __launch_bounds__(kBlock) void k_hess(BsrDev Q, const double* __restr
 //        direction update ride in the SpMM epilogue instead of costing a second gather or a separate
 //        kernel: 3 -> 2 launches per tCG iteration), and the <delta, H delta> partial.
 // The oracle has the same option (hess_recurrence) for trajectory-level parity tests.
-template <int D, int R>
-__global__ __launch_bounds__(kBlock) void k_tcg_hess(BsrDev Q, const double* __restrict__ X,
+template <int D, int R, int SPLIT>
+__global__ __launch_bounds__(kBlock, DPGO_LB_HESS) void k_tcg_hess(BsrDev Q, const double* __restrict__ X,
                                                      const double* __restrict__ S, const double* __restrict__ z,
                                                      double* __restrict__ delta, double* __restrict__ Hd,
                                                      const double* __restrict__ pin, int nb_in,
                                                      double* __restrict__ pout, const DevState* __restrict__ sin,
                                                      DevState* __restrict__ sout, int first, int n,
                                                      unsigned long long* hflag, unsigned gen) {
-  using GEO = Geo<D, R>;
+  using GEO = Geo<D, R, SPLIT>;
   __shared__ double sm[kWaves][3][GEO::G][GEO::T];
   __shared__ double red[kWaves * kNP];
-  DevState st = *sin;
+  DevState st;
+  load_state(st, sin);
   if (st.rtr_stop || st.tcg_done) {
     if (blockIdx.x == 0 && threadIdx.x == 0) {
-      *sout = st;
+      store_state(sout, st);
       publish_progress(hflag, gen, st);
     }
     return;
@@ -499,45 +562,57 @@ __global__ __launch_bounds__(kBlock) void k_tcg_hess(BsrDev Q, const double* __r
     }
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) {
-    *sout = st;
+    store_state(sout, st);
     publish_progress(hflag, gen, st);
   }
   if (!go) return;
 
-  const LaneId L = lane_id<D>();
+  const LaneId L = lane_id<D, SPLIT>();
   const int ntiles = (n + GEO::P - 1) / GEO::P;
   double part[1] = {0.0};
   const TileIter ti_ = tile_iter(ntiles);
   for (int tile = ti_.first; tile < ti_.last; tile += ti_.step) {
     const int i = tile * GEO::P + L.wave * GEO::G + L.g;
-    const bool ok = (L.g < GEO::G) && (i < n);
+    const bool okp = (L.g < GEO::G) && (i < n);
+    const bool ok = okp && (L.s == 0);
     double h[R], zc[R], x[R];
     const size_t off = (size_t)i * GEO::T + L.c * R;
     double* ys = ok ? &sm[L.wave][0][L.g][0] : nullptr;
     double* vs = ok ? &sm[L.wave][1][L.g][0] : nullptr;
     double* hs = ok ? &sm[L.wave][2][L.g][0] : nullptr;
-    spmm_col<D, R>(Q.rowptr, Q.colidx, Q.vals, z, i, L.c, ok, h);
+    // issue the epilogue's loads first: they overlap the gather's index -> tile latency chain
+    double srow[D], dl[R], hd[R];
     if (ok) {
       load_col<R>(X + off, x);
       load_col<R>(z + off, zc);
+      if (L.c < D) {
+#pragma unroll
+        for (int a = 0; a < D; ++a) srow[a] = S[(size_t)i * D * D + L.c * D + a];
+      }
+      if (!first) {
+        load_col<R>(delta + off, dl);
+        load_col<R>(Hd + off, hd);
+      }
+    }
+    spmm_col<D, R, SPLIT>(Q.rowptr, Q.colidx, Q.vals, z, i, L.s, L.c, okp, h);
+    if (ok) {
       store_col<R>(ys + L.c * R, x);
       store_col<R>(vs + L.c * R, zc);
     }
-    __syncthreads();
+    wave_sync();
     if (ok) {
       if (L.c < D) {
 #pragma unroll
         for (int a = 0; a < D; ++a) {
-          const double sac = S[(size_t)i * D * D + L.c * D + a];
 #pragma unroll
-          for (int k = 0; k < R; ++k) h[k] = fma(-vs[a * R + k], sac, h[k]);
+          for (int k = 0; k < R; ++k) h[k] = fma(-vs[a * R + k], srow[a], h[k]);
         }
       }
       store_col<R>(hs + L.c * R, h);
     }
-    __syncthreads();
+    wave_sync();
     if (ok) {
-      double hz[R], s[D], dl[R], hd[R];
+      double hz[R], s[D];
       proj_col<D, R>(ys, hs, L.c, h, hz, s);
       if (first) {
 #pragma unroll
@@ -546,8 +621,6 @@ __global__ __launch_bounds__(kBlock) void k_tcg_hess(BsrDev Q, const double* __r
           hd[a] = -hz[a];
         }
       } else {
-        load_col<R>(delta + off, dl);
-        load_col<R>(Hd + off, hd);
 #pragma unroll
         for (int a = 0; a < R; ++a) {
           dl[a] = fma(beta, dl[a], -zc[a]);
@@ -559,7 +632,7 @@ __global__ __launch_bounds__(kBlock) void k_tcg_hess(BsrDev Q, const double* __r
       store_col<R>(delta + off, dl);
       store_col<R>(Hd + off, hd);
     }
-    __syncthreads();
+    wave_sync();
   }
   store_partials<1>(part, pout, red);
 }
@@ -590,7 +663,7 @@ __global__ __launch_bounds__(kBlock) void k_precond(const double* __restrict__ X
       store_col<R>(ys + L.c * R, x);
       store_col<R>(vs + L.c * R, v);
     }
-    __syncthreads();
+    wave_sync();
     if (ok) {
       if (dinv) {
         jacobi_col<D, R>(vs, dinv + (size_t)i * GEO::BB + L.c * GEO::B, z);
@@ -600,13 +673,13 @@ __global__ __launch_bounds__(kBlock) void k_precond(const double* __restrict__ X
       }
       store_col<R>(zs + L.c * R, z);
     }
-    __syncthreads();
+    wave_sync();
     if (ok) {
       double out[R], s[D];
       proj_col<D, R>(ys, zs, L.c, z, out, s);
       store_col<R>(Z + off, out);
     }
-    __syncthreads();
+    wave_sync();
   }
 }
 
@@ -616,7 +689,7 @@ __global__ __launch_bounds__(kBlock) void k_precond(const double* __restrict__ X
 //   d_Hd (from k_hess partials) -> alpha, e_Pe';  boundary / negative curvature -> eta += tau*delta, stop
 //   else eta += alpha*delta; r += alpha*Hd; z = P(r);  partials: [0] <r,r>  [1] <z,r>
 template <int D, int R>
-__global__ __launch_bounds__(kBlock) void k_tcg_update(const double* __restrict__ X, const double* __restrict__ g,
+__global__ __launch_bounds__(kBlock, DPGO_LB_UPDATE) void k_tcg_update(const double* __restrict__ X, const double* __restrict__ g,
                                                        const double* __restrict__ dinv,
                                                        const double* __restrict__ delta,
                                                        const double* __restrict__ Hd, double* __restrict__ eta,
@@ -628,10 +701,11 @@ __global__ __launch_bounds__(kBlock) void k_tcg_update(const double* __restrict_
   using GEO = Geo<D, R>;
   __shared__ double sm[kWaves][3][GEO::G][GEO::T];
   __shared__ double red[kWaves * kNP];
-  DevState st = *sin;
+  DevState st;
+  load_state(st, sin);
   if (st.rtr_stop || (!first && st.tcg_done)) {
     if (blockIdx.x == 0 && threadIdx.x == 0) {
-      *sout = st;
+      store_state(sout, st);
       publish_progress(hflag, gen, st);
     }
     return;
@@ -664,7 +738,7 @@ __global__ __launch_bounds__(kBlock) void k_tcg_update(const double* __restrict_
     }
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) {
-    *sout = st;
+    store_state(sout, st);
     publish_progress(hflag, gen, st);
   }
 
@@ -690,8 +764,14 @@ __global__ __launch_bounds__(kBlock) void k_tcg_update(const double* __restrict_
     double* ys = ok ? &sm[L.wave][0][L.g][0] : nullptr;
     double* rs = ok ? &sm[L.wave][1][L.g][0] : nullptr;
     double* zs = ok ? &sm[L.wave][2][L.g][0] : nullptr;
-    double rr[R], x[R], zz[R];
+    double rr[R], x[R], zz[R], drow[GEO::B];
     if (ok) {
+      // all of this pose's loads are issued back to back (independent addresses)
+      load_col<R>(X + off, x);
+      if (dinv) {
+#pragma unroll
+        for (int k = 0; k < GEO::B; ++k) drow[k] = dinv[(size_t)i * GEO::BB + L.c * GEO::B + k];
+      }
       if (mode == 2) {
         load_col<R>(g + off, rr);
         double e[R];
@@ -714,21 +794,20 @@ __global__ __launch_bounds__(kBlock) void k_tcg_update(const double* __restrict_
       store_col<R>(r + off, rr);
 #pragma unroll
       for (int a = 0; a < R; ++a) part[0] = fma(rr[a], rr[a], part[0]);
-      load_col<R>(X + off, x);
       store_col<R>(ys + L.c * R, x);
       store_col<R>(rs + L.c * R, rr);
     }
-    __syncthreads();
+    wave_sync();
     if (ok) {
       if (dinv) {
-        jacobi_col<D, R>(rs, dinv + (size_t)i * GEO::BB + L.c * GEO::B, zz);
+        jacobi_col<D, R>(rs, drow, zz);
       } else {
 #pragma unroll
         for (int a = 0; a < R; ++a) zz[a] = rr[a];
       }
       store_col<R>(zs + L.c * R, zz);
     }
-    __syncthreads();
+    wave_sync();
     if (ok) {
       double out[R], s[D];
       proj_col<D, R>(ys, zs, L.c, zz, out, s);
@@ -736,64 +815,9 @@ __global__ __launch_bounds__(kBlock) void k_tcg_update(const double* __restrict_
       for (int a = 0; a < R; ++a) part[1] = fma(out[a], rr[a], part[1]);
       store_col<R>(z + off, out);
     }
-    __syncthreads();
+    wave_sync();
   }
   if (mode != 1) store_partials<2>(part, pout, red);
-}
-
-// ================================================================ K7b: tCG search-direction update
-// Second half of the inner iteration: convergence test |r| <= |r0| min(|r0|^theta, kappa),
-// beta = z_r'/z_r, delta = beta*delta - z, e_Pd, d_Pd recurrences (first = 1: delta = -z and the
-// initial scalars norm_r0, z_r, d_Pd).
-template <int D, int R>
-__global__ __launch_bounds__(kBlock) void k_tcg_dir(const double* __restrict__ z, double* __restrict__ delta,
-                                                    const double* __restrict__ pin, int nb_in,
-                                                    const DevState* __restrict__ sin, DevState* __restrict__ sout,
-                                                    int first, int n) {
-  using GEO = Geo<D, R>;
-  __shared__ double red[kWaves * kNP];
-  DevState st = *sin;
-  if (st.rtr_stop || st.tcg_done) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) *sout = st;
-    return;
-  }
-  double pr[2];
-  load_partials<2>(pin, nb_in, pr, red);
-  const double r_r = pr[0], z_r_new = pr[1];
-  double beta = 0.0;
-  bool update = true;
-  if (first) {
-    st.norm_r0 = sqrt(r_r);
-    st.z_r = z_r_new;
-    st.d_Pd = z_r_new;
-    st.e_Pd = 0.0;
-    if (st.max_inner <= 0) st.tcg_done = 1;
-  } else {
-    const double norm_r = sqrt(r_r);
-    const double pw = pow(st.norm_r0, st.theta);
-    if (st.tcg_j >= st.min_inner && norm_r <= st.norm_r0 * (pw < st.kappa ? pw : st.kappa)) {
-      st.tcg_status = (st.kappa < pw) ? TCG_LCON : TCG_SCON;
-      st.tcg_done = 1;
-      update = false;
-    } else {
-      beta = z_r_new / st.z_r;
-      st.e_Pd = beta * (st.e_Pd + st.alpha * st.d_Pd);
-      st.d_Pd = z_r_new + beta * beta * st.d_Pd;
-      st.z_r = z_r_new;
-      st.tcg_j += 1;
-      if (st.tcg_j >= st.max_inner) {
-        st.tcg_done = 1;
-        st.tcg_status = TCG_MAXITER;
-      }
-    }
-  }
-  if (blockIdx.x == 0 && threadIdx.x == 0) *sout = st;
-  if (!update) return;
-  const size_t total = (size_t)n * GEO::T;
-  for (size_t e = (size_t)blockIdx.x * kBlock + threadIdx.x; e < total; e += (size_t)gridDim.x * kBlock) {
-    const double zv = z[e];
-    delta[e] = first ? -zv : fma(beta, delta[e], -zv);
-  }
 }
 
 // ================================================================ K4: retraction
@@ -824,7 +848,7 @@ __global__ __launch_bounds__(kBlock) void k_retract(const double* __restrict__ X
       for (int k = 0; k < R; ++k) a[k] = fma(scale, e[k], x[k]);
       store_col<R>(as + L.c * R, a);
     }
-    __syncthreads();
+    wave_sync();
     if (ok) {
       if (L.c < D) {
         double q[D][R];
@@ -859,7 +883,7 @@ __global__ __launch_bounds__(kBlock) void k_retract(const double* __restrict__ X
       }
       store_col<R>(X2 + off, a);
     }
-    __syncthreads();
+    wave_sync();
   }
 }
 
@@ -878,9 +902,10 @@ __global__ __launch_bounds__(kBlock) void k_rtr_update(double* __restrict__ x1, 
                                                        int n) {
   using GEO = Geo<D, R>;
   __shared__ double red[kWaves * kNP];
-  DevState st = *sin;
+  DevState st;
+  load_state(st, sin);
   if (st.rtr_stop) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) *sout = st;
+    if (blockIdx.x == 0 && threadIdx.x == 0) store_state(sout, st);
     return;
   }
   double e3[3], h2[2];
@@ -909,7 +934,7 @@ __global__ __launch_bounds__(kBlock) void k_rtr_update(double* __restrict__ x1, 
     st.n_accept += 1;
     st.rtr_stop = (ngf2 < st.tol) ? 1 : 0;
   }
-  if (blockIdx.x == 0 && threadIdx.x == 0) *sout = st;
+  if (blockIdx.x == 0 && threadIdx.x == 0) store_state(sout, st);
   if (!accept) return;
   const size_t total = (size_t)n * GEO::T;
   const size_t stride = (size_t)gridDim.x * kBlock;
@@ -955,8 +980,8 @@ __global__ void k_rtr_begin(const double* __restrict__ pe, int nb_e, DevState* _
     st.max_inner = max_inner;
     st.n_hess = 0;
     st.min_inner = 0;
-    s0[0] = st;
-    s0[1] = st;
+    store_state(s0, st);
+    store_state(s0 + 1, st);
   }
 }
 
@@ -991,7 +1016,7 @@ __global__ __launch_bounds__(kBlock) void k_axpby_project(double a, const double
       }
       store_col<R>(ms + L.c * R, m);
     }
-    __syncthreads();
+    wave_sync();
     if (ok) {
       if (project && L.c < D) {
         // C = M^T M (D x D), eigen-decompose C = W diag(lam) W^T, out col c = sum_a M[:,a] * F[a][c],
@@ -1070,7 +1095,7 @@ __global__ __launch_bounds__(kBlock) void k_axpby_project(double a, const double
       }
       store_col<R>(out + off, m);
     }
-    __syncthreads();
+    wave_sync();
   }
 }
 

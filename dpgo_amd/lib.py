@@ -13,7 +13,7 @@ from typing import Optional
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdpgo_hip.so")
+LIB_PATH = os.environ.get("DPGO_LIB") or os.path.join(_HERE, "libdpgo_hip.so")  # DPGO_LIB: kernel A/B builds
 
 OK, ERR_INVALID, ERR_HIP, ERR_UNSUPPORTED, ERR_STATE = 0, 1, 2, 3, 4
 METHOD_RTR, METHOD_RGD = 0, 1
