@@ -127,6 +127,13 @@ class DeviceAgent:
         lo, hi = self.plan.recv_range[self.id][q]
         return self.nbr[lo:hi]
 
+    def snapshot(self) -> None:
+        """Remember the current iterate (benchmarks restore it so that every timed step does the same work)."""
+        self._snap = self.X.clone()
+
+    def restore(self) -> None:
+        self.X.copy_(self._snap)
+
     # ---- the hot path ----
     def update(self) -> ROPTResult:
         """PGOAgent::updateX(doOptimization = true): G from the neighbour buffer, then optimize."""

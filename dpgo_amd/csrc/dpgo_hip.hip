@@ -582,7 +582,15 @@ int dpgo_problem_set_stream(dpgo_problem_t p, void* hip_stream) {
   if (!p) return fail(DPGO_ERR_INVALID, "null handle");
   CHK(set_device(p));
   HIPC(hipStreamSynchronize(p->stream));
-  p->stream = hip_stream ? (hipStream_t)hip_stream : p->own_stream;
+  p->stream = (hipStream_t)hip_stream;  // NULL = the default (null) stream
+  return DPGO_OK;
+}
+
+int dpgo_problem_use_own_stream(dpgo_problem_t p) {
+  if (!p) return fail(DPGO_ERR_INVALID, "null handle");
+  CHK(set_device(p));
+  HIPC(hipStreamSynchronize(p->stream));
+  p->stream = p->own_stream;
   return DPGO_OK;
 }
 

@@ -153,6 +153,22 @@ __device__ __forceinline__ void wave_sync() {
 #endif
 }
 
+// ---------------------------------------------------------------- span access
+// A wave's G poses are ONE contiguous span of G*T doubles whose memory layout is exactly the LDS tile
+// layout [pose][column][R].  When T is even (always in 3-D: T = 4r) the span is moved with lane-linear
+// 16-byte accesses (1 KiB per wave instruction) instead of 8-byte accesses at a 40-byte stride
+// (tools/stream_lab.hip: 6.1 -> 7.0 TB/s on streaming kernels); element-wise updates are done in
+// that "span layout" and only the per-pose coupling uses the lane = (pose, column) layout.
+typedef double dbl2 __attribute__((ext_vector_type(2)));
+template <int D, int R, int SPLIT>
+struct Span {
+  using GEO = Geo<D, R, SPLIT>;
+  static constexpr bool kOk = (GEO::T % 2 == 0);
+  static constexpr int SP = GEO::G * GEO::T;  // doubles per wave span
+  static constexpr int NPC = SP / 2;          // 16-byte pieces
+  static constexpr int NIT = (NPC + 63) / 64; // pieces per lane
+};
+
 // ---------------------------------------------------------------- reductions
 __device__ __forceinline__ double wave_allreduce(double v) {
   // xor butterfly: every lane ends with the same bits (each level adds a commutative pair)
@@ -516,7 +532,7 @@ __global__ __launch_bounds__(kBlock, DPGO_LB_HESS) void k_tcg_hess(BsrDev Q, con
                                                      DevState* __restrict__ sout, int first, int n,
                                                      unsigned long long* hflag, unsigned gen) {
   using GEO = Geo<D, R, SPLIT>;
-  __shared__ double sm[kWaves][3][GEO::G][GEO::T];
+  __shared__ __attribute__((aligned(16))) double sm[kWaves][4][GEO::G][GEO::T];
   __shared__ double red[kWaves * kNP];
   DevState st;
   load_state(st, sin);
@@ -571,68 +587,157 @@ __global__ __launch_bounds__(kBlock, DPGO_LB_HESS) void k_tcg_hess(BsrDev Q, con
   const int ntiles = (n + GEO::P - 1) / GEO::P;
   double part[1] = {0.0};
   const TileIter ti_ = tile_iter(ntiles);
-  for (int tile = ti_.first; tile < ti_.last; tile += ti_.step) {
-    const int i = tile * GEO::P + L.wave * GEO::G + L.g;
-    const bool okp = (L.g < GEO::G) && (i < n);
-    const bool ok = okp && (L.s == 0);
-    double h[R], zc[R], x[R];
-    const size_t off = (size_t)i * GEO::T + L.c * R;
-    double* ys = ok ? &sm[L.wave][0][L.g][0] : nullptr;
-    double* vs = ok ? &sm[L.wave][1][L.g][0] : nullptr;
-    double* hs = ok ? &sm[L.wave][2][L.g][0] : nullptr;
-    // issue the epilogue's loads first: they overlap the gather's index -> tile latency chain
-    double srow[D], dl[R], hd[R];
-    if (ok) {
-      load_col<R>(X + off, x);
-      load_col<R>(z + off, zc);
-      if (L.c < D) {
+  if constexpr (Span<D, R, SPLIT>::kOk) {
+    // ---- span path (T even): own-tile vectors move as 16-byte pieces through the LDS tiles; the direction /
+    // H-direction recurrences run in span layout
+    using SPN = Span<D, R, SPLIT>;
+    const int lane = threadIdx.x & 63;
+    double* ys = &sm[L.wave][0][0][0];
+    double* vs = &sm[L.wave][1][0][0];
+    double* hs = &sm[L.wave][2][0][0];
+    double* os = &sm[L.wave][3][0][0];
+    for (int tile = ti_.first; tile < ti_.last; tile += ti_.step) {
+      const int p0 = tile * GEO::P + L.wave * GEO::G;
+      const int npose = (n - p0) < GEO::G ? (n - p0) : GEO::G;
+      const int valid = npose > 0 ? npose * GEO::T : 0;
+      const size_t base = (size_t)p0 * GEO::T;
+      const int i = p0 + L.g;
+      const bool okp = (L.g < GEO::G) && (i < n);
+      const bool ok = okp && (L.s == 0);
+      const dbl2* X2 = reinterpret_cast<const dbl2*>(X + base);
+      const dbl2* z2 = reinterpret_cast<const dbl2*>(z + base);
+      dbl2* d2 = reinterpret_cast<dbl2*>(delta + base);
+      dbl2* h2 = reinterpret_cast<dbl2*>(Hd + base);
+      // issue every own-tile load before the gather: they overlap its index -> tile latency chain
+      dbl2 dv[SPN::NIT], hv[SPN::NIT];
+      double srow[D];
+#pragma unroll
+      for (int it = 0; it < SPN::NIT; ++it) {
+        const int pc = lane + 64 * it;
+        if (2 * pc < valid) {
+          reinterpret_cast<dbl2*>(ys)[pc] = X2[pc];
+          reinterpret_cast<dbl2*>(vs)[pc] = z2[pc];
+          if (!first) {
+            dv[it] = d2[pc];
+            hv[it] = h2[pc];
+          }
+        }
+      }
+      if (ok && L.c < D) {
 #pragma unroll
         for (int a = 0; a < D; ++a) srow[a] = S[(size_t)i * D * D + L.c * D + a];
       }
-      if (!first) {
-        load_col<R>(delta + off, dl);
-        load_col<R>(Hd + off, hd);
+      double h[R];
+      spmm_col<D, R, SPLIT>(Q.rowptr, Q.colidx, Q.vals, z, i, L.s, L.c, okp, h);
+      wave_sync();
+      if (ok) {
+        if (L.c < D) {
+          const double* vt = vs + L.g * GEO::T;
+#pragma unroll
+          for (int a = 0; a < D; ++a) {
+#pragma unroll
+            for (int k = 0; k < R; ++k) h[k] = fma(-vt[a * R + k], srow[a], h[k]);
+          }
+        }
+        store_col<R>(hs + L.g * GEO::T + L.c * R, h);
       }
-    }
-    spmm_col<D, R, SPLIT>(Q.rowptr, Q.colidx, Q.vals, z, i, L.s, L.c, okp, h);
-    if (ok) {
-      store_col<R>(ys + L.c * R, x);
-      store_col<R>(vs + L.c * R, zc);
-    }
-    wave_sync();
-    if (ok) {
-      if (L.c < D) {
+      wave_sync();
+      if (ok) {
+        double hz[R], sdummy[D];
+        proj_col<D, R>(ys + L.g * GEO::T, hs + L.g * GEO::T, L.c, h, hz, sdummy);
+        store_col<R>(os + L.g * GEO::T + L.c * R, hz);
+      }
+      wave_sync();
 #pragma unroll
-        for (int a = 0; a < D; ++a) {
-#pragma unroll
-          for (int k = 0; k < R; ++k) h[k] = fma(-vs[a * R + k], srow[a], h[k]);
+      for (int it = 0; it < SPN::NIT; ++it) {
+        const int pc = lane + 64 * it;
+        if (2 * pc < valid) {
+          const dbl2 zv = reinterpret_cast<const dbl2*>(vs)[pc];
+          const dbl2 hzv = reinterpret_cast<const dbl2*>(os)[pc];
+          dbl2 dn, hn;
+          if (first) {
+            dn.x = -zv.x;
+            dn.y = -zv.y;
+            hn.x = -hzv.x;
+            hn.y = -hzv.y;
+          } else {
+            dn.x = fma(beta, dv[it].x, -zv.x);
+            dn.y = fma(beta, dv[it].y, -zv.y);
+            hn.x = fma(beta, hv[it].x, -hzv.x);
+            hn.y = fma(beta, hv[it].y, -hzv.y);
+          }
+          d2[pc] = dn;
+          h2[pc] = hn;
+          part[0] = fma(dn.x, hn.x, part[0]);
+          part[0] = fma(dn.y, hn.y, part[0]);
         }
       }
-      store_col<R>(hs + L.c * R, h);
+      wave_sync();
     }
-    wave_sync();
-    if (ok) {
-      double hz[R], s[D];
-      proj_col<D, R>(ys, hs, L.c, h, hz, s);
-      if (first) {
-#pragma unroll
-        for (int a = 0; a < R; ++a) {
-          dl[a] = -zc[a];
-          hd[a] = -hz[a];
+  } else {
+    for (int tile = ti_.first; tile < ti_.last; tile += ti_.step) {
+      const int i = tile * GEO::P + L.wave * GEO::G + L.g;
+      const bool okp = (L.g < GEO::G) && (i < n);
+      const bool ok = okp && (L.s == 0);
+      double h[R], zc[R], x[R];
+      const size_t off = (size_t)i * GEO::T + L.c * R;
+      double* ys = ok ? &sm[L.wave][0][L.g][0] : nullptr;
+      double* vs = ok ? &sm[L.wave][1][L.g][0] : nullptr;
+      double* hs = ok ? &sm[L.wave][2][L.g][0] : nullptr;
+      // issue the epilogue's loads first: they overlap the gather's index -> tile latency chain
+      double srow[D], dl[R], hd[R];
+      if (ok) {
+        load_col<R>(X + off, x);
+        load_col<R>(z + off, zc);
+        if (L.c < D) {
+  #pragma unroll
+          for (int a = 0; a < D; ++a) srow[a] = S[(size_t)i * D * D + L.c * D + a];
         }
-      } else {
-#pragma unroll
-        for (int a = 0; a < R; ++a) {
-          dl[a] = fma(beta, dl[a], -zc[a]);
-          hd[a] = fma(beta, hd[a], -hz[a]);
+        if (!first) {
+          load_col<R>(delta + off, dl);
+          load_col<R>(Hd + off, hd);
         }
       }
-#pragma unroll
-      for (int a = 0; a < R; ++a) part[0] = fma(dl[a], hd[a], part[0]);
-      store_col<R>(delta + off, dl);
-      store_col<R>(Hd + off, hd);
+      spmm_col<D, R, SPLIT>(Q.rowptr, Q.colidx, Q.vals, z, i, L.s, L.c, okp, h);
+      if (ok) {
+        store_col<R>(ys + L.c * R, x);
+        store_col<R>(vs + L.c * R, zc);
+      }
+      wave_sync();
+      if (ok) {
+        if (L.c < D) {
+  #pragma unroll
+          for (int a = 0; a < D; ++a) {
+  #pragma unroll
+            for (int k = 0; k < R; ++k) h[k] = fma(-vs[a * R + k], srow[a], h[k]);
+          }
+        }
+        store_col<R>(hs + L.c * R, h);
+      }
+      wave_sync();
+      if (ok) {
+        double hz[R], s[D];
+        proj_col<D, R>(ys, hs, L.c, h, hz, s);
+        if (first) {
+  #pragma unroll
+          for (int a = 0; a < R; ++a) {
+            dl[a] = -zc[a];
+            hd[a] = -hz[a];
+          }
+        } else {
+  #pragma unroll
+          for (int a = 0; a < R; ++a) {
+            dl[a] = fma(beta, dl[a], -zc[a]);
+            hd[a] = fma(beta, hd[a], -hz[a]);
+          }
+        }
+  #pragma unroll
+        for (int a = 0; a < R; ++a) part[0] = fma(dl[a], hd[a], part[0]);
+        store_col<R>(delta + off, dl);
+        store_col<R>(Hd + off, hd);
+      }
+      wave_sync();
     }
-    wave_sync();
   }
   store_partials<1>(part, pout, red);
 }
@@ -699,7 +804,7 @@ __global__ __launch_bounds__(kBlock, DPGO_LB_UPDATE) void k_tcg_update(const dou
                                                        DevState* __restrict__ sout, int first, int n,
                                                        unsigned long long* hflag, unsigned gen) {
   using GEO = Geo<D, R>;
-  __shared__ double sm[kWaves][3][GEO::G][GEO::T];
+  __shared__ __attribute__((aligned(16))) double sm[kWaves][4][GEO::G][GEO::T];
   __shared__ double red[kWaves * kNP];
   DevState st;
   load_state(st, sin);
@@ -746,76 +851,176 @@ __global__ __launch_bounds__(kBlock, DPGO_LB_UPDATE) void k_tcg_update(const dou
   const int ntiles = (n + GEO::P - 1) / GEO::P;
   double part[2] = {0.0, 0.0};
   const TileIter ti_ = tile_iter(ntiles);
-  for (int tile = ti_.first; tile < ti_.last; tile += ti_.step) {
-    const int i = tile * GEO::P + L.wave * GEO::G + L.g;
-    const bool ok = (L.g < GEO::G) && (i < n);
-    const size_t off = (size_t)i * GEO::T + L.c * R;
-    if (mode == 1) {  // workgroup-uniform
-      if (ok) {
-        double e[R], dl[R];
-        load_col<R>(eta + off, e);
-        load_col<R>(delta + off, dl);
+  if constexpr (Span<D, R, 1>::kOk) {
+    // ---- span path (T even): vectors move as 16-byte pieces; r, X staged straight into the LDS tiles
+    using SPN = Span<D, R, 1>;
+    const int lane = threadIdx.x & 63;
+    double* ys = &sm[L.wave][0][0][0];
+    double* rs = &sm[L.wave][1][0][0];
+    double* zs = &sm[L.wave][2][0][0];
+    double* os = &sm[L.wave][3][0][0];
+    for (int tile = ti_.first; tile < ti_.last; tile += ti_.step) {
+      const int p0 = tile * GEO::P + L.wave * GEO::G;
+      const int npose = (n - p0) < GEO::G ? (n - p0) : GEO::G;
+      const int valid = npose > 0 ? npose * GEO::T : 0;  // doubles of this wave's span inside the array
+      const size_t base = (size_t)p0 * GEO::T;
+      const int i = p0 + L.g;
+      const bool ok = (L.g < GEO::G) && (i < n);
+      dbl2* eta2 = reinterpret_cast<dbl2*>(eta + base);
+      const dbl2* dl2 = reinterpret_cast<const dbl2*>(delta + base);
+      if (mode == 1) {  // workgroup-uniform: eta += tau * delta, then tCG stops
 #pragma unroll
-        for (int a = 0; a < R; ++a) e[a] = fma(tau, dl[a], e[a]);
-        store_col<R>(eta + off, e);
+        for (int it = 0; it < SPN::NIT; ++it) {
+          const int pc = lane + 64 * it;
+          if (2 * pc < valid) {
+            dbl2 e = eta2[pc];
+            const dbl2 dv = dl2[pc];
+            e.x = fma(tau, dv.x, e.x);
+            e.y = fma(tau, dv.y, e.y);
+            eta2[pc] = e;
+          }
+        }
+        continue;
       }
-      continue;
-    }
-    double* ys = ok ? &sm[L.wave][0][L.g][0] : nullptr;
-    double* rs = ok ? &sm[L.wave][1][L.g][0] : nullptr;
-    double* zs = ok ? &sm[L.wave][2][L.g][0] : nullptr;
-    double rr[R], x[R], zz[R], drow[GEO::B];
-    if (ok) {
-      // all of this pose's loads are issued back to back (independent addresses)
-      load_col<R>(X + off, x);
-      if (dinv) {
+      double drow[GEO::B];
+      if (ok && dinv) {
 #pragma unroll
         for (int k = 0; k < GEO::B; ++k) drow[k] = dinv[(size_t)i * GEO::BB + L.c * GEO::B + k];
       }
-      if (mode == 2) {
-        load_col<R>(g + off, rr);
-        double e[R];
+      const dbl2* X2 = reinterpret_cast<const dbl2*>(X + base);
+      const dbl2* g2 = reinterpret_cast<const dbl2*>(g + base);
+      const dbl2* hd2 = reinterpret_cast<const dbl2*>(Hd + base);
+      dbl2* r2 = reinterpret_cast<dbl2*>(r + base);
 #pragma unroll
-        for (int a = 0; a < R; ++a) e[a] = 0.0;
-        store_col<R>(eta + off, e);
-      } else {
-        double e[R], dl[R], hd[R];
-        load_col<R>(eta + off, e);
-        load_col<R>(delta + off, dl);
-        load_col<R>(Hd + off, hd);
-        load_col<R>(r + off, rr);
-#pragma unroll
-        for (int a = 0; a < R; ++a) {
-          e[a] = fma(alpha, dl[a], e[a]);
-          rr[a] = fma(alpha, hd[a], rr[a]);
+      for (int it = 0; it < SPN::NIT; ++it) {
+        const int pc = lane + 64 * it;
+        if (2 * pc < valid) {
+          reinterpret_cast<dbl2*>(ys)[pc] = X2[pc];
+          dbl2 rv;
+          if (mode == 2) {
+            rv = g2[pc];
+            dbl2 zero;
+            zero.x = 0.0;
+            zero.y = 0.0;
+            eta2[pc] = zero;
+          } else {
+            dbl2 e = eta2[pc];
+            const dbl2 dv = dl2[pc], hv = hd2[pc];
+            rv = r2[pc];
+            e.x = fma(alpha, dv.x, e.x);
+            e.y = fma(alpha, dv.y, e.y);
+            rv.x = fma(alpha, hv.x, rv.x);
+            rv.y = fma(alpha, hv.y, rv.y);
+            eta2[pc] = e;
+          }
+          r2[pc] = rv;
+          reinterpret_cast<dbl2*>(rs)[pc] = rv;
+          part[0] = fma(rv.x, rv.x, part[0]);
+          part[0] = fma(rv.y, rv.y, part[0]);
         }
-        store_col<R>(eta + off, e);
       }
-      store_col<R>(r + off, rr);
+      wave_sync();
+      double zz[R];
+      if (ok) {
+        const double* rt = rs + L.g * GEO::T;
+        if (dinv) {
+          jacobi_col<D, R>(rt, drow, zz);
+        } else {
 #pragma unroll
-      for (int a = 0; a < R; ++a) part[0] = fma(rr[a], rr[a], part[0]);
-      store_col<R>(ys + L.c * R, x);
-      store_col<R>(rs + L.c * R, rr);
-    }
-    wave_sync();
-    if (ok) {
-      if (dinv) {
-        jacobi_col<D, R>(rs, drow, zz);
-      } else {
-#pragma unroll
-        for (int a = 0; a < R; ++a) zz[a] = rr[a];
+          for (int a = 0; a < R; ++a) zz[a] = rt[L.c * R + a];
+        }
+        store_col<R>(zs + L.g * GEO::T + L.c * R, zz);
       }
-      store_col<R>(zs + L.c * R, zz);
-    }
-    wave_sync();
-    if (ok) {
-      double out[R], s[D];
-      proj_col<D, R>(ys, zs, L.c, zz, out, s);
+      wave_sync();
+      if (ok) {
+        double out[R], sdummy[D];
+        proj_col<D, R>(ys + L.g * GEO::T, zs + L.g * GEO::T, L.c, zz, out, sdummy);
+        const double* rt = rs + L.g * GEO::T + L.c * R;
 #pragma unroll
-      for (int a = 0; a < R; ++a) part[1] = fma(out[a], rr[a], part[1]);
-      store_col<R>(z + off, out);
+        for (int a = 0; a < R; ++a) part[1] = fma(out[a], rt[a], part[1]);
+        store_col<R>(os + L.g * GEO::T + L.c * R, out);
+      }
+      wave_sync();
+      dbl2* z2 = reinterpret_cast<dbl2*>(z + base);
+#pragma unroll
+      for (int it = 0; it < SPN::NIT; ++it) {
+        const int pc = lane + 64 * it;
+        if (2 * pc < valid) z2[pc] = reinterpret_cast<const dbl2*>(os)[pc];
+      }
+      wave_sync();
     }
-    wave_sync();
+  } else {
+    for (int tile = ti_.first; tile < ti_.last; tile += ti_.step) {
+      const int i = tile * GEO::P + L.wave * GEO::G + L.g;
+      const bool ok = (L.g < GEO::G) && (i < n);
+      const size_t off = (size_t)i * GEO::T + L.c * R;
+      if (mode == 1) {  // workgroup-uniform
+        if (ok) {
+          double e[R], dl[R];
+          load_col<R>(eta + off, e);
+          load_col<R>(delta + off, dl);
+  #pragma unroll
+          for (int a = 0; a < R; ++a) e[a] = fma(tau, dl[a], e[a]);
+          store_col<R>(eta + off, e);
+        }
+        continue;
+      }
+      double* ys = ok ? &sm[L.wave][0][L.g][0] : nullptr;
+      double* rs = ok ? &sm[L.wave][1][L.g][0] : nullptr;
+      double* zs = ok ? &sm[L.wave][2][L.g][0] : nullptr;
+      double rr[R], x[R], zz[R], drow[GEO::B];
+      if (ok) {
+        // all of this pose's loads are issued back to back (independent addresses)
+        load_col<R>(X + off, x);
+        if (dinv) {
+  #pragma unroll
+          for (int k = 0; k < GEO::B; ++k) drow[k] = dinv[(size_t)i * GEO::BB + L.c * GEO::B + k];
+        }
+        if (mode == 2) {
+          load_col<R>(g + off, rr);
+          double e[R];
+  #pragma unroll
+          for (int a = 0; a < R; ++a) e[a] = 0.0;
+          store_col<R>(eta + off, e);
+        } else {
+          double e[R], dl[R], hd[R];
+          load_col<R>(eta + off, e);
+          load_col<R>(delta + off, dl);
+          load_col<R>(Hd + off, hd);
+          load_col<R>(r + off, rr);
+  #pragma unroll
+          for (int a = 0; a < R; ++a) {
+            e[a] = fma(alpha, dl[a], e[a]);
+            rr[a] = fma(alpha, hd[a], rr[a]);
+          }
+          store_col<R>(eta + off, e);
+        }
+        store_col<R>(r + off, rr);
+  #pragma unroll
+        for (int a = 0; a < R; ++a) part[0] = fma(rr[a], rr[a], part[0]);
+        store_col<R>(ys + L.c * R, x);
+        store_col<R>(rs + L.c * R, rr);
+      }
+      wave_sync();
+      if (ok) {
+        if (dinv) {
+          jacobi_col<D, R>(rs, drow, zz);
+        } else {
+  #pragma unroll
+          for (int a = 0; a < R; ++a) zz[a] = rr[a];
+        }
+        store_col<R>(zs + L.c * R, zz);
+      }
+      wave_sync();
+      if (ok) {
+        double out[R], s[D];
+        proj_col<D, R>(ys, zs, L.c, zz, out, s);
+  #pragma unroll
+        for (int a = 0; a < R; ++a) part[1] = fma(out[a], rr[a], part[1]);
+        store_col<R>(z + off, out);
+      }
+      wave_sync();
+    }
   }
   if (mode != 1) store_partials<2>(part, pout, red);
 }

@@ -58,6 +58,7 @@ SIGNATURES = {
     "dpgo_problem_create": ([C.POINTER(_P), _I, _I, _I, _I], _I),
     "dpgo_problem_destroy": ([_P], _I),
     "dpgo_problem_set_stream": ([_P, _P], _I),
+    "dpgo_problem_use_own_stream": ([_P], _I),
     "dpgo_problem_dims": ([_P, C.POINTER(_I), C.POINTER(_I), C.POINTER(_I), C.POINTER(_I)], _I),
     "dpgo_problem_set_Q_bsr": ([_P, _I, _P, _P, _P], _I),
     "dpgo_problem_set_Q_csr": ([_P, _P, _P, _P], _I),

@@ -381,7 +381,12 @@ class QuadraticProblem:
 
     # ---- device-resident flavour (torch tensors or raw device addresses) ----
     def setStream(self, hip_stream: Optional[int]) -> None:
-        L.check(self._lib.dpgo_problem_set_stream(self._h, hip_stream))
+        """Order this problem's device work with an external stream (torch's current stream);
+        0 / None = the default (null) stream.  useOwnStream() reverts to the private stream."""
+        L.check(self._lib.dpgo_problem_set_stream(self._h, hip_stream or None))
+
+    def useOwnStream(self) -> None:
+        L.check(self._lib.dpgo_problem_use_own_stream(self._h))
 
     def setCouplingFromPoseGraph(self) -> list:
         """Upload the G operator once; returns the neighbour slot order (list of (robot, frame))."""

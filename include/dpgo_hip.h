@@ -110,8 +110,12 @@ int dpgo_supported(int d, int r);
  * iteration, src/PGOAgent.cpp:968-969, which is free on the CPU but not on a device). */
 int dpgo_problem_create(dpgo_problem_t* out, int r, int d, int n, int device);
 int dpgo_problem_destroy(dpgo_problem_t h);
-/* use an external HIP stream (e.g. torch's current stream); NULL restores the handle's own */
+/* Run this handle's work on an external HIP stream, e.g. torch's current stream, so that it is ordered
+ * with the caller's own device work.  hip_stream = NULL selects the device's DEFAULT (null) stream --
+ * which is what torch.cuda.current_stream().cuda_stream is unless the caller switched streams.
+ * dpgo_problem_use_own_stream goes back to the handle's private non-blocking stream. */
 int dpgo_problem_set_stream(dpgo_problem_t h, void* hip_stream);
+int dpgo_problem_use_own_stream(dpgo_problem_t h);
 int dpgo_problem_dims(dpgo_problem_t h, int* r, int* d, int* n, int* nnzb);
 
 /* PoseGraph::quadraticMatrix() (include/DPGO/PoseGraph.h:162).  Host arrays; rowptr has

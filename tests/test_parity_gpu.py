@@ -346,3 +346,27 @@ def test_multi_agent_rbcd_on_one_gpu_matches_oracle(oracle, name, robots, sweeps
     X = np.concatenate([agents[a].X.cpu().numpy() for a in range(robots)], axis=0)
     assert relerr(X, Xref) < 1e-7
     assert costs[-1] < costs[0]
+
+
+def test_external_stream_ordering_is_deterministic(oracle):
+    """Regression: work of a handle bound to torch's current stream (the NULL / default stream) is ordered
+    with torch ops on that stream -- restoring an iterate with tensor.copy_ and solving again gives the
+    bit-identical result every time."""
+    import torch
+    import dpgo_amd
+    from dpgo_amd.agent import DeviceAgent, ExchangePlan, build_pose_graphs
+    om, n, Ttrue = oracle.synthetic_grid(20, 20, 10, seed=5)
+    X0 = oracle.lift(oracle.perturbed_truth(Ttrue, seed=6), 5)
+    ranges, graphs = build_pose_graphs(to_product_measurements(om), n, 1, 5)
+    ag = DeviceAgent(graphs, ExchangePlan(graphs), 0, X0, dpgo_amd.ROptParameters())
+    for _ in range(2):
+        ag.update()
+    ag.snapshot()
+    outs = []
+    for _ in range(6):
+        ag.restore()
+        res = ag.update()
+        outs.append((res.fInit, res.fOpt, res.tcg_iterations, ag.X.clone()))
+    for o in outs[1:]:
+        assert o[:3] == outs[0][:3]
+        assert torch.equal(o[3], outs[0][3])
