@@ -83,9 +83,10 @@ def hess_bytes(n, nnzb, d, r):
     return nnzb * (8 * b * b + 4) + 4 * (n + 1) + v + (v + 8 * d * d * n) + 2 * v + 2 * v
 
 
-def cpu_baseline(meas_p, n, X0, r, budget_s):
-    """CPU oracle ("port": NumPy/SciPy restatement, 1 thread) timed on a bounded sample of the same
-    workload: whole RBCD iterations if one fits the budget, else tCG iterations extrapolated."""
+def cpu_baseline(meas_p, n, X_state, r, budget_s):
+    """CPU oracle ("port": NumPy/SciPy restatement of the same algorithm, 1 thread) timed on the SAME step the
+    GPU is timed on: one RBCD iteration (RTR 3 x <=50 tCG, block-Jacobi, H-direction recurrence) from the
+    settled iterate.  If one full step does not fit the budget the tCG cap is lowered and the time scaled."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import dpgo_oracle as O
     d = meas_p.d
@@ -94,43 +95,30 @@ def cpu_baseline(meas_p, n, X0, r, budget_s):
                         meas_p.fixedWeight)
     Q = O.construct_Q(n, d, om)
     prob = O.QuadraticProblem(Q, None, r, d, precond="jacobi")
-    # time a few Hessian-vector products first to size the sample
-    X = X0.copy()
+    X = np.ascontiguousarray(X_state)
     EG = prob.euc_grad(X)
     S = prob.sym_ytg(X, EG)
     g = O.tangent_project(X, EG, d)
     t0 = time.perf_counter()
     reps = 0
-    while reps < 3 or (time.perf_counter() - t0 < 1.0 and reps < 50):
+    while reps < 2 or (time.perf_counter() - t0 < 1.0 and reps < 50):
         prob.rie_hess(X, S, g)
         prob.precondition(X, g)
         reps += 1
     per_tcg = (time.perf_counter() - t0) / reps
     max_inner = 50
-    est_full = 3 * max_inner * per_tcg * 1.15
-    if est_full <= budget_s:
-        opt = O.QuadraticOptimizer(prob, O.ROptParameters())
-        t0 = time.perf_counter()
-        steps = 0
-        while True:
-            X = opt.optimize(X)
-            steps += 1
-            el = time.perf_counter() - t0
-            if el + el / steps > budget_s:
-                break
-        return dict(value=steps / el, unit="it/s", cores=1, kind="port",
-                    sample="%d full RBCD iteration(s) (RTR 3x<=50 tCG, block-Jacobi) of the same workload, "
-                           "NumPy/SciPy oracle, %.1f s" % (steps, el),
-                    spmm_ms=None)
-    inner = max(2, int(budget_s / 3 / per_tcg / 1.15))
-    opt = O.QuadraticOptimizer(prob, O.ROptParameters(RTR_tCG_iterations=inner))
+    inner = max_inner if 3 * max_inner * per_tcg * 1.2 <= budget_s else max(2, int(budget_s / 3 / per_tcg / 1.2))
+    opt = O.QuadraticOptimizer(prob, O.ROptParameters(RTR_tCG_iterations=inner), hess_recurrence=True)
     t0 = time.perf_counter()
     opt.optimize(X)
     el = time.perf_counter() - t0
-    scaled = el * (max_inner / inner)
-    return dict(value=1.0 / scaled, unit="it/s", cores=1, kind="port",
-                sample="1 RBCD iteration with tCG capped at %d (of 50) inner iterations, %.1f s, time scaled by %.2f; "
-                       "NumPy/SciPy oracle, block-Jacobi" % (inner, el, max_inner / inner))
+    scale = max_inner / inner
+    return dict(value=1.0 / (el * scale), unit="it/s", cores=1, kind="port",
+                sample="1 RBCD iteration from the same settled iterate, %d tCG Hessian-vector products in %.1f s%s; "
+                       "NumPy/SciPy oracle (single thread), same algorithm as the device path" % (
+                           opt.result.tcg_iters, el,
+                           "" if inner == max_inner else " (tCG capped at %d of 50, time scaled x%.2f)" % (inner, scale)),
+                tcg_iterations=opt.result.tcg_iters, seconds=el)
 
 
 def main():
@@ -229,10 +217,23 @@ def main():
     hb = hess_bytes(n_local, nnzb_local, d, r)
     sb = spmm_bytes(n_local, nnzb_local, d, r)
     ach = hb / (ms_hess.value * 1e-3) / 1e9
+    traffic = None
+    traffic_src = None
+    pmc_file = os.path.join(ROOT, "profiles", "r01_v5_pmc_fetch_write.json")
+    if world == 1 and args.workload == "grid100k" and r == 5 and os.path.exists(pmc_file):
+        # HBM-side bytes per launch from rocprofv3 PMC passes of this same command (separate FETCH_SIZE and
+        # WRITE_SIZE passes): FETCH_SIZE x 2 (gfx950 correction, calibrated on k_retract / k_rtr_update whose
+        # byte counts are exact) + WRITE_SIZE, KB -> bytes; "max" = the full (non-early-exit) launches
+        pmc = json.load(open(pmc_file))
+        key = "k_tcg_hess<%d, %d, 1>" % (d, r)
+        if key in pmc.get("FETCH_SIZE_KB", {}) and key in pmc.get("WRITE_SIZE_KB", {}):
+            traffic = (2.0 * pmc["FETCH_SIZE_KB"][key]["max"] + pmc["WRITE_SIZE_KB"][key]["max"]) * 1024.0
+            traffic_src = "profiles/r01_v5_pmc_fetch_write.json"
     roofline = dict(bound="hbm",
                     kernel="k_tcg_hess<%d,%d> (one tCG step: Q*z block-SpMM + Riemannian-Hessian epilogue + in-place "
                            "direction / H-direction recurrences)" % (d, r),
-                    achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS, traffic=None,
+                    achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS, traffic=traffic,
+                    traffic_source=traffic_src,
                     bytes_per_launch=hb, avg_launch_us=ms_hess.value * 1e3,
                     spmm_only=dict(kernel="k_spmm<%d,%d> (plain Q*X)" % (d, r), bytes_per_launch=sb,
                                    avg_launch_us=ms_spmm.value * 1e3,
@@ -241,7 +242,8 @@ def main():
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(meas, n, X0, r, args.cpu_budget_s)
+        agent.restore()
+        cpu = cpu_baseline(meas, n, agent.X.cpu().numpy(), r, args.cpu_budget_s)
 
     if rank == 0:
         out = {
