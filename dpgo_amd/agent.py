@@ -72,6 +72,10 @@ class ExchangePlan:
             self.colour[a] = c
         self.num_colours = (max(self.colour) + 1) if self.num_agents else 0
 
+    def messages_to(self, q: int) -> List[Tuple[int, int]]:
+        """(sender, q) pairs: what the demo's selected robot pulls (MultiRobotExample.cpp:183-204)."""
+        return [(a, q) for a in self.adj[q]]
+
     def messages(self, receivers: Optional[int] = None) -> List[Tuple[int, int]]:
         """(sender, receiver) pairs of one exchange; receivers = colour class that needs fresh
         neighbour poses (None = everyone).  Deterministic order on every rank."""
@@ -84,7 +88,11 @@ class ExchangePlan:
 
 
 class DeviceAgent:
-    """One agent on one GPU: device-resident X, neighbour tile buffer and problem handle."""
+    """One agent on one GPU: device-resident X, neighbour tile buffer and problem handle.
+
+    With enable_acceleration() it also carries the Nesterov state of PGOAgent (XPrev, Y, V, gamma, alpha,
+    restart every `restartInterval` iterations; src/PGOAgent.cpp:880-936) on the device; updateY / updateV
+    are one fused kernel each (linear combination + polar projection, dpgo_axpby_project_device)."""
 
     def __init__(self, graphs: Sequence[PoseGraph], plan: ExchangePlan, my_id: int, X0_tiles: np.ndarray,
                  params: Optional[ROptParameters] = None, device: int = 0):
@@ -114,18 +122,73 @@ class DeviceAgent:
         self.send_buf = {q: torch.empty((len(ix), self.b, self.r), dtype=torch.float64, device=self.device)
                          for q, ix in self.send_idx.items()}
         self.last_result: Optional[ROPTResult] = None
+        self.acceleration = False
+        self.iteration = 0
+        self.tcg_total = 0
 
-    # ---- K11: pack / unpack of public poses (PGOAgent::getSharedPoseDict / updateNeighborPoses) ----
-    def pack(self, q: int):
-        ix, buf = self.send_idx[q], self.send_buf[q]
-        L.check(self.problem._lib.dpgo_gather_tiles_device(self.r, self.d, L.ptr(self.X), L.ptr(ix), len(ix),
+    def enable_acceleration(self, num_robots: int, restart_interval: int = 30) -> None:
+        """PGOAgent::initializeAcceleration (src/PGOAgent.cpp:899-908); restartInterval default 30
+        (include/DPGO/PGOAgent.h:118)."""
+        self.acceleration = True
+        self.num_robots, self.restart_interval = int(num_robots), int(restart_interval)
+        self.XPrev, self.Y, self.V = self.X.clone(), self.X.clone(), self.X.clone()
+        self.gamma = self.alpha = 0.0
+        self.nbr_aux = self.torch.zeros_like(self.nbr)
+        self.send_buf_aux = {q: self.torch.empty_like(b) for q, b in self.send_buf.items()}
+
+    # ---- K11: pack / unpack of public poses (PGOAgent::getSharedPoseDict / getAuxSharedPoseDict) ----
+    def pack(self, q: int, aux: bool = False):
+        ix = self.send_idx[q]
+        buf = self.send_buf_aux[q] if aux else self.send_buf[q]
+        src = self.Y if aux else self.X
+        L.check(self.problem._lib.dpgo_gather_tiles_device(self.r, self.d, L.ptr(src), L.ptr(ix), len(ix),
                                                            L.ptr(buf),
-                                                           self.torch.cuda.current_stream().cuda_stream))
+                                                           self.torch.cuda.current_stream().cuda_stream or None))
         return buf
 
-    def recv_view(self, q: int):
+    def recv_view(self, q: int, aux: bool = False):
         lo, hi = self.plan.recv_range[self.id][q]
-        return self.nbr[lo:hi]
+        return (self.nbr_aux if aux else self.nbr)[lo:hi]
+
+    def _combine_project(self, a, A, b, B, c, Cm, out) -> None:
+        """out = polar(a*A + b*B + c*C) per pose: LiftedSEManifold::project of a linear combination."""
+        L.check(self.problem._lib.dpgo_axpby_project_device(
+            self.r, self.d, self.n, float(a), L.ptr(A), float(b), L.ptr(B), float(c), L.ptr(Cm), 1, L.ptr(out),
+            self.torch.cuda.current_stream().cuda_stream or None))
+
+    def _update_x(self, do_opt: bool, acceleration: bool) -> None:
+        """PGOAgent::updateX (src/PGOAgent.cpp:938-995)."""
+        if not do_opt:
+            if acceleration:
+                self.X.copy_(self.Y)
+            return
+        if self.has_neighbours:
+            self.problem.updateLinearMatrixFromNeighbors(self.nbr_aux if acceleration else self.nbr)
+        if acceleration:
+            self.X.copy_(self.Y)  # X0 = Y (:973-978)
+        self.last_result = self.optimizer.optimizeDevice(self.X)
+        self.tcg_total += self.last_result.tcg_iterations
+
+    def iterate(self, do_opt: bool = True) -> None:
+        """PGOAgent::iterate(bool) (src/PGOAgent.cpp:376-432), INITIALIZED state."""
+        self.iteration += 1
+        if not self.acceleration:
+            self._update_x(do_opt, False)
+            return
+        import math
+        self.XPrev.copy_(self.X)
+        N = self.num_robots
+        self.gamma = (1 + math.sqrt(1 + 4 * N ** 2 * self.gamma ** 2)) / (2 * N)  # updateGamma (:910-914)
+        self.alpha = 1 / (self.gamma * N)  # updateAlpha (:916-920)
+        self._combine_project(1 - self.alpha, self.X, self.alpha, self.V, 0.0, None, self.Y)  # updateY (:922-928)
+        self._update_x(do_opt, True)
+        self._combine_project(1.0, self.V, self.gamma, self.X, -self.gamma, self.Y, self.V)  # updateV (:930-936)
+        if (self.iteration + 1) % self.restart_interval == 0:  # shouldRestart (:880-885)
+            self.X.copy_(self.XPrev)  # restartNesterovAcceleration (:887-897)
+            self._update_x(do_opt, False)
+            self.V.copy_(self.X)
+            self.Y.copy_(self.X)
+            self.gamma = self.alpha = 0.0
 
     def snapshot(self) -> None:
         """Remember the current iterate (benchmarks restore it so that every timed step does the same work)."""
@@ -173,23 +236,24 @@ class RBCDCluster:
         each colour of a chain / ring partition on every GPU, so no GPU idles during a colour phase)."""
         return agent_id // self.agents_per_rank if self.world > 1 else 0
 
-    def exchange(self, receivers: Optional[int] = None) -> None:
-        """Public-pose exchange: every (sender a -> receiver q) message of ExchangePlan.messages.
-        Local pairs are device copies; remote pairs form ONE grouped batch of isend/irecv
-        (ncclGroupStart/End under RCCL), so no ordering between ranks can deadlock."""
+    def exchange(self, receivers: Optional[int] = None, messages=None, aux: bool = False) -> None:
+        """Public-pose exchange: every (sender a -> receiver q) message of ExchangePlan.messages (or the
+        given list); aux = the auxiliary sequence Y (PGOAgent::getAuxSharedPoseDict).  Local pairs are
+        device copies; remote pairs form ONE grouped batch of isend/irecv (ncclGroupStart/End under
+        RCCL), so no ordering between ranks can deadlock."""
         ops, staged = [], []
         dist = None
-        for a, q in self.plan.messages(receivers):
+        for a, q in (messages if messages is not None else self.plan.messages(receivers)):
             a_here, q_here = a in self.agents, q in self.agents
             if a_here and q_here:
-                self.agents[q].recv_view(a).copy_(self.agents[a].pack(q))
+                self.agents[q].recv_view(a, aux).copy_(self.agents[a].pack(q, aux))
             elif a_here:
                 import torch.distributed as dist
-                buf = self.agents[a].pack(q)
+                buf = self.agents[a].pack(q, aux)
                 ops.append(dist.P2POp(dist.isend, buf.cpu() if self.stage else buf, self.owner(q)))
             elif q_here:
                 import torch.distributed as dist
-                view = self.agents[q].recv_view(a)
+                view = self.agents[q].recv_view(a, aux)
                 if self.stage:
                     tmp = view.cpu()
                     staged.append((view, tmp))
@@ -209,6 +273,49 @@ class RBCDCluster:
             for a, agent in self.agents.items():
                 if self.plan.colour[a] == c:
                     agent.update()
+
+    def block_terms(self) -> np.ndarray:
+        """[num_agents, 2] array of (0.5 (xqx + xg), |rgrad_a|^2) per agent, identical on every rank."""
+        self.exchange(None)
+        out = np.zeros((self.plan.num_agents, 2))
+        for a, agent in self.agents.items():
+            xqx, xg, g2 = agent.local_terms()
+            out[a] = [0.5 * (xqx + xg), g2]
+        if self.world > 1:
+            import torch
+            import torch.distributed as dist
+            dev = getattr(next(iter(self.agents.values())), "device", "cpu")
+            t = torch.tensor(out, dtype=torch.float64, device="cpu" if self.stage else dev)
+            dist.all_reduce(t)
+            out = t.cpu().numpy()
+        return out
+
+    def run_greedy(self, max_iters: int = 1000, gradnorm_stop: float = 0.1):
+        """The reference demo's schedule (examples/MultiRobotExample.cpp:170-255): every non-selected agent
+        iterate(false); the selected agent pulls its neighbours' public (and auxiliary) poses and
+        iterate(true); stop when the central gradnorm < 0.1; next = argmax of the block gradnorms.
+        The central gradient block of agent a equals a's local gradient (SURVEY 8c'), so the selection is
+        computed from agent-local evaluations + one tiny all-reduce instead of a central problem."""
+        selected, order, trace = 0, [], []
+        for _ in range(max_iters):
+            for a, agent in self.agents.items():
+                if a != selected:
+                    agent.iterate(False)
+            self.exchange(messages=self.plan.messages_to(selected))
+            accel = any(getattr(ag, "acceleration", False) for ag in self.agents.values())
+            if accel:
+                self.exchange(messages=self.plan.messages_to(selected), aux=True)
+            if selected in self.agents:
+                self.agents[selected].iterate(True)
+            terms = self.block_terms()
+            cost, gn = 2.0 * terms[:, 0].sum(), float(np.sqrt(terms[:, 1].sum()))
+            order.append(selected)
+            trace.append((cost, gn))
+            if gn < gradnorm_stop:
+                break
+            if self.plan.adj[selected]:
+                selected = int(np.argmax(terms[:, 1]))
+        return dict(iterations=len(order), cost=trace[-1][0], gradnorm=trace[-1][1], selected=order, trace=trace)
 
     def central_cost_and_gradnorm(self) -> Tuple[float, float]:
         """Central cost f(X) and Riemannian gradient norm (what examples/MultiRobotExample.cpp:220-225

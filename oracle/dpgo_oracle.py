@@ -892,3 +892,111 @@ def rbcd_coloured(meas: Measurements, n: int, num_robots: int, r: int, X0, sweep
         costs.append(2 * central.f(X))
         gns.append(central.rie_grad_norm(X))
     return X, costs, gns
+
+
+# --------------------------------------------------------------------------
+# The reference demo's schedule: greedy block selection + Nesterov acceleration with restarts
+#   examples/MultiRobotExample.cpp:170-255, src/PGOAgent.cpp:376-432 (iterate), :880-995
+# --------------------------------------------------------------------------
+
+
+class OracleAgent:
+    """The part of PGOAgent the demo exercises: X, XPrev, Y, V, gamma, alpha, iteration counter, the
+    neighbour pose caches (plain and auxiliary) and iterate(doOptimization)."""
+
+    def __init__(self, agent_id, num_robots, Q, shared, r, d, X0, precond, params, acceleration=True,
+                 restart_interval=30, hess_recurrence=False):
+        self.id, self.N, self.Q, self.shared, self.r, self.d = agent_id, num_robots, Q, shared, r, d
+        self.precond, self.params, self.acc = precond, params or ROptParameters(), acceleration
+        self.restart_interval = restart_interval  # PGOAgentParameters::restartInterval (PGOAgent.h:118)
+        self.hess_recurrence = hess_recurrence
+        self.X = X0.copy()
+        self.n = X0.shape[0]
+        need = set()
+        for k in range(shared.m):
+            need.add((int(shared.r2[k]), int(shared.p2[k])) if shared.r1[k] == agent_id else
+                     (int(shared.r1[k]), int(shared.p1[k])))
+        self.need = sorted(need)
+        self.neighbors = sorted({rob for rob, _ in self.need})
+        self.nbr, self.nbr_aux = {}, {}
+        self.iteration = 0
+        self.tcg_total = 0
+        # initializeAcceleration (PGOAgent.cpp:899-908)
+        self.XPrev, self.V, self.Y = self.X.copy(), self.X.copy(), self.X.copy()
+        self.gamma = self.alpha = 0.0
+
+    def _update_x(self, do_opt, acceleration):  # PGOAgent::updateX (:938-995)
+        if not do_opt:
+            if acceleration:
+                self.X = self.Y.copy()
+            return
+        nbr = self.nbr_aux if acceleration else self.nbr
+        G = construct_G(self.n, self.d, self.r, self.shared, self.id, nbr)
+        prob = QuadraticProblem(self.Q, G, self.r, self.d, precond=self.precond)
+        opt = QuadraticOptimizer(prob, self.params, hess_recurrence=self.hess_recurrence)
+        X0 = self.Y if acceleration else self.X
+        self.X = opt.optimize(X0.copy())
+        self.tcg_total += opt.result.tcg_iters
+
+    def iterate(self, do_opt):  # PGOAgent::iterate (:376-432)
+        self.iteration += 1
+        self.XPrev = self.X.copy()
+        if self.acc:
+            N = self.N
+            self.gamma = (1 + math.sqrt(1 + 4 * N ** 2 * self.gamma ** 2)) / (2 * N)  # updateGamma (:910-914)
+            self.alpha = 1 / (self.gamma * N)  # updateAlpha (:916-920)
+            self.Y = polar_project((1 - self.alpha) * self.X + self.alpha * self.V, self.d)  # updateY (:922-928)
+            self._update_x(do_opt, True)
+            self.V = polar_project(self.V + self.gamma * (self.X - self.Y), self.d)  # updateV (:930-936)
+            if (self.iteration + 1) % self.restart_interval == 0:  # shouldRestart (:880-885)
+                self.X = self.XPrev.copy()  # restartNesterovAcceleration (:887-897)
+                self._update_x(do_opt, False)
+                self.V, self.Y = self.X.copy(), self.X.copy()
+                self.gamma = self.alpha = 0.0
+        else:
+            self._update_x(do_opt, False)
+
+
+def multi_robot_example(meas: Measurements, n: int, num_robots: int, r: int, X0, max_iters: int = 1000,
+                        acceleration: bool = True, precond: str = "exact", params: Optional[ROptParameters] = None,
+                        gradnorm_stop: float = 0.1, hess_recurrence: bool = False):
+    """examples/MultiRobotExample.cpp:170-255: per iteration every non-selected agent iterate(false), the selected
+    agent pulls the others' public poses (and aux poses when accelerated) and iterate(true); central cost 2f and
+    gradnorm are evaluated; stop when gradnorm < 0.1; next agent = argmax block gradnorm.
+    Returns dict(X, iterations, cost (2f), gradnorm, tcg_total, selected (list), trace)."""
+    d = meas.d
+    ranges, per = partition_contiguous(meas, n, num_robots)
+    agents = []
+    for a in range(num_robots):
+        s, e = ranges[a]
+        priv = Measurements.concat([per[a]["odometry"], per[a]["private"]])
+        Qa = construct_Q(e - s, d, priv, per[a]["shared"], my_id=a)
+        agents.append(OracleAgent(a, num_robots, Qa, per[a]["shared"], r, d, X0[s:e], precond, params,
+                                  acceleration=acceleration, hess_recurrence=hess_recurrence))
+    central = QuadraticProblem(construct_Q(n, d, meas), None, r, d)
+    selected, order, trace = 0, [], []
+    X = X0.copy()
+    for it in range(max_iters):
+        sel = agents[selected]
+        for ag in agents:
+            if ag.id != selected:
+                ag.iterate(False)
+        for rob, fr in sel.need:  # :183-204
+            sel.nbr[(rob, fr)] = agents[rob].X[fr].copy()
+            if acceleration:
+                sel.nbr_aux[(rob, fr)] = agents[rob].Y[fr].copy()
+        sel.iterate(True)
+        for ag in agents:
+            s, e = ranges[ag.id]
+            X[s:e] = ag.X
+        RG = central.rie_grad(X)
+        gn = float(np.linalg.norm(RG))
+        cost = 2 * central.f(X)
+        order.append(selected)
+        trace.append((cost, gn))
+        if gn < gradnorm_stop:  # :229
+            break
+        if sel.neighbors:  # :234-247
+            selected = int(np.argmax([np.linalg.norm(RG[s:e]) for s, e in ranges]))
+    return dict(X=X, iterations=len(order), cost=trace[-1][0], gradnorm=trace[-1][1],
+                tcg_total=sum(a.tcg_total for a in agents), selected=order, trace=trace)

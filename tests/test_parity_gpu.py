@@ -370,3 +370,36 @@ def test_external_stream_ordering_is_deterministic(oracle):
     for o in outs[1:]:
         assert o[:3] == outs[0][:3]
         assert torch.equal(o[3], outs[0][3])
+
+
+def test_greedy_accelerated_schedule_matches_oracle(oracle):
+    """BASELINE configs[0]: smallGrid3D, 5 agents, r = 5 with the reference demo's schedule (greedy selection,
+    Nesterov acceleration, restart every 30 iterations; examples/MultiRobotExample.cpp:170-255,
+    src/PGOAgent.cpp:376-432).  Device agents (Y, V on the GPU, updateY / updateV through the polar-projection
+    kernel) vs the oracle driver at matched settings: same selection sequence, same stop iteration, same cost.
+    The oracle in the reference configuration (exact preconditioner) stops at iteration index 86 with
+    2f = 1025.39835."""
+    import dpgo_amd
+    from dpgo_amd.agent import DeviceAgent, ExchangePlan, RBCDCluster, build_pose_graphs
+    r, robots = 5, 5
+    om, n = oracle.read_g2o(os.path.join(DATA, "smallGrid3D.g2o"))
+    d = om.d
+    X0 = oracle.lift(oracle.chordal_initialization(om, n), r)
+    ref = oracle.multi_robot_example(om, n, robots, r, X0, precond="exact")
+    assert ref["iterations"] == 87 and abs(ref["cost"] - 1025.39835) < 5e-6 and ref["gradnorm"] < 0.1
+    want = oracle.multi_robot_example(om, n, robots, r, X0, precond="jacobi", hess_recurrence=True)
+    ranges, graphs = build_pose_graphs(to_product_measurements(om), n, robots, r)
+    plan = ExchangePlan(graphs)
+    agents = {a: DeviceAgent(graphs, plan, a, X0[ranges[a][0]:ranges[a][1]], dpgo_amd.ROptParameters())
+              for a in range(robots)}
+    for ag in agents.values():
+        ag.enable_acceleration(robots)
+    got = RBCDCluster(plan, agents).run_greedy()
+    assert got["selected"] == want["selected"]
+    assert got["iterations"] == want["iterations"]
+    assert abs(got["cost"] - want["cost"]) <= 1e-9 * want["cost"]
+    assert abs(got["gradnorm"] - want["gradnorm"]) <= 1e-5 * want["gradnorm"]
+    assert sum(a.tcg_total for a in agents.values()) == want["tcg_total"]
+    X = np.concatenate([agents[a].X.cpu().numpy() for a in range(robots)], axis=0)
+    assert relerr(X, want["X"]) < 1e-7
+    assert abs(got["cost"] - ref["cost"]) <= 1e-6 * ref["cost"]  # same optimum as the reference configuration
