@@ -119,6 +119,14 @@ struct dpgo_problem_s {
   unsigned long long* hflag = nullptr;  // pinned, host-coherent: device-published tCG progress word
   unsigned gen = 0;
   bool saw_rtr_stop = false;  // set from the progress word in just-in-time mode
+  // re-weightable edges (GNC)
+  int em = 0;
+  int32_t *e_p1 = nullptr, *e_p2 = nullptr, *c_ptr = nullptr, *c_edge = nullptr;
+  double *e_R = nullptr, *e_t = nullptr, *e_kappa = nullptr, *e_tau = nullptr, *e_w = nullptr, *e_rsq = nullptr,
+         *q_base = nullptr;
+  uint8_t *e_fixed = nullptr, *c_kind = nullptr;
+  int* e_counts = nullptr;
+  EdgeDev edges() const { return EdgeDev{e_p1, e_p2, e_R, e_t, e_kappa, e_tau, e_fixed, e_w, e_rsq, em}; }
   int cur = 0;
   size_t vec_bytes() const { return (size_t)n * T * sizeof(double); }
   double* pE() const { return partials; }
@@ -471,6 +479,44 @@ int d2h(dpgo_problem_s* p, double* dst, const double* src) {
 
 }  // namespace
 
+namespace {
+int free_edges(dpgo_problem_s* p) {
+  void* ptrs[] = {p->e_p1, p->e_p2, p->c_ptr, p->c_edge, p->e_R, p->e_t, p->e_kappa, p->e_tau, p->e_w, p->e_rsq,
+                  p->q_base, p->e_fixed, p->c_kind, p->e_counts};
+  for (void* q : ptrs)
+    if (q) (void)hipFree(q);
+  p->e_p1 = p->e_p2 = p->c_ptr = p->c_edge = nullptr;
+  p->e_R = p->e_t = p->e_kappa = p->e_tau = p->e_w = p->e_rsq = p->q_base = nullptr;
+  p->e_fixed = p->c_kind = nullptr;
+  p->e_counts = nullptr;
+  p->em = 0;
+  return DPGO_OK;
+}
+template <class Tp>
+int upload(Tp** dst, const Tp* src, size_t count, hipStream_t s) {
+  HIPC(hipMalloc(dst, sizeof(Tp) * (count > 0 ? count : 1)));
+  if (count > 0) HIPC(hipMemcpyAsync(*dst, src, sizeof(Tp) * count, hipMemcpyHostToDevice, s));
+  return DPGO_OK;
+}
+int rebuild_Q_from_weights(dpgo_problem_s* p, const double* base, double sign, double* out) {
+  const int g = std::max(1, std::min(kMaxGrid, (p->Q.nnzb + kBlock - 1) / kBlock));
+  if (p->d == 2)
+    hipLaunchKernelGGL(k_rebuild_Q<2>, dim3(g), dim3(kBlock), 0, p->stream, p->edges(), p->c_ptr, p->c_edge, p->c_kind,
+                       base, sign, out, p->Q.nnzb);
+  else
+    hipLaunchKernelGGL(k_rebuild_Q<3>, dim3(g), dim3(kBlock), 0, p->stream, p->edges(), p->c_ptr, p->c_edge, p->c_kind,
+                       base, sign, out, p->Q.nnzb);
+  HIPC(hipGetLastError());
+  return DPGO_OK;
+}
+int refresh_after_weights(dpgo_problem_s* p) {
+  CHK(rebuild_Q_from_weights(p, p->q_base, 1.0, p->Q.vals));
+  const double s = p->dinv_shift > 0 ? p->dinv_shift : 1e-1;
+  p->dinv_shift = -1.0;  // clearQuadraticMatrix also drops the preconditioner (src/PoseGraph.cpp:352-355)
+  return build_dinv(p, s);
+}
+}  // namespace
+
 // =====================================================================================
 extern "C" {
 
@@ -566,6 +612,7 @@ int dpgo_problem_destroy(dpgo_problem_t p) {
   if (p->own_stream) (void)hipStreamSynchronize(p->own_stream);
   free_bsr(p->Q);
   free_bsr(p->C);
+  free_edges(p);
   double* vecs[] = {p->x1, p->x2, p->g1, p->g2, p->eta, p->delta, p->delta2, p->Hd, p->rr, p->z, p->G, p->G0,
                     p->S1, p->S2, p->dinv, p->partials};
   for (auto v : vecs)
@@ -654,6 +701,121 @@ int dpgo_problem_set_Q_csr(dpgo_problem_t p, const int32_t* outer, const int32_t
     rowptr[i + 1] = (int32_t)colidx.size();
   }
   return dpgo_problem_set_Q_bsr(p, (int)colidx.size(), rowptr.data(), colidx.data(), vals.data());
+}
+
+int dpgo_problem_set_reweightable_edges(dpgo_problem_t p, int m, const int32_t* p1, const int32_t* p2, const double* R,
+                                        const double* t, const double* kappa, const double* tau, const double* weight,
+                                        const uint8_t* fixed_weight) {
+  CHK(check_ready(p));
+  if (m < 0 || (m > 0 && (!p1 || !p2 || !R || !t || !kappa || !tau || !weight || !fixed_weight)))
+    return fail(DPGO_ERR_INVALID, "null edge arrays");
+  const int n = p->n, d = p->d, nnzb = p->Q.nnzb;
+  // host copy of the pattern to locate the slots
+  std::vector<int32_t> rowptr(n + 1), colidx(nnzb);
+  HIPC(hipMemcpy(rowptr.data(), p->Q.rowptr, sizeof(int32_t) * (n + 1), hipMemcpyDeviceToHost));
+  HIPC(hipMemcpy(colidx.data(), p->Q.colidx, sizeof(int32_t) * nnzb, hipMemcpyDeviceToHost));
+  auto slot = [&](int i, int j) -> int {
+    const int32_t* b = colidx.data() + rowptr[i];
+    const int32_t* e = colidx.data() + rowptr[i + 1];
+    const int32_t* it = std::lower_bound(b, e, (int32_t)j);
+    return (it != e && *it == j) ? (int)(it - colidx.data()) : -1;
+  };
+  std::vector<std::vector<std::pair<int, uint8_t>>> lists(nnzb);
+  for (int e = 0; e < m; ++e) {
+    const int i = p1[e], j = p2[e];
+    if (i < 0 || i >= n || j < 0 || j >= n || i == j) return fail(DPGO_ERR_INVALID, "edge endpoint out of range");
+    const int sii = slot(i, i), sjj = slot(j, j), sij = slot(i, j), sji = slot(j, i);
+    if (sii < 0 || sjj < 0 || sij < 0 || sji < 0)
+      return fail(DPGO_ERR_STATE, "edge does not fit the block pattern of Q");
+    lists[sii].push_back({e, 0});
+    lists[sjj].push_back({e, 1});
+    lists[sij].push_back({e, 2});
+    lists[sji].push_back({e, 3});
+  }
+  std::vector<int32_t> cptr(nnzb + 1, 0), cedge;
+  std::vector<uint8_t> ckind;
+  for (int s = 0; s < nnzb; ++s) {
+    for (auto& pr : lists[s]) {
+      cedge.push_back(pr.first);
+      ckind.push_back(pr.second);
+    }
+    cptr[s + 1] = (int32_t)cedge.size();
+  }
+  CHK(free_edges(p));
+  p->em = m;
+  CHK(upload(&p->e_p1, p1, (size_t)m, p->stream));
+  CHK(upload(&p->e_p2, p2, (size_t)m, p->stream));
+  CHK(upload(&p->e_R, R, (size_t)m * d * d, p->stream));
+  CHK(upload(&p->e_t, t, (size_t)m * d, p->stream));
+  CHK(upload(&p->e_kappa, kappa, (size_t)m, p->stream));
+  CHK(upload(&p->e_tau, tau, (size_t)m, p->stream));
+  CHK(upload(&p->e_w, weight, (size_t)m, p->stream));
+  CHK(upload(&p->e_fixed, fixed_weight, (size_t)m, p->stream));
+  CHK(upload(&p->c_ptr, cptr.data(), cptr.size(), p->stream));
+  CHK(upload(&p->c_edge, cedge.data(), cedge.size(), p->stream));
+  CHK(upload(&p->c_kind, ckind.data(), ckind.size(), p->stream));
+  HIPC(hipMalloc(&p->e_rsq, sizeof(double) * (m > 0 ? m : 1)));
+  HIPC(hipMalloc(&p->e_counts, sizeof(int) * 4));
+  HIPC(hipMalloc(&p->q_base, sizeof(double) * (size_t)nnzb * p->b * p->b));
+  // base = Q(current weights) - sum of the private-edge contributions at those weights
+  CHK(rebuild_Q_from_weights(p, p->Q.vals, -1.0, p->q_base));
+  HIPC(hipStreamSynchronize(p->stream));
+  return DPGO_OK;
+}
+
+int dpgo_problem_gnc_reweight_device(dpgo_problem_t p, const double* X_dev, double mu, double barc, double w_tol,
+                                     int update, int counts[3], double* max_rsq) {
+  CHK(check_ready(p));
+  if (!p->e_w) return fail(DPGO_ERR_STATE, "re-weightable edges not set");
+  if (!X_dev) return fail(DPGO_ERR_INVALID, "null X");
+  if (update && !(mu > 0.0)) return fail(DPGO_ERR_INVALID, "GNC mu must be positive");
+  HIPC(hipMemsetAsync(p->e_counts, 0, sizeof(int) * 4, p->stream));
+  const int g = std::max(1, std::min(kMaxGrid, (p->em + kBlock - 1) / kBlock));
+  DISPATCH(p->d, p->r, hipLaunchKernelGGL((k_edge_weights<D, R>), dim3(g), dim3(kBlock), 0, p->stream, p->edges(), X_dev,
+                                          mu, barc, w_tol, update, p->e_counts));
+  HIPC(hipGetLastError());
+  if (update) CHK(refresh_after_weights(p));
+  int h[4] = {0, 0, 0, 0};
+  HIPC(hipMemcpyAsync(h, p->e_counts, sizeof(int) * 4, hipMemcpyDeviceToHost, p->stream));
+  std::vector<double> rs;
+  if (max_rsq) {
+    rs.resize(p->em > 0 ? p->em : 1, 0.0);
+    if (p->em > 0)
+      HIPC(hipMemcpyAsync(rs.data(), p->e_rsq, sizeof(double) * p->em, hipMemcpyDeviceToHost, p->stream));
+  }
+  HIPC(hipStreamSynchronize(p->stream));
+  if (counts) {
+    counts[0] = h[0];
+    counts[1] = h[1];
+    counts[2] = h[2];
+  }
+  if (max_rsq) {
+    double mx = 0.0;
+    for (int e = 0; e < p->em; ++e) mx = std::max(mx, rs[e]);
+    *max_rsq = mx;
+  }
+  return DPGO_OK;
+}
+
+int dpgo_problem_set_edge_weights(dpgo_problem_t p, const double* weight_host) {
+  CHK(check_ready(p));
+  if (!p->e_w) return fail(DPGO_ERR_STATE, "re-weightable edges not set");
+  if (!weight_host) return fail(DPGO_ERR_INVALID, "null weights");
+  if (p->em > 0) HIPC(hipMemcpyAsync(p->e_w, weight_host, sizeof(double) * p->em, hipMemcpyHostToDevice, p->stream));
+  CHK(refresh_after_weights(p));
+  HIPC(hipStreamSynchronize(p->stream));
+  return DPGO_OK;
+}
+
+int dpgo_problem_get_edge_weights(dpgo_problem_t p, double* weight_host, double* rsq_host) {
+  CHK(check_ready(p));
+  if (!p->e_w) return fail(DPGO_ERR_STATE, "re-weightable edges not set");
+  if (weight_host && p->em > 0)
+    HIPC(hipMemcpyAsync(weight_host, p->e_w, sizeof(double) * p->em, hipMemcpyDeviceToHost, p->stream));
+  if (rsq_host && p->em > 0)
+    HIPC(hipMemcpyAsync(rsq_host, p->e_rsq, sizeof(double) * p->em, hipMemcpyDeviceToHost, p->stream));
+  HIPC(hipStreamSynchronize(p->stream));
+  return DPGO_OK;
 }
 
 int dpgo_problem_update_Q_values(dpgo_problem_t p, const double* vals) {

@@ -63,6 +63,10 @@ SIGNATURES = {
     "dpgo_problem_set_Q_bsr": ([_P, _I, _P, _P, _P], _I),
     "dpgo_problem_set_Q_csr": ([_P, _P, _P, _P], _I),
     "dpgo_problem_update_Q_values": ([_P, _P], _I),
+    "dpgo_problem_set_reweightable_edges": ([_P, _I, _P, _P, _P, _P, _P, _P, _P, _P], _I),
+    "dpgo_problem_gnc_reweight_device": ([_P, _P, _D, _D, _D, _I, C.POINTER(C.c_int * 3), C.POINTER(_D)], _I),
+    "dpgo_problem_set_edge_weights": ([_P, _P], _I),
+    "dpgo_problem_get_edge_weights": ([_P, _P, _P], _I),
     "dpgo_problem_set_G": ([_P, _P], _I),
     "dpgo_problem_set_G_device": ([_P, _P], _I),
     "dpgo_problem_set_G_coupling": ([_P, _I, _I, _P, _P, _P, _P], _I),

@@ -131,7 +131,9 @@ class PoseGraph:
             if key not in seen:
                 seen.add(key)
                 first.append(e)
-        m = m.select(np.array(first, dtype=np.int64))
+        kept_in_selected = np.array(first, dtype=np.int64)
+        self.kept_index = np.nonzero(keep)[0][kept_in_selected]  # positions in the caller's array
+        m = m.select(kept_in_selected)
         self._meas = m
         mine1 = m.r1 == self.id_
         mine2 = m.r2 == self.id_

@@ -132,6 +132,26 @@ int dpgo_problem_set_Q_csr(dpgo_problem_t h, const int32_t* outer, const int32_t
 /* same pattern, new values (GNC re-weighting: PGOAgent.cpp:1122 clearDataMatrices path) */
 int dpgo_problem_update_Q_values(dpgo_problem_t h, const double* vals);
 
+/* ---- robust re-weighting on the device (GNC): replaces the "rebuild PoseGraph + constructQ + re-factorise"
+ * loop of solveRobustPGO (src/DPGO_solver.cpp:335-412) and PGOAgent::updateMeasurementWeights
+ * (src/PGOAgent.cpp:1104-1142), whose pattern-preserving part is values-only.
+ * set_reweightable_edges: the private edges (both poses owned by this agent; R row-major per edge) whose
+ * weights may change, with their CURRENT weights (the ones Q was built with) and fixedWeight flags
+ * (RelativeSEMeasurement.h:44-47).  Call after dpgo_problem_set_Q_*.  Everything else in Q (shared-edge
+ * diagonal terms, priors) is kept as a constant base. */
+int dpgo_problem_set_reweightable_edges(dpgo_problem_t h, int m, const int32_t* p1, const int32_t* p2,
+                                        const double* R, const double* t, const double* kappa, const double* tau,
+                                        const double* weight, const uint8_t* fixed_weight);
+/* Residuals rSq_e = computeMeasurementError (src/DPGO_utils.cpp:501-507) at the device iterate X_dev; if
+ * update != 0 the non-fixed weights become RobustCost::weight(sqrt(rSq)) for GNC_TLS with the given mu and
+ * barc (src/DPGO_robust.cpp:80-92) and Q's values + the preconditioner are rebuilt on the device.
+ * counts[3] = {inliers, outliers, undecided} among non-fixed edges (w_tol as in DPGO_solver.cpp:340).
+ * max_rsq (optional) = max residual over all edges (used for muInit, DPGO_solver.cpp:358). */
+int dpgo_problem_gnc_reweight_device(dpgo_problem_t h, const double* X_dev, double mu, double barc, double w_tol,
+                                     int update, int counts[3], double* max_rsq);
+int dpgo_problem_set_edge_weights(dpgo_problem_t h, const double* weight_host);   /* + rebuild Q, preconditioner */
+int dpgo_problem_get_edge_weights(dpgo_problem_t h, double* weight_host, double* rsq_host /* may be NULL */);
+
 /* PoseGraph::linearMatrix() (include/DPGO/PoseGraph.h:171): dense r x (d+1)n; NULL = zero */
 int dpgo_problem_set_G(dpgo_problem_t h, const double* G_host);
 int dpgo_problem_set_G_device(dpgo_problem_t h, const double* G_dev);

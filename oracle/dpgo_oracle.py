@@ -1000,3 +1000,57 @@ def multi_robot_example(meas: Measurements, n: int, num_robots: int, r: int, X0,
             selected = int(np.argmax([np.linalg.norm(RG[s:e]) for s, e in ranges]))
     return dict(X=X, iterations=len(order), cost=trace[-1][0], gradnorm=trace[-1][1],
                 tcg_total=sum(a.tcg_total for a in agents), selected=order, trace=trace)
+
+
+# --------------------------------------------------------------------------
+# Robust PGO (GNC-TLS) -- src/DPGO_robust.cpp:54-134, src/DPGO_solver.cpp:335-412
+# --------------------------------------------------------------------------
+
+
+def gnc_tls_weight(r, mu, barc):
+    """RobustCost::weight for GNC_TLS (src/DPGO_robust.cpp:80-92), vectorised."""
+    r = np.asarray(r, dtype=np.float64)
+    rSq, bSq = r * r, barc * barc
+    upper, lower = (mu + 1) / mu * bSq, mu / (mu + 1) * bSq
+    with np.errstate(divide="ignore", invalid="ignore"):
+        mid = np.sqrt(bSq * mu * (mu + 1) / rSq) - mu
+    return np.where(rSq >= upper, 0.0, np.where(rSq <= lower, 1.0, mid))
+
+
+def solve_robust_pgo(meas: Measurements, n: int, T0, opt_params: Optional[ROptParameters] = None, barc: float = 5.0,
+                     mu_step: float = 1.4, max_iters: int = 20, precond: str = "exact", hess_recurrence: bool = False):
+    """solveRobustPGO restated (src/DPGO_solver.cpp:335-412): rank r = d; every solve restarts from T0;
+    weights of non-fixed edges from GNC-TLS; stop when no weight is undecided.  meas.weight is updated in
+    place.  Returns (T, info)."""
+    d = meas.d
+    prm = opt_params or ROptParameters()
+    w_tol = 1e-8
+
+    def solve():
+        Q = construct_Q(n, d, meas)
+        opt = QuadraticOptimizer(QuadraticProblem(Q, None, d, d, precond=precond), prm, hess_recurrence=hess_recurrence)
+        T = opt.optimize(T0.copy())
+        return T, opt.result
+
+    T, _ = solve()
+    meas.weight[:] = 1.0
+    rsq = measurement_error(meas, T)
+    muInit = barc * barc / (2 * rsq.max() - barc * barc)
+    info = dict(muInit=muInit, gnc_iterations=0, history=[])
+    if muInit > 0:
+        mu = muInit
+        for it in range(max_iters):
+            T, res = solve()
+            rsq = measurement_error(meas, T)
+            w = gnc_tls_weight(np.sqrt(rsq), mu, barc)
+            meas.weight[~meas.fixed] = w[~meas.fixed]
+            nf = meas.weight[~meas.fixed]
+            n_out = int((nf < w_tol).sum()); n_in = int((nf > 1 - w_tol).sum()); n_und = len(nf) - n_in - n_out
+            info["history"].append(dict(mu=mu, inliers=n_in, outliers=n_out, undecided=n_und, f=res.fOpt))
+            info["gnc_iterations"] = it + 1
+            if n_und == 0:
+                break
+            mu = mu_step * mu  # RobustCost::update (the GNCMaxNumIters guard cannot fire inside this loop)
+    T, res = solve()
+    info["fOpt"] = res.fOpt
+    return T, info

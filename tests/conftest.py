@@ -56,5 +56,6 @@ def matrix_to_tiles(X, d):
 def to_product_measurements(om):
     """oracle Measurements -> dpgo_amd.RelativeSEMeasurements"""
     import dpgo_amd
-    return dpgo_amd.RelativeSEMeasurements(om.d, om.r1, om.p1, om.r2, om.p2, om.R, om.t, om.kappa, om.tau,
-                                           om.weight, om.fixed)
+    c = np.copy  # no aliasing: solveRobustPGO updates the product-side weights in place
+    return dpgo_amd.RelativeSEMeasurements(om.d, c(om.r1), c(om.p1), c(om.r2), c(om.p2), c(om.R), c(om.t), c(om.kappa),
+                                           c(om.tau), c(om.weight), c(om.fixed))

@@ -403,3 +403,68 @@ def test_greedy_accelerated_schedule_matches_oracle(oracle):
     X = np.concatenate([agents[a].X.cpu().numpy() for a in range(robots)], axis=0)
     assert relerr(X, want["X"]) < 1e-7
     assert abs(got["cost"] - ref["cost"]) <= 1e-6 * ref["cost"]  # same optimum as the reference configuration
+
+
+def test_robust_pgo_known_answer_on_device(oracle):
+    """tests/testPGO.cpp:193-271 (testRobustPGO) through the device path: solveRobustPGO with GNC-TLS
+    (barc = 7, tol 1e-1, 50 RTR iterations, odometry start) classifies the inlier (w = 1) and the outlier
+    (w = 0) within 1e-6; residual / weight kernel (K10) and the on-device rebuild of Q's values (K9)."""
+    import dpgo_amd
+    from dpgo_amd.robust import RobustCostParameters, solveRobustPGO, solveRobustPGOParams
+    from test_oracle import robust_chain_problem
+    om, n, T0 = robust_chain_problem(oracle)
+    pm = to_product_measurements(om)
+    prm = solveRobustPGOParams(opt_params=dpgo_amd.ROptParameters(gradnorm_tol=1e-1, RTR_iterations=50),
+                               robust_params=RobustCostParameters("GNC_TLS", GNCBarc=7.0))
+    T, info = solveRobustPGO(pm, n, prm, T0=T0)
+    assert abs(pm.weight[3] - 1) <= 1e-6 and abs(pm.weight[4]) <= 1e-6
+    assert np.all(pm.weight[:3] == 1.0)
+    To, info_o = oracle.solve_robust_pgo(om, n, T0, oracle.ROptParameters(gradnorm_tol=1e-1, RTR_iterations=50),
+                                         barc=7.0, precond="jacobi", hess_recurrence=True)
+    assert info["gnc_iterations"] == info_o["gnc_iterations"]
+    assert abs(info["muInit"] - info_o["muInit"]) <= 1e-6 * abs(info_o["muInit"])
+    assert relerr(T, To) < 1e-6
+
+
+def test_gnc_reweighting_with_outliers_matches_oracle(oracle):
+    """BASELINE configs[4] flavour (single agent): kitti_00 (2-D, EDGE_SE2) plus 25 synthetic outlier loop
+    closures; GNC-TLS (barc = 5, mu step 1.4, reference defaults).  Device vs oracle at matched settings:
+    the same edges are rejected, weights agree, Q rebuilt on the device equals Q rebuilt from the weights on
+    the host, and every injected outlier ends with weight 0."""
+    import dpgo_amd
+    from dpgo_amd.robust import RobustCostParameters, solveRobustPGO, solveRobustPGOParams
+    om, n = oracle.read_g2o(os.path.join(DATA, "kitti_00.g2o"))
+    rng = np.random.default_rng(11)
+    k = 25
+    i = rng.integers(0, n - 600, k)
+    j = i + rng.integers(300, 600, k)
+    th = rng.uniform(-np.pi, np.pi, k)
+    Rk = np.stack([np.array([[np.cos(a), -np.sin(a)], [np.sin(a), np.cos(a)]]) for a in th])
+    lc = np.nonzero(~om.fixed)[0]
+    kap, tau = np.median(om.kappa[lc]), np.median(om.tau[lc])
+    z = np.zeros(k, dtype=np.int64)
+    out = oracle.Measurements(2, z, i, z.copy(), j, Rk, rng.uniform(-5, 5, (k, 2)), np.full(k, kap), np.full(k, tau),
+                              np.ones(k), np.zeros(k, dtype=bool))
+    allm = oracle.Measurements.concat([om, out])
+    T0 = oracle.chordal_initialization(om, n)  # initial guess from the clean graph (same on both sides)
+    opt_o = oracle.ROptParameters(RTR_iterations=10, RTR_tCG_iterations=100)
+    To, info_o = oracle.solve_robust_pgo(allm, n, T0, opt_o, barc=5.0, precond="jacobi", hess_recurrence=True,
+                                         max_iters=20)
+    pm = to_product_measurements(oracle.Measurements.concat([om, out]))
+    pm.weight[:] = 1.0
+    prm = solveRobustPGOParams(opt_params=dpgo_amd.ROptParameters(RTR_iterations=10, RTR_tCG_iterations=100,
+                                                                  time_bound_s=60.0),
+                               robust_params=RobustCostParameters("GNC_TLS"))
+    T, info = solveRobustPGO(pm, n, prm, T0=T0)
+    assert info["gnc_iterations"] == info_o["gnc_iterations"]
+    assert np.array_equal(pm.weight < 1e-8, allm.weight < 1e-8)
+    assert np.abs(pm.weight - allm.weight).max() < 1e-5
+    assert np.all(pm.weight[-k:] < 1e-8)  # every injected outlier is rejected
+    assert np.all(pm.weight[om.fixed.nonzero()[0]] == 1.0)
+    assert abs(info["fOpt"] - info_o["fOpt"]) <= 1e-6 * abs(info_o["fOpt"])
+    # values-only rebuild (K9) == full host construction with the final weights
+    pg = dpgo_amd.PoseGraph(0, 2, 2)
+    pg.setMeasurements(pm)
+    Qh = oracle.construct_Q(n, 2, allm)
+    rp, ci, v = pg.quadraticMatrix()
+    assert np.array_equal(ci, Qh.colidx) and np.abs(v - Qh.vals).max() <= 1e-9 * np.abs(Qh.vals).max()
