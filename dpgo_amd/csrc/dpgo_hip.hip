@@ -112,7 +112,7 @@ struct dpgo_problem_s {
   double dinv_shift = -1.0;
   // work vectors
   double *x1 = nullptr, *x2 = nullptr, *g1 = nullptr, *g2 = nullptr, *eta = nullptr, *delta = nullptr,
-         *delta2 = nullptr, *Hd = nullptr, *rr = nullptr, *z = nullptr, *S1 = nullptr, *S2 = nullptr;
+         *Hd = nullptr, *rr = nullptr, *z = nullptr, *S1 = nullptr, *S2 = nullptr;
   double* partials = nullptr;  // 5 regions of kMaxGrid*kNP
   DevState* dstate = nullptr;  // 2 slots
   DevState* hstate = nullptr;  // pinned
@@ -245,20 +245,35 @@ int launch_hess(dpgo_problem_s* p, const double* X, const double* S, const doubl
 
 int launch_tcg_update(dpgo_problem_s* p, const double* dinv, int first) {
   const int g = p->grid();
-  DISPATCH(p->d, p->r,
-           hipLaunchKernelGGL((k_tcg_update<D, R>), dim3(g), dim3(kBlock), 0, p->stream, p->x1, p->g1, dinv,
-                              p->delta, p->Hd, p->eta, p->rr, p->z, p->pA(), p->grid_s(), p->pB(), p->dstate + p->cur,
-                              p->dstate + (p->cur ^ 1), first, p->n, p->hflag, p->gen));
+  DISPATCH(p->d, p->r, {
+    if constexpr (Span<D, R, 1>::kOk)
+      hipLaunchKernelGGL((k_tcg_update_span<D, R>), dim3(g), dim3(kBlock), 0, p->stream, p->x1, p->g1, dinv, p->delta,
+                         p->Hd, p->eta, p->rr, p->z, p->pA(), p->grid_s(), p->pB(), p->dstate + p->cur,
+                         p->dstate + (p->cur ^ 1), first, p->n, p->hflag, p->gen);
+    else
+      hipLaunchKernelGGL((k_tcg_update<D, R>), dim3(g), dim3(kBlock), 0, p->stream, p->x1, p->g1, dinv, p->delta,
+                         p->Hd, p->eta, p->rr, p->z, p->pA(), p->grid_s(), p->pB(), p->dstate + p->cur,
+                         p->dstate + (p->cur ^ 1), first, p->n, p->hflag, p->gen);
+  });
   HIPC(hipGetLastError());
   p->cur ^= 1;
   return DPGO_OK;
 }
 
 // fused direction update + Riemannian Hessian-vector product (one tCG step)
+// the tCG-step kernel: span variant whenever the pose tile size is even (all 3-D cases)
+#define LAUNCH_TCG_HESS(p, SIN, SOUT, FIRST, HFLAG, GEN)                                                          \
+  do {                                                                                                            \
+    if constexpr (Span<D, R, 1>::kOk)                                                                             \
+      LAUNCH_SPLIT(p, k_tcg_hess_span, (p)->grid_s(), (p)->Q.dev(), (p)->x1, (p)->S1, (p)->z, (p)->delta, (p)->Hd, \
+                   (p)->pB(), (p)->grid(), (p)->pA(), SIN, SOUT, FIRST, (p)->n, HFLAG, GEN);                      \
+    else                                                                                                          \
+      LAUNCH_SPLIT(p, k_tcg_hess, (p)->grid_s(), (p)->Q.dev(), (p)->x1, (p)->S1, (p)->z, (p)->delta, (p)->Hd,      \
+                   (p)->pB(), (p)->grid(), (p)->pA(), SIN, SOUT, FIRST, (p)->n, HFLAG, GEN);                      \
+  } while (0)
+
 int launch_tcg_hess(dpgo_problem_s* p, int first) {
-  DISPATCH(p->d, p->r,
-           LAUNCH_SPLIT(p, k_tcg_hess, p->grid_s(), p->Q.dev(), p->x1, p->S1, p->z, p->delta, p->Hd, p->pB(), p->grid(),
-                        p->pA(), p->dstate + p->cur, p->dstate + (p->cur ^ 1), first, p->n, p->hflag, p->gen));
+  DISPATCH(p->d, p->r, LAUNCH_TCG_HESS(p, p->dstate + p->cur, p->dstate + (p->cur ^ 1), first, p->hflag, p->gen));
   HIPC(hipGetLastError());
   p->cur ^= 1;
   return DPGO_OK;
@@ -581,7 +596,7 @@ int dpgo_problem_create(dpgo_problem_t* out, int r, int d, int n, int device) {
     HIPC(hipStreamCreateWithFlags(&p->own_stream, hipStreamNonBlocking));
     p->stream = p->own_stream;
     const size_t vb = p->vec_bytes();
-    double** vecs[] = {&p->x1, &p->x2, &p->g1, &p->g2, &p->eta, &p->delta, &p->delta2, &p->Hd, &p->rr, &p->z, &p->G, &p->G0};
+    double** vecs[] = {&p->x1, &p->x2, &p->g1, &p->g2, &p->eta, &p->delta, &p->Hd, &p->rr, &p->z, &p->G, &p->G0};
     for (auto v : vecs) {
       HIPC(hipMalloc(v, vb));
       HIPC(hipMemsetAsync(*v, 0, vb, p->stream));
@@ -613,7 +628,7 @@ int dpgo_problem_destroy(dpgo_problem_t p) {
   free_bsr(p->Q);
   free_bsr(p->C);
   free_edges(p);
-  double* vecs[] = {p->x1, p->x2, p->g1, p->g2, p->eta, p->delta, p->delta2, p->Hd, p->rr, p->z, p->G, p->G0,
+  double* vecs[] = {p->x1, p->x2, p->g1, p->g2, p->eta, p->delta, p->Hd, p->rr, p->z, p->G, p->G0,
                     p->S1, p->S2, p->dinv, p->partials};
   for (auto v : vecs)
     if (v) (void)hipFree(v);
@@ -1034,9 +1049,7 @@ int dpgo_bench_hess(dpgo_problem_t p, int reps, int warmup, double* avg_ms) {
   p->hstate->max_inner = 1 << 30;
   CHK(push_state(p));
   auto launch = [&]() -> int {
-    DISPATCH(p->d, p->r,
-             LAUNCH_SPLIT(p, k_tcg_hess, p->grid_s(), p->Q.dev(), p->x1, p->S1, p->z, p->delta, p->Hd, p->pB(),
-                          p->grid(), p->pA(), p->dstate, p->dstate + 1, 0, p->n, (unsigned long long*)nullptr, 0u));
+    DISPATCH(p->d, p->r, LAUNCH_TCG_HESS(p, p->dstate, p->dstate + 1, 0, (unsigned long long*)nullptr, 0u));
     HIPC(hipGetLastError());
     return DPGO_OK;
   };

@@ -288,10 +288,29 @@ __device__ __forceinline__ void store_col(double* __restrict__ p, const double (
 // gather loop (the kernel is bound by that latency chain, not by HBM: tools/spmm_lab.hip, 27.2 -> 24.6 us
 // at 100k poses).  Each lane streams row c of the Q block (32 B for D = 3: the quad reads the 128-B
 // block exactly once, coalesced) and the full gathered tile V_j (160 B, L2-resident).
+struct RowIdx {
+  int t0, deg, ja, jb;
+};
+// Row pointer + preloaded column indices of pose i (wave-cooperative: call with all 64 lanes).
+template <int D, int SPLIT>
+__device__ __forceinline__ RowIdx row_idx_load(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colidx,
+                                               int i, int s, int c, bool ok) {
+  constexpr int B = D + 1, LPP = B * SPLIT;
+  constexpr int NJ = (SPLIT == 1) ? 2 : 1;
+  RowIdx ri;
+  const int lp = s * B + c;
+  ri.t0 = ok ? rowptr[i] : 0;
+  const int t1 = ok ? rowptr[i + 1] : 0;
+  ri.deg = t1 - ri.t0;
+  ri.ja = (lp < ri.deg) ? colidx[ri.t0 + lp] : 0;
+  ri.jb = (NJ == 2 && lp + LPP < ri.deg) ? colidx[ri.t0 + lp + LPP] : 0;
+  return ri;
+}
+
 template <int D, int R, int SPLIT>
-__device__ __forceinline__ void spmm_col(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colidx,
-                                         const double* __restrict__ vals, const double* __restrict__ V,
-                                         int i, int s, int c, bool ok, double (&acc)[R]) {
+__device__ __forceinline__ void spmm_col_pre(const RowIdx& ri, const int32_t* __restrict__ colidx,
+                                             const double* __restrict__ vals, const double* __restrict__ V, int s,
+                                             int c, double (&acc)[R]) {
   constexpr int B = D + 1, T = B * R, BB = B * B, LPP = B * SPLIT;
   constexpr int NJ = (SPLIT == 1) ? 2 : 1;   // preloaded indices per lane
   constexpr int NPRE = NJ * LPP;             // preloaded indices per pose (2B for SPLIT = 1)
@@ -300,10 +319,8 @@ __device__ __forceinline__ void spmm_col(const int32_t* __restrict__ rowptr, con
   const int lane = threadIdx.x & 63;
   const int lp = s * B + c;
   const int gbase = lane - lp;
-  const int t0 = ok ? rowptr[i] : 0, t1 = ok ? rowptr[i + 1] : 0;
-  const int deg = t1 - t0;
-  const int ja = (lp < deg) ? colidx[t0 + lp] : 0;
-  const int jb = (NJ == 2 && lp + LPP < deg) ? colidx[t0 + lp + LPP] : 0;
+  const int t0 = ri.t0, deg = ri.deg, t1 = ri.t0 + ri.deg;
+  const int ja = ri.ja, jb = ri.jb;
   int maxdeg = deg;
 #pragma unroll
   for (int o = 32; o >= 1; o >>= 1) maxdeg = max(maxdeg, __shfl_xor(maxdeg, o));
@@ -345,6 +362,14 @@ __device__ __forceinline__ void spmm_col(const int32_t* __restrict__ rowptr, con
       for (int a = 0; a < R; ++a) acc[a] += __shfl_down(acc[a], o * B);
     }
   }
+}
+
+template <int D, int R, int SPLIT>
+__device__ __forceinline__ void spmm_col(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colidx,
+                                         const double* __restrict__ vals, const double* __restrict__ V,
+                                         int i, int s, int c, bool ok, double (&acc)[R]) {
+  const RowIdx ri = row_idx_load<D, SPLIT>(rowptr, colidx, i, s, c, ok);
+  spmm_col_pre<D, R, SPLIT>(ri, colidx, vals, V, s, c, acc);
 }
 
 // ---------------------------------------------------------------- kernel arguments
@@ -740,6 +765,388 @@ __global__ __launch_bounds__(kBlock, DPGO_LB_HESS) void k_tcg_hess(BsrDev Q, con
     }
   }
   store_partials<1>(part, pout, red);
+}
+
+
+// ---------------------------------------------------------------- tCG scalar prologues (shared)
+// Direction-update scalars (ROPTLIB tCG_TR): returns false when this launch has nothing left to do.
+__device__ __forceinline__ bool tcg_hess_prologue(DevState& st, const double* __restrict__ pin, int nb_in, int first,
+                                                  double* red, double& beta) {
+  double pr[2];
+  load_partials<2>(pin, nb_in, pr, red);
+  const double r_r = pr[0], z_r_new = pr[1];
+  beta = 0.0;
+  if (first) {
+    st.norm_r0 = sqrt(r_r);
+    st.z_r = z_r_new;
+    st.d_Pd = z_r_new;
+    st.e_Pd = 0.0;
+    if (st.max_inner <= 0) {
+      st.tcg_done = 1;
+      return false;
+    }
+    return true;
+  }
+  const double norm_r = sqrt(r_r);
+  const double pw = pow(st.norm_r0, st.theta);
+  if (st.tcg_j >= st.min_inner && norm_r <= st.norm_r0 * (pw < st.kappa ? pw : st.kappa)) {
+    st.tcg_status = (st.kappa < pw) ? TCG_LCON : TCG_SCON;
+    st.tcg_done = 1;
+    return false;
+  }
+  beta = z_r_new / st.z_r;
+  st.e_Pd = beta * (st.e_Pd + st.alpha * st.d_Pd);
+  st.d_Pd = z_r_new + beta * beta * st.d_Pd;
+  st.z_r = z_r_new;
+  st.tcg_j += 1;
+  if (st.tcg_j >= st.max_inner) {
+    st.tcg_done = 1;
+    st.tcg_status = TCG_MAXITER;
+    return false;
+  }
+  return true;
+}
+
+// Step-length scalars: mode 0 = normal step, 1 = boundary step (eta += tau*delta, stop), 2 = initialisation.
+__device__ __forceinline__ int tcg_update_prologue(DevState& st, const double* __restrict__ pin, int nb_in, int first,
+                                                   double* red, double& alpha, double& tau) {
+  alpha = 0.0;
+  tau = 0.0;
+  if (first) {
+    st.tcg_done = 0;
+    st.tcg_j = 0;
+    st.tcg_status = TCG_MAXITER;
+    st.e_Pe = 0.0;
+    st.e_Pd = 0.0;
+    return 2;
+  }
+  double dh[1];
+  load_partials<1>(pin, nb_in, dh, red);
+  const double d_Hd = dh[0];
+  alpha = st.z_r / d_Hd;
+  const double e_Pe_new = st.e_Pe + 2.0 * alpha * st.e_Pd + alpha * alpha * st.d_Pd;
+  st.n_hess += 1;
+  st.alpha = alpha;
+  const double D2 = st.Delta * st.Delta;
+  if (d_Hd <= 0.0 || e_Pe_new >= D2) {
+    tau = (-st.e_Pd + sqrt(st.e_Pd * st.e_Pd + st.d_Pd * (D2 - st.e_Pe))) / st.d_Pd;
+    st.tcg_status = (d_Hd < 0.0) ? TCG_NEGCURV : TCG_EXCREGION;
+    st.tcg_done = 1;
+    return 1;
+  }
+  st.e_Pe = e_Pe_new;
+  return 0;
+}
+
+// ================================================================ span kernels (pose tile size even: all 3-D cases)
+// Same arithmetic as k_tcg_hess / k_tcg_update; the differences are purely about memory:
+//  * own-tile vectors move as lane-linear 16-byte pieces (Span<>), element-wise recurrences run in span layout;
+//  * the FIRST tile's global loads (row pointer, column indices, vector pieces) are issued before the scalar
+//    prologue (state record + partial-sum reduction), so the two dependent-latency chains overlap -- this is
+//    what matters for small blocks (multi-GPU strong scaling), where a kernel is a chain of ~15 memory latencies.
+template <int D, int R, int SPLIT>
+__global__ __launch_bounds__(kBlock) void k_tcg_hess_span(BsrDev Q, const double* __restrict__ X,
+                                                          const double* __restrict__ S, const double* __restrict__ z,
+                                                          double* __restrict__ delta, double* __restrict__ Hd,
+                                                          const double* __restrict__ pin, int nb_in,
+                                                          double* __restrict__ pout, const DevState* __restrict__ sin,
+                                                          DevState* __restrict__ sout, int first, int n,
+                                                          unsigned long long* hflag, unsigned gen) {
+  using GEO = Geo<D, R, SPLIT>;
+  using SPN = Span<D, R, SPLIT>;
+  __shared__ __attribute__((aligned(16))) double sm[kWaves][4][GEO::G][GEO::T];
+  __shared__ double red[kWaves * kNP];
+  const LaneId L = lane_id<D, SPLIT>();
+  const int lane = threadIdx.x & 63;
+  const int ntiles = (n + GEO::P - 1) / GEO::P;
+  const TileIter ti_ = tile_iter(ntiles);
+  double* ys = &sm[L.wave][0][0][0];
+  double* vs = &sm[L.wave][1][0][0];
+  double* hs = &sm[L.wave][2][0][0];
+  double* os = &sm[L.wave][3][0][0];
+
+  // ---- per-tile prefetch state
+  RowIdx ri;
+  dbl2 xv[SPN::NIT], zv[SPN::NIT], dv[SPN::NIT], hv[SPN::NIT];
+  double srow[D];
+  int p0 = 0, valid = 0, i = 0;
+  bool okp = false, ok = false;
+  auto prefetch = [&](int tile) {
+    p0 = tile * GEO::P + L.wave * GEO::G;
+    const int npose = (n - p0) < GEO::G ? (n - p0) : GEO::G;
+    valid = npose > 0 ? npose * GEO::T : 0;
+    i = p0 + L.g;
+    okp = (L.g < GEO::G) && (i < n);
+    ok = okp && (L.s == 0);
+    ri = row_idx_load<D, SPLIT>(Q.rowptr, Q.colidx, i, L.s, L.c, okp);
+    const size_t base = (size_t)p0 * GEO::T;
+    const dbl2* X2 = reinterpret_cast<const dbl2*>(X + base);
+    const dbl2* z2 = reinterpret_cast<const dbl2*>(z + base);
+    const dbl2* d2 = reinterpret_cast<const dbl2*>(delta + base);
+    const dbl2* h2 = reinterpret_cast<const dbl2*>(Hd + base);
+#pragma unroll
+    for (int it = 0; it < SPN::NIT; ++it) {
+      const int pc = lane + 64 * it;
+      if (2 * pc < valid) {
+        xv[it] = X2[pc];
+        zv[it] = z2[pc];
+        if (!first) {
+          dv[it] = d2[pc];
+          hv[it] = h2[pc];
+        }
+      }
+    }
+    if (ok && L.c < D) {
+#pragma unroll
+      for (int a = 0; a < D; ++a) srow[a] = S[(size_t)i * D * D + L.c * D + a];
+    }
+  };
+  int tile = ti_.first;
+  bool have = tile < ti_.last;
+  if (have) prefetch(tile);
+
+  // ---- scalar prologue
+  DevState st;
+  load_state(st, sin);
+  if (st.rtr_stop || st.tcg_done) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+      store_state(sout, st);
+      publish_progress(hflag, gen, st);
+    }
+    return;
+  }
+  double beta;
+  const bool go = tcg_hess_prologue(st, pin, nb_in, first, red, beta);
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    store_state(sout, st);
+    publish_progress(hflag, gen, st);
+  }
+  if (!go) return;
+
+  double part[1] = {0.0};
+  while (have) {
+#pragma unroll
+    for (int it = 0; it < SPN::NIT; ++it) {
+      const int pc = lane + 64 * it;
+      if (2 * pc < valid) {
+        reinterpret_cast<dbl2*>(ys)[pc] = xv[it];
+        reinterpret_cast<dbl2*>(vs)[pc] = zv[it];
+      }
+    }
+    double h[R];
+    spmm_col_pre<D, R, SPLIT>(ri, Q.colidx, Q.vals, z, L.s, L.c, h);
+    wave_sync();
+    if (ok) {
+      if (L.c < D) {
+        const double* vt = vs + L.g * GEO::T;
+#pragma unroll
+        for (int a = 0; a < D; ++a) {
+#pragma unroll
+          for (int k = 0; k < R; ++k) h[k] = fma(-vt[a * R + k], srow[a], h[k]);
+        }
+      }
+      store_col<R>(hs + L.g * GEO::T + L.c * R, h);
+    }
+    wave_sync();
+    if (ok) {
+      double hz[R], sdummy[D];
+      proj_col<D, R>(ys + L.g * GEO::T, hs + L.g * GEO::T, L.c, h, hz, sdummy);
+      store_col<R>(os + L.g * GEO::T + L.c * R, hz);
+    }
+    wave_sync();
+    {
+      const size_t base = (size_t)p0 * GEO::T;
+      dbl2* d2 = reinterpret_cast<dbl2*>(delta + base);
+      dbl2* h2 = reinterpret_cast<dbl2*>(Hd + base);
+#pragma unroll
+      for (int it = 0; it < SPN::NIT; ++it) {
+        const int pc = lane + 64 * it;
+        if (2 * pc < valid) {
+          const dbl2 hzv = reinterpret_cast<const dbl2*>(os)[pc];
+          dbl2 dn, hn;
+          if (first) {
+            dn.x = -zv[it].x;
+            dn.y = -zv[it].y;
+            hn.x = -hzv.x;
+            hn.y = -hzv.y;
+          } else {
+            dn.x = fma(beta, dv[it].x, -zv[it].x);
+            dn.y = fma(beta, dv[it].y, -zv[it].y);
+            hn.x = fma(beta, hv[it].x, -hzv.x);
+            hn.y = fma(beta, hv[it].y, -hzv.y);
+          }
+          d2[pc] = dn;
+          h2[pc] = hn;
+          part[0] = fma(dn.x, hn.x, part[0]);
+          part[0] = fma(dn.y, hn.y, part[0]);
+        }
+      }
+    }
+    wave_sync();
+    tile += ti_.step;
+    have = tile < ti_.last;
+    if (have) prefetch(tile);
+  }
+  store_partials<1>(part, pout, red);
+}
+
+template <int D, int R>
+__global__ __launch_bounds__(kBlock) void k_tcg_update_span(const double* __restrict__ X, const double* __restrict__ g,
+                                                            const double* __restrict__ dinv,
+                                                            const double* __restrict__ delta,
+                                                            const double* __restrict__ Hd, double* __restrict__ eta,
+                                                            double* __restrict__ r, double* __restrict__ z,
+                                                            const double* __restrict__ pin, int nb_in,
+                                                            double* __restrict__ pout, const DevState* __restrict__ sin,
+                                                            DevState* __restrict__ sout, int first, int n,
+                                                            unsigned long long* hflag, unsigned gen) {
+  using GEO = Geo<D, R>;
+  using SPN = Span<D, R, 1>;
+  __shared__ __attribute__((aligned(16))) double sm[kWaves][4][GEO::G][GEO::T];
+  __shared__ double red[kWaves * kNP];
+  const LaneId L = lane_id<D>();
+  const int lane = threadIdx.x & 63;
+  const int ntiles = (n + GEO::P - 1) / GEO::P;
+  const TileIter ti_ = tile_iter(ntiles);
+  double* ys = &sm[L.wave][0][0][0];
+  double* rs = &sm[L.wave][1][0][0];
+  double* zs = &sm[L.wave][2][0][0];
+  double* os = &sm[L.wave][3][0][0];
+
+  dbl2 xv[SPN::NIT], ev[SPN::NIT], dv[SPN::NIT], hv[SPN::NIT], rv[SPN::NIT];
+  double drow[GEO::B];
+  int p0 = 0, valid = 0, i = 0;
+  bool ok = false;
+  auto prefetch = [&](int tile) {
+    p0 = tile * GEO::P + L.wave * GEO::G;
+    const int npose = (n - p0) < GEO::G ? (n - p0) : GEO::G;
+    valid = npose > 0 ? npose * GEO::T : 0;
+    i = p0 + L.g;
+    ok = (L.g < GEO::G) && (i < n);
+    const size_t base = (size_t)p0 * GEO::T;
+    const dbl2* X2 = reinterpret_cast<const dbl2*>(X + base);
+    const dbl2* g2 = reinterpret_cast<const dbl2*>(g + base);
+    const dbl2* e2 = reinterpret_cast<const dbl2*>(eta + base);
+    const dbl2* d2 = reinterpret_cast<const dbl2*>(delta + base);
+    const dbl2* h2 = reinterpret_cast<const dbl2*>(Hd + base);
+    const dbl2* r2 = reinterpret_cast<const dbl2*>(r + base);
+#pragma unroll
+    for (int it = 0; it < SPN::NIT; ++it) {
+      const int pc = lane + 64 * it;
+      if (2 * pc < valid) {
+        xv[it] = X2[pc];
+        if (first) {
+          rv[it] = g2[pc];
+        } else {
+          ev[it] = e2[pc];
+          dv[it] = d2[pc];
+          hv[it] = h2[pc];
+          rv[it] = r2[pc];
+        }
+      }
+    }
+    if (ok && dinv) {
+#pragma unroll
+      for (int k = 0; k < GEO::B; ++k) drow[k] = dinv[(size_t)i * GEO::BB + L.c * GEO::B + k];
+    }
+  };
+  int tile = ti_.first;
+  bool have = tile < ti_.last;
+  if (have) prefetch(tile);
+
+  DevState st;
+  load_state(st, sin);
+  if (st.rtr_stop || (!first && st.tcg_done)) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+      store_state(sout, st);
+      publish_progress(hflag, gen, st);
+    }
+    return;
+  }
+  double alpha, tau;
+  const int mode = tcg_update_prologue(st, pin, nb_in, first, red, alpha, tau);
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    store_state(sout, st);
+    publish_progress(hflag, gen, st);
+  }
+
+  double part[2] = {0.0, 0.0};
+  while (have) {
+    const size_t base = (size_t)p0 * GEO::T;
+    dbl2* eta2 = reinterpret_cast<dbl2*>(eta + base);
+    if (mode == 1) {  // workgroup-uniform: eta += tau * delta, then tCG stops
+#pragma unroll
+      for (int it = 0; it < SPN::NIT; ++it) {
+        const int pc = lane + 64 * it;
+        if (2 * pc < valid) {
+          dbl2 e = ev[it];
+          e.x = fma(tau, dv[it].x, e.x);
+          e.y = fma(tau, dv[it].y, e.y);
+          eta2[pc] = e;
+        }
+      }
+    } else {
+      dbl2* r2 = reinterpret_cast<dbl2*>(r + base);
+#pragma unroll
+      for (int it = 0; it < SPN::NIT; ++it) {
+        const int pc = lane + 64 * it;
+        if (2 * pc < valid) {
+          reinterpret_cast<dbl2*>(ys)[pc] = xv[it];
+          dbl2 rr = rv[it];
+          if (mode == 2) {
+            dbl2 zero;
+            zero.x = 0.0;
+            zero.y = 0.0;
+            eta2[pc] = zero;
+          } else {
+            dbl2 e = ev[it];
+            e.x = fma(alpha, dv[it].x, e.x);
+            e.y = fma(alpha, dv[it].y, e.y);
+            rr.x = fma(alpha, hv[it].x, rr.x);
+            rr.y = fma(alpha, hv[it].y, rr.y);
+            eta2[pc] = e;
+          }
+          r2[pc] = rr;
+          reinterpret_cast<dbl2*>(rs)[pc] = rr;
+          part[0] = fma(rr.x, rr.x, part[0]);
+          part[0] = fma(rr.y, rr.y, part[0]);
+        }
+      }
+      wave_sync();
+      double zz[R];
+      if (ok) {
+        const double* rt = rs + L.g * GEO::T;
+        if (dinv) {
+          jacobi_col<D, R>(rt, drow, zz);
+        } else {
+#pragma unroll
+          for (int a = 0; a < R; ++a) zz[a] = rt[L.c * R + a];
+        }
+        store_col<R>(zs + L.g * GEO::T + L.c * R, zz);
+      }
+      wave_sync();
+      if (ok) {
+        double out[R], sdummy[D];
+        proj_col<D, R>(ys + L.g * GEO::T, zs + L.g * GEO::T, L.c, zz, out, sdummy);
+        const double* rt = rs + L.g * GEO::T + L.c * R;
+#pragma unroll
+        for (int a = 0; a < R; ++a) part[1] = fma(out[a], rt[a], part[1]);
+        store_col<R>(os + L.g * GEO::T + L.c * R, out);
+      }
+      wave_sync();
+      dbl2* z2 = reinterpret_cast<dbl2*>(z + base);
+#pragma unroll
+      for (int it = 0; it < SPN::NIT; ++it) {
+        const int pc = lane + 64 * it;
+        if (2 * pc < valid) z2[pc] = reinterpret_cast<const dbl2*>(os)[pc];
+      }
+      wave_sync();
+    }
+    tile += ti_.step;
+    have = tile < ti_.last;
+    if (have) prefetch(tile);
+  }
+  if (mode != 1) store_partials<2>(part, pout, red);
 }
 
 // ================================================================ K6: preconditioner (stand-alone)
