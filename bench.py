@@ -139,12 +139,23 @@ def main():
         raise SystemExit("bench.py needs a HIP device: the product path has no CPU fallback")
     dev_index = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(dev_index)
+    backend = None
     if world > 1:
-        # "nccl" IS RCCL on ROCm; DPGO_DIST_BACKEND=gloo (host-staged) lets the N > 1 path be exercised
-        # on a single-GPU box with all ranks sharing device 0
+        # "nccl" IS RCCL on ROCm.  DPGO_DIST_BACKEND=gloo (host-staged exchange) lets the N > 1 path be exercised
+        # on a single-GPU box with all ranks sharing device 0; it is also the fallback if RCCL cannot initialise.
         backend = os.environ.get("DPGO_DIST_BACKEND", "nccl")
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+            try:
+                dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+                t = torch.ones(1, device="cuda")
+                dist.all_reduce(t)  # create the communicator eagerly, before the first grouped p2p batch
+                torch.cuda.synchronize()
+            except Exception as exc:  # noqa: BLE001 -- report and degrade rather than lose the measurement
+                sys.stderr.write("bench.py: RCCL initialisation failed (%r); falling back to gloo\n" % (exc,))
+                if dist.is_initialized():
+                    dist.destroy_process_group()
+                backend = "gloo"
+                dist.init_process_group("gloo")
         else:
             dist.init_process_group(backend)
 
@@ -187,6 +198,18 @@ def main():
     for a in agents.values():
         a.snapshot()
 
+    t_exchange = [0.0]
+    _exchange = cluster.exchange
+
+    def timed_exchange(*a, **k):
+        t = time.perf_counter()
+        _exchange(*a, **k)
+        torch.cuda.synchronize()
+        t_exchange[0] += time.perf_counter() - t
+
+    if world > 1:
+        cluster.exchange = timed_exchange
+
     def step():
         for a in agents.values():
             a.restore()
@@ -195,6 +218,7 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
+    t_exchange[0] = 0.0
     t0 = time.perf_counter()
     tcg_total = 0
     for _ in range(args.steps):
@@ -265,6 +289,7 @@ def main():
                        "%d-colour parallel RBCD; 1 step = 1 sweep (every agent updates once); public-pose "
                        "exchange over %s" % (plan.num_colours, "device copies" if world == 1 else
                                              ("RCCL p2p" if not cluster.stage else "gloo (host-staged)")),
+                       "dist_backend": backend,
                        "poses_per_agent": n_local, "nnzb_per_agent": nnzb_local},
             "roofline": roofline,
             "cpu_baseline": cpu,
@@ -272,7 +297,8 @@ def main():
                         "cost_2f_trajectory": [c for c, _ in trajectory],
                         "gradnorm_trajectory": [g for _, g in trajectory],
                         "cost_2f_after_step": 2 * f1, "gradnorm_after_step": g1,
-                        "tcg_iterations_per_step_rank0": tcg_total / max(args.steps, 1)},
+                        "tcg_iterations_per_step_rank0": tcg_total / max(args.steps, 1),
+                        "exchange_ms_per_step_rank0": 1e3 * t_exchange[0] / max(args.steps, 1)},
         }
         print(json.dumps(out))
     if world > 1:
