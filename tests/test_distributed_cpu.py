@@ -26,11 +26,11 @@ class HostAgent:
         self.Q = O.construct_Q(X0_tiles.shape[0], d, priv, self.shared, my_id=my_id)
         self.device = "cpu"
 
-    def pack(self, q):
+    def pack(self, q, aux=False):
         import torch
         return self.X[torch.tensor(self.plan.send_frames[self.id][q], dtype=torch.long)].contiguous()
 
-    def recv_view(self, q):
+    def recv_view(self, q, aux=False):
         lo, hi = self.plan.recv_range[self.id][q]
         return self.nbr[lo:hi]
 

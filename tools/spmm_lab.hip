@@ -438,6 +438,299 @@ __global__ __launch_bounds__(256) void v8(const int* __restrict__ rowptr, const 
   }
 }
 
+// ---------------- V9: symmetric storage.  Only blocks (i, j >= i) are stored; row i additionally walks a list of
+// references (j < i, slot of block (j, i)) and uses those blocks TRANSPOSED (column c instead of row c).  Every
+// block is touched twice; the bet is that the second touch is an L2 hit, so HBM sees ~half of Q.
+__global__ __launch_bounds__(256) void v9(const int* __restrict__ rpu, const int* __restrict__ ciu,
+                                          const double* __restrict__ valsu, const int* __restrict__ rpl,
+                                          const int* __restrict__ cil, const int* __restrict__ slotl,
+                                          const double* __restrict__ V, double* __restrict__ OUT, int n) {
+  const int l = threadIdx.x & 63, wave = threadIdx.x >> 6, g = l >> 2, c = l & 3;
+  const int ntiles = (n + 63) / 64;
+  const TileIter ti = tile_iter(ntiles);
+  for (int tile = ti.first; tile < ti.last; tile += ti.step) {
+    const int i = tile * 64 + wave * 16 + g;
+    if (i < n) {
+      double acc[R] = {0, 0, 0, 0, 0};
+      for (int t = rpu[i]; t < rpu[i + 1]; ++t) {
+        const int j = ciu[t];
+        double q[B], x[T];
+        load_qrow(valsu + (size_t)t * BB + c * B, q);
+        load_tile(V + (size_t)j * T, x);
+        fma_tile(x, q, acc);
+      }
+      for (int t = rpl[i]; t < rpl[i + 1]; ++t) {
+        const int j = cil[t];
+        const double* __restrict__ blk = valsu + (size_t)slotl[t] * BB;
+        double q[B], x[T];
+#pragma unroll
+        for (int k = 0; k < B; ++k) q[k] = blk[k * B + c];
+        load_tile(V + (size_t)j * T, x);
+        fma_tile(x, q, acc);
+      }
+#pragma unroll
+      for (int a = 0; a < R; ++a) OUT[(size_t)i * T + c * R + a] = acc[a];
+    }
+  }
+}
+
+// ---------------- V11: outer-product accumulation.  Lane c of a quad loads only column c of the gathered tile
+// (40 B) and column c of the Q block (32 B, blocks stored transposed), accumulates the 5x4 partial
+// P_c[a][c'] = X_j[a][c] * Q_ij[c'][c]; ONE quad reduction per row (not per block) yields OUT_i.  Load
+// instructions per 16 blocks: 2 (Q) + 5 x 8-byte (tile column) instead of 2 + 10 x 16-byte.
+template <bool PRELOAD>
+__global__ __launch_bounds__(256) void v11(const int* __restrict__ rowptr, const int* __restrict__ colidx,
+                                           const double* __restrict__ valsT, const double* __restrict__ V,
+                                           double* __restrict__ OUT, int n) {
+  const int l = threadIdx.x & 63, wave = threadIdx.x >> 6, g = l >> 2, c = l & 3;
+  const int ntiles = (n + 63) / 64;
+  const TileIter ti = tile_iter(ntiles);
+  for (int tile = ti.first; tile < ti.last; tile += ti.step) {
+    const int i = tile * 64 + wave * 16 + g;
+    const bool ok = i < n;
+    double acc[B][R];
+#pragma unroll
+    for (int cc = 0; cc < B; ++cc)
+#pragma unroll
+      for (int a = 0; a < R; ++a) acc[cc][a] = 0.0;
+    const int t0 = ok ? rowptr[i] : 0, t1 = ok ? rowptr[i + 1] : 0;
+    if (PRELOAD) {
+      const int deg = t1 - t0;
+      const int ja = (c < deg) ? colidx[t0 + c] : 0;
+      const int jb = (c + 4 < deg) ? colidx[t0 + c + 4] : 0;
+      int maxdeg = deg;
+#pragma unroll
+      for (int o = 32; o >= 1; o >>= 1) maxdeg = max(maxdeg, __shfl_xor(maxdeg, o));
+      const int lim = maxdeg < 8 ? maxdeg : 8;
+      for (int k = 0; k < lim; ++k) {
+        const int j = __shfl((k < 4) ? ja : jb, (l & ~3) | (k & 3));
+        if (k < deg) {
+          double q[B], xc[R];
+          load_qrow(valsT + (size_t)(t0 + k) * BB + c * B, q);
+#pragma unroll
+          for (int a = 0; a < R; ++a) xc[a] = V[(size_t)j * T + c * R + a];
+#pragma unroll
+          for (int cc = 0; cc < B; ++cc)
+#pragma unroll
+            for (int a = 0; a < R; ++a) acc[cc][a] = fma(xc[a], q[cc], acc[cc][a]);
+        }
+      }
+      for (int t = t0 + 8; t < t1; ++t) {
+        const int j = colidx[t];
+        double q[B], xc[R];
+        load_qrow(valsT + (size_t)t * BB + c * B, q);
+#pragma unroll
+        for (int a = 0; a < R; ++a) xc[a] = V[(size_t)j * T + c * R + a];
+#pragma unroll
+        for (int cc = 0; cc < B; ++cc)
+#pragma unroll
+          for (int a = 0; a < R; ++a) acc[cc][a] = fma(xc[a], q[cc], acc[cc][a]);
+      }
+    } else {
+      for (int t = t0; t < t1; ++t) {
+        const int j = colidx[t];
+        double q[B], xc[R];
+        load_qrow(valsT + (size_t)t * BB + c * B, q);
+#pragma unroll
+        for (int a = 0; a < R; ++a) xc[a] = V[(size_t)j * T + c * R + a];
+#pragma unroll
+        for (int cc = 0; cc < B; ++cc)
+#pragma unroll
+          for (int a = 0; a < R; ++a) acc[cc][a] = fma(xc[a], q[cc], acc[cc][a]);
+      }
+    }
+    // quad reduction: every lane gets the full sums, lane c keeps column c
+    double out[R];
+#pragma unroll
+    for (int cc = 0; cc < B; ++cc)
+#pragma unroll
+      for (int a = 0; a < R; ++a) {
+        double v = acc[cc][a];
+        v += __shfl_xor(v, 1);
+        v += __shfl_xor(v, 2);
+        if (cc == c) out[a] = v;
+      }
+    if (ok) {
+#pragma unroll
+      for (int a = 0; a < R; ++a) OUT[(size_t)i * T + c * R + a] = out[a];
+    }
+  }
+}
+
+// ---------------- V12: V11 (outer-product, index preload) on symmetric storage: upper blocks stored transposed
+// (column c contiguous); lower references use the stored block of (j, i) through its rows (strided 8-byte loads).
+__global__ __launch_bounds__(256) void v12(const int* __restrict__ rpu, const int* __restrict__ ciu,
+                                           const double* __restrict__ valsuT, const int* __restrict__ rpl,
+                                           const int* __restrict__ cil, const int* __restrict__ slotl,
+                                           const double* __restrict__ V, double* __restrict__ OUT, int n) {
+  const int l = threadIdx.x & 63, wave = threadIdx.x >> 6, g = l >> 2, c = l & 3;
+  const int ntiles = (n + 63) / 64;
+  const TileIter ti = tile_iter(ntiles);
+  for (int tile = ti.first; tile < ti.last; tile += ti.step) {
+    const int i = tile * 64 + wave * 16 + g;
+    const bool ok = i < n;
+    double acc[B][R];
+#pragma unroll
+    for (int cc = 0; cc < B; ++cc)
+#pragma unroll
+      for (int a = 0; a < R; ++a) acc[cc][a] = 0.0;
+    const int u0 = ok ? rpu[i] : 0, u1 = ok ? rpu[i + 1] : 0, l0 = ok ? rpl[i] : 0, l1 = ok ? rpl[i + 1] : 0;
+    const int du = u1 - u0, dl = l1 - l0;
+    const int ju = (c < du) ? ciu[u0 + c] : 0;
+    const int jl = (c < dl) ? cil[l0 + c] : 0;
+    const int sl = (c < dl) ? slotl[l0 + c] : 0;
+    int mu = du, ml = dl;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) { mu = max(mu, __shfl_xor(mu, o)); ml = max(ml, __shfl_xor(ml, o)); }
+    const int lu = mu < 4 ? mu : 4, ll = ml < 4 ? ml : 4;
+    for (int k = 0; k < lu; ++k) {
+      const int j = __shfl(ju, (l & ~3) | k);
+      if (k < du) {
+        double q[B], xc[R];
+        load_qrow(valsuT + (size_t)(u0 + k) * BB + c * B, q);
+#pragma unroll
+        for (int a = 0; a < R; ++a) xc[a] = V[(size_t)j * T + c * R + a];
+#pragma unroll
+        for (int cc = 0; cc < B; ++cc)
+#pragma unroll
+          for (int a = 0; a < R; ++a) acc[cc][a] = fma(xc[a], q[cc], acc[cc][a]);
+      }
+    }
+    for (int t = u0 + 4; t < u1; ++t) {
+      const int j = ciu[t];
+      double q[B], xc[R];
+      load_qrow(valsuT + (size_t)t * BB + c * B, q);
+#pragma unroll
+      for (int a = 0; a < R; ++a) xc[a] = V[(size_t)j * T + c * R + a];
+#pragma unroll
+      for (int cc = 0; cc < B; ++cc)
+#pragma unroll
+        for (int a = 0; a < R; ++a) acc[cc][a] = fma(xc[a], q[cc], acc[cc][a]);
+    }
+    for (int k = 0; k < ll; ++k) {
+      const int j = __shfl(jl, (l & ~3) | k);
+      const int sb = __shfl(sl, (l & ~3) | k);
+      if (k < dl) {
+        const double* __restrict__ blk = valsuT + (size_t)sb * BB;  // transposed storage of Q[j,i]: blk[p*4+q] = Q[j,i][q][p]
+        double q[B], xc[R];
+        // need column c of Q[i,j] = row c of Q[j,i] = blk[p*4 + c], p = 0..3
+#pragma unroll
+        for (int pp = 0; pp < B; ++pp) q[pp] = blk[pp * B + c];
+#pragma unroll
+        for (int a = 0; a < R; ++a) xc[a] = V[(size_t)j * T + c * R + a];
+#pragma unroll
+        for (int cc = 0; cc < B; ++cc)
+#pragma unroll
+          for (int a = 0; a < R; ++a) acc[cc][a] = fma(xc[a], q[cc], acc[cc][a]);
+      }
+    }
+    for (int t = l0 + 4; t < l1; ++t) {
+      const int j = cil[t];
+      const double* __restrict__ blk = valsuT + (size_t)slotl[t] * BB;
+      double q[B], xc[R];
+#pragma unroll
+      for (int pp = 0; pp < B; ++pp) q[pp] = blk[pp * B + c];
+#pragma unroll
+      for (int a = 0; a < R; ++a) xc[a] = V[(size_t)j * T + c * R + a];
+#pragma unroll
+      for (int cc = 0; cc < B; ++cc)
+#pragma unroll
+        for (int a = 0; a < R; ++a) acc[cc][a] = fma(xc[a], q[cc], acc[cc][a]);
+    }
+    double out[R];
+#pragma unroll
+    for (int cc = 0; cc < B; ++cc)
+#pragma unroll
+      for (int a = 0; a < R; ++a) {
+        double v = acc[cc][a];
+        v += __shfl_xor(v, 1);
+        v += __shfl_xor(v, 2);
+        if (cc == c) out[a] = v;
+      }
+    if (ok) {
+#pragma unroll
+      for (int a = 0; a < R; ++a) OUT[(size_t)i * T + c * R + a] = out[a];
+    }
+  }
+}
+
+// ---------------- V13: V11 + batched issue.  The loads of NB consecutive blocks of the row (column indices are
+// preloaded) are all issued before the first FMA, so a row costs ceil(deg/NB) memory round trips instead of deg.
+template <int NB>
+__global__ __launch_bounds__(256) void v13(const int* __restrict__ rowptr, const int* __restrict__ colidx,
+                                           const double* __restrict__ valsT, const double* __restrict__ V,
+                                           double* __restrict__ OUT, int n) {
+  const int l = threadIdx.x & 63, wave = threadIdx.x >> 6, g = l >> 2, c = l & 3;
+  const int ntiles = (n + 63) / 64;
+  const TileIter ti = tile_iter(ntiles);
+  for (int tile = ti.first; tile < ti.last; tile += ti.step) {
+    const int i = tile * 64 + wave * 16 + g;
+    const bool ok = i < n;
+    double acc[B][R];
+#pragma unroll
+    for (int cc = 0; cc < B; ++cc)
+#pragma unroll
+      for (int a = 0; a < R; ++a) acc[cc][a] = 0.0;
+    const int t0 = ok ? rowptr[i] : 0, t1 = ok ? rowptr[i + 1] : 0;
+    const int deg = t1 - t0;
+    const int ja = (c < deg) ? colidx[t0 + c] : 0;
+    const int jb = (c + 4 < deg) ? colidx[t0 + c + 4] : 0;
+    int maxdeg = deg;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) maxdeg = max(maxdeg, __shfl_xor(maxdeg, o));
+    const int lim = maxdeg < 8 ? maxdeg : 8;
+    for (int k0 = 0; k0 < lim; k0 += NB) {
+      double q[NB][B], xc[NB][R];
+#pragma unroll
+      for (int u = 0; u < NB; ++u) {
+        const int k = k0 + u;
+        const int j = __shfl((k < 4) ? ja : jb, (l & ~3) | (k & 3));
+        const bool on = k < deg;
+        const size_t tq = on ? (size_t)(t0 + k) : (size_t)0;
+        const size_t jj = on ? (size_t)j : (size_t)0;
+        load_qrow(valsT + tq * BB + c * B, q[u]);
+#pragma unroll
+        for (int a = 0; a < R; ++a) xc[u][a] = V[jj * T + c * R + a];
+        if (!on) {
+#pragma unroll
+          for (int cc = 0; cc < B; ++cc) q[u][cc] = 0.0;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < NB; ++u)
+#pragma unroll
+        for (int cc = 0; cc < B; ++cc)
+#pragma unroll
+          for (int a = 0; a < R; ++a) acc[cc][a] = fma(xc[u][a], q[u][cc], acc[cc][a]);
+    }
+    for (int t = t0 + 8; t < t1; ++t) {
+      const int j = colidx[t];
+      double q[B], xc[R];
+      load_qrow(valsT + (size_t)t * BB + c * B, q);
+#pragma unroll
+      for (int a = 0; a < R; ++a) xc[a] = V[(size_t)j * T + c * R + a];
+#pragma unroll
+      for (int cc = 0; cc < B; ++cc)
+#pragma unroll
+        for (int a = 0; a < R; ++a) acc[cc][a] = fma(xc[a], q[cc], acc[cc][a]);
+    }
+    double out[R];
+#pragma unroll
+    for (int cc = 0; cc < B; ++cc)
+#pragma unroll
+      for (int a = 0; a < R; ++a) {
+        double v = acc[cc][a];
+        v += __shfl_xor(v, 1);
+        v += __shfl_xor(v, 2);
+        if (cc == c) out[a] = v;
+      }
+    if (ok) {
+#pragma unroll
+      for (int a = 0; a < R; ++a) OUT[(size_t)i * T + c * R + a] = out[a];
+    }
+  }
+}
+
 int main(int argc, char** argv) {
   const int nx = 50, ny = 50, nz = 40, n = nx * ny * nz;
   std::vector<int> rowptr(n + 1, 0), colidx;
@@ -462,6 +755,16 @@ int main(int argc, char** argv) {
   srand(1);
   for (auto& v : vals) v = (rand() / (double)RAND_MAX) - 0.5;
   for (auto& v : Vh) v = (rand() / (double)RAND_MAX) - 0.5;
+  // make Q symmetric: block (j,i) = block (i,j)^T, diagonal blocks symmetric
+  {
+    auto slot = [&](int i, int j) { for (int t = rowptr[i]; t < rowptr[i + 1]; ++t) if (colidx[t] == j) return t; return -1; };
+    for (int i = 0; i < n; ++i)
+      for (int t = rowptr[i]; t < rowptr[i + 1]; ++t) {
+        const int j = colidx[t];
+        if (j > i) { const int u = slot(j, i); for (int p = 0; p < B; ++p) for (int q = 0; q < B; ++q) vals[(size_t)u * BB + q * B + p] = vals[(size_t)t * BB + p * B + q]; }
+        if (j == i) for (int p = 0; p < B; ++p) for (int q = p + 1; q < B; ++q) vals[(size_t)t * BB + q * B + p] = vals[(size_t)t * BB + p * B + q];
+      }
+  }
   const double bytes = (double)nnzb * (8 * BB + 4) + 4.0 * (n + 1) + 16.0 * R * B * n;
   printf("n=%d nnzb=%d algorithmic bytes=%.1f MB\n", n, nnzb, bytes / 1e6);
 
@@ -567,6 +870,63 @@ int main(int argc, char** argv) {
     char nm[64];
     snprintf(nm, 64, "v8 block-par RW=32 MAXB=224 grid=%d", grid);
     run(nm, [&] { hipLaunchKernelGGL((v8<32, 224>), dim3(grid), dim3(256), 0, 0, d_rp, d_ci, d_vals, d_V, d_O, n); }, false);
+  }
+  {  // symmetric storage arrays
+    std::vector<int> rpu(n + 1, 0), ciu, rpl(n + 1, 0), cil, slotl;
+    std::vector<double> valsu;
+    std::vector<int> slot_of_full(nnzb, -1);
+    for (int i = 0; i < n; ++i) {
+      for (int t = rowptr[i]; t < rowptr[i + 1]; ++t)
+        if (colidx[t] >= i) { slot_of_full[t] = (int)ciu.size(); ciu.push_back(colidx[t]); for (int q = 0; q < BB; ++q) valsu.push_back(vals[(size_t)t * BB + q]); }
+      rpu[i + 1] = (int)ciu.size();
+    }
+    for (int i = 0; i < n; ++i) {
+      for (int t = rowptr[i]; t < rowptr[i + 1]; ++t) {
+        const int j = colidx[t];
+        if (j < i) { int u = -1; for (int tt = rowptr[j]; tt < rowptr[j + 1]; ++tt) if (colidx[tt] == i) u = slot_of_full[tt]; cil.push_back(j); slotl.push_back(u); }
+      }
+      rpl[i + 1] = (int)cil.size();
+    }
+    int *d_rpu, *d_ciu, *d_rpl, *d_cil, *d_sl; double* d_vu;
+    HC(hipMalloc(&d_rpu, 4 * (n + 1))); HC(hipMalloc(&d_ciu, 4 * ciu.size())); HC(hipMalloc(&d_rpl, 4 * (n + 1)));
+    HC(hipMalloc(&d_cil, 4 * cil.size())); HC(hipMalloc(&d_sl, 4 * slotl.size())); HC(hipMalloc(&d_vu, 8 * valsu.size()));
+    HC(hipMemcpy(d_rpu, rpu.data(), 4 * (n + 1), hipMemcpyHostToDevice)); HC(hipMemcpy(d_ciu, ciu.data(), 4 * ciu.size(), hipMemcpyHostToDevice));
+    HC(hipMemcpy(d_rpl, rpl.data(), 4 * (n + 1), hipMemcpyHostToDevice)); HC(hipMemcpy(d_cil, cil.data(), 4 * cil.size(), hipMemcpyHostToDevice));
+    HC(hipMemcpy(d_sl, slotl.data(), 4 * slotl.size(), hipMemcpyHostToDevice)); HC(hipMemcpy(d_vu, valsu.data(), 8 * valsu.size(), hipMemcpyHostToDevice));
+    printf("symmetric storage: %zu upper blocks (%.1f MB) + %zu lower refs\n", ciu.size(), valsu.size() * 8 / 1e6, cil.size());
+    for (int grid : {1024, 1563, 2048}) {
+      char nm[64];
+      snprintf(nm, 64, "v9 symmetric storage grid=%d", grid);
+      run(nm, [&] { hipLaunchKernelGGL(v9, dim3(grid), dim3(256), 0, 0, d_rpu, d_ciu, d_vu, d_rpl, d_cil, d_sl, d_V, d_O, n); }, false);
+    }
+    {
+      std::vector<double> vuT(valsu.size());
+      for (size_t t = 0; t < ciu.size(); ++t) for (int p = 0; p < B; ++p) for (int q = 0; q < B; ++q) vuT[t * BB + q * B + p] = valsu[t * BB + p * B + q];
+      double* d_vuT; HC(hipMalloc(&d_vuT, 8 * vuT.size())); HC(hipMemcpy(d_vuT, vuT.data(), 8 * vuT.size(), hipMemcpyHostToDevice));
+      for (int grid : {1024, 1563, 2048}) {
+        char nm[64];
+        snprintf(nm, 64, "v12 outer-product symmetric grid=%d", grid);
+        run(nm, [&] { hipLaunchKernelGGL(v12, dim3(grid), dim3(256), 0, 0, d_rpu, d_ciu, d_vuT, d_rpl, d_cil, d_sl, d_V, d_O, n); }, false);
+      }
+    }
+  }
+  {  // transposed blocks for v11
+    std::vector<double> vT(vals.size());
+    for (int t = 0; t < nnzb; ++t) for (int p = 0; p < B; ++p) for (int q = 0; q < B; ++q) vT[(size_t)t * BB + q * B + p] = vals[(size_t)t * BB + p * B + q];
+    double* d_vT; HC(hipMalloc(&d_vT, 8 * vT.size())); HC(hipMemcpy(d_vT, vT.data(), 8 * vT.size(), hipMemcpyHostToDevice));
+    for (int grid : {1024, 1563, 2048}) {
+      char nm[64];
+      snprintf(nm, 64, "v11 outer-product grid=%d", grid);
+      run(nm, [&] { hipLaunchKernelGGL(v11<false>, dim3(grid), dim3(256), 0, 0, d_rp, d_ci, d_vT, d_V, d_O, n); }, false);
+      snprintf(nm, 64, "v11 outer-product+preload grid=%d", grid);
+      run(nm, [&] { hipLaunchKernelGGL(v11<true>, dim3(grid), dim3(256), 0, 0, d_rp, d_ci, d_vT, d_V, d_O, n); }, false);
+      snprintf(nm, 64, "v13 batched x2 grid=%d", grid);
+      run(nm, [&] { hipLaunchKernelGGL(v13<2>, dim3(grid), dim3(256), 0, 0, d_rp, d_ci, d_vT, d_V, d_O, n); }, false);
+      snprintf(nm, 64, "v13 batched x4 grid=%d", grid);
+      run(nm, [&] { hipLaunchKernelGGL(v13<4>, dim3(grid), dim3(256), 0, 0, d_rp, d_ci, d_vT, d_V, d_O, n); }, false);
+      snprintf(nm, 64, "v13 batched x8 grid=%d", grid);
+      run(nm, [&] { hipLaunchKernelGGL(v13<8>, dim3(grid), dim3(256), 0, 0, d_rp, d_ci, d_vT, d_V, d_O, n); }, false);
+    }
   }
   return 0;
 }
