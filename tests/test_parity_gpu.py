@@ -468,3 +468,125 @@ def test_gnc_reweighting_with_outliers_matches_oracle(oracle):
     Qh = oracle.construct_Q(n, 2, allm)
     rp, ci, v = pg.quadraticMatrix()
     assert np.array_equal(ci, Qh.colidx) and np.abs(v - Qh.vals).max() <= 1e-9 * np.abs(Qh.vals).max()
+
+
+def _random_graph(oracle, d, n, n_lc, hub_edges, seed):
+    """Chain odometry + random loop closures + one hub pose with `hub_edges` extra edges (a block row far
+    longer than the preloaded index window of the gather core)."""
+    rng = np.random.default_rng(seed)
+    if d == 3:
+        q = rng.standard_normal((n, 4))
+        Rg = oracle._quat_batch(q / np.linalg.norm(q, axis=1, keepdims=True))
+    else:
+        th = rng.uniform(-np.pi, np.pi, n)
+        Rg = np.stack([np.array([[np.cos(a), -np.sin(a)], [np.sin(a), np.cos(a)]]) for a in th])
+    tg = np.cumsum(rng.standard_normal((n, d)), axis=0)
+    hub = n // 3
+    pairs = [(i, i + 1) for i in range(n - 1)]
+    seen = set(pairs)
+    while len(pairs) < n - 1 + n_lc:
+        i, j = sorted(rng.integers(0, n, 2))
+        if j > i + 1 and (i, j) not in seen:
+            seen.add((i, j)); pairs.append((int(i), int(j)))
+    others = rng.permutation(np.setdiff1d(np.arange(n), [hub - 1, hub, hub + 1]))[:hub_edges]
+    for o in others:
+        e = (hub, int(o)) if rng.random() < 0.5 else (int(o), hub)  # both orientations, incl. p2 < p1
+        if e not in seen and (e[1], e[0]) not in seen:
+            seen.add(e); pairs.append(e)
+    p1 = np.array([p[0] for p in pairs]); p2 = np.array([p[1] for p in pairs])
+    m = len(pairs)
+    R = np.swapaxes(Rg[p1], 1, 2) @ Rg[p2]
+    t = (np.swapaxes(Rg[p1], 1, 2) @ (tg[p2] - tg[p1])[:, :, None])[:, :, 0] + 0.05 * rng.standard_normal((m, d))
+    z = np.zeros(m, dtype=np.int64)
+    om = oracle.Measurements(d, z, p1, z.copy(), p2, R, t, rng.uniform(5, 50, m), rng.uniform(5, 50, m), np.ones(m),
+                             p1 + 1 == p2)
+    T = np.zeros((n, d + 1, d))
+    T[:, :d, :] = np.swapaxes(Rg, 1, 2)
+    T[:, d, :] = tg
+    return om, T, hub
+
+
+@pytest.mark.parametrize("d,r,n,hub_edges", [(3, 5, 300, 60), (2, 4, 300, 60), (2, 5, 257, 40), (3, 3, 64, 30),
+                                             (3, 5, 41000, 70)])
+def test_high_degree_rows_and_ragged_sizes(oracle, d, r, n, hub_edges):
+    """Rows longer than the preloaded index window (tail loops of the gather core), both split layouts
+    (n < 40000: 4 lane groups per pose; n >= 40000: 1), 2-D and 3-D, span and generic vector paths (odd / even
+    tile size), pose counts that are not multiples of the wave / workgroup tile."""
+    import dpgo_amd
+    om, T, hub = _random_graph(oracle, d, n, n // 2, hub_edges, seed=100 + n + d)
+    Q = oracle.construct_Q(n, d, om)
+    assert np.diff(Q.rowptr).max() >= hub_edges
+    pg = dpgo_amd.PoseGraph(0, r, d)
+    pg.setMeasurements(to_product_measurements(om))
+    prob = dpgo_amd.QuadraticProblem(pg)
+    op = oracle.QuadraticProblem(Q, None, r, d, precond="jacobi")
+    rng = np.random.default_rng(1)
+    X = oracle.polar_project(oracle.lift(T, r) + 0.1 * rng.standard_normal((n, d + 1, r)), d)
+    V = oracle.tangent_project(X, rng.standard_normal((n, d + 1, r)), d)
+    Xm, Vm = tiles_to_matrix(X), tiles_to_matrix(V)
+    assert relerr(matrix_to_tiles(prob.EucHessianEta(Xm, Vm), d), op.euc_hess(V)) < RTOL_ELEM
+    assert relerr(matrix_to_tiles(prob.RieGrad(Xm), d), op.rie_grad(X)) < RTOL_ELEM
+    S = op.sym_ytg(X, op.euc_grad(X))
+    assert relerr(matrix_to_tiles(prob.RieHessianEta(Xm, Vm), d), op.rie_hess(X, S, V)) < RTOL_ELEM
+    if n <= 1000:
+        oo = oracle.QuadraticOptimizer(op, oracle.ROptParameters(), hess_recurrence=True)
+        Xo = oo.optimize(X)
+        go = dpgo_amd.QuadraticOptimizer(prob, dpgo_amd.ROptParameters())
+        Xg = matrix_to_tiles(go.optimize(Xm), d)
+        rg = go.getOptResult()
+        if rg.tcg_iterations == oo.result.tcg_iters:
+            # random, badly scaled problems (a hub with dozens of edges, r = d) amplify round-off through the
+            # trust-region boundary steps far more than the benchmark datasets do (those agree to 1e-7)
+            # (measured on the r = d = 3 case: agreement 6e-16 after two outer iterations / 18 tCG steps, 1.6e-5
+            # after the third, ill-conditioned, tCG run with identical iteration counts and statuses)
+            assert relerr(Xg, Xo) < 1e-4
+            assert abs(rg.fOpt - oo.result.fOpt) <= 1e-3 * abs(oo.result.fOpt)
+            two = dpgo_amd.ROptParameters(RTR_iterations=2)
+            o2 = oracle.QuadraticOptimizer(op, oracle.ROptParameters(RTR_iterations=2), hess_recurrence=True)
+            X2o = o2.optimize(X)
+            X2g = matrix_to_tiles(dpgo_amd.QuadraticOptimizer(prob, two).optimize(Xm), d)
+            assert relerr(X2g, X2o) < 1e-10
+        else:
+            # the tCG stopping test |r| <= |r0| min(|r0|, 0.1) is a discontinuous decision: on a random problem
+            # round-off can move it by one iteration; both runs must still be the same descent
+            assert abs(rg.tcg_iterations - oo.result.tcg_iters) <= 1 and rg.rtr_iterations == oo.result.outer_iters
+            assert abs(rg.fOpt - oo.result.fOpt) <= 0.05 * abs(oo.result.fOpt) and rg.fOpt < 0.01 * rg.fInit
+    else:
+        go = dpgo_amd.QuadraticOptimizer(prob, dpgo_amd.ROptParameters(RTR_iterations=1, RTR_tCG_iterations=10))
+        oo = oracle.QuadraticOptimizer(op, oracle.ROptParameters(RTR_iterations=1, RTR_tCG_iterations=10),
+                                       hess_recurrence=True)
+        Xo = oo.optimize(X)
+        Xg = matrix_to_tiles(go.optimize(Xm), d)
+        assert relerr(Xg, Xo) < 1e-8
+
+
+def test_single_pose_and_two_pose_graphs(oracle):
+    """Smallest inputs: n = 2 (one edge), and an agent whose block is a single pose with only shared edges."""
+    import dpgo_amd
+    z = np.zeros(1, dtype=np.int64)
+    Rm = oracle._quat_batch(np.array([[0.9, 0.1, -0.3, 0.2]]) / np.linalg.norm([0.9, 0.1, -0.3, 0.2]))
+    om = oracle.Measurements(3, z, np.array([0]), z.copy(), np.array([1]), Rm, np.array([[1.0, 2.0, 3.0]]),
+                             np.array([10.0]), np.array([4.0]), np.ones(1), np.array([True]))
+    pg = dpgo_amd.PoseGraph(0, 5, 3)
+    pg.setMeasurements(to_product_measurements(om))
+    prob = dpgo_amd.QuadraticProblem(pg)
+    X0 = oracle.lift(np.stack([np.vstack([np.eye(3), np.zeros((1, 3))])] * 2), 5)
+    opt = dpgo_amd.QuadraticOptimizer(prob, dpgo_amd.ROptParameters(gradnorm_tol=1e-9, RTR_iterations=30))
+    Xg = matrix_to_tiles(opt.optimize(tiles_to_matrix(X0)), 3)
+    assert opt.getOptResult().fOpt < 1e-12  # one edge can be satisfied exactly
+    # single-pose agent: robot 1 owns one pose, linked to robot 0 by one shared edge
+    shared = oracle.Measurements(3, z, np.array([1]), np.ones(1, dtype=np.int64), np.array([0]), Rm,
+                                 np.array([[1.0, 2.0, 3.0]]), np.array([10.0]), np.array([4.0]), np.ones(1),
+                                 np.array([False]))
+    pg1 = dpgo_amd.PoseGraph(1, 5, 3)
+    pg1.setMeasurements(to_product_measurements(shared))
+    assert pg1.n() == 1 and len(pg1.quadraticMatrix()[1]) == 1
+    nbr = {(0, 1): Xg[1]}
+    pg1.setNeighborPoses({k: v.T for k, v in nbr.items()})
+    prob1 = dpgo_amd.QuadraticProblem(pg1)
+    Qa = oracle.construct_Q(1, 3, oracle.Measurements.empty(3), shared, my_id=1)
+    Ga = oracle.construct_G(1, 3, 5, shared, 1, nbr)
+    pa = oracle.QuadraticProblem(Qa, Ga, 5, 3)
+    Xa = X0[:1]
+    assert abs(prob1.f(tiles_to_matrix(Xa)) - pa.f(Xa)) <= 1e-12 * abs(pa.f(Xa))
+    assert relerr(matrix_to_tiles(prob1.RieGrad(tiles_to_matrix(Xa)), 3), pa.rie_grad(Xa)) < RTOL_ELEM
