@@ -124,9 +124,17 @@ struct dpgo_problem_s {
   int32_t *e_p1 = nullptr, *e_p2 = nullptr, *c_ptr = nullptr, *c_edge = nullptr;
   double *e_R = nullptr, *e_t = nullptr, *e_kappa = nullptr, *e_tau = nullptr, *e_w = nullptr, *e_rsq = nullptr,
          *q_base = nullptr;
-  uint8_t *e_fixed = nullptr, *c_kind = nullptr;
+  uint8_t *e_fixed = nullptr, *c_kind = nullptr, *e_role = nullptr;
+  int32_t* e_slot = nullptr;
+  // contributions of shared re-weightable edges to the coupling matrix C
+  int32_t *g_ptr = nullptr, *g_edge = nullptr;
+  uint8_t* g_kind = nullptr;
+  double* c_base = nullptr;
+  int n_shared_edges = 0;
   int* e_counts = nullptr;
-  EdgeDev edges() const { return EdgeDev{e_p1, e_p2, e_R, e_t, e_kappa, e_tau, e_fixed, e_w, e_rsq, em}; }
+  EdgeDev edges() const {
+    return EdgeDev{e_p1, e_p2, e_R, e_t, e_kappa, e_tau, e_fixed, e_role, e_slot, e_w, e_rsq, em};
+  }
   int cur = 0;
   size_t vec_bytes() const { return (size_t)n * T * sizeof(double); }
   double* pE() const { return partials; }
@@ -496,10 +504,15 @@ int d2h(dpgo_problem_s* p, double* dst, const double* src) {
 
 namespace {
 int free_edges(dpgo_problem_s* p) {
-  void* ptrs[] = {p->e_p1, p->e_p2, p->c_ptr, p->c_edge, p->e_R, p->e_t, p->e_kappa, p->e_tau, p->e_w, p->e_rsq,
-                  p->q_base, p->e_fixed, p->c_kind, p->e_counts};
+  void* ptrs[] = {p->e_p1,  p->e_p2,    p->c_ptr,  p->c_edge,   p->e_R,    p->e_t,    p->e_kappa,
+                  p->e_tau, p->e_w,     p->e_rsq,  p->q_base,   p->e_fixed, p->c_kind, p->e_counts,
+                  p->e_role, p->e_slot, p->g_ptr,  p->g_edge,   p->g_kind, p->c_base};
   for (void* q : ptrs)
     if (q) (void)hipFree(q);
+  p->e_role = p->g_kind = nullptr;
+  p->e_slot = p->g_ptr = p->g_edge = nullptr;
+  p->c_base = nullptr;
+  p->n_shared_edges = 0;
   p->e_p1 = p->e_p2 = p->c_ptr = p->c_edge = nullptr;
   p->e_R = p->e_t = p->e_kappa = p->e_tau = p->e_w = p->e_rsq = p->q_base = nullptr;
   p->e_fixed = p->c_kind = nullptr;
@@ -513,19 +526,29 @@ int upload(Tp** dst, const Tp* src, size_t count, hipStream_t s) {
   if (count > 0) HIPC(hipMemcpyAsync(*dst, src, sizeof(Tp) * count, hipMemcpyHostToDevice, s));
   return DPGO_OK;
 }
-int rebuild_Q_from_weights(dpgo_problem_s* p, const double* base, double sign, double* out) {
-  const int g = std::max(1, std::min(kMaxGrid, (p->Q.nnzb + kBlock - 1) / kBlock));
+int rebuild_vals(dpgo_problem_s* p, int nnzb, const int32_t* cptr, const int32_t* cedge, const uint8_t* ckind,
+                 const double* base, double sign, double* out) {
+  if (nnzb <= 0) return DPGO_OK;
+  const int g = std::max(1, std::min(kMaxGrid, (nnzb + kBlock - 1) / kBlock));
   if (p->d == 2)
-    hipLaunchKernelGGL(k_rebuild_Q<2>, dim3(g), dim3(kBlock), 0, p->stream, p->edges(), p->c_ptr, p->c_edge, p->c_kind,
-                       base, sign, out, p->Q.nnzb);
+    hipLaunchKernelGGL(k_rebuild_Q<2>, dim3(g), dim3(kBlock), 0, p->stream, p->edges(), cptr, cedge, ckind, base,
+                       sign, out, nnzb);
   else
-    hipLaunchKernelGGL(k_rebuild_Q<3>, dim3(g), dim3(kBlock), 0, p->stream, p->edges(), p->c_ptr, p->c_edge, p->c_kind,
-                       base, sign, out, p->Q.nnzb);
+    hipLaunchKernelGGL(k_rebuild_Q<3>, dim3(g), dim3(kBlock), 0, p->stream, p->edges(), cptr, cedge, ckind, base,
+                       sign, out, nnzb);
   HIPC(hipGetLastError());
   return DPGO_OK;
 }
+int rebuild_Q_from_weights(dpgo_problem_s* p, const double* base, double sign, double* out) {
+  return rebuild_vals(p, p->Q.nnzb, p->c_ptr, p->c_edge, p->c_kind, base, sign, out);
+}
+int rebuild_C_from_weights(dpgo_problem_s* p, const double* base, double sign, double* out) {
+  if (!p->g_ptr) return DPGO_OK;
+  return rebuild_vals(p, p->C.nnzb, p->g_ptr, p->g_edge, p->g_kind, base, sign, out);
+}
 int refresh_after_weights(dpgo_problem_s* p) {
   CHK(rebuild_Q_from_weights(p, p->q_base, 1.0, p->Q.vals));
+  CHK(rebuild_C_from_weights(p, p->c_base, 1.0, p->C.vals));  // G itself is refreshed by the next update_G call
   const double s = p->dinv_shift > 0 ? p->dinv_shift : 1e-1;
   p->dinv_shift = -1.0;  // clearQuadraticMatrix also drops the preconditioner (src/PoseGraph.cpp:352-355)
   return build_dinv(p, s);
@@ -718,48 +741,91 @@ int dpgo_problem_set_Q_csr(dpgo_problem_t p, const int32_t* outer, const int32_t
   return dpgo_problem_set_Q_bsr(p, (int)colidx.size(), rowptr.data(), colidx.data(), vals.data());
 }
 
-int dpgo_problem_set_reweightable_edges(dpgo_problem_t p, int m, const int32_t* p1, const int32_t* p2, const double* R,
-                                        const double* t, const double* kappa, const double* tau, const double* weight,
-                                        const uint8_t* fixed_weight) {
+int dpgo_problem_set_reweightable_edges_ex(dpgo_problem_t p, int m, const int32_t* p1, const int32_t* p2,
+                                           const uint8_t* role, const int32_t* slot_in, const double* R,
+                                           const double* t, const double* kappa, const double* tau,
+                                           const double* weight, const uint8_t* fixed_weight) {
   CHK(check_ready(p));
   if (m < 0 || (m > 0 && (!p1 || !p2 || !R || !t || !kappa || !tau || !weight || !fixed_weight)))
     return fail(DPGO_ERR_INVALID, "null edge arrays");
+  if (role && !slot_in) return fail(DPGO_ERR_INVALID, "roles given without neighbour slots");
   const int n = p->n, d = p->d, nnzb = p->Q.nnzb;
-  // host copy of the pattern to locate the slots
+  // host copy of the patterns to locate the blocks each edge contributes to
   std::vector<int32_t> rowptr(n + 1), colidx(nnzb);
   HIPC(hipMemcpy(rowptr.data(), p->Q.rowptr, sizeof(int32_t) * (n + 1), hipMemcpyDeviceToHost));
   HIPC(hipMemcpy(colidx.data(), p->Q.colidx, sizeof(int32_t) * nnzb, hipMemcpyDeviceToHost));
-  auto slot = [&](int i, int j) -> int {
-    const int32_t* b = colidx.data() + rowptr[i];
-    const int32_t* e = colidx.data() + rowptr[i + 1];
+  int n_shared = 0;
+  for (int e = 0; e < m; ++e)
+    if (role && role[e]) ++n_shared;
+  std::vector<int32_t> crow, ccol;
+  const int cnnz = (n_shared > 0) ? p->C.nnzb : 0;
+  if (n_shared > 0) {
+    if (!p->C.rowptr) return fail(DPGO_ERR_STATE, "shared re-weightable edges need the G coupling first");
+    crow.resize(n + 1);
+    ccol.resize(cnnz > 0 ? cnnz : 1);
+    HIPC(hipMemcpy(crow.data(), p->C.rowptr, sizeof(int32_t) * (n + 1), hipMemcpyDeviceToHost));
+    if (cnnz > 0) HIPC(hipMemcpy(ccol.data(), p->C.colidx, sizeof(int32_t) * cnnz, hipMemcpyDeviceToHost));
+  }
+  auto find = [](const std::vector<int32_t>& rp, const std::vector<int32_t>& ci, int i, int j) -> int {
+    const int32_t* b = ci.data() + rp[i];
+    const int32_t* e = ci.data() + rp[i + 1];
     const int32_t* it = std::lower_bound(b, e, (int32_t)j);
-    return (it != e && *it == j) ? (int)(it - colidx.data()) : -1;
+    return (it != e && *it == j) ? (int)(it - ci.data()) : -1;
   };
-  std::vector<std::vector<std::pair<int, uint8_t>>> lists(nnzb);
+  std::vector<std::vector<std::pair<int, uint8_t>>> lists(nnzb), glists(cnnz);
+  std::vector<uint8_t> role_v(m > 0 ? m : 1, 0);
+  std::vector<int32_t> slot_v(m > 0 ? m : 1, 0);
   for (int e = 0; e < m; ++e) {
     const int i = p1[e], j = p2[e];
-    if (i < 0 || i >= n || j < 0 || j >= n || i == j) return fail(DPGO_ERR_INVALID, "edge endpoint out of range");
-    const int sii = slot(i, i), sjj = slot(j, j), sij = slot(i, j), sji = slot(j, i);
-    if (sii < 0 || sjj < 0 || sij < 0 || sji < 0)
-      return fail(DPGO_ERR_STATE, "edge does not fit the block pattern of Q");
-    lists[sii].push_back({e, 0});
-    lists[sjj].push_back({e, 1});
-    lists[sij].push_back({e, 2});
-    lists[sji].push_back({e, 3});
-  }
-  std::vector<int32_t> cptr(nnzb + 1, 0), cedge;
-  std::vector<uint8_t> ckind;
-  for (int s = 0; s < nnzb; ++s) {
-    for (auto& pr : lists[s]) {
-      cedge.push_back(pr.first);
-      ckind.push_back(pr.second);
+    const int ro = role ? role[e] : 0;
+    role_v[e] = (uint8_t)ro;
+    if (ro == 0) {
+      if (i < 0 || i >= n || j < 0 || j >= n || i == j) return fail(DPGO_ERR_INVALID, "edge endpoint out of range");
+      const int sii = find(rowptr, colidx, i, i), sjj = find(rowptr, colidx, j, j), sij = find(rowptr, colidx, i, j),
+                sji = find(rowptr, colidx, j, i);
+      if (sii < 0 || sjj < 0 || sij < 0 || sji < 0)
+        return fail(DPGO_ERR_STATE, "edge does not fit the block pattern of Q");
+      lists[sii].push_back({e, 0});
+      lists[sjj].push_back({e, 1});
+      lists[sij].push_back({e, 2});
+      lists[sji].push_back({e, 3});
+    } else if (ro == 1 || ro == 2) {
+      // outgoing: Q_ii += T Om T^T, C(i, slot) = -T Om; incoming: Q_jj += Om, C(j, slot) = -Om T^T
+      // (PoseGraph::constructQ :462-486, constructG :533-562)
+      const int mine = (ro == 1) ? i : j;
+      const int sl = slot_in[e];
+      if (mine < 0 || mine >= n || sl < 0 || sl >= p->C.ncols)
+        return fail(DPGO_ERR_INVALID, "shared edge endpoint / neighbour slot out of range");
+      slot_v[e] = sl;
+      const int sd = find(rowptr, colidx, mine, mine), sc = find(crow, ccol, mine, sl);
+      if (sd < 0 || sc < 0) return fail(DPGO_ERR_STATE, "shared edge does not fit the pattern of Q / the G coupling");
+      lists[sd].push_back({e, (uint8_t)(ro == 1 ? 0 : 1)});
+      glists[sc].push_back({e, (uint8_t)(ro == 1 ? 2 : 3)});
+    } else {
+      return fail(DPGO_ERR_INVALID, "edge role must be 0, 1 or 2");
     }
-    cptr[s + 1] = (int32_t)cedge.size();
   }
+  auto flatten = [](const std::vector<std::vector<std::pair<int, uint8_t>>>& L, std::vector<int32_t>& ptr,
+                    std::vector<int32_t>& edge, std::vector<uint8_t>& kind) {
+    ptr.assign(L.size() + 1, 0);
+    for (size_t s = 0; s < L.size(); ++s) {
+      for (auto& pr : L[s]) {
+        edge.push_back(pr.first);
+        kind.push_back(pr.second);
+      }
+      ptr[s + 1] = (int32_t)edge.size();
+    }
+  };
+  std::vector<int32_t> cptr, cedge, gptr, gedge;
+  std::vector<uint8_t> ckind, gkind;
+  flatten(lists, cptr, cedge, ckind);
   CHK(free_edges(p));
   p->em = m;
+  p->n_shared_edges = n_shared;
   CHK(upload(&p->e_p1, p1, (size_t)m, p->stream));
   CHK(upload(&p->e_p2, p2, (size_t)m, p->stream));
+  CHK(upload(&p->e_role, role_v.data(), (size_t)m, p->stream));
+  CHK(upload(&p->e_slot, slot_v.data(), (size_t)m, p->stream));
   CHK(upload(&p->e_R, R, (size_t)m * d * d, p->stream));
   CHK(upload(&p->e_t, t, (size_t)m * d, p->stream));
   CHK(upload(&p->e_kappa, kappa, (size_t)m, p->stream));
@@ -772,22 +838,38 @@ int dpgo_problem_set_reweightable_edges(dpgo_problem_t p, int m, const int32_t* 
   HIPC(hipMalloc(&p->e_rsq, sizeof(double) * (m > 0 ? m : 1)));
   HIPC(hipMalloc(&p->e_counts, sizeof(int) * 4));
   HIPC(hipMalloc(&p->q_base, sizeof(double) * (size_t)nnzb * p->b * p->b));
-  // base = Q(current weights) - sum of the private-edge contributions at those weights
+  // base = Q(current weights) - sum of the listed edges' contributions at those weights
   CHK(rebuild_Q_from_weights(p, p->Q.vals, -1.0, p->q_base));
+  if (n_shared > 0 && cnnz > 0) {
+    flatten(glists, gptr, gedge, gkind);
+    CHK(upload(&p->g_ptr, gptr.data(), gptr.size(), p->stream));
+    CHK(upload(&p->g_edge, gedge.data(), gedge.size(), p->stream));
+    CHK(upload(&p->g_kind, gkind.data(), gkind.size(), p->stream));
+    HIPC(hipMalloc(&p->c_base, sizeof(double) * (size_t)cnnz * p->b * p->b));
+    CHK(rebuild_C_from_weights(p, p->C.vals, -1.0, p->c_base));
+  }
   HIPC(hipStreamSynchronize(p->stream));
   return DPGO_OK;
 }
 
-int dpgo_problem_gnc_reweight_device(dpgo_problem_t p, const double* X_dev, double mu, double barc, double w_tol,
-                                     int update, int counts[3], double* max_rsq) {
+int dpgo_problem_set_reweightable_edges(dpgo_problem_t p, int m, const int32_t* p1, const int32_t* p2, const double* R,
+                                        const double* t, const double* kappa, const double* tau, const double* weight,
+                                        const uint8_t* fixed_weight) {
+  return dpgo_problem_set_reweightable_edges_ex(p, m, p1, p2, nullptr, nullptr, R, t, kappa, tau, weight,
+                                                fixed_weight);
+}
+
+int dpgo_problem_gnc_reweight_device(dpgo_problem_t p, const double* X_dev, const double* nbr_tiles_dev, double mu,
+                                     double barc, double w_tol, int update, int counts[3], double* max_rsq) {
   CHK(check_ready(p));
   if (!p->e_w) return fail(DPGO_ERR_STATE, "re-weightable edges not set");
   if (!X_dev) return fail(DPGO_ERR_INVALID, "null X");
+  if (p->n_shared_edges > 0 && !nbr_tiles_dev) return fail(DPGO_ERR_INVALID, "shared edges need the neighbour tiles");
   if (update && !(mu > 0.0)) return fail(DPGO_ERR_INVALID, "GNC mu must be positive");
   HIPC(hipMemsetAsync(p->e_counts, 0, sizeof(int) * 4, p->stream));
   const int g = std::max(1, std::min(kMaxGrid, (p->em + kBlock - 1) / kBlock));
   DISPATCH(p->d, p->r, hipLaunchKernelGGL((k_edge_weights<D, R>), dim3(g), dim3(kBlock), 0, p->stream, p->edges(), X_dev,
-                                          mu, barc, w_tol, update, p->e_counts));
+                                          nbr_tiles_dev, mu, barc, w_tol, update, p->e_counts));
   HIPC(hipGetLastError());
   if (update) CHK(refresh_after_weights(p));
   int h[4] = {0, 0, 0, 0};
@@ -877,6 +959,8 @@ int dpgo_problem_set_G_coupling(dpgo_problem_t p, int ncols, int nnzb, const int
   if (nnzb > 0 && !vals) return fail(DPGO_ERR_INVALID, "null vals");
   CHK(validate_bsr(p->n, ncols, nnzb, rowptr, colidx, false));
   CHK(set_device(p));
+  // shared re-weightable edges index into the old coupling pattern: drop them (the caller re-registers)
+  if (p->n_shared_edges > 0) CHK(free_edges(p));
   CHK(upload_bsr(p->C, p->n, ncols, nnzb, p->b, rowptr, colidx, vals, p->stream));
   if (G0_host) {
     CHK(h2d(p, p->G0, G0_host));

@@ -1794,19 +1794,24 @@ struct EdgeDev {
   const double* kappa;
   const double* tau;
   const uint8_t* fixed;
+  const uint8_t* role;   // 0 private, 1 shared outgoing (p1 mine, other pose = neighbour slot), 2 shared incoming
+  const int32_t* slot;   // neighbour-tile slot of the other pose (roles 1, 2)
   double* weight;
   double* rsq;
   int m;
 };
 
 template <int D, int R>
-__global__ __launch_bounds__(kBlock) void k_edge_weights(EdgeDev E, const double* __restrict__ X, double mu,
-                                                         double barc, double w_tol, int update_weights,
-                                                         int* __restrict__ counts) {
+__global__ __launch_bounds__(kBlock) void k_edge_weights(EdgeDev E, const double* __restrict__ X,
+                                                         const double* __restrict__ nbr, double mu, double barc,
+                                                         double w_tol, int update_weights, int* __restrict__ counts) {
   constexpr int B = D + 1, T = B * R;
   for (int e = blockIdx.x * kBlock + threadIdx.x; e < E.m; e += gridDim.x * kBlock) {
-    const double* __restrict__ xi = X + (size_t)E.p1[e] * T;
-    const double* __restrict__ xj = X + (size_t)E.p2[e] * T;
+    // shared edges (PGOAgent::computeMeasurementResidual, src/PGOAgent.cpp:1048-1102): the pose owned by the
+    // neighbour comes from the public-pose buffer
+    const int role = E.role[e];
+    const double* __restrict__ xi = (role == 2) ? nbr + (size_t)E.slot[e] * T : X + (size_t)E.p1[e] * T;
+    const double* __restrict__ xj = (role == 1) ? nbr + (size_t)E.slot[e] * T : X + (size_t)E.p2[e] * T;
     const double* __restrict__ Rm = E.Rm + (size_t)e * D * D;
     const double* __restrict__ tv = E.t + (size_t)e * D;
     double rot = 0.0, tr = 0.0;
@@ -1836,7 +1841,7 @@ __global__ __launch_bounds__(kBlock) void k_edge_weights(EdgeDev E, const double
         else w = sqrt(bSq * mu * (mu + 1.0) / rSq) - mu;
         E.weight[e] = w;
       }
-      if (counts) {
+      if (counts && role != 2) {  // a shared edge is counted by the agent that owns its source pose
         if (w < w_tol) atomicAdd(&counts[1], 1);
         else if (w > 1.0 - w_tol) atomicAdd(&counts[0], 1);
         else atomicAdd(&counts[2], 1);

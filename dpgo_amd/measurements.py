@@ -137,8 +137,10 @@ def partition_contiguous(dataset: RelativeSEMeasurements, num_poses: int, num_ro
     robot_of = np.minimum(np.arange(num_poses) // per, num_robots - 1)
     local = np.arange(num_poses) - starts[robot_of]
     m = len(dataset)
+    # (the demo's relabelled measurements get weight 1 / fixedWeight false from the RelativeSEMeasurement
+    # constructor; weights and flags of the input are carried through so GNC drivers can partition too)
     g = RelativeSEMeasurements(dataset.d, robot_of[dataset.p1], local[dataset.p1], robot_of[dataset.p2],
                                local[dataset.p2], dataset.R, dataset.t, dataset.kappa, dataset.tau,
-                               np.ones(m), np.zeros(m, dtype=bool))
+                               dataset.weight.copy(), dataset.fixedWeight.copy())
     per_robot = [g.select((g.r1 == a) | (g.r2 == a)) for a in range(num_robots)]
     return [(int(s), int(e)) for s, e in zip(starts, ends)], per_robot

@@ -106,15 +106,11 @@ class _DeviceSolve:
         self.problem.setStream(torch.cuda.current_stream().cuda_stream)
         self.m = self.pg.measurements()
         self.kept = self.pg.kept_index  # positions of the kept edges in the caller's array
-        fixed = np.ascontiguousarray(self.m.fixedWeight, dtype=np.uint8)
-        L.check(self.problem._lib.dpgo_problem_set_reweightable_edges(
-            self.problem.handle, len(self.m), L.ptr(self.m.p1), L.ptr(self.m.p2), L.ptr(self.m.R), L.ptr(self.m.t),
-            L.ptr(self.m.kappa), L.ptr(self.m.tau), L.ptr(self.m.weight), L.ptr(fixed)))
+        self.problem.setReweightableEdges()
         self.device = torch.device("cuda", device)
 
     def set_weights(self, w: np.ndarray) -> None:
-        w = np.ascontiguousarray(w, dtype=np.float64)
-        L.check(self.problem._lib.dpgo_problem_set_edge_weights(self.problem.handle, L.ptr(w)))
+        self.problem.setEdgeWeights(w)
 
     def solve(self, T0_tiles: np.ndarray, params: ROptParameters):
         X = self.torch.tensor(np.ascontiguousarray(T0_tiles), dtype=self.torch.float64, device=self.device)
@@ -123,18 +119,10 @@ class _DeviceSolve:
         return X, opt.getOptResult()
 
     def reweight(self, X, mu: float, barc: float, w_tol: float, update: bool):
-        counts = (C.c_int * 3)()
-        mx = C.c_double(0.0)
-        L.check(self.problem._lib.dpgo_problem_gnc_reweight_device(
-            self.problem.handle, L.ptr(X), float(mu), float(barc), float(w_tol), int(update), C.byref(counts),
-            C.byref(mx)))
-        return tuple(counts), mx.value
+        return self.problem.gncReweightDevice(X, None, mu, barc, w_tol, update)
 
     def weights(self):
-        w = np.zeros(len(self.m))
-        rs = np.zeros(len(self.m))
-        L.check(self.problem._lib.dpgo_problem_get_edge_weights(self.problem.handle, L.ptr(w), L.ptr(rs)))
-        return w, rs
+        return self.problem.getEdgeWeights()
 
 
 def solvePGO(measurements: RelativeSEMeasurements, num_poses: int, params: Optional[ROptParameters] = None,
@@ -182,3 +170,86 @@ def solveRobustPGO(mutable_measurements: RelativeSEMeasurements, num_poses: int,
     meas.weight[ds.kept] = w
     info["fOpt"] = res.fOpt
     return X.cpu().numpy(), info
+
+
+class DistributedGNC:
+    """Synchronous distributed GNC-TLS over an RBCDCluster (BASELINE configs[4]).
+
+    Assembled from the reference's per-agent pieces -- the in-tree library never drives them itself, the
+    external dpgo_ros node does:
+      * PGOAgent::updateMeasurementWeights (src/PGOAgent.cpp:1104-1142): every agent re-weights ALL its
+        non-fixed loop closures, private and shared, from its iterate and its neighbours' public poses
+        (computeMeasurementResidual, :1048-1102); RobustCost::update (mu <- GNCMuStep * mu); the data
+        matrices are refreshed (clearDataMatrices -> here: Q / coupling / preconditioner VALUES rebuilt on
+        the device, pattern fixed); warm start (robustOptNumResets = 0);
+      * initial mu as solveRobustPGO (src/DPGO_solver.cpp:358) from the largest residual after the first
+        block of sweeps; stop when no weight is undecided (tolerance 1e-8, :340, :403).
+    Both endpoints of a shared edge evaluate the same residual on the same poses and hence agree on its
+    weight without a message (the reference ships weights from the owner instead; same values).
+    Global scalars (max residual, the three counters) are one tiny all-reduce each per weight update."""
+
+    def __init__(self, cluster, robust_params: Optional[RobustCostParameters] = None, inner_sweeps: int = 5):
+        self.cluster = cluster
+        self.params = robust_params or RobustCostParameters("GNC_TLS", GNCMaxNumIters=30)
+        if self.params.costType != "GNC_TLS":
+            raise ValueError("CHECK(costType == GNC_TLS) failed")
+        self.inner_sweeps = int(inner_sweeps)
+        for agent in cluster.agents.values():
+            agent.problem.setReweightableEdges(include_shared=True)
+
+    def _allreduce(self, values, op: str):
+        c = self.cluster
+        if c.world == 1:
+            return np.asarray(values, dtype=np.float64)
+        import torch
+        import torch.distributed as dist
+        dev = getattr(next(iter(c.agents.values())), "device", "cpu")
+        t = torch.tensor(values, dtype=torch.float64, device="cpu" if c.stage else dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX if op == "max" else dist.ReduceOp.SUM)
+        return t.cpu().numpy()
+
+    def _reweight_all(self, mu: float, update: bool):
+        self.cluster.exchange(None)  # everyone's public poses are current
+        counts, mx = np.zeros(3), 0.0
+        for agent in self.cluster.agents.values():
+            c, m = agent.problem.gncReweightDevice(agent.X, agent.nbr if agent.has_neighbours else None, mu,
+                                                   self.params.GNCBarc, 1e-8, update)
+            counts += c
+            mx = max(mx, m)
+        counts = self._allreduce(counts, "sum")
+        mx = float(self._allreduce([mx], "max")[0])
+        return tuple(int(v) for v in counts), mx
+
+    def _sweeps(self) -> None:
+        for _ in range(self.inner_sweeps):
+            self.cluster.sweep()
+
+    def run(self):
+        """Returns info = {muInit, updates, history[], cost, gradnorm}; the iterates stay on the agents."""
+        p = self.params
+        for agent in self.cluster.agents.values():
+            agent.problem.setEdgeWeights(np.ones(len(agent.problem.reweightable_index)))
+        self._sweeps()
+        _, max_rsq = self._reweight_all(1.0, update=False)
+        barcSq = p.GNCBarc ** 2
+        muInit = barcSq / (2 * max_rsq - barcSq)
+        info = dict(muInit=muInit, updates=0, history=[])
+        if muInit > 0:
+            mu = muInit
+            for it in range(p.GNCMaxNumIters):
+                (n_in, n_out, n_und), _ = self._reweight_all(mu, update=True)
+                info["history"].append(dict(mu=mu, inliers=n_in, outliers=n_out, undecided=n_und))
+                info["updates"] = it + 1
+                if n_und == 0:
+                    break
+                mu = p.GNCMuStep * mu
+                self._sweeps()
+        self._sweeps()
+        f, gn = self.cluster.central_cost_and_gradnorm()
+        info["cost"], info["gradnorm"] = 2 * f, gn
+        return info
+
+    def weights(self):
+        """{agent id: (positions in that agent's pose_graph.measurements(), weights)} of the local agents."""
+        return {a: (ag.problem.reweightable_index, ag.problem.getEdgeWeights()[0])
+                for a, ag in self.cluster.agents.items()}

@@ -403,6 +403,55 @@ class QuadraticProblem:
         L.check(self._lib.dpgo_problem_update_G_from_neighbors_device(self._h, L.ptr(nbr_tiles_dev)))
         self._g_obj = None
 
+    # ---- GNC re-weighting on the device (PGOAgent::updateMeasurementWeights, src/PGOAgent.cpp:1104-1142) ----
+    def setReweightableEdges(self, include_shared: bool = False) -> int:
+        """Register the pose graph's edges as re-weightable: private edges always, shared loop closures
+        too when include_shared (needs setCouplingFromPoseGraph first).  Edge order = measurements() order
+        (optionally without the shared ones).  Returns the number of registered edges."""
+        pg = self.pose_graph_
+        m = pg.measurements()
+        shared = m.r1 != m.r2
+        sel = np.arange(len(m)) if include_shared else np.nonzero(~shared)[0]
+        m = m.select(sel)
+        role = np.zeros(len(m), dtype=np.uint8)
+        slot = np.zeros(len(m), dtype=np.int32)
+        if include_shared and (m.r1 != m.r2).any():
+            slot_index = {pid: k for k, pid in enumerate(pg.couplingMatrix()[0])}
+            for e in np.nonzero(m.r1 != m.r2)[0]:
+                if m.r1[e] == pg.id():
+                    role[e], slot[e] = 1, slot_index[(int(m.r2[e]), int(m.p2[e]))]
+                else:
+                    role[e], slot[e] = 2, slot_index[(int(m.r1[e]), int(m.p1[e]))]
+        fixed = np.ascontiguousarray(m.fixedWeight, dtype=np.uint8)
+        w = np.ascontiguousarray(m.weight, dtype=np.float64)
+        L.check(self._lib.dpgo_problem_set_reweightable_edges_ex(
+            self._h, len(m), L.ptr(m.p1), L.ptr(m.p2), L.ptr(role), L.ptr(slot), L.ptr(m.R), L.ptr(m.t),
+            L.ptr(m.kappa), L.ptr(m.tau), L.ptr(w), L.ptr(fixed)))
+        self.reweightable_index = sel  # positions in pose_graph.measurements()
+        return len(m)
+
+    def gncReweightDevice(self, X_dev, nbr_tiles_dev, mu: float, barc: float, w_tol: float = 1e-8,
+                          update: bool = True):
+        """Residuals (and, if update, GNC-TLS weights + rebuilt Q / coupling / preconditioner values) at a
+        device iterate.  Returns ((inliers, outliers, undecided), max residual^2)."""
+        counts = (C.c_int * 3)()
+        mx = C.c_double(0.0)
+        L.check(self._lib.dpgo_problem_gnc_reweight_device(
+            self._h, L.ptr(X_dev), L.ptr(nbr_tiles_dev) if nbr_tiles_dev is not None else None, float(mu),
+            float(barc), float(w_tol), int(update), C.byref(counts), C.byref(mx)))
+        return tuple(counts), mx.value
+
+    def setEdgeWeights(self, w: np.ndarray) -> None:
+        w = np.ascontiguousarray(w, dtype=np.float64)
+        L.check(self._lib.dpgo_problem_set_edge_weights(self._h, L.ptr(w)))
+
+    def getEdgeWeights(self):
+        """(weights, squared residuals of the last gncReweightDevice) of the registered edges."""
+        m = len(self.reweightable_index)
+        w, rs = np.zeros(m), np.zeros(m)
+        L.check(self._lib.dpgo_problem_get_edge_weights(self._h, L.ptr(w), L.ptr(rs)))
+        return w, rs
+
     def evalDevice(self, X_dev) -> Tuple[float, float]:
         f, g = C.c_double(0.0), C.c_double(0.0)
         L.check(self._lib.dpgo_problem_eval_device(self._h, L.ptr(X_dev), C.byref(f), C.byref(g)))

@@ -142,13 +142,23 @@ int dpgo_problem_update_Q_values(dpgo_problem_t h, const double* vals);
 int dpgo_problem_set_reweightable_edges(dpgo_problem_t h, int m, const int32_t* p1, const int32_t* p2,
                                         const double* R, const double* t, const double* kappa, const double* tau,
                                         const double* weight, const uint8_t* fixed_weight);
-/* Residuals rSq_e = computeMeasurementError (src/DPGO_utils.cpp:501-507) at the device iterate X_dev; if
- * update != 0 the non-fixed weights become RobustCost::weight(sqrt(rSq)) for GNC_TLS with the given mu and
- * barc (src/DPGO_robust.cpp:80-92) and Q's values + the preconditioner are rebuilt on the device.
- * counts[3] = {inliers, outliers, undecided} among non-fixed edges (w_tol as in DPGO_solver.cpp:340).
- * max_rsq (optional) = max residual over all edges (used for muInit, DPGO_solver.cpp:358). */
-int dpgo_problem_gnc_reweight_device(dpgo_problem_t h, const double* X_dev, double mu, double barc, double w_tol,
-                                     int update, int counts[3], double* max_rsq);
+/* General form including SHARED loop closures (distributed GNC: PGOAgent::updateMeasurementWeights re-weights
+ * private and shared edges alike, src/PGOAgent.cpp:1104-1118).  role[e]: 0 private (p1, p2 both mine),
+ * 1 shared outgoing (p1 mine; the other pose is neighbour-tile slot[e]), 2 shared incoming (p2 mine).
+ * A shared edge contributes to Q's diagonal block of my pose and to one block of the G-coupling matrix
+ * (call dpgo_problem_set_G_coupling first); both are rebuilt on the device after a weight change. */
+int dpgo_problem_set_reweightable_edges_ex(dpgo_problem_t h, int m, const int32_t* p1, const int32_t* p2,
+                                           const uint8_t* role, const int32_t* slot, const double* R,
+                                           const double* t, const double* kappa, const double* tau,
+                                           const double* weight, const uint8_t* fixed_weight);
+/* Residuals rSq_e = computeMeasurementError (src/DPGO_utils.cpp:501-507) at the device iterate X_dev (shared
+ * edges: other pose from nbr_tiles_dev, may be NULL if there are none); if update != 0 the non-fixed weights
+ * become RobustCost::weight(sqrt(rSq)) for GNC_TLS with the given mu and barc (src/DPGO_robust.cpp:80-92) and
+ * Q's values, the coupling values and the preconditioner are rebuilt on the device.
+ * counts[3] = {inliers, outliers, undecided} among non-fixed edges whose source pose this agent owns
+ * (w_tol as in DPGO_solver.cpp:340).  max_rsq (optional) = max residual over all edges (muInit, :358). */
+int dpgo_problem_gnc_reweight_device(dpgo_problem_t h, const double* X_dev, const double* nbr_tiles_dev, double mu,
+                                     double barc, double w_tol, int update, int counts[3], double* max_rsq);
 int dpgo_problem_set_edge_weights(dpgo_problem_t h, const double* weight_host);   /* + rebuild Q, preconditioner */
 int dpgo_problem_get_edge_weights(dpgo_problem_t h, double* weight_host, double* rsq_host /* may be NULL */);
 

@@ -158,8 +158,10 @@ def partition_contiguous(meas: Measurements, n: int, num_robots: int):
     ends[-1] = n
     robot_of = np.minimum(np.arange(n) // per, num_robots - 1)
     local = np.arange(n) - np.array(starts)[robot_of]
+    # the demo relabels with weight 1 / fixedWeight false (RelativeSEMeasurement ctor); weights and flags of the
+    # input are carried through here so that GNC drivers can partition a re-weighted graph
     g = Measurements(meas.d, robot_of[meas.p1], local[meas.p1], robot_of[meas.p2], local[meas.p2],
-                     meas.R, meas.t, meas.kappa, meas.tau, np.ones(meas.m), np.zeros(meas.m, dtype=bool))
+                     meas.R, meas.t, meas.kappa, meas.tau, meas.weight.copy(), meas.fixed.copy())
     out = []
     for a in range(num_robots):
         same = (g.r1 == a) & (g.r2 == a)
@@ -1054,3 +1056,58 @@ def solve_robust_pgo(meas: Measurements, n: int, T0, opt_params: Optional[ROptPa
     T, res = solve()
     info["fOpt"] = res.fOpt
     return T, info
+
+
+# --------------------------------------------------------------------------
+# Multi-agent GNC (checker for dpgo_amd.robust.DistributedGNC)
+# --------------------------------------------------------------------------
+
+
+def multi_agent_gnc(meas: Measurements, n: int, num_robots: int, r: int, X0, inner_sweeps: int = 5, barc: float = 5.0,
+                    mu_step: float = 1.4, max_updates: int = 30, params: Optional[ROptParameters] = None,
+                    precond: str = "jacobi", hess_recurrence: bool = False):
+    """Synchronous distributed GNC-TLS assembled from the reference's per-agent pieces (the in-tree library never
+    calls them itself; the external dpgo_ros driver does):
+      * PGOAgent::updateMeasurementWeights (src/PGOAgent.cpp:1104-1142): every agent re-weights ALL its non-fixed
+        loop closures, private and shared, from its own iterate and its neighbours' public poses
+        (computeMeasurementResidual, :1048-1102), w = RobustCost::weight(residual), then mu <- mu_step * mu
+        (RobustCost::update) and the data matrices are rebuilt (clearDataMatrices); warm start (robustOptNumResets = 0);
+      * initial mu as in solveRobustPGO (src/DPGO_solver.cpp:358) from the largest residual of the first solve;
+      * between weight updates: `inner_sweeps` coloured RBCD sweeps (robustOptInnerIters analogue);
+      * stop when no weight is undecided (tolerance 1e-8, DPGO_solver.cpp:340) or after max_updates.
+    Both endpoints of a shared edge compute the same residual from the same poses, hence the same weight.
+    `meas` holds GLOBAL indices; its weight array is updated in place.  Returns (X, info)."""
+    d = meas.d
+    prm = params or ROptParameters()
+    w_tol = 1e-8
+    central_n = n
+
+    def sweeps(X, k):
+        for _ in range(k):
+            X, _, _ = rbcd_coloured(meas, central_n, num_robots, r, X, 1, prm, precond, hess_recurrence)
+        return X
+
+    meas.weight[:] = 1.0
+    X = sweeps(X0.copy(), inner_sweeps)
+    rsq = measurement_error(meas, X)
+    muInit = barc * barc / (2 * rsq.max() - barc * barc)
+    info = dict(muInit=muInit, updates=0, history=[])
+    if muInit > 0:
+        mu = muInit
+        for it in range(max_updates):
+            rsq = measurement_error(meas, X)
+            w = gnc_tls_weight(np.sqrt(rsq), mu, barc)
+            meas.weight[~meas.fixed] = w[~meas.fixed]
+            nf = meas.weight[~meas.fixed]
+            n_out = int((nf < w_tol).sum()); n_in = int((nf > 1 - w_tol).sum()); n_und = len(nf) - n_in - n_out
+            info["history"].append(dict(mu=mu, inliers=n_in, outliers=n_out, undecided=n_und))
+            info["updates"] = it + 1
+            if n_und == 0:
+                break
+            mu = mu_step * mu
+            X = sweeps(X, inner_sweeps)
+    X = sweeps(X, inner_sweeps)
+    central = QuadraticProblem(construct_Q(n, d, meas), None, r, d)
+    info["cost"] = 2 * central.f(X)
+    info["gradnorm"] = central.rie_grad_norm(X)
+    return X, info

@@ -1,0 +1,49 @@
+"""bench.py / __graft_entry__ contract checks."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+REQUIRED = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+            "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"}
+
+
+def test_algorithmic_byte_formulas_match_the_survey():
+    """bytes = nnzb (8 b^2 + 4) + 4 (n + 1) + 16 r b n; 100k grid: 122.7 MB ("123.1" with MB = 1e6)."""
+    sys.path.insert(0, ROOT)
+    import bench
+    assert bench.spmm_bytes(100000, 687000, 3, 5) == 687000 * 132 + 4 * 100001 + 320 * 100000 == 123084004
+    assert bench.spmm_bytes(2500, 12398, 3, 5) == 2446540  # sphere2500: 2.44 MB
+    assert bench.hess_bytes(100000, 687000, 3, 5) == 687000 * 132 + 4 * 100001 + 100000 * (6 * 160 + 72)
+    assert bench.HBM_PEAK_GBS == 8000.0
+
+
+def test_entry_points_exist():
+    sys.path.insert(0, ROOT)
+    import __graft_entry__ as g
+    assert callable(g.build) and callable(g.smoke)
+
+
+@pytest.mark.gpu
+def test_bench_prints_one_valid_json_line():
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "grid:12x10x6", "--steps", "2",
+                        "--warmup", "1", "--settle", "2", "--cpu-budget-s", "3", "--spmm-reps", "20"],
+                       capture_output=True, text=True, cwd=ROOT, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    assert REQUIRED <= set(j)
+    assert j["metric"] == "rbcd_iterations_per_sec" and j["unit"] == "it/s" and j["higher_is_better"] is True
+    assert j["n_gpus"] == 1 and j["steps"] == 2 and j["warmup"] == 1 and j["dtype"] == "f64" and j["vs_baseline"] is None
+    assert j["value"] > 0 and abs(j["value"] - 1e3 / j["ms_per_step"]) < 1e-6 * j["value"]
+    assert "workload" in j["config"] and "model" not in j["config"]
+    rf = j["roofline"]
+    assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12 and rf["achieved"] > 0
+    cb = j["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] == 1 and cb["value"] > 0 and cb["unit"] == "it/s"

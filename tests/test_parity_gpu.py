@@ -590,3 +590,101 @@ def test_single_pose_and_two_pose_graphs(oracle):
     Xa = X0[:1]
     assert abs(prob1.f(tiles_to_matrix(Xa)) - pa.f(Xa)) <= 1e-12 * abs(pa.f(Xa))
     assert relerr(matrix_to_tiles(prob1.RieGrad(tiles_to_matrix(Xa)), 3), pa.rie_grad(Xa)) < RTOL_ELEM
+
+
+def _inject_outliers(oracle, om, n, k, seed):
+    """k random loop closures (random rotation, translation in [-5, 5]^d) with median precisions, weight 1."""
+    rng = np.random.default_rng(seed)
+    d = om.d
+    # no duplicate (src, dst) pairs: PoseGraph::addMeasurement drops those (src/PoseGraph.cpp:83-88)
+    taken = set(zip(om.p1.tolist(), om.p2.tolist()))
+    p1, p2 = [], []
+    while len(p1) < k:
+        a = int(rng.integers(0, n))
+        b = int((a + rng.integers(5, n - 5)) % n)
+        if (a, b) not in taken:
+            taken.add((a, b))
+            p1.append(a)
+            p2.append(b)
+    p1, p2 = np.array(p1), np.array(p2)
+    Rs = np.stack([np.linalg.qr(rng.standard_normal((d, d)))[0] for _ in range(k)])
+    for q in range(k):
+        if np.linalg.det(Rs[q]) < 0:
+            Rs[q][:, 0] *= -1
+    z = np.zeros(k, dtype=np.int64)
+    out = oracle.Measurements(d, z, p1, z.copy(), p2, Rs, rng.uniform(-5, 5, size=(k, d)),
+                              np.full(k, np.median(om.kappa)), np.full(k, np.median(om.tau)), np.ones(k),
+                              np.zeros(k, dtype=bool))
+    return oracle.Measurements.concat([om, out])
+
+
+def test_distributed_gnc_matches_oracle(oracle):
+    """BASELINE configs[4] (multi-agent GNC): smallGrid3D + 10 injected outlier loop closures, 3 agents on one
+    GPU.  Private AND shared loop closures are re-weighted on the device (shared ones read the neighbour tile
+    buffer; Q's diagonal terms, the coupling blocks and the preconditioner are rebuilt in place).  Against the
+    oracle's synchronous protocol at matched settings: same number of weight updates, same muInit, same
+    classification, weights within 1e-6, final cost within 1e-6 relative; every injected outlier is rejected,
+    no inlier is, and the final cost is the optimum of the clean graph."""
+    import dpgo_amd
+    from dpgo_amd.agent import DeviceAgent, ExchangePlan, RBCDCluster, build_pose_graphs
+    from dpgo_amd.robust import DistributedGNC, RobustCostParameters
+    r, robots, k, sweeps = 5, 3, 10, 2
+    om, n = oracle.read_g2o(os.path.join(DATA, "smallGrid3D.g2o"))
+    d = om.d
+    allm = _inject_outliers(oracle, om, n, k, seed=7)
+    X0 = oracle.lift(oracle.chordal_initialization(om, n), r)
+    ref_meas = _inject_outliers(oracle, om, n, k, seed=7)
+    Xref, info_o = oracle.multi_agent_gnc(ref_meas, n, robots, r, X0, inner_sweeps=sweeps, barc=5.0, mu_step=1.4,
+                                          max_updates=40, hess_recurrence=True)
+    assert info_o["history"][-1]["undecided"] == 0  # the protocol terminated by classification
+
+    pm = to_product_measurements(allm)
+    ranges, graphs = build_pose_graphs(pm, n, robots, r)
+    plan = ExchangePlan(graphs)
+    agents = {a: DeviceAgent(graphs, plan, a, X0[ranges[a][0]:ranges[a][1]], dpgo_amd.ROptParameters())
+              for a in range(robots)}
+    cluster = RBCDCluster(plan, agents)
+    gnc = DistributedGNC(cluster, RobustCostParameters("GNC_TLS", GNCMaxNumIters=40, GNCBarc=5.0, GNCMuStep=1.4),
+                         inner_sweeps=sweeps)
+    info = gnc.run()
+    assert info["updates"] == info_o["updates"]
+    assert abs(info["muInit"] - info_o["muInit"]) <= 1e-8 * info_o["muInit"]
+    for h, ho in zip(info["history"], info_o["history"]):
+        assert (h["inliers"], h["outliers"], h["undecided"]) == (ho["inliers"], ho["outliers"], ho["undecided"])
+    assert abs(info["cost"] - info_o["cost"]) <= 1e-6 * info_o["cost"]
+    X = np.concatenate([agents[a].X.cpu().numpy() for a in range(robots)], axis=0)
+    assert relerr(X, Xref) < 1e-6
+
+    # weights: map every agent's edges back to global edges through (robot, frame) keys
+    key_to_global = {}
+    per = n // robots
+    rob = np.minimum(np.arange(n) // per, robots - 1)
+    loc = np.arange(n) - rob * per
+    for e in range(ref_meas.m):
+        key_to_global[(rob[ref_meas.p1[e]], loc[ref_meas.p1[e]], rob[ref_meas.p2[e]], loc[ref_meas.p2[e]])] = e
+    seen = np.zeros(ref_meas.m, dtype=bool)
+    for a, (idx, w) in gnc.weights().items():
+        m = graphs[a].measurements()
+        for pos, wv in zip(idx, w):
+            e = key_to_global[(int(m.r1[pos]), int(m.p1[pos]), int(m.r2[pos]), int(m.p2[pos]))]
+            seen[e] = True
+            assert abs(wv - ref_meas.weight[e]) <= 1e-6, (a, e, wv, ref_meas.weight[e])
+    assert seen.all()
+    assert np.all(ref_meas.weight[-k:] < 1e-8) and np.all(ref_meas.weight[:om.m] > 1 - 1e-8)
+
+    # the coupling rebuilt on the device gives the same G as constructG with the final weights
+    cluster.exchange(None)
+    _, per_robot = oracle.partition_contiguous(ref_meas, n, robots)
+    for a in range(robots):
+        s, e = ranges[a]
+        agents[a].problem.updateLinearMatrixFromNeighbors(agents[a].nbr)
+        Gdev = matrix_to_tiles(agents[a].problem.EucGrad(tiles_to_matrix(np.zeros((e - s, d + 1, r)))), d)
+        sh = per_robot[a]["shared"]
+        nbr = {}
+        for q in range(sh.m):
+            rb, fr = (int(sh.r2[q]), int(sh.p2[q])) if sh.r1[q] == a else (int(sh.r1[q]), int(sh.p1[q]))
+            nbr[(rb, fr)] = X[ranges[rb][0] + fr]
+        Gref = oracle.construct_G(e - s, d, r, sh, a, nbr)
+        assert np.abs(Gdev - Gref).max() <= 1e-10 * max(1.0, np.abs(Gref).max())
+    # and the outliers do not move the optimum: the clean graph's cost at its 5-robot demo optimum
+    assert abs(info["cost"] - 1025.398) < 0.05
