@@ -240,6 +240,17 @@ def main():
     dpgo_amd.lib.check(lib.dpgo_bench_spmm(agent.problem.handle, args.spmm_reps, 10, C.byref(ms_spmm)))
     hb = hess_bytes(n_local, nnzb_local, d, r)
     sb = spmm_bytes(n_local, nnzb_local, d, r)
+    # the same SpMM cycling through enough private operand sets to exceed the 256 MB Infinity Cache
+    # (">= 3 buffer sets > 256 MB total"): the rate that can only come from HBM
+    ms_rot, set_bytes = C.c_double(0.0), C.c_double(0.0)
+    set_b = nnzb_local * (8 * (d + 1) ** 2 + 4) + 2 * 8 * r * (d + 1) * n_local
+    nsets = int(min(512, max(3, -(-3 * 256 * 2 ** 20 // max(set_b, 1)) // 2 + 1)))  # >= 1.5 x 256 MB in total
+    dpgo_amd.lib.check(lib.dpgo_bench_spmm_rotating(agent.problem.handle, nsets, args.spmm_reps, 10,
+                                                    C.byref(ms_rot), C.byref(set_bytes)))
+    ms_hrot = C.c_double(0.0)
+    hsets = max(3, nsets // 2 + 1)  # a tCG-step operand set is ~1.7x an SpMM set
+    dpgo_amd.lib.check(lib.dpgo_bench_hess_rotating(agent.problem.handle, hsets, args.spmm_reps, 10,
+                                                    C.byref(ms_hrot)))
     ach = hb / (ms_hess.value * 1e-3) / 1e9
     traffic = None
     traffic_src = None
@@ -259,10 +270,17 @@ def main():
                     achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS, traffic=traffic,
                     traffic_source=traffic_src,
                     bytes_per_launch=hb, avg_launch_us=ms_hess.value * 1e3,
+                    rotating=dict(buffer_sets=hsets, avg_launch_us=ms_hrot.value * 1e3,
+                                  achieved=hb / (ms_hrot.value * 1e-3) / 1e9,
+                                  frac=hb / (ms_hrot.value * 1e-3) / 1e9 / HBM_PEAK_GBS),
                     spmm_only=dict(kernel="k_spmm<%d,%d> (plain Q*X)" % (d, r), bytes_per_launch=sb,
                                    avg_launch_us=ms_spmm.value * 1e3,
                                    achieved=sb / (ms_spmm.value * 1e-3) / 1e9,
-                                   frac=sb / (ms_spmm.value * 1e-3) / 1e9 / HBM_PEAK_GBS))
+                                   frac=sb / (ms_spmm.value * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                   rotating=dict(buffer_sets=nsets, total_MB=nsets * set_bytes.value / 1e6,
+                                                 avg_launch_us=ms_rot.value * 1e3,
+                                                 achieved=sb / (ms_rot.value * 1e-3) / 1e9,
+                                                 frac=sb / (ms_rot.value * 1e-3) / 1e9 / HBM_PEAK_GBS)))
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

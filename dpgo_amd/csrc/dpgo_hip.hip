@@ -1122,6 +1122,140 @@ int dpgo_bench_spmm(dpgo_problem_t p, int reps, int warmup, double* avg_ms) {
   return DPGO_OK;
 }
 
+int dpgo_bench_hess_rotating(dpgo_problem_t p, int nsets, int reps, int warmup, double* avg_ms) {
+  CHK(check_ready(p));
+  if (nsets < 1 || nsets > 512 || reps <= 0 || !avg_ms) return fail(DPGO_ERR_INVALID, "bad arguments");
+  std::memset(p->hstate, 0, sizeof(DevState));  // as dpgo_bench_hess: a state without early exits
+  p->hstate->z_r = 1.0;
+  p->hstate->theta = 1.0;
+  p->hstate->kappa = -1.0;
+  p->hstate->max_inner = 1 << 30;
+  CHK(push_state(p));
+  // every operand of the tCG-step kernel gets nsets private copies; the handle's pointers are swapped per launch
+  const size_t vbytes = sizeof(double) * (size_t)p->Q.nnzb * p->b * p->b;
+  const size_t cbytes = sizeof(int32_t) * (size_t)p->Q.nnzb;
+  const size_t sbytes = sizeof(double) * (size_t)p->n * p->d * p->d;
+  struct Set {
+    double *vals = nullptr, *x1 = nullptr, *S1 = nullptr, *z = nullptr, *delta = nullptr, *Hd = nullptr;
+    int32_t* colidx = nullptr;
+  };
+  std::vector<Set> sets(nsets);
+  const Set orig{p->Q.vals, p->x1, p->S1, p->z, p->delta, p->Hd, p->Q.colidx};
+  bool ok = true;
+  auto dup = [&](auto** dst, const void* src, size_t bytes) {
+    if (!ok) return;
+    if (hipMalloc(dst, bytes) != hipSuccess) {
+      ok = false;
+      return;
+    }
+    (void)hipMemcpyAsync(*dst, src, bytes, hipMemcpyDeviceToDevice, p->stream);
+  };
+  for (auto& st : sets) {
+    dup(&st.vals, orig.vals, vbytes);
+    dup(&st.colidx, orig.colidx, cbytes);
+    dup(&st.x1, orig.x1, p->vec_bytes());
+    dup(&st.S1, orig.S1, sbytes);
+    dup(&st.z, orig.z, p->vec_bytes());
+    dup(&st.delta, orig.delta, p->vec_bytes());
+    dup(&st.Hd, orig.Hd, p->vec_bytes());
+  }
+  auto use = [&](const Set& st) {
+    p->Q.vals = st.vals;
+    p->Q.colidx = st.colidx;
+    p->x1 = st.x1;
+    p->S1 = st.S1;
+    p->z = st.z;
+    p->delta = st.delta;
+    p->Hd = st.Hd;
+  };
+  int rc = ok ? DPGO_OK : fail(DPGO_ERR_HIP, "hipMalloc failed for the rotating buffer sets");
+  auto launch = [&](int i) -> int {
+    use(sets[i % nsets]);
+    DISPATCH(p->d, p->r, LAUNCH_TCG_HESS(p, p->dstate, p->dstate + 1, 0, (unsigned long long*)nullptr, 0u));
+    HIPC(hipGetLastError());
+    return DPGO_OK;
+  };
+  float ms = 0.f;
+  if (rc == DPGO_OK) {
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0);
+    (void)hipEventCreate(&e1);
+    for (int i = 0; i < warmup && rc == DPGO_OK; ++i) rc = launch(i);
+    (void)hipEventRecord(e0, p->stream);
+    for (int i = 0; i < reps && rc == DPGO_OK; ++i) rc = launch(i);
+    (void)hipEventRecord(e1, p->stream);
+    (void)hipEventSynchronize(e1);
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+  }
+  use(orig);
+  (void)hipStreamSynchronize(p->stream);
+  for (auto& st : sets) {
+    void* ptrs[] = {st.vals, st.colidx, st.x1, st.S1, st.z, st.delta, st.Hd};
+    for (void* q : ptrs)
+      if (q) (void)hipFree(q);
+  }
+  if (rc != DPGO_OK) return rc;
+  *avg_ms = (double)ms / reps;
+  return DPGO_OK;
+}
+
+int dpgo_bench_spmm_rotating(dpgo_problem_t p, int nsets, int reps, int warmup, double* avg_ms,
+                             double* set_bytes) {
+  CHK(check_ready(p));
+  if (nsets < 1 || nsets > 512 || reps <= 0 || !avg_ms) return fail(DPGO_ERR_INVALID, "bad arguments");
+  // nsets private copies of (Q values, block columns, X, OUT): cycling through them makes every launch read
+  // data that left the 256 MB Infinity Cache ("rotate >= 3 buffer sets > 256 MB total")
+  const size_t vbytes = sizeof(double) * (size_t)p->Q.nnzb * p->b * p->b;
+  const size_t cbytes = sizeof(int32_t) * (size_t)p->Q.nnzb;
+  std::vector<Bsr> mats(nsets);
+  std::vector<double*> xs(nsets, nullptr), outs(nsets, nullptr);
+  int rc = DPGO_OK;
+  auto cleanup = [&]() {
+    for (int k = 0; k < nsets; ++k) {
+      if (mats[k].vals) (void)hipFree(mats[k].vals);
+      if (mats[k].colidx) (void)hipFree(mats[k].colidx);
+      if (xs[k]) (void)hipFree(xs[k]);
+      if (outs[k]) (void)hipFree(outs[k]);
+    }
+  };
+  for (int k = 0; k < nsets && rc == DPGO_OK; ++k) {
+    mats[k] = p->Q;  // shares rowptr (0.4 MB)
+    mats[k].vals = nullptr;
+    mats[k].colidx = nullptr;
+    if (hipMalloc(&mats[k].vals, vbytes) != hipSuccess || hipMalloc(&mats[k].colidx, cbytes) != hipSuccess ||
+        hipMalloc(&xs[k], p->vec_bytes()) != hipSuccess || hipMalloc(&outs[k], p->vec_bytes()) != hipSuccess) {
+      rc = fail(DPGO_ERR_HIP, "hipMalloc failed for the rotating buffer sets");
+      break;
+    }
+    (void)hipMemcpyAsync(mats[k].vals, p->Q.vals, vbytes, hipMemcpyDeviceToDevice, p->stream);
+    (void)hipMemcpyAsync(mats[k].colidx, p->Q.colidx, cbytes, hipMemcpyDeviceToDevice, p->stream);
+    (void)hipMemcpyAsync(xs[k], p->x1, p->vec_bytes(), hipMemcpyDeviceToDevice, p->stream);
+  }
+  if (rc != DPGO_OK) {
+    cleanup();
+    return rc;
+  }
+  hipEvent_t e0, e1;
+  (void)hipEventCreate(&e0);
+  (void)hipEventCreate(&e1);
+  for (int i = 0; i < warmup && rc == DPGO_OK; ++i) rc = launch_spmm(p, mats[i % nsets], xs[i % nsets], nullptr, outs[i % nsets]);
+  (void)hipEventRecord(e0, p->stream);
+  for (int i = 0; i < reps && rc == DPGO_OK; ++i) rc = launch_spmm(p, mats[i % nsets], xs[i % nsets], nullptr, outs[i % nsets]);
+  (void)hipEventRecord(e1, p->stream);
+  (void)hipEventSynchronize(e1);
+  float ms = 0.f;
+  (void)hipEventElapsedTime(&ms, e0, e1);
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  cleanup();
+  if (rc != DPGO_OK) return rc;
+  *avg_ms = (double)ms / reps;
+  if (set_bytes) *set_bytes = (double)(vbytes + cbytes + 2 * p->vec_bytes());
+  return DPGO_OK;
+}
+
 int dpgo_bench_hess(dpgo_problem_t p, int reps, int warmup, double* avg_ms) {
   CHK(check_ready(p));
   if (reps <= 0 || !avg_ms) return fail(DPGO_ERR_INVALID, "bad arguments");

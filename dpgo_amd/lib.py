@@ -85,6 +85,8 @@ SIGNATURES = {
     "dpgo_problem_eval_device": ([_P, _P, C.POINTER(_D), C.POINTER(_D)], _I),
     "dpgo_problem_eval_terms_device": ([_P, _P, C.POINTER(_D), C.POINTER(_D), C.POINTER(_D)], _I),
     "dpgo_bench_spmm": ([_P, _I, _I, C.POINTER(_D)], _I),
+    "dpgo_bench_spmm_rotating": ([_P, _I, _I, _I, C.POINTER(_D), C.POINTER(_D)], _I),
+    "dpgo_bench_hess_rotating": ([_P, _I, _I, _I, C.POINTER(_D)], _I),
     "dpgo_bench_hess": ([_P, _I, _I, C.POINTER(_D)], _I),
     "dpgo_manifold_project": ([_I, _I, _I, _P, _P, _I], _I),
     "dpgo_manifold_tangent_project": ([_I, _I, _I, _P, _P, _P, _I], _I),

@@ -212,9 +212,14 @@ int dpgo_problem_eval_terms_device(dpgo_problem_t h, const double* X_dev, double
 /* time `reps` back-to-back SpMM launches with HIP events on the handle's stream;
  * n_buffers >= 1 rotates that many (V, OUT) buffer pairs; returns average ms per launch */
 int dpgo_bench_spmm(dpgo_problem_t h, int reps, int warmup, double* avg_ms);
+/* As dpgo_bench_spmm, but cycling through nsets private copies of (Q values, block columns, X, OUT) so that no
+ * launch finds its operands in the 256 MB Infinity Cache; set_bytes (optional) = bytes of one set. */
+int dpgo_bench_spmm_rotating(dpgo_problem_t h, int nsets, int reps, int warmup, double* avg_ms, double* set_bytes);
 /* same for the dominant kernel of a solve: the fused Q*X + Riemannian-Hessian kernel (one per tCG
  * iteration), on the solver's own buffers (iterate, cached S, search direction) */
 int dpgo_bench_hess(dpgo_problem_t h, int reps, int warmup, double* avg_ms);
+/* As dpgo_bench_hess with every operand cycling through nsets private copies (see dpgo_bench_spmm_rotating). */
+int dpgo_bench_hess_rotating(dpgo_problem_t h, int nsets, int reps, int warmup, double* avg_ms);
 
 /* ---- manifold: LiftedSEManifold (include/DPGO/manifold/LiftedSEManifold.h:28-43) + the
  * ROPTLIB Stiefel x Euclidean product-manifold operations it configures
