@@ -14,6 +14,10 @@ from .measurements import RelativeSEMeasurements, partition_contiguous, read_g2o
 from .solver import (LiftedSEManifold, PoseGraph, QuadraticOptimizer, QuadraticProblem,  # noqa: E402
                      ROptParameters, ROPTResult)
 
-__all__ = ["DpgoError", "device_count", "RelativeSEMeasurements", "partition_contiguous", "read_g2o_file",
+from .trajectory import (load_trajectory, log_measurements, log_trajectory, round_trajectory,  # noqa: E402
+                         round_trajectory_device)
+
+__all__ = ["load_trajectory", "log_measurements", "log_trajectory", "round_trajectory", "round_trajectory_device",
+           "DpgoError", "device_count", "RelativeSEMeasurements", "partition_contiguous", "read_g2o_file",
            "LiftedSEManifold", "PoseGraph", "QuadraticOptimizer", "QuadraticProblem", "ROptParameters",
            "ROPTResult"]

@@ -190,6 +190,17 @@ class DeviceAgent:
             self.Y.copy_(self.X)
             self.gamma = self.alpha = 0.0
 
+    # ---- rounding (PGOAgent::getTrajectoryInLocalFrame / InGlobalFrame, src/PGOAgent.cpp:718-767) ----
+    def getTrajectoryInLocalFrame(self):
+        """Rounded tiles [n, d+1, d] on the device, in the frame of this agent's pose 0."""
+        from .trajectory import round_trajectory_device
+        return round_trajectory_device(self.X, None)
+
+    def getTrajectoryInGlobalFrame(self, anchor):
+        """anchor: r x (d+1) lifted pose (PGOAgent::setGlobalAnchor); rounded tiles [n, d+1, d] on the device."""
+        from .trajectory import round_trajectory_device
+        return round_trajectory_device(self.X, anchor)
+
     def snapshot(self) -> None:
         """Remember the current iterate (benchmarks restore it so that every timed step does the same work)."""
         self._snap = self.X.clone()
@@ -316,6 +327,28 @@ class RBCDCluster:
             if self.plan.adj[selected]:
                 selected = int(np.argmax(terms[:, 1]))
         return dict(iterations=len(order), cost=trace[-1][0], gradnorm=trace[-1][1], selected=order, trace=trace)
+
+    def global_anchor(self) -> np.ndarray:
+        """The lifted pose 0 of agent 0 as r x (d+1) (what the reference's drivers pass to setGlobalAnchor),
+        identical on every rank."""
+        any_agent = next(iter(self.agents.values()))
+        b, r = any_agent.b, any_agent.r
+        a = np.zeros((b, r))
+        if 0 in self.agents:
+            a = self.agents[0].X[0].cpu().numpy()
+        if self.world > 1:
+            import torch
+            import torch.distributed as dist
+            dev = getattr(any_agent, "device", "cpu")
+            t = torch.tensor(a, dtype=torch.float64, device="cpu" if self.stage else dev)
+            dist.broadcast(t, src=self.owner(0))
+            a = t.cpu().numpy()
+        return np.ascontiguousarray(a.T)  # tile [d+1, r] -> matrix r x (d+1)
+
+    def trajectories_in_global_frame(self) -> Dict[int, object]:
+        """{agent id: rounded device tiles [n_a, d+1, d]} of the local agents in the frame of agent 0's pose 0."""
+        anchor = self.global_anchor()
+        return {a: ag.getTrajectoryInGlobalFrame(anchor) for a, ag in self.agents.items()}
 
     def central_cost_and_gradnorm(self) -> Tuple[float, float]:
         """Central cost f(X) and Riemannian gradient norm (what examples/MultiRobotExample.cpp:220-225

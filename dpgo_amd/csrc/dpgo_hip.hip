@@ -113,7 +113,7 @@ struct dpgo_problem_s {
   // work vectors
   double *x1 = nullptr, *x2 = nullptr, *g1 = nullptr, *g2 = nullptr, *eta = nullptr, *delta = nullptr,
          *Hd = nullptr, *rr = nullptr, *z = nullptr, *S1 = nullptr, *S2 = nullptr;
-  double* partials = nullptr;  // 5 regions of kMaxGrid*kNP
+  double* partials = nullptr;  // 5 regions of kPartialCap*kNP
   DevState* dstate = nullptr;  // 2 slots
   DevState* hstate = nullptr;  // pinned
   unsigned long long* hflag = nullptr;  // pinned, host-coherent: device-published tCG progress word
@@ -138,17 +138,24 @@ struct dpgo_problem_s {
   int cur = 0;
   size_t vec_bytes() const { return (size_t)n * T * sizeof(double); }
   double* pE() const { return partials; }
-  double* pA() const { return partials + 1 * kMaxGrid * kNP; }
-  double* pB() const { return partials + 2 * kMaxGrid * kNP; }
-  double* pH() const { return partials + 3 * kMaxGrid * kNP; }
+  double* pA() const { return partials + 1 * kPartialCap * kNP; }
+  double* pB() const { return partials + 2 * kPartialCap * kNP; }
+  double* pH() const { return partials + 3 * kPartialCap * kNP; }
   int grid() const {
     const int P = (64 / b) * kWaves;
     int tiles = (n + P - 1) / P;
     if (tiles < 1) tiles = 1;
-    return tiles < kMaxGrid ? tiles : kMaxGrid;
+    return tiles < cap_u ? tiles : cap_u;
   }
+  int cap_u = kMaxGrid, cap_h = kMaxGrid;  // launch caps of the streaming / SpMM kernel families
   int split = 1;  // lane groups per pose in the SpMM kernels (latency layout for small blocks)
   int grid_s() const {  // SpMM kernels (k_spmm, k_grad, k_hess, k_tcg_hess)
+    const int P = (64 / (b * split)) * kWaves;
+    int tiles = (n + P - 1) / P;
+    if (tiles < 1) tiles = 1;
+    return tiles < cap_h ? tiles : cap_h;
+  }
+  int grid_spmm() const {  // plain k_spmm: no partial sums, higher occupancy than the fused tCG kernel
     const int P = (64 / (b * split)) * kWaves;
     int tiles = (n + P - 1) / P;
     if (tiles < 1) tiles = 1;
@@ -230,7 +237,7 @@ int push_state(dpgo_problem_s* p) {
 
 // ---- kernel launch helpers (templated on D, R through DISPATCH) ----
 int launch_spmm(dpgo_problem_s* p, const Bsr& M, const double* V, const double* Gadd, double* OUT) {
-  DISPATCH(p->d, p->r, LAUNCH_SPLIT(p, k_spmm, p->grid_s(), M.dev(), V, Gadd, OUT, p->n));
+  DISPATCH(p->d, p->r, LAUNCH_SPLIT(p, k_spmm, p->grid_spmm(), M.dev(), V, Gadd, OUT, p->n));
   HIPC(hipGetLastError());
   return DPGO_OK;
 }
@@ -555,6 +562,49 @@ int refresh_after_weights(dpgo_problem_s* p) {
 }
 }  // namespace
 
+namespace {
+// The two kernels of the tCG loop run as persistent grids: one workgroup per resident slot (occupancy x CUs).
+// More workgroups than slots only add prologues (state record + partial-sum reduction) and a ragged second
+// round: 100k poses, same box: caps 1024/1024 -> 70.7 us per tCG iteration, 512/768 (= the resident counts of
+// k_tcg_update / k_tcg_hess at 203 / 164 VGPRs) -> 64.7 us.  The other kernels keep the family's cap.
+template <class K>
+int resident_blocks(K kernel, int* out) {
+  int per_cu = 0;
+  HIPC(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kBlock, 0));
+  int dev = 0, cus = 0;
+  HIPC(hipGetDevice(&dev));
+  HIPC(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+  *out = std::max(1, std::min(kPartialCap, per_cu * cus));
+  return DPGO_OK;
+}
+int tune_launch_caps(dpgo_problem_s* p) {
+  DISPATCH(p->d, p->r, {
+    if constexpr (Span<D, R, 1>::kOk) {
+      CHK(resident_blocks(k_tcg_update_span<D, R>, &p->cap_u));
+      if (p->split == 4)
+        CHK(resident_blocks(k_tcg_hess_span<D, R, 4>, &p->cap_h));
+      else if (p->split == 2)
+        CHK(resident_blocks(k_tcg_hess_span<D, R, 2>, &p->cap_h));
+      else
+        CHK(resident_blocks(k_tcg_hess_span<D, R, 1>, &p->cap_h));
+    } else {
+      CHK(resident_blocks(k_tcg_update<D, R>, &p->cap_u));
+      if (p->split == 4)
+        CHK(resident_blocks(k_tcg_hess<D, R, 4>, &p->cap_h));
+      else if (p->split == 2)
+        CHK(resident_blocks(k_tcg_hess<D, R, 2>, &p->cap_h));
+      else
+        CHK(resident_blocks(k_tcg_hess<D, R, 1>, &p->cap_h));
+    }
+  });
+  // tuning knobs (any value up to the partial-sum capacity is valid)
+  if (const char* e = std::getenv("DPGO_GRID_UPDATE")) p->cap_u = std::max(1, std::min(kPartialCap, std::atoi(e)));
+  if (const char* e = std::getenv("DPGO_GRID_HESS")) p->cap_h = std::max(1, std::min(kPartialCap, std::atoi(e)));
+  return DPGO_OK;
+}
+
+}  // namespace
+
 // =====================================================================================
 extern "C" {
 
@@ -616,6 +666,7 @@ int dpgo_problem_create(dpgo_problem_t* out, int r, int d, int n, int device) {
   }
   int rc = [&]() -> int {
     HIPC(hipSetDevice(device));
+    CHK(tune_launch_caps(p));
     HIPC(hipStreamCreateWithFlags(&p->own_stream, hipStreamNonBlocking));
     p->stream = p->own_stream;
     const size_t vb = p->vec_bytes();
@@ -627,8 +678,8 @@ int dpgo_problem_create(dpgo_problem_t* out, int r, int d, int n, int device) {
     HIPC(hipMalloc(&p->S1, sizeof(double) * (size_t)n * d * d));
     HIPC(hipMalloc(&p->S2, sizeof(double) * (size_t)n * d * d));
     HIPC(hipMalloc(&p->dinv, sizeof(double) * (size_t)n * p->b * p->b));
-    HIPC(hipMalloc(&p->partials, sizeof(double) * 5 * kMaxGrid * kNP));
-    HIPC(hipMemsetAsync(p->partials, 0, sizeof(double) * 5 * kMaxGrid * kNP, p->stream));
+    HIPC(hipMalloc(&p->partials, sizeof(double) * 5 * kPartialCap * kNP));
+    HIPC(hipMemsetAsync(p->partials, 0, sizeof(double) * 5 * kPartialCap * kNP, p->stream));
     HIPC(hipMalloc(&p->dstate, sizeof(DevState) * 2));
     HIPC(hipHostMalloc(&p->hstate, sizeof(DevState)));
     HIPC(hipHostMalloc(&p->hflag, 64, hipHostMallocCoherent | hipHostMallocMapped));
@@ -1329,6 +1380,37 @@ int dpgo_axpby_project_device(int r, int d, int n, double a, const double* A_dev
   DISPATCH(d, r, hipLaunchKernelGGL((k_axpby_project<D, R>), dim3(tiles_grid(d, n)), dim3(kBlock), 0,
                                     (hipStream_t)stream, a, A_dev, b, B_dev, c, C_dev, project, out_dev, n));
   HIPC(hipGetLastError());
+  return DPGO_OK;
+}
+
+int dpgo_round_trajectory_device(int r, int d, int n, const double* X_dev, const double* anchor_host, double* T_dev,
+                                 void* stream) {
+  if (!X_dev || !T_dev) return fail(DPGO_ERR_INVALID, "null pointer");
+  if (n <= 0) return fail(DPGO_ERR_INVALID, "n <= 0");
+  if (!dpgo_supported(d, r)) return fail(DPGO_ERR_UNSUPPORTED, "unsupported (d, r)");
+  AnchorArg an;
+  std::memset(&an, 0, sizeof(an));
+  an.use = anchor_host ? 1 : 0;
+  if (anchor_host) std::memcpy(an.v, anchor_host, sizeof(double) * (size_t)(d + 1) * r);
+  int g = (n + kBlock - 1) / kBlock;
+  if (g > kMaxGrid) g = kMaxGrid;
+  DISPATCH(d, r, hipLaunchKernelGGL((k_round<D, R>), dim3(g), dim3(kBlock), 0, (hipStream_t)stream, X_dev, an, T_dev, n));
+  HIPC(hipGetLastError());
+  return DPGO_OK;
+}
+
+int dpgo_round_trajectory(int r, int d, int n, const double* X_host, const double* anchor_host, double* T_host,
+                          int device) {
+  if (!X_host || !T_host) return fail(DPGO_ERR_INVALID, "null pointer");
+  CHK(manifold_args(r, d, n, device));
+  TmpDev tmp;
+  const size_t xb = sizeof(double) * (size_t)n * (d + 1) * r, tb = sizeof(double) * (size_t)n * (d + 1) * d;
+  double *X = nullptr, *T = nullptr;
+  CHK(tmp.alloc(&X, xb));
+  CHK(tmp.alloc(&T, tb));
+  HIPC(hipMemcpy(X, X_host, xb, hipMemcpyHostToDevice));
+  CHK(dpgo_round_trajectory_device(r, d, n, X, anchor_host, T, nullptr));
+  HIPC(hipMemcpy(T_host, T, tb, hipMemcpyDeviceToHost));
   return DPGO_OK;
 }
 

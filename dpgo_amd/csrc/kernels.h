@@ -23,7 +23,8 @@ namespace dpgo {
 
 constexpr int kBlock = 256;
 constexpr int kWaves = kBlock / 64;
-constexpr int kMaxGrid = 1024;  // 4 workgroups per CU on 256 CUs
+constexpr int kMaxGrid = 1024;  // default launch cap: 4 workgroups per CU on 256 CUs
+constexpr int kPartialCap = 2048;  // capacity of the per-workgroup partial-sum regions (upper bound of any grid)
 constexpr int kNP = 4;          // partial sums per workgroup (max over kernels)
 
 enum : int { TCG_NEGCURV = 0, TCG_EXCREGION = 1, TCG_LCON = 2, TCG_SCON = 3, TCG_MAXITER = 4 };
@@ -1708,6 +1709,147 @@ __global__ __launch_bounds__(kBlock) void k_axpby_project(double a, const double
       store_col<R>(out + off, m);
     }
     wave_sync();
+  }
+}
+
+// ================================================================ K12: rounding to SE(d)
+// PGOAgent::getTrajectoryInLocalFrame / getTrajectoryInGlobalFrame (src/PGOAgent.cpp:718-767):
+//   T_i = [ projectToRotationGroup(Ya^T Y_i) | Ya^T p_i - t0 ],  t0 = Ya^T pa,
+// anchor (Ya, pa) = the global anchor, or pose 0 of X (local frame).  projectToRotationGroup
+// (src/DPGO_utils.cpp:464-478: U V^T, last column of U negated when det U det V < 0) is evaluated as
+// M V diag(s_k / sigma_k) V^T from the eigen-decomposition M^T M = V diag(sigma^2) V^T (cyclic Jacobi), with
+// s_k = -1 on the SMALLEST singular value when det M < 0.  One lane per pose; output tiles [n][d+1][d]
+// (= the reference's d x (d+1)n column-major Matrix).
+struct AnchorArg {
+  double v[4 * 6];  // (d+1) x r tile, same layout as a pose tile of X
+  int use;          // 0: take pose 0 of X
+};
+template <int D, int R>
+__global__ __launch_bounds__(kBlock) void k_round(const double* __restrict__ X, AnchorArg anchor,
+                                                  double* __restrict__ T, int n) {
+  constexpr int B = D + 1, TS = B * R;
+  double Ya[D][R], pa[R];
+#pragma unroll
+  for (int a = 0; a < D; ++a)
+#pragma unroll
+    for (int k = 0; k < R; ++k) Ya[a][k] = anchor.use ? anchor.v[a * R + k] : X[a * R + k];
+#pragma unroll
+  for (int k = 0; k < R; ++k) pa[k] = anchor.use ? anchor.v[D * R + k] : X[D * R + k];
+  double t0[D];
+#pragma unroll
+  for (int a = 0; a < D; ++a) {
+    double s = 0.0;
+#pragma unroll
+    for (int k = 0; k < R; ++k) s = fma(Ya[a][k], pa[k], s);
+    t0[a] = s;
+  }
+  for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+    const double* __restrict__ x = X + (size_t)i * TS;
+    double M[D][D], tt[D];
+#pragma unroll
+    for (int a = 0; a < D; ++a) {
+#pragma unroll
+      for (int b = 0; b < D; ++b) {
+        double s = 0.0;
+#pragma unroll
+        for (int k = 0; k < R; ++k) s = fma(Ya[a][k], x[b * R + k], s);
+        M[a][b] = s;
+      }
+      double s = 0.0;
+#pragma unroll
+      for (int k = 0; k < R; ++k) s = fma(Ya[a][k], x[D * R + k], s);
+      tt[a] = s - t0[a];
+    }
+    double det;
+    if constexpr (D == 2) {
+      det = M[0][0] * M[1][1] - M[0][1] * M[1][0];
+    } else {
+      det = M[0][0] * (M[1][1] * M[2][2] - M[1][2] * M[2][1]) - M[0][1] * (M[1][0] * M[2][2] - M[1][2] * M[2][0]) +
+            M[0][2] * (M[1][0] * M[2][1] - M[1][1] * M[2][0]);
+    }
+    double C[D][D], W[D][D];
+#pragma unroll
+    for (int p = 0; p < D; ++p)
+#pragma unroll
+      for (int q = 0; q < D; ++q) {
+        double s = 0.0;
+#pragma unroll
+        for (int a = 0; a < D; ++a) s = fma(M[a][p], M[a][q], s);
+        C[p][q] = s;
+        W[p][q] = (p == q) ? 1.0 : 0.0;
+      }
+    for (int sweep = 0; sweep < 16; ++sweep) {
+      double offn = 0.0, dn = 0.0;
+#pragma unroll
+      for (int p = 0; p < D; ++p) {
+        dn += C[p][p] * C[p][p];
+#pragma unroll
+        for (int q = p + 1; q < D; ++q) offn += C[p][q] * C[p][q];
+      }
+      if (offn <= 1e-32 * dn) break;
+#pragma unroll
+      for (int p = 0; p < D; ++p)
+#pragma unroll
+        for (int q = p + 1; q < D; ++q) {
+          const double apq = C[p][q];
+          if (apq != 0.0) {
+            const double th = (C[q][q] - C[p][p]) / (2.0 * apq);
+            const double t = (th >= 0.0 ? 1.0 : -1.0) / (fabs(th) + sqrt(th * th + 1.0));
+            const double cs = 1.0 / sqrt(t * t + 1.0), sn = t * cs;
+#pragma unroll
+            for (int k = 0; k < D; ++k) {
+              const double ckp = C[k][p], ckq = C[k][q];
+              C[k][p] = cs * ckp - sn * ckq;
+              C[k][q] = sn * ckp + cs * ckq;
+            }
+#pragma unroll
+            for (int k = 0; k < D; ++k) {
+              const double cpk = C[p][k], cqk = C[q][k];
+              C[p][k] = cs * cpk - sn * cqk;
+              C[q][k] = sn * cpk + cs * cqk;
+            }
+#pragma unroll
+            for (int k = 0; k < D; ++k) {
+              const double wkp = W[k][p], wkq = W[k][q];
+              W[k][p] = cs * wkp - sn * wkq;
+              W[k][q] = sn * wkp + cs * wkq;
+            }
+          }
+        }
+    }
+    int kmin = 0;
+#pragma unroll
+    for (int k = 1; k < D; ++k) kmin = (C[k][k] < C[kmin][kmin]) ? k : kmin;
+    double sc[D];
+#pragma unroll
+    for (int k = 0; k < D; ++k) {
+      const double lam = C[k][k] > 0.0 ? C[k][k] : 0.0;
+      const double inv = lam > 0.0 ? 1.0 / sqrt(lam) : 0.0;
+      sc[k] = (det < 0.0 && k == kmin) ? -inv : inv;
+    }
+    // F = W diag(sc) W^T ; Rot = M F
+    double F[D][D];
+#pragma unroll
+    for (int p = 0; p < D; ++p)
+#pragma unroll
+      for (int q = 0; q < D; ++q) {
+        double s = 0.0;
+#pragma unroll
+        for (int k = 0; k < D; ++k) s = fma(W[p][k] * sc[k], W[q][k], s);
+        F[p][q] = s;
+      }
+    double* __restrict__ o = T + (size_t)i * B * D;
+#pragma unroll
+    for (int c = 0; c < D; ++c)
+#pragma unroll
+      for (int a = 0; a < D; ++a) {
+        double s = 0.0;
+#pragma unroll
+        for (int p = 0; p < D; ++p) s = fma(M[a][p], F[p][c], s);
+        o[c * D + a] = s;
+      }
+#pragma unroll
+    for (int a = 0; a < D; ++a) o[D * D + a] = tt[a];
   }
 }
 

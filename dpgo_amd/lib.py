@@ -92,6 +92,8 @@ SIGNATURES = {
     "dpgo_manifold_tangent_project": ([_I, _I, _I, _P, _P, _P, _I], _I),
     "dpgo_manifold_retract": ([_I, _I, _I, _P, _P, _D, _P, _I], _I),
     "dpgo_manifold_project_device": ([_I, _I, _I, _P, _P, _P], _I),
+    "dpgo_round_trajectory": ([_I, _I, _I, _P, _P, _P, _I], _I),
+    "dpgo_round_trajectory_device": ([_I, _I, _I, _P, _P, _P, _P], _I),
     "dpgo_gather_tiles_device": ([_I, _I, _P, _P, _I, _P, _P], _I),
     "dpgo_axpby_project_device": ([_I, _I, _I, _D, _P, _D, _P, _D, _P, _I, _P, _P], _I),
     "dpgo_build_Q_bsr": ([_I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _D, _D,

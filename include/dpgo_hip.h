@@ -234,6 +234,16 @@ int dpgo_manifold_retract(int r, int d, int n, const double* X, const double* et
                           double* out, int device);
 /* device-pointer versions on a caller-supplied stream (NULL = default stream) */
 int dpgo_manifold_project_device(int r, int d, int n, const double* M_dev, double* out_dev, void* stream);
+/* Rounding to SE(d): PGOAgent::getTrajectoryInLocalFrame / getTrajectoryInGlobalFrame
+ * (src/PGOAgent.cpp:718-767).  T (d x (d+1)n column-major, as the reference's Matrix) gets, per pose,
+ * [ projectToRotationGroup(Ya^T Y_i) | Ya^T p_i - Ya^T pa ] (src/DPGO_utils.cpp:464-478) with the anchor
+ * (Ya | pa) = anchor_host (r x (d+1) column-major, host memory: PGOAgent::setGlobalAnchor, :838-844) or, when
+ * NULL, pose 0 of X (local frame). */
+int dpgo_round_trajectory(int r, int d, int n, const double* X_host, const double* anchor_host, double* T_host,
+                          int device);
+int dpgo_round_trajectory_device(int r, int d, int n, const double* X_dev, const double* anchor_host, double* T_dev,
+                                 void* stream);
+
 /* out[k] = src tile idx[k]  (K11 pack for the public-pose exchange:
  * PGOAgent::getSharedPoseDict, src/PGOAgent.cpp:97-166) */
 int dpgo_gather_tiles_device(int r, int d, const double* src_dev, const int32_t* idx_dev, int count,

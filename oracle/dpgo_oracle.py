@@ -1111,3 +1111,35 @@ def multi_agent_gnc(meas: Measurements, n: int, num_robots: int, r: int, X0, inn
     info["cost"] = 2 * central.f(X)
     info["gradnorm"] = central.rie_grad_norm(X)
     return X, info
+
+
+# --------------------------------------------------------------------------
+# Rounding
+# --------------------------------------------------------------------------
+
+
+def project_to_rotation_group(M):
+    """projectToRotationGroup (src/DPGO_utils.cpp:464-478): U V^T from the full SVD, last column of U negated
+    when det(U) det(V) < 0."""
+    U, _, Vt = np.linalg.svd(M)
+    if np.linalg.det(U) * np.linalg.det(Vt) > 0:
+        return U @ Vt
+    U = U.copy()
+    U[:, -1] *= -1
+    return U @ Vt
+
+
+def round_trajectory(X, d, anchor=None):
+    """PGOAgent::getTrajectoryInLocalFrame (anchor None: pose 0) / getTrajectoryInGlobalFrame
+    (src/PGOAgent.cpp:718-767).  X: tiles [n, d+1, r]; anchor: tile [d+1, r].  Returns tiles [n, d+1, d]
+    (rows 0..d-1 = the columns of the rotation, row d = translation), i.e. the d x (d+1)n matrix column-major."""
+    n = X.shape[0]
+    A = X[0] if anchor is None else anchor
+    Ya = A[:d].T  # r x d
+    t0 = Ya.T @ A[d]
+    T = np.zeros((n, d + 1, d))
+    for i in range(n):
+        M = Ya.T @ X[i, :d].T  # d x d
+        T[i, :d] = project_to_rotation_group(M).T
+        T[i, d] = Ya.T @ X[i, d] - t0
+    return T

@@ -147,3 +147,33 @@ def test_duplicate_and_irrelevant_edges(oracle):
     pg2 = dpgo_amd.PoseGraph(0, 5, 3)
     pg2.setMeasurements(pm)
     assert np.array_equal(pg.quadraticMatrix()[2], pg2.quadraticMatrix()[2])
+
+
+def test_trajectory_csv_round_trip(tmp_path):
+    """PGOLogger::logTrajectory / loadTrajectory (src/PGOLogger.cpp:56-155): header, quaternion convention
+    (Eigen: x, y, z, w columns), 3-D only."""
+    from dpgo_amd.trajectory import load_trajectory, log_measurements, log_trajectory
+    import dpgo_amd
+    rng = np.random.default_rng(5)
+    n, d = 7, 3
+    T = np.zeros((d, (d + 1) * n), order="F")
+    for i in range(n):
+        Q, _ = np.linalg.qr(rng.standard_normal((d, d)))
+        if np.linalg.det(Q) < 0:
+            Q[:, 0] *= -1
+        T[:, 4 * i:4 * i + 3] = Q
+        T[:, 4 * i + 3] = rng.standard_normal(3)
+    f = str(tmp_path / "traj.csv")
+    assert log_trajectory(d, n, T, f)
+    assert open(f).readline().strip() == "pose_index,qx,qy,qz,qw,tx,ty,tz"
+    assert np.abs(load_trajectory(f) - T).max() < 1e-14
+    assert log_trajectory(2, n, np.zeros((2, 3 * n)), f) is False  # the reference returns silently for d == 2
+    # identity rotation -> quaternion (0, 0, 0, 1)
+    log_trajectory(3, 1, np.hstack([np.eye(3), np.zeros((3, 1))]), f)
+    assert open(f).read().splitlines()[1].split(",")[1:5] == ["0", "0", "0", "1"]
+    meas, _ = dpgo_amd.read_g2o_file(os.path.join(DATA, "tinyGrid3D.g2o"))
+    g = str(tmp_path / "meas.csv")
+    assert log_measurements(meas, g)
+    lines = open(g).read().splitlines()
+    assert lines[0].startswith("robot_src,pose_src,robot_dst,pose_dst,qx,qy,qz,qw,tx,ty,tz,kappa,tau,")
+    assert len(lines) == len(meas) + 1

@@ -688,3 +688,52 @@ def test_distributed_gnc_matches_oracle(oracle):
         assert np.abs(Gdev - Gref).max() <= 1e-10 * max(1.0, np.abs(Gref).max())
     # and the outliers do not move the optimum: the clean graph's cost at its 5-robot demo optimum
     assert abs(info["cost"] - 1025.398) < 0.05
+
+
+@pytest.mark.parametrize("d,r", [(3, 5), (3, 3), (2, 3), (2, 2), (3, 6)])
+def test_rounding_matches_oracle(oracle, d, r):
+    """K12 vs the SVD-based restatement of getTrajectoryInLocalFrame / InGlobalFrame (src/PGOAgent.cpp:718-767):
+    a noisy lifted trajectory (the rounding input at a nearly rank-d solution), some blocks reflected so that the
+    det < 0 branch of projectToRotationGroup runs; host-pointer and device flavours."""
+    import torch
+    import dpgo_amd
+    rng = np.random.default_rng(100 * d + r)
+    n = 333
+    Ylift, _ = np.linalg.qr(rng.standard_normal((r, d)))
+    X = np.zeros((n, d + 1, r))
+    for i in range(n):
+        Q, _ = np.linalg.qr(rng.standard_normal((d, d)))
+        if np.linalg.det(Q) < 0:
+            Q[:, 0] *= -1
+        if i % 17 == 5:
+            Q[:, 1] *= -1  # a reflected block: the det < 0 branch of projectToRotationGroup
+        X[i, :d] = (Ylift @ Q + 0.05 * rng.standard_normal((r, d))).T
+        X[i, d] = 3 * rng.standard_normal(r)
+    for anchor in (None, X[7].copy()):
+        ref = oracle.round_trajectory(X, d, anchor)
+        assert (np.linalg.det(ref[:, :d]) > 0).all()
+        Tm = dpgo_amd.round_trajectory(tiles_to_matrix(X), r, d, None if anchor is None else anchor.T)
+        got = np.ascontiguousarray(np.asfortranarray(Tm).T).reshape(n, d + 1, d)
+        assert np.abs(got - ref).max() < 1e-11
+        Xd = torch.tensor(X, dtype=torch.float64, device="cuda")
+        got_d = dpgo_amd.round_trajectory_device(Xd, None if anchor is None else anchor.T).cpu().numpy()
+        assert np.abs(got_d - ref).max() < 1e-11
+        assert np.abs(np.linalg.det(got_d[:, :d]) - 1).max() < 1e-12
+
+
+def test_end_to_end_g2o_to_trajectory(oracle, tmp_path):
+    """.g2o -> chordal initialisation -> device solve at rank d -> rounding -> CSV: on
+    smallGrid3D the rounded rank-3 solution reaches the literature optimum and survives the CSV round trip."""
+    import dpgo_amd
+    from dpgo_amd.robust import solvePGO
+    meas, n = dpgo_amd.read_g2o_file(os.path.join(DATA, "smallGrid3D.g2o"))
+    T = solvePGO(meas, n, dpgo_amd.ROptParameters(gradnorm_tol=1e-6, RTR_iterations=100, RTR_tCG_iterations=200))
+    Tm = dpgo_amd.round_trajectory(tiles_to_matrix(T), 3, 3)
+    tiles = matrix_to_tiles(Tm, 3)
+    om, _ = oracle.read_g2o(os.path.join(DATA, "smallGrid3D.g2o"))
+    cost = 2 * oracle.QuadraticProblem(oracle.construct_Q(n, 3, om), None, 3, 3).f(tiles)
+    assert abs(cost - 1025.398) < 2e-3  # rank-3 optimum == certified global optimum for this dataset
+    assert np.abs(tiles[0, :3] - np.eye(3)).max() < 1e-12 and np.abs(tiles[0, 3]).max() < 1e-12
+    f = str(tmp_path / "traj.csv")
+    assert dpgo_amd.log_trajectory(3, n, Tm, f)
+    assert np.abs(dpgo_amd.load_trajectory(f) - Tm).max() < 1e-12
