@@ -271,19 +271,23 @@ def main():
     ach = hb / (ms_hess.value * 1e-3) / 1e9
     traffic = None
     traffic_src = None
-    pmc_file = os.path.join(ROOT, "profiles", "r01_v5_pmc_fetch_write.json")
-    if world == 1 and args.workload == "grid100k" and r == 5 and os.path.exists(pmc_file):
+    import glob
+    pmc_files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_fetch_write.json")))
+    if world == 1 and args.workload == "grid100k" and r == 5 and pmc_files:
         # HBM-side bytes per launch from rocprofv3 PMC passes of this same command (separate FETCH_SIZE and
-        # WRITE_SIZE passes): FETCH_SIZE x 2 (gfx950 correction, calibrated on k_retract / k_rtr_update whose
-        # byte counts are exact) + WRITE_SIZE, KB -> bytes; "max" = the full (non-early-exit) launches
-        pmc = json.load(open(pmc_file))
-        key = "k_tcg_hess<%d, %d, 1>" % (d, r)
-        if key in pmc.get("FETCH_SIZE_KB", {}) and key in pmc.get("WRITE_SIZE_KB", {}):
-            traffic = (2.0 * pmc["FETCH_SIZE_KB"][key]["max"] + pmc["WRITE_SIZE_KB"][key]["max"]) * 1024.0
-            traffic_src = "profiles/r01_v5_pmc_fetch_write.json"
+        # WRITE_SIZE passes, tools/profile_round.sh): FETCH_SIZE x 2 (gfx950 correction, calibrated on
+        # k_retract / k_rtr_update whose byte counts are exact) + WRITE_SIZE, KB -> bytes; "max" = the full
+        # (non-early-exit) launches.  The newest committed summary is used.
+        pmc = json.load(open(pmc_files[-1]))
+        for key in ("k_tcg_hess_span<%d, %d, 1>" % (d, r), "k_tcg_hess<%d, %d, 1>" % (d, r)):
+            if key in pmc.get("FETCH_SIZE_KB", {}) and key in pmc.get("WRITE_SIZE_KB", {}):
+                traffic = (2.0 * pmc["FETCH_SIZE_KB"][key]["max"] + pmc["WRITE_SIZE_KB"][key]["max"]) * 1024.0
+                traffic_src = os.path.relpath(pmc_files[-1], ROOT)
+                break
     roofline = dict(bound="hbm",
-                    kernel="k_tcg_hess<%d,%d> (one tCG step: Q*z block-SpMM + Riemannian-Hessian epilogue + in-place "
-                           "direction / H-direction recurrences)" % (d, r),
+                    kernel="%s<%d,%d,1> (one tCG step: Q*z block-SpMM + Riemannian-Hessian epilogue + in-place "
+                           "direction / H-direction recurrences)"
+                           % ("k_tcg_hess_span" if ((d + 1) * r) % 2 == 0 else "k_tcg_hess", d, r),
                     achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS, traffic=traffic,
                     traffic_source=traffic_src,
                     bytes_per_launch=hb, avg_launch_us=ms_hess.value * 1e3,
