@@ -24,7 +24,7 @@ namespace dpgo {
 constexpr int kBlock = 256;
 constexpr int kWaves = kBlock / 64;
 constexpr int kMaxGrid = 1024;  // default launch cap: 4 workgroups per CU on 256 CUs
-constexpr int kPartialCap = 2048;  // capacity of the per-workgroup partial-sum regions (upper bound of any grid)
+constexpr int kPartialCap = 1024;  // capacity of the per-workgroup partial-sum regions (upper bound of any grid)
 constexpr int kNP = 4;          // partial sums per workgroup (max over kernels)
 
 enum : int { TCG_NEGCURV = 0, TCG_EXCREGION = 1, TCG_LCON = 2, TCG_SCON = 3, TCG_MAXITER = 4 };
@@ -211,6 +211,34 @@ __device__ __forceinline__ void load_partials(const double* __restrict__ p, int 
   block_allreduce<K>(out, red);
 }
 
+// Two-phase variant for latency-bound launches: the global loads are issued early (together with the other
+// independent loads of the kernel prologue) and reduced later.
+constexpr int kPartialTrips = kPartialCap / kBlock;
+template <int K>
+struct PartialRaw {
+  double v[kPartialTrips][K];
+};
+template <int K>
+__device__ __forceinline__ void partials_issue(const double* __restrict__ p, int nb, PartialRaw<K>& raw) {
+#pragma unroll
+  for (int t = 0; t < kPartialTrips; ++t) {
+    const int i = threadIdx.x + t * kBlock;
+#pragma unroll
+    for (int k = 0; k < K; ++k) raw.v[t][k] = (i < nb) ? p[i * kNP + k] : 0.0;
+  }
+}
+template <int K>
+__device__ __forceinline__ void partials_finish(const PartialRaw<K>& raw, double (&out)[K], double* red) {
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    double a = raw.v[0][k];
+#pragma unroll
+    for (int t = 1; t < kPartialTrips; ++t) a += raw.v[t][k];  // same order as load_partials
+    out[k] = a;
+  }
+  block_allreduce<K>(out, red);
+}
+
 template <int K>
 __device__ __forceinline__ void store_partials(double (&v)[K], double* __restrict__ p, double* red) {
   block_allreduce<K>(v, red);
@@ -326,6 +354,46 @@ __device__ __forceinline__ void spmm_col_pre(const RowIdx& ri, const int32_t* __
 #pragma unroll
   for (int o = 32; o >= 1; o >>= 1) maxdeg = max(maxdeg, __shfl_xor(maxdeg, o));
   const int kmax = maxdeg < NPRE ? maxdeg : NPRE;
+  if constexpr (SPLIT > 1) {
+    // latency layout: the loads of two blocks are in flight together (same FMA order as the plain loop)
+    for (int k0 = 0; k0 < kmax; k0 += 2 * SPLIT) {
+      const int kA = k0 + s, kB = k0 + SPLIT + s;
+      const int jA = __shfl(ja, gbase + (kA < LPP ? kA : 0));
+      const int jB = __shfl(ja, gbase + (kB < LPP ? kB : 0));
+      const bool okA = kA < deg && kA < NPRE, okB = kB < deg && kB < NPRE;
+      double qa[B], qb[B], xa[T], xb[T];
+      if (okA) {
+        const double* __restrict__ q = vals + (size_t)(t0 + kA) * BB + c * B;
+        const double* __restrict__ x = V + (size_t)jA * T;
+#pragma unroll
+        for (int kk = 0; kk < B; ++kk) qa[kk] = q[kk];
+#pragma unroll
+        for (int e = 0; e < T; ++e) xa[e] = x[e];
+      }
+      if (okB) {
+        const double* __restrict__ q = vals + (size_t)(t0 + kB) * BB + c * B;
+        const double* __restrict__ x = V + (size_t)jB * T;
+#pragma unroll
+        for (int kk = 0; kk < B; ++kk) qb[kk] = q[kk];
+#pragma unroll
+        for (int e = 0; e < T; ++e) xb[e] = x[e];
+      }
+      if (okA) {
+#pragma unroll
+        for (int kk = 0; kk < B; ++kk) {
+#pragma unroll
+          for (int a = 0; a < R; ++a) acc[a] = fma(xa[kk * R + a], qa[kk], acc[a]);
+        }
+      }
+      if (okB) {
+#pragma unroll
+        for (int kk = 0; kk < B; ++kk) {
+#pragma unroll
+          for (int a = 0; a < R; ++a) acc[a] = fma(xb[kk * R + a], qb[kk], acc[a]);
+        }
+      }
+    }
+  } else
   for (int k0 = 0; k0 < kmax; k0 += SPLIT) {
     const int k = k0 + s;  // this slice's block
     const int src = (k < LPP) ? k : k - LPP;
@@ -772,9 +840,12 @@ __global__ __launch_bounds__(kBlock, DPGO_LB_HESS) void k_tcg_hess(BsrDev Q, con
 // ---------------------------------------------------------------- tCG scalar prologues (shared)
 // Direction-update scalars (ROPTLIB tCG_TR): returns false when this launch has nothing left to do.
 __device__ __forceinline__ bool tcg_hess_prologue(DevState& st, const double* __restrict__ pin, int nb_in, int first,
-                                                  double* red, double& beta) {
+                                                  double* red, double& beta, const PartialRaw<2>* early = nullptr) {
   double pr[2];
-  load_partials<2>(pin, nb_in, pr, red);
+  if (early)
+    partials_finish<2>(*early, pr, red);
+  else
+    load_partials<2>(pin, nb_in, pr, red);
   const double r_r = pr[0], z_r_new = pr[1];
   beta = 0.0;
   if (first) {
@@ -810,7 +881,8 @@ __device__ __forceinline__ bool tcg_hess_prologue(DevState& st, const double* __
 
 // Step-length scalars: mode 0 = normal step, 1 = boundary step (eta += tau*delta, stop), 2 = initialisation.
 __device__ __forceinline__ int tcg_update_prologue(DevState& st, const double* __restrict__ pin, int nb_in, int first,
-                                                   double* red, double& alpha, double& tau) {
+                                                   double* red, double& alpha, double& tau,
+                                                   const PartialRaw<1>* early = nullptr) {
   alpha = 0.0;
   tau = 0.0;
   if (first) {
@@ -822,7 +894,10 @@ __device__ __forceinline__ int tcg_update_prologue(DevState& st, const double* _
     return 2;
   }
   double dh[1];
-  load_partials<1>(pin, nb_in, dh, red);
+  if (early)
+    partials_finish<1>(*early, dh, red);
+  else
+    load_partials<1>(pin, nb_in, dh, red);
   const double d_Hd = dh[0];
   alpha = st.z_r / d_Hd;
   const double e_Pe_new = st.e_Pe + 2.0 * alpha * st.e_Pd + alpha * alpha * st.d_Pd;
@@ -902,13 +977,19 @@ __global__ __launch_bounds__(kBlock) void k_tcg_hess_span(BsrDev Q, const double
       for (int a = 0; a < D; ++a) srow[a] = S[(size_t)i * D * D + L.c * D + a];
     }
   };
+  // ---- everything the prologue needs is requested before the first wait: state record (scalar loads), the
+  // previous kernel's partial sums (small blocks only: the registers would cost the big-block kernel an
+  // occupancy step), then the first tile.  A small-block launch is a chain of dependent memory round trips
+  // (rocprof: 9.4 us for 2500 poses); this takes two of them off the chain.
+  DevState st;
+  load_state(st, sin);
+  [[maybe_unused]] PartialRaw<2> praw;
+  if constexpr (SPLIT > 1) partials_issue<2>(pin, nb_in, praw);
   int tile = ti_.first;
   bool have = tile < ti_.last;
   if (have) prefetch(tile);
 
   // ---- scalar prologue
-  DevState st;
-  load_state(st, sin);
   if (st.rtr_stop || st.tcg_done) {
     if (blockIdx.x == 0 && threadIdx.x == 0) {
       store_state(sout, st);
@@ -917,7 +998,7 @@ __global__ __launch_bounds__(kBlock) void k_tcg_hess_span(BsrDev Q, const double
     return;
   }
   double beta;
-  const bool go = tcg_hess_prologue(st, pin, nb_in, first, red, beta);
+  const bool go = tcg_hess_prologue(st, pin, nb_in, first, red, beta, (SPLIT > 1) ? &praw : nullptr);
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     store_state(sout, st);
     publish_progress(hflag, gen, st);
@@ -1051,12 +1132,15 @@ __global__ __launch_bounds__(kBlock) void k_tcg_update_span(const double* __rest
       for (int k = 0; k < GEO::B; ++k) drow[k] = dinv[(size_t)i * GEO::BB + L.c * GEO::B + k];
     }
   };
+  // state record and partial sums are requested before the first tile (see k_tcg_hess_span)
+  DevState st;
+  load_state(st, sin);
+  PartialRaw<1> praw;
+  partials_issue<1>(pin, nb_in, praw);
   int tile = ti_.first;
   bool have = tile < ti_.last;
   if (have) prefetch(tile);
 
-  DevState st;
-  load_state(st, sin);
   if (st.rtr_stop || (!first && st.tcg_done)) {
     if (blockIdx.x == 0 && threadIdx.x == 0) {
       store_state(sout, st);
@@ -1065,7 +1149,7 @@ __global__ __launch_bounds__(kBlock) void k_tcg_update_span(const double* __rest
     return;
   }
   double alpha, tau;
-  const int mode = tcg_update_prologue(st, pin, nb_in, first, red, alpha, tau);
+  const int mode = tcg_update_prologue(st, pin, nb_in, first, red, alpha, tau, &praw);
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     store_state(sout, st);
     publish_progress(hflag, gen, st);
