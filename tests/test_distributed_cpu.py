@@ -135,3 +135,145 @@ def test_exchange_plan_structure(oracle):
         per_colour = sum((plan.messages(c) for c in range(plan.num_colours)), [])
         assert sorted(per_colour) == sorted(msgs)
     assert ExchangePlan(build_pose_graphs(pm, n, 8, 5)[1]).num_colours == 2  # ring of 8 agents
+
+
+# ---------------------------------------------------------------------------------------------
+# Distributed GNC over two gloo ranks (driver: dpgo_amd.robust.DistributedGNC; per-agent work: oracle)
+# ---------------------------------------------------------------------------------------------
+class HostGncProblem:
+    """CPU stand-in for the GNC methods of dpgo_amd.QuadraticProblem, backed by the oracle's formulas."""
+
+    def __init__(self, agent):
+        self.a = agent
+        self.reweightable_index = None
+
+    def _all(self):
+        a = self.a
+        return a.O.Measurements.concat([a.odo, a.priv, a.shared])
+
+    def setReweightableEdges(self, include_shared=False):
+        assert include_shared
+        self.reweightable_index = np.arange(self._all().m)
+        return len(self.reweightable_index)
+
+    def setEdgeWeights(self, w):
+        a = self.a
+        k1, k2 = a.odo.m, a.odo.m + a.priv.m
+        a.odo.weight[:], a.priv.weight[:], a.shared.weight[:] = w[:k1], w[k1:k2], w[k2:]
+
+    def getEdgeWeights(self):
+        m = self._all()
+        return m.weight.copy(), np.zeros(m.m)
+
+    def gncReweightDevice(self, X, nbr, mu, barc, w_tol=1e-8, update=True):
+        a, O = self.a, self.a.O
+        m = self._all()
+        d = m.d
+        Xn, slot = X.numpy(), {pid: k for k, pid in enumerate(a.plan.slots[a.id])}
+        rsq = np.zeros(m.m)
+        for e in range(m.m):
+            mine1, mine2 = m.r1[e] == a.id, m.r2[e] == a.id
+            xi = Xn[m.p1[e]] if mine1 else nbr[slot[(int(m.r1[e]), int(m.p1[e]))]].numpy()
+            xj = Xn[m.p2[e]] if mine2 else nbr[slot[(int(m.r2[e]), int(m.p2[e]))]].numpy()
+            Yi, Yj = xi[:d].T, xj[:d].T
+            rsq[e] = m.kappa[e] * np.sum((Yi @ m.R[e] - Yj) ** 2) + m.tau[e] * np.sum((xj[d] - xi[d] - Yi @ m.t[e]) ** 2)
+        w = m.weight.copy()
+        if update:
+            nf = ~m.fixed
+            w[nf] = O.gnc_tls_weight(np.sqrt(rsq[nf]), mu, barc)
+            self.setEdgeWeights(w)
+        counted = (~m.fixed) & (m.r1 == a.id)  # a shared edge is counted by the owner of its source pose
+        wc = w[counted]
+        n_out, n_in = int((wc < w_tol).sum()), int((wc > 1 - w_tol).sum())
+        return (n_in, n_out, len(wc) - n_in - n_out), float(rsq.max())
+
+
+class HostGncAgent(HostAgent):
+    def __init__(self, O, plan, my_id, om_local, X0_tiles, r, d):
+        super().__init__(O, plan, my_id, om_local, X0_tiles, r, d)
+        self.odo, self.priv = om_local["odometry"], om_local["private"]
+        self.has_neighbours = True
+        self.problem = HostGncProblem(self)
+
+    def _problem(self):  # Q is rebuilt from the current weights (PoseGraph::clearDataMatrices after a weight update)
+        O = self.O
+        self.Q = O.construct_Q(self.X.shape[0], self.d, O.Measurements.concat([self.odo, self.priv]), self.shared,
+                               my_id=self.id)
+        return super()._problem()
+
+
+def _gnc_case(O):
+    om, n, Ttrue = O.synthetic_grid(5, 4, 3, seed=5)
+    rng = np.random.default_rng(9)
+    k, d = 6, 3
+    taken = set(zip(om.p1.tolist(), om.p2.tolist()))
+    p1, p2 = [], []
+    while len(p1) < k:
+        a = int(rng.integers(0, n))
+        b = int((a + rng.integers(3, n - 3)) % n)
+        if (a, b) not in taken:
+            taken.add((a, b))
+            p1.append(a)
+            p2.append(b)
+    Rs = np.stack([np.linalg.qr(rng.standard_normal((d, d)))[0] for _ in range(k)])
+    for q in range(k):
+        if np.linalg.det(Rs[q]) < 0:
+            Rs[q][:, 0] *= -1
+    z = np.zeros(k, dtype=np.int64)
+    out = O.Measurements(d, z, np.array(p1), z.copy(), np.array(p2), Rs, rng.uniform(-5, 5, (k, d)),
+                         np.full(k, np.median(om.kappa)), np.full(k, np.median(om.tau)), np.ones(k),
+                         np.zeros(k, dtype=bool))
+    return O.Measurements.concat([om, out]), n, O.lift(O.perturbed_truth(Ttrue, seed=6), 5), om.m
+
+
+def _gnc_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    import dpgo_oracle as O
+    from dpgo_amd.agent import ExchangePlan, RBCDCluster, build_pose_graphs
+    from dpgo_amd.robust import DistributedGNC, RobustCostParameters
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        allm, n, X0, _ = _gnc_case(O)
+        ranges, graphs = build_pose_graphs(to_product_measurements(allm), n, world, 5)
+        _, per = O.partition_contiguous(allm, n, world)
+        plan = ExchangePlan(graphs)
+        s, e = ranges[rank]
+        agent = HostGncAgent(O, plan, rank, per[rank], X0[s:e], 5, 3)
+        cluster = RBCDCluster(plan, {rank: agent}, rank, world)
+        gnc = DistributedGNC(cluster, RobustCostParameters("GNC_TLS", GNCMaxNumIters=40, GNCBarc=5.0, GNCMuStep=1.4),
+                             inner_sweeps=2)
+        info = gnc.run()
+        hist = np.array([[h["mu"], h["inliers"], h["outliers"], h["undecided"]] for h in info["history"]])
+        np.savez(os.path.join(out_dir, "gnc%d.npz" % rank), X=agent.X.numpy(), hist=hist, s=s, e=e,
+                 muInit=info["muInit"], cost=info["cost"], updates=info["updates"])
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_gloo_distributed_gnc_matches_oracle(oracle, tmp_path):
+    """The N > 1 path of DistributedGNC (global max residual and classification counters by all-reduce, shared
+    edges counted once, every rank taking the same decisions) against oracle.multi_agent_gnc."""
+    import torch.multiprocessing as mp
+    O = oracle
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    mp.spawn(_gnc_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    allm, n, X0, m_clean = _gnc_case(O)
+    Xref, info_o = O.multi_agent_gnc(allm, n, 2, 5, X0, inner_sweeps=2, barc=5.0, mu_step=1.4, max_updates=40)
+    z = [np.load(os.path.join(str(tmp_path), "gnc%d.npz" % k)) for k in range(2)]
+    assert np.array_equal(z[0]["hist"], z[1]["hist"])  # both ranks took identical decisions
+    assert int(z[0]["updates"]) == info_o["updates"]
+    assert abs(float(z[0]["muInit"]) - info_o["muInit"]) <= 1e-12 * info_o["muInit"]
+    ho = np.array([[h["mu"], h["inliers"], h["outliers"], h["undecided"]] for h in info_o["history"]])
+    assert np.allclose(z[0]["hist"], ho, rtol=1e-12)
+    X = np.zeros_like(Xref)
+    for k in range(2):
+        X[int(z[k]["s"]):int(z[k]["e"])] = z[k]["X"]
+    assert np.abs(X - Xref).max() <= 1e-9
+    assert abs(float(z[0]["cost"]) - info_o["cost"]) <= 1e-9 * info_o["cost"]
+    assert info_o["history"][-1]["undecided"] == 0 and np.all(allm.weight[m_clean:] < 1e-8)
