@@ -945,6 +945,15 @@ int dpgo_problem_gnc_reweight_device(dpgo_problem_t p, const double* X_dev, cons
   return DPGO_OK;
 }
 
+int dpgo_problem_gnc_reweight(dpgo_problem_t p, const double* X_host, double mu, double barc, double w_tol, int update,
+                              int counts[3], double* max_rsq) {
+  CHK(check_ready(p));
+  if (!X_host) return fail(DPGO_ERR_INVALID, "null X");
+  if (p->n_shared_edges > 0) return fail(DPGO_ERR_STATE, "shared edges need the device flavour (neighbour tiles)");
+  CHK(h2d(p, p->x2, X_host));
+  return dpgo_problem_gnc_reweight_device(p, p->x2, nullptr, mu, barc, w_tol, update, counts, max_rsq);
+}
+
 int dpgo_problem_set_edge_weights(dpgo_problem_t p, const double* weight_host) {
   CHK(check_ready(p));
   if (!p->e_w) return fail(DPGO_ERR_STATE, "re-weightable edges not set");

@@ -66,6 +66,7 @@ SIGNATURES = {
     "dpgo_problem_set_reweightable_edges": ([_P, _I, _P, _P, _P, _P, _P, _P, _P, _P], _I),
     "dpgo_problem_set_reweightable_edges_ex": ([_P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P], _I),
     "dpgo_problem_gnc_reweight_device": ([_P, _P, _P, _D, _D, _D, _I, C.POINTER(C.c_int * 3), C.POINTER(_D)], _I),
+    "dpgo_problem_gnc_reweight": ([_P, _P, _D, _D, _D, _I, C.POINTER(C.c_int * 3), C.POINTER(_D)], _I),
     "dpgo_problem_set_edge_weights": ([_P, _P], _I),
     "dpgo_problem_get_edge_weights": ([_P, _P, _P], _I),
     "dpgo_problem_set_G": ([_P, _P], _I),

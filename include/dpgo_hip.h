@@ -159,6 +159,9 @@ int dpgo_problem_set_reweightable_edges_ex(dpgo_problem_t h, int m, const int32_
  * (w_tol as in DPGO_solver.cpp:340).  max_rsq (optional) = max residual over all edges (muInit, :358). */
 int dpgo_problem_gnc_reweight_device(dpgo_problem_t h, const double* X_dev, const double* nbr_tiles_dev, double mu,
                                      double barc, double w_tol, int update, int counts[3], double* max_rsq);
+/* Host-pointer flavour of dpgo_problem_gnc_reweight_device (X_host: r x (d+1)n column-major; private edges only). */
+int dpgo_problem_gnc_reweight(dpgo_problem_t h, const double* X_host, double mu, double barc, double w_tol, int update,
+                              int counts[3], double* max_rsq);
 int dpgo_problem_set_edge_weights(dpgo_problem_t h, const double* weight_host);   /* + rebuild Q, preconditioner */
 int dpgo_problem_get_edge_weights(dpgo_problem_t h, double* weight_host, double* rsq_host /* may be NULL */);
 

@@ -173,6 +173,7 @@ class PoseGraph {
     ++q_version_;
   }
   unsigned long qVersion() const { return q_version_; }
+  const std::vector<RelativeSEMeasurement>& measurements() const { return meas_; }  // after duplicate removal
   bool hasLinearTerm() const {
     if (!priors_.empty()) return true;
     for (const auto& m : meas_)
@@ -397,5 +398,148 @@ class LiftedSEManifold {
   unsigned r_, d_, n_;
   int device_;
 };
+
+// ---------------------------------------------------------------------------------------------------------
+// Rounding: PGOAgent::getTrajectoryInLocalFrame / getTrajectoryInGlobalFrame (src/PGOAgent.cpp:718-767).
+// X: r x (d+1)n; anchor: r x (d+1) lifted pose or nullptr (frame of pose 0).  Returns d x (d+1)n.
+inline Matrix roundTrajectory(const Matrix& X, unsigned d, const Matrix* anchor = nullptr, int device = 0) {
+  const unsigned r = (unsigned)X.rows();
+  if (X.cols() % (d + 1) != 0) throw Error(DPGO_ERR_INVALID, "matrix shape mismatch");
+  if (anchor && (anchor->rows() != r || anchor->cols() != d + 1))
+    throw Error(DPGO_ERR_INVALID, "CHECK(M.rows() == relaxation_rank() && M.cols() == dimension() + 1) failed");
+  const unsigned n = (unsigned)(X.cols() / (d + 1));
+  Matrix T(d, (size_t)(d + 1) * n);
+  check(dpgo_round_trajectory((int)r, (int)d, (int)n, X.data(), anchor ? anchor->data() : nullptr, T.data(), device));
+  return T;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// DPGO::RobustCostParameters / RobustCost (include/DPGO/DPGO_robust.h:20-133, src/DPGO_robust.cpp:49-134)
+struct RobustCostParameters {
+  enum class Type { L2, L1, TLS, Huber, GM, GNC_TLS };
+  Type costType = Type::L2;
+  unsigned GNCMaxNumIters = 20;
+  double GNCBarc = 5.0, GNCMuStep = 1.4, GNCInitMu = 1e-4, HuberThreshold = 3.0, TLSThreshold = 10.0;
+};
+class RobustCost {
+ public:
+  explicit RobustCost(const RobustCostParameters& p) : params_(p), mu_(p.GNCInitMu) {}
+  double weight(double r) const {  // src/DPGO_robust.cpp:54-98
+    using T = RobustCostParameters::Type;
+    switch (params_.costType) {
+      case T::L2: return 1.0;
+      case T::L1: return 1.0 / r;
+      case T::Huber: return r < params_.HuberThreshold ? 1.0 : params_.HuberThreshold / r;
+      case T::TLS: return r < params_.TLSThreshold ? 1.0 : 0.0;
+      case T::GM: { const double a = 1 + r * r; return 1.0 / (a * a); }
+      case T::GNC_TLS: {
+        const double rSq = r * r, bSq = params_.GNCBarc * params_.GNCBarc;
+        const double upper = (mu_ + 1) / mu_ * bSq, lower = mu_ / (mu_ + 1) * bSq;
+        if (rSq >= upper) return 0.0;
+        if (rSq <= lower) return 1.0;
+        return std::sqrt(bSq * mu_ * (mu_ + 1) / rSq) - mu_;
+      }
+    }
+    throw std::runtime_error("weight function for selected cost function is not implemented !");  // :95
+  }
+  void update() {  // :106-121 (only GNC_TLS has state)
+    if (params_.costType != RobustCostParameters::Type::GNC_TLS) return;
+    ++iteration_;
+    if (iteration_ > params_.GNCMaxNumIters) return;
+    mu_ *= params_.GNCMuStep;
+  }
+  double mu() const { return mu_; }
+
+ private:
+  RobustCostParameters params_;
+  double mu_;
+  unsigned iteration_ = 0;
+};
+
+// DPGO::solvePGO / solveRobustPGO (include/DPGO/DPGO_solver.h:100-123, src/DPGO_solver.cpp:305-412).  T0 is
+// required here (the reference falls back to its SPQR-based chordal initialisation, which is outside the path).
+struct solveRobustPGOParams {
+  ROptParameters opt_params;
+  RobustCostParameters robust_params;
+  bool verbose = false;
+  solveRobustPGOParams() { robust_params.costType = RobustCostParameters::Type::GNC_TLS; }
+};
+
+inline Matrix solvePGO(const std::vector<RelativeSEMeasurement>& measurements, const ROptParameters& params,
+                       const Matrix* T0, int device = 0) {
+  if (measurements.empty()) throw Error(DPGO_ERR_INVALID, "no measurements");
+  if (!T0) throw Error(DPGO_ERR_UNSUPPORTED, "solvePGO needs an initial guess T0");
+  const unsigned d = (unsigned)measurements[0].R.rows();
+  auto pg = std::make_shared<PoseGraph>(0, d, d);  // rank r = d (src/DPGO_solver.cpp:322)
+  pg->setMeasurements(measurements);
+  QuadraticProblem problem(pg, device);
+  QuadraticOptimizer optimizer(&problem, params);
+  return optimizer.optimize(*T0);
+}
+
+// GNC with truncated least squares.  One device problem serves all outer iterations: the weights are updated
+// and Q's values / the preconditioner rebuilt ON THE DEVICE (the reference rebuilds a PoseGraph per iteration).
+inline Matrix solveRobustPGO(std::vector<RelativeSEMeasurement>& mutable_measurements,
+                             const solveRobustPGOParams& params, const Matrix* T0, int device = 0) {
+  if (mutable_measurements.empty()) throw Error(DPGO_ERR_INVALID, "no measurements");
+  if (!T0) throw Error(DPGO_ERR_UNSUPPORTED, "solveRobustPGO needs an initial guess T0");
+  if (params.robust_params.costType != RobustCostParameters::Type::GNC_TLS)
+    throw Error(DPGO_ERR_INVALID, "CHECK(params.robust_params.costType == GNC_TLS) failed");  // :355
+  const double w_tol = 1e-8;  // :340
+  const unsigned d = (unsigned)mutable_measurements[0].R.rows();
+  auto pg = std::make_shared<PoseGraph>(0, d, d);
+  pg->setMeasurements(mutable_measurements);
+  QuadraticProblem problem(pg, device);
+  QuadraticOptimizer optimizer(&problem, params.opt_params);
+  const auto& ms = pg->measurements();
+  const int m = (int)ms.size();
+  std::vector<int32_t> p1(m), p2(m);
+  std::vector<double> R((size_t)m * d * d), t((size_t)m * d), kappa(m), tau(m), w(m, 1.0);
+  std::vector<uint8_t> fixed(m);
+  for (int e = 0; e < m; ++e) {
+    p1[e] = (int32_t)ms[e].p1;
+    p2[e] = (int32_t)ms[e].p2;
+    for (unsigned a = 0; a < d; ++a) {
+      for (unsigned b = 0; b < d; ++b) R[((size_t)e * d + a) * d + b] = ms[e].R(a, b);
+      t[(size_t)e * d + a] = ms[e].t(a, 0);
+    }
+    kappa[e] = ms[e].kappa;
+    tau[e] = ms[e].tau;
+    w[e] = ms[e].weight;
+    fixed[e] = ms[e].fixedWeight ? 1 : 0;
+  }
+  Matrix T = optimizer.optimize(*T0);  // :342 initial estimate (current weights)
+  check(dpgo_problem_set_reweightable_edges(problem.handle(), m, p1.data(), p2.data(), R.data(), t.data(), kappa.data(),
+                                            tau.data(), w.data(), fixed.data()));
+  std::fill(w.begin(), w.end(), 1.0);  // :346 meas.weight = 1
+  check(dpgo_problem_set_edge_weights(problem.handle(), w.data()));
+  int counts[3] = {0, 0, 0};
+  double max_rsq = 0.0;
+  check(dpgo_problem_gnc_reweight(problem.handle(), T.data(), 1.0, params.robust_params.GNCBarc, w_tol, 0, counts,
+                                  &max_rsq));  // residuals only (:347-351)
+  const double barcSq = params.robust_params.GNCBarc * params.robust_params.GNCBarc;
+  const double muInit = barcSq / (2 * max_rsq - barcSq);  // :358
+  if (muInit > 0) {  // negative: small residuals, GNC is skipped (:367)
+    RobustCostParameters pg_params = params.robust_params;
+    pg_params.GNCInitMu = muInit;
+    RobustCost cost(pg_params);
+    for (unsigned iter = 0; iter < pg_params.GNCMaxNumIters; ++iter) {
+      T = optimizer.optimize(*T0);  // always restarted from T0 (:372)
+      check(dpgo_problem_gnc_reweight(problem.handle(), T.data(), cost.mu(), pg_params.GNCBarc, w_tol, 1, counts,
+                                      nullptr));
+      if (counts[2] == 0) break;  // no undecided weight (:403)
+      cost.update();
+    }
+  }
+  T = optimizer.optimize(*T0);  // :409
+  check(dpgo_problem_get_edge_weights(problem.handle(), w.data(), nullptr));
+  for (auto& mm : mutable_measurements)  // duplicates (dropped by PoseGraph) keep their weight
+    for (int e = 0; e < m; ++e)
+      if (mm.r1 == ms[e].r1 && mm.p1 == ms[e].p1 && mm.r2 == ms[e].r2 && mm.p2 == ms[e].p2) {
+        mm.weight = w[e];
+        break;
+      }
+  return T;
+}
 
 }  // namespace dpgo_hip

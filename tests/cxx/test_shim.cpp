@@ -186,6 +186,98 @@ static int run() {
     }
     std::printf("project: ok\n");
   }
+  // ---------------- rounding (PGOAgent::getTrajectoryInLocalFrame, src/PGOAgent.cpp:718-738): the triangle
+  // solution rounded in the frame of pose 0 is Ttrue again; with pose 1 as the global anchor, pose 1 is identity
+  {
+    Matrix Tl = roundTrajectory(Topt, d);
+    double e2 = 0;
+    for (int i = 0; i < 3; ++i)
+      for (int a = 0; a < 3; ++a)
+        for (int b = 0; b < 4; ++b) e2 += std::pow(Tl(a, i * 4 + b) - (*Tw[i])(a, b), 2);
+    std::printf("rounding: |Ttrue - round(T)| = %.3e\n", std::sqrt(e2));
+    REQUIRE(std::sqrt(e2) <= 1e-4);
+    Matrix anchor = Topt.block(0, 4, 3, 4);
+    Matrix Tg = roundTrajectory(Topt, d, &anchor);
+    double ea = 0;
+    for (int a = 0; a < 3; ++a)
+      for (int b = 0; b < 4; ++b) ea += std::pow(Tg(a, 4 + b) - (a == b ? 1.0 : 0.0), 2);
+    REQUIRE(std::sqrt(ea) <= 1e-12);
+  }
+
+  // ---------------- robust PGO (testPGO.cpp:193-271): 4-pose chain, one inlier and one outlier loop closure;
+  // GNC-TLS with barc = 7, tol 1e-1, 50 RTR iterations drives the weights to 1 and 0
+  {
+    const int nn = 4;
+    const double kap = 10000, ta = 100;
+    auto rot = [](double ax, double ay, double az, double ang) {  // Rodrigues
+      const double nrm = std::sqrt(ax * ax + ay * ay + az * az);
+      ax /= nrm, ay /= nrm, az /= nrm;
+      const double c = std::cos(ang), s_ = std::sin(ang), C = 1 - c;
+      Matrix Rm(3, 3);
+      Rm(0, 0) = c + ax * ax * C, Rm(0, 1) = ax * ay * C - az * s_, Rm(0, 2) = ax * az * C + ay * s_;
+      Rm(1, 0) = ay * ax * C + az * s_, Rm(1, 1) = c + ay * ay * C, Rm(1, 2) = ay * az * C - ax * s_;
+      Rm(2, 0) = az * ax * C - ay * s_, Rm(2, 1) = az * ay * C + ax * s_, Rm(2, 2) = c + az * az * C;
+      return Rm;
+    };
+    std::vector<Matrix> Tg;
+    const double axes[4][4] = {{1, 2, 3, 0.7}, {-2, 1, 0.5, 2.1}, {0.3, -1, 2, 1.3}, {2, 2, -1, 2.9}};
+    for (int i = 0; i < nn; ++i) {
+      Matrix Ti = Matrix::Identity(4, 4);
+      Ti.setBlock(0, 0, rot(axes[i][0], axes[i][1], axes[i][2], axes[i][3]));
+      for (int k = 0; k < 3; ++k) Ti(k, 3) = i;
+      Tg.push_back(Ti);
+    }
+    std::vector<RelativeSEMeasurement> meas;
+    for (int i = 0; i + 1 < nn; ++i) {
+      RelativeSEMeasurement m = between(i, i + 1, Tg[i], Tg[i + 1]);
+      m.kappa = kap, m.tau = ta, m.fixedWeight = true;
+      meas.push_back(m);
+    }
+    RelativeSEMeasurement inl = between(0, 3, Tg[0], Tg[3]);
+    inl.kappa = kap, inl.tau = ta, inl.fixedWeight = false;
+    meas.push_back(inl);
+    RelativeSEMeasurement outl(0, 0, 1, 3, rot(-1, 0.2, 0.4, 2.4), Matrix::Zero(3, 1), kap, ta);
+    outl.fixedWeight = false;
+    meas.push_back(outl);
+    // odometryInitialization (src/DPGO_solver.cpp:271-303)
+    Matrix TOdom(3, 4 * nn), acc = Matrix::Identity(4, 4);
+    for (int i = 0; i < nn; ++i) {
+      if (i > 0) {
+        Matrix dT = Matrix::Identity(4, 4);
+        dT.setBlock(0, 0, meas[i - 1].R);
+        dT.setBlock(0, 3, meas[i - 1].t);
+        acc = mul(acc, dT);
+      }
+      TOdom.setBlock(0, i * 4, acc.block(0, 0, 3, 4));
+    }
+    solveRobustPGOParams rp;
+    rp.opt_params.gradnorm_tol = 1e-1;
+    rp.opt_params.RTR_iterations = 50;
+    rp.robust_params.GNCBarc = 7.0;
+    auto mutable_measurements = meas;
+    Matrix Tr = solveRobustPGO(mutable_measurements, rp, &TOdom);
+    REQUIRE(Tr.cols() == (size_t)4 * nn);
+    for (const auto& m : mutable_measurements) {
+      if (m.fixedWeight) {
+        REQUIRE(m.weight == 1.0);
+      } else if (m.p1 == 0 && m.p2 == 3) {
+        std::printf("robust: inlier weight %.3e\n", m.weight);
+        REQUIRE(std::fabs(m.weight - 1) <= 1e-6);
+      } else if (m.p1 == 1 && m.p2 == 3) {
+        std::printf("robust: outlier weight %.3e\n", m.weight);
+        REQUIRE(std::fabs(m.weight) <= 1e-6);
+      }
+    }
+    // RobustCost::weight known values (GNC-TLS, src/DPGO_robust.cpp:80-92)
+    RobustCostParameters cp;
+    cp.costType = RobustCostParameters::Type::GNC_TLS;
+    cp.GNCInitMu = 1.0;
+    cp.GNCBarc = 2.0;
+    RobustCost rc(cp);
+    REQUIRE(rc.weight(1.0) == 1.0 && rc.weight(3.0) == 0.0);  // rSq <= mu/(mu+1) barc^2 = 2 ; rSq >= 8
+    REQUIRE(std::fabs(rc.weight(2.0) - (std::sqrt(4.0 * 2.0 / 4.0) - 1.0)) < 1e-15);
+  }
+
   // ---------------- error behaviour: shape mismatch is reported, not aborted
   try {
     problem.f(Matrix(2, 5));
