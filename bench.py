@@ -108,7 +108,10 @@ def cpu_baseline(meas_p, n, X_state, r, budget_s):
     per_tcg = (time.perf_counter() - t0) / reps
     max_inner = 50
     inner = max_inner if 3 * max_inner * per_tcg * 1.2 <= budget_s else max(2, int(budget_s / 3 / per_tcg / 1.2))
-    opt = O.QuadraticOptimizer(prob, O.ROptParameters(RTR_tCG_iterations=inner), hess_recurrence=True)
+    # same tCG arithmetic as the device runs for a block of this size (pipelined scheme for small blocks)
+    mode = "pipelined" if (os.environ.get("DPGO_PIPE", "0") not in ("", "0") and n < 40000
+                                                and ((d + 1) * r) % 2 == 0) else True
+    opt = O.QuadraticOptimizer(prob, O.ROptParameters(RTR_tCG_iterations=inner), hess_recurrence=mode)
     t0 = time.perf_counter()
     opt.optimize(X)
     el = time.perf_counter() - t0

@@ -490,6 +490,77 @@ def dot(A, B):
     return float(np.sum(A * B))
 
 
+def tcg_pipelined(problem: "QuadraticProblem", X, g, S, Delta, max_inner, theta=1.0, kappa=0.1, min_inner=0,
+                  trace=None):
+    """tCG_TR with ONE global reduction per iteration (what the MI355X path runs on small, latency-bound
+    blocks).  Same iterates as `tcg` in exact arithmetic.  With P the preconditioner and H
+    the Riemannian Hessian (both linear on the tangent space) keep, besides r, z = P r, delta and H delta,
+        w = H z,  m = P w,  q = P H delta,  t = H q
+    and advance them by recurrences, so that the only operator application of iteration j is n_j = H m_j on a
+    vector that is complete when the iteration starts (pipelined PCG, Ghysels & Vanroose 2014):
+        delta_j = -z_j + b delta_{j-1}      H delta_j = -w_j + b H delta_{j-1}
+        q_j     = -m_j + b q_{j-1}          t_j       = -n_j + b t_{j-1}
+        eta += a delta_j;  r += a H delta_j;  z += a q_j;  w += a t_j;  m = P w
+    <delta_j, H delta_j> is not summed but derived: mu_j - b^2 <delta_{j-1}, H delta_{j-1}>, mu_j = <z_j, w_j>
+    (conjugacy of the directions), so the three sums <z,r>, <r,r>, <z,w> of iteration j+1 are the only
+    reduction.  Returns (eta, status, inner_iters, n_hess)."""
+    r = g.copy()
+    eta = np.zeros_like(g)
+    z = problem.precondition(X, r)
+    w = problem.rie_hess(X, S, z)
+    m = problem.precondition(X, w)
+    n_hess = 1
+    zr, rr, mu = dot(z, r), dot(r, r), dot(z, w)
+    norm_r0 = math.sqrt(rr)
+    z_r, d_Pd, e_Pd, e_Pe = zr, zr, 0.0, 0.0
+    delta = Hd = q = t = None
+    d_Hd, alpha, beta = mu, 0.0, 0.0
+    status = TCG_MAXITER
+    j = 0
+    while j < max_inner:
+        if j > 0:
+            norm_r = math.sqrt(rr)
+            if j - 1 >= min_inner and norm_r <= norm_r0 * min(norm_r0 ** theta, kappa):
+                status = TCG_LCON if kappa < norm_r0 ** theta else TCG_SCON
+                j -= 1
+                break
+            beta = zr / z_r
+            e_Pd = beta * (e_Pd + alpha * d_Pd)
+            d_Pd = zr + beta * beta * d_Pd
+            z_r = zr
+            d_Hd = mu - beta * beta * d_Hd
+        delta = -z if j == 0 else beta * delta - z
+        alpha = z_r / d_Hd if d_Hd != 0 else math.inf
+        e_Pe_new = e_Pe + 2.0 * alpha * e_Pd + alpha * alpha * d_Pd
+        if d_Hd <= 0 or e_Pe_new >= Delta * Delta:
+            tau = (-e_Pd + math.sqrt(e_Pd * e_Pd + d_Pd * (Delta * Delta - e_Pe))) / d_Pd
+            eta = eta + tau * delta
+            status = TCG_NEGCURV if d_Hd < 0 else TCG_EXCREGION
+            if trace is not None:
+                trace.append(dict(j=j, d_Hd=d_Hd, alpha=alpha, tau=tau, status=status))
+            break
+        e_Pe = e_Pe_new
+        nvec = problem.rie_hess(X, S, m)
+        n_hess += 1
+        Hd = -w if j == 0 else beta * Hd - w
+        q = -m if j == 0 else beta * q - m
+        t = -nvec if j == 0 else beta * t - nvec
+        eta = eta + alpha * delta
+        r = r + alpha * Hd
+        z = z + alpha * q
+        w = w + alpha * t
+        m = problem.precondition(X, w)
+        zr, rr, mu = dot(z, r), dot(r, r), dot(z, w)
+        if trace is not None:
+            trace.append(dict(j=j, d_Hd=d_Hd, alpha=alpha, norm_r=math.sqrt(rr)))
+        j += 1
+    else:
+        # max_inner reached: the reference leaves the loop with j == max_inner after the last update; the
+        # convergence test of that last residual is not evaluated (MAXITER)
+        pass
+    return eta, status, j, n_hess
+
+
 def tcg(problem: QuadraticProblem, X, g, S, Delta, max_inner, theta=1.0, kappa=0.1, min_inner=0, trace=None,
         hess_recurrence=False):
     """ROPTLIB SolversTR::tCG_TR restated (SURVEY 8a row a8), eta0 = 0 (useRand = false).
@@ -498,7 +569,10 @@ def tcg(problem: QuadraticProblem, X, g, S, Delta, max_inner, theta=1.0, kappa=0
     hess_recurrence = False is the reference's arithmetic (H applied to delta every iteration).
     hess_recurrence = True is what the MI355X path computes: H is applied to the preconditioned
     residual z and H delta follows the direction recurrence, H delta' = beta * H delta - H z (exact in
-    exact arithmetic because H is linear on the tangent space)."""
+    exact arithmetic because H is linear on the tangent space).
+    hess_recurrence = "pipelined" selects tcg_pipelined (one reduction per iteration; small blocks on the device)."""
+    if hess_recurrence == "pipelined":
+        return tcg_pipelined(problem, X, g, S, Delta, max_inner, theta, kappa, min_inner, trace)
     r = g.copy()
     e_Pe = 0.0
     r_r = dot(r, r)

@@ -1,6 +1,7 @@
 import os
 import sys
 
+
 import numpy as np
 import pytest
 
@@ -59,3 +60,11 @@ def to_product_measurements(om):
     c = np.copy  # no aliasing: solveRobustPGO updates the product-side weights in place
     return dpgo_amd.RelativeSEMeasurements(om.d, c(om.r1), c(om.p1), c(om.r2), c(om.p2), c(om.R), c(om.t), c(om.kappa),
                                            c(om.tau), c(om.weight), c(om.fixed))
+
+
+def device_tcg_mode(n, d, r):
+    """The tCG arithmetic the device runs for a block of n poses (oracle `hess_recurrence` argument): with DPGO_PIPE=1
+    small blocks with an even tile size use the pipelined one-reduction scheme, everything else (and the default)
+    is the H-direction recurrence."""
+    pipe = os.environ.get("DPGO_PIPE", "0") not in ("", "0")  # opt-in, read by the library at problem creation
+    return "pipelined" if (pipe and n < 40000 and ((d + 1) * r) % 2 == 0) else True

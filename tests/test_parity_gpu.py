@@ -10,7 +10,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import DATA, matrix_to_tiles, tiles_to_matrix, to_product_measurements
+from conftest import DATA, matrix_to_tiles, tiles_to_matrix, to_product_measurements, device_tcg_mode
 
 pytestmark = pytest.mark.gpu
 
@@ -100,7 +100,7 @@ def test_optimize_matches_oracle_at_matched_settings(oracle, name, r, precond):
         T = oracle.chordal_initialization(om, n)
     X0 = oracle.lift(T, r)
     op = oracle.QuadraticProblem(Q, None, r, d, precond=precond)
-    oopt = oracle.QuadraticOptimizer(op, oracle.ROptParameters(), hess_recurrence=True)
+    oopt = oracle.QuadraticOptimizer(op, oracle.ROptParameters(), hess_recurrence=device_tcg_mode(n, d, r))
     Xo = oopt.optimize(X0)
     gopt = dpgo_amd.QuadraticOptimizer(prob, dpgo_amd.ROptParameters(precond=precond))
     Xg = matrix_to_tiles(gopt.optimize(tiles_to_matrix(X0)), d)
@@ -166,7 +166,7 @@ def test_feed_modes_and_single_iteration_radius_shrink(oracle):
                                                                       outs[0][1].rtr_iterations, outs[0][1].fOpt)
     # single-iteration mode: a tiny initial radius is accepted at once, result equals the oracle's
     prm_o = oracle.ROptParameters(RTR_iterations=1, RTR_initial_radius=1.0)
-    oo = oracle.QuadraticOptimizer(oracle.QuadraticProblem(Q, None, 5, d, precond="jacobi"), prm_o, hess_recurrence=True)
+    oo = oracle.QuadraticOptimizer(oracle.QuadraticProblem(Q, None, 5, d, precond="jacobi"), prm_o, hess_recurrence=device_tcg_mode(n, d, 5))
     Xo = oo.optimize(matrix_to_tiles(X0, d))
     go = dpgo_amd.QuadraticOptimizer(prob, dpgo_amd.ROptParameters(RTR_iterations=1, RTR_initial_radius=1.0))
     Xg = matrix_to_tiles(go.optimize(X0), d)
@@ -328,7 +328,7 @@ def test_multi_agent_rbcd_on_one_gpu_matches_oracle(oracle, name, robots, sweeps
     om, n = oracle.read_g2o(os.path.join(DATA, name + ".g2o"))
     d = om.d
     X0 = oracle.lift(oracle.chordal_initialization(om, n), r)
-    Xref, costs, gns = oracle.rbcd_coloured(om, n, robots, r, X0, sweeps, hess_recurrence=True)
+    Xref, costs, gns = oracle.rbcd_coloured(om, n, robots, r, X0, sweeps, hess_recurrence=device_tcg_mode(n // robots, d, r))
     ranges, graphs = build_pose_graphs(to_product_measurements(om), n, robots, r)
     plan = ExchangePlan(graphs)
     agents = {a: DeviceAgent(graphs, plan, a, X0[ranges[a][0]:ranges[a][1]], dpgo_amd.ROptParameters())
@@ -387,7 +387,7 @@ def test_greedy_accelerated_schedule_matches_oracle(oracle):
     X0 = oracle.lift(oracle.chordal_initialization(om, n), r)
     ref = oracle.multi_robot_example(om, n, robots, r, X0, precond="exact")
     assert ref["iterations"] == 87 and abs(ref["cost"] - 1025.39835) < 5e-6 and ref["gradnorm"] < 0.1
-    want = oracle.multi_robot_example(om, n, robots, r, X0, precond="jacobi", hess_recurrence=True)
+    want = oracle.multi_robot_example(om, n, robots, r, X0, precond="jacobi", hess_recurrence=device_tcg_mode(n // robots, om.d, r))
     ranges, graphs = build_pose_graphs(to_product_measurements(om), n, robots, r)
     plan = ExchangePlan(graphs)
     agents = {a: DeviceAgent(graphs, plan, a, X0[ranges[a][0]:ranges[a][1]], dpgo_amd.ROptParameters())
@@ -420,7 +420,7 @@ def test_robust_pgo_known_answer_on_device(oracle):
     assert abs(pm.weight[3] - 1) <= 1e-6 and abs(pm.weight[4]) <= 1e-6
     assert np.all(pm.weight[:3] == 1.0)
     To, info_o = oracle.solve_robust_pgo(om, n, T0, oracle.ROptParameters(gradnorm_tol=1e-1, RTR_iterations=50),
-                                         barc=7.0, precond="jacobi", hess_recurrence=True)
+                                         barc=7.0, precond="jacobi", hess_recurrence=device_tcg_mode(n, 3, 3))
     assert info["gnc_iterations"] == info_o["gnc_iterations"]
     assert abs(info["muInit"] - info_o["muInit"]) <= 1e-6 * abs(info_o["muInit"])
     assert relerr(T, To) < 1e-6
@@ -448,7 +448,7 @@ def test_gnc_reweighting_with_outliers_matches_oracle(oracle):
     allm = oracle.Measurements.concat([om, out])
     T0 = oracle.chordal_initialization(om, n)  # initial guess from the clean graph (same on both sides)
     opt_o = oracle.ROptParameters(RTR_iterations=10, RTR_tCG_iterations=100)
-    To, info_o = oracle.solve_robust_pgo(allm, n, T0, opt_o, barc=5.0, precond="jacobi", hess_recurrence=True,
+    To, info_o = oracle.solve_robust_pgo(allm, n, T0, opt_o, barc=5.0, precond="jacobi", hess_recurrence=device_tcg_mode(n, 2, 2),
                                          max_iters=20)
     pm = to_product_measurements(oracle.Measurements.concat([om, out]))
     pm.weight[:] = 1.0
@@ -529,7 +529,7 @@ def test_high_degree_rows_and_ragged_sizes(oracle, d, r, n, hub_edges):
     S = op.sym_ytg(X, op.euc_grad(X))
     assert relerr(matrix_to_tiles(prob.RieHessianEta(Xm, Vm), d), op.rie_hess(X, S, V)) < RTOL_ELEM
     if n <= 1000:
-        oo = oracle.QuadraticOptimizer(op, oracle.ROptParameters(), hess_recurrence=True)
+        oo = oracle.QuadraticOptimizer(op, oracle.ROptParameters(), hess_recurrence=device_tcg_mode(n, d, r))
         Xo = oo.optimize(X)
         go = dpgo_amd.QuadraticOptimizer(prob, dpgo_amd.ROptParameters())
         Xg = matrix_to_tiles(go.optimize(Xm), d)
@@ -542,7 +542,7 @@ def test_high_degree_rows_and_ragged_sizes(oracle, d, r, n, hub_edges):
             assert relerr(Xg, Xo) < 1e-4
             assert abs(rg.fOpt - oo.result.fOpt) <= 1e-3 * abs(oo.result.fOpt)
             two = dpgo_amd.ROptParameters(RTR_iterations=2)
-            o2 = oracle.QuadraticOptimizer(op, oracle.ROptParameters(RTR_iterations=2), hess_recurrence=True)
+            o2 = oracle.QuadraticOptimizer(op, oracle.ROptParameters(RTR_iterations=2), hess_recurrence=device_tcg_mode(n, d, r))
             X2o = o2.optimize(X)
             X2g = matrix_to_tiles(dpgo_amd.QuadraticOptimizer(prob, two).optimize(Xm), d)
             assert relerr(X2g, X2o) < 1e-10
@@ -554,7 +554,7 @@ def test_high_degree_rows_and_ragged_sizes(oracle, d, r, n, hub_edges):
     else:
         go = dpgo_amd.QuadraticOptimizer(prob, dpgo_amd.ROptParameters(RTR_iterations=1, RTR_tCG_iterations=10))
         oo = oracle.QuadraticOptimizer(op, oracle.ROptParameters(RTR_iterations=1, RTR_tCG_iterations=10),
-                                       hess_recurrence=True)
+                                       hess_recurrence=device_tcg_mode(n, d, r))
         Xo = oo.optimize(X)
         Xg = matrix_to_tiles(go.optimize(Xm), d)
         assert relerr(Xg, Xo) < 1e-8
@@ -635,7 +635,7 @@ def test_distributed_gnc_matches_oracle(oracle):
     X0 = oracle.lift(oracle.chordal_initialization(om, n), r)
     ref_meas = _inject_outliers(oracle, om, n, k, seed=7)
     Xref, info_o = oracle.multi_agent_gnc(ref_meas, n, robots, r, X0, inner_sweeps=sweeps, barc=5.0, mu_step=1.4,
-                                          max_updates=40, hess_recurrence=True)
+                                          max_updates=40, hess_recurrence=device_tcg_mode(n // robots, d, r))
     assert info_o["history"][-1]["undecided"] == 0  # the protocol terminated by classification
 
     pm = to_product_measurements(allm)
@@ -737,3 +737,35 @@ def test_end_to_end_g2o_to_trajectory(oracle, tmp_path):
     f = str(tmp_path / "traj.csv")
     assert dpgo_amd.log_trajectory(3, n, Tm, f)
     assert np.abs(dpgo_amd.load_trajectory(f) - Tm).max() < 1e-12
+
+
+@pytest.mark.parametrize("name", ["smallGrid3D", "sphere2500"])
+def test_pipelined_tcg_option_matches_oracle(oracle, name, monkeypatch):
+    """DPGO_PIPE=1: small blocks run one launch / one reduction per tCG iteration (k_tcg_pipe).  Same iterates as
+    the oracle's tcg_pipelined (iteration counts, status, X to 1e-7) and, because both schemes are the same
+    algorithm in exact arithmetic, the same result as the default two-kernel scheme to 1e-6."""
+    import dpgo_amd
+    r = 5
+    om, n = oracle.read_g2o(os.path.join(DATA, name + ".g2o"))
+    d = om.d
+    X0 = oracle.lift(oracle.chordal_initialization(om, n), r)
+    pm = to_product_measurements(om)
+
+    def solve():
+        pg = dpgo_amd.PoseGraph(0, r, d)
+        pg.setMeasurements(pm)
+        opt = dpgo_amd.QuadraticOptimizer(dpgo_amd.QuadraticProblem(pg), dpgo_amd.ROptParameters())
+        return matrix_to_tiles(opt.optimize(tiles_to_matrix(X0)), d), opt.getOptResult()
+
+    Xd, rd = solve()  # default scheme
+    monkeypatch.setenv("DPGO_PIPE", "1")
+    Xp, rp = solve()
+    oo = oracle.QuadraticOptimizer(oracle.QuadraticProblem(oracle.construct_Q(n, d, om), None, r, d, precond="jacobi"),
+                                   oracle.ROptParameters(), hess_recurrence="pipelined")
+    Xo = oo.optimize(X0)
+    assert rp.tcg_iterations == oo.result.tcg_iters and rp.rtr_iterations == oo.result.outer_iters
+    assert relerr(Xp, Xo) < 1e-7
+    assert abs(rp.fOpt - oo.result.fOpt) <= 1e-9 * abs(oo.result.fOpt)
+    # at most one extra H application (w0) per tCG run (none when the run ends on the trust-region boundary)
+    assert rd.tcg_iterations <= rp.tcg_iterations <= rd.tcg_iterations + rp.rtr_iterations
+    assert relerr(Xp, Xd) < 1e-6 and abs(rp.fOpt - rd.fOpt) <= 1e-9 * abs(rd.fOpt)
