@@ -1220,6 +1220,14 @@ int dpgo_problem_eval_terms_device(dpgo_problem_t p, const double* X_dev, double
   return DPGO_OK;
 }
 
+#ifdef DPGO_TIMELINE
+int dpgo_debug_timeline(long long* out /* [2][16] */) {
+  HIPC(hipDeviceSynchronize());
+  HIPC(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_timeline), sizeof(long long) * 32));
+  return DPGO_OK;
+}
+#endif
+
 int dpgo_bench_spmm(dpgo_problem_t p, int reps, int warmup, double* avg_ms) {
   CHK(check_ready(p));
   if (reps <= 0 || !avg_ms) return fail(DPGO_ERR_INVALID, "bad arguments");

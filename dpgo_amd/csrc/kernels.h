@@ -142,6 +142,22 @@ __device__ __forceinline__ TileIter tile_iter(int ntiles) {
 #ifndef DPGO_LB_UPDATE
 #define DPGO_LB_UPDATE 1
 #endif
+// Optional in-kernel timeline (diagnostic builds only, -DDPGO_TIMELINE): workgroup 0 / lane 0 stamps the 100 MHz
+// wall clock at phase boundaries of the two tCG kernels into a global array read back by dpgo_debug_timeline.
+#ifdef DPGO_TIMELINE
+__device__ long long g_timeline[2][16];
+#define DPGO_TL_DECL long long tl_[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define DPGO_STAMP(K, I) tl_[I] = wall_clock64()
+#define DPGO_COMMIT(K)                                     \
+  do {                                                     \
+    if (blockIdx.x == 0 && threadIdx.x == 0)               \
+      for (int q_ = 0; q_ < 8; ++q_) g_timeline[K][q_] = tl_[q_]; \
+  } while (0)
+#else
+#define DPGO_TL_DECL do { } while (0)
+#define DPGO_STAMP(K, I) do { } while (0)
+#define DPGO_COMMIT(K) do { } while (0)
+#endif
 #ifndef DPGO_WAVE_SYNC
 #define DPGO_WAVE_SYNC 1
 #endif
@@ -654,7 +670,7 @@ __global__ __launch_bounds__(kBlock, DPGO_LB_HESS) void k_tcg_hess(BsrDev Q, con
     }
   } else {
     const double norm_r = sqrt(r_r);
-    const double pw = pow(st.norm_r0, st.theta);
+    const double pw = (st.theta == 1.0) ? st.norm_r0 : pow(st.norm_r0, st.theta);  // theta = 1 (reference default)
     if (st.tcg_j >= st.min_inner && norm_r <= st.norm_r0 * (pw < st.kappa ? pw : st.kappa)) {
       st.tcg_status = (st.kappa < pw) ? TCG_LCON : TCG_SCON;
       st.tcg_done = 1;
@@ -861,7 +877,7 @@ __device__ __forceinline__ bool tcg_hess_prologue(DevState& st, const double* __
     return true;
   }
   const double norm_r = sqrt(r_r);
-  const double pw = pow(st.norm_r0, st.theta);
+  const double pw = (st.theta == 1.0) ? st.norm_r0 : pow(st.norm_r0, st.theta);  // theta = 1 (reference default)
   if (st.tcg_j >= st.min_inner && norm_r <= st.norm_r0 * (pw < st.kappa ? pw : st.kappa)) {
     st.tcg_status = (st.kappa < pw) ? TCG_LCON : TCG_SCON;
     st.tcg_done = 1;
@@ -982,6 +998,8 @@ __global__ __launch_bounds__(kBlock) void k_tcg_hess_span(BsrDev Q, const double
   // previous kernel's partial sums (small blocks only: the registers would cost the big-block kernel an
   // occupancy step), then the first tile.  A small-block launch is a chain of dependent memory round trips
   // (rocprof: 9.4 us for 2500 poses); this takes two of them off the chain.
+  DPGO_TL_DECL;
+  DPGO_STAMP(0, 0);
   DevState st;
   load_state(st, sin);
   [[maybe_unused]] PartialRaw<2> praw;
@@ -990,6 +1008,7 @@ __global__ __launch_bounds__(kBlock) void k_tcg_hess_span(BsrDev Q, const double
   bool have = tile < ti_.last;
   if (have) prefetch(tile);
 
+  DPGO_STAMP(0, 1);
   // ---- scalar prologue
   if (st.rtr_stop || st.tcg_done) {
     if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -1005,6 +1024,7 @@ __global__ __launch_bounds__(kBlock) void k_tcg_hess_span(BsrDev Q, const double
     publish_progress(hflag, gen, st);
   }
   if (!go) return;
+  DPGO_STAMP(0, 2);
 
   double part[1] = {0.0};
   while (have) {
@@ -1016,9 +1036,11 @@ __global__ __launch_bounds__(kBlock) void k_tcg_hess_span(BsrDev Q, const double
         reinterpret_cast<dbl2*>(vs)[pc] = zv[it];
       }
     }
+    DPGO_STAMP(0, 3);
     double h[R];
     spmm_col_pre<D, R, SPLIT>(ri, Q.colidx, Q.vals, z, L.s, L.c, h);
     wave_sync();
+    DPGO_STAMP(0, 4);
     if (ok) {
       if (L.c < D) {
         const double* vt = vs + L.g * GEO::T;
@@ -1066,11 +1088,14 @@ __global__ __launch_bounds__(kBlock) void k_tcg_hess_span(BsrDev Q, const double
       }
     }
     wave_sync();
+    DPGO_STAMP(0, 5);
     tile += ti_.step;
     have = tile < ti_.last;
     if (have) prefetch(tile);
   }
   store_partials<1>(part, pout, red);
+  DPGO_STAMP(0, 6);
+  DPGO_COMMIT(0);
 }
 
 template <int D, int R>
@@ -1133,6 +1158,8 @@ __global__ __launch_bounds__(kBlock) void k_tcg_update_span(const double* __rest
       for (int k = 0; k < GEO::B; ++k) drow[k] = dinv[(size_t)i * GEO::BB + L.c * GEO::B + k];
     }
   };
+  DPGO_TL_DECL;
+  DPGO_STAMP(1, 0);
   // state record and partial sums are requested before the first tile (see k_tcg_hess_span)
   DevState st;
   load_state(st, sin);
@@ -1156,6 +1183,7 @@ __global__ __launch_bounds__(kBlock) void k_tcg_update_span(const double* __rest
     publish_progress(hflag, gen, st);
   }
 
+  DPGO_STAMP(1, 2);
   double part[2] = {0.0, 0.0};
   while (have) {
     const size_t base = (size_t)p0 * GEO::T;
@@ -1228,11 +1256,14 @@ __global__ __launch_bounds__(kBlock) void k_tcg_update_span(const double* __rest
       }
       wave_sync();
     }
+    DPGO_STAMP(1, 5);
     tile += ti_.step;
     have = tile < ti_.last;
     if (have) prefetch(tile);
   }
   if (mode != 1) store_partials<2>(part, pout, red);
+  DPGO_STAMP(1, 6);
+  DPGO_COMMIT(1);
 }
 
 // ================================================================ pipelined tCG step (small, latency-bound blocks)
@@ -1363,7 +1394,7 @@ __global__ __launch_bounds__(kBlock) void k_tcg_pipe(BsrDev Q, const double* __r
       st.d_Hd = pr[2];  // delta_0 = -z_0: <delta,H delta> = <z,w>
     } else {
       const double norm_r = sqrt(pr[0]);
-      const double pw = pow(st.norm_r0, st.theta);
+      const double pw = (st.theta == 1.0) ? st.norm_r0 : pow(st.norm_r0, st.theta);  // theta = 1 (reference default)
       if (st.tcg_j >= st.min_inner && norm_r <= st.norm_r0 * (pw < st.kappa ? pw : st.kappa)) {
         st.tcg_status = (st.kappa < pw) ? TCG_LCON : TCG_SCON;
         st.tcg_done = 1;
