@@ -84,9 +84,10 @@ def hess_bytes(n, nnzb, d, r):
 
 
 def cpu_baseline(meas_p, n, X_state, r, budget_s):
-    """CPU oracle ("port": NumPy/SciPy restatement of the same algorithm, 1 thread) timed on the SAME step the
-    GPU is timed on: one RBCD iteration (RTR 3 x <=50 tCG, block-Jacobi, H-direction recurrence) from the
-    settled iterate.  If one full step does not fit the budget the tCG cap is lowered and the time scaled."""
+    """CPU restatement ("port") timed on the SAME step the GPU is timed on: one RBCD iteration (RTR 3 x <=50 tCG,
+    block-Jacobi, H-direction recurrence) from the settled iterate, one thread like the reference (ENABLE_OPENMP
+    OFF).  Preferred: the plain-C oracle (oracle/dpgo_oracle_c.c, gcc -O3 -march=x86-64-v3); fallback: the NumPy/SciPy
+    oracle.  If one full step does not fit the budget the tCG cap is lowered and the time scaled."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import dpgo_oracle as O
     d = meas_p.d
@@ -94,34 +95,54 @@ def cpu_baseline(meas_p, n, X_state, r, budget_s):
                         meas_p.p2.astype(np.int64), meas_p.R, meas_p.t, meas_p.kappa, meas_p.tau, meas_p.weight,
                         meas_p.fixedWeight)
     Q = O.construct_Q(n, d, om)
-    prob = O.QuadraticProblem(Q, None, r, d, precond="jacobi")
     X = np.ascontiguousarray(X_state)
-    EG = prob.euc_grad(X)
-    S = prob.sym_ytg(X, EG)
-    g = O.tangent_project(X, EG, d)
-    t0 = time.perf_counter()
-    reps = 0
-    while reps < 2 or (time.perf_counter() - t0 < 1.0 and reps < 50):
-        prob.rie_hess(X, S, g)
-        prob.precondition(X, g)
-        reps += 1
-    per_tcg = (time.perf_counter() - t0) / reps
-    max_inner = 50
-    inner = max_inner if 3 * max_inner * per_tcg * 1.2 <= budget_s else max(2, int(budget_s / 3 / per_tcg / 1.2))
-    # same tCG arithmetic as the device runs for a block of this size (pipelined scheme for small blocks)
+    # same tCG arithmetic as the device runs for a block of this size (pipelined scheme only when opted in)
     mode = "pipelined" if (os.environ.get("DPGO_PIPE", "0") not in ("", "0") and n < 40000
-                                                and ((d + 1) * r) % 2 == 0) else True
-    opt = O.QuadraticOptimizer(prob, O.ROptParameters(RTR_tCG_iterations=inner), hess_recurrence=mode)
-    t0 = time.perf_counter()
-    opt.optimize(X)
-    el = time.perf_counter() - t0
+                           and ((d + 1) * r) % 2 == 0) else True
+    max_inner = 50
+    CO = None
+    if mode is True:
+        try:
+            import c_oracle as CO
+            CO.load()
+        except Exception as exc:  # noqa: BLE001 -- no gcc / no prebuilt library: fall back to NumPy
+            sys.stderr.write("bench.py: C oracle unavailable (%r); timing the NumPy oracle\n" % (exc,))
+            CO = None
+    if CO is not None:
+        t0 = time.perf_counter()
+        CO.spmm(Q, X, reps=2)
+        per_tcg = 1.6 * (time.perf_counter() - t0) / 2  # one tCG iteration ~ one SpMM + O(n) passes
+        inner = max_inner if 3 * max_inner * per_tcg * 1.2 <= budget_s else max(2, int(budget_s / 3 / per_tcg / 1.2))
+        t0 = time.perf_counter()
+        _, res = CO.optimize(Q, None, X, RTR_tCG_iterations=inner, hess_recurrence=True)
+        el = time.perf_counter() - t0
+        iters, what = res.tcg_iterations, "plain-C oracle (gcc -O3 -march=x86-64-v3, single thread)"
+    else:
+        prob = O.QuadraticProblem(Q, None, r, d, precond="jacobi")
+        EG = prob.euc_grad(X)
+        S = prob.sym_ytg(X, EG)
+        g = O.tangent_project(X, EG, d)
+        t0 = time.perf_counter()
+        reps = 0
+        while reps < 2 or (time.perf_counter() - t0 < 1.0 and reps < 50):
+            prob.rie_hess(X, S, g)
+            prob.precondition(X, g)
+            reps += 1
+        per_tcg = (time.perf_counter() - t0) / reps
+        inner = max_inner if 3 * max_inner * per_tcg * 1.2 <= budget_s else max(2, int(budget_s / 3 / per_tcg / 1.2))
+        opt = O.QuadraticOptimizer(prob, O.ROptParameters(RTR_tCG_iterations=inner), hess_recurrence=mode)
+        t0 = time.perf_counter()
+        opt.optimize(X)
+        el = time.perf_counter() - t0
+        iters, what = opt.result.tcg_iters, "NumPy/SciPy oracle (single thread)"
     scale = max_inner / inner
     return dict(value=1.0 / (el * scale), unit="it/s", cores=1, kind="port",
                 sample="1 RBCD iteration from the same settled iterate, %d tCG Hessian-vector products in %.1f s%s; "
-                       "NumPy/SciPy oracle (single thread), same algorithm as the device path" % (
-                           opt.result.tcg_iters, el,
-                           "" if inner == max_inner else " (tCG capped at %d of 50, time scaled x%.2f)" % (inner, scale)),
-                tcg_iterations=opt.result.tcg_iters, seconds=el)
+                       "%s, same algorithm as the device path" % (
+                           iters, el,
+                           "" if inner == max_inner else " (tCG capped at %d of 50, time scaled x%.2f)" % (inner, scale),
+                           what),
+                tcg_iterations=iters, seconds=el)
 
 
 def main():
