@@ -110,13 +110,16 @@ def cpu_baseline(meas_p, n, X_state, r, budget_s):
             CO = None
     if CO is not None:
         t0 = time.perf_counter()
-        CO.spmm(Q, X, reps=2)
-        per_tcg = 1.6 * (time.perf_counter() - t0) / 2  # one tCG iteration ~ one SpMM + O(n) passes
+        CO.spmm(Q, X, reps=3)
+        spmm_s = (time.perf_counter() - t0) / 3
+        per_tcg = 1.6 * spmm_s  # one tCG iteration ~ one SpMM + O(n) passes
         inner = max_inner if 3 * max_inner * per_tcg * 1.2 <= budget_s else max(2, int(budget_s / 3 / per_tcg / 1.2))
         t0 = time.perf_counter()
         _, res = CO.optimize(Q, None, X, RTR_tCG_iterations=inner, hess_recurrence=True)
         el = time.perf_counter() - t0
         iters, what = res.tcg_iterations, "plain-C oracle (gcc -O3 -march=x86-64-v3, single thread)"
+        extra = dict(spmm_ms_1core=1e3 * spmm_s,
+                     spmm_GBs_1core=spmm_bytes(n, len(Q.colidx), d, r) / spmm_s / 1e9, host_cores=os.cpu_count())
     else:
         prob = O.QuadraticProblem(Q, None, r, d, precond="jacobi")
         EG = prob.euc_grad(X)
@@ -135,6 +138,7 @@ def cpu_baseline(meas_p, n, X_state, r, budget_s):
         opt.optimize(X)
         el = time.perf_counter() - t0
         iters, what = opt.result.tcg_iters, "NumPy/SciPy oracle (single thread)"
+        extra = dict(host_cores=os.cpu_count())
     scale = max_inner / inner
     return dict(value=1.0 / (el * scale), unit="it/s", cores=1, kind="port",
                 sample="1 RBCD iteration from the same settled iterate, %d tCG Hessian-vector products in %.1f s%s; "
@@ -142,7 +146,7 @@ def cpu_baseline(meas_p, n, X_state, r, budget_s):
                            iters, el,
                            "" if inner == max_inner else " (tCG capped at %d of 50, time scaled x%.2f)" % (inner, scale),
                            what),
-                tcg_iterations=iters, seconds=el)
+                tcg_iterations=iters, seconds=el, **extra)
 
 
 def main():
