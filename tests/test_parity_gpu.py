@@ -769,3 +769,34 @@ def test_pipelined_tcg_option_matches_oracle(oracle, name, monkeypatch):
     # at most one extra H application (w0) per tCG run (none when the run ends on the trust-region boundary)
     assert rd.tcg_iterations <= rp.tcg_iterations <= rd.tcg_iterations + rp.rtr_iterations
     assert relerr(Xp, Xd) < 1e-6 and abs(rp.fOpt - rd.fOpt) <= 1e-9 * abs(rd.fOpt)
+
+
+def test_example_scripts_run_end_to_end(tmp_path):
+    """examples/ (counterparts of the reference's MultiRobotExample / SingleRobotExample): the demo schedule
+    converges below the reference's stop threshold (gradnorm < 0.1, examples/MultiRobotExample.cpp:227-229) to the
+    known optimum and the rounded trajectories are written in the PGOLogger CSV format."""
+    import subprocess
+    import sys
+    import dpgo_amd
+    root = os.path.dirname(DATA)
+    out_dir = str(tmp_path / "traj")
+    p = subprocess.run([sys.executable, os.path.join(root, "examples", "multi_robot_example.py"), "5",
+                        os.path.join(DATA, "smallGrid3D.g2o"), "--out-dir", out_dir], capture_output=True, text=True,
+                       stdin=subprocess.DEVNULL, timeout=600)
+    assert p.returncode == 0, p.stdout + p.stderr
+    iters = [ln for ln in p.stdout.splitlines() if ln.startswith("Iter = ")]
+    assert iters and len(iters) < 1000
+    last = dict(kv.split(" = ") for kv in iters[-1].split(" | "))
+    assert float(last["gradnorm"]) < 0.1 and abs(float(last["cost"]) - 1025.4) < 0.05
+    T0 = dpgo_amd.load_trajectory(os.path.join(out_dir, "robot0.csv"))
+    assert T0.shape == (3, 4 * 25) and np.abs(T0[:, :4] - np.eye(3, 4)).max() < 1e-9  # anchor = robot 0, pose 0
+    for a in range(1, 5):
+        Ta = dpgo_amd.load_trajectory(os.path.join(out_dir, "robot%d.csv" % a))
+        R = Ta[:, :3]
+        assert np.abs(R.T @ R - np.eye(3)).max() < 1e-9 and abs(np.linalg.det(R) - 1) < 1e-9
+    single = str(tmp_path / "single.csv")
+    p = subprocess.run([sys.executable, os.path.join(root, "examples", "single_robot_example.py"),
+                        os.path.join(DATA, "smallGrid3D.g2o"), "--out", single], capture_output=True, text=True,
+                       stdin=subprocess.DEVNULL, timeout=600)
+    assert p.returncode == 0, p.stdout + p.stderr
+    assert "wrote" in p.stdout and dpgo_amd.load_trajectory(single).shape == (3, 4 * 125)
