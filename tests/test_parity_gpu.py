@@ -800,3 +800,72 @@ def test_example_scripts_run_end_to_end(tmp_path):
                        stdin=subprocess.DEVNULL, timeout=600)
     assert p.returncode == 0, p.stdout + p.stderr
     assert "wrote" in p.stdout and dpgo_amd.load_trajectory(single).shape == (3, 4 * 125)
+
+
+def test_distributed_gnc_kitti_four_agents(oracle):
+    """BASELINE configs[4] itself: kitti_00 (2-D, EDGE_SE2) cut into 4 agents, 25 injected outlier loop closures,
+    GNC-TLS with barc = 5.  r = 3 (tile size 9: the non-span kernels with a coupling term); a coarse mu schedule
+    (x8 per update) keeps the CPU oracle at seconds.  Same classification history as the oracle, every injected
+    outlier rejected, no original loop closure rejected, weights within 1e-6, final cost within 1e-6 relative."""
+    import dpgo_amd
+    from dpgo_amd.agent import DeviceAgent, ExchangePlan, RBCDCluster, build_pose_graphs
+    from dpgo_amd.robust import DistributedGNC, RobustCostParameters
+    r, robots, k, sweeps = 3, 4, 25, 2
+    om, n = oracle.read_g2o(os.path.join(DATA, "kitti_00.g2o"))
+
+    def with_outliers():
+        rng = np.random.default_rng(11)
+        taken = set(zip(om.p1.tolist(), om.p2.tolist()))
+        p1, p2 = [], []
+        while len(p1) < k:
+            a = int(rng.integers(0, n - 600))
+            b = int(a + rng.integers(300, 600))
+            if (a, b) not in taken:
+                taken.add((a, b))
+                p1.append(a)
+                p2.append(b)
+        th = rng.uniform(-np.pi, np.pi, k)
+        Rk = np.stack([np.array([[np.cos(a), -np.sin(a)], [np.sin(a), np.cos(a)]]) for a in th])
+        lc = np.nonzero(~om.fixed)[0]
+        z = np.zeros(k, dtype=np.int64)
+        out = oracle.Measurements(2, z, np.array(p1), z.copy(), np.array(p2), Rk, rng.uniform(-5, 5, (k, 2)),
+                                  np.full(k, np.median(om.kappa[lc])), np.full(k, np.median(om.tau[lc])), np.ones(k),
+                                  np.zeros(k, dtype=bool))
+        return oracle.Measurements.concat([om, out])
+
+    ref_meas = with_outliers()
+    X0 = oracle.lift(oracle.chordal_initialization(om, n), r)
+    Xref, info_o = oracle.multi_agent_gnc(ref_meas, n, robots, r, X0, inner_sweeps=sweeps, barc=5.0, mu_step=8.0,
+                                          max_updates=12, hess_recurrence=device_tcg_mode(n // robots, 2, r))
+    assert info_o["history"][-1]["undecided"] == 0
+    ranges, graphs = build_pose_graphs(to_product_measurements(with_outliers()), n, robots, r)
+    plan = ExchangePlan(graphs)
+    agents = {a: DeviceAgent(graphs, plan, a, X0[ranges[a][0]:ranges[a][1]], dpgo_amd.ROptParameters())
+              for a in range(robots)}
+    gnc = DistributedGNC(RBCDCluster(plan, agents),
+                         RobustCostParameters("GNC_TLS", GNCMaxNumIters=12, GNCBarc=5.0, GNCMuStep=8.0),
+                         inner_sweeps=sweeps)
+    info = gnc.run()
+    assert info["updates"] == info_o["updates"]
+    assert abs(info["muInit"] - info_o["muInit"]) <= 1e-7 * info_o["muInit"]
+    for h, ho in zip(info["history"], info_o["history"]):
+        assert (h["inliers"], h["outliers"], h["undecided"]) == (ho["inliers"], ho["outliers"], ho["undecided"])
+    assert abs(info["cost"] - info_o["cost"]) <= 1e-6 * info_o["cost"]
+    assert np.all(ref_meas.weight[-k:] < 1e-8) and np.all(ref_meas.weight[:om.m] > 1 - 1e-8)
+    # device weights: all injected outliers (the last k global edges) end at 0 on whichever agent(s) hold them
+    per = n // robots
+    rob = np.minimum(np.arange(n) // per, robots - 1)
+    loc = np.arange(n) - rob * per
+    outlier_keys = {(int(rob[a]), int(loc[a]), int(rob[b]), int(loc[b]))
+                    for a, b in zip(ref_meas.p1[-k:], ref_meas.p2[-k:])}
+    seen = set()
+    for a, (idx, w) in gnc.weights().items():
+        m = graphs[a].measurements()
+        for pos, wv in zip(idx, w):
+            key = (int(m.r1[pos]), int(m.p1[pos]), int(m.r2[pos]), int(m.p2[pos]))
+            if key in outlier_keys:
+                seen.add(key)
+                assert wv < 1e-8
+            elif not m.fixedWeight[pos]:
+                assert wv > 1 - 1e-6
+    assert seen == outlier_keys
