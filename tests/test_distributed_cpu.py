@@ -51,7 +51,7 @@ class HostAgent:
         return xqx, xg, p.rie_grad_norm(X) ** 2
 
 
-def _worker(rank, world, port, sweeps, out_dir):
+def _worker(rank, world, port, sweeps, out_dir, apr=1):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -64,41 +64,46 @@ def _worker(rank, world, port, sweeps, out_dir):
         om, n, Ttrue = O.synthetic_grid(6, 5, 4, seed=3)
         r, d = 5, 3
         X0 = O.lift(O.perturbed_truth(Ttrue, seed=4), r)
-        ranges, graphs = build_pose_graphs(to_product_measurements(om), n, world, r)
-        oranges, per = O.partition_contiguous(om, n, world)
+        num_agents = world * apr
+        ranges, graphs = build_pose_graphs(to_product_measurements(om), n, num_agents, r)
+        oranges, per = O.partition_contiguous(om, n, num_agents)
         assert ranges == oranges
         plan = ExchangePlan(graphs)
-        assert plan.num_colours == 2 and plan.adj == [[1], [0]]
-        s, e = ranges[rank]
-        agent = HostAgent(O, plan, rank, per[rank], X0[s:e], r, d)
-        cluster = RBCDCluster(plan, {rank: agent}, rank, world)
+        assert plan.num_colours == 2
+        if apr == 1:
+            assert plan.adj == [[1], [0]]
+        mine = list(range(rank * apr, (rank + 1) * apr))  # consecutive agents share a rank (RBCDCluster.owner)
+        local = {a: HostAgent(O, plan, a, per[a], X0[ranges[a][0]:ranges[a][1]], r, d) for a in mine}
+        cluster = RBCDCluster(plan, local, rank, world, agents_per_rank=apr)
+        assert all(cluster.owner(a) == a // apr for a in range(num_agents))
         f0, g0 = cluster.central_cost_and_gradnorm()
         trace = [(2 * f0, g0)]
         for _ in range(sweeps):
             cluster.sweep()
             f, g = cluster.central_cost_and_gradnorm()
             trace.append((2 * f, g))
-        np.savez(os.path.join(out_dir, "rank%d.npz" % rank), X=agent.X.numpy(), trace=np.array(trace), s=s, e=e)
+        s, e = ranges[mine[0]][0], ranges[mine[-1]][1]
+        X = np.concatenate([local[a].X.numpy() for a in mine], axis=0)
+        np.savez(os.path.join(out_dir, "rank%d.npz" % rank), X=X, trace=np.array(trace), s=s, e=e)
     finally:
         dist.destroy_process_group()
 
 
-def _from_conftest():
-    pass
-
-
-def test_two_rank_gloo_rbcd_matches_single_process_oracle(oracle, tmp_path):
+@pytest.mark.parametrize("apr", [1, 2])
+def test_two_rank_gloo_rbcd_matches_single_process_oracle(oracle, tmp_path, apr):
+    """apr = agents per rank: 1 (one agent per process) and 2 (bench.py's layout for N > 1 GPUs: two consecutive
+    agents of different colours per process; local pairs exchange by copies, remote pairs by grouped p2p)."""
     import torch.multiprocessing as mp
     O = oracle
     sweeps = 3
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
-    mp.spawn(_worker, args=(2, port, sweeps, str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, port, sweeps, str(tmp_path), apr), nprocs=2, join=True)
     om, n, Ttrue = O.synthetic_grid(6, 5, 4, seed=3)
     X0 = O.lift(O.perturbed_truth(Ttrue, seed=4), 5)
     central = O.QuadraticProblem(O.construct_Q(n, 3, om), None, 5, 3)
-    Xref, costs, gns = O.rbcd_coloured(om, n, 2, 5, X0, sweeps)
+    Xref, costs, gns = O.rbcd_coloured(om, n, 2 * apr, 5, X0, sweeps)
     X = np.zeros_like(Xref)
     traces = []
     for rank in range(2):
