@@ -195,8 +195,42 @@ __device__ __forceinline__ double wave_allreduce(double v) {
   return v;
 }
 
+// Wave sum that lands in lane 63, built from DPP row shifts / row broadcasts (VALU lane crossing, no LDS
+// round trips: six dependent steps of a few cycles each instead of six ds_bpermute round trips per 32-bit
+// half).  Fixed summation tree, hence deterministic.  Lanes other than 63 hold partial sums.
+#ifndef DPGO_DPP_REDUCE
+#define DPGO_DPP_REDUCE 1
+#endif
+template <int CTRL, int ROW_MASK, int BANK_MASK>
+__device__ __forceinline__ double dpp_shifted(double v) {
+  // lanes without a source (or masked off) receive 0.0
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, BANK_MASK, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, BANK_MASK, false);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_reduce_lane63(double v) {
+  double s = v;
+  s += dpp_shifted<0x111, 0xf, 0xf>(v);  // row_shr:1
+  s += dpp_shifted<0x112, 0xf, 0xf>(v);  // row_shr:2
+  s += dpp_shifted<0x113, 0xf, 0xf>(v);  // row_shr:3   -> s[i] = v[i-3..i] within a row of 16
+  s += dpp_shifted<0x114, 0xf, 0xe>(s);  // row_shr:4, banks 1..3
+  s += dpp_shifted<0x118, 0xf, 0xc>(s);  // row_shr:8, banks 2..3 -> lane 15 of each row holds the row sum
+  s += dpp_shifted<0x142, 0xa, 0xf>(s);  // row_bcast:15 into rows 1 and 3
+  s += dpp_shifted<0x143, 0xc, 0xf>(s);  // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave sum
+  return s;
+}
+
 template <int K>
 __device__ __forceinline__ void block_allreduce(double (&v)[K], double* red /* >= kWaves*K */) {
+#if DPGO_DPP_REDUCE
+#pragma unroll
+  for (int k = 0; k < K; ++k) v[k] = wave_reduce_lane63(v[k]);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 63) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) red[(threadIdx.x >> 6) * K + k] = v[k];
+  }
+#else
 #pragma unroll
   for (int k = 0; k < K; ++k) v[k] = wave_allreduce(v[k]);
   __syncthreads();
@@ -204,6 +238,7 @@ __device__ __forceinline__ void block_allreduce(double (&v)[K], double* red /* >
 #pragma unroll
     for (int k = 0; k < K; ++k) red[(threadIdx.x >> 6) * K + k] = v[k];
   }
+#endif
   __syncthreads();
 #pragma unroll
   for (int k = 0; k < K; ++k) {
