@@ -41,6 +41,8 @@ def parse_args():
                     help="untimed RBCD iterations from the initial guess before the benchmark state is frozen")
     ap.add_argument("--workload", default="grid100k")
     ap.add_argument("--rank", type=int, default=5, help="relaxation rank r")
+    ap.add_argument("--precond", default="jacobi", choices=["jacobi", "multilevel"],
+                    help="tCG preconditioner: block-Jacobi (default) or the two-level multigrid cycle (blocks < 40k poses)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget-s", type=float, default=25.0)
     ap.add_argument("--spmm-reps", type=int, default=200)
@@ -83,7 +85,7 @@ def hess_bytes(n, nnzb, d, r):
     return nnzb * (8 * b * b + 4) + 4 * (n + 1) + v + (v + 8 * d * d * n) + 2 * v + 2 * v
 
 
-def cpu_baseline(meas_p, n, X_state, r, budget_s):
+def cpu_baseline(meas_p, n, X_state, r, budget_s, precond="jacobi"):
     """CPU restatement ("port") timed on the SAME step the GPU is timed on: one RBCD iteration (RTR 3 x <=50 tCG,
     block-Jacobi, H-direction recurrence) from the settled iterate, one thread like the reference (ENABLE_OPENMP
     OFF).  Preferred: the plain-C oracle (oracle/dpgo_oracle_c.c, gcc -O3 -march=x86-64-v3); fallback: the NumPy/SciPy
@@ -101,7 +103,7 @@ def cpu_baseline(meas_p, n, X_state, r, budget_s):
                            and ((d + 1) * r) % 2 == 0) else True
     max_inner = 50
     CO = None
-    if mode is True:
+    if mode is True and precond == "jacobi":
         try:
             import c_oracle as CO
             CO.load()
@@ -121,7 +123,7 @@ def cpu_baseline(meas_p, n, X_state, r, budget_s):
         extra = dict(spmm_ms_1core=1e3 * spmm_s,
                      spmm_GBs_1core=spmm_bytes(n, len(Q.colidx), d, r) / spmm_s / 1e9, host_cores=os.cpu_count())
     else:
-        prob = O.QuadraticProblem(Q, None, r, d, precond="jacobi")
+        prob = O.QuadraticProblem(Q, None, r, d, precond="jacobi" if precond == "jacobi" else "amg2")
         EG = prob.euc_grad(X)
         S = prob.sym_ytg(X, EG)
         g = O.tangent_project(X, EG, d)
@@ -196,7 +198,7 @@ def main():
     apg = args.agents_per_gpu if args.agents_per_gpu > 0 else (1 if world == 1 else 2)
     num_agents = world * apg
     ranges, graphs = build_pose_graphs(meas, n, num_agents, r)
-    params = dpgo_amd.ROptParameters()  # reference defaults + block-Jacobi
+    params = dpgo_amd.ROptParameters(precond=args.precond)  # reference defaults + block-Jacobi (or multilevel)
     plan = ExchangePlan(graphs)
     my_ids = list(range(rank * apg, (rank + 1) * apg))
     agents = {a: DeviceAgent(graphs, plan, a, X0[ranges[a][0]:ranges[a][1]], params, device=dev_index)
@@ -334,7 +336,7 @@ def main():
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         agent.restore()
-        cpu = cpu_baseline(meas, n, agent.X.cpu().numpy(), r, args.cpu_budget_s)
+        cpu = cpu_baseline(meas, n, agent.X.cpu().numpy(), r, args.cpu_budget_s, args.precond)
 
     if rank == 0:
         out = {
@@ -351,7 +353,8 @@ def main():
             "dtype": "f64",
             "data": "synthetic" if args.workload.startswith("grid") else "g2o dataset shipped in data/",
             "config": {"workload": desc, "agents": num_agents, "agents_per_gpu": apg, "r": r, "d": d,
-                       "local_solver": "RTR 3x<=50 tCG, Delta0=100, tol=1e-2 (reference defaults), block-Jacobi precond",
+                       "local_solver": "RTR 3x<=50 tCG, Delta0=100, tol=1e-2 (reference defaults), %s precond" % (
+                           "block-Jacobi" if args.precond == "jacobi" else "two-level multigrid"),
                        "schedule": "single agent" if num_agents == 1 else
                        "%d-colour parallel RBCD; 1 step = 1 sweep (every agent updates once); public-pose "
                        "exchange over %s" % (plan.num_colours, "device copies" if world == 1 else

@@ -116,6 +116,13 @@ struct dpgo_problem_s {
   // pipelined tCG (small blocks): w = H z, m = P w, q = P H delta, t = H q
   double *pw = nullptr, *pm = nullptr, *pm2 = nullptr, *pq = nullptr, *pt = nullptr;
   bool pipe = false;
+  // two-level (aggregation multigrid) preconditioner, optional (dpgo_problem_set_multilevel)
+  bool ml_ready = false;
+  int ml_k = 0, ml_nc = 0;
+  double ml_omega = 0.7, ml_shift = 1e-1;
+  Bsr ml_P, ml_Pt;            // rectangular n x nc / nc x n
+  double* ml_Aneg = nullptr;  // -(Q + shift I) on Q's pattern
+  double *ml_inv = nullptr, *ml_x1 = nullptr, *ml_res = nullptr, *ml_x = nullptr, *ml_rc = nullptr, *ml_xc = nullptr;
   double* partials = nullptr;  // 5 regions of kPartialCap*kNP
   DevState* dstate = nullptr;  // 2 slots
   DevState* hstate = nullptr;  // pinned
@@ -239,8 +246,14 @@ int push_state(dpgo_problem_s* p) {
 }
 
 // ---- kernel launch helpers (templated on D, R through DISPATCH) ----
-int launch_spmm(dpgo_problem_s* p, const Bsr& M, const double* V, const double* Gadd, double* OUT) {
-  DISPATCH(p->d, p->r, LAUNCH_SPLIT(p, k_spmm, p->grid_spmm(), M.dev(), V, Gadd, OUT, p->n));
+int launch_spmm(dpgo_problem_s* p, const Bsr& M, const double* V, const double* Gadd, double* OUT, int nrows = -1) {
+  const int rows = nrows >= 0 ? nrows : p->n;
+  int g = p->grid_spmm();
+  if (nrows >= 0) {  // rectangular operator with its own row count (restriction)
+    const int P = (64 / (p->b * p->split)) * kWaves;
+    g = std::max(1, std::min(kMaxGrid, (rows + P - 1) / P));
+  }
+  DISPATCH(p->d, p->r, LAUNCH_SPLIT(p, k_spmm, g, M.dev(), V, Gadd, OUT, rows));
   HIPC(hipGetLastError());
   return DPGO_OK;
 }
@@ -365,12 +378,48 @@ struct Counters {
 
 // One ROPTLIB SolversTR::Run outer iteration: tCG + retraction + rho test.  State stays on the
 // device; the host polls the tCG "done" flag every `poll` inner iterations.
+// One cycle of the two-level preconditioner: z = proj_X(M^-1 r) with r = p->rr, X = Xdev; the partial <z, r> goes
+// to slot 1 of partial region `pout` (NULL: not needed).  `gate`: state record for early exit (may be NULL).
+int launch_ml_cycle(dpgo_problem_s* p, const double* Xdev, const double* r, double* z, double* pout,
+                    const DevState* gate) {
+  if (!p->ml_ready) return fail(DPGO_ERR_STATE, "multilevel preconditioner not set (dpgo_problem_set_multilevel)");
+  const int g = p->grid();
+  Bsr Aneg = p->Q;  // same pattern, negated + shifted values
+  Aneg.vals = p->ml_Aneg;
+  const int N = p->ml_nc * p->b;
+  const int gd = std::max(1, std::min(kMaxGrid, (N + kWaves - 1) / kWaves));
+  DISPATCH(p->d, p->r, {
+    hipLaunchKernelGGL((k_ml_presmooth<D, R>), dim3(g), dim3(kBlock), 0, p->stream, r, p->dinv, p->ml_omega, p->ml_x1,
+                       gate, p->n);
+  });
+  HIPC(hipGetLastError());
+  CHK(launch_spmm(p, Aneg, p->ml_x1, r, p->ml_res));                      // res = r - A x1
+  CHK(launch_spmm(p, p->ml_Pt, p->ml_res, nullptr, p->ml_rc, p->ml_nc));  // rc = P^T res
+  DISPATCH(p->d, p->r, {
+    (void)D;
+    hipLaunchKernelGGL((k_ml_dense_apply<R>), dim3(gd), dim3(kBlock), 0, p->stream, p->ml_inv, p->ml_rc, p->ml_xc, gate,
+                       N);
+  });
+  HIPC(hipGetLastError());
+  CHK(launch_spmm(p, p->ml_P, p->ml_xc, p->ml_x1, p->ml_x));  // x = x1 + P xc
+  CHK(launch_spmm(p, Aneg, p->ml_x, r, p->ml_res));          // res = r - A x
+  DISPATCH(p->d, p->r, {
+    hipLaunchKernelGGL((k_ml_finish<D, R>), dim3(g), dim3(kBlock), 0, p->stream, Xdev, p->ml_x, p->ml_res, r, p->dinv,
+                       p->ml_omega, z, pout, gate, p->n);
+  });
+  HIPC(hipGetLastError());
+  return DPGO_OK;
+}
+
 int rtr_outer_iteration(dpgo_problem_s* p, const dpgo_ropt_params* prm, const double* dinv, Counters& cnt,
                         bool poll_at_end) {
   p->gen += 1;
+  const bool ml = prm->precond == DPGO_PRECOND_MULTILEVEL;
   CHK(launch_tcg_update(p, dinv, 1));
+  // multilevel: the update kernel's block-Jacobi z and its <z, r> partial are replaced by the cycle's
+  if (ml) CHK(launch_ml_cycle(p, p->x1, p->rr, p->z, p->pB(), p->dstate + p->cur));
   const int max_inner = prm->RTR_tCG_iterations;
-  const bool pipe = p->pipe && max_inner > 0;
+  const bool pipe = p->pipe && max_inner > 0 && !ml;
   // pipelined scheme: init launch (w0 = H z0, m0 = P w0), then ONE launch per iteration; `step` hides the scheme
   int pipe_launches = 0;
   if (pipe) CHK(launch_tcg_pipe(p, dinv, 1, /*in_is_B=*/true));  // k_tcg_update(first) wrote region B
@@ -382,7 +431,9 @@ int rtr_outer_iteration(dpgo_problem_s* p, const dpgo_ropt_params* prm, const do
       return launch_tcg_pipe(p, dinv, j == 0 ? 2 : 0, in_is_B);
     }
     CHK(launch_tcg_hess(p, j == 0 ? 1 : 0));
-    return launch_tcg_update(p, dinv, 0);
+    CHK(launch_tcg_update(p, dinv, 0));
+    if (ml) CHK(launch_ml_cycle(p, p->x1, p->rr, p->z, p->pB(), p->dstate + p->cur));
+    return DPGO_OK;
   };
   if (max_inner <= 0) CHK(launch_tcg_hess(p, 1));  // only finalises the tCG state (eta = 0)
   bool done = false;
@@ -403,7 +454,7 @@ int rtr_outer_iteration(dpgo_problem_s* p, const dpgo_ropt_params* prm, const do
   } else {
     // just-in-time feed: stay kAhead iterations ahead of the progress word the device publishes into
     // host-coherent memory; no synchronisation, no copy, at most kAhead wasted (early-exit) iterations
-    constexpr int kAhead = 4;
+    const int kAhead = ml ? 2 : 4;  // a multilevel iteration is 9 launches: waste fewer of them after tCG stops
     int enq = 0;
     const auto t_start = std::chrono::steady_clock::now();
     while (true) {
@@ -456,6 +507,11 @@ int run_optimize(dpgo_problem_s* p, const dpgo_ropt_params* prm, dpgo_ropt_resul
   const double* dinv = nullptr;
   if (prm->precond == DPGO_PRECOND_BLOCK_JACOBI) {
     CHK(build_dinv(p, prm->precond_shift));
+    dinv = p->dinv;
+  } else if (prm->precond == DPGO_PRECOND_MULTILEVEL) {
+    if (!p->ml_ready) return fail(DPGO_ERR_STATE, "multilevel preconditioner not set (dpgo_problem_set_multilevel)");
+    if (prm->method != DPGO_METHOD_RTR) return fail(DPGO_ERR_UNSUPPORTED, "multilevel preconditioner: RTR only");
+    CHK(build_dinv(p, p->ml_shift));  // the smoother's block-Jacobi factor
     dinv = p->dinv;
   } else if (prm->precond != DPGO_PRECOND_NONE) {
     return fail(DPGO_ERR_INVALID, "unknown preconditioner");
@@ -600,6 +656,7 @@ int rebuild_C_from_weights(dpgo_problem_s* p, const double* base, double sign, d
 int refresh_after_weights(dpgo_problem_s* p) {
   CHK(rebuild_Q_from_weights(p, p->q_base, 1.0, p->Q.vals));
   CHK(rebuild_C_from_weights(p, p->c_base, 1.0, p->C.vals));  // G itself is refreshed by the next update_G call
+  p->ml_ready = false;
   const double s = p->dinv_shift > 0 ? p->dinv_shift : 1e-1;
   p->dinv_shift = -1.0;  // clearQuadraticMatrix also drops the preconditioner (src/PoseGraph.cpp:352-355)
   return build_dinv(p, s);
@@ -758,6 +815,13 @@ int dpgo_problem_destroy(dpgo_problem_t p) {
   if (p->own_stream) (void)hipStreamSynchronize(p->own_stream);
   free_bsr(p->Q);
   free_bsr(p->C);
+  free_bsr(p->ml_P);
+  free_bsr(p->ml_Pt);
+  {
+    double* mlb[] = {p->ml_Aneg, p->ml_inv, p->ml_x1, p->ml_res, p->ml_x, p->ml_rc, p->ml_xc};
+    for (auto q : mlb)
+      if (q) (void)hipFree(q);
+  }
   free_edges(p);
   double* vecs[] = {p->x1, p->x2, p->g1, p->g2, p->eta, p->delta, p->Hd, p->rr, p->z, p->G, p->G0,
                     p->S1, p->S2, p->dinv, p->partials, p->pw, p->pm, p->pm2, p->pq, p->pt};
@@ -803,6 +867,7 @@ int dpgo_problem_set_Q_bsr(dpgo_problem_t p, int nnzb, const int32_t* rowptr, co
   CHK(validate_bsr(p->n, p->n, nnzb, rowptr, colidx, true));
   CHK(set_device(p));
   CHK(upload_bsr(p->Q, p->n, p->n, nnzb, p->b, rowptr, colidx, vals, p->stream));
+  p->ml_ready = false;  // the multilevel hierarchy belongs to the old values
   p->dinv_shift = -1.0;
   CHK(build_dinv(p, 1e-1));  // src/PoseGraph.cpp:603
   HIPC(hipStreamSynchronize(p->stream));
@@ -1039,8 +1104,67 @@ int dpgo_problem_update_Q_values(dpgo_problem_t p, const double* vals) {
                       p->stream));
   const double s = p->dinv_shift > 0 ? p->dinv_shift : 1e-1;
   p->dinv_shift = -1.0;  // PoseGraph::clearQuadraticMatrix also drops the preconditioner (src/PoseGraph.cpp:352-355)
+  p->ml_ready = false;
   CHK(build_dinv(p, s));
   HIPC(hipStreamSynchronize(p->stream));
+  return DPGO_OK;
+}
+
+int dpgo_problem_get_Q_values(dpgo_problem_t p, double* vals_host) {
+  CHK(check_ready(p));
+  if (!vals_host) return fail(DPGO_ERR_INVALID, "null vals");
+  HIPC(hipMemcpyAsync(vals_host, p->Q.vals, sizeof(double) * (size_t)p->Q.nnzb * p->b * p->b, hipMemcpyDeviceToHost,
+                      p->stream));
+  HIPC(hipStreamSynchronize(p->stream));
+  return DPGO_OK;
+}
+
+int dpgo_problem_set_multilevel(dpgo_problem_t p, int k, const double* P_blocks, const double* AcInv, double omega,
+                                double shift) {
+  CHK(check_ready(p));
+  if (k < 2 || !P_blocks || !AcInv || !(omega > 0.0) || !(shift >= 0.0))
+    return fail(DPGO_ERR_INVALID, "bad multilevel arguments");
+  const int n = p->n, b = p->b, nc = (n + k - 1) / k;
+  const size_t N = (size_t)nc * b;
+  // P: n x nc, one block per row;  P^T: nc x n, the aggregate's poses per row (blocks transposed)
+  std::vector<int32_t> prow(n + 1), pcol(n), trow(nc + 1), tcol(n);
+  std::vector<double> tvals((size_t)n * b * b);
+  for (int i = 0; i <= n; ++i) prow[i] = i;
+  for (int i = 0; i < n; ++i) {
+    pcol[i] = i / k;
+    tcol[i] = i;
+    for (int a = 0; a < b; ++a)
+      for (int c = 0; c < b; ++c) tvals[(size_t)i * b * b + a * b + c] = P_blocks[(size_t)i * b * b + c * b + a];
+  }
+  for (int a = 0; a <= nc; ++a) trow[a] = std::min(a * k, n);
+  CHK(upload_bsr(p->ml_P, n, nc, n, b, prow.data(), pcol.data(), P_blocks, p->stream));
+  CHK(upload_bsr(p->ml_Pt, nc, n, n, b, trow.data(), tcol.data(), tvals.data(), p->stream));
+  double** bufs[] = {&p->ml_Aneg, &p->ml_inv, &p->ml_x1, &p->ml_res, &p->ml_x, &p->ml_rc, &p->ml_xc};
+  for (auto q : bufs)
+    if (*q) {
+      (void)hipFree(*q);
+      *q = nullptr;
+    }
+  HIPC(hipMalloc(&p->ml_Aneg, sizeof(double) * (size_t)p->Q.nnzb * b * b));
+  HIPC(hipMalloc(&p->ml_inv, sizeof(double) * N * N));
+  HIPC(hipMalloc(&p->ml_x1, p->vec_bytes()));
+  HIPC(hipMalloc(&p->ml_res, p->vec_bytes()));
+  HIPC(hipMalloc(&p->ml_x, p->vec_bytes()));
+  HIPC(hipMalloc(&p->ml_rc, sizeof(double) * N * p->r));
+  HIPC(hipMalloc(&p->ml_xc, sizeof(double) * N * p->r));
+  HIPC(hipMemcpyAsync(p->ml_inv, AcInv, sizeof(double) * N * N, hipMemcpyHostToDevice, p->stream));
+  const int g = std::max(1, std::min(kMaxGrid, (n + kBlock - 1) / kBlock));
+  if (p->d == 2)
+    hipLaunchKernelGGL(k_ml_neg_shift<2>, dim3(g), dim3(kBlock), 0, p->stream, p->Q.dev(), shift, p->ml_Aneg, n);
+  else
+    hipLaunchKernelGGL(k_ml_neg_shift<3>, dim3(g), dim3(kBlock), 0, p->stream, p->Q.dev(), shift, p->ml_Aneg, n);
+  HIPC(hipGetLastError());
+  HIPC(hipStreamSynchronize(p->stream));
+  p->ml_k = k;
+  p->ml_nc = nc;
+  p->ml_omega = omega;
+  p->ml_shift = shift;
+  p->ml_ready = true;
   return DPGO_OK;
 }
 
@@ -1165,6 +1289,11 @@ int dpgo_problem_precondition(dpgo_problem_t p, int precond, double shift, const
   if (precond == DPGO_PRECOND_BLOCK_JACOBI) {
     CHK(build_dinv(p, shift));
     dinv = p->dinv;
+  } else if (precond == DPGO_PRECOND_MULTILEVEL) {
+    if (!p->ml_ready) return fail(DPGO_ERR_STATE, "multilevel preconditioner not set (dpgo_problem_set_multilevel)");
+    CHK(build_dinv(p, p->ml_shift));
+    CHK(launch_ml_cycle(p, p->x2, p->eta, p->g2, nullptr, nullptr));
+    return d2h(p, Z, p->g2);
   } else if (precond != DPGO_PRECOND_NONE) {
     return fail(DPGO_ERR_INVALID, "unknown preconditioner");
   }

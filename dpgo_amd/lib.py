@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get("DPGO_LIB") or os.path.join(_HERE, "libdpgo_hip.so")  
 
 OK, ERR_INVALID, ERR_HIP, ERR_UNSUPPORTED, ERR_STATE = 0, 1, 2, 3, 4
 METHOD_RTR, METHOD_RGD = 0, 1
-PRECOND_NONE, PRECOND_BLOCK_JACOBI = 0, 1
+PRECOND_NONE, PRECOND_BLOCK_JACOBI, PRECOND_MULTILEVEL = 0, 1, 2
 TCG_STATUS = ["NEGCURVTURE", "EXCREGION", "LCON", "SCON", "MAXITER"]
 
 
@@ -69,6 +69,8 @@ SIGNATURES = {
     "dpgo_problem_gnc_reweight": ([_P, _P, _D, _D, _D, _I, C.POINTER(C.c_int * 3), C.POINTER(_D)], _I),
     "dpgo_problem_set_edge_weights": ([_P, _P], _I),
     "dpgo_problem_get_edge_weights": ([_P, _P, _P], _I),
+    "dpgo_problem_get_Q_values": ([_P, _P], _I),
+    "dpgo_problem_set_multilevel": ([_P, _I, _P, _P, _D, _D], _I),
     "dpgo_problem_set_G": ([_P, _P], _I),
     "dpgo_problem_set_G_device": ([_P, _P], _I),
     "dpgo_problem_set_G_coupling": ([_P, _I, _I, _P, _P, _P, _P], _I),

@@ -38,7 +38,7 @@ class ROptParameters:
     RTR_tCG_iterations: int = 50
     RTR_initial_radius: float = 100.0
     # extensions
-    precond: str = "jacobi"  # "jacobi" (block-Jacobi of Q + shift I) | "none"
+    precond: str = "jacobi"  # "jacobi" (block-Jacobi of Q + shift I) | "multilevel" (two-level multigrid) | "none"
     precond_shift: float = 1e-1  # src/PoseGraph.cpp:603
     accept_tiny_decrease: bool = True
     tcg_poll_interval: int = 0  # 0 = just-in-time feed (default); k > 0 = poll every k tCG iterations
@@ -54,7 +54,8 @@ class ROptParameters:
         c.RTR_iterations = self.RTR_iterations
         c.RTR_tCG_iterations = self.RTR_tCG_iterations
         c.RTR_initial_radius = self.RTR_initial_radius
-        c.precond = {"jacobi": L.PRECOND_BLOCK_JACOBI, "none": L.PRECOND_NONE}[self.precond]
+        c.precond = {"jacobi": L.PRECOND_BLOCK_JACOBI, "none": L.PRECOND_NONE,
+                     "multilevel": L.PRECOND_MULTILEVEL}[self.precond]
         c.precond_shift = self.precond_shift
         c.accept_tiny_decrease = int(self.accept_tiny_decrease)
         c.tcg_poll_interval = self.tcg_poll_interval
@@ -366,7 +367,9 @@ class QuadraticProblem:
 
     def PreConditioner(self, X, inVec, precond: str = "jacobi", shift: float = 1e-1) -> np.ndarray:  # :56-69
         Xc, Vc, o = self._in(X), self._in(inVec, "inVec"), self._out()
-        pc = {"jacobi": L.PRECOND_BLOCK_JACOBI, "none": L.PRECOND_NONE}[precond]
+        pc = {"jacobi": L.PRECOND_BLOCK_JACOBI, "none": L.PRECOND_NONE, "multilevel": L.PRECOND_MULTILEVEL}[precond]
+        if precond == "multilevel":
+            self.ensureMultilevel(shift)
         L.check(self._lib.dpgo_problem_precondition(self._h, pc, shift, L.ptr(Xc), L.ptr(Vc), L.ptr(o)))
         return o
 
@@ -402,6 +405,22 @@ class QuadraticProblem:
         """constructG on the device from the neighbour tile buffer (src/PoseGraph.cpp:493-580)."""
         L.check(self._lib.dpgo_problem_update_G_from_neighbors_device(self._h, L.ptr(nbr_tiles_dev)))
         self._g_obj = None
+
+    # ---- optional two-level preconditioner (host setup once per Q, like PoseGraph::constructPreconditioner) ----
+    def ensureMultilevel(self, shift: float = 1e-1, k: int = 0, omega: float = 0.7) -> int:
+        """Build and upload the hierarchy for the current Q values if it is not there yet.  Returns k."""
+        self.refresh()
+        key = (self.pose_graph_.q_version, float(shift), int(k), float(omega))
+        if getattr(self, "_ml_key", None) != key:
+            from . import multilevel
+            rowptr, colidx, vals = self.pose_graph_.quadraticMatrix()
+            vals = np.empty_like(vals)  # the device's values (GNC re-weights them in place), pattern from the host
+            L.check(self._lib.dpgo_problem_get_Q_values(self._h, L.ptr(vals)))
+            kk, Pb, AcInv = multilevel.build(rowptr, colidx, vals, self.dimension(), shift, k)
+            L.check(self._lib.dpgo_problem_set_multilevel(self._h, kk, L.ptr(Pb), L.ptr(AcInv), float(omega),
+                                                          float(shift)))
+            self._ml_key, self._ml_k = key, kk
+        return self._ml_k
 
     # ---- GNC re-weighting on the device (PGOAgent::updateMeasurementWeights, src/PGOAgent.cpp:1104-1142) ----
     def setReweightableEdges(self, include_shared: bool = False) -> int:
@@ -439,11 +458,14 @@ class QuadraticProblem:
         L.check(self._lib.dpgo_problem_gnc_reweight_device(
             self._h, L.ptr(X_dev), L.ptr(nbr_tiles_dev) if nbr_tiles_dev is not None else None, float(mu),
             float(barc), float(w_tol), int(update), C.byref(counts), C.byref(mx)))
+        if update:
+            self._ml_key = None  # Q's values changed on the device: the multilevel hierarchy is stale
         return tuple(counts), mx.value
 
     def setEdgeWeights(self, w: np.ndarray) -> None:
         w = np.ascontiguousarray(w, dtype=np.float64)
         L.check(self._lib.dpgo_problem_set_edge_weights(self._h, L.ptr(w)))
+        self._ml_key = None
 
     def getEdgeWeights(self):
         """(weights, squared residuals of the last gncReweightDevice) of the registered edges."""
@@ -497,6 +519,8 @@ class QuadraticOptimizer:
         Yc = p._in(Y)
         out = p._out()
         cp, cr = self.params_.to_c(), L.RoptResultC()
+        if self.params_.precond == "multilevel":
+            p.ensureMultilevel(self.params_.precond_shift)
         L.check(p._lib.dpgo_optimize(p._h, C.byref(cp), L.ptr(Yc), L.ptr(out), C.byref(cr)))
         self.result_ = ROPTResult.from_c(cr)
         return out
@@ -505,6 +529,8 @@ class QuadraticOptimizer:
         """Device-resident flavour: X_dev (torch tensor / device address) is updated in place."""
         p = self.problem_
         cp, cr = self.params_.to_c(), L.RoptResultC()
+        if self.params_.precond == "multilevel":
+            p.ensureMultilevel(self.params_.precond_shift)
         L.check(p._lib.dpgo_optimize_device(p._h, C.byref(cp), L.ptr(X_dev), C.byref(cr)))
         self.result_ = ROPTResult.from_c(cr)
         return self.result_

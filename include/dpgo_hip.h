@@ -49,6 +49,7 @@ extern "C" {
  * (same fixed point, different tCG trajectory). */
 #define DPGO_PRECOND_NONE 0
 #define DPGO_PRECOND_BLOCK_JACOBI 1
+#define DPGO_PRECOND_MULTILEVEL 2 /* two-level aggregation multigrid; needs dpgo_problem_set_multilevel */
 
 /* tCG termination status; replaces ROPTLIB::tCGstatusSet in ROPTResult
  * (include/DPGO/DPGO_types.h:106). */
@@ -164,6 +165,19 @@ int dpgo_problem_gnc_reweight(dpgo_problem_t h, const double* X_host, double mu,
                               int counts[3], double* max_rsq);
 int dpgo_problem_set_edge_weights(dpgo_problem_t h, const double* weight_host);   /* + rebuild Q, preconditioner */
 int dpgo_problem_get_edge_weights(dpgo_problem_t h, double* weight_host, double* rsq_host /* may be NULL */);
+
+/* Q's current values (nnzb blocks, same order as set_Q_bsr) -- they change on the device under GNC re-weighting. */
+int dpgo_problem_get_Q_values(dpgo_problem_t h, double* vals_host);
+/* Optional two-level (aggregation multigrid) preconditioner for precond = DPGO_PRECOND_MULTILEVEL: a much closer
+ * stand-in for the reference's exact solve of Q + 0.1 I (src/PoseGraph.cpp:598-613, src/QuadraticProblem.cpp:56-69)
+ * than block-Jacobi.  Aggregates are runs of k consecutive poses (the last may be shorter), nc = ceil(n / k).
+ *   P_blocks : n blocks (d+1)x(d+1), row-major: the prolongation block of pose i (relative pose from the aggregate's
+ *              first pose to pose i, transposed -- dpgo_amd/multilevel.py / oracle amg_prolongation_blocks)
+ *   AcInv    : dense inverse of P^T (Q + shift I) P, (nc (d+1))^2 doubles, row-major (symmetric)
+ *   omega    : damping of the block-Jacobi smoother;  shift: the reference's 0.1
+ * Host memory; call again after Q's values change (set_Q_*, update_Q_values and the GNC re-weighting drop it). */
+int dpgo_problem_set_multilevel(dpgo_problem_t h, int k, const double* P_blocks, const double* AcInv, double omega,
+                                double shift);
 
 /* PoseGraph::linearMatrix() (include/DPGO/PoseGraph.h:171): dense r x (d+1)n; NULL = zero */
 int dpgo_problem_set_G(dpgo_problem_t h, const double* G_host);

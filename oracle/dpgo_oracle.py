@@ -372,6 +372,48 @@ def project_to_rotation_group(M):
 # --------------------------------------------------------------------------
 
 
+def amg_default_k(n: int, b: int, max_coarse: int = 3200) -> int:
+    """Aggregate size of the two-level preconditioner: the smallest power of two >= 4 that keeps the dense coarse
+    operator at <= max_coarse unknowns (82 MB in fp64: it stays in the 256 MB Infinity Cache)."""
+    k = 4
+    while ((n + k - 1) // k) * b > max_coarse:
+        k *= 2
+    return k
+
+
+def amg_prolongation_blocks(Q: "BSR", d: int, k: int):
+    """Pb[i] = G(root -> i)^T for the aggregate {root = (i // k) k, ..., root + k - 1}: the homogeneous relative pose
+    composed along the odometry chain, read off Q's own blocks: for an edge i -> i+1 the block Q_{i,i+1} is
+    -T Om = -[w kappa R, w tau t; 0, w tau] (src/DPGO_utils.cpp:307-329), so w tau = -Q[d][d], t = -Q[:d, d] / (w tau),
+    w kappa = |first column of Q[:d, :d]|, R = -Q[:d, :d] / (w kappa).  Missing block: the chain restarts at identity.
+    With these blocks P C reproduces, on every aggregate, the kernel vectors V_i = G_i^T C of the chain's Laplacian."""
+    n, b = Q.n, d + 1
+    Pb = np.zeros((n, b, b))
+    G = np.eye(b)
+    for i in range(n):
+        if i % k == 0:
+            G = np.eye(b)
+        else:
+            T = np.eye(b)
+            blk = None
+            for t in range(Q.rowptr[i - 1], Q.rowptr[i]):
+                if Q.colidx[t] == i:
+                    blk = Q.vals[t]
+            if blk is not None and -blk[d, d] > 0:
+                wt = -blk[d, d]
+                wk = np.linalg.norm(blk[:d, 0])
+                if wk > 0:
+                    T[:d, :d] = -blk[:d, :d] / wk
+                    T[:d, d] = -blk[:d, d] / wt
+                    G = G @ T
+                else:
+                    G = np.eye(b)
+            else:
+                G = np.eye(b)
+        Pb[i] = G.T
+    return Pb
+
+
 class QuadraticProblem:
     """f(X) = 0.5 <Q, X^T X> + <X, G>  (include/DPGO/QuadraticProblem.h:28-32).
 
@@ -379,11 +421,16 @@ class QuadraticProblem:
                          CHOLMOD path (src/PoseGraph.cpp:598-613, src/QuadraticProblem.cpp:56-69);
              'jacobi' -> inverse of the (d+1)x(d+1) diagonal blocks of Q + 0.1 I (what the
                          MI355X path runs; same fixed point, different trajectory);
-             'none'   -> identity.
-    All three are followed by the tangent projection (QuadraticProblem.cpp:68)."""
+             'none'   -> identity;
+             'amg2'   -> two-level aggregation multigrid cycle for Q + 0.1 I (the device's optional
+                         "multilevel" preconditioner): aggregates of k consecutive poses,
+                         prolongation blocks = relative poses read off Q's odometry blocks, exact coarse solve,
+                         damped block-Jacobi pre- and post-smoothing.
+    All of them are followed by the tangent projection (QuadraticProblem.cpp:68)."""
 
     def __init__(self, Q: BSR, G: Optional[np.ndarray], r: int, d: int, precond: str = "exact",
-                 shift: float = 0.1):
+                 shift: float = 0.1, amg_k: Optional[int] = None, amg_omega: float = 0.7):
+        self.amg_k, self.amg_omega, self._amg = amg_k, amg_omega, None
         self.Q, self.r, self.d, self.n = Q, r, d, Q.n
         self.b = d + 1
         self.N = self.n * self.b
@@ -444,9 +491,38 @@ class QuadraticProblem:
             Z = self.dinv_blocks() @ V
         elif self.precond == "none":
             Z = V.copy()
+        elif self.precond == "amg2":
+            Z = self.amg2_cycle(V)
         else:
             raise ValueError(self.precond)
         return tangent_project(X, Z, self.d)
+
+    # --- two-level aggregation multigrid (device option "multilevel") ---
+    def amg2_setup(self):
+        if self._amg is None:
+            k = self.amg_k or amg_default_k(self.n, self.b)
+            Pb = amg_prolongation_blocks(self.Q, self.d, k)  # [n, b, b]
+            n, b = self.n, self.b
+            nc = (n + k - 1) // k
+            rows = (np.arange(n)[:, None, None] * b + np.arange(b)[None, :, None]) + np.zeros((1, 1, b), dtype=np.int64)
+            cols = ((np.arange(n) // k)[:, None, None] * b + np.arange(b)[None, None, :]) + np.zeros((1, b, 1), dtype=np.int64)
+            P = sp.csr_matrix((Pb.ravel(), (rows.ravel(), cols.ravel())), shape=(n * b, nc * b))
+            A = (self.Qs + self.shift * sp.identity(self.N, format="csr")).tocsr()
+            Ac = (P.T @ A @ P).toarray()
+            self._amg = dict(k=k, P=P, A=A, AcInv=np.linalg.inv(Ac), nc=nc)
+        return self._amg
+
+    def amg2_cycle(self, V):
+        m = self.amg2_setup()
+        A, P, w = m["A"], m["P"], self.amg_omega
+        Dinv = self.dinv_blocks()
+        r = V.reshape(self.N, self.r)
+        smooth = lambda res: (Dinv @ res.reshape(self.n, self.b, self.r)).reshape(self.N, self.r)  # noqa: E731
+        x1 = w * smooth(r)
+        rc = P.T @ (r - A @ x1)
+        x = x1 + P @ (m["AcInv"] @ rc)
+        z = x + w * smooth(r - A @ x)
+        return z.reshape(V.shape)
 
 
 # --------------------------------------------------------------------------

@@ -2,6 +2,7 @@
 import ctypes as C
 import os
 import re
+import sys
 
 import numpy as np
 import pytest
@@ -177,3 +178,36 @@ def test_trajectory_csv_round_trip(tmp_path):
     lines = open(g).read().splitlines()
     assert lines[0].startswith("robot_src,pose_src,robot_dst,pose_dst,qx,qy,qz,qw,tx,ty,tz,kappa,tau,")
     assert len(lines) == len(meas) + 1
+
+
+@pytest.mark.parametrize("name", ["smallGrid3D", "kitti_00"])
+def test_multilevel_host_setup_matches_oracle(name):
+    """dpgo_amd.multilevel.build (product, host side of precond = "multilevel") against the oracle's independent
+    restatement: same aggregate size rule, same prolongation blocks, same coarse inverse; the prolongation
+    reproduces the chain Laplacian's kernel: for an odometry-only graph (Q + 0 I) P C = 0 ... A P has no
+    odometry residual inside an aggregate."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import dpgo_oracle as O
+    from dpgo_amd import multilevel
+    om, n = O.read_g2o(os.path.join(DATA, name + ".g2o"))
+    d = om.d
+    Q = O.construct_Q(n, d, om)
+    k, Pb, AcInv = multilevel.build(Q.rowptr, Q.colidx, Q.vals, d)
+    op = O.QuadraticProblem(Q, None, d + 2, d, precond="amg2")
+    m = op.amg2_setup()
+    assert k == m["k"] == O.amg_default_k(n, d + 1)
+    assert np.abs(Pb - O.amg_prolongation_blocks(Q, d, k)).max() == 0.0
+    assert np.abs(AcInv - m["AcInv"]).max() <= 1e-10 * np.abs(AcInv).max()
+    # kernel property on the odometry chain alone
+    odo = om.subset(np.nonzero(om.p1 + 1 == om.p2)[0])
+    Qo = O.construct_Q(n, d, odo)
+    Pbo = multilevel.prolongation_blocks(Qo.rowptr, Qo.colidx, Qo.vals, d, k)
+    b = d + 1
+    V = np.zeros((n * b, b))
+    for i in range(n):
+        V[i * b:(i + 1) * b] = Pbo[i]
+    R = (Qo.to_scipy() @ V).reshape(n, b, b)
+    inner = np.array([i for i in range(n) if i % k not in (0, k - 1) and i != n - 1])  # rows not touching a cut
+    # (1e-9-level: the g2o rotations are not exactly orthonormal, so T is recovered to ~1e-9)
+    assert np.abs(R[inner]).max() <= 1e-7 * np.abs(Qo.vals).max()
+    assert np.abs(R[np.arange(k - 1, n - 1, k)]).max() > 1e-3 * np.abs(Qo.vals).max()  # cut rows do see a residual
