@@ -158,6 +158,10 @@ struct dpgo_problem_s {
     return tiles < cap_u ? tiles : cap_u;
   }
   int cap_u = kMaxGrid, cap_h = kMaxGrid;  // launch caps of the streaming / SpMM kernel families
+  // entries of partial region B (<r,r>, <z,r>) that k_tcg_hess has to sum: written by k_tcg_update (its grid) or,
+  // with the fused multilevel cycle, by k_ml_post (SpMM-family grid)
+  bool zr_from_post = false;
+  int nb_zr() const { return zr_from_post ? grid_s() : grid(); }
   int split = 1;  // lane groups per pose in the SpMM kernels (latency layout for small blocks)
   int grid_s() const {  // SpMM kernels (k_spmm, k_grad, k_hess, k_tcg_hess)
     const int P = (64 / (b * split)) * kWaves;
@@ -274,17 +278,19 @@ int launch_hess(dpgo_problem_s* p, const double* X, const double* S, const doubl
   return DPGO_OK;
 }
 
-int launch_tcg_update(dpgo_problem_s* p, const double* dinv, int first) {
+int launch_tcg_update(dpgo_problem_s* p, const double* dinv, int first, double* z_out = nullptr,
+                      double ml_omega = 0.0) {
   const int g = p->grid();
+  double* zt = z_out ? z_out : p->z;
   DISPATCH(p->d, p->r, {
     if constexpr (Span<D, R, 1>::kOk)
       hipLaunchKernelGGL((k_tcg_update_span<D, R>), dim3(g), dim3(kBlock), 0, p->stream, p->x1, p->g1, dinv, p->delta,
-                         p->Hd, p->eta, p->rr, p->z, p->pA(), p->grid_s(), p->pB(), p->dstate + p->cur,
-                         p->dstate + (p->cur ^ 1), first, p->n, p->hflag, p->gen);
+                         p->Hd, p->eta, p->rr, zt, p->pA(), p->grid_s(), p->pB(), p->dstate + p->cur,
+                         p->dstate + (p->cur ^ 1), first, p->n, p->hflag, p->gen, ml_omega);
     else
       hipLaunchKernelGGL((k_tcg_update<D, R>), dim3(g), dim3(kBlock), 0, p->stream, p->x1, p->g1, dinv, p->delta,
-                         p->Hd, p->eta, p->rr, p->z, p->pA(), p->grid_s(), p->pB(), p->dstate + p->cur,
-                         p->dstate + (p->cur ^ 1), first, p->n, p->hflag, p->gen);
+                         p->Hd, p->eta, p->rr, zt, p->pA(), p->grid_s(), p->pB(), p->dstate + p->cur,
+                         p->dstate + (p->cur ^ 1), first, p->n, p->hflag, p->gen, ml_omega);
   });
   HIPC(hipGetLastError());
   p->cur ^= 1;
@@ -297,10 +303,10 @@ int launch_tcg_update(dpgo_problem_s* p, const double* dinv, int first) {
   do {                                                                                                            \
     if constexpr (Span<D, R, 1>::kOk)                                                                             \
       LAUNCH_SPLIT(p, k_tcg_hess_span, (p)->grid_s(), (p)->Q.dev(), (p)->x1, (p)->S1, (p)->z, (p)->delta, (p)->Hd, \
-                   (p)->pB(), (p)->grid(), (p)->pA(), SIN, SOUT, FIRST, (p)->n, HFLAG, GEN);                      \
+                   (p)->pB(), (p)->nb_zr(), (p)->pA(), SIN, SOUT, FIRST, (p)->n, HFLAG, GEN);                   \
     else                                                                                                          \
       LAUNCH_SPLIT(p, k_tcg_hess, (p)->grid_s(), (p)->Q.dev(), (p)->x1, (p)->S1, (p)->z, (p)->delta, (p)->Hd,      \
-                   (p)->pB(), (p)->grid(), (p)->pA(), SIN, SOUT, FIRST, (p)->n, HFLAG, GEN);                      \
+                   (p)->pB(), (p)->nb_zr(), (p)->pA(), SIN, SOUT, FIRST, (p)->n, HFLAG, GEN);                   \
   } while (0)
 
 int launch_tcg_hess(dpgo_problem_s* p, int first) {
@@ -411,13 +417,48 @@ int launch_ml_cycle(dpgo_problem_s* p, const double* Xdev, const double* r, doub
   return DPGO_OK;
 }
 
+// Fused form: k_tcg_update already left x1 = w Dinv r in ml_x1; three launches finish the cycle.
+bool ml_fusable(const dpgo_problem_s* p) {
+  const int P = (64 / (p->b * p->split)) * kWaves;
+  if (const char* e = std::getenv("DPGO_ML_FUSED"))
+    if (std::atoi(e) == 0) return false;
+  return p->ml_ready && p->ml_k >= 1 && (P % p->ml_k) == 0;
+}
+int launch_ml_fused_tail(dpgo_problem_s* p, const DevState* gate) {
+  const int gs = p->grid_s();
+  const int gc = std::max(1, std::min(kMaxGrid, p->ml_nc));
+  DISPATCH(p->d, p->r, LAUNCH_SPLIT(p, k_ml_restrict, gs, p->Q.dev(), p->ml_x1, p->rr, p->ml_P.vals, p->ml_shift, p->ml_k,
+                                    p->ml_rc, gate, p->n));
+  HIPC(hipGetLastError());
+  DISPATCH(p->d, p->r, {
+    hipLaunchKernelGGL((k_ml_coarse_prolong<D, R>), dim3(gc), dim3(kBlock), 0, p->stream, p->ml_inv, p->ml_rc, p->ml_x1,
+                       p->ml_P.vals, p->ml_k, p->ml_x, gate, p->n, p->ml_nc);
+  });
+  HIPC(hipGetLastError());
+  DISPATCH(p->d, p->r, LAUNCH_SPLIT(p, k_ml_post, gs, p->Q.dev(), p->x1, p->ml_x, p->rr, p->dinv, p->ml_omega, p->ml_shift,
+                                    p->z, p->pB(), gate, p->n));
+  HIPC(hipGetLastError());
+  return DPGO_OK;
+}
+
 int rtr_outer_iteration(dpgo_problem_s* p, const dpgo_ropt_params* prm, const double* dinv, Counters& cnt,
                         bool poll_at_end) {
   p->gen += 1;
   const bool ml = prm->precond == DPGO_PRECOND_MULTILEVEL;
-  CHK(launch_tcg_update(p, dinv, 1));
-  // multilevel: the update kernel's block-Jacobi z and its <z, r> partial are replaced by the cycle's
-  if (ml) CHK(launch_ml_cycle(p, p->x1, p->rr, p->z, p->pB(), p->dstate + p->cur));
+  const bool mlf = ml && ml_fusable(p);
+  p->zr_from_post = mlf;
+  // multilevel: the update kernel's block-Jacobi z and its <z, r> partial are replaced by the cycle's (7 launches),
+  // or -- fused -- the update kernel writes the pre-smoothing step and three launches finish the cycle
+  auto update = [&](int first) -> int {
+    if (mlf) {
+      CHK(launch_tcg_update(p, dinv, first, p->ml_x1, p->ml_omega));
+      return launch_ml_fused_tail(p, p->dstate + p->cur);
+    }
+    CHK(launch_tcg_update(p, dinv, first));
+    if (ml) CHK(launch_ml_cycle(p, p->x1, p->rr, p->z, p->pB(), p->dstate + p->cur));
+    return DPGO_OK;
+  };
+  CHK(update(1));
   const int max_inner = prm->RTR_tCG_iterations;
   const bool pipe = p->pipe && max_inner > 0 && !ml;
   // pipelined scheme: init launch (w0 = H z0, m0 = P w0), then ONE launch per iteration; `step` hides the scheme
@@ -431,9 +472,7 @@ int rtr_outer_iteration(dpgo_problem_s* p, const dpgo_ropt_params* prm, const do
       return launch_tcg_pipe(p, dinv, j == 0 ? 2 : 0, in_is_B);
     }
     CHK(launch_tcg_hess(p, j == 0 ? 1 : 0));
-    CHK(launch_tcg_update(p, dinv, 0));
-    if (ml) CHK(launch_ml_cycle(p, p->x1, p->rr, p->z, p->pB(), p->dstate + p->cur));
-    return DPGO_OK;
+    return update(0);
   };
   if (max_inner <= 0) CHK(launch_tcg_hess(p, 1));  // only finalises the tCG state (eta = 0)
   bool done = false;
