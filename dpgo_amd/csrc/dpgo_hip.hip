@@ -122,7 +122,8 @@ struct dpgo_problem_s {
   double ml_omega = 0.7, ml_shift = 1e-1;
   Bsr ml_P, ml_Pt;            // rectangular n x nc / nc x n
   double* ml_Aneg = nullptr;  // -(Q + shift I) on Q's pattern
-  double *ml_inv = nullptr, *ml_x1 = nullptr, *ml_res = nullptr, *ml_x = nullptr, *ml_rc = nullptr, *ml_xc = nullptr;
+  float* ml_inv = nullptr;    // dense coarse inverse, stored in fp32
+  double *ml_x1 = nullptr, *ml_res = nullptr, *ml_x = nullptr, *ml_rc = nullptr, *ml_xc = nullptr;
   double* partials = nullptr;  // 5 regions of kPartialCap*kNP
   DevState* dstate = nullptr;  // 2 slots
   DevState* hstate = nullptr;  // pinned
@@ -857,9 +858,10 @@ int dpgo_problem_destroy(dpgo_problem_t p) {
   free_bsr(p->ml_P);
   free_bsr(p->ml_Pt);
   {
-    double* mlb[] = {p->ml_Aneg, p->ml_inv, p->ml_x1, p->ml_res, p->ml_x, p->ml_rc, p->ml_xc};
+    double* mlb[] = {p->ml_Aneg, p->ml_x1, p->ml_res, p->ml_x, p->ml_rc, p->ml_xc};
     for (auto q : mlb)
       if (q) (void)hipFree(q);
+    if (p->ml_inv) (void)hipFree(p->ml_inv);
   }
   free_edges(p);
   double* vecs[] = {p->x1, p->x2, p->g1, p->g2, p->eta, p->delta, p->Hd, p->rr, p->z, p->G, p->G0,
@@ -1178,20 +1180,26 @@ int dpgo_problem_set_multilevel(dpgo_problem_t p, int k, const double* P_blocks,
   for (int a = 0; a <= nc; ++a) trow[a] = std::min(a * k, n);
   CHK(upload_bsr(p->ml_P, n, nc, n, b, prow.data(), pcol.data(), P_blocks, p->stream));
   CHK(upload_bsr(p->ml_Pt, nc, n, n, b, trow.data(), tcol.data(), tvals.data(), p->stream));
-  double** bufs[] = {&p->ml_Aneg, &p->ml_inv, &p->ml_x1, &p->ml_res, &p->ml_x, &p->ml_rc, &p->ml_xc};
+  if (p->ml_inv) {
+    (void)hipFree(p->ml_inv);
+    p->ml_inv = nullptr;
+  }
+  double** bufs[] = {&p->ml_Aneg, &p->ml_x1, &p->ml_res, &p->ml_x, &p->ml_rc, &p->ml_xc};
   for (auto q : bufs)
     if (*q) {
       (void)hipFree(*q);
       *q = nullptr;
     }
   HIPC(hipMalloc(&p->ml_Aneg, sizeof(double) * (size_t)p->Q.nnzb * b * b));
-  HIPC(hipMalloc(&p->ml_inv, sizeof(double) * N * N));
+  HIPC(hipMalloc(&p->ml_inv, sizeof(float) * N * N));
   HIPC(hipMalloc(&p->ml_x1, p->vec_bytes()));
   HIPC(hipMalloc(&p->ml_res, p->vec_bytes()));
   HIPC(hipMalloc(&p->ml_x, p->vec_bytes()));
   HIPC(hipMalloc(&p->ml_rc, sizeof(double) * N * p->r));
   HIPC(hipMalloc(&p->ml_xc, sizeof(double) * N * p->r));
-  HIPC(hipMemcpyAsync(p->ml_inv, AcInv, sizeof(double) * N * N, hipMemcpyHostToDevice, p->stream));
+  std::vector<float> inv32(N * N);
+  for (size_t q = 0; q < N * N; ++q) inv32[q] = (float)AcInv[q];  // round to nearest, as numpy's astype(float32)
+  HIPC(hipMemcpyAsync(p->ml_inv, inv32.data(), sizeof(float) * N * N, hipMemcpyHostToDevice, p->stream));
   const int g = std::max(1, std::min(kMaxGrid, (n + kBlock - 1) / kBlock));
   if (p->d == 2)
     hipLaunchKernelGGL(k_ml_neg_shift<2>, dim3(g), dim3(kBlock), 0, p->stream, p->Q.dev(), shift, p->ml_Aneg, n);

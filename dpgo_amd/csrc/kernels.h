@@ -1705,20 +1705,21 @@ __global__ __launch_bounds__(kBlock) void k_ml_finish(const double* __restrict__
 }
 
 // Dense coarse solve: OUT (N x R, R contiguous) = M (N x N, row-major) * V (N x R).  One wave per output row;
-// M streams once (Infinity-Cache / HBM), V is re-read by every wave through L2.
+// M streams once (Infinity-Cache / HBM), V is re-read by every wave through L2.  M is STORED in fp32 (it is a
+// preconditioner: iteration counts are unchanged, the dominant stream of the cycle halves); accumulation is fp64.
 template <int R>
-__global__ __launch_bounds__(kBlock) void k_ml_dense_apply(const double* __restrict__ M, const double* __restrict__ V,
+__global__ __launch_bounds__(kBlock) void k_ml_dense_apply(const float* __restrict__ M, const double* __restrict__ V,
                                                            double* __restrict__ OUT, const DevState* __restrict__ gate,
                                                            int N) {
   if (gate && (gate->tcg_done || gate->rtr_stop)) return;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (int row = blockIdx.x * kWaves + wave; row < N; row += gridDim.x * kWaves) {
-    const double* __restrict__ m = M + (size_t)row * N;
+    const float* __restrict__ m = M + (size_t)row * N;
     double acc[R];
 #pragma unroll
     for (int a = 0; a < R; ++a) acc[a] = 0.0;
     for (int j = lane; j < N; j += 64) {
-      const double mv = m[j];
+      const double mv = (double)m[j];
 #pragma unroll
       for (int a = 0; a < R; ++a) acc[a] = fma(mv, V[(size_t)j * R + a], acc[a]);
     }
@@ -1815,7 +1816,7 @@ __global__ __launch_bounds__(kBlock) void k_ml_restrict(BsrDev Q, const double* 
 // One workgroup per aggregate a: waves 0..B-1 compute the B rows of xc_a = (Ac^-1 rc)_a, then the workgroup writes
 // x_i = x1_i + P_i xc_a for the aggregate's poses.
 template <int D, int R>
-__global__ __launch_bounds__(kBlock) void k_ml_coarse_prolong(const double* __restrict__ M, const double* __restrict__ rc,
+__global__ __launch_bounds__(kBlock) void k_ml_coarse_prolong(const float* __restrict__ M, const double* __restrict__ rc,
                                                               const double* __restrict__ x1,
                                                               const double* __restrict__ Pb, int k,
                                                               double* __restrict__ x, const DevState* __restrict__ gate,
@@ -1827,12 +1828,12 @@ __global__ __launch_bounds__(kBlock) void k_ml_coarse_prolong(const double* __re
   const int N = nc * B;
   for (int a = blockIdx.x; a < nc; a += gridDim.x) {
     if (wave < B) {
-      const double* __restrict__ m = M + (size_t)(a * B + wave) * N;
+      const float* __restrict__ m = M + (size_t)(a * B + wave) * N;
       double acc[R];
 #pragma unroll
       for (int q = 0; q < R; ++q) acc[q] = 0.0;
       for (int j = lane; j < N; j += 64) {
-        const double mv = m[j];
+        const double mv = (double)m[j];
 #pragma unroll
         for (int q = 0; q < R; ++q) acc[q] = fma(mv, rc[(size_t)j * R + q], acc[q]);
       }

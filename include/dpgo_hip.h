@@ -173,7 +173,8 @@ int dpgo_problem_get_Q_values(dpgo_problem_t h, double* vals_host);
  * than block-Jacobi.  Aggregates are runs of k consecutive poses (the last may be shorter), nc = ceil(n / k).
  *   P_blocks : n blocks (d+1)x(d+1), row-major: the prolongation block of pose i (relative pose from the aggregate's
  *              first pose to pose i, transposed -- dpgo_amd/multilevel.py / oracle amg_prolongation_blocks)
- *   AcInv    : dense inverse of P^T (Q + shift I) P, (nc (d+1))^2 doubles, row-major (symmetric)
+ *   AcInv    : dense inverse of P^T (Q + shift I) P, (nc (d+1))^2 doubles, row-major (symmetric); kept on the device
+ *              in fp32 (accumulation in fp64)
  *   omega    : damping of the block-Jacobi smoother;  shift: the reference's 0.1
  * Host memory; call again after Q's values change (set_Q_*, update_Q_values and the GNC re-weighting drop it). */
 int dpgo_problem_set_multilevel(dpgo_problem_t h, int k, const double* P_blocks, const double* AcInv, double omega,

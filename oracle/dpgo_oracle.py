@@ -509,7 +509,9 @@ class QuadraticProblem:
             P = sp.csr_matrix((Pb.ravel(), (rows.ravel(), cols.ravel())), shape=(n * b, nc * b))
             A = (self.Qs + self.shift * sp.identity(self.N, format="csr")).tocsr()
             Ac = (P.T @ A @ P).toarray()
-            self._amg = dict(k=k, P=P, A=A, AcInv=np.linalg.inv(Ac), nc=nc)
+            Ac = 0.5 * (Ac + Ac.T)
+            # the device keeps the coarse inverse in fp32 (a preconditioner: iteration counts are unchanged)
+            self._amg = dict(k=k, P=P, A=A, AcInv=np.linalg.inv(Ac).astype(np.float32).astype(np.float64), nc=nc)
         return self._amg
 
     def amg2_cycle(self, V):

@@ -197,7 +197,8 @@ def test_multilevel_host_setup_matches_oracle(name):
     m = op.amg2_setup()
     assert k == m["k"] == O.amg_default_k(n, d + 1)
     assert np.abs(Pb - O.amg_prolongation_blocks(Q, d, k)).max() == 0.0
-    assert np.abs(AcInv - m["AcInv"]).max() <= 1e-10 * np.abs(AcInv).max()
+    # (the oracle keeps the inverse as the device does, rounded to fp32)
+    assert np.abs(AcInv.astype(np.float32).astype(np.float64) - m["AcInv"]).max() <= 2e-7 * np.abs(AcInv).max()
     # kernel property on the odometry chain alone
     odo = om.subset(np.nonzero(om.p1 + 1 == om.p2)[0])
     Qo = O.construct_Q(n, d, odo)

@@ -874,7 +874,7 @@ def test_distributed_gnc_kitti_four_agents(oracle):
 @pytest.mark.parametrize("name,r", [("smallGrid3D", 5), ("sphere2500", 5), ("kitti_00", 3), ("torus3D", 4)])
 def test_multilevel_preconditioner_matches_oracle(oracle, name, r):
     """precond = "multilevel": the two-level aggregation multigrid cycle (stand-in for the reference's exact solve of
-    Q + 0.1 I, src/QuadraticProblem.cpp:56-69) against the oracle's restatement (`amg2`): one application to 1e-10,
+    Q + 0.1 I, src/QuadraticProblem.cpp:56-69) against the oracle's restatement (`amg2`): one application to 1e-8,
     one optimize at matched settings with identical iteration counts and iterates to 1e-7, far fewer Hessian-vector
     products than block-Jacobi, same optimum."""
     import dpgo_amd
@@ -883,7 +883,7 @@ def test_multilevel_preconditioner_matches_oracle(oracle, name, r):
     op = oracle.QuadraticProblem(Q, None, r, d, precond="amg2")
     V = oracle.tangent_project(X0, np.random.default_rng(4).standard_normal(X0.shape), d)
     Zd = matrix_to_tiles(prob.PreConditioner(tiles_to_matrix(X0), tiles_to_matrix(V), precond="multilevel"), d)
-    assert relerr(Zd, op.precondition(X0, V)) < 1e-10
+    assert relerr(Zd, op.precondition(X0, V)) < 1e-8  # the coarse inverse is kept in fp32 on both sides
     assert op.amg2_setup()["k"] == prob._ml_k
     oo = oracle.QuadraticOptimizer(op, oracle.ROptParameters(), hess_recurrence=True)
     Xo = oo.optimize(X0)
