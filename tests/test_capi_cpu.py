@@ -212,3 +212,81 @@ def test_multilevel_host_setup_matches_oracle(name):
     # (1e-9-level: the g2o rotations are not exactly orthonormal, so T is recovered to ~1e-9)
     assert np.abs(R[inner]).max() <= 1e-7 * np.abs(Qo.vals).max()
     assert np.abs(R[np.arange(k - 1, n - 1, k)]).max() > 1e-3 * np.abs(Qo.vals).max()  # cut rows do see a residual
+
+
+def _random_multi_robot_graph(rng, d, n, robots, extra):
+    """Random connected pose graph (odometry chain + `extra` random loop closures, some reversed, random weights),
+    cut into `robots` contiguous blocks; returns oracle-style global arrays."""
+    def rot():
+        Qm, _ = np.linalg.qr(rng.standard_normal((d, d)))
+        if np.linalg.det(Qm) < 0:
+            Qm[:, 0] *= -1
+        return Qm
+    p1 = list(range(n - 1))
+    p2 = list(range(1, n))
+    seen = set(zip(p1, p2))
+    extra = min(extra, n * (n - 1) - (n - 1))  # distinct ordered pairs still available
+    while len(p1) < n - 1 + extra:
+        a, b = (int(v) for v in rng.integers(0, n, 2))
+        if a != b and (a, b) not in seen:
+            seen.add((a, b))
+            p1.append(a)
+            p2.append(b)
+    m = len(p1)
+    return dict(p1=np.array(p1), p2=np.array(p2), R=np.stack([rot() for _ in range(m)]),
+                t=rng.standard_normal((m, d)), kappa=rng.uniform(0.5, 50, m), tau=rng.uniform(0.5, 50, m),
+                weight=rng.uniform(0.1, 1.0, m))
+
+
+def test_host_builders_on_random_multi_robot_graphs(oracle):
+    """Property test (hypothesis): dpgo_build_Q_bsr / dpgo_build_G_coupling (the host C++ restatements of
+    PoseGraph::constructQ / constructG, src/PoseGraph.cpp:381-580) against the oracle on random graphs -- 2-D and 3-D,
+    reversed loop closures, non-unit weights, uneven blocks, priors, every robot's view."""
+    from hypothesis import given, settings, strategies as st
+    import dpgo_amd
+    O = oracle
+
+    @settings(max_examples=25, deadline=None)
+    @given(seed=st.integers(0, 10 ** 6), d=st.sampled_from([2, 3]), n=st.integers(4, 40), robots=st.integers(1, 4),
+           extra=st.integers(0, 30), r_extra=st.integers(0, 2))
+    def check(seed, d, n, robots, extra, r_extra):
+        robots = min(robots, n)
+        rng = np.random.default_rng(seed)
+        g = _random_multi_robot_graph(rng, d, n, robots, extra)
+        r = d + r_extra
+        z = np.zeros(len(g["p1"]), dtype=np.int64)
+        om = O.Measurements(d, z, g["p1"], z.copy(), g["p2"], g["R"], g["t"], g["kappa"], g["tau"], g["weight"],
+                            np.zeros(len(z), dtype=bool))
+        pm = to_product_measurements(om)
+        ranges, per = O.partition_contiguous(om, n, robots)
+        ranges_p, per_p = dpgo_amd.partition_contiguous(pm, n, robots)
+        assert ranges == ranges_p
+        X = O.polar_project(rng.standard_normal((n, d + 1, r)), d)
+        for a in range(robots):
+            s, e = ranges[a]
+            pg = dpgo_amd.PoseGraph(a, r, d)
+            pg.setMeasurements(per_p[a])
+            assert pg.n() == e - s
+            prior = {0: X[s]} if (seed + a) % 2 == 0 else None
+            if prior:
+                pg.setPrior(0, X[s].T)
+            priv = O.Measurements.concat([per[a]["odometry"], per[a]["private"]])
+            Qa = O.construct_Q(e - s, d, priv, per[a]["shared"], my_id=a, priors=prior)
+            rp, ci, v = pg.quadraticMatrix()
+            assert np.array_equal(rp, Qa.rowptr) and np.array_equal(ci, Qa.colidx)
+            assert np.abs(v - Qa.vals).max() <= 1e-12 * max(1.0, np.abs(Qa.vals).max())
+            nbr = {pid: X[ranges[pid[0]][0] + pid[1]] for pid in pg.neighborPoseIDs()}
+            pg.setNeighborPoses({k: t.T for k, t in nbr.items()})
+            if per[a]["shared"].m or prior:
+                Ga = O.construct_G(e - s, d, r, per[a]["shared"], a, nbr, priors=prior)
+                Gt = np.ascontiguousarray(pg.linearMatrix().T).reshape(e - s, d + 1, r)
+                assert np.abs(Gt - Ga).max() <= 1e-12 * max(1.0, np.abs(Ga).max())
+                # the coupling-operator form used on the device gives the same G
+                slots, crp, cci, cv, G0 = pg.couplingMatrix()
+                Gop = np.ascontiguousarray(G0.T).reshape(e - s, d + 1, r).copy()
+                for i in range(e - s):
+                    for t in range(crp[i], crp[i + 1]):
+                        Gop[i] += cv[t] @ nbr[slots[cci[t]]]
+                assert np.abs(Gop - Ga).max() <= 1e-12 * max(1.0, np.abs(Ga).max())
+
+    check()
