@@ -1167,6 +1167,8 @@ int dpgo_problem_set_multilevel(dpgo_problem_t p, int k, const double* P_blocks,
     return fail(DPGO_ERR_INVALID, "bad multilevel arguments");
   const int n = p->n, b = p->b, nc = (n + k - 1) / k;
   const size_t N = (size_t)nc * b;
+  if (N > 16384)  // the coarse operator is a DENSE inverse: 1 GB in fp32 at 16384 unknowns, and it is read every cycle
+    return fail(DPGO_ERR_INVALID, "multilevel: coarse operator too large (choose k so that ceil(n/k) (d+1) <= 16384)");
   // P: n x nc, one block per row;  P^T: nc x n, the aggregate's poses per row (blocks transposed)
   std::vector<int32_t> prow(n + 1), pcol(n), trow(nc + 1), tcol(n);
   std::vector<double> tvals((size_t)n * b * b);
