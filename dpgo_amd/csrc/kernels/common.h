@@ -1,0 +1,484 @@
+// kernels/common.h -- shared definitions: solver state record, thread geometry, XCD-aware tile walk, span access, reductions,
+// small dense pieces (projection, block-Jacobi), the block-SpMM gather core.
+// Part of kernels.h (included inside namespace dpgo, in this order: common.h, problem.h, tcg.h, tcg_pipe.h, multilevel.h, manifold.h, rtr.h, agent.h).
+#pragma once
+
+
+constexpr int kBlock = 256;
+constexpr int kWaves = kBlock / 64;
+constexpr int kMaxGrid = 1024;  // default launch cap: 4 workgroups per CU on 256 CUs
+constexpr int kPartialCap = 1024;  // capacity of the per-workgroup partial-sum regions (upper bound of any grid)
+constexpr int kNP = 4;          // partial sums per workgroup (max over kernels)
+
+enum : int { TCG_NEGCURV = 0, TCG_EXCREGION = 1, TCG_LCON = 2, TCG_SCON = 3, TCG_MAXITER = 4 };
+
+// Device-resident solver state (two slots; kernels read slot `in`, workgroup 0 writes `in^1`).
+struct DevState {
+  // --- RTR (ROPTLIB SolversTR::Run; reference configuration src/QuadraticOptimizer.cpp:64-78)
+  double f1, ngf, Delta, Delta_max, tol;
+  double f2, rho, fInit, gnInit;
+  double xqx, xg;  // sum(XQ.X), sum(X.G) of the last k_rtr_begin evaluation
+  int outer_iter, rtr_stop, accepted_last, n_accept;
+  int accept_tiny, pad0;
+  // --- tCG (ROPTLIB SolversTR::tCG_TR)
+  double z_r, d_Pd, e_Pd, e_Pe, norm_r0, alpha, theta, kappa;
+  double d_Hd;  // <delta, H delta> of the last iteration (pipelined tCG derives the next one from it)
+  int tcg_j, tcg_done, tcg_status, max_inner;
+  int n_hess, min_inner;
+};
+
+// Progress word published by workgroup 0 into host-coherent pinned memory (system-scope relaxed
+// store).  The host feeds tCG-step kernels just-in-time, a few iterations ahead of `j`, instead of
+// synchronising every few iterations; it is a HINT only -- the device state above is the truth and
+// kernels enqueued after tCG finished exit in their prologue.
+//   [63:32] generation (one per tCG run)   [31:8] tcg_j   [1] rtr_stop   [0] tcg_done
+__device__ __forceinline__ void publish_progress(unsigned long long* hflag, unsigned gen, const DevState& st) {
+  if (hflag) {
+    const unsigned long long w = ((unsigned long long)gen << 32) |
+                                 ((unsigned long long)((unsigned)st.tcg_j & 0xFFFFFFu) << 8) |
+                                 (st.rtr_stop ? 2ull : 0ull) | (st.tcg_done ? 1ull : 0ull);
+    __hip_atomic_store(hflag, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
+// Field-wise state copies: copying the whole struct by value (read, modify, write back) is lowered through
+// scratch memory (120 B/lane measured with -Rpass-analysis=kernel-resource-usage), i.e. extra memory
+// round trips on the critical path of every solver kernel.  Field by field it is scalar loads into SGPRs.
+#define DPGO_STATE_FIELDS(X)                                                                              \
+  X(f1) X(ngf) X(Delta) X(Delta_max) X(tol) X(f2) X(rho) X(fInit) X(gnInit) X(xqx) X(xg) X(outer_iter)      \
+  X(rtr_stop) X(accepted_last) X(n_accept) X(accept_tiny) X(pad0) X(z_r) X(d_Pd) X(e_Pd) X(e_Pe) X(norm_r0) \
+  X(alpha) X(theta) X(kappa) X(d_Hd) X(tcg_j) X(tcg_done) X(tcg_status) X(max_inner) X(n_hess) X(min_inner)
+__device__ __forceinline__ void load_state(DevState& st, const DevState* __restrict__ p) {
+#define X(f) st.f = p->f;
+  DPGO_STATE_FIELDS(X)
+#undef X
+}
+__device__ __forceinline__ void store_state(DevState* __restrict__ p, const DevState& st) {
+#define X(f) p->f = st.f;
+  DPGO_STATE_FIELDS(X)
+#undef X
+}
+
+// SPLIT > 1 (SpMM kernels only): SPLIT lane groups share one pose and take every SPLIT-th block of its
+// row; the partial columns are summed with log2(SPLIT) shuffles.  It shortens the dependent
+// index -> tile load chain per wave (latency-bound regime: small agents / many GPUs); SPLIT = 1 is the
+// throughput layout used for big blocks.
+template <int D, int R, int SPLIT = 1>
+struct Geo {
+  static constexpr int B = D + 1;
+  static constexpr int T = B * R;         // doubles per pose tile
+  static constexpr int BB = B * B;        // doubles per Q block
+  static constexpr int LPP = B * SPLIT;   // lanes per pose
+  static constexpr int G = 64 / LPP;      // poses per wavefront
+  static constexpr int P = G * kWaves;    // poses per workgroup tile
+};
+
+struct LaneId {
+  int wave, g, s, c;
+};
+template <int D, int SPLIT = 1>
+__device__ __forceinline__ LaneId lane_id() {
+  constexpr int B = D + 1, LPP = B * SPLIT;
+  LaneId id;
+  const int l = threadIdx.x & 63;
+  id.wave = threadIdx.x >> 6;
+  id.g = l / LPP;
+  const int lp = l - id.g * LPP;
+  id.s = lp / B;
+  id.c = lp - id.s * B;
+  return id;
+}
+
+// ---------------------------------------------------------------- XCD-aware tile walk
+// MI355X has 8 XCDs with private 4 MiB L2s; workgroup b is observed to run on XCD b % 8
+// (MI355X_MICROARCH.md, "Workgroup dispatch"; used for SPEED only -- any placement is correct).
+// Give each XCD one contiguous eighth of the pose tiles so the X tiles gathered by the block-SpMM
+// (own rows + graph neighbours, mostly nearby indices) stay in that XCD's L2 instead of being
+// fetched by all eight.  Measured with FETCH_SIZE: 156 MB -> see profiles/ per launch at 100k poses.
+struct TileIter {
+  int first, last, step;
+};
+__device__ __forceinline__ TileIter tile_iter(int ntiles) {
+  TileIter it;
+  const int G = gridDim.x;
+  if (G < 16 || ntiles < 16) {
+    it.first = blockIdx.x;
+    it.last = ntiles;
+    it.step = G;
+    return it;
+  }
+  const int x = blockIdx.x & 7, lb = blockIdx.x >> 3;
+  const int nbx = (G - x + 7) >> 3;  // workgroups that land on this XCD
+  const int lo = (int)(((long long)ntiles * x) >> 3), hi = (int)(((long long)ntiles * (x + 1)) >> 3);
+  it.first = lo + lb;
+  it.last = hi;
+  it.step = nbx;
+  return it;
+}
+
+// The pose tiles exchanged through LDS are private to one wavefront, so a wave-level barrier (plus a
+// wavefront-scope fence that orders the DS operations) replaces __syncthreads(): no cross-wave stall.
+// occupancy hints (waves per SIMD) for the two kernels of the tCG loop; A/B-tuned on MI355X
+#ifndef DPGO_LB_HESS
+#define DPGO_LB_HESS 1
+#endif
+#ifndef DPGO_LB_UPDATE
+#define DPGO_LB_UPDATE 1
+#endif
+// Optional in-kernel timeline (diagnostic builds only, -DDPGO_TIMELINE): workgroup 0 / lane 0 stamps the 100 MHz
+// wall clock at phase boundaries of the two tCG kernels into a global array read back by dpgo_debug_timeline.
+#ifdef DPGO_TIMELINE
+__device__ long long g_timeline[2][16];
+#define DPGO_TL_DECL long long tl_[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define DPGO_STAMP(K, I) tl_[I] = wall_clock64()
+#define DPGO_COMMIT(K)                                     \
+  do {                                                     \
+    if (blockIdx.x == 0 && threadIdx.x == 0)               \
+      for (int q_ = 0; q_ < 8; ++q_) g_timeline[K][q_] = tl_[q_]; \
+  } while (0)
+#else
+#define DPGO_TL_DECL do { } while (0)
+#define DPGO_STAMP(K, I) do { } while (0)
+#define DPGO_COMMIT(K) do { } while (0)
+#endif
+#ifndef DPGO_WAVE_SYNC
+#define DPGO_WAVE_SYNC 1
+#endif
+__device__ __forceinline__ void wave_sync() {
+#if DPGO_WAVE_SYNC
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#else
+  __syncthreads();
+#endif
+}
+
+// ---------------------------------------------------------------- span access
+// A wave's G poses are ONE contiguous span of G*T doubles whose memory layout is exactly the LDS tile
+// layout [pose][column][R].  When T is even (always in 3-D: T = 4r) the span is moved with lane-linear
+// 16-byte accesses (1 KiB per wave instruction) instead of 8-byte accesses at a 40-byte stride
+// (tools/stream_lab.hip: 6.1 -> 7.0 TB/s on streaming kernels); element-wise updates are done in
+// that "span layout" and only the per-pose coupling uses the lane = (pose, column) layout.
+typedef double dbl2 __attribute__((ext_vector_type(2)));
+template <int D, int R, int SPLIT>
+struct Span {
+  using GEO = Geo<D, R, SPLIT>;
+  static constexpr bool kOk = (GEO::T % 2 == 0);
+  static constexpr int SP = GEO::G * GEO::T;  // doubles per wave span
+  static constexpr int NPC = SP / 2;          // 16-byte pieces
+  static constexpr int NIT = (NPC + 63) / 64; // pieces per lane
+};
+
+// ---------------------------------------------------------------- reductions
+__device__ __forceinline__ double wave_allreduce(double v) {
+  // xor butterfly: every lane ends with the same bits (each level adds a commutative pair)
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+// Wave sum that lands in lane 63, built from DPP row shifts / row broadcasts (VALU lane crossing, no LDS
+// round trips: six dependent steps of a few cycles each instead of six ds_bpermute round trips per 32-bit
+// half).  Fixed summation tree, hence deterministic.  Lanes other than 63 hold partial sums.
+#ifndef DPGO_DPP_REDUCE
+#define DPGO_DPP_REDUCE 1
+#endif
+template <int CTRL, int ROW_MASK, int BANK_MASK>
+__device__ __forceinline__ double dpp_shifted(double v) {
+  // lanes without a source (or masked off) receive 0.0
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, BANK_MASK, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, BANK_MASK, false);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_reduce_lane63(double v) {
+  double s = v;
+  s += dpp_shifted<0x111, 0xf, 0xf>(v);  // row_shr:1
+  s += dpp_shifted<0x112, 0xf, 0xf>(v);  // row_shr:2
+  s += dpp_shifted<0x113, 0xf, 0xf>(v);  // row_shr:3   -> s[i] = v[i-3..i] within a row of 16
+  s += dpp_shifted<0x114, 0xf, 0xe>(s);  // row_shr:4, banks 1..3
+  s += dpp_shifted<0x118, 0xf, 0xc>(s);  // row_shr:8, banks 2..3 -> lane 15 of each row holds the row sum
+  s += dpp_shifted<0x142, 0xa, 0xf>(s);  // row_bcast:15 into rows 1 and 3
+  s += dpp_shifted<0x143, 0xc, 0xf>(s);  // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave sum
+  return s;
+}
+
+template <int K>
+__device__ __forceinline__ void block_allreduce(double (&v)[K], double* red /* >= kWaves*K */) {
+#if DPGO_DPP_REDUCE
+#pragma unroll
+  for (int k = 0; k < K; ++k) v[k] = wave_reduce_lane63(v[k]);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 63) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) red[(threadIdx.x >> 6) * K + k] = v[k];
+  }
+#else
+#pragma unroll
+  for (int k = 0; k < K; ++k) v[k] = wave_allreduce(v[k]);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) red[(threadIdx.x >> 6) * K + k] = v[k];
+  }
+#endif
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    double s = red[k];
+#pragma unroll
+    for (int w = 1; w < kWaves; ++w) s += red[w * K + k];
+    v[k] = s;
+  }
+}
+
+// Sum the per-workgroup partials of the previous kernel; identical result in every thread
+// of every workgroup.
+template <int K>
+__device__ __forceinline__ void load_partials(const double* __restrict__ p, int nb, double (&out)[K],
+                                              double* red) {
+#pragma unroll
+  for (int k = 0; k < K; ++k) out[k] = 0.0;
+  for (int i = threadIdx.x; i < nb; i += kBlock) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) out[k] += p[i * kNP + k];
+  }
+  block_allreduce<K>(out, red);
+}
+
+// Two-phase variant for latency-bound launches: the global loads are issued early (together with the other
+// independent loads of the kernel prologue) and reduced later.
+constexpr int kPartialTrips = kPartialCap / kBlock;
+template <int K>
+struct PartialRaw {
+  double v[kPartialTrips][K];
+};
+template <int K>
+__device__ __forceinline__ void partials_issue(const double* __restrict__ p, int nb, PartialRaw<K>& raw) {
+#pragma unroll
+  for (int t = 0; t < kPartialTrips; ++t) {
+    const int i = threadIdx.x + t * kBlock;
+#pragma unroll
+    for (int k = 0; k < K; ++k) raw.v[t][k] = (i < nb) ? p[i * kNP + k] : 0.0;
+  }
+}
+template <int K>
+__device__ __forceinline__ void partials_finish(const PartialRaw<K>& raw, double (&out)[K], double* red) {
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    double a = raw.v[0][k];
+#pragma unroll
+    for (int t = 1; t < kPartialTrips; ++t) a += raw.v[t][k];  // same order as load_partials
+    out[k] = a;
+  }
+  block_allreduce<K>(out, red);
+}
+
+template <int K>
+__device__ __forceinline__ void store_partials(double (&v)[K], double* __restrict__ p, double* red) {
+  block_allreduce<K>(v, red);
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) p[blockIdx.x * kNP + k] = v[k];
+  }
+}
+
+// ---------------------------------------------------------------- small dense pieces
+// Tangent projection of column c of W at Y (ROPTLIB Stiefel::ExtrProjection; the Euclidean
+// factor -- column D -- is untouched).  ys / ws: pose tiles in LDS ([col][R]).
+// Optionally returns s[a] = sym(Y^T W)[a][c].
+template <int D, int R>
+__device__ __forceinline__ void proj_col(const double* ys, const double* ws, int c, const double (&w)[R],
+                                         double (&out)[R], double (&s)[D]) {
+  if (c < D) {
+#pragma unroll
+    for (int a = 0; a < D; ++a) {
+      double p = 0.0, q = 0.0;
+#pragma unroll
+      for (int k = 0; k < R; ++k) {
+        p = fma(ys[a * R + k], ws[c * R + k], p);
+        q = fma(ws[a * R + k], ys[c * R + k], q);
+      }
+      s[a] = 0.5 * (p + q);
+    }
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+      double v = w[k];
+#pragma unroll
+      for (int a = 0; a < D; ++a) v = fma(-ys[a * R + k], s[a], v);
+      out[k] = v;
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < R; ++k) out[k] = w[k];
+#pragma unroll
+    for (int a = 0; a < D; ++a) s[a] = 0.0;
+  }
+}
+
+// Block-Jacobi: z[:,c] = sum_k v[:,k] * Dinv[k][c]   (Dinv symmetric; lane reads row c)
+template <int D, int R>
+__device__ __forceinline__ void jacobi_col(const double* vs /* LDS tile */, const double* __restrict__ dinv_row,
+                                           double (&z)[R]) {
+  constexpr int B = D + 1;
+#pragma unroll
+  for (int a = 0; a < R; ++a) z[a] = 0.0;
+#pragma unroll
+  for (int k = 0; k < B; ++k) {
+    const double dk = dinv_row[k];
+#pragma unroll
+    for (int a = 0; a < R; ++a) z[a] = fma(vs[k * R + a], dk, z[a]);
+  }
+}
+
+template <int R>
+__device__ __forceinline__ void load_col(const double* __restrict__ p, double (&v)[R]) {
+#pragma unroll
+  for (int a = 0; a < R; ++a) v[a] = p[a];
+}
+template <int R>
+__device__ __forceinline__ void store_col(double* __restrict__ p, const double (&v)[R]) {
+#pragma unroll
+  for (int a = 0; a < R; ++a) p[a] = v[a];
+}
+
+// ---------------------------------------------------------------- block-SpMM core
+// acc[:] = (V*Q)[i][c][:] = sum_j sum_k V_j[:,k] * Q[i,j][c][k]      (Q symmetric)
+// replaces Eigen's dense x RowMajor-sparse product in src/QuadraticProblem.cpp:33,39,46,53.
+//
+// Wave-cooperative: must be called by ALL 64 lanes (lanes without a row pass ok = false).  The B
+// lanes of a pose preload the row's first 2B column indices (one coalesced load each) and broadcast
+// them with ds_bpermute, which removes the dependent colidx -> tile load from every iteration of the
+// gather loop (the kernel is bound by that latency chain, not by HBM: tools/spmm_lab.hip, 27.2 -> 24.6 us
+// at 100k poses).  Each lane streams row c of the Q block (32 B for D = 3: the quad reads the 128-B
+// block exactly once, coalesced) and the full gathered tile V_j (160 B, L2-resident).
+struct RowIdx {
+  int t0, deg, ja, jb;
+};
+// Row pointer + preloaded column indices of pose i (wave-cooperative: call with all 64 lanes).
+template <int D, int SPLIT>
+__device__ __forceinline__ RowIdx row_idx_load(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colidx,
+                                               int i, int s, int c, bool ok) {
+  constexpr int B = D + 1, LPP = B * SPLIT;
+  constexpr int NJ = (SPLIT == 1) ? 2 : 1;
+  RowIdx ri;
+  const int lp = s * B + c;
+  ri.t0 = ok ? rowptr[i] : 0;
+  const int t1 = ok ? rowptr[i + 1] : 0;
+  ri.deg = t1 - ri.t0;
+  ri.ja = (lp < ri.deg) ? colidx[ri.t0 + lp] : 0;
+  ri.jb = (NJ == 2 && lp + LPP < ri.deg) ? colidx[ri.t0 + lp + LPP] : 0;
+  return ri;
+}
+
+template <int D, int R, int SPLIT>
+__device__ __forceinline__ void spmm_col_pre(const RowIdx& ri, const int32_t* __restrict__ colidx,
+                                             const double* __restrict__ vals, const double* __restrict__ V, int s,
+                                             int c, double (&acc)[R]) {
+  constexpr int B = D + 1, T = B * R, BB = B * B, LPP = B * SPLIT;
+  constexpr int NJ = (SPLIT == 1) ? 2 : 1;   // preloaded indices per lane
+  constexpr int NPRE = NJ * LPP;             // preloaded indices per pose (2B for SPLIT = 1)
+#pragma unroll
+  for (int a = 0; a < R; ++a) acc[a] = 0.0;
+  const int lane = threadIdx.x & 63;
+  const int lp = s * B + c;
+  const int gbase = lane - lp;
+  const int t0 = ri.t0, deg = ri.deg, t1 = ri.t0 + ri.deg;
+  const int ja = ri.ja, jb = ri.jb;
+  int maxdeg = deg;
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) maxdeg = max(maxdeg, __shfl_xor(maxdeg, o));
+  const int kmax = maxdeg < NPRE ? maxdeg : NPRE;
+  if constexpr (SPLIT > 1) {
+    // latency layout: the loads of two blocks are in flight together (same FMA order as the plain loop)
+    for (int k0 = 0; k0 < kmax; k0 += 2 * SPLIT) {
+      const int kA = k0 + s, kB = k0 + SPLIT + s;
+      const int jA = __shfl(ja, gbase + (kA < LPP ? kA : 0));
+      const int jB = __shfl(ja, gbase + (kB < LPP ? kB : 0));
+      const bool okA = kA < deg && kA < NPRE, okB = kB < deg && kB < NPRE;
+      double qa[B], qb[B], xa[T], xb[T];
+      if (okA) {
+        const double* __restrict__ q = vals + (size_t)(t0 + kA) * BB + c * B;
+        const double* __restrict__ x = V + (size_t)jA * T;
+#pragma unroll
+        for (int kk = 0; kk < B; ++kk) qa[kk] = q[kk];
+#pragma unroll
+        for (int e = 0; e < T; ++e) xa[e] = x[e];
+      }
+      if (okB) {
+        const double* __restrict__ q = vals + (size_t)(t0 + kB) * BB + c * B;
+        const double* __restrict__ x = V + (size_t)jB * T;
+#pragma unroll
+        for (int kk = 0; kk < B; ++kk) qb[kk] = q[kk];
+#pragma unroll
+        for (int e = 0; e < T; ++e) xb[e] = x[e];
+      }
+      if (okA) {
+#pragma unroll
+        for (int kk = 0; kk < B; ++kk) {
+#pragma unroll
+          for (int a = 0; a < R; ++a) acc[a] = fma(xa[kk * R + a], qa[kk], acc[a]);
+        }
+      }
+      if (okB) {
+#pragma unroll
+        for (int kk = 0; kk < B; ++kk) {
+#pragma unroll
+          for (int a = 0; a < R; ++a) acc[a] = fma(xb[kk * R + a], qb[kk], acc[a]);
+        }
+      }
+    }
+  } else
+  for (int k0 = 0; k0 < kmax; k0 += SPLIT) {
+    const int k = k0 + s;  // this slice's block
+    const int src = (k < LPP) ? k : k - LPP;
+    const int j = __shfl((NJ == 2 && k >= LPP) ? jb : ja, gbase + (src < LPP ? src : 0));
+    if (k < deg && k < NPRE) {
+      const double* __restrict__ q = vals + (size_t)(t0 + k) * BB + c * B;
+      const double* __restrict__ x = V + (size_t)j * T;
+      double qk[B];
+#pragma unroll
+      for (int kk = 0; kk < B; ++kk) qk[kk] = q[kk];
+#pragma unroll
+      for (int kk = 0; kk < B; ++kk) {
+#pragma unroll
+        for (int a = 0; a < R; ++a) acc[a] = fma(x[kk * R + a], qk[kk], acc[a]);
+      }
+    }
+  }
+  for (int t = t0 + NPRE + s; t < t1; t += SPLIT) {  // rows with more than NPRE blocks
+    const int j = colidx[t];
+    const double* __restrict__ q = vals + (size_t)t * BB + c * B;
+    const double* __restrict__ x = V + (size_t)j * T;
+    double qk[B];
+#pragma unroll
+    for (int kk = 0; kk < B; ++kk) qk[kk] = q[kk];
+#pragma unroll
+    for (int kk = 0; kk < B; ++kk) {
+#pragma unroll
+      for (int a = 0; a < R; ++a) acc[a] = fma(x[kk * R + a], qk[kk], acc[a]);
+    }
+  }
+  if (SPLIT > 1) {  // fixed-order tree over the slices; the sum lands in slice 0
+#pragma unroll
+    for (int o = SPLIT / 2; o >= 1; o >>= 1) {
+#pragma unroll
+      for (int a = 0; a < R; ++a) acc[a] += __shfl_down(acc[a], o * B);
+    }
+  }
+}
+
+template <int D, int R, int SPLIT>
+__device__ __forceinline__ void spmm_col(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colidx,
+                                         const double* __restrict__ vals, const double* __restrict__ V,
+                                         int i, int s, int c, bool ok, double (&acc)[R]) {
+  const RowIdx ri = row_idx_load<D, SPLIT>(rowptr, colidx, i, s, c, ok);
+  spmm_col_pre<D, R, SPLIT>(ri, colidx, vals, V, s, c, acc);
+}
+
+// ---------------------------------------------------------------- kernel arguments
+struct BsrDev {
+  const int32_t* rowptr;
+  const int32_t* colidx;
+  const double* vals;
+};
