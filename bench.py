@@ -44,6 +44,7 @@ def parse_args():
     ap.add_argument("--precond", default="jacobi", choices=["jacobi", "multilevel"],
                     help="tCG preconditioner: block-Jacobi (default) or the two-level multigrid cycle (blocks < 40k poses)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the sphere2500 side measurement (`also` field)")
     ap.add_argument("--cpu-budget-s", type=float, default=25.0)
     ap.add_argument("--spmm-reps", type=int, default=200)
     ap.add_argument("--agents-per-gpu", type=int, default=0, help="0 = auto (1 if one GPU, else 2)")
@@ -149,6 +150,41 @@ def cpu_baseline(meas_p, n, X_state, r, budget_s, precond="jacobi"):
                            "" if inner == max_inner else " (tCG capped at %d of 50, time scaled x%.2f)" % (inner, scale),
                            what),
                 tcg_iterations=iters, seconds=el, **extra)
+
+
+def secondary_single_agent(workload, r, precond, steps, warmup, settle):
+    """The same fixed-work measurement for a second, small workload (single agent, single GPU): BASELINE's metric is
+    quoted on sphere2500 as well as on the 100k grid.  Returns a small dict for the `also` field of the JSON line."""
+    import torch
+    import dpgo_amd
+    from dpgo_amd.agent import DeviceAgent, ExchangePlan, build_pose_graphs
+    meas, n, X0, desc = make_workload(workload, r)
+    ranges, graphs = build_pose_graphs(meas, n, 1, r)
+    ag = DeviceAgent(graphs, ExchangePlan(graphs), 0, X0, dpgo_amd.ROptParameters(precond=precond))
+    states, works, gns = [], [], []
+    for _ in range(settle + 1):
+        states.append(ag.X.clone())
+        res = ag.update()
+        works.append(res.tcg_iterations)
+        gns.append(res.gradNormInit)
+    k = max(i for i in range(len(works)) if works[i] >= 0.5 * works[0])
+    ag.X.copy_(states[k])
+    ag.snapshot()
+    for _ in range(warmup):
+        ag.restore()
+        ag.update()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    tcg = 0
+    for _ in range(steps):
+        ag.restore()
+        res = ag.update()
+        tcg += res.tcg_iterations
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    return dict(workload=desc, precond=precond, it_per_s=steps / el, ms_per_step=1e3 * el / steps,
+                tcg_iterations_per_step=tcg / steps, settle_iterations=k, gradnorm_before_step=gns[k],
+                gradnorm_after_step=res.gradNormOpt)
 
 
 def main():
@@ -338,6 +374,13 @@ def main():
         agent.restore()
         cpu = cpu_baseline(meas, n, agent.X.cpu().numpy(), r, args.cpu_budget_s, args.precond)
 
+    also = None
+    if rank == 0 and world == 1 and args.workload == "grid100k" and not args.no_secondary:
+        # sphere2500 (BASELINE configs[1]) with the default preconditioner and with the opt-in multilevel one
+        also = {"sphere2500": secondary_single_agent("sphere2500", r, "jacobi", args.steps, args.warmup, args.settle),
+                "sphere2500_multilevel": secondary_single_agent("sphere2500", r, "multilevel", args.steps, args.warmup,
+                                                                args.settle)}
+
     if rank == 0:
         out = {
             "metric": "rbcd_iterations_per_sec",
@@ -363,6 +406,7 @@ def main():
                        "poses_per_agent": n_local, "nnzb_per_agent": nnzb_local},
             "roofline": roofline,
             "cpu_baseline": cpu,
+            "also": also,
             "quality": {"settle_iterations": settled,
                         "cost_2f_trajectory": [c for c, _ in trajectory],
                         "gradnorm_trajectory": [g for _, g in trajectory],

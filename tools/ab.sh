@@ -2,7 +2,7 @@
 # usage: tools/ab.sh <workload> lib1.so lib2.so ...   -- interleaved A/B of kernel builds on one box
 W=$1; shift
 for rep in 1 2 3; do for L in "$@"; do
-DPGO_LIB=$PWD/$L timeout 300 python bench.py --workload $W --steps 10 --warmup 2 --no-cpu-baseline 2>/dev/null | tail -1 > /tmp/b.json
+DPGO_LIB=$PWD/$L timeout 300 python bench.py --workload $W --steps 10 --warmup 2 --no-cpu-baseline --no-secondary 2>/dev/null | tail -1 > /tmp/b.json
 python - <<PY
 import json
 j=json.load(open("/tmp/b.json")); t=j["quality"]["tcg_iterations_per_step_rank0"]

@@ -2,7 +2,7 @@
 # usage: tools/grid_sweep.sh "U1 H1" "U2 H2" ...  -- sweeps the launch caps of the two tCG kernels on one box (100k grid)
 for cfg in "$@"; do
 set -- $cfg
-DPGO_GRID_UPDATE=$1 DPGO_GRID_HESS=$2 timeout 300 python bench.py --steps 10 --warmup 2 --no-cpu-baseline 2>/dev/null | tail -1 > /tmp/b.json
+DPGO_GRID_UPDATE=$1 DPGO_GRID_HESS=$2 timeout 300 python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-secondary 2>/dev/null | tail -1 > /tmp/b.json
 python - <<PY
 import json
 j=json.load(open("/tmp/b.json")); t=j["quality"]["tcg_iterations_per_step_rank0"]

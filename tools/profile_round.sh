@@ -6,10 +6,10 @@ TAG=${1:-rXX}
 R=${GRAFT_REPO_ROOT:-$PWD}
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$TAG -o bench -- \
-  python $R/bench.py --no-cpu-baseline > $R/gpurun_out/prof_$TAG.log 2>&1
+  python $R/bench.py --no-cpu-baseline --no-secondary > $R/gpurun_out/prof_$TAG.log 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --output-format csv -d $R/gpurun_out/pmc_${TAG}_$c -o b -- \
-    python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --spmm-reps 5 > $R/gpurun_out/pmc_${TAG}_$c.log 2>&1
+    python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-secondary --spmm-reps 5 > $R/gpurun_out/pmc_${TAG}_$c.log 2>&1
 done
 cd $R
 python tools/summarize_prof.py stats gpurun_out/prof_$TAG gpurun_out/${TAG}_bench_kernel_stats.csv

@@ -1,7 +1,7 @@
 #!/bin/bash
 # usage: tools/size_sweep.sh  (on the GPU box): mid-size kernel / iteration times for DPGO_SPLIT variants
 for sp in 1 2 4; do for w in grid:50x50x5 grid:25x25x5 sphere2500; do
-DPGO_SPLIT=$sp timeout 200 python bench.py --workload $w --steps 10 --warmup 0 --no-cpu-baseline 2>/dev/null | tail -1 > /tmp/b.json
+DPGO_SPLIT=$sp timeout 200 python bench.py --workload $w --steps 10 --warmup 0 --no-cpu-baseline --no-secondary 2>/dev/null | tail -1 > /tmp/b.json
 python - <<PY
 import json
 j=json.load(open("/tmp/b.json"))
