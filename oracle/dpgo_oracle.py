@@ -378,6 +378,10 @@ def amg_default_k(n: int, b: int, max_coarse: int = 3200) -> int:
     k = 4
     while ((n + k - 1) // k) * b > max_coarse:
         k *= 2
+    # aggregates larger than 16 poses straddle the workgroup tiles of the fused cycle (16 poses in 3-D): prefer
+    # k = 16 with a larger coarse operator (<= 8192 unknowns, 268 MB in fp32) over the 9-launch fallback
+    if k > 16 and ((n + 15) // 16) * b <= 8192:
+        k = 16
     return k
 
 
