@@ -216,25 +216,45 @@ __global__ __launch_bounds__(kBlock) void k_ml_coarse_prolong(const float* __res
   constexpr int B = D + 1, T = B * R, BB = B * B;
   if (gate && (gate->tcg_done || gate->rtr_stop)) return;
   __shared__ double xc_s[B][R];
+  __shared__ double part_s[kWaves][B][R];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int N = nc * B;
   for (int a = blockIdx.x; a < nc; a += gridDim.x) {
-    if (wave < B) {
-      const float* __restrict__ m = M + (size_t)(a * B + wave) * N;
-      double acc[R];
+    // every wave takes a quarter of the columns and ALL B rows of this aggregate: one read of rc per workgroup
+    // (rc is 10x the bytes of a matrix row: read per row it dominated the L2 traffic of the cycle)
+    {
+      const float* __restrict__ m = M + (size_t)(a * B) * N;
+      double acc[B][R];
 #pragma unroll
-      for (int q = 0; q < R; ++q) acc[q] = 0.0;
-      for (int j = lane; j < N; j += 64) {
-        const double mv = (double)m[j];
+      for (int c = 0; c < B; ++c)
 #pragma unroll
-        for (int q = 0; q < R; ++q) acc[q] = fma(mv, rc[(size_t)j * R + q], acc[q]);
+        for (int q = 0; q < R; ++q) acc[c][q] = 0.0;
+      for (int j = wave * 64 + lane; j < N; j += kBlock) {
+        double rv[R];
+#pragma unroll
+        for (int q = 0; q < R; ++q) rv[q] = rc[(size_t)j * R + q];
+#pragma unroll
+        for (int c = 0; c < B; ++c) {
+          const double mv = (double)m[(size_t)c * N + j];
+#pragma unroll
+          for (int q = 0; q < R; ++q) acc[c][q] = fma(mv, rv[q], acc[c][q]);
+        }
       }
 #pragma unroll
-      for (int q = 0; q < R; ++q) acc[q] = wave_reduce_lane63(acc[q]);
-      if (lane == 63) {
+      for (int c = 0; c < B; ++c)
 #pragma unroll
-        for (int q = 0; q < R; ++q) xc_s[wave][q] = acc[q];
-      }
+        for (int q = 0; q < R; ++q) {
+          const double sum = wave_reduce_lane63(acc[c][q]);
+          if (lane == 63) part_s[wave][c][q] = sum;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < B * R) {  // fixed-order sum over the waves
+      const int c = threadIdx.x / R, q = threadIdx.x % R;
+      double sum = part_s[0][c][q];
+#pragma unroll
+      for (int w2 = 1; w2 < kWaves; ++w2) sum += part_s[w2][c][q];
+      xc_s[c][q] = sum;
     }
     __syncthreads();
     for (int tsk = threadIdx.x; tsk < k * B; tsk += kBlock) {  // (pose, row c) tasks of the aggregate
