@@ -70,6 +70,8 @@ SIGNATURES = {
     "dpgo_problem_set_edge_weights": ([_P, _P], _I),
     "dpgo_problem_get_edge_weights": ([_P, _P, _P], _I),
     "dpgo_problem_get_Q_values": ([_P, _P], _I),
+    "dpgo_multilevel_default_k": ([_I, _I], _I),
+    "dpgo_build_multilevel": ([_I, _I, _P, _P, _P, _D, _I, _P, _P], _I),
     "dpgo_problem_set_multilevel": ([_P, _I, _P, _P, _D, _D], _I),
     "dpgo_problem_set_G": ([_P, _P], _I),
     "dpgo_problem_set_G_device": ([_P, _P], _I),

@@ -179,6 +179,13 @@ int dpgo_problem_get_Q_values(dpgo_problem_t h, double* vals_host);
  * Host memory; call again after Q's values change (set_Q_*, update_Q_values and the GNC re-weighting drop it). */
 int dpgo_problem_set_multilevel(dpgo_problem_t h, int k, const double* P_blocks, const double* AcInv, double omega,
                                 double shift);
+/* Host setup of that hierarchy from Q's block-CSR arrays (no GPU code; the analogue of
+ * PoseGraph::constructPreconditioner).  k = aggregate size (dpgo_multilevel_default_k: smallest power of two >= 4
+ * with <= 3200 coarse unknowns, 16 preferred over larger ones).  P_blocks: n (d+1)^2 doubles out;
+ * AcInv: (ceil(n/k) (d+1))^2 doubles out (dense Cholesky inverse: O(N^3), seconds at N = 3200). */
+int dpgo_multilevel_default_k(int n, int d);
+int dpgo_build_multilevel(int d, int n, const int32_t* rowptr, const int32_t* colidx, const double* vals, double shift,
+                          int k, double* P_blocks, double* AcInv);
 
 /* PoseGraph::linearMatrix() (include/DPGO/PoseGraph.h:171): dense r x (d+1)n; NULL = zero */
 int dpgo_problem_set_G(dpgo_problem_t h, const double* G_host);

@@ -104,6 +104,10 @@ class ROptParameters {
   int RTR_iterations = 3;
   int RTR_tCG_iterations = 50;
   double RTR_initial_radius = 100;
+  // not in the reference struct: tCG preconditioner of the device path (DPGO_PRECOND_*).  The reference always uses
+  // the exact solve of Q + 0.1 I; BLOCK_JACOBI is this library's default, MULTILEVEL (QuadraticProblem::
+  // enableMultilevel) the closest stand-in for the exact solve on blocks below ~40k poses.
+  int precond = DPGO_PRECOND_BLOCK_JACOBI;
   dpgo_ropt_params to_c() const {
     dpgo_ropt_params c;
     dpgo_ropt_params_default(&c);
@@ -115,6 +119,7 @@ class ROptParameters {
     c.RTR_iterations = RTR_iterations;
     c.RTR_tCG_iterations = RTR_tCG_iterations;
     c.RTR_initial_radius = RTR_initial_radius;
+    c.precond = precond;
     return c;
   }
 };
@@ -304,6 +309,20 @@ class QuadraticProblem {
       check(dpgo_problem_set_G(h_, pose_graph_->linearMatrix().data()));
     else
       check(dpgo_problem_set_G(h_, nullptr));
+  }
+  // Host setup + upload of the optional two-level preconditioner for the CURRENT Q (the analogue of
+  // PoseGraph::constructPreconditioner, src/PoseGraph.cpp:598-613); call again after the measurements change.
+  // Returns the aggregate size used.  Then solve with ROptParameters::precond = DPGO_PRECOND_MULTILEVEL.
+  int enableMultilevel(double shift = 0.1, double omega = 0.7, int k = 0) {
+    refresh();
+    const auto& Q = pose_graph_->quadraticMatrix();
+    const int d = (int)dimension(), n = (int)num_poses(), b = d + 1;
+    if (k <= 0) k = dpgo_multilevel_default_k(n, d);
+    const size_t N = (size_t)((n + k - 1) / k) * b;
+    std::vector<double> Pb((size_t)n * b * b), inv(N * N);
+    check(dpgo_build_multilevel(d, n, Q.rowptr.data(), Q.colidx.data(), Q.vals.data(), shift, k, Pb.data(), inv.data()));
+    check(dpgo_problem_set_multilevel(h_, k, Pb.data(), inv.data(), omega, shift));
+    return k;
   }
   double f(const Matrix& Y) const {  // src/QuadraticProblem.cpp:29-35
     shape(Y);

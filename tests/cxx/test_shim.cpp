@@ -278,6 +278,27 @@ static int run() {
     REQUIRE(std::fabs(rc.weight(2.0) - (std::sqrt(4.0 * 2.0 / 4.0) - 1.0)) < 1e-15);
   }
 
+  // ---------------- optional multilevel preconditioner through the C++ mirror: same optimum as the default on the
+  // triangle graph (3 poses -> one aggregate: the coarse solve is exact on the kernel modes)
+  {
+    const int kk = problem.enableMultilevel();
+    REQUIRE(kk == 4);
+    ROptParameters pm;
+    pm.gradnorm_tol = 1e-9;
+    pm.RTR_iterations = 20;
+    pm.precond = DPGO_PRECOND_MULTILEVEL;
+    QuadraticOptimizer om(&problem, pm);
+    Matrix Tm = om.optimize(T0);
+    REQUIRE(om.getOptResult().success);
+    std::printf("multilevel: f %.3e -> %.3e (default precond: %.3e)\n", om.getOptResult().fInit, om.getOptResult().fOpt,
+                optimizer.getOptResult().fOpt);
+    REQUIRE(om.getOptResult().fOpt <= om.getOptResult().fInit * (1 + 1e-12) + 1e-12);
+    REQUIRE(std::fabs(om.getOptResult().fOpt - optimizer.getOptResult().fOpt) <= 1e-9);
+    double dm = 0;
+    for (size_t q = 0; q < Tm.rows() * Tm.cols(); ++q) dm = std::max(dm, std::fabs(Tm.data()[q] - Topt.data()[q]));
+    REQUIRE(dm <= 1e-5);
+  }
+
   // ---------------- error behaviour: shape mismatch is reported, not aborted
   try {
     problem.f(Matrix(2, 5));

@@ -318,3 +318,31 @@ def test_host_initialisations_match_oracle(oracle, name):
     R0 = Rg[0]
     assert np.abs(np.swapaxes(Te[:, :om.d, :], 1, 2) - R0.T @ Rg).max() < 1e-7
     assert np.abs(Te[:, om.d, :] - (tg - tg[0]) @ R0).max() < 1e-6 * max(1.0, np.abs(tg).max())
+
+
+@pytest.mark.parametrize("name", ["smallGrid3D", "kitti_00", "sphere2500"])
+def test_cxx_multilevel_setup_matches_python(name):
+    """dpgo_build_multilevel (host C++, what a C++ caller uses instead of dpgo_amd/multilevel.py): same aggregate-size
+    rule, same prolongation blocks, same coarse inverse (own dense Cholesky, no LAPACK) to 1e-9."""
+    import time
+    import dpgo_amd
+    from dpgo_amd import multilevel
+    import dpgo_amd.lib as L
+    lib = L.load()
+    pm, n = dpgo_amd.read_g2o_file(os.path.join(DATA, name + ".g2o"))
+    d = pm.d
+    pg = dpgo_amd.PoseGraph(0, d + 2, d)
+    pg.setMeasurements(pm)
+    rowptr, colidx, vals = pg.quadraticMatrix()
+    k = lib.dpgo_multilevel_default_k(n, d)
+    assert k == multilevel.default_aggregate_size(n, d + 1)
+    b, nc = d + 1, (n + k - 1) // k
+    Pb = np.zeros((n, b, b))
+    inv = np.zeros((nc * b, nc * b))
+    t0 = time.perf_counter()
+    L.check(lib.dpgo_build_multilevel(d, n, L.ptr(rowptr), L.ptr(colidx), L.ptr(vals), 0.1, k, L.ptr(Pb), L.ptr(inv)))
+    assert time.perf_counter() - t0 < 60
+    k2, Pb2, inv2 = multilevel.build(rowptr, colidx, vals, d, 0.1, k)
+    assert np.abs(Pb - Pb2).max() <= 1e-12
+    assert np.abs(inv - inv2).max() <= 1e-9 * np.abs(inv2).max()
+    assert np.abs(inv - inv.T).max() <= 1e-12 * np.abs(inv).max()
