@@ -20,6 +20,7 @@ class HostAgent:
         import torch
         self.O, self.plan, self.id, self.r, self.d = O, plan, my_id, r, d
         self.X = torch.tensor(np.ascontiguousarray(X0_tiles))
+        self.b = d + 1
         self.nbr = torch.zeros((max(len(plan.slots[my_id]), 1), d + 1, r), dtype=torch.float64)
         priv = O.Measurements.concat([om_local["odometry"], om_local["private"]])
         self.shared = om_local["shared"]
@@ -42,6 +43,10 @@ class HostAgent:
     def update(self):
         opt = self.O.QuadraticOptimizer(self._problem(), self.O.ROptParameters())
         self.X.copy_(__import__("torch").tensor(opt.optimize(self.X.numpy().copy())))
+
+    def getTrajectoryInGlobalFrame(self, anchor):
+        import torch
+        return torch.tensor(self.O.round_trajectory(self.X.numpy(), self.d, np.ascontiguousarray(np.asarray(anchor).T)))
 
     def local_terms(self):
         p = self._problem()
@@ -84,7 +89,11 @@ def _worker(rank, world, port, sweeps, out_dir, apr=1):
             trace.append((2 * f, g))
         s, e = ranges[mine[0]][0], ranges[mine[-1]][1]
         X = np.concatenate([local[a].X.numpy() for a in mine], axis=0)
-        np.savez(os.path.join(out_dir, "rank%d.npz" % rank), X=X, trace=np.array(trace), s=s, e=e)
+        # rounding in the frame of agent 0's first pose: the anchor is broadcast from its owner
+        anchor = cluster.global_anchor()
+        traj = cluster.trajectories_in_global_frame()
+        T = np.concatenate([traj[a].numpy() for a in mine], axis=0)
+        np.savez(os.path.join(out_dir, "rank%d.npz" % rank), X=X, trace=np.array(trace), s=s, e=e, anchor=anchor, T=T)
     finally:
         dist.destroy_process_group()
 
@@ -111,6 +120,11 @@ def test_two_rank_gloo_rbcd_matches_single_process_oracle(oracle, tmp_path, apr)
         X[int(z["s"]):int(z["e"])] = z["X"]
         traces.append(z["trace"])
     assert np.allclose(traces[0], traces[1], rtol=1e-13)  # both ranks see the same central numbers
+    z0, z1 = (np.load(os.path.join(str(tmp_path), "rank%d.npz" % k)) for k in range(2))
+    assert np.array_equal(z0["anchor"], z1["anchor"]) and np.array_equal(z0["anchor"].T, z0["X"][0])
+    Tall = np.concatenate([z0["T"], z1["T"]], axis=0)  # PGOAgent::getTrajectoryInGlobalFrame on every agent
+    assert np.abs(Tall - O.round_trajectory(X, 3, X[0])).max() <= 1e-12
+    assert np.abs(Tall[0, :3] - np.eye(3)).max() < 1e-12 and np.abs(Tall[0, 3]).max() < 1e-12
     assert np.abs(X - Xref).max() <= 1e-12
     assert abs(traces[0][0, 0] - 2 * central.f(X0)) <= 1e-10 * abs(2 * central.f(X0))
     assert abs(traces[0][0, 1] - central.rie_grad_norm(X0)) <= 1e-10 * central.rie_grad_norm(X0)
