@@ -346,3 +346,24 @@ def test_cxx_multilevel_setup_matches_python(name):
     assert np.abs(Pb - Pb2).max() <= 1e-12
     assert np.abs(inv - inv2).max() <= 1e-9 * np.abs(inv2).max()
     assert np.abs(inv - inv.T).max() <= 1e-12 * np.abs(inv).max()
+
+
+def test_python_mirror_rejects_bad_arguments_before_touching_the_device():
+    """The reference aborts on these through glog CHECKs (src/PoseGraph.cpp:19, src/QuadraticProblem.cpp:30-31,
+    src/PGOAgent.cpp:838-840); the mirror raises."""
+    import dpgo_amd
+    from dpgo_amd.trajectory import round_trajectory
+    with pytest.raises(ValueError):
+        dpgo_amd.PoseGraph(0, 2, 3)  # r < d
+    with pytest.raises(ValueError):
+        round_trajectory(np.zeros((5, 7)), 5, 3)  # columns not a multiple of d + 1
+    with pytest.raises(ValueError):
+        round_trajectory(np.zeros((5, 8)), 5, 3, anchor=np.zeros((5, 3)))  # anchor must be r x (d + 1)
+    with pytest.raises(KeyError):
+        dpgo_amd.ROptParameters(precond="cholesky").to_c()
+    pm, n = dpgo_amd.read_g2o_file(os.path.join(DATA, "tinyGrid3D.g2o"))
+    pg = dpgo_amd.PoseGraph(0, 5, 2)
+    with pytest.raises(ValueError):
+        pg.setMeasurements(pm)  # 3-D measurements into a 2-D graph
+    with pytest.raises(ValueError):
+        dpgo_amd.partition_contiguous(pm, n, n + 1)  # more robots than poses (examples/MultiRobotExample.cpp:74-77)
