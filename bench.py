@@ -99,9 +99,7 @@ def cpu_baseline(meas_p, n, X_state, r, budget_s, precond="jacobi"):
                         meas_p.fixedWeight)
     Q = O.construct_Q(n, d, om)
     X = np.ascontiguousarray(X_state)
-    # same tCG arithmetic as the device runs for a block of this size (pipelined scheme only when opted in)
-    mode = "pipelined" if (os.environ.get("DPGO_PIPE", "0") not in ("", "0") and n < 40000
-                           and ((d + 1) * r) % 2 == 0) else True
+    mode = True  # same tCG arithmetic as the device (H-direction recurrence)
     max_inner = 50
     CO = None
     if mode is True and precond == "jacobi":
@@ -124,7 +122,7 @@ def cpu_baseline(meas_p, n, X_state, r, budget_s, precond="jacobi"):
         extra = dict(spmm_ms_1core=1e3 * spmm_s,
                      spmm_GBs_1core=spmm_bytes(n, len(Q.colidx), d, r) / spmm_s / 1e9, host_cores=os.cpu_count())
     else:
-        prob = O.QuadraticProblem(Q, None, r, d, precond="jacobi" if precond == "jacobi" else "amg2")
+        prob = O.QuadraticProblem(Q, None, r, d, precond="jacobi" if precond == "jacobi" else "amg")
         EG = prob.euc_grad(X)
         S = prob.sym_ytg(X, EG)
         g = O.tangent_project(X, EG, d)

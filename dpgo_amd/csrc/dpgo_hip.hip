@@ -113,17 +113,23 @@ struct dpgo_problem_s {
   // work vectors
   double *x1 = nullptr, *x2 = nullptr, *g1 = nullptr, *g2 = nullptr, *eta = nullptr, *delta = nullptr,
          *Hd = nullptr, *rr = nullptr, *z = nullptr, *S1 = nullptr, *S2 = nullptr;
-  // pipelined tCG (small blocks): w = H z, m = P w, q = P H delta, t = H q
-  double *pw = nullptr, *pm = nullptr, *pm2 = nullptr, *pq = nullptr, *pt = nullptr;
-  bool pipe = false;
-  // two-level (aggregation multigrid) preconditioner, optional (dpgo_problem_set_multilevel)
-  bool ml_ready = false;
-  int ml_k = 0, ml_nc = 0;
+  // multilevel (aggregation multigrid) preconditioner: levels[0] = the pose level ... levels.back() = the dense level
+  struct MlLevel {
+    int n = 0;      // nodes
+    int k = 0;      // aggregate size towards the next level (0 on the dense level)
+    int split = 1;  // lane groups per node of this level's SpMM-family kernels
+    Bsr A;          // level >= 1: Galerkin operator (level 0: Q + shift I, never formed)
+    int32_t* slot_row = nullptr;  // level >= 1: block row of every slot of A
+    double *dinv = nullptr, *Pb = nullptr;            // smoother factors; prolongation blocks towards level + 1
+    double *r = nullptr, *x1 = nullptr, *x = nullptr;  // restricted residual, pre-smoothed iterate, corrected iterate
+  };
+  std::vector<MlLevel> ml;
+  std::vector<int32_t> h_rowptr, h_colidx;  // host copy of Q's block pattern (symbolic setup of the hierarchy)
+  bool ml_symbolic = false, ml_ready = false, ml_user_ks = false;
   double ml_omega = 0.7, ml_shift = 1e-1;
-  Bsr ml_P, ml_Pt;            // rectangular n x nc / nc x n
-  double* ml_Aneg = nullptr;  // -(Q + shift I) on Q's pattern
-  float* ml_inv = nullptr;    // dense coarse inverse, stored in fp32
-  double *ml_x1 = nullptr, *ml_res = nullptr, *ml_x = nullptr, *ml_rc = nullptr, *ml_xc = nullptr;
+  double* ml_dense = nullptr;  // inverse of the coarsest operator, row-major, leading dimension ml_lda
+  int ml_lda = 0;
+  double *ml_W = nullptr, *ml_Rx = nullptr;  // Gauss-Jordan panels (setup only)
   double* partials = nullptr;  // 5 regions of kPartialCap*kNP
   DevState* dstate = nullptr;  // 2 slots
   DevState* hstate = nullptr;  // pinned
@@ -203,12 +209,30 @@ int upload_bsr(Bsr& m, int nrows, int ncols, int nnzb, int b, const int32_t* row
   HIPC(hipMemcpyAsync(m.rowptr, rowptr, sizeof(int32_t) * (nrows + 1), hipMemcpyHostToDevice, s));
   if (nnzb > 0) {
     HIPC(hipMemcpyAsync(m.colidx, colidx, sizeof(int32_t) * nnzb, hipMemcpyHostToDevice, s));
-    HIPC(hipMemcpyAsync(m.vals, vals, sizeof(double) * (size_t)nnzb * b * b, hipMemcpyHostToDevice, s));
+    if (vals) HIPC(hipMemcpyAsync(m.vals, vals, sizeof(double) * (size_t)nnzb * b * b, hipMemcpyHostToDevice, s));
   }
   HIPC(hipStreamSynchronize(s));
   return DPGO_OK;
 }
 
+template <class Tp>
+int upload(Tp** dst, const Tp* src, size_t count, hipStream_t s) {
+  HIPC(hipMalloc(dst, sizeof(Tp) * (count > 0 ? count : 1)));
+  if (count > 0) HIPC(hipMemcpyAsync(*dst, src, sizeof(Tp) * count, hipMemcpyHostToDevice, s));
+  return DPGO_OK;
+}
+
+struct TmpDev {
+  std::vector<void*> ptrs;
+  ~TmpDev() {
+    for (auto q : ptrs) (void)hipFree(q);
+  }
+  int alloc(double** out, size_t bytes) {
+    HIPC(hipMalloc(out, bytes));
+    ptrs.push_back(*out);
+    return DPGO_OK;
+  }
+};
 int validate_bsr(int nrows, int ncols, int nnzb, const int32_t* rowptr, const int32_t* colidx, bool need_diag) {
   if (!rowptr || nnzb < 0 || (nnzb > 0 && !colidx)) return fail(DPGO_ERR_INVALID, "null BSR arrays");
   if (rowptr[0] != 0 || rowptr[nrows] != nnzb) return fail(DPGO_ERR_INVALID, "BSR rowptr does not span nnzb");
@@ -217,6 +241,8 @@ int validate_bsr(int nrows, int ncols, int nnzb, const int32_t* rowptr, const in
     bool diag = false;
     for (int t = rowptr[i]; t < rowptr[i + 1]; ++t) {
       if (colidx[t] < 0 || colidx[t] >= ncols) return fail(DPGO_ERR_INVALID, "BSR column index out of range");
+      if (t > rowptr[i] && colidx[t] <= colidx[t - 1])
+        return fail(DPGO_ERR_INVALID, "BSR column indices must be sorted and unique within a block row");
       if (colidx[t] == i) diag = true;
     }
     if (need_diag && !diag) return fail(DPGO_ERR_INVALID, "BSR block row without diagonal block");
@@ -317,34 +343,6 @@ int launch_tcg_hess(dpgo_problem_s* p, int first) {
   return DPGO_OK;
 }
 
-// one pipelined tCG launch; kind: 0 = iteration j >= 1, 1 = init, 2 = iteration 0.  Partial sums alternate
-// between the regions A and B (a launch reads what the previous one wrote).
-int launch_tcg_pipe(dpgo_problem_s* p, const double* dinv, int kind, bool in_is_B) {
-  const double* pin = in_is_B ? p->pB() : p->pA();
-  double* pout = in_is_B ? p->pA() : p->pB();
-  const int nb_in = (kind == 1) ? p->grid() : p->grid_s();  // init reads k_tcg_update's partials
-  // m is double-buffered with the same parity as the partial sums: init writes pm, iteration 0 reads pm ...
-  const double* m_in = in_is_B ? p->pm2 : p->pm;
-  double* m_out = in_is_B ? p->pm : p->pm2;
-  DISPATCH(p->d, p->r, {
-    if constexpr (Span<D, R, 1>::kOk) {
-      if (p->split == 4)
-        hipLaunchKernelGGL((k_tcg_pipe<D, R, 4>), dim3(p->grid_s()), dim3(kBlock), 0, p->stream, p->Q.dev(), p->x1,
-                           p->S1, dinv, m_in, m_out, p->z, p->pw, p->delta, p->Hd, p->pq, p->pt, p->eta, p->rr, pin, nb_in,
-                           pout, p->dstate + p->cur, p->dstate + (p->cur ^ 1), kind, p->n, p->hflag, p->gen);
-      else
-        hipLaunchKernelGGL((k_tcg_pipe<D, R, 2>), dim3(p->grid_s()), dim3(kBlock), 0, p->stream, p->Q.dev(), p->x1,
-                           p->S1, dinv, m_in, m_out, p->z, p->pw, p->delta, p->Hd, p->pq, p->pt, p->eta, p->rr, pin, nb_in,
-                           pout, p->dstate + p->cur, p->dstate + (p->cur ^ 1), kind, p->n, p->hflag, p->gen);
-    } else {
-      return fail(DPGO_ERR_STATE, "pipelined tCG needs an even tile size");
-    }
-  });
-  HIPC(hipGetLastError());
-  p->cur ^= 1;
-  return DPGO_OK;
-}
-
 int launch_retract(dpgo_problem_s* p, const double* X, const double* eta, double scale, double* X2,
                    const DevState* st) {
   DISPATCH(p->d, p->r, hipLaunchKernelGGL((k_retract<D, R>), dim3(p->grid()), dim3(kBlock), 0, p->stream, X, eta,
@@ -383,95 +381,275 @@ struct Counters {
   int spmm = 0;
 };
 
-// One ROPTLIB SolversTR::Run outer iteration: tCG + retraction + rho test.  State stays on the
-// device; the host polls the tCG "done" flag every `poll` inner iterations.
-// One cycle of the two-level preconditioner: z = proj_X(M^-1 r) with r = p->rr, X = Xdev; the partial <z, r> goes
-// to slot 1 of partial region `pout` (NULL: not needed).  `gate`: state record for early exit (may be NULL).
-int launch_ml_cycle(dpgo_problem_s* p, const double* Xdev, const double* r, double* z, double* pout,
-                    const DevState* gate) {
-  if (!p->ml_ready) return fail(DPGO_ERR_STATE, "multilevel preconditioner not set (dpgo_problem_set_multilevel)");
-  const int g = p->grid();
-  Bsr Aneg = p->Q;  // same pattern, negated + shifted values
-  Aneg.vals = p->ml_Aneg;
-  const int N = p->ml_nc * p->b;
-  const int gd = std::max(1, std::min(kMaxGrid, (N + kWaves - 1) / kWaves));
-  DISPATCH(p->d, p->r, {
-    hipLaunchKernelGGL((k_ml_presmooth<D, R>), dim3(g), dim3(kBlock), 0, p->stream, r, p->dinv, p->ml_omega, p->ml_x1,
-                       gate, p->n);
-  });
-  HIPC(hipGetLastError());
-  CHK(launch_spmm(p, Aneg, p->ml_x1, r, p->ml_res));                      // res = r - A x1
-  CHK(launch_spmm(p, p->ml_Pt, p->ml_res, nullptr, p->ml_rc, p->ml_nc));  // rc = P^T res
-  DISPATCH(p->d, p->r, {
-    (void)D;
-    hipLaunchKernelGGL((k_ml_dense_apply<R>), dim3(gd), dim3(kBlock), 0, p->stream, p->ml_inv, p->ml_rc, p->ml_xc, gate,
-                       N);
-  });
-  HIPC(hipGetLastError());
-  CHK(launch_spmm(p, p->ml_P, p->ml_xc, p->ml_x1, p->ml_x));  // x = x1 + P xc
-  CHK(launch_spmm(p, Aneg, p->ml_x, r, p->ml_res));          // res = r - A x
-  DISPATCH(p->d, p->r, {
-    hipLaunchKernelGGL((k_ml_finish<D, R>), dim3(g), dim3(kBlock), 0, p->stream, Xdev, p->ml_x, p->ml_res, r, p->dinv,
-                       p->ml_omega, z, pout, gate, p->n);
-  });
+// ---------------------------------------------------------------------------------------------------------
+// Multilevel preconditioner: hierarchy setup (symbolic on the host once per block pattern, numeric on the device
+// for every new set of Q values) and the per-iteration launches.  DESIGN.md section 5.
+int ml_tile(int b, int split) { return (64 / (b * split)) * kWaves; }
+int ml_level_split(int n) { return n < 40000 ? 4 : 1; }
+
+// Aggregate sizes per coarsening.  Every k must divide the workgroup tile of its level (fused restriction); the
+// coarsest operator is a dense inverse of at most kMlDense unknowns (Infinity-Cache resident), kMlDenseMax if that is
+// what it takes to get there in one coarsening; otherwise one more level.
+constexpr int kMlDense = 3200, kMlDenseMax = 6400;
+std::vector<int> ml_default_ks(int n, int b, int split0) {
+  std::vector<int> ks;
+  int cur = n, split = split0;
+  for (int guard = 0; guard < 16; ++guard) {
+    const int P = ml_tile(b, split);
+    int pick = 0;
+    for (int limit : {kMlDense, kMlDenseMax}) {
+      for (int k = 4; k <= P && !pick; ++k)
+        if (P % k == 0 && (long long)((cur + k - 1) / k) * b <= limit) pick = k;
+      if (pick) break;
+    }
+    if (pick) {
+      ks.push_back(pick);
+      return ks;
+    }
+    int k = 2;
+    for (int c = 2; c <= 8; ++c)
+      if (P % c == 0) k = c;
+    ks.push_back(k);
+    cur = (cur + k - 1) / k;
+    split = ml_level_split(cur);
+  }
+  return ks;
+}
+
+void ml_free(dpgo_problem_s* p) {
+  for (auto& L : p->ml) {
+    free_bsr(L.A);
+    void* ptrs[] = {L.slot_row, L.dinv, L.Pb, L.r, L.x1, L.x};
+    for (void* q : ptrs)
+      if (q) (void)hipFree(q);
+  }
+  p->ml.clear();
+  void* ptrs[] = {p->ml_dense, p->ml_W, p->ml_Rx};
+  for (void* q : ptrs)
+    if (q) (void)hipFree(q);
+  p->ml_dense = p->ml_W = p->ml_Rx = nullptr;
+  p->ml_lda = 0;
+  p->ml_symbolic = p->ml_ready = false;
+}
+
+// Symbolic setup: level sizes, block patterns of the Galerkin operators, buffers.
+int ml_symbolic_setup(dpgo_problem_s* p, const std::vector<int>& ks) {
+  ml_free(p);
+  if ((int)p->h_rowptr.size() != p->n + 1) return fail(DPGO_ERR_STATE, "multilevel: Q's block pattern is not set");
+  const int b = p->b, bb = b * b;
+  const size_t tb = sizeof(double) * p->T;
+  std::vector<int32_t> rowptr = p->h_rowptr, colidx = p->h_colidx;
+  int cur = p->n;
+  p->ml.resize(ks.size() + 1);
+  for (size_t l = 0; l <= ks.size(); ++l) {
+    auto& L = p->ml[l];
+    L.n = cur;
+    L.split = (l == 0) ? p->split : ml_level_split(cur);
+    L.k = (l < ks.size()) ? ks[l] : 0;
+    if (L.k) {
+      if (L.k < 2 || ml_tile(b, L.split) % L.k)
+        return fail(DPGO_ERR_INVALID, "multilevel: aggregate size must divide the workgroup tile of its level (" +
+                                          std::to_string(ml_tile(b, L.split)) + " nodes)");
+    }
+    if (l > 0) {
+      CHK(upload_bsr(L.A, cur, cur, (int)colidx.size(), b, rowptr.data(), colidx.data(), nullptr, p->stream));
+      std::vector<int32_t> srow(colidx.size());
+      for (int i = 0; i < cur; ++i)
+        for (int t = rowptr[i]; t < rowptr[i + 1]; ++t) srow[t] = i;
+      CHK(upload(&L.slot_row, srow.data(), srow.size(), p->stream));
+      HIPC(hipMalloc(&L.r, tb * cur));
+    }
+    if (L.k) {
+      if (l > 0) HIPC(hipMalloc(&L.dinv, sizeof(double) * (size_t)cur * bb));
+      HIPC(hipMalloc(&L.Pb, sizeof(double) * (size_t)cur * bb));
+      HIPC(hipMalloc(&L.x1, tb * cur));
+      HIPC(hipMalloc(&L.x, tb * cur));
+      // pattern of the next level: block columns j / k of the rows of every aggregate
+      const int k = L.k, nc = (cur + k - 1) / k;
+      std::vector<int32_t> crow(nc + 1, 0), ccol;
+      std::vector<int32_t> mark(nc, -1);
+      for (int a = 0; a < nc; ++a) {
+        const size_t first = ccol.size();
+        for (int i = a * k; i < std::min(cur, a * k + k); ++i)
+          for (int t = rowptr[i]; t < rowptr[i + 1]; ++t) {
+            const int c = colidx[t] / k;
+            if (mark[c] != a) {
+              mark[c] = a;
+              ccol.push_back(c);
+            }
+          }
+        std::sort(ccol.begin() + first, ccol.end());
+        crow[a + 1] = (int32_t)ccol.size();
+      }
+      rowptr.swap(crow);
+      colidx.swap(ccol);
+      cur = nc;
+    }
+  }
+  const int N = cur * b;
+  if (N > 16384) return fail(DPGO_ERR_INVALID, "multilevel: dense coarsest operator too large (" + std::to_string(N) +
+                                                   " unknowns): use more levels / larger aggregates");
+  p->ml_lda = ((N + kNB - 1) / kNB) * kNB;
+  HIPC(hipMalloc(&p->ml_dense, sizeof(double) * (size_t)p->ml_lda * p->ml_lda));
+  HIPC(hipMalloc(&p->ml_W, sizeof(double) * (size_t)p->ml_lda * kNB));
+  HIPC(hipMalloc(&p->ml_Rx, sizeof(double) * (size_t)p->ml_lda * kNB));
+  HIPC(hipStreamSynchronize(p->stream));
+  p->ml_symbolic = true;
+  return DPGO_OK;
+}
+
+int flat_grid(size_t items) {
+  size_t g = (items + kBlock - 1) / kBlock;
+  if (g < 1) g = 1;
+  return g < (size_t)kMaxGrid ? (int)g : kMaxGrid;
+}
+
+bool gj_use_mfma() {
+  if (const char* e = std::getenv("DPGO_GJ_MFMA")) return std::atoi(e) != 0;
+  return true;
+}
+
+// In-place inverse of the dense SPD lda x lda array M (lda a multiple of 64); W, Rx: lda x 64 panels.
+int dense_spd_inverse(hipStream_t s, double* M, int lda, double* W, double* Rx, bool mfma) {
+  const int nt = lda / kNB;
+  for (int kb = 0; kb < nt; ++kb) {
+    hipLaunchKernelGGL(k_gj_panel, dim3(nt), dim3(kBlock), 0, s, M, lda, kb, W, Rx);
+    if (mfma)
+      hipLaunchKernelGGL(k_gj_update<true>, dim3(nt, nt), dim3(kBlock), 0, s, M, lda, kb, W, Rx);
+    else
+      hipLaunchKernelGGL(k_gj_update<false>, dim3(nt, nt), dim3(kBlock), 0, s, M, lda, kb, W, Rx);
+  }
   HIPC(hipGetLastError());
   return DPGO_OK;
 }
 
-// Fused form: k_tcg_update already left x1 = w Dinv r in ml_x1; three launches finish the cycle.
-bool ml_fusable(const dpgo_problem_s* p) {
-  const int P = (64 / (p->b * p->split)) * kWaves;
-  if (const char* e = std::getenv("DPGO_ML_FUSED"))
-    if (std::atoi(e) == 0) return false;
-  return p->ml_ready && p->ml_k >= 1 && (P % p->ml_k) == 0;
+template <int D>
+int ml_numeric_setup_d(dpgo_problem_s* p) {
+  const int nl = (int)p->ml.size();
+  long long stride = 1;
+  for (int l = 0; l + 1 < nl; ++l) {
+    auto& L = p->ml[l];
+    auto& C = p->ml[l + 1];
+    const long long span = stride * L.k;
+    hipLaunchKernelGGL(k_ml_build_P<D>, dim3(flat_grid(C.n)), dim3(kBlock), 0, p->stream, p->Q.dev(), p->n, (int)stride,
+                       (int)span, L.Pb, C.n);
+    const BsrDev A = (l == 0) ? p->Q.dev() : L.A.dev();
+    hipLaunchKernelGGL(k_ml_galerkin<D>, dim3(flat_grid(C.A.nnzb)), dim3(kBlock), 0, p->stream, A,
+                       (l == 0) ? p->ml_shift : 0.0, L.Pb, L.k, L.n, C.slot_row, C.A.colidx, C.A.vals, C.A.nnzb);
+    if (C.k)  // smoother of the next level (level 0 uses the handle's block-Jacobi factors)
+      hipLaunchKernelGGL(k_build_dinv<D>, dim3(flat_grid(C.n)), dim3(kBlock), 0, p->stream, C.A.dev(), 0.0, C.dinv, C.n);
+    stride = span;
+  }
+  HIPC(hipGetLastError());
+  auto& Lc = p->ml.back();
+  const int lda = p->ml_lda, N = Lc.n * p->b;
+  HIPC(hipMemsetAsync(p->ml_dense, 0, sizeof(double) * (size_t)lda * lda, p->stream));
+  hipLaunchKernelGGL(k_dense_pad_identity, dim3(1), dim3(kBlock), 0, p->stream, p->ml_dense, lda, N);
+  hipLaunchKernelGGL(k_ml_dense_assemble<D>, dim3(flat_grid(Lc.A.nnzb)), dim3(kBlock), 0, p->stream, Lc.A.dev(),
+                     Lc.slot_row, p->ml_dense, lda, Lc.A.nnzb);
+  HIPC(hipGetLastError());
+  return dense_spd_inverse(p->stream, p->ml_dense, lda, p->ml_W, p->ml_Rx, gj_use_mfma());
 }
-int launch_ml_fused_tail(dpgo_problem_s* p, const DevState* gate) {
-  const int gs = p->grid_s();
-  const int gc = std::max(1, std::min(kMaxGrid, p->ml_nc));
-  DISPATCH(p->d, p->r, LAUNCH_SPLIT(p, k_ml_restrict, gs, p->Q.dev(), p->ml_x1, p->rr, p->ml_P.vals, p->ml_shift, p->ml_k,
-                                    p->ml_rc, gate, p->n));
-  HIPC(hipGetLastError());
-  DISPATCH(p->d, p->r, {
-    hipLaunchKernelGGL((k_ml_coarse_prolong<D, R>), dim3(gc), dim3(kBlock), 0, p->stream, p->ml_inv, p->ml_rc, p->ml_x1,
-                       p->ml_P.vals, p->ml_k, p->ml_x, gate, p->n, p->ml_nc);
-  });
-  HIPC(hipGetLastError());
-  DISPATCH(p->d, p->r, LAUNCH_SPLIT(p, k_ml_post, gs, p->Q.dev(), p->x1, p->ml_x, p->rr, p->dinv, p->ml_omega, p->ml_shift,
-                                    p->z, p->pB(), gate, p->n));
+
+// Numeric setup for the CURRENT values of Q (device only; redone after every re-weighting).
+int ml_numeric_setup(dpgo_problem_s* p) {
+  if (!p->ml_symbolic) return fail(DPGO_ERR_STATE, "multilevel: symbolic setup missing");
+  CHK(build_dinv(p, p->ml_shift));
+  if (p->d == 2)
+    CHK(ml_numeric_setup_d<2>(p));
+  else
+    CHK(ml_numeric_setup_d<3>(p));
+  p->ml_ready = true;
+  return DPGO_OK;
+}
+
+// Make the hierarchy match the handle's Q (lazily, like the reference's constructPreconditioner inside the first
+// PreConditioner call, src/PoseGraph.cpp:582-586).
+int ml_ensure(dpgo_problem_s* p, double shift) {
+  if (p->ml_ready && p->ml_shift == shift) return DPGO_OK;
+  if (!p->ml_symbolic) CHK(ml_symbolic_setup(p, ml_default_ks(p->n, p->b, p->split)));
+  p->ml_shift = shift;
+  return ml_numeric_setup(p);
+}
+
+// The launches of one cycle after the pre-smoothing step of level 0 (x1 = w Dinv r is in ml[0].x1):
+// z = proj_X(M^-1 r); partial sums <r,r>, <z,r> into `pout` (may be NULL).  `gate`: state record for early exit.
+int launch_ml_tail(dpgo_problem_s* p, const double* Xdev, const double* r, double* z, double* pout,
+                   const DevState* gate) {
+  const int nl = (int)p->ml.size();
+  auto A_of = [&](int l) { return l == 0 ? p->Q.dev() : p->ml[l].A.dev(); };
+  auto r_of = [&](int l) { return l == 0 ? r : (const double*)p->ml[l].r; };
+  auto grid_of = [&](const dpgo_problem_s::MlLevel& L) {
+    if (&L == &p->ml[0]) return p->grid_s();
+    const int P = ml_tile(p->b, L.split);
+    return std::max(1, std::min(kMaxGrid, (L.n + P - 1) / P));
+  };
+#define ML_SPLIT_LAUNCH(L, KERNEL, ...)                                                                  \
+  do {                                                                                                   \
+    const int g_ = grid_of(L);                                                                           \
+    if ((L).split == 4)                                                                                  \
+      hipLaunchKernelGGL((KERNEL<D, R, 4>), dim3(g_), dim3(kBlock), 0, p->stream, __VA_ARGS__);          \
+    else if ((L).split == 2)                                                                             \
+      hipLaunchKernelGGL((KERNEL<D, R, 2>), dim3(g_), dim3(kBlock), 0, p->stream, __VA_ARGS__);          \
+    else                                                                                                 \
+      hipLaunchKernelGGL((KERNEL<D, R, 1>), dim3(g_), dim3(kBlock), 0, p->stream, __VA_ARGS__);          \
+  } while (0)
+  for (int l = 0; l + 1 < nl; ++l) {  // down
+    auto& L = p->ml[l];
+    auto& C = p->ml[l + 1];
+    DISPATCH(p->d, p->r, ML_SPLIT_LAUNCH(L, k_ml_restrict, A_of(l), L.x1, r_of(l), L.Pb, l == 0 ? p->ml_shift : 0.0, L.k,
+                                         C.r, C.k ? C.dinv : (const double*)nullptr, p->ml_omega, C.x1, gate, L.n));
+  }
+  {  // dense level + prolongation
+    auto& L = p->ml[nl - 2];
+    auto& C = p->ml[nl - 1];
+    // balanced rounds: every workgroup takes the same number of coarsest nodes (a ragged last round would leave most
+    // of the chip idle while the dense inverse streams)
+    const int rounds = (C.n + kMaxGrid - 1) / kMaxGrid;
+    const int gc = std::max(1, (C.n + rounds - 1) / rounds);
+    DISPATCH(p->d, p->r, hipLaunchKernelGGL((k_ml_coarse_prolong<D, R>), dim3(gc), dim3(kBlock), 0, p->stream,
+                                            p->ml_dense, p->ml_lda, C.r, L.x1, L.Pb, L.k, L.x, gate, L.n, C.n));
+  }
+  for (int l = nl - 2; l >= 1; --l) {  // up
+    auto& L = p->ml[l];
+    auto& F = p->ml[l - 1];
+    DISPATCH(p->d, p->r, ML_SPLIT_LAUNCH(L, k_ml_post_mid, L.A.dev(), L.x, L.r, L.dinv, p->ml_omega, F.x1, F.Pb, F.k, F.x,
+                                         F.n, gate, L.n));
+  }
+  DISPATCH(p->d, p->r, ML_SPLIT_LAUNCH(p->ml[0], k_ml_post, p->Q.dev(), Xdev, p->ml[0].x, r, p->dinv, p->ml_omega,
+                                       p->ml_shift, z, pout, gate, p->n));
+#undef ML_SPLIT_LAUNCH
   HIPC(hipGetLastError());
   return DPGO_OK;
 }
 
+// Stand-alone application z = proj_X(M^-1 v) (QuadraticProblem::PreConditioner outside the tCG loop).
+int launch_ml_apply(dpgo_problem_s* p, const double* Xdev, const double* v, double* z) {
+  DISPATCH(p->d, p->r, hipLaunchKernelGGL((k_ml_presmooth<D, R>), dim3(p->grid()), dim3(kBlock), 0, p->stream, v, p->dinv,
+                                          p->ml_omega, p->ml[0].x1, (const DevState*)nullptr, p->n));
+  HIPC(hipGetLastError());
+  return launch_ml_tail(p, Xdev, v, z, nullptr, nullptr);
+}
+
+// One ROPTLIB SolversTR::Run outer iteration: tCG + retraction + rho test.  State stays on the device; the host
+// feeds tCG-step kernels just-in-time (or polls the state every `tcg_poll_interval` inner iterations).
 int rtr_outer_iteration(dpgo_problem_s* p, const dpgo_ropt_params* prm, const double* dinv, Counters& cnt,
                         bool poll_at_end) {
   p->gen += 1;
   const bool ml = prm->precond == DPGO_PRECOND_MULTILEVEL;
-  const bool mlf = ml && ml_fusable(p);
-  p->zr_from_post = mlf;
-  // multilevel: the update kernel's block-Jacobi z and its <z, r> partial are replaced by the cycle's (7 launches),
-  // or -- fused -- the update kernel writes the pre-smoothing step and three launches finish the cycle
+  p->zr_from_post = ml;
+  // multilevel: the update kernel writes the pre-smoothing step of level 0 instead of the block-Jacobi z; the cycle's
+  // last kernel produces z and the partial sums <r,r>, <z,r>
   auto update = [&](int first) -> int {
-    if (mlf) {
-      CHK(launch_tcg_update(p, dinv, first, p->ml_x1, p->ml_omega));
-      return launch_ml_fused_tail(p, p->dstate + p->cur);
+    if (ml) {
+      CHK(launch_tcg_update(p, dinv, first, p->ml[0].x1, p->ml_omega));
+      return launch_ml_tail(p, p->x1, p->rr, p->z, p->pB(), p->dstate + p->cur);
     }
-    CHK(launch_tcg_update(p, dinv, first));
-    if (ml) CHK(launch_ml_cycle(p, p->x1, p->rr, p->z, p->pB(), p->dstate + p->cur));
-    return DPGO_OK;
+    return launch_tcg_update(p, dinv, first);
   };
   CHK(update(1));
   const int max_inner = prm->RTR_tCG_iterations;
-  const bool pipe = p->pipe && max_inner > 0 && !ml;
-  // pipelined scheme: init launch (w0 = H z0, m0 = P w0), then ONE launch per iteration; `step` hides the scheme
-  int pipe_launches = 0;
-  if (pipe) CHK(launch_tcg_pipe(p, dinv, 1, /*in_is_B=*/true));  // k_tcg_update(first) wrote region B
   auto step = [&](int j) -> int {
-    if (pipe) {
-      // init read B and wrote A; iteration launch k reads A for even k, B for odd k
-      const bool in_is_B = (pipe_launches & 1) != 0;
-      pipe_launches += 1;
-      return launch_tcg_pipe(p, dinv, j == 0 ? 2 : 0, in_is_B);
-    }
     CHK(launch_tcg_hess(p, j == 0 ? 1 : 0));
     return update(0);
   };
@@ -494,9 +672,9 @@ int rtr_outer_iteration(dpgo_problem_s* p, const dpgo_ropt_params* prm, const do
   } else {
     // just-in-time feed: stay kAhead iterations ahead of the progress word the device publishes into
     // host-coherent memory; no synchronisation, no copy, at most kAhead wasted (early-exit) iterations
-    const int kAhead = ml ? 2 : 4;  // a multilevel iteration is 9 launches: waste fewer of them after tCG stops
-    int enq = 0;
-    const auto t_start = std::chrono::steady_clock::now();
+    const int kAhead = ml ? 2 : 4;  // a multilevel iteration is 5+ launches: waste fewer of them after tCG stops
+    int enq = 0, last_j = -1;
+    auto t_progress = std::chrono::steady_clock::now();
     while (true) {
       const unsigned long long w = __atomic_load_n(p->hflag, __ATOMIC_ACQUIRE);
       int dev_j = 0;
@@ -509,24 +687,23 @@ int rtr_outer_iteration(dpgo_problem_s* p, const dpgo_ropt_params* prm, const do
         }
       }
       if (enq >= max_inner) break;
+      if (dev_j != last_j) {  // the watchdog measures time WITHOUT progress, not time since the loop started
+        last_j = dev_j;
+        t_progress = std::chrono::steady_clock::now();
+      }
       if (enq < dev_j + kAhead) {
         CHK(step(enq));
         enq += 1;
       } else {
         __builtin_ia32_pause();
-        if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count() > 60.0) {
+        if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t_progress).count() > 60.0) {
           HIPC(hipStreamSynchronize(p->stream));  // surfaces a device fault instead of spinning forever
           return fail(DPGO_ERR_HIP, "tCG progress word did not advance for 60 s");
         }
       }
     }
   }
-  if (!done) {  // max_inner iterations enqueued and not (yet known to be) finished: one more prologue
-    if (pipe)
-      CHK(step(max_inner));  // applies the last convergence test / marks MAXITER
-    else
-      CHK(launch_tcg_hess(p, 0));
-  }
+  if (!done) CHK(launch_tcg_hess(p, 0));  // max_inner iterations enqueued, not (yet known to be) finished: last prologue
   if (p->saw_rtr_stop) return DPGO_OK;  // the previous outer iteration already met the stop test
   CHK(launch_retract(p, p->x1, p->eta, 1.0, p->x2, p->dstate + p->cur));
   CHK(launch_grad(p, p->x2, p->g2, p->S2, nullptr, p->dstate + p->cur));
@@ -549,10 +726,9 @@ int run_optimize(dpgo_problem_s* p, const dpgo_ropt_params* prm, dpgo_ropt_resul
     CHK(build_dinv(p, prm->precond_shift));
     dinv = p->dinv;
   } else if (prm->precond == DPGO_PRECOND_MULTILEVEL) {
-    if (!p->ml_ready) return fail(DPGO_ERR_STATE, "multilevel preconditioner not set (dpgo_problem_set_multilevel)");
-    if (prm->method != DPGO_METHOD_RTR) return fail(DPGO_ERR_UNSUPPORTED, "multilevel preconditioner: RTR only");
-    CHK(build_dinv(p, p->ml_shift));  // the smoother's block-Jacobi factor
-    dinv = p->dinv;
+    // built lazily for the current Q, like the reference's factor (src/PoseGraph.cpp:582-586)
+    CHK(ml_ensure(p, prm->precond_shift));
+    dinv = p->dinv;  // the smoother's block-Jacobi factors (same shift)
   } else if (prm->precond != DPGO_PRECOND_NONE) {
     return fail(DPGO_ERR_INVALID, "unknown preconditioner");
   }
@@ -609,7 +785,10 @@ int run_optimize(dpgo_problem_s* p, const dpgo_ropt_params* prm, dpgo_ropt_resul
     // gradientDescent(): src/QuadraticOptimizer.cpp:110-137 (one fixed-step preconditioned step)
     const double* step = p->g1;
     if (prm->RGD_use_preconditioner) {
-      CHK(launch_precond(p, p->x1, p->g1, dinv, p->z));
+      if (prm->precond == DPGO_PRECOND_MULTILEVEL)
+        CHK(launch_ml_apply(p, p->x1, p->g1, p->z));
+      else
+        CHK(launch_precond(p, p->x1, p->g1, dinv, p->z));
       step = p->z;
     }
     CHK(launch_retract(p, p->x1, step, -prm->RGD_stepsize, p->x2, nullptr));
@@ -665,12 +844,6 @@ int free_edges(dpgo_problem_s* p) {
   p->e_fixed = p->c_kind = nullptr;
   p->e_counts = nullptr;
   p->em = 0;
-  return DPGO_OK;
-}
-template <class Tp>
-int upload(Tp** dst, const Tp* src, size_t count, hipStream_t s) {
-  HIPC(hipMalloc(dst, sizeof(Tp) * (count > 0 ? count : 1)));
-  if (count > 0) HIPC(hipMemcpyAsync(*dst, src, sizeof(Tp) * count, hipMemcpyHostToDevice, s));
   return DPGO_OK;
 }
 int rebuild_vals(dpgo_problem_s* p, int nnzb, const int32_t* cptr, const int32_t* cedge, const uint8_t* ckind,
@@ -774,7 +947,7 @@ void dpgo_ropt_params_default(dpgo_ropt_params* p) {
   p->RTR_iterations = 3;
   p->RTR_tCG_iterations = 50;
   p->RTR_initial_radius = 100.0;
-  p->precond = DPGO_PRECOND_BLOCK_JACOBI;
+  p->precond = DPGO_PRECOND_MULTILEVEL;
   p->precond_shift = 1e-1;
   p->accept_tiny_decrease = 1;
   p->tcg_poll_interval = 0;
@@ -816,19 +989,6 @@ int dpgo_problem_create(dpgo_problem_t* out, int r, int d, int n, int device) {
       HIPC(hipMalloc(v, vb));
       HIPC(hipMemsetAsync(*v, 0, vb, p->stream));
     }
-    // opt-in (DPGO_PIPE=1): small blocks run the pipelined, one-launch-per-iteration tCG (five more vectors).
-    // +13 % on 2500..6250-pose blocks, but its recurrences amplify round-off on ill-conditioned graphs (a hub
-    // with dozens of edges: 1.5e-3 relative cost difference to the oracle after 59 tCG steps, against 1e-7 for
-    // the default scheme), so it is not the default.
-    p->pipe = false;
-    if (const char* e = std::getenv("DPGO_PIPE")) p->pipe = (std::atoi(e) != 0) && (p->split > 1) && ((p->T % 2) == 0);
-    if (p->pipe) {
-      double** pv[] = {&p->pw, &p->pm, &p->pm2, &p->pq, &p->pt};
-      for (auto v : pv) {
-        HIPC(hipMalloc(v, vb));
-        HIPC(hipMemsetAsync(*v, 0, vb, p->stream));
-      }
-    }
     HIPC(hipMalloc(&p->S1, sizeof(double) * (size_t)n * d * d));
     HIPC(hipMalloc(&p->S2, sizeof(double) * (size_t)n * d * d));
     HIPC(hipMalloc(&p->dinv, sizeof(double) * (size_t)n * p->b * p->b));
@@ -855,17 +1015,10 @@ int dpgo_problem_destroy(dpgo_problem_t p) {
   if (p->own_stream) (void)hipStreamSynchronize(p->own_stream);
   free_bsr(p->Q);
   free_bsr(p->C);
-  free_bsr(p->ml_P);
-  free_bsr(p->ml_Pt);
-  {
-    double* mlb[] = {p->ml_Aneg, p->ml_x1, p->ml_res, p->ml_x, p->ml_rc, p->ml_xc};
-    for (auto q : mlb)
-      if (q) (void)hipFree(q);
-    if (p->ml_inv) (void)hipFree(p->ml_inv);
-  }
+  ml_free(p);
   free_edges(p);
   double* vecs[] = {p->x1, p->x2, p->g1, p->g2, p->eta, p->delta, p->Hd, p->rr, p->z, p->G, p->G0,
-                    p->S1, p->S2, p->dinv, p->partials, p->pw, p->pm, p->pm2, p->pq, p->pt};
+                    p->S1, p->S2, p->dinv, p->partials};
   for (auto v : vecs)
     if (v) (void)hipFree(v);
   if (p->dstate) (void)hipFree(p->dstate);
@@ -907,8 +1060,24 @@ int dpgo_problem_set_Q_bsr(dpgo_problem_t p, int nnzb, const int32_t* rowptr, co
   if (!vals) return fail(DPGO_ERR_INVALID, "null vals");
   CHK(validate_bsr(p->n, p->n, nnzb, rowptr, colidx, true));
   CHK(set_device(p));
+  // registered re-weightable edges index into the old pattern: drop them (the caller re-registers)
+  if (p->e_w) CHK(free_edges(p));
   CHK(upload_bsr(p->Q, p->n, p->n, nnzb, p->b, rowptr, colidx, vals, p->stream));
-  p->ml_ready = false;  // the multilevel hierarchy belongs to the old values
+  const bool same_pattern = (int)p->h_rowptr.size() == p->n + 1 && (int)p->h_colidx.size() == nnzb &&
+                            std::equal(rowptr, rowptr + p->n + 1, p->h_rowptr.begin()) &&
+                            std::equal(colidx, colidx + nnzb, p->h_colidx.begin());
+  if (!same_pattern) {
+    p->h_rowptr.assign(rowptr, rowptr + p->n + 1);
+    p->h_colidx.assign(colidx, colidx + nnzb);
+    if (p->ml_user_ks && p->ml_symbolic) {  // keep the caller's aggregate sizes across a pattern change
+      std::vector<int> ks;
+      for (size_t l = 0; l + 1 < p->ml.size(); ++l) ks.push_back(p->ml[l].k);
+      CHK(ml_symbolic_setup(p, ks));
+    } else {
+      ml_free(p);
+    }
+  }
+  p->ml_ready = false;  // the hierarchy's values belong to the old Q: rebuilt on the device at the next use
   p->dinv_shift = -1.0;
   CHK(build_dinv(p, 1e-1));  // src/PoseGraph.cpp:603
   HIPC(hipStreamSynchronize(p->stream));
@@ -1143,6 +1312,9 @@ int dpgo_problem_update_Q_values(dpgo_problem_t p, const double* vals) {
   if (!vals) return fail(DPGO_ERR_INVALID, "null vals");
   HIPC(hipMemcpyAsync(p->Q.vals, vals, sizeof(double) * (size_t)p->Q.nnzb * p->b * p->b, hipMemcpyHostToDevice,
                       p->stream));
+  // registered re-weightable edges: the constant part of Q is whatever the new values hold beyond the listed
+  // edges' contributions at the current weights
+  if (p->e_w) CHK(rebuild_Q_from_weights(p, p->Q.vals, -1.0, p->q_base));
   const double s = p->dinv_shift > 0 ? p->dinv_shift : 1e-1;
   p->dinv_shift = -1.0;  // PoseGraph::clearQuadraticMatrix also drops the preconditioner (src/PoseGraph.cpp:352-355)
   p->ml_ready = false;
@@ -1160,60 +1332,105 @@ int dpgo_problem_get_Q_values(dpgo_problem_t p, double* vals_host) {
   return DPGO_OK;
 }
 
-int dpgo_problem_set_multilevel(dpgo_problem_t p, int k, const double* P_blocks, const double* AcInv, double omega,
-                                double shift) {
+int dpgo_multilevel_default_ks(int n, int d, int* ks, int* nks) {
+  if (n <= 0 || d < 2 || d > 3 || !nks) return fail(DPGO_ERR_INVALID, "bad arguments");
+  int split = (n < 40000) ? 4 : 1;
+  if (const char* e = std::getenv("DPGO_SPLIT")) {
+    const int v = std::atoi(e);
+    if (v == 1 || v == 2 || v == 4) split = v;
+  }
+  const std::vector<int> v = ml_default_ks(n, d + 1, split);
+  if (ks)
+    for (size_t l = 0; l < v.size() && (int)l < *nks; ++l) ks[l] = v[l];
+  *nks = (int)v.size();
+  return DPGO_OK;
+}
+
+int dpgo_problem_setup_multilevel(dpgo_problem_t p, int nks, const int* ks, double omega, double shift) {
   CHK(check_ready(p));
-  if (k < 2 || !P_blocks || !AcInv || !(omega > 0.0) || !(shift >= 0.0))
+  if (nks < 0 || nks > 8 || (nks > 0 && !ks) || !(omega > 0.0) || !(shift >= 0.0))
     return fail(DPGO_ERR_INVALID, "bad multilevel arguments");
-  const int n = p->n, b = p->b, nc = (n + k - 1) / k;
-  const size_t N = (size_t)nc * b;
-  if (N > 16384)  // the coarse operator is a DENSE inverse: 1 GB in fp32 at 16384 unknowns, and it is read every cycle
-    return fail(DPGO_ERR_INVALID, "multilevel: coarse operator too large (choose k so that ceil(n/k) (d+1) <= 16384)");
-  // P: n x nc, one block per row;  P^T: nc x n, the aggregate's poses per row (blocks transposed)
-  std::vector<int32_t> prow(n + 1), pcol(n), trow(nc + 1), tcol(n);
-  std::vector<double> tvals((size_t)n * b * b);
-  for (int i = 0; i <= n; ++i) prow[i] = i;
-  for (int i = 0; i < n; ++i) {
-    pcol[i] = i / k;
-    tcol[i] = i;
-    for (int a = 0; a < b; ++a)
-      for (int c = 0; c < b; ++c) tvals[(size_t)i * b * b + a * b + c] = P_blocks[(size_t)i * b * b + c * b + a];
-  }
-  for (int a = 0; a <= nc; ++a) trow[a] = std::min(a * k, n);
-  CHK(upload_bsr(p->ml_P, n, nc, n, b, prow.data(), pcol.data(), P_blocks, p->stream));
-  CHK(upload_bsr(p->ml_Pt, nc, n, n, b, trow.data(), tcol.data(), tvals.data(), p->stream));
-  if (p->ml_inv) {
-    (void)hipFree(p->ml_inv);
-    p->ml_inv = nullptr;
-  }
-  double** bufs[] = {&p->ml_Aneg, &p->ml_x1, &p->ml_res, &p->ml_x, &p->ml_rc, &p->ml_xc};
-  for (auto q : bufs)
-    if (*q) {
-      (void)hipFree(*q);
-      *q = nullptr;
-    }
-  HIPC(hipMalloc(&p->ml_Aneg, sizeof(double) * (size_t)p->Q.nnzb * b * b));
-  HIPC(hipMalloc(&p->ml_inv, sizeof(float) * N * N));
-  HIPC(hipMalloc(&p->ml_x1, p->vec_bytes()));
-  HIPC(hipMalloc(&p->ml_res, p->vec_bytes()));
-  HIPC(hipMalloc(&p->ml_x, p->vec_bytes()));
-  HIPC(hipMalloc(&p->ml_rc, sizeof(double) * N * p->r));
-  HIPC(hipMalloc(&p->ml_xc, sizeof(double) * N * p->r));
-  std::vector<float> inv32(N * N);
-  for (size_t q = 0; q < N * N; ++q) inv32[q] = (float)AcInv[q];  // round to nearest, as numpy's astype(float32)
-  HIPC(hipMemcpyAsync(p->ml_inv, inv32.data(), sizeof(float) * N * N, hipMemcpyHostToDevice, p->stream));
-  const int g = std::max(1, std::min(kMaxGrid, (n + kBlock - 1) / kBlock));
-  if (p->d == 2)
-    hipLaunchKernelGGL(k_ml_neg_shift<2>, dim3(g), dim3(kBlock), 0, p->stream, p->Q.dev(), shift, p->ml_Aneg, n);
-  else
-    hipLaunchKernelGGL(k_ml_neg_shift<3>, dim3(g), dim3(kBlock), 0, p->stream, p->Q.dev(), shift, p->ml_Aneg, n);
-  HIPC(hipGetLastError());
-  HIPC(hipStreamSynchronize(p->stream));
-  p->ml_k = k;
-  p->ml_nc = nc;
+  std::vector<int> v = nks > 0 ? std::vector<int>(ks, ks + nks) : ml_default_ks(p->n, p->b, p->split);
+  bool same = p->ml_symbolic && p->ml.size() == v.size() + 1;
+  for (size_t l = 0; same && l < v.size(); ++l) same = p->ml[l].k == v[l];
+  if (!same) CHK(ml_symbolic_setup(p, v));
+  p->ml_user_ks = nks > 0;
   p->ml_omega = omega;
   p->ml_shift = shift;
-  p->ml_ready = true;
+  CHK(ml_numeric_setup(p));
+  HIPC(hipStreamSynchronize(p->stream));
+  return DPGO_OK;
+}
+
+int dpgo_problem_multilevel_info(dpgo_problem_t p, int* nlevels, int* sizes, int* ks, int* nnzb) {
+  if (!p) return fail(DPGO_ERR_INVALID, "null handle");
+  if (!p->ml_symbolic) return fail(DPGO_ERR_STATE, "multilevel hierarchy not set up");
+  const int cap = nlevels ? *nlevels : 0;
+  for (int l = 0; l < (int)p->ml.size() && l < cap; ++l) {
+    if (sizes) sizes[l] = p->ml[l].n;
+    if (ks) ks[l] = p->ml[l].k;
+    if (nnzb) nnzb[l] = (l == 0) ? p->Q.nnzb : p->ml[l].A.nnzb;
+  }
+  if (nlevels) *nlevels = (int)p->ml.size();
+  return DPGO_OK;
+}
+
+int dpgo_problem_multilevel_get(dpgo_problem_t p, int level, int what, void* out_host) {
+  CHK(check_ready(p));
+  if (!p->ml_ready) return fail(DPGO_ERR_STATE, "multilevel hierarchy not built");
+  if (!out_host || level < 0 || level >= (int)p->ml.size()) return fail(DPGO_ERR_INVALID, "bad level / null pointer");
+  auto& L = p->ml[level];
+  const int bb = p->b * p->b;
+  const void* src = nullptr;
+  size_t bytes = 0;
+  switch (what) {
+    case DPGO_ML_P_BLOCKS:
+      src = L.Pb, bytes = sizeof(double) * (size_t)L.n * bb;
+      break;
+    case DPGO_ML_A_ROWPTR:
+      src = L.A.rowptr, bytes = sizeof(int32_t) * ((size_t)L.n + 1);
+      break;
+    case DPGO_ML_A_COLIDX:
+      src = L.A.colidx, bytes = sizeof(int32_t) * (size_t)L.A.nnzb;
+      break;
+    case DPGO_ML_A_VALUES:
+      src = L.A.vals, bytes = sizeof(double) * (size_t)L.A.nnzb * bb;
+      break;
+    case DPGO_ML_DENSE_INVERSE: {
+      if (level + 1 != (int)p->ml.size()) return fail(DPGO_ERR_INVALID, "the dense inverse belongs to the last level");
+      const int N = L.n * p->b;  // the N x N corner of the padded lda x lda array
+      HIPC(hipMemcpy2DAsync(out_host, sizeof(double) * N, p->ml_dense, sizeof(double) * p->ml_lda, sizeof(double) * N, N,
+                            hipMemcpyDeviceToHost, p->stream));
+      HIPC(hipStreamSynchronize(p->stream));
+      return DPGO_OK;
+    }
+    default:
+      return fail(DPGO_ERR_INVALID, "unknown item");
+  }
+  if (!src) return fail(DPGO_ERR_INVALID, "this level does not hold that item");
+  HIPC(hipMemcpyAsync(out_host, src, bytes, hipMemcpyDeviceToHost, p->stream));
+  HIPC(hipStreamSynchronize(p->stream));
+  return DPGO_OK;
+}
+
+int dpgo_dense_spd_inverse(int N, const double* A_host, double* Ainv_host, int device, int use_mfma) {
+  if (N <= 0 || N > 16384 || !A_host || !Ainv_host) return fail(DPGO_ERR_INVALID, "bad arguments");
+  int cnt = 0;
+  CHK(dpgo_device_count(&cnt));
+  if (cnt <= 0) return fail(DPGO_ERR_HIP, "no HIP device (this library has no CPU fallback)");
+  if (device < 0 || device >= cnt) return fail(DPGO_ERR_INVALID, "device index out of range");
+  HIPC(hipSetDevice(device));
+  const int lda = ((N + kNB - 1) / kNB) * kNB;
+  TmpDev tmp;
+  double *M = nullptr, *W = nullptr, *Rx = nullptr;
+  CHK(tmp.alloc(&M, sizeof(double) * (size_t)lda * lda));
+  CHK(tmp.alloc(&W, sizeof(double) * (size_t)lda * kNB));
+  CHK(tmp.alloc(&Rx, sizeof(double) * (size_t)lda * kNB));
+  HIPC(hipMemset(M, 0, sizeof(double) * (size_t)lda * lda));
+  HIPC(hipMemcpy2D(M, sizeof(double) * lda, A_host, sizeof(double) * N, sizeof(double) * N, N, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(k_dense_pad_identity, dim3(1), dim3(kBlock), 0, (hipStream_t) nullptr, M, lda, N);
+  CHK(dense_spd_inverse(nullptr, M, lda, W, Rx, use_mfma != 0));
+  HIPC(hipMemcpy2D(Ainv_host, sizeof(double) * N, M, sizeof(double) * lda, sizeof(double) * N, N, hipMemcpyDeviceToHost));
   return DPGO_OK;
 }
 
@@ -1339,9 +1556,8 @@ int dpgo_problem_precondition(dpgo_problem_t p, int precond, double shift, const
     CHK(build_dinv(p, shift));
     dinv = p->dinv;
   } else if (precond == DPGO_PRECOND_MULTILEVEL) {
-    if (!p->ml_ready) return fail(DPGO_ERR_STATE, "multilevel preconditioner not set (dpgo_problem_set_multilevel)");
-    CHK(build_dinv(p, p->ml_shift));
-    CHK(launch_ml_cycle(p, p->x2, p->eta, p->g2, nullptr, nullptr));
+    CHK(ml_ensure(p, shift));
+    CHK(launch_ml_apply(p, p->x2, p->eta, p->g2));
     return d2h(p, Z, p->g2);
   } else if (precond != DPGO_PRECOND_NONE) {
     return fail(DPGO_ERR_INVALID, "unknown preconditioner");
@@ -1592,17 +1808,6 @@ int dpgo_bench_hess(dpgo_problem_t p, int reps, int warmup, double* avg_ms) {
 
 // ---- manifold ----
 namespace {
-struct TmpDev {
-  std::vector<void*> ptrs;
-  ~TmpDev() {
-    for (auto q : ptrs) (void)hipFree(q);
-  }
-  int alloc(double** out, size_t bytes) {
-    HIPC(hipMalloc(out, bytes));
-    ptrs.push_back(*out);
-    return DPGO_OK;
-  }
-};
 int manifold_args(int r, int d, int n, int device) {
   if (n <= 0 || r < d || d < 2 || d > 3) return fail(DPGO_ERR_INVALID, "need n > 0, r >= d, d in {2,3}");
   if (!supported(d, r)) return fail(DPGO_ERR_UNSUPPORTED, "(d, r) not compiled in");

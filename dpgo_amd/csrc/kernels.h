@@ -24,8 +24,8 @@ namespace dpgo {
 #include "kernels/common.h"
 #include "kernels/problem.h"
 #include "kernels/tcg.h"
-#include "kernels/tcg_pipe.h"
 #include "kernels/multilevel.h"
+#include "kernels/dense.h"
 #include "kernels/manifold.h"
 #include "kernels/rtr.h"
 #include "kernels/agent.h"

@@ -1,5 +1,5 @@
 // kernels/manifold.h -- manifold operations: stand-alone preconditioner / projection, qf retraction, polar projection, rounding to SE(d).
-// Part of kernels.h (included inside namespace dpgo, in this order: common.h, problem.h, tcg.h, tcg_pipe.h, multilevel.h, manifold.h, rtr.h, agent.h).
+// Part of kernels.h (included inside namespace dpgo, in this order: common.h, problem.h, tcg.h, multilevel.h, dense.h, manifold.h, rtr.h, agent.h).
 #pragma once
 
 // ================================================================ K6: preconditioner (stand-alone)
@@ -202,6 +202,12 @@ __global__ __launch_bounds__(kBlock) void k_axpby_project(double a, const double
               }
             }
         }
+        // singular values are clamped at 1e-14 sigma_max: a rank-deficient block (which the reference's SVD maps to
+        // SOME finite U V^T) stays finite here too instead of dividing by zero
+        double lmax = 0.0;
+#pragma unroll
+        for (int k = 0; k < D; ++k) lmax = fmax(lmax, Cmat[k][k]);
+        const double lfloor = fmax(1e-28 * lmax, 1e-300);
         double F[D];  // column c of F
 #pragma unroll
         for (int p = 0; p < D; ++p) {
@@ -211,7 +217,7 @@ __global__ __launch_bounds__(kBlock) void k_axpby_project(double a, const double
             double wck = 0.0;
 #pragma unroll
             for (int cc = 0; cc < D; ++cc) wck = (cc == L.c) ? W[cc][k] : wck;
-            s += W[p][k] * wck / sqrt(Cmat[k][k]);
+            s += W[p][k] * wck / sqrt(fmax(Cmat[k][k], lfloor));
           }
           F[p] = s;
         }

@@ -1,16 +1,20 @@
-// kernels/multilevel.h -- opt-in two-level (aggregation multigrid) preconditioner.
-// Part of kernels.h (included inside namespace dpgo, in this order: common.h, problem.h, tcg.h, tcg_pipe.h, multilevel.h, manifold.h, rtr.h, agent.h).
+// kernels/multilevel.h -- aggregation-multigrid preconditioner (the device path's default): per-iteration cycle kernels and
+// the on-device setup of the hierarchy (prolongation blocks, Galerkin operators, dense inverse of the coarsest operator).
+// Part of kernels.h (included inside namespace dpgo, in this order: common.h, problem.h, tcg.h, multilevel.h, dense.h, manifold.h, rtr.h, agent.h).
 #pragma once
 
-// ================================================================ two-level (aggregation multigrid) preconditioner
-// Optional replacement of the block-Jacobi solve inside QuadraticProblem::PreConditioner (the reference applies an
-// exact CHOLMOD solve of Q + 0.1 I there, src/QuadraticProblem.cpp:56-69).  One cycle for A = Q + shift I:
-//   x1 = w Dinv r;  rc = P^T (r - A x1);  xc = Ac^-1 rc;  x = x1 + P xc;  z = proj_X( x + w Dinv (r - A x) )
-// Aggregates are runs of k consecutive poses; P's blocks are relative poses composed along the odometry chain
-// (host setup, oracle: amg_prolongation_blocks); Ac = P^T A P is kept as a dense inverse in HBM (<= 3200 unknowns,
-// Infinity-Cache resident).  The four products with A, P, P^T run on the block-SpMM kernel (k_spmm with -A and the
-// rectangular P / P^T); the kernels below are the three pieces that are not an SpMM.  `gate`: the solver's state
-// record -- launches enqueued after tCG finished return at once.
+// ================================================================ multilevel preconditioner
+// Replaces the exact CHOLMOD solve of Q + 0.1 I inside QuadraticProblem::PreConditioner (src/QuadraticProblem.cpp:56-69;
+// factor built by PoseGraph::constructPreconditioner, src/PoseGraph.cpp:598-613) by one V(1,1) cycle for A_0 = Q + shift I:
+//   level l:  x1 = w Dinv_l r_l;  r_{l+1} = P_l^T (r_l - A_l x1);  xc = cycle_{l+1}(r_{l+1});  x = x1 + P_l xc;
+//             z_l = x + w Dinv_l (r_l - A_l x);        coarsest level: z = A_L^-1 r_L (dense inverse in HBM)
+// followed by the tangent projection (:68).  Level l+1's nodes are runs of k_l consecutive level-l nodes; P_l's blocks are
+// relative poses composed along the odometry chain (k_ml_build_P), A_{l+1} = P_l^T A_l P_l (k_ml_galerkin).
+// Launches per tCG iteration for L levels (L-1 coarsenings): k_tcg_hess | k_tcg_update (writes x1 of level 0) |
+// k_ml_restrict x (L-1) | k_ml_coarse_prolong | k_ml_post_mid x (L-2) | k_ml_post  =  2L + 1.
+// `gate`: the solver's state record -- launches enqueued after tCG finished return at once.
+
+// x1 = w Dinv v (stand-alone pre-smoothing step; inside the tCG loop k_tcg_update produces it)
 template <int D, int R>
 __global__ __launch_bounds__(kBlock) void k_ml_presmooth(const double* __restrict__ V, const double* __restrict__ dinv,
                                                          double omega, double* __restrict__ OUT,
@@ -42,130 +46,31 @@ __global__ __launch_bounds__(kBlock) void k_ml_presmooth(const double* __restric
   }
 }
 
-// z = proj_X( x + w Dinv res ),  partial <z, r> into slot 1 of the update kernel's partial-sum region (the launch
-// uses the update kernel's grid, so every workgroup entry is rewritten).
-template <int D, int R>
-__global__ __launch_bounds__(kBlock) void k_ml_finish(const double* __restrict__ X, const double* __restrict__ xv,
-                                                      const double* __restrict__ res, const double* __restrict__ r,
-                                                      const double* __restrict__ dinv, double omega,
-                                                      double* __restrict__ Z, double* __restrict__ pout,
-                                                      const DevState* __restrict__ gate, int n) {
-  using GEO = Geo<D, R>;
-  if (gate && (gate->tcg_done || gate->rtr_stop)) return;
-  __shared__ double sm[kWaves][3][GEO::G][GEO::T];
-  __shared__ double red[kWaves * kNP];
-  const LaneId L = lane_id<D>();
-  const int ntiles = (n + GEO::P - 1) / GEO::P;
-  const TileIter ti_ = tile_iter(ntiles);
-  double part[1] = {0.0};
-  for (int tile = ti_.first; tile < ti_.last; tile += ti_.step) {
-    const int i = tile * GEO::P + L.wave * GEO::G + L.g;
-    const bool ok = (L.g < GEO::G) && (i < n);
-    const size_t off = (size_t)i * GEO::T + L.c * R;
-    double* ys = ok ? &sm[L.wave][0][L.g][0] : nullptr;
-    double* vs = ok ? &sm[L.wave][1][L.g][0] : nullptr;
-    double* zs = ok ? &sm[L.wave][2][L.g][0] : nullptr;
-    double x[R], v[R], z[R];
-    if (ok) {
-      load_col<R>(X + off, x);
-      load_col<R>(res + off, v);
-      store_col<R>(ys + L.c * R, x);
-      store_col<R>(vs + L.c * R, v);
-    }
-    wave_sync();
-    if (ok) {
-      double xc[R];
-      load_col<R>(xv + off, xc);
-      jacobi_col<D, R>(vs, dinv + (size_t)i * GEO::BB + L.c * GEO::B, z);
-#pragma unroll
-      for (int a = 0; a < R; ++a) z[a] = fma(omega, z[a], xc[a]);
-      store_col<R>(zs + L.c * R, z);
-    }
-    wave_sync();
-    if (ok) {
-      double out[R], s[D], rr[R];
-      proj_col<D, R>(ys, zs, L.c, z, out, s);
-      store_col<R>(Z + off, out);
-      load_col<R>(r + off, rr);
-#pragma unroll
-      for (int a = 0; a < R; ++a) part[0] = fma(out[a], rr[a], part[0]);
-    }
-    wave_sync();
-  }
-  block_allreduce<1>(part, red);
-  if (threadIdx.x == 0 && pout) pout[blockIdx.x * kNP + 1] = part[0];
-}
-
-// Dense coarse solve: OUT (N x R, R contiguous) = M (N x N, row-major) * V (N x R).  One wave per output row;
-// M streams once (Infinity-Cache / HBM), V is re-read by every wave through L2.  M is STORED in fp32 (it is a
-// preconditioner: iteration counts are unchanged, the dominant stream of the cycle halves); accumulation is fp64.
-template <int R>
-__global__ __launch_bounds__(kBlock) void k_ml_dense_apply(const float* __restrict__ M, const double* __restrict__ V,
-                                                           double* __restrict__ OUT, const DevState* __restrict__ gate,
-                                                           int N) {
-  if (gate && (gate->tcg_done || gate->rtr_stop)) return;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int row = blockIdx.x * kWaves + wave; row < N; row += gridDim.x * kWaves) {
-    const float* __restrict__ m = M + (size_t)row * N;
-    double acc[R];
-#pragma unroll
-    for (int a = 0; a < R; ++a) acc[a] = 0.0;
-    for (int j = lane; j < N; j += 64) {
-      const double mv = (double)m[j];
-#pragma unroll
-      for (int a = 0; a < R; ++a) acc[a] = fma(mv, V[(size_t)j * R + a], acc[a]);
-    }
-#pragma unroll
-    for (int a = 0; a < R; ++a) acc[a] = wave_reduce_lane63(acc[a]);
-    if (lane == 63) {
-#pragma unroll
-      for (int a = 0; a < R; ++a) OUT[(size_t)row * R + a] = acc[a];
-    }
-  }
-}
-
-// vals_out = -(Q + shift I) on Q's pattern (the SpMM kernel then yields r - A v in one pass: OUT = v (-A) + r)
-template <int D>
-__global__ __launch_bounds__(kBlock) void k_ml_neg_shift(BsrDev Q, double shift, double* __restrict__ vals_out, int n) {
-  constexpr int B = D + 1, BB = B * B;
-  for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
-    for (int t = Q.rowptr[i]; t < Q.rowptr[i + 1]; ++t) {
-      const bool diag = Q.colidx[t] == i;
-#pragma unroll
-      for (int e = 0; e < BB; ++e) {
-        double v = -Q.vals[(size_t)t * BB + e];
-        if (diag && (e / B) == (e % B)) v -= shift;
-        vals_out[(size_t)t * BB + e] = v;
-      }
-    }
-  }
-}
-
-// ---------------------------------------------------------------- fused form of the cycle (5 launches per tCG iteration)
-// k_tcg_update(ml_omega) writes x1 = w Dinv r;  k_ml_restrict: rc = P^T (r - A x1) in one pass (needs aggregates that
-// do not straddle workgroup tiles: P % k == 0);  k_ml_coarse_prolong: xc = Ac^-1 rc and x = x1 + P xc, one workgroup
-// per aggregate;  k_ml_post: z = proj_X(x + w Dinv (r - A x)) in the SpMM's epilogue, with the partial sums <r,r>, <z,r>
-// for the next k_tcg_hess (slots 0 and 1 of every entry of ITS grid).
+// Restriction of level l:  rc = P^T (r - (A + shift I) x1)  in one pass over A (needs aggregates that do not straddle
+// workgroup tiles: GEO::P % k == 0).  With `dinv_next` (the next level is not the dense one) the pre-smoothing step of
+// level l+1, x1c = w Dinv_{l+1} rc, rides in the epilogue.
 template <int D, int R, int SPLIT>
-__global__ __launch_bounds__(kBlock) void k_ml_restrict(BsrDev Q, const double* __restrict__ x1,
+__global__ __launch_bounds__(kBlock) void k_ml_restrict(BsrDev A, const double* __restrict__ x1,
                                                         const double* __restrict__ r, const double* __restrict__ Pb,
                                                         double shift, int k, double* __restrict__ rc,
-                                                        const DevState* __restrict__ gate, int n) {
+                                                        const double* __restrict__ dinv_next, double omega,
+                                                        double* __restrict__ x1c, const DevState* __restrict__ gate,
+                                                        int n) {
   using GEO = Geo<D, R, SPLIT>;
   if (gate && (gate->tcg_done || gate->rtr_stop)) return;
   __shared__ double res_s[kWaves][GEO::G][GEO::T];  // residual tiles (per wave)
-  __shared__ double t_s[GEO::P][GEO::T];            // P_i^T res_i of every pose of the workgroup tile
+  __shared__ double t_s[GEO::P][GEO::T];            // P_i^T res_i of every node of the workgroup tile
   const LaneId L = lane_id<D, SPLIT>();
   const int ntiles = (n + GEO::P - 1) / GEO::P;
   const TileIter ti_ = tile_iter(ntiles);
   for (int tile = ti_.first; tile < ti_.last; tile += ti_.step) {
-    const int lp = L.wave * GEO::G + L.g;  // pose slot inside the workgroup tile
+    const int lp = L.wave * GEO::G + L.g;  // node slot inside the workgroup tile
     const int i = tile * GEO::P + lp;
     const bool okp = (L.g < GEO::G) && (i < n);
     const bool ok = okp && (L.s == 0);
     const size_t off = (size_t)i * GEO::T + L.c * R;
     double h[R];
-    spmm_col<D, R, SPLIT>(Q.rowptr, Q.colidx, Q.vals, x1, i, L.s, L.c, okp, h);
+    spmm_col<D, R, SPLIT>(A.rowptr, A.colidx, A.vals, x1, i, L.s, L.c, okp, h);
     if (ok) {
       double xr[R], rr[R];
       load_col<R>(x1 + off, xr);
@@ -188,11 +93,12 @@ __global__ __launch_bounds__(kBlock) void k_ml_restrict(BsrDev Q, const double* 
           for (int a = 0; a < R; ++a) t[a] = fma(pv, res_s[L.wave][L.g][cc * R + a], t[a]);
         }
       }
-      store_col<R>(&t_s[lp][L.c * R], t);  // zeros for poses beyond n
+      store_col<R>(&t_s[lp][L.c * R], t);  // zeros for nodes beyond n
     }
     __syncthreads();
-    if (ok && (i % k) == 0) {  // the aggregate's first pose sums its members (all inside this tile)
-      double acc[R];
+    const bool head = ok && (i % k) == 0;  // the aggregate's first node sums its members (all inside this tile)
+    double acc[R];
+    if (head) {
 #pragma unroll
       for (int a = 0; a < R; ++a) acc[a] = 0.0;
       for (int m = 0; m < k && lp + m < GEO::P; ++m) {
@@ -202,13 +108,26 @@ __global__ __launch_bounds__(kBlock) void k_ml_restrict(BsrDev Q, const double* 
       store_col<R>(rc + (size_t)(i / k) * GEO::T + L.c * R, acc);
     }
     __syncthreads();
+    if (dinv_next) {  // kernel-uniform
+      if (head) store_col<R>(&t_s[lp][L.c * R], acc);  // the aggregate's B columns meet in its head's slot
+      wave_sync();                                     // the B lanes of one node sit in one wavefront
+      if (head) {
+        double z[R];
+        jacobi_col<D, R>(&t_s[lp][0], dinv_next + (size_t)(i / k) * GEO::BB + L.c * GEO::B, z);
+#pragma unroll
+        for (int a = 0; a < R; ++a) z[a] *= omega;
+        store_col<R>(x1c + (size_t)(i / k) * GEO::T + L.c * R, z);
+      }
+      __syncthreads();
+    }
   }
 }
 
-// One workgroup per aggregate a: waves 0..B-1 compute the B rows of xc_a = (Ac^-1 rc)_a, then the workgroup writes
-// x_i = x1_i + P_i xc_a for the aggregate's poses.
+// Coarsest level + prolongation to the level above it.  One workgroup per coarsest node a: its B rows of
+// xc = M rc (M = dense inverse, row-major with leading dimension lda), then x_i = x1_i + P_i xc_a for the aggregate's nodes.
 template <int D, int R>
-__global__ __launch_bounds__(kBlock) void k_ml_coarse_prolong(const float* __restrict__ M, const double* __restrict__ rc,
+__global__ __launch_bounds__(kBlock) void k_ml_coarse_prolong(const double* __restrict__ M, int lda,
+                                                              const double* __restrict__ rc,
                                                               const double* __restrict__ x1,
                                                               const double* __restrict__ Pb, int k,
                                                               double* __restrict__ x, const DevState* __restrict__ gate,
@@ -220,24 +139,37 @@ __global__ __launch_bounds__(kBlock) void k_ml_coarse_prolong(const float* __res
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int N = nc * B;
   for (int a = blockIdx.x; a < nc; a += gridDim.x) {
-    // every wave takes a quarter of the columns and ALL B rows of this aggregate: one read of rc per workgroup
-    // (rc is 10x the bytes of a matrix row: read per row it dominated the L2 traffic of the cycle)
+    // every wave takes a quarter of the columns and ALL B rows of this node: one read of rc per workgroup
+    // (rc is 10x the bytes of a matrix row: read per row it dominated the L2 traffic of the cycle).  A lane owns
+    // column PAIRS: 16-byte loads of the B matrix rows and of the 2R right-hand-side values, two pairs in flight per
+    // trip -- the 100k-pose block streams a 313 MB inverse through here and needs the bytes in flight to do it
     {
-      const float* __restrict__ m = M + (size_t)(a * B) * N;
+      const double* __restrict__ m = M + (size_t)(a * B) * lda;
       double acc[B][R];
 #pragma unroll
       for (int c = 0; c < B; ++c)
 #pragma unroll
         for (int q = 0; q < R; ++q) acc[c][q] = 0.0;
-      for (int j = wave * 64 + lane; j < N; j += kBlock) {
-        double rv[R];
+      const int npair = (N + 1) >> 1;  // lda is even and >= N: the matrix may be read one column past N (zeros)
+#pragma unroll 2
+      for (int j2 = wave * 64 + lane; j2 < npair; j2 += kBlock) {
+        dbl2 mv[B];
 #pragma unroll
-        for (int q = 0; q < R; ++q) rv[q] = rc[(size_t)j * R + q];
+        for (int c = 0; c < B; ++c) mv[c] = *reinterpret_cast<const dbl2*>(m + (size_t)c * lda + 2 * j2);
+        double rv[2 * R];
+        const bool full = 2 * j2 + 1 < N;
+#pragma unroll
+        for (int q = 0; q < R; ++q) {
+          rv[q] = rc[(size_t)(2 * j2) * R + q];
+          rv[R + q] = full ? rc[(size_t)(2 * j2 + 1) * R + q] : 0.0;
+        }
 #pragma unroll
         for (int c = 0; c < B; ++c) {
-          const double mv = (double)m[(size_t)c * N + j];
 #pragma unroll
-          for (int q = 0; q < R; ++q) acc[c][q] = fma(mv, rv[q], acc[c][q]);
+          for (int q = 0; q < R; ++q) {
+            acc[c][q] = fma(mv[c].x, rv[q], acc[c][q]);
+            acc[c][q] = fma(mv[c].y, rv[R + q], acc[c][q]);
+          }
         }
       }
 #pragma unroll
@@ -257,7 +189,7 @@ __global__ __launch_bounds__(kBlock) void k_ml_coarse_prolong(const float* __res
       xc_s[c][q] = sum;
     }
     __syncthreads();
-    for (int tsk = threadIdx.x; tsk < k * B; tsk += kBlock) {  // (pose, row c) tasks of the aggregate
+    for (int tsk = threadIdx.x; tsk < k * B; tsk += kBlock) {  // (node, row c) tasks of the aggregate
       const int i = a * k + tsk / B, c = tsk % B;
       if (i < n) {
         const double* __restrict__ pb = Pb + (size_t)i * BB + c * B;
@@ -275,6 +207,69 @@ __global__ __launch_bounds__(kBlock) void k_ml_coarse_prolong(const float* __res
   }
 }
 
+// Post-smoothing of an intermediate level l (0 < l < L-1) + prolongation to level l-1:
+//   z_a = x_a + w Dinv_a (r_a - (A x)_a);    xf_i = x1f_i + Pf_i z_a  for the kf level-(l-1) nodes i of aggregate a.
+template <int D, int R, int SPLIT>
+__global__ __launch_bounds__(kBlock) void k_ml_post_mid(BsrDev A, const double* __restrict__ xv,
+                                                        const double* __restrict__ r, const double* __restrict__ dinv,
+                                                        double omega, const double* __restrict__ x1f,
+                                                        const double* __restrict__ Pbf, int kf, double* __restrict__ xf,
+                                                        int nf, const DevState* __restrict__ gate, int n) {
+  using GEO = Geo<D, R, SPLIT>;
+  if (gate && (gate->tcg_done || gate->rtr_stop)) return;
+  __shared__ double sm[kWaves][2][GEO::G][GEO::T];
+  const LaneId L = lane_id<D, SPLIT>();
+  const int ntiles = (n + GEO::P - 1) / GEO::P;
+  const TileIter ti_ = tile_iter(ntiles);
+  for (int tile = ti_.first; tile < ti_.last; tile += ti_.step) {
+    const int i = tile * GEO::P + L.wave * GEO::G + L.g;
+    const bool okp = (L.g < GEO::G) && (i < n);
+    const bool ok = okp && (L.s == 0);
+    const size_t off = (size_t)i * GEO::T + L.c * R;
+    double* vs = ok ? &sm[L.wave][0][L.g][0] : nullptr;
+    double* zs = ok ? &sm[L.wave][1][L.g][0] : nullptr;
+    double h[R], xr[R], z[R];
+    spmm_col<D, R, SPLIT>(A.rowptr, A.colidx, A.vals, xv, i, L.s, L.c, okp, h);
+    if (ok) {
+      double rr[R];
+      load_col<R>(xv + off, xr);
+      load_col<R>(r + off, rr);
+#pragma unroll
+      for (int a = 0; a < R; ++a) h[a] = rr[a] - h[a];  // r - A x (the shift lives in A's values on coarse levels)
+      store_col<R>(vs + L.c * R, h);
+    }
+    wave_sync();
+    if (ok) {
+      jacobi_col<D, R>(vs, dinv + (size_t)i * GEO::BB + L.c * GEO::B, z);
+#pragma unroll
+      for (int a = 0; a < R; ++a) z[a] = fma(omega, z[a], xr[a]);
+      store_col<R>(zs + L.c * R, z);
+    }
+    wave_sync();
+    if (ok) {
+      for (int m = 0; m < kf; ++m) {
+        const int fi = i * kf + m;
+        if (fi < nf) {
+          const double* __restrict__ pb = Pbf + (size_t)fi * GEO::BB + L.c * GEO::B;
+          const size_t foff = (size_t)fi * GEO::T + L.c * R;
+          double out[R];
+          load_col<R>(x1f + foff, out);
+#pragma unroll
+          for (int cc = 0; cc < GEO::B; ++cc) {
+            const double pv = pb[cc];
+#pragma unroll
+            for (int a = 0; a < R; ++a) out[a] = fma(pv, zs[cc * R + a], out[a]);
+          }
+          store_col<R>(xf + foff, out);
+        }
+      }
+    }
+    wave_sync();
+  }
+}
+
+// Post-smoothing of level 0 in the SpMM's epilogue, tangent projection, and the partial sums <r,r>, <z,r> for the next
+// k_tcg_hess (slots 0 and 1 of every entry of ITS grid):  z = proj_X( x + w Dinv (r - (Q + shift I) x) ).
 template <int D, int R, int SPLIT>
 __global__ __launch_bounds__(kBlock) void k_ml_post(BsrDev Q, const double* __restrict__ X,
                                                     const double* __restrict__ xv, const double* __restrict__ r,
@@ -329,5 +324,162 @@ __global__ __launch_bounds__(kBlock) void k_ml_post(BsrDev Q, const double* __re
     }
     wave_sync();
   }
-  store_partials<2>(part, pout, red);
+  if (pout) store_partials<2>(part, pout, red);
+}
+
+// ================================================================ on-device setup of the hierarchy
+// (the analogue of PoseGraph::constructPreconditioner, src/PoseGraph.cpp:598-613; values-only: the coarse block
+// patterns are symbolic and built once per pattern of Q on the host)
+
+// Prolongation blocks of one coarsening.  One thread per PARENT node walks its `span` fine poses along the odometry
+// chain, composing G(parent root -> pose): the relative pose T = [R t; 0 1] of the edge i-1 -> i is read off
+// Q_{i-1,i} = -T Om = -[w kappa R, w tau t; 0, w tau] (src/DPGO_utils.cpp:307-329); a missing / zero-weight link restarts
+// the chain at the identity.  Every `stride`-th pose is the root of a child node c = i / stride:  Pb[c] = G^T.
+template <int D>
+__global__ __launch_bounds__(kBlock) void k_ml_build_P(BsrDev Q, int n_fine, int stride, int span,
+                                                       double* __restrict__ Pb, int n_parent) {
+  constexpr int B = D + 1, BB = B * B;
+  for (int a = blockIdx.x * kBlock + threadIdx.x; a < n_parent; a += gridDim.x * kBlock) {
+    double G[B][B];
+#pragma unroll
+    for (int p = 0; p < B; ++p)
+#pragma unroll
+      for (int q = 0; q < B; ++q) G[p][q] = (p == q) ? 1.0 : 0.0;
+    const long long first = (long long)a * span;
+    const long long last = (first + span < (long long)n_fine) ? first + span : (long long)n_fine;
+    for (long long il = first; il < last; ++il) {
+      const int i = (int)il;
+      if (il != first) {
+        int tb = -1;
+        for (int t = Q.rowptr[i - 1]; t < Q.rowptr[i]; ++t)
+          if (Q.colidx[t] == i) tb = t;
+        bool ok = tb >= 0;
+        double wt = 0.0, wk = 0.0;
+        const double* __restrict__ blk = Q.vals + (size_t)(tb >= 0 ? tb : 0) * BB;
+        if (ok) {
+          wt = -blk[D * B + D];
+#pragma unroll
+          for (int p = 0; p < D; ++p) wk = fma(blk[p * B], blk[p * B], wk);
+          wk = sqrt(wk);
+          ok = (wt > 0.0) && (wk > 0.0);
+        }
+        if (ok) {
+          double Tm[B][B], Gn[B][B];
+#pragma unroll
+          for (int p = 0; p < B; ++p)
+#pragma unroll
+            for (int q = 0; q < B; ++q) Tm[p][q] = (p == q) ? 1.0 : 0.0;
+#pragma unroll
+          for (int p = 0; p < D; ++p) {
+#pragma unroll
+            for (int q = 0; q < D; ++q) Tm[p][q] = -blk[p * B + q] / wk;
+            Tm[p][D] = -blk[p * B + D] / wt;
+          }
+#pragma unroll
+          for (int p = 0; p < B; ++p)
+#pragma unroll
+            for (int q = 0; q < B; ++q) {
+              double s = 0.0;
+#pragma unroll
+              for (int m = 0; m < B; ++m) s = fma(G[p][m], Tm[m][q], s);
+              Gn[p][q] = s;
+            }
+#pragma unroll
+          for (int p = 0; p < B; ++p)
+#pragma unroll
+            for (int q = 0; q < B; ++q) G[p][q] = Gn[p][q];
+        } else {
+#pragma unroll
+          for (int p = 0; p < B; ++p)
+#pragma unroll
+            for (int q = 0; q < B; ++q) G[p][q] = (p == q) ? 1.0 : 0.0;
+        }
+      }
+      if (i % stride == 0) {
+        double* __restrict__ out = Pb + (size_t)(i / stride) * BB;
+#pragma unroll
+        for (int p = 0; p < B; ++p)
+#pragma unroll
+          for (int q = 0; q < B; ++q) out[p * B + q] = G[q][p];
+      }
+    }
+  }
+}
+
+// Galerkin operator, values only:  Ac[a][bc] = sum_{i in a} sum_{j in bc} P_i^T (A_ij + [i == j] shift I) P_j.
+// One thread per coarse slot (its block row in slot_row) scans the k fine rows of aggregate a: fixed summation order.
+template <int D>
+__global__ __launch_bounds__(kBlock) void k_ml_galerkin(BsrDev A, double shift, const double* __restrict__ Pb, int k,
+                                                        int n_fine, const int32_t* __restrict__ slot_row,
+                                                        const int32_t* __restrict__ ccol, double* __restrict__ cvals,
+                                                        int cnnzb) {
+  constexpr int B = D + 1, BB = B * B;
+  for (int s = blockIdx.x * kBlock + threadIdx.x; s < cnnzb; s += gridDim.x * kBlock) {
+    const int a = slot_row[s], bc = ccol[s];
+    double acc[B][B];
+#pragma unroll
+    for (int p = 0; p < B; ++p)
+#pragma unroll
+      for (int q = 0; q < B; ++q) acc[p][q] = 0.0;
+    const int i1 = (a * k + k < n_fine) ? a * k + k : n_fine;
+    for (int i = a * k; i < i1; ++i) {
+      const double* __restrict__ Pi = Pb + (size_t)i * BB;
+      for (int t = A.rowptr[i]; t < A.rowptr[i + 1]; ++t) {
+        const int j = A.colidx[t];
+        if (j / k != bc) continue;
+        const double* __restrict__ av = A.vals + (size_t)t * BB;
+        const double* __restrict__ Pj = Pb + (size_t)j * BB;
+        double AP[B][B];
+#pragma unroll
+        for (int p = 0; p < B; ++p)
+#pragma unroll
+          for (int q = 0; q < B; ++q) {
+            double sv = 0.0;
+#pragma unroll
+            for (int m = 0; m < B; ++m) {
+              const double am = av[p * B + m] + ((j == i && p == m) ? shift : 0.0);
+              sv = fma(am, Pj[m * B + q], sv);
+            }
+            AP[p][q] = sv;
+          }
+#pragma unroll
+        for (int p = 0; p < B; ++p)
+#pragma unroll
+          for (int q = 0; q < B; ++q) {
+            double sv = acc[p][q];
+#pragma unroll
+            for (int m = 0; m < B; ++m) sv = fma(Pi[m * B + p], AP[m][q], sv);
+            acc[p][q] = sv;
+          }
+      }
+    }
+    double* __restrict__ out = cvals + (size_t)s * BB;
+#pragma unroll
+    for (int p = 0; p < B; ++p)
+#pragma unroll
+      for (int q = 0; q < B; ++q) out[p * B + q] = acc[p][q];
+  }
+}
+
+// Dense copy of the coarsest operator, symmetrised (0.5 (Ac + Ac^T), as the oracle), into a zero-filled lda x lda array
+// whose padding rows carry a unit diagonal (written by the host wrapper with a separate launch of k_dense_pad_identity).
+template <int D>
+__global__ __launch_bounds__(kBlock) void k_ml_dense_assemble(BsrDev A, const int32_t* __restrict__ slot_row,
+                                                              double* __restrict__ M, int lda, int nnzb) {
+  constexpr int B = D + 1, BB = B * B;
+  for (int s = blockIdx.x * kBlock + threadIdx.x; s < nnzb; s += gridDim.x * kBlock) {
+    const int a = slot_row[s], bc = A.colidx[s];
+    int st = -1;  // the transposed slot (bc, a); the pattern is symmetric
+    for (int t = A.rowptr[bc]; t < A.rowptr[bc + 1]; ++t)
+      if (A.colidx[t] == a) st = t;
+    const double* __restrict__ v = A.vals + (size_t)s * BB;
+    const double* __restrict__ vt = A.vals + (size_t)(st >= 0 ? st : s) * BB;
+#pragma unroll
+    for (int p = 0; p < B; ++p)
+#pragma unroll
+      for (int q = 0; q < B; ++q) {
+        const double w = (st >= 0) ? 0.5 * (v[p * B + q] + vt[q * B + p]) : v[p * B + q];
+        M[(size_t)(a * B + p) * lda + bc * B + q] = w;
+      }
+  }
 }

@@ -18,6 +18,7 @@ LIB_PATH = os.environ.get("DPGO_LIB") or os.path.join(_HERE, "libdpgo_hip.so")  
 OK, ERR_INVALID, ERR_HIP, ERR_UNSUPPORTED, ERR_STATE = 0, 1, 2, 3, 4
 METHOD_RTR, METHOD_RGD = 0, 1
 PRECOND_NONE, PRECOND_BLOCK_JACOBI, PRECOND_MULTILEVEL = 0, 1, 2
+ML_P_BLOCKS, ML_A_ROWPTR, ML_A_COLIDX, ML_A_VALUES, ML_DENSE_INVERSE = 0, 1, 2, 3, 4
 TCG_STATUS = ["NEGCURVTURE", "EXCREGION", "LCON", "SCON", "MAXITER"]
 
 
@@ -70,9 +71,11 @@ SIGNATURES = {
     "dpgo_problem_set_edge_weights": ([_P, _P], _I),
     "dpgo_problem_get_edge_weights": ([_P, _P, _P], _I),
     "dpgo_problem_get_Q_values": ([_P, _P], _I),
-    "dpgo_multilevel_default_k": ([_I, _I], _I),
-    "dpgo_build_multilevel": ([_I, _I, _P, _P, _P, _D, _I, _P, _P], _I),
-    "dpgo_problem_set_multilevel": ([_P, _I, _P, _P, _D, _D], _I),
+    "dpgo_multilevel_default_ks": ([_I, _I, _P, C.POINTER(_I)], _I),
+    "dpgo_problem_setup_multilevel": ([_P, _I, _P, _D, _D], _I),
+    "dpgo_problem_multilevel_info": ([_P, C.POINTER(_I), _P, _P, _P], _I),
+    "dpgo_problem_multilevel_get": ([_P, _I, _I, _P], _I),
+    "dpgo_dense_spd_inverse": ([_I, _P, _P, _I, _I], _I),
     "dpgo_problem_set_G": ([_P, _P], _I),
     "dpgo_problem_set_G_device": ([_P, _P], _I),
     "dpgo_problem_set_G_coupling": ([_P, _I, _I, _P, _P, _P, _P], _I),

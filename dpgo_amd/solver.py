@@ -38,7 +38,9 @@ class ROptParameters:
     RTR_tCG_iterations: int = 50
     RTR_initial_radius: float = 100.0
     # extensions
-    precond: str = "jacobi"  # "jacobi" (block-Jacobi of Q + shift I) | "multilevel" (two-level multigrid) | "none"
+    # "multilevel" (aggregation-multigrid V-cycle for Q + shift I, the default: the stand-in for the reference's exact
+    # solve) | "jacobi" (block-Jacobi of Q + shift I) | "none"
+    precond: str = "multilevel"
     precond_shift: float = 1e-1  # src/PoseGraph.cpp:603
     accept_tiny_decrease: bool = True
     tcg_poll_interval: int = 0  # 0 = just-in-time feed (default); k > 0 = poll every k tCG iterations
@@ -324,6 +326,15 @@ class QuadraticProblem:
             L.check(self._lib.dpgo_problem_set_Q_bsr(self._h, len(colidx), L.ptr(rowptr), L.ptr(colidx), L.ptr(vals)))
             self._q_version = pg.q_version
             self._g_obj = None
+            # a new Q drops the device's re-weightable edge lists (they index the old values): register them again
+            if getattr(self, "reweightable_index", None) is not None and not getattr(self, "_in_reregister", False):
+                self._in_reregister = True
+                try:
+                    if self._reweight_shared:
+                        self.setCouplingFromPoseGraph()
+                    self.setReweightableEdges(self._reweight_shared)
+                finally:
+                    self._in_reregister = False
         has_shared = self._host_G and (len(pg.sharedLoopClosures()) > 0 or len(pg.priors_) > 0)
         if not self._host_G:
             return
@@ -365,11 +376,9 @@ class QuadraticProblem:
         L.check(self._lib.dpgo_problem_rie_hess(self._h, L.ptr(Xc), L.ptr(Vc), L.ptr(o)))
         return o
 
-    def PreConditioner(self, X, inVec, precond: str = "jacobi", shift: float = 1e-1) -> np.ndarray:  # :56-69
+    def PreConditioner(self, X, inVec, precond: str = "multilevel", shift: float = 1e-1) -> np.ndarray:  # :56-69
         Xc, Vc, o = self._in(X), self._in(inVec, "inVec"), self._out()
         pc = {"jacobi": L.PRECOND_BLOCK_JACOBI, "none": L.PRECOND_NONE, "multilevel": L.PRECOND_MULTILEVEL}[precond]
-        if precond == "multilevel":
-            self.ensureMultilevel(shift)
         L.check(self._lib.dpgo_problem_precondition(self._h, pc, shift, L.ptr(Xc), L.ptr(Vc), L.ptr(o)))
         return o
 
@@ -406,27 +415,51 @@ class QuadraticProblem:
         L.check(self._lib.dpgo_problem_update_G_from_neighbors_device(self._h, L.ptr(nbr_tiles_dev)))
         self._g_obj = None
 
-    # ---- optional two-level preconditioner (host setup once per Q, like PoseGraph::constructPreconditioner) ----
-    def ensureMultilevel(self, shift: float = 1e-1, k: int = 0, omega: float = 0.7) -> int:
-        """Build and upload the hierarchy for the current Q values if it is not there yet.  Returns k."""
+    # ---- multilevel preconditioner (built on the device; lazily by the first solve, like
+    # PoseGraph::constructPreconditioner inside the first PreConditioner call, src/PoseGraph.cpp:582-586) ----
+    def setupMultilevel(self, ks=None, omega: float = 0.7, shift: float = 1e-1) -> dict:
+        """Explicit setup for the current Q: ks = aggregate sizes per coarsening (None: the library's defaults).
+        Returns multilevelInfo()."""
         self.refresh()
-        key = (self.pose_graph_.q_version, float(shift), int(k), float(omega))
-        if getattr(self, "_ml_key", None) != key:
-            from . import multilevel
-            rowptr, colidx, vals = self.pose_graph_.quadraticMatrix()
-            vals = np.empty_like(vals)  # the device's values (GNC re-weights them in place), pattern from the host
-            L.check(self._lib.dpgo_problem_get_Q_values(self._h, L.ptr(vals)))
-            kk, Pb, AcInv = multilevel.build(rowptr, colidx, vals, self.dimension(), shift, k)
-            L.check(self._lib.dpgo_problem_set_multilevel(self._h, kk, L.ptr(Pb), L.ptr(AcInv), float(omega),
-                                                          float(shift)))
-            self._ml_key, self._ml_k = key, kk
-        return self._ml_k
+        ks = L.i32(ks if ks is not None else [])
+        L.check(self._lib.dpgo_problem_setup_multilevel(self._h, len(ks), L.ptr(ks) if len(ks) else None,
+                                                        float(omega), float(shift)))
+        return self.multilevelInfo()
+
+    def multilevelInfo(self) -> dict:
+        """{"sizes": nodes per level, "ks": aggregate size per coarsening, "nnzb": blocks of A_l per level}."""
+        cap = 16
+        nl = C.c_int(cap)
+        sizes, ks, nnzb = (np.zeros(cap, dtype=np.int32) for _ in range(3))
+        L.check(self._lib.dpgo_problem_multilevel_info(self._h, C.byref(nl), L.ptr(sizes), L.ptr(ks), L.ptr(nnzb)))
+        n = nl.value
+        return dict(sizes=[int(v) for v in sizes[:n]], ks=[int(v) for v in ks[:n - 1]], nnzb=[int(v) for v in nnzb[:n]])
+
+    def multilevelGet(self, level: int, what: str) -> np.ndarray:
+        """Copy of one item of the built hierarchy: "P" (prolongation blocks of a level), "rowptr" / "colidx" / "A"
+        (Galerkin operator of a level >= 1), "inverse" (dense inverse of the last level)."""
+        info = self.multilevelInfo()
+        b = self.dimension() + 1
+        n_l, nz = info["sizes"][level], info["nnzb"][level]
+        code, out = {"P": (L.ML_P_BLOCKS, np.zeros((n_l, b, b))),
+                     "rowptr": (L.ML_A_ROWPTR, np.zeros(n_l + 1, dtype=np.int32)),
+                     "colidx": (L.ML_A_COLIDX, np.zeros(nz, dtype=np.int32)),
+                     "A": (L.ML_A_VALUES, np.zeros((nz, b, b))),
+                     "inverse": (L.ML_DENSE_INVERSE, np.zeros((n_l * b, n_l * b)))}[what]
+        L.check(self._lib.dpgo_problem_multilevel_get(self._h, int(level), code, L.ptr(out)))
+        return out
 
     # ---- GNC re-weighting on the device (PGOAgent::updateMeasurementWeights, src/PGOAgent.cpp:1104-1142) ----
     def setReweightableEdges(self, include_shared: bool = False) -> int:
         """Register the pose graph's edges as re-weightable: private edges always, shared loop closures
         too when include_shared (needs setCouplingFromPoseGraph first).  Edge order = measurements() order
-        (optionally without the shared ones).  Returns the number of registered edges."""
+        (optionally without the shared ones).  Returns the number of registered edges.
+
+        On the agent path (include_shared) odometry edges are never re-weighted whatever their fixedWeight flag
+        says: PGOAgent::updateMeasurementWeights only walks activeLoopClosures() (src/PGOAgent.cpp:1104-1142;
+        PoseGraph::addOdometry keeps odometry apart, src/PoseGraph.cpp:73-77).  The single-agent solveRobustPGO
+        follows the flags alone (src/DPGO_solver.cpp:376-380)."""
+        self._reweight_shared = bool(include_shared)
         pg = self.pose_graph_
         m = pg.measurements()
         shared = m.r1 != m.r2
@@ -441,7 +474,10 @@ class QuadraticProblem:
                     role[e], slot[e] = 1, slot_index[(int(m.r2[e]), int(m.p2[e]))]
                 else:
                     role[e], slot[e] = 2, slot_index[(int(m.r1[e]), int(m.p1[e]))]
-        fixed = np.ascontiguousarray(m.fixedWeight, dtype=np.uint8)
+        fixed = np.asarray(m.fixedWeight, dtype=bool)
+        if include_shared:
+            fixed = fixed | ((m.r1 == m.r2) & (m.p1 + 1 == m.p2))
+        fixed = np.ascontiguousarray(fixed, dtype=np.uint8)
         w = np.ascontiguousarray(m.weight, dtype=np.float64)
         L.check(self._lib.dpgo_problem_set_reweightable_edges_ex(
             self._h, len(m), L.ptr(m.p1), L.ptr(m.p2), L.ptr(role), L.ptr(slot), L.ptr(m.R), L.ptr(m.t),
@@ -458,14 +494,11 @@ class QuadraticProblem:
         L.check(self._lib.dpgo_problem_gnc_reweight_device(
             self._h, L.ptr(X_dev), L.ptr(nbr_tiles_dev) if nbr_tiles_dev is not None else None, float(mu),
             float(barc), float(w_tol), int(update), C.byref(counts), C.byref(mx)))
-        if update:
-            self._ml_key = None  # Q's values changed on the device: the multilevel hierarchy is stale
         return tuple(counts), mx.value
 
     def setEdgeWeights(self, w: np.ndarray) -> None:
         w = np.ascontiguousarray(w, dtype=np.float64)
         L.check(self._lib.dpgo_problem_set_edge_weights(self._h, L.ptr(w)))
-        self._ml_key = None
 
     def getEdgeWeights(self):
         """(weights, squared residuals of the last gncReweightDevice) of the registered edges."""
@@ -519,8 +552,6 @@ class QuadraticOptimizer:
         Yc = p._in(Y)
         out = p._out()
         cp, cr = self.params_.to_c(), L.RoptResultC()
-        if self.params_.precond == "multilevel":
-            p.ensureMultilevel(self.params_.precond_shift)
         L.check(p._lib.dpgo_optimize(p._h, C.byref(cp), L.ptr(Yc), L.ptr(out), C.byref(cr)))
         self.result_ = ROPTResult.from_c(cr)
         return out
@@ -529,8 +560,6 @@ class QuadraticOptimizer:
         """Device-resident flavour: X_dev (torch tensor / device address) is updated in place."""
         p = self.problem_
         cp, cr = self.params_.to_c(), L.RoptResultC()
-        if self.params_.precond == "multilevel":
-            p.ensureMultilevel(self.params_.precond_shift)
         L.check(p._lib.dpgo_optimize_device(p._h, C.byref(cp), L.ptr(X_dev), C.byref(cr)))
         self.result_ = ROPTResult.from_c(cr)
         return self.result_

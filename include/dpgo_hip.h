@@ -49,7 +49,7 @@ extern "C" {
  * (same fixed point, different tCG trajectory). */
 #define DPGO_PRECOND_NONE 0
 #define DPGO_PRECOND_BLOCK_JACOBI 1
-#define DPGO_PRECOND_MULTILEVEL 2 /* two-level aggregation multigrid; needs dpgo_problem_set_multilevel */
+#define DPGO_PRECOND_MULTILEVEL 2 /* aggregation-multigrid V-cycle for Q + shift I (default; built on the device) */
 
 /* tCG termination status; replaces ROPTLIB::tCGstatusSet in ROPTResult
  * (include/DPGO/DPGO_types.h:106). */
@@ -72,7 +72,7 @@ typedef struct dpgo_ropt_params {
   int RTR_tCG_iterations;     /*                          default 50   */
   double RTR_initial_radius;  /*                          default 100  */
   /* --- extensions --- */
-  int precond;                /* DPGO_PRECOND_*           default BLOCK_JACOBI */
+  int precond;                /* DPGO_PRECOND_*           default MULTILEVEL */
   double precond_shift;       /* reference: 1e-1 (src/PoseGraph.cpp:603) */
   int accept_tiny_decrease;   /* ROPTLIB's second acceptance clause (SURVEY 8c' item 5), default 1 */
   int tcg_poll_interval;      /* 0 (default): just-in-time kernel feed driven by the progress word the
@@ -168,24 +168,35 @@ int dpgo_problem_get_edge_weights(dpgo_problem_t h, double* weight_host, double*
 
 /* Q's current values (nnzb blocks, same order as set_Q_bsr) -- they change on the device under GNC re-weighting. */
 int dpgo_problem_get_Q_values(dpgo_problem_t h, double* vals_host);
-/* Optional two-level (aggregation multigrid) preconditioner for precond = DPGO_PRECOND_MULTILEVEL: a much closer
- * stand-in for the reference's exact solve of Q + 0.1 I (src/PoseGraph.cpp:598-613, src/QuadraticProblem.cpp:56-69)
- * than block-Jacobi.  Aggregates are runs of k consecutive poses (the last may be shorter), nc = ceil(n / k).
- *   P_blocks : n blocks (d+1)x(d+1), row-major: the prolongation block of pose i (relative pose from the aggregate's
- *              first pose to pose i, transposed -- dpgo_amd/multilevel.py / oracle amg_prolongation_blocks)
- *   AcInv    : dense inverse of P^T (Q + shift I) P, (nc (d+1))^2 doubles, row-major (symmetric); kept on the device
- *              in fp32 (accumulation in fp64)
- *   omega    : damping of the block-Jacobi smoother;  shift: the reference's 0.1
- * Host memory; call again after Q's values change (set_Q_*, update_Q_values and the GNC re-weighting drop it). */
-int dpgo_problem_set_multilevel(dpgo_problem_t h, int k, const double* P_blocks, const double* AcInv, double omega,
-                                double shift);
-/* Host setup of that hierarchy from Q's block-CSR arrays (no GPU code; the analogue of
- * PoseGraph::constructPreconditioner).  k = aggregate size (dpgo_multilevel_default_k: smallest power of two >= 4
- * with <= 3200 coarse unknowns, 16 preferred over larger ones).  P_blocks: n (d+1)^2 doubles out;
- * AcInv: (ceil(n/k) (d+1))^2 doubles out (dense Cholesky inverse: O(N^3), seconds at N = 3200). */
-int dpgo_multilevel_default_k(int n, int d);
-int dpgo_build_multilevel(int d, int n, const int32_t* rowptr, const int32_t* colidx, const double* vals, double shift,
-                          int k, double* P_blocks, double* AcInv);
+/* Multilevel (aggregation multigrid) preconditioner, precond = DPGO_PRECOND_MULTILEVEL (the default): the device
+ * path's stand-in for the reference's exact solve of Q + 0.1 I inside QuadraticProblem::PreConditioner
+ * (src/QuadraticProblem.cpp:56-69; factor from PoseGraph::constructPreconditioner, src/PoseGraph.cpp:598-613).
+ * One V(1,1) cycle: damped block-Jacobi smoothing on every level, level l+1's nodes = runs of ks[l] consecutive
+ * level-l nodes, prolongation blocks = relative poses composed along the odometry chain (read off Q's own blocks),
+ * Galerkin coarse operators, dense inverse of the coarsest operator -- all fp64, all built ON THE DEVICE (the block
+ * patterns of the coarse operators are the only host step, once per pattern of Q).  The hierarchy is built lazily by
+ * the first solve that needs it and rebuilt (values only) after Q's values changed (set_Q_*, update_Q_values, GNC
+ * re-weighting), exactly where the reference drops its factor (src/PoseGraph.cpp:352-355,582-586).
+ *   dpgo_problem_setup_multilevel: explicit setup.  nks = 0: default aggregate sizes (dpgo_multilevel_default_ks);
+ *     otherwise nks coarsenings with the given sizes (each must divide the workgroup tile of its level:
+ *     16 nodes for levels below 40 000 nodes in 3-D, 64 above; 20 / 84 in 2-D).  omega: smoother damping (0.7);
+ *     shift: the reference's 0.1.  Explicit sizes stick to the handle until the next call.
+ *   dpgo_problem_multilevel_info: *nlevels in = capacity of the arrays, out = number of levels (coarsenings + 1);
+ *     sizes[l] = nodes, ks[l] = aggregate size towards level l+1 (0 on the last), nnzb[l] = blocks of A_l.
+ *   dpgo_problem_multilevel_get: copy one item of a built hierarchy to the host (tests / inspection). */
+#define DPGO_ML_P_BLOCKS 0      /* level < last: n_l blocks (d+1)x(d+1), row-major                  (double) */
+#define DPGO_ML_A_ROWPTR 1      /* level >= 1: n_l + 1                                              (int32)  */
+#define DPGO_ML_A_COLIDX 2      /* level >= 1: nnzb_l                                               (int32)  */
+#define DPGO_ML_A_VALUES 3      /* level >= 1: nnzb_l blocks, row-major                             (double) */
+#define DPGO_ML_DENSE_INVERSE 4 /* last level: (n_L (d+1))^2, row-major                             (double) */
+int dpgo_multilevel_default_ks(int n, int d, int* ks, int* nks); /* *nks in: capacity of ks, out: count */
+int dpgo_problem_setup_multilevel(dpgo_problem_t h, int nks, const int* ks, double omega, double shift);
+int dpgo_problem_multilevel_info(dpgo_problem_t h, int* nlevels, int* sizes, int* ks, int* nnzb);
+int dpgo_problem_multilevel_get(dpgo_problem_t h, int level, int what, void* out_host);
+/* In-place blocked Gauss-Jordan inverse of a dense SPD matrix on the device (the kernel pair that inverts the coarsest
+ * operator; exposed for tests).  N <= 16384, row-major host arrays; use_mfma: fp64 matrix cores for the rank-64
+ * updates (v_mfma_f64_16x16x4_f64) or plain FMAs. */
+int dpgo_dense_spd_inverse(int N, const double* A_host, double* Ainv_host, int device, int use_mfma);
 
 /* PoseGraph::linearMatrix() (include/DPGO/PoseGraph.h:171): dense r x (d+1)n; NULL = zero */
 int dpgo_problem_set_G(dpgo_problem_t h, const double* G_host);

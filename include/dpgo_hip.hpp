@@ -105,9 +105,9 @@ class ROptParameters {
   int RTR_tCG_iterations = 50;
   double RTR_initial_radius = 100;
   // not in the reference struct: tCG preconditioner of the device path (DPGO_PRECOND_*).  The reference always uses
-  // the exact solve of Q + 0.1 I; BLOCK_JACOBI is this library's default, MULTILEVEL (QuadraticProblem::
-  // enableMultilevel) the closest stand-in for the exact solve on blocks below ~40k poses.
-  int precond = DPGO_PRECOND_BLOCK_JACOBI;
+  // the exact solve of Q + 0.1 I (src/QuadraticProblem.cpp:56-69); MULTILEVEL -- an aggregation-multigrid V-cycle for the
+  // same matrix, built on the device by the first solve -- is this library's default stand-in for it.
+  int precond = DPGO_PRECOND_MULTILEVEL;
   dpgo_ropt_params to_c() const {
     dpgo_ropt_params c;
     dpgo_ropt_params_default(&c);
@@ -310,19 +310,16 @@ class QuadraticProblem {
     else
       check(dpgo_problem_set_G(h_, nullptr));
   }
-  // Host setup + upload of the optional two-level preconditioner for the CURRENT Q (the analogue of
-  // PoseGraph::constructPreconditioner, src/PoseGraph.cpp:598-613); call again after the measurements change.
-  // Returns the aggregate size used.  Then solve with ROptParameters::precond = DPGO_PRECOND_MULTILEVEL.
-  int enableMultilevel(double shift = 0.1, double omega = 0.7, int k = 0) {
+  // Explicit setup of the multilevel preconditioner for the CURRENT Q (the analogue of
+  // PoseGraph::constructPreconditioner, src/PoseGraph.cpp:598-613).  Optional: a solve with
+  // ROptParameters::precond = DPGO_PRECOND_MULTILEVEL builds / refreshes it by itself.  ks: aggregate sizes per
+  // coarsening (empty = defaults).  Returns the number of levels.
+  int setupMultilevel(const std::vector<int>& ks = {}, double omega = 0.7, double shift = 0.1) {
     refresh();
-    const auto& Q = pose_graph_->quadraticMatrix();
-    const int d = (int)dimension(), n = (int)num_poses(), b = d + 1;
-    if (k <= 0) k = dpgo_multilevel_default_k(n, d);
-    const size_t N = (size_t)((n + k - 1) / k) * b;
-    std::vector<double> Pb((size_t)n * b * b), inv(N * N);
-    check(dpgo_build_multilevel(d, n, Q.rowptr.data(), Q.colidx.data(), Q.vals.data(), shift, k, Pb.data(), inv.data()));
-    check(dpgo_problem_set_multilevel(h_, k, Pb.data(), inv.data(), omega, shift));
-    return k;
+    check(dpgo_problem_setup_multilevel(h_, (int)ks.size(), ks.empty() ? nullptr : ks.data(), omega, shift));
+    int nl = 0;
+    check(dpgo_problem_multilevel_info(h_, &nl, nullptr, nullptr, nullptr));
+    return nl;
   }
   double f(const Matrix& Y) const {  // src/QuadraticProblem.cpp:29-35
     shape(Y);
@@ -346,7 +343,7 @@ class QuadraticProblem {
   void EucGrad(const double* x, double* g) const { check(dpgo_problem_euc_grad(h_, x, g)); }            // :43-47
   void EucHessianEta(const double*, const double* v, double* Hv) const { check(dpgo_problem_euc_hess(h_, v, Hv)); }  // :49-54
   void PreConditioner(const double* x, const double* in, double* out) const {                            // :56-69
-    check(dpgo_problem_precondition(h_, DPGO_PRECOND_BLOCK_JACOBI, 1e-1, x, in, out));
+    check(dpgo_problem_precondition(h_, DPGO_PRECOND_MULTILEVEL, 1e-1, x, in, out));
   }
 
  private:
@@ -489,7 +486,7 @@ inline Matrix solvePGO(const std::vector<RelativeSEMeasurement>& measurements, c
   if (measurements.empty()) throw Error(DPGO_ERR_INVALID, "no measurements");
   if (!T0) throw Error(DPGO_ERR_UNSUPPORTED, "solvePGO needs an initial guess T0");
   const unsigned d = (unsigned)measurements[0].R.rows();
-  auto pg = std::make_shared<PoseGraph>(0, d, d);  // rank r = d (src/DPGO_solver.cpp:322)
+  auto pg = std::make_shared<PoseGraph>(measurements[0].r1, d, d);  // robot id of the data, rank r = d (src/DPGO_solver.cpp:322-324)
   pg->setMeasurements(measurements);
   QuadraticProblem problem(pg, device);
   QuadraticOptimizer optimizer(&problem, params);
@@ -506,7 +503,7 @@ inline Matrix solveRobustPGO(std::vector<RelativeSEMeasurement>& mutable_measure
     throw Error(DPGO_ERR_INVALID, "CHECK(params.robust_params.costType == GNC_TLS) failed");  // :355
   const double w_tol = 1e-8;  // :340
   const unsigned d = (unsigned)mutable_measurements[0].R.rows();
-  auto pg = std::make_shared<PoseGraph>(0, d, d);
+  auto pg = std::make_shared<PoseGraph>(mutable_measurements[0].r1, d, d);
   pg->setMeasurements(mutable_measurements);
   QuadraticProblem problem(pg, device);
   QuadraticOptimizer optimizer(&problem, params.opt_params);

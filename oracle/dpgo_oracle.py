@@ -372,50 +372,82 @@ def project_to_rotation_group(M):
 # --------------------------------------------------------------------------
 
 
-def amg_default_k(n: int, b: int, max_coarse: int = 3200) -> int:
-    """Aggregate size of the two-level preconditioner: the smallest power of two >= 4 that keeps the dense coarse
-    operator at <= max_coarse unknowns (82 MB in fp64: it stays in the 256 MB Infinity Cache)."""
-    k = 4
-    while ((n + k - 1) // k) * b > max_coarse:
-        k *= 2
-    # aggregates larger than 16 poses straddle the workgroup tiles of the fused cycle (16 poses in 3-D): prefer
-    # k = 16 with a larger coarse operator (<= 8192 unknowns, 268 MB in fp32) over the 9-launch fallback
-    if k > 16 and ((n + 15) // 16) * b <= 8192:
-        k = 16
-    return k
+AMG_DENSE, AMG_DENSE_MAX = 3200, 6400  # unknowns of the dense coarsest operator (82 MB / 328 MB in fp64)
+
+
+def amg_default_ks(n: int, b: int, split0: Optional[int] = None) -> List[int]:
+    """Aggregate sizes (one per coarsening) of the device's multilevel preconditioner; mirrors ml_default_ks
+    (dpgo_amd/csrc/dpgo_hip.hip).  Every k divides the workgroup tile of its level ((64 / (b split)) * 4 nodes, split = 4
+    lane groups per node below 40 000 nodes, else 1); the coarsest operator is a dense inverse of at most AMG_DENSE
+    unknowns, AMG_DENSE_MAX if that is what it takes to get there in one coarsening; otherwise one more level."""
+    lsplit = lambda m: 4 if m < 40000 else 1  # noqa: E731
+    ks: List[int] = []
+    cur, split = n, (split0 or lsplit(n))
+    for _ in range(16):
+        P = (64 // (b * split)) * 4
+        pick = 0
+        for limit in (AMG_DENSE, AMG_DENSE_MAX):
+            for k in range(4, P + 1):
+                if P % k == 0 and ((cur + k - 1) // k) * b <= limit:
+                    pick = k
+                    break
+            if pick:
+                break
+        if pick:
+            ks.append(pick)
+            return ks
+        k = max(c for c in range(2, 9) if P % c == 0)
+        ks.append(k)
+        cur = (cur + k - 1) // k
+        split = lsplit(cur)
+    return ks
+
+
+def amg_chain_prolongations(Q: "BSR", d: int, ks: List[int]):
+    """Prolongation blocks of every coarsening.  Level l has n_l nodes; node a stands for the run of stride_l
+    consecutive poses that starts at the fine pose a * stride_l (its root), stride_0 = 1, stride_{l+1} = k_l stride_l.
+    Pb[l][a] = G(root of a's parent -> root of a)^T: the homogeneous relative pose composed along the ODOMETRY chain of
+    the fine graph, read off Q's own blocks: for an edge i -> i+1 the block Q_{i,i+1} is
+    -T Om = -[w kappa R, w tau t; 0, w tau] (src/DPGO_utils.cpp:307-329), so w tau = -Q[d][d], t = -Q[:d, d] / (w tau),
+    w kappa = |first column of Q[:d, :d]|, R = -Q[:d, :d] / (w kappa).  Missing block: the chain restarts at identity.
+    With these blocks P_0 P_1 ... C reproduces, on every aggregate, the kernel vectors V_i = G_i^T C of the chain's
+    Laplacian ("rigid-body" coarse modes)."""
+    n, b = Q.n, d + 1
+    # relative pose of every odometry link i-1 -> i (None where the chain is broken)
+    link = [None] * n
+    for i in range(1, n):
+        blk = None
+        for t in range(Q.rowptr[i - 1], Q.rowptr[i]):
+            if Q.colidx[t] == i:
+                blk = Q.vals[t]
+        if blk is not None and -blk[d, d] > 0:
+            wt = -blk[d, d]
+            wk = np.linalg.norm(blk[:d, 0])
+            if wk > 0:
+                T = np.eye(b)
+                T[:d, :d] = -blk[:d, :d] / wk
+                T[:d, d] = -blk[:d, d] / wt
+                link[i] = T
+    out, stride, cur = [], 1, n
+    for k in ks:
+        span = stride * k
+        Pb = np.zeros((cur, b, b))
+        G = np.eye(b)
+        for i in range(n):
+            if i % span == 0:
+                G = np.eye(b)
+            else:
+                G = G @ link[i] if link[i] is not None else np.eye(b)
+            if i % stride == 0:
+                Pb[i // stride] = G.T
+        out.append(Pb)
+        stride, cur = span, (cur + k - 1) // k
+    return out
 
 
 def amg_prolongation_blocks(Q: "BSR", d: int, k: int):
-    """Pb[i] = G(root -> i)^T for the aggregate {root = (i // k) k, ..., root + k - 1}: the homogeneous relative pose
-    composed along the odometry chain, read off Q's own blocks: for an edge i -> i+1 the block Q_{i,i+1} is
-    -T Om = -[w kappa R, w tau t; 0, w tau] (src/DPGO_utils.cpp:307-329), so w tau = -Q[d][d], t = -Q[:d, d] / (w tau),
-    w kappa = |first column of Q[:d, :d]|, R = -Q[:d, :d] / (w kappa).  Missing block: the chain restarts at identity.
-    With these blocks P C reproduces, on every aggregate, the kernel vectors V_i = G_i^T C of the chain's Laplacian."""
-    n, b = Q.n, d + 1
-    Pb = np.zeros((n, b, b))
-    G = np.eye(b)
-    for i in range(n):
-        if i % k == 0:
-            G = np.eye(b)
-        else:
-            T = np.eye(b)
-            blk = None
-            for t in range(Q.rowptr[i - 1], Q.rowptr[i]):
-                if Q.colidx[t] == i:
-                    blk = Q.vals[t]
-            if blk is not None and -blk[d, d] > 0:
-                wt = -blk[d, d]
-                wk = np.linalg.norm(blk[:d, 0])
-                if wk > 0:
-                    T[:d, :d] = -blk[:d, :d] / wk
-                    T[:d, d] = -blk[:d, d] / wt
-                    G = G @ T
-                else:
-                    G = np.eye(b)
-            else:
-                G = np.eye(b)
-        Pb[i] = G.T
-    return Pb
+    """Two-level case: Pb[i] = G(root -> i)^T for the aggregate {root = (i // k) k, ..., root + k - 1}."""
+    return amg_chain_prolongations(Q, d, [k])[0]
 
 
 class QuadraticProblem:
@@ -426,15 +458,16 @@ class QuadraticProblem:
              'jacobi' -> inverse of the (d+1)x(d+1) diagonal blocks of Q + 0.1 I (what the
                          MI355X path runs; same fixed point, different trajectory);
              'none'   -> identity;
-             'amg2'   -> two-level aggregation multigrid cycle for Q + 0.1 I (the device's optional
-                         "multilevel" preconditioner): aggregates of k consecutive poses,
-                         prolongation blocks = relative poses read off Q's odometry blocks, exact coarse solve,
-                         damped block-Jacobi pre- and post-smoothing.
+             'amg'    -> aggregation-multigrid V(1,1) cycle for Q + 0.1 I (the device's default "multilevel"
+                         preconditioner): level l+1's nodes = runs of amg_k[l] consecutive level-l
+                         nodes, prolongation blocks = relative poses read off Q's odometry blocks, Galerkin operators,
+                         dense inverse on the coarsest level, damped block-Jacobi pre- and post-smoothing.
     All of them are followed by the tangent projection (QuadraticProblem.cpp:68)."""
 
     def __init__(self, Q: BSR, G: Optional[np.ndarray], r: int, d: int, precond: str = "exact",
-                 shift: float = 0.1, amg_k: Optional[int] = None, amg_omega: float = 0.7):
+                 shift: float = 0.1, amg_k=None, amg_omega: float = 0.7, amg_gamma: int = 1, amg_nu: int = 1):
         self.amg_k, self.amg_omega, self._amg = amg_k, amg_omega, None
+        self.amg_gamma, self.amg_nu = amg_gamma, amg_nu  # coarse-level cycle index / smoothing sweeps (experiments)
         self.Q, self.r, self.d, self.n = Q, r, d, Q.n
         self.b = d + 1
         self.N = self.n * self.b
@@ -495,40 +528,64 @@ class QuadraticProblem:
             Z = self.dinv_blocks() @ V
         elif self.precond == "none":
             Z = V.copy()
-        elif self.precond == "amg2":
-            Z = self.amg2_cycle(V)
+        elif self.precond in ("amg", "amg2"):
+            Z = self.amg_cycle(V)
         else:
             raise ValueError(self.precond)
         return tangent_project(X, Z, self.d)
 
-    # --- two-level aggregation multigrid (device option "multilevel") ---
-    def amg2_setup(self):
+    # --- aggregation multigrid V(1,1) cycle (device option "multilevel") ---
+    def amg_setup(self):
+        """Hierarchy for A_0 = Q + shift I: A_{l+1} = P_l^T A_l P_l (Galerkin), damped block-Jacobi smoother on every
+        level (the diagonal blocks of A_l), dense inverse of the coarsest operator.  All fp64."""
         if self._amg is None:
-            k = self.amg_k or amg_default_k(self.n, self.b)
-            Pb = amg_prolongation_blocks(self.Q, self.d, k)  # [n, b, b]
-            n, b = self.n, self.b
-            nc = (n + k - 1) // k
-            rows = (np.arange(n)[:, None, None] * b + np.arange(b)[None, :, None]) + np.zeros((1, 1, b), dtype=np.int64)
-            cols = ((np.arange(n) // k)[:, None, None] * b + np.arange(b)[None, None, :]) + np.zeros((1, b, 1), dtype=np.int64)
-            P = sp.csr_matrix((Pb.ravel(), (rows.ravel(), cols.ravel())), shape=(n * b, nc * b))
+            ks = self.amg_k
+            if ks is None:
+                ks = amg_default_ks(self.n, self.b)
+            elif isinstance(ks, (int, np.integer)):
+                ks = [int(ks)]
+            ks = [int(k) for k in ks]
+            Pbs = amg_chain_prolongations(self.Q, self.d, ks)
+            b = self.b
             A = (self.Qs + self.shift * sp.identity(self.N, format="csr")).tocsr()
-            Ac = (P.T @ A @ P).toarray()
+            levels, cur = [], self.n
+            for k, Pb in zip(ks, Pbs):
+                nc = (cur + k - 1) // k
+                rows = (np.arange(cur)[:, None, None] * b + np.arange(b)[None, :, None]) + np.zeros((1, 1, b), dtype=np.int64)
+                cols = ((np.arange(cur) // k)[:, None, None] * b + np.arange(b)[None, None, :]) + np.zeros((1, b, 1), dtype=np.int64)
+                P = sp.csr_matrix((Pb.ravel(), (rows.ravel(), cols.ravel())), shape=(cur * b, nc * b))
+                Ab = A.tobsr(blocksize=(b, b))
+                Ab.sort_indices()
+                rr = np.repeat(np.arange(cur), np.diff(Ab.indptr))
+                D = np.zeros((cur, b, b))
+                D[rr[rr == Ab.indices]] = Ab.data[rr == Ab.indices]
+                levels.append(dict(k=k, n=cur, A=A, P=P, Pb=Pb, Dinv=np.linalg.inv(D)))
+                A = (P.T @ A @ P).tocsr()
+                cur = nc
+            Ac = A.toarray()
             Ac = 0.5 * (Ac + Ac.T)
-            # the device keeps the coarse inverse in fp32 (a preconditioner: iteration counts are unchanged)
-            self._amg = dict(k=k, P=P, A=A, AcInv=np.linalg.inv(Ac).astype(np.float32).astype(np.float64), nc=nc)
+            self._amg = dict(ks=ks, levels=levels, Ac=Ac, AcInv=np.linalg.inv(Ac), nc=cur)
         return self._amg
 
-    def amg2_cycle(self, V):
-        m = self.amg2_setup()
-        A, P, w = m["A"], m["P"], self.amg_omega
-        Dinv = self.dinv_blocks()
-        r = V.reshape(self.N, self.r)
-        smooth = lambda res: (Dinv @ res.reshape(self.n, self.b, self.r)).reshape(self.N, self.r)  # noqa: E731
-        x1 = w * smooth(r)
-        rc = P.T @ (r - A @ x1)
-        x = x1 + P @ (m["AcInv"] @ rc)
-        z = x + w * smooth(r - A @ x)
-        return z.reshape(V.shape)
+    def amg_cycle(self, V):
+        m = self.amg_setup()
+        w, b, r = self.amg_omega, self.b, self.r
+
+        def cycle(lv, rhs):
+            if lv == len(m["levels"]):
+                return m["AcInv"] @ rhs
+            L = m["levels"][lv]
+            smooth = lambda res: (L["Dinv"] @ res.reshape(L["n"], b, r)).reshape(res.shape)  # noqa: E731
+            x = w * smooth(rhs)
+            for _ in range((self.amg_nu if lv > 0 else 1) - 1):
+                x = x + w * smooth(rhs - L["A"] @ x)
+            for g in range(self.amg_gamma if (lv > 0 and lv + 1 < len(m["levels"])) else 1):
+                x = x + L["P"] @ cycle(lv + 1, L["P"].T @ (rhs - L["A"] @ x))
+            for _ in range(self.amg_nu if lv > 0 else 1):
+                x = x + w * smooth(rhs - L["A"] @ x)
+            return x
+
+        return cycle(0, V.reshape(self.N, self.r)).reshape(V.shape)
 
 
 # --------------------------------------------------------------------------
@@ -572,77 +629,6 @@ def dot(A, B):
     return float(np.sum(A * B))
 
 
-def tcg_pipelined(problem: "QuadraticProblem", X, g, S, Delta, max_inner, theta=1.0, kappa=0.1, min_inner=0,
-                  trace=None):
-    """tCG_TR with ONE global reduction per iteration (what the MI355X path runs on small, latency-bound
-    blocks).  Same iterates as `tcg` in exact arithmetic.  With P the preconditioner and H
-    the Riemannian Hessian (both linear on the tangent space) keep, besides r, z = P r, delta and H delta,
-        w = H z,  m = P w,  q = P H delta,  t = H q
-    and advance them by recurrences, so that the only operator application of iteration j is n_j = H m_j on a
-    vector that is complete when the iteration starts (pipelined PCG, Ghysels & Vanroose 2014):
-        delta_j = -z_j + b delta_{j-1}      H delta_j = -w_j + b H delta_{j-1}
-        q_j     = -m_j + b q_{j-1}          t_j       = -n_j + b t_{j-1}
-        eta += a delta_j;  r += a H delta_j;  z += a q_j;  w += a t_j;  m = P w
-    <delta_j, H delta_j> is not summed but derived: mu_j - b^2 <delta_{j-1}, H delta_{j-1}>, mu_j = <z_j, w_j>
-    (conjugacy of the directions), so the three sums <z,r>, <r,r>, <z,w> of iteration j+1 are the only
-    reduction.  Returns (eta, status, inner_iters, n_hess)."""
-    r = g.copy()
-    eta = np.zeros_like(g)
-    z = problem.precondition(X, r)
-    w = problem.rie_hess(X, S, z)
-    m = problem.precondition(X, w)
-    n_hess = 1
-    zr, rr, mu = dot(z, r), dot(r, r), dot(z, w)
-    norm_r0 = math.sqrt(rr)
-    z_r, d_Pd, e_Pd, e_Pe = zr, zr, 0.0, 0.0
-    delta = Hd = q = t = None
-    d_Hd, alpha, beta = mu, 0.0, 0.0
-    status = TCG_MAXITER
-    j = 0
-    while j < max_inner:
-        if j > 0:
-            norm_r = math.sqrt(rr)
-            if j - 1 >= min_inner and norm_r <= norm_r0 * min(norm_r0 ** theta, kappa):
-                status = TCG_LCON if kappa < norm_r0 ** theta else TCG_SCON
-                j -= 1
-                break
-            beta = zr / z_r
-            e_Pd = beta * (e_Pd + alpha * d_Pd)
-            d_Pd = zr + beta * beta * d_Pd
-            z_r = zr
-            d_Hd = mu - beta * beta * d_Hd
-        delta = -z if j == 0 else beta * delta - z
-        alpha = z_r / d_Hd if d_Hd != 0 else math.inf
-        e_Pe_new = e_Pe + 2.0 * alpha * e_Pd + alpha * alpha * d_Pd
-        if d_Hd <= 0 or e_Pe_new >= Delta * Delta:
-            tau = (-e_Pd + math.sqrt(e_Pd * e_Pd + d_Pd * (Delta * Delta - e_Pe))) / d_Pd
-            eta = eta + tau * delta
-            status = TCG_NEGCURV if d_Hd < 0 else TCG_EXCREGION
-            if trace is not None:
-                trace.append(dict(j=j, d_Hd=d_Hd, alpha=alpha, tau=tau, status=status))
-            break
-        e_Pe = e_Pe_new
-        nvec = problem.rie_hess(X, S, m)
-        n_hess += 1
-        Hd = -w if j == 0 else beta * Hd - w
-        q = -m if j == 0 else beta * q - m
-        t = -nvec if j == 0 else beta * t - nvec
-        eta = eta + alpha * delta
-        r = r + alpha * Hd
-        z = z + alpha * q
-        w = w + alpha * t
-        m = problem.precondition(X, w)
-        zr, rr, mu = dot(z, r), dot(r, r), dot(z, w)
-        if trace is not None:
-            trace.append(dict(j=j, d_Hd=d_Hd, alpha=alpha, norm_r=math.sqrt(rr)))
-        j += 1
-    else:
-        # max_inner reached: the reference leaves the loop with j == max_inner after the last update; the
-        # convergence test of that last residual is not evaluated (MAXITER)
-        pass
-    return eta, status, j, n_hess
-
-
 def tcg(problem: QuadraticProblem, X, g, S, Delta, max_inner, theta=1.0, kappa=0.1, min_inner=0, trace=None,
         hess_recurrence=False):
     """ROPTLIB SolversTR::tCG_TR restated (SURVEY 8a row a8), eta0 = 0 (useRand = false).
@@ -651,10 +637,7 @@ def tcg(problem: QuadraticProblem, X, g, S, Delta, max_inner, theta=1.0, kappa=0
     hess_recurrence = False is the reference's arithmetic (H applied to delta every iteration).
     hess_recurrence = True is what the MI355X path computes: H is applied to the preconditioned
     residual z and H delta follows the direction recurrence, H delta' = beta * H delta - H z (exact in
-    exact arithmetic because H is linear on the tangent space).
-    hess_recurrence = "pipelined" selects tcg_pipelined (one reduction per iteration; small blocks on the device)."""
-    if hess_recurrence == "pipelined":
-        return tcg_pipelined(problem, X, g, S, Delta, max_inner, theta, kappa, min_inner, trace)
+    exact arithmetic because H is linear on the tangent space)."""
     r = g.copy()
     e_Pe = 0.0
     r_r = dot(r, r)
@@ -1025,7 +1008,10 @@ def rbcd_coloured(meas: Measurements, n: int, num_robots: int, r: int, X0, sweep
         need = set()
         for k in range(sh.m):
             need.add((int(sh.r2[k]), int(sh.p2[k])) if sh.r1[k] == a else (int(sh.r1[k]), int(sh.p1[k])))
-        agents.append(dict(Q=Qa, shared=sh, need=sorted(need), adj=sorted({rob for rob, _ in need})))
+        # one problem object per agent for the whole run (Q and the preconditioner belong to the PoseGraph's lifetime,
+        # include/DPGO/PoseGraph.h:324-331); only G changes between solves
+        agents.append(dict(Q=Qa, shared=sh, need=sorted(need), adj=sorted({rob for rob, _ in need}),
+                           prob=QuadraticProblem(Qa, None, r, d, precond=precond)))
     colour = [-1] * num_robots
     for a in range(num_robots):
         used = {colour[q] for q in agents[a]["adj"] if colour[q] >= 0}
@@ -1043,8 +1029,8 @@ def rbcd_coloured(meas: Measurements, n: int, num_robots: int, r: int, X0, sweep
                     continue
                 s, e = ranges[a]
                 nbr = {(rob, fr): X[ranges[rob][0] + fr] for rob, fr in agents[a]["need"]}
-                G = construct_G(e - s, d, r, agents[a]["shared"], a, nbr)
-                prob = QuadraticProblem(agents[a]["Q"], G, r, d, precond=precond)
+                prob = agents[a]["prob"]
+                prob.G = construct_G(e - s, d, r, agents[a]["shared"], a, nbr)
                 opt = QuadraticOptimizer(prob, params or ROptParameters(), hess_recurrence=hess_recurrence)
                 X[s:e] = opt.optimize(X[s:e])
         costs.append(2 * central.f(X))

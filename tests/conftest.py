@@ -63,8 +63,6 @@ def to_product_measurements(om):
 
 
 def device_tcg_mode(n, d, r):
-    """The tCG arithmetic the device runs for a block of n poses (oracle `hess_recurrence` argument): with DPGO_PIPE=1
-    small blocks with an even tile size use the pipelined one-reduction scheme, everything else (and the default)
-    is the H-direction recurrence."""
-    pipe = os.environ.get("DPGO_PIPE", "0") not in ("", "0")  # opt-in, read by the library at problem creation
-    return "pipelined" if (pipe and n < 40000 and ((d + 1) * r) % 2 == 0) else True
+    """The tCG arithmetic the device runs (oracle `hess_recurrence` argument): H delta is advanced by the recurrence
+    H delta' = beta H delta - H z."""
+    return True

@@ -278,20 +278,21 @@ static int run() {
     REQUIRE(std::fabs(rc.weight(2.0) - (std::sqrt(4.0 * 2.0 / 4.0) - 1.0)) < 1e-15);
   }
 
-  // ---------------- optional multilevel preconditioner through the C++ mirror: same optimum as the default on the
-  // triangle graph (3 poses -> one aggregate: the coarse solve is exact on the kernel modes)
-  {
-    const int kk = problem.enableMultilevel();
-    REQUIRE(kk == 4);
+  // ---------------- the preconditioners through the C++ mirror: block-Jacobi and an explicitly set-up multilevel
+  // hierarchy reach the same optimum as the default (= multilevel, built by the first solve) on the triangle graph
+  // (3 poses -> one aggregate: the coarse solve is exact on the kernel modes)
+  for (int pc : {DPGO_PRECOND_BLOCK_JACOBI, DPGO_PRECOND_MULTILEVEL}) {
+    if (pc == DPGO_PRECOND_MULTILEVEL) REQUIRE(problem.setupMultilevel({2}) == 2);
     ROptParameters pm;
+    REQUIRE(pm.precond == DPGO_PRECOND_MULTILEVEL);
     pm.gradnorm_tol = 1e-9;
     pm.RTR_iterations = 20;
-    pm.precond = DPGO_PRECOND_MULTILEVEL;
+    pm.precond = pc;
     QuadraticOptimizer om(&problem, pm);
     Matrix Tm = om.optimize(T0);
     REQUIRE(om.getOptResult().success);
-    std::printf("multilevel: f %.3e -> %.3e (default precond: %.3e)\n", om.getOptResult().fInit, om.getOptResult().fOpt,
-                optimizer.getOptResult().fOpt);
+    std::printf("precond %d: f %.3e -> %.3e (default precond: %.3e)\n", pc, om.getOptResult().fInit,
+                om.getOptResult().fOpt, optimizer.getOptResult().fOpt);
     REQUIRE(om.getOptResult().fOpt <= om.getOptResult().fInit * (1 + 1e-12) + 1e-12);
     REQUIRE(std::fabs(om.getOptResult().fOpt - optimizer.getOptResult().fOpt) <= 1e-9);
     double dm = 0;

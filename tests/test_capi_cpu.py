@@ -180,38 +180,44 @@ def test_trajectory_csv_round_trip(tmp_path):
     assert len(lines) == len(meas) + 1
 
 
-@pytest.mark.parametrize("name", ["smallGrid3D", "kitti_00"])
-def test_multilevel_host_setup_matches_oracle(name):
-    """dpgo_amd.multilevel.build (product, host side of precond = "multilevel") against the oracle's independent
-    restatement: same aggregate size rule, same prolongation blocks, same coarse inverse; the prolongation
-    reproduces the chain Laplacian's kernel: for an odometry-only graph (Q + 0 I) P C = 0 ... A P has no
-    odometry residual inside an aggregate."""
+@pytest.mark.parametrize("name,ks", [("smallGrid3D", None), ("kitti_00", None), ("sphere2500", [4, 8])])
+def test_multilevel_hierarchy_rules(name, ks):
+    """Host-side rules of precond = "multilevel": the library's default aggregate sizes (dpgo_multilevel_default_ks, no
+    GPU code) equal the oracle's mirror on the benchmark sizes, and the chain prolongations the device kernel
+    (k_ml_build_P) restates reproduce the chain Laplacian's kernel on every level: for an odometry-only graph
+    Q P_0 P_1 ... C has no residual inside an aggregate."""
+    import ctypes as C
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import dpgo_oracle as O
-    from dpgo_amd import multilevel
+    import dpgo_amd.lib as L
+    lib = L.load()
+    for n_, d_ in [(1, 3), (25, 3), (125, 3), (2500, 3), (5000, 3), (12500, 3), (25000, 3), (50000, 3), (100000, 3),
+                   (1000000, 3), (4541, 2), (1136, 2), (39999, 2), (40000, 2)]:
+        buf = np.zeros(16, dtype=np.int32)
+        cnt = C.c_int(16)
+        L.check(lib.dpgo_multilevel_default_ks(n_, d_, L.ptr(buf), C.byref(cnt)))
+        assert [int(v) for v in buf[:cnt.value]] == O.amg_default_ks(n_, d_ + 1), (n_, d_)
     om, n = O.read_g2o(os.path.join(DATA, name + ".g2o"))
-    d = om.d
-    Q = O.construct_Q(n, d, om)
-    k, Pb, AcInv = multilevel.build(Q.rowptr, Q.colidx, Q.vals, d)
-    op = O.QuadraticProblem(Q, None, d + 2, d, precond="amg2")
-    m = op.amg2_setup()
-    assert k == m["k"] == O.amg_default_k(n, d + 1)
-    assert np.abs(Pb - O.amg_prolongation_blocks(Q, d, k)).max() == 0.0
-    # (the oracle keeps the inverse as the device does, rounded to fp32)
-    assert np.abs(AcInv.astype(np.float32).astype(np.float64) - m["AcInv"]).max() <= 2e-7 * np.abs(AcInv).max()
-    # kernel property on the odometry chain alone
+    d, b = om.d, om.d + 1
+    ks = ks or O.amg_default_ks(n, b)
     odo = om.subset(np.nonzero(om.p1 + 1 == om.p2)[0])
     Qo = O.construct_Q(n, d, odo)
-    Pbo = multilevel.prolongation_blocks(Qo.rowptr, Qo.colidx, Qo.vals, d, k)
-    b = d + 1
-    V = np.zeros((n * b, b))
+    Pbs = O.amg_chain_prolongations(Qo, d, ks)
+    # V = P_0 P_1 ... restricted to blocks: V_i = Pb_0[i] Pb_1[i // k_0] ...
+    V = np.zeros((n, b, b))
     for i in range(n):
-        V[i * b:(i + 1) * b] = Pbo[i]
-    R = (Qo.to_scipy() @ V).reshape(n, b, b)
-    inner = np.array([i for i in range(n) if i % k not in (0, k - 1) and i != n - 1])  # rows not touching a cut
+        M, node = np.eye(b), i
+        for Pb, k in zip(Pbs, ks):
+            M = M @ Pb[node]
+            node //= k
+        V[i] = M
+    R = (Qo.to_scipy() @ V.reshape(n * b, b)).reshape(n, b, b)
+    span = int(np.prod(ks))
+    inner = np.array([i for i in range(n) if i % span not in (0, span - 1) and i != n - 1])  # rows not touching a cut
     # (1e-9-level: the g2o rotations are not exactly orthonormal, so T is recovered to ~1e-9)
     assert np.abs(R[inner]).max() <= 1e-7 * np.abs(Qo.vals).max()
-    assert np.abs(R[np.arange(k - 1, n - 1, k)]).max() > 1e-3 * np.abs(Qo.vals).max()  # cut rows do see a residual
+    assert np.abs(R[np.arange(span - 1, n - 1, span)]).max() > 1e-3 * np.abs(Qo.vals).max()  # cut rows see a residual
+
 
 
 def _random_multi_robot_graph(rng, d, n, robots, extra):
@@ -318,34 +324,6 @@ def test_host_initialisations_match_oracle(oracle, name):
     R0 = Rg[0]
     assert np.abs(np.swapaxes(Te[:, :om.d, :], 1, 2) - R0.T @ Rg).max() < 1e-7
     assert np.abs(Te[:, om.d, :] - (tg - tg[0]) @ R0).max() < 1e-6 * max(1.0, np.abs(tg).max())
-
-
-@pytest.mark.parametrize("name", ["smallGrid3D", "kitti_00", "sphere2500"])
-def test_cxx_multilevel_setup_matches_python(name):
-    """dpgo_build_multilevel (host C++, what a C++ caller uses instead of dpgo_amd/multilevel.py): same aggregate-size
-    rule, same prolongation blocks, same coarse inverse (own dense Cholesky, no LAPACK) to 1e-9."""
-    import time
-    import dpgo_amd
-    from dpgo_amd import multilevel
-    import dpgo_amd.lib as L
-    lib = L.load()
-    pm, n = dpgo_amd.read_g2o_file(os.path.join(DATA, name + ".g2o"))
-    d = pm.d
-    pg = dpgo_amd.PoseGraph(0, d + 2, d)
-    pg.setMeasurements(pm)
-    rowptr, colidx, vals = pg.quadraticMatrix()
-    k = lib.dpgo_multilevel_default_k(n, d)
-    assert k == multilevel.default_aggregate_size(n, d + 1)
-    b, nc = d + 1, (n + k - 1) // k
-    Pb = np.zeros((n, b, b))
-    inv = np.zeros((nc * b, nc * b))
-    t0 = time.perf_counter()
-    L.check(lib.dpgo_build_multilevel(d, n, L.ptr(rowptr), L.ptr(colidx), L.ptr(vals), 0.1, k, L.ptr(Pb), L.ptr(inv)))
-    assert time.perf_counter() - t0 < 60
-    k2, Pb2, inv2 = multilevel.build(rowptr, colidx, vals, d, 0.1, k)
-    assert np.abs(Pb - Pb2).max() <= 1e-12
-    assert np.abs(inv - inv2).max() <= 1e-9 * np.abs(inv2).max()
-    assert np.abs(inv - inv.T).max() <= 1e-12 * np.abs(inv).max()
 
 
 def test_python_mirror_rejects_bad_arguments_before_touching_the_device():
