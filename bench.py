@@ -6,7 +6,7 @@
 One "step" = one RBCD iteration from a fixed, settled iterate (identical full work every step; see main()):
 every agent runs QuadraticOptimizer::optimize once (RTR, 3 outer
 iterations x <=50 tCG, Delta0 = 100, tol 1e-2: the reference defaults, include/DPGO/DPGO_types.h:53-61)
-on its block, with the block-Jacobi preconditioner.  N = 1: a single agent owns the whole graph.
+on its block, with the default (multilevel) preconditioner.  N = 1: a single agent owns the whole graph.
 N > 1: the graph is cut into N contiguous blocks (examples/MultiRobotExample.cpp:71-88), one agent per
 GPU / process; agents of one colour update in parallel, then the other colour (two-colour RBCD),
 with the public-pose exchange over RCCL point-to-point.  Total work is fixed as N grows ("strong").
@@ -14,9 +14,12 @@ with the public-pose exchange over RCCL point-to-point.  Total work is fixed as 
 Workload at N = 1: the synthetic 100k-pose 3-D grid of BASELINE.json (configs[3], the configuration the
 HBM-roofline target is quoted on; it fits one GPU).  Inputs are resident in HBM before the timed region.
 
-Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel, k_tcg_hess (the fused
-Q*z SpMM + Riemannian-Hessian epilogue + direction recurrences, launched once per tCG iteration); `cpu_baseline` times the CPU
-oracle ("port") on the same workload on the host cores (rank 0, N = 1 only).
+Prints ONE JSON line (rank 0).  `roofline` is for k_tcg_hess (the fused Q*z SpMM + Riemannian-Hessian epilogue +
+direction recurrences, launched once per tCG iteration -- the Q*X kernel BASELINE's metric names): `frac` is the
+HBM-only figure (every operand cycling through > 256 MB of private copies), `warm` the Infinity-Cache-resident
+one the solver sees; `roofline.kernels` lists the other kernels of one preconditioned tCG iteration.  `cpu_baseline`
+times the CPU oracle on the host cores (rank 0, N = 1 only): the reference configuration (exact sparse factor of
+Q + 0.1 I, the graph cut into 8 agents, one core per agent) and, beside it, the 1-core C port of the device algorithm.
 """
 import argparse
 import json
@@ -41,8 +44,8 @@ def parse_args():
                     help="untimed RBCD iterations from the initial guess before the benchmark state is frozen")
     ap.add_argument("--workload", default="grid100k")
     ap.add_argument("--rank", type=int, default=5, help="relaxation rank r")
-    ap.add_argument("--precond", default="jacobi", choices=["jacobi", "multilevel"],
-                    help="tCG preconditioner: block-Jacobi (default) or the two-level multigrid cycle (blocks < 40k poses)")
+    ap.add_argument("--precond", default="multilevel", choices=["jacobi", "multilevel"],
+                    help="tCG preconditioner: the multilevel cycle (library default) or block-Jacobi")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the sphere2500 side measurement (`also` field)")
     ap.add_argument("--cpu-budget-s", type=float, default=25.0)
@@ -119,7 +122,7 @@ def cpu_baseline(meas_p, n, X_state, r, budget_s, precond="jacobi"):
         _, res = CO.optimize(Q, None, X, RTR_tCG_iterations=inner, hess_recurrence=True)
         el = time.perf_counter() - t0
         iters, what = res.tcg_iterations, "plain-C oracle (gcc -O3 -march=x86-64-v3, single thread)"
-        extra = dict(spmm_ms_1core=1e3 * spmm_s,
+        extra = dict(fOpt=res.fOpt if inner == max_inner else None, spmm_ms_1core=1e3 * spmm_s,
                      spmm_GBs_1core=spmm_bytes(n, len(Q.colidx), d, r) / spmm_s / 1e9, host_cores=os.cpu_count())
     else:
         prob = O.QuadraticProblem(Q, None, r, d, precond="jacobi" if precond == "jacobi" else "amg")
@@ -139,15 +142,95 @@ def cpu_baseline(meas_p, n, X_state, r, budget_s, precond="jacobi"):
         opt.optimize(X)
         el = time.perf_counter() - t0
         iters, what = opt.result.tcg_iters, "NumPy/SciPy oracle (single thread)"
-        extra = dict(host_cores=os.cpu_count())
+        extra = dict(fOpt=opt.result.fOpt if inner == max_inner else None, host_cores=os.cpu_count())
     scale = max_inner / inner
     return dict(value=1.0 / (el * scale), unit="it/s", cores=1, kind="port",
                 sample="1 RBCD iteration from the same settled iterate, %d tCG Hessian-vector products in %.1f s%s; "
-                       "%s, same algorithm as the device path" % (
+                       "%s, the device path's algorithm with its block-Jacobi preconditioner" % (
                            iters, el,
                            "" if inner == max_inner else " (tCG capped at %d of 50, time scaled x%.2f)" % (inner, scale),
                            what),
                 tcg_iterations=iters, seconds=el, **extra)
+
+
+def _ref_agent_solve(task):
+    """Worker of cpu_baseline_reference (one process = one core = one agent, as the reference's one thread per agent):
+    PGOAgent::updateX on the CPU oracle with the reference's exact preconditioner; the sparse factor is built lazily
+    inside the first solve (src/PoseGraph.cpp:582-586) and timed separately."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import dpgo_oracle as O
+    try:
+        from threadpoolctl import threadpool_limits
+        limiter = threadpool_limits(limits=1)  # one thread per agent (ENABLE_OPENMP OFF, CMakeLists.txt:55)
+    except Exception:  # noqa: BLE001
+        limiter = None
+    Qa, G, r, d, Xa = task
+    prob = O.QuadraticProblem(Qa, G, r, d, precond="exact")
+    t0 = time.perf_counter()
+    prob.precondition(Xa, np.zeros_like(Xa))  # forces the factorisation
+    t_fact = time.perf_counter() - t0
+    opt = O.QuadraticOptimizer(prob, O.ROptParameters())
+    t0 = time.perf_counter()
+    Xn = opt.optimize(Xa)
+    t_solve = time.perf_counter() - t0
+    del limiter
+    return Xn, opt.result.tcg_iters, t_fact, t_solve
+
+
+def cpu_baseline_reference(meas_p, n, X_tiles, r, num_agents=8):
+    """The reference's own configuration of this workload (BASELINE configs[3]: the 100k-pose grid, 8 agents) on the
+    host cores: contiguous blocks (examples/MultiRobotExample.cpp:71-88), one process per agent, local solve =
+    RTR 3 x <=50 tCG with the EXACT sparse factor of Q_a + 0.1 I (SciPy SuperLU standing in for CHOLMOD), one
+    two-colour sweep from the given iterate.  A single agent owning all 100k poses -- the GPU's N = 1 step -- is out of
+    reach of a sparse direct factor on a 3-D grid, so the sample is the partitioned problem.
+    Returns a dict; time per sweep = sum over the colour phases of the slowest agent."""
+    import multiprocessing as mp
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import dpgo_oracle as O
+    d = meas_p.d
+    om = O.Measurements(d, meas_p.r1.astype(np.int64), meas_p.p1.astype(np.int64), meas_p.r2.astype(np.int64),
+                        meas_p.p2.astype(np.int64), meas_p.R, meas_p.t, meas_p.kappa, meas_p.tau, meas_p.weight,
+                        meas_p.fixedWeight)
+    ranges, per = O.partition_contiguous(om, n, num_agents)
+    X = np.ascontiguousarray(X_tiles).copy()
+    info = []
+    for a in range(num_agents):
+        s, e = ranges[a]
+        priv = O.Measurements.concat([per[a]["odometry"], per[a]["private"]])
+        sh = per[a]["shared"]
+        need = sorted({(int(sh.r2[k]), int(sh.p2[k])) if sh.r1[k] == a else (int(sh.r1[k]), int(sh.p1[k]))
+                       for k in range(sh.m)})
+        info.append(dict(Q=O.construct_Q(e - s, d, priv, sh, my_id=a), shared=sh, need=need,
+                         adj=sorted({rob for rob, _ in need})))
+    colour = [-1] * num_agents
+    for a in range(num_agents):
+        used = {colour[q] for q in info[a]["adj"] if colour[q] >= 0}
+        colour[a] = min(c for c in range(num_agents) if c not in used)
+    cores = min(num_agents, os.cpu_count() or 1)
+    t_sweep, t_fact, products = 0.0, 0.0, 0
+    with mp.get_context("fork").Pool(cores) as pool:
+        for c in range(max(colour) + 1):
+            ids = [a for a in range(num_agents) if colour[a] == c]
+            tasks = []
+            for a in ids:
+                s, e = ranges[a]
+                nbr = {(rob, fr): X[ranges[rob][0] + fr] for rob, fr in info[a]["need"]}
+                tasks.append((info[a]["Q"], O.construct_G(e - s, d, r, info[a]["shared"], a, nbr), r, d, X[s:e]))
+            out = pool.map(_ref_agent_solve, tasks)
+            for a, (Xn, its, tf, ts) in zip(ids, out):
+                X[ranges[a][0]:ranges[a][1]] = Xn
+                products += its
+            t_sweep += max(ts for _, _, _, ts in out)
+            t_fact = max(t_fact, max(tf for _, _, tf, _ in out))
+    central = O.QuadraticProblem(O.construct_Q(n, d, om), None, r, d, precond="none")
+    return dict(value=1.0 / t_sweep, unit="it/s", cores=cores, kind="port",
+                sample="reference configuration of this workload: %d agents x %d poses, one core each, exact sparse "
+                       "factor of Q_a + 0.1 I (SciPy SuperLU for CHOLMOD), RTR 3x<=50 tCG; ONE two-colour sweep "
+                       "(1 it = every agent updates once) from the benchmark's initial iterate: %.2f s + %.2f s once "
+                       "for the factorisations (inside the first solve, src/PoseGraph.cpp:582-586); NumPy/SciPy "
+                       "oracle" % (num_agents, n // num_agents, t_sweep, t_fact),
+                seconds_per_sweep=t_sweep, factorisation_seconds=t_fact, tcg_iterations=products,
+                cost_2f_after=2 * central.f(X), gradnorm_after=central.rie_grad_norm(X), host_cores=os.cpu_count())
 
 
 def secondary_single_agent(workload, r, precond, steps, warmup, settle):
@@ -185,6 +268,33 @@ def secondary_single_agent(workload, r, precond, steps, warmup, settle):
                 gradnorm_after_step=res.gradNormOpt)
 
 
+def time_to_tolerance(workload, r, precond, tol=1e-2, max_calls=12):
+    """Products-to-tolerance and time-to-gradnorm: QuadraticOptimizer::optimize (reference defaults) called from the
+    initial guess until |rgrad| < tol (the local solver's own tolerance), single agent, single GPU."""
+    import torch
+    import dpgo_amd
+    from dpgo_amd.agent import DeviceAgent, ExchangePlan, build_pose_graphs
+    meas, n, X0, desc = make_workload(workload, r)
+    ranges, graphs = build_pose_graphs(meas, n, 1, r)
+    ag = DeviceAgent(graphs, ExchangePlan(graphs), 0, X0, dpgo_amd.ROptParameters(precond=precond))
+    ag.update()  # untimed: builds the preconditioner (as the reference, inside the first solve) and warms up
+    ag.X.copy_(torch.tensor(X0, device=ag.X.device))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    products, calls, gn = 0, 0, None
+    for _ in range(max_calls):
+        res = ag.update()
+        products += res.tcg_iterations
+        calls += 1
+        gn = res.gradNormOpt
+        if gn < tol:
+            break
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    return dict(products=products, rbcd_iterations=calls, ms=1e3 * el, gradnorm=gn, reached=bool(gn < tol),
+                us_per_product=1e6 * el / max(products, 1))
+
+
 def main():
     args = parse_args()
     import torch
@@ -204,22 +314,20 @@ def main():
     dev_index = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(dev_index)
     backend = None
+    comm = None
     if world > 1:
         # "nccl" IS RCCL on ROCm.  DPGO_DIST_BACKEND=gloo (host-staged exchange) lets the N > 1 path be exercised
         # on a single-GPU box with all ranks sharing device 0; it is also the fallback if RCCL cannot initialise.
         backend = os.environ.get("DPGO_DIST_BACKEND", "nccl")
         if backend == "nccl":
-            try:
-                dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
-                t = torch.ones(1, device="cuda")
-                dist.all_reduce(t)  # create the communicator eagerly, before the first grouped p2p batch
-                torch.cuda.synchronize()
-            except Exception as exc:  # noqa: BLE001 -- report and degrade rather than lose the measurement
-                sys.stderr.write("bench.py: RCCL initialisation failed (%r); falling back to gloo\n" % (exc,))
-                if dist.is_initialized():
-                    dist.destroy_process_group()
-                backend = "gloo"
-                dist.init_process_group("gloo")
+            # no silent degradation: if RCCL cannot initialise the run FAILS (non-zero exit) -- a host-staged number
+            # must never stand in for the xGMI one
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+            t = torch.ones(1, device="cuda")
+            dist.all_reduce(t)  # create torch's communicator eagerly (barriers of the timing protocol)
+            torch.cuda.synchronize()
+            from dpgo_amd.comm import DeviceComm
+            comm = DeviceComm.from_torch_distributed(dev_index)  # the data path's own communicator (C ABI dpgo_comm_*)
         else:
             dist.init_process_group(backend)
 
@@ -237,7 +345,7 @@ def main():
     my_ids = list(range(rank * apg, (rank + 1) * apg))
     agents = {a: DeviceAgent(graphs, plan, a, X0[ranges[a][0]:ranges[a][1]], params, device=dev_index)
               for a in my_ids}
-    cluster = RBCDCluster(plan, agents, rank, world, agents_per_rank=apg)
+    cluster = RBCDCluster(plan, agents, rank, world, agents_per_rank=apg, comm=comm)
     big = max(my_ids, key=lambda a: graphs[a].n())  # the agent whose kernels are profiled below
     agent = agents[big]
     nnzb_local = len(graphs[big].quadraticMatrix()[1])
@@ -348,45 +456,107 @@ def main():
                 traffic = (2.0 * pmc["FETCH_SIZE_KB"][key]["max"] + pmc["WRITE_SIZE_KB"][key]["max"]) * 1024.0
                 traffic_src = os.path.relpath(pmc_files[-1], ROOT)
                 break
+    # HBM figure first (SURVEY 8d protocol: every operand of the launch cycles through > 256 MB of private copies, so
+    # the 256 MB Infinity Cache cannot serve it); `warm` = back-to-back launches on the solver's own buffers, which is
+    # what the tCG loop sees for blocks whose working set fits that cache (all of BASELINE's configurations)
+    ach_rot = hb / (ms_hrot.value * 1e-3) / 1e9
+    kname = "%s<%d,%d,%d>" % ("k_tcg_hess_span" if ((d + 1) * r) % 2 == 0 else "k_tcg_hess", d, r,
+                              4 if n_local < 40000 else 1)
+    b_ = d + 1
+    vec = 8 * r * b_ * n_local
+    ms_it = (C.c_double * 5)()
+    dpgo_amd.lib.check(lib.dpgo_bench_iteration_kernels(agent.problem.handle, args.spmm_reps, 10, ms_it))
+    kernels = [dict(kernel="k_tcg_update (eta, r updates, pre-smoothing / block-Jacobi, <r,r>)",
+                    bytes_per_launch=8 * vec + 8 * b_ * b_ * n_local, avg_launch_us=ms_it[0] * 1e3)]
+    ml_info = None
+    if args.precond == "multilevel":
+        ml_info = agent.problem.multilevelInfo()
+        qb = nnzb_local * (8 * b_ * b_ + 4) + 4 * (n_local + 1)
+        pbb = 8 * b_ * b_ * n_local
+        Nc = ml_info["sizes"][-1] * b_
+        kernels += [
+            dict(kernel="k_ml_restrict, level 0 (r - A x1 in one pass over Q, P^T, aggregate sums)",
+                 bytes_per_launch=qb + 2 * vec + pbb + vec // ml_info["ks"][0], avg_launch_us=ms_it[1] * 1e3),
+            dict(kernel="k_ml_coarse_prolong (dense inverse of %d unknowns, fp64, + prolongation)" % Nc,
+                 bytes_per_launch=8 * Nc * Nc + 8 * r * Nc + (2 * vec + pbb if len(ml_info["ks"]) == 1 else 0),
+                 avg_launch_us=ms_it[2] * 1e3),
+            dict(kernel="k_ml_post (post-smoothing in the SpMM epilogue, projection, <r,r>, <z,r>)",
+                 bytes_per_launch=qb + 4 * vec + pbb, avg_launch_us=ms_it[3] * 1e3),
+        ]
+    for k_ in kernels:
+        k_["achieved"] = k_["bytes_per_launch"] / max(k_["avg_launch_us"], 1e-9) / 1e3
+        k_["frac"] = k_["achieved"] / HBM_PEAK_GBS
     roofline = dict(bound="hbm",
-                    kernel="%s<%d,%d,1> (one tCG step: Q*z block-SpMM + Riemannian-Hessian epilogue + in-place "
-                           "direction / H-direction recurrences)"
-                           % ("k_tcg_hess_span" if ((d + 1) * r) % 2 == 0 else "k_tcg_hess", d, r),
-                    achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS, traffic=traffic,
-                    traffic_source=traffic_src,
-                    bytes_per_launch=hb, avg_launch_us=ms_hess.value * 1e3,
-                    rotating=dict(buffer_sets=hsets, avg_launch_us=ms_hrot.value * 1e3,
-                                  achieved=hb / (ms_hrot.value * 1e-3) / 1e9,
-                                  frac=hb / (ms_hrot.value * 1e-3) / 1e9 / HBM_PEAK_GBS),
+                    kernel="%s (one tCG step: Q*z block-SpMM + Riemannian-Hessian epilogue + in-place direction / "
+                           "H-direction recurrences)" % kname,
+                    achieved=ach_rot, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach_rot / HBM_PEAK_GBS, traffic=traffic,
+                    traffic_source=traffic_src, bytes_per_launch=hb, avg_launch_us=ms_hrot.value * 1e3,
+                    protocol="HIP events over %d launches, every operand rotating through %d private sets (> 256 MB "
+                             "in total): HBM-only rate" % (args.spmm_reps, hsets),
+                    warm=dict(avg_launch_us=ms_hess.value * 1e3, achieved=ach, frac=ach / HBM_PEAK_GBS,
+                              protocol="back-to-back launches on the solver's own buffers (Infinity-Cache resident "
+                                       "working set, what the tCG loop sees)"),
                     spmm_only=dict(kernel="k_spmm<%d,%d> (plain Q*X)" % (d, r), bytes_per_launch=sb,
-                                   avg_launch_us=ms_spmm.value * 1e3,
-                                   achieved=sb / (ms_spmm.value * 1e-3) / 1e9,
-                                   frac=sb / (ms_spmm.value * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                   rotating=dict(buffer_sets=nsets, total_MB=nsets * set_bytes.value / 1e6,
-                                                 avg_launch_us=ms_rot.value * 1e3,
-                                                 achieved=sb / (ms_rot.value * 1e-3) / 1e9,
-                                                 frac=sb / (ms_rot.value * 1e-3) / 1e9 / HBM_PEAK_GBS)))
+                                   avg_launch_us=ms_rot.value * 1e3,
+                                   achieved=sb / (ms_rot.value * 1e-3) / 1e9,
+                                   frac=sb / (ms_rot.value * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                   buffer_sets=nsets, total_MB=nsets * set_bytes.value / 1e6,
+                                   warm=dict(avg_launch_us=ms_spmm.value * 1e3,
+                                             achieved=sb / (ms_spmm.value * 1e-3) / 1e9,
+                                             frac=sb / (ms_spmm.value * 1e-3) / 1e9 / HBM_PEAK_GBS)),
+                    kernels=kernels, cycle_tail_us=ms_it[4] * 1e3, multilevel=ml_info)
 
     cpu = None
+    jac_step = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         agent.restore()
-        try:
-            cpu = cpu_baseline(meas, n, agent.X.cpu().numpy(), r, args.cpu_budget_s, args.precond)
+        X_state = agent.X.cpu().numpy()
+        try:  # the device's block-Jacobi step from the same iterate: what the 1-core port below restates
+            Xj = agent.X.clone()
+            rj = dpgo_amd.QuadraticOptimizer(agent.problem, dpgo_amd.ROptParameters(precond="jacobi")).optimizeDevice(Xj)
+            jac_step = dict(fOpt=rj.fOpt, tcg_iterations=rj.tcg_iterations)
+        except Exception as exc:  # noqa: BLE001
+            sys.stderr.write("bench.py: device block-Jacobi comparison step failed: %r\n" % (exc,))
+        try:  # reference configuration (exact factor, 8 agents on 8 cores), from the benchmark's initial iterate
+            cpu = cpu_baseline_reference(meas, n, X0, r)
         except Exception as exc:  # noqa: BLE001 -- report instead of losing the GPU measurement
-            sys.stderr.write("bench.py: cpu_baseline failed: %r\n" % (exc,))
-            cpu = None
+            sys.stderr.write("bench.py: cpu_baseline (reference configuration) failed: %r\n" % (exc,))
+        try:  # the device algorithm on one core, same step as the GPU's (same settled iterate)
+            port = cpu_baseline(meas, n, X_state, r, args.cpu_budget_s, "jacobi")
+            if cpu is None:
+                cpu = port
+            else:
+                cpu["single_agent_port"] = port
+        except Exception as exc:  # noqa: BLE001
+            sys.stderr.write("bench.py: cpu_baseline (port) failed: %r\n" % (exc,))
 
     also = None
-    if rank == 0 and world == 1 and args.workload == "grid100k" and not args.no_secondary:
-        # sphere2500 (BASELINE configs[1]) with the default preconditioner and with the opt-in multilevel one
-        also = {}
-        for key, pc in (("sphere2500", "jacobi"), ("sphere2500_multilevel", "multilevel")):
-            try:  # a side measurement must never cost the main line
-                also[key] = secondary_single_agent("sphere2500", r, pc, args.steps, args.warmup, args.settle)
-            except Exception as exc:  # noqa: BLE001
-                also[key] = {"error": repr(exc)}
+    to_tol = None
+    if rank == 0 and world == 1 and not args.no_secondary:
+        # products-to-tolerance and time-to-gradnorm on this workload with both preconditioners, and the same for
+        # sphere2500 (BASELINE configs[1]); then the fixed-work step rate of sphere2500
+        to_tol = {}
+        for wl in ([args.workload] + (["sphere2500"] if args.workload == "grid100k" else [])):
+            for pc in ("multilevel", "jacobi"):
+                try:  # a side measurement must never cost the main line
+                    to_tol["%s/%s" % (wl, pc)] = time_to_tolerance(wl, r, pc)
+                except Exception as exc:  # noqa: BLE001
+                    to_tol["%s/%s" % (wl, pc)] = {"error": repr(exc)}
+        if args.workload == "grid100k":
+            also = {}
+            for key, pc in (("sphere2500", "multilevel"), ("sphere2500_jacobi", "jacobi")):
+                try:
+                    also[key] = secondary_single_agent("sphere2500", r, pc, args.steps, args.warmup, args.settle)
+                except Exception as exc:  # noqa: BLE001
+                    also[key] = {"error": repr(exc)}
 
     if rank == 0:
+        if cpu and cpu.get("single_agent_port", cpu).get("fOpt") is not None:
+            port = cpu.get("single_agent_port", cpu)
+            port["device_fOpt_same_step"] = jac_step["fOpt"] if jac_step else None
+            if jac_step:
+                port["rel_diff_fOpt_vs_device"] = abs(port["fOpt"] - jac_step["fOpt"]) / abs(port["fOpt"])
+                port["device_tcg_iterations_same_step"] = jac_step["tcg_iterations"]
         out = {
             "metric": "rbcd_iterations_per_sec",
             "value": args.steps / elapsed,
@@ -402,11 +572,13 @@ def main():
             "data": "synthetic" if args.workload.startswith("grid") else "g2o dataset shipped in data/",
             "config": {"workload": desc, "agents": num_agents, "agents_per_gpu": apg, "r": r, "d": d,
                        "local_solver": "RTR 3x<=50 tCG, Delta0=100, tol=1e-2 (reference defaults), %s precond" % (
-                           "block-Jacobi" if args.precond == "jacobi" else "two-level multigrid"),
+                           "block-Jacobi" if args.precond == "jacobi" else "multilevel (library default)"),
                        "schedule": "single agent" if num_agents == 1 else
                        "%d-colour parallel RBCD; 1 step = 1 sweep (every agent updates once); public-pose "
                        "exchange over %s" % (plan.num_colours, "device copies" if world == 1 else
-                                             ("RCCL p2p" if not cluster.stage else "gloo (host-staged)")),
+                                             ("RCCL p2p on the solver's stream (C ABI dpgo_comm_exchange)" if comm
+                                              else ("torch.distributed nccl p2p" if not cluster.stage
+                                                    else "gloo (host-staged)"))),
                        "dist_backend": backend,
                        "poses_per_agent": n_local, "nnzb_per_agent": nnzb_local},
             "roofline": roofline,
@@ -417,7 +589,9 @@ def main():
                         "gradnorm_trajectory": [g for _, g in trajectory],
                         "cost_2f_after_step": 2 * f1, "gradnorm_after_step": g1,
                         "tcg_iterations_per_step_rank0": tcg_total / max(args.steps, 1),
-                        "exchange_ms_per_step_rank0": 1e3 * t_exchange[0] / max(args.steps, 1)},
+                        "us_per_tcg_iteration_rank0": 1e6 * elapsed / max(tcg_total, 1),
+                        "exchange_ms_per_step_rank0": 1e3 * t_exchange[0] / max(args.steps, 1),
+                        "to_tolerance": to_tol},
         }
         print(json.dumps(out))
     if world > 1:

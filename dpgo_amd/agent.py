@@ -7,8 +7,9 @@ What the reference does per RBCD iteration (src/PGOAgent.cpp:376-432, 938-995):
 Here X, the neighbour tile buffer, G and Q stay in HBM; one agent maps to one GPU / one process
 and the public-pose exchange (examples/MultiRobotExample.cpp:183-204 does it by pointer calls
 inside one process; the wire unit is the LiftedPose, r x (d+1) doubles keyed by PoseID) is carried
-by RCCL point-to-point send/recv (torch.distributed, backend "nccl"), one grouped batch per
-exchange.  The same classes also run N agents inside one process on one GPU (device-to-device
+by RCCL point-to-point send/recv issued by the solver library itself on the solver's stream
+(dpgo_amd/comm.py -> C ABI dpgo_comm_exchange: one grouped ncclSend / ncclRecv batch per exchange, no host
+wait; torch.distributed is the rendezvous and the fallback transport).  The same classes also run N agents inside one process on one GPU (device-to-device
 copies instead of RCCL) -- used by the single-GPU parity tests.
 
 Schedule for parallel runs: the two-colour RBCD of SURVEY 8e -- agents of one colour update
@@ -233,14 +234,22 @@ class RBCDCluster:
     agents [k*apr, (k+1)*apr) on rank k under torch.distributed (one process per GPU)."""
 
     def __init__(self, plan: ExchangePlan, local_agents: Dict[int, object], rank: int = 0, world: int = 1,
-                 stage_through_host: Optional[bool] = None, agents_per_rank: int = 1):
+                 stage_through_host: Optional[bool] = None, agents_per_rank: int = 1, comm=None,
+                 loopback: bool = False):
+        """comm: a dpgo_amd.comm.DeviceComm -- the exchange and the reductions are then issued by the solver library
+        itself (RCCL on the solver's stream, no host wait); None: torch.distributed carries them (gloo on CPU test
+        boxes, or "nccl" without the library-owned communicator).  loopback (with comm): pairs of agents hosted by
+        this process also travel through the communicator (self send / recv) instead of device copies -- runs the
+        whole transport on a single GPU."""
         self.plan, self.agents, self.rank, self.world = plan, local_agents, rank, world
         self.agents_per_rank = int(agents_per_rank)
-        if world > 1:
+        self.comm = comm
+        self.loopback = bool(loopback) and comm is not None
+        if world > 1 and comm is None:
             import torch.distributed as dist
             if stage_through_host is None:
                 stage_through_host = dist.get_backend() == "gloo"
-        self.stage = bool(stage_through_host)
+        self.stage = bool(stage_through_host) and comm is None
 
     def owner(self, agent_id: int) -> int:
         """Rank hosting an agent: consecutive ids share a rank (agents_per_rank = 2 puts one agent of
@@ -253,11 +262,17 @@ class RBCDCluster:
         device copies; remote pairs form ONE grouped batch of isend/irecv (ncclGroupStart/End under
         RCCL), so no ordering between ranks can deadlock."""
         ops, staged = [], []
+        sends, recvs = [], []
         dist = None
         for a, q in (messages if messages is not None else self.plan.messages(receivers)):
             a_here, q_here = a in self.agents, q in self.agents
-            if a_here and q_here:
+            if a_here and q_here and not self.loopback:
                 self.agents[q].recv_view(a, aux).copy_(self.agents[a].pack(q, aux))
+            elif self.comm is not None:
+                if a_here:
+                    sends.append((self.owner(q), self.agents[a].pack(q, aux)))
+                if q_here:
+                    recvs.append((self.owner(a), self.agents[q].recv_view(a, aux)))
             elif a_here:
                 import torch.distributed as dist
                 buf = self.agents[a].pack(q, aux)
@@ -271,11 +286,30 @@ class RBCDCluster:
                     ops.append(dist.P2POp(dist.irecv, tmp, self.owner(a)))
                 else:
                     ops.append(dist.P2POp(dist.irecv, view, self.owner(a)))
+        if sends or recvs:  # library-owned RCCL communicator: one grouped batch on the solver's stream, no host wait
+            any_agent = next(iter(self.agents.values()))
+            self.comm.exchange(sends, recvs, any_agent.torch.cuda.current_stream().cuda_stream)
         if ops:
             for w in dist.batch_isend_irecv(ops):
                 w.wait()
             for view, tmp in staged:
                 view.copy_(tmp)
+
+    def _allreduce_host(self, values: np.ndarray) -> np.ndarray:
+        """Sum of a small host array over the ranks (cost / gradient-norm terms)."""
+        if self.world == 1:
+            return values
+        import torch
+        any_agent = next(iter(self.agents.values()))
+        dev = getattr(any_agent, "device", "cpu")
+        if self.comm is not None:
+            t = torch.tensor(values, dtype=torch.float64, device=dev)
+            self.comm.allreduce(t, 0, torch.cuda.current_stream().cuda_stream)
+            return t.cpu().numpy()
+        import torch.distributed as dist
+        t = torch.tensor(values, dtype=torch.float64, device="cpu" if self.stage else dev)
+        dist.all_reduce(t)
+        return t.cpu().numpy()
 
     def sweep(self) -> None:
         """One RBCD iteration: every colour class updates once (parallel within a class)."""
@@ -292,14 +326,7 @@ class RBCDCluster:
         for a, agent in self.agents.items():
             xqx, xg, g2 = agent.local_terms()
             out[a] = [0.5 * (xqx + xg), g2]
-        if self.world > 1:
-            import torch
-            import torch.distributed as dist
-            dev = getattr(next(iter(self.agents.values())), "device", "cpu")
-            t = torch.tensor(out, dtype=torch.float64, device="cpu" if self.stage else dev)
-            dist.all_reduce(t)
-            out = t.cpu().numpy()
-        return out
+        return self._allreduce_host(out)
 
     def run_greedy(self, max_iters: int = 1000, gradnorm_stop: float = 0.1):
         """The reference demo's schedule (examples/MultiRobotExample.cpp:170-255): every non-selected agent
@@ -338,10 +365,14 @@ class RBCDCluster:
             a = self.agents[0].X[0].cpu().numpy()
         if self.world > 1:
             import torch
-            import torch.distributed as dist
             dev = getattr(any_agent, "device", "cpu")
-            t = torch.tensor(a, dtype=torch.float64, device="cpu" if self.stage else dev)
-            dist.broadcast(t, src=self.owner(0))
+            if self.comm is not None:
+                t = torch.tensor(a, dtype=torch.float64, device=dev)
+                self.comm.broadcast(t, self.owner(0), torch.cuda.current_stream().cuda_stream)
+            else:
+                import torch.distributed as dist
+                t = torch.tensor(a, dtype=torch.float64, device="cpu" if self.stage else dev)
+                dist.broadcast(t, src=self.owner(0))
             a = t.cpu().numpy()
         return np.ascontiguousarray(a.T)  # tile [d+1, r] -> matrix r x (d+1)
 
@@ -358,12 +389,5 @@ class RBCDCluster:
         for agent in self.agents.values():
             xqx, xg, g2 = agent.local_terms()
             acc += [0.5 * (xqx + xg), g2]
-        if self.world > 1:
-            import torch
-            import torch.distributed as dist
-            any_agent = next(iter(self.agents.values()))
-            dev = getattr(any_agent, "device", "cpu")
-            t = torch.tensor(acc, dtype=torch.float64, device="cpu" if self.stage else dev)
-            dist.all_reduce(t)
-            acc = t.cpu().numpy()
+        acc = self._allreduce_host(acc)
         return float(acc[0]), float(acc[1]) ** 0.5

@@ -130,6 +130,11 @@ struct dpgo_problem_s {
   double* ml_dense = nullptr;  // inverse of the coarsest operator, row-major, leading dimension ml_lda
   int ml_lda = 0;
   double *ml_W = nullptr, *ml_Rx = nullptr;  // Gauss-Jordan panels (setup only)
+  // persistent single-XCD tCG kernel (small blocks, block-Jacobi / no preconditioner)
+  bool persist = false;
+  int persist_wgs = 0;  // wanted participants (workgroups on one XCD)
+  PersistCtrl* pctrl = nullptr;
+  PersistCtrl* hctrl = nullptr;  // pinned
   double* partials = nullptr;  // 5 regions of kPartialCap*kNP
   DevState* dstate = nullptr;  // 2 slots
   DevState* hstate = nullptr;  // pinned
@@ -490,7 +495,8 @@ int ml_symbolic_setup(dpgo_problem_s* p, const std::vector<int>& ks) {
   if (N > 16384) return fail(DPGO_ERR_INVALID, "multilevel: dense coarsest operator too large (" + std::to_string(N) +
                                                    " unknowns): use more levels / larger aggregates");
   p->ml_lda = ((N + kNB - 1) / kNB) * kNB;
-  HIPC(hipMalloc(&p->ml_dense, sizeof(double) * (size_t)p->ml_lda * p->ml_lda));
+  // + 8 rows: the apply kernel reads (and discards) the rows of a ghost node behind a ragged last node group
+  HIPC(hipMalloc(&p->ml_dense, sizeof(double) * (size_t)p->ml_lda * (p->ml_lda + 8)));
   HIPC(hipMalloc(&p->ml_W, sizeof(double) * (size_t)p->ml_lda * kNB));
   HIPC(hipMalloc(&p->ml_Rx, sizeof(double) * (size_t)p->ml_lda * kNB));
   HIPC(hipStreamSynchronize(p->stream));
@@ -543,7 +549,7 @@ int ml_numeric_setup_d(dpgo_problem_s* p) {
   HIPC(hipGetLastError());
   auto& Lc = p->ml.back();
   const int lda = p->ml_lda, N = Lc.n * p->b;
-  HIPC(hipMemsetAsync(p->ml_dense, 0, sizeof(double) * (size_t)lda * lda, p->stream));
+  HIPC(hipMemsetAsync(p->ml_dense, 0, sizeof(double) * (size_t)lda * (lda + 8), p->stream));
   hipLaunchKernelGGL(k_dense_pad_identity, dim3(1), dim3(kBlock), 0, p->stream, p->ml_dense, lda, N);
   hipLaunchKernelGGL(k_ml_dense_assemble<D>, dim3(flat_grid(Lc.A.nnzb)), dim3(kBlock), 0, p->stream, Lc.A.dev(),
                      Lc.slot_row, p->ml_dense, lda, Lc.A.nnzb);
@@ -570,6 +576,27 @@ int ml_ensure(dpgo_problem_s* p, double shift) {
   if (!p->ml_symbolic) CHK(ml_symbolic_setup(p, ml_default_ks(p->n, p->b, p->split)));
   p->ml_shift = shift;
   return ml_numeric_setup(p);
+}
+
+// Dense level + prolongation.  Large coarsest levels: two nodes per workgroup (halves the right-hand-side loads per
+// matrix byte); balanced rounds: every workgroup takes the same number of node groups (a ragged last round would leave
+// most of the chip idle while the dense inverse streams).
+int launch_coarse_prolong(dpgo_problem_s* p, const dpgo_problem_s::MlLevel& L, const dpgo_problem_s::MlLevel& C,
+                          const DevState* gate) {
+  const int nodes = C.n >= 1024 ? 2 : 1;
+  const int groups = (C.n + nodes - 1) / nodes;
+  const int rounds = (groups + kMaxGrid - 1) / kMaxGrid;
+  const int gc = std::max(1, (groups + rounds - 1) / rounds);
+  DISPATCH(p->d, p->r, {
+    if (nodes == 2)
+      hipLaunchKernelGGL((k_ml_coarse_prolong<D, R, 2>), dim3(gc), dim3(kBlock), 0, p->stream, p->ml_dense, p->ml_lda, C.r,
+                         L.x1, L.Pb, L.k, L.x, gate, L.n, C.n);
+    else
+      hipLaunchKernelGGL((k_ml_coarse_prolong<D, R, 1>), dim3(gc), dim3(kBlock), 0, p->stream, p->ml_dense, p->ml_lda, C.r,
+                         L.x1, L.Pb, L.k, L.x, gate, L.n, C.n);
+  });
+  HIPC(hipGetLastError());
+  return DPGO_OK;
 }
 
 // The launches of one cycle after the pre-smoothing step of level 0 (x1 = w Dinv r is in ml[0].x1):
@@ -603,12 +630,7 @@ int launch_ml_tail(dpgo_problem_s* p, const double* Xdev, const double* r, doubl
   {  // dense level + prolongation
     auto& L = p->ml[nl - 2];
     auto& C = p->ml[nl - 1];
-    // balanced rounds: every workgroup takes the same number of coarsest nodes (a ragged last round would leave most
-    // of the chip idle while the dense inverse streams)
-    const int rounds = (C.n + kMaxGrid - 1) / kMaxGrid;
-    const int gc = std::max(1, (C.n + rounds - 1) / rounds);
-    DISPATCH(p->d, p->r, hipLaunchKernelGGL((k_ml_coarse_prolong<D, R>), dim3(gc), dim3(kBlock), 0, p->stream,
-                                            p->ml_dense, p->ml_lda, C.r, L.x1, L.Pb, L.k, L.x, gate, L.n, C.n));
+    CHK(launch_coarse_prolong(p, L, C, gate));
   }
   for (int l = nl - 2; l >= 1; --l) {  // up
     auto& L = p->ml[l];
@@ -631,6 +653,44 @@ int launch_ml_apply(dpgo_problem_s* p, const double* Xdev, const double* v, doub
   return launch_ml_tail(p, Xdev, v, z, nullptr, nullptr);
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Persistent tCG (kernels/persist.h): one launch runs the whole tCG_TR loop of an outer iteration on one XCD.
+__global__ void k_persist_reset(PersistCtrl* c) {
+  c->counts = 0ull;
+  c->target = -1;
+  c->bar = 0u;
+  c->error = 0;
+  c->iters = 0u;
+  c->members = 0u;
+}
+
+// returns DPGO_OK with *used = false when the kernel reported a time-out (the caller falls back to the two-kernel scheme)
+int run_tcg_persistent(dpgo_problem_s* p, const double* dinv, bool* used) {
+  *used = false;
+  hipLaunchKernelGGL(k_persist_reset, dim3(1), dim3(1), 0, p->stream, p->pctrl);
+  const int grid = 8 * p->persist_wgs;
+  DISPATCH(p->d, p->r, LAUNCH_SPLIT(p, k_tcg_persist, grid, p->Q.dev(), p->x1, p->S1, p->g1, dinv, p->delta, p->Hd, p->eta,
+                                    p->rr, p->z, p->pA(), p->pB(), p->dstate + p->cur, p->dstate + (p->cur ^ 1), p->pctrl,
+                                    p->n, p->hflag, p->gen));
+  HIPC(hipGetLastError());
+  HIPC(hipMemcpyAsync(p->hctrl, p->pctrl, sizeof(PersistCtrl), hipMemcpyDeviceToHost, p->stream));
+  HIPC(hipMemcpyAsync(p->hstate, p->dstate + (p->cur ^ 1), sizeof(DevState), hipMemcpyDeviceToHost, p->stream));
+  HIPC(hipStreamSynchronize(p->stream));
+  if (p->hctrl->error || p->hctrl->members == 0) {
+    p->persist = false;  // placement did not hold on this box: do not try again on this handle
+    if (std::getenv("DPGO_PERSIST_VERBOSE"))
+      std::fprintf(stderr, "dpgo_hip: persistent tCG timed out (members %u); falling back to the two-kernel scheme\n",
+                   p->hctrl->members);
+    return DPGO_OK;
+  }
+  if (std::getenv("DPGO_PERSIST_VERBOSE"))
+    std::fprintf(stderr, "dpgo_hip: persistent tCG: %u participants on XCD %d, %u iterations\n", p->hctrl->members,
+                 p->hctrl->target, p->hctrl->iters);
+  p->cur ^= 1;
+  *used = true;
+  return DPGO_OK;
+}
+
 // One ROPTLIB SolversTR::Run outer iteration: tCG + retraction + rho test.  State stays on the device; the host
 // feeds tCG-step kernels just-in-time (or polls the state every `tcg_poll_interval` inner iterations).
 int rtr_outer_iteration(dpgo_problem_s* p, const dpgo_ropt_params* prm, const double* dinv, Counters& cnt,
@@ -638,6 +698,24 @@ int rtr_outer_iteration(dpgo_problem_s* p, const dpgo_ropt_params* prm, const do
   p->gen += 1;
   const bool ml = prm->precond == DPGO_PRECOND_MULTILEVEL;
   p->zr_from_post = ml;
+  if (p->persist && !ml) {
+    bool used = false;
+    CHK(run_tcg_persistent(p, dinv, &used));
+    if (used) {
+      if (p->hstate->rtr_stop) {
+        p->saw_rtr_stop = true;
+        return DPGO_OK;
+      }
+      CHK(launch_retract(p, p->x1, p->eta, 1.0, p->x2, p->dstate + p->cur));
+      CHK(launch_grad(p, p->x2, p->g2, p->S2, nullptr, p->dstate + p->cur));
+      cnt.spmm += 1;
+      CHK(launch_hess(p, p->x1, p->S1, p->eta, p->g1, p->Hd, p->pH(), p->dstate + p->cur, 0));
+      cnt.spmm += 1;
+      CHK(launch_rtr_update(p));
+      if (poll_at_end) CHK(poll_state(p));
+      return DPGO_OK;
+    }
+  }
   // multilevel: the update kernel writes the pre-smoothing step of level 0 instead of the block-Jacobi z; the cycle's
   // last kernel produces z and the partial sums <r,r>, <z,r>
   auto update = [&](int first) -> int {
@@ -721,6 +799,7 @@ int run_optimize(dpgo_problem_s* p, const dpgo_ropt_params* prm, dpgo_ropt_resul
   Counters cnt;
   std::memset(res, 0, sizeof(*res));
   res->tCGStatus = DPGO_TCG_MAXITER;
+  if (p->hctrl) std::memset(p->hctrl, 0, sizeof(PersistCtrl));
   const double* dinv = nullptr;
   if (prm->precond == DPGO_PRECOND_BLOCK_JACOBI) {
     CHK(build_dinv(p, prm->precond_shift));
@@ -917,6 +996,36 @@ int tune_launch_caps(dpgo_problem_s* p) {
   return DPGO_OK;
 }
 
+// Persistent tCG: used for blocks whose tCG working set stays in one XCD's 4 MiB L2 neighbourhood and whose SpMM tiles
+// can be spread over the workgroups ONE XCD can hold at once (32 CUs x occupancy).  DPGO_PERSIST=0/1 overrides.
+int tune_persist(dpgo_problem_s* p) {
+  p->persist = false;
+  int occ = 0;
+  DISPATCH(p->d, p->r, {
+    if (p->split == 4)
+      HIPC(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_tcg_persist<D, R, 4>, kBlock, 0));
+    else if (p->split == 2)
+      HIPC(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_tcg_persist<D, R, 2>, kBlock, 0));
+    else
+      HIPC(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_tcg_persist<D, R, 1>, kBlock, 0));
+  });
+  int dev = 0, cus = 0;
+  HIPC(hipGetDevice(&dev));
+  HIPC(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+  const int per_xcd = std::max(1, cus / 8);
+  // the occupancy API can be one block per CU high when the SGPR file is the limit (MI355X_MICROARCH.md, residency);
+  // this kernel is VGPR-bound (2-3 blocks per CU), where it is exact -- and a wrong count only costs the time-out
+  const int cap = std::max(1, std::min(kPartialCap, per_xcd * std::max(1, occ >= 7 ? occ - 1 : occ)));
+  const int P = (64 / (p->b * p->split)) * kWaves;
+  const int tiles = std::max(1, (p->n + P - 1) / P);
+  p->persist_wgs = std::min(tiles, cap);
+  if (const char* e = std::getenv("DPGO_PERSIST_WGS")) p->persist_wgs = std::max(1, std::min(cap, std::atoi(e)));
+  bool on = false;  // opt-in until the single-XCD placement has been validated on the target box
+  if (const char* e = std::getenv("DPGO_PERSIST")) on = std::atoi(e) != 0;
+  p->persist = on && tiles <= 4 * cap;
+  return DPGO_OK;
+}
+
 }  // namespace
 
 // =====================================================================================
@@ -924,6 +1033,7 @@ extern "C" {
 
 const char* dpgo_version(void) { return "dpgo_hip 0.1 (gfx950)"; }
 const char* dpgo_last_error(void) { return g_err.c_str(); }
+void dpgo_set_last_error(const char* msg) { g_err = msg ? msg : ""; }  // for the other translation units of the library
 
 int dpgo_device_count(int* count) {
   if (!count) return fail(DPGO_ERR_INVALID, "null count");
@@ -996,6 +1106,9 @@ int dpgo_problem_create(dpgo_problem_t* out, int r, int d, int n, int device) {
     HIPC(hipMemsetAsync(p->partials, 0, sizeof(double) * 5 * kPartialCap * kNP, p->stream));
     HIPC(hipMalloc(&p->dstate, sizeof(DevState) * 2));
     HIPC(hipHostMalloc(&p->hstate, sizeof(DevState)));
+    HIPC(hipMalloc(&p->pctrl, sizeof(PersistCtrl)));
+    HIPC(hipHostMalloc(&p->hctrl, sizeof(PersistCtrl)));
+    CHK(tune_persist(p));
     HIPC(hipHostMalloc(&p->hflag, 64, hipHostMallocCoherent | hipHostMallocMapped));
     *p->hflag = 0ull;
     HIPC(hipStreamSynchronize(p->stream));
@@ -1024,6 +1137,8 @@ int dpgo_problem_destroy(dpgo_problem_t p) {
   if (p->dstate) (void)hipFree(p->dstate);
   if (p->hstate) (void)hipHostFree(p->hstate);
   if (p->hflag) (void)hipHostFree(p->hflag);
+  if (p->pctrl) (void)hipFree(p->pctrl);
+  if (p->hctrl) (void)hipHostFree(p->hctrl);
   if (p->own_stream) (void)hipStreamDestroy(p->own_stream);
   delete p;
   return DPGO_OK;
@@ -1622,6 +1737,26 @@ int dpgo_debug_timeline(long long* out /* [2][16] */) {
 }
 #endif
 
+int dpgo_problem_persistent_info(dpgo_problem_t p, int* enabled, int* workgroups, int* last_members, int* last_iterations,
+                                 int* last_xcd) {
+  if (!p) return fail(DPGO_ERR_INVALID, "null handle");
+  if (enabled) *enabled = p->persist ? 1 : 0;
+  if (workgroups) *workgroups = p->persist_wgs;
+  if (last_members) *last_members = p->hctrl ? (int)p->hctrl->members : 0;
+  if (last_iterations) *last_iterations = p->hctrl ? (int)p->hctrl->iters : 0;
+  if (last_xcd) *last_xcd = p->hctrl ? p->hctrl->target : -1;
+  return DPGO_OK;
+}
+
+int dpgo_problem_set_persistent(dpgo_problem_t p, int enable) {
+  if (!p) return fail(DPGO_ERR_INVALID, "null handle");
+  const int P = (64 / (p->b * p->split)) * kWaves;
+  const int tiles = std::max(1, (p->n + P - 1) / P);
+  if (enable && tiles > 4 * kPartialCap) return fail(DPGO_ERR_UNSUPPORTED, "block too large for the persistent tCG kernel");
+  p->persist = enable != 0;
+  return DPGO_OK;
+}
+
 int dpgo_bench_spmm(dpgo_problem_t p, int reps, int warmup, double* avg_ms) {
   CHK(check_ready(p));
   if (reps <= 0 || !avg_ms) return fail(DPGO_ERR_INVALID, "bad arguments");
@@ -1804,6 +1939,75 @@ int dpgo_bench_hess(dpgo_problem_t p, int reps, int warmup, double* avg_ms) {
   HIPC(hipEventDestroy(e1));
   *avg_ms = (double)ms / reps;
   return DPGO_OK;
+}
+
+int dpgo_bench_iteration_kernels(dpgo_problem_t p, int reps, int warmup, double out_ms[5]) {
+  CHK(check_ready(p));
+  if (reps <= 0 || !out_ms) return fail(DPGO_ERR_INVALID, "bad arguments");
+  for (int q = 0; q < 5; ++q) out_ms[q] = 0.0;
+  // a state in which no kernel takes an early exit (as dpgo_bench_hess); alpha = z_r / d_Hd stays finite
+  std::memset(p->hstate, 0, sizeof(DevState));
+  p->hstate->z_r = 1.0;
+  p->hstate->theta = 1.0;
+  p->hstate->kappa = -1.0;
+  p->hstate->max_inner = 1 << 30;
+  p->hstate->Delta = 1e300;
+  CHK(push_state(p));
+  CHK(build_dinv(p, p->ml_ready ? p->ml_shift : 1e-1));
+  {  // <delta, H delta> partials of a "previous k_tcg_hess": positive, so that the update kernel takes its regular path
+    std::vector<double> ones((size_t)kPartialCap * kNP, 1.0);
+    HIPC(hipMemcpyAsync(p->pA(), ones.data(), sizeof(double) * ones.size(), hipMemcpyHostToDevice, p->stream));
+    HIPC(hipStreamSynchronize(p->stream));
+  }
+  hipEvent_t e0, e1;
+  HIPC(hipEventCreate(&e0));
+  HIPC(hipEventCreate(&e1));
+  auto timed = [&](auto&& launch, double* out) -> int {
+    for (int i = 0; i < warmup; ++i) CHK(launch());
+    HIPC(hipEventRecord(e0, p->stream));
+    for (int i = 0; i < reps; ++i) CHK(launch());
+    HIPC(hipEventRecord(e1, p->stream));
+    HIPC(hipEventSynchronize(e1));
+    float ms = 0.f;
+    HIPC(hipEventElapsedTime(&ms, e0, e1));
+    *out = (double)ms / reps;
+    return DPGO_OK;
+  };
+  const bool ml = p->ml_ready;
+  int rc = timed([&]() -> int {
+    const int cur = p->cur;
+    int r2 = launch_tcg_update(p, p->dinv, 0, ml ? p->ml[0].x1 : nullptr, ml ? p->ml_omega : 0.0);
+    p->cur = cur;  // keep reading the pushed state
+    return r2;
+  }, &out_ms[0]);
+  if (rc == DPGO_OK && ml) {
+    const int nl = (int)p->ml.size();
+    auto& L0 = p->ml[0];
+    auto& C1 = p->ml[1];
+    rc = timed([&]() -> int {
+      DISPATCH(p->d, p->r, LAUNCH_SPLIT(p, k_ml_restrict, p->grid_s(), p->Q.dev(), L0.x1, p->rr, L0.Pb, p->ml_shift, L0.k,
+                                        C1.r, C1.k ? C1.dinv : (const double*)nullptr, p->ml_omega, C1.x1,
+                                        (const DevState*)nullptr, p->n));
+      HIPC(hipGetLastError());
+      return DPGO_OK;
+    }, &out_ms[1]);
+    if (rc == DPGO_OK) rc = timed([&]() -> int {
+      auto& L = p->ml[nl - 2];
+      auto& Cc = p->ml[nl - 1];
+      return launch_coarse_prolong(p, L, Cc, nullptr);
+    }, &out_ms[2]);
+    if (rc == DPGO_OK) rc = timed([&]() -> int {
+      DISPATCH(p->d, p->r, LAUNCH_SPLIT(p, k_ml_post, p->grid_s(), p->Q.dev(), p->x1, L0.x, p->rr, p->dinv, p->ml_omega,
+                                        p->ml_shift, p->z, p->pB(), (const DevState*)nullptr, p->n));
+      HIPC(hipGetLastError());
+      return DPGO_OK;
+    }, &out_ms[3]);
+    if (rc == DPGO_OK)
+      rc = timed([&]() -> int { return launch_ml_tail(p, p->x1, p->rr, p->z, p->pB(), nullptr); }, &out_ms[4]);
+  }
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  return rc;
 }
 
 // ---- manifold ----

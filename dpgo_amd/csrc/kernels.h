@@ -24,6 +24,7 @@ namespace dpgo {
 #include "kernels/common.h"
 #include "kernels/problem.h"
 #include "kernels/tcg.h"
+#include "kernels/persist.h"
 #include "kernels/multilevel.h"
 #include "kernels/dense.h"
 #include "kernels/manifold.h"

@@ -1,6 +1,6 @@
 // kernels/common.h -- shared definitions: solver state record, thread geometry, XCD-aware tile walk, span access, reductions,
 // small dense pieces (projection, block-Jacobi), the block-SpMM gather core.
-// Part of kernels.h (included inside namespace dpgo, in this order: common.h, problem.h, tcg.h, multilevel.h, dense.h, manifold.h, rtr.h, agent.h).
+// Part of kernels.h (included inside namespace dpgo, in this order: common.h, problem.h, tcg.h, persist.h, multilevel.h, dense.h, manifold.h, rtr.h, agent.h).
 #pragma once
 
 
@@ -371,7 +371,17 @@ __device__ __forceinline__ RowIdx row_idx_load(const int32_t* __restrict__ rowpt
   return ri;
 }
 
-template <int D, int R, int SPLIT>
+// NT: the gathered tiles of V are loaded with the nontemporal policy, which is served by the XCD's L2 and never by this
+// CU's L1 (MI355X_MICROARCH.md, "Workgroup dispatch ... visibility") -- used by the persistent tCG kernel, where V was
+// written by other workgroups of the SAME launch.
+template <bool NT>
+__device__ __forceinline__ double ld_tile(const double* __restrict__ p) {
+  if constexpr (NT)
+    return __builtin_nontemporal_load(p);
+  else
+    return *p;
+}
+template <int D, int R, int SPLIT, bool NT = false>
 __device__ __forceinline__ void spmm_col_pre(const RowIdx& ri, const int32_t* __restrict__ colidx,
                                              const double* __restrict__ vals, const double* __restrict__ V, int s,
                                              int c, double (&acc)[R]) {
@@ -403,7 +413,7 @@ __device__ __forceinline__ void spmm_col_pre(const RowIdx& ri, const int32_t* __
 #pragma unroll
         for (int kk = 0; kk < B; ++kk) qa[kk] = q[kk];
 #pragma unroll
-        for (int e = 0; e < T; ++e) xa[e] = x[e];
+        for (int e = 0; e < T; ++e) xa[e] = ld_tile<NT>(x + e);
       }
       if (okB) {
         const double* __restrict__ q = vals + (size_t)(t0 + kB) * BB + c * B;
@@ -411,7 +421,7 @@ __device__ __forceinline__ void spmm_col_pre(const RowIdx& ri, const int32_t* __
 #pragma unroll
         for (int kk = 0; kk < B; ++kk) qb[kk] = q[kk];
 #pragma unroll
-        for (int e = 0; e < T; ++e) xb[e] = x[e];
+        for (int e = 0; e < T; ++e) xb[e] = ld_tile<NT>(x + e);
       }
       if (okA) {
 #pragma unroll
@@ -442,7 +452,7 @@ __device__ __forceinline__ void spmm_col_pre(const RowIdx& ri, const int32_t* __
 #pragma unroll
       for (int kk = 0; kk < B; ++kk) {
 #pragma unroll
-        for (int a = 0; a < R; ++a) acc[a] = fma(x[kk * R + a], qk[kk], acc[a]);
+        for (int a = 0; a < R; ++a) acc[a] = fma(ld_tile<NT>(x + kk * R + a), qk[kk], acc[a]);
       }
     }
   }
@@ -456,7 +466,7 @@ __device__ __forceinline__ void spmm_col_pre(const RowIdx& ri, const int32_t* __
 #pragma unroll
     for (int kk = 0; kk < B; ++kk) {
 #pragma unroll
-      for (int a = 0; a < R; ++a) acc[a] = fma(x[kk * R + a], qk[kk], acc[a]);
+      for (int a = 0; a < R; ++a) acc[a] = fma(ld_tile<NT>(x + kk * R + a), qk[kk], acc[a]);
     }
   }
   if (SPLIT > 1) {  // fixed-order tree over the slices; the sum lands in slice 0
@@ -468,12 +478,12 @@ __device__ __forceinline__ void spmm_col_pre(const RowIdx& ri, const int32_t* __
   }
 }
 
-template <int D, int R, int SPLIT>
+template <int D, int R, int SPLIT, bool NT = false>
 __device__ __forceinline__ void spmm_col(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colidx,
                                          const double* __restrict__ vals, const double* __restrict__ V,
                                          int i, int s, int c, bool ok, double (&acc)[R]) {
   const RowIdx ri = row_idx_load<D, SPLIT>(rowptr, colidx, i, s, c, ok);
-  spmm_col_pre<D, R, SPLIT>(ri, colidx, vals, V, s, c, acc);
+  spmm_col_pre<D, R, SPLIT, NT>(ri, colidx, vals, V, s, c, acc);
 }
 
 // ---------------------------------------------------------------- kernel arguments

@@ -1,6 +1,6 @@
 // kernels/multilevel.h -- aggregation-multigrid preconditioner (the device path's default): per-iteration cycle kernels and
 // the on-device setup of the hierarchy (prolongation blocks, Galerkin operators, dense inverse of the coarsest operator).
-// Part of kernels.h (included inside namespace dpgo, in this order: common.h, problem.h, tcg.h, multilevel.h, dense.h, manifold.h, rtr.h, agent.h).
+// Part of kernels.h (included inside namespace dpgo, in this order: common.h, problem.h, tcg.h, persist.h, multilevel.h, dense.h, manifold.h, rtr.h, agent.h).
 #pragma once
 
 // ================================================================ multilevel preconditioner
@@ -123,48 +123,61 @@ __global__ __launch_bounds__(kBlock) void k_ml_restrict(BsrDev A, const double* 
   }
 }
 
-// Coarsest level + prolongation to the level above it.  One workgroup per coarsest node a: its B rows of
-// xc = M rc (M = dense inverse, row-major with leading dimension lda), then x_i = x1_i + P_i xc_a for the aggregate's nodes.
-template <int D, int R>
+// Coarsest level + prolongation to the level above it.  One workgroup per NODES coarsest nodes: their B rows each of
+// xc = M rc (M = dense inverse, row-major with leading dimension lda), then x_i = x1_i + P_i xc_a for the aggregates'
+// nodes.  Every wave takes a quarter of the columns and ALL rows of the workgroup's nodes: the right-hand side rc
+// (R doubles per column: 10x the bytes of a matrix row) is read once per workgroup, not once per row.  A lane owns
+// column PAIRS, so that the matrix rows AND the 2R right-hand-side values move as 16-byte loads (with 8-byte loads the
+// kernel is bound by load issue, not by bytes); NODES = 2 halves the right-hand-side loads per matrix byte once more
+// (the 100k-pose block streams a 313 MB inverse through here).
+template <int D, int R, int NODES>
 __global__ __launch_bounds__(kBlock) void k_ml_coarse_prolong(const double* __restrict__ M, int lda,
                                                               const double* __restrict__ rc,
                                                               const double* __restrict__ x1,
                                                               const double* __restrict__ Pb, int k,
                                                               double* __restrict__ x, const DevState* __restrict__ gate,
                                                               int n, int nc) {
-  constexpr int B = D + 1, T = B * R, BB = B * B;
+  constexpr int B = D + 1, T = B * R, BB = B * B, NR = NODES * B;
   if (gate && (gate->tcg_done || gate->rtr_stop)) return;
-  __shared__ double xc_s[B][R];
-  __shared__ double part_s[kWaves][B][R];
+  __shared__ double xc_s[NR][R];
+  __shared__ double part_s[kWaves][NR][R];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int N = nc * B;
-  for (int a = blockIdx.x; a < nc; a += gridDim.x) {
-    // every wave takes a quarter of the columns and ALL B rows of this node: one read of rc per workgroup
-    // (rc is 10x the bytes of a matrix row: read per row it dominated the L2 traffic of the cycle).  A lane owns
-    // column PAIRS: 16-byte loads of the B matrix rows and of the 2R right-hand-side values, two pairs in flight per
-    // trip -- the 100k-pose block streams a 313 MB inverse through here and needs the bytes in flight to do it
+  const int ngroups = (nc + NODES - 1) / NODES;
+  for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+    const int a0 = grp * NODES;
     {
-      const double* __restrict__ m = M + (size_t)(a * B) * lda;
-      double acc[B][R];
+      // rows a0*B .. a0*B + NR - 1; rows past N (ragged last group) are padding rows of the lda x lda array: finite
+      const double* __restrict__ m = M + (size_t)(a0 * B) * lda;
+      double acc[NR][R];
 #pragma unroll
-      for (int c = 0; c < B; ++c)
+      for (int c = 0; c < NR; ++c)
 #pragma unroll
         for (int q = 0; q < R; ++q) acc[c][q] = 0.0;
       const int npair = (N + 1) >> 1;  // lda is even and >= N: the matrix may be read one column past N (zeros)
+      const dbl2* __restrict__ rc2 = reinterpret_cast<const dbl2*>(rc);
 #pragma unroll 2
       for (int j2 = wave * 64 + lane; j2 < npair; j2 += kBlock) {
-        dbl2 mv[B];
+        dbl2 mv[NR];
 #pragma unroll
-        for (int c = 0; c < B; ++c) mv[c] = *reinterpret_cast<const dbl2*>(m + (size_t)c * lda + 2 * j2);
-        double rv[2 * R];
-        const bool full = 2 * j2 + 1 < N;
+        for (int c = 0; c < NR; ++c) mv[c] = *reinterpret_cast<const dbl2*>(m + (size_t)c * lda + 2 * j2);
+        double rv[2 * R];  // rc of column 2 j2 in [0, R), of column 2 j2 + 1 in [R, 2R)
+        if (2 * j2 + 1 < N) {
 #pragma unroll
-        for (int q = 0; q < R; ++q) {
-          rv[q] = rc[(size_t)(2 * j2) * R + q];
-          rv[R + q] = full ? rc[(size_t)(2 * j2 + 1) * R + q] : 0.0;
+          for (int q = 0; q < R; ++q) {
+            const dbl2 v = rc2[(size_t)j2 * R + q];
+            rv[2 * q] = v.x;
+            rv[2 * q + 1] = v.y;
+          }
+        } else {
+#pragma unroll
+          for (int q = 0; q < R; ++q) {
+            rv[q] = rc[(size_t)(2 * j2) * R + q];
+            rv[R + q] = 0.0;
+          }
         }
 #pragma unroll
-        for (int c = 0; c < B; ++c) {
+        for (int c = 0; c < NR; ++c) {
 #pragma unroll
           for (int q = 0; q < R; ++q) {
             acc[c][q] = fma(mv[c].x, rv[q], acc[c][q]);
@@ -173,7 +186,7 @@ __global__ __launch_bounds__(kBlock) void k_ml_coarse_prolong(const double* __re
         }
       }
 #pragma unroll
-      for (int c = 0; c < B; ++c)
+      for (int c = 0; c < NR; ++c)
 #pragma unroll
         for (int q = 0; q < R; ++q) {
           const double sum = wave_reduce_lane63(acc[c][q]);
@@ -181,7 +194,7 @@ __global__ __launch_bounds__(kBlock) void k_ml_coarse_prolong(const double* __re
         }
     }
     __syncthreads();
-    if (threadIdx.x < B * R) {  // fixed-order sum over the waves
+    if (threadIdx.x < NR * R) {  // fixed-order sum over the waves
       const int c = threadIdx.x / R, q = threadIdx.x % R;
       double sum = part_s[0][c][q];
 #pragma unroll
@@ -189,16 +202,17 @@ __global__ __launch_bounds__(kBlock) void k_ml_coarse_prolong(const double* __re
       xc_s[c][q] = sum;
     }
     __syncthreads();
-    for (int tsk = threadIdx.x; tsk < k * B; tsk += kBlock) {  // (node, row c) tasks of the aggregate
-      const int i = a * k + tsk / B, c = tsk % B;
+    for (int tsk = threadIdx.x; tsk < NODES * k * B; tsk += kBlock) {  // (node, row c) tasks of the aggregates
+      const int i = a0 * k + tsk / B, c = tsk % B;
       if (i < n) {
+        const int an = (tsk / B) / k;  // which of the workgroup's coarsest nodes
         const double* __restrict__ pb = Pb + (size_t)i * BB + c * B;
         const size_t off = (size_t)i * T + c * R;
 #pragma unroll
         for (int q = 0; q < R; ++q) {
           double v = x1[off + q];
 #pragma unroll
-          for (int cc = 0; cc < B; ++cc) v = fma(pb[cc], xc_s[cc][q], v);
+          for (int cc = 0; cc < B; ++cc) v = fma(pb[cc], xc_s[an * B + cc][q], v);
           x[off + q] = v;
         }
       }

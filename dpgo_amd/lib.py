@@ -96,6 +96,7 @@ SIGNATURES = {
     "dpgo_bench_spmm_rotating": ([_P, _I, _I, _I, C.POINTER(_D), C.POINTER(_D)], _I),
     "dpgo_bench_hess_rotating": ([_P, _I, _I, _I, C.POINTER(_D)], _I),
     "dpgo_bench_hess": ([_P, _I, _I, C.POINTER(_D)], _I),
+    "dpgo_bench_iteration_kernels": ([_P, _I, _I, _P], _I),
     "dpgo_manifold_project": ([_I, _I, _I, _P, _P, _I], _I),
     "dpgo_manifold_tangent_project": ([_I, _I, _I, _P, _P, _P, _I], _I),
     "dpgo_manifold_retract": ([_I, _I, _I, _P, _P, _D, _P, _I], _I),
@@ -104,6 +105,15 @@ SIGNATURES = {
     "dpgo_round_trajectory_device": ([_I, _I, _I, _P, _P, _P, _P], _I),
     "dpgo_gather_tiles_device": ([_I, _I, _P, _P, _I, _P, _P], _I),
     "dpgo_axpby_project_device": ([_I, _I, _I, _D, _P, _D, _P, _D, _P, _I, _P, _P], _I),
+    "dpgo_problem_set_persistent": ([_P, _I], _I),
+    "dpgo_problem_persistent_info": ([_P, C.POINTER(_I), C.POINTER(_I), C.POINTER(_I), C.POINTER(_I), C.POINTER(_I)], _I),
+    "dpgo_comm_unique_id": ([_P], _I),
+    "dpgo_comm_create": ([C.POINTER(_P), _I, _I, _P, _I], _I),
+    "dpgo_comm_destroy": ([_P], _I),
+    "dpgo_comm_info": ([_P, C.POINTER(_I), C.POINTER(_I)], _I),
+    "dpgo_comm_exchange": ([_P, _I, _P, _P, _P, _I, _P, _P, _P, _P], _I),
+    "dpgo_comm_allreduce": ([_P, _P, _I, _I, _P], _I),
+    "dpgo_comm_broadcast": ([_P, _P, _I, _I, _P], _I),
     "dpgo_build_Q_bsr": ([_I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _D, _D,
                           C.POINTER(_I), _P, _P, _P], _I),
     "dpgo_build_G_coupling": ([_I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,

@@ -202,8 +202,12 @@ class DistributedGNC:
         if c.world == 1:
             return np.asarray(values, dtype=np.float64)
         import torch
-        import torch.distributed as dist
         dev = getattr(next(iter(c.agents.values())), "device", "cpu")
+        if getattr(c, "comm", None) is not None:  # library-owned RCCL communicator
+            t = torch.tensor(values, dtype=torch.float64, device=dev)
+            c.comm.allreduce(t, 1 if op == "max" else 0, torch.cuda.current_stream().cuda_stream)
+            return t.cpu().numpy()
+        import torch.distributed as dist
         t = torch.tensor(values, dtype=torch.float64, device="cpu" if c.stage else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX if op == "max" else dist.ReduceOp.SUM)
         return t.cpu().numpy()

@@ -415,6 +415,17 @@ class QuadraticProblem:
         L.check(self._lib.dpgo_problem_update_G_from_neighbors_device(self._h, L.ptr(nbr_tiles_dev)))
         self._g_obj = None
 
+    # ---- persistent single-XCD tCG kernel (small blocks, block-Jacobi / no preconditioner) ----
+    def setPersistent(self, enable: bool = True) -> None:
+        L.check(self._lib.dpgo_problem_set_persistent(self._h, int(enable)))
+
+    def persistentInfo(self) -> dict:
+        """{"enabled", "workgroups", "last_members", "last_iterations", "last_xcd"}: last_members = 0 means the last
+        optimize call ran the two-kernel scheme."""
+        v = [C.c_int(0) for _ in range(5)]
+        L.check(self._lib.dpgo_problem_persistent_info(self._h, *[C.byref(x) for x in v]))
+        return dict(zip(("enabled", "workgroups", "last_members", "last_iterations", "last_xcd"), (x.value for x in v)))
+
     # ---- multilevel preconditioner (built on the device; lazily by the first solve, like
     # PoseGraph::constructPreconditioner inside the first PreConditioner call, src/PoseGraph.cpp:582-586) ----
     def setupMultilevel(self, ks=None, omega: float = 0.7, shift: float = 1e-1) -> dict:

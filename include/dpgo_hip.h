@@ -256,6 +256,45 @@ int dpgo_bench_spmm_rotating(dpgo_problem_t h, int nsets, int reps, int warmup, 
 int dpgo_bench_hess(dpgo_problem_t h, int reps, int warmup, double* avg_ms);
 /* As dpgo_bench_hess with every operand cycling through nsets private copies (see dpgo_bench_spmm_rotating). */
 int dpgo_bench_hess_rotating(dpgo_problem_t h, int nsets, int reps, int warmup, double* avg_ms);
+/* Average launch time of the other kernels of one preconditioned tCG iteration, each timed as `reps` back-to-back
+ * launches on the solver's buffers: out_ms[0] = k_tcg_update, then (multilevel hierarchy built; else zeros)
+ * [1] = k_ml_restrict of level 0, [2] = k_ml_coarse_prolong, [3] = k_ml_post, [4] = the whole cycle tail
+ * (all restrictions, dense level, all post-smoothing launches) as launched per iteration. */
+int dpgo_bench_iteration_kernels(dpgo_problem_t h, int reps, int warmup, double out_ms[5]);
+
+/* Persistent tCG (kernels/persist.h): for small blocks with the block-Jacobi / no preconditioner the whole tCG_TR loop
+ * of an outer iteration runs as ONE launch on one XCD (in-kernel barriers instead of two kernel boundaries per
+ * iteration).  Off by default (environment DPGO_PERSIST=1 or set_persistent turn it on); if the run-time placement check
+ * times out the handle falls back to the two-kernel scheme by itself.  info: what the LAST optimize call did
+ * (last_members = 0: the two-kernel scheme ran). */
+int dpgo_problem_set_persistent(dpgo_problem_t h, int enable);
+int dpgo_problem_persistent_info(dpgo_problem_t h, int* enabled, int* workgroups, int* last_members,
+                                 int* last_iterations, int* last_xcd);
+
+/* ---- RCCL transport of the public-pose exchange (one process per GPU; dpgo_amd/csrc/comm.cpp) ----
+ * Replaces, for agents living in different processes, the in-process pointer calls of the reference's driver
+ * (examples/MultiRobotExample.cpp:183-204: getSharedPoseDict -> updateNeighborPoses) and its central reductions
+ * (:220-254).  Everything is enqueued on the caller's HIP stream: the pack kernel (dpgo_gather_tiles_device) before,
+ * the coupling SpMM (dpgo_problem_update_G_from_neighbors_device) after, no host wait in between.
+ *   unique_id : rank 0 creates the 128-byte id (ncclGetUniqueId) and hands it to the other ranks by any means
+ *   create    : collective over all ranks (ncclCommInitRank) on `device`
+ *   exchange  : ONE grouped batch of ncclSend / ncclRecv of packed pose tiles (counts in doubles); messages between
+ *               one pair of ranks are matched in list order
+ *   allreduce : in place, op = DPGO_COMM_SUM | DPGO_COMM_MAX;  broadcast: in place from `root`
+ * RCCL is bound at run time (librccl.so.1); without it these return DPGO_ERR_HIP and the rest of the library works. */
+#define DPGO_COMM_ID_BYTES 128
+#define DPGO_COMM_SUM 0
+#define DPGO_COMM_MAX 1
+typedef struct dpgo_comm_s* dpgo_comm_t;
+int dpgo_comm_unique_id(char id[DPGO_COMM_ID_BYTES]);
+int dpgo_comm_create(dpgo_comm_t* out, int nranks, int rank, const char id[DPGO_COMM_ID_BYTES], int device);
+int dpgo_comm_destroy(dpgo_comm_t c);
+int dpgo_comm_info(dpgo_comm_t c, int* nranks, int* rank);
+int dpgo_comm_exchange(dpgo_comm_t c, int nsend, const int* send_peer, const double* const* send_dev,
+                       const int* send_count, int nrecv, const int* recv_peer, double* const* recv_dev,
+                       const int* recv_count, void* stream);
+int dpgo_comm_allreduce(dpgo_comm_t c, double* buf_dev, int count, int op, void* stream);
+int dpgo_comm_broadcast(dpgo_comm_t c, double* buf_dev, int count, int root, void* stream);
 
 /* ---- manifold: LiftedSEManifold (include/DPGO/manifold/LiftedSEManifold.h:28-43) + the
  * ROPTLIB Stiefel x Euclidean product-manifold operations it configures

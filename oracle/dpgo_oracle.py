@@ -576,6 +576,8 @@ class QuadraticProblem:
                 return m["AcInv"] @ rhs
             L = m["levels"][lv]
             smooth = lambda res: (L["Dinv"] @ res.reshape(L["n"], b, r)).reshape(res.shape)  # noqa: E731
+            if getattr(self, "amg_additive", False):  # experiment: additive (BPX-like) combination
+                return getattr(self, "amg_add_w", w) * smooth(rhs) + L["P"] @ cycle(lv + 1, L["P"].T @ rhs)
             x = w * smooth(rhs)
             for _ in range((self.amg_nu if lv > 0 else 1) - 1):
                 x = x + w * smooth(rhs - L["A"] @ x)

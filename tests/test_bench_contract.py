@@ -45,5 +45,14 @@ def test_bench_prints_one_valid_json_line():
     rf = j["roofline"]
     assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12 and rf["achieved"] > 0
-    cb = j["cpu_baseline"]
-    assert cb["kind"] == "port" and cb["cores"] == 1 and cb["value"] > 0 and cb["unit"] == "it/s"
+    assert rf["warm"]["frac"] > 0 and rf["spmm_only"]["frac"] > 0  # frac = rotating (HBM-only), warm beside it
+    assert [k["kernel"].split()[0].rstrip(",") for k in rf["kernels"]] == ["k_tcg_update", "k_ml_restrict",
+                                                                           "k_ml_coarse_prolong", "k_ml_post"]
+    assert all(k["avg_launch_us"] > 0 for k in rf["kernels"])
+    cb = j["cpu_baseline"]  # reference configuration (exact factor, one core per agent) + the 1-core port beside it
+    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and cb["unit"] == "it/s"
+    assert "exact sparse factor" in cb["sample"]
+    port = cb["single_agent_port"]
+    assert port["cores"] == 1 and port["value"] > 0 and port["rel_diff_fOpt_vs_device"] < 1e-6
+    tt = j["quality"]["to_tolerance"]
+    assert set(tt) == {"grid:12x10x6/multilevel", "grid:12x10x6/jacobi"} and all("products" in v for v in tt.values())

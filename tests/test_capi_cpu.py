@@ -56,6 +56,11 @@ def test_no_cpu_fallback_without_device():
     M = np.zeros((5, 8), order="F")
     with pytest.raises(dpgo_amd.DpgoError):
         dpgo_amd.LiftedSEManifold(5, 3, 2).project(M)
+    # the RCCL transport and the dense-inverse kernels refuse too (no host-staged or CPU stand-in)
+    hc = L._P()
+    assert L.load().dpgo_comm_create(C.byref(hc), 1, 0, b"\0" * 128, 0) == L.ERR_HIP
+    A = np.eye(3)
+    assert L.load().dpgo_dense_spd_inverse(3, L.ptr(A), L.ptr(A.copy()), 0, 1) == L.ERR_HIP
 
 
 def test_invalid_arguments_are_reported_not_aborted():
