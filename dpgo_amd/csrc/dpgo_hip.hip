@@ -134,6 +134,7 @@ struct dpgo_problem_s {
   bool persist = false;
   int persist_wgs = 0;  // wanted participants (workgroups on one XCD)
   PersistCtrl* pctrl = nullptr;
+  dbl2* pgran = nullptr;  // hand-off granules of the in-kernel all-reduce: [2 buffers][kPersistMax][2]
   PersistCtrl* hctrl = nullptr;  // pinned
   double* partials = nullptr;  // 5 regions of kPartialCap*kNP
   DevState* dstate = nullptr;  // 2 slots
@@ -662,6 +663,7 @@ __global__ void k_persist_reset(PersistCtrl* c) {
   c->error = 0;
   c->iters = 0u;
   c->members = 0u;
+  for (int q = 0; q < 8; ++q) c->ticks[q] = 0ull;
 }
 
 // returns DPGO_OK with *used = false when the kernel reported a time-out (the caller falls back to the two-kernel scheme)
@@ -670,8 +672,8 @@ int run_tcg_persistent(dpgo_problem_s* p, const double* dinv, bool* used) {
   hipLaunchKernelGGL(k_persist_reset, dim3(1), dim3(1), 0, p->stream, p->pctrl);
   const int grid = 8 * p->persist_wgs;
   DISPATCH(p->d, p->r, LAUNCH_SPLIT(p, k_tcg_persist, grid, p->Q.dev(), p->x1, p->S1, p->g1, dinv, p->delta, p->Hd, p->eta,
-                                    p->rr, p->z, p->pA(), p->pB(), p->dstate + p->cur, p->dstate + (p->cur ^ 1), p->pctrl,
-                                    p->n, p->hflag, p->gen));
+                                    p->rr, p->z, p->pgran, (double)p->gen * 1048576.0, p->dstate + p->cur,
+                                    p->dstate + (p->cur ^ 1), p->pctrl, p->n, p->hflag, p->gen));
   HIPC(hipGetLastError());
   HIPC(hipMemcpyAsync(p->hctrl, p->pctrl, sizeof(PersistCtrl), hipMemcpyDeviceToHost, p->stream));
   HIPC(hipMemcpyAsync(p->hstate, p->dstate + (p->cur ^ 1), sizeof(DevState), hipMemcpyDeviceToHost, p->stream));
@@ -684,8 +686,14 @@ int run_tcg_persistent(dpgo_problem_s* p, const double* dinv, bool* used) {
     return DPGO_OK;
   }
   if (std::getenv("DPGO_PERSIST_VERBOSE"))
-    std::fprintf(stderr, "dpgo_hip: persistent tCG: %u participants on XCD %d, %u iterations\n", p->hctrl->members,
-                 p->hctrl->target, p->hctrl->iters);
+    std::fprintf(stderr,
+                 "dpgo_hip: persistent tCG: %u participants on XCD %d, %u iterations; per iteration (us): Hessian phase "
+                 "%.2f, all-reduce %.2f, update phase %.2f, all-reduce %.2f\n",
+                 p->hctrl->members, p->hctrl->target, p->hctrl->iters,
+                 0.01 * (double)p->hctrl->ticks[0] / std::max<double>(1.0, (double)p->hctrl->ticks[4]),
+                 0.01 * (double)p->hctrl->ticks[1] / std::max<double>(1.0, (double)p->hctrl->ticks[4]),
+                 0.01 * (double)p->hctrl->ticks[2] / std::max<double>(1.0, (double)p->hctrl->ticks[4]),
+                 0.01 * (double)p->hctrl->ticks[3] / std::max<double>(1.0, (double)p->hctrl->ticks[4]));
   p->cur ^= 1;
   *used = true;
   return DPGO_OK;
@@ -1015,7 +1023,7 @@ int tune_persist(dpgo_problem_s* p) {
   const int per_xcd = std::max(1, cus / 8);
   // the occupancy API can be one block per CU high when the SGPR file is the limit (MI355X_MICROARCH.md, residency);
   // this kernel is VGPR-bound (2-3 blocks per CU), where it is exact -- and a wrong count only costs the time-out
-  const int cap = std::max(1, std::min(kPartialCap, per_xcd * std::max(1, occ >= 7 ? occ - 1 : occ)));
+  const int cap = std::max(1, std::min(kPersistMax, per_xcd * std::max(1, occ >= 7 ? occ - 1 : occ)));
   const int P = (64 / (p->b * p->split)) * kWaves;
   const int tiles = std::max(1, (p->n + P - 1) / P);
   p->persist_wgs = std::min(tiles, cap);
@@ -1107,6 +1115,8 @@ int dpgo_problem_create(dpgo_problem_t* out, int r, int d, int n, int device) {
     HIPC(hipMalloc(&p->dstate, sizeof(DevState) * 2));
     HIPC(hipHostMalloc(&p->hstate, sizeof(DevState)));
     HIPC(hipMalloc(&p->pctrl, sizeof(PersistCtrl)));
+    HIPC(hipMalloc(&p->pgran, sizeof(dbl2) * 2 * kPersistMax * 2));
+    HIPC(hipMemsetAsync(p->pgran, 0, sizeof(dbl2) * 2 * kPersistMax * 2, p->stream));
     HIPC(hipHostMalloc(&p->hctrl, sizeof(PersistCtrl)));
     CHK(tune_persist(p));
     HIPC(hipHostMalloc(&p->hflag, 64, hipHostMallocCoherent | hipHostMallocMapped));
@@ -1138,6 +1148,7 @@ int dpgo_problem_destroy(dpgo_problem_t p) {
   if (p->hstate) (void)hipHostFree(p->hstate);
   if (p->hflag) (void)hipHostFree(p->hflag);
   if (p->pctrl) (void)hipFree(p->pctrl);
+  if (p->pgran) (void)hipFree(p->pgran);
   if (p->hctrl) (void)hipHostFree(p->hctrl);
   if (p->own_stream) (void)hipStreamDestroy(p->own_stream);
   delete p;
@@ -1752,7 +1763,7 @@ int dpgo_problem_set_persistent(dpgo_problem_t p, int enable) {
   if (!p) return fail(DPGO_ERR_INVALID, "null handle");
   const int P = (64 / (p->b * p->split)) * kWaves;
   const int tiles = std::max(1, (p->n + P - 1) / P);
-  if (enable && tiles > 4 * kPartialCap) return fail(DPGO_ERR_UNSUPPORTED, "block too large for the persistent tCG kernel");
+  if (enable && tiles > 16 * kPersistMax) return fail(DPGO_ERR_UNSUPPORTED, "block too large for the persistent tCG kernel");
   p->persist = enable != 0;
   return DPGO_OK;
 }
@@ -2008,6 +2019,231 @@ int dpgo_bench_iteration_kernels(dpgo_problem_t p, int reps, int warmup, double 
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);
   return rc;
+}
+
+int dpgo_device_malloc(void** out, size_t bytes, int device) {
+  if (!out) return fail(DPGO_ERR_INVALID, "null out");
+  *out = nullptr;
+  int cnt = 0;
+  CHK(dpgo_device_count(&cnt));
+  if (cnt <= 0) return fail(DPGO_ERR_HIP, "no HIP device (this library has no CPU fallback)");
+  if (device < 0 || device >= cnt) return fail(DPGO_ERR_INVALID, "device index out of range");
+  HIPC(hipSetDevice(device));
+  HIPC(hipMalloc(out, bytes > 0 ? bytes : 1));
+  return DPGO_OK;
+}
+
+int dpgo_device_free(void* p) {
+  if (p) HIPC(hipFree(p));
+  return DPGO_OK;
+}
+
+int dpgo_device_memcpy(void* dst, const void* src, size_t bytes, int kind, void* stream) {
+  if (bytes == 0) return DPGO_OK;
+  if (!dst || !src) return fail(DPGO_ERR_INVALID, "null pointer");
+  hipMemcpyKind k;
+  switch (kind) {
+    case DPGO_COPY_H2D: k = hipMemcpyHostToDevice; break;
+    case DPGO_COPY_D2H: k = hipMemcpyDeviceToHost; break;
+    case DPGO_COPY_D2D: k = hipMemcpyDeviceToDevice; break;
+    default: return fail(DPGO_ERR_INVALID, "unknown copy kind");
+  }
+  HIPC(hipMemcpyAsync(dst, src, bytes, k, (hipStream_t)stream));
+  if (kind == DPGO_COPY_D2H) HIPC(hipStreamSynchronize((hipStream_t)stream));
+  return DPGO_OK;
+}
+
+int dpgo_device_synchronize(void* stream) {
+  HIPC(hipStreamSynchronize((hipStream_t)stream));
+  return DPGO_OK;
+}
+
+// ---- initial guesses ----
+namespace {
+// Masked PCG: solve  mask A mask x = rhs  (rhs already masked) for the tiles x; A = the handle's Q.  Host-driven
+// (two tiny read-backs per iteration): initialisation runs once per problem, outside the hot path.
+struct InitBufs {
+  double *x, *r, *z, *p, *Ap, *diag, *partial;
+};
+int init_dot(dpgo_problem_s* h, const double* a, const double* b, InitBufs& w, size_t total, int g, double* out) {
+  hipLaunchKernelGGL(k_init_dot, dim3(g), dim3(kBlock), 0, h->stream, a, b, w.partial, total);
+  HIPC(hipGetLastError());
+  std::vector<double> host(g);
+  HIPC(hipMemcpyAsync(host.data(), w.partial, sizeof(double) * g, hipMemcpyDeviceToHost, h->stream));
+  HIPC(hipStreamSynchronize(h->stream));
+  double s = 0.0;
+  for (double v : host) s += v;
+  *out = s;
+  return DPGO_OK;
+}
+int init_pcg(dpgo_problem_s* h, InitBufs& w, const double* rhs, int mode, double tol, int max_iter, int* iters) {
+  const int T = h->T, R = h->r, D = h->d;
+  const size_t total = (size_t)h->n * T;
+  const int g = std::max(1, std::min(kMaxGrid, (int)((total + kBlock - 1) / kBlock)));
+  auto axpby = [&](double a, const double* x, double b, double* y) -> int {
+    hipLaunchKernelGGL(k_init_axpby, dim3(g), dim3(kBlock), 0, h->stream, a, x, b, y, total, T, R, D, mode);
+    HIPC(hipGetLastError());
+    return DPGO_OK;
+  };
+  auto apply = [&](const double* v, double* out) -> int {  // out = mask(A v), v masked
+    CHK(launch_spmm(h, h->Q, v, nullptr, out));
+    return axpby(1.0, out, 0.0, out);
+  };
+  auto precond = [&](const double* r, double* z) -> int {
+    hipLaunchKernelGGL(k_init_jacobi, dim3(g), dim3(kBlock), 0, h->stream, r, w.diag, z, total, T, R, D, mode);
+    HIPC(hipGetLastError());
+    return DPGO_OK;
+  };
+  HIPC(hipMemsetAsync(w.x, 0, sizeof(double) * total, h->stream));
+  CHK(axpby(1.0, rhs, 0.0, w.r));
+  CHK(precond(w.r, w.z));
+  CHK(axpby(1.0, w.z, 0.0, w.p));
+  double rz = 0.0, r0 = 0.0;
+  CHK(init_dot(h, w.r, w.z, w, total, g, &rz));
+  CHK(init_dot(h, w.r, w.r, w, total, g, &r0));
+  *iters = 0;
+  if (!(r0 > 0.0)) return DPGO_OK;
+  double best = r0;
+  for (int it = 0; it < max_iter; ++it) {
+    CHK(apply(w.p, w.Ap));
+    double pAp = 0.0;
+    CHK(init_dot(h, w.p, w.Ap, w, total, g, &pAp));
+    if (!(pAp > 0.0)) break;
+    const double alpha = rz / pAp;
+    CHK(axpby(alpha, w.p, 1.0, w.x));
+    CHK(axpby(-alpha, w.Ap, 1.0, w.r));
+    CHK(precond(w.r, w.z));
+    double rz_new = 0.0, rr = 0.0;
+    CHK(init_dot(h, w.r, w.z, w, total, g, &rz_new));
+    CHK(init_dot(h, w.r, w.r, w, total, g, &rr));
+    *iters = it + 1;
+    best = std::min(best, rr);
+    if (rr <= tol * tol * r0) break;
+    CHK(axpby(1.0, w.z, rz_new / rz, w.p));
+    rz = rz_new;
+  }
+  return DPGO_OK;
+}
+}  // namespace
+
+int dpgo_chordal_initialization(int d, int n, int m, const int32_t* p1, const int32_t* p2, const double* R,
+                                const double* t, const double* kappa, const double* tau, double tol, int max_iter,
+                                double* T_host, int iters_out[2], int device) {
+  if ((d != 2 && d != 3) || n <= 0 || m < 0 || !T_host || (m > 0 && (!p1 || !p2 || !R || !t || !kappa || !tau)))
+    return fail(DPGO_ERR_INVALID, "bad arguments");
+  if (!(tol > 0.0)) tol = 1e-13;
+  if (max_iter <= 0) max_iter = (int)std::min<long long>(20ll * n + 100, 200000);
+  const int b = d + 1, r = d;  // tiles [n][d+1][d]: the rank-d "lifted" problem IS the SE(d) problem
+  std::vector<int32_t> zero(std::max(m, 1), 0);
+  std::vector<double> ones(std::max(m, 1), 1.0), tau0(std::max(m, 1), 0.0);
+  dpgo_problem_t hq[2] = {nullptr, nullptr};  // [0]: rotation-only connection Laplacian (tau = 0), [1]: Q
+  struct Cleanup {
+    dpgo_problem_t* h;
+    ~Cleanup() {
+      dpgo_problem_destroy(h[0]);
+      dpgo_problem_destroy(h[1]);
+    }
+  } cleanup{hq};
+  for (int which = 0; which < 2; ++which) {
+    const double* tw = which == 0 ? tau0.data() : tau;
+    int nnzb = 0;
+    int rc = dpgo_build_Q_bsr(0, d, n, m, zero.data(), p1, zero.data(), p2, R, t, kappa, tw, ones.data(), 0, nullptr, 0.0,
+                              0.0, &nnzb, nullptr, nullptr, nullptr);
+    if (rc != DPGO_OK) return fail(rc, "chordal initialisation: measurement index out of range");
+    std::vector<int32_t> rowptr(n + 1), colidx(nnzb);
+    std::vector<double> vals((size_t)nnzb * b * b);
+    rc = dpgo_build_Q_bsr(0, d, n, m, zero.data(), p1, zero.data(), p2, R, t, kappa, tw, ones.data(), 0, nullptr, 0.0, 0.0,
+                          &nnzb, rowptr.data(), colidx.data(), vals.data());
+    if (rc != DPGO_OK) return fail(rc, "chordal initialisation: could not build the data matrix");
+    CHK(dpgo_problem_create(&hq[which], r, d, n, device));
+    CHK(dpgo_problem_set_Q_bsr(hq[which], nnzb, rowptr.data(), colidx.data(), vals.data()));
+  }
+  dpgo_problem_s* hr = hq[0];
+  dpgo_problem_s* ht = hq[1];
+  const size_t total = (size_t)n * hr->T;
+  TmpDev tmp;
+  InitBufs w{};
+  double *rhs = nullptr, *V = nullptr, *Tr = nullptr;
+  for (double** v : {&w.x, &w.r, &w.z, &w.p, &w.Ap, &rhs, &V, &Tr}) CHK(tmp.alloc(v, sizeof(double) * total));
+  CHK(tmp.alloc(&w.diag, sizeof(double) * (size_t)n * b));
+  CHK(tmp.alloc(&w.partial, sizeof(double) * kMaxGrid));
+  const int gflat = std::max(1, std::min(kMaxGrid, (n + kBlock - 1) / kBlock));
+  const int gtot = std::max(1, std::min(kMaxGrid, (int)((total + kBlock - 1) / kBlock)));
+  int it_rot = 0, it_tr = 0;
+  // ---- rotations: minimise sum kappa |R_j - R_i R_ij|^2, R_0 = I.  With E0 = tile 0 = [I | 0]:  L (E0 + x) = 0 on
+  // the free rows  =>  mask L mask x = -mask(L E0)
+  std::vector<double> e0(hr->T, 0.0);
+  for (int c = 0; c < d; ++c) e0[(size_t)c * r + c] = 1.0;
+  HIPC(hipMemsetAsync(V, 0, sizeof(double) * total, hr->stream));
+  HIPC(hipMemcpyAsync(V, e0.data(), sizeof(double) * hr->T, hipMemcpyHostToDevice, hr->stream));
+  CHK(launch_spmm(hr, hr->Q, V, nullptr, rhs));
+  hipLaunchKernelGGL(k_init_axpby, dim3(gtot), dim3(kBlock), 0, hr->stream, -1.0, rhs, 0.0, rhs, total, hr->T, r, d, 0);
+  if (d == 2)
+    hipLaunchKernelGGL(k_init_diag<2>, dim3(gflat), dim3(kBlock), 0, hr->stream, hr->Q.dev(), w.diag, n);
+  else
+    hipLaunchKernelGGL(k_init_diag<3>, dim3(gflat), dim3(kBlock), 0, hr->stream, hr->Q.dev(), w.diag, n);
+  HIPC(hipGetLastError());
+  CHK(init_pcg(hr, w, rhs, 0, tol, max_iter, &it_rot));
+  // V = E0 + x, then every block to SO(d) (projectToRotationGroup, src/DPGO_utils.cpp:464-478): the rounding kernel with
+  // the identity as anchor
+  hipLaunchKernelGGL(k_init_axpby, dim3(gtot), dim3(kBlock), 0, hr->stream, 1.0, w.x, 0.0, w.x, total, hr->T, r, d, 0);
+  HIPC(hipMemcpyAsync(V, w.x, sizeof(double) * total, hipMemcpyDeviceToDevice, hr->stream));
+  HIPC(hipMemcpyAsync(V, e0.data(), sizeof(double) * hr->T, hipMemcpyHostToDevice, hr->stream));
+  HIPC(hipStreamSynchronize(hr->stream));
+  CHK(dpgo_round_trajectory_device(r, d, n, V, e0.data(), Tr, hr->stream));
+  HIPC(hipStreamSynchronize(hr->stream));
+  // ---- translations: minimise sum tau |t_j - t_i - R_i t_ij|^2, t_0 = 0: the translation columns of Q [R | t] = 0
+  CHK(launch_spmm(ht, ht->Q, Tr, nullptr, rhs));
+  hipLaunchKernelGGL(k_init_axpby, dim3(gtot), dim3(kBlock), 0, ht->stream, -1.0, rhs, 0.0, rhs, total, ht->T, r, d, 1);
+  if (d == 2)
+    hipLaunchKernelGGL(k_init_diag<2>, dim3(gflat), dim3(kBlock), 0, ht->stream, ht->Q.dev(), w.diag, n);
+  else
+    hipLaunchKernelGGL(k_init_diag<3>, dim3(gflat), dim3(kBlock), 0, ht->stream, ht->Q.dev(), w.diag, n);
+  HIPC(hipGetLastError());
+  CHK(init_pcg(ht, w, rhs, 1, tol, max_iter, &it_tr));
+  // T = [R | t]: rotation columns from Tr, translation column from the solve (pose 0: zero)
+  hipLaunchKernelGGL(k_init_axpby, dim3(gtot), dim3(kBlock), 0, ht->stream, 1.0, w.x, 0.0, w.x, total, ht->T, r, d, 1);
+  hipLaunchKernelGGL(k_axpby_plain, dim3(gtot), dim3(kBlock), 0, ht->stream, 1.0, w.x, 1.0, Tr, total);
+  HIPC(hipGetLastError());
+  HIPC(hipMemcpyAsync(T_host, Tr, sizeof(double) * total, hipMemcpyDeviceToHost, ht->stream));
+  HIPC(hipStreamSynchronize(ht->stream));
+  if (iters_out) {
+    iters_out[0] = it_rot;
+    iters_out[1] = it_tr;
+  }
+  return DPGO_OK;
+}
+
+int dpgo_odometry_initialization(int d, int n, int m, const int32_t* p1, const int32_t* p2, const double* R,
+                                 const double* t, double* T_host) {
+  if ((d != 2 && d != 3) || n <= 0 || m < 0 || !T_host || (m > 0 && (!p1 || !p2 || !R || !t)))
+    return fail(DPGO_ERR_INVALID, "bad arguments");
+  const int b = d + 1;
+  std::vector<int> edge_of(n, -1);  // odometry edge leaving pose i (i -> i + 1)
+  for (int e = 0; e < m; ++e)
+    if (p1[e] >= 0 && p1[e] + 1 == p2[e] && p2[e] < n && edge_of[p1[e]] < 0) edge_of[p1[e]] = e;
+  std::memset(T_host, 0, sizeof(double) * (size_t)n * b * d);
+  for (int c = 0; c < d; ++c) T_host[(size_t)c * d + c] = 1.0;  // tile 0 = [I | 0]
+  for (int dst = 1; dst < n; ++dst) {
+    const int e = edge_of[dst - 1];
+    if (e < 0) return fail(DPGO_ERR_INVALID, "odometry initialisation: no odometry edge " + std::to_string(dst - 1) +
+                                                 " -> " + std::to_string(dst));  // reference: CHECK(m.p1 == src)
+    const double* Ts = T_host + (size_t)(dst - 1) * b * d;  // tile [c][row]: R(row, c) at c*d + row, t(row) at d*d + row
+    double* Td = T_host + (size_t)dst * b * d;
+    const double* Re = R + (size_t)e * d * d;  // R[e][row][col]
+    const double* te = t + (size_t)e * d;
+    for (int row = 0; row < d; ++row) {
+      for (int c = 0; c < d; ++c) {
+        double s = 0.0;
+        for (int k = 0; k < d; ++k) s += Ts[(size_t)k * d + row] * Re[k * d + c];  // (R_src R_e)(row, c)
+        Td[(size_t)c * d + row] = s;
+      }
+      double s = Ts[(size_t)d * d + row];
+      for (int k = 0; k < d; ++k) s += Ts[(size_t)k * d + row] * te[k];  // t_src + R_src t_e
+      Td[(size_t)d * d + row] = s;
+    }
+  }
+  return DPGO_OK;
 }
 
 // ---- manifold ----

@@ -30,5 +30,6 @@ namespace dpgo {
 #include "kernels/manifold.h"
 #include "kernels/rtr.h"
 #include "kernels/agent.h"
+#include "kernels/init.h"
 
 }  // namespace dpgo

@@ -1,5 +1,5 @@
 // kernels/agent.h -- agent-level kernels: public-pose packing, edge residuals + GNC-TLS weights, value rebuild of Q / coupling blocks.
-// Part of kernels.h (included inside namespace dpgo, in this order: common.h, problem.h, tcg.h, persist.h, multilevel.h, dense.h, manifold.h, rtr.h, agent.h).
+// Part of kernels.h (included inside namespace dpgo, in this order: common.h, problem.h, tcg.h, persist.h, multilevel.h, dense.h, manifold.h, rtr.h, agent.h, init.h).
 #pragma once
 
 // ================================================================ K11: pack public poses

@@ -1,6 +1,6 @@
 // kernels/common.h -- shared definitions: solver state record, thread geometry, XCD-aware tile walk, span access, reductions,
 // small dense pieces (projection, block-Jacobi), the block-SpMM gather core.
-// Part of kernels.h (included inside namespace dpgo, in this order: common.h, problem.h, tcg.h, persist.h, multilevel.h, dense.h, manifold.h, rtr.h, agent.h).
+// Part of kernels.h (included inside namespace dpgo, in this order: common.h, problem.h, tcg.h, persist.h, multilevel.h, dense.h, manifold.h, rtr.h, agent.h, init.h).
 #pragma once
 
 

@@ -1,5 +1,5 @@
 // kernels/dense.h -- in-place inverse of the dense SPD coarsest operator of the multilevel preconditioner (blocked Gauss-Jordan).
-// Part of kernels.h (included inside namespace dpgo, in this order: common.h, problem.h, tcg.h, persist.h, multilevel.h, dense.h, manifold.h, rtr.h, agent.h).
+// Part of kernels.h (included inside namespace dpgo, in this order: common.h, problem.h, tcg.h, persist.h, multilevel.h, dense.h, manifold.h, rtr.h, agent.h, init.h).
 #pragma once
 
 // The reference factors Q + 0.1 I with CHOLMOD on the host (PoseGraph::constructPreconditioner, src/PoseGraph.cpp:598-613).

@@ -1,5 +1,5 @@
 // kernels/manifold.h -- manifold operations: stand-alone preconditioner / projection, qf retraction, polar projection, rounding to SE(d).
-// Part of kernels.h (included inside namespace dpgo, in this order: common.h, problem.h, tcg.h, persist.h, multilevel.h, dense.h, manifold.h, rtr.h, agent.h).
+// Part of kernels.h (included inside namespace dpgo, in this order: common.h, problem.h, tcg.h, persist.h, multilevel.h, dense.h, manifold.h, rtr.h, agent.h, init.h).
 #pragma once
 
 // ================================================================ K6: preconditioner (stand-alone)

@@ -1,6 +1,6 @@
 // kernels/multilevel.h -- aggregation-multigrid preconditioner (the device path's default): per-iteration cycle kernels and
 // the on-device setup of the hierarchy (prolongation blocks, Galerkin operators, dense inverse of the coarsest operator).
-// Part of kernels.h (included inside namespace dpgo, in this order: common.h, problem.h, tcg.h, persist.h, multilevel.h, dense.h, manifold.h, rtr.h, agent.h).
+// Part of kernels.h (included inside namespace dpgo, in this order: common.h, problem.h, tcg.h, persist.h, multilevel.h, dense.h, manifold.h, rtr.h, agent.h, init.h).
 #pragma once
 
 // ================================================================ multilevel preconditioner

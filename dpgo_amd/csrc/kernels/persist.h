@@ -1,5 +1,5 @@
 // kernels/persist.h -- persistent single-XCD tCG kernel for small blocks (the latency regime of multi-GPU strong scaling).
-// Part of kernels.h (included inside namespace dpgo, in this order: common.h, problem.h, tcg.h, persist.h, multilevel.h, dense.h, manifold.h, rtr.h, agent.h).
+// Part of kernels.h (included inside namespace dpgo, in this order: common.h, problem.h, tcg.h, persist.h, multilevel.h, dense.h, manifold.h, rtr.h, agent.h, init.h).
 #pragma once
 
 // ================================================================ one launch per tCG run
@@ -12,8 +12,9 @@
 //   phase B: alpha / boundary test;  eta += alpha delta,  r += alpha H delta,  z = proj_X(r Dinv),
 //            partials <r,r>, <z,r>                                                                       | barrier
 // What makes the barriers cheap is that every participant sits on ONE XCD: the XCD's L2 is then the coherence point,
-// so a barrier is an atomic arrival + a poll (no cache write-back / invalidate, which is what the 4-7 us of a
-// chip-wide barrier are made of -- MI355X_MICROARCH.md, price list), provided that
+// so a barrier is one 16-byte store and a poll of the other participants' stores -- no atomics, no cache write-back /
+// invalidate (which is what the 4-7 us of a chip-wide barrier are made of, MI355X_MICROARCH.md price list) -- and it
+// carries the partial sums of the step's dot products with it (xcd_allreduce), provided that
 //   * a producer's stores have reached the L2 before it arrives        (s_waitcnt vmcnt(0) + workgroup barrier),
 //   * consumers read other workgroups' data with L1-bypassing loads    (nontemporal / agent-scope atomic loads).
 // Placement is undefined by HIP, so it is ESTABLISHED at run time, not assumed: the launch has 8x the wanted workgroups,
@@ -23,11 +24,14 @@
 struct PersistCtrl {          // zeroed (target = -1) by the host before every launch
   unsigned long long counts;  // [31:0] workgroups that have started, [63:32] of them on the target XCD (one atomic)
   int target;                 // XCC id of the participants
-  unsigned bar;               // barrier arrivals (monotonic)
+  unsigned bar;               // unused (kept for layout)
   int error;                  // a spin ran out: results invalid
   unsigned iters;             // diagnostic: tCG iterations executed
   unsigned members;           // diagnostic: participants
   unsigned pad;
+  // diagnostic timeline of participant 0 (100 MHz wall clock ticks, summed over the iterations after the first):
+  // [0] phase A (Hessian step)  [1] all-reduce after A  [2] phase B (update)  [3] all-reduce after B  [4] iterations
+  unsigned long long ticks[8];
 };
 
 constexpr unsigned kSpinLimit = 1u << 21;  // polls (with s_sleep) before a spin gives up: ~0.5 s
@@ -47,20 +51,6 @@ __device__ __forceinline__ bool spin_until_ge(unsigned* p, unsigned want, int* e
   return false;
 }
 
-// Barrier of the `members` participants (all on one XCD).  Returns false when a spin timed out anywhere.
-__device__ __forceinline__ bool xcd_barrier(PersistCtrl* c, unsigned members, unsigned& epoch, int* ok_s) {
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this thread's stores have been acknowledged by the L2
-  __syncthreads();
-  epoch += 1;
-  if (threadIdx.x == 0) {
-    __hip_atomic_fetch_add(&c->bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    *ok_s = spin_until_ge(&c->bar, members * epoch, &c->error) ? 1 : 0;
-  }
-  __syncthreads();
-  return *ok_s != 0;
-}
-
-// Sum of the participants' partials (K per entry); L1-bypassing loads, same order in every workgroup.
 // Every vector the launch itself writes (eta, r, z, delta, H delta) is read with L1-bypassing loads: the two phases
 // map poses to workgroups differently, so "own rows" of one phase may have been written by another workgroup.
 template <int R>
@@ -69,22 +59,65 @@ __device__ __forceinline__ void load_col_nt(const double* p, double (&v)[R]) {
   for (int a = 0; a < R; ++a) v[a] = __builtin_nontemporal_load(p + a);
 }
 
+// Barrier + all-reduce of the participants in one step, without atomics: every workgroup publishes its K partial sums
+// as K granules {tag, value} -- one naturally aligned 16-byte store each, so tag and value arrive together
+// (MI355X_MICROARCH.md, hand-off granules) -- and thread t of every workgroup polls participant t's granules with
+// 16-byte L1-bypassing loads until the tag of THIS step shows up.  The sums are then formed in the same fixed order by
+// everybody.  tag = tagbase + epoch is unique per launch and step (no clearing between launches); two buffers
+// alternate, which suffices because nobody can be more than one step ahead of the slowest participant.
+constexpr int kPersistMax = kBlock;  // participants <= threads of a workgroup (one poller per participant)
 template <int K>
-__device__ __forceinline__ void persist_partials(const double* p, int members, double (&out)[K], double* red) {
+__device__ __forceinline__ bool xcd_allreduce(dbl2* gran, int rank, int members, double tagbase, unsigned& epoch,
+                                              double (&val)[K], double* red, int* error, int* ok_s) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this thread's vector stores have been acknowledged by the L2
+  if (threadIdx.x == 0) *ok_s = 1;
+  __syncthreads();
+  epoch += 1;
+  const double tag = tagbase + (double)epoch;
+  dbl2* buf = gran + (size_t)(epoch & 1u) * kPersistMax * 2;
 #pragma unroll
-  for (int k = 0; k < K; ++k) out[k] = 0.0;
-  for (int i = threadIdx.x; i < members; i += kBlock) {
-#pragma unroll
-    for (int k = 0; k < K; ++k) out[k] += __builtin_nontemporal_load(p + i * kNP + k);
+  for (int k = 0; k < K; ++k) {
+    if ((int)threadIdx.x == k) {  // block_allreduce left the workgroup's sums in every thread
+      dbl2 gv;
+      gv.x = tag;
+      gv.y = val[k];
+      buf[rank * 2 + k] = gv;
+    }
   }
-  block_allreduce<K>(out, red);
+  double v[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) v[k] = 0.0;
+  if ((int)threadIdx.x < members) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      bool got = false;
+      for (unsigned it = 0; it < kSpinLimit; ++it) {
+        const dbl2 gv = __builtin_nontemporal_load(buf + threadIdx.x * 2 + k);
+        if (gv.x == tag) {
+          v[k] = gv.y;
+          got = true;
+          break;
+        }
+        if ((it & 255u) == 255u && __hip_atomic_load(error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+        __builtin_amdgcn_s_sleep(1);
+      }
+      if (!got) {
+        __hip_atomic_store(error, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        *ok_s = 0;
+      }
+    }
+  }
+  block_allreduce<K>(v, red);  // two workgroup barriers inside: ok_s is settled afterwards
+#pragma unroll
+  for (int k = 0; k < K; ++k) val[k] = v[k];
+  return *ok_s != 0;
 }
 
 template <int D, int R, int SPLIT>
 __global__ __launch_bounds__(kBlock) void k_tcg_persist(BsrDev Q, const double* __restrict__ X,
                                                         const double* __restrict__ S, const double* __restrict__ g,
                                                         const double* __restrict__ dinv, double* delta, double* Hd,
-                                                        double* eta, double* r, double* z, double* pA, double* pB,
+                                                        double* eta, double* r, double* z, dbl2* gran, double tagbase,
                                                         const DevState* __restrict__ sin, DevState* __restrict__ sout,
                                                         PersistCtrl* ctrl, int n, unsigned long long* hflag,
                                                         unsigned gen) {
@@ -147,8 +180,8 @@ __global__ __launch_bounds__(kBlock) void k_tcg_persist(BsrDev Q, const double* 
   const int ntiles_u = (n + GEU::P - 1) / GEU::P;
 
   // ---- phase B: (first) r = g, eta = 0 | eta += alpha delta, r += alpha H delta;  z = proj_X(r Dinv);  partials
-  auto phase_update = [&](bool first, double alpha) {
-    double part[2] = {0.0, 0.0};
+  auto phase_update = [&](bool first, double alpha, double (&part)[2]) {
+    part[0] = part[1] = 0.0;
     for (int tile = rank; tile < ntiles_u; tile += members) {
       const int i = tile * GEU::P + U.wave * GEU::G + U.g;
       const bool ok = (U.g < GEU::G) && (i < n);
@@ -209,15 +242,11 @@ __global__ __launch_bounds__(kBlock) void k_tcg_persist(BsrDev Q, const double* 
       wave_sync();
     }
     block_allreduce<2>(part, red);
-    if (threadIdx.x == 0) {
-      pB[rank * kNP + 0] = part[0];
-      pB[rank * kNP + 1] = part[1];
-    }
   };
 
   // ---- phase A: Hz on the own rows (gather of z bypasses L1), direction recurrences, partial <delta, H delta>
-  auto phase_hess = [&](bool first, double beta) {
-    double part[1] = {0.0};
+  auto phase_hess = [&](bool first, double beta, double (&part)[1]) {
+    part[0] = 0.0;
     for (int tile = rank; tile < ntiles_s; tile += members) {
       const int i = tile * GEO::P + L.wave * GEO::G + L.g;
       const bool okp = (L.g < GEO::G) && (i < n);
@@ -281,7 +310,6 @@ __global__ __launch_bounds__(kBlock) void k_tcg_persist(BsrDev Q, const double* 
       wave_sync();
     }
     block_allreduce<1>(part, red);
-    if (threadIdx.x == 0) pA[rank * kNP + 0] = part[0];
   };
 
   // ---- tCG_TR (ROPTLIB): the scalar logic of tcg_update_prologue / tcg_hess_prologue, evaluated redundantly (and
@@ -292,11 +320,10 @@ __global__ __launch_bounds__(kBlock) void k_tcg_persist(BsrDev Q, const double* 
   st.e_Pe = 0.0;
   st.e_Pd = 0.0;
   bool alive = true;
-  phase_update(true, 0.0);
-  alive = xcd_barrier(ctrl, (unsigned)members, epoch, &ok_s);
   double pr[2];
+  phase_update(true, 0.0, pr);
+  alive = xcd_allreduce<2>(gran, rank, members, tagbase, epoch, pr, red, &ctrl->error, &ok_s);
   if (alive) {
-    persist_partials<2>(pB, members, pr, red);
     st.norm_r0 = sqrt(pr[0]);
     st.z_r = pr[1];
     st.d_Pd = pr[1];
@@ -306,11 +333,14 @@ __global__ __launch_bounds__(kBlock) void k_tcg_persist(BsrDev Q, const double* 
   double beta = 0.0;
   bool first = true;
   unsigned iters = 0;
+  unsigned long long tk[5] = {0, 0, 0, 0, 0};
   while (alive && !st.tcg_done) {
-    phase_hess(first, beta);
-    if (!(alive = xcd_barrier(ctrl, (unsigned)members, epoch, &ok_s))) break;
+    const unsigned long long t0 = wall_clock64();
     double dh[1];
-    persist_partials<1>(pA, members, dh, red);
+    phase_hess(first, beta, dh);
+    const unsigned long long t1 = wall_clock64();
+    if (!(alive = xcd_allreduce<1>(gran, rank, members, tagbase, epoch, dh, red, &ctrl->error, &ok_s))) break;
+    const unsigned long long t2 = wall_clock64();
     const double d_Hd = dh[0];
     const double alpha = st.z_r / d_Hd;
     const double e_Pe_new = st.e_Pe + 2.0 * alpha * st.e_Pd + alpha * alpha * st.d_Pd;
@@ -337,9 +367,17 @@ __global__ __launch_bounds__(kBlock) void k_tcg_persist(BsrDev Q, const double* 
       break;
     }
     st.e_Pe = e_Pe_new;
-    phase_update(false, alpha);
-    if (!(alive = xcd_barrier(ctrl, (unsigned)members, epoch, &ok_s))) break;
-    persist_partials<2>(pB, members, pr, red);
+    phase_update(false, alpha, pr);
+    const unsigned long long t3 = wall_clock64();
+    if (!(alive = xcd_allreduce<2>(gran, rank, members, tagbase, epoch, pr, red, &ctrl->error, &ok_s))) break;
+    const unsigned long long t4 = wall_clock64();
+    if (!first) {
+      tk[0] += t1 - t0;
+      tk[1] += t2 - t1;
+      tk[2] += t3 - t2;
+      tk[3] += t4 - t3;
+      tk[4] += 1;
+    }
     const double norm_r = sqrt(pr[0]), z_r_new = pr[1];
     const double pw = (st.theta == 1.0) ? st.norm_r0 : pow(st.norm_r0, st.theta);
     if (st.tcg_j >= st.min_inner && norm_r <= st.norm_r0 * (pw < st.kappa ? pw : st.kappa)) {
@@ -364,5 +402,7 @@ __global__ __launch_bounds__(kBlock) void k_tcg_persist(BsrDev Q, const double* 
       publish_progress(hflag, gen, st);
     }
     ctrl->iters = iters;
+#pragma unroll
+    for (int q = 0; q < 5; ++q) ctrl->ticks[q] = tk[q];
   }
 }

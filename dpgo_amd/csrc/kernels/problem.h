@@ -1,5 +1,5 @@
 // kernels/problem.h -- QuadraticProblem evaluations: plain SpMM, cost + Riemannian gradient, Riemannian Hessian-vector product.
-// Part of kernels.h (included inside namespace dpgo, in this order: common.h, problem.h, tcg.h, persist.h, multilevel.h, dense.h, manifold.h, rtr.h, agent.h).
+// Part of kernels.h (included inside namespace dpgo, in this order: common.h, problem.h, tcg.h, persist.h, multilevel.h, dense.h, manifold.h, rtr.h, agent.h, init.h).
 #pragma once
 
 // ================================================================ K1: plain SpMM

@@ -1,5 +1,5 @@
 // kernels/rtr.h -- trust-region acceptance test and state transitions (tail of ROPTLIB SolversTR::Run).
-// Part of kernels.h (included inside namespace dpgo, in this order: common.h, problem.h, tcg.h, persist.h, multilevel.h, dense.h, manifold.h, rtr.h, agent.h).
+// Part of kernels.h (included inside namespace dpgo, in this order: common.h, problem.h, tcg.h, persist.h, multilevel.h, dense.h, manifold.h, rtr.h, agent.h, init.h).
 #pragma once
 
 // ================================================================ K7c: RTR acceptance test

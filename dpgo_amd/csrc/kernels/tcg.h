@@ -1,5 +1,5 @@
 // kernels/tcg.h -- the two kernels of the tCG loop (fused Hessian step and residual / iterate update), generic and span variants.
-// Part of kernels.h (included inside namespace dpgo, in this order: common.h, problem.h, tcg.h, persist.h, multilevel.h, dense.h, manifold.h, rtr.h, agent.h).
+// Part of kernels.h (included inside namespace dpgo, in this order: common.h, problem.h, tcg.h, persist.h, multilevel.h, dense.h, manifold.h, rtr.h, agent.h, init.h).
 #pragma once
 
 // ================================================================ K7b + K1/K3/K2 fused: one tCG step

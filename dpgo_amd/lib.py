@@ -107,6 +107,12 @@ SIGNATURES = {
     "dpgo_axpby_project_device": ([_I, _I, _I, _D, _P, _D, _P, _D, _P, _I, _P, _P], _I),
     "dpgo_problem_set_persistent": ([_P, _I], _I),
     "dpgo_problem_persistent_info": ([_P, C.POINTER(_I), C.POINTER(_I), C.POINTER(_I), C.POINTER(_I), C.POINTER(_I)], _I),
+    "dpgo_chordal_initialization": ([_I, _I, _I, _P, _P, _P, _P, _P, _P, _D, _I, _P, _P, _I], _I),
+    "dpgo_odometry_initialization": ([_I, _I, _I, _P, _P, _P, _P, _P], _I),
+    "dpgo_device_malloc": ([C.POINTER(_P), C.c_size_t, _I], _I),
+    "dpgo_device_free": ([_P], _I),
+    "dpgo_device_memcpy": ([_P, _P, C.c_size_t, _I, _P], _I),
+    "dpgo_device_synchronize": ([_P], _I),
     "dpgo_comm_unique_id": ([_P], _I),
     "dpgo_comm_create": ([C.POINTER(_P), _I, _I, _P, _I], _I),
     "dpgo_comm_destroy": ([_P], _I),

@@ -27,6 +27,7 @@
 #ifndef DPGO_HIP_H
 #define DPGO_HIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -270,6 +271,34 @@ int dpgo_bench_iteration_kernels(dpgo_problem_t h, int reps, int warmup, double 
 int dpgo_problem_set_persistent(dpgo_problem_t h, int enable);
 int dpgo_problem_persistent_info(dpgo_problem_t h, int* enabled, int* workgroups, int* last_members,
                                  int* last_iterations, int* last_xcd);
+
+/* ---- initial guesses (src/DPGO_solver.cpp:220-303) ----
+ * chordal: the two linear least-squares problems of chordalInitialization (rotations with pose 0 pinned to the
+ *   identity, projected to SO(d); then translations) -- the reference solves them with SPQR (constructBMatrices /
+ *   recoverTranslations, src/DPGO_utils.cpp:346-462); here their normal equations are solved ON THE DEVICE by
+ *   Jacobi-preconditioned conjugate gradients over the block-SpMM of the hot path, the SO(d) projection by the
+ *   rounding kernel.  Single-robot measurements (all poses of one robot, frames 0 .. n-1); weights are not used
+ *   (as in the reference).  tol: relative residual of the CG solves (<= 0: 1e-13); max_iter <= 0: 20 n.
+ *   iters_out (optional): CG iterations of the rotation and of the translation solve.
+ * odometry: poses composed along the odometry chain p -> p+1 (odometryInitialization, :271-303); host only.
+ * T_host: tiles [n][d+1][d] (= the reference's d x (d+1)n column-major Matrix [R_0 t_0 ... ]). */
+int dpgo_chordal_initialization(int d, int n, int m, const int32_t* p1, const int32_t* p2, const double* R,
+                                const double* t, const double* kappa, const double* tau, double tol, int max_iter,
+                                double* T_host, int iters_out[2], int device);
+int dpgo_odometry_initialization(int d, int n, int m, const int32_t* p1, const int32_t* p2, const double* R,
+                                 const double* t, double* T_host);
+
+/* ---- device memory for callers above the C ABI that keep their iterates in HBM (the C++ / Python agent mirrors keep
+ * X, Y, V, XPrev and the neighbour tile buffers there; src/PGOAgent.cpp:376-432,880-936 keeps them in Eigen matrices).
+ * kind: DPGO_COPY_H2D | DPGO_COPY_D2H | DPGO_COPY_D2D; the copy is enqueued on `stream` (NULL = default stream) and,
+ * for D2H, completed before the call returns. */
+#define DPGO_COPY_H2D 0
+#define DPGO_COPY_D2H 1
+#define DPGO_COPY_D2D 2
+int dpgo_device_malloc(void** out, size_t bytes, int device);
+int dpgo_device_free(void* p);
+int dpgo_device_memcpy(void* dst, const void* src, size_t bytes, int kind, void* stream);
+int dpgo_device_synchronize(void* stream);
 
 /* ---- RCCL transport of the public-pose exchange (one process per GPU; dpgo_amd/csrc/comm.cpp) ----
  * Replaces, for agents living in different processes, the in-process pointer calls of the reference's driver

@@ -22,6 +22,7 @@
 #include <cstdint>
 #include <map>
 #include <memory>
+#include <cstring>
 #include <stdexcept>
 #include <string>
 #include <utility>
@@ -212,6 +213,62 @@ class PoseGraph {
     }
     return Q_;
   }
+  // Sorted ids of the neighbour poses this agent's shared loop closures touch (nbr_shared_pose_ids_) = column order of
+  // the device's neighbour tile buffer; and the ids of this agent's own public poses (local_shared_pose_ids_).
+  std::vector<PoseID> neighborPoseIDs() const {
+    std::vector<PoseID> ids;
+    for (const auto& m : meas_)
+      if (m.r1 != m.r2) ids.push_back(m.r1 == id_ ? PoseID((unsigned)m.r2, (unsigned)m.p2) : PoseID((unsigned)m.r1, (unsigned)m.p1));
+    std::sort(ids.begin(), ids.end());
+    ids.erase(std::unique(ids.begin(), ids.end()), ids.end());
+    return ids;
+  }
+  std::vector<unsigned> localSharedPoseIDs() const {
+    std::vector<unsigned> ids;
+    for (const auto& m : meas_)
+      if (m.r1 != m.r2) ids.push_back((unsigned)(m.r1 == id_ ? m.p1 : m.p2));
+    std::sort(ids.begin(), ids.end());
+    ids.erase(std::unique(ids.begin(), ids.end()), ids.end());
+    return ids;
+  }
+  // Operator form of constructG (:493-580): G = G0 + Xnbr * C over the neighbour tile buffer (slot order above);
+  // G0 carries the priors (:565-574).  Built by dpgo_build_G_coupling.
+  struct Coupling {
+    std::vector<PoseID> slots;
+    Bsr C;
+    Matrix G0;
+  };
+  Coupling couplingMatrix() {
+    Coupling out;
+    out.slots = neighborPoseIDs();
+    std::map<PoseID, int32_t> index;
+    for (size_t k = 0; k < out.slots.size(); ++k) index[out.slots[k]] = (int32_t)k;
+    Soa s = soa();
+    std::vector<int32_t> slot_of_edge(meas_.size(), -1);
+    for (size_t e = 0; e < meas_.size(); ++e) {
+      const auto& m = meas_[e];
+      if (m.r1 != m.r2)
+        slot_of_edge[e] = index[m.r1 == id_ ? PoseID((unsigned)m.r2, (unsigned)m.p2) : PoseID((unsigned)m.r1, (unsigned)m.p1)];
+    }
+    int nnzb = 0;
+    check(dpgo_build_G_coupling((int)id_, (int)d_, (int)n_, (int)meas_.size(), s.r1.data(), s.p1.data(), s.r2.data(),
+                                s.p2.data(), s.R.data(), s.t.data(), s.kappa.data(), s.tau.data(), s.w.data(),
+                                slot_of_edge.data(), &nnzb, nullptr, nullptr, nullptr));
+    const unsigned b = d_ + 1;
+    out.C.rowptr.assign(n_ + 1, 0);
+    out.C.colidx.assign(std::max(nnzb, 1), 0);
+    out.C.vals.assign((size_t)std::max(nnzb, 1) * b * b, 0.0);
+    check(dpgo_build_G_coupling((int)id_, (int)d_, (int)n_, (int)meas_.size(), s.r1.data(), s.p1.data(), s.r2.data(),
+                                s.p2.data(), s.R.data(), s.t.data(), s.kappa.data(), s.tau.data(), s.w.data(),
+                                slot_of_edge.data(), &nnzb, out.C.rowptr.data(), out.C.colidx.data(), out.C.vals.data()));
+    out.C.colidx.resize(nnzb);
+    out.C.vals.resize((size_t)nnzb * b * b);
+    out.G0 = Matrix(r_, (size_t)b * n_);
+    for (const auto& kv : priors_)
+      for (unsigned c = 0; c < b; ++c)
+        for (unsigned a = 0; a < r_; ++a) out.G0(a, (size_t)kv.first * b + c) -= kv.second(a, c) * (c < d_ ? 10000.0 : 100.0);
+    return out;
+  }
   // PoseGraph::linearMatrix (:359-364), constructG (:493-580); throws if an active neighbour pose is missing
   const Matrix& linearMatrix() {
     if (!has_G_) {
@@ -286,7 +343,10 @@ class PoseGraph {
 // (which rebuilds the problem every iteration, src/PGOAgent.cpp:968) keep it alive next to the PoseGraph.
 class QuadraticProblem {
  public:
-  explicit QuadraticProblem(const std::shared_ptr<PoseGraph>& pose_graph, int device = 0) : pose_graph_(pose_graph) {
+  // host_linear_term = false: G is not taken from PoseGraph::linearMatrix() on the host but built on the device from
+  // the neighbour tile buffer (setCouplingFromPoseGraph + updateLinearMatrixFromNeighbors) -- the agent path.
+  explicit QuadraticProblem(const std::shared_ptr<PoseGraph>& pose_graph, int device = 0, bool host_linear_term = true)
+      : pose_graph_(pose_graph), host_G_(host_linear_term) {
     check(dpgo_problem_create(&h_, (int)pose_graph_->r(), (int)pose_graph_->d(), (int)pose_graph_->n(), device));
     refresh();
   }
@@ -305,10 +365,24 @@ class QuadraticProblem {
       check(dpgo_problem_set_Q_bsr(h_, (int)Q.colidx.size(), Q.rowptr.data(), Q.colidx.data(), Q.vals.data()));
       q_version_ = pose_graph_->qVersion();
     }
+    if (!host_G_) return;
     if (pose_graph_->hasLinearTerm())
       check(dpgo_problem_set_G(h_, pose_graph_->linearMatrix().data()));
     else
       check(dpgo_problem_set_G(h_, nullptr));
+  }
+  // Upload the G operator once (pattern + values); returns the neighbour slot order.
+  std::vector<PoseGraph::PoseID> setCouplingFromPoseGraph() {
+    auto cp = pose_graph_->couplingMatrix();
+    const int nnzb = (int)cp.C.colidx.size();
+    check(dpgo_problem_set_G_coupling(h_, (int)cp.slots.size(), nnzb, cp.C.rowptr.data(),
+                                      nnzb ? cp.C.colidx.data() : nullptr, nnzb ? cp.C.vals.data() : nullptr,
+                                      cp.G0.data()));
+    return cp.slots;
+  }
+  // constructG on the device from the neighbour tile buffer (device pointer, slot order of setCouplingFromPoseGraph)
+  void updateLinearMatrixFromNeighbors(const double* nbr_tiles_dev) {
+    check(dpgo_problem_update_G_from_neighbors_device(h_, nbr_tiles_dev));
   }
   // Explicit setup of the multilevel preconditioner for the CURRENT Q (the analogue of
   // PoseGraph::constructPreconditioner, src/PoseGraph.cpp:598-613).  Optional: a solve with
@@ -352,6 +426,7 @@ class QuadraticProblem {
       throw Error(DPGO_ERR_INVALID, "matrix shape mismatch");
   }
   std::shared_ptr<PoseGraph> pose_graph_;
+  bool host_G_ = true;
   dpgo_problem_t h_ = nullptr;
   unsigned long q_version_ = (unsigned long)-1;
 };
@@ -372,6 +447,17 @@ class QuadraticOptimizer {
     result_.tcgIterations = res.tcg_iterations;
     result_.rtrIterations = res.rtr_iterations;
     return out;
+  }
+  // Device-resident flavour: X_dev (r x (d+1)n doubles in HBM) is updated in place.
+  ROPTResult optimizeDevice(double* X_dev) {
+    dpgo_ropt_params c = params_.to_c();
+    dpgo_ropt_result res;
+    check(dpgo_optimize_device(problem_->handle(), &c, X_dev, &res));
+    result_ = ROPTResult(res.success != 0, res.fInit, res.gradNormInit, res.fOpt, res.gradNormOpt, res.elapsedMs);
+    result_.tCGStatus = res.tCGStatus;
+    result_.tcgIterations = res.tcg_iterations;
+    result_.rtrIterations = res.rtr_iterations;
+    return result_;
   }
   void setProblem(QuadraticProblem* p) { problem_ = p; }
   void setVerbose(bool v) { params_.verbose = v; }
@@ -413,6 +499,291 @@ class LiftedSEManifold {
  private:
   unsigned r_, d_, n_;
   int device_;
+};
+
+// Writable view of a block of columns of a column-major matrix (the role Eigen::Ref<Matrix> plays in the reference).
+class MatrixRef {
+ public:
+  MatrixRef(double* p, size_t rows, size_t cols) : p_(p), r_(rows), c_(cols) {}
+  size_t rows() const { return r_; }
+  size_t cols() const { return c_; }
+  double* data() { return p_; }
+  double& operator()(size_t i, size_t j) { return p_[j * r_ + i]; }
+  double operator()(size_t i, size_t j) const { return p_[j * r_ + i]; }
+  MatrixRef& operator=(const Matrix& m) {
+    if (m.rows() != r_ || m.cols() != c_) throw Error(DPGO_ERR_INVALID, "matrix shape mismatch");
+    std::memcpy(p_, m.data(), sizeof(double) * r_ * c_);
+    return *this;
+  }
+  operator Matrix() const {
+    Matrix m(r_, c_);
+    std::memcpy(m.data(), p_, sizeof(double) * r_ * c_);
+    return m;
+  }
+
+ private:
+  double* p_;
+  size_t r_, c_;
+};
+
+// DPGO::LiftedSEVariable (include/DPGO/manifold/LiftedSEVariable.h:33-119, src/manifold/LiftedSEVariable.cpp:15-67):
+// n lifted poses X = [Y1 p1 ... Yn pn], r x (d+1)n.  The reference stores them in a ROPTLIB ProductElement whose flat
+// memory IS this column-major matrix (tests/testEigenMap.cpp:12-36); here the matrix is the storage, and it is also
+// exactly what the device kernels read (n consecutive pose tiles) -- no conversion on either side.
+class LiftedSEVariable {
+ public:
+  LiftedSEVariable(unsigned r, unsigned d, unsigned n) : r_(r), d_(d), n_(n), X_(r, (size_t)(d + 1) * n) {
+    if (r < d) throw Error(DPGO_ERR_INVALID, "CHECK(r >= d) failed");
+    for (unsigned i = 0; i < n; ++i)  // Y_i = [I_d; 0], p_i = 0 (src/manifold/LiftedSEVariable.cpp:22-27)
+      for (unsigned k = 0; k < d; ++k) X_(k, (size_t)i * (d + 1) + k) = 1.0;
+  }
+  unsigned r() const { return r_; }
+  unsigned d() const { return d_; }
+  unsigned n() const { return n_; }
+  Matrix getData() const { return X_; }
+  void setData(const Matrix& X) {  // CHECKs of :59-61
+    if (X.rows() != r_ || X.cols() != (size_t)(d_ + 1) * n_) throw Error(DPGO_ERR_INVALID, "matrix shape mismatch");
+    X_ = X;
+  }
+  double* data() { return X_.data(); }  // what var()->ObtainWriteEntireData() returns in the reference
+  const double* data() const { return X_.data(); }
+  MatrixRef pose(unsigned index) { return MatrixRef(col(index, 0), r_, d_ + 1); }
+  Matrix pose(unsigned index) const { return X_.block(0, (size_t)chk(index) * (d_ + 1), r_, d_ + 1); }
+  MatrixRef rotation(unsigned index) { return MatrixRef(col(index, 0), r_, d_); }
+  Matrix rotation(unsigned index) const { return X_.block(0, (size_t)chk(index) * (d_ + 1), r_, d_); }
+  MatrixRef translation(unsigned index) { return MatrixRef(col(index, d_), r_, 1); }
+  Matrix translation(unsigned index) const { return X_.block(0, (size_t)chk(index) * (d_ + 1) + d_, r_, 1); }
+
+ private:
+  unsigned chk(unsigned index) const {
+    if (index >= n_) throw Error(DPGO_ERR_INVALID, "CHECK(index < n_) failed");
+    return index;
+  }
+  double* col(unsigned index, unsigned c) { return X_.data() + ((size_t)chk(index) * (d_ + 1) + c) * r_; }
+  unsigned r_, d_, n_;
+  Matrix X_;
+};
+
+// DPGO::LiftedSEVector (include/DPGO/manifold/LiftedSEVector.h:28-47, src/manifold/LiftedSEVector.cpp:16-54): a tangent
+// vector of the product manifold in the ambient (extrinsic) representation, same r x (d+1)n layout, zero-initialised.
+class LiftedSEVector {
+ public:
+  LiftedSEVector(int r, int d, int n) : r_(r), d_(d), n_(n), V_((size_t)r, (size_t)(d + 1) * n) {}
+  Matrix getData() const { return V_; }
+  void setData(const Matrix& Y) {
+    if (Y.rows() != (size_t)r_ || Y.cols() != (size_t)(d_ + 1) * n_) throw Error(DPGO_ERR_INVALID, "matrix shape mismatch");
+    V_ = Y;
+  }
+  double* data() { return V_.data(); }  // vec()->ObtainWriteEntireData()
+  const double* data() const { return V_.data(); }
+
+ private:
+  int r_, d_, n_;
+  Matrix V_;
+};
+
+// ---------------------------------------------------------------------------------------------------------
+// The part of DPGO::PGOAgent that drives the hot path (include/DPGO/PGOAgent.h:250-548, src/PGOAgent.cpp:376-432,
+// 880-995): iterate(bool) with Nesterov acceleration and restarts, the public-pose dictionaries, setX / getX.
+// X, XPrev, Y, V and the neighbour tile buffers live in HBM; updateY / updateV are one fused kernel each (linear
+// combination + LiftedSEManifold::project), updateX is constructG on the device + QuadraticOptimizer::optimize on the
+// device iterate.  Public poses cross the ABI as the reference's PoseDict (host maps): a few hundred small tiles.
+// Not mirrored: the state machine / initialisation in a global frame / threads / logging / robust weights.
+struct PGOAgentParameters {  // the fields of DPGO::PGOAgentParameters (PGOAgent.h:49-160) this path reads
+  unsigned d = 3, r = 5, numRobots = 1;
+  bool acceleration = false;
+  unsigned restartInterval = 30;
+  ROptParameters localOptimizationParams;
+  PGOAgentParameters(unsigned dIn, unsigned rIn, unsigned numRobotsIn = 1, ROptParameters local = ROptParameters(),
+                     bool accel = false, unsigned restart = 30)
+      : d(dIn), r(rIn), numRobots(numRobotsIn), acceleration(accel), restartInterval(restart),
+        localOptimizationParams(local) {}
+};
+
+using PoseID = PoseGraph::PoseID;
+using PoseDict = std::map<PoseID, Matrix>;  // DPGO::PoseDict (manifold/Poses.h:218): PoseID -> r x (d+1) lifted pose
+
+class PGOAgent {
+ public:
+  PGOAgent(unsigned ID, const PGOAgentParameters& params, int device = 0)
+      : id_(ID), prm_(params), device_(device), pg_(std::make_shared<PoseGraph>(ID, params.r, params.d)) {}
+  ~PGOAgent() { release(); }
+  PGOAgent(const PGOAgent&) = delete;
+  PGOAgent& operator=(const PGOAgent&) = delete;
+
+  unsigned getID() const { return id_; }
+  unsigned num_poses() const { return pg_->n(); }
+  unsigned dimension() const { return prm_.d; }
+  unsigned relaxation_rank() const { return prm_.r; }
+  unsigned iteration_number() const { return iteration_; }
+
+  // PGOAgent::setMeasurements (:263): odometry, private and shared loop closures of this robot
+  void setMeasurements(const std::vector<RelativeSEMeasurement>& inputOdometry,
+                       const std::vector<RelativeSEMeasurement>& inputPrivateLoopClosures,
+                       const std::vector<RelativeSEMeasurement>& inputSharedLoopClosures) {
+    std::vector<RelativeSEMeasurement> all(inputOdometry);
+    all.insert(all.end(), inputPrivateLoopClosures.begin(), inputPrivateLoopClosures.end());
+    all.insert(all.end(), inputSharedLoopClosures.begin(), inputSharedLoopClosures.end());
+    setMeasurements(all);
+  }
+  void setMeasurements(const std::vector<RelativeSEMeasurement>& all) {
+    release();
+    pg_->setMeasurements(all);
+    const size_t T = (size_t)(prm_.d + 1) * prm_.r, n = pg_->n();
+    problem_.reset(new QuadraticProblem(pg_, device_, /*host_linear_term=*/false));
+    check(dpgo_problem_set_stream(problem_->handle(), nullptr));  // one stream (the default one) for everything below
+    optimizer_.reset(new QuadraticOptimizer(problem_.get(), prm_.localOptimizationParams));
+    slots_ = problem_->setCouplingFromPoseGraph();
+    pub_ = pg_->localSharedPoseIDs();
+    for (double** v : {&X_, &XPrev_, &Y_, &V_}) check(dpgo_device_malloc((void**)v, sizeof(double) * T * n, device_));
+    const size_t ns = std::max<size_t>(slots_.size(), 1), np = std::max<size_t>(pub_.size(), 1);
+    check(dpgo_device_malloc((void**)&nbr_, sizeof(double) * T * ns, device_));
+    check(dpgo_device_malloc((void**)&nbr_aux_, sizeof(double) * T * ns, device_));
+    check(dpgo_device_malloc((void**)&pack_, sizeof(double) * T * np, device_));
+    check(dpgo_device_malloc((void**)&pub_idx_, sizeof(int32_t) * np, device_));
+    std::vector<int32_t> idx(pub_.begin(), pub_.end());
+    if (!idx.empty()) check(dpgo_device_memcpy(pub_idx_, idx.data(), sizeof(int32_t) * idx.size(), DPGO_COPY_H2D, nullptr));
+    nbr_h_.assign(T * ns, 0.0);
+    nbr_aux_h_.assign(T * ns, 0.0);
+    // Y_i = [I; 0] like PGOAgent's default initial iterate
+    setX(LiftedSEVariable(prm_.r, prm_.d, (unsigned)n).getData());
+  }
+
+  // PGOAgent::setX (:465) -- also (re)starts the acceleration state (initializeAcceleration, src/PGOAgent.cpp:899-908)
+  void setX(const Matrix& Xin) {
+    const size_t bytes = shape(Xin);
+    check(dpgo_device_memcpy(X_, Xin.data(), bytes, DPGO_COPY_H2D, nullptr));
+    for (double* v : {XPrev_, Y_, V_}) check(dpgo_device_memcpy(v, X_, bytes, DPGO_COPY_D2D, nullptr));
+    gamma_ = alpha_ = 0.0;
+    iteration_ = 0;
+  }
+  bool getX(Matrix& Mout) {  // :477
+    Mout = Matrix(prm_.r, (size_t)(prm_.d + 1) * pg_->n());
+    check(dpgo_device_memcpy(Mout.data(), X_, sizeof(double) * Mout.rows() * Mout.cols(), DPGO_COPY_D2H, nullptr));
+    return true;
+  }
+  // PGOAgent::getSharedPoseDict / getAuxSharedPoseDict (:442, :454): this robot's public poses (of X, of Y)
+  bool getSharedPoseDict(PoseDict& map) { return sharedDict(X_, map); }
+  bool getAuxSharedPoseDict(PoseDict& map) { return sharedDict(prm_.acceleration ? Y_ : X_, map); }
+  // PGOAgent::updateNeighborPoses / updateAuxNeighborPoses (:532, :538)
+  void updateNeighborPoses(unsigned neighborID, const PoseDict& poseDict) { fill(neighborID, poseDict, nbr_h_, nbr_dirty_); }
+  void updateAuxNeighborPoses(unsigned neighborID, const PoseDict& poseDict) { fill(neighborID, poseDict, nbr_aux_h_, aux_dirty_); }
+
+  // PGOAgent::iterate (src/PGOAgent.cpp:376-432), INITIALIZED state
+  bool iterate(bool doOptimization = true) {
+    iteration_ += 1;
+    const size_t bytes = sizeof(double) * (size_t)(prm_.d + 1) * prm_.r * pg_->n();
+    if (!prm_.acceleration) return updateX(doOptimization, false);
+    check(dpgo_device_memcpy(XPrev_, X_, bytes, DPGO_COPY_D2D, nullptr));  // XPrev = X (:386)
+    const double N = (double)prm_.numRobots;
+    gamma_ = (1 + std::sqrt(1 + 4 * N * N * gamma_ * gamma_)) / (2 * N);  // updateGamma (:910-914)
+    alpha_ = 1 / (gamma_ * N);                                              // updateAlpha (:916-920)
+    combineProject(1 - alpha_, X_, alpha_, V_, 0.0, nullptr, Y_);           // updateY (:922-928)
+    const bool ok = updateX(doOptimization, true);
+    combineProject(1.0, V_, gamma_, X_, -gamma_, Y_, V_);                   // updateV (:930-936)
+    if ((iteration_ + 1) % prm_.restartInterval == 0) {                     // shouldRestart (:880-885)
+      check(dpgo_device_memcpy(X_, XPrev_, bytes, DPGO_COPY_D2D, nullptr));  // restartNesterovAcceleration (:887-897)
+      updateX(doOptimization, false);
+      check(dpgo_device_memcpy(V_, X_, bytes, DPGO_COPY_D2D, nullptr));
+      check(dpgo_device_memcpy(Y_, X_, bytes, DPGO_COPY_D2D, nullptr));
+      gamma_ = alpha_ = 0.0;
+    }
+    return ok;
+  }
+  const ROPTResult& latestResult() const { return result_; }
+
+  // This agent's block of the central objective with the neighbour poses received last: 0.5 (<X Q, X> + <X, G>) and
+  // |rgrad_a|^2 -- the agent-local gradient IS its block of the central gradient, so a driver can evaluate the central
+  // cost / gradient norm / greedy selection (examples/MultiRobotExample.cpp:220-247) from these.
+  void localTerms(double* half_cost, double* gradnorm_sq) {
+    syncNeighbours(false);
+    if (!slots_.empty()) problem_->updateLinearMatrixFromNeighbors(nbr_);
+    double xqx = 0, xg = 0, g2 = 0;
+    check(dpgo_problem_eval_terms_device(problem_->handle(), X_, &xqx, &xg, &g2));
+    if (half_cost) *half_cost = 0.5 * (xqx + xg);
+    if (gradnorm_sq) *gradnorm_sq = g2;
+  }
+
+ private:
+  size_t shape(const Matrix& M) const {
+    if (M.rows() != prm_.r || M.cols() != (size_t)(prm_.d + 1) * pg_->n()) throw Error(DPGO_ERR_INVALID, "matrix shape mismatch");
+    return sizeof(double) * M.rows() * M.cols();
+  }
+  void release() {
+    for (double** v : {&X_, &XPrev_, &Y_, &V_, &nbr_, &nbr_aux_, &pack_}) {
+      if (*v) dpgo_device_free(*v);
+      *v = nullptr;
+    }
+    if (pub_idx_) dpgo_device_free(pub_idx_);
+    pub_idx_ = nullptr;
+    optimizer_.reset();
+    problem_.reset();
+  }
+  bool sharedDict(const double* src, PoseDict& map) {
+    map.clear();
+    if (pub_.empty()) return true;
+    const size_t T = (size_t)(prm_.d + 1) * prm_.r;
+    check(dpgo_gather_tiles_device((int)prm_.r, (int)prm_.d, src, pub_idx_, (int)pub_.size(), pack_, nullptr));
+    std::vector<double> host(T * pub_.size());
+    check(dpgo_device_memcpy(host.data(), pack_, sizeof(double) * host.size(), DPGO_COPY_D2H, nullptr));
+    for (size_t k = 0; k < pub_.size(); ++k) {
+      Matrix M(prm_.r, prm_.d + 1);
+      std::memcpy(M.data(), host.data() + k * T, sizeof(double) * T);
+      map[PoseID(id_, pub_[k])] = M;
+    }
+    return true;
+  }
+  void fill(unsigned neighborID, const PoseDict& dict, std::vector<double>& host, bool& dirty) {
+    const size_t T = (size_t)(prm_.d + 1) * prm_.r;
+    for (size_t k = 0; k < slots_.size(); ++k) {
+      if (slots_[k].first != neighborID) continue;
+      auto it = dict.find(slots_[k]);
+      if (it == dict.end()) continue;
+      if (it->second.rows() != prm_.r || it->second.cols() != prm_.d + 1) throw Error(DPGO_ERR_INVALID, "matrix shape mismatch");
+      std::memcpy(host.data() + k * T, it->second.data(), sizeof(double) * T);
+      dirty = true;
+    }
+  }
+  void syncNeighbours(bool aux) {
+    bool& dirty = aux ? aux_dirty_ : nbr_dirty_;
+    if (!dirty) return;
+    auto& host = aux ? nbr_aux_h_ : nbr_h_;
+    check(dpgo_device_memcpy(aux ? nbr_aux_ : nbr_, host.data(), sizeof(double) * host.size(), DPGO_COPY_H2D, nullptr));
+    dirty = false;
+  }
+  void combineProject(double a, const double* A, double b, const double* B, double c, const double* Cm, double* out) {
+    check(dpgo_axpby_project_device((int)prm_.r, (int)prm_.d, (int)pg_->n(), a, A, b, B, c, Cm, 1, out, nullptr));
+  }
+  bool updateX(bool doOptimization, bool acceleration) {  // PGOAgent::updateX (:938-995)
+    const size_t bytes = sizeof(double) * (size_t)(prm_.d + 1) * prm_.r * pg_->n();
+    if (!doOptimization) {
+      if (acceleration) check(dpgo_device_memcpy(X_, Y_, bytes, DPGO_COPY_D2D, nullptr));
+      return true;
+    }
+    if (!slots_.empty()) {
+      syncNeighbours(acceleration);
+      problem_->updateLinearMatrixFromNeighbors(acceleration ? nbr_aux_ : nbr_);
+    }
+    if (acceleration) check(dpgo_device_memcpy(X_, Y_, bytes, DPGO_COPY_D2D, nullptr));  // X0 = Y (:973-978)
+    result_ = optimizer_->optimizeDevice(X_);
+    return result_.success;
+  }
+
+  unsigned id_;
+  PGOAgentParameters prm_;
+  int device_;
+  std::shared_ptr<PoseGraph> pg_;
+  std::unique_ptr<QuadraticProblem> problem_;
+  std::unique_ptr<QuadraticOptimizer> optimizer_;
+  std::vector<PoseID> slots_;   // neighbour poses, slot order of the tile buffers
+  std::vector<unsigned> pub_;   // my public frames
+  double *X_ = nullptr, *XPrev_ = nullptr, *Y_ = nullptr, *V_ = nullptr, *nbr_ = nullptr, *nbr_aux_ = nullptr, *pack_ = nullptr;
+  int32_t* pub_idx_ = nullptr;
+  std::vector<double> nbr_h_, nbr_aux_h_;
+  bool nbr_dirty_ = false, aux_dirty_ = false;
+  double gamma_ = 0.0, alpha_ = 0.0;
+  unsigned iteration_ = 0;
+  ROPTResult result_;
 };
 
 // ---------------------------------------------------------------------------------------------------------

@@ -5,6 +5,7 @@
 // plus the CSR hand-over (dpgo_problem_set_Q_csr) a reference-side PoseGraph would use.
 // Exit code 0 = pass, 77 = no HIP device (the library has no CPU fallback), 1 = failure.
 #include <cstdio>
+#include <fstream>
 #include <cstdlib>
 
 #include "dpgo_hip.hpp"
@@ -300,6 +301,46 @@ static int run() {
     REQUIRE(dm <= 1e-5);
   }
 
+  // ---------------- LiftedSEVariable / LiftedSEVector (tests/testEigenMap.cpp:12-36: the flat storage is the matrix)
+  {
+    LiftedSEVariable var(5, 3, 7);
+    Matrix X = var.getData();
+    REQUIRE(X.rows() == 5 && X.cols() == 28);
+    for (unsigned i = 0; i < 7; ++i)
+      for (unsigned a = 0; a < 5; ++a)
+        for (unsigned c = 0; c < 4; ++c) REQUIRE(X(a, i * 4 + c) == ((c < 3 && a == c) ? 1.0 : 0.0));
+    Matrix Yi(5, 3), ti(5, 1);
+    for (unsigned a = 0; a < 5; ++a) {
+      for (unsigned c = 0; c < 3; ++c) Yi(a, c) = 10.0 * a + c;
+      ti(a, 0) = -1.0 - a;
+    }
+    var.rotation(2) = Yi;       // writable views (Eigen::Ref in the reference)
+    var.translation(2) = ti;
+    var.pose(6)(4, 3) = 42.0;
+    const LiftedSEVariable& cv = var;
+    REQUIRE(cv.pose(2)(3, 1) == 31.0 && cv.pose(2)(2, 3) == -3.0 && cv.translation(6)(4, 0) == 42.0);
+    REQUIRE(var.data()[(2 * 4 + 1) * 5 + 3] == 31.0);  // column-major r x (d+1)n, pose tiles consecutive
+    LiftedSEVariable copy(var);
+    copy.pose(0)(0, 0) = 7.0;
+    REQUIRE(var.getData()(0, 0) == 1.0 && copy.getData()(0, 0) == 7.0);
+    LiftedSEVector vec(5, 3, 7);
+    REQUIRE(vec.getData().norm() == 0.0);
+    vec.setData(var.getData());
+    REQUIRE(vec.getData()(3, 9) == 31.0);
+    bool threw = false;
+    try {
+      var.setData(Matrix(5, 27));
+    } catch (const Error& e) {
+      threw = e.code == DPGO_ERR_INVALID;
+    }
+    REQUIRE(threw);
+    // the variable's storage feeds the device path unchanged
+    LiftedSEManifold man(5, 3, 7);
+    Matrix P = man.project(var.getData());
+    REQUIRE(P.rows() == 5 && P.cols() == 28);
+    std::printf("lifted variable: ok\n");
+  }
+
   // ---------------- error behaviour: shape mismatch is reported, not aborted
   try {
     problem.f(Matrix(2, 5));
@@ -310,7 +351,93 @@ static int run() {
   return 0;
 }
 
-int main() {
+// ---------------- the reference demo's schedule through the C++ PGOAgent mirror (examples/MultiRobotExample.cpp:170-255):
+// greedy block selection + Nesterov acceleration with restarts, public poses exchanged as PoseDicts.  The scenario file
+// (written by tests/test_cxx_shim.py from the Python driver's run on the same GPU) holds the measurements, the
+// partition, the initial iterate and the expected selection sequence / final cost.
+static int run_greedy_scenario(const char* path) {
+  std::ifstream in(path);
+  REQUIRE(in.good());
+  unsigned d, r, robots, n, m, restart;
+  in >> d >> r >> robots >> n >> m >> restart;
+  std::vector<RelativeSEMeasurement> all(m);
+  for (auto& e : all) {
+    int fixed;
+    in >> e.r1 >> e.p1 >> e.r2 >> e.p2 >> e.kappa >> e.tau >> fixed;
+    e.fixedWeight = fixed != 0;
+    e.R = Matrix(d, d);
+    e.t = Matrix(d, 1);
+    for (unsigned p = 0; p < d; ++p)
+      for (unsigned q = 0; q < d; ++q) in >> e.R(p, q);
+    for (unsigned p = 0; p < d; ++p) in >> e.t(p, 0);
+  }
+  std::vector<unsigned> start(robots), end(robots);
+  for (unsigned a = 0; a < robots; ++a) in >> start[a] >> end[a];
+  Matrix X0(r, (size_t)(d + 1) * n);
+  for (size_t q = 0; q < X0.rows() * X0.cols(); ++q) in >> X0.data()[q];
+  unsigned K;
+  in >> K;
+  std::vector<unsigned> want(K);
+  for (auto& v : want) in >> v;
+  double want_cost, want_gn;
+  in >> want_cost >> want_gn;
+  REQUIRE(in.good());
+
+  PGOAgentParameters prm(d, r, robots, ROptParameters(), /*acceleration=*/true, restart);
+  std::vector<std::unique_ptr<PGOAgent>> agents;
+  for (unsigned a = 0; a < robots; ++a) {
+    agents.emplace_back(new PGOAgent(a, prm));
+    agents[a]->setMeasurements(all);  // PoseGraph keeps the edges that touch robot a
+    REQUIRE(agents[a]->num_poses() == end[a] - start[a]);
+    agents[a]->setX(X0.block(0, (size_t)start[a] * (d + 1), r, (size_t)(end[a] - start[a]) * (d + 1)));
+  }
+  auto exchange_to = [&](unsigned q, bool aux) {
+    for (unsigned a = 0; a < robots; ++a) {
+      if (a == q) continue;
+      PoseDict dict;
+      if (aux)
+        agents[a]->getAuxSharedPoseDict(dict);
+      else
+        agents[a]->getSharedPoseDict(dict);
+      if (aux)
+        agents[q]->updateAuxNeighborPoses(a, dict);
+      else
+        agents[q]->updateNeighborPoses(a, dict);
+    }
+  };
+  unsigned selected = 0;
+  std::vector<unsigned> order;
+  double cost = 0, gn = 0;
+  for (unsigned it = 0; it < 1000; ++it) {
+    for (unsigned a = 0; a < robots; ++a)
+      if (a != selected) agents[a]->iterate(false);
+    exchange_to(selected, false);
+    exchange_to(selected, true);
+    agents[selected]->iterate(true);
+    for (unsigned q = 0; q < robots; ++q) exchange_to(q, false);
+    std::vector<double> g2(robots);
+    cost = 0;
+    double gsum = 0;
+    for (unsigned a = 0; a < robots; ++a) {
+      double hc = 0;
+      agents[a]->localTerms(&hc, &g2[a]);
+      cost += 2.0 * hc;
+      gsum += g2[a];
+    }
+    gn = std::sqrt(gsum);
+    order.push_back(selected);
+    if (gn < 0.1) break;  // examples/MultiRobotExample.cpp:229
+    selected = (unsigned)(std::max_element(g2.begin(), g2.end()) - g2.begin());
+  }
+  std::printf("greedy: %zu iterations, cost %.8f, gradnorm %.4f (Python driver: %u, %.8f, %.4f)\n", order.size(), cost, gn,
+              K, want_cost, want_gn);
+  REQUIRE(order.size() == K);
+  for (unsigned k = 0; k < K; ++k) REQUIRE(order[k] == want[k]);
+  REQUIRE(std::fabs(cost - want_cost) <= 1e-9 * std::fabs(want_cost));
+  return 0;
+}
+
+int main(int argc, char** argv) {
   int count = 0;
   if (dpgo_device_count(&count) != DPGO_OK || count < 1) {
     // still exercise the failure path: creation must fail with DPGO_ERR_HIP, never fall back
@@ -327,7 +454,9 @@ int main() {
     }
   }
   try {
-    return run();
+    const int rc = run();
+    if (rc != 0 || argc < 2) return rc;
+    return run_greedy_scenario(argv[1]);
   } catch (const std::exception& e) {
     std::printf("exception: %s\n", e.what());
     return 1;

@@ -27,11 +27,54 @@ def test_cxx_shim_compiles_and_refuses_without_device(tmp_path):
     assert p.returncode == 77, p.stdout + p.stderr  # DPGO_ERR_HIP, no CPU fallback
 
 
+def _write_greedy_scenario(path):
+    """smallGrid3D / 5 robots: measurements, partition, chordal initial iterate and what the Python driver
+    (RBCDCluster.run_greedy: greedy selection + Nesterov acceleration, restart 30) does with them on this GPU."""
+    import numpy as np
+    import dpgo_amd
+    from dpgo_amd.agent import DeviceAgent, ExchangePlan, RBCDCluster, build_pose_graphs
+    from dpgo_amd.initialization import chordal_initialization
+    from dpgo_amd import synthetic
+    r, robots, restart = 5, 5, 30
+    meas, n = dpgo_amd.read_g2o_file(os.path.join(ROOT, "data", "smallGrid3D.g2o"))
+    d = meas.d
+    X0 = synthetic.lift_tiles(chordal_initialization(meas, n), r)
+    ranges, graphs = build_pose_graphs(meas, n, robots, r)
+    plan = ExchangePlan(graphs)
+    agents = {a: DeviceAgent(graphs, plan, a, X0[ranges[a][0]:ranges[a][1]], dpgo_amd.ROptParameters())
+              for a in range(robots)}
+    for ag in agents.values():
+        ag.enable_acceleration(robots, restart)
+    out = RBCDCluster(plan, agents).run_greedy()
+    with open(path, "w") as fh:
+        # the demo's relabelling (examples/MultiRobotExample.cpp:71-119), edges in the dataset's own order
+        per = n // robots
+        robot_of = np.minimum(np.arange(n) // per, robots - 1)
+        local = np.arange(n) - robot_of * per
+        fh.write("%d %d %d %d %d %d\n" % (d, r, robots, n, len(meas), restart))
+        for e in range(len(meas)):
+            fh.write("%d %d %d %d %.17g %.17g %d " % (robot_of[meas.p1[e]], local[meas.p1[e]], robot_of[meas.p2[e]],
+                                                       local[meas.p2[e]], meas.kappa[e], meas.tau[e],
+                                                       int(meas.fixedWeight[e])))
+            fh.write(" ".join("%.17g" % v for v in np.asarray(meas.R[e]).reshape(-1)) + " ")
+            fh.write(" ".join("%.17g" % v for v in np.asarray(meas.t[e]).reshape(-1)) + "\n")
+        for a in range(robots):
+            fh.write("%d %d\n" % ranges[a])
+        fh.write(" ".join("%.17g" % v for v in np.ascontiguousarray(X0).reshape(-1)) + "\n")  # tiles = column-major matrix
+        fh.write("%d\n" % out["iterations"] + " ".join(str(v) for v in out["selected"]) + "\n")
+        fh.write("%.17g %.17g\n" % (out["cost"], out["gradnorm"]))
+    return out
+
+
 @pytest.mark.gpu
 def test_cxx_shim_reference_known_answers(tmp_path):
     exe = _build(tmp_path)
-    p = subprocess.run([exe], capture_output=True, text=True)
+    scenario = os.path.join(str(tmp_path), "greedy.txt")
+    want = _write_greedy_scenario(scenario)
+    p = subprocess.run([exe, scenario], capture_output=True, text=True)
     assert p.returncode == 0, p.stdout + p.stderr
+    assert "lifted variable: ok" in p.stdout
+    assert "greedy: %d iterations" % want["iterations"] in p.stdout  # same selection sequence as the Python driver
     assert "triangle" in p.stdout and "prior" in p.stdout and "project: ok" in p.stdout
     assert "rounding" in p.stdout and "robust: inlier" in p.stdout and "robust: outlier" in p.stdout
     assert "precond 1:" in p.stdout and "precond 2:" in p.stdout  # block-Jacobi and multilevel

