@@ -852,10 +852,53 @@ struct solveRobustPGOParams {
   solveRobustPGOParams() { robust_params.costType = RobustCostParameters::Type::GNC_TLS; }
 };
 
+// chordalInitialization / odometryInitialization (src/DPGO_solver.cpp:220-303) for the poses of one robot: d x (d+1)n.
+// The chordal relaxation is solved on the device (dpgo_chordal_initialization).
+namespace detail {
+struct EdgeSoa {
+  std::vector<int32_t> p1, p2;
+  std::vector<double> R, t, kappa, tau;
+  unsigned d = 0, n = 0;
+  explicit EdgeSoa(const std::vector<RelativeSEMeasurement>& ms) {
+    if (ms.empty()) throw Error(DPGO_ERR_INVALID, "no measurements");
+    d = (unsigned)ms[0].R.rows();
+    for (const auto& m : ms) {
+      p1.push_back((int32_t)m.p1);
+      p2.push_back((int32_t)m.p2);
+      for (unsigned p = 0; p < d; ++p)
+        for (unsigned q = 0; q < d; ++q) R.push_back(m.R(p, q));
+      for (unsigned p = 0; p < d; ++p) t.push_back(m.t(p, 0));
+      kappa.push_back(m.kappa);
+      tau.push_back(m.tau);
+      n = std::max<unsigned>(n, (unsigned)std::max(m.p1, m.p2) + 1);
+    }
+  }
+};
+}  // namespace detail
+inline Matrix chordalInitialization(const std::vector<RelativeSEMeasurement>& measurements, int device = 0) {
+  detail::EdgeSoa s(measurements);
+  Matrix T(s.d, (size_t)(s.d + 1) * s.n);
+  check(dpgo_chordal_initialization((int)s.d, (int)s.n, (int)measurements.size(), s.p1.data(), s.p2.data(), s.R.data(),
+                                    s.t.data(), s.kappa.data(), s.tau.data(), 0.0, 0, T.data(), nullptr, device));
+  return T;
+}
+inline Matrix odometryInitialization(const std::vector<RelativeSEMeasurement>& odometry) {
+  detail::EdgeSoa s(odometry);
+  Matrix T(s.d, (size_t)(s.d + 1) * s.n);
+  check(dpgo_odometry_initialization((int)s.d, (int)s.n, (int)odometry.size(), s.p1.data(), s.p2.data(), s.R.data(),
+                                     s.t.data(), T.data()));
+  return T;
+}
+
+// solvePGO (src/DPGO_solver.cpp:305-333): T0 = nullptr -> chordal initialisation, as the reference
 inline Matrix solvePGO(const std::vector<RelativeSEMeasurement>& measurements, const ROptParameters& params,
-                       const Matrix* T0, int device = 0) {
+                       const Matrix* T0 = nullptr, int device = 0) {
   if (measurements.empty()) throw Error(DPGO_ERR_INVALID, "no measurements");
-  if (!T0) throw Error(DPGO_ERR_UNSUPPORTED, "solvePGO needs an initial guess T0");
+  Matrix Tinit;
+  if (!T0) {
+    Tinit = chordalInitialization(measurements, device);
+    T0 = &Tinit;
+  }
   const unsigned d = (unsigned)measurements[0].R.rows();
   auto pg = std::make_shared<PoseGraph>(measurements[0].r1, d, d);  // robot id of the data, rank r = d (src/DPGO_solver.cpp:322-324)
   pg->setMeasurements(measurements);
@@ -867,9 +910,13 @@ inline Matrix solvePGO(const std::vector<RelativeSEMeasurement>& measurements, c
 // GNC with truncated least squares.  One device problem serves all outer iterations: the weights are updated
 // and Q's values / the preconditioner rebuilt ON THE DEVICE (the reference rebuilds a PoseGraph per iteration).
 inline Matrix solveRobustPGO(std::vector<RelativeSEMeasurement>& mutable_measurements,
-                             const solveRobustPGOParams& params, const Matrix* T0, int device = 0) {
+                             const solveRobustPGOParams& params, const Matrix* T0 = nullptr, int device = 0) {
   if (mutable_measurements.empty()) throw Error(DPGO_ERR_INVALID, "no measurements");
-  if (!T0) throw Error(DPGO_ERR_UNSUPPORTED, "solveRobustPGO needs an initial guess T0");
+  Matrix Tinit;
+  if (!T0) {  // src/DPGO_solver.cpp:341: chordal initialisation on the full measurement set
+    Tinit = chordalInitialization(mutable_measurements, device);
+    T0 = &Tinit;
+  }
   if (params.robust_params.costType != RobustCostParameters::Type::GNC_TLS)
     throw Error(DPGO_ERR_INVALID, "CHECK(params.robust_params.costType == GNC_TLS) failed");  // :355
   const double w_tol = 1e-8;  // :340

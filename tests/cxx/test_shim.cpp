@@ -86,6 +86,34 @@ static int run() {
     }
     T0.setBlock(0, i * 4, cur.block(0, 0, 3, 4));
   }
+  {  // the library's initial guesses: odometryInitialization equals the hand composition above; solvePGO without an
+     // initial guess runs the chordal initialisation on the device and lands at the same optimum (noiseless triangle)
+    Matrix Todo = odometryInitialization({ms[0], ms[1]});
+    double dmax = 0;
+    for (size_t q = 0; q < T0.rows() * T0.cols(); ++q) dmax = std::max(dmax, std::fabs(Todo.data()[q] - T0.data()[q]));
+    REQUIRE(dmax <= 1e-14);
+    Matrix Tch = chordalInitialization(ms);
+    REQUIRE(Tch.rows() == 3 && Tch.cols() == 12);
+    ROptParameters pp;
+    pp.gradnorm_tol = 1e-9;
+    pp.RTR_iterations = 20;
+    Matrix Ts = solvePGO(ms, pp);  // T0 = nullptr
+    const Matrix* Twp[3] = {&Tw0, &Tw1, &Tw2};
+    Matrix R0s = transpose(Ts.block(0, 0, 3, 3));
+    double e2 = 0;
+    for (int i = 0; i < 3; ++i) {  // trajectory in the frame of pose 0 vs Ttrue
+      Matrix Ri = mul(R0s, Ts.block(0, i * 4, 3, 3));
+      Matrix dt(3, 1);
+      for (int k = 0; k < 3; ++k) dt(k, 0) = Ts(k, i * 4 + 3) - Ts(k, 3);
+      Matrix ti = mul(R0s, dt);
+      for (int a = 0; a < 3; ++a) {
+        for (int b = 0; b < 3; ++b) e2 += std::pow(Ri(a, b) - (*Twp[i])(a, b), 2);
+        e2 += std::pow(ti(a, 0) - (*Twp[i])(a, 3), 2);
+      }
+    }
+    std::printf("solvePGO from the chordal initialisation: |Ttrue - T| = %.3e\n", std::sqrt(e2));
+    REQUIRE(std::sqrt(e2) <= 1e-4);
+  }
   // solve to a tight tolerance so the optimizer really runs (a correct solver lands within 9.1e-5 of
   // Ttrue: the margin of the reference's 1e-4 is consumed by the 4-digit literals)
   QuadraticOptimizer optimizer(&problem);
