@@ -1,0 +1,19 @@
+#!/bin/bash
+# usage (on the GPU box, from the repo root): tools/profile_extra.sh <tag>
+# rocprofv3 kernel-stats summaries the bench profile cannot give by itself: (1) the rotating-operand (HBM-only) launches
+# alone, (2) the small-block regime (sphere2500, 12.5k-pose slab, 625-pose block) with the multilevel, block-Jacobi and
+# persistent paths.  Writes gpurun_out/<tag>_rotating_kernel_stats.csv and gpurun_out/<tag>_small_blocks_kernel_stats.csv.
+TAG=${1:-rXX}
+R=${GRAFT_REPO_ROOT:-$PWD}
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_rot_$TAG -o rot -- \
+  python $R/tools/rotating_probe.py > $R/gpurun_out/${TAG}_rotating.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_small_$TAG -o small -- \
+  python $R/tools/ml_probe.py grid625 sphere slab > $R/gpurun_out/${TAG}_small_blocks.log 2>&1
+cd $R
+python tools/summarize_prof.py stats gpurun_out/prof_rot_$TAG gpurun_out/${TAG}_rotating_kernel_stats.csv
+python tools/summarize_prof.py stats gpurun_out/prof_small_$TAG gpurun_out/${TAG}_small_blocks_kernel_stats.csv
+rm -rf gpurun_out/prof_rot_$TAG gpurun_out/prof_small_$TAG
+tail -2 gpurun_out/${TAG}_rotating.log
+head -8 gpurun_out/${TAG}_rotating_kernel_stats.csv | cut -c1-140
+grep -v "^dpgo_hip" gpurun_out/${TAG}_small_blocks.log | tail -12
