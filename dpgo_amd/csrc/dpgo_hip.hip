@@ -671,9 +671,9 @@ int run_tcg_persistent(dpgo_problem_s* p, const double* dinv, bool* used) {
   *used = false;
   hipLaunchKernelGGL(k_persist_reset, dim3(1), dim3(1), 0, p->stream, p->pctrl);
   const int grid = 8 * p->persist_wgs;
-  DISPATCH(p->d, p->r, LAUNCH_SPLIT(p, k_tcg_persist, grid, p->Q.dev(), p->x1, p->S1, p->g1, dinv, p->delta, p->Hd, p->eta,
-                                    p->rr, p->z, p->pgran, (double)p->gen * 1048576.0, p->dstate + p->cur,
-                                    p->dstate + (p->cur ^ 1), p->pctrl, p->n, p->hflag, p->gen));
+  DISPATCH(p->d, p->r, hipLaunchKernelGGL((k_tcg_persist<D, R, 4>), dim3(grid), dim3(kBlock), 0, p->stream, p->Q.dev(),
+                                          p->x1, p->S1, p->g1, dinv, p->eta, p->z, p->pgran, (double)p->gen * 1048576.0,
+                                          p->dstate + p->cur, p->dstate + (p->cur ^ 1), p->pctrl, p->n, p->hflag, p->gen));
   HIPC(hipGetLastError());
   HIPC(hipMemcpyAsync(p->hctrl, p->pctrl, sizeof(PersistCtrl), hipMemcpyDeviceToHost, p->stream));
   HIPC(hipMemcpyAsync(p->hstate, p->dstate + (p->cur ^ 1), sizeof(DevState), hipMemcpyDeviceToHost, p->stream));
@@ -1009,14 +1009,8 @@ int tune_launch_caps(dpgo_problem_s* p) {
 int tune_persist(dpgo_problem_s* p) {
   p->persist = false;
   int occ = 0;
-  DISPATCH(p->d, p->r, {
-    if (p->split == 4)
-      HIPC(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_tcg_persist<D, R, 4>, kBlock, 0));
-    else if (p->split == 2)
-      HIPC(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_tcg_persist<D, R, 2>, kBlock, 0));
-    else
-      HIPC(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_tcg_persist<D, R, 1>, kBlock, 0));
-  });
+  if (p->split != 4) return DPGO_OK;  // the kernel exists for the small-block (SPLIT = 4) geometry only
+  DISPATCH(p->d, p->r, HIPC(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_tcg_persist<D, R, 4>, kBlock, 0)));
   int dev = 0, cus = 0;
   HIPC(hipGetDevice(&dev));
   HIPC(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
@@ -1030,7 +1024,7 @@ int tune_persist(dpgo_problem_s* p) {
   if (const char* e = std::getenv("DPGO_PERSIST_WGS")) p->persist_wgs = std::max(1, std::min(cap, std::atoi(e)));
   bool on = false;  // opt-in until the single-XCD placement has been validated on the target box
   if (const char* e = std::getenv("DPGO_PERSIST")) on = std::atoi(e) != 0;
-  p->persist = on && tiles <= 4 * cap;
+  p->persist = on && tiles <= kResidentTiles * cap;  // every workgroup keeps its tiles resident in LDS
   return DPGO_OK;
 }
 
@@ -1763,7 +1757,8 @@ int dpgo_problem_set_persistent(dpgo_problem_t p, int enable) {
   if (!p) return fail(DPGO_ERR_INVALID, "null handle");
   const int P = (64 / (p->b * p->split)) * kWaves;
   const int tiles = std::max(1, (p->n + P - 1) / P);
-  if (enable && tiles > 16 * kPersistMax) return fail(DPGO_ERR_UNSUPPORTED, "block too large for the persistent tCG kernel");
+  if (enable && (p->split != 4 || tiles > kResidentTiles * p->persist_wgs))
+    return fail(DPGO_ERR_UNSUPPORTED, "block too large for the persistent tCG kernel (its tiles must fit one XCD's LDS)");
   p->persist = enable != 0;
   return DPGO_OK;
 }
@@ -1795,6 +1790,7 @@ int dpgo_bench_hess_rotating(dpgo_problem_t p, int nsets, int reps, int warmup, 
   p->hstate->theta = 1.0;
   p->hstate->kappa = -1.0;
   p->hstate->max_inner = 1 << 30;
+  p->hstate->min_inner = 1 << 30;  // the convergence test is never evaluated, whatever the partial sums hold
   CHK(push_state(p));
   // every operand of the tCG-step kernel gets nsets private copies; the handle's pointers are swapped per launch
   const size_t vbytes = sizeof(double) * (size_t)p->Q.nnzb * p->b * p->b;
@@ -1930,6 +1926,7 @@ int dpgo_bench_hess(dpgo_problem_t p, int reps, int warmup, double* avg_ms) {
   p->hstate->theta = 1.0;
   p->hstate->kappa = -1.0;  // convergence test can never fire
   p->hstate->max_inner = 1 << 30;
+  p->hstate->min_inner = 1 << 30;  // the convergence test is never evaluated, whatever the partial sums hold
   CHK(push_state(p));
   auto launch = [&]() -> int {
     DISPATCH(p->d, p->r, LAUNCH_TCG_HESS(p, p->dstate, p->dstate + 1, 0, (unsigned long long*)nullptr, 0u));
@@ -1962,6 +1959,7 @@ int dpgo_bench_iteration_kernels(dpgo_problem_t p, int reps, int warmup, double 
   p->hstate->theta = 1.0;
   p->hstate->kappa = -1.0;
   p->hstate->max_inner = 1 << 30;
+  p->hstate->min_inner = 1 << 30;  // the convergence test is never evaluated, whatever the partial sums hold
   p->hstate->Delta = 1e300;
   CHK(push_state(p));
   CHK(build_dinv(p, p->ml_ready ? p->ml_shift : 1e-1));

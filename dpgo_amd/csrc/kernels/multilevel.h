@@ -160,7 +160,9 @@ __global__ __launch_bounds__(kBlock) void k_ml_coarse_prolong(const double* __re
       for (int j2 = wave * 64 + lane; j2 < npair; j2 += kBlock) {
         dbl2 mv[NR];
 #pragma unroll
-        for (int c = 0; c < NR; ++c) mv[c] = *reinterpret_cast<const dbl2*>(m + (size_t)c * lda + 2 * j2);
+        for (int c = 0; c < NR; ++c)  // streamed once per cycle by exactly one workgroup: non-temporal, so that the
+                                      // inverse does not push Q and the tCG vectors out of the Infinity Cache
+          mv[c] = __builtin_nontemporal_load(reinterpret_cast<const dbl2*>(m + (size_t)c * lda + 2 * j2));
         double rv[2 * R];  // rc of column 2 j2 in [0, R), of column 2 j2 + 1 in [R, 2R)
         if (2 * j2 + 1 < N) {
 #pragma unroll

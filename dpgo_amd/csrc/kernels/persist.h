@@ -113,27 +113,33 @@ __device__ __forceinline__ bool xcd_allreduce(dbl2* gran, int rank, int members,
   return *ok_s != 0;
 }
 
+// Tiles a workgroup may own.  Its rows of X, S, Dinv and of every tCG vector stay in LDS for the whole launch, the row
+// pointers / preloaded column indices in registers: a phase is then ONE hop of loads (the gathered z tiles and the Q
+// blocks, issued together) instead of a chain of dependent ones -- in this regime a kernel is latency, not bytes.
+constexpr int kResidentTiles = 3;
+
 template <int D, int R, int SPLIT>
 __global__ __launch_bounds__(kBlock) void k_tcg_persist(BsrDev Q, const double* __restrict__ X,
                                                         const double* __restrict__ S, const double* __restrict__ g,
-                                                        const double* __restrict__ dinv, double* delta, double* Hd,
-                                                        double* eta, double* r, double* z, dbl2* gran, double tagbase,
-                                                        const DevState* __restrict__ sin, DevState* __restrict__ sout,
-                                                        PersistCtrl* ctrl, int n, unsigned long long* hflag,
-                                                        unsigned gen) {
-  using GEO = Geo<D, R, SPLIT>;   // SpMM phase: SPLIT lane groups per pose
-  using GEU = Geo<D, R, 1>;       // update phase: one lane per (pose, column)
-  __shared__ __attribute__((aligned(16))) double sm[kWaves][4][GEU::G][GEU::T];
+                                                        const double* __restrict__ dinv, double* eta, double* z,
+                                                        dbl2* gran, double tagbase, const DevState* __restrict__ sin,
+                                                        DevState* __restrict__ sout, PersistCtrl* ctrl, int n,
+                                                        unsigned long long* hflag, unsigned gen) {
+  using GEO = Geo<D, R, SPLIT>;
+  constexpr int P = GEO::P, G = GEO::G, T = GEO::T, B = GEO::B, BB = GEO::BB, MT = kResidentTiles;
+  __shared__ __attribute__((aligned(16))) double Xs[MT][P][T], Es[MT][P][T], Rs[MT][P][T], Ds[MT][P][T], Hs[MT][P][T],
+      Zs[MT][P][T];
+  __shared__ double Ss[MT][P][D * D], Vs[MT][P][BB];
+  __shared__ double ex[kWaves][G][T];  // wave-private exchange tile (columns of one pose meet here)
   __shared__ double red[kWaves * kNP];
   __shared__ int ok_s, rank_s, members_s;
 
   // ---- establish the participants: the workgroups that landed on the target XCD
   if (threadIdx.x == 0) {
     const int xcc = xcc_id();
-    int tgt = -1;
     // first arrival fixes the target (agent-scope CAS); everybody reads the winner back
     const int prev = atomicCAS(&ctrl->target, -1, xcc);
-    tgt = (prev == -1) ? xcc : prev;
+    const int tgt = (prev == -1) ? xcc : prev;
     // one atomic reports the arrival and, on the target XCD, takes a rank
     const bool mine = (xcc == tgt);
     const unsigned long long old = atomicAdd(&ctrl->counts, 1ull | (mine ? (1ull << 32) : 0ull));
@@ -151,7 +157,8 @@ __global__ __launch_bounds__(kBlock) void k_tcg_persist(BsrDev Q, const double* 
           __builtin_amdgcn_s_sleep(1);
         }
       }
-      if (!done) {
+      const int ntiles = (n + P - 1) / P;
+      if (!done || members > kPersistMax || (long long)members * MT < ntiles) {  // placement did not hold: give up
         __hip_atomic_store(&ctrl->error, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         rank = -1;
       }
@@ -162,7 +169,7 @@ __global__ __launch_bounds__(kBlock) void k_tcg_persist(BsrDev Q, const double* 
   }
   __syncthreads();
   const int rank = rank_s, members = members_s;
-  if (rank < 0 || members <= 0) return;  // not on the target XCD (or time-out: error flag is set)
+  if (rank < 0 || members <= 0) return;  // not on the target XCD (or the error flag is set)
 
   DevState st;
   load_state(st, sin);
@@ -175,137 +182,120 @@ __global__ __launch_bounds__(kBlock) void k_tcg_persist(BsrDev Q, const double* 
   }
   unsigned epoch = 0;
   const LaneId L = lane_id<D, SPLIT>();
-  const LaneId U = lane_id<D, 1>();
-  const int ntiles_s = (n + GEO::P - 1) / GEO::P;
-  const int ntiles_u = (n + GEU::P - 1) / GEU::P;
+  const int lp = L.wave * G + L.g;  // pose slot inside a workgroup tile
+  const int ntiles = (n + P - 1) / P;
+
+  // ---- resident data of the workgroup's tiles
+  RowIdx ri[MT];
+  int pose[MT];
+  bool okp[MT], own[MT];
+#pragma unroll
+  for (int k = 0; k < MT; ++k) {
+    const int tile = rank + k * members;
+    pose[k] = tile * P + lp;
+    okp[k] = (tile < ntiles) && (L.g < G) && (pose[k] < n);
+    own[k] = okp[k] && (L.s == 0);
+    ri[k] = row_idx_load<D, SPLIT>(Q.rowptr, Q.colidx, pose[k], L.s, L.c, okp[k]);
+    if (own[k]) {
+      const size_t off = (size_t)pose[k] * T + L.c * R;
+#pragma unroll
+      for (int a = 0; a < R; ++a) {
+        Xs[k][lp][L.c * R + a] = X[off + a];
+        Rs[k][lp][L.c * R + a] = g[off + a];  // r0 = g
+        Es[k][lp][L.c * R + a] = 0.0;         // eta0 = 0
+        Ds[k][lp][L.c * R + a] = 0.0;
+        Hs[k][lp][L.c * R + a] = 0.0;
+      }
+      if (L.c < D) {
+#pragma unroll
+        for (int a = 0; a < D; ++a) Ss[k][lp][L.c * D + a] = S[(size_t)pose[k] * D * D + L.c * D + a];
+      }
+#pragma unroll
+      for (int a = 0; a < B; ++a) Vs[k][lp][L.c * B + a] = dinv ? dinv[(size_t)pose[k] * BB + L.c * B + a] : 0.0;
+    }
+  }
+  wave_sync();
 
   // ---- phase B: (first) r = g, eta = 0 | eta += alpha delta, r += alpha H delta;  z = proj_X(r Dinv);  partials
   auto phase_update = [&](bool first, double alpha, double (&part)[2]) {
     part[0] = part[1] = 0.0;
-    for (int tile = rank; tile < ntiles_u; tile += members) {
-      const int i = tile * GEU::P + U.wave * GEU::G + U.g;
-      const bool ok = (U.g < GEU::G) && (i < n);
-      const size_t off = (size_t)i * GEU::T + U.c * R;
-      double* ys = ok ? &sm[U.wave][0][U.g][0] : nullptr;
-      double* rs = ok ? &sm[U.wave][1][U.g][0] : nullptr;
-      double* zs = ok ? &sm[U.wave][2][U.g][0] : nullptr;
-      double rr[R], x[R], zz[R], drow[GEU::B];
-      if (ok) {
-        load_col<R>(X + off, x);
-        if (dinv) {
 #pragma unroll
-          for (int k = 0; k < GEU::B; ++k) drow[k] = dinv[(size_t)i * GEU::BB + U.c * GEU::B + k];
-        }
-        if (first) {
-          load_col<R>(g + off, rr);
-          double e[R];
+    for (int k = 0; k < MT; ++k) {
+      double rr[R], zz[R];
+      if (own[k]) {
 #pragma unroll
-          for (int a = 0; a < R; ++a) e[a] = 0.0;
-          store_col<R>(eta + off, e);
-        } else {
-          double e[R], dl[R], hd[R];
-          load_col_nt<R>(eta + off, e);
-          load_col_nt<R>(delta + off, dl);
-          load_col_nt<R>(Hd + off, hd);
-          load_col_nt<R>(r + off, rr);
-#pragma unroll
-          for (int a = 0; a < R; ++a) {
-            e[a] = fma(alpha, dl[a], e[a]);
-            rr[a] = fma(alpha, hd[a], rr[a]);
+        for (int a = 0; a < R; ++a) {
+          const int e = L.c * R + a;
+          double rv = Rs[k][lp][e];
+          if (!first) {
+            Es[k][lp][e] = fma(alpha, Ds[k][lp][e], Es[k][lp][e]);
+            rv = fma(alpha, Hs[k][lp][e], rv);
+            Rs[k][lp][e] = rv;
           }
-          store_col<R>(eta + off, e);
+          rr[a] = rv;
+          part[0] = fma(rv, rv, part[0]);
         }
-        store_col<R>(r + off, rr);
-#pragma unroll
-        for (int a = 0; a < R; ++a) part[0] = fma(rr[a], rr[a], part[0]);
-        store_col<R>(ys + U.c * R, x);
-        store_col<R>(rs + U.c * R, rr);
       }
-      wave_sync();
-      if (ok) {
+      wave_sync();  // the pose's B columns of r are in LDS
+      if (own[k]) {
         if (dinv) {
-          jacobi_col<D, R>(rs, drow, zz);
+          jacobi_col<D, R>(&Rs[k][lp][0], &Vs[k][lp][L.c * B], zz);
         } else {
 #pragma unroll
           for (int a = 0; a < R; ++a) zz[a] = rr[a];
         }
-        store_col<R>(zs + U.c * R, zz);
+        store_col<R>(&ex[L.wave][L.g][L.c * R], zz);
       }
       wave_sync();
-      if (ok) {
+      if (own[k]) {
         double out[R], s[D];
-        proj_col<D, R>(ys, zs, U.c, zz, out, s);
+        proj_col<D, R>(&Xs[k][lp][0], &ex[L.wave][L.g][0], L.c, zz, out, s);
+        const size_t off = (size_t)pose[k] * T + L.c * R;
 #pragma unroll
-        for (int a = 0; a < R; ++a) part[1] = fma(out[a], rr[a], part[1]);
-        store_col<R>(z + off, out);
+        for (int a = 0; a < R; ++a) {
+          part[1] = fma(out[a], rr[a], part[1]);
+          Zs[k][lp][L.c * R + a] = out[a];
+          z[off + a] = out[a];  // the copy the other workgroups gather
+        }
       }
       wave_sync();
     }
     block_allreduce<2>(part, red);
   };
 
-  // ---- phase A: Hz on the own rows (gather of z bypasses L1), direction recurrences, partial <delta, H delta>
+  // ---- phase A: Hz on the own rows (one hop: Q blocks + gathered z tiles), direction recurrences, <delta, H delta>
   auto phase_hess = [&](bool first, double beta, double (&part)[1]) {
     part[0] = 0.0;
-    for (int tile = rank; tile < ntiles_s; tile += members) {
-      const int i = tile * GEO::P + L.wave * GEO::G + L.g;
-      const bool okp = (L.g < GEO::G) && (i < n);
-      const bool ok = okp && (L.s == 0);
-      double h[R], zc[R], x[R];
-      const size_t off = (size_t)i * GEO::T + L.c * R;
-      double* ys = ok ? &sm[L.wave][0][L.g][0] : nullptr;
-      double* vs = ok ? &sm[L.wave][1][L.g][0] : nullptr;
-      double* hs = ok ? &sm[L.wave][2][L.g][0] : nullptr;
-      double srow[D], dl[R], hd[R];
-      if (ok) {
-        load_col<R>(X + off, x);
-        load_col_nt<R>(z + off, zc);
-        if (L.c < D) {
 #pragma unroll
-          for (int a = 0; a < D; ++a) srow[a] = S[(size_t)i * D * D + L.c * D + a];
-        }
-        if (!first) {
-          load_col_nt<R>(delta + off, dl);
-          load_col_nt<R>(Hd + off, hd);
-        }
-      }
-      spmm_col<D, R, SPLIT, true>(Q.rowptr, Q.colidx, Q.vals, z, i, L.s, L.c, okp, h);
-      if (ok) {
-        store_col<R>(ys + L.c * R, x);
-        store_col<R>(vs + L.c * R, zc);
-      }
-      wave_sync();
-      if (ok) {
+    for (int k = 0; k < MT; ++k) {
+      if (rank + k * members >= ntiles) break;  // workgroup-uniform
+      double h[R];
+      spmm_col_pre<D, R, SPLIT, true>(ri[k], Q.colidx, Q.vals, z, L.s, L.c, h);
+      if (own[k]) {
         if (L.c < D) {
 #pragma unroll
           for (int a = 0; a < D; ++a) {
+            const double sac = Ss[k][lp][L.c * D + a];
 #pragma unroll
-            for (int k = 0; k < R; ++k) h[k] = fma(-vs[a * R + k], srow[a], h[k]);
+            for (int q = 0; q < R; ++q) h[q] = fma(-Zs[k][lp][a * R + q], sac, h[q]);
           }
         }
-        store_col<R>(hs + L.c * R, h);
+        store_col<R>(&ex[L.wave][L.g][L.c * R], h);
       }
       wave_sync();
-      if (ok) {
+      if (own[k]) {
         double hz[R], s[D];
-        proj_col<D, R>(ys, hs, L.c, h, hz, s);
-        if (first) {
+        proj_col<D, R>(&Xs[k][lp][0], &ex[L.wave][L.g][0], L.c, h, hz, s);
 #pragma unroll
-          for (int a = 0; a < R; ++a) {
-            dl[a] = -zc[a];
-            hd[a] = -hz[a];
-          }
-        } else {
-#pragma unroll
-          for (int a = 0; a < R; ++a) {
-            dl[a] = fma(beta, dl[a], -zc[a]);
-            hd[a] = fma(beta, hd[a], -hz[a]);
-          }
+        for (int a = 0; a < R; ++a) {
+          const int e = L.c * R + a;
+          const double zc = Zs[k][lp][e];
+          const double dn = first ? -zc : fma(beta, Ds[k][lp][e], -zc);
+          const double hn = first ? -hz[a] : fma(beta, Hs[k][lp][e], -hz[a]);
+          Ds[k][lp][e] = dn;
+          Hs[k][lp][e] = hn;
+          part[0] = fma(dn, hn, part[0]);
         }
-#pragma unroll
-        for (int a = 0; a < R; ++a) part[0] = fma(dl[a], hd[a], part[0]);
-        store_col<R>(delta + off, dl);
-        store_col<R>(Hd + off, hd);
       }
       wave_sync();
     }
@@ -352,16 +342,11 @@ __global__ __launch_bounds__(kBlock) void k_tcg_persist(BsrDev Q, const double* 
       const double tau = (-st.e_Pd + sqrt(st.e_Pd * st.e_Pd + st.d_Pd * (D2 - st.e_Pe))) / st.d_Pd;
       st.tcg_status = (d_Hd < 0.0) ? TCG_NEGCURV : TCG_EXCREGION;
       st.tcg_done = 1;
-      for (int tile = rank; tile < ntiles_u; tile += members) {
-        const int i = tile * GEU::P + U.wave * GEU::G + U.g;
-        if ((U.g < GEU::G) && (i < n)) {
-          const size_t off = (size_t)i * GEU::T + U.c * R;
-          double e[R], dl[R];
-          load_col_nt<R>(eta + off, e);
-          load_col_nt<R>(delta + off, dl);
 #pragma unroll
-          for (int a = 0; a < R; ++a) e[a] = fma(tau, dl[a], e[a]);
-          store_col<R>(eta + off, e);
+      for (int k = 0; k < MT; ++k) {
+        if (own[k]) {
+#pragma unroll
+          for (int a = 0; a < R; ++a) Es[k][lp][L.c * R + a] = fma(tau, Ds[k][lp][L.c * R + a], Es[k][lp][L.c * R + a]);
         }
       }
       break;
@@ -395,6 +380,15 @@ __global__ __launch_bounds__(kBlock) void k_tcg_persist(BsrDev Q, const double* 
       st.tcg_status = TCG_MAXITER;
     }
     first = false;
+  }
+  // the step eta leaves the launch (the retraction and the model decrease read it); r, delta, H delta die here
+#pragma unroll
+  for (int k = 0; k < MT; ++k) {
+    if (own[k]) {
+      const size_t off = (size_t)pose[k] * T + L.c * R;
+#pragma unroll
+      for (int a = 0; a < R; ++a) eta[off + a] = Es[k][lp][L.c * R + a];
+    }
   }
   if (rank == 0 && threadIdx.x == 0) {
     if (alive) {

@@ -47,7 +47,11 @@ for name in (sys.argv[1:] or ["sphere", "slab", "grid100k"]):
             ts.append(time.perf_counter() - t0)
         print("%-9s setup mfma=%s: %s ms  %s" % (name, mf, ["%.2f" % (1e3 * t) for t in ts], info), flush=True)
     for pc in ("multilevel", "jacobi", "jacobi+persistent"):
-        prob.setPersistent(pc.endswith("persistent"))
+        try:
+            prob.setPersistent(pc.endswith("persistent"))
+        except dpgo_amd.DpgoError as exc:
+            print("%-9s %-17s not available: %s" % (name, pc, exc), flush=True)
+            continue
         opt = dpgo_amd.QuadraticOptimizer(prob, dpgo_amd.ROptParameters(precond=pc.split("+")[0]))
         Xd = torch.tensor(X0, device="cuda", dtype=torch.float64)
         rows, tot, ms = [], 0, 0.0
