@@ -6,7 +6,7 @@
 One "step" = one RBCD iteration from a fixed, settled iterate (identical full work every step; see main()):
 every agent runs QuadraticOptimizer::optimize once (RTR, 3 outer
 iterations x <=50 tCG, Delta0 = 100, tol 1e-2: the reference defaults, include/DPGO/DPGO_types.h:53-61)
-on its block, with the default (multilevel) preconditioner.  N = 1: a single agent owns the whole graph.
+on its block, with the library's default preconditioner selection ("auto").  N = 1: a single agent owns the whole graph.
 N > 1: the graph is cut into N contiguous blocks (examples/MultiRobotExample.cpp:71-88), one agent per
 GPU / process; agents of one colour update in parallel, then the other colour (two-colour RBCD),
 with the public-pose exchange over RCCL point-to-point.  Total work is fixed as N grows ("strong").
@@ -44,8 +44,9 @@ def parse_args():
                     help="untimed RBCD iterations from the initial guess before the benchmark state is frozen")
     ap.add_argument("--workload", default="grid100k")
     ap.add_argument("--rank", type=int, default=5, help="relaxation rank r")
-    ap.add_argument("--precond", default="multilevel", choices=["jacobi", "multilevel"],
-                    help="tCG preconditioner: the multilevel cycle (library default) or block-Jacobi")
+    ap.add_argument("--precond", default="auto", choices=["auto", "jacobi", "multilevel"],
+                    help="tCG preconditioner: auto (library default: multilevel when the tCG budget binds, block-Jacobi "
+                         "while it does not), or one of the two all the time")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the sphere2500 side measurement (`also` field)")
     ap.add_argument("--cpu-budget-s", type=float, default=25.0)
@@ -277,13 +278,17 @@ def time_to_tolerance(workload, r, precond, tol=1e-2, max_calls=12):
     meas, n, X0, desc = make_workload(workload, r)
     ranges, graphs = build_pose_graphs(meas, n, 1, r)
     ag = DeviceAgent(graphs, ExchangePlan(graphs), 0, X0, dpgo_amd.ROptParameters(precond=precond))
-    ag.update()  # untimed: builds the preconditioner (as the reference, inside the first solve) and warms up
+    ag.update()  # untimed warm-up
+    if precond != "jacobi":
+        ag.problem.setupMultilevel()  # the hierarchy is a one-time cost per Q (the reference factors inside its first solve)
+    ag.problem.autoState(False)       # "auto" starts where a fresh handle starts
     ag.X.copy_(torch.tensor(X0, device=ag.X.device))
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    products, calls, gn = 0, 0, None
+    products, calls, gn, used = 0, 0, None, []
     for _ in range(max_calls):
         res = ag.update()
+        used.append(res.precond_used)
         products += res.tcg_iterations
         calls += 1
         gn = res.gradNormOpt
@@ -292,7 +297,7 @@ def time_to_tolerance(workload, r, precond, tol=1e-2, max_calls=12):
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
     return dict(products=products, rbcd_iterations=calls, ms=1e3 * el, gradnorm=gn, reached=bool(gn < tol),
-                us_per_product=1e6 * el / max(products, 1))
+                us_per_product=1e6 * el / max(products, 1), preconditioners=used)
 
 
 def main():
@@ -410,9 +415,11 @@ def main():
     t_exchange[0] = 0.0
     t0 = time.perf_counter()
     tcg_total = 0
+    used_precond = set()
     for _ in range(args.steps):
         step()
         tcg_total += sum(a.last_result.tcg_iterations for a in agents.values() if a.last_result)
+        used_precond |= {a.last_result.precond_used for a in agents.values() if a.last_result}
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -469,8 +476,8 @@ def main():
     kernels = [dict(kernel="k_tcg_update (eta, r updates, pre-smoothing / block-Jacobi, <r,r>)",
                     bytes_per_launch=8 * vec + 8 * b_ * b_ * n_local, avg_launch_us=ms_it[0] * 1e3)]
     ml_info = None
-    if args.precond == "multilevel":
-        ml_info = agent.problem.multilevelInfo()
+    if args.precond != "jacobi":
+        ml_info = agent.problem.setupMultilevel()  # (auto may not have built it yet)
         qb = nnzb_local * (8 * b_ * b_ + 4) + 4 * (n_local + 1)
         pbb = 8 * b_ * b_ * n_local
         Nc = ml_info["sizes"][-1] * b_
@@ -537,14 +544,14 @@ def main():
         # sphere2500 (BASELINE configs[1]); then the fixed-work step rate of sphere2500
         to_tol = {}
         for wl in ([args.workload] + (["sphere2500"] if args.workload == "grid100k" else [])):
-            for pc in ("multilevel", "jacobi"):
+            for pc in ("auto", "multilevel", "jacobi"):
                 try:  # a side measurement must never cost the main line
                     to_tol["%s/%s" % (wl, pc)] = time_to_tolerance(wl, r, pc)
                 except Exception as exc:  # noqa: BLE001
                     to_tol["%s/%s" % (wl, pc)] = {"error": repr(exc)}
         if args.workload == "grid100k":
             also = {}
-            for key, pc in (("sphere2500", "multilevel"), ("sphere2500_jacobi", "jacobi")):
+            for key, pc in (("sphere2500", "auto"), ("sphere2500_multilevel", "multilevel"), ("sphere2500_jacobi", "jacobi")):
                 try:
                     also[key] = secondary_single_agent("sphere2500", r, pc, args.steps, args.warmup, args.settle)
                 except Exception as exc:  # noqa: BLE001
@@ -571,8 +578,11 @@ def main():
             "dtype": "f64",
             "data": "synthetic" if args.workload.startswith("grid") else "g2o dataset shipped in data/",
             "config": {"workload": desc, "agents": num_agents, "agents_per_gpu": apg, "r": r, "d": d,
-                       "local_solver": "RTR 3x<=50 tCG, Delta0=100, tol=1e-2 (reference defaults), %s precond" % (
-                           "block-Jacobi" if args.precond == "jacobi" else "multilevel (library default)"),
+                       "local_solver": "RTR 3x<=50 tCG, Delta0=100, tol=1e-2 (reference defaults), precond = %s" % (
+                           {"jacobi": "block-Jacobi", "multilevel": "multilevel",
+                            "auto": "auto (library default: multilevel when the tCG budget binds, else block-Jacobi)"}[
+                               args.precond]),
+                       "precond_used_in_timed_steps": sorted(used_precond),
                        "schedule": "single agent" if num_agents == 1 else
                        "%d-colour parallel RBCD; 1 step = 1 sweep (every agent updates once); public-pose "
                        "exchange over %s" % (plan.num_colours, "device copies" if world == 1 else

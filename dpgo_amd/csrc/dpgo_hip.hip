@@ -130,6 +130,7 @@ struct dpgo_problem_s {
   double* ml_dense = nullptr;  // inverse of the coarsest operator, row-major, leading dimension ml_lda
   int ml_lda = 0;
   double *ml_W = nullptr, *ml_Rx = nullptr;  // Gauss-Jordan panels (setup only)
+  bool auto_ml = false;  // DPGO_PRECOND_AUTO: the multilevel cycle is currently selected
   // persistent single-XCD tCG kernel (small blocks, block-Jacobi / no preconditioner)
   bool persist = false;
   int persist_wgs = 0;  // wanted participants (workgroups on one XCD)
@@ -808,6 +809,11 @@ int run_optimize(dpgo_problem_s* p, const dpgo_ropt_params* prm, dpgo_ropt_resul
   std::memset(res, 0, sizeof(*res));
   res->tCGStatus = DPGO_TCG_MAXITER;
   if (p->hctrl) std::memset(p->hctrl, 0, sizeof(PersistCtrl));
+  dpgo_ropt_params resolved = *prm;  // DPGO_PRECOND_AUTO -> what this handle currently runs
+  if (prm->precond == DPGO_PRECOND_AUTO)
+    resolved.precond = (p->auto_ml && prm->method == DPGO_METHOD_RTR) ? DPGO_PRECOND_MULTILEVEL : DPGO_PRECOND_BLOCK_JACOBI;
+  const bool is_auto = prm->precond == DPGO_PRECOND_AUTO;
+  prm = &resolved;
   const double* dinv = nullptr;
   if (prm->precond == DPGO_PRECOND_BLOCK_JACOBI) {
     CHK(build_dinv(p, prm->precond_shift));
@@ -891,6 +897,12 @@ int run_optimize(dpgo_problem_s* p, const dpgo_ropt_params* prm, dpgo_ropt_resul
     return fail(DPGO_ERR_INVALID, "unknown method");
   }
   res->tcg_iterations = n_hess_total;
+  res->precond_used = prm->precond;
+  if (is_auto && prm->method == DPGO_METHOD_RTR) {  // hysteresis on how much of the tCG budget the solve used
+    const int budget = std::max(1, prm->RTR_iterations) * std::max(1, prm->RTR_tCG_iterations);
+    if (!p->auto_ml && 2 * n_hess_total >= budget) p->auto_ml = true;
+    else if (p->auto_ml && 10 * n_hess_total <= budget) p->auto_ml = false;
+  }
   res->spmm_count = cnt.spmm + n_hess_total;
   res->success = 1;  // :44 (set unconditionally after a solve)
   res->elapsedMs = 1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
@@ -1059,7 +1071,7 @@ void dpgo_ropt_params_default(dpgo_ropt_params* p) {
   p->RTR_iterations = 3;
   p->RTR_tCG_iterations = 50;
   p->RTR_initial_radius = 100.0;
-  p->precond = DPGO_PRECOND_MULTILEVEL;
+  p->precond = DPGO_PRECOND_AUTO;
   p->precond_shift = 1e-1;
   p->accept_tiny_decrease = 1;
   p->tcg_poll_interval = 0;
@@ -1533,6 +1545,13 @@ int dpgo_problem_multilevel_get(dpgo_problem_t p, int level, int what, void* out
   return DPGO_OK;
 }
 
+int dpgo_problem_auto_state(dpgo_problem_t p, int* use_multilevel) {
+  if (!p || !use_multilevel) return fail(DPGO_ERR_INVALID, "null pointer");
+  if (*use_multilevel >= 0) p->auto_ml = *use_multilevel != 0;
+  *use_multilevel = p->auto_ml ? 1 : 0;
+  return DPGO_OK;
+}
+
 int dpgo_dense_spd_inverse(int N, const double* A_host, double* Ainv_host, int device, int use_mfma) {
   if (N <= 0 || N > 16384 || !A_host || !Ainv_host) return fail(DPGO_ERR_INVALID, "bad arguments");
   int cnt = 0;
@@ -1672,6 +1691,7 @@ int dpgo_problem_precondition(dpgo_problem_t p, int precond, double shift, const
   CHK(eval_common(p, X));
   CHK(h2d(p, p->eta, V));
   const double* dinv = nullptr;
+  if (precond == DPGO_PRECOND_AUTO) precond = p->auto_ml ? DPGO_PRECOND_MULTILEVEL : DPGO_PRECOND_BLOCK_JACOBI;
   if (precond == DPGO_PRECOND_BLOCK_JACOBI) {
     CHK(build_dinv(p, shift));
     dinv = p->dinv;

@@ -69,12 +69,17 @@ __global__ __launch_bounds__(kBlock) void k_ml_restrict(BsrDev A, const double* 
     const bool okp = (L.g < GEO::G) && (i < n);
     const bool ok = okp && (L.s == 0);
     const size_t off = (size_t)i * GEO::T + L.c * R;
-    double h[R];
-    spmm_col<D, R, SPLIT>(A.rowptr, A.colidx, A.vals, x1, i, L.s, L.c, okp, h);
+    // the own-row loads are issued first: they overlap the gather's index -> tile latency chain
+    double h[R], xr[R], rr[R], pcol[GEO::B];
     if (ok) {
-      double xr[R], rr[R];
       load_col<R>(x1 + off, xr);
       load_col<R>(r + off, rr);
+      const double* __restrict__ pb = Pb + (size_t)i * GEO::BB;
+#pragma unroll
+      for (int cc = 0; cc < GEO::B; ++cc) pcol[cc] = pb[cc * GEO::B + L.c];
+    }
+    spmm_col<D, R, SPLIT>(A.rowptr, A.colidx, A.vals, x1, i, L.s, L.c, okp, h);
+    if (ok) {
 #pragma unroll
       for (int a = 0; a < R; ++a) h[a] = rr[a] - h[a] - shift * xr[a];
       store_col<R>(&res_s[L.wave][L.g][L.c * R], h);
@@ -85,10 +90,9 @@ __global__ __launch_bounds__(kBlock) void k_ml_restrict(BsrDev A, const double* 
 #pragma unroll
       for (int a = 0; a < R; ++a) t[a] = 0.0;
       if (ok) {  // row c of P_i^T res_i = sum_c' P_i[c'][c] res_i[c'][:]
-        const double* __restrict__ pb = Pb + (size_t)i * GEO::BB;
 #pragma unroll
         for (int cc = 0; cc < GEO::B; ++cc) {
-          const double pv = pb[cc * GEO::B + L.c];
+          const double pv = pcol[cc];
 #pragma unroll
           for (int a = 0; a < R; ++a) t[a] = fma(pv, res_s[L.wave][L.g][cc * R + a], t[a]);
         }
@@ -308,13 +312,16 @@ __global__ __launch_bounds__(kBlock) void k_ml_post(BsrDev Q, const double* __re
     double* ys = ok ? &sm[L.wave][0][L.g][0] : nullptr;
     double* vs = ok ? &sm[L.wave][1][L.g][0] : nullptr;
     double* zs = ok ? &sm[L.wave][2][L.g][0] : nullptr;
-    double h[R], xr[R], rr[R], z[R];
-    spmm_col<D, R, SPLIT>(Q.rowptr, Q.colidx, Q.vals, xv, i, L.s, L.c, okp, h);
-    if (ok) {
-      double x[R];
+    double h[R], xr[R], rr[R], z[R], x[R], drow[GEO::B];
+    if (ok) {  // own-row loads first: they overlap the gather's index -> tile latency chain
       load_col<R>(X + off, x);
       load_col<R>(xv + off, xr);
       load_col<R>(r + off, rr);
+#pragma unroll
+      for (int k = 0; k < GEO::B; ++k) drow[k] = dinv[(size_t)i * GEO::BB + L.c * GEO::B + k];
+    }
+    spmm_col<D, R, SPLIT>(Q.rowptr, Q.colidx, Q.vals, xv, i, L.s, L.c, okp, h);
+    if (ok) {
 #pragma unroll
       for (int a = 0; a < R; ++a) {
         h[a] = rr[a] - h[a] - shift * xr[a];  // r - A x
@@ -325,7 +332,7 @@ __global__ __launch_bounds__(kBlock) void k_ml_post(BsrDev Q, const double* __re
     }
     wave_sync();
     if (ok) {
-      jacobi_col<D, R>(vs, dinv + (size_t)i * GEO::BB + L.c * GEO::B, z);
+      jacobi_col<D, R>(vs, drow, z);
 #pragma unroll
       for (int a = 0; a < R; ++a) z[a] = fma(omega, z[a], xr[a]);
       store_col<R>(zs + L.c * R, z);

@@ -1,4 +1,5 @@
-// kernels/tcg.h -- the two kernels of the tCG loop (fused Hessian step and residual / iterate update), generic and span variants.
+// kernels/tcg.h -- the two kernels of the tCG loop (fused Hessian step and residual / iterate update): shared scalar prologues,
+// the generic-layout kernels (odd tile size) and the span kernels (even tile size: every 3-D case).
 // Part of kernels.h (included inside namespace dpgo, in this order: common.h, problem.h, tcg.h, persist.h, multilevel.h, dense.h, manifold.h, rtr.h, agent.h, init.h).
 #pragma once
 
@@ -13,226 +14,6 @@
 //        direction update ride in the SpMM epilogue instead of costing a second gather or a separate
 //        kernel: 3 -> 2 launches per tCG iteration), and the <delta, H delta> partial.
 // The oracle has the same option (hess_recurrence) for trajectory-level parity tests.
-template <int D, int R, int SPLIT>
-__global__ __launch_bounds__(kBlock, DPGO_LB_HESS) void k_tcg_hess(BsrDev Q, const double* __restrict__ X,
-                                                     const double* __restrict__ S, const double* __restrict__ z,
-                                                     double* __restrict__ delta, double* __restrict__ Hd,
-                                                     const double* __restrict__ pin, int nb_in,
-                                                     double* __restrict__ pout, const DevState* __restrict__ sin,
-                                                     DevState* __restrict__ sout, int first, int n,
-                                                     unsigned long long* hflag, unsigned gen) {
-  using GEO = Geo<D, R, SPLIT>;
-  __shared__ __attribute__((aligned(16))) double sm[kWaves][4][GEO::G][GEO::T];
-  __shared__ double red[kWaves * kNP];
-  DevState st;
-  load_state(st, sin);
-  if (st.rtr_stop || st.tcg_done) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-      store_state(sout, st);
-      publish_progress(hflag, gen, st);
-    }
-    return;
-  }
-  double pr[2];
-  load_partials<2>(pin, nb_in, pr, red);
-  const double r_r = pr[0], z_r_new = pr[1];
-  double beta = 0.0;
-  bool go = true;
-  if (first) {
-    st.norm_r0 = sqrt(r_r);
-    st.z_r = z_r_new;
-    st.d_Pd = z_r_new;
-    st.e_Pd = 0.0;
-    if (st.max_inner <= 0) {
-      st.tcg_done = 1;
-      go = false;
-    }
-  } else {
-    const double norm_r = sqrt(r_r);
-    const double pw = (st.theta == 1.0) ? st.norm_r0 : pow(st.norm_r0, st.theta);  // theta = 1 (reference default)
-    if (st.tcg_j >= st.min_inner && norm_r <= st.norm_r0 * (pw < st.kappa ? pw : st.kappa)) {
-      st.tcg_status = (st.kappa < pw) ? TCG_LCON : TCG_SCON;
-      st.tcg_done = 1;
-      go = false;
-    } else {
-      beta = z_r_new / st.z_r;
-      st.e_Pd = beta * (st.e_Pd + st.alpha * st.d_Pd);
-      st.d_Pd = z_r_new + beta * beta * st.d_Pd;
-      st.z_r = z_r_new;
-      st.tcg_j += 1;
-      if (st.tcg_j >= st.max_inner) {
-        st.tcg_done = 1;
-        st.tcg_status = TCG_MAXITER;
-        go = false;
-      }
-    }
-  }
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
-    store_state(sout, st);
-    publish_progress(hflag, gen, st);
-  }
-  if (!go) return;
-
-  const LaneId L = lane_id<D, SPLIT>();
-  const int ntiles = (n + GEO::P - 1) / GEO::P;
-  double part[1] = {0.0};
-  const TileIter ti_ = tile_iter(ntiles);
-  if constexpr (Span<D, R, SPLIT>::kOk) {
-    // ---- span path (T even): own-tile vectors move as 16-byte pieces through the LDS tiles; the direction /
-    // H-direction recurrences run in span layout
-    using SPN = Span<D, R, SPLIT>;
-    const int lane = threadIdx.x & 63;
-    double* ys = &sm[L.wave][0][0][0];
-    double* vs = &sm[L.wave][1][0][0];
-    double* hs = &sm[L.wave][2][0][0];
-    double* os = &sm[L.wave][3][0][0];
-    for (int tile = ti_.first; tile < ti_.last; tile += ti_.step) {
-      const int p0 = tile * GEO::P + L.wave * GEO::G;
-      const int npose = (n - p0) < GEO::G ? (n - p0) : GEO::G;
-      const int valid = npose > 0 ? npose * GEO::T : 0;
-      const size_t base = (size_t)p0 * GEO::T;
-      const int i = p0 + L.g;
-      const bool okp = (L.g < GEO::G) && (i < n);
-      const bool ok = okp && (L.s == 0);
-      const dbl2* X2 = reinterpret_cast<const dbl2*>(X + base);
-      const dbl2* z2 = reinterpret_cast<const dbl2*>(z + base);
-      dbl2* d2 = reinterpret_cast<dbl2*>(delta + base);
-      dbl2* h2 = reinterpret_cast<dbl2*>(Hd + base);
-      // issue every own-tile load before the gather: they overlap its index -> tile latency chain
-      dbl2 dv[SPN::NIT], hv[SPN::NIT];
-      double srow[D];
-#pragma unroll
-      for (int it = 0; it < SPN::NIT; ++it) {
-        const int pc = lane + 64 * it;
-        if (2 * pc < valid) {
-          reinterpret_cast<dbl2*>(ys)[pc] = X2[pc];
-          reinterpret_cast<dbl2*>(vs)[pc] = z2[pc];
-          if (!first) {
-            dv[it] = d2[pc];
-            hv[it] = h2[pc];
-          }
-        }
-      }
-      if (ok && L.c < D) {
-#pragma unroll
-        for (int a = 0; a < D; ++a) srow[a] = S[(size_t)i * D * D + L.c * D + a];
-      }
-      double h[R];
-      spmm_col<D, R, SPLIT>(Q.rowptr, Q.colidx, Q.vals, z, i, L.s, L.c, okp, h);
-      wave_sync();
-      if (ok) {
-        if (L.c < D) {
-          const double* vt = vs + L.g * GEO::T;
-#pragma unroll
-          for (int a = 0; a < D; ++a) {
-#pragma unroll
-            for (int k = 0; k < R; ++k) h[k] = fma(-vt[a * R + k], srow[a], h[k]);
-          }
-        }
-        store_col<R>(hs + L.g * GEO::T + L.c * R, h);
-      }
-      wave_sync();
-      if (ok) {
-        double hz[R], sdummy[D];
-        proj_col<D, R>(ys + L.g * GEO::T, hs + L.g * GEO::T, L.c, h, hz, sdummy);
-        store_col<R>(os + L.g * GEO::T + L.c * R, hz);
-      }
-      wave_sync();
-#pragma unroll
-      for (int it = 0; it < SPN::NIT; ++it) {
-        const int pc = lane + 64 * it;
-        if (2 * pc < valid) {
-          const dbl2 zv = reinterpret_cast<const dbl2*>(vs)[pc];
-          const dbl2 hzv = reinterpret_cast<const dbl2*>(os)[pc];
-          dbl2 dn, hn;
-          if (first) {
-            dn.x = -zv.x;
-            dn.y = -zv.y;
-            hn.x = -hzv.x;
-            hn.y = -hzv.y;
-          } else {
-            dn.x = fma(beta, dv[it].x, -zv.x);
-            dn.y = fma(beta, dv[it].y, -zv.y);
-            hn.x = fma(beta, hv[it].x, -hzv.x);
-            hn.y = fma(beta, hv[it].y, -hzv.y);
-          }
-          d2[pc] = dn;
-          h2[pc] = hn;
-          part[0] = fma(dn.x, hn.x, part[0]);
-          part[0] = fma(dn.y, hn.y, part[0]);
-        }
-      }
-      wave_sync();
-    }
-  } else {
-    for (int tile = ti_.first; tile < ti_.last; tile += ti_.step) {
-      const int i = tile * GEO::P + L.wave * GEO::G + L.g;
-      const bool okp = (L.g < GEO::G) && (i < n);
-      const bool ok = okp && (L.s == 0);
-      double h[R], zc[R], x[R];
-      const size_t off = (size_t)i * GEO::T + L.c * R;
-      double* ys = ok ? &sm[L.wave][0][L.g][0] : nullptr;
-      double* vs = ok ? &sm[L.wave][1][L.g][0] : nullptr;
-      double* hs = ok ? &sm[L.wave][2][L.g][0] : nullptr;
-      // issue the epilogue's loads first: they overlap the gather's index -> tile latency chain
-      double srow[D], dl[R], hd[R];
-      if (ok) {
-        load_col<R>(X + off, x);
-        load_col<R>(z + off, zc);
-        if (L.c < D) {
-  #pragma unroll
-          for (int a = 0; a < D; ++a) srow[a] = S[(size_t)i * D * D + L.c * D + a];
-        }
-        if (!first) {
-          load_col<R>(delta + off, dl);
-          load_col<R>(Hd + off, hd);
-        }
-      }
-      spmm_col<D, R, SPLIT>(Q.rowptr, Q.colidx, Q.vals, z, i, L.s, L.c, okp, h);
-      if (ok) {
-        store_col<R>(ys + L.c * R, x);
-        store_col<R>(vs + L.c * R, zc);
-      }
-      wave_sync();
-      if (ok) {
-        if (L.c < D) {
-  #pragma unroll
-          for (int a = 0; a < D; ++a) {
-  #pragma unroll
-            for (int k = 0; k < R; ++k) h[k] = fma(-vs[a * R + k], srow[a], h[k]);
-          }
-        }
-        store_col<R>(hs + L.c * R, h);
-      }
-      wave_sync();
-      if (ok) {
-        double hz[R], s[D];
-        proj_col<D, R>(ys, hs, L.c, h, hz, s);
-        if (first) {
-  #pragma unroll
-          for (int a = 0; a < R; ++a) {
-            dl[a] = -zc[a];
-            hd[a] = -hz[a];
-          }
-        } else {
-  #pragma unroll
-          for (int a = 0; a < R; ++a) {
-            dl[a] = fma(beta, dl[a], -zc[a]);
-            hd[a] = fma(beta, hd[a], -hz[a]);
-          }
-        }
-  #pragma unroll
-        for (int a = 0; a < R; ++a) part[0] = fma(dl[a], hd[a], part[0]);
-        store_col<R>(delta + off, dl);
-        store_col<R>(Hd + off, hd);
-      }
-      wave_sync();
-    }
-  }
-  store_partials<1>(part, pout, red);
-}
-
-
 // ---------------------------------------------------------------- tCG scalar prologues (shared)
 // Direction-update scalars (ROPTLIB tCG_TR): returns false when this launch has nothing left to do.
 __device__ __forceinline__ bool tcg_hess_prologue(DevState& st, const double* __restrict__ pin, int nb_in, int first,
@@ -308,6 +89,105 @@ __device__ __forceinline__ int tcg_update_prologue(DevState& st, const double* _
   }
   st.e_Pe = e_Pe_new;
   return 0;
+}
+
+template <int D, int R, int SPLIT>
+__global__ __launch_bounds__(kBlock, DPGO_LB_HESS) void k_tcg_hess(BsrDev Q, const double* __restrict__ X,
+                                                     const double* __restrict__ S, const double* __restrict__ z,
+                                                     double* __restrict__ delta, double* __restrict__ Hd,
+                                                     const double* __restrict__ pin, int nb_in,
+                                                     double* __restrict__ pout, const DevState* __restrict__ sin,
+                                                     DevState* __restrict__ sout, int first, int n,
+                                                     unsigned long long* hflag, unsigned gen) {
+  // generic layout (odd tile size: the 2-D cases with odd r); even tile sizes run k_tcg_hess_span
+  using GEO = Geo<D, R, SPLIT>;
+  __shared__ __attribute__((aligned(16))) double sm[kWaves][3][GEO::G][GEO::T];
+  __shared__ double red[kWaves * kNP];
+  DevState st;
+  load_state(st, sin);
+  if (st.rtr_stop || st.tcg_done) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+      store_state(sout, st);
+      publish_progress(hflag, gen, st);
+    }
+    return;
+  }
+  double beta;
+  const bool go = tcg_hess_prologue(st, pin, nb_in, first, red, beta);
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    store_state(sout, st);
+    publish_progress(hflag, gen, st);
+  }
+  if (!go) return;
+
+  const LaneId L = lane_id<D, SPLIT>();
+  const int ntiles = (n + GEO::P - 1) / GEO::P;
+  double part[1] = {0.0};
+  const TileIter ti_ = tile_iter(ntiles);
+  for (int tile = ti_.first; tile < ti_.last; tile += ti_.step) {
+    const int i = tile * GEO::P + L.wave * GEO::G + L.g;
+    const bool okp = (L.g < GEO::G) && (i < n);
+    const bool ok = okp && (L.s == 0);
+    double h[R], zc[R], x[R];
+    const size_t off = (size_t)i * GEO::T + L.c * R;
+    double* ys = ok ? &sm[L.wave][0][L.g][0] : nullptr;
+    double* vs = ok ? &sm[L.wave][1][L.g][0] : nullptr;
+    double* hs = ok ? &sm[L.wave][2][L.g][0] : nullptr;
+    // issue the epilogue's loads first: they overlap the gather's index -> tile latency chain
+    double srow[D], dl[R], hd[R];
+    if (ok) {
+      load_col<R>(X + off, x);
+      load_col<R>(z + off, zc);
+      if (L.c < D) {
+#pragma unroll
+        for (int a = 0; a < D; ++a) srow[a] = S[(size_t)i * D * D + L.c * D + a];
+      }
+      if (!first) {
+        load_col<R>(delta + off, dl);
+        load_col<R>(Hd + off, hd);
+      }
+    }
+    spmm_col<D, R, SPLIT>(Q.rowptr, Q.colidx, Q.vals, z, i, L.s, L.c, okp, h);
+    if (ok) {
+      store_col<R>(ys + L.c * R, x);
+      store_col<R>(vs + L.c * R, zc);
+    }
+    wave_sync();
+    if (ok) {
+      if (L.c < D) {
+#pragma unroll
+        for (int a = 0; a < D; ++a) {
+#pragma unroll
+          for (int k = 0; k < R; ++k) h[k] = fma(-vs[a * R + k], srow[a], h[k]);
+        }
+      }
+      store_col<R>(hs + L.c * R, h);
+    }
+    wave_sync();
+    if (ok) {
+      double hz[R], s[D];
+      proj_col<D, R>(ys, hs, L.c, h, hz, s);
+      if (first) {
+#pragma unroll
+        for (int a = 0; a < R; ++a) {
+          dl[a] = -zc[a];
+          hd[a] = -hz[a];
+        }
+      } else {
+#pragma unroll
+        for (int a = 0; a < R; ++a) {
+          dl[a] = fma(beta, dl[a], -zc[a]);
+          hd[a] = fma(beta, hd[a], -hz[a]);
+        }
+      }
+#pragma unroll
+      for (int a = 0; a < R; ++a) part[0] = fma(dl[a], hd[a], part[0]);
+      store_col<R>(delta + off, dl);
+      store_col<R>(Hd + off, hd);
+    }
+    wave_sync();
+  }
+  store_partials<1>(part, pout, red);
 }
 
 // ================================================================ span kernels (pose tile size even: all 3-D cases)
@@ -667,8 +547,9 @@ __global__ __launch_bounds__(kBlock, DPGO_LB_UPDATE) void k_tcg_update(const dou
                                                        double* __restrict__ pout, const DevState* __restrict__ sin,
                                                        DevState* __restrict__ sout, int first, int n,
                                                        unsigned long long* hflag, unsigned gen, double ml_omega) {
+  // generic layout (odd tile size); even tile sizes run k_tcg_update_span
   using GEO = Geo<D, R>;
-  __shared__ __attribute__((aligned(16))) double sm[kWaves][4][GEO::G][GEO::T];
+  __shared__ __attribute__((aligned(16))) double sm[kWaves][3][GEO::G][GEO::T];
   __shared__ double red[kWaves * kNP];
   DevState st;
   load_state(st, sin);
@@ -679,33 +560,8 @@ __global__ __launch_bounds__(kBlock, DPGO_LB_UPDATE) void k_tcg_update(const dou
     }
     return;
   }
-  int mode = 0;  // 0: normal step, 1: boundary step (eta += tau*delta, stop), 2: init
-  double alpha = 0.0, tau = 0.0;
-  if (first) {
-    mode = 2;
-    st.tcg_done = 0;
-    st.tcg_j = 0;
-    st.tcg_status = TCG_MAXITER;
-    st.e_Pe = 0.0;
-    st.e_Pd = 0.0;
-  } else {
-    double dh[1];
-    load_partials<1>(pin, nb_in, dh, red);
-    const double d_Hd = dh[0];
-    alpha = st.z_r / d_Hd;
-    const double e_Pe_new = st.e_Pe + 2.0 * alpha * st.e_Pd + alpha * alpha * st.d_Pd;
-    st.n_hess += 1;
-    st.alpha = alpha;
-    const double D2 = st.Delta * st.Delta;
-    if (d_Hd <= 0.0 || e_Pe_new >= D2) {
-      tau = (-st.e_Pd + sqrt(st.e_Pd * st.e_Pd + st.d_Pd * (D2 - st.e_Pe))) / st.d_Pd;
-      mode = 1;
-      st.tcg_status = (d_Hd < 0.0) ? TCG_NEGCURV : TCG_EXCREGION;
-      st.tcg_done = 1;
-    } else {
-      st.e_Pe = e_Pe_new;
-    }
-  }
+  double alpha, tau;
+  const int mode = tcg_update_prologue(st, pin, nb_in, first, red, alpha, tau);  // 0: step, 1: boundary step, 2: init
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     store_state(sout, st);
     publish_progress(hflag, gen, st);
@@ -715,186 +571,81 @@ __global__ __launch_bounds__(kBlock, DPGO_LB_UPDATE) void k_tcg_update(const dou
   const int ntiles = (n + GEO::P - 1) / GEO::P;
   double part[2] = {0.0, 0.0};
   const TileIter ti_ = tile_iter(ntiles);
-  if constexpr (Span<D, R, 1>::kOk) {
-    // ---- span path (T even): vectors move as 16-byte pieces; r, X staged straight into the LDS tiles
-    using SPN = Span<D, R, 1>;
-    const int lane = threadIdx.x & 63;
-    double* ys = &sm[L.wave][0][0][0];
-    double* rs = &sm[L.wave][1][0][0];
-    double* zs = &sm[L.wave][2][0][0];
-    double* os = &sm[L.wave][3][0][0];
-    for (int tile = ti_.first; tile < ti_.last; tile += ti_.step) {
-      const int p0 = tile * GEO::P + L.wave * GEO::G;
-      const int npose = (n - p0) < GEO::G ? (n - p0) : GEO::G;
-      const int valid = npose > 0 ? npose * GEO::T : 0;  // doubles of this wave's span inside the array
-      const size_t base = (size_t)p0 * GEO::T;
-      const int i = p0 + L.g;
-      const bool ok = (L.g < GEO::G) && (i < n);
-      dbl2* eta2 = reinterpret_cast<dbl2*>(eta + base);
-      const dbl2* dl2 = reinterpret_cast<const dbl2*>(delta + base);
-      if (mode == 1) {  // workgroup-uniform: eta += tau * delta, then tCG stops
+  for (int tile = ti_.first; tile < ti_.last; tile += ti_.step) {
+    const int i = tile * GEO::P + L.wave * GEO::G + L.g;
+    const bool ok = (L.g < GEO::G) && (i < n);
+    const size_t off = (size_t)i * GEO::T + L.c * R;
+    if (mode == 1) {  // workgroup-uniform
+      if (ok) {
+        double e[R], dl[R];
+        load_col<R>(eta + off, e);
+        load_col<R>(delta + off, dl);
 #pragma unroll
-        for (int it = 0; it < SPN::NIT; ++it) {
-          const int pc = lane + 64 * it;
-          if (2 * pc < valid) {
-            dbl2 e = eta2[pc];
-            const dbl2 dv = dl2[pc];
-            e.x = fma(tau, dv.x, e.x);
-            e.y = fma(tau, dv.y, e.y);
-            eta2[pc] = e;
-          }
-        }
-        continue;
+        for (int a = 0; a < R; ++a) e[a] = fma(tau, dl[a], e[a]);
+        store_col<R>(eta + off, e);
       }
-      double drow[GEO::B];
-      if (ok && dinv) {
+      continue;
+    }
+    double* ys = ok ? &sm[L.wave][0][L.g][0] : nullptr;
+    double* rs = ok ? &sm[L.wave][1][L.g][0] : nullptr;
+    double* zs = ok ? &sm[L.wave][2][L.g][0] : nullptr;
+    double rr[R], x[R], zz[R], drow[GEO::B];
+    if (ok) {
+      // all of this pose's loads are issued back to back (independent addresses)
+      load_col<R>(X + off, x);
+      if (dinv) {
 #pragma unroll
         for (int k = 0; k < GEO::B; ++k) drow[k] = dinv[(size_t)i * GEO::BB + L.c * GEO::B + k];
       }
-      const dbl2* X2 = reinterpret_cast<const dbl2*>(X + base);
-      const dbl2* g2 = reinterpret_cast<const dbl2*>(g + base);
-      const dbl2* hd2 = reinterpret_cast<const dbl2*>(Hd + base);
-      dbl2* r2 = reinterpret_cast<dbl2*>(r + base);
+      if (mode == 2) {
+        load_col<R>(g + off, rr);
+        double e[R];
 #pragma unroll
-      for (int it = 0; it < SPN::NIT; ++it) {
-        const int pc = lane + 64 * it;
-        if (2 * pc < valid) {
-          reinterpret_cast<dbl2*>(ys)[pc] = X2[pc];
-          dbl2 rv;
-          if (mode == 2) {
-            rv = g2[pc];
-            dbl2 zero;
-            zero.x = 0.0;
-            zero.y = 0.0;
-            eta2[pc] = zero;
-          } else {
-            dbl2 e = eta2[pc];
-            const dbl2 dv = dl2[pc], hv = hd2[pc];
-            rv = r2[pc];
-            e.x = fma(alpha, dv.x, e.x);
-            e.y = fma(alpha, dv.y, e.y);
-            rv.x = fma(alpha, hv.x, rv.x);
-            rv.y = fma(alpha, hv.y, rv.y);
-            eta2[pc] = e;
-          }
-          r2[pc] = rv;
-          reinterpret_cast<dbl2*>(rs)[pc] = rv;
-          part[0] = fma(rv.x, rv.x, part[0]);
-          part[0] = fma(rv.y, rv.y, part[0]);
+        for (int a = 0; a < R; ++a) e[a] = 0.0;
+        store_col<R>(eta + off, e);
+      } else {
+        double e[R], dl[R], hd[R];
+        load_col<R>(eta + off, e);
+        load_col<R>(delta + off, dl);
+        load_col<R>(Hd + off, hd);
+        load_col<R>(r + off, rr);
+#pragma unroll
+        for (int a = 0; a < R; ++a) {
+          e[a] = fma(alpha, dl[a], e[a]);
+          rr[a] = fma(alpha, hd[a], rr[a]);
         }
+        store_col<R>(eta + off, e);
       }
-      wave_sync();
-      double zz[R];
-      if (ok) {
-        const double* rt = rs + L.g * GEO::T;
-        if (dinv) {
-          jacobi_col<D, R>(rt, drow, zz);
-        } else {
+      store_col<R>(r + off, rr);
 #pragma unroll
-          for (int a = 0; a < R; ++a) zz[a] = rt[L.c * R + a];
-        }
-        store_col<R>(zs + L.g * GEO::T + L.c * R, zz);
-      }
-      wave_sync();
-      if (ok) {
-        double out[R], sdummy[D];
-        if (ml_omega > 0.0) {
-#pragma unroll
-          for (int a = 0; a < R; ++a) out[a] = ml_omega * zz[a];
-        } else {
-          proj_col<D, R>(ys + L.g * GEO::T, zs + L.g * GEO::T, L.c, zz, out, sdummy);
-        }
-        const double* rt = rs + L.g * GEO::T + L.c * R;
-#pragma unroll
-        for (int a = 0; a < R; ++a) part[1] = fma(out[a], rt[a], part[1]);
-        store_col<R>(os + L.g * GEO::T + L.c * R, out);
-      }
-      wave_sync();
-      dbl2* z2 = reinterpret_cast<dbl2*>(z + base);
-#pragma unroll
-      for (int it = 0; it < SPN::NIT; ++it) {
-        const int pc = lane + 64 * it;
-        if (2 * pc < valid) z2[pc] = reinterpret_cast<const dbl2*>(os)[pc];
-      }
-      wave_sync();
+      for (int a = 0; a < R; ++a) part[0] = fma(rr[a], rr[a], part[0]);
+      store_col<R>(ys + L.c * R, x);
+      store_col<R>(rs + L.c * R, rr);
     }
-  } else {
-    for (int tile = ti_.first; tile < ti_.last; tile += ti_.step) {
-      const int i = tile * GEO::P + L.wave * GEO::G + L.g;
-      const bool ok = (L.g < GEO::G) && (i < n);
-      const size_t off = (size_t)i * GEO::T + L.c * R;
-      if (mode == 1) {  // workgroup-uniform
-        if (ok) {
-          double e[R], dl[R];
-          load_col<R>(eta + off, e);
-          load_col<R>(delta + off, dl);
-  #pragma unroll
-          for (int a = 0; a < R; ++a) e[a] = fma(tau, dl[a], e[a]);
-          store_col<R>(eta + off, e);
-        }
-        continue;
+    wave_sync();
+    if (ok) {
+      if (dinv) {
+        jacobi_col<D, R>(rs, drow, zz);
+      } else {
+#pragma unroll
+        for (int a = 0; a < R; ++a) zz[a] = rr[a];
       }
-      double* ys = ok ? &sm[L.wave][0][L.g][0] : nullptr;
-      double* rs = ok ? &sm[L.wave][1][L.g][0] : nullptr;
-      double* zs = ok ? &sm[L.wave][2][L.g][0] : nullptr;
-      double rr[R], x[R], zz[R], drow[GEO::B];
-      if (ok) {
-        // all of this pose's loads are issued back to back (independent addresses)
-        load_col<R>(X + off, x);
-        if (dinv) {
-  #pragma unroll
-          for (int k = 0; k < GEO::B; ++k) drow[k] = dinv[(size_t)i * GEO::BB + L.c * GEO::B + k];
-        }
-        if (mode == 2) {
-          load_col<R>(g + off, rr);
-          double e[R];
-  #pragma unroll
-          for (int a = 0; a < R; ++a) e[a] = 0.0;
-          store_col<R>(eta + off, e);
-        } else {
-          double e[R], dl[R], hd[R];
-          load_col<R>(eta + off, e);
-          load_col<R>(delta + off, dl);
-          load_col<R>(Hd + off, hd);
-          load_col<R>(r + off, rr);
-  #pragma unroll
-          for (int a = 0; a < R; ++a) {
-            e[a] = fma(alpha, dl[a], e[a]);
-            rr[a] = fma(alpha, hd[a], rr[a]);
-          }
-          store_col<R>(eta + off, e);
-        }
-        store_col<R>(r + off, rr);
-  #pragma unroll
-        for (int a = 0; a < R; ++a) part[0] = fma(rr[a], rr[a], part[0]);
-        store_col<R>(ys + L.c * R, x);
-        store_col<R>(rs + L.c * R, rr);
-      }
-      wave_sync();
-      if (ok) {
-        if (dinv) {
-          jacobi_col<D, R>(rs, drow, zz);
-        } else {
-  #pragma unroll
-          for (int a = 0; a < R; ++a) zz[a] = rr[a];
-        }
-        store_col<R>(zs + L.c * R, zz);
-      }
-      wave_sync();
-      if (ok) {
-        double out[R], s[D];
-        if (ml_omega > 0.0) {
-  #pragma unroll
-          for (int a = 0; a < R; ++a) out[a] = ml_omega * zz[a];
-        } else {
-          proj_col<D, R>(ys, zs, L.c, zz, out, s);
-        }
-  #pragma unroll
-        for (int a = 0; a < R; ++a) part[1] = fma(out[a], rr[a], part[1]);
-        store_col<R>(z + off, out);
-      }
-      wave_sync();
+      store_col<R>(zs + L.c * R, zz);
     }
+    wave_sync();
+    if (ok) {
+      double out[R], s[D];
+      if (ml_omega > 0.0) {
+#pragma unroll
+        for (int a = 0; a < R; ++a) out[a] = ml_omega * zz[a];
+      } else {
+        proj_col<D, R>(ys, zs, L.c, zz, out, s);
+      }
+#pragma unroll
+      for (int a = 0; a < R; ++a) part[1] = fma(out[a], rr[a], part[1]);
+      store_col<R>(z + off, out);
+    }
+    wave_sync();
   }
   if (mode != 1) store_partials<2>(part, pout, red);
 }

@@ -17,7 +17,8 @@ LIB_PATH = os.environ.get("DPGO_LIB") or os.path.join(_HERE, "libdpgo_hip.so")  
 
 OK, ERR_INVALID, ERR_HIP, ERR_UNSUPPORTED, ERR_STATE = 0, 1, 2, 3, 4
 METHOD_RTR, METHOD_RGD = 0, 1
-PRECOND_NONE, PRECOND_BLOCK_JACOBI, PRECOND_MULTILEVEL = 0, 1, 2
+PRECOND_NONE, PRECOND_BLOCK_JACOBI, PRECOND_MULTILEVEL, PRECOND_AUTO = 0, 1, 2, 3
+PRECOND_NAMES = ["none", "jacobi", "multilevel", "auto"]
 ML_P_BLOCKS, ML_A_ROWPTR, ML_A_COLIDX, ML_A_VALUES, ML_DENSE_INVERSE = 0, 1, 2, 3, 4
 TCG_STATUS = ["NEGCURVTURE", "EXCREGION", "LCON", "SCON", "MAXITER"]
 
@@ -40,7 +41,8 @@ class RoptResultC(C.Structure):
     _fields_ = [("success", C.c_int), ("fInit", C.c_double), ("gradNormInit", C.c_double),
                 ("fOpt", C.c_double), ("gradNormOpt", C.c_double), ("elapsedMs", C.c_double),
                 ("tCGStatus", C.c_int), ("rtr_iterations", C.c_int), ("rtr_accepted", C.c_int),
-                ("tcg_iterations", C.c_int), ("spmm_count", C.c_int), ("latest_step_accepted", C.c_int)]
+                ("tcg_iterations", C.c_int), ("spmm_count", C.c_int), ("latest_step_accepted", C.c_int),
+                ("precond_used", C.c_int)]
 
 
 _P = C.c_void_p
@@ -76,6 +78,7 @@ SIGNATURES = {
     "dpgo_problem_multilevel_info": ([_P, C.POINTER(_I), _P, _P, _P], _I),
     "dpgo_problem_multilevel_get": ([_P, _I, _I, _P], _I),
     "dpgo_dense_spd_inverse": ([_I, _P, _P, _I, _I], _I),
+    "dpgo_problem_auto_state": ([_P, C.POINTER(_I)], _I),
     "dpgo_problem_set_G": ([_P, _P], _I),
     "dpgo_problem_set_G_device": ([_P, _P], _I),
     "dpgo_problem_set_G_coupling": ([_P, _I, _I, _P, _P, _P, _P], _I),

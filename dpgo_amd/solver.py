@@ -38,9 +38,10 @@ class ROptParameters:
     RTR_tCG_iterations: int = 50
     RTR_initial_radius: float = 100.0
     # extensions
-    # "multilevel" (aggregation-multigrid V-cycle for Q + shift I, the default: the stand-in for the reference's exact
-    # solve) | "jacobi" (block-Jacobi of Q + shift I) | "none"
-    precond: str = "multilevel"
+    # "auto" (default: the multilevel cycle when the tCG budget binds, block-Jacobi while it does not -- decided per
+    # problem handle from the solves themselves, ROPTResult.precond_used tells) | "multilevel" (aggregation-multigrid
+    # V-cycle for Q + shift I, the stand-in for the reference's exact solve) | "jacobi" (block-Jacobi) | "none"
+    precond: str = "auto"
     precond_shift: float = 1e-1  # src/PoseGraph.cpp:603
     accept_tiny_decrease: bool = True
     tcg_poll_interval: int = 0  # 0 = just-in-time feed (default); k > 0 = poll every k tCG iterations
@@ -57,7 +58,7 @@ class ROptParameters:
         c.RTR_tCG_iterations = self.RTR_tCG_iterations
         c.RTR_initial_radius = self.RTR_initial_radius
         c.precond = {"jacobi": L.PRECOND_BLOCK_JACOBI, "none": L.PRECOND_NONE,
-                     "multilevel": L.PRECOND_MULTILEVEL}[self.precond]
+                     "multilevel": L.PRECOND_MULTILEVEL, "auto": L.PRECOND_AUTO}[self.precond]
         c.precond_shift = self.precond_shift
         c.accept_tiny_decrease = int(self.accept_tiny_decrease)
         c.tcg_poll_interval = self.tcg_poll_interval
@@ -80,12 +81,13 @@ class ROPTResult:
     tcg_iterations: int = 0
     spmm_count: int = 0
     latest_step_accepted: bool = False
+    precond_used: str = ""
 
     @staticmethod
     def from_c(c: L.RoptResultC) -> "ROPTResult":
         return ROPTResult(bool(c.success), c.fInit, c.gradNormInit, c.fOpt, c.gradNormOpt, c.elapsedMs,
                           L.TCG_STATUS[c.tCGStatus], c.rtr_iterations, c.rtr_accepted, c.tcg_iterations,
-                          c.spmm_count, bool(c.latest_step_accepted))
+                          c.spmm_count, bool(c.latest_step_accepted), L.PRECOND_NAMES[c.precond_used])
 
 
 def _colmajor(X, r: int, N: int, what: str = "Matrix") -> np.ndarray:
@@ -378,7 +380,8 @@ class QuadraticProblem:
 
     def PreConditioner(self, X, inVec, precond: str = "multilevel", shift: float = 1e-1) -> np.ndarray:  # :56-69
         Xc, Vc, o = self._in(X), self._in(inVec, "inVec"), self._out()
-        pc = {"jacobi": L.PRECOND_BLOCK_JACOBI, "none": L.PRECOND_NONE, "multilevel": L.PRECOND_MULTILEVEL}[precond]
+        pc = {"jacobi": L.PRECOND_BLOCK_JACOBI, "none": L.PRECOND_NONE, "multilevel": L.PRECOND_MULTILEVEL,
+              "auto": L.PRECOND_AUTO}[precond]
         L.check(self._lib.dpgo_problem_precondition(self._h, pc, shift, L.ptr(Xc), L.ptr(Vc), L.ptr(o)))
         return o
 
@@ -436,6 +439,12 @@ class QuadraticProblem:
         L.check(self._lib.dpgo_problem_setup_multilevel(self._h, len(ks), L.ptr(ks) if len(ks) else None,
                                                         float(omega), float(shift)))
         return self.multilevelInfo()
+
+    def autoState(self, use_multilevel=None) -> bool:
+        """What precond = "auto" currently runs on this handle (True: the multilevel cycle); a bool argument sets it."""
+        v = C.c_int(-1 if use_multilevel is None else int(bool(use_multilevel)))
+        L.check(self._lib.dpgo_problem_auto_state(self._h, C.byref(v)))
+        return bool(v.value)
 
     def multilevelInfo(self) -> dict:
         """{"sizes": nodes per level, "ks": aggregate size per coarsening, "nnzb": blocks of A_l per level}."""

@@ -50,7 +50,15 @@ extern "C" {
  * (same fixed point, different tCG trajectory). */
 #define DPGO_PRECOND_NONE 0
 #define DPGO_PRECOND_BLOCK_JACOBI 1
-#define DPGO_PRECOND_MULTILEVEL 2 /* aggregation-multigrid V-cycle for Q + shift I (default; built on the device) */
+#define DPGO_PRECOND_MULTILEVEL 2 /* aggregation-multigrid V-cycle for Q + shift I (built on the device) */
+/* DEFAULT.  The multilevel cycle whenever it pays, block-Jacobi otherwise, decided per handle from the solves themselves:
+ * a block-Jacobi solve that used >= half of its tCG budget (RTR_iterations x RTR_tCG_iterations Hessian-vector products)
+ * makes the next solves multilevel; a multilevel solve that needed <= a tenth of the budget hands back to block-Jacobi.
+ * Rationale: a multilevel iteration costs ~3.3x a block-Jacobi one and needs 4-7x fewer of them
+ * when the tCG budget binds (single-agent solves, the locally dominated end phase) -- but in multi-agent RBCD far from
+ * the optimum the trust-region boundary and the coupling, not the preconditioner, end the local solves.
+ * dpgo_ropt_result::precond_used says what a call ran. */
+#define DPGO_PRECOND_AUTO 3
 
 /* tCG termination status; replaces ROPTLIB::tCGstatusSet in ROPTResult
  * (include/DPGO/DPGO_types.h:106). */
@@ -73,7 +81,7 @@ typedef struct dpgo_ropt_params {
   int RTR_tCG_iterations;     /*                          default 50   */
   double RTR_initial_radius;  /*                          default 100  */
   /* --- extensions --- */
-  int precond;                /* DPGO_PRECOND_*           default MULTILEVEL */
+  int precond;                /* DPGO_PRECOND_*           default AUTO */
   double precond_shift;       /* reference: 1e-1 (src/PoseGraph.cpp:603) */
   int accept_tiny_decrease;   /* ROPTLIB's second acceptance clause (SURVEY 8c' item 5), default 1 */
   int tcg_poll_interval;      /* 0 (default): just-in-time kernel feed driven by the progress word the
@@ -92,6 +100,7 @@ typedef struct dpgo_ropt_result {
   int tcg_iterations;     /* Hessian-vector products inside tCG (all outer iterations) */
   int spmm_count;         /* Q*X block-SpMM launches in this call */
   int latest_step_accepted;
+  int precond_used;       /* DPGO_PRECOND_* this call ran (what DPGO_PRECOND_AUTO resolved to) */
 } dpgo_ropt_result;
 
 typedef struct dpgo_problem_s* dpgo_problem_t;
@@ -169,7 +178,8 @@ int dpgo_problem_get_edge_weights(dpgo_problem_t h, double* weight_host, double*
 
 /* Q's current values (nnzb blocks, same order as set_Q_bsr) -- they change on the device under GNC re-weighting. */
 int dpgo_problem_get_Q_values(dpgo_problem_t h, double* vals_host);
-/* Multilevel (aggregation multigrid) preconditioner, precond = DPGO_PRECOND_MULTILEVEL (the default): the device
+/* Multilevel (aggregation multigrid) preconditioner, precond = DPGO_PRECOND_MULTILEVEL (what DPGO_PRECOND_AUTO, the
+ * default, switches to when the tCG budget binds): the device
  * path's stand-in for the reference's exact solve of Q + 0.1 I inside QuadraticProblem::PreConditioner
  * (src/QuadraticProblem.cpp:56-69; factor from PoseGraph::constructPreconditioner, src/PoseGraph.cpp:598-613).
  * One V(1,1) cycle: damped block-Jacobi smoothing on every level, level l+1's nodes = runs of ks[l] consecutive
@@ -194,6 +204,8 @@ int dpgo_multilevel_default_ks(int n, int d, int* ks, int* nks); /* *nks in: cap
 int dpgo_problem_setup_multilevel(dpgo_problem_t h, int nks, const int* ks, double omega, double shift);
 int dpgo_problem_multilevel_info(dpgo_problem_t h, int* nlevels, int* sizes, int* ks, int* nnzb);
 int dpgo_problem_multilevel_get(dpgo_problem_t h, int level, int what, void* out_host);
+/* State of DPGO_PRECOND_AUTO on this handle: *use_multilevel in/out; a negative input only queries. */
+int dpgo_problem_auto_state(dpgo_problem_t h, int* use_multilevel);
 /* In-place blocked Gauss-Jordan inverse of a dense SPD matrix on the device (the kernel pair that inverts the coarsest
  * operator; exposed for tests).  N <= 16384, row-major host arrays; use_mfma: fp64 matrix cores for the rank-64
  * updates (v_mfma_f64_16x16x4_f64) or plain FMAs. */

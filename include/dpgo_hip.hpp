@@ -107,8 +107,9 @@ class ROptParameters {
   double RTR_initial_radius = 100;
   // not in the reference struct: tCG preconditioner of the device path (DPGO_PRECOND_*).  The reference always uses
   // the exact solve of Q + 0.1 I (src/QuadraticProblem.cpp:56-69); MULTILEVEL -- an aggregation-multigrid V-cycle for the
-  // same matrix, built on the device by the first solve -- is this library's default stand-in for it.
-  int precond = DPGO_PRECOND_MULTILEVEL;
+  // same matrix, built on the device -- is this library's stand-in for it, and the default (AUTO) runs it whenever the
+  // tCG budget binds and the cheaper block-Jacobi while it does not (include/dpgo_hip.h).
+  int precond = DPGO_PRECOND_AUTO;
   dpgo_ropt_params to_c() const {
     dpgo_ropt_params c;
     dpgo_ropt_params_default(&c);
@@ -133,6 +134,7 @@ struct ROPTResult {
   double fInit, gradNormInit, fOpt, gradNormOpt, elapsedMs;
   int tCGStatus = DPGO_TCG_MAXITER;
   int tcgIterations = 0, rtrIterations = 0;
+  int precondUsed = DPGO_PRECOND_NONE;  // what the call ran (DPGO_PRECOND_AUTO resolved)
 };
 
 // Data-matrix part of DPGO::PoseGraph: measurements -> Q (block-CSR), G (dense), with the reference's
@@ -445,6 +447,7 @@ class QuadraticOptimizer {
     result_ = ROPTResult(res.success != 0, res.fInit, res.gradNormInit, res.fOpt, res.gradNormOpt, res.elapsedMs);
     result_.tCGStatus = res.tCGStatus;
     result_.tcgIterations = res.tcg_iterations;
+    result_.precondUsed = res.precond_used;
     result_.rtrIterations = res.rtr_iterations;
     return out;
   }
@@ -456,6 +459,7 @@ class QuadraticOptimizer {
     result_ = ROPTResult(res.success != 0, res.fInit, res.gradNormInit, res.fOpt, res.gradNormOpt, res.elapsedMs);
     result_.tCGStatus = res.tCGStatus;
     result_.tcgIterations = res.tcg_iterations;
+    result_.precondUsed = res.precond_used;
     result_.rtrIterations = res.rtr_iterations;
     return result_;
   }

@@ -313,7 +313,7 @@ static int run() {
   for (int pc : {DPGO_PRECOND_BLOCK_JACOBI, DPGO_PRECOND_MULTILEVEL}) {
     if (pc == DPGO_PRECOND_MULTILEVEL) REQUIRE(problem.setupMultilevel({2}) == 2);
     ROptParameters pm;
-    REQUIRE(pm.precond == DPGO_PRECOND_MULTILEVEL);
+    REQUIRE(pm.precond == DPGO_PRECOND_AUTO);
     pm.gradnorm_tol = 1e-9;
     pm.RTR_iterations = 20;
     pm.precond = pc;

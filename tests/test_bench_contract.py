@@ -55,4 +55,5 @@ def test_bench_prints_one_valid_json_line():
     port = cb["single_agent_port"]
     assert port["cores"] == 1 and port["value"] > 0 and port["rel_diff_fOpt_vs_device"] < 1e-6
     tt = j["quality"]["to_tolerance"]
-    assert set(tt) == {"grid:12x10x6/multilevel", "grid:12x10x6/jacobi"} and all("products" in v for v in tt.values())
+    assert set(tt) == {"grid:12x10x6/auto", "grid:12x10x6/multilevel", "grid:12x10x6/jacobi"}
+    assert all("products" in v for v in tt.values())

@@ -1074,10 +1074,10 @@ def test_multilevel_preconditioner_matches_oracle(oracle, name, r, ks):
     assert relerr(Zd, op.precondition(X0, V)) < 1e-9
     oo = oracle.QuadraticOptimizer(op, oracle.ROptParameters(), hess_recurrence=True)
     Xo = oo.optimize(X0)
-    go = dpgo_amd.QuadraticOptimizer(prob, dpgo_amd.ROptParameters())  # default = multilevel
-    assert go.params_.precond == "multilevel"
+    go = dpgo_amd.QuadraticOptimizer(prob, dpgo_amd.ROptParameters(precond="multilevel"))
     Xg = matrix_to_tiles(go.optimize(tiles_to_matrix(X0)), d)
     rg = go.getOptResult()
+    assert rg.precond_used == "multilevel"
     Xa = np.abs(Xo).reshape(n * (d + 1), r)  # f is a cancellation-heavy sum (kitti_00): error scales with |X|^T|Q||X|
     scale = float((Xa * (abs(op.Qs) @ Xa)).sum())
     if name == "kitti_00" and rg.tcg_iterations != oo.result.tcg_iters:
@@ -1097,6 +1097,36 @@ def test_multilevel_preconditioner_matches_oracle(oracle, name, r, ks):
             assert rg.gradNormOpt < 0.5 * rj.gradNormOpt  # one RBCD iteration gets much further
 
 
+@pytest.mark.parametrize("name", ["sphere2500", "smallGrid3D"])
+def test_default_preconditioner_selection_matches_oracle(oracle, name):
+    """precond = "auto" (the default): block-Jacobi until a solve uses half of its tCG budget, then the multilevel
+    cycle (and back when a multilevel solve needs a tenth of it).  Whatever a call ran (ROPTResult.precond_used), it
+    matches the oracle run with that preconditioner at matched settings; on sphere2500 from the chordal initialisation
+    the first call (95 of 150 products with block-Jacobi) switches the handle to multilevel."""
+    import dpgo_amd
+    om, n, d, Q, pg, prob = build_single_agent(oracle, name, 5)
+    r = 5
+    go = dpgo_amd.QuadraticOptimizer(prob, dpgo_amd.ROptParameters())
+    assert go.params_.precond == "auto"
+    Xo = Xg = oracle.lift(oracle.chordal_initialization(om, n), r)
+    used = []
+    ops = {"jacobi": oracle.QuadraticProblem(Q, None, r, d, precond="jacobi")}
+    for call in range(3):
+        Xg = matrix_to_tiles(go.optimize(tiles_to_matrix(Xg)), d)
+        rg = go.getOptResult()
+        used.append(rg.precond_used)
+        if rg.precond_used == "multilevel" and "multilevel" not in ops:
+            ops["multilevel"] = oracle.QuadraticProblem(Q, None, r, d, precond="amg", amg_k=prob.multilevelInfo()["ks"])
+        oo = oracle.QuadraticOptimizer(ops[rg.precond_used], oracle.ROptParameters(), hess_recurrence=True)
+        Xo = oo.optimize(Xo)
+        assert (rg.tcg_iterations, rg.rtr_iterations) == (oo.result.tcg_iters, oo.result.outer_iters), (call, used)
+        assert relerr(Xg, Xo) < 1e-7
+    if name == "sphere2500":
+        assert used == ["jacobi", "multilevel", "multilevel"]
+    else:
+        assert used[0] == "jacobi"
+
+
 def test_multilevel_hierarchy_follows_Q_values(oracle):
     """The hierarchy belongs to Q's values: after a re-weighting (here: every loop closure at weight 0.5, then a loop
     closure switched off, which breaks no chain, then an ODOMETRY edge at weight 0, which does) the next solve rebuilds
@@ -1106,7 +1136,7 @@ def test_multilevel_hierarchy_follows_Q_values(oracle):
     om, n, d, Q, pg, prob = build_single_agent(oracle, "smallGrid3D", 5)
     r = 5
     X0 = oracle.lift(oracle.chordal_initialization(om, n), r)
-    opt = dpgo_amd.QuadraticOptimizer(prob, dpgo_amd.ROptParameters())
+    opt = dpgo_amd.QuadraticOptimizer(prob, dpgo_amd.ROptParameters(precond="multilevel"))
     opt.optimize(tiles_to_matrix(X0))
     prob.setReweightableEdges()
     idx = prob.reweightable_index
@@ -1130,7 +1160,7 @@ def test_multilevel_hierarchy_follows_Q_values(oracle):
         assert (rg.tcg_iterations, rg.rtr_iterations) == (oo.result.tcg_iters, oo.result.outer_iters)
         assert relerr(Xg, Xo) < 1e-7
     # one preconditioned RGD step (src/QuadraticOptimizer.cpp:110-137) with the multilevel operator
-    go = dpgo_amd.QuadraticOptimizer(prob, dpgo_amd.ROptParameters(method="RGD"))
+    go = dpgo_amd.QuadraticOptimizer(prob, dpgo_amd.ROptParameters(method="RGD", precond="multilevel"))
     Xg = matrix_to_tiles(go.optimize(tiles_to_matrix(X0)), d)
     oo = oracle.QuadraticOptimizer(op, oracle.ROptParameters(method="RGD"))
     assert relerr(Xg, oo.optimize(X0)) < 1e-9
