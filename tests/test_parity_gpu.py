@@ -61,6 +61,50 @@ def test_problem_evaluations_match_oracle(oracle, name, r):
         assert relerr(matrix_to_tiles(prob.PreConditioner(Xm, Vm, pc), d), op.precondition(X, V)) < RTOL_ELEM
 
 
+def test_committed_golden_vectors():
+    """The HIP path against the COMMITTED fixtures (tests/golden/, written by make_golden.py) with no oracle in the loop:
+    Q*X, Riemannian gradient / Hessian, block-Jacobi preconditioner, qf retraction and polar projection on smallGrid3D
+    (element-wise, 1e-11); f and |rgrad| at a seeded point on all five datasets; the RTR trace of one optimize
+    (iteration counts, cost)."""
+    import json
+    import dpgo_amd
+    from conftest import GOLDEN
+    g = np.load(os.path.join(GOLDEN, "smallGrid3D_vectors.npz"))
+    sc = json.load(open(os.path.join(GOLDEN, "golden_scalars.json")))
+    meas, n = dpgo_amd.read_g2o_file(os.path.join(DATA, "smallGrid3D.g2o"))
+    d, r = 3, 5
+    pg = dpgo_amd.PoseGraph(0, r, d)
+    pg.setMeasurements(meas)
+    prob = dpgo_amd.QuadraticProblem(pg)
+    X, V = tiles_to_matrix(g["X"]), tiles_to_matrix(g["V"])
+    man = dpgo_amd.LiftedSEManifold(r, d, n)
+    for got, want in ((prob.EucHessianEta(X, X), "XQ"), (prob.RieGrad(X), "rgrad"), (prob.RieHessianEta(X, V), "rhess"),
+                      (prob.PreConditioner(X, V, "jacobi"), "precond_jacobi"),
+                      (man.Retraction(X, tiles_to_matrix(g["eta"])), "retract"), (man.project(tiles_to_matrix(g["M"])), "polar")):
+        assert relerr(matrix_to_tiles(got, d), g[want]) < RTOL_ELEM, want
+    for name, ref in sc["datasets"].items():
+        m2, n2 = dpgo_amd.read_g2o_file(os.path.join(DATA, name + ".g2o"))
+        assert (n2, len(m2), m2.d) == (ref["n"], ref["m"], ref["d"])
+        pg2 = dpgo_amd.PoseGraph(0, 5, m2.d)
+        pg2.setMeasurements(m2)
+        assert len(pg2.quadraticMatrix()[1]) == ref["nnzb"]
+        assert abs(pg2.quadraticMatrix()[2].sum() - ref["Q_sum"]) <= 1e-9 * ref["Q_abs_sum"]
+        M = np.random.default_rng(ref["seed"]).standard_normal((n2, m2.d + 1, 5))
+        Xr = dpgo_amd.LiftedSEManifold(5, m2.d, n2).project(tiles_to_matrix(M))  # the fixture's seeded point
+        p2 = dpgo_amd.QuadraticProblem(pg2)
+        # f is a cancellation-heavy sum when kappa is large (kitti_00): tolerance relative to sum |Q|
+        assert abs(p2.f(Xr) - ref["f_random"]) <= 1e-10 * max(abs(ref["f_random"]), 1e-3 * ref["Q_abs_sum"]), name
+        assert abs(p2.RieGradNorm(Xr) - ref["gradnorm_random"]) <= 1e-9 * ref["gradnorm_random"], name
+    from dpgo_amd.initialization import chordal_initialization
+    from dpgo_amd import synthetic
+    tr = sc["smallGrid3D_rtr_trace_jacobi"]
+    opt = dpgo_amd.QuadraticOptimizer(prob, dpgo_amd.ROptParameters(precond="jacobi"))
+    opt.optimize(tiles_to_matrix(synthetic.lift_tiles(chordal_initialization(meas, n), r)))
+    res = opt.getOptResult()
+    assert (res.tcg_iterations, res.rtr_iterations) == (tr["tcg_iters"], tr["outer_iters"])
+    assert abs(res.fInit - tr["fInit"]) <= 1e-8 * abs(tr["fInit"]) and abs(res.fOpt - tr["fOpt"]) <= 1e-8 * abs(tr["fOpt"])
+
+
 @pytest.mark.parametrize("d,r,n", [(3, 5, 1000), (3, 3, 17), (2, 2, 64), (2, 5, 333), (3, 6, 129), (3, 5, 1)])
 def test_manifold_ops_match_oracle(oracle, d, r, n):
     """LiftedSEManifold::project (tests/testUtils.cpp:40-54 tolerance 1e-5 on Y^T Y = I; here also
