@@ -69,17 +69,13 @@ __global__ __launch_bounds__(kBlock) void k_ml_restrict(BsrDev A, const double* 
     const bool okp = (L.g < GEO::G) && (i < n);
     const bool ok = okp && (L.s == 0);
     const size_t off = (size_t)i * GEO::T + L.c * R;
-    // the own-row loads are issued first: they overlap the gather's index -> tile latency chain
-    double h[R], xr[R], rr[R], pcol[GEO::B];
-    if (ok) {
-      load_col<R>(x1 + off, xr);
-      load_col<R>(r + off, rr);
-      const double* __restrict__ pb = Pb + (size_t)i * GEO::BB;
-#pragma unroll
-      for (int cc = 0; cc < GEO::B; ++cc) pcol[cc] = pb[cc * GEO::B + L.c];
-    }
+    // (loading the own rows BEFORE the gather was tried and is slower: 35.3 -> 44.3 us at 100k poses)
+    double h[R];
     spmm_col<D, R, SPLIT>(A.rowptr, A.colidx, A.vals, x1, i, L.s, L.c, okp, h);
     if (ok) {
+      double xr[R], rr[R];
+      load_col<R>(x1 + off, xr);
+      load_col<R>(r + off, rr);
 #pragma unroll
       for (int a = 0; a < R; ++a) h[a] = rr[a] - h[a] - shift * xr[a];
       store_col<R>(&res_s[L.wave][L.g][L.c * R], h);
@@ -90,9 +86,10 @@ __global__ __launch_bounds__(kBlock) void k_ml_restrict(BsrDev A, const double* 
 #pragma unroll
       for (int a = 0; a < R; ++a) t[a] = 0.0;
       if (ok) {  // row c of P_i^T res_i = sum_c' P_i[c'][c] res_i[c'][:]
+        const double* __restrict__ pb = Pb + (size_t)i * GEO::BB;
 #pragma unroll
         for (int cc = 0; cc < GEO::B; ++cc) {
-          const double pv = pcol[cc];
+          const double pv = pb[cc * GEO::B + L.c];
 #pragma unroll
           for (int a = 0; a < R; ++a) t[a] = fma(pv, res_s[L.wave][L.g][cc * R + a], t[a]);
         }
@@ -312,16 +309,13 @@ __global__ __launch_bounds__(kBlock) void k_ml_post(BsrDev Q, const double* __re
     double* ys = ok ? &sm[L.wave][0][L.g][0] : nullptr;
     double* vs = ok ? &sm[L.wave][1][L.g][0] : nullptr;
     double* zs = ok ? &sm[L.wave][2][L.g][0] : nullptr;
-    double h[R], xr[R], rr[R], z[R], x[R], drow[GEO::B];
-    if (ok) {  // own-row loads first: they overlap the gather's index -> tile latency chain
+    double h[R], xr[R], rr[R], z[R];
+    spmm_col<D, R, SPLIT>(Q.rowptr, Q.colidx, Q.vals, xv, i, L.s, L.c, okp, h);
+    if (ok) {  // (loading the own rows BEFORE the gather was tried and is slower: 30.4 -> 37.3 us at 100k poses)
+      double x[R];
       load_col<R>(X + off, x);
       load_col<R>(xv + off, xr);
       load_col<R>(r + off, rr);
-#pragma unroll
-      for (int k = 0; k < GEO::B; ++k) drow[k] = dinv[(size_t)i * GEO::BB + L.c * GEO::B + k];
-    }
-    spmm_col<D, R, SPLIT>(Q.rowptr, Q.colidx, Q.vals, xv, i, L.s, L.c, okp, h);
-    if (ok) {
 #pragma unroll
       for (int a = 0; a < R; ++a) {
         h[a] = rr[a] - h[a] - shift * xr[a];  // r - A x
@@ -332,7 +326,7 @@ __global__ __launch_bounds__(kBlock) void k_ml_post(BsrDev Q, const double* __re
     }
     wave_sync();
     if (ok) {
-      jacobi_col<D, R>(vs, drow, z);
+      jacobi_col<D, R>(vs, dinv + (size_t)i * GEO::BB + L.c * GEO::B, z);
 #pragma unroll
       for (int a = 0; a < R; ++a) z[a] = fma(omega, z[a], xr[a]);
       store_col<R>(zs + L.c * R, z);
