@@ -830,9 +830,17 @@ int run_optimize(dpgo_problem_s* p, const dpgo_ropt_params* prm, dpgo_ropt_resul
   cnt.spmm += 1;
   CHK(launch_rtr_begin(p, prm->gradnorm_tol, prm->RTR_initial_radius, 5.0 * prm->RTR_initial_radius,
                        prm->RTR_tCG_iterations, prm->accept_tiny_decrease));
-  CHK(poll_state(p));
-  res->fInit = p->hstate->fInit;
-  res->gradNormInit = p->hstate->gnInit;
+  // The initial statistics are read back together with the final ones when the solve is fed just-in-time (one
+  // synchronisation per call instead of two): an iterate that already meets the tolerance (:57-59) makes the first tCG
+  // launch publish rtr_stop, which ends the loop below before anything is changed.
+  const bool deferred = prm->method == DPGO_METHOD_RTR && prm->RTR_iterations != 1 && prm->tcg_poll_interval <= 0;
+  if (!deferred) {
+    CHK(poll_state(p));
+    res->fInit = p->hstate->fInit;
+    res->gradNormInit = p->hstate->gnInit;
+  } else {
+    p->hstate->rtr_stop = 0;
+  }
   int n_hess_total = 0;
   int shrink_tries = 0;
 
@@ -865,6 +873,10 @@ int run_optimize(dpgo_problem_s* p, const dpgo_ropt_params* prm, dpgo_ropt_resul
           if (prm->time_bound_s > 0 && el > prm->time_bound_s) break;  // Solver.TimeBound (:78)
         }
         CHK(poll_state(p));
+        if (deferred) {
+          res->fInit = p->hstate->fInit;
+          res->gradNormInit = p->hstate->gnInit;
+        }
       }
       res->tCGStatus = p->hstate->tcg_status;
       res->rtr_iterations = (prm->RTR_iterations == 1) ? shrink_tries : p->hstate->outer_iter;
@@ -1718,9 +1730,13 @@ int dpgo_optimize(dpgo_problem_t p, const dpgo_ropt_params* params, const double
 int dpgo_optimize_device(dpgo_problem_t p, const dpgo_ropt_params* params, double* X_dev, dpgo_ropt_result* result) {
   CHK(check_ready(p));
   if (!params || !X_dev || !result) return fail(DPGO_ERR_INVALID, "null pointer");
-  HIPC(hipMemcpyAsync(p->x1, X_dev, p->vec_bytes(), hipMemcpyDeviceToDevice, p->stream));
-  CHK(run_optimize(p, params, result));
-  HIPC(hipMemcpyAsync(X_dev, p->x1, p->vec_bytes(), hipMemcpyDeviceToDevice, p->stream));
+  // the caller's buffer IS the iterate for the duration of the call (no copies in or out): accepted steps are written
+  // into it by k_rtr_update, rejected ones leave it untouched
+  double* own = p->x1;
+  p->x1 = X_dev;
+  const int rc = run_optimize(p, params, result);
+  p->x1 = own;
+  if (rc != DPGO_OK) return rc;
   HIPC(hipStreamSynchronize(p->stream));
   return DPGO_OK;
 }
