@@ -131,6 +131,32 @@ struct dpgo_problem_s {
   int ml_lda = 0;
   double *ml_W = nullptr, *ml_Rx = nullptr;  // Gauss-Jordan panels (setup only)
   bool auto_ml = false;  // DPGO_PRECOND_AUTO: the multilevel cycle is currently selected
+  // symmetric copy of Q for the plain SpMM on Infinity-Cache-cold blocks (k_spmm_sym): upper blocks transposed + lower references
+  struct SymQ {
+    int nu = 0, nl = 0;
+    int32_t *urow = nullptr, *ucol = nullptr, *usrc = nullptr, *lrow = nullptr, *lcol = nullptr, *lslot = nullptr,
+            *lsrc = nullptr;
+    double* uvalsT = nullptr;
+    int* flag = nullptr;       // device: set by k_sym_check when a lower block is not the transpose of its upper one
+    bool symbolic = false;     // pattern arrays belong to the current block pattern
+    bool pattern_ok = false;   // the pattern is structurally symmetric
+    bool ready = false;        // uvalsT holds the current values and they passed the symmetry check
+    bool values_ok = false;
+    BsrSymDev dev() const { return BsrSymDev{urow, ucol, uvalsT, lrow, lcol, lslot}; }
+  } sym;
+  int spmm_variant = DPGO_SPMM_AUTO;
+  bool tcg_sym = false;  // the fused tCG-step kernel reads the symmetric copy (resolved before a solve / a kernel probe)
+  int cap_hs = kMaxGrid; // launch cap of k_tcg_hess_sym
+  bool sym_wanted() const {
+    if (spmm_variant == DPGO_SPMM_PLAIN || split != 1) return false;
+    if (spmm_variant == DPGO_SPMM_SYMMETRIC) return true;
+    // AUTO: when the tCG loop's working set (Q and eight pose vectors) no longer fits the 256 MB Infinity Cache, i.e. when
+    // Q's bytes come from HBM: there the half-size storage wins (k_tcg_hess 45.5 against 49.4 us, plain product 28.4 against
+    // 36.6 us at 100k poses with cold operands), while on cache-resident operands the fused kernels gain nothing
+    // (DESIGN.md section 3).  DPGO_SPMM_SYMMETRIC=0/1 in the environment overrides.
+    if (const char* e = std::getenv("DPGO_SPMM_SYMMETRIC")) return std::atoi(e) != 0;
+    return sizeof(double) * ((size_t)Q.nnzb * b * b + 8 * (size_t)n * T) + sizeof(int32_t) * (size_t)Q.nnzb > ((size_t)256 << 20);
+  }
   // persistent single-XCD tCG kernel (small blocks, block-Jacobi / no preconditioner)
   bool persist = false;
   int persist_wgs = 0;  // wanted participants (workgroups on one XCD)
@@ -181,7 +207,8 @@ struct dpgo_problem_s {
     const int P = (64 / (b * split)) * kWaves;
     int tiles = (n + P - 1) / P;
     if (tiles < 1) tiles = 1;
-    return tiles < cap_h ? tiles : cap_h;
+    const int cap = tcg_sym ? cap_hs : cap_h;
+    return tiles < cap ? tiles : cap;
   }
   int grid_spmm() const {  // plain k_spmm: no partial sums, higher occupancy than the fused tCG kernel
     const int P = (64 / (b * split)) * kWaves;
@@ -283,8 +310,119 @@ int push_state(dpgo_problem_s* p) {
   return DPGO_OK;
 }
 
+// ---- symmetric copy of Q (plain SpMM on cold blocks) ----
+void sym_free(dpgo_problem_s* p) {
+  auto& S = p->sym;
+  void* ptrs[] = {S.urow, S.ucol, S.usrc, S.lrow, S.lcol, S.lslot, S.lsrc, S.uvalsT, S.flag};
+  for (void* q : ptrs)
+    if (q) (void)hipFree(q);
+  S = dpgo_problem_s::SymQ();
+  p->tcg_sym = false;
+}
+
+template <typename T>
+int sym_upload(T** dst, const std::vector<T>& v, hipStream_t stream) {
+  HIPC(hipMalloc(dst, sizeof(T) * std::max<size_t>(1, v.size())));
+  if (!v.empty()) HIPC(hipMemcpyAsync(*dst, v.data(), sizeof(T) * v.size(), hipMemcpyHostToDevice, stream));
+  return DPGO_OK;
+}
+
+// pattern arrays from the host copy of Q's block pattern; a pattern that is not structurally symmetric leaves
+// pattern_ok = false (the plain kernel stays in use), it is not an error
+int sym_symbolic_setup(dpgo_problem_s* p) {
+  sym_free(p);
+  auto& S = p->sym;
+  S.symbolic = true;
+  const int n = p->n;
+  if ((int)p->h_rowptr.size() != n + 1) return DPGO_OK;
+  const auto& rp = p->h_rowptr;
+  const auto& ci = p->h_colidx;
+  std::vector<int32_t> urow(n + 1, 0), lrow(n + 1, 0), ucol, usrc, lcol, lslot, lsrc;
+  ucol.reserve(ci.size() / 2 + n);
+  for (int i = 0; i < n; ++i) {
+    for (int t = rp[i]; t < rp[i + 1]; ++t)
+      if (ci[t] >= i) {
+        ucol.push_back(ci[t]);
+        usrc.push_back(t);
+      }
+    urow[i + 1] = (int32_t)ucol.size();
+  }
+  for (int i = 0; i < n; ++i) {
+    for (int t = rp[i]; t < rp[i + 1]; ++t) {
+      const int j = ci[t];
+      if (j >= i) break;  // columns are sorted
+      const auto b0 = ucol.begin() + urow[j], b1 = ucol.begin() + urow[j + 1];
+      const auto it = std::lower_bound(b0, b1, (int32_t)i);
+      if (it == b1 || *it != i) return DPGO_OK;  // block (i, j) without block (j, i)
+      lcol.push_back(j);
+      lslot.push_back((int32_t)(it - ucol.begin()));
+      lsrc.push_back(t);
+    }
+    lrow[i + 1] = (int32_t)lcol.size();
+  }
+  if (ucol.size() + lcol.size() != ci.size()) return DPGO_OK;
+  if (2 * lcol.size() + (size_t)n != ci.size()) return DPGO_OK;  // an upper block without its lower one
+  S.nu = (int)ucol.size();
+  S.nl = (int)lcol.size();
+  CHK(sym_upload(&S.urow, urow, p->stream));
+  CHK(sym_upload(&S.ucol, ucol, p->stream));
+  CHK(sym_upload(&S.usrc, usrc, p->stream));
+  CHK(sym_upload(&S.lrow, lrow, p->stream));
+  CHK(sym_upload(&S.lcol, lcol, p->stream));
+  CHK(sym_upload(&S.lslot, lslot, p->stream));
+  CHK(sym_upload(&S.lsrc, lsrc, p->stream));
+  HIPC(hipMalloc(&S.uvalsT, sizeof(double) * (size_t)std::max(1, S.nu) * p->b * p->b));
+  HIPC(hipMalloc(&S.flag, sizeof(int)));
+  HIPC(hipStreamSynchronize(p->stream));  // the host vectors go out of scope
+  S.pattern_ok = true;
+  return DPGO_OK;
+}
+
+// true when the symmetric copy is usable for Q's current values (refreshes it when they changed)
+int sym_ensure(dpgo_problem_s* p, bool* usable) {
+  *usable = false;
+  auto& S = p->sym;
+  if (!S.symbolic) CHK(sym_symbolic_setup(p));
+  if (!S.pattern_ok) return DPGO_OK;
+  if (!S.ready) {
+    const size_t total = (size_t)S.nu * p->b * p->b;
+    const int g = (int)std::min<size_t>(kMaxGrid, (total + kBlock - 1) / kBlock);
+    HIPC(hipMemsetAsync(S.flag, 0, sizeof(int), p->stream));
+    if (p->d == 2) {
+      hipLaunchKernelGGL(k_sym_refresh<2>, dim3(g), dim3(kBlock), 0, p->stream, p->Q.vals, S.usrc, S.uvalsT, S.nu);
+      hipLaunchKernelGGL(k_sym_check<2>, dim3(g), dim3(kBlock), 0, p->stream, p->Q.vals, S.lsrc, S.lslot, S.uvalsT, S.nl,
+                         S.flag);
+    } else {
+      hipLaunchKernelGGL(k_sym_refresh<3>, dim3(g), dim3(kBlock), 0, p->stream, p->Q.vals, S.usrc, S.uvalsT, S.nu);
+      hipLaunchKernelGGL(k_sym_check<3>, dim3(g), dim3(kBlock), 0, p->stream, p->Q.vals, S.lsrc, S.lslot, S.uvalsT, S.nl,
+                         S.flag);
+    }
+    HIPC(hipGetLastError());
+    int bad = 0;
+    HIPC(hipMemcpyAsync(&bad, S.flag, sizeof(int), hipMemcpyDeviceToHost, p->stream));
+    HIPC(hipStreamSynchronize(p->stream));
+    S.values_ok = (bad == 0);
+    S.ready = true;
+  }
+  *usable = S.values_ok;
+  return DPGO_OK;
+}
+
 // ---- kernel launch helpers (templated on D, R through DISPATCH) ----
+int launch_spmm_sym(dpgo_problem_s* p, const BsrSymDev& M, const double* V, const double* Gadd, double* OUT) {
+  const int g = p->grid_spmm();
+  DISPATCH(p->d, p->r,
+           hipLaunchKernelGGL((k_spmm_sym<D, R>), dim3(g), dim3(kBlock), 0, p->stream, M, V, Gadd, OUT, p->n));
+  HIPC(hipGetLastError());
+  return DPGO_OK;
+}
+
 int launch_spmm(dpgo_problem_s* p, const Bsr& M, const double* V, const double* Gadd, double* OUT, int nrows = -1) {
+  if (&M == &p->Q && nrows < 0 && p->sym_wanted()) {
+    bool usable = false;
+    CHK(sym_ensure(p, &usable));
+    if (usable) return launch_spmm_sym(p, p->sym.dev(), V, Gadd, OUT);
+  }
   const int rows = nrows >= 0 ? nrows : p->n;
   int g = p->grid_spmm();
   if (nrows >= 0) {  // rectangular operator with its own row count (restriction)
@@ -335,10 +473,15 @@ int launch_tcg_update(dpgo_problem_s* p, const double* dinv, int first, double* 
 // the tCG-step kernel: span variant whenever the pose tile size is even (all 3-D cases)
 #define LAUNCH_TCG_HESS(p, SIN, SOUT, FIRST, HFLAG, GEN)                                                          \
   do {                                                                                                            \
-    if constexpr (Span<D, R, 1>::kOk)                                                                             \
+    if constexpr (Span<D, R, 1>::kOk) {                                                                           \
+      if ((p)->tcg_sym)                                                                                           \
+        hipLaunchKernelGGL((k_tcg_hess_sym<D, R>), dim3((p)->grid_s()), dim3(kBlock), 0, (p)->stream,             \
+                           (p)->sym.dev(), (p)->x1, (p)->S1, (p)->z, (p)->delta, (p)->Hd, (p)->pB(), (p)->nb_zr(), \
+                           (p)->pA(), SIN, SOUT, FIRST, (p)->n, HFLAG, GEN);                                      \
+      else                                                                                                        \
       LAUNCH_SPLIT(p, k_tcg_hess_span, (p)->grid_s(), (p)->Q.dev(), (p)->x1, (p)->S1, (p)->z, (p)->delta, (p)->Hd, \
                    (p)->pB(), (p)->nb_zr(), (p)->pA(), SIN, SOUT, FIRST, (p)->n, HFLAG, GEN);                   \
-    else                                                                                                          \
+    } else                                                                                                        \
       LAUNCH_SPLIT(p, k_tcg_hess, (p)->grid_s(), (p)->Q.dev(), (p)->x1, (p)->S1, (p)->z, (p)->delta, (p)->Hd,      \
                    (p)->pB(), (p)->nb_zr(), (p)->pA(), SIN, SOUT, FIRST, (p)->n, HFLAG, GEN);                   \
   } while (0)
@@ -347,6 +490,18 @@ int launch_tcg_hess(dpgo_problem_s* p, int first) {
   DISPATCH(p->d, p->r, LAUNCH_TCG_HESS(p, p->dstate + p->cur, p->dstate + (p->cur ^ 1), first, p->hflag, p->gen));
   HIPC(hipGetLastError());
   p->cur ^= 1;
+  return DPGO_OK;
+}
+
+// which storage of Q the tCG-step kernel of the coming launches reads (Q does not change inside a solve)
+int resolve_tcg_storage(dpgo_problem_s* p) {
+  p->tcg_sym = false;
+  bool span = false;
+  DISPATCH(p->d, p->r, { span = Span<D, R, 1>::kOk; });
+  if (!span || !p->sym_wanted()) return DPGO_OK;
+  bool usable = false;
+  CHK(sym_ensure(p, &usable));
+  p->tcg_sym = usable;
   return DPGO_OK;
 }
 
@@ -626,8 +781,14 @@ int launch_ml_tail(dpgo_problem_s* p, const double* Xdev, const double* r, doubl
   for (int l = 0; l + 1 < nl; ++l) {  // down
     auto& L = p->ml[l];
     auto& C = p->ml[l + 1];
-    DISPATCH(p->d, p->r, ML_SPLIT_LAUNCH(L, k_ml_restrict, A_of(l), L.x1, r_of(l), L.Pb, l == 0 ? p->ml_shift : 0.0, L.k,
-                                         C.r, C.k ? C.dinv : (const double*)nullptr, p->ml_omega, C.x1, gate, L.n));
+    if (l == 0 && p->tcg_sym) {  // level 0 reads Q: the symmetric copy when the tCG-step kernel does
+      DISPATCH(p->d, p->r, hipLaunchKernelGGL((k_ml_restrict<D, R, 1, BsrSymDev>), dim3(p->grid_s()), dim3(kBlock), 0,
+                                              p->stream, p->sym.dev(), L.x1, r, L.Pb, p->ml_shift, L.k, C.r,
+                                              C.k ? C.dinv : (const double*)nullptr, p->ml_omega, C.x1, gate, L.n));
+    } else {
+      DISPATCH(p->d, p->r, ML_SPLIT_LAUNCH(L, k_ml_restrict, A_of(l), L.x1, r_of(l), L.Pb, l == 0 ? p->ml_shift : 0.0, L.k,
+                                           C.r, C.k ? C.dinv : (const double*)nullptr, p->ml_omega, C.x1, gate, L.n));
+    }
   }
   {  // dense level + prolongation
     auto& L = p->ml[nl - 2];
@@ -640,8 +801,14 @@ int launch_ml_tail(dpgo_problem_s* p, const double* Xdev, const double* r, doubl
     DISPATCH(p->d, p->r, ML_SPLIT_LAUNCH(L, k_ml_post_mid, L.A.dev(), L.x, L.r, L.dinv, p->ml_omega, F.x1, F.Pb, F.k, F.x,
                                          F.n, gate, L.n));
   }
-  DISPATCH(p->d, p->r, ML_SPLIT_LAUNCH(p->ml[0], k_ml_post, p->Q.dev(), Xdev, p->ml[0].x, r, p->dinv, p->ml_omega,
-                                       p->ml_shift, z, pout, gate, p->n));
+  if (p->tcg_sym) {
+    DISPATCH(p->d, p->r, hipLaunchKernelGGL((k_ml_post<D, R, 1, BsrSymDev>), dim3(p->grid_s()), dim3(kBlock), 0, p->stream,
+                                            p->sym.dev(), Xdev, p->ml[0].x, r, p->dinv, p->ml_omega, p->ml_shift, z, pout,
+                                            gate, p->n));
+  } else {
+    DISPATCH(p->d, p->r, ML_SPLIT_LAUNCH(p->ml[0], k_ml_post, p->Q.dev(), Xdev, p->ml[0].x, r, p->dinv, p->ml_omega,
+                                         p->ml_shift, z, pout, gate, p->n));
+  }
 #undef ML_SPLIT_LAUNCH
   HIPC(hipGetLastError());
   return DPGO_OK;
@@ -825,6 +992,7 @@ int run_optimize(dpgo_problem_s* p, const dpgo_ropt_params* prm, dpgo_ropt_resul
   } else if (prm->precond != DPGO_PRECOND_NONE) {
     return fail(DPGO_ERR_INVALID, "unknown preconditioner");
   }
+  CHK(resolve_tcg_storage(p));
   // statistics before optimisation (:28-29) -- one fused pass: f, rgrad, S
   CHK(launch_grad(p, p->x1, p->g1, p->S1, nullptr));
   cnt.spmm += 1;
@@ -981,6 +1149,7 @@ int refresh_after_weights(dpgo_problem_s* p) {
   CHK(rebuild_Q_from_weights(p, p->q_base, 1.0, p->Q.vals));
   CHK(rebuild_C_from_weights(p, p->c_base, 1.0, p->C.vals));  // G itself is refreshed by the next update_G call
   p->ml_ready = false;
+  p->sym.ready = p->tcg_sym = false;
   const double s = p->dinv_shift > 0 ? p->dinv_shift : 1e-1;
   p->dinv_shift = -1.0;  // clearQuadraticMatrix also drops the preconditioner (src/PoseGraph.cpp:352-355)
   return build_dinv(p, s);
@@ -1012,6 +1181,7 @@ int tune_launch_caps(dpgo_problem_s* p) {
         CHK(resident_blocks(k_tcg_hess_span<D, R, 2>, &p->cap_h));
       else
         CHK(resident_blocks(k_tcg_hess_span<D, R, 1>, &p->cap_h));
+      CHK(resident_blocks(k_tcg_hess_sym<D, R>, &p->cap_hs));
     } else {
       CHK(resident_blocks(k_tcg_update<D, R>, &p->cap_u));
       if (p->split == 4)
@@ -1025,6 +1195,7 @@ int tune_launch_caps(dpgo_problem_s* p) {
   // tuning knobs (any value up to the partial-sum capacity is valid)
   if (const char* e = std::getenv("DPGO_GRID_UPDATE")) p->cap_u = std::max(1, std::min(kPartialCap, std::atoi(e)));
   if (const char* e = std::getenv("DPGO_GRID_HESS")) p->cap_h = std::max(1, std::min(kPartialCap, std::atoi(e)));
+  if (const char* e = std::getenv("DPGO_GRID_HESS_SYM")) p->cap_hs = std::max(1, std::min(kPartialCap, std::atoi(e)));
   return DPGO_OK;
 }
 
@@ -1157,6 +1328,7 @@ int dpgo_problem_destroy(dpgo_problem_t p) {
   free_bsr(p->Q);
   free_bsr(p->C);
   ml_free(p);
+  sym_free(p);
   free_edges(p);
   double* vecs[] = {p->x1, p->x2, p->g1, p->g2, p->eta, p->delta, p->Hd, p->rr, p->z, p->G, p->G0,
                     p->S1, p->S2, p->dinv, p->partials};
@@ -1220,7 +1392,9 @@ int dpgo_problem_set_Q_bsr(dpgo_problem_t p, int nnzb, const int32_t* rowptr, co
     } else {
       ml_free(p);
     }
+    sym_free(p);
   }
+  p->sym.ready = p->tcg_sym = false;
   p->ml_ready = false;  // the hierarchy's values belong to the old Q: rebuilt on the device at the next use
   p->dinv_shift = -1.0;
   CHK(build_dinv(p, 1e-1));  // src/PoseGraph.cpp:603
@@ -1462,6 +1636,7 @@ int dpgo_problem_update_Q_values(dpgo_problem_t p, const double* vals) {
   const double s = p->dinv_shift > 0 ? p->dinv_shift : 1e-1;
   p->dinv_shift = -1.0;  // PoseGraph::clearQuadraticMatrix also drops the preconditioner (src/PoseGraph.cpp:352-355)
   p->ml_ready = false;
+  p->sym.ready = p->tcg_sym = false;
   CHK(build_dinv(p, s));
   HIPC(hipStreamSynchronize(p->stream));
   return DPGO_OK;
@@ -1832,12 +2007,17 @@ int dpgo_bench_hess_rotating(dpgo_problem_t p, int nsets, int reps, int warmup, 
   const size_t vbytes = sizeof(double) * (size_t)p->Q.nnzb * p->b * p->b;
   const size_t cbytes = sizeof(int32_t) * (size_t)p->Q.nnzb;
   const size_t sbytes = sizeof(double) * (size_t)p->n * p->d * p->d;
+  CHK(resolve_tcg_storage(p));
+  const bool symq = p->tcg_sym;  // the kernel reads the symmetric copy: that is what rotates
+  auto& SY = p->sym;
   struct Set {
     double *vals = nullptr, *x1 = nullptr, *S1 = nullptr, *z = nullptr, *delta = nullptr, *Hd = nullptr;
     int32_t* colidx = nullptr;
+    double* uv = nullptr;
+    int32_t *uc = nullptr, *lc = nullptr, *ls = nullptr;
   };
   std::vector<Set> sets(nsets);
-  const Set orig{p->Q.vals, p->x1, p->S1, p->z, p->delta, p->Hd, p->Q.colidx};
+  const Set orig{p->Q.vals, p->x1, p->S1, p->z, p->delta, p->Hd, p->Q.colidx, SY.uvalsT, SY.ucol, SY.lcol, SY.lslot};
   bool ok = true;
   auto dup = [&](auto** dst, const void* src, size_t bytes) {
     if (!ok) return;
@@ -1848,8 +2028,15 @@ int dpgo_bench_hess_rotating(dpgo_problem_t p, int nsets, int reps, int warmup, 
     (void)hipMemcpyAsync(*dst, src, bytes, hipMemcpyDeviceToDevice, p->stream);
   };
   for (auto& st : sets) {
-    dup(&st.vals, orig.vals, vbytes);
-    dup(&st.colidx, orig.colidx, cbytes);
+    if (symq) {
+      dup(&st.uv, orig.uv, sizeof(double) * (size_t)SY.nu * p->b * p->b);
+      dup(&st.uc, orig.uc, sizeof(int32_t) * (size_t)SY.nu);
+      dup(&st.lc, orig.lc, sizeof(int32_t) * (size_t)std::max(1, SY.nl));
+      dup(&st.ls, orig.ls, sizeof(int32_t) * (size_t)std::max(1, SY.nl));
+    } else {
+      dup(&st.vals, orig.vals, vbytes);
+      dup(&st.colidx, orig.colidx, cbytes);
+    }
     dup(&st.x1, orig.x1, p->vec_bytes());
     dup(&st.S1, orig.S1, sbytes);
     dup(&st.z, orig.z, p->vec_bytes());
@@ -1857,8 +2044,15 @@ int dpgo_bench_hess_rotating(dpgo_problem_t p, int nsets, int reps, int warmup, 
     dup(&st.Hd, orig.Hd, p->vec_bytes());
   }
   auto use = [&](const Set& st) {
-    p->Q.vals = st.vals;
-    p->Q.colidx = st.colidx;
+    if (symq) {
+      SY.uvalsT = st.uv;
+      SY.ucol = st.uc;
+      SY.lcol = st.lc;
+      SY.lslot = st.ls;
+    } else {
+      p->Q.vals = st.vals;
+      p->Q.colidx = st.colidx;
+    }
     p->x1 = st.x1;
     p->S1 = st.S1;
     p->z = st.z;
@@ -1889,7 +2083,7 @@ int dpgo_bench_hess_rotating(dpgo_problem_t p, int nsets, int reps, int warmup, 
   use(orig);
   (void)hipStreamSynchronize(p->stream);
   for (auto& st : sets) {
-    void* ptrs[] = {st.vals, st.colidx, st.x1, st.S1, st.z, st.delta, st.Hd};
+    void* ptrs[] = {st.vals, st.colidx, st.x1, st.S1, st.z, st.delta, st.Hd, st.uv, st.uc, st.lc, st.ls};
     for (void* q : ptrs)
       if (q) (void)hipFree(q);
   }
@@ -1898,10 +2092,87 @@ int dpgo_bench_hess_rotating(dpgo_problem_t p, int nsets, int reps, int warmup, 
   return DPGO_OK;
 }
 
+int dpgo_problem_set_spmm_variant(dpgo_problem_t p, int variant, int* in_use) {
+  CHK(check_ready(p));
+  if (variant != DPGO_SPMM_AUTO && variant != DPGO_SPMM_PLAIN && variant != DPGO_SPMM_SYMMETRIC)
+    return fail(DPGO_ERR_INVALID, "unknown product storage");
+  p->spmm_variant = variant;
+  bool usable = false;
+  if (p->sym_wanted()) CHK(sym_ensure(p, &usable));
+  if (in_use) *in_use = usable ? DPGO_SPMM_SYMMETRIC : DPGO_SPMM_PLAIN;
+  return DPGO_OK;
+}
+
+namespace {
+// rotating copies of the symmetric storage (values, column indices, references; the row pointers are shared)
+int bench_spmm_sym_rotating(dpgo_problem_s* p, int nsets, int reps, int warmup, double* avg_ms, double* set_bytes) {
+  const auto& S = p->sym;
+  const size_t vbytes = sizeof(double) * (size_t)S.nu * p->b * p->b;
+  struct Set {
+    double *v = nullptr, *x = nullptr, *o = nullptr;
+    int32_t *uc = nullptr, *lc = nullptr, *ls = nullptr;
+  };
+  std::vector<Set> sets(nsets);
+  int rc = DPGO_OK;
+  auto cleanup = [&]() {
+    for (auto& st : sets) {
+      void* ptrs[] = {st.v, st.x, st.o, st.uc, st.lc, st.ls};
+      for (void* q : ptrs)
+        if (q) (void)hipFree(q);
+    }
+  };
+  for (auto& st : sets) {
+    if (hipMalloc(&st.v, vbytes) != hipSuccess || hipMalloc(&st.x, p->vec_bytes()) != hipSuccess ||
+        hipMalloc(&st.o, p->vec_bytes()) != hipSuccess || hipMalloc(&st.uc, sizeof(int32_t) * S.nu) != hipSuccess ||
+        hipMalloc(&st.lc, sizeof(int32_t) * std::max(1, S.nl)) != hipSuccess ||
+        hipMalloc(&st.ls, sizeof(int32_t) * std::max(1, S.nl)) != hipSuccess) {
+      rc = fail(DPGO_ERR_HIP, "hipMalloc failed for the rotating buffer sets");
+      break;
+    }
+    (void)hipMemcpyAsync(st.v, S.uvalsT, vbytes, hipMemcpyDeviceToDevice, p->stream);
+    (void)hipMemcpyAsync(st.uc, S.ucol, sizeof(int32_t) * S.nu, hipMemcpyDeviceToDevice, p->stream);
+    (void)hipMemcpyAsync(st.lc, S.lcol, sizeof(int32_t) * S.nl, hipMemcpyDeviceToDevice, p->stream);
+    (void)hipMemcpyAsync(st.ls, S.lslot, sizeof(int32_t) * S.nl, hipMemcpyDeviceToDevice, p->stream);
+    (void)hipMemcpyAsync(st.x, p->x1, p->vec_bytes(), hipMemcpyDeviceToDevice, p->stream);
+  }
+  if (rc != DPGO_OK) {
+    cleanup();
+    return rc;
+  }
+  auto launch = [&](int i) {
+    const Set& st = sets[i % nsets];
+    return launch_spmm_sym(p, BsrSymDev{S.urow, st.uc, st.v, S.lrow, st.lc, st.ls}, st.x, nullptr, st.o);
+  };
+  hipEvent_t e0, e1;
+  (void)hipEventCreate(&e0);
+  (void)hipEventCreate(&e1);
+  for (int i = 0; i < warmup && rc == DPGO_OK; ++i) rc = launch(i);
+  (void)hipEventRecord(e0, p->stream);
+  for (int i = 0; i < reps && rc == DPGO_OK; ++i) rc = launch(i);
+  (void)hipEventRecord(e1, p->stream);
+  (void)hipEventSynchronize(e1);
+  float ms = 0.f;
+  (void)hipEventElapsedTime(&ms, e0, e1);
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  cleanup();
+  if (rc != DPGO_OK) return rc;
+  *avg_ms = (double)ms / reps;
+  if (set_bytes)
+    *set_bytes = (double)(vbytes + sizeof(int32_t) * ((size_t)S.nu + 2 * (size_t)S.nl) + 2 * p->vec_bytes());
+  return DPGO_OK;
+}
+}  // namespace
+
 int dpgo_bench_spmm_rotating(dpgo_problem_t p, int nsets, int reps, int warmup, double* avg_ms,
                              double* set_bytes) {
   CHK(check_ready(p));
   if (nsets < 1 || nsets > 512 || reps <= 0 || !avg_ms) return fail(DPGO_ERR_INVALID, "bad arguments");
+  if (p->sym_wanted()) {
+    bool usable = false;
+    CHK(sym_ensure(p, &usable));
+    if (usable) return bench_spmm_sym_rotating(p, nsets, reps, warmup, avg_ms, set_bytes);
+  }
   // nsets private copies of (Q values, block columns, X, OUT): cycling through them makes every launch read
   // data that left the 256 MB Infinity Cache ("rotate >= 3 buffer sets > 256 MB total")
   const size_t vbytes = sizeof(double) * (size_t)p->Q.nnzb * p->b * p->b;
@@ -1956,6 +2227,7 @@ int dpgo_bench_spmm_rotating(dpgo_problem_t p, int nsets, int reps, int warmup, 
 int dpgo_bench_hess(dpgo_problem_t p, int reps, int warmup, double* avg_ms) {
   CHK(check_ready(p));
   if (reps <= 0 || !avg_ms) return fail(DPGO_ERR_INVALID, "bad arguments");
+  CHK(resolve_tcg_storage(p));
   // a state in which the tCG-step kernel never takes an early exit
   std::memset(p->hstate, 0, sizeof(DevState));
   p->hstate->z_r = 1.0;
@@ -1989,6 +2261,7 @@ int dpgo_bench_iteration_kernels(dpgo_problem_t p, int reps, int warmup, double 
   CHK(check_ready(p));
   if (reps <= 0 || !out_ms) return fail(DPGO_ERR_INVALID, "bad arguments");
   for (int q = 0; q < 5; ++q) out_ms[q] = 0.0;
+  CHK(resolve_tcg_storage(p));
   // a state in which no kernel takes an early exit (as dpgo_bench_hess); alpha = z_r / d_Hd stays finite
   std::memset(p->hstate, 0, sizeof(DevState));
   p->hstate->z_r = 1.0;
@@ -2030,9 +2303,16 @@ int dpgo_bench_iteration_kernels(dpgo_problem_t p, int reps, int warmup, double 
     auto& L0 = p->ml[0];
     auto& C1 = p->ml[1];
     rc = timed([&]() -> int {
-      DISPATCH(p->d, p->r, LAUNCH_SPLIT(p, k_ml_restrict, p->grid_s(), p->Q.dev(), L0.x1, p->rr, L0.Pb, p->ml_shift, L0.k,
-                                        C1.r, C1.k ? C1.dinv : (const double*)nullptr, p->ml_omega, C1.x1,
-                                        (const DevState*)nullptr, p->n));
+      if (p->tcg_sym) {
+        DISPATCH(p->d, p->r, hipLaunchKernelGGL((k_ml_restrict<D, R, 1, BsrSymDev>), dim3(p->grid_s()), dim3(kBlock), 0,
+                                                p->stream, p->sym.dev(), L0.x1, p->rr, L0.Pb, p->ml_shift, L0.k, C1.r,
+                                                C1.k ? C1.dinv : (const double*)nullptr, p->ml_omega, C1.x1,
+                                                (const DevState*)nullptr, p->n));
+      } else {
+        DISPATCH(p->d, p->r, LAUNCH_SPLIT(p, k_ml_restrict, p->grid_s(), p->Q.dev(), L0.x1, p->rr, L0.Pb, p->ml_shift,
+                                          L0.k, C1.r, C1.k ? C1.dinv : (const double*)nullptr, p->ml_omega, C1.x1,
+                                          (const DevState*)nullptr, p->n));
+      }
       HIPC(hipGetLastError());
       return DPGO_OK;
     }, &out_ms[1]);
@@ -2042,8 +2322,14 @@ int dpgo_bench_iteration_kernels(dpgo_problem_t p, int reps, int warmup, double 
       return launch_coarse_prolong(p, L, Cc, nullptr);
     }, &out_ms[2]);
     if (rc == DPGO_OK) rc = timed([&]() -> int {
-      DISPATCH(p->d, p->r, LAUNCH_SPLIT(p, k_ml_post, p->grid_s(), p->Q.dev(), p->x1, L0.x, p->rr, p->dinv, p->ml_omega,
-                                        p->ml_shift, p->z, p->pB(), (const DevState*)nullptr, p->n));
+      if (p->tcg_sym) {
+        DISPATCH(p->d, p->r, hipLaunchKernelGGL((k_ml_post<D, R, 1, BsrSymDev>), dim3(p->grid_s()), dim3(kBlock), 0,
+                                                p->stream, p->sym.dev(), p->x1, L0.x, p->rr, p->dinv, p->ml_omega,
+                                                p->ml_shift, p->z, p->pB(), (const DevState*)nullptr, p->n));
+      } else {
+        DISPATCH(p->d, p->r, LAUNCH_SPLIT(p, k_ml_post, p->grid_s(), p->Q.dev(), p->x1, L0.x, p->rr, p->dinv, p->ml_omega,
+                                          p->ml_shift, p->z, p->pB(), (const DevState*)nullptr, p->n));
+      }
       HIPC(hipGetLastError());
       return DPGO_OK;
     }, &out_ms[3]);

@@ -122,6 +122,9 @@ __device__ __forceinline__ TileIter tile_iter(int ntiles) {
 #ifndef DPGO_LB_HESS
 #define DPGO_LB_HESS 1
 #endif
+#ifndef DPGO_SYM_WAVES
+#define DPGO_SYM_WAVES 3  // waves per SIMD k_tcg_hess_sym is compiled for (<= 168 VGPRs)
+#endif
 #ifndef DPGO_LB_UPDATE
 #define DPGO_LB_UPDATE 1
 #endif
@@ -492,3 +495,133 @@ struct BsrDev {
   const int32_t* colidx;
   const double* vals;
 };
+
+// ---------------------------------------------------------------- block product on symmetric storage
+// Q is symmetric, Q[j,i] = Q[i,j]^T.  Only the blocks (i, j >= i) are stored, TRANSPOSED (column c of a block is
+// contiguous); block row i walks its upper blocks and a list of references (j < i, slot of block (j, i)) whose
+// stored block is used through its rows.  HBM sees ~half of Q's values, and the gather is by outer products: lane c of
+// a pose loads only column c of the gathered tile (R doubles instead of the whole (D+1) x R tile) and of the block, keeps
+// the (D+1) x R partial  P_c[c'][a] = V_j[a][c] Q_ij[c'][c], and ONE cross-lane reduce-scatter per row (not per block)
+// leaves row c of (Q V)_i in lane c.  The first (D+1) upper and lower column indices of a row are preloaded by the pose's
+// lanes and broadcast by shuffles.  One pose per (D+1) lanes (SPLIT = 1) only.  100k-pose grid, plain product: 28.4 us
+// against 36.6 us with Infinity-Cache-cold operands, 22.9 against 24.4 us warm (profiles/).
+struct BsrSymDev {
+  const int32_t* urow;   // [n + 1] upper blocks (j >= i) of every block row
+  const int32_t* ucol;
+  const double* uvalsT;  // transposed blocks: uvalsT[u][p][q] = Q[i, j][q][p]
+  const int32_t* lrow;   // [n + 1] lower references (j < i)
+  const int32_t* lcol;
+  const int32_t* lslot;  // upper slot of block (j, i)
+};
+struct SymIdx {
+  int u0, du, l0, dl, ju, jl, sl;
+};
+template <int D>
+__device__ __forceinline__ SymIdx sym_idx_load(const BsrSymDev& Q, int i, int c, bool ok) {
+  SymIdx si;
+  si.u0 = ok ? Q.urow[i] : 0;
+  si.du = (ok ? Q.urow[i + 1] : 0) - si.u0;
+  si.l0 = ok ? Q.lrow[i] : 0;
+  si.dl = (ok ? Q.lrow[i + 1] : 0) - si.l0;
+  si.ju = (c < si.du) ? Q.ucol[si.u0 + c] : 0;
+  si.jl = (c < si.dl) ? Q.lcol[si.l0 + c] : 0;
+  si.sl = (c < si.dl) ? Q.lslot[si.l0 + c] : 0;
+  return si;
+}
+// wave-cooperative (all 64 lanes); out = row c of (Q V)_i for the lane (g, c) of pose i
+template <int D, int R>
+__device__ __forceinline__ void spmm_sym_pre(const SymIdx& si, const BsrSymDev& Q, const double* __restrict__ V, int c,
+                                             double (&out)[R]) {
+  constexpr int B = D + 1, T = B * R, BB = B * B;
+  const int lane = threadIdx.x & 63, gbase = lane - c;
+  double acc[B][R];
+#pragma unroll
+  for (int cc = 0; cc < B; ++cc)
+#pragma unroll
+    for (int a = 0; a < R; ++a) acc[cc][a] = 0.0;
+  const int u0 = si.u0, du = si.du, l0 = si.l0, dl = si.dl;
+  int mu = du, ml = dl;
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) {
+    mu = max(mu, __shfl_xor(mu, o));
+    ml = max(ml, __shfl_xor(ml, o));
+  }
+  const int lu = mu < B ? mu : B, ll = ml < B ? ml : B;
+  auto fma_block = [&](const double (&q)[B], int j) {
+    double xc[R];
+#pragma unroll
+    for (int a = 0; a < R; ++a) xc[a] = V[(size_t)j * T + c * R + a];
+#pragma unroll
+    for (int cc = 0; cc < B; ++cc)
+#pragma unroll
+      for (int a = 0; a < R; ++a) acc[cc][a] = fma(xc[a], q[cc], acc[cc][a]);
+  };
+  for (int k = 0; k < lu; ++k) {  // upper blocks: column c of Q[i,j] = row c of the transposed storage
+    const int j = __shfl(si.ju, gbase + k);
+    if (k < du) {
+      double q[B];
+#pragma unroll
+      for (int pp = 0; pp < B; ++pp) q[pp] = Q.uvalsT[(size_t)(u0 + k) * BB + c * B + pp];
+      fma_block(q, j);
+    }
+  }
+  for (int t = u0 + B; t < u0 + du; ++t) {
+    double q[B];
+#pragma unroll
+    for (int pp = 0; pp < B; ++pp) q[pp] = Q.uvalsT[(size_t)t * BB + c * B + pp];
+    fma_block(q, Q.ucol[t]);
+  }
+  for (int k = 0; k < ll; ++k) {  // lower references: column c of Q[i,j] = row c of Q[j,i] = strided in its storage
+    const int j = __shfl(si.jl, gbase + k);
+    const int sb = __shfl(si.sl, gbase + k);
+    if (k < dl) {
+      double q[B];
+#pragma unroll
+      for (int pp = 0; pp < B; ++pp) q[pp] = Q.uvalsT[(size_t)sb * BB + pp * B + c];
+      fma_block(q, j);
+    }
+  }
+  for (int t = l0 + B; t < l0 + dl; ++t) {
+    double q[B];
+    const size_t sb = (size_t)Q.lslot[t];
+#pragma unroll
+    for (int pp = 0; pp < B; ++pp) q[pp] = Q.uvalsT[sb * BB + pp * B + c];
+    fma_block(q, Q.lcol[t]);
+  }
+  if constexpr (B == 4) {
+    // reduce-scatter butterfly inside the quad (DPP quad_perm, no LDS crossbar): after the xor-1 step a lane holds rows
+    // (c & 1) and 2 + (c & 1) summed over its pair, after the xor-2 step row c summed over the quad
+    const bool p1 = c & 1, p2 = c & 2;
+#pragma unroll
+    for (int a = 0; a < R; ++a) {
+      const double r01 = (p1 ? acc[1][a] : acc[0][a]) + dpp_shifted<0xB1, 0xf, 0xf>(p1 ? acc[0][a] : acc[1][a]);
+      const double r23 = (p1 ? acc[3][a] : acc[2][a]) + dpp_shifted<0xB1, 0xf, 0xf>(p1 ? acc[2][a] : acc[3][a]);
+      out[a] = (p2 ? r23 : r01) + dpp_shifted<0x4E, 0xf, 0xf>(p2 ? r01 : r23);
+    }
+  } else {
+#pragma unroll
+    for (int cc = 0; cc < B; ++cc)
+#pragma unroll
+      for (int a = 0; a < R; ++a) {
+        double v = 0.0;
+#pragma unroll
+        for (int k = 0; k < B; ++k) v += __shfl(acc[cc][a], gbase + k);
+        if (cc == c) out[a] = v;
+      }
+  }
+}
+
+// storage-generic row gather: h = row c of (A V)_i for the lane (g, s, c) of node i
+template <int D, int R, int SPLIT>
+__device__ __forceinline__ void q_gather(const BsrDev& A, const double* __restrict__ V, int i, int s, int c, bool okp,
+                                         double (&h)[R]) {
+  spmm_col<D, R, SPLIT>(A.rowptr, A.colidx, A.vals, V, i, s, c, okp, h);
+}
+template <int D, int R, int SPLIT>
+__device__ __forceinline__ void q_gather(const BsrSymDev& A, const double* __restrict__ V, int i, int s, int c, bool okp,
+                                         double (&h)[R]) {
+  static_assert(SPLIT == 1, "symmetric storage: one node per D+1 lanes");
+  const SymIdx si = sym_idx_load<D>(A, i, c, okp);
+  spmm_sym_pre<D, R>(si, A, V, c, h);
+}
+

@@ -49,8 +49,8 @@ __global__ __launch_bounds__(kBlock) void k_ml_presmooth(const double* __restric
 // Restriction of level l:  rc = P^T (r - (A + shift I) x1)  in one pass over A (needs aggregates that do not straddle
 // workgroup tiles: GEO::P % k == 0).  With `dinv_next` (the next level is not the dense one) the pre-smoothing step of
 // level l+1, x1c = w Dinv_{l+1} rc, rides in the epilogue.
-template <int D, int R, int SPLIT>
-__global__ __launch_bounds__(kBlock) void k_ml_restrict(BsrDev A, const double* __restrict__ x1,
+template <int D, int R, int SPLIT, class MAT = BsrDev>
+__global__ __launch_bounds__(kBlock) void k_ml_restrict(MAT A, const double* __restrict__ x1,
                                                         const double* __restrict__ r, const double* __restrict__ Pb,
                                                         double shift, int k, double* __restrict__ rc,
                                                         const double* __restrict__ dinv_next, double omega,
@@ -71,7 +71,7 @@ __global__ __launch_bounds__(kBlock) void k_ml_restrict(BsrDev A, const double* 
     const size_t off = (size_t)i * GEO::T + L.c * R;
     // (loading the own rows BEFORE the gather was tried and is slower: 35.3 -> 44.3 us at 100k poses)
     double h[R];
-    spmm_col<D, R, SPLIT>(A.rowptr, A.colidx, A.vals, x1, i, L.s, L.c, okp, h);
+    q_gather<D, R, SPLIT>(A, x1, i, L.s, L.c, okp, h);
     if (ok) {
       double xr[R], rr[R];
       load_col<R>(x1 + off, xr);
@@ -287,8 +287,8 @@ __global__ __launch_bounds__(kBlock) void k_ml_post_mid(BsrDev A, const double* 
 
 // Post-smoothing of level 0 in the SpMM's epilogue, tangent projection, and the partial sums <r,r>, <z,r> for the next
 // k_tcg_hess (slots 0 and 1 of every entry of ITS grid):  z = proj_X( x + w Dinv (r - (Q + shift I) x) ).
-template <int D, int R, int SPLIT>
-__global__ __launch_bounds__(kBlock) void k_ml_post(BsrDev Q, const double* __restrict__ X,
+template <int D, int R, int SPLIT, class MAT = BsrDev>
+__global__ __launch_bounds__(kBlock) void k_ml_post(MAT Q, const double* __restrict__ X,
                                                     const double* __restrict__ xv, const double* __restrict__ r,
                                                     const double* __restrict__ dinv, double omega, double shift,
                                                     double* __restrict__ Z, double* __restrict__ pout,
@@ -310,7 +310,7 @@ __global__ __launch_bounds__(kBlock) void k_ml_post(BsrDev Q, const double* __re
     double* vs = ok ? &sm[L.wave][1][L.g][0] : nullptr;
     double* zs = ok ? &sm[L.wave][2][L.g][0] : nullptr;
     double h[R], xr[R], rr[R], z[R];
-    spmm_col<D, R, SPLIT>(Q.rowptr, Q.colidx, Q.vals, xv, i, L.s, L.c, okp, h);
+    q_gather<D, R, SPLIT>(Q, xv, i, L.s, L.c, okp, h);
     if (ok) {  // (loading the own rows BEFORE the gather was tried and is slower: 30.4 -> 37.3 us at 100k poses)
       double x[R];
       load_col<R>(X + off, x);

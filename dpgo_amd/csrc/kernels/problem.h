@@ -31,6 +31,59 @@ __global__ __launch_bounds__(kBlock) void k_spmm(BsrDev Q, const double* __restr
   }
 }
 
+// ================================================================ K1 on symmetric storage (common.h, spmm_sym_pre)
+template <int D, int R>
+__global__ __launch_bounds__(kBlock) void k_spmm_sym(BsrSymDev Q, const double* __restrict__ V,
+                                                     const double* __restrict__ Gadd, double* __restrict__ OUT, int n) {
+  using GEO = Geo<D, R, 1>;
+  const LaneId L = lane_id<D, 1>();
+  const int ntiles = (n + GEO::P - 1) / GEO::P;
+  const TileIter ti_ = tile_iter(ntiles);
+  for (int tile = ti_.first; tile < ti_.last; tile += ti_.step) {
+    const int i = tile * GEO::P + L.wave * GEO::G + L.g;
+    const bool ok = (L.g < GEO::G) && (i < n);
+    const SymIdx si = sym_idx_load<D>(Q, i, L.c, ok);
+    double out[R];
+    spmm_sym_pre<D, R>(si, Q, V, L.c, out);
+    if (ok) {
+      const size_t off = (size_t)i * GEO::T + L.c * R;
+      if (Gadd) {
+#pragma unroll
+        for (int a = 0; a < R; ++a) out[a] += Gadd[off + a];
+      }
+      store_col<R>(OUT + off, out);
+    }
+  }
+}
+
+// refresh of the transposed upper copy after Q's values changed: uvalsT[u][p][q] = vals[src[u]][q][p]
+template <int D>
+__global__ __launch_bounds__(kBlock) void k_sym_refresh(const double* __restrict__ vals, const int32_t* __restrict__ src,
+                                                        double* __restrict__ uvalsT, int nu) {
+  constexpr int B = D + 1, BB = B * B;
+  for (size_t e = (size_t)blockIdx.x * kBlock + threadIdx.x; e < (size_t)nu * BB; e += (size_t)gridDim.x * kBlock) {
+    const size_t u = e / BB;
+    const int p = (int)(e % BB) / B, q = (int)(e % BB) % B;
+    uvalsT[e] = vals[(size_t)src[u] * BB + q * B + p];
+  }
+}
+
+// lower block l (slot lsrc[l] of Q) must be the transpose of its upper block: Q[i,j][p][q] = Q[j,i][q][p] = uvalsT[u][p][q]
+template <int D>
+__global__ __launch_bounds__(kBlock) void k_sym_check(const double* __restrict__ vals, const int32_t* __restrict__ lsrc,
+                                                      const int32_t* __restrict__ lslot, const double* __restrict__ uvalsT,
+                                                      int nl, int* __restrict__ flag) {
+  constexpr int BB = (D + 1) * (D + 1);
+  bool bad = false;
+  for (size_t e = (size_t)blockIdx.x * kBlock + threadIdx.x; e < (size_t)nl * BB; e += (size_t)gridDim.x * kBlock) {
+    const size_t l = e / BB;
+    const int k = (int)(e % BB);
+    const double a = vals[(size_t)lsrc[l] * BB + k], b = uvalsT[(size_t)lslot[l] * BB + k];
+    if (!(fabs(a - b) <= 1e-12 * (fabs(a) + fabs(b)))) bad = true;
+  }
+  if (bad) atomicOr(flag, 1);
+}
+
 // ================================================================ K1+K2: cost + Riemannian gradient
 // One pass over Q gives f(X) = 0.5<XQ,X> + <X,G> (src/QuadraticProblem.cpp:29-41),
 // EG = XQ + G (:43-47), S = sym(Y^T EG_rot) (cached for the Hessian, ROPTLIB EucGradToGrad),

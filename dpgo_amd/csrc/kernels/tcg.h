@@ -357,6 +357,181 @@ __global__ __launch_bounds__(kBlock) void k_tcg_hess_span(BsrDev Q, const double
   DPGO_COMMIT(0);
 }
 
+// k_tcg_hess_span on the symmetric storage of Q (spmm_sym_pre, common.h): big blocks only (one pose per D+1 lanes).  The
+// own-tile pieces of delta / H delta are requested after the gather instead of one tile ahead and z is re-read from LDS, so
+// that the outer-product accumulators fit without losing an occupancy step.
+template <int D, int R>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(DPGO_SYM_WAVES, DPGO_SYM_WAVES))) void k_tcg_hess_sym(BsrSymDev Q, const double* __restrict__ X,
+                                                          const double* __restrict__ S, const double* __restrict__ z,
+                                                          double* __restrict__ delta, double* __restrict__ Hd,
+                                                          const double* __restrict__ pin, int nb_in,
+                                                          double* __restrict__ pout, const DevState* __restrict__ sin,
+                                                          DevState* __restrict__ sout, int first, int n,
+                                                          unsigned long long* hflag, unsigned gen) {
+  constexpr int SPLIT = 1;
+  using GEO = Geo<D, R, SPLIT>;
+  using SPN = Span<D, R, SPLIT>;
+  __shared__ __attribute__((aligned(16))) double sm[kWaves][4][GEO::G][GEO::T];
+  __shared__ double red[kWaves * kNP];
+  const LaneId L = lane_id<D, SPLIT>();
+  const int lane = threadIdx.x & 63;
+  const int ntiles = (n + GEO::P - 1) / GEO::P;
+  const TileIter ti_ = tile_iter(ntiles);
+  double* ys = &sm[L.wave][0][0][0];
+  double* vs = &sm[L.wave][1][0][0];
+  double* hs = &sm[L.wave][2][0][0];
+  double* os = &sm[L.wave][3][0][0];
+
+  // ---- per-tile prefetch state
+  SymIdx si;
+  dbl2 xv[SPN::NIT], zv[SPN::NIT];
+  double srow[D];
+  int p0 = 0, valid = 0, i = 0;
+  bool okp = false, ok = false;
+  auto prefetch = [&](int tile) {
+    p0 = tile * GEO::P + L.wave * GEO::G;
+    const int npose = (n - p0) < GEO::G ? (n - p0) : GEO::G;
+    valid = npose > 0 ? npose * GEO::T : 0;
+    i = p0 + L.g;
+    okp = (L.g < GEO::G) && (i < n);
+    ok = okp && (L.s == 0);
+    si = sym_idx_load<D>(Q, i, L.c, okp);
+    const size_t base = (size_t)p0 * GEO::T;
+    const dbl2* X2 = reinterpret_cast<const dbl2*>(X + base);
+    const dbl2* z2 = reinterpret_cast<const dbl2*>(z + base);
+#pragma unroll
+    for (int it = 0; it < SPN::NIT; ++it) {
+      const int pc = lane + 64 * it;
+      if (2 * pc < valid) {
+        xv[it] = X2[pc];
+        zv[it] = z2[pc];
+      }
+    }
+    if (ok && L.c < D) {
+#pragma unroll
+      for (int a = 0; a < D; ++a) srow[a] = S[(size_t)i * D * D + L.c * D + a];
+    }
+  };
+  // ---- everything the prologue needs is requested before the first wait: state record (scalar loads), the
+  // previous kernel's partial sums (small blocks only: the registers would cost the big-block kernel an
+  // occupancy step), then the first tile.  A small-block launch is a chain of dependent memory round trips
+  // (rocprof: 9.4 us for 2500 poses); this takes two of them off the chain.
+  DPGO_TL_DECL;
+  DPGO_STAMP(0, 0);
+  DevState st;
+  load_state(st, sin);
+  [[maybe_unused]] PartialRaw<2> praw;
+  int tile = ti_.first;
+  bool have = tile < ti_.last;
+  if (have) prefetch(tile);
+
+  DPGO_STAMP(0, 1);
+  // ---- scalar prologue
+  if (st.rtr_stop || st.tcg_done) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+      store_state(sout, st);
+      publish_progress(hflag, gen, st);
+    }
+    return;
+  }
+  double beta;
+  const bool go = tcg_hess_prologue(st, pin, nb_in, first, red, beta, (SPLIT > 1) ? &praw : nullptr);
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    store_state(sout, st);
+    publish_progress(hflag, gen, st);
+  }
+  if (!go) return;
+  DPGO_STAMP(0, 2);
+
+  double part[1] = {0.0};
+  while (have) {
+#pragma unroll
+    for (int it = 0; it < SPN::NIT; ++it) {
+      const int pc = lane + 64 * it;
+      if (2 * pc < valid) {
+        reinterpret_cast<dbl2*>(ys)[pc] = xv[it];
+        reinterpret_cast<dbl2*>(vs)[pc] = zv[it];
+      }
+    }
+    DPGO_STAMP(0, 3);
+    double h[R];
+    spmm_sym_pre<D, R>(si, Q, z, L.c, h);
+    // delta, H delta of the own tile: requested after the gather (its accumulators need the registers), consumed after
+    // the projection
+    dbl2 dv[SPN::NIT], hv[SPN::NIT];
+    if (!first) {
+      const size_t base = (size_t)p0 * GEO::T;
+      const dbl2* d2 = reinterpret_cast<const dbl2*>(delta + base);
+      const dbl2* h2 = reinterpret_cast<const dbl2*>(Hd + base);
+#pragma unroll
+      for (int it = 0; it < SPN::NIT; ++it) {
+        const int pc = lane + 64 * it;
+        if (2 * pc < valid) {
+          dv[it] = d2[pc];
+          hv[it] = h2[pc];
+        }
+      }
+    }
+    wave_sync();
+    DPGO_STAMP(0, 4);
+    if (ok) {
+      if (L.c < D) {
+        const double* vt = vs + L.g * GEO::T;
+#pragma unroll
+        for (int a = 0; a < D; ++a) {
+#pragma unroll
+          for (int k = 0; k < R; ++k) h[k] = fma(-vt[a * R + k], srow[a], h[k]);
+        }
+      }
+      store_col<R>(hs + L.g * GEO::T + L.c * R, h);
+    }
+    wave_sync();
+    if (ok) {
+      double hz[R], sdummy[D];
+      proj_col<D, R>(ys + L.g * GEO::T, hs + L.g * GEO::T, L.c, h, hz, sdummy);
+      store_col<R>(os + L.g * GEO::T + L.c * R, hz);
+    }
+    wave_sync();
+    {
+      const size_t base = (size_t)p0 * GEO::T;
+      dbl2* d2 = reinterpret_cast<dbl2*>(delta + base);
+      dbl2* h2 = reinterpret_cast<dbl2*>(Hd + base);
+#pragma unroll
+      for (int it = 0; it < SPN::NIT; ++it) {
+        const int pc = lane + 64 * it;
+        if (2 * pc < valid) {
+          const dbl2 hzv = reinterpret_cast<const dbl2*>(os)[pc];
+          const dbl2 zl = reinterpret_cast<const dbl2*>(vs)[pc];
+          dbl2 dn, hn;
+          if (first) {
+            dn.x = -zl.x;
+            dn.y = -zl.y;
+            hn.x = -hzv.x;
+            hn.y = -hzv.y;
+          } else {
+            dn.x = fma(beta, dv[it].x, -zl.x);
+            dn.y = fma(beta, dv[it].y, -zl.y);
+            hn.x = fma(beta, hv[it].x, -hzv.x);
+            hn.y = fma(beta, hv[it].y, -hzv.y);
+          }
+          d2[pc] = dn;
+          h2[pc] = hn;
+          part[0] = fma(dn.x, hn.x, part[0]);
+          part[0] = fma(dn.y, hn.y, part[0]);
+        }
+      }
+    }
+    wave_sync();
+    DPGO_STAMP(0, 5);
+    tile += ti_.step;
+    have = tile < ti_.last;
+    if (have) prefetch(tile);
+  }
+  store_partials<1>(part, pout, red);
+  DPGO_STAMP(0, 6);
+  DPGO_COMMIT(0);
+}
+
 template <int D, int R>
 __global__ __launch_bounds__(kBlock) void k_tcg_update_span(const double* __restrict__ X, const double* __restrict__ g,
                                                             const double* __restrict__ dinv,

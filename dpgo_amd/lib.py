@@ -96,6 +96,7 @@ SIGNATURES = {
     "dpgo_problem_eval_device": ([_P, _P, C.POINTER(_D), C.POINTER(_D)], _I),
     "dpgo_problem_eval_terms_device": ([_P, _P, C.POINTER(_D), C.POINTER(_D), C.POINTER(_D)], _I),
     "dpgo_bench_spmm": ([_P, _I, _I, C.POINTER(_D)], _I),
+    "dpgo_problem_set_spmm_variant": ([_P, _I, C.POINTER(_I)], _I),
     "dpgo_bench_spmm_rotating": ([_P, _I, _I, _I, C.POINTER(_D), C.POINTER(_D)], _I),
     "dpgo_bench_hess_rotating": ([_P, _I, _I, _I, C.POINTER(_D)], _I),
     "dpgo_bench_hess": ([_P, _I, _I, C.POINTER(_D)], _I),

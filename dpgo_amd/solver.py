@@ -440,6 +440,17 @@ class QuadraticProblem:
                                                         float(omega), float(shift)))
         return self.multilevelInfo()
 
+    def setSpmmVariant(self, variant: str = "auto") -> str:
+        """Storage the plain Q*V products of this handle read: "plain", "symmetric" (upper blocks only, transposed; for
+        Infinity-Cache-cold blocks) or "auto" (by size).  Returns what the next product will read."""
+        self.refresh()
+        names = {"auto": 0, "plain": 1, "symmetric": 2}
+        if variant not in names:
+            raise ValueError("variant must be one of %s" % sorted(names))
+        v = C.c_int(0)
+        L.check(self._lib.dpgo_problem_set_spmm_variant(self._h, names[variant], C.byref(v)))
+        return "symmetric" if v.value == 2 else "plain"
+
     def autoState(self, use_multilevel=None) -> bool:
         """What precond = "auto" currently runs on this handle (True: the multilevel cycle); a bool argument sets it."""
         v = C.c_int(-1 if use_multilevel is None else int(bool(use_multilevel)))

@@ -258,11 +258,25 @@ int dpgo_problem_eval_device(dpgo_problem_t h, const double* X_dev, double* f, d
  * (f = 0.5 xqx + xg).  Lets a driver assemble the CENTRAL cost 0.5 sum_a (xqx_a + xg_a) from
  * agent-local evaluations (examples/MultiRobotExample.cpp:220-225 does it on a central problem). */
 int dpgo_problem_eval_terms_device(dpgo_problem_t h, const double* X_dev, double* xqx, double* xg, double* g2);
+/* Storage of Q that its products read -- the plain Q*V product (dpgo_spmm_device, dpgo_problem_euc_grad / euc_hess, the
+ * initialisation's PCG) and, in a solve, the fused tCG-step kernel and the level-0 kernels of the multilevel cycle:
+ * PLAIN = the block-CSR arrays as given; SYMMETRIC = upper blocks only, stored transposed, lower blocks by reference
+ * (half of Q's bytes, outer-product gather: faster once Q comes from HBM instead of the 256 MB Infinity Cache, no gain for
+ * cache-resident blocks -- DESIGN.md section 3); AUTO (default) = SYMMETRIC when Q plus eight pose vectors (the tCG loop's
+ * working set) exceed 256 MiB, about 120 000 poses of a 3-D grid.  SYMMETRIC needs one pose per (d+1) lanes (blocks of
+ * >= 40 000 poses) and Q[j,i] == Q[i,j]^T to 1e-12 relative (checked on the device whenever the values change); when either
+ * does not hold the plain arrays are read.  Same results either way up to summation order.  *in_use (optional) = what the
+ * next product will read. */
+#define DPGO_SPMM_AUTO 0
+#define DPGO_SPMM_PLAIN 1
+#define DPGO_SPMM_SYMMETRIC 2
+int dpgo_problem_set_spmm_variant(dpgo_problem_t h, int variant, int* in_use);
 /* time `reps` back-to-back SpMM launches with HIP events on the handle's stream;
  * n_buffers >= 1 rotates that many (V, OUT) buffer pairs; returns average ms per launch */
 int dpgo_bench_spmm(dpgo_problem_t h, int reps, int warmup, double* avg_ms);
 /* As dpgo_bench_spmm, but cycling through nsets private copies of (Q values, block columns, X, OUT) so that no
- * launch finds its operands in the 256 MB Infinity Cache; set_bytes (optional) = bytes of one set. */
+ * launch finds its operands in the 256 MB Infinity Cache; set_bytes (optional) = bytes of one set.  Times the
+ * storage the handle's products read (dpgo_problem_set_spmm_variant). */
 int dpgo_bench_spmm_rotating(dpgo_problem_t h, int nsets, int reps, int warmup, double* avg_ms, double* set_bytes);
 /* same for the dominant kernel of a solve: the fused Q*X + Riemannian-Hessian kernel (one per tCG
  * iteration), on the solver's own buffers (iterate, cached S, search direction) */

@@ -6,12 +6,17 @@
 //   DPGO::LiftedSEManifold    include/DPGO/manifold/LiftedSEManifold.h:28-43
 //   DPGO::ROptParameters / ROPTResult   include/DPGO/DPGO_types.h:44-107
 //   DPGO::PoseGraph (data-matrix part)  include/DPGO/PoseGraph.h:59-69,106-194
+//   DPGO::LiftedSEVariable / LiftedSEVector   include/DPGO/manifold/LiftedSEVariable.h:33-119, LiftedSEVector.h:28-47
+//   DPGO::PGOAgent (hot-path subset: iterate, pose dictionaries, setX / getX)   include/DPGO/PGOAgent.h:250-548
+//   solvePGO / solveRobustPGO / chordalInitialization / odometryInitialization   include/DPGO/DPGO_solver.h
 //
-// so that PGOAgent::updateX (src/PGOAgent.cpp:961-991) and solvePGO (src/DPGO_solver.cpp:322-331)
-// compile unchanged against it.  The reference's Matrix is Eigen::MatrixXd (column-major); this
-// header uses a minimal column-major Matrix with the same data layout so that it builds without
-// Eigen -- with Eigen present, Eigen::Map<const Eigen::MatrixXd>(m.data(), m.rows(), m.cols()) and
-// back are zero-copy views (INTEGRATION.md shows the Eigen-typed shim).
+// so that the bodies of PGOAgent::updateX (src/PGOAgent.cpp:961-991) and solvePGO (src/DPGO_solver.cpp:322-331) read
+// the same against it.  UNTESTED against the reference's own headers: Eigen, ROPTLIB, glog and Boost are absent from
+// this image, so the namespace is dpgo_hip:: (not DPGO::), Matrix is a minimal column-major class of this header with
+// Eigen::MatrixXd's data layout (with Eigen present, Eigen::Map<const Eigen::MatrixXd>(m.data(), m.rows(), m.cols())
+// and back are zero-copy views) and the ROPTLIB-typed virtuals appear as double*-based overloads; INTEGRATION.md
+// shows the Eigen-typed shim a maintainer would write.  What IS tested: this header compiles with g++ -std=c++17 and
+// re-runs the reference's known-answer tests and the demo schedule on the GPU (tests/cxx/test_shim.cpp).
 //
 // Errors: the reference aborts through glog CHECK; here a dpgo_hip::Error (std::runtime_error) is
 // thrown with the C ABI's message.  Nothing in this header computes on the CPU: without a HIP

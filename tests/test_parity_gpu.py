@@ -381,6 +381,84 @@ def test_spmm_properties_at_full_size(oracle):
     assert relerr(XQ.cpu().numpy(), ref) < 1e-13
 
 
+def _grid2d_measurements(oracle, nx, ny, seed):
+    """SE(2) measurements on an nx x ny lattice (snake odometry + the lattice's other edges), random relative poses."""
+    rng = np.random.default_rng(seed)
+    idx = np.arange(nx * ny).reshape(ny, nx)
+    idx[1::2] = idx[1::2, ::-1].copy()  # boustrophedon numbering: consecutive indices are lattice neighbours
+    pairs = set()
+    for y in range(ny):
+        for x in range(nx):
+            if x + 1 < nx:
+                pairs.add((min(idx[y, x], idx[y, x + 1]), max(idx[y, x], idx[y, x + 1])))
+            if y + 1 < ny:
+                pairs.add((min(idx[y, x], idx[y + 1, x]), max(idx[y, x], idx[y + 1, x])))
+    pairs = np.array(sorted(pairs), dtype=np.int32)
+    m = len(pairs)
+    th = rng.uniform(-np.pi, np.pi, m)
+    R = np.stack([np.stack([np.cos(th), -np.sin(th)], -1), np.stack([np.sin(th), np.cos(th)], -1)], -2)
+    z = np.zeros(m, dtype=np.int32)
+    return oracle.Measurements(2, z, pairs[:, 0].copy(), z.copy(), pairs[:, 1].copy(), R, rng.standard_normal((m, 2)),
+                               rng.uniform(1.0, 50.0, m), rng.uniform(1.0, 50.0, m), np.ones(m),
+                               np.zeros(m, dtype=bool)), nx * ny
+
+
+@pytest.mark.parametrize("d,r", [(3, 5), (3, 4), (2, 3)])
+def test_symmetric_storage_product_matches_plain_and_oracle(oracle, d, r):
+    """DPGO_SPMM_SYMMETRIC (upper blocks only, transposed, outer-product gather): same Q*V (+G) as the plain block-CSR
+    kernel and the oracle's CSR product, also after Q's values change; refused (plain arrays read) for a Q whose lower
+    blocks are not the transposes of the upper ones."""
+    import torch
+    import dpgo_amd
+    if d == 3:
+        meas, n, _ = oracle.synthetic_grid(40, 40, 25, seed=3)
+    else:
+        meas, n = _grid2d_measurements(oracle, 250, 200, seed=4)
+    pg = dpgo_amd.PoseGraph(0, r, d)
+    pg.setMeasurements(to_product_measurements(meas))
+    assert pg.n() == n and n >= 40000
+    rp, ci, v = pg.quadraticMatrix()
+    prob = dpgo_amd.QuadraticProblem(pg)
+    prob.setStream(torch.cuda.current_stream().cuda_stream)
+    assert prob.setSpmmVariant("auto") == "plain"  # below the size switch: the Infinity Cache holds the working set
+    g = torch.Generator(device="cuda").manual_seed(7)
+    X = torch.randn((n, d + 1, r), device="cuda", dtype=torch.float64, generator=g)
+    plain, sym = torch.empty_like(X), torch.empty_like(X)
+    prob.spmmDevice(X, plain)
+    assert prob.setSpmmVariant("symmetric") == "symmetric"
+    prob.spmmDevice(X, sym)
+    torch.cuda.synchronize()
+    Qs = oracle.BSR(n, d + 1, rp, ci, v).to_scipy().tocsr()
+    ref = (Qs @ X.cpu().numpy().reshape(n * (d + 1), r)).reshape(n, d + 1, r)
+    assert relerr(sym.cpu().numpy(), ref) < 1e-13
+    assert relerr(sym.cpu().numpy(), plain.cpu().numpy()) < 1e-13
+    # new values on the same pattern: the transposed copy follows
+    v2 = np.asarray(v) * 1.5
+    dpgo_amd.lib.check(prob._lib.dpgo_problem_update_Q_values(prob.handle, dpgo_amd.lib.ptr(np.ascontiguousarray(v2))))
+    assert prob.setSpmmVariant("symmetric") == "symmetric"
+    prob.spmmDevice(X, sym)
+    torch.cuda.synchronize()
+    assert relerr(sym.cpu().numpy(), 1.5 * ref) < 1e-13
+    # a Q that is not symmetric in its values: the plain arrays are read, the product is still that matrix's
+    v3 = np.array(v, copy=True).reshape(len(ci), d + 1, d + 1)
+    row_of = np.repeat(np.arange(n), np.diff(rp))
+    low = np.nonzero(np.asarray(ci) < row_of)[0][0]
+    v3[low, 0, 1] += 1.0
+    dpgo_amd.lib.check(prob._lib.dpgo_problem_update_Q_values(prob.handle, dpgo_amd.lib.ptr(np.ascontiguousarray(v3))))
+    assert prob.setSpmmVariant("symmetric") == "plain"
+    prob.spmmDevice(X, sym)
+    torch.cuda.synchronize()
+    Q3 = oracle.BSR(n, d + 1, rp, ci, v3).to_scipy().tocsr()
+    ref3 = (Q3 @ X.cpu().numpy().reshape(n * (d + 1), r)).reshape(n, d + 1, r)
+    assert relerr(sym.cpu().numpy(), ref3) < 1e-13
+
+
+def test_symmetric_storage_needs_big_blocks(oracle):
+    import dpgo_amd
+    om, n, d, Q, pg, prob = build_single_agent(oracle, "sphere2500", 5)
+    assert prob.setSpmmVariant("symmetric") == "plain"  # 4 lane groups per pose below 40 000 poses
+
+
 @pytest.mark.parametrize("name,robots,sweeps,precond", [("smallGrid3D", 5, 4, "jacobi"), ("torus3D", 8, 10, "jacobi"),
                                                         ("smallGrid3D", 5, 4, "multilevel"),
                                                         ("torus3D", 8, 10, "multilevel"),
@@ -421,14 +499,17 @@ def test_multi_agent_rbcd_on_one_gpu_matches_oracle(oracle, name, robots, sweeps
     assert costs[-1] < costs[0]
 
 
-def test_whole_solve_at_full_size_matches_oracle(oracle):
+@pytest.mark.parametrize("storage", ["plain", "symmetric"])
+def test_whole_solve_at_full_size_matches_oracle(oracle, storage):
     """BASELINE.json config 4 at full size (100 000 poses, one agent): the first RBCD iterations of the bench's run --
     QuadraticOptimizer::optimize with the reference's default parameters from the perturbed-truth iterate, repeated --
     against the oracles at matched settings: block-Jacobi against the plain-C restatement, the default multilevel
     preconditioner (hierarchy [64], dense coarsest operator of 6 252 unknowns built on the device) against the NumPy
     one.  Every call starts from the oracle's current iterate (far from the optimum the trust-region boundary decides
     the steps and round-off differences between two implementations grow from call to call); per call: same RTR / tCG
-    iteration counts, cost to 1e-9 (+ 1e-4 of the call's decrease), iterate to 1e-6 (1e-4 in calls that move far)."""
+    iteration counts, cost to 1e-9 (+ 1e-4 of the call's decrease), iterate to 1e-6 (1e-4 in calls that move far).
+    storage = "symmetric": the same with every Q product of the tCG loop (k_tcg_hess_sym, level-0 restriction and
+    post-smoothing) on the symmetric storage that blocks beyond the Infinity Cache's size select by themselves."""
     import torch
     import dpgo_amd
     import c_oracle as CO
@@ -439,6 +520,7 @@ def test_whole_solve_at_full_size_matches_oracle(oracle):
     pg = dpgo_amd.PoseGraph(0, r, d)
     pg.setMeasurements(to_product_measurements(meas))
     prob = dpgo_amd.QuadraticProblem(pg)
+    assert prob.setSpmmVariant(storage) == storage
     for precond, calls in (("jacobi", 6), ("multilevel", 6)):
         opt = dpgo_amd.QuadraticOptimizer(prob, dpgo_amd.ROptParameters(precond=precond))
         Xd = torch.tensor(X0, device="cuda", dtype=torch.float64)
@@ -467,6 +549,39 @@ def test_whole_solve_at_full_size_matches_oracle(oracle):
             assert relerr(Xd.cpu().numpy(), Xo) < (1e-6 if dec < 1e-4 * abs(want[2]) else 1e-4), (precond, it)
             total += res.tcg_iterations
         assert total > 60  # the calls reach the regime in which the tCG budget is actually used
+
+
+def test_symmetric_storage_solve_2d_matches_oracle(oracle):
+    """k_tcg_hess_sym for SE(2) (three lanes per pose: shuffle reduction instead of the quad butterfly): 50 000-pose
+    lattice, r = 4, block-Jacobi, two calls against the plain-C restatement; and the same calls on the plain storage."""
+    import torch
+    import dpgo_amd
+    import c_oracle as CO
+    meas, n = _grid2d_measurements(oracle, 250, 200, seed=4)
+    d, r = 2, 4
+    Q = oracle.construct_Q(n, d, meas)
+    pg = dpgo_amd.PoseGraph(0, r, d)
+    pg.setMeasurements(to_product_measurements(meas))
+    prob = dpgo_amd.QuadraticProblem(pg)
+    X0 = random_point(oracle, n, d, r, 11)
+    want = []
+    Xo = X0.copy()
+    for _ in range(2):
+        Xo, ro = CO.optimize(Q, None, Xo, hess_recurrence=True)
+        want.append((Xo.copy(), ro))
+    for storage in ("symmetric", "plain"):
+        assert prob.setSpmmVariant(storage) == storage
+        opt = dpgo_amd.QuadraticOptimizer(prob, dpgo_amd.ROptParameters(precond="jacobi"))
+        Xd = torch.tensor(X0, device="cuda", dtype=torch.float64)
+        for it in range(2):
+            if it:
+                Xd.copy_(torch.tensor(want[it - 1][0]))
+            res = opt.optimizeDevice(Xd)
+            Xw, ro = want[it]
+            assert (res.tcg_iterations, res.rtr_iterations) == (ro.tcg_iterations, ro.rtr_iterations), (storage, it)
+            dec = abs(res.fInit - res.fOpt)
+            assert abs(res.fOpt - ro.fOpt) <= 1e-9 * abs(ro.fOpt) + 1e-4 * dec, (storage, it)
+            assert relerr(Xd.cpu().numpy(), Xw) < 1e-5, (storage, it)
 
 
 @pytest.mark.parametrize("name,r,precond", [("smallGrid3D", 5, "jacobi"), ("sphere2500", 5, "jacobi"),
