@@ -519,11 +519,14 @@ def main():
         qb = nnzb_local * (8 * b_ * b_ + 4) + 4 * (n_local + 1)
         pbb = 8 * b_ * b_ * n_local
         Nc = ml_info["sizes"][-1] * b_
+        cbits = agent.problem.multilevelCoarseBits()
+        ml_info["coarse_inverse_bits"] = cbits
         kernels += [
             dict(kernel="k_ml_restrict, level 0 (r - A x1 in one pass over Q, P^T, aggregate sums)",
                  bytes_per_launch=qb + 2 * vec + pbb + vec // ml_info["ks"][0], avg_launch_us=ms_it[1] * 1e3),
-            dict(kernel="k_ml_coarse_prolong (dense inverse of %d unknowns, fp64, + prolongation)" % Nc,
-                 bytes_per_launch=8 * Nc * Nc + 8 * r * Nc + (2 * vec + pbb if len(ml_info["ks"]) == 1 else 0),
+            dict(kernel="k_ml_coarse_prolong (dense inverse of %d unknowns stored in fp%d, fp64 arithmetic, + "
+                        "prolongation)" % (Nc, cbits),
+                 bytes_per_launch=(cbits // 8) * Nc * Nc + 8 * r * Nc + (2 * vec + pbb if len(ml_info["ks"]) == 1 else 0),
                  avg_launch_us=ms_it[2] * 1e3),
             dict(kernel="k_ml_post (post-smoothing in the SpMM epilogue, projection, <r,r>, <z,r>)",
                  bytes_per_launch=qb + 4 * vec + pbb, avg_launch_us=ms_it[3] * 1e3),

@@ -128,6 +128,8 @@ struct dpgo_problem_s {
   bool ml_symbolic = false, ml_ready = false, ml_user_ks = false;
   double ml_omega = 0.7, ml_shift = 1e-1;
   double* ml_dense = nullptr;  // inverse of the coarsest operator, row-major, leading dimension ml_lda
+  float* ml_dense32 = nullptr;  // its fp32 storage (what the cycle streams when ml_coarse_bits == 32)
+  int ml_coarse_bits = 32;
   int ml_lda = 0;
   double *ml_W = nullptr, *ml_Rx = nullptr;  // Gauss-Jordan panels (setup only)
   bool auto_ml = false;  // DPGO_PRECOND_AUTO: the multilevel cycle is currently selected
@@ -586,10 +588,11 @@ void ml_free(dpgo_problem_s* p) {
       if (q) (void)hipFree(q);
   }
   p->ml.clear();
-  void* ptrs[] = {p->ml_dense, p->ml_W, p->ml_Rx};
+  void* ptrs[] = {p->ml_dense, p->ml_W, p->ml_Rx, p->ml_dense32};
   for (void* q : ptrs)
     if (q) (void)hipFree(q);
   p->ml_dense = p->ml_W = p->ml_Rx = nullptr;
+  p->ml_dense32 = nullptr;
   p->ml_lda = 0;
   p->ml_symbolic = p->ml_ready = false;
 }
@@ -654,6 +657,7 @@ int ml_symbolic_setup(dpgo_problem_s* p, const std::vector<int>& ks) {
   p->ml_lda = ((N + kNB - 1) / kNB) * kNB;
   // + 8 rows: the apply kernel reads (and discards) the rows of a ghost node behind a ragged last node group
   HIPC(hipMalloc(&p->ml_dense, sizeof(double) * (size_t)p->ml_lda * (p->ml_lda + 8)));
+  HIPC(hipMalloc(&p->ml_dense32, sizeof(float) * (size_t)p->ml_lda * (p->ml_lda + 8)));
   HIPC(hipMalloc(&p->ml_W, sizeof(double) * (size_t)p->ml_lda * kNB));
   HIPC(hipMalloc(&p->ml_Rx, sizeof(double) * (size_t)p->ml_lda * kNB));
   HIPC(hipStreamSynchronize(p->stream));
@@ -711,7 +715,14 @@ int ml_numeric_setup_d(dpgo_problem_s* p) {
   hipLaunchKernelGGL(k_ml_dense_assemble<D>, dim3(flat_grid(Lc.A.nnzb)), dim3(kBlock), 0, p->stream, Lc.A.dev(),
                      Lc.slot_row, p->ml_dense, lda, Lc.A.nnzb);
   HIPC(hipGetLastError());
-  return dense_spd_inverse(p->stream, p->ml_dense, lda, p->ml_W, p->ml_Rx, gj_use_mfma());
+  CHK(dense_spd_inverse(p->stream, p->ml_dense, lda, p->ml_W, p->ml_Rx, gj_use_mfma()));
+  if (p->ml_coarse_bits == 32) {
+    const size_t total = (size_t)lda * (lda + 8);
+    hipLaunchKernelGGL(k_dense_round_f32, dim3(flat_grid(total)), dim3(kBlock), 0, p->stream, p->ml_dense, p->ml_dense32,
+                       total);
+    HIPC(hipGetLastError());
+  }
+  return DPGO_OK;
 }
 
 // Numeric setup for the CURRENT values of Q (device only; redone after every re-weighting).
@@ -740,18 +751,33 @@ int ml_ensure(dpgo_problem_s* p, double shift) {
 // most of the chip idle while the dense inverse streams).
 int launch_coarse_prolong(dpgo_problem_s* p, const dpgo_problem_s::MlLevel& L, const dpgo_problem_s::MlLevel& C,
                           const DevState* gate) {
-  const int nodes = C.n >= 1024 ? 2 : 1;
+  int nodes = C.n >= 1024 ? 2 : 1;
+  if (const char* e = std::getenv("DPGO_COARSE_NODES")) {  // tuning knob
+    const int v = std::atoi(e);
+    nodes = (v == 4 || v == 2) ? v : 1;
+  }
   const int groups = (C.n + nodes - 1) / nodes;
   const int rounds = (groups + kMaxGrid - 1) / kMaxGrid;
   const int gc = std::max(1, (groups + rounds - 1) / rounds);
+  const bool f32 = p->ml_coarse_bits == 32;
+#define COARSE_LAUNCH(NODES, MT, MPTR)                                                                               \
+  hipLaunchKernelGGL((k_ml_coarse_prolong<D, R, NODES, MT>), dim3(gc), dim3(kBlock), 0, p->stream, MPTR, p->ml_lda,   \
+                     reinterpret_cast<const MT*>(C.r), L.x1, L.Pb, L.k, L.x, gate, L.n, C.n)
   DISPATCH(p->d, p->r, {
-    if (nodes == 2)
-      hipLaunchKernelGGL((k_ml_coarse_prolong<D, R, 2>), dim3(gc), dim3(kBlock), 0, p->stream, p->ml_dense, p->ml_lda, C.r,
-                         L.x1, L.Pb, L.k, L.x, gate, L.n, C.n);
+    if (nodes == 4 && f32)
+      COARSE_LAUNCH(4, float, p->ml_dense32);
+    else if (nodes == 4)
+      COARSE_LAUNCH(4, double, p->ml_dense);
+    else if (nodes == 2 && f32)
+      COARSE_LAUNCH(2, float, p->ml_dense32);
+    else if (nodes == 2)
+      COARSE_LAUNCH(2, double, p->ml_dense);
+    else if (f32)
+      COARSE_LAUNCH(1, float, p->ml_dense32);
     else
-      hipLaunchKernelGGL((k_ml_coarse_prolong<D, R, 1>), dim3(gc), dim3(kBlock), 0, p->stream, p->ml_dense, p->ml_lda, C.r,
-                         L.x1, L.Pb, L.k, L.x, gate, L.n, C.n);
+      COARSE_LAUNCH(1, double, p->ml_dense);
   });
+#undef COARSE_LAUNCH
   HIPC(hipGetLastError());
   return DPGO_OK;
 }
@@ -761,6 +787,10 @@ int launch_coarse_prolong(dpgo_problem_s* p, const dpgo_problem_s::MlLevel& L, c
 int launch_ml_tail(dpgo_problem_s* p, const double* Xdev, const double* r, double* z, double* pout,
                    const DevState* gate) {
   const int nl = (int)p->ml.size();
+  // the dense level reads its right-hand side in the precision its inverse is stored in (same buffer)
+  auto rc32_of = [&](const dpgo_problem_s::MlLevel& C) {
+    return (C.k == 0 && p->ml_coarse_bits == 32) ? reinterpret_cast<float*>(C.r) : (float*)nullptr;
+  };
   auto A_of = [&](int l) { return l == 0 ? p->Q.dev() : p->ml[l].A.dev(); };
   auto r_of = [&](int l) { return l == 0 ? r : (const double*)p->ml[l].r; };
   auto grid_of = [&](const dpgo_problem_s::MlLevel& L) {
@@ -783,11 +813,11 @@ int launch_ml_tail(dpgo_problem_s* p, const double* Xdev, const double* r, doubl
     auto& C = p->ml[l + 1];
     if (l == 0 && p->tcg_sym) {  // level 0 reads Q: the symmetric copy when the tCG-step kernel does
       DISPATCH(p->d, p->r, hipLaunchKernelGGL((k_ml_restrict<D, R, 1, BsrSymDev>), dim3(p->grid_s()), dim3(kBlock), 0,
-                                              p->stream, p->sym.dev(), L.x1, r, L.Pb, p->ml_shift, L.k, C.r,
+                                              p->stream, p->sym.dev(), L.x1, r, L.Pb, p->ml_shift, L.k, C.r, rc32_of(C),
                                               C.k ? C.dinv : (const double*)nullptr, p->ml_omega, C.x1, gate, L.n));
     } else {
       DISPATCH(p->d, p->r, ML_SPLIT_LAUNCH(L, k_ml_restrict, A_of(l), L.x1, r_of(l), L.Pb, l == 0 ? p->ml_shift : 0.0, L.k,
-                                           C.r, C.k ? C.dinv : (const double*)nullptr, p->ml_omega, C.x1, gate, L.n));
+                                           C.r, rc32_of(C), C.k ? C.dinv : (const double*)nullptr, p->ml_omega, C.x1, gate, L.n));
     }
   }
   {  // dense level + prolongation
@@ -1681,6 +1711,20 @@ int dpgo_problem_setup_multilevel(dpgo_problem_t p, int nks, const int* ks, doub
   return DPGO_OK;
 }
 
+int dpgo_problem_multilevel_coarse_bits(dpgo_problem_t p, int* bits) {
+  if (!p || !bits) return fail(DPGO_ERR_INVALID, "null handle / pointer");
+  if (*bits < 0) {
+    *bits = p->ml_coarse_bits;
+    return DPGO_OK;
+  }
+  if (*bits != 32 && *bits != 64) return fail(DPGO_ERR_INVALID, "the coarsest inverse is stored in 32 or 64 bits");
+  if (*bits != p->ml_coarse_bits) {
+    p->ml_coarse_bits = *bits;
+    p->ml_ready = false;  // the stored inverse is rebuilt at the next use
+  }
+  return DPGO_OK;
+}
+
 int dpgo_problem_multilevel_info(dpgo_problem_t p, int* nlevels, int* sizes, int* ks, int* nnzb) {
   if (!p) return fail(DPGO_ERR_INVALID, "null handle");
   if (!p->ml_symbolic) return fail(DPGO_ERR_STATE, "multilevel hierarchy not set up");
@@ -2302,15 +2346,18 @@ int dpgo_bench_iteration_kernels(dpgo_problem_t p, int reps, int warmup, double 
     const int nl = (int)p->ml.size();
     auto& L0 = p->ml[0];
     auto& C1 = p->ml[1];
+    auto rc32_of = [&](const dpgo_problem_s::MlLevel& C) {
+      return (C.k == 0 && p->ml_coarse_bits == 32) ? reinterpret_cast<float*>(C.r) : (float*)nullptr;
+    };
     rc = timed([&]() -> int {
       if (p->tcg_sym) {
         DISPATCH(p->d, p->r, hipLaunchKernelGGL((k_ml_restrict<D, R, 1, BsrSymDev>), dim3(p->grid_s()), dim3(kBlock), 0,
                                                 p->stream, p->sym.dev(), L0.x1, p->rr, L0.Pb, p->ml_shift, L0.k, C1.r,
-                                                C1.k ? C1.dinv : (const double*)nullptr, p->ml_omega, C1.x1,
+                                                rc32_of(C1), C1.k ? C1.dinv : (const double*)nullptr, p->ml_omega, C1.x1,
                                                 (const DevState*)nullptr, p->n));
       } else {
         DISPATCH(p->d, p->r, LAUNCH_SPLIT(p, k_ml_restrict, p->grid_s(), p->Q.dev(), L0.x1, p->rr, L0.Pb, p->ml_shift,
-                                          L0.k, C1.r, C1.k ? C1.dinv : (const double*)nullptr, p->ml_omega, C1.x1,
+                                          L0.k, C1.r, rc32_of(C1), C1.k ? C1.dinv : (const double*)nullptr, p->ml_omega, C1.x1,
                                           (const DevState*)nullptr, p->n));
       }
       HIPC(hipGetLastError());

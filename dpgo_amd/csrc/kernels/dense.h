@@ -160,3 +160,13 @@ __global__ __launch_bounds__(kBlock) void k_gj_update(double* __restrict__ M, in
 __global__ __launch_bounds__(kBlock) void k_dense_pad_identity(double* __restrict__ M, int lda, int N) {
   for (int i = N + blockIdx.x * kBlock + threadIdx.x; i < lda; i += gridDim.x * kBlock) M[(size_t)i * lda + i] = 1.0;
 }
+
+// fp32 storage of the finished inverse; the fp64 array keeps the SAME (rounded) values, so that what the caller can read
+// back (dpgo_problem_multilevel_get) is exactly what the cycle applies
+__global__ __launch_bounds__(kBlock) void k_dense_round_f32(double* __restrict__ M, float* __restrict__ M32, size_t total) {
+  for (size_t e = (size_t)blockIdx.x * kBlock + threadIdx.x; e < total; e += (size_t)gridDim.x * kBlock) {
+    const float v = (float)M[e];
+    M32[e] = v;
+    M[e] = (double)v;
+  }
+}

@@ -48,11 +48,13 @@ __global__ __launch_bounds__(kBlock) void k_ml_presmooth(const double* __restric
 
 // Restriction of level l:  rc = P^T (r - (A + shift I) x1)  in one pass over A (needs aggregates that do not straddle
 // workgroup tiles: GEO::P % k == 0).  With `dinv_next` (the next level is not the dense one) the pre-smoothing step of
-// level l+1, x1c = w Dinv_{l+1} rc, rides in the epilogue.
+// level l+1, x1c = w Dinv_{l+1} rc, rides in the epilogue.  `rc32` (the next level is the dense one and its inverse is
+// stored in fp32): rc is written in fp32 instead.
 template <int D, int R, int SPLIT, class MAT = BsrDev>
 __global__ __launch_bounds__(kBlock) void k_ml_restrict(MAT A, const double* __restrict__ x1,
                                                         const double* __restrict__ r, const double* __restrict__ Pb,
                                                         double shift, int k, double* __restrict__ rc,
+                                                        float* __restrict__ rc32,
                                                         const double* __restrict__ dinv_next, double omega,
                                                         double* __restrict__ x1c, const DevState* __restrict__ gate,
                                                         int n) {
@@ -106,7 +108,12 @@ __global__ __launch_bounds__(kBlock) void k_ml_restrict(MAT A, const double* __r
 #pragma unroll
         for (int a = 0; a < R; ++a) acc[a] += t_s[lp + m][L.c * R + a];
       }
-      store_col<R>(rc + (size_t)(i / k) * GEO::T + L.c * R, acc);
+      if (rc32) {  // the dense level reads its right-hand side in the precision its inverse is stored in
+#pragma unroll
+        for (int a = 0; a < R; ++a) rc32[(size_t)(i / k) * GEO::T + L.c * R + a] = (float)acc[a];
+      } else {
+        store_col<R>(rc + (size_t)(i / k) * GEO::T + L.c * R, acc);
+      }
     }
     __syncthreads();
     if (dinv_next) {  // kernel-uniform
@@ -128,20 +135,38 @@ __global__ __launch_bounds__(kBlock) void k_ml_restrict(MAT A, const double* __r
 // xc = M rc (M = dense inverse, row-major with leading dimension lda), then x_i = x1_i + P_i xc_a for the aggregates'
 // nodes.  Every wave takes a quarter of the columns and ALL rows of the workgroup's nodes: the right-hand side rc
 // (R doubles per column: 10x the bytes of a matrix row) is read once per workgroup, not once per row.  A lane owns
-// column PAIRS, so that the matrix rows AND the 2R right-hand-side values move as 16-byte loads (with 8-byte loads the
-// kernel is bound by load issue, not by bytes); NODES = 2 halves the right-hand-side loads per matrix byte once more
-// (the 100k-pose block streams a 313 MB inverse through here).
-template <int D, int R, int NODES>
-__global__ __launch_bounds__(kBlock) void k_ml_coarse_prolong(const double* __restrict__ M, int lda,
-                                                              const double* __restrict__ rc,
+// groups of 16 bytes' worth of columns (2 for an fp64 inverse, 4 for an fp32 one), so that the matrix rows AND the
+// right-hand-side values move as 16-byte loads (with 8-byte loads the kernel is bound by load issue, not by bytes);
+// NODES = 2 halves the right-hand-side loads per matrix byte once more.
+// MT = float: the inverse AND the restricted residual it multiplies are STORED in fp32 (the 100k-pose block streams 156 MB
+// instead of 313 MB through here every cycle, and every workgroup reads the whole right-hand side: that traffic halves
+// too); every product and sum stays fp64.  The coarse-grid correction of a preconditioner does not need more: the
+// Hessian-vector products to the tolerance are the same (oracle experiment in DESIGN.md section 5).
+#ifndef DPGO_COARSE_WAVES
+#define DPGO_COARSE_WAVES 2   // waves per SIMD the kernel is compiled for (<= 256 VGPRs)
+#endif
+#ifndef DPGO_COARSE_UNROLL
+#define DPGO_COARSE_UNROLL 1  // streaming steps whose loads are in flight together (measured: 1 -> 49.4, 2 -> 56.6 us)
+#endif
+template <int D, int R, int NODES, class MT>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(DPGO_COARSE_WAVES, DPGO_COARSE_WAVES))) void k_ml_coarse_prolong(const MT* __restrict__ M, int lda,
+                                                              const MT* __restrict__ rc,
                                                               const double* __restrict__ x1,
                                                               const double* __restrict__ Pb, int k,
                                                               double* __restrict__ x, const DevState* __restrict__ gate,
                                                               int n, int nc) {
   constexpr int B = D + 1, T = B * R, BB = B * B, NR = NODES * B;
+  constexpr int CPL = 16 / (int)sizeof(MT);  // columns per lane and step
+  struct alignas(16) Pack {
+    MT v[CPL];
+  };
   if (gate && (gate->tcg_done || gate->rtr_stop)) return;
+  // partial sums of all 256 threads, one row per (matrix row, right-hand side): summed by a fixed two-stage tree through
+  // LDS (40 wavefront reductions per wave and node group cost more instructions than the streaming loop itself)
+  constexpr int NV = B * R, SEG = 8, SEGLEN = kBlock / SEG;  // one node's values at a time: 40 KB of LDS for d = 3, r = 5
   __shared__ double xc_s[NR][R];
-  __shared__ double part_s[kWaves][NR][R];
+  __shared__ double all_s[NV][kBlock];
+  __shared__ double seg_s[NV][SEG];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int N = nc * B;
   const int ngroups = (nc + NODES - 1) / NODES;
@@ -149,60 +174,72 @@ __global__ __launch_bounds__(kBlock) void k_ml_coarse_prolong(const double* __re
     const int a0 = grp * NODES;
     {
       // rows a0*B .. a0*B + NR - 1; rows past N (ragged last group) are padding rows of the lda x lda array: finite
-      const double* __restrict__ m = M + (size_t)(a0 * B) * lda;
+      const MT* __restrict__ m = M + (size_t)(a0 * B) * lda;
       double acc[NR][R];
 #pragma unroll
       for (int c = 0; c < NR; ++c)
 #pragma unroll
         for (int q = 0; q < R; ++q) acc[c][q] = 0.0;
-      const int npair = (N + 1) >> 1;  // lda is even and >= N: the matrix may be read one column past N (zeros)
-      const dbl2* __restrict__ rc2 = reinterpret_cast<const dbl2*>(rc);
-#pragma unroll 2
-      for (int j2 = wave * 64 + lane; j2 < npair; j2 += kBlock) {
-        dbl2 mv[NR];
+      const int npack = (N + CPL - 1) / CPL;  // lda is a multiple of 64 and >= N: columns past N hold zeros
+      const dbl2* __restrict__ rc2 = reinterpret_cast<const dbl2*>(rc);  // 16-byte pieces: R of them per column pack
+      struct alignas(16) RPack {
+        MT v[CPL * R];
+      };
+#pragma unroll DPGO_COARSE_UNROLL
+      for (int j = wave * 64 + lane; j < npack; j += kBlock) {
+        Pack mv[NR];
 #pragma unroll
-        for (int c = 0; c < NR; ++c)  // streamed once per cycle by exactly one workgroup: non-temporal, so that the
-                                      // inverse does not push Q and the tCG vectors out of the Infinity Cache
-          mv[c] = __builtin_nontemporal_load(reinterpret_cast<const dbl2*>(m + (size_t)c * lda + 2 * j2));
-        double rv[2 * R];  // rc of column 2 j2 in [0, R), of column 2 j2 + 1 in [R, 2R)
-        if (2 * j2 + 1 < N) {
+        for (int c = 0; c < NR; ++c) {  // streamed once per cycle by exactly one workgroup: non-temporal, so that the
+                                        // inverse does not push Q and the tCG vectors out of the Infinity Cache
+          const dbl2 raw = __builtin_nontemporal_load(reinterpret_cast<const dbl2*>(m + (size_t)c * lda + CPL * j));
+          __builtin_memcpy(&mv[c], &raw, 16);
+        }
+        RPack rp;  // rc of column CPL j + cc in [cc R, (cc + 1) R)
+        if (CPL * j + CPL <= N) {
+          dbl2 raw[R];
 #pragma unroll
-          for (int q = 0; q < R; ++q) {
-            const dbl2 v = rc2[(size_t)j2 * R + q];
-            rv[2 * q] = v.x;
-            rv[2 * q + 1] = v.y;
-          }
+          for (int q = 0; q < R; ++q) raw[q] = rc2[(size_t)j * R + q];
+          __builtin_memcpy(&rp, raw, sizeof(rp));
         } else {
 #pragma unroll
-          for (int q = 0; q < R; ++q) {
-            rv[q] = rc[(size_t)(2 * j2) * R + q];
-            rv[R + q] = 0.0;
-          }
+          for (int e = 0; e < CPL * R; ++e)
+            rp.v[e] = (CPL * j + e / R < N) ? rc[(size_t)(CPL * j) * R + e] : (MT)0;
         }
+        double rv[CPL * R];
+#pragma unroll
+        for (int e = 0; e < CPL * R; ++e) rv[e] = (double)rp.v[e];
 #pragma unroll
         for (int c = 0; c < NR; ++c) {
 #pragma unroll
           for (int q = 0; q < R; ++q) {
-            acc[c][q] = fma(mv[c].x, rv[q], acc[c][q]);
-            acc[c][q] = fma(mv[c].y, rv[R + q], acc[c][q]);
+#pragma unroll
+            for (int cc = 0; cc < CPL; ++cc) acc[c][q] = fma((double)mv[c].v[cc], rv[cc * R + q], acc[c][q]);
           }
         }
       }
 #pragma unroll
-      for (int c = 0; c < NR; ++c)
+      for (int nd = 0; nd < NODES; ++nd) {
 #pragma unroll
-        for (int q = 0; q < R; ++q) {
-          const double sum = wave_reduce_lane63(acc[c][q]);
-          if (lane == 63) part_s[wave][c][q] = sum;
+        for (int c = 0; c < B; ++c)
+#pragma unroll
+          for (int q = 0; q < R; ++q) all_s[c * R + q][threadIdx.x] = acc[nd * B + c][q];
+        __syncthreads();
+        for (int tsk = threadIdx.x; tsk < NV * SEG; tsk += kBlock) {  // stage 1: SEG segments of 32 consecutive threads
+          const int v = tsk / SEG, sg = tsk % SEG;
+          double sum = 0.0;
+#pragma unroll 8
+          for (int e = 0; e < SEGLEN; ++e)  // start rotated by the task index: the wave's reads spread over the LDS banks
+            sum += all_s[v][sg * SEGLEN + ((e + tsk) & (SEGLEN - 1))];
+          seg_s[v][sg] = sum;
         }
-    }
-    __syncthreads();
-    if (threadIdx.x < NR * R) {  // fixed-order sum over the waves
-      const int c = threadIdx.x / R, q = threadIdx.x % R;
-      double sum = part_s[0][c][q];
+        __syncthreads();
+        if (threadIdx.x < NV) {  // stage 2
+          double sum = seg_s[threadIdx.x][0];
 #pragma unroll
-      for (int w2 = 1; w2 < kWaves; ++w2) sum += part_s[w2][c][q];
-      xc_s[c][q] = sum;
+          for (int sg = 1; sg < SEG; ++sg) sum += seg_s[threadIdx.x][sg];
+          xc_s[nd * B + threadIdx.x / R][threadIdx.x % R] = sum;
+        }
+      }
     }
     __syncthreads();
     for (int tsk = threadIdx.x; tsk < NODES * k * B; tsk += kBlock) {  // (node, row c) tasks of the aggregates

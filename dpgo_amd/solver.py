@@ -431,10 +431,19 @@ class QuadraticProblem:
 
     # ---- multilevel preconditioner (built on the device; lazily by the first solve, like
     # PoseGraph::constructPreconditioner inside the first PreConditioner call, src/PoseGraph.cpp:582-586) ----
-    def setupMultilevel(self, ks=None, omega: float = 0.7, shift: float = 1e-1) -> dict:
-        """Explicit setup for the current Q: ks = aggregate sizes per coarsening (None: the library's defaults).
+    def multilevelCoarseBits(self, bits=None) -> int:
+        """Storage precision (32 or 64 bits) of the dense inverse of the coarsest operator; an argument sets it."""
+        v = C.c_int(-1 if bits is None else int(bits))
+        L.check(self._lib.dpgo_problem_multilevel_coarse_bits(self._h, C.byref(v)))
+        return int(v.value)
+
+    def setupMultilevel(self, ks=None, omega: float = 0.7, shift: float = 1e-1, coarse_bits=None) -> dict:
+        """Explicit setup for the current Q: ks = aggregate sizes per coarsening (None: the library's defaults),
+        coarse_bits = storage precision of the coarsest inverse (None: keep the handle's, 32 by default).
         Returns multilevelInfo()."""
         self.refresh()
+        if coarse_bits is not None:
+            self.multilevelCoarseBits(coarse_bits)
         ks = L.i32(ks if ks is not None else [])
         L.check(self._lib.dpgo_problem_setup_multilevel(self._h, len(ks), L.ptr(ks) if len(ks) else None,
                                                         float(omega), float(shift)))

@@ -465,8 +465,10 @@ class QuadraticProblem:
     All of them are followed by the tangent projection (QuadraticProblem.cpp:68)."""
 
     def __init__(self, Q: BSR, G: Optional[np.ndarray], r: int, d: int, precond: str = "exact",
-                 shift: float = 0.1, amg_k=None, amg_omega: float = 0.7, amg_gamma: int = 1, amg_nu: int = 1):
+                 shift: float = 0.1, amg_k=None, amg_omega: float = 0.7, amg_gamma: int = 1, amg_nu: int = 1,
+                 amg_coarse_bits: int = 32):
         self.amg_k, self.amg_omega, self._amg = amg_k, amg_omega, None
+        self.amg_coarse_bits = amg_coarse_bits  # storage precision of the coarsest inverse (device default: 32)
         self.amg_gamma, self.amg_nu = amg_gamma, amg_nu  # coarse-level cycle index / smoothing sweeps (experiments)
         self.Q, self.r, self.d, self.n = Q, r, d, Q.n
         self.b = d + 1
@@ -537,7 +539,8 @@ class QuadraticProblem:
     # --- aggregation multigrid V(1,1) cycle (device option "multilevel") ---
     def amg_setup(self):
         """Hierarchy for A_0 = Q + shift I: A_{l+1} = P_l^T A_l P_l (Galerkin), damped block-Jacobi smoother on every
-        level (the diagonal blocks of A_l), dense inverse of the coarsest operator.  All fp64."""
+        level (the diagonal blocks of A_l), dense inverse of the coarsest operator.  All fp64, except that the finished
+        inverse is rounded to fp32 values (`amg_coarse_bits` = 32, the device's storage default; 64 keeps it)."""
         if self._amg is None:
             ks = self.amg_k
             if ks is None:
@@ -564,7 +567,10 @@ class QuadraticProblem:
                 cur = nc
             Ac = A.toarray()
             Ac = 0.5 * (Ac + Ac.T)
-            self._amg = dict(ks=ks, levels=levels, Ac=Ac, AcInv=np.linalg.inv(Ac), nc=cur)
+            AcInv = np.linalg.inv(Ac)
+            if self.amg_coarse_bits == 32:  # the device STORES the inverse in fp32 (products stay fp64)
+                AcInv = AcInv.astype(np.float32).astype(np.float64)
+            self._amg = dict(ks=ks, levels=levels, Ac=Ac, AcInv=AcInv, nc=cur)
         return self._amg
 
     def amg_cycle(self, V):
@@ -573,6 +579,8 @@ class QuadraticProblem:
 
         def cycle(lv, rhs):
             if lv == len(m["levels"]):
+                if self.amg_coarse_bits == 32:  # the dense level reads its right-hand side in its storage precision
+                    rhs = rhs.astype(np.float32).astype(np.float64)
                 return m["AcInv"] @ rhs
             L = m["levels"][lv]
             smooth = lambda res: (L["Dinv"] @ res.reshape(L["n"], b, r)).reshape(res.shape)  # noqa: E731
