@@ -99,12 +99,27 @@ __global__ __launch_bounds__(kBlock) void k_ml_restrict(MAT A, const double* __r
       store_col<R>(&t_s[lp][L.c * R], t);  // zeros for nodes beyond n
     }
     __syncthreads();
-    const bool head = ok && (i % k) == 0;  // the aggregate's first node sums its members (all inside this tile)
+    // Sum over the aggregate's members (all inside this tile).  Large aggregates: all threads first fold runs of 8
+    // members in place (entry e of rows row0 .. row0+7 into row0), the head node then adds k/8 rows instead of k -- a
+    // single node's lanes walking 64 rows serially was a visible part of the kernel.  Fixed order either way.
+    const int mstep = (k >= 16) ? 8 : 1;  // kernel-uniform
+    if (mstep == 8) {
+      const int nseg = (k + 7) / 8, nagg = GEO::P / k;
+      for (int tsk = threadIdx.x; tsk < nagg * nseg * GEO::T; tsk += kBlock) {
+        const int e = tsk % GEO::T, sg = (tsk / GEO::T) % nseg, ag = tsk / (GEO::T * nseg);
+        const int row0 = ag * k + sg * 8;
+        double sacc = t_s[row0][e];
+        for (int m = 1; m < 8 && sg * 8 + m < k; ++m) sacc += t_s[row0 + m][e];
+        t_s[row0][e] = sacc;
+      }
+      __syncthreads();
+    }
+    const bool head = ok && (i % k) == 0;
     double acc[R];
     if (head) {
 #pragma unroll
       for (int a = 0; a < R; ++a) acc[a] = 0.0;
-      for (int m = 0; m < k && lp + m < GEO::P; ++m) {
+      for (int m = 0; m < k && lp + m < GEO::P; m += mstep) {
 #pragma unroll
         for (int a = 0; a < R; ++a) acc[a] += t_s[lp + m][L.c * R + a];
       }
