@@ -269,7 +269,7 @@ def secondary_single_agent(workload, r, precond, steps, warmup, settle):
                 gradnorm_after_step=res.gradNormOpt)
 
 
-def time_to_tolerance(workload, r, precond, tol=1e-2, max_calls=12):
+def time_to_tolerance(workload, r, precond, tol=1e-2, max_calls=12, coarse_bits=None):
     """Products-to-tolerance and time-to-gradnorm: QuadraticOptimizer::optimize (reference defaults) called from the
     initial guess until |rgrad| < tol (the local solver's own tolerance), single agent, single GPU."""
     import torch
@@ -279,6 +279,8 @@ def time_to_tolerance(workload, r, precond, tol=1e-2, max_calls=12):
     ranges, graphs = build_pose_graphs(meas, n, 1, r)
     ag = DeviceAgent(graphs, ExchangePlan(graphs), 0, X0, dpgo_amd.ROptParameters(precond=precond))
     ag.update()  # untimed warm-up
+    if coarse_bits is not None:
+        ag.problem.multilevelCoarseBits(coarse_bits)
     if precond != "jacobi":
         ag.problem.setupMultilevel()  # the hierarchy is a one-time cost per Q (the reference factors inside its first solve)
     ag.problem.autoState(False)       # "auto" starts where a fresh handle starts
@@ -595,6 +597,10 @@ def main():
                     to_tol["%s/%s" % (wl, pc)] = time_to_tolerance(wl, r, pc)
                 except Exception as exc:  # noqa: BLE001
                     to_tol["%s/%s" % (wl, pc)] = {"error": repr(exc)}
+            try:  # opt-in storage mode (NOT the headline configuration): dense level of the hierarchy kept in fp32
+                to_tol["%s/multilevel+fp32_dense_level" % wl] = time_to_tolerance(wl, r, "multilevel", coarse_bits=32)
+            except Exception as exc:  # noqa: BLE001
+                to_tol["%s/multilevel+fp32_dense_level" % wl] = {"error": repr(exc)}
         if args.workload == "grid100k":
             also = {}
             for key, pc in (("sphere2500", "auto"), ("sphere2500_multilevel", "multilevel"), ("sphere2500_jacobi", "jacobi")):

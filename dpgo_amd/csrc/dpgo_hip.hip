@@ -129,7 +129,7 @@ struct dpgo_problem_s {
   double ml_omega = 0.7, ml_shift = 1e-1;
   double* ml_dense = nullptr;  // inverse of the coarsest operator, row-major, leading dimension ml_lda
   float* ml_dense32 = nullptr;  // its fp32 storage (what the cycle streams when ml_coarse_bits == 32)
-  int ml_coarse_bits = 32;
+  int ml_coarse_bits = 64;  // 32: opt-in (dpgo_problem_multilevel_coarse_bits)
   int ml_lda = 0;
   double *ml_W = nullptr, *ml_Rx = nullptr;  // Gauss-Jordan panels (setup only)
   bool auto_ml = false;  // DPGO_PRECOND_AUTO: the multilevel cycle is currently selected
@@ -680,12 +680,13 @@ bool gj_use_mfma() {
 int dense_spd_inverse(hipStream_t s, double* M, int lda, double* W, double* Rx, bool mfma) {
   const int nt = lda / kNB;
   for (int kb = 0; kb < nt; ++kb) {
-    hipLaunchKernelGGL(k_gj_panel, dim3(nt), dim3(kBlock), 0, s, M, lda, kb, W, Rx);
+    hipLaunchKernelGGL(k_sweep_panel, dim3(nt), dim3(kBlock), 0, s, M, lda, kb, W, Rx);
     if (mfma)
-      hipLaunchKernelGGL(k_gj_update<true>, dim3(nt, nt), dim3(kBlock), 0, s, M, lda, kb, W, Rx);
+      hipLaunchKernelGGL(k_sweep_update<true>, dim3(nt, nt), dim3(kBlock), 0, s, M, lda, kb, W, Rx);
     else
-      hipLaunchKernelGGL(k_gj_update<false>, dim3(nt, nt), dim3(kBlock), 0, s, M, lda, kb, W, Rx);
+      hipLaunchKernelGGL(k_sweep_update<false>, dim3(nt, nt), dim3(kBlock), 0, s, M, lda, kb, W, Rx);
   }
+  hipLaunchKernelGGL(k_sweep_finish, dim3(nt, nt), dim3(kBlock), 0, s, M, lda);
   HIPC(hipGetLastError());
   return DPGO_OK;
 }

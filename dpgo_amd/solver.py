@@ -439,7 +439,7 @@ class QuadraticProblem:
 
     def setupMultilevel(self, ks=None, omega: float = 0.7, shift: float = 1e-1, coarse_bits=None) -> dict:
         """Explicit setup for the current Q: ks = aggregate sizes per coarsening (None: the library's defaults),
-        coarse_bits = storage precision of the coarsest inverse (None: keep the handle's, 32 by default).
+        coarse_bits = storage precision of the dense level (None: keep the handle's, 64 by default; 32 = opt-in).
         Returns multilevelInfo()."""
         self.refresh()
         if coarse_bits is not None:

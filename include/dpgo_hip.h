@@ -204,9 +204,10 @@ int dpgo_multilevel_default_ks(int n, int d, int* ks, int* nks); /* *nks in: cap
 int dpgo_problem_setup_multilevel(dpgo_problem_t h, int nks, const int* ks, double omega, double shift);
 int dpgo_problem_multilevel_info(dpgo_problem_t h, int* nlevels, int* sizes, int* ks, int* nnzb);
 int dpgo_problem_multilevel_get(dpgo_problem_t h, int level, int what, void* out_host);
-/* Storage precision of the dense inverse of the coarsest operator: *bits = 32 (default: the cycle streams half the bytes;
- * every product and sum stays fp64, and the number of Hessian-vector products to the tolerance is unchanged -- DESIGN.md
- * section 5) or 64; a negative input only queries.  DPGO_ML_DENSE_INVERSE returns the values the cycle applies. */
+/* Storage precision of the dense level (the inverse of the coarsest operator and the restricted residual it multiplies):
+ * *bits = 64 (default) or 32 (opt-in: the cycle streams half the bytes; every product and sum stays fp64, the number of
+ * Hessian-vector products to the tolerance is unchanged and the optimum does not depend on the preconditioner -- DESIGN.md
+ * section 5); a negative input only queries.  DPGO_ML_DENSE_INVERSE returns the values the cycle applies. */
 int dpgo_problem_multilevel_coarse_bits(dpgo_problem_t h, int* bits);
 /* State of DPGO_PRECOND_AUTO on this handle: *use_multilevel in/out; a negative input only queries. */
 int dpgo_problem_auto_state(dpgo_problem_t h, int* use_multilevel);

@@ -466,9 +466,9 @@ class QuadraticProblem:
 
     def __init__(self, Q: BSR, G: Optional[np.ndarray], r: int, d: int, precond: str = "exact",
                  shift: float = 0.1, amg_k=None, amg_omega: float = 0.7, amg_gamma: int = 1, amg_nu: int = 1,
-                 amg_coarse_bits: int = 32):
+                 amg_coarse_bits: int = 64):
         self.amg_k, self.amg_omega, self._amg = amg_k, amg_omega, None
-        self.amg_coarse_bits = amg_coarse_bits  # storage precision of the coarsest inverse (device default: 32)
+        self.amg_coarse_bits = amg_coarse_bits  # storage precision of the dense level (device default: 64; 32 = opt-in)
         self.amg_gamma, self.amg_nu = amg_gamma, amg_nu  # coarse-level cycle index / smoothing sweeps (experiments)
         self.Q, self.r, self.d, self.n = Q, r, d, Q.n
         self.b = d + 1
@@ -540,7 +540,7 @@ class QuadraticProblem:
     def amg_setup(self):
         """Hierarchy for A_0 = Q + shift I: A_{l+1} = P_l^T A_l P_l (Galerkin), damped block-Jacobi smoother on every
         level (the diagonal blocks of A_l), dense inverse of the coarsest operator.  All fp64, except that the finished
-        inverse is rounded to fp32 values (`amg_coarse_bits` = 32, the device's storage default; 64 keeps it)."""
+        inverse is rounded to fp32 values when `amg_coarse_bits` = 32 (the device's opt-in storage mode; default 64)."""
         if self._amg is None:
             ks = self.amg_k
             if ks is None:

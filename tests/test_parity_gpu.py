@@ -525,12 +525,14 @@ def test_whole_solve_at_full_size_matches_oracle(oracle, storage):
         opt = dpgo_amd.QuadraticOptimizer(prob, dpgo_amd.ROptParameters(precond=precond))
         Xd = torch.tensor(X0, device="cuda", dtype=torch.float64)
         if precond == "multilevel":
-            info = prob.setupMultilevel()
+            bits = 32 if storage == "symmetric" else 64  # the opt-in fp32 storage of the dense level rides along
+            info = prob.setupMultilevel(coarse_bits=bits)
             assert info["ks"] == [64] and info["sizes"] == [100000, 1563]
-            op = oracle.QuadraticProblem(Q, None, r, d, precond="amg", amg_k=info["ks"])
-            inv = prob.multilevelGet(1, "inverse")  # stored in fp32 (the default): see _hierarchy_check
-            assert relerr(inv, op.amg_setup()["AcInv"]) < 1e-7
-            op.amg_setup()["AcInv"] = inv
+            op = oracle.QuadraticProblem(Q, None, r, d, precond="amg", amg_k=info["ks"], amg_coarse_bits=bits)
+            if bits == 32:  # both sides run with the SAME stored inverse (see _hierarchy_check)
+                inv = prob.multilevelGet(1, "inverse")
+                assert relerr(inv, op.amg_setup()["AcInv"]) < 1e-7
+                op.amg_setup()["AcInv"] = inv
         Xo = X0.copy()
         total = 0
         for it in range(calls):
@@ -1234,11 +1236,11 @@ def test_multilevel_preconditioner_matches_oracle(oracle, name, r, ks, bits):
     restatement (`amg`), with the default hierarchy and with explicit 3- and 4-level ones: the device-built hierarchy
     piece by piece, one application to 1e-9, one optimize at matched settings with identical iteration counts and
     iterates to 1e-7, fewer Hessian-vector products / a smaller gradient than block-Jacobi.  bits = storage precision of
-    the coarsest inverse (32 is the default; every product and sum is fp64 either way)."""
+    the dense level (64 is the default, 32 an opt-in; every product and sum is fp64 either way)."""
     import dpgo_amd
     om, n, d, Q, pg, prob = build_single_agent(oracle, name, r)
     X0 = oracle.lift(oracle.chordal_initialization(om, n), r)
-    assert prob.multilevelCoarseBits() == 32
+    assert prob.multilevelCoarseBits() == 64  # the default; 32 is opt-in
     info = prob.setupMultilevel(ks, coarse_bits=bits)
     if ks is None:
         assert info["ks"] == oracle.amg_default_ks(n, d + 1)
