@@ -498,10 +498,12 @@ def main():
         # k_retract / k_rtr_update whose byte counts are exact) + WRITE_SIZE, KB -> bytes; "max" = the full
         # (non-early-exit) launches.  The newest committed summary is used.
         pmc = json.load(open(pmc_files[-1]))
-        for key in ("k_tcg_hess_span<%d, %d, 1>" % (d, r), "k_tcg_hess<%d, %d, 1>" % (d, r)):
+        # (the cold figure's kernel first: k_tcg_hess_sym when the symmetric storage is what HBM-bound blocks run)
+        for key in ("k_tcg_hess_sym<%d, %d>" % (d, r), "k_tcg_hess_span<%d, %d, 1>" % (d, r),
+                    "k_tcg_hess<%d, %d, 1>" % (d, r)):
             if key in pmc.get("FETCH_SIZE_KB", {}) and key in pmc.get("WRITE_SIZE_KB", {}):
                 traffic = (2.0 * pmc["FETCH_SIZE_KB"][key]["max"] + pmc["WRITE_SIZE_KB"][key]["max"]) * 1024.0
-                traffic_src = os.path.relpath(pmc_files[-1], ROOT)
+                traffic_src = "%s [%s]" % (os.path.relpath(pmc_files[-1], ROOT), key)
                 break
     # HBM figure first (SURVEY 8d protocol: every operand of the launch cycles through > 256 MB of private copies, so
     # the 256 MB Infinity Cache cannot serve it); `warm` = back-to-back launches on the solver's own buffers, which is
