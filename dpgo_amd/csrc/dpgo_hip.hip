@@ -758,7 +758,9 @@ int launch_coarse_prolong(dpgo_problem_s* p, const dpgo_problem_s::MlLevel& L, c
     nodes = (v == 4 || v == 2) ? v : 1;
   }
   const int groups = (C.n + nodes - 1) / nodes;
-  const int rounds = (groups + kMaxGrid - 1) / kMaxGrid;
+  int cap = kMaxGrid;
+  if (const char* e = std::getenv("DPGO_COARSE_GRID")) cap = std::max(1, std::atoi(e));  // tuning knob
+  const int rounds = (groups + cap - 1) / cap;
   const int gc = std::max(1, (groups + rounds - 1) / rounds);
   const bool f32 = p->ml_coarse_bits == 32;
 #define COARSE_LAUNCH(NODES, MT, MPTR)                                                                               \

@@ -402,6 +402,18 @@ class QuadraticProblem {
     check(dpgo_problem_multilevel_info(h_, &nl, nullptr, nullptr, nullptr));
     return nl;
   }
+  // Storage of the dense coarsest level (64 bits by default, 32 = opt-in) and of Q for its products (DPGO_SPMM_*; the
+  // default picks the half-size symmetric storage for blocks that no longer fit the Infinity Cache).  See dpgo_hip.h.
+  int multilevelCoarseBits(int bits = -1) {
+    check(dpgo_problem_multilevel_coarse_bits(h_, &bits));
+    return bits;
+  }
+  int setSpmmVariant(int variant = DPGO_SPMM_AUTO) {
+    refresh();
+    int in_use = DPGO_SPMM_PLAIN;
+    check(dpgo_problem_set_spmm_variant(h_, variant, &in_use));
+    return in_use;
+  }
   double f(const Matrix& Y) const {  // src/QuadraticProblem.cpp:29-35
     shape(Y);
     double out = 0;

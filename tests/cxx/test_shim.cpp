@@ -311,7 +311,12 @@ static int run() {
   // hierarchy reach the same optimum as the default (= multilevel, built by the first solve) on the triangle graph
   // (3 poses -> one aggregate: the coarse solve is exact on the kernel modes)
   for (int pc : {DPGO_PRECOND_BLOCK_JACOBI, DPGO_PRECOND_MULTILEVEL}) {
-    if (pc == DPGO_PRECOND_MULTILEVEL) REQUIRE(problem.setupMultilevel({2}) == 2);
+    if (pc == DPGO_PRECOND_MULTILEVEL) {
+      REQUIRE(problem.multilevelCoarseBits() == 64);  // storage defaults: full precision, plain block-CSR on a small block
+      REQUIRE(problem.setSpmmVariant(DPGO_SPMM_SYMMETRIC) == DPGO_SPMM_PLAIN);  // needs blocks of >= 40 000 poses
+      REQUIRE(problem.setSpmmVariant(DPGO_SPMM_AUTO) == DPGO_SPMM_PLAIN);
+      REQUIRE(problem.setupMultilevel({2}) == 2);
+    }
     ROptParameters pm;
     REQUIRE(pm.precond == DPGO_PRECOND_AUTO);
     pm.gradnorm_tol = 1e-9;
