@@ -403,17 +403,18 @@ def _grid2d_measurements(oracle, nx, ny, seed):
                                np.zeros(m, dtype=bool)), nx * ny
 
 
-@pytest.mark.parametrize("d,r", [(3, 5), (3, 4), (2, 3)])
-def test_symmetric_storage_product_matches_plain_and_oracle(oracle, d, r):
+@pytest.mark.parametrize("d,r,dims", [(3, 5, (40, 40, 25)), (3, 4, (41, 41, 24)), (3, 6, (41, 41, 24)), (2, 3, (250, 200)),
+                                      (2, 2, (201, 203))])
+def test_symmetric_storage_product_matches_plain_and_oracle(oracle, d, r, dims):
     """DPGO_SPMM_SYMMETRIC (upper blocks only, transposed, outer-product gather): same Q*V (+G) as the plain block-CSR
     kernel and the oracle's CSR product, also after Q's values change; refused (plain arrays read) for a Q whose lower
     blocks are not the transposes of the upper ones."""
     import torch
     import dpgo_amd
-    if d == 3:
-        meas, n, _ = oracle.synthetic_grid(40, 40, 25, seed=3)
+    if d == 3:  # (41 x 41 x 24 = 40 344 poses: ragged last workgroup tile)
+        meas, n, _ = oracle.synthetic_grid(*dims, seed=3)
     else:
-        meas, n = _grid2d_measurements(oracle, 250, 200, seed=4)
+        meas, n = _grid2d_measurements(oracle, *dims, seed=4)
     pg = dpgo_amd.PoseGraph(0, r, d)
     pg.setMeasurements(to_product_measurements(meas))
     assert pg.n() == n and n >= 40000
