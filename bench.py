@@ -525,16 +525,39 @@ def main():
         Nc = ml_info["sizes"][-1] * b_
         cbits = agent.problem.multilevelCoarseBits()
         ml_info["coarse_inverse_bits"] = cbits
+        path = agent.problem.multilevelPath()
+        ml_info["path"] = path
+        two = len(ml_info["ks"]) == 1
+        nnzb_ap = None
+        if path["ap"]:  # blocks of A P: the distinct aggregates the block columns of every row fall into
+            rp_, ci_, _ = agent.problem.pose_graph_.quadraticMatrix()
+            rows_ = np.repeat(np.arange(n_local, dtype=np.int64), np.diff(rp_))
+            nnzb_ap = int(np.unique(rows_ * (ml_info["sizes"][1] + 1) + np.asarray(ci_) // ml_info["ks"][0]).size)
+        if path["packed_dense"]:
+            nt_ = -(-Nc // 64)
+            dense = dict(kernel="k_ml_coarse_prolong -> k_dense_sym_apply + k_dense_sym_finish (packed lower triangle of the "
+                                "inverse of %d unknowns, fp64, matrix cores)" % Nc,
+                         bytes_per_launch=8 * 64 * 64 * nt_ * (nt_ + 1) // 2 + 2 * 8 * r * Nc + 2 * 8 * r * 64 * nt_ * nt_ // 2)
+        else:
+            dense = dict(kernel="k_ml_coarse_prolong (dense inverse of %d unknowns stored in fp%d, fp64 arithmetic%s)"
+                                % (Nc, cbits, "" if path["ap"] else ", + prolongation"),
+                         bytes_per_launch=(cbits // 8) * Nc * Nc + 8 * r * Nc
+                         + (2 * vec + pbb if two and not path["ap"] else 0))
+        dense["avg_launch_us"] = ms_it[2] * 1e3
+        if path["ap"]:
+            post = dict(kernel="k_ml_post -> k_ml_post_ap (post-smoothing through A P and the coarse solution, prolongation, "
+                               "projection, <r,r>, <z,r>)",
+                        bytes_per_launch=nnzb_ap * (8 * b_ * b_ + 4) + 4 * (n_local + 1) + 4 * vec + 2 * pbb)
+        else:
+            post = dict(kernel="k_ml_post (post-smoothing in the SpMM epilogue, projection, <r,r>, <z,r>)",
+                        bytes_per_launch=qb + 4 * vec + pbb)
+        post["avg_launch_us"] = ms_it[3] * 1e3
         kernels += [
-            dict(kernel="k_ml_restrict, level 0 (r - A x1 in one pass over Q, P^T, aggregate sums)",
-                 bytes_per_launch=qb + 2 * vec + pbb + vec // ml_info["ks"][0], avg_launch_us=ms_it[1] * 1e3),
-            dict(kernel="k_ml_coarse_prolong (dense inverse of %d unknowns stored in fp%d, fp64 arithmetic, + "
-                        "prolongation)" % (Nc, cbits),
-                 bytes_per_launch=(cbits // 8) * Nc * Nc + 8 * r * Nc + (2 * vec + pbb if len(ml_info["ks"]) == 1 else 0),
-                 avg_launch_us=ms_it[2] * 1e3),
-            dict(kernel="k_ml_post (post-smoothing in the SpMM epilogue, projection, <r,r>, <z,r>)",
-                 bytes_per_launch=qb + 4 * vec + pbb, avg_launch_us=ms_it[3] * 1e3),
-        ]
+            dict(kernel="k_ml_restrict, level 0 (r - A x1 in one pass over Q, P^T, aggregate sums%s)"
+                        % (", residual kept" if path["ap"] else ""),
+                 bytes_per_launch=qb + 2 * vec + pbb + vec // ml_info["ks"][0] + (vec if path["ap"] else 0),
+                 avg_launch_us=ms_it[1] * 1e3),
+            dense, post]
     for k_ in kernels:
         k_["achieved"] = k_["bytes_per_launch"] / max(k_["avg_launch_us"], 1e-9) / 1e3
         k_["frac"] = k_["achieved"] / HBM_PEAK_GBS

@@ -122,6 +122,11 @@ struct dpgo_problem_s {
     int32_t* slot_row = nullptr;  // level >= 1: block row of every slot of A
     double *dinv = nullptr, *Pb = nullptr;            // smoother factors; prolongation blocks towards level + 1
     double *r = nullptr, *x1 = nullptr, *x = nullptr;  // restricted residual, pre-smoothed iterate, corrected iterate
+    // level 0 of a two-level hierarchy: AP = (Q + shift I) P (block rows = poses, block columns = level-1 nodes) and the
+    // residual after pre-smoothing, so that the post-smoothing kernel gathers from the SMALL coarse vector:
+    // r - A (x1 + P xc) = (r - A x1) - (A P) xc
+    Bsr AP;
+    double* res1 = nullptr;
   };
   std::vector<MlLevel> ml;
   std::vector<int32_t> h_rowptr, h_colidx;  // host copy of Q's block pattern (symbolic setup of the hierarchy)
@@ -129,10 +134,32 @@ struct dpgo_problem_s {
   double ml_omega = 0.7, ml_shift = 1e-1;
   double* ml_dense = nullptr;  // inverse of the coarsest operator, row-major, leading dimension ml_lda
   float* ml_dense32 = nullptr;  // its fp32 storage (what the cycle streams when ml_coarse_bits == 32)
+  // lower block triangle of the (exactly symmetric) inverse, packed 64 x 64 tiles: what a two-level cycle streams in 64-bit
+  // mode (k_dense_sym_apply: half the bytes); chunk table, partial-sum buffers
+  double *ml_packed = nullptr, *ml_pd = nullptr, *ml_pt = nullptr;
+  DenseChunk* ml_chunks = nullptr;
+  int* ml_chunk_first = nullptr;
+  int ml_nchunks = 0;
+  bool ml_use_dense_sym() const {
+    static const int env = [] {
+      const char* e = std::getenv("DPGO_ML_DENSE_SYM");
+      return e ? std::atoi(e) : -1;
+    }();
+    if (!ml_use_ap() || ml_coarse_bits != 64 || !ml_packed || env == 0) return false;
+    return env == 1 || ml_lda >= 3072;  // below, the row-streaming kernel (one launch, cache-resident inverse) is as fast
+  }
   int ml_coarse_bits = 64;  // 32: opt-in (dpgo_problem_multilevel_coarse_bits)
   int ml_lda = 0;
   double *ml_W = nullptr, *ml_Rx = nullptr;  // Gauss-Jordan panels (setup only)
   bool auto_ml = false;  // DPGO_PRECOND_AUTO: the multilevel cycle is currently selected
+  // two-level hierarchies: level-0 post-smoothing through A P and the coarse solution (k_ml_post_ap); DPGO_ML_AP=0 disables
+  bool ml_use_ap() const {
+    static const bool off = [] {
+      const char* e = std::getenv("DPGO_ML_AP");
+      return e && std::atoi(e) == 0;
+    }();
+    return !off && ml.size() == 2 && ml[0].AP.vals != nullptr;
+  }
   // symmetric copy of Q for the plain SpMM on Infinity-Cache-cold blocks (k_spmm_sym): upper blocks transposed + lower references
   struct SymQ {
     int nu = 0, nl = 0;
@@ -203,7 +230,7 @@ struct dpgo_problem_s {
   // entries of partial region B (<r,r>, <z,r>) that k_tcg_hess has to sum: written by k_tcg_update (its grid) or,
   // with the fused multilevel cycle, by k_ml_post (SpMM-family grid)
   bool zr_from_post = false;
-  int nb_zr() const { return zr_from_post ? grid_s() : grid(); }
+  int nb_zr() const { return zr_from_post ? grid_post() : grid(); }
   int split = 1;  // lane groups per pose in the SpMM kernels (latency layout for small blocks)
   int grid_s() const {  // SpMM kernels (k_spmm, k_grad, k_hess, k_tcg_hess)
     const int P = (64 / (b * split)) * kWaves;
@@ -212,6 +239,17 @@ struct dpgo_problem_s {
     const int cap = tcg_sym ? cap_hs : cap_h;
     return tiles < cap ? tiles : cap;
   }
+  // level-0 restriction / post-smoothing of the multilevel cycle: their own resident-slot counts (lighter kernels than
+  // k_tcg_hess: with 4 instead of 3 waves per SIMD the 1 563 tiles of the 100k block take 2 rounds instead of 3)
+  int cap_restrict = kMaxGrid, cap_post = kMaxGrid;
+  int grid_tiles(int cap) const {
+    const int P = (64 / (b * split)) * kWaves;
+    int tiles = (n + P - 1) / P;
+    if (tiles < 1) tiles = 1;
+    return tiles < cap ? tiles : cap;
+  }
+  int grid_restrict() const { return grid_tiles(cap_restrict); }
+  int grid_post() const { return grid_tiles(cap_post); }
   int grid_spmm() const {  // plain k_spmm: no partial sums, higher occupancy than the fused tCG kernel
     const int P = (64 / (b * split)) * kWaves;
     int tiles = (n + P - 1) / P;
@@ -583,16 +621,22 @@ std::vector<int> ml_default_ks(int n, int b, int split0) {
 void ml_free(dpgo_problem_s* p) {
   for (auto& L : p->ml) {
     free_bsr(L.A);
-    void* ptrs[] = {L.slot_row, L.dinv, L.Pb, L.r, L.x1, L.x};
+    free_bsr(L.AP);
+    void* ptrs[] = {L.slot_row, L.dinv, L.Pb, L.r, L.x1, L.x, L.res1};
     for (void* q : ptrs)
       if (q) (void)hipFree(q);
   }
   p->ml.clear();
-  void* ptrs[] = {p->ml_dense, p->ml_W, p->ml_Rx, p->ml_dense32};
+  void* ptrs[] = {p->ml_dense, p->ml_W, p->ml_Rx, p->ml_dense32, p->ml_packed, p->ml_pd, p->ml_pt, p->ml_chunks,
+                  p->ml_chunk_first};
   for (void* q : ptrs)
     if (q) (void)hipFree(q);
   p->ml_dense = p->ml_W = p->ml_Rx = nullptr;
   p->ml_dense32 = nullptr;
+  p->ml_packed = p->ml_pd = p->ml_pt = nullptr;
+  p->ml_chunks = nullptr;
+  p->ml_chunk_first = nullptr;
+  p->ml_nchunks = 0;
   p->ml_lda = 0;
   p->ml_symbolic = p->ml_ready = false;
 }
@@ -623,6 +667,21 @@ int ml_symbolic_setup(dpgo_problem_s* p, const std::vector<int>& ks) {
         for (int t = rowptr[i]; t < rowptr[i + 1]; ++t) srow[t] = i;
       CHK(upload(&L.slot_row, srow.data(), srow.size(), p->stream));
       HIPC(hipMalloc(&L.r, tb * cur));
+      if (!L.k) HIPC(hipMalloc(&L.x, tb * cur));  // dense level: its solution, read by the level above
+    }
+    if (l == 0 && L.k) {  // pattern of A P: the aggregates the block columns of every row fall into
+      const int k = L.k;
+      std::vector<int32_t> arow(cur + 1, 0), acol;
+      acol.reserve(colidx.size());
+      for (int i = 0; i < cur; ++i) {
+        const size_t first = acol.size();
+        for (int t = rowptr[i]; t < rowptr[i + 1]; ++t) acol.push_back(colidx[t] / k);
+        std::sort(acol.begin() + first, acol.end());
+        acol.erase(std::unique(acol.begin() + first, acol.end()), acol.end());
+        arow[i + 1] = (int32_t)acol.size();
+      }
+      CHK(upload_bsr(L.AP, cur, (cur + k - 1) / k, (int)acol.size(), b, arow.data(), acol.data(), nullptr, p->stream));
+      HIPC(hipMalloc(&L.res1, tb * cur));
     }
     if (L.k) {
       if (l > 0) HIPC(hipMalloc(&L.dinv, sizeof(double) * (size_t)cur * bb));
@@ -658,6 +717,25 @@ int ml_symbolic_setup(dpgo_problem_s* p, const std::vector<int>& ks) {
   // + 8 rows: the apply kernel reads (and discards) the rows of a ghost node behind a ragged last node group
   HIPC(hipMalloc(&p->ml_dense, sizeof(double) * (size_t)p->ml_lda * (p->ml_lda + 8)));
   HIPC(hipMalloc(&p->ml_dense32, sizeof(float) * (size_t)p->ml_lda * (p->ml_lda + 8)));
+  if (p->ml.size() == 2) {  // two levels: the packed lower triangle and the bookkeeping of k_dense_sym_apply
+    const int nT = p->ml_lda / kNB;
+    int chunk = kDenseChunk;
+    if (const char* e = std::getenv("DPGO_DENSE_CHUNK")) chunk = std::max(1, std::atoi(e));  // tuning knob
+    std::vector<DenseChunk> chunks;
+    std::vector<int> first(nT + 1, 0);
+    for (int I = 0; I < nT; ++I) {
+      first[I] = (int)chunks.size();
+      for (int J0 = 0; J0 <= I; J0 += chunk) chunks.push_back(DenseChunk{I, J0, std::min(chunk, I + 1 - J0), 0});
+    }
+    first[nT] = (int)chunks.size();
+    p->ml_nchunks = (int)chunks.size();
+    CHK(upload(&p->ml_chunks, chunks.data(), chunks.size(), p->stream));
+    CHK(upload(&p->ml_chunk_first, first.data(), first.size(), p->stream));
+    HIPC(hipMalloc(&p->ml_packed, sizeof(double) * (size_t)nT * (nT + 1) / 2 * kNB * kNB));
+    HIPC(hipMalloc(&p->ml_pd, sizeof(double) * (size_t)p->ml_nchunks * kNB * p->r));
+    HIPC(hipMalloc(&p->ml_pt, sizeof(double) * (size_t)nT * p->ml_lda * p->r));
+    HIPC(hipStreamSynchronize(p->stream));  // the host vectors go out of scope
+  }
   HIPC(hipMalloc(&p->ml_W, sizeof(double) * (size_t)p->ml_lda * kNB));
   HIPC(hipMalloc(&p->ml_Rx, sizeof(double) * (size_t)p->ml_lda * kNB));
   HIPC(hipStreamSynchronize(p->stream));
@@ -706,6 +784,9 @@ int ml_numeric_setup_d(dpgo_problem_s* p) {
                        (l == 0) ? p->ml_shift : 0.0, L.Pb, L.k, L.n, C.slot_row, C.A.colidx, C.A.vals, C.A.nnzb);
     if (C.k)  // smoother of the next level (level 0 uses the handle's block-Jacobi factors)
       hipLaunchKernelGGL(k_build_dinv<D>, dim3(flat_grid(C.n)), dim3(kBlock), 0, p->stream, C.A.dev(), 0.0, C.dinv, C.n);
+    if (l == 0 && L.AP.vals)
+      hipLaunchKernelGGL(k_ml_build_AP<D>, dim3(flat_grid(L.n)), dim3(kBlock), 0, p->stream, p->Q.dev(), p->ml_shift, L.Pb,
+                         L.k, L.n, L.AP.dev(), L.AP.vals);
     stride = span;
   }
   HIPC(hipGetLastError());
@@ -717,6 +798,11 @@ int ml_numeric_setup_d(dpgo_problem_s* p) {
                      Lc.slot_row, p->ml_dense, lda, Lc.A.nnzb);
   HIPC(hipGetLastError());
   CHK(dense_spd_inverse(p->stream, p->ml_dense, lda, p->ml_W, p->ml_Rx, gj_use_mfma()));
+  if (p->ml_packed) {
+    const int nT = lda / kNB;
+    hipLaunchKernelGGL(k_dense_pack_lower, dim3(nT, nT), dim3(kBlock), 0, p->stream, p->ml_dense, lda, p->ml_packed);
+    HIPC(hipGetLastError());
+  }
   if (p->ml_coarse_bits == 32) {
     const size_t total = (size_t)lda * (lda + 8);
     hipLaunchKernelGGL(k_dense_round_f32, dim3(flat_grid(total)), dim3(kBlock), 0, p->stream, p->ml_dense, p->ml_dense32,
@@ -751,7 +837,7 @@ int ml_ensure(dpgo_problem_s* p, double shift) {
 // matrix byte); balanced rounds: every workgroup takes the same number of node groups (a ragged last round would leave
 // most of the chip idle while the dense inverse streams).
 int launch_coarse_prolong(dpgo_problem_s* p, const dpgo_problem_s::MlLevel& L, const dpgo_problem_s::MlLevel& C,
-                          const DevState* gate) {
+                          const DevState* gate, double* xc_out = nullptr) {
   int nodes = C.n >= 1024 ? 2 : 1;
   if (const char* e = std::getenv("DPGO_COARSE_NODES")) {  // tuning knob
     const int v = std::atoi(e);
@@ -765,7 +851,7 @@ int launch_coarse_prolong(dpgo_problem_s* p, const dpgo_problem_s::MlLevel& L, c
   const bool f32 = p->ml_coarse_bits == 32;
 #define COARSE_LAUNCH(NODES, MT, MPTR)                                                                               \
   hipLaunchKernelGGL((k_ml_coarse_prolong<D, R, NODES, MT>), dim3(gc), dim3(kBlock), 0, p->stream, MPTR, p->ml_lda,   \
-                     reinterpret_cast<const MT*>(C.r), L.x1, L.Pb, L.k, L.x, gate, L.n, C.n)
+                     reinterpret_cast<const MT*>(C.r), L.x1, L.Pb, L.k, L.x, gate, L.n, C.n, xc_out)
   DISPATCH(p->d, p->r, {
     if (nodes == 4 && f32)
       COARSE_LAUNCH(4, float, p->ml_dense32);
@@ -785,6 +871,30 @@ int launch_coarse_prolong(dpgo_problem_s* p, const dpgo_problem_s::MlLevel& L, c
   return DPGO_OK;
 }
 
+// Dense level from the packed lower triangle: xc = A_c^-1 rc into C.x (two launches: partial products, fixed-order sums)
+int launch_dense_sym(dpgo_problem_s* p, const dpgo_problem_s::MlLevel& C, const DevState* gate) {
+  const int N = C.n * p->b, nT = p->ml_lda / kNB;
+  switch (p->r) {
+#define DENSE_SYM_CASE(RR)                                                                                              \
+  case RR:                                                                                                              \
+    hipLaunchKernelGGL((k_dense_sym_apply<RR>), dim3(p->ml_nchunks), dim3(kBlock), 0, p->stream, p->ml_packed,          \
+                       p->ml_chunks, C.r, N, p->ml_lda, p->ml_pd, p->ml_pt, gate);                                       \
+    hipLaunchKernelGGL((k_dense_sym_finish<RR>), dim3(nT, 4), dim3(kBlock), 0, p->stream, p->ml_pd, p->ml_pt,            \
+                       p->ml_chunk_first, nT, N, p->ml_lda, C.x, gate);                                                  \
+    break;
+    DENSE_SYM_CASE(2)
+    DENSE_SYM_CASE(3)
+    DENSE_SYM_CASE(4)
+    DENSE_SYM_CASE(5)
+    DENSE_SYM_CASE(6)
+#undef DENSE_SYM_CASE
+    default:
+      return fail(DPGO_ERR_UNSUPPORTED, "unsupported r");
+  }
+  HIPC(hipGetLastError());
+  return DPGO_OK;
+}
+
 // The launches of one cycle after the pre-smoothing step of level 0 (x1 = w Dinv r is in ml[0].x1):
 // z = proj_X(M^-1 r); partial sums <r,r>, <z,r> into `pout` (may be NULL).  `gate`: state record for early exit.
 int launch_ml_tail(dpgo_problem_s* p, const double* Xdev, const double* r, double* z, double* pout,
@@ -796,8 +906,9 @@ int launch_ml_tail(dpgo_problem_s* p, const double* Xdev, const double* r, doubl
   };
   auto A_of = [&](int l) { return l == 0 ? p->Q.dev() : p->ml[l].A.dev(); };
   auto r_of = [&](int l) { return l == 0 ? r : (const double*)p->ml[l].r; };
+  int g0 = p->grid_restrict();  // grid of the level-0 launches: restriction first, post-smoothing later
   auto grid_of = [&](const dpgo_problem_s::MlLevel& L) {
-    if (&L == &p->ml[0]) return p->grid_s();
+    if (&L == &p->ml[0]) return g0;
     const int P = ml_tile(p->b, L.split);
     return std::max(1, std::min(kMaxGrid, (L.n + P - 1) / P));
   };
@@ -811,22 +922,37 @@ int launch_ml_tail(dpgo_problem_s* p, const double* Xdev, const double* r, doubl
     else                                                                                                 \
       hipLaunchKernelGGL((KERNEL<D, R, 1>), dim3(g_), dim3(kBlock), 0, p->stream, __VA_ARGS__);          \
   } while (0)
+  const bool ap = p->ml_use_ap();  // two levels: the residual after pre-smoothing is kept, the dense level hands over xc
   for (int l = 0; l + 1 < nl; ++l) {  // down
     auto& L = p->ml[l];
     auto& C = p->ml[l + 1];
+    double* res_out = (ap && l == 0) ? L.res1 : nullptr;
     if (l == 0 && p->tcg_sym) {  // level 0 reads Q: the symmetric copy when the tCG-step kernel does
-      DISPATCH(p->d, p->r, hipLaunchKernelGGL((k_ml_restrict<D, R, 1, BsrSymDev>), dim3(p->grid_s()), dim3(kBlock), 0,
+      DISPATCH(p->d, p->r, hipLaunchKernelGGL((k_ml_restrict<D, R, 1, BsrSymDev>), dim3(g0), dim3(kBlock), 0,
                                               p->stream, p->sym.dev(), L.x1, r, L.Pb, p->ml_shift, L.k, C.r, rc32_of(C),
-                                              C.k ? C.dinv : (const double*)nullptr, p->ml_omega, C.x1, gate, L.n));
+                                              C.k ? C.dinv : (const double*)nullptr, p->ml_omega, C.x1, gate, L.n,
+                                              res_out));
     } else {
       DISPATCH(p->d, p->r, ML_SPLIT_LAUNCH(L, k_ml_restrict, A_of(l), L.x1, r_of(l), L.Pb, l == 0 ? p->ml_shift : 0.0, L.k,
-                                           C.r, rc32_of(C), C.k ? C.dinv : (const double*)nullptr, p->ml_omega, C.x1, gate, L.n));
+                                           C.r, rc32_of(C), C.k ? C.dinv : (const double*)nullptr, p->ml_omega, C.x1, gate, L.n,
+                                           res_out));
     }
   }
-  {  // dense level + prolongation
+  {  // dense level (+ prolongation unless the level above does it itself)
     auto& L = p->ml[nl - 2];
     auto& C = p->ml[nl - 1];
-    CHK(launch_coarse_prolong(p, L, C, gate));
+    if (p->ml_use_dense_sym())
+      CHK(launch_dense_sym(p, C, gate));
+    else
+      CHK(launch_coarse_prolong(p, L, C, gate, ap ? C.x : nullptr));
+  }
+  g0 = p->grid_post();
+  if (ap) {
+    auto& L0 = p->ml[0];
+    DISPATCH(p->d, p->r, ML_SPLIT_LAUNCH(L0, k_ml_post_ap, L0.AP.dev(), Xdev, r, L0.res1, p->ml[1].x, L0.Pb, L0.k, p->dinv,
+                                         p->ml_omega, z, pout, gate, p->n));
+    HIPC(hipGetLastError());
+    return DPGO_OK;
   }
   for (int l = nl - 2; l >= 1; --l) {  // up
     auto& L = p->ml[l];
@@ -835,7 +961,7 @@ int launch_ml_tail(dpgo_problem_s* p, const double* Xdev, const double* r, doubl
                                          F.n, gate, L.n));
   }
   if (p->tcg_sym) {
-    DISPATCH(p->d, p->r, hipLaunchKernelGGL((k_ml_post<D, R, 1, BsrSymDev>), dim3(p->grid_s()), dim3(kBlock), 0, p->stream,
+    DISPATCH(p->d, p->r, hipLaunchKernelGGL((k_ml_post<D, R, 1, BsrSymDev>), dim3(g0), dim3(kBlock), 0, p->stream,
                                             p->sym.dev(), Xdev, p->ml[0].x, r, p->dinv, p->ml_omega, p->ml_shift, z, pout,
                                             gate, p->n));
   } else {
@@ -1225,6 +1351,21 @@ int tune_launch_caps(dpgo_problem_s* p) {
         CHK(resident_blocks(k_tcg_hess<D, R, 1>, &p->cap_h));
     }
   });
+  DISPATCH(p->d, p->r, {
+    if (p->split == 4) {
+      CHK(resident_blocks(k_ml_restrict<D, R, 4, BsrDev>, &p->cap_restrict));
+      CHK(resident_blocks(k_ml_post_ap<D, R, 4>, &p->cap_post));
+    } else if (p->split == 2) {
+      CHK(resident_blocks(k_ml_restrict<D, R, 2, BsrDev>, &p->cap_restrict));
+      CHK(resident_blocks(k_ml_post_ap<D, R, 2>, &p->cap_post));
+    } else {
+      CHK(resident_blocks(k_ml_restrict<D, R, 1, BsrDev>, &p->cap_restrict));
+      CHK(resident_blocks(k_ml_post_ap<D, R, 1>, &p->cap_post));
+    }
+  });
+  if (const char* e = std::getenv("DPGO_GRID_ML")) {
+    p->cap_restrict = p->cap_post = std::max(1, std::min(kPartialCap, std::atoi(e)));
+  }
   // tuning knobs (any value up to the partial-sum capacity is valid)
   if (const char* e = std::getenv("DPGO_GRID_UPDATE")) p->cap_u = std::max(1, std::min(kPartialCap, std::atoi(e)));
   if (const char* e = std::getenv("DPGO_GRID_HESS")) p->cap_h = std::max(1, std::min(kPartialCap, std::atoi(e)));
@@ -1711,6 +1852,13 @@ int dpgo_problem_setup_multilevel(dpgo_problem_t p, int nks, const int* ks, doub
   p->ml_shift = shift;
   CHK(ml_numeric_setup(p));
   HIPC(hipStreamSynchronize(p->stream));
+  return DPGO_OK;
+}
+
+int dpgo_problem_multilevel_path(dpgo_problem_t p, int* flags) {
+  if (!p || !flags) return fail(DPGO_ERR_INVALID, "null handle / pointer");
+  if (!p->ml_symbolic) return fail(DPGO_ERR_STATE, "multilevel hierarchy not set up");
+  *flags = (p->ml_use_ap() ? DPGO_ML_PATH_AP : 0) | (p->ml_use_dense_sym() ? DPGO_ML_PATH_PACKED_DENSE : 0);
   return DPGO_OK;
 }
 
@@ -2352,16 +2500,18 @@ int dpgo_bench_iteration_kernels(dpgo_problem_t p, int reps, int warmup, double 
     auto rc32_of = [&](const dpgo_problem_s::MlLevel& C) {
       return (C.k == 0 && p->ml_coarse_bits == 32) ? reinterpret_cast<float*>(C.r) : (float*)nullptr;
     };
+    const bool ap = p->ml_use_ap();
+    double* res_out = ap ? L0.res1 : nullptr;
     rc = timed([&]() -> int {
       if (p->tcg_sym) {
-        DISPATCH(p->d, p->r, hipLaunchKernelGGL((k_ml_restrict<D, R, 1, BsrSymDev>), dim3(p->grid_s()), dim3(kBlock), 0,
+        DISPATCH(p->d, p->r, hipLaunchKernelGGL((k_ml_restrict<D, R, 1, BsrSymDev>), dim3(p->grid_restrict()), dim3(kBlock), 0,
                                                 p->stream, p->sym.dev(), L0.x1, p->rr, L0.Pb, p->ml_shift, L0.k, C1.r,
                                                 rc32_of(C1), C1.k ? C1.dinv : (const double*)nullptr, p->ml_omega, C1.x1,
-                                                (const DevState*)nullptr, p->n));
+                                                (const DevState*)nullptr, p->n, res_out));
       } else {
-        DISPATCH(p->d, p->r, LAUNCH_SPLIT(p, k_ml_restrict, p->grid_s(), p->Q.dev(), L0.x1, p->rr, L0.Pb, p->ml_shift,
+        DISPATCH(p->d, p->r, LAUNCH_SPLIT(p, k_ml_restrict, p->grid_restrict(), p->Q.dev(), L0.x1, p->rr, L0.Pb, p->ml_shift,
                                           L0.k, C1.r, rc32_of(C1), C1.k ? C1.dinv : (const double*)nullptr, p->ml_omega, C1.x1,
-                                          (const DevState*)nullptr, p->n));
+                                          (const DevState*)nullptr, p->n, res_out));
       }
       HIPC(hipGetLastError());
       return DPGO_OK;
@@ -2369,15 +2519,19 @@ int dpgo_bench_iteration_kernels(dpgo_problem_t p, int reps, int warmup, double 
     if (rc == DPGO_OK) rc = timed([&]() -> int {
       auto& L = p->ml[nl - 2];
       auto& Cc = p->ml[nl - 1];
-      return launch_coarse_prolong(p, L, Cc, nullptr);
+      if (p->ml_use_dense_sym()) return launch_dense_sym(p, Cc, nullptr);
+      return launch_coarse_prolong(p, L, Cc, nullptr, ap ? Cc.x : nullptr);
     }, &out_ms[2]);
     if (rc == DPGO_OK) rc = timed([&]() -> int {
-      if (p->tcg_sym) {
-        DISPATCH(p->d, p->r, hipLaunchKernelGGL((k_ml_post<D, R, 1, BsrSymDev>), dim3(p->grid_s()), dim3(kBlock), 0,
+      if (ap) {
+        DISPATCH(p->d, p->r, LAUNCH_SPLIT(p, k_ml_post_ap, p->grid_post(), L0.AP.dev(), p->x1, p->rr, L0.res1, C1.x, L0.Pb, L0.k,
+                                          p->dinv, p->ml_omega, p->z, p->pB(), (const DevState*)nullptr, p->n));
+      } else if (p->tcg_sym) {
+        DISPATCH(p->d, p->r, hipLaunchKernelGGL((k_ml_post<D, R, 1, BsrSymDev>), dim3(p->grid_post()), dim3(kBlock), 0,
                                                 p->stream, p->sym.dev(), p->x1, L0.x, p->rr, p->dinv, p->ml_omega,
                                                 p->ml_shift, p->z, p->pB(), (const DevState*)nullptr, p->n));
       } else {
-        DISPATCH(p->d, p->r, LAUNCH_SPLIT(p, k_ml_post, p->grid_s(), p->Q.dev(), p->x1, L0.x, p->rr, p->dinv, p->ml_omega,
+        DISPATCH(p->d, p->r, LAUNCH_SPLIT(p, k_ml_post, p->grid_post(), p->Q.dev(), p->x1, L0.x, p->rr, p->dinv, p->ml_omega,
                                           p->ml_shift, p->z, p->pB(), (const DevState*)nullptr, p->n));
       }
       HIPC(hipGetLastError());

@@ -253,3 +253,164 @@ __global__ __launch_bounds__(kBlock) void k_dense_round_f32(double* __restrict__
     M[e] = (double)v;
   }
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Applying the inverse from its LOWER block triangle (the inverse is exactly symmetric, k_sweep_finish): half the bytes of
+// the row-streaming kernel (k_ml_coarse_prolong) for the same fp64 result.  Packed storage: tile (I, J <= I) at index
+// I (I + 1) / 2 + J, 64 x 64 row-major.  Every tile is used twice -- xc_I += T rc_J and, off the diagonal,
+// xc_J += T^T rc_I -- so a workgroup (one chunk = kDenseChunk consecutive tiles of one block row: small chunks, many workgroups -- the kernel is latency-bound per tile) produces partial
+// sums: its share of the DIRECT products of block row I (pd[chunk]) and the TRANSPOSED product of each of its tiles
+// (pt[I][J], one writer each).  k_dense_sym_finish adds them in a fixed order.  Tiles are streamed with non-temporal loads
+// (read once per cycle), the next tile is requested before the current one is used.
+constexpr int kDenseChunk = 2;  // measured at 6 252 unknowns: 2 -> 47.9 us (apply + finish), 4 -> 50.4, 8 -> 53.5, 16 -> 71.0
+struct DenseChunk {
+  int I, J0, cnt, pad;
+};
+
+__global__ __launch_bounds__(kBlock) void k_dense_pack_lower(const double* __restrict__ M, int lda,
+                                                             double* __restrict__ packed) {
+  const int tj = blockIdx.x, ti = blockIdx.y;
+  if (tj > ti) return;
+  const int i = threadIdx.x >> 2, q0 = (threadIdx.x & 3) * 16;
+  const double* __restrict__ src = M + (size_t)(ti * kNB + i) * lda + tj * kNB + q0;
+  double* __restrict__ dst = packed + ((size_t)ti * (ti + 1) / 2 + tj) * (kNB * kNB) + i * kNB + q0;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) dst[q] = src[q];
+}
+
+template <int R>
+__global__ __launch_bounds__(kBlock) void k_dense_sym_apply(const double* __restrict__ packed,
+                                                            const DenseChunk* __restrict__ chunks,
+                                                            const double* __restrict__ rc, int N, int lda,
+                                                            double* __restrict__ pd, double* __restrict__ pt,
+                                                            const DevState* __restrict__ gate) {
+  if (gate && (gate->tcg_done || gate->rtr_stop)) return;
+  __shared__ double Ts[kNB][kNB + 1];
+  __shared__ double rcI[kNB][R];
+  __shared__ double rcJ[kNB][R];
+  const DenseChunk ch = chunks[blockIdx.x];
+  auto load_rc = [&](double (*dst)[R], int blk) {
+    for (int e = threadIdx.x; e < kNB * R; e += kBlock) {
+      const int rr = blk * kNB + e / R;
+      dst[e / R][e % R] = (rr < N) ? rc[(size_t)rr * R + e % R] : 0.0;
+    }
+  };
+  // lane-contiguous 16-byte pieces (piece v * 256 + t of the tile's 2048): every load instruction of a wave covers 1 KB of
+  // consecutive bytes.  (A thread reading its own 128 contiguous bytes makes each instruction touch 64 different cache
+  // lines, which non-temporal loads do not keep: 123 us instead of 30.)
+  auto load_tile = [&](int J, dbl2 (&t)[8]) {
+    const dbl2* __restrict__ src = reinterpret_cast<const dbl2*>(
+        packed + ((size_t)ch.I * (ch.I + 1) / 2 + J) * (kNB * kNB)) + threadIdx.x;
+#pragma unroll
+    for (int v = 0; v < 8; ++v) t[v] = __builtin_nontemporal_load(src + v * kBlock);
+  };
+  load_rc(rcI, ch.I);
+  // right-hand-side rows of a block: kNB * R values, threads 0 .. kNB*R/2 - 1 carry two each (requested one tile ahead)
+  constexpr int kRcPairs = kNB * R / 2;
+  auto fetch_rc = [&](int blk, double (&v)[2]) {
+    v[0] = v[1] = 0.0;
+    if ((int)threadIdx.x < kRcPairs) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int e = 2 * threadIdx.x + h, rr = blk * kNB + e / R;
+        if (rr < N) v[h] = rc[(size_t)rr * R + e % R];
+      }
+    }
+  };
+  // Both products of a tile run on the fp64 matrix cores (v_mfma_f64_16x16x4_f64; fragments: A lane l = A[l & 15][l >> 4],
+  // B lane l = B[l >> 4][l & 15], C/D register g = row (l >> 4) + 4 g, column l & 15): wave w owns rows 16 w .. 16 w + 15 of
+  // T (direct) and of T^T (transposed); the R right-hand sides sit in the first R of the 16 B columns.  With plain FMAs the
+  // kernel was bound by LDS reads of the right-hand sides (192 per thread and tile; now 64).
+  const int l = threadIdx.x & 63, w = threadIdx.x >> 6, lr = l & 15, lk = l >> 4;
+  const bool bcol = lr < R;
+  dbl4 accd = dbl4{0.0, 0.0, 0.0, 0.0};
+  dbl2 tnext[8];
+  double rnext[2];
+  load_tile(ch.J0, tnext);
+  fetch_rc(ch.J0, rnext);
+  for (int jj = 0; jj < ch.cnt; ++jj) {
+    const int J = ch.J0 + jj;
+    dbl2 tcur[8];
+#pragma unroll
+    for (int v = 0; v < 8; ++v) tcur[v] = tnext[v];
+    const double rcur[2] = {rnext[0], rnext[1]};
+    if (jj + 1 < ch.cnt) {
+      load_tile(J + 1, tnext);
+      fetch_rc(J + 1, rnext);
+    }
+    __syncthreads();  // the previous tile's LDS reads are done
+#pragma unroll
+    for (int v = 0; v < 8; ++v) {  // piece v * 256 + t = row v * 8 + t / 32, columns 2 (t % 32), + 1
+      const int pr = v * 8 + (threadIdx.x >> 5), pc = (threadIdx.x & 31) * 2;
+      Ts[pr][pc] = tcur[v].x;
+      Ts[pr][pc + 1] = tcur[v].y;
+    }
+    if ((int)threadIdx.x < kRcPairs) {
+      (&rcJ[0][0])[2 * threadIdx.x] = rcur[0];
+      (&rcJ[0][0])[2 * threadIdx.x + 1] = rcur[1];
+    }
+    __syncthreads();
+    // (the K index a lane group lk supplies in step s is 16 lk + s -- any assignment works as long as A and B agree -- which
+    // makes the fragment reads of both products conflict-free on the pitch-65 tile: bank = lr + 16 lk (mod 32))
+#pragma unroll 4
+    for (int st = 0; st < 16; ++st) {  // xc_I += T rc_J
+      const double a = Ts[w * 16 + lr][16 * lk + st];
+      const double b = bcol ? rcJ[16 * lk + st][lr] : 0.0;
+      accd = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, accd, 0, 0, 0);
+    }
+    if (J != ch.I) {  // xc_J += T^T rc_I
+      dbl4 acct = dbl4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll 4
+      for (int st = 0; st < 16; ++st) {
+        const double a = Ts[16 * lk + st][w * 16 + lr];
+        const double b = bcol ? rcI[16 * lk + st][lr] : 0.0;
+        acct = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acct, 0, 0, 0);
+      }
+      if (bcol) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          pt[((size_t)ch.I * lda + (size_t)J * kNB + w * 16 + lk + 4 * g) * R + lr] = acct[g];
+      }
+    }
+  }
+  if (bcol) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) pd[((size_t)blockIdx.x * kNB + w * 16 + lk + 4 * g) * R + lr] = accd[g];
+  }
+}
+
+// xc rows of block J: the transposed products of the tiles below it (block rows I > J) + its direct partial sums (the chunks
+// first[J] .. first[J + 1] - 1 of block row J).  One workgroup per (J, 16 rows): the 16 lanes of a row take every 16th
+// partial each (all loads of a lane independent, <= 7 of them) and join by a butterfly: fixed order.
+template <int R>
+__global__ __launch_bounds__(kBlock) void k_dense_sym_finish(const double* __restrict__ pd, const double* __restrict__ pt,
+                                                             const int* __restrict__ first, int nT, int N, int lda,
+                                                             double* __restrict__ xc,
+                                                             const DevState* __restrict__ gate) {
+  if (gate && (gate->tcg_done || gate->rtr_stop)) return;
+  const int J = blockIdx.x, row = blockIdx.y * 16 + (threadIdx.x >> 4), part = threadIdx.x & 15;
+  double sum[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) sum[r] = 0.0;
+  const double* __restrict__ col = pt + ((size_t)J * kNB + row) * R;
+#pragma unroll 8
+  for (int I = J + 1 + part; I < nT; I += 16) {
+    const double* __restrict__ src = col + (size_t)I * lda * R;
+#pragma unroll
+    for (int r = 0; r < R; ++r) sum[r] += src[r];
+  }
+  for (int c = first[J] + part; c < first[J + 1]; c += 16) {
+    const double* __restrict__ src = pd + ((size_t)c * kNB + row) * R;
+#pragma unroll
+    for (int r = 0; r < R; ++r) sum[r] += src[r];
+  }
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+#pragma unroll
+    for (int o = 8; o >= 1; o >>= 1) sum[r] += __shfl_xor(sum[r], o);
+  }
+  if (part == 0 && J * kNB + row < N) {
+#pragma unroll
+    for (int r = 0; r < R; ++r) xc[((size_t)J * kNB + row) * R + r] = sum[r];
+  }
+}

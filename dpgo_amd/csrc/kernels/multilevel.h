@@ -49,7 +49,7 @@ __global__ __launch_bounds__(kBlock) void k_ml_presmooth(const double* __restric
 // Restriction of level l:  rc = P^T (r - (A + shift I) x1)  in one pass over A (needs aggregates that do not straddle
 // workgroup tiles: GEO::P % k == 0).  With `dinv_next` (the next level is not the dense one) the pre-smoothing step of
 // level l+1, x1c = w Dinv_{l+1} rc, rides in the epilogue.  `rc32` (the next level is the dense one and its inverse is
-// stored in fp32): rc is written in fp32 instead.
+// stored in fp32): rc is written in fp32 instead.  `res_out`: the residual r - A x1 itself is kept (k_ml_post_ap).
 template <int D, int R, int SPLIT, class MAT = BsrDev>
 __global__ __launch_bounds__(kBlock) void k_ml_restrict(MAT A, const double* __restrict__ x1,
                                                         const double* __restrict__ r, const double* __restrict__ Pb,
@@ -57,7 +57,7 @@ __global__ __launch_bounds__(kBlock) void k_ml_restrict(MAT A, const double* __r
                                                         float* __restrict__ rc32,
                                                         const double* __restrict__ dinv_next, double omega,
                                                         double* __restrict__ x1c, const DevState* __restrict__ gate,
-                                                        int n) {
+                                                        int n, double* __restrict__ res_out = nullptr) {
   using GEO = Geo<D, R, SPLIT>;
   if (gate && (gate->tcg_done || gate->rtr_stop)) return;
   __shared__ double res_s[kWaves][GEO::G][GEO::T];  // residual tiles (per wave)
@@ -81,6 +81,7 @@ __global__ __launch_bounds__(kBlock) void k_ml_restrict(MAT A, const double* __r
 #pragma unroll
       for (int a = 0; a < R; ++a) h[a] = rr[a] - h[a] - shift * xr[a];
       store_col<R>(&res_s[L.wave][L.g][L.c * R], h);
+      if (res_out) store_col<R>(res_out + off, h);  // kept for k_ml_post_ap
     }
     wave_sync();
     if (L.s == 0 && L.g < GEO::G) {
@@ -169,7 +170,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(DPGO_COA
                                                               const double* __restrict__ x1,
                                                               const double* __restrict__ Pb, int k,
                                                               double* __restrict__ x, const DevState* __restrict__ gate,
-                                                              int n, int nc) {
+                                                              int n, int nc, double* __restrict__ xc_out = nullptr) {
   constexpr int B = D + 1, T = B * R, BB = B * B, NR = NODES * B;
   constexpr int CPL = 16 / (int)sizeof(MT);  // columns per lane and step
   struct alignas(16) Pack {
@@ -257,6 +258,12 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(DPGO_COA
       }
     }
     __syncthreads();
+    if (xc_out) {  // the level above forms x = x1 + P xc itself (k_ml_post_ap): only the solution leaves
+      if (threadIdx.x < NR * R && a0 * B + threadIdx.x / R < N)
+        xc_out[(size_t)(a0 * B) * R + threadIdx.x] = xc_s[threadIdx.x / R][threadIdx.x % R];
+      __syncthreads();
+      continue;
+    }
     for (int tsk = threadIdx.x; tsk < NODES * k * B; tsk += kBlock) {  // (node, row c) tasks of the aggregates
       const int i = a0 * k + tsk / B, c = tsk % B;
       if (i < n) {
@@ -337,10 +344,13 @@ __global__ __launch_bounds__(kBlock) void k_ml_post_mid(BsrDev A, const double* 
   }
 }
 
+#ifndef DPGO_POST_WAVES
+#define DPGO_POST_WAVES 4  // waves per SIMD the level-0 post-smoothing kernels are compiled for (<= 128 VGPRs, see grid_post())
+#endif
 // Post-smoothing of level 0 in the SpMM's epilogue, tangent projection, and the partial sums <r,r>, <z,r> for the next
 // k_tcg_hess (slots 0 and 1 of every entry of ITS grid):  z = proj_X( x + w Dinv (r - (Q + shift I) x) ).
 template <int D, int R, int SPLIT, class MAT = BsrDev>
-__global__ __launch_bounds__(kBlock) void k_ml_post(MAT Q, const double* __restrict__ X,
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(SPLIT == 1 ? DPGO_POST_WAVES : 1))) void k_ml_post(MAT Q, const double* __restrict__ X,
                                                     const double* __restrict__ xv, const double* __restrict__ r,
                                                     const double* __restrict__ dinv, double omega, double shift,
                                                     double* __restrict__ Z, double* __restrict__ pout,
@@ -387,6 +397,85 @@ __global__ __launch_bounds__(kBlock) void k_ml_post(MAT Q, const double* __restr
     if (ok) {
       double out[R], s[D];
       proj_col<D, R>(ys, zs, L.c, z, out, s);
+      store_col<R>(Z + off, out);
+#pragma unroll
+      for (int a = 0; a < R; ++a) part[1] = fma(out[a], rr[a], part[1]);
+    }
+    wave_sync();
+  }
+  if (pout) store_partials<2>(part, pout, red);
+}
+
+// Level-0 post-smoothing of a TWO-level hierarchy without a gather from a pose vector:
+//   x = x1 + P xc,   r - A x = (r - A x1) - (A P) xc = res1 - AP xc,   z = proj_X( x + w Dinv (res1 - AP xc) ).
+// AP has about half of Q's blocks and its gather reads the coarse solution (a few hundred KB: L2-resident) instead of a 16 MB
+// pose vector; x1 = w Dinv r is recomputed from r (read anyway for <r,r>, <z,r>), the prolongation x1 + P xc happens here and
+// not in the dense kernel.  Same operator as k_ml_post up to summation order.
+template <int D, int R, int SPLIT>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(SPLIT == 1 ? DPGO_POST_WAVES : 1))) void k_ml_post_ap(BsrDev AP, const double* __restrict__ X,
+                                                       const double* __restrict__ r, const double* __restrict__ res1,
+                                                       const double* __restrict__ xc, const double* __restrict__ Pb, int k,
+                                                       const double* __restrict__ dinv, double omega,
+                                                       double* __restrict__ Z, double* __restrict__ pout,
+                                                       const DevState* __restrict__ gate, int n) {
+  using GEO = Geo<D, R, SPLIT>;
+  if (gate && (gate->tcg_done || gate->rtr_stop)) return;
+  __shared__ double sm[kWaves][3][GEO::G][GEO::T];
+  __shared__ double red[kWaves * kNP];
+  const LaneId L = lane_id<D, SPLIT>();
+  const int ntiles = (n + GEO::P - 1) / GEO::P;
+  const TileIter ti_ = tile_iter(ntiles);
+  double part[2] = {0.0, 0.0};
+  for (int tile = ti_.first; tile < ti_.last; tile += ti_.step) {
+    const int i = tile * GEO::P + L.wave * GEO::G + L.g;
+    const bool okp = (L.g < GEO::G) && (i < n);
+    const bool ok = okp && (L.s == 0);
+    const size_t off = (size_t)i * GEO::T + L.c * R;
+    double* ys = ok ? &sm[L.wave][0][L.g][0] : nullptr;
+    double* vs = ok ? &sm[L.wave][1][L.g][0] : nullptr;
+    double* zs = ok ? &sm[L.wave][2][L.g][0] : nullptr;
+    double h[R], rr[R], xcol[R], z[R], dr[GEO::B];
+    spmm_col<D, R, SPLIT>(AP.rowptr, AP.colidx, AP.vals, xc, i, L.s, L.c, okp, h);
+    if (ok) {
+      double x[R], rs[R];
+      load_col<R>(X + off, x);
+      load_col<R>(r + off, rr);
+      load_col<R>(res1 + off, rs);
+#pragma unroll
+      for (int q = 0; q < GEO::B; ++q) dr[q] = dinv[(size_t)i * GEO::BB + L.c * GEO::B + q];
+#pragma unroll
+      for (int a = 0; a < R; ++a) {
+        h[a] = rs[a] - h[a];  // r - A x
+        part[0] = fma(rr[a], rr[a], part[0]);
+      }
+      store_col<R>(ys + L.c * R, x);
+      store_col<R>(vs + L.c * R, rr);
+      store_col<R>(zs + L.c * R, h);
+    }
+    wave_sync();
+    if (ok) {
+      double x1c[R], zc[R];
+      jacobi_col<D, R>(vs, dr, x1c);  // x1 = w Dinv r
+      jacobi_col<D, R>(zs, dr, zc);   // Dinv (r - A x)
+      const double* __restrict__ pb = Pb + (size_t)i * GEO::BB + L.c * GEO::B;
+      const double* __restrict__ xa = xc + (size_t)(i / k) * GEO::T;
+#pragma unroll
+      for (int a = 0; a < R; ++a) xcol[a] = omega * x1c[a];
+#pragma unroll
+      for (int cc = 0; cc < GEO::B; ++cc) {
+        const double pv = pb[cc];
+#pragma unroll
+        for (int a = 0; a < R; ++a) xcol[a] = fma(pv, xa[cc * R + a], xcol[a]);
+      }
+#pragma unroll
+      for (int a = 0; a < R; ++a) z[a] = fma(omega, zc[a], xcol[a]);
+    }
+    wave_sync();  // every lane of the pose has read vs / zs before zs is overwritten
+    if (ok) store_col<R>(zs + L.c * R, z);
+    wave_sync();
+    if (ok) {
+      double out[R], sdummy[D];
+      proj_col<D, R>(ys, zs, L.c, z, out, sdummy);
       store_col<R>(Z + off, out);
 #pragma unroll
       for (int a = 0; a < R; ++a) part[1] = fma(out[a], rr[a], part[1]);
@@ -527,6 +616,41 @@ __global__ __launch_bounds__(kBlock) void k_ml_galerkin(BsrDev A, double shift, 
     for (int p = 0; p < B; ++p)
 #pragma unroll
       for (int q = 0; q < B; ++q) out[p * B + q] = acc[p][q];
+  }
+}
+
+// A P of level 0, values only:  AP[i][a] = sum_{j in a} (Q_ij + [i == j] shift I) P_j.  One thread per block row.
+template <int D>
+__global__ __launch_bounds__(kBlock) void k_ml_build_AP(BsrDev Q, double shift, const double* __restrict__ Pb, int k,
+                                                        int n, BsrDev AP, double* __restrict__ apvals) {
+  constexpr int B = D + 1, BB = B * B;
+  for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+    for (int s = AP.rowptr[i]; s < AP.rowptr[i + 1]; ++s) {
+      const int a = AP.colidx[s];
+      double acc[B][B];
+#pragma unroll
+      for (int p = 0; p < B; ++p)
+#pragma unroll
+        for (int q = 0; q < B; ++q) acc[p][q] = 0.0;
+      for (int t = Q.rowptr[i]; t < Q.rowptr[i + 1]; ++t) {
+        const int j = Q.colidx[t];
+        if (j / k != a) continue;
+        const double* __restrict__ Aij = Q.vals + (size_t)t * BB;
+        const double* __restrict__ Pj = Pb + (size_t)j * BB;
+#pragma unroll
+        for (int p = 0; p < B; ++p)
+#pragma unroll
+          for (int m = 0; m < B; ++m) {
+            const double av = Aij[p * B + m] + ((i == j && p == m) ? shift : 0.0);
+#pragma unroll
+            for (int q = 0; q < B; ++q) acc[p][q] = fma(av, Pj[m * B + q], acc[p][q]);
+          }
+      }
+#pragma unroll
+      for (int p = 0; p < B; ++p)
+#pragma unroll
+        for (int q = 0; q < B; ++q) apvals[(size_t)s * BB + p * B + q] = acc[p][q];
+    }
   }
 }
 

@@ -78,6 +78,7 @@ SIGNATURES = {
     "dpgo_problem_multilevel_info": ([_P, C.POINTER(_I), _P, _P, _P], _I),
     "dpgo_problem_multilevel_get": ([_P, _I, _I, _P], _I),
     "dpgo_dense_spd_inverse": ([_I, _P, _P, _I, _I], _I),
+    "dpgo_problem_multilevel_path": ([_P, C.POINTER(_I)], _I),
     "dpgo_problem_multilevel_coarse_bits": ([_P, C.POINTER(_I)], _I),
     "dpgo_problem_auto_state": ([_P, C.POINTER(_I)], _I),
     "dpgo_problem_set_G": ([_P, _P], _I),

@@ -431,6 +431,12 @@ class QuadraticProblem:
 
     # ---- multilevel preconditioner (built on the device; lazily by the first solve, like
     # PoseGraph::constructPreconditioner inside the first PreConditioner call, src/PoseGraph.cpp:582-586) ----
+    def multilevelPath(self) -> dict:
+        """Which kernels a cycle of the current hierarchy runs: {"ap": bool, "packed_dense": bool} (see dpgo_hip.h)."""
+        v = C.c_int(0)
+        L.check(self._lib.dpgo_problem_multilevel_path(self._h, C.byref(v)))
+        return dict(ap=bool(v.value & 1), packed_dense=bool(v.value & 2))
+
     def multilevelCoarseBits(self, bits=None) -> int:
         """Storage precision (32 or 64 bits) of the dense inverse of the coarsest operator; an argument sets it."""
         v = C.c_int(-1 if bits is None else int(bits))

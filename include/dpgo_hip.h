@@ -204,6 +204,13 @@ int dpgo_multilevel_default_ks(int n, int d, int* ks, int* nks); /* *nks in: cap
 int dpgo_problem_setup_multilevel(dpgo_problem_t h, int nks, const int* ks, double omega, double shift);
 int dpgo_problem_multilevel_info(dpgo_problem_t h, int* nlevels, int* sizes, int* ks, int* nnzb);
 int dpgo_problem_multilevel_get(dpgo_problem_t h, int level, int what, void* out_host);
+/* Which kernels a cycle of the current hierarchy runs (informational; same operator either way up to summation order):
+ * DPGO_ML_PATH_AP = two-level hierarchy: the level-0 post-smoothing reads A P and the coarse solution (k_ml_post_ap) instead of
+ * gathering a pose vector through Q; DPGO_ML_PATH_PACKED_DENSE = the dense level is applied from the packed lower triangle of
+ * its (exactly symmetric) inverse on the fp64 matrix cores (k_dense_sym_apply; 64-bit storage, >= 3072 unknowns). */
+#define DPGO_ML_PATH_AP 1
+#define DPGO_ML_PATH_PACKED_DENSE 2
+int dpgo_problem_multilevel_path(dpgo_problem_t h, int* flags);
 /* Storage precision of the dense level (the inverse of the coarsest operator and the restricted residual it multiplies):
  * *bits = 64 (default) or 32 (opt-in: the cycle streams half the bytes; every product and sum stays fp64, the number of
  * Hessian-vector products to the tolerance is unchanged and the optimum does not depend on the preconditioner -- DESIGN.md

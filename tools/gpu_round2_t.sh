@@ -1,2 +1,3 @@
 #!/bin/bash
-timeout 1200 python -m pytest tests/test_parity_gpu.py -q -m gpu -x -k "symmetric_storage" 2>&1 | tail -3
+timeout 300 python tools/coarse_probe.py "default" 2>&1 | grep -v amdgpu.ids
+timeout 2400 python -m pytest tests -q -m gpu -x 2>&1 | tail -3
