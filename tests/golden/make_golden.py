@@ -36,9 +36,17 @@ X = O.polar_project(rng.standard_normal((n, 4, 5)), 3)
 V = O.tangent_project(X, rng.standard_normal((n, 4, 5)), 3)
 eta = 0.2 * V
 S = p.sym_ytg(X, p.euc_grad(X))
+# the device's multilevel preconditioner (default hierarchy, 64-bit dense level): one application and one optimize
+pm = O.QuadraticProblem(Q, None, 5, 3, precond="amg")
 np.savez_compressed(os.path.join(HERE, "smallGrid3D_vectors.npz"), X=X, V=V, eta=eta, M=M, XQ=p.XQ(X),
                     rgrad=p.rie_grad(X), rhess=p.rie_hess(X, S, V), precond_jacobi=p.precondition(X, V),
+                    precond_multilevel=pm.precondition(X, V),
                     retract=O.qf_retract(X, eta, 3), polar=O.polar_project(M, 3))
+optm = O.QuadraticOptimizer(pm, O.ROptParameters(), hess_recurrence=True)  # the arithmetic the device runs
+optm.optimize(O.lift(O.chordal_initialization(om, n), 5))
+out["smallGrid3D_rtr_trace_multilevel"] = dict(
+    ks=pm.amg_setup()["ks"], tcg_iters=optm.result.tcg_iters, outer_iters=optm.result.outer_iters,
+    fInit=optm.result.fInit, fOpt=optm.result.fOpt, gradNormOpt=optm.result.gradNormOpt)
 opt = O.QuadraticOptimizer(p, O.ROptParameters())
 opt.optimize(O.lift(O.chordal_initialization(om, n), 5))
 out["smallGrid3D_rtr_trace_jacobi"] = dict(

@@ -64,8 +64,8 @@ def test_problem_evaluations_match_oracle(oracle, name, r):
 def test_committed_golden_vectors():
     """The HIP path against the COMMITTED fixtures (tests/golden/, written by make_golden.py) with no oracle in the loop:
     Q*X, Riemannian gradient / Hessian, block-Jacobi preconditioner, qf retraction and polar projection on smallGrid3D
-    (element-wise, 1e-11); f and |rgrad| at a seeded point on all five datasets; the RTR trace of one optimize
-    (iteration counts, cost)."""
+    (element-wise, 1e-11), the multilevel preconditioner (1e-9); f and |rgrad| at a seeded point on all five datasets; the
+    RTR trace of one optimize with either preconditioner (iteration counts, cost)."""
     import json
     import dpgo_amd
     from conftest import GOLDEN
@@ -78,6 +78,7 @@ def test_committed_golden_vectors():
     prob = dpgo_amd.QuadraticProblem(pg)
     X, V = tiles_to_matrix(g["X"]), tiles_to_matrix(g["V"])
     man = dpgo_amd.LiftedSEManifold(r, d, n)
+    assert relerr(matrix_to_tiles(prob.PreConditioner(X, V, "multilevel"), d), g["precond_multilevel"]) < 1e-9
     for got, want in ((prob.EucHessianEta(X, X), "XQ"), (prob.RieGrad(X), "rgrad"), (prob.RieHessianEta(X, V), "rhess"),
                       (prob.PreConditioner(X, V, "jacobi"), "precond_jacobi"),
                       (man.Retraction(X, tiles_to_matrix(g["eta"])), "retract"), (man.project(tiles_to_matrix(g["M"])), "polar")):
@@ -103,6 +104,13 @@ def test_committed_golden_vectors():
     res = opt.getOptResult()
     assert (res.tcg_iterations, res.rtr_iterations) == (tr["tcg_iters"], tr["outer_iters"])
     assert abs(res.fInit - tr["fInit"]) <= 1e-8 * abs(tr["fInit"]) and abs(res.fOpt - tr["fOpt"]) <= 1e-8 * abs(tr["fOpt"])
+    trm = sc["smallGrid3D_rtr_trace_multilevel"]  # the multilevel preconditioner (default hierarchy)
+    optm = dpgo_amd.QuadraticOptimizer(prob, dpgo_amd.ROptParameters(precond="multilevel"))
+    optm.optimize(tiles_to_matrix(synthetic.lift_tiles(chordal_initialization(meas, n), r)))
+    resm = optm.getOptResult()
+    assert prob.multilevelInfo()["ks"] == trm["ks"]
+    assert (resm.tcg_iterations, resm.rtr_iterations) == (trm["tcg_iters"], trm["outer_iters"])
+    assert abs(resm.fOpt - trm["fOpt"]) <= 1e-8 * abs(trm["fOpt"])
 
 
 @pytest.mark.parametrize("d,r,n", [(3, 5, 1000), (3, 3, 17), (2, 2, 64), (2, 5, 333), (3, 6, 129), (3, 5, 1)])
