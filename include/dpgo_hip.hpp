@@ -408,6 +408,11 @@ class QuadraticProblem {
     check(dpgo_problem_multilevel_coarse_bits(h_, &bits));
     return bits;
   }
+  int multilevelPath() {  // DPGO_ML_PATH_* flags of the kernels a cycle of the current hierarchy runs
+    int flags = 0;
+    check(dpgo_problem_multilevel_path(h_, &flags));
+    return flags;
+  }
   int setSpmmVariant(int variant = DPGO_SPMM_AUTO) {
     refresh();
     int in_use = DPGO_SPMM_PLAIN;

@@ -316,6 +316,7 @@ static int run() {
       REQUIRE(problem.setSpmmVariant(DPGO_SPMM_SYMMETRIC) == DPGO_SPMM_PLAIN);  // needs blocks of >= 40 000 poses
       REQUIRE(problem.setSpmmVariant(DPGO_SPMM_AUTO) == DPGO_SPMM_PLAIN);
       REQUIRE(problem.setupMultilevel({2}) == 2);
+      REQUIRE(problem.multilevelPath() == DPGO_ML_PATH_AP);  // two levels, tiny dense level: row-streaming dense kernel
     }
     ROptParameters pm;
     REQUIRE(pm.precond == DPGO_PRECOND_AUTO);
