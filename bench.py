@@ -14,12 +14,17 @@ with the public-pose exchange over RCCL point-to-point.  Total work is fixed as 
 Workload at N = 1: the synthetic 100k-pose 3-D grid of BASELINE.json (configs[3], the configuration the
 HBM-roofline target is quoted on; it fits one GPU).  Inputs are resident in HBM before the timed region.
 
-Prints ONE JSON line (rank 0).  `roofline` is for k_tcg_hess (the fused Q*z SpMM + Riemannian-Hessian epilogue +
-direction recurrences, launched once per tCG iteration -- the Q*X kernel BASELINE's metric names): `frac` is the
-HBM-only figure (every operand cycling through > 256 MB of private copies), `warm` the Infinity-Cache-resident
-one the solver sees; `roofline.kernels` lists the other kernels of one preconditioned tCG iteration.  `cpu_baseline`
-times the CPU oracle on the host cores (rank 0, N = 1 only): the reference configuration (exact sparse factor of
-Q + 0.1 I, the graph cut into 8 agents, one core per agent) and, beside it, the 1-core C port of the device algorithm.
+Prints ONE JSON line (rank 0).  `roofline` describes the tCG-step kernel THE TIMED LOOP LAUNCHES (k_tcg_hess_span on the
+plain block-CSR arrays for every BASELINE configuration; k_tcg_hess_sym where the size switch selects the symmetric
+storage): `frac` is its HBM-only figure (every operand cycling through > 256 MB of private copies), `warm`
+the back-to-back one the Infinity-Cache-resident loop sees; the other storage's figures stand beside it
+(`symmetric_storage` / `plain_storage`, with the fraction on the bytes that storage really moves);
+`roofline.kernels` lists the other kernels of one preconditioned tCG iteration.  `products_per_step` and
+`time_to_tolerance_ms` are top-level: "it/s" alone does not say how much a step does.  `cpu_baseline` (rank 0, N = 1
+only) = the reference configuration of the workload on the host cores (the graph cut into 8 agents, one core each,
+exact sparse factor of Q_a + 0.1 I, ONE two-colour sweep from the initial iterate) and, in `gpu_same_work`, this GPU
+running exactly that: same 8 blocks, same initial iterate, same one sweep, cost and gradient norm after it printed for
+both; beside it the 1-core C port of the device algorithm on the timed single-agent step.
 """
 import argparse
 import json
@@ -51,7 +56,10 @@ def parse_args():
     ap.add_argument("--no-secondary", action="store_true", help="skip the sphere2500 side measurement (`also` field)")
     ap.add_argument("--cpu-budget-s", type=float, default=25.0)
     ap.add_argument("--spmm-reps", type=int, default=200)
-    ap.add_argument("--agents-per-gpu", type=int, default=0, help="0 = auto (1 if one GPU, else 2)")
+    ap.add_argument("--agents-per-gpu", type=int, default=0, help="0 = auto (1 if one GPU, else 2; 8 with --loopback)")
+    ap.add_argument("--loopback", action="store_true",
+                    help="single GPU, several agents: every public-pose exchange and reduction travels through a 1-rank "
+                         "RCCL communicator owned by the solver library (the N > 1 data path on one device)")
     return ap.parse_args()
 
 
@@ -234,6 +242,45 @@ def cpu_baseline_reference(meas_p, n, X_tiles, r, num_agents=8):
                 cost_2f_after=2 * central.f(X), gradnorm_after=central.rie_grad_norm(X), host_cores=os.cpu_count())
 
 
+def gpu_same_decomposition(meas, n, X0, r, num_agents, precond, device):
+    """What cpu_baseline_reference times, on this GPU: the same `num_agents` contiguous blocks, the same initial iterate,
+    ONE two-colour sweep (every agent updates once, RTR 3 x <= 50 tCG, the library's default preconditioner selection),
+    agents of a colour solved concurrently.  Cost and gradient norm of the central problem after the sweep are returned
+    so that the two measurements can be compared as work, not only as time."""
+    import torch
+    import dpgo_amd
+    from dpgo_amd.agent import DeviceAgent, ExchangePlan, RBCDCluster, build_pose_graphs
+    ranges, graphs = build_pose_graphs(meas, n, num_agents, r)
+    plan = ExchangePlan(graphs)
+    params = dpgo_amd.ROptParameters(precond=precond)
+    agents = {a: DeviceAgent(graphs, plan, a, X0[ranges[a][0]:ranges[a][1]], params, device=device)
+              for a in range(num_agents)}
+    cluster = RBCDCluster(plan, agents)
+    for ag in agents.values():
+        ag.snapshot()
+    cluster.sweep()  # untimed: first-use setup (block-Jacobi factors, launch caches)
+    best, products = None, 0
+    for _ in range(3):
+        for ag in agents.values():
+            ag.restore()
+            if precond == "auto":
+                ag.problem.autoState(False)  # a fresh block of a multi-agent problem starts on block-Jacobi
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        cluster.sweep()
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        if best is None or el < best:
+            best = el
+        products = sum(ag.last_result.tcg_iterations for ag in agents.values())
+    f, g = cluster.central_cost_and_gradnorm()
+    return dict(value=1.0 / best, unit="it/s", seconds_per_sweep=best, agents=num_agents,
+                poses_per_agent=n // num_agents, tcg_iterations=products, cost_2f_after=2 * f, gradnorm_after=g,
+                preconditioners=sorted({ag.last_result.precond_used for ag in agents.values()}),
+                sample="this GPU on the reference configuration: the same %d blocks, the same initial iterate, ONE "
+                       "two-colour sweep, same-colour agents solved concurrently (best of 3)" % num_agents)
+
+
 def secondary_single_agent(workload, r, precond, steps, warmup, settle):
     """The same fixed-work measurement for a second, small workload (single agent, single GPU): BASELINE's metric is
     quoted on sphere2500 as well as on the 100k grid.  Returns a small dict for the `also` field of the JSON line."""
@@ -337,6 +384,9 @@ def main():
             comm = DeviceComm.from_torch_distributed(dev_index)  # the data path's own communicator (C ABI dpgo_comm_*)
         else:
             dist.init_process_group(backend)
+    elif args.loopback:
+        from dpgo_amd.comm import DeviceComm, unique_id
+        comm = DeviceComm(1, 0, unique_id(), dev_index)  # 1-rank RCCL communicator: self send / recv, all-reduce
 
     r = args.rank
     meas, n, X0, desc = make_workload(args.workload, r)
@@ -344,7 +394,7 @@ def main():
     # agents: 1 for a single GPU (one agent owns the whole graph, BASELINE configs[1] style);
     # for N > 1 GPUs two agents per GPU by default -- consecutive blocks of a chain / ring partition
     # alternate colours, so every GPU hosts one agent of each colour and works in BOTH colour phases
-    apg = args.agents_per_gpu if args.agents_per_gpu > 0 else (1 if world == 1 else 2)
+    apg = args.agents_per_gpu if args.agents_per_gpu > 0 else ((8 if args.loopback else 1) if world == 1 else 2)
     num_agents = world * apg
     ranges, graphs = build_pose_graphs(meas, n, num_agents, r)
     params = dpgo_amd.ROptParameters(precond=args.precond)  # reference defaults + block-Jacobi (or multilevel)
@@ -352,7 +402,7 @@ def main():
     my_ids = list(range(rank * apg, (rank + 1) * apg))
     agents = {a: DeviceAgent(graphs, plan, a, X0[ranges[a][0]:ranges[a][1]], params, device=dev_index)
               for a in my_ids}
-    cluster = RBCDCluster(plan, agents, rank, world, agents_per_rank=apg, comm=comm)
+    cluster = RBCDCluster(plan, agents, rank, world, agents_per_rank=apg, comm=comm, loopback=args.loopback)
     big = max(my_ids, key=lambda a: graphs[a].n())  # the agent whose kernels are profiled below
     agent = agents[big]
     nnzb_local = len(graphs[big].quadraticMatrix()[1])
@@ -394,16 +444,19 @@ def main():
     for a in agents.values():
         a.snapshot()
 
-    t_exchange = [0.0]
+    # device time of the public-pose exchanges, from event pairs on the stream they are enqueued on -- no host wait is
+    # added to the path being timed (pack kernel -> RCCL batch / device copies -> consumed by the coupling SpMM)
+    ex_events = []
     _exchange = cluster.exchange
 
     def timed_exchange(*a, **k):
-        t = time.perf_counter()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
         _exchange(*a, **k)
-        torch.cuda.synchronize()
-        t_exchange[0] += time.perf_counter() - t
+        e1.record()
+        ex_events.append((e0, e1))
 
-    if world > 1:
+    if num_agents > 1:
         cluster.exchange = timed_exchange
 
     def step():
@@ -414,7 +467,7 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
-    t_exchange[0] = 0.0
+    del ex_events[:]
     t0 = time.perf_counter()
     tcg_total = 0
     used_precond = set()
@@ -428,14 +481,14 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if cluster.stage else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    exchange_ms = sum(e0.elapsed_time(e1) for e0, e1 in ex_events)
+    cluster.exchange = _exchange
     f1, g1 = cluster.central_cost_and_gradnorm()
 
     # ---- dominant-kernel roofline, measured live with HIP events on the solver's stream ----
     lib = dpgo_amd.lib.load()
     import ctypes as C
-    ms_hess, ms_spmm = C.c_double(0.0), C.c_double(0.0)
-    agent.problem.setSpmmVariant("auto")
-    dpgo_amd.lib.check(lib.dpgo_bench_hess(agent.problem.handle, args.spmm_reps, 10, C.byref(ms_hess)))
+    ms_spmm = C.c_double(0.0)
     agent.problem.setSpmmVariant("plain")
     dpgo_amd.lib.check(lib.dpgo_bench_spmm(agent.problem.handle, args.spmm_reps, 10, C.byref(ms_spmm)))
     hb = hess_bytes(n_local, nnzb_local, d, r)
@@ -459,34 +512,53 @@ def main():
                         bytes_per_launch=sb, avg_launch_us=ms_srot.value * 1e3,
                         achieved=sb / (ms_srot.value * 1e-3) / 1e9, frac=sb / (ms_srot.value * 1e-3) / 1e9 / HBM_PEAK_GBS,
                         stored_bytes_per_launch=sset.value, buffer_sets=2 * nsets, total_MB=2 * nsets * sset.value / 1e6,
+                        achieved_own_bytes=sset.value / (ms_srot.value * 1e-3) / 1e9,
+                        frac_own_bytes=sset.value / (ms_srot.value * 1e-3) / 1e9 / HBM_PEAK_GBS,
                         warm=dict(avg_launch_us=ms_swarm.value * 1e3, achieved=sb / (ms_swarm.value * 1e-3) / 1e9,
                                   frac=sb / (ms_swarm.value * 1e-3) / 1e9 / HBM_PEAK_GBS),
                         note="rates are the product's ALGORITHMIC bytes (full Q) over its time, comparable with "
                              "spmm_only; this storage moves stored_bytes_per_launch")
+    # ---- the tCG-step kernel: both storages, HBM-only (rotating) and back-to-back; the HEADLINE is the kernel the timed
+    # loop launched (`in_use`: what the library's size switch selects for this block)
     in_use = agent.problem.setSpmmVariant("auto")
-    ms_hrot = C.c_double(0.0)
     hsets = max(3, nsets // 2 + 1)  # a tCG-step operand set is ~1.7x an SpMM set
-    dpgo_amd.lib.check(lib.dpgo_bench_hess_rotating(agent.problem.handle, hsets, args.spmm_reps, 10,
-                                                    C.byref(ms_hrot)))
-    # The rotating protocol emulates blocks whose operands come from HBM.  For such blocks the library's size switch
-    # (DPGO_SPMM_AUTO) runs the tCG-step kernel on the symmetric storage of Q; the 100k workload itself is Infinity-Cache
-    # resident and runs on the plain block-CSR arrays (`warm`).  Both cold figures are measured; the headline one is the
-    # kernel the library runs in the regime the protocol stands for.
-    ms_hrot_plain = ms_hrot.value
-    hess_cold_kernel = None
-    if in_use == "plain" and agent.problem.setSpmmVariant("symmetric") == "symmetric":
-        ms_hs = C.c_double(0.0)
-        dpgo_amd.lib.check(lib.dpgo_bench_hess_rotating(agent.problem.handle, hsets + 1, args.spmm_reps, 10,
-                                                        C.byref(ms_hs)))
-        ms_hrot = ms_hs
-        hess_cold_kernel = "k_tcg_hess_sym<%d,%d>" % (d, r)
-    elif in_use == "symmetric":
-        hess_cold_kernel = "k_tcg_hess_sym<%d,%d>" % (d, r)
-        agent.problem.setSpmmVariant("plain")
-        ms_hp = C.c_double(0.0)
-        dpgo_amd.lib.check(lib.dpgo_bench_hess_rotating(agent.problem.handle, hsets, args.spmm_reps, 10, C.byref(ms_hp)))
-        ms_hrot_plain = ms_hp.value
+    split = 4 if n_local < 40000 else 1
+    span = ((d + 1) * r) % 2 == 0
+    names = {"plain": "%s<%d,%d,%d>" % ("k_tcg_hess_span" if span else "k_tcg_hess", d, r, split),
+             "symmetric": "k_tcg_hess_sym<%d,%d>" % (d, r)}
+    hess = {}
+    for variant in ("plain", "symmetric"):
+        if agent.problem.setSpmmVariant(variant) != variant:
+            continue  # (the symmetric storage needs one pose per d+1 lanes: blocks >= 40 000 poses)
+        cold, warm_ = C.c_double(0.0), C.c_double(0.0)
+        dpgo_amd.lib.check(lib.dpgo_bench_hess_rotating(agent.problem.handle, hsets + (variant == "symmetric"),
+                                                        args.spmm_reps, 10, C.byref(cold)))
+        dpgo_amd.lib.check(lib.dpgo_bench_hess(agent.problem.handle, args.spmm_reps, 10, C.byref(warm_)))
+        hess[variant] = dict(kernel=names[variant], cold_us=cold.value * 1e3, warm_us=warm_.value * 1e3)
     agent.problem.setSpmmVariant("auto")
+    b_ = d + 1
+    nu_ = (nnzb_local + n_local) // 2  # stored upper blocks (diagonal + one of every off-diagonal pair)
+    hb_sym_own = (nu_ * (8 * b_ * b_ + 4) + (nnzb_local - nu_) * 8 + 2 * 4 * (n_local + 1)
+                  + hb - (nnzb_local * (8 * b_ * b_ + 4) + 4 * (n_local + 1)))
+
+    def hess_entry(variant):
+        h = hess[variant]
+        e = dict(kernel=h["kernel"], bytes_per_launch=hb, avg_launch_us=h["cold_us"],
+                 achieved=hb / h["cold_us"] / 1e3, frac=hb / h["cold_us"] / 1e3 / HBM_PEAK_GBS,
+                 warm=dict(avg_launch_us=h["warm_us"], achieved=hb / h["warm_us"] / 1e3,
+                           frac=hb / h["warm_us"] / 1e3 / HBM_PEAK_GBS))
+        if variant == "symmetric":  # effective rate above (full-Q bytes over its time); the bytes it really moves:
+            e.update(stored_bytes_per_launch=hb_sym_own, achieved_own_bytes=hb_sym_own / h["cold_us"] / 1e3,
+                     frac_own_bytes=hb_sym_own / h["cold_us"] / 1e3 / HBM_PEAK_GBS,
+                     note="achieved / frac = the step's ALGORITHMIC bytes (full Q, SURVEY 8d) over this kernel's time, "
+                          "comparable with the plain kernel; frac_own_bytes = the bytes this storage moves")
+        return e
+
+    timed = in_use if in_use in hess else "plain"
+    other = "symmetric" if timed == "plain" else "plain"
+    ms_hess = C.c_double(hess[timed]["warm_us"] * 1e-3)
+    ms_hrot = C.c_double(hess[timed]["cold_us"] * 1e-3)
+    kname = hess[timed]["kernel"]
     ach = hb / (ms_hess.value * 1e-3) / 1e9
     traffic = None
     traffic_src = None
@@ -496,22 +568,17 @@ def main():
         # HBM-side bytes per launch from rocprofv3 PMC passes of this same command (separate FETCH_SIZE and
         # WRITE_SIZE passes, tools/profile_round.sh): FETCH_SIZE x 2 (gfx950 correction, calibrated on
         # k_retract / k_rtr_update whose byte counts are exact) + WRITE_SIZE, KB -> bytes; "max" = the full
-        # (non-early-exit) launches.  The newest committed summary is used.
+        # (non-early-exit) launches.  The newest committed summary is used -- a constant of the committed profile, not
+        # a measurement of this run (traffic_source says which file).
         pmc = json.load(open(pmc_files[-1]))
-        # (the cold figure's kernel first: k_tcg_hess_sym when the symmetric storage is what HBM-bound blocks run)
-        for key in ("k_tcg_hess_sym<%d, %d>" % (d, r), "k_tcg_hess_span<%d, %d, 1>" % (d, r),
-                    "k_tcg_hess<%d, %d, 1>" % (d, r)):
-            if key in pmc.get("FETCH_SIZE_KB", {}) and key in pmc.get("WRITE_SIZE_KB", {}):
-                traffic = (2.0 * pmc["FETCH_SIZE_KB"][key]["max"] + pmc["WRITE_SIZE_KB"][key]["max"]) * 1024.0
-                traffic_src = "%s [%s]" % (os.path.relpath(pmc_files[-1], ROOT), key)
-                break
+        key = kname.replace(",", ", ")
+        if key in pmc.get("FETCH_SIZE_KB", {}) and key in pmc.get("WRITE_SIZE_KB", {}):
+            traffic = (2.0 * pmc["FETCH_SIZE_KB"][key]["max"] + pmc["WRITE_SIZE_KB"][key]["max"]) * 1024.0
+            traffic_src = "%s [%s]" % (os.path.relpath(pmc_files[-1], ROOT), key)
     # HBM figure first (SURVEY 8d protocol: every operand of the launch cycles through > 256 MB of private copies, so
     # the 256 MB Infinity Cache cannot serve it); `warm` = back-to-back launches on the solver's own buffers, which is
     # what the tCG loop sees for blocks whose working set fits that cache (all of BASELINE's configurations)
     ach_rot = hb / (ms_hrot.value * 1e-3) / 1e9
-    kname = "%s<%d,%d,%d>" % ("k_tcg_hess_span" if ((d + 1) * r) % 2 == 0 else "k_tcg_hess", d, r,
-                              4 if n_local < 40000 else 1)
-    b_ = d + 1
     vec = 8 * r * b_ * n_local
     ms_it = (C.c_double * 5)()
     dpgo_amd.lib.check(lib.dpgo_bench_iteration_kernels(agent.problem.handle, args.spmm_reps, 10, ms_it))
@@ -566,12 +633,10 @@ def main():
                            "H-direction recurrences)" % kname,
                     achieved=ach_rot, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach_rot / HBM_PEAK_GBS, traffic=traffic,
                     traffic_source=traffic_src, bytes_per_launch=hb, avg_launch_us=ms_hrot.value * 1e3,
-                    protocol="HIP events over %d launches, every operand rotating through %d private sets (> 256 MB "
-                             "in total): HBM-only rate" % (args.spmm_reps, hsets),
-                    cold_kernel=hess_cold_kernel or kname,
-                    cold_plain_storage=dict(kernel=kname, avg_launch_us=ms_hrot_plain * 1e3,
-                                            achieved=hb / (ms_hrot_plain * 1e-3) / 1e9,
-                                            frac=hb / (ms_hrot_plain * 1e-3) / 1e9 / HBM_PEAK_GBS),
+                    protocol="HIP events over %d launches of the kernel the timed loop launches (storage selected: %s), "
+                             "every operand rotating through %d private sets (> 256 MB in total): HBM-only rate"
+                             % (args.spmm_reps, timed, hsets),
+                    **{("%s_storage" % other): (hess_entry(other) if other in hess else None)},
                     warm=dict(avg_launch_us=ms_hess.value * 1e3, achieved=ach, frac=ach / HBM_PEAK_GBS,
                               protocol="back-to-back launches on the solver's own buffers (Infinity-Cache resident "
                                        "working set, what the tCG loop sees)"),
@@ -601,6 +666,13 @@ def main():
             cpu = cpu_baseline_reference(meas, n, X0, r)
         except Exception as exc:  # noqa: BLE001 -- report instead of losing the GPU measurement
             sys.stderr.write("bench.py: cpu_baseline (reference configuration) failed: %r\n" % (exc,))
+        if cpu is not None:
+            try:  # the same decomposition, iterate and stop on this GPU: the like-for-like pair of cpu_baseline.value
+                same = gpu_same_decomposition(meas, n, X0, r, 8, args.precond, dev_index)
+                cpu["gpu_same_work"] = same
+                cpu["gpu_over_cpu_same_work"] = same["value"] / cpu["value"]
+            except Exception as exc:  # noqa: BLE001
+                sys.stderr.write("bench.py: gpu_same_work failed: %r\n" % (exc,))
         try:  # the device algorithm on one core, same step as the GPU's (same settled iterate)
             port = cpu_baseline(meas, n, X_state, r, args.cpu_budget_s, "jacobi")
             if cpu is None:
@@ -641,6 +713,8 @@ def main():
             if jac_step:
                 port["rel_diff_fOpt_vs_device"] = abs(port["fOpt"] - jac_step["fOpt"]) / abs(port["fOpt"])
                 port["device_tcg_iterations_same_step"] = jac_step["tcg_iterations"]
+        tt_key = "%s/%s" % (args.workload, args.precond)
+        tt_main = (to_tol or {}).get(tt_key) or {}
         out = {
             "metric": "rbcd_iterations_per_sec",
             "value": args.steps / elapsed,
@@ -649,6 +723,13 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps,
+            # what a step is: Hessian-vector products (tCG iterations) of this rank's agents per step, and how far they
+            # take the iterate; time from the initial guess to |rgrad| < 1e-2 with the same settings (single agent)
+            "products_per_step": tcg_total / max(args.steps, 1),
+            "gradnorm_before_step": trajectory[-1][1] if trajectory else None,
+            "gradnorm_after_step": g1,
+            "time_to_tolerance_ms": tt_main.get("ms") if tt_main.get("reached") else None,
+            "products_to_tolerance": tt_main.get("products") if tt_main.get("reached") else None,
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
@@ -661,11 +742,13 @@ def main():
                                args.precond]),
                        "precond_used_in_timed_steps": sorted(used_precond),
                        "schedule": "single agent" if num_agents == 1 else
-                       "%d-colour parallel RBCD; 1 step = 1 sweep (every agent updates once); public-pose "
-                       "exchange over %s" % (plan.num_colours, "device copies" if world == 1 else
-                                             ("RCCL p2p on the solver's stream (C ABI dpgo_comm_exchange)" if comm
-                                              else ("torch.distributed nccl p2p" if not cluster.stage
-                                                    else "gloo (host-staged)"))),
+                       "%d-colour parallel RBCD; 1 step = 1 sweep (every agent updates once; same-colour agents of a "
+                       "GPU solved concurrently); public-pose exchange over %s" % (
+                           plan.num_colours,
+                           "RCCL p2p on the solver's stream (C ABI dpgo_comm_exchange)%s" % (
+                               " through a 1-rank communicator (loop-back)" if world == 1 else "") if comm
+                           else ("device copies" if world == 1 else
+                                 ("torch.distributed nccl p2p" if not cluster.stage else "gloo (host-staged)"))),
                        "dist_backend": backend,
                        "poses_per_agent": n_local, "nnzb_per_agent": nnzb_local},
             "roofline": roofline,
@@ -677,7 +760,9 @@ def main():
                         "cost_2f_after_step": 2 * f1, "gradnorm_after_step": g1,
                         "tcg_iterations_per_step_rank0": tcg_total / max(args.steps, 1),
                         "us_per_tcg_iteration_rank0": 1e6 * elapsed / max(tcg_total, 1),
-                        "exchange_ms_per_step_rank0": 1e3 * t_exchange[0] / max(args.steps, 1),
+                        "exchange_ms_per_step_rank0": exchange_ms / max(args.steps, 1),
+                        "exchange_timing": "device time between event pairs around every exchange on its stream (no "
+                                           "host synchronisation inside the timed loop)",
                         "to_tolerance": to_tol},
         }
         print(json.dumps(out))

@@ -25,7 +25,8 @@ import numpy as np
 
 from . import lib as L
 from .measurements import RelativeSEMeasurements, partition_contiguous
-from .solver import PoseGraph, QuadraticOptimizer, QuadraticProblem, ROptParameters, ROPTResult
+from .solver import (PoseGraph, QuadraticOptimizer, QuadraticProblem, ROptParameters, ROPTResult,
+                     eval_terms_device_many, optimize_device_many)
 
 
 def build_pose_graphs(dataset: RelativeSEMeasurements, num_poses: int, num_robots: int, r: int):
@@ -245,6 +246,9 @@ class RBCDCluster:
         self.agents_per_rank = int(agents_per_rank)
         self.comm = comm
         self.loopback = bool(loopback) and comm is not None
+        # same-colour local agents are solved concurrently (sweep); DPGO_SEQUENTIAL_SWEEP=1: one after the other (A/B)
+        import os
+        self.concurrent = os.environ.get("DPGO_SEQUENTIAL_SWEEP", "0") != "1"
         if world > 1 and comm is None:
             import torch.distributed as dist
             if stage_through_host is None:
@@ -296,8 +300,9 @@ class RBCDCluster:
                 view.copy_(tmp)
 
     def _allreduce_host(self, values: np.ndarray) -> np.ndarray:
-        """Sum of a small host array over the ranks (cost / gradient-norm terms)."""
-        if self.world == 1:
+        """Sum of a small host array over the ranks (cost / gradient-norm terms).  Loop-back mode sends it through the
+        1-rank communicator as well (the identity), so that the whole N > 1 data path runs on one GPU."""
+        if self.world == 1 and not self.loopback:
             return values
         import torch
         any_agent = next(iter(self.agents.values()))
@@ -311,22 +316,46 @@ class RBCDCluster:
         dist.all_reduce(t)
         return t.cpu().numpy()
 
+    def _main_stream(self):
+        any_agent = next(iter(self.agents.values()))
+        return any_agent.torch.cuda.current_stream().cuda_stream
+
     def sweep(self) -> None:
-        """One RBCD iteration: every colour class updates once (parallel within a class)."""
+        """One RBCD iteration: every colour class updates once.  The agents of a colour hosted by THIS process are
+        updated concurrently (C ABI dpgo_optimize_device_many: each on its own stream behind the exchange, one feeding
+        host thread each), so a GPU that hosts several same-colour agents overlaps their latency-bound solves instead of
+        running them one after the other."""
         for c in range(self.plan.num_colours):
             self.exchange(receivers=c)
-            for a, agent in self.agents.items():
-                if self.plan.colour[a] == c:
-                    agent.update()
+            ids = [a for a in self.agents if self.plan.colour[a] == c]
+            if self.concurrent and len(ids) > 1 and all(hasattr(self.agents[a], "optimizer") for a in ids):
+                ags = [self.agents[a] for a in ids]
+                res = optimize_device_many([g.optimizer for g in ags], [g.X for g in ags],
+                                           [g.nbr if g.has_neighbours else None for g in ags], self._main_stream())
+                for g, r_ in zip(ags, res):
+                    g.last_result = r_
+            else:
+                for a in ids:
+                    self.agents[a].update()
 
     def block_terms(self) -> np.ndarray:
         """[num_agents, 2] array of (0.5 (xqx + xg), |rgrad_a|^2) per agent, identical on every rank."""
         self.exchange(None)
         out = np.zeros((self.plan.num_agents, 2))
-        for a, agent in self.agents.items():
-            xqx, xg, g2 = agent.local_terms()
+        for a, (xqx, xg, g2) in self._local_terms().items():
             out[a] = [0.5 * (xqx + xg), g2]
         return self._allreduce_host(out)
+
+    def _local_terms(self) -> Dict[int, Tuple[float, float, float]]:
+        """{agent id: (xqx, xg, |rgrad|^2)} of the local agents with the current neighbour buffers: one concurrent
+        device pass and one read-back per agent (dpgo_problem_eval_terms_device_many)."""
+        ids = list(self.agents)
+        if self.concurrent and len(ids) > 1 and all(hasattr(self.agents[a], "problem") for a in ids):
+            ags = [self.agents[a] for a in ids]
+            t = eval_terms_device_many([g.problem for g in ags], [g.X for g in ags],
+                                       [g.nbr if g.has_neighbours else None for g in ags], self._main_stream())
+            return {a: tuple(t[k]) for k, a in enumerate(ids)}
+        return {a: self.agents[a].local_terms() for a in ids}
 
     def run_greedy(self, max_iters: int = 1000, gradnorm_stop: float = 0.1):
         """The reference demo's schedule (examples/MultiRobotExample.cpp:170-255): every non-selected agent
@@ -386,8 +415,7 @@ class RBCDCluster:
         evaluates on a central problem), assembled from agent-local terms + one tiny all-reduce."""
         self.exchange(None)
         acc = np.zeros(2)
-        for agent in self.agents.values():
-            xqx, xg, g2 = agent.local_terms()
+        for xqx, xg, g2 in self._local_terms().values():
             acc += [0.5 * (xqx + xg), g2]
         acc = self._allreduce_host(acc)
         return float(acc[0]), float(acc[1]) ** 0.5

@@ -12,6 +12,7 @@
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -51,16 +52,31 @@ Rccl& rccl() {
   static std::once_flag once;
   std::call_once(once, [&] {
     const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
-    for (const char* nm : names) {  // a copy the process already holds first
-      r.so = dlopen(nm, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL);
-      if (r.so) break;
-    }
-    for (const char* nm : names) {
-      if (r.so) break;
-      r.so = dlopen(nm, RTLD_NOW | RTLD_GLOBAL);
+    // DPGO_RCCL_LIBRARY: load this file instead of the default names (also how the tests hide RCCL)
+    const char* forced = std::getenv("DPGO_RCCL_LIBRARY");
+    std::string why;
+    if (forced && *forced) {
+      r.so = dlopen(forced, RTLD_NOW | RTLD_GLOBAL);
+      if (!r.so) {
+        const char* e = dlerror();  // ONE call: dlerror() clears the message it returns
+        why = e ? e : "not found";
+      }
+    } else {
+      for (const char* nm : names) {  // a copy the process already holds first
+        r.so = dlopen(nm, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL);
+        if (r.so) break;
+      }
+      for (const char* nm : names) {
+        if (r.so) break;
+        r.so = dlopen(nm, RTLD_NOW | RTLD_GLOBAL);
+        if (!r.so) {
+          const char* e = dlerror();
+          why = e ? e : "not found";
+        }
+      }
     }
     if (!r.so) {
-      r.error = std::string("cannot load RCCL (librccl.so.1): ") + (dlerror() ? dlerror() : "not found");
+      r.error = std::string("cannot load RCCL (") + (forced && *forced ? forced : "librccl.so.1") + "): " + why;
       return;
     }
     bool ok = true;
@@ -181,11 +197,25 @@ int dpgo_comm_exchange(dpgo_comm_t c, int nsend, const int* send_peer, const dou
   // one group: all sends and receives of the exchange progress together, no ordering between ranks can deadlock;
   // messages between one pair of ranks match in issue order (the plan lists them in the same order on both sides)
   NCCLC(R.GroupStart());
-  for (int k = 0; k < nsend; ++k)
-    if (send_count[k] > 0) NCCLC(R.Send(send_dev[k], (size_t)send_count[k], ncclFloat64, send_peer[k], c->comm, s));
-  for (int k = 0; k < nrecv; ++k)
-    if (recv_count[k] > 0) NCCLC(R.Recv(recv_dev[k], (size_t)recv_count[k], ncclFloat64, recv_peer[k], c->comm, s));
-  NCCLC(R.GroupEnd());
+  // an error inside the bracket must not leave the communicator with an open group (later calls would queue forever):
+  // remember the first failure, close the group, then report
+  ncclResult_t first = ncclSuccess;
+  const char* what = "";
+  for (int k = 0; k < nsend && first == ncclSuccess; ++k)
+    if (send_count[k] > 0) {
+      first = R.Send(send_dev[k], (size_t)send_count[k], ncclFloat64, send_peer[k], c->comm, s);
+      what = "ncclSend";
+    }
+  for (int k = 0; k < nrecv && first == ncclSuccess; ++k)
+    if (recv_count[k] > 0) {
+      first = R.Recv(recv_dev[k], (size_t)recv_count[k], ncclFloat64, recv_peer[k], c->comm, s);
+      what = "ncclRecv";
+    }
+  const ncclResult_t end = R.GroupEnd();
+  if (first != ncclSuccess)
+    return fail(DPGO_ERR_HIP, std::string(what) + ": " + (R.GetErrorString ? R.GetErrorString(first) : "RCCL error"));
+  if (end != ncclSuccess)
+    return fail(DPGO_ERR_HIP, std::string("ncclGroupEnd: ") + (R.GetErrorString ? R.GetErrorString(end) : "RCCL error"));
   return DPGO_OK;
 }
 

@@ -8,6 +8,10 @@
 
 #include <algorithm>
 #include <chrono>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
+#include <thread>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -151,7 +155,17 @@ struct dpgo_problem_s {
   int ml_coarse_bits = 64;  // 32: opt-in (dpgo_problem_multilevel_coarse_bits)
   int ml_lda = 0;
   double *ml_W = nullptr, *ml_Rx = nullptr;  // Gauss-Jordan panels (setup only)
-  bool auto_ml = false;  // DPGO_PRECOND_AUTO: the multilevel cycle is currently selected
+  // DPGO_PRECOND_AUTO: the multilevel cycle is currently selected.  Decided afresh at the first "auto" use after every
+  // change of Q (a function of the problem only, so repeated runs reproduce): multilevel for a block without coupling
+  // to other agents -- there the tCG budget, not the trust-region boundary, ends the local solves --, block-Jacobi
+  // for a block of a multi-agent problem; then hysteresis on the share of the tCG budget each solve used.
+  bool auto_ml = false, auto_decided = false;
+  void auto_decide() {
+    if (!auto_decided) {
+      auto_ml = !(has_G || C.nnzb > 0);
+      auto_decided = true;
+    }
+  }
   // two-level hierarchies: level-0 post-smoothing through A P and the coarse solution (k_ml_post_ap); DPGO_ML_AP=0 disables
   bool ml_use_ap() const {
     static const bool off = [] {
@@ -666,6 +680,7 @@ int ml_symbolic_setup(dpgo_problem_s* p, const std::vector<int>& ks) {
       for (int i = 0; i < cur; ++i)
         for (int t = rowptr[i]; t < rowptr[i + 1]; ++t) srow[t] = i;
       CHK(upload(&L.slot_row, srow.data(), srow.size(), p->stream));
+      HIPC(hipStreamSynchronize(p->stream));  // srow goes out of scope at the end of this block
       HIPC(hipMalloc(&L.r, tb * cur));
       if (!L.k) HIPC(hipMalloc(&L.x, tb * cur));  // dense level: its solution, read by the level above
     }
@@ -827,7 +842,9 @@ int ml_numeric_setup(dpgo_problem_s* p) {
 // Make the hierarchy match the handle's Q (lazily, like the reference's constructPreconditioner inside the first
 // PreConditioner call, src/PoseGraph.cpp:582-586).
 int ml_ensure(dpgo_problem_s* p, double shift) {
-  if (p->ml_ready && p->ml_shift == shift) return DPGO_OK;
+  // level 0 smooths with the handle's shared block-Jacobi factors: a block-Jacobi solve with another shift in between
+  // has overwritten them, so they are re-derived for THIS shift even when the hierarchy itself is current (no-op otherwise)
+  if (p->ml_ready && p->ml_shift == shift) return build_dinv(p, shift);
   if (!p->ml_symbolic) CHK(ml_symbolic_setup(p, ml_default_ks(p->n, p->b, p->split)));
   p->ml_shift = shift;
   return ml_numeric_setup(p);
@@ -1136,6 +1153,7 @@ int run_optimize(dpgo_problem_s* p, const dpgo_ropt_params* prm, dpgo_ropt_resul
   res->tCGStatus = DPGO_TCG_MAXITER;
   if (p->hctrl) std::memset(p->hctrl, 0, sizeof(PersistCtrl));
   dpgo_ropt_params resolved = *prm;  // DPGO_PRECOND_AUTO -> what this handle currently runs
+  if (prm->precond == DPGO_PRECOND_AUTO) p->auto_decide();
   if (prm->precond == DPGO_PRECOND_AUTO)
     resolved.precond = (p->auto_ml && prm->method == DPGO_METHOD_RTR) ? DPGO_PRECOND_MULTILEVEL : DPGO_PRECOND_BLOCK_JACOBI;
   const bool is_auto = prm->precond == DPGO_PRECOND_AUTO;
@@ -1308,6 +1326,7 @@ int refresh_after_weights(dpgo_problem_s* p) {
   CHK(rebuild_Q_from_weights(p, p->q_base, 1.0, p->Q.vals));
   CHK(rebuild_C_from_weights(p, p->c_base, 1.0, p->C.vals));  // G itself is refreshed by the next update_G call
   p->ml_ready = false;
+  p->auto_decided = false;
   p->sym.ready = p->tcg_sym = false;
   const double s = p->dinv_shift > 0 ? p->dinv_shift : 1e-1;
   p->dinv_shift = -1.0;  // clearQuadraticMatrix also drops the preconditioner (src/PoseGraph.cpp:352-355)
@@ -1570,6 +1589,7 @@ int dpgo_problem_set_Q_bsr(dpgo_problem_t p, int nnzb, const int32_t* rowptr, co
   }
   p->sym.ready = p->tcg_sym = false;
   p->ml_ready = false;  // the hierarchy's values belong to the old Q: rebuilt on the device at the next use
+  p->auto_decided = false;
   p->dinv_shift = -1.0;
   CHK(build_dinv(p, 1e-1));  // src/PoseGraph.cpp:603
   HIPC(hipStreamSynchronize(p->stream));
@@ -1810,6 +1830,7 @@ int dpgo_problem_update_Q_values(dpgo_problem_t p, const double* vals) {
   const double s = p->dinv_shift > 0 ? p->dinv_shift : 1e-1;
   p->dinv_shift = -1.0;  // PoseGraph::clearQuadraticMatrix also drops the preconditioner (src/PoseGraph.cpp:352-355)
   p->ml_ready = false;
+  p->auto_decided = false;
   p->sym.ready = p->tcg_sym = false;
   CHK(build_dinv(p, s));
   HIPC(hipStreamSynchronize(p->stream));
@@ -1929,7 +1950,12 @@ int dpgo_problem_multilevel_get(dpgo_problem_t p, int level, int what, void* out
 
 int dpgo_problem_auto_state(dpgo_problem_t p, int* use_multilevel) {
   if (!p || !use_multilevel) return fail(DPGO_ERR_INVALID, "null pointer");
-  if (*use_multilevel >= 0) p->auto_ml = *use_multilevel != 0;
+  if (*use_multilevel >= 0) {
+    p->auto_ml = *use_multilevel != 0;
+    p->auto_decided = true;
+  } else {
+    p->auto_decide();
+  }
   *use_multilevel = p->auto_ml ? 1 : 0;
   return DPGO_OK;
 }
@@ -2073,7 +2099,10 @@ int dpgo_problem_precondition(dpgo_problem_t p, int precond, double shift, const
   CHK(eval_common(p, X));
   CHK(h2d(p, p->eta, V));
   const double* dinv = nullptr;
-  if (precond == DPGO_PRECOND_AUTO) precond = p->auto_ml ? DPGO_PRECOND_MULTILEVEL : DPGO_PRECOND_BLOCK_JACOBI;
+  if (precond == DPGO_PRECOND_AUTO) {
+    p->auto_decide();
+    precond = p->auto_ml ? DPGO_PRECOND_MULTILEVEL : DPGO_PRECOND_BLOCK_JACOBI;
+  }
   if (precond == DPGO_PRECOND_BLOCK_JACOBI) {
     CHK(build_dinv(p, shift));
     dinv = p->dinv;
@@ -2109,6 +2138,150 @@ int dpgo_optimize_device(dpgo_problem_t p, const dpgo_ropt_params* params, doubl
   if (rc != DPGO_OK) return rc;
   HIPC(hipStreamSynchronize(p->stream));
   return DPGO_OK;
+}
+
+// ---- several agents of one process updated concurrently (same-colour agents of a parallel RBCD sweep) ----
+namespace {
+// Host threads that feed the just-in-time tCG loops of several handles at once: one worker per concurrently solved handle,
+// created on first use and kept (a solve is a few milliseconds; creating threads per sweep would show).
+class FeedPool {
+ public:
+  static FeedPool& get() {
+    static FeedPool* pool = new FeedPool();  // never destroyed: workers may outlive static destructors
+    return *pool;
+  }
+  // runs job(0..count-1): job(0) on the calling thread, the others on workers; returns when all are done
+  void run(int count, const std::function<void(int)>& job) {
+    std::unique_lock<std::mutex> call(call_mu_);  // one batch at a time
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      while ((int)workers_.size() < count - 1) {
+        const int id = (int)workers_.size();
+        workers_.emplace_back([this, id] { loop(id); });
+        workers_.back().detach();
+      }
+      job_ = &job;
+      count_ = count;
+      pending_ = count - 1;
+      epoch_ += 1;
+    }
+    cv_.notify_all();
+    job(0);
+    std::unique_lock<std::mutex> lk(mu_);
+    done_.wait(lk, [this] { return pending_ == 0; });
+    job_ = nullptr;
+  }
+
+ private:
+  void loop(int id) {
+    unsigned long long seen = 0;
+    while (true) {
+      const std::function<void(int)>* job = nullptr;
+      {
+        std::unique_lock<std::mutex> lk(mu_);
+        cv_.wait(lk, [&] { return epoch_ != seen; });
+        seen = epoch_;
+        if (id + 1 < count_) job = job_;
+      }
+      if (job) {
+        (*job)(id + 1);
+        std::lock_guard<std::mutex> lk(mu_);
+        if (--pending_ == 0) done_.notify_all();
+      }
+    }
+  }
+  std::mutex call_mu_, mu_;
+  std::condition_variable cv_, done_;
+  std::vector<std::thread> workers_;
+  const std::function<void(int)>* job_ = nullptr;
+  int count_ = 0, pending_ = 0;
+  unsigned long long epoch_ = 0;
+};
+
+// Runs body(k) for every handle on its OWN stream, ordered after `after_stream`; the handles' previous streams are
+// restored afterwards.  Returns the first failure (its message becomes this thread's dpgo_last_error).
+static int run_many(int count, const dpgo_problem_t* handles, void* after_stream, const std::function<int(int)>& body) {
+  if (count <= 0) return DPGO_OK;
+  if (!handles) return fail(DPGO_ERR_INVALID, "null handle array");
+  for (int k = 0; k < count; ++k) {
+    CHK(check_ready(handles[k]));
+    if (handles[k]->device != handles[0]->device) return fail(DPGO_ERR_INVALID, "handles on different devices");
+    for (int q = 0; q < k; ++q)
+      if (handles[q] == handles[k]) return fail(DPGO_ERR_INVALID, "a handle appears twice");
+  }
+  std::vector<hipStream_t> prev(count);
+  hipEvent_t ev = nullptr;
+  HIPC(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+  hipError_t e = hipEventRecord(ev, (hipStream_t)after_stream);
+  for (int k = 0; k < count && e == hipSuccess; ++k) {
+    prev[k] = handles[k]->stream;
+    if (prev[k] != handles[k]->own_stream) e = hipStreamSynchronize(prev[k]);  // earlier work of the handle itself
+    handles[k]->stream = handles[k]->own_stream;
+    if (e == hipSuccess) e = hipStreamWaitEvent(handles[k]->own_stream, ev, 0);
+  }
+  std::vector<int> rc(count, DPGO_OK);
+  std::vector<std::string> msg(count);
+  if (e == hipSuccess) {
+    FeedPool::get().run(count, [&](int k) {
+      int r = (hipSetDevice(handles[k]->device) == hipSuccess) ? body(k) : fail(DPGO_ERR_HIP, "hipSetDevice failed");
+      if (r == DPGO_OK && hipStreamSynchronize(handles[k]->stream) != hipSuccess)
+        r = fail(DPGO_ERR_HIP, "hipStreamSynchronize failed");
+      rc[k] = r;
+      if (r != DPGO_OK) msg[k] = g_err;  // thread-local message of the worker
+    });
+  }
+  for (int k = 0; k < count; ++k) handles[k]->stream = prev[k];
+  (void)hipEventDestroy(ev);
+  if (e != hipSuccess) return fail(DPGO_ERR_HIP, std::string("stream ordering of the concurrent update: ") + hipGetErrorString(e));
+  for (int k = 0; k < count; ++k)
+    if (rc[k] != DPGO_OK) return fail(rc[k], "handle " + std::to_string(k) + ": " + msg[k]);
+  return DPGO_OK;
+}
+}  // namespace
+
+int dpgo_optimize_device_many(int count, const dpgo_problem_t* handles, const dpgo_ropt_params* params,
+                              double* const* X_dev, const double* const* nbr_tiles_dev, void* after_stream,
+                              dpgo_ropt_result* results) {
+  if (count <= 0) return DPGO_OK;
+  if (!params || !X_dev || !results) return fail(DPGO_ERR_INVALID, "null pointer");
+  for (int k = 0; k < count; ++k)
+    if (!X_dev[k]) return fail(DPGO_ERR_INVALID, "null iterate");
+  return run_many(count, handles, after_stream, [&](int k) -> int {
+    dpgo_problem_s* p = handles[k];
+    if (nbr_tiles_dev && nbr_tiles_dev[k]) {  // PGOAgent::updateX: G from the neighbours' public poses first
+      if (!p->C.rowptr) return fail(DPGO_ERR_STATE, "G coupling not set");
+      CHK(launch_spmm(p, p->C, nbr_tiles_dev[k], p->G0, p->G));
+      p->has_G = true;
+    }
+    double* own = p->x1;
+    p->x1 = X_dev[k];
+    const int rc = run_optimize(p, params, &results[k]);
+    p->x1 = own;
+    return rc;
+  });
+}
+
+int dpgo_problem_eval_terms_device_many(int count, const dpgo_problem_t* handles, const double* const* X_dev,
+                                        const double* const* nbr_tiles_dev, void* after_stream, double* terms) {
+  if (count <= 0) return DPGO_OK;
+  if (!X_dev || !terms) return fail(DPGO_ERR_INVALID, "null pointer");
+  for (int k = 0; k < count; ++k)
+    if (!X_dev[k]) return fail(DPGO_ERR_INVALID, "null iterate");
+  return run_many(count, handles, after_stream, [&](int k) -> int {
+    dpgo_problem_s* p = handles[k];
+    if (nbr_tiles_dev && nbr_tiles_dev[k]) {
+      if (!p->C.rowptr) return fail(DPGO_ERR_STATE, "G coupling not set");
+      CHK(launch_spmm(p, p->C, nbr_tiles_dev[k], p->G0, p->G));
+      p->has_G = true;
+    }
+    CHK(launch_grad(p, X_dev[k], nullptr, nullptr, nullptr));
+    CHK(launch_rtr_begin(p, 0.0, 1.0, 1.0, 0, 0));
+    CHK(poll_state(p));
+    terms[3 * k + 0] = p->hstate->xqx;
+    terms[3 * k + 1] = p->hstate->xg;
+    terms[3 * k + 2] = p->hstate->ngf * p->hstate->ngf;
+    return DPGO_OK;
+  });
 }
 
 int dpgo_spmm_device(dpgo_problem_t p, const double* V_dev, double* OUT_dev, int add_G) {

@@ -611,6 +611,56 @@ class QuadraticOptimizer:
         return self.result_
 
 
+def _ptr_array(ptrs):
+    arr = (C.c_void_p * len(ptrs))()
+    for k, v in enumerate(ptrs):
+        arr[k] = v
+    return arr
+
+
+def _addr(x):
+    return L.ptr(x)
+
+
+def optimize_device_many(optimizers, X_devs, nbr_tiles=None, after_stream=None):
+    """QuadraticOptimizer::optimize of several agents hosted by this process, CONCURRENTLY (C ABI
+    dpgo_optimize_device_many): every problem runs on its own stream, ordered after `after_stream`; nbr_tiles[k]
+    (or None) is agent k's neighbour tile buffer, from which G is rebuilt first (PGOAgent::updateX).  All optimizers
+    must carry the same parameters.  Returns the list of ROPTResult (also stored in each optimizer)."""
+    if not optimizers:
+        return []
+    lib = optimizers[0].problem_._lib
+    cp = optimizers[0].params_.to_c()
+    n = len(optimizers)
+    handles = _ptr_array([o.problem_._h.value for o in optimizers])
+    xs = _ptr_array([_addr(x) for x in X_devs])
+    nb = _ptr_array([_addr(t) for t in nbr_tiles]) if nbr_tiles is not None else None
+    res = (L.RoptResultC * n)()
+    L.check(lib.dpgo_optimize_device_many(n, handles, C.byref(cp), xs, nb, after_stream or None, res))
+    out = []
+    for o, cr in zip(optimizers, res):
+        o.result_ = ROPTResult.from_c(cr)
+        if nbr_tiles is not None:
+            o.problem_._g_obj = None
+        out.append(o.result_)
+    return out
+
+
+def eval_terms_device_many(problems, X_devs, nbr_tiles=None, after_stream=None):
+    """(sum(XQ.X), sum(X.G), |rgrad|^2) of several agents in one concurrent pass (dpgo_problem_eval_terms_device_many);
+    returns an [n, 3] array."""
+    n = len(problems)
+    out = np.zeros((n, 3))
+    if n == 0:
+        return out
+    lib = problems[0]._lib
+    handles = _ptr_array([p._h.value for p in problems])
+    xs = _ptr_array([_addr(x) for x in X_devs])
+    nb = _ptr_array([_addr(t) for t in nbr_tiles]) if nbr_tiles is not None else None
+    L.check(lib.dpgo_problem_eval_terms_device_many(n, handles, xs, nb, after_stream or None, L.ptr(out)))
+    return out
+
+
 # --------------------------------------------------------------------------- LiftedSEManifold
 class LiftedSEManifold:
     """DPGO::LiftedSEManifold (include/DPGO/manifold/LiftedSEManifold.h:28-43) =

@@ -261,6 +261,21 @@ int dpgo_optimize(dpgo_problem_t h, const dpgo_ropt_params* params, const double
 int dpgo_optimize_device(dpgo_problem_t h, const dpgo_ropt_params* params, double* X_dev,
                          dpgo_ropt_result* result);
 
+/* Several agents hosted by one process / GPU updated CONCURRENTLY: the agents of one colour class of a parallel RBCD
+ * sweep (examples/MultiRobotExample.cpp:170-255 updates its robots one after the other inside one process; the reference's
+ * asynchronous mode runs one optimisation thread per agent, src/PGOAgent.cpp:483-520).  Per handle k, on the handle's OWN
+ * stream and ordered after everything enqueued on `after_stream` so far (the public-pose exchange): G from the neighbour
+ * tile buffer nbr_tiles_dev[k] (PGOAgent::updateX -> constructG; NULL entry or NULL array: G is left as it is), then
+ * QuadraticOptimizer::optimize on X_dev[k] in place.  One host thread per handle feeds its kernels, so the solves overlap
+ * on the device.  Returns when every stream has finished; results[k] as dpgo_optimize_device.  Handles must be distinct
+ * and on one device. */
+int dpgo_optimize_device_many(int count, const dpgo_problem_t* handles, const dpgo_ropt_params* params,
+                              double* const* X_dev, const double* const* nbr_tiles_dev, void* after_stream,
+                              dpgo_ropt_result* results);
+/* The same for dpgo_problem_eval_terms_device: terms[3k..3k+2] = (sum(XQ.X), sum(X.G), |rgrad|^2) of handle k. */
+int dpgo_problem_eval_terms_device_many(int count, const dpgo_problem_t* handles, const double* const* X_dev,
+                                        const double* const* nbr_tiles_dev, void* after_stream, double* terms);
+
 /* ---- device-pointer building blocks (bench / agent loop) ---- */
 /* OUT = V*Q (+G if add_G): the named north-star kernel */
 int dpgo_spmm_device(dpgo_problem_t h, const double* V_dev, double* OUT_dev, int add_G);

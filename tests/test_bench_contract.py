@@ -46,17 +46,40 @@ def test_bench_prints_one_valid_json_line():
     assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12 and rf["achieved"] > 0
     assert rf["warm"]["frac"] > 0 and rf["spmm_only"]["frac"] > 0  # frac = rotating (HBM-only), warm beside it
+    # the headline describes the kernel the timed loop launched: name, time and rate belong together
+    assert rf["spmm_storage_selected"] == "plain" and rf["kernel"].startswith("k_tcg_hess_span<3,5,4>")
+    assert abs(rf["achieved"] - rf["bytes_per_launch"] / rf["avg_launch_us"] / 1e3) < 1e-9 * rf["achieved"]
+    assert abs(rf["warm"]["achieved"] - rf["bytes_per_launch"] / rf["warm"]["avg_launch_us"] / 1e3) < 1e-9 * rf["achieved"]
+    assert rf["symmetric_storage"] is None  # (this small block cannot run the symmetric kernels: 4 lane groups per pose)
+    assert j["products_per_step"] > 0 and j["time_to_tolerance_ms"] > 0 and j["products_to_tolerance"] > 0
     assert [k["kernel"].split()[0].rstrip(",") for k in rf["kernels"]] == ["k_tcg_update", "k_ml_restrict",
                                                                            "k_ml_coarse_prolong", "k_ml_post"]
     assert all(k["avg_launch_us"] > 0 for k in rf["kernels"])
     cb = j["cpu_baseline"]  # reference configuration (exact factor, one core per agent) + the 1-core port beside it
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and cb["unit"] == "it/s"
     assert "exact sparse factor" in cb["sample"]
+    same = cb["gpu_same_work"]  # the like-for-like pair: same 8 blocks, same iterate, same one sweep, on the GPU
+    assert same["agents"] == 8 and same["value"] > 0 and same["gradnorm_after"] > 0 and cb["gradnorm_after"] > 0
+    assert abs(cb["gpu_over_cpu_same_work"] - same["value"] / cb["value"]) < 1e-9 * cb["gpu_over_cpu_same_work"]
     port = cb["single_agent_port"]
     assert port["cores"] == 1 and port["value"] > 0 and port["rel_diff_fOpt_vs_device"] < 1e-6
     tt = j["quality"]["to_tolerance"]
     assert set(tt) == {"grid:12x10x6/auto", "grid:12x10x6/multilevel", "grid:12x10x6/jacobi",
                        "grid:12x10x6/multilevel+fp32_dense_level"}  # the last: opt-in storage mode, beside the headline
     assert rf["multilevel"]["coarse_inverse_bits"] == 64  # the headline configuration keeps everything in fp64
-    assert rf["cold_plain_storage"]["frac"] > 0 and rf["spmm_storage_selected"] == "plain"
     assert all("products" in v for v in tt.values())
+
+
+@pytest.mark.gpu
+def test_bench_loopback_runs_the_multi_agent_path_through_rccl():
+    """bench.py --loopback: 4 agents on one GPU, every exchange and reduction through the library-owned 1-rank RCCL
+    communicator (the N > 1 data path), same-colour agents solved concurrently, exchange time from device events."""
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "grid:12x10x8", "--steps", "2",
+                        "--warmup", "1", "--settle", "1", "--loopback", "--agents-per-gpu", "4", "--no-cpu-baseline",
+                        "--no-secondary", "--spmm-reps", "10"],
+                       capture_output=True, text=True, cwd=ROOT, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    j = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][0])
+    assert j["config"]["agents"] == 4 and "RCCL" in j["config"]["schedule"] and "loop-back" in j["config"]["schedule"]
+    assert j["quality"]["exchange_ms_per_step_rank0"] > 0 and j["value"] > 0
+    assert j["quality"]["cost_2f_after_step"] < j["quality"]["cost_2f_trajectory"][0]

@@ -708,6 +708,41 @@ def test_rccl_transport_on_one_gpu(oracle):
     comm.close()
 
 
+def test_concurrent_same_colour_agents_match_sequential_updates(oracle):
+    """dpgo_optimize_device_many: the agents of a colour hosted by one GPU are solved CONCURRENTLY (own streams behind the
+    exchange, one feeding thread each).  Every solve is a deterministic function of its own inputs, so three sweeps of
+    a 5-agent (smallGrid3D) and an 8-agent (torus3D) problem give bit-identical iterates, iteration counts and central
+    cost with and without the concurrency; so does the concurrent evaluation of the block terms."""
+    import torch
+    import dpgo_amd
+    from dpgo_amd.agent import DeviceAgent, ExchangePlan, RBCDCluster, build_pose_graphs
+    r = 5
+    for name, robots in (("smallGrid3D", 5), ("torus3D", 8)):
+        om, n = oracle.read_g2o(os.path.join(DATA, name + ".g2o"))
+        X0 = oracle.lift(oracle.chordal_initialization(om, n), r)
+        runs = []
+        for concurrent in (False, True):
+            ranges, graphs = build_pose_graphs(to_product_measurements(om), n, robots, r)
+            plan = ExchangePlan(graphs)
+            agents = {a: DeviceAgent(graphs, plan, a, X0[ranges[a][0]:ranges[a][1]], dpgo_amd.ROptParameters())
+                      for a in range(robots)}
+            cluster = RBCDCluster(plan, agents)
+            cluster.concurrent = concurrent
+            trace, counts = [cluster.central_cost_and_gradnorm()], []
+            for _ in range(3):
+                cluster.sweep()
+                counts.append([(agents[a].last_result.tcg_iterations, agents[a].last_result.rtr_iterations,
+                                agents[a].last_result.precond_used) for a in range(robots)])
+                trace.append(cluster.central_cost_and_gradnorm())
+            torch.cuda.synchronize()
+            runs.append((trace, counts, [agents[a].X.clone() for a in range(robots)]))
+        assert runs[0][1] == runs[1][1]
+        for a in range(robots):
+            assert torch.equal(runs[0][2][a], runs[1][2][a])
+        assert runs[0][0] == runs[1][0]
+        assert runs[1][0][-1][0] < runs[1][0][0][0]
+
+
 def test_external_stream_ordering_is_deterministic(oracle):
     """Regression: work of a handle bound to torch's current stream (the NULL / default stream) is ordered
     with torch ops on that stream -- restoring an iterate with tensor.copy_ and solving again gives the
@@ -1285,10 +1320,11 @@ def test_multilevel_preconditioner_matches_oracle(oracle, name, r, ks, bits):
 
 @pytest.mark.parametrize("name", ["sphere2500", "smallGrid3D"])
 def test_default_preconditioner_selection_matches_oracle(oracle, name):
-    """precond = "auto" (the default): block-Jacobi until a solve uses half of its tCG budget, then the multilevel
-    cycle (and back when a multilevel solve needs a tenth of it).  Whatever a call ran (ROPTResult.precond_used), it
-    matches the oracle run with that preconditioner at matched settings; on sphere2500 from the chordal initialisation
-    the first call (95 of 150 products with block-Jacobi) switches the handle to multilevel."""
+    """precond = "auto" (the default).  A block WITHOUT coupling to other agents starts on the multilevel cycle (the tCG
+    budget, not the trust-region boundary, ends its solves) and hands back to block-Jacobi when a solve needs a tenth
+    of the budget; a handle forced to block-Jacobi switches to multilevel after a solve that used half of it.  The
+    decision is a function of the problem: setting Q again resets it.  Whatever a call ran
+    (ROPTResult.precond_used), it matches the oracle run with that preconditioner at matched settings."""
     import dpgo_amd
     om, n, d, Q, pg, prob = build_single_agent(oracle, name, 5)
     r = 5
@@ -1297,6 +1333,8 @@ def test_default_preconditioner_selection_matches_oracle(oracle, name):
     Xo = Xg = oracle.lift(oracle.chordal_initialization(om, n), r)
     used = []
     ops = {"jacobi": oracle.QuadraticProblem(Q, None, r, d, precond="jacobi")}
+    assert prob.autoState() is True  # single block, no coupling: multilevel from the first call
+    prob.autoState(False)            # ... the hysteresis is followed from the block-Jacobi side
     for call in range(3):
         Xg = matrix_to_tiles(go.optimize(tiles_to_matrix(Xg)), d)
         rg = go.getOptResult()
@@ -1311,6 +1349,12 @@ def test_default_preconditioner_selection_matches_oracle(oracle, name):
         assert used == ["jacobi", "multilevel", "multilevel"]
     else:
         assert used[0] == "jacobi"
+    # a new Q resets the decision (repeated runs reproduce)
+    prob.autoState(False)
+    rowptr, colidx, vals = pg.quadraticMatrix()
+    dpgo_amd.lib.check(prob._lib.dpgo_problem_set_Q_bsr(prob.handle, len(colidx), dpgo_amd.lib.ptr(rowptr),
+                                                        dpgo_amd.lib.ptr(colidx), dpgo_amd.lib.ptr(vals)))
+    assert prob.autoState() is True
 
 
 def test_multilevel_hierarchy_follows_Q_values(oracle):
