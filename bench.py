@@ -264,7 +264,7 @@ def gpu_same_decomposition(meas, n, X0, r, num_agents, precond, device):
         for ag in agents.values():
             ag.restore()
             if precond == "auto":
-                ag.problem.autoState(False)  # a fresh block of a multi-agent problem starts on block-Jacobi
+                ag.problem.autoState("reset")  # (a fresh block of a multi-agent problem starts on block-Jacobi)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         cluster.sweep()
@@ -330,7 +330,7 @@ def time_to_tolerance(workload, r, precond, tol=1e-2, max_calls=12, coarse_bits=
         ag.problem.multilevelCoarseBits(coarse_bits)
     if precond != "jacobi":
         ag.problem.setupMultilevel()  # the hierarchy is a one-time cost per Q (the reference factors inside its first solve)
-    ag.problem.autoState(False)       # "auto" starts where a fresh handle starts
+    ag.problem.autoState("reset")     # "auto" starts where a fresh handle starts
     ag.X.copy_(torch.tensor(X0, device=ag.X.device))
     torch.cuda.synchronize()
     t0 = time.perf_counter()

@@ -7,6 +7,7 @@
 #include "kernels.h"
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <condition_variable>
 #include <functional>
@@ -200,11 +201,14 @@ struct dpgo_problem_s {
     if (const char* e = std::getenv("DPGO_SPMM_SYMMETRIC")) return std::atoi(e) != 0;
     return sizeof(double) * ((size_t)Q.nnzb * b * b + 8 * (size_t)n * T) + sizeof(int32_t) * (size_t)Q.nnzb > ((size_t)256 << 20);
   }
-  // persistent single-XCD tCG kernel (small blocks, block-Jacobi / no preconditioner)
-  bool persist = false;
-  int persist_wgs = 0;  // wanted participants (workgroups on one XCD)
+  // persistent whole-chip tCG kernel (blocks in the latency regime, block-Jacobi / no preconditioner): kernels/persist.h
+  bool persist = false;      // enabled for this handle (by size; DPGO_PERSIST=0/1, dpgo_problem_set_persistent)
+  int persist_share = 1;     // agents solved concurrently on this device: each may take 1/share of the resident slots
+  int persist_wgs = 0, persist_split = 0, persist_mt = 0;  // geometry of the current / last launch
+  int persist_reserved = 0;  // resident-slot reservation held by the running solve
+  bool persist_failed_once = false;
   PersistCtrl* pctrl = nullptr;
-  dbl2* pgran = nullptr;  // hand-off granules of the in-kernel all-reduce: [2 buffers][kPersistMax][2]
+  unsigned long long* pgran = nullptr;  // granule table of the in-kernel all-reduce (kGranWords 8-byte words)
   PersistCtrl* hctrl = nullptr;  // pinned
   double* partials = nullptr;  // 5 regions of kPartialCap*kNP
   DevState* dstate = nullptr;  // 2 slots
@@ -999,48 +1003,118 @@ int launch_ml_apply(dpgo_problem_s* p, const double* Xdev, const double* v, doub
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// Persistent tCG (kernels/persist.h): one launch runs the whole tCG_TR loop of an outer iteration on one XCD.
-__global__ void k_persist_reset(PersistCtrl* c) {
-  c->counts = 0ull;
-  c->target = -1;
-  c->bar = 0u;
-  c->error = 0;
-  c->iters = 0u;
-  c->members = 0u;
-  for (int q = 0; q < 8; ++q) c->ticks[q] = 0ull;
+// Persistent tCG (kernels/persist.h): one launch runs the whole tCG_TR loop of an outer iteration.
+//
+// Residency.  Every workgroup of such a launch waits for all the others, so all of them must be resident at once.  The
+// grid is therefore sized against a per-device count of resident slots shared by all handles of the process (one slot =
+// one 256-thread workgroup; capacity = one per CU: whatever the kernel variant's register budget, and whatever else
+// runs, a CU can always hold one), reserved for the duration of the solve.  A handle that cannot reserve runs the
+// two-kernel scheme.  Other processes are not covered: every in-kernel spin is bounded, a time-out poisons the state
+// record (rtr_stop = kPersistPoison) so that the kernels enqueued behind it exit, and run_optimize resumes from the last
+// consistent state with the two-kernel scheme.
+constexpr int kPersistPoison = 3;
+constexpr int kMaxDevices = 64;
+std::atomic<int> g_persist_used[kMaxDevices];
+std::atomic<int> g_persist_cap[kMaxDevices];  // 0 = not yet queried
+
+int persist_capacity(int device) {
+  int cap = g_persist_cap[device % kMaxDevices].load();
+  if (cap == 0) {
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus <= 0) cus = 1;
+    cap = cus;
+    g_persist_cap[device % kMaxDevices].store(cap);
+  }
+  return cap;
+}
+bool persist_reserve(dpgo_problem_s* p, int slots) {
+  const int cap = persist_capacity(p->device);
+  auto& used = g_persist_used[p->device % kMaxDevices];
+  int cur = used.load();
+  while (cur + slots <= cap)
+    if (used.compare_exchange_weak(cur, cur + slots)) {
+      p->persist_reserved = slots;
+      return true;
+    }
+  return false;
+}
+void persist_release(dpgo_problem_s* p) {
+  if (p->persist_reserved > 0) g_persist_used[p->device % kMaxDevices].fetch_sub(p->persist_reserved);
+  p->persist_reserved = 0;
 }
 
-// returns DPGO_OK with *used = false when the kernel reported a time-out (the caller falls back to the two-kernel scheme)
-int run_tcg_persistent(dpgo_problem_s* p, const double* dinv, bool* used) {
-  *used = false;
-  hipLaunchKernelGGL(k_persist_reset, dim3(1), dim3(1), 0, p->stream, p->pctrl);
-  const int grid = 8 * p->persist_wgs;
-  DISPATCH(p->d, p->r, hipLaunchKernelGGL((k_tcg_persist<D, R, 4>), dim3(grid), dim3(kBlock), 0, p->stream, p->Q.dev(),
-                                          p->x1, p->S1, p->g1, dinv, p->eta, p->z, p->pgran, (double)p->gen * 1048576.0,
-                                          p->dstate + p->cur, p->dstate + (p->cur ^ 1), p->pctrl, p->n, p->hflag, p->gen));
-  HIPC(hipGetLastError());
-  HIPC(hipMemcpyAsync(p->hctrl, p->pctrl, sizeof(PersistCtrl), hipMemcpyDeviceToHost, p->stream));
-  HIPC(hipMemcpyAsync(p->hstate, p->dstate + (p->cur ^ 1), sizeof(DevState), hipMemcpyDeviceToHost, p->stream));
-  HIPC(hipStreamSynchronize(p->stream));
-  if (p->hctrl->error || p->hctrl->members == 0) {
-    p->persist = false;  // placement did not hold on this box: do not try again on this handle
-    if (std::getenv("DPGO_PERSIST_VERBOSE"))
-      std::fprintf(stderr, "dpgo_hip: persistent tCG timed out (members %u); falling back to the two-kernel scheme\n",
-                   p->hctrl->members);
-    return DPGO_OK;
+// Geometry of a launch: lane groups per pose (SPLIT), tiles per workgroup (MT), workgroups.  The smallest-latency layout
+// whose grid fits the handle's share of the resident slots: 4 lane groups per pose (short gather chains) while the tiles
+// fit, otherwise one pose per (d+1) lanes with up to 4 tiles per workgroup.
+struct PersistGeo {
+  int split = 0, mt = 0, wgs = 0;
+};
+PersistGeo persist_geometry(const dpgo_problem_s* p, int wcap) {
+  static const int env_split = [] { const char* e = std::getenv("DPGO_PERSIST_SPLIT"); return e ? std::atoi(e) : 0; }();
+  static const int env_mt = [] { const char* e = std::getenv("DPGO_PERSIST_MT"); return e ? std::atoi(e) : 0; }();
+  const int cand[5][2] = {{4, 1}, {4, 2}, {1, 1}, {1, 2}, {1, 4}};
+  PersistGeo g;
+  wcap = std::min(wcap, kPersistMax);
+  for (auto& c : cand) {
+    if (env_split && c[0] != env_split) continue;
+    if (env_mt && c[1] != env_mt) continue;
+    const int P = (64 / (p->b * c[0])) * kWaves;
+    const int tiles = std::max(1, (p->n + P - 1) / P);
+    const int wgs = (tiles + c[1] - 1) / c[1];
+    if (wgs <= wcap) {
+      g.split = c[0];
+      g.mt = c[1];
+      g.wgs = wgs;
+      return g;
+    }
   }
-  if (std::getenv("DPGO_PERSIST_VERBOSE"))
-    std::fprintf(stderr,
-                 "dpgo_hip: persistent tCG: %u participants on XCD %d, %u iterations; per iteration (us): Hessian phase "
-                 "%.2f, all-reduce %.2f, update phase %.2f, all-reduce %.2f\n",
-                 p->hctrl->members, p->hctrl->target, p->hctrl->iters,
-                 0.01 * (double)p->hctrl->ticks[0] / std::max<double>(1.0, (double)p->hctrl->ticks[4]),
-                 0.01 * (double)p->hctrl->ticks[1] / std::max<double>(1.0, (double)p->hctrl->ticks[4]),
-                 0.01 * (double)p->hctrl->ticks[2] / std::max<double>(1.0, (double)p->hctrl->ticks[4]),
-                 0.01 * (double)p->hctrl->ticks[3] / std::max<double>(1.0, (double)p->hctrl->ticks[4]));
+  return g;
+}
+
+// Enqueues the persistent tCG launch of one outer iteration (no host wait).  *used = false: not launched (no geometry /
+// no free slots) -- the caller runs the two-kernel scheme.
+int launch_tcg_persistent(dpgo_problem_s* p, const double* dinv, bool* used) {
+  *used = false;
+  if (p->persist_reserved == 0) {
+    const PersistGeo g = persist_geometry(p, std::max(1, persist_capacity(p->device) / std::max(1, p->persist_share)));
+    if (g.wgs <= 0 || !persist_reserve(p, g.wgs)) return DPGO_OK;
+    p->persist_split = g.split;
+    p->persist_mt = g.mt;
+    p->persist_wgs = g.wgs;
+  }
+  HIPC(hipMemsetAsync(p->pctrl, 0, sizeof(PersistCtrl), p->stream));
+  HIPC(hipMemsetAsync(p->pgran, 0, sizeof(unsigned long long) * kGranWords, p->stream));
+  const unsigned salt = ((p->gen & 0x7ffu) + 1u) << 20;  // never 0; the in-launch step counter fills the low 20 bits
+#define PERSIST_LAUNCH(SP, MT_)                                                                                       \
+  hipLaunchKernelGGL((k_tcg_persist<D, R, SP, MT_>), dim3(p->persist_wgs), dim3(kBlock), 0, p->stream, p->Q.dev(),    \
+                     p->x1, p->S1, p->g1, dinv, p->eta, p->z, p->pgran, salt, p->dstate + p->cur,                     \
+                     p->dstate + (p->cur ^ 1), p->pctrl, p->n, p->hflag, p->gen)
+  DISPATCH(p->d, p->r, {
+    if (p->persist_split == 4 && p->persist_mt == 1) PERSIST_LAUNCH(4, 1);
+    else if (p->persist_split == 4) PERSIST_LAUNCH(4, 2);
+    else if (p->persist_mt == 1) PERSIST_LAUNCH(1, 1);
+    else if (p->persist_mt == 2) PERSIST_LAUNCH(1, 2);
+    else PERSIST_LAUNCH(1, 4);
+  });
+#undef PERSIST_LAUNCH
+  HIPC(hipGetLastError());
   p->cur ^= 1;
   *used = true;
   return DPGO_OK;
+}
+
+void persist_report(dpgo_problem_s* p) {
+  if (!std::getenv("DPGO_PERSIST_VERBOSE")) return;
+  if (hipMemcpyAsync(p->hctrl, p->pctrl, sizeof(PersistCtrl), hipMemcpyDeviceToHost, p->stream) != hipSuccess ||
+      hipStreamSynchronize(p->stream) != hipSuccess)
+    return;
+  const double it = std::max<double>(1.0, (double)p->hctrl->ticks[4]);
+  std::fprintf(stderr,
+               "dpgo_hip: persistent tCG: %u workgroups (%d lane groups per pose, %d tiles each)%s, %u iterations; per "
+               "iteration (us): Hessian phase %.2f, all-reduce %.2f, update phase %.2f, all-reduce %.2f\n",
+               p->hctrl->members, p->persist_split, p->persist_mt, p->hctrl->error ? " TIMED OUT" : "", p->hctrl->iters,
+               0.01 * (double)p->hctrl->ticks[0] / it, 0.01 * (double)p->hctrl->ticks[1] / it,
+               0.01 * (double)p->hctrl->ticks[2] / it, 0.01 * (double)p->hctrl->ticks[3] / it);
 }
 
 // One ROPTLIB SolversTR::Run outer iteration: tCG + retraction + rho test.  State stays on the device; the host
@@ -1050,21 +1124,21 @@ int rtr_outer_iteration(dpgo_problem_s* p, const dpgo_ropt_params* prm, const do
   p->gen += 1;
   const bool ml = prm->precond == DPGO_PRECOND_MULTILEVEL;
   p->zr_from_post = ml;
-  if (p->persist && !ml) {
+  if (p->persist && !ml && !p->persist_failed_once) {
     bool used = false;
-    CHK(run_tcg_persistent(p, dinv, &used));
-    if (used) {
-      if (p->hstate->rtr_stop) {
-        p->saw_rtr_stop = true;
-        return DPGO_OK;
-      }
+    CHK(launch_tcg_persistent(p, dinv, &used));
+    if (used) {  // the whole outer iteration is enqueued without a host wait; a stop test met earlier makes these exit
       CHK(launch_retract(p, p->x1, p->eta, 1.0, p->x2, p->dstate + p->cur));
       CHK(launch_grad(p, p->x2, p->g2, p->S2, nullptr, p->dstate + p->cur));
       cnt.spmm += 1;
       CHK(launch_hess(p, p->x1, p->S1, p->eta, p->g1, p->Hd, p->pH(), p->dstate + p->cur, 0));
       cnt.spmm += 1;
       CHK(launch_rtr_update(p));
+      persist_report(p);
       if (poll_at_end) CHK(poll_state(p));
+      else if (__atomic_load_n(p->hflag, __ATOMIC_ACQUIRE) >> 32 == p->gen &&
+               (__atomic_load_n(p->hflag, __ATOMIC_ACQUIRE) & 2ull))
+        p->saw_rtr_stop = true;  // (opportunistic: the device is usually far behind the enqueueing host)
       return DPGO_OK;
     }
   }
@@ -1152,6 +1226,22 @@ int run_optimize(dpgo_problem_s* p, const dpgo_ropt_params* prm, dpgo_ropt_resul
   std::memset(res, 0, sizeof(*res));
   res->tCGStatus = DPGO_TCG_MAXITER;
   if (p->hctrl) std::memset(p->hctrl, 0, sizeof(PersistCtrl));
+  struct SlotGuard {  // the resident-slot reservation of the persistent kernel lives as long as the solve
+    dpgo_problem_s* p;
+    ~SlotGuard() { persist_release(p); }
+  } slot_guard{p};
+  // a persistent launch that timed out left the state record poisoned and everything behind it skipped: clear the mark,
+  // stop using the kernel on this handle, and let the caller resume from the (consistent) state with the two-kernel scheme
+  auto persist_recover = [&]() -> int {
+    if (p->hstate->rtr_stop != kPersistPoison) return 0;
+    p->persist_failed_once = true;
+    persist_release(p);
+    if (std::getenv("DPGO_PERSIST_VERBOSE"))
+      std::fprintf(stderr, "dpgo_hip: persistent tCG timed out; this handle continues with the two-kernel scheme\n");
+    p->hstate->rtr_stop = 0;
+    p->saw_rtr_stop = false;
+    return 1;
+  };
   dpgo_ropt_params resolved = *prm;  // DPGO_PRECOND_AUTO -> what this handle currently runs
   if (prm->precond == DPGO_PRECOND_AUTO) p->auto_decide();
   if (prm->precond == DPGO_PRECOND_AUTO)
@@ -1203,6 +1293,10 @@ int run_optimize(dpgo_problem_s* p, const dpgo_ropt_params* prm, dpgo_ropt_resul
           CHK(push_state(p));
           p->saw_rtr_stop = false;
           CHK(rtr_outer_iteration(p, prm, dinv, cnt, true));
+          if (persist_recover()) {  // (push_state at the top of the loop re-installs the state)
+            shrink_tries -= 1;
+            continue;
+          }
           if (p->hstate->accepted_last) break;
           if (total_steps > 10) break;  // "Too many RTR rejections. Returning initial guess." (x1 untouched)
           radius /= 4.0;
@@ -1211,13 +1305,22 @@ int run_optimize(dpgo_problem_s* p, const dpgo_ropt_params* prm, dpgo_ropt_resul
       } else {
         const bool polling = prm->tcg_poll_interval > 0;
         p->saw_rtr_stop = false;
-        for (int it = 0; it < prm->RTR_iterations; ++it) {
-          CHK(rtr_outer_iteration(p, prm, dinv, cnt, polling));
-          if (polling ? (p->hstate->rtr_stop != 0) : p->saw_rtr_stop) break;
-          const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-          if (prm->time_bound_s > 0 && el > prm->time_bound_s) break;  // Solver.TimeBound (:78)
+        int it = 0;
+        while (true) {
+          for (; it < prm->RTR_iterations; ++it) {
+            CHK(rtr_outer_iteration(p, prm, dinv, cnt, polling));
+            if (polling ? (p->hstate->rtr_stop != 0) : p->saw_rtr_stop) break;
+            const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            if (prm->time_bound_s > 0 && el > prm->time_bound_s) break;  // Solver.TimeBound (:78)
+          }
+          if (p->persist_reserved > 0)
+            HIPC(hipMemcpyAsync(p->hctrl, p->pctrl, sizeof(PersistCtrl), hipMemcpyDeviceToHost, p->stream));
+          CHK(poll_state(p));
+          if (!persist_recover()) break;
+          it = p->hstate->outer_iter;  // completed outer iterations; the rest runs on the two-kernel scheme
+          CHK(push_state(p));
+          p->cur = 0;
         }
-        CHK(poll_state(p));
         if (deferred) {
           res->fInit = p->hstate->fInit;
           res->gradNormInit = p->hstate->gnInit;
@@ -1392,27 +1495,14 @@ int tune_launch_caps(dpgo_problem_s* p) {
   return DPGO_OK;
 }
 
-// Persistent tCG: used for blocks whose tCG working set stays in one XCD's 4 MiB L2 neighbourhood and whose SpMM tiles
-// can be spread over the workgroups ONE XCD can hold at once (32 CUs x occupancy).  DPGO_PERSIST=0/1 overrides.
+// Persistent tCG: on by size -- blocks in the latency regime (DPGO_PERSIST_MAX_POSES, default 16 384 poses: above, a tCG
+// iteration is bytes, not latency, and the streaming two-kernel scheme wins).  DPGO_PERSIST=0/1 overrides.
 int tune_persist(dpgo_problem_s* p) {
-  p->persist = false;
-  int occ = 0;
-  if (p->split != 4) return DPGO_OK;  // the kernel exists for the small-block (SPLIT = 4) geometry only
-  DISPATCH(p->d, p->r, HIPC(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_tcg_persist<D, R, 4>, kBlock, 0)));
-  int dev = 0, cus = 0;
-  HIPC(hipGetDevice(&dev));
-  HIPC(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-  const int per_xcd = std::max(1, cus / 8);
-  // the occupancy API can be one block per CU high when the SGPR file is the limit (MI355X_MICROARCH.md, residency);
-  // this kernel is VGPR-bound (2-3 blocks per CU), where it is exact -- and a wrong count only costs the time-out
-  const int cap = std::max(1, std::min(kPersistMax, per_xcd * std::max(1, occ >= 7 ? occ - 1 : occ)));
-  const int P = (64 / (p->b * p->split)) * kWaves;
-  const int tiles = std::max(1, (p->n + P - 1) / P);
-  p->persist_wgs = std::min(tiles, cap);
-  if (const char* e = std::getenv("DPGO_PERSIST_WGS")) p->persist_wgs = std::max(1, std::min(cap, std::atoi(e)));
-  bool on = false;  // opt-in until the single-XCD placement has been validated on the target box
-  if (const char* e = std::getenv("DPGO_PERSIST")) on = std::atoi(e) != 0;
-  p->persist = on && tiles <= kResidentTiles * cap;  // every workgroup keeps its tiles resident in LDS
+  static const int max_poses = [] { const char* e = std::getenv("DPGO_PERSIST_MAX_POSES"); return e ? std::atoi(e) : 16384; }();
+  const bool fits = persist_geometry(p, persist_capacity(p->device)).wgs > 0;
+  bool on = fits && p->n <= max_poses;
+  if (const char* e = std::getenv("DPGO_PERSIST")) on = fits && std::atoi(e) != 0;
+  p->persist = on;
   return DPGO_OK;
 }
 
@@ -1497,8 +1587,8 @@ int dpgo_problem_create(dpgo_problem_t* out, int r, int d, int n, int device) {
     HIPC(hipMalloc(&p->dstate, sizeof(DevState) * 2));
     HIPC(hipHostMalloc(&p->hstate, sizeof(DevState)));
     HIPC(hipMalloc(&p->pctrl, sizeof(PersistCtrl)));
-    HIPC(hipMalloc(&p->pgran, sizeof(dbl2) * 2 * kPersistMax * 2));
-    HIPC(hipMemsetAsync(p->pgran, 0, sizeof(dbl2) * 2 * kPersistMax * 2, p->stream));
+    HIPC(hipMalloc(&p->pgran, sizeof(unsigned long long) * kGranWords));
+    HIPC(hipMemsetAsync(p->pgran, 0, sizeof(unsigned long long) * kGranWords, p->stream));
     HIPC(hipHostMalloc(&p->hctrl, sizeof(PersistCtrl)));
     CHK(tune_persist(p));
     HIPC(hipHostMalloc(&p->hflag, 64, hipHostMallocCoherent | hipHostMallocMapped));
@@ -1954,6 +2044,7 @@ int dpgo_problem_auto_state(dpgo_problem_t p, int* use_multilevel) {
     p->auto_ml = *use_multilevel != 0;
     p->auto_decided = true;
   } else {
+    if (*use_multilevel == -2) p->auto_decided = false;  // back to the decision a fresh handle takes for this problem
     p->auto_decide();
   }
   *use_multilevel = p->auto_ml ? 1 : 0;
@@ -2217,6 +2308,7 @@ static int run_many(int count, const dpgo_problem_t* handles, void* after_stream
     prev[k] = handles[k]->stream;
     if (prev[k] != handles[k]->own_stream) e = hipStreamSynchronize(prev[k]);  // earlier work of the handle itself
     handles[k]->stream = handles[k]->own_stream;
+    handles[k]->persist_share = count;  // persistent tCG launches: each handle sizes its grid to 1/count of the chip
     if (e == hipSuccess) e = hipStreamWaitEvent(handles[k]->own_stream, ev, 0);
   }
   std::vector<int> rc(count, DPGO_OK);
@@ -2230,7 +2322,10 @@ static int run_many(int count, const dpgo_problem_t* handles, void* after_stream
       if (r != DPGO_OK) msg[k] = g_err;  // thread-local message of the worker
     });
   }
-  for (int k = 0; k < count; ++k) handles[k]->stream = prev[k];
+  for (int k = 0; k < count; ++k) {
+    handles[k]->stream = prev[k];
+    handles[k]->persist_share = 1;
+  }
   (void)hipEventDestroy(ev);
   if (e != hipSuccess) return fail(DPGO_ERR_HIP, std::string("stream ordering of the concurrent update: ") + hipGetErrorString(e));
   for (int k = 0; k < count; ++k)
@@ -2322,23 +2417,22 @@ int dpgo_debug_timeline(long long* out /* [2][16] */) {
 #endif
 
 int dpgo_problem_persistent_info(dpgo_problem_t p, int* enabled, int* workgroups, int* last_members, int* last_iterations,
-                                 int* last_xcd) {
+                                 int* last_layout) {
   if (!p) return fail(DPGO_ERR_INVALID, "null handle");
-  if (enabled) *enabled = p->persist ? 1 : 0;
+  if (enabled) *enabled = (p->persist && !p->persist_failed_once) ? 1 : 0;
   if (workgroups) *workgroups = p->persist_wgs;
   if (last_members) *last_members = p->hctrl ? (int)p->hctrl->members : 0;
   if (last_iterations) *last_iterations = p->hctrl ? (int)p->hctrl->iters : 0;
-  if (last_xcd) *last_xcd = p->hctrl ? p->hctrl->target : -1;
+  if (last_layout) *last_layout = (p->hctrl && p->hctrl->members) ? p->persist_split * 16 + p->persist_mt : 0;
   return DPGO_OK;
 }
 
 int dpgo_problem_set_persistent(dpgo_problem_t p, int enable) {
   if (!p) return fail(DPGO_ERR_INVALID, "null handle");
-  const int P = (64 / (p->b * p->split)) * kWaves;
-  const int tiles = std::max(1, (p->n + P - 1) / P);
-  if (enable && (p->split != 4 || tiles > kResidentTiles * p->persist_wgs))
-    return fail(DPGO_ERR_UNSUPPORTED, "block too large for the persistent tCG kernel (its tiles must fit one XCD's LDS)");
+  if (enable && persist_geometry(p, persist_capacity(p->device)).wgs <= 0)
+    return fail(DPGO_ERR_UNSUPPORTED, "block too large for the persistent tCG kernel (at most 4 tiles on each of 256 workgroups)");
   p->persist = enable != 0;
+  if (enable) p->persist_failed_once = false;
   return DPGO_OK;
 }
 

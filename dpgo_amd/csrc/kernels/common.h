@@ -374,17 +374,21 @@ __device__ __forceinline__ RowIdx row_idx_load(const int32_t* __restrict__ rowpt
   return ri;
 }
 
-// NT: the gathered tiles of V are loaded with the nontemporal policy, which is served by the XCD's L2 and never by this
-// CU's L1 (MI355X_MICROARCH.md, "Workgroup dispatch ... visibility") -- used by the persistent tCG kernel, where V was
-// written by other workgroups of the SAME launch.
-template <bool NT>
+// LD: 0 = plain, 1 = nontemporal, 2 = agent-scope relaxed atomic (global_load sc1: coherent with write-through stores of
+// workgroups on other XCDs -- the persistent tCG kernel, where V is rewritten by the other workgroups of the SAME launch)
+template <int LD>
 __device__ __forceinline__ double ld_tile(const double* __restrict__ p) {
-  if constexpr (NT)
+  if constexpr (LD == 2) {
+    const unsigned long long b =
+        __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return __longlong_as_double((long long)b);
+  } else if constexpr (LD == 1) {
     return __builtin_nontemporal_load(p);
-  else
+  } else {
     return *p;
+  }
 }
-template <int D, int R, int SPLIT, bool NT = false>
+template <int D, int R, int SPLIT, int NT = 0>
 __device__ __forceinline__ void spmm_col_pre(const RowIdx& ri, const int32_t* __restrict__ colidx,
                                              const double* __restrict__ vals, const double* __restrict__ V, int s,
                                              int c, double (&acc)[R]) {
@@ -481,7 +485,7 @@ __device__ __forceinline__ void spmm_col_pre(const RowIdx& ri, const int32_t* __
   }
 }
 
-template <int D, int R, int SPLIT, bool NT = false>
+template <int D, int R, int SPLIT, int NT = 0>
 __device__ __forceinline__ void spmm_col(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colidx,
                                          const double* __restrict__ vals, const double* __restrict__ V,
                                          int i, int s, int c, bool ok, double (&acc)[R]) {

@@ -1,33 +1,36 @@
-// kernels/persist.h -- persistent single-XCD tCG kernel for small blocks (the latency regime of multi-GPU strong scaling).
+// kernels/persist.h -- persistent whole-chip tCG kernel for blocks in the latency regime (what a GPU runs when a graph is
+// cut over many agents / GPUs: <= ~65k poses).
 // Part of kernels.h (included inside namespace dpgo, in this order: common.h, problem.h, tcg.h, persist.h, multilevel.h, dense.h, manifold.h, rtr.h, agent.h, init.h).
 #pragma once
 
 // ================================================================ one launch per tCG run
-// Below ~6k poses a tCG iteration of the two-kernel scheme (k_tcg_hess | k_tcg_update) is half kernel boundary
-// (~4 us from the last instruction of one kernel to the first of the next, twice per iteration).
-// This kernel runs ROPTLIB's whole tCG_TR loop (same arithmetic, same scalar recurrences as the
-// two-kernel scheme) in ONE launch, with in-kernel barriers between the phases of an iteration:
+// Below a few ten thousand poses a tCG iteration of the two-kernel scheme (k_tcg_hess | k_tcg_update) is made of kernel
+// boundaries and prologues, not of bytes (2 500 poses 14.4 us, 12 500 poses 20.8 us per iteration
+// whatever they compute).  This kernel runs ROPTLIB's whole tCG_TR loop of one outer iteration (same
+// arithmetic, same scalar recurrences as the two-kernel scheme) in ONE launch on up to 256 workgroups:
 //   phase A: Hz = proj_X(z Q - z_rot S) on the workgroup's own rows (the gather reads the neighbours' z),
-//            delta <- beta delta - z,  H delta <- beta H delta - Hz,  partial <delta, H delta>          | barrier
+//            delta <- beta delta - z,  H delta <- beta H delta - Hz,  partial <delta, H delta>          | all-reduce
 //   phase B: alpha / boundary test;  eta += alpha delta,  r += alpha H delta,  z = proj_X(r Dinv),
-//            partials <r,r>, <z,r>                                                                       | barrier
-// What makes the barriers cheap is that every participant sits on ONE XCD: the XCD's L2 is then the coherence point,
-// so a barrier is one 16-byte store and a poll of the other participants' stores -- no atomics, no cache write-back /
-// invalidate (which is what the 4-7 us of a chip-wide barrier are made of, MI355X_MICROARCH.md price list) -- and it
-// carries the partial sums of the step's dot products with it (xcd_allreduce), provided that
-//   * a producer's stores have reached the L2 before it arrives        (s_waitcnt vmcnt(0) + workgroup barrier),
-//   * consumers read other workgroups' data with L1-bypassing loads    (nontemporal / agent-scope atomic loads).
-// Placement is undefined by HIP, so it is ESTABLISHED at run time, not assumed: the launch has 8x the wanted workgroups,
-// each reads its XCC id; the first arrival fixes the target XCD, workgroups elsewhere leave at once, and the ones on
-// the target wait until every launched workgroup has reported before they count themselves.  Every spin is bounded;
-// a time-out raises PersistCtrl::error and the host reruns the outer iteration with the two-kernel scheme.
-struct PersistCtrl {          // zeroed (target = -1) by the host before every launch
-  unsigned long long counts;  // [31:0] workgroups that have started, [63:32] of them on the target XCD (one atomic)
-  int target;                 // XCC id of the participants
-  unsigned bar;               // unused (kept for layout)
-  int error;                  // a spin ran out: results invalid
-  unsigned iters;             // diagnostic: tCG iterations executed
-  unsigned members;           // diagnostic: participants
+//            partials <r,r>, <z,r>                                                                       | all-reduce
+// * Every tCG vector of the workgroup's rows (r, eta, delta, H delta, z, and X, S, Dinv, the row pointers and preloaded
+//   column indices) lives in REGISTERS for the whole launch -- one lane = one column of one pose, as everywhere; only
+//   the columns of a pose meet through a wave-private LDS tile.  The single vector that crosses workgroups is z.
+// * Placement-independent hand-off (MI355X_MICROARCH.md, "Workgroup dispatch ... visibility"; cdna_hip_programming.md
+//   Guideline 16): the 8 XCDs' L2s are not coherent and HIP promises nothing about where a workgroup runs, so z is stored
+//   WRITE-THROUGH (agent-scope relaxed atomic stores = sc1) and gathered with agent-scope loads (sc1: never served by
+//   this CU's L1 or a stale L2 line), every storing wave drains its stores (s_waitcnt vmcnt(0)) before the workgroup
+//   publishes, and the publish IS the all-reduce: each workgroup stores its K partial sums as 8-byte granules
+//   {epoch, 32-bit half} (one atomic store each, so tag and payload arrive together), ONE wave per workgroup sweeps all
+//   participants' granules until every tag carries this step's epoch, and everybody forms the sums in the same fixed
+//   order -- so every workgroup takes the same data-dependent decisions (negative curvature, boundary, kappa/theta stop).
+//   Seeing a participant's step-e granules implies its z stores of step e have reached memory.
+// * Every participant must be resident: the host sizes the grid to what the chip holds at once (and reserves those
+//   slots process-wide, so that concurrently solved agents never wait for each other's workgroups); every spin is
+//   bounded, a time-out raises PersistCtrl::error and the host reruns the outer iteration with the two-kernel scheme.
+struct PersistCtrl {
+  int error;       // a spin ran out: results invalid
+  unsigned iters;  // diagnostic: tCG iterations executed
+  unsigned members;
   unsigned pad;
   // diagnostic timeline of participant 0 (100 MHz wall clock ticks, summed over the iterations after the first):
   // [0] phase A (Hessian step)  [1] all-reduce after A  [2] phase B (update)  [3] all-reduce after B  [4] iterations
@@ -35,142 +38,113 @@ struct PersistCtrl {          // zeroed (target = -1) by the host before every l
 };
 
 constexpr unsigned kSpinLimit = 1u << 21;  // polls (with s_sleep) before a spin gives up: ~0.5 s
+constexpr int kPersistMax = kBlock;        // participants (workgroups) of one launch
+constexpr int kGranVals = 2;               // partial sums per all-reduce (max)
+constexpr int kGranRows = 2 * kGranVals;   // 8-byte words per participant: {epoch, low half}, {epoch, high half} per value
+// granule table: [2 buffers][kGranRows][kPersistMax] words -- a row is contiguous over the participants, so a sweep is
+// kGranRows coalesced loads per 64 participants
+constexpr size_t kGranWords = (size_t)2 * kGranRows * kPersistMax;
 
-__device__ __forceinline__ int xcc_id() {
-  // s_getreg_b32 hwreg(HW_REG_XCC_ID = 20, offset 0, size 4)
-  return (int)(__builtin_amdgcn_s_getreg(((4 - 1) << 11) | (0 << 6) | 20) & 0xf);
+__device__ __forceinline__ double ld_agent(const double* p) {
+  // agent-scope relaxed load (global_load_dwordx2 sc1): coherent with other workgroups' write-through stores
+  const unsigned long long b =
+      __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return __longlong_as_double((long long)b);
+}
+__device__ __forceinline__ void st_agent(double* p, double v) {
+  // agent-scope relaxed store (global_store_dwordx2 sc1): write-through, visible to every XCD once acknowledged
+  __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED,
+                     __HIP_MEMORY_SCOPE_AGENT);
 }
 
-__device__ __forceinline__ bool spin_until_ge(unsigned* p, unsigned want, int* error) {
-  for (unsigned it = 0; it < kSpinLimit; ++it) {
-    if (__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= want) return true;
-    if ((it & 63u) == 63u && __hip_atomic_load(error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return false;
-    __builtin_amdgcn_s_sleep(1);
-  }
-  __hip_atomic_store(error, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  return false;
-}
-
-// Every vector the launch itself writes (eta, r, z, delta, H delta) is read with L1-bypassing loads: the two phases
-// map poses to workgroups differently, so "own rows" of one phase may have been written by another workgroup.
-template <int R>
-__device__ __forceinline__ void load_col_nt(const double* p, double (&v)[R]) {
-#pragma unroll
-  for (int a = 0; a < R; ++a) v[a] = __builtin_nontemporal_load(p + a);
-}
-
-// Barrier + all-reduce of the participants in one step, without atomics: every workgroup publishes its K partial sums
-// as K granules {tag, value} -- one naturally aligned 16-byte store each, so tag and value arrive together
-// (MI355X_MICROARCH.md, hand-off granules) -- and thread t of every workgroup polls participant t's granules with
-// 16-byte L1-bypassing loads until the tag of THIS step shows up.  The sums are then formed in the same fixed order by
-// everybody.  tag = tagbase + epoch is unique per launch and step (no clearing between launches); two buffers
-// alternate, which suffices because nobody can be more than one step ahead of the slowest participant.
-constexpr int kPersistMax = kBlock;  // participants <= threads of a workgroup (one poller per participant)
+// Barrier + all-reduce of the launch's workgroups in one step.  PRECONDITION: every thread has executed
+// `s_waitcnt vmcnt(0)` after its last store that other workgroups read, and a workgroup barrier followed (the
+// block_allreduce that produced `val` provides it; `val` is identical in all threads of the workgroup).
 template <int K>
-__device__ __forceinline__ bool xcd_allreduce(dbl2* gran, int rank, int members, double tagbase, unsigned& epoch,
-                                              double (&val)[K], double* red, int* error, int* ok_s) {
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this thread's vector stores have been acknowledged by the L2
+__device__ __forceinline__ bool chip_allreduce(unsigned long long* gran, int rank, int members, unsigned salt, unsigned& step,
+                                               double (&val)[K], double* red, int* error, int* ok_s) {
+  static_assert(K <= kGranVals, "granule rows");
+  step += 1;
+  const unsigned long long epoch = (unsigned long long)(salt | step);  // never 0; unique per launch and step
+  unsigned long long* buf = gran + (size_t)(step & 1u) * kGranRows * kPersistMax;
   if (threadIdx.x == 0) *ok_s = 1;
-  __syncthreads();
-  epoch += 1;
-  const double tag = tagbase + (double)epoch;
-  dbl2* buf = gran + (size_t)(epoch & 1u) * kPersistMax * 2;
-#pragma unroll
-  for (int k = 0; k < K; ++k) {
-    if ((int)threadIdx.x == k) {  // block_allreduce left the workgroup's sums in every thread
-      dbl2 gv;
-      gv.x = tag;
-      gv.y = val[k];
-      buf[rank * 2 + k] = gv;
-    }
+  if ((int)threadIdx.x < 2 * K) {
+    const int k = threadIdx.x >> 1, half = threadIdx.x & 1;
+    const unsigned long long bits = (unsigned long long)__double_as_longlong(val[k]);
+    const unsigned long long w = (epoch << 32) | (half ? (bits >> 32) : (bits & 0xffffffffull));
+    __hip_atomic_store(buf + (size_t)threadIdx.x * kPersistMax + rank, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
-  double v[K];
+  __syncthreads();  // ok_s initialised before a poller may clear it
+  if (threadIdx.x < 64) {  // ONE wave sweeps: lane l takes participants l, l + 64, l + 128, l + 192
+    double acc[K];
 #pragma unroll
-  for (int k = 0; k < K; ++k) v[k] = 0.0;
-  if ((int)threadIdx.x < members) {
+    for (int k = 0; k < K; ++k) acc[k] = 0.0;
+    bool fine = true;
 #pragma unroll
-    for (int k = 0; k < K; ++k) {
-      bool got = false;
-      for (unsigned it = 0; it < kSpinLimit; ++it) {
-        const dbl2 gv = __builtin_nontemporal_load(buf + threadIdx.x * 2 + k);
-        if (gv.x == tag) {
-          v[k] = gv.y;
-          got = true;
-          break;
-        }
-        if ((it & 255u) == 255u && __hip_atomic_load(error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
-        __builtin_amdgcn_s_sleep(1);
-      }
-      if (!got) {
-        __hip_atomic_store(error, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        *ok_s = 0;
-      }
-    }
-  }
-  block_allreduce<K>(v, red);  // two workgroup barriers inside: ok_s is settled afterwards
+    for (int q = 0; q < kPersistMax / 64; ++q) {
+      const int t = (int)threadIdx.x + 64 * q;
+      if (q * 64 >= members) break;  // wave-uniform
+      if (t < members) {
+        bool got = false;
+        for (unsigned it = 0; it < kSpinLimit; ++it) {
+          unsigned long long w[2 * K];
 #pragma unroll
-  for (int k = 0; k < K; ++k) val[k] = v[k];
-  return *ok_s != 0;
-}
-
-// Tiles a workgroup may own.  Its rows of X, S, Dinv and of every tCG vector stay in LDS for the whole launch, the row
-// pointers / preloaded column indices in registers: a phase is then ONE hop of loads (the gathered z tiles and the Q
-// blocks, issued together) instead of a chain of dependent ones -- in this regime a kernel is latency, not bytes.
-constexpr int kResidentTiles = 3;
-
-template <int D, int R, int SPLIT>
-__global__ __launch_bounds__(kBlock) void k_tcg_persist(BsrDev Q, const double* __restrict__ X,
-                                                        const double* __restrict__ S, const double* __restrict__ g,
-                                                        const double* __restrict__ dinv, double* eta, double* z,
-                                                        dbl2* gran, double tagbase, const DevState* __restrict__ sin,
-                                                        DevState* __restrict__ sout, PersistCtrl* ctrl, int n,
-                                                        unsigned long long* hflag, unsigned gen) {
-  using GEO = Geo<D, R, SPLIT>;
-  constexpr int P = GEO::P, G = GEO::G, T = GEO::T, B = GEO::B, BB = GEO::BB, MT = kResidentTiles;
-  __shared__ __attribute__((aligned(16))) double Xs[MT][P][T], Es[MT][P][T], Rs[MT][P][T], Ds[MT][P][T], Hs[MT][P][T],
-      Zs[MT][P][T];
-  __shared__ double Ss[MT][P][D * D], Vs[MT][P][BB];
-  __shared__ double ex[kWaves][G][T];  // wave-private exchange tile (columns of one pose meet here)
-  __shared__ double red[kWaves * kNP];
-  __shared__ int ok_s, rank_s, members_s;
-
-  // ---- establish the participants: the workgroups that landed on the target XCD
-  if (threadIdx.x == 0) {
-    const int xcc = xcc_id();
-    // first arrival fixes the target (agent-scope CAS); everybody reads the winner back
-    const int prev = atomicCAS(&ctrl->target, -1, xcc);
-    const int tgt = (prev == -1) ? xcc : prev;
-    // one atomic reports the arrival and, on the target XCD, takes a rank
-    const bool mine = (xcc == tgt);
-    const unsigned long long old = atomicAdd(&ctrl->counts, 1ull | (mine ? (1ull << 32) : 0ull));
-    int rank = mine ? (int)(old >> 32) : -1;
-    int members = 0;
-    if (rank >= 0) {
-      // every launched workgroup has reported => the member count is final
-      bool done = false;
-      for (unsigned it = 0; it < kSpinLimit && !done; ++it) {
-        const unsigned long long v = __hip_atomic_load(&ctrl->counts, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if ((unsigned)(v & 0xffffffffull) >= gridDim.x) {
-          members = (int)(v >> 32);
-          done = true;
-        } else {
+          for (int j = 0; j < 2 * K; ++j)
+            w[j] = __hip_atomic_load(buf + (size_t)j * kPersistMax + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          bool all = true;
+#pragma unroll
+          for (int j = 0; j < 2 * K; ++j) all = all && ((w[j] >> 32) == epoch);
+          if (all) {
+#pragma unroll
+            for (int k = 0; k < K; ++k)
+              acc[k] += __longlong_as_double((long long)((w[2 * k] & 0xffffffffull) | (w[2 * k + 1] << 32)));
+            got = true;
+            break;
+          }
+          if ((it & 255u) == 255u && __hip_atomic_load(error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
           __builtin_amdgcn_s_sleep(1);
         }
+        fine = fine && got;
       }
-      const int ntiles = (n + P - 1) / P;
-      if (!done || members > kPersistMax || (long long)members * MT < ntiles) {  // placement did not hold: give up
-        __hip_atomic_store(&ctrl->error, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        rank = -1;
-      }
-      if (rank == 0) ctrl->members = (unsigned)members;
     }
-    rank_s = rank;
-    members_s = members;
+    if (!fine) {
+      __hip_atomic_store(error, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      *ok_s = 0;
+    }
+    // lane l holds the sum over its participants (ascending); fixed DPP tree over the lanes: the same bits everywhere
+#pragma unroll
+    for (int k = 0; k < K; ++k) acc[k] = wave_reduce_lane63(acc[k]);
+    if (threadIdx.x == 63) {
+#pragma unroll
+      for (int k = 0; k < K; ++k) red[k] = acc[k];
+    }
   }
   __syncthreads();
-  const int rank = rank_s, members = members_s;
-  if (rank < 0 || members <= 0) return;  // not on the target XCD (or the error flag is set)
+#pragma unroll
+  for (int k = 0; k < K; ++k) val[k] = red[k];
+  const bool ok = *ok_s != 0;
+  __syncthreads();  // red / ok_s may be rewritten by the next reduction
+  return ok;
+}
 
+// MT = tiles (of Geo::P poses) a workgroup owns: tile = rank + k * members, k < MT.
+template <int D, int R, int SPLIT, int MT>
+__global__ __launch_bounds__(kBlock) void k_tcg_persist(BsrDev Q, const double* __restrict__ X,
+                                                        const double* __restrict__ S, const double* __restrict__ g,
+                                                        const double* __restrict__ dinv, double* __restrict__ eta, double* z,
+                                                        unsigned long long* gran, unsigned salt,
+                                                        const DevState* __restrict__ sin, DevState* __restrict__ sout,
+                                                        PersistCtrl* ctrl, int n, unsigned long long* hflag, unsigned gen) {
+  using GEO = Geo<D, R, SPLIT>;
+  constexpr int P = GEO::P, G = GEO::G, T = GEO::T, B = GEO::B, BB = GEO::BB;
+  // resident in LDS: the poses' X (projections need all rotation columns of a pose) and z (Hessian correction);
+  // ex: two wave-private exchange tiles (the columns of one pose meet here)
+  __shared__ __attribute__((aligned(16))) double Xs[MT][P][T], Zs[MT][P][T];
+  __shared__ __attribute__((aligned(16))) double ex[2][kWaves][G][T];
+  __shared__ double red[kWaves * kNP];
+  __shared__ int ok_s;
+
+  const int rank = blockIdx.x, members = gridDim.x;
   DevState st;
   load_state(st, sin);
   if (st.rtr_stop) {
@@ -180,15 +154,17 @@ __global__ __launch_bounds__(kBlock) void k_tcg_persist(BsrDev Q, const double* 
     }
     return;
   }
-  unsigned epoch = 0;
+  unsigned step = 0;
   const LaneId L = lane_id<D, SPLIT>();
   const int lp = L.wave * G + L.g;  // pose slot inside a workgroup tile
   const int ntiles = (n + P - 1) / P;
+  const int co = L.c * R;
 
-  // ---- resident data of the workgroup's tiles
+  // ---- resident data of the workgroup's rows (registers; X and z also in LDS)
   RowIdx ri[MT];
   int pose[MT];
   bool okp[MT], own[MT];
+  double rr[MT][R], ee[MT][R], dl[MT][R], hd[MT][R], zc[MT][R], srow[MT][D], drow[MT][B];
 #pragma unroll
   for (int k = 0; k < MT; ++k) {
     const int tile = rank + k * members;
@@ -196,22 +172,27 @@ __global__ __launch_bounds__(kBlock) void k_tcg_persist(BsrDev Q, const double* 
     okp[k] = (tile < ntiles) && (L.g < G) && (pose[k] < n);
     own[k] = okp[k] && (L.s == 0);
     ri[k] = row_idx_load<D, SPLIT>(Q.rowptr, Q.colidx, pose[k], L.s, L.c, okp[k]);
+#pragma unroll
+    for (int a = 0; a < R; ++a) rr[k][a] = ee[k][a] = dl[k][a] = hd[k][a] = zc[k][a] = 0.0;
+#pragma unroll
+    for (int a = 0; a < D; ++a) srow[k][a] = 0.0;
+#pragma unroll
+    for (int a = 0; a < B; ++a) drow[k][a] = 0.0;
     if (own[k]) {
-      const size_t off = (size_t)pose[k] * T + L.c * R;
+      const size_t off = (size_t)pose[k] * T + co;
 #pragma unroll
       for (int a = 0; a < R; ++a) {
-        Xs[k][lp][L.c * R + a] = X[off + a];
-        Rs[k][lp][L.c * R + a] = g[off + a];  // r0 = g
-        Es[k][lp][L.c * R + a] = 0.0;         // eta0 = 0
-        Ds[k][lp][L.c * R + a] = 0.0;
-        Hs[k][lp][L.c * R + a] = 0.0;
+        Xs[k][lp][co + a] = X[off + a];
+        rr[k][a] = g[off + a];  // r0 = g
       }
       if (L.c < D) {
 #pragma unroll
-        for (int a = 0; a < D; ++a) Ss[k][lp][L.c * D + a] = S[(size_t)pose[k] * D * D + L.c * D + a];
+        for (int a = 0; a < D; ++a) srow[k][a] = S[(size_t)pose[k] * D * D + L.c * D + a];
       }
+      if (dinv) {
 #pragma unroll
-      for (int a = 0; a < B; ++a) Vs[k][lp][L.c * B + a] = dinv ? dinv[(size_t)pose[k] * BB + L.c * B + a] : 0.0;
+        for (int a = 0; a < B; ++a) drow[k][a] = dinv[(size_t)pose[k] * BB + L.c * B + a];
+      }
     }
   }
   wave_sync();
@@ -221,83 +202,85 @@ __global__ __launch_bounds__(kBlock) void k_tcg_persist(BsrDev Q, const double* 
     part[0] = part[1] = 0.0;
 #pragma unroll
     for (int k = 0; k < MT; ++k) {
-      double rr[R], zz[R];
+      if (rank + k * members >= ntiles) break;  // workgroup-uniform
+      double zz[R];
       if (own[k]) {
 #pragma unroll
         for (int a = 0; a < R; ++a) {
-          const int e = L.c * R + a;
-          double rv = Rs[k][lp][e];
           if (!first) {
-            Es[k][lp][e] = fma(alpha, Ds[k][lp][e], Es[k][lp][e]);
-            rv = fma(alpha, Hs[k][lp][e], rv);
-            Rs[k][lp][e] = rv;
+            ee[k][a] = fma(alpha, dl[k][a], ee[k][a]);
+            rr[k][a] = fma(alpha, hd[k][a], rr[k][a]);
           }
-          rr[a] = rv;
-          part[0] = fma(rv, rv, part[0]);
+          part[0] = fma(rr[k][a], rr[k][a], part[0]);
         }
+        if (dinv) store_col<R>(&ex[0][L.wave][L.g][co], rr[k]);
       }
-      wave_sync();  // the pose's B columns of r are in LDS
-      if (own[k]) {
-        if (dinv) {
-          jacobi_col<D, R>(&Rs[k][lp][0], &Vs[k][lp][L.c * B], zz);
-        } else {
+      if (dinv) {
+        wave_sync();  // the pose's B columns of r are in LDS
+        if (own[k]) jacobi_col<D, R>(&ex[0][L.wave][L.g][0], drow[k], zz);
+      } else {
 #pragma unroll
-          for (int a = 0; a < R; ++a) zz[a] = rr[a];
-        }
-        store_col<R>(&ex[L.wave][L.g][L.c * R], zz);
+        for (int a = 0; a < R; ++a) zz[a] = rr[k][a];
       }
+      if (own[k]) store_col<R>(&ex[1][L.wave][L.g][co], zz);
       wave_sync();
       if (own[k]) {
         double out[R], s[D];
-        proj_col<D, R>(&Xs[k][lp][0], &ex[L.wave][L.g][0], L.c, zz, out, s);
-        const size_t off = (size_t)pose[k] * T + L.c * R;
+        proj_col<D, R>(&Xs[k][lp][0], &ex[1][L.wave][L.g][0], L.c, zz, out, s);
+        const size_t off = (size_t)pose[k] * T + co;
 #pragma unroll
         for (int a = 0; a < R; ++a) {
-          part[1] = fma(out[a], rr[a], part[1]);
-          Zs[k][lp][L.c * R + a] = out[a];
-          z[off + a] = out[a];  // the copy the other workgroups gather
+          part[1] = fma(out[a], rr[k][a], part[1]);
+          zc[k][a] = out[a];
+          Zs[k][lp][co + a] = out[a];
+          st_agent(z + off + a, out[a]);  // the copy the other workgroups gather
         }
       }
-      wave_sync();
+      // ex[0] / ex[1] of the next tile are written only after this tile's reads: with block-Jacobi the next tile's first
+      // wave_sync stands between them; without a preconditioner this one does
+      if (!dinv) wave_sync();
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this thread's z stores have been acknowledged
     block_allreduce<2>(part, red);
   };
 
-  // ---- phase A: Hz on the own rows (one hop: Q blocks + gathered z tiles), direction recurrences, <delta, H delta>
+  // ---- phase A: Hz on the own rows (one hop: Q blocks + gathered z tiles of ALL owned tiles are requested before the
+  // first epilogue), direction recurrences, <delta, H delta>
   auto phase_hess = [&](bool first, double beta, double (&part)[1]) {
     part[0] = 0.0;
+    double h[MT][R];
 #pragma unroll
     for (int k = 0; k < MT; ++k) {
       if (rank + k * members >= ntiles) break;  // workgroup-uniform
-      double h[R];
-      spmm_col_pre<D, R, SPLIT, true>(ri[k], Q.colidx, Q.vals, z, L.s, L.c, h);
+      spmm_col_pre<D, R, SPLIT, 2>(ri[k], Q.colidx, Q.vals, z, L.s, L.c, h[k]);
+    }
+#pragma unroll
+    for (int k = 0; k < MT; ++k) {
+      if (rank + k * members >= ntiles) break;
+      double* xt = &ex[k & 1][L.wave][L.g][0];
       if (own[k]) {
         if (L.c < D) {
 #pragma unroll
           for (int a = 0; a < D; ++a) {
-            const double sac = Ss[k][lp][L.c * D + a];
 #pragma unroll
-            for (int q = 0; q < R; ++q) h[q] = fma(-Zs[k][lp][a * R + q], sac, h[q]);
+            for (int q = 0; q < R; ++q) h[k][q] = fma(-Zs[k][lp][a * R + q], srow[k][a], h[k][q]);
           }
         }
-        store_col<R>(&ex[L.wave][L.g][L.c * R], h);
+        store_col<R>(xt + co, h[k]);
       }
       wave_sync();
       if (own[k]) {
         double hz[R], s[D];
-        proj_col<D, R>(&Xs[k][lp][0], &ex[L.wave][L.g][0], L.c, h, hz, s);
+        proj_col<D, R>(&Xs[k][lp][0], xt, L.c, h[k], hz, s);
 #pragma unroll
         for (int a = 0; a < R; ++a) {
-          const int e = L.c * R + a;
-          const double zc = Zs[k][lp][e];
-          const double dn = first ? -zc : fma(beta, Ds[k][lp][e], -zc);
-          const double hn = first ? -hz[a] : fma(beta, Hs[k][lp][e], -hz[a]);
-          Ds[k][lp][e] = dn;
-          Hs[k][lp][e] = hn;
+          const double dn = first ? -zc[k][a] : fma(beta, dl[k][a], -zc[k][a]);
+          const double hn = first ? -hz[a] : fma(beta, hd[k][a], -hz[a]);
+          dl[k][a] = dn;
+          hd[k][a] = hn;
           part[0] = fma(dn, hn, part[0]);
         }
       }
-      wave_sync();
     }
     block_allreduce<1>(part, red);
   };
@@ -312,7 +295,7 @@ __global__ __launch_bounds__(kBlock) void k_tcg_persist(BsrDev Q, const double* 
   bool alive = true;
   double pr[2];
   phase_update(true, 0.0, pr);
-  alive = xcd_allreduce<2>(gran, rank, members, tagbase, epoch, pr, red, &ctrl->error, &ok_s);
+  alive = chip_allreduce<2>(gran, rank, members, salt, step, pr, red, &ctrl->error, &ok_s);
   if (alive) {
     st.norm_r0 = sqrt(pr[0]);
     st.z_r = pr[1];
@@ -329,13 +312,14 @@ __global__ __launch_bounds__(kBlock) void k_tcg_persist(BsrDev Q, const double* 
     double dh[1];
     phase_hess(first, beta, dh);
     const unsigned long long t1 = wall_clock64();
-    if (!(alive = xcd_allreduce<1>(gran, rank, members, tagbase, epoch, dh, red, &ctrl->error, &ok_s))) break;
+    if (!(alive = chip_allreduce<1>(gran, rank, members, salt, step, dh, red, &ctrl->error, &ok_s))) break;
     const unsigned long long t2 = wall_clock64();
     const double d_Hd = dh[0];
     const double alpha = st.z_r / d_Hd;
     const double e_Pe_new = st.e_Pe + 2.0 * alpha * st.e_Pd + alpha * alpha * st.d_Pd;
     st.n_hess += 1;
     st.alpha = alpha;
+    st.d_Hd = d_Hd;
     iters += 1;
     const double D2 = st.Delta * st.Delta;
     if (d_Hd <= 0.0 || e_Pe_new >= D2) {  // negative curvature / trust-region boundary: eta += tau delta, stop
@@ -344,17 +328,15 @@ __global__ __launch_bounds__(kBlock) void k_tcg_persist(BsrDev Q, const double* 
       st.tcg_done = 1;
 #pragma unroll
       for (int k = 0; k < MT; ++k) {
-        if (own[k]) {
 #pragma unroll
-          for (int a = 0; a < R; ++a) Es[k][lp][L.c * R + a] = fma(tau, Ds[k][lp][L.c * R + a], Es[k][lp][L.c * R + a]);
-        }
+        for (int a = 0; a < R; ++a) ee[k][a] = fma(tau, dl[k][a], ee[k][a]);
       }
       break;
     }
     st.e_Pe = e_Pe_new;
     phase_update(false, alpha, pr);
     const unsigned long long t3 = wall_clock64();
-    if (!(alive = xcd_allreduce<2>(gran, rank, members, tagbase, epoch, pr, red, &ctrl->error, &ok_s))) break;
+    if (!(alive = chip_allreduce<2>(gran, rank, members, salt, step, pr, red, &ctrl->error, &ok_s))) break;
     const unsigned long long t4 = wall_clock64();
     if (!first) {
       tk[0] += t1 - t0;
@@ -385,17 +367,28 @@ __global__ __launch_bounds__(kBlock) void k_tcg_persist(BsrDev Q, const double* 
 #pragma unroll
   for (int k = 0; k < MT; ++k) {
     if (own[k]) {
-      const size_t off = (size_t)pose[k] * T + L.c * R;
+      const size_t off = (size_t)pose[k] * T + co;
 #pragma unroll
-      for (int a = 0; a < R; ++a) eta[off + a] = Es[k][lp][L.c * R + a];
+      for (int a = 0; a < R; ++a) eta[off + a] = ee[k][a];
     }
   }
   if (rank == 0 && threadIdx.x == 0) {
-    if (alive) {
+    // a participant that passed every all-reduce of the run saw everybody's granules of the last step, so nobody can
+    // still fail: the error flag is final here
+    if (alive && !__hip_atomic_load(&ctrl->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
       store_state(sout, st);
       publish_progress(hflag, gen, st);
+    } else {
+      // time-out: hand the UNCHANGED state on, poisoned, so that every kernel enqueued behind this launch exits and the
+      // host resumes from this state with the two-kernel scheme (kPersistPoison in dpgo_hip.hip)
+      DevState s0;
+      load_state(s0, sin);
+      s0.rtr_stop = 3;
+      store_state(sout, s0);
+      publish_progress(hflag, gen, s0);
     }
     ctrl->iters = iters;
+    ctrl->members = (unsigned)members;
 #pragma unroll
     for (int q = 0; q < 5; ++q) ctrl->ticks[q] = tk[q];
   }

@@ -418,16 +418,19 @@ class QuadraticProblem:
         L.check(self._lib.dpgo_problem_update_G_from_neighbors_device(self._h, L.ptr(nbr_tiles_dev)))
         self._g_obj = None
 
-    # ---- persistent single-XCD tCG kernel (small blocks, block-Jacobi / no preconditioner) ----
+    # ---- persistent whole-chip tCG kernel (blocks in the latency regime, block-Jacobi / no preconditioner) ----
     def setPersistent(self, enable: bool = True) -> None:
         L.check(self._lib.dpgo_problem_set_persistent(self._h, int(enable)))
 
     def persistentInfo(self) -> dict:
-        """{"enabled", "workgroups", "last_members", "last_iterations", "last_xcd"}: last_members = 0 means the last
-        optimize call ran the two-kernel scheme."""
+        """{"enabled", "workgroups", "last_members", "last_iterations", "last_split", "last_tiles"}: last_members = 0
+        means the last optimize call ran the two-kernel scheme; last_split = lane groups per pose, last_tiles = pose
+        tiles per workgroup of the last persistent launch."""
         v = [C.c_int(0) for _ in range(5)]
         L.check(self._lib.dpgo_problem_persistent_info(self._h, *[C.byref(x) for x in v]))
-        return dict(zip(("enabled", "workgroups", "last_members", "last_iterations", "last_xcd"), (x.value for x in v)))
+        out = dict(zip(("enabled", "workgroups", "last_members", "last_iterations"), (x.value for x in v[:4])))
+        out["last_split"], out["last_tiles"] = v[4].value // 16, v[4].value % 16
+        return out
 
     # ---- multilevel preconditioner (built on the device; lazily by the first solve, like
     # PoseGraph::constructPreconditioner inside the first PreConditioner call, src/PoseGraph.cpp:582-586) ----
@@ -467,8 +470,9 @@ class QuadraticProblem:
         return "symmetric" if v.value == 2 else "plain"
 
     def autoState(self, use_multilevel=None) -> bool:
-        """What precond = "auto" currently runs on this handle (True: the multilevel cycle); a bool argument sets it."""
-        v = C.c_int(-1 if use_multilevel is None else int(bool(use_multilevel)))
+        """What precond = "auto" currently runs on this handle (True: the multilevel cycle); a bool argument sets it,
+        "reset" returns to the decision a fresh handle takes for this problem."""
+        v = C.c_int(-1 if use_multilevel is None else (-2 if use_multilevel == "reset" else int(bool(use_multilevel))))
         L.check(self._lib.dpgo_problem_auto_state(self._h, C.byref(v)))
         return bool(v.value)
 

@@ -216,7 +216,9 @@ int dpgo_problem_multilevel_path(dpgo_problem_t h, int* flags);
  * Hessian-vector products to the tolerance is unchanged and the optimum does not depend on the preconditioner -- DESIGN.md
  * section 5); a negative input only queries.  DPGO_ML_DENSE_INVERSE returns the values the cycle applies. */
 int dpgo_problem_multilevel_coarse_bits(dpgo_problem_t h, int* bits);
-/* State of DPGO_PRECOND_AUTO on this handle: *use_multilevel in/out; a negative input only queries. */
+/* State of DPGO_PRECOND_AUTO on this handle: *use_multilevel in/out; 0 / 1 set it, -1 only queries, -2 returns to the
+ * decision a fresh handle takes for the current problem (multilevel for a block without coupling to other agents,
+ * block-Jacobi for a block of a multi-agent problem; every change of Q does the same). */
 int dpgo_problem_auto_state(dpgo_problem_t h, int* use_multilevel);
 /* In-place blocked Gauss-Jordan inverse of a dense SPD matrix on the device (the kernel pair that inverts the coarsest
  * operator; exposed for tests).  N <= 16384, row-major host arrays; use_mfma: fp64 matrix cores for the rank-64
@@ -316,14 +318,18 @@ int dpgo_bench_hess_rotating(dpgo_problem_t h, int nsets, int reps, int warmup, 
  * (all restrictions, dense level, all post-smoothing launches) as launched per iteration. */
 int dpgo_bench_iteration_kernels(dpgo_problem_t h, int reps, int warmup, double out_ms[5]);
 
-/* Persistent tCG (kernels/persist.h): for small blocks with the block-Jacobi / no preconditioner the whole tCG_TR loop
- * of an outer iteration runs as ONE launch on one XCD (in-kernel barriers instead of two kernel boundaries per
- * iteration).  Off by default (environment DPGO_PERSIST=1 or set_persistent turn it on); if the run-time placement check
- * times out the handle falls back to the two-kernel scheme by itself.  info: what the LAST optimize call did
- * (last_members = 0: the two-kernel scheme ran). */
+/* Persistent tCG (kernels/persist.h): for blocks in the latency regime (by default <= 16 384 poses; environment
+ * DPGO_PERSIST_MAX_POSES) with the block-Jacobi / no preconditioner, the whole tCG_TR loop of an outer iteration runs as
+ * ONE launch on up to 256 resident workgroups: every tCG vector of a workgroup's rows stays in registers, the only vector
+ * exchanged is z (write-through stores, agent-scope gathers), and the barrier between the two phases of an iteration is
+ * the all-reduce of its dot products.  On by size (DPGO_PERSIST=0/1 or set_persistent override).  A solve then enqueues
+ * everything without a host wait and reads the result back once.  If a launch times out (its workgroups were not all
+ * resident, e.g. because another process occupies the device) the solve resumes by itself with the two-kernel scheme and
+ * the handle stops using the kernel.  info: what the LAST optimize call did (last_members = 0: the two-kernel scheme
+ * ran; last_layout = 16 * lane groups per pose + tiles per workgroup). */
 int dpgo_problem_set_persistent(dpgo_problem_t h, int enable);
 int dpgo_problem_persistent_info(dpgo_problem_t h, int* enabled, int* workgroups, int* last_members,
-                                 int* last_iterations, int* last_xcd);
+                                 int* last_iterations, int* last_layout);
 
 /* ---- initial guesses (src/DPGO_solver.cpp:220-303) ----
  * chordal: the two linear least-squares problems of chordalInitialization (rotations with pose 0 pinned to the

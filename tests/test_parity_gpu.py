@@ -6,6 +6,8 @@ and the final cost against the reference-configuration oracle (exact preconditio
 1e-6 relative that BASELINE.json's north_star states.
 """
 import os
+import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -598,22 +600,33 @@ def test_symmetric_storage_solve_2d_matches_oracle(oracle):
             assert relerr(Xd.cpu().numpy(), Xw) < 1e-5, (storage, it)
 
 
-@pytest.mark.parametrize("name,r,precond", [("smallGrid3D", 5, "jacobi"), ("sphere2500", 5, "jacobi"),
-                                            ("sphere2500", 5, "none"), ("sphere2500", 3, "jacobi"),
-                                            ("tinyGrid3D", 5, "jacobi"), ("smallGrid3D", 6, "none")])
-def test_persistent_tcg_matches_oracle(oracle, name, r, precond):
-    """The persistent single-XCD tCG kernel (one launch per tCG run, in-kernel barriers; kernels/persist.h) against the
-    oracle at matched settings, exactly as the two-kernel scheme is tested: same RTR / tCG iteration counts and status,
-    iterate to 1e-7, cost to 1e-9 -- and it must really have run (participants > 0, all on one XCD).  Blocks whose tiles
-    do not fit one XCD's LDS are refused (torus3D: 5 000 poses = 313 tiles of 16)."""
+@pytest.mark.parametrize("name,r,precond,layout", [
+    ("smallGrid3D", 5, "jacobi", None), ("sphere2500", 5, "jacobi", None), ("sphere2500", 5, "none", None),
+    ("sphere2500", 3, "jacobi", None), ("tinyGrid3D", 5, "jacobi", None), ("smallGrid3D", 6, "none", None),
+    ("torus3D", 5, "jacobi", None), ("kitti_00", 5, "jacobi", None), ("kitti_00", 4, "none", None),
+    ("sphere2500", 5, "jacobi", (1, 1)), ("sphere2500", 5, "jacobi", (4, 2)), ("torus3D", 5, "jacobi", (1, 2)),
+    ("sphere2500", 5, "jacobi", (1, 4)), ("kitti_00", 5, "jacobi", (1, 2))])
+def test_persistent_tcg_matches_oracle(oracle, name, r, precond, layout):
+    """The persistent whole-chip tCG kernel (one launch per tCG run, the all-reduces of an iteration's dot products are
+    its barriers; kernels/persist.h) against the oracle at matched settings, exactly as the two-kernel scheme is tested:
+    same RTR / tCG iteration counts and status, iterate to 1e-7, cost to 1e-9 -- and it must really have run
+    (participants > 0), in the default layout of the block's size and in forced layouts (lane groups per pose, tiles per
+    workgroup; a subprocess, because the knobs are read once), in 3-D and 2-D."""
+    if layout is not None:
+        env = dict(os.environ, DPGO_PERSIST_SPLIT=str(layout[0]), DPGO_PERSIST_MT=str(layout[1]), DPGO_PERSIST="1")
+        code = ("import sys; sys.path.insert(0, %r); import conftest, dpgo_oracle, test_parity_gpu as t; "
+                "t._persistent_case(dpgo_oracle, %r, %d, %r, %r)" % (os.path.dirname(os.path.abspath(__file__)), name, r,
+                                                                    precond, layout))
+        p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, p.stderr[-3000:]
+        return
+    _persistent_case(oracle, name, r, precond, None)
+
+
+def _persistent_case(oracle, name, r, precond, layout):
     import dpgo_amd
-    from dpgo_amd.lib import DpgoError
     om, n, d, Q, pg, prob = build_single_agent(oracle, name, r)
     prob.setPersistent(True)
-    if name == "sphere2500" and r == 5 and precond == "jacobi":
-        big = build_single_agent(oracle, "torus3D", 3)[-1]
-        with pytest.raises(DpgoError):
-            big.setPersistent(True)
     X0 = oracle.lift(oracle.chordal_initialization(om, n), r)
     op = oracle.QuadraticProblem(Q, None, r, d, precond=precond)
     oo = oracle.QuadraticOptimizer(op, oracle.ROptParameters(), hess_recurrence=True)
@@ -624,13 +637,47 @@ def test_persistent_tcg_matches_oracle(oracle, name, r, precond):
         Xg = matrix_to_tiles(go.optimize(tiles_to_matrix(Xg)), d)
         rg = go.getOptResult()
         info = prob.persistentInfo()
-        assert info["enabled"] == 1 and info["last_members"] >= 1 and 0 <= info["last_xcd"] < 8, info
+        assert info["enabled"] == 1 and info["last_members"] >= 1 and info["last_members"] == info["workgroups"], info
+        if layout is not None:
+            assert (info["last_split"], info["last_tiles"]) == tuple(layout), info
         assert (rg.tcg_iterations, rg.rtr_iterations, rg.tCGStatus) == (oo.result.tcg_iters, oo.result.outer_iters,
                                                                          oracle.TCG_NAMES[oo.result.tCGStatus])
         assert relerr(Xg, Xo) < 1e-7
         Xa = np.abs(Xo).reshape(n * (d + 1), r)
         scale = float((Xa * (abs(op.Qs) @ Xa)).sum())
         assert abs(rg.fOpt - oo.result.fOpt) <= 1e-9 * abs(oo.result.fOpt) + 1e-14 * scale
+
+
+def test_persistent_tcg_is_refused_beyond_its_capacity_and_follows_the_size_switch(oracle):
+    """Blocks that need more than 4 tiles on each of 256 workgroups are refused (explicit request: error); the default
+    is on by size: sphere2500 runs the persistent kernel without being asked, the single-iteration radius-shrink mode
+    and an iterate that already meets the tolerance behave as on the two-kernel scheme."""
+    import dpgo_amd
+    from dpgo_amd.lib import DpgoError
+    om, n, d, Q, pg, prob = build_single_agent(oracle, "sphere2500", 5)
+    assert prob.persistentInfo()["enabled"] == 1
+    X0 = oracle.lift(oracle.chordal_initialization(om, n), 5)
+    two = build_single_agent(oracle, "sphere2500", 5)[-1]
+    two.setPersistent(False)
+    for prm in (dpgo_amd.ROptParameters(precond="jacobi", RTR_iterations=1, RTR_initial_radius=1e4),
+                dpgo_amd.ROptParameters(precond="jacobi", gradnorm_tol=1e9),
+                dpgo_amd.ROptParameters(precond="jacobi", RTR_tCG_iterations=0)):
+        a = dpgo_amd.QuadraticOptimizer(prob, prm)
+        b = dpgo_amd.QuadraticOptimizer(two, prm)
+        Xa, Xb = a.optimize(tiles_to_matrix(X0)), b.optimize(tiles_to_matrix(X0))
+        ra, rb = a.getOptResult(), b.getOptResult()
+        assert (ra.tcg_iterations, ra.rtr_iterations, ra.tCGStatus, ra.latest_step_accepted) == (
+            rb.tcg_iterations, rb.rtr_iterations, rb.tCGStatus, rb.latest_step_accepted)
+        assert relerr(Xa, Xb) < 1e-9 and abs(ra.fOpt - rb.fOpt) <= 1e-10 * abs(rb.fOpt)
+    assert two.persistentInfo()["last_members"] == 0
+    from dpgo_amd import synthetic
+    meas, nbig, _ = synthetic.synthetic_grid(50, 50, 30, seed=0)  # 75 000 poses: 1 172 tiles of 64 > 4 x 256
+    pgb = dpgo_amd.PoseGraph(0, 5, 3)
+    pgb.setMeasurements(meas)
+    big = dpgo_amd.QuadraticProblem(pgb)
+    assert big.persistentInfo()["enabled"] == 0
+    with pytest.raises(DpgoError):
+        big.setPersistent(True)
 
 
 @pytest.mark.parametrize("name", ["tinyGrid3D", "smallGrid3D", "sphere2500", "torus3D", "kitti_00"])
