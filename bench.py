@@ -32,6 +32,11 @@ import os
 import sys
 import time
 
+# Agents that share a GPU are solved concurrently, one HIP stream each; the ROCm runtime maps streams onto 4 hardware
+# queues by default, so more than 4 same-colour agents would queue behind each other.  Must be set before the runtime
+# initialises (i.e. before torch / the library are imported).
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+
 import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))

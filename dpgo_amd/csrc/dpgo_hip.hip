@@ -203,7 +203,7 @@ struct dpgo_problem_s {
   }
   // persistent whole-chip tCG kernel (blocks in the latency regime, block-Jacobi / no preconditioner): kernels/persist.h
   bool persist = false;      // enabled for this handle (by size; DPGO_PERSIST=0/1, dpgo_problem_set_persistent)
-  int persist_share = 1;     // agents solved concurrently on this device: each may take 1/share of the resident slots
+  int persist_share = 1;     // agents solved concurrently on this device (> 1: the most compact layout is preferred)
   int persist_wgs = 0, persist_split = 0, persist_mt = 0;  // geometry of the current / last launch
   int persist_reserved = 0;  // resident-slot reservation held by the running solve
   bool persist_failed_once = false;
@@ -1007,8 +1007,8 @@ int launch_ml_apply(dpgo_problem_s* p, const double* Xdev, const double* v, doub
 //
 // Residency.  Every workgroup of such a launch waits for all the others, so all of them must be resident at once.  The
 // grid is therefore sized against a per-device count of resident slots shared by all handles of the process (one slot =
-// one 256-thread workgroup; capacity = one per CU: whatever the kernel variant's register budget, and whatever else
-// runs, a CU can always hold one), reserved for the duration of the solve.  A handle that cannot reserve runs the
+// one 256-thread workgroup; capacity = two per CU: every variant of the kernel is compiled for two workgroups per CU
+// -- registers, LDS --, whatever else runs), reserved for the duration of the solve.  A handle that cannot reserve runs the
 // two-kernel scheme.  Other processes are not covered: every in-kernel spin is bounded, a time-out poisons the state
 // record (rtr_stop = kPersistPoison) so that the kernels enqueued behind it exit, and run_optimize resumes from the last
 // consistent state with the two-kernel scheme.
@@ -1022,7 +1022,7 @@ int persist_capacity(int device) {
   if (cap == 0) {
     int cus = 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus <= 0) cus = 1;
-    cap = cus;
+    cap = 2 * cus;
     g_persist_cap[device % kMaxDevices].store(cap);
   }
   return cap;
@@ -1045,30 +1045,30 @@ void persist_release(dpgo_problem_s* p) {
 
 // Geometry of a launch: lane groups per pose (SPLIT), tiles per workgroup (MT), workgroups.  The smallest-latency layout
 // whose grid fits the handle's share of the resident slots: 4 lane groups per pose (short gather chains) while the tiles
-// fit, otherwise one pose per (d+1) lanes with up to 4 tiles per workgroup.
+// fit, otherwise one pose per (d+1) lanes, with up to 2 tiles per workgroup.
 struct PersistGeo {
-  int split = 0, mt = 0, wgs = 0;
+  int split = 0, mt = 0, wgs = 0, slots = 0;
 };
-PersistGeo persist_geometry(const dpgo_problem_s* p, int wcap) {
+// `free_slots`: what may be reserved now.  Alone on the device: the lowest-latency layout that fits (4 lane groups per pose
+// while the tiles fit, then one pose per (d+1) lanes).  Sharing the device with other concurrently solved agents
+// (share > 1): the layout with the fewest slots, so that as many agents as possible run the kernel at once.
+PersistGeo persist_geometry(const dpgo_problem_s* p, int free_slots, int share = 1) {
   static const int env_split = [] { const char* e = std::getenv("DPGO_PERSIST_SPLIT"); return e ? std::atoi(e) : 0; }();
   static const int env_mt = [] { const char* e = std::getenv("DPGO_PERSIST_MT"); return e ? std::atoi(e) : 0; }();
-  const int cand[5][2] = {{4, 1}, {4, 2}, {1, 1}, {1, 2}, {1, 4}};
-  PersistGeo g;
-  wcap = std::min(wcap, kPersistMax);
+  const int cand[4][2] = {{4, 1}, {4, 2}, {1, 1}, {1, 2}};
+  PersistGeo best;
   for (auto& c : cand) {
     if (env_split && c[0] != env_split) continue;
     if (env_mt && c[1] != env_mt) continue;
     const int P = (64 / (p->b * c[0])) * kWaves;
     const int tiles = std::max(1, (p->n + P - 1) / P);
     const int wgs = (tiles + c[1] - 1) / c[1];
-    if (wgs <= wcap) {
-      g.split = c[0];
-      g.mt = c[1];
-      g.wgs = wgs;
-      return g;
-    }
+    const int slots = wgs * persist_slots_per_wg(c[0], c[1]);
+    if (wgs > kPersistMax || slots > free_slots) continue;
+    if (best.wgs == 0 || (share > 1 && slots < best.slots)) best = PersistGeo{c[0], c[1], wgs, slots};
+    if (share <= 1) break;
   }
-  return g;
+  return best;
 }
 
 // Enqueues the persistent tCG launch of one outer iteration (no host wait).  *used = false: not launched (no geometry /
@@ -1076,25 +1076,36 @@ PersistGeo persist_geometry(const dpgo_problem_s* p, int wcap) {
 int launch_tcg_persistent(dpgo_problem_s* p, const double* dinv, bool* used) {
   *used = false;
   if (p->persist_reserved == 0) {
-    const PersistGeo g = persist_geometry(p, std::max(1, persist_capacity(p->device) / std::max(1, p->persist_share)));
-    if (g.wgs <= 0 || !persist_reserve(p, g.wgs)) return DPGO_OK;
+    const int free_slots = persist_capacity(p->device) - g_persist_used[p->device % kMaxDevices].load();
+    const PersistGeo g = persist_geometry(p, free_slots, p->persist_share);
+    if (g.wgs <= 0 || !persist_reserve(p, g.slots)) return DPGO_OK;
     p->persist_split = g.split;
     p->persist_mt = g.mt;
     p->persist_wgs = g.wgs;
+    // once per solve: the error word is sticky (a launch behind a timed-out one sees it and leaves at once), the
+    // diagnostics accumulate, and the granules' epochs are salted per launch (cleared here against wrap-around)
+    HIPC(hipMemsetAsync(p->pctrl, 0, sizeof(PersistCtrl), p->stream));
+    HIPC(hipMemsetAsync(p->pgran, 0, sizeof(unsigned long long) * kGranWords, p->stream));
   }
-  HIPC(hipMemsetAsync(p->pctrl, 0, sizeof(PersistCtrl), p->stream));
-  HIPC(hipMemsetAsync(p->pgran, 0, sizeof(unsigned long long) * kGranWords, p->stream));
   const unsigned salt = ((p->gen & 0x7ffu) + 1u) << 20;  // never 0; the in-launch step counter fills the low 20 bits
+  // granule sweeps of the in-kernel all-reduce: wait before the first one (a granule needs ~1 us to cross the chip and
+  // the slowest of more workgroups arrives later; sweeping earlier only loads the fabric: sphere2500 11.9 -> 7.9 us per
+  // iteration, 12.5k slab 15.3 -> 12.1), back off between sweeps.  DPGO_POLL_FIRST / DPGO_POLL_SLEEP override.
+  static const int env_first = [] { const char* e = std::getenv("DPGO_POLL_FIRST"); return e ? std::atoi(e) : -1; }();
+  static const int env_sleep = [] { const char* e = std::getenv("DPGO_POLL_SLEEP"); return e ? std::atoi(e) : -1; }();
+  const int first = env_first >= 0 ? std::min(255, env_first) : (p->persist_wgs <= 160 ? kPollFirstSleep : 44);
+  const int between = env_sleep >= 0 ? std::min(255, env_sleep) : kPollSleep;
+  const int poll = (first << 8) | between;
+
 #define PERSIST_LAUNCH(SP, MT_)                                                                                       \
   hipLaunchKernelGGL((k_tcg_persist<D, R, SP, MT_>), dim3(p->persist_wgs), dim3(kBlock), 0, p->stream, p->Q.dev(),    \
                      p->x1, p->S1, p->g1, dinv, p->eta, p->z, p->pgran, salt, p->dstate + p->cur,                     \
-                     p->dstate + (p->cur ^ 1), p->pctrl, p->n, p->hflag, p->gen)
+                     p->dstate + (p->cur ^ 1), p->pctrl, p->n, p->hflag, p->gen, poll)
   DISPATCH(p->d, p->r, {
     if (p->persist_split == 4 && p->persist_mt == 1) PERSIST_LAUNCH(4, 1);
     else if (p->persist_split == 4) PERSIST_LAUNCH(4, 2);
     else if (p->persist_mt == 1) PERSIST_LAUNCH(1, 1);
-    else if (p->persist_mt == 2) PERSIST_LAUNCH(1, 2);
-    else PERSIST_LAUNCH(1, 4);
+    else PERSIST_LAUNCH(1, 2);
   });
 #undef PERSIST_LAUNCH
   HIPC(hipGetLastError());
@@ -1495,10 +1506,12 @@ int tune_launch_caps(dpgo_problem_s* p) {
   return DPGO_OK;
 }
 
-// Persistent tCG: on by size -- blocks in the latency regime (DPGO_PERSIST_MAX_POSES, default 16 384 poses: above, a tCG
-// iteration is bytes, not latency, and the streaming two-kernel scheme wins).  DPGO_PERSIST=0/1 overrides.
+// Persistent tCG: on by size -- every block the kernel can hold (two 64-pose tiles on each of 256 workgroups: 32 768 poses
+// in 3-D; measured per tCG iteration against the two-kernel scheme: 625 poses 7.5 / 12.6 us, sphere2500 7.3 / 14.3,
+// 6 250 11.2 / 16.7, 12.5k slab 11.4 / 19.4, 25k 18.7 / 26.5).  DPGO_PERSIST_MAX_POSES lowers the limit, DPGO_PERSIST=0/1
+// overrides.
 int tune_persist(dpgo_problem_s* p) {
-  static const int max_poses = [] { const char* e = std::getenv("DPGO_PERSIST_MAX_POSES"); return e ? std::atoi(e) : 16384; }();
+  static const int max_poses = [] { const char* e = std::getenv("DPGO_PERSIST_MAX_POSES"); return e ? std::atoi(e) : 1 << 30; }();
   const bool fits = persist_geometry(p, persist_capacity(p->device)).wgs > 0;
   bool on = fits && p->n <= max_poses;
   if (const char* e = std::getenv("DPGO_PERSIST")) on = fits && std::atoi(e) != 0;
@@ -2308,7 +2321,7 @@ static int run_many(int count, const dpgo_problem_t* handles, void* after_stream
     prev[k] = handles[k]->stream;
     if (prev[k] != handles[k]->own_stream) e = hipStreamSynchronize(prev[k]);  // earlier work of the handle itself
     handles[k]->stream = handles[k]->own_stream;
-    handles[k]->persist_share = count;  // persistent tCG launches: each handle sizes its grid to 1/count of the chip
+    handles[k]->persist_share = count;  // persistent tCG launches: prefer the layout with the fewest resident slots
     if (e == hipSuccess) e = hipStreamWaitEvent(handles[k]->own_stream, ev, 0);
   }
   std::vector<int> rc(count, DPGO_OK);
@@ -2430,7 +2443,7 @@ int dpgo_problem_persistent_info(dpgo_problem_t p, int* enabled, int* workgroups
 int dpgo_problem_set_persistent(dpgo_problem_t p, int enable) {
   if (!p) return fail(DPGO_ERR_INVALID, "null handle");
   if (enable && persist_geometry(p, persist_capacity(p->device)).wgs <= 0)
-    return fail(DPGO_ERR_UNSUPPORTED, "block too large for the persistent tCG kernel (at most 4 tiles on each of 256 workgroups)");
+    return fail(DPGO_ERR_UNSUPPORTED, "block too large for the persistent tCG kernel (at most 2 tiles on each of 256 workgroups)");
   p->persist = enable != 0;
   if (enable) p->persist_failed_once = false;
   return DPGO_OK;

@@ -500,6 +500,36 @@ struct BsrDev {
   const double* vals;
 };
 
+// ---------------------------------------------------------------- reduce-scatter over the lanes of a pose
+// Every lane (pose, column c) holds a (D+1) x R partial acc[cc][a]; afterwards out[a] = sum over the pose's lanes of their
+// acc[c][a], i.e. lane c keeps row c of the sum.  D = 3: butterfly inside the quad with DPP quad_perm (no LDS crossbar):
+// after the xor-1 step a lane holds rows (c & 1) and 2 + (c & 1) summed over its pair, after the xor-2 step row c summed
+// over the quad.  D = 2: three lanes per pose, shuffles.  Wave-cooperative (all 64 lanes).
+template <int D, int R>
+__device__ __forceinline__ void pose_reduce_scatter(const double (&acc)[D + 1][R], int c, double (&out)[R]) {
+  constexpr int B = D + 1;
+  if constexpr (B == 4) {
+    const bool p1 = c & 1, p2 = c & 2;
+#pragma unroll
+    for (int a = 0; a < R; ++a) {
+      const double r01 = (p1 ? acc[1][a] : acc[0][a]) + dpp_shifted<0xB1, 0xf, 0xf>(p1 ? acc[0][a] : acc[1][a]);
+      const double r23 = (p1 ? acc[3][a] : acc[2][a]) + dpp_shifted<0xB1, 0xf, 0xf>(p1 ? acc[2][a] : acc[3][a]);
+      out[a] = (p2 ? r23 : r01) + dpp_shifted<0x4E, 0xf, 0xf>(p2 ? r01 : r23);
+    }
+  } else {
+    const int gbase = (int)(threadIdx.x & 63) - c;
+#pragma unroll
+    for (int cc = 0; cc < B; ++cc)
+#pragma unroll
+      for (int a = 0; a < R; ++a) {
+        double v = 0.0;
+#pragma unroll
+        for (int k = 0; k < B; ++k) v += __shfl(acc[cc][a], gbase + k);
+        if (cc == c) out[a] = v;
+      }
+  }
+}
+
 // ---------------------------------------------------------------- block product on symmetric storage
 // Q is symmetric, Q[j,i] = Q[i,j]^T.  Only the blocks (i, j >= i) are stored, TRANSPOSED (column c of a block is
 // contiguous); block row i walks its upper blocks and a list of references (j < i, slot of block (j, i)) whose
@@ -592,27 +622,7 @@ __device__ __forceinline__ void spmm_sym_pre(const SymIdx& si, const BsrSymDev& 
     for (int pp = 0; pp < B; ++pp) q[pp] = Q.uvalsT[sb * BB + pp * B + c];
     fma_block(q, Q.lcol[t]);
   }
-  if constexpr (B == 4) {
-    // reduce-scatter butterfly inside the quad (DPP quad_perm, no LDS crossbar): after the xor-1 step a lane holds rows
-    // (c & 1) and 2 + (c & 1) summed over its pair, after the xor-2 step row c summed over the quad
-    const bool p1 = c & 1, p2 = c & 2;
-#pragma unroll
-    for (int a = 0; a < R; ++a) {
-      const double r01 = (p1 ? acc[1][a] : acc[0][a]) + dpp_shifted<0xB1, 0xf, 0xf>(p1 ? acc[0][a] : acc[1][a]);
-      const double r23 = (p1 ? acc[3][a] : acc[2][a]) + dpp_shifted<0xB1, 0xf, 0xf>(p1 ? acc[2][a] : acc[3][a]);
-      out[a] = (p2 ? r23 : r01) + dpp_shifted<0x4E, 0xf, 0xf>(p2 ? r01 : r23);
-    }
-  } else {
-#pragma unroll
-    for (int cc = 0; cc < B; ++cc)
-#pragma unroll
-      for (int a = 0; a < R; ++a) {
-        double v = 0.0;
-#pragma unroll
-        for (int k = 0; k < B; ++k) v += __shfl(acc[cc][a], gbase + k);
-        if (cc == c) out[a] = v;
-      }
-  }
+  pose_reduce_scatter<D, R>(acc, c, out);
 }
 
 // storage-generic row gather: h = row c of (A V)_i for the lane (g, s, c) of node i

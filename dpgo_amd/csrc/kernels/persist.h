@@ -1,5 +1,5 @@
 // kernels/persist.h -- persistent whole-chip tCG kernel for blocks in the latency regime (what a GPU runs when a graph is
-// cut over many agents / GPUs: <= ~65k poses).
+// cut over many agents / GPUs: <= ~32k poses).
 // Part of kernels.h (included inside namespace dpgo, in this order: common.h, problem.h, tcg.h, persist.h, multilevel.h, dense.h, manifold.h, rtr.h, agent.h, init.h).
 #pragma once
 
@@ -38,6 +38,12 @@ struct PersistCtrl {
 };
 
 constexpr unsigned kSpinLimit = 1u << 21;  // polls (with s_sleep) before a spin gives up: ~0.5 s
+// s_sleep units (64 clocks each) before the first granule sweep of a reduction and between sweeps; packed into one
+// kernel argument (first << 8 | between) so that they can be tuned at run time (DPGO_POLL_FIRST / DPGO_POLL_SLEEP)
+constexpr int kPollFirstSleep = 24, kPollSleep = 3;
+__device__ __forceinline__ void sleep_units(int n) {
+  for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(1);
+}
 constexpr int kPersistMax = kBlock;        // participants (workgroups) of one launch
 constexpr int kGranVals = 2;               // partial sums per all-reduce (max)
 constexpr int kGranRows = 2 * kGranVals;   // 8-byte words per participant: {epoch, low half}, {epoch, high half} per value
@@ -57,98 +63,250 @@ __device__ __forceinline__ void st_agent(double* p, double v) {
                      __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// Barrier + all-reduce of the launch's workgroups in one step.  PRECONDITION: every thread has executed
-// `s_waitcnt vmcnt(0)` after its last store that other workgroups read, and a workgroup barrier followed (the
-// block_allreduce that produced `val` provides it; `val` is identical in all threads of the workgroup).
+// Column loads / tile stores of the exchanged vector through a buffer descriptor: 16-byte pieces with the sc1 policy
+// (aux bit 4 on gfx950; cdna_hip_programming.md Guideline 16 R1) -- an R-double column is R/2 16-byte loads (+ one 8-byte
+// load), a pose tile leaves as 16-byte write-through stores instead of 8-byte ones (each of which is a fabric write of its
+// own).  Only dword alignment is required of multi-dword global accesses.
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+constexpr int kAuxSc1 = 16;
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t vec_rsrc(double* p, size_t bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(p, 0, (int)bytes, 0x00020000);
+}
+template <int R>
+__device__ __forceinline__ void ld_col_agent(__amdgpu_buffer_rsrc_t rz, int byte_off, double (&x)[R]) {
+#pragma unroll
+  for (int a = 0; a + 1 < R; a += 2) {
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rz, byte_off + 8 * a, 0, kAuxSc1);
+    x[a] = __longlong_as_double((long long)(((unsigned long long)v.y << 32) | v.x));
+    x[a + 1] = __longlong_as_double((long long)(((unsigned long long)v.w << 32) | v.z));
+  }
+  if constexpr (R & 1) {
+    const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rz, byte_off + 8 * (R - 1), 0, kAuxSc1);
+    x[R - 1] = __longlong_as_double((long long)(((unsigned long long)v.y << 32) | v.x));
+  }
+}
+
+// Barrier + all-reduce of the launch's workgroups in one step, two workgroup barriers in all.  part: in = this THREAD's
+// partial sums, out = the sums over the launch (identical bits in every thread of every workgroup).  PRECONDITION: every
+// thread has executed `s_waitcnt vmcnt(0)` after its last store that other workgroups read (the first barrier below then
+// orders the whole workgroup's stores before the publish).  red: 2 x (2 * kWaves * kGranVals) doubles.  *ok_s: 1 at kernel start.
 template <int K>
 __device__ __forceinline__ bool chip_allreduce(unsigned long long* gran, int rank, int members, unsigned salt, unsigned& step,
-                                               double (&val)[K], double* red, int* error, int* ok_s) {
+                                               double (&part)[K], double* red, int* error, int* ok_s, int poll) {
   static_assert(K <= kGranVals, "granule rows");
   step += 1;
   const unsigned long long epoch = (unsigned long long)(salt | step);  // never 0; unique per launch and step
   unsigned long long* buf = gran + (size_t)(step & 1u) * kGranRows * kPersistMax;
-  if (threadIdx.x == 0) *ok_s = 1;
-  if ((int)threadIdx.x < 2 * K) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // two sets of scratch alternate: a wave that runs ahead into the next reduction must not overwrite sums a slower wave
+  // of this one still reads (only wave-level barriers separate the two)
+  red += (step & 1u) * (2 * kWaves * kGranVals);
+#pragma unroll
+  for (int k = 0; k < K; ++k) part[k] = wave_reduce_lane63(part[k]);
+  if (lane == 63) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) red[wave * K + k] = part[k];
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < 2 * K) {  // the workgroup's sums (waves in order), one granule per 32-bit half
     const int k = threadIdx.x >> 1, half = threadIdx.x & 1;
-    const unsigned long long bits = (unsigned long long)__double_as_longlong(val[k]);
+    double sum = red[k];
+#pragma unroll
+    for (int w = 1; w < kWaves; ++w) sum += red[w * K + k];
+    const unsigned long long bits = (unsigned long long)__double_as_longlong(sum);
     const unsigned long long w = (epoch << 32) | (half ? (bits >> 32) : (bits & 0xffffffffull));
     __hip_atomic_store(buf + (size_t)threadIdx.x * kPersistMax + rank, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
-  __syncthreads();  // ok_s initialised before a poller may clear it
-  if (threadIdx.x < 64) {  // ONE wave sweeps: lane l takes participants l, l + 64, l + 128, l + 192
-    double acc[K];
+  // thread t sweeps participant t's granules (one pass = 2K loads in flight, a row of the table per load instruction)
+  double v[K];
 #pragma unroll
-    for (int k = 0; k < K; ++k) acc[k] = 0.0;
-    bool fine = true;
+  for (int k = 0; k < K; ++k) v[k] = 0.0;
+  if ((int)threadIdx.x < members) {
+    const int t = threadIdx.x;
+    bool got = false;
+    // a granule needs ~1 us to cross the chip: polls before that only load the fabric the granules travel on (sweeping
+    // at once made the reduction 1 us SLOWER at 196 workgroups), so the first sweep waits and the later ones back off
+    sleep_units(poll >> 8);
+    for (unsigned it = 0; it < kSpinLimit; ++it) {
+      unsigned long long w[2 * K];
 #pragma unroll
-    for (int q = 0; q < kPersistMax / 64; ++q) {
-      const int t = (int)threadIdx.x + 64 * q;
-      if (q * 64 >= members) break;  // wave-uniform
-      if (t < members) {
-        bool got = false;
-        for (unsigned it = 0; it < kSpinLimit; ++it) {
-          unsigned long long w[2 * K];
+      for (int j = 0; j < 2 * K; ++j)
+        w[j] = __hip_atomic_load(buf + (size_t)j * kPersistMax + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      bool all = true;
 #pragma unroll
-          for (int j = 0; j < 2 * K; ++j)
-            w[j] = __hip_atomic_load(buf + (size_t)j * kPersistMax + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          bool all = true;
+      for (int j = 0; j < 2 * K; ++j) all = all && ((w[j] >> 32) == epoch);
+      if (all) {
 #pragma unroll
-          for (int j = 0; j < 2 * K; ++j) all = all && ((w[j] >> 32) == epoch);
-          if (all) {
-#pragma unroll
-            for (int k = 0; k < K; ++k)
-              acc[k] += __longlong_as_double((long long)((w[2 * k] & 0xffffffffull) | (w[2 * k + 1] << 32)));
-            got = true;
-            break;
-          }
-          if ((it & 255u) == 255u && __hip_atomic_load(error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
-          __builtin_amdgcn_s_sleep(1);
-        }
-        fine = fine && got;
+        for (int k = 0; k < K; ++k)
+          v[k] = __longlong_as_double((long long)((w[2 * k] & 0xffffffffull) | (w[2 * k + 1] << 32)));
+        got = true;
+        break;
       }
+      if ((it & 255u) == 255u && __hip_atomic_load(error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+      sleep_units(poll & 0xff);
     }
-    if (!fine) {
+    if (!got) {
       __hip_atomic_store(error, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      *ok_s = 0;
+      *ok_s = 0;  // sticky: the launch is abandoned
     }
-    // lane l holds the sum over its participants (ascending); fixed DPP tree over the lanes: the same bits everywhere
+  }
+  // fixed tree (DPP inside a wave, waves in order): the same bits in every thread of every workgroup
+  double* red2 = red + kWaves * K;
 #pragma unroll
-    for (int k = 0; k < K; ++k) acc[k] = wave_reduce_lane63(acc[k]);
-    if (threadIdx.x == 63) {
+  for (int k = 0; k < K; ++k) v[k] = wave_reduce_lane63(v[k]);
+  if (lane == 63) {
 #pragma unroll
-      for (int k = 0; k < K; ++k) red[k] = acc[k];
-    }
+    for (int k = 0; k < K; ++k) red2[wave * K + k] = v[k];
   }
   __syncthreads();
 #pragma unroll
-  for (int k = 0; k < K; ++k) val[k] = red[k];
-  const bool ok = *ok_s != 0;
-  __syncthreads();  // red / ok_s may be rewritten by the next reduction
-  return ok;
+  for (int k = 0; k < K; ++k) {
+    double sum = red2[k];
+#pragma unroll
+    for (int w = 1; w < kWaves; ++w) sum += red2[w * K + k];
+    part[k] = sum;
+  }
+  return *ok_s != 0;
 }
 
-// MT = tiles (of Geo::P poses) a workgroup owns: tile = rank + k * members, k < MT.
+// ---------------------------------------------------------------- the gather of the persistent kernel
+// Row c of (Q z)_i for the lane (pose i, slice s, column c), with EVERY load of a tile issued before the first use: a
+// phase then costs one memory round trip, not one per block (with one wave per SIMD nothing else hides them).  Outer-
+// product form (cf. spmm_sym_pre): the lane loads only column c of a gathered tile (R doubles) and of the block, keeps the
+// (D+1) x R partial, and one reduce-scatter over the pose's lanes per row leaves row c in lane c; slices (SPLIT lane
+// groups taking every SPLIT-th block) are summed by a fixed shuffle tree into slice 0.  The first 2 (D+1) blocks of a row
+// are covered by unconditional loads (absent blocks: a valid address and a zero block column); longer rows (hubs) take
+// the loop.  QRES: the block columns stay in registers for the whole launch (Q does not change); otherwise they are
+// loaded with the tiles (plain loads: L2-resident).
+template <int D, int SPLIT>
+struct GatherGeo {
+  static constexpr int B = D + 1;
+  static constexpr int NPRE = 2 * B;                       // blocks of a row covered without a loop
+  static constexpr int NB = (NPRE + SPLIT - 1) / SPLIT;    // of them, per lane group
+};
+template <int D, int R, int SPLIT, bool QRES>
+struct GatherOps {
+  using GG = GatherGeo<D, SPLIT>;
+  int t0, deg;
+  int j[GG::NB];  // gathered pose of block m (own pose / pose 0 when the block is absent)
+  double q[QRES ? GG::NB : 1][GG::B];
+};
+template <int D, int R, int SPLIT, bool QRES>
+__device__ __forceinline__ void gather_setup(GatherOps<D, R, SPLIT, QRES>& go, const BsrDev& Q, int i, int s, int c, bool okp) {
+  using GG = GatherGeo<D, SPLIT>;
+  constexpr int B = GG::B, BB = B * B;
+  go.t0 = okp ? Q.rowptr[i] : 0;
+  go.deg = (okp ? Q.rowptr[i + 1] : 0) - go.t0;
+#pragma unroll
+  for (int m = 0; m < GG::NB; ++m) {
+    const int blk = s + m * SPLIT;
+    const bool on = blk < go.deg && blk < GG::NPRE;
+    go.j[m] = on ? Q.colidx[go.t0 + blk] : (okp ? i : 0);
+    if constexpr (QRES) {
+#pragma unroll
+      for (int cc = 0; cc < B; ++cc) go.q[m][cc] = on ? Q.vals[(size_t)(go.t0 + blk) * BB + cc * B + c] : 0.0;
+    }
+  }
+}
+template <int D, int R, int SPLIT, bool QRES>
+__device__ __forceinline__ void gather_issue(const GatherOps<D, R, SPLIT, QRES>& go, const BsrDev& Q,
+                                             __amdgpu_buffer_rsrc_t rz, int s, int c,
+                                             double (&xc)[GatherGeo<D, SPLIT>::NB][R],
+                                             double (&qc)[GatherGeo<D, SPLIT>::NB][D + 1]) {
+  using GG = GatherGeo<D, SPLIT>;
+  constexpr int B = GG::B, BB = B * B, T = B * R;
+#pragma unroll
+  for (int m = 0; m < GG::NB; ++m) {
+    ld_col_agent<R>(rz, (go.j[m] * T + c * R) * 8, xc[m]);
+    if constexpr (QRES) {
+#pragma unroll
+      for (int cc = 0; cc < B; ++cc) qc[m][cc] = go.q[m][cc];
+    } else {
+      const int blk = s + m * SPLIT;
+      const bool on = blk < go.deg && blk < GG::NPRE;
+      const double* qp = Q.vals + (size_t)(go.t0 + (on ? blk : 0)) * BB + c;  // (absent block: the row's first, times 0)
+#pragma unroll
+      for (int cc = 0; cc < B; ++cc) {
+        const double v = qp[cc * B];
+        qc[m][cc] = on ? v : 0.0;
+      }
+    }
+  }
+}
+template <int D, int R, int SPLIT, bool QRES>
+__device__ __forceinline__ void gather_finish(const GatherOps<D, R, SPLIT, QRES>& go, const BsrDev& Q,
+                                              __amdgpu_buffer_rsrc_t rz, int s, int c, const double (&xc)[GatherGeo<D, SPLIT>::NB][R],
+                                              const double (&qc)[GatherGeo<D, SPLIT>::NB][D + 1], double (&h)[R]) {
+  using GG = GatherGeo<D, SPLIT>;
+  constexpr int B = GG::B, BB = B * B, T = B * R;
+  double acc[B][R];
+#pragma unroll
+  for (int cc = 0; cc < B; ++cc)
+#pragma unroll
+    for (int a = 0; a < R; ++a) acc[cc][a] = 0.0;
+#pragma unroll
+  for (int m = 0; m < GG::NB; ++m)
+#pragma unroll
+    for (int cc = 0; cc < B; ++cc)
+#pragma unroll
+      for (int a = 0; a < R; ++a) acc[cc][a] = fma(xc[m][a], qc[m][cc], acc[cc][a]);
+  for (int t = go.t0 + GG::NPRE + s; t < go.t0 + go.deg; t += SPLIT) {  // rows with more than 2 (D+1) blocks
+    double xr[R], qr[B];
+    ld_col_agent<R>(rz, (Q.colidx[t] * T + c * R) * 8, xr);
+#pragma unroll
+    for (int cc = 0; cc < B; ++cc) qr[cc] = Q.vals[(size_t)t * BB + cc * B + c];
+#pragma unroll
+    for (int cc = 0; cc < B; ++cc)
+#pragma unroll
+      for (int a = 0; a < R; ++a) acc[cc][a] = fma(xr[a], qr[cc], acc[cc][a]);
+  }
+  pose_reduce_scatter<D, R>(acc, c, h);
+  if constexpr (SPLIT > 1) {  // fixed-order tree over the slices; the sum lands in slice 0
+#pragma unroll
+    for (int o = SPLIT / 2; o >= 1; o >>= 1) {
+#pragma unroll
+      for (int a = 0; a < R; ++a) h[a] += __shfl_down(h[a], o * B);
+    }
+  }
+}
+
+// MT = tiles (of Geo::P poses) a workgroup owns: tile = rank + k * members, k < MT.  Resident slots (the host reserves
+// against 2 per CU): the (SPLIT = 4, MT = 1) variant fits two workgroups per CU (<= 256 registers) and costs one slot per
+// workgroup; the others keep up to 512 registers per lane (one workgroup per CU) and cost two.
+constexpr int persist_slots_per_wg(int split, int mt) { return (split == 4 && mt == 1) ? 1 : 2; }
 template <int D, int R, int SPLIT, int MT>
-__global__ __launch_bounds__(kBlock) void k_tcg_persist(BsrDev Q, const double* __restrict__ X,
+__global__ __launch_bounds__(kBlock, 3 - persist_slots_per_wg(SPLIT, MT)) void k_tcg_persist(BsrDev Q, const double* __restrict__ X,
                                                         const double* __restrict__ S, const double* __restrict__ g,
                                                         const double* __restrict__ dinv, double* __restrict__ eta, double* z,
                                                         unsigned long long* gran, unsigned salt,
                                                         const DevState* __restrict__ sin, DevState* __restrict__ sout,
-                                                        PersistCtrl* ctrl, int n, unsigned long long* hflag, unsigned gen) {
+                                                        PersistCtrl* ctrl, int n, unsigned long long* hflag, unsigned gen,
+                                                        int poll) {
   using GEO = Geo<D, R, SPLIT>;
   constexpr int P = GEO::P, G = GEO::G, T = GEO::T, B = GEO::B, BB = GEO::BB;
   // resident in LDS: the poses' X (projections need all rotation columns of a pose) and z (Hessian correction);
   // ex: two wave-private exchange tiles (the columns of one pose meet here)
   __shared__ __attribute__((aligned(16))) double Xs[MT][P][T], Zs[MT][P][T];
   __shared__ __attribute__((aligned(16))) double ex[2][kWaves][G][T];
-  __shared__ double red[kWaves * kNP];
+  __shared__ double red[2 * 2 * kWaves * kGranVals];
   __shared__ int ok_s;
 
   const int rank = blockIdx.x, members = gridDim.x;
+  if (threadIdx.x == 0) ok_s = 1;  // (ordered before its first use by the barriers of the first all-reduce)
   DevState st;
   load_state(st, sin);
   if (st.rtr_stop) {
     if (rank == 0 && threadIdx.x == 0) {
+      store_state(sout, st);
+      publish_progress(hflag, gen, st);
+    }
+    return;
+  }
+  if (__hip_atomic_load(&ctrl->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+    // an earlier launch of this solve timed out (the word is cleared once per solve): hand the poisoned state on
+    if (rank == 0 && threadIdx.x == 0) {
+      st.rtr_stop = 3;
       store_state(sout, st);
       publish_progress(hflag, gen, st);
     }
@@ -161,7 +319,12 @@ __global__ __launch_bounds__(kBlock) void k_tcg_persist(BsrDev Q, const double* 
   const int co = L.c * R;
 
   // ---- resident data of the workgroup's rows (registers; X and z also in LDS)
-  RowIdx ri[MT];
+  // block columns resident in registers (2 blocks per lane group with SPLIT = 4, 8 with SPLIT = 1: only where one tile
+  // per workgroup leaves the room)
+  constexpr bool QRES = (SPLIT > 1) || (MT == 1);
+  const __amdgpu_buffer_rsrc_t rz = vec_rsrc(z, (size_t)n * T * sizeof(double));
+  using GG = GatherGeo<D, SPLIT>;
+  GatherOps<D, R, SPLIT, QRES> go[MT];
   int pose[MT];
   bool okp[MT], own[MT];
   double rr[MT][R], ee[MT][R], dl[MT][R], hd[MT][R], zc[MT][R], srow[MT][D], drow[MT][B];
@@ -171,7 +334,7 @@ __global__ __launch_bounds__(kBlock) void k_tcg_persist(BsrDev Q, const double* 
     pose[k] = tile * P + lp;
     okp[k] = (tile < ntiles) && (L.g < G) && (pose[k] < n);
     own[k] = okp[k] && (L.s == 0);
-    ri[k] = row_idx_load<D, SPLIT>(Q.rowptr, Q.colidx, pose[k], L.s, L.c, okp[k]);
+    gather_setup<D, R, SPLIT, QRES>(go[k], Q, pose[k], L.s, L.c, okp[k]);
 #pragma unroll
     for (int a = 0; a < R; ++a) rr[k][a] = ee[k][a] = dl[k][a] = hd[k][a] = zc[k][a] = 0.0;
 #pragma unroll
@@ -233,7 +396,29 @@ __global__ __launch_bounds__(kBlock) void k_tcg_persist(BsrDev Q, const double* 
           part[1] = fma(out[a], rr[k][a], part[1]);
           zc[k][a] = out[a];
           Zs[k][lp][co + a] = out[a];
-          st_agent(z + off + a, out[a]);  // the copy the other workgroups gather
+          if constexpr (T % 2 != 0) st_agent(z + off + a, out[a]);  // the copy the other workgroups gather
+        }
+      }
+      if constexpr (T % 2 == 0) {
+        // the wave's poses are one contiguous span of z whose layout is the LDS tile's: it leaves as lane-linear 16-byte
+        // write-through pieces
+        wave_sync();
+        const int p0w = (rank + k * members) * P + L.wave * G;
+        const int npose = (n - p0w) < G ? (n - p0w) : G;
+        const int pieces = npose > 0 ? npose * (T / 2) : 0;
+        const dbl2* span = reinterpret_cast<const dbl2*>(&Zs[k][L.wave * G][0]);
+#pragma unroll
+        for (int it = 0; it < (G * (T / 2) + 63) / 64; ++it) {
+          const int pc = (int)(threadIdx.x & 63) + 64 * it;
+          if (pc < pieces) {
+            const dbl2 v = span[pc];
+            u32x4 w;
+            w.x = (unsigned)__double2loint(v.x);
+            w.y = (unsigned)__double2hiint(v.x);
+            w.z = (unsigned)__double2loint(v.y);
+            w.w = (unsigned)__double2hiint(v.y);
+            __builtin_amdgcn_raw_buffer_store_b128(w, rz, (p0w * T + 2 * pc) * 8, 0, kAuxSc1);
+          }
         }
       }
       // ex[0] / ex[1] of the next tile are written only after this tile's reads: with block-Jacobi the next tile's first
@@ -241,7 +426,6 @@ __global__ __launch_bounds__(kBlock) void k_tcg_persist(BsrDev Q, const double* 
       if (!dinv) wave_sync();
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this thread's z stores have been acknowledged
-    block_allreduce<2>(part, red);
   };
 
   // ---- phase A: Hz on the own rows (one hop: Q blocks + gathered z tiles of ALL owned tiles are requested before the
@@ -249,10 +433,19 @@ __global__ __launch_bounds__(kBlock) void k_tcg_persist(BsrDev Q, const double* 
   auto phase_hess = [&](bool first, double beta, double (&part)[1]) {
     part[0] = 0.0;
     double h[MT][R];
+    if constexpr (SPLIT > 1) {  // few loads per tile: all tiles' requests go out before the first reduction
+      double xc[MT][GG::NB][R], qc[MT][GG::NB][B];
 #pragma unroll
-    for (int k = 0; k < MT; ++k) {
-      if (rank + k * members >= ntiles) break;  // workgroup-uniform
-      spmm_col_pre<D, R, SPLIT, 2>(ri[k], Q.colidx, Q.vals, z, L.s, L.c, h[k]);
+      for (int k = 0; k < MT; ++k) gather_issue<D, R, SPLIT, QRES>(go[k], Q, rz, L.s, L.c, xc[k], qc[k]);
+#pragma unroll
+      for (int k = 0; k < MT; ++k) gather_finish<D, R, SPLIT, QRES>(go[k], Q, rz, L.s, L.c, xc[k], qc[k], h[k]);
+    } else {  // one pose per (D+1) lanes: a tile's 2 (D+1) R + 2 (D+1)^2 loads fill the register budget; tile after tile
+#pragma unroll
+      for (int k = 0; k < MT; ++k) {
+        double xc[GG::NB][R], qc[GG::NB][B];
+        gather_issue<D, R, SPLIT, QRES>(go[k], Q, rz, L.s, L.c, xc, qc);
+        gather_finish<D, R, SPLIT, QRES>(go[k], Q, rz, L.s, L.c, xc, qc, h[k]);
+      }
     }
 #pragma unroll
     for (int k = 0; k < MT; ++k) {
@@ -282,7 +475,6 @@ __global__ __launch_bounds__(kBlock) void k_tcg_persist(BsrDev Q, const double* 
         }
       }
     }
-    block_allreduce<1>(part, red);
   };
 
   // ---- tCG_TR (ROPTLIB): the scalar logic of tcg_update_prologue / tcg_hess_prologue, evaluated redundantly (and
@@ -295,7 +487,7 @@ __global__ __launch_bounds__(kBlock) void k_tcg_persist(BsrDev Q, const double* 
   bool alive = true;
   double pr[2];
   phase_update(true, 0.0, pr);
-  alive = chip_allreduce<2>(gran, rank, members, salt, step, pr, red, &ctrl->error, &ok_s);
+  alive = chip_allreduce<2>(gran, rank, members, salt, step, pr, red, &ctrl->error, &ok_s, poll);
   if (alive) {
     st.norm_r0 = sqrt(pr[0]);
     st.z_r = pr[1];
@@ -312,7 +504,7 @@ __global__ __launch_bounds__(kBlock) void k_tcg_persist(BsrDev Q, const double* 
     double dh[1];
     phase_hess(first, beta, dh);
     const unsigned long long t1 = wall_clock64();
-    if (!(alive = chip_allreduce<1>(gran, rank, members, salt, step, dh, red, &ctrl->error, &ok_s))) break;
+    if (!(alive = chip_allreduce<1>(gran, rank, members, salt, step, dh, red, &ctrl->error, &ok_s, poll))) break;
     const unsigned long long t2 = wall_clock64();
     const double d_Hd = dh[0];
     const double alpha = st.z_r / d_Hd;
@@ -336,7 +528,7 @@ __global__ __launch_bounds__(kBlock) void k_tcg_persist(BsrDev Q, const double* 
     st.e_Pe = e_Pe_new;
     phase_update(false, alpha, pr);
     const unsigned long long t3 = wall_clock64();
-    if (!(alive = chip_allreduce<2>(gran, rank, members, salt, step, pr, red, &ctrl->error, &ok_s))) break;
+    if (!(alive = chip_allreduce<2>(gran, rank, members, salt, step, pr, red, &ctrl->error, &ok_s, poll))) break;
     const unsigned long long t4 = wall_clock64();
     if (!first) {
       tk[0] += t1 - t0;
@@ -387,7 +579,7 @@ __global__ __launch_bounds__(kBlock) void k_tcg_persist(BsrDev Q, const double* 
       store_state(sout, s0);
       publish_progress(hflag, gen, s0);
     }
-    ctrl->iters = iters;
+    ctrl->iters += iters;  // (zeroed by the host once per solve)
     ctrl->members = (unsigned)members;
 #pragma unroll
     for (int q = 0; q < 5; ++q) ctrl->ticks[q] = tk[q];

@@ -605,7 +605,7 @@ def test_symmetric_storage_solve_2d_matches_oracle(oracle):
     ("sphere2500", 3, "jacobi", None), ("tinyGrid3D", 5, "jacobi", None), ("smallGrid3D", 6, "none", None),
     ("torus3D", 5, "jacobi", None), ("kitti_00", 5, "jacobi", None), ("kitti_00", 4, "none", None),
     ("sphere2500", 5, "jacobi", (1, 1)), ("sphere2500", 5, "jacobi", (4, 2)), ("torus3D", 5, "jacobi", (1, 2)),
-    ("sphere2500", 5, "jacobi", (1, 4)), ("kitti_00", 5, "jacobi", (1, 2))])
+    ("kitti_00", 5, "jacobi", (1, 2))])
 def test_persistent_tcg_matches_oracle(oracle, name, r, precond, layout):
     """The persistent whole-chip tCG kernel (one launch per tCG run, the all-reduces of an iteration's dot products are
     its barriers; kernels/persist.h) against the oracle at matched settings, exactly as the two-kernel scheme is tested:
@@ -649,7 +649,7 @@ def _persistent_case(oracle, name, r, precond, layout):
 
 
 def test_persistent_tcg_is_refused_beyond_its_capacity_and_follows_the_size_switch(oracle):
-    """Blocks that need more than 4 tiles on each of 256 workgroups are refused (explicit request: error); the default
+    """Blocks that need more than 2 tiles on each of 256 workgroups are refused (explicit request: error); the default
     is on by size: sphere2500 runs the persistent kernel without being asked, the single-iteration radius-shrink mode
     and an iterate that already meets the tolerance behave as on the two-kernel scheme."""
     import dpgo_amd
@@ -671,7 +671,7 @@ def test_persistent_tcg_is_refused_beyond_its_capacity_and_follows_the_size_swit
         assert relerr(Xa, Xb) < 1e-9 and abs(ra.fOpt - rb.fOpt) <= 1e-10 * abs(rb.fOpt)
     assert two.persistentInfo()["last_members"] == 0
     from dpgo_amd import synthetic
-    meas, nbig, _ = synthetic.synthetic_grid(50, 50, 30, seed=0)  # 75 000 poses: 1 172 tiles of 64 > 4 x 256
+    meas, nbig, _ = synthetic.synthetic_grid(50, 50, 16, seed=0)  # 40 000 poses: 625 tiles of 64 > 2 x 256
     pgb = dpgo_amd.PoseGraph(0, 5, 3)
     pgb.setMeasurements(meas)
     big = dpgo_amd.QuadraticProblem(pgb)
@@ -757,9 +757,11 @@ def test_rccl_transport_on_one_gpu(oracle):
 
 def test_concurrent_same_colour_agents_match_sequential_updates(oracle):
     """dpgo_optimize_device_many: the agents of a colour hosted by one GPU are solved CONCURRENTLY (own streams behind the
-    exchange, one feeding thread each).  Every solve is a deterministic function of its own inputs, so three sweeps of
-    a 5-agent (smallGrid3D) and an 8-agent (torus3D) problem give bit-identical iterates, iteration counts and central
-    cost with and without the concurrency; so does the concurrent evaluation of the block terms."""
+    exchange, one feeding thread each).  Every solve is a function of its own inputs only, so three sweeps of a 5-agent
+    (smallGrid3D) and an 8-agent (torus3D) problem give the same iteration counts, iterates and central cost with and
+    without the concurrency -- to round-off, not bit for bit: agents that share the device pick the most compact layout
+    of the persistent tCG kernel, whose sums run in another order --, and so does the concurrent evaluation of the
+    block terms."""
     import torch
     import dpgo_amd
     from dpgo_amd.agent import DeviceAgent, ExchangePlan, RBCDCluster, build_pose_graphs
@@ -785,8 +787,9 @@ def test_concurrent_same_colour_agents_match_sequential_updates(oracle):
             runs.append((trace, counts, [agents[a].X.clone() for a in range(robots)]))
         assert runs[0][1] == runs[1][1]
         for a in range(robots):
-            assert torch.equal(runs[0][2][a], runs[1][2][a])
-        assert runs[0][0] == runs[1][0]
+            assert relerr(runs[1][2][a].cpu().numpy(), runs[0][2][a].cpu().numpy()) < 1e-9
+        for (f0, g0), (f1, g1) in zip(runs[0][0], runs[1][0]):
+            assert abs(f0 - f1) <= 1e-10 * abs(f0) and abs(g0 - g1) <= 1e-7 * max(g0, 1e-3)
         assert runs[1][0][-1][0] < runs[1][0][0][0]
 
 
