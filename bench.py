@@ -62,6 +62,9 @@ def parse_args():
     ap.add_argument("--cpu-budget-s", type=float, default=25.0)
     ap.add_argument("--spmm-reps", type=int, default=200)
     ap.add_argument("--agents-per-gpu", type=int, default=0, help="0 = auto (1 if one GPU, else 2; 8 with --loopback)")
+    ap.add_argument("--sequential", action="store_true",
+                    help="diagnostic: the agents a process hosts are solved one after the other (DPGO_SEQUENTIAL_SWEEP=1) -- "
+                         "the sum of the solo solve times, from which a many-GPU sweep time can be predicted")
     ap.add_argument("--loopback", action="store_true",
                     help="single GPU, several agents: every public-pose exchange and reduction travels through a 1-rank "
                          "RCCL communicator owned by the solver library (the N > 1 data path on one device)")
@@ -356,6 +359,8 @@ def time_to_tolerance(workload, r, precond, tol=1e-2, max_calls=12, coarse_bits=
 
 def main():
     args = parse_args()
+    if args.sequential:
+        os.environ["DPGO_SEQUENTIAL_SWEEP"] = "1"
     import torch
     import torch.distributed as dist
     import dpgo_amd
@@ -746,6 +751,7 @@ def main():
                             "auto": "auto (library default: multilevel when the tCG budget binds, else block-Jacobi)"}[
                                args.precond]),
                        "precond_used_in_timed_steps": sorted(used_precond),
+                       "same_colour_agents": "sequential (diagnostic)" if args.sequential else "concurrent",
                        "schedule": "single agent" if num_agents == 1 else
                        "%d-colour parallel RBCD; 1 step = 1 sweep (every agent updates once; same-colour agents of a "
                        "GPU solved concurrently); public-pose exchange over %s" % (

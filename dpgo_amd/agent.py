@@ -19,6 +19,7 @@ updated once.
 """
 from __future__ import annotations
 
+from dataclasses import dataclass, replace
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
@@ -27,6 +28,61 @@ from . import lib as L
 from .measurements import RelativeSEMeasurements, partition_contiguous
 from .solver import (PoseGraph, QuadraticOptimizer, QuadraticProblem, ROptParameters, ROPTResult,
                      eval_terms_device_many, optimize_device_many)
+
+
+@dataclass
+class PGOAgentParameters:
+    """The fields of DPGO::PGOAgentParameters that the status / termination rules read, with the reference's
+    defaults (include/DPGO/PGOAgent.h:121-137)."""
+    robust: bool = False  # robustCostParams.costType != L2
+    robustOptNumWeightUpdates: int = 10
+    robustOptInnerIters: int = 30
+    robustOptMinConvergenceRatio: float = 0.8
+    maxNumIters: int = 500
+    relChangeTol: float = 5e-3
+
+
+@dataclass
+class PGOAgentStatus:
+    """DPGO::PGOAgentStatus (include/DPGO/PGOAgent.h:196-227)."""
+    agentID: int = 0
+    state: str = "WAIT_FOR_DATA"
+    instanceNumber: int = 0
+    iterationNumber: int = 0
+    readyToTerminate: bool = False
+    relativeChange: float = 0.0
+
+
+def should_terminate(iteration: int, prm: PGOAgentParameters, weight_update_count: int,
+                     team: Dict[int, PGOAgentStatus], num_robots: int) -> bool:
+    """PGOAgent::shouldTerminate (src/PGOAgent.cpp:846-878), every robot active."""
+    if iteration >= prm.maxNumIters:
+        return True
+    if prm.robust and weight_update_count < prm.robustOptNumWeightUpdates:
+        return False
+    for rob in range(num_robots):
+        st = team.get(rob)
+        if st is None or st.state != "INITIALIZED" or not st.readyToTerminate:
+            return False
+    return True
+
+
+def should_update_measurement_weights(prm: PGOAgentParameters, weight_update_count: int, inner_iter: int,
+                                      latest_update_iteration: int, team: Dict[int, PGOAgentStatus],
+                                      num_robots: int) -> bool:
+    """PGOAgent::shouldUpdateMeasurementWeights (src/PGOAgent.cpp:997-1045)."""
+    if not prm.robust:
+        return False
+    if weight_update_count >= prm.robustOptNumWeightUpdates:
+        return False
+    if inner_iter >= prm.robustOptInnerIters:
+        return True
+    for rob in range(num_robots):
+        st = team.get(rob)
+        if st is None or st.iterationNumber < latest_update_iteration or st.state != "INITIALIZED" \
+                or not st.readyToTerminate:
+            return False
+    return True
 
 
 def build_pose_graphs(dataset: RelativeSEMeasurements, num_poses: int, num_robots: int, r: int):
@@ -89,7 +145,43 @@ class ExchangePlan:
         return out
 
 
-class DeviceAgent:
+class AgentStatusMixin:
+    """The host half of PGOAgent's status block (src/PGOAgent.cpp:399-420), shared by DeviceAgent and the CPU stand-in
+    of the gloo tests.  Needs: id, X, torch; provides enable_status / finish_status; measure_relative_change is the
+    agent's own (a device kernel for DeviceAgent)."""
+
+    def enable_status(self, agent_params: Optional[PGOAgentParameters] = None) -> None:
+        """Track PGOAgentStatus: relativeChange = maxTranslationDistance(X, XPrev) is evaluated after every optimising
+        update (on the device: dpgo_max_translation_distance_device) and left in a one-element tensor; the cluster
+        reads the scalars of all its agents back together."""
+        self.agent_params = agent_params or PGOAgentParameters()
+        if not hasattr(self, "XPrev"):
+            self.XPrev = self.X.clone()
+        self.rel_dev = self.torch.zeros(1, dtype=self.torch.float64, device=self.X.device)
+        self.status = PGOAgentStatus(self.id, "INITIALIZED")
+        self.weight_update_count = 0
+        self.lc_weights = None  # weights of this agent's loop closures (None: never re-weighted = all 1)
+        self.track_status = True
+
+    def finish_status(self, iteration: int, relative_change: float, success: bool) -> PGOAgentStatus:
+        """The status block (src/PGOAgent.cpp:401-420) once relativeChange is known."""
+        prm = self.agent_params
+        ready = bool(success)
+        tol = prm.relChangeTol
+        if prm.robust and self.weight_update_count == 0:  # loose threshold before the first weight update (:411-415)
+            tol = 5.0
+        if relative_change > tol:
+            ready = False
+        w = self.lc_weights
+        if w is not None and len(w) > 0:
+            ratio = float(((w == 1).sum() + (w == 0).sum()) / len(w))
+            if ratio < prm.robustOptMinConvergenceRatio:
+                ready = False
+        self.status = PGOAgentStatus(self.id, "INITIALIZED", 0, int(iteration), ready, float(relative_change))
+        return self.status
+
+
+class DeviceAgent(AgentStatusMixin):
     """One agent on one GPU: device-resident X, neighbour tile buffer and problem handle.
 
     With enable_acceleration() it also carries the Nesterov state of PGOAgent (XPrev, Y, V, gamma, alpha,
@@ -137,6 +229,22 @@ class DeviceAgent:
         self.gamma = self.alpha = 0.0
         self.nbr_aux = self.torch.zeros_like(self.nbr)
         self.send_buf_aux = {q: self.torch.empty_like(b) for q, b in self.send_buf.items()}
+
+    # ---- status (PGOAgent::iterate, src/PGOAgent.cpp:399-420): host half in AgentStatusMixin ----
+    def loop_closure_weights(self) -> np.ndarray:
+        """Current weights of the agent's loop closures, private and shared (what PoseGraph::statistics walks,
+        src/PoseGraph.cpp:305-340); needs setReweightableEdges(include_shared=True)."""
+        m = self.pg.measurements()
+        idx = self.problem.reweightable_index
+        w, _ = self.problem.getEdgeWeights()
+        lc = ~((m.r1[idx] == m.r2[idx]) & (m.p1[idx] + 1 == m.p2[idx]))
+        return np.asarray(w)[lc]
+
+    def measure_relative_change(self, stream=None) -> None:
+        """Enqueue relativeChange of (X, XPrev) into this agent's device scalar."""
+        L.check(self.problem._lib.dpgo_max_translation_distance_device(
+            self.r, self.d, self.n, L.ptr(self.X), L.ptr(self.XPrev), L.ptr(self.rel_dev), None,
+            stream if stream is not None else (self.torch.cuda.current_stream().cuda_stream or None)))
 
     # ---- K11: pack / unpack of public poses (PGOAgent::getSharedPoseDict / getAuxSharedPoseDict) ----
     def pack(self, q: int, aux: bool = False):
@@ -319,6 +427,67 @@ class RBCDCluster:
     def _main_stream(self):
         any_agent = next(iter(self.agents.values()))
         return any_agent.torch.cuda.current_stream().cuda_stream
+
+    def phase(self, c: int, iteration: Optional[int] = None) -> None:
+        """One colour phase = one global iteration of the coloured schedule: exchange, the agents of colour c update
+        (concurrently when this process hosts several).  With status tracking (DeviceAgent.enable_status) and an
+        iteration number, XPrev is saved before and the agents' relative changes are measured on the device after the
+        solves, read back together (one small copy per phase) and turned into PGOAgentStatus records."""
+        self.exchange(receivers=c)
+        ids = [a for a in self.agents if self.plan.colour[a] == c]
+        tracked = [a for a in ids if getattr(self.agents[a], "track_status", False)] if iteration is not None else []
+        for a in tracked:
+            self.agents[a].XPrev.copy_(self.agents[a].X)
+        if self.concurrent and len(ids) > 1 and all(hasattr(self.agents[a], "optimizer") for a in ids):
+            ags = [self.agents[a] for a in ids]
+            res = optimize_device_many([g.optimizer for g in ags], [g.X for g in ags],
+                                       [g.nbr if g.has_neighbours else None for g in ags], self._main_stream())
+            for g, r_ in zip(ags, res):
+                g.last_result = r_
+        else:
+            for a in ids:
+                self.agents[a].update()
+        if tracked:
+            torch = self.agents[tracked[0]].torch
+            for a in tracked:
+                self.agents[a].measure_relative_change()
+            rel = torch.cat([self.agents[a].rel_dev for a in tracked]).cpu().numpy()  # ONE read-back per phase
+            for a, v in zip(tracked, rel):
+                ag = self.agents[a]
+                ag.finish_status(iteration, float(v), bool(getattr(getattr(ag, "last_result", None), "success", True)))
+
+    def team_status(self) -> Dict[int, PGOAgentStatus]:
+        """Statuses of ALL agents, identical on every rank (the reference's agents publish theirs to the team,
+        PGOAgent::setNeighborStatus): one all-reduce of a [num_agents, 4] array, every row owned by one rank."""
+        rows = np.zeros((self.plan.num_agents, 4))
+        for a, ag in self.agents.items():
+            st = getattr(ag, "status", None)
+            if st is not None and st.iterationNumber > 0:
+                rows[a] = [1.0, st.iterationNumber, 1.0 if st.readyToTerminate else 0.0, st.relativeChange]
+        rows = self._allreduce_host(rows)
+        return {a: PGOAgentStatus(a, "INITIALIZED", 0, int(rows[a, 1]), bool(rows[a, 2] > 0.5), float(rows[a, 3]))
+                for a in range(self.plan.num_agents) if rows[a, 0] > 0.5}
+
+    def run_until_terminated(self, agent_params: Optional[PGOAgentParameters] = None, max_phases: int = 10000):
+        """The coloured schedule driven by the reference's own stopping rule (PGOAgent::shouldTerminate,
+        src/PGOAgent.cpp:846-878): one global iteration = one colour phase; after every phase the team status is
+        shared and every agent evaluates the vote on the same statuses, so all ranks stop together.  Returns
+        dict(iterations, statuses, relative_changes)."""
+        prm = agent_params or PGOAgentParameters()
+        for ag in self.agents.values():
+            if not getattr(ag, "track_status", False):
+                ag.enable_status(prm)
+            ag.agent_params = prm
+        iteration, trace, team = 0, [], {}
+        while iteration < max_phases:
+            c = iteration % self.plan.num_colours
+            iteration += 1
+            self.phase(c, iteration)
+            team = self.team_status()
+            trace.append({a: st.relativeChange for a, st in team.items()})
+            if should_terminate(iteration, prm, 0, team, self.plan.num_agents):
+                break
+        return dict(iterations=iteration, statuses=team, relative_changes=trace)
 
     def sweep(self) -> None:
         """One RBCD iteration: every colour class updates once.  The agents of a colour hosted by THIS process are

@@ -1027,11 +1027,10 @@ int persist_capacity(int device) {
   }
   return cap;
 }
-bool persist_reserve(dpgo_problem_s* p, int slots) {
-  const int cap = persist_capacity(p->device);
+bool persist_reserve(dpgo_problem_s* p, int slots, int limit) {
   auto& used = g_persist_used[p->device % kMaxDevices];
   int cur = used.load();
-  while (cur + slots <= cap)
+  while (cur + slots <= limit)
     if (used.compare_exchange_weak(cur, cur + slots)) {
       p->persist_reserved = slots;
       return true;
@@ -1076,9 +1075,27 @@ PersistGeo persist_geometry(const dpgo_problem_s* p, int free_slots, int share =
 int launch_tcg_persistent(dpgo_problem_s* p, const double* dinv, bool* used) {
   *used = false;
   if (p->persist_reserved == 0) {
-    const int free_slots = persist_capacity(p->device) - g_persist_used[p->device % kMaxDevices].load();
-    const PersistGeo g = persist_geometry(p, free_slots, p->persist_share);
-    if (g.wgs <= 0 || !persist_reserve(p, g.slots)) return DPGO_OK;
+    // Alone on the device: what is free now, first come first served.  Sharing it with other concurrently solved agents:
+    // the most compact layout, at most 4/5 of the slots in use at once (a CU that holds a persistent workgroup has no
+    // registers left for anything else, and every agent's other kernels -- gradient, retraction, rho test -- need
+    // somewhere to run: packing the chip full made a 16-agent sweep slower), and a solve that finds no room WAITS for
+    // another one to finish (a solve is well under a millisecond) instead of taking the slow path.
+    const int cap = persist_capacity(p->device);
+    auto& used = g_persist_used[p->device % kMaxDevices];
+    PersistGeo g;
+    if (p->persist_share <= 1) {
+      g = persist_geometry(p, cap - used.load(), 1);
+      if (g.wgs <= 0 || !persist_reserve(p, g.slots, cap)) return DPGO_OK;
+    } else {
+      const int limit = cap - cap / 5;
+      g = persist_geometry(p, limit, p->persist_share);
+      if (g.wgs <= 0) return DPGO_OK;
+      const auto t0 = std::chrono::steady_clock::now();
+      while (!persist_reserve(p, g.slots, limit)) {
+        if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 0.05) return DPGO_OK;
+        std::this_thread::yield();
+      }
+    }
     p->persist_split = g.split;
     p->persist_mt = g.mt;
     p->persist_wgs = g.wgs;
@@ -3128,6 +3145,22 @@ int dpgo_gather_tiles_device(int r, int d, const double* src_dev, const int32_t*
   DISPATCH(d, r, hipLaunchKernelGGL((k_gather_tiles<D, R>), dim3(g), dim3(kBlock), 0, (hipStream_t)stream, src_dev,
                                     idx_dev, count, dst_dev));
   HIPC(hipGetLastError());
+  return DPGO_OK;
+}
+
+int dpgo_max_translation_distance_device(int r, int d, int n, const double* X_dev, const double* Xprev_dev,
+                                         double* out_dev, double* out_host, void* stream) {
+  if (!X_dev || !Xprev_dev || !out_dev || n <= 0) return fail(DPGO_ERR_INVALID, "bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  HIPC(hipMemsetAsync(out_dev, 0, sizeof(double), s));
+  const int g = std::max(1, std::min(kMaxGrid, (n + kBlock - 1) / kBlock));
+  DISPATCH(d, r, hipLaunchKernelGGL((k_max_translation_distance<D, R>), dim3(g), dim3(kBlock), 0, s, X_dev, Xprev_dev, n,
+                                    reinterpret_cast<unsigned long long*>(out_dev)));
+  HIPC(hipGetLastError());
+  if (out_host) {
+    HIPC(hipMemcpyAsync(out_host, out_dev, sizeof(double), hipMemcpyDeviceToHost, s));
+    HIPC(hipStreamSynchronize(s));
+  }
   return DPGO_OK;
 }
 

@@ -15,6 +15,33 @@ __global__ __launch_bounds__(kBlock) void k_gather_tiles(const double* __restric
   }
 }
 
+// ================================================================ agent status: relative change of the iterate
+// LiftedPoseArray::maxTranslationDistance (src/manifold/Poses.cpp:86-94) = max_i |p_i - p_i'| over the translation columns
+// of two lifted pose arrays; PGOAgent::iterate stores it as mStatus.relativeChange (src/PGOAgent.cpp:406).  One thread per
+// pose, wave maximum by shuffles, one atomic maximum per wave on the BIT PATTERN (non-negative doubles order like their
+// bits; *out is zeroed before the launch), so the result does not depend on the order of arrival.
+template <int D, int R>
+__global__ __launch_bounds__(kBlock) void k_max_translation_distance(const double* __restrict__ X,
+                                                                     const double* __restrict__ Xp, int n,
+                                                                     unsigned long long* __restrict__ out) {
+  constexpr int T = (D + 1) * R;
+  double m = 0.0;
+  for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+    const double* a = X + (size_t)i * T + D * R;
+    const double* b = Xp + (size_t)i * T + D * R;
+    double s = 0.0;
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+      const double dlt = a[k] - b[k];
+      s = fma(dlt, dlt, s);
+    }
+    m = fmax(m, sqrt(s));
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) m = fmax(m, __shfl_xor(m, o));
+  if ((threadIdx.x & 63) == 0) atomicMax(out, (unsigned long long)__double_as_longlong(m));
+}
+
 // Block-Jacobi factors: Dinv_i = (Q_ii + shift I)^-1 by Gauss-Jordan on the SPD (D+1)x(D+1) block.
 template <int D>
 __global__ __launch_bounds__(kBlock) void k_build_dinv(BsrDev Q, double shift, double* __restrict__ dinv, int n) {

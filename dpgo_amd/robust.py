@@ -188,14 +188,30 @@ class DistributedGNC:
     weight without a message (the reference ships weights from the owner instead; same values).
     Global scalars (max residual, the three counters) are one tiny all-reduce each per weight update."""
 
-    def __init__(self, cluster, robust_params: Optional[RobustCostParameters] = None, inner_sweeps: int = 5):
+    def __init__(self, cluster, robust_params: Optional[RobustCostParameters] = None, inner_sweeps: int = 5,
+                 agent_params=None):
+        """agent_params (a dpgo_amd.agent.PGOAgentParameters): the weight updates follow the reference's own trigger,
+        PGOAgent::shouldUpdateMeasurementWeights (src/PGOAgent.cpp:997-1045) -- global iterations (= colour phases)
+        until every agent is readyToTerminate (relative change of its last update <= relChangeTol, 5 before the first
+        weight update; converged-weight ratio >= robustOptMinConvergenceRatio) or robustOptInnerIters of them have
+        passed -- instead of a fixed number of sweeps; info["inner_iterations"] lists the count of every block."""
         self.cluster = cluster
         self.params = robust_params or RobustCostParameters("GNC_TLS", GNCMaxNumIters=30)
         if self.params.costType != "GNC_TLS":
             raise ValueError("CHECK(costType == GNC_TLS) failed")
         self.inner_sweeps = int(inner_sweeps)
+        self.agent_params = None
+        self.iteration = 0
+        self.weight_updates = 0
+        self.inner_counts = []
         for agent in cluster.agents.values():
             agent.problem.setReweightableEdges(include_shared=True)
+        if agent_params is not None:
+            from dataclasses import replace
+            self.agent_params = replace(agent_params, robust=True)
+            for agent in cluster.agents.values():
+                agent.enable_status(self.agent_params)
+                agent.lc_weights = agent.loop_closure_weights()
 
     def _allreduce(self, values, op: str):
         c = self.cluster
@@ -222,11 +238,34 @@ class DistributedGNC:
             mx = max(mx, m)
         counts = self._allreduce(counts, "sum")
         mx = float(self._allreduce([mx], "max")[0])
+        if update and self.agent_params is not None:  # PGOAgent::updateMeasurementWeights (:1119-1125)
+            for agent in self.cluster.agents.values():
+                agent.lc_weights = agent.loop_closure_weights()
+                agent.status.readyToTerminate = False
+                agent.status.relativeChange = 0.0
         return tuple(int(v) for v in counts), mx
 
     def _sweeps(self) -> None:
-        for _ in range(self.inner_sweeps):
-            self.cluster.sweep()
+        if self.agent_params is None:
+            for _ in range(self.inner_sweeps):
+                self.cluster.sweep()
+            return
+        from .agent import should_update_measurement_weights
+        c, prm = self.cluster, self.agent_params
+        for agent in c.agents.values():
+            agent.weight_update_count = self.weight_updates
+            agent.status.iterationNumber = 0  # mTeamStatus.clear() after a weight update (:1124)
+        inner, latest = 0, self.iteration
+        while True:
+            colour = self.iteration % c.plan.num_colours
+            self.iteration += 1
+            inner += 1
+            c.phase(colour, self.iteration)
+            team = c.team_status()
+            # (the cap on the NUMBER of updates is run()'s loop bound, so the count passed here is 0)
+            if should_update_measurement_weights(prm, 0, inner, latest, team, c.plan.num_agents):
+                break
+        self.inner_counts.append(inner)
 
     def run(self):
         """Returns info = {muInit, updates, history[], cost, gradnorm}; the iterates stay on the agents."""
@@ -244,11 +283,13 @@ class DistributedGNC:
                 (n_in, n_out, n_und), _ = self._reweight_all(mu, update=True)
                 info["history"].append(dict(mu=mu, inliers=n_in, outliers=n_out, undecided=n_und))
                 info["updates"] = it + 1
+                self.weight_updates = it + 1
                 if n_und == 0:
                     break
                 mu = p.GNCMuStep * mu
                 self._sweeps()
         self._sweeps()
+        info["inner_iterations"] = list(self.inner_counts)
         f, gn = self.cluster.central_cost_and_gradnorm()
         info["cost"], info["gradnorm"] = 2 * f, gn
         return info

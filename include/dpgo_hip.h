@@ -407,6 +407,12 @@ int dpgo_round_trajectory(int r, int d, int n, const double* X_host, const doubl
 int dpgo_round_trajectory_device(int r, int d, int n, const double* X_dev, const double* anchor_host, double* T_dev,
                                  void* stream);
 
+/* Agent status (PGOAgent::iterate, src/PGOAgent.cpp:399-420): relativeChange = LiftedPoseArray::maxTranslationDistance
+ * (src/manifold/Poses.cpp:86-94) of the iterate and the previous one, max_i |p_i - p_i'| over the translation columns.
+ * The result is left in *out_dev (device double: e.g. a slot of the vector a termination vote all-reduces with
+ * DPGO_COMM_MAX); out_host != NULL additionally copies it back (one synchronisation). */
+int dpgo_max_translation_distance_device(int r, int d, int n, const double* X_dev, const double* Xprev_dev,
+                                         double* out_dev, double* out_host, void* stream);
 /* out[k] = src tile idx[k]  (K11 pack for the public-pose exchange:
  * PGOAgent::getSharedPoseDict, src/PGOAgent.cpp:97-166) */
 int dpgo_gather_tiles_device(int r, int d, const double* src_dev, const int32_t* idx_dev, int count,

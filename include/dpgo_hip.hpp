@@ -614,16 +614,35 @@ class LiftedSEVector {
 // X, XPrev, Y, V and the neighbour tile buffers live in HBM; updateY / updateV are one fused kernel each (linear
 // combination + LiftedSEManifold::project), updateX is constructG on the device + QuadraticOptimizer::optimize on the
 // device iterate.  Public poses cross the ABI as the reference's PoseDict (host maps): a few hundred small tiles.
+// Status and the termination vote (PGOAgentStatus, getStatus / setNeighborStatus / shouldTerminate, src/PGOAgent.cpp:399-420,
+// 846-878): relativeChange is LiftedPoseArray::maxTranslationDistance(X, XPrev) evaluated on the device.
 // Not mirrored: the state machine / initialisation in a global frame / threads / logging / robust weights.
 struct PGOAgentParameters {  // the fields of DPGO::PGOAgentParameters (PGOAgent.h:49-160) this path reads
   unsigned d = 3, r = 5, numRobots = 1;
   bool acceleration = false;
   unsigned restartInterval = 30;
   ROptParameters localOptimizationParams;
+  unsigned maxNumIters = 500;   // PGOAgent.h:135
+  double relChangeTol = 5e-3;   // PGOAgent.h:136
   PGOAgentParameters(unsigned dIn, unsigned rIn, unsigned numRobotsIn = 1, ROptParameters local = ROptParameters(),
-                     bool accel = false, unsigned restart = 30)
+                     bool accel = false, unsigned restart = 30, unsigned maxIters = 500, double changeTol = 5e-3)
       : d(dIn), r(rIn), numRobots(numRobotsIn), acceleration(accel), restartInterval(restart),
-        localOptimizationParams(local) {}
+        localOptimizationParams(local), maxNumIters(maxIters), relChangeTol(changeTol) {}
+};
+
+enum class PGOAgentState { WAIT_FOR_DATA, WAIT_FOR_INITIALIZATION, INITIALIZED };  // PGOAgent.h:36-47
+
+struct PGOAgentStatus {  // DPGO::PGOAgentStatus (PGOAgent.h:196-227)
+  unsigned agentID = 0;
+  PGOAgentState state = PGOAgentState::WAIT_FOR_DATA;
+  unsigned instanceNumber = 0;
+  unsigned iterationNumber = 0;
+  bool readyToTerminate = false;
+  double relativeChange = 0;
+  explicit PGOAgentStatus(unsigned id = 0, PGOAgentState s = PGOAgentState::WAIT_FOR_DATA, unsigned instance = 0,
+                          unsigned iteration = 0, bool ready_to_terminate = false, double relative_change = 0)
+      : agentID(id), state(s), instanceNumber(instance), iterationNumber(iteration),
+        readyToTerminate(ready_to_terminate), relativeChange(relative_change) {}
 };
 
 using PoseID = PoseGraph::PoseID;
@@ -642,6 +661,21 @@ class PGOAgent {
   unsigned dimension() const { return prm_.d; }
   unsigned relaxation_rank() const { return prm_.r; }
   unsigned iteration_number() const { return iteration_; }
+
+  // PGOAgent::getStatus / setNeighborStatus (PGOAgent.h:300-310, src/PGOAgent.cpp:604-610) and shouldTerminate (:846-878)
+  PGOAgentStatus getStatus() const { return status_; }
+  void setNeighborStatus(const PGOAgentStatus& status) { team_[status.agentID] = status; }
+  bool shouldTerminate() {
+    if (iteration_number() >= prm_.maxNumIters) return true;
+    team_[id_] = status_;
+    for (unsigned robot = 0; robot < prm_.numRobots; ++robot) {
+      auto it = team_.find(robot);
+      if (it == team_.end()) return false;
+      if (it->second.state != PGOAgentState::INITIALIZED) return false;
+      if (!it->second.readyToTerminate) return false;
+    }
+    return true;
+  }
 
   // PGOAgent::setMeasurements (:263): odometry, private and shared loop closures of this robot
   void setMeasurements(const std::vector<RelativeSEMeasurement>& inputOdometry,
@@ -662,6 +696,9 @@ class PGOAgent {
     slots_ = problem_->setCouplingFromPoseGraph();
     pub_ = pg_->localSharedPoseIDs();
     for (double** v : {&X_, &XPrev_, &Y_, &V_}) check(dpgo_device_malloc((void**)v, sizeof(double) * T * n, device_));
+    check(dpgo_device_malloc((void**)&rel_, sizeof(double), device_));
+    status_ = PGOAgentStatus(id_, PGOAgentState::INITIALIZED);
+    team_.clear();
     const size_t ns = std::max<size_t>(slots_.size(), 1), np = std::max<size_t>(pub_.size(), 1);
     check(dpgo_device_malloc((void**)&nbr_, sizeof(double) * T * ns, device_));
     check(dpgo_device_malloc((void**)&nbr_aux_, sizeof(double) * T * ns, device_));
@@ -699,8 +736,12 @@ class PGOAgent {
   bool iterate(bool doOptimization = true) {
     iteration_ += 1;
     const size_t bytes = sizeof(double) * (size_t)(prm_.d + 1) * prm_.r * pg_->n();
-    if (!prm_.acceleration) return updateX(doOptimization, false);
     check(dpgo_device_memcpy(XPrev_, X_, bytes, DPGO_COPY_D2D, nullptr));  // XPrev = X (:386)
+    if (!prm_.acceleration) {
+      const bool ok = updateX(doOptimization, false);
+      if (doOptimization) updateStatus(ok);
+      return ok;
+    }
     const double N = (double)prm_.numRobots;
     gamma_ = (1 + std::sqrt(1 + 4 * N * N * gamma_ * gamma_)) / (2 * N);  // updateGamma (:910-914)
     alpha_ = 1 / (gamma_ * N);                                              // updateAlpha (:916-920)
@@ -714,6 +755,7 @@ class PGOAgent {
       check(dpgo_device_memcpy(Y_, X_, bytes, DPGO_COPY_D2D, nullptr));
       gamma_ = alpha_ = 0.0;
     }
+    if (doOptimization) updateStatus(ok);
     return ok;
   }
   const ROPTResult& latestResult() const { return result_; }
@@ -736,7 +778,7 @@ class PGOAgent {
     return sizeof(double) * M.rows() * M.cols();
   }
   void release() {
-    for (double** v : {&X_, &XPrev_, &Y_, &V_, &nbr_, &nbr_aux_, &pack_}) {
+    for (double** v : {&X_, &XPrev_, &Y_, &V_, &nbr_, &nbr_aux_, &pack_, &rel_}) {
       if (*v) dpgo_device_free(*v);
       *v = nullptr;
     }
@@ -744,6 +786,11 @@ class PGOAgent {
     pub_idx_ = nullptr;
     optimizer_.reset();
     problem_.reset();
+  }
+  void updateStatus(bool success) {  // src/PGOAgent.cpp:399-420 (L2 cost: no weight statistics)
+    double rel = 0.0;
+    check(dpgo_max_translation_distance_device((int)prm_.r, (int)prm_.d, (int)pg_->n(), X_, XPrev_, rel_, &rel, nullptr));
+    status_ = PGOAgentStatus(id_, PGOAgentState::INITIALIZED, 0, iteration_, success && rel <= prm_.relChangeTol, rel);
   }
   bool sharedDict(const double* src, PoseDict& map) {
     map.clear();
@@ -804,6 +851,9 @@ class PGOAgent {
   std::vector<PoseID> slots_;   // neighbour poses, slot order of the tile buffers
   std::vector<unsigned> pub_;   // my public frames
   double *X_ = nullptr, *XPrev_ = nullptr, *Y_ = nullptr, *V_ = nullptr, *nbr_ = nullptr, *nbr_aux_ = nullptr, *pack_ = nullptr;
+  double* rel_ = nullptr;  // device scalar: relativeChange of the last optimising iterate
+  PGOAgentStatus status_;
+  std::map<unsigned, PGOAgentStatus> team_;
   int32_t* pub_idx_ = nullptr;
   std::vector<double> nbr_h_, nbr_aux_h_;
   bool nbr_dirty_ = false, aux_dirty_ = false;

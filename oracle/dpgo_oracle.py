@@ -1217,7 +1217,7 @@ def solve_robust_pgo(meas: Measurements, n: int, T0, opt_params: Optional[ROptPa
 
 def multi_agent_gnc(meas: Measurements, n: int, num_robots: int, r: int, X0, inner_sweeps: int = 5, barc: float = 5.0,
                     mu_step: float = 1.4, max_updates: int = 30, params: Optional[ROptParameters] = None,
-                    precond: str = "jacobi", hess_recurrence: bool = False):
+                    precond: str = "jacobi", hess_recurrence: bool = False, agent_params=None):
     """Synchronous distributed GNC-TLS assembled from the reference's per-agent pieces (the in-tree library never
     calls them itself; the external dpgo_ros driver does):
       * PGOAgent::updateMeasurementWeights (src/PGOAgent.cpp:1104-1142): every agent re-weights ALL its non-fixed
@@ -1225,7 +1225,12 @@ def multi_agent_gnc(meas: Measurements, n: int, num_robots: int, r: int, X0, inn
         (computeMeasurementResidual, :1048-1102), w = RobustCost::weight(residual), then mu <- mu_step * mu
         (RobustCost::update) and the data matrices are rebuilt (clearDataMatrices); warm start (robustOptNumResets = 0);
       * initial mu as in solveRobustPGO (src/DPGO_solver.cpp:358) from the largest residual of the first solve;
-      * between weight updates: `inner_sweeps` coloured RBCD sweeps (robustOptInnerIters analogue);
+      * between weight updates: `inner_sweeps` coloured RBCD sweeps (robustOptInnerIters analogue) -- or, with
+        agent_params (an AgentParameters), the reference's own trigger, PGOAgent::shouldUpdateMeasurementWeights
+        (src/PGOAgent.cpp:997-1045): global iterations (= colour phases) until every agent is readyToTerminate
+        (relative change of its last update <= relChangeTol, 5 before the first weight update; converged-weight ratio
+        >= robustOptMinConvergenceRatio) or robustOptInnerIters of them have passed; info["inner_iterations"] lists
+        the count of every block;
       * stop when no weight is undecided (tolerance 1e-8, DPGO_solver.cpp:340) or after max_updates.
     Both endpoints of a shared edge compute the same residual from the same poses, hence the same weight.
     `meas` holds GLOBAL indices; its weight array is updated in place.  Returns (X, info)."""
@@ -1234,9 +1239,51 @@ def multi_agent_gnc(meas: Measurements, n: int, num_robots: int, r: int, X0, inn
     w_tol = 1e-8
     central_n = n
 
+    inner_counts = []
+    state = dict(weight_updates=0, iteration=0)
+
     def sweeps(X, k):
-        for _ in range(k):
-            X, _, _ = rbcd_coloured(meas, central_n, num_robots, r, X, 1, prm, precond, hess_recurrence)
+        if agent_params is None:
+            for _ in range(k):
+                X, _, _ = rbcd_coloured(meas, central_n, num_robots, r, X, 1, prm, precond, hess_recurrence)
+            return X
+        ap = agent_params
+        ranges, per = partition_contiguous(meas, central_n, num_robots)
+        ags = []
+        for a in range(num_robots):
+            s_, e_ = ranges[a]
+            priv = Measurements.concat([per[a]["odometry"], per[a]["private"]])
+            sh = per[a]["shared"]
+            need = sorted({(int(sh.r2[q]), int(sh.p2[q])) if sh.r1[q] == a else (int(sh.r1[q]), int(sh.p1[q]))
+                           for q in range(sh.m)})
+            lcw = np.concatenate([per[a]["private"].weight, sh.weight])
+            ags.append(dict(shared=sh, need=need, adj=sorted({rob for rob, _ in need}), lcw=lcw,
+                            prob=QuadraticProblem(construct_Q(e_ - s_, d, priv, sh, my_id=a), None, r, d, precond=precond)))
+        colour = [-1] * num_robots
+        for a in range(num_robots):
+            used = {colour[q] for q in ags[a]["adj"] if colour[q] >= 0}
+            colour[a] = min(c for c in range(num_robots + 1) if c not in used)
+        ncol = max(colour) + 1
+        team, inner, latest = {}, 0, state["iteration"]
+        while True:
+            c = state["iteration"] % ncol
+            state["iteration"] += 1
+            inner += 1
+            for a in range(num_robots):
+                if colour[a] != c:
+                    continue
+                s_, e_ = ranges[a]
+                nbr = {(rob, fr): X[ranges[rob][0] + fr] for rob, fr in ags[a]["need"]}
+                ags[a]["prob"].G = construct_G(e_ - s_, d, r, ags[a]["shared"], a, nbr)
+                opt = QuadraticOptimizer(ags[a]["prob"], prm, hess_recurrence=hess_recurrence)
+                XPrev = X[s_:e_].copy()
+                X[s_:e_] = opt.optimize(X[s_:e_])
+                team[a] = local_status(a, state["iteration"], X[s_:e_], XPrev, opt.result.success, ap,
+                                       state["weight_updates"], ags[a]["lcw"])
+            # (the cap on the NUMBER of updates is the caller's loop bound, so the count passed here is 0)
+            if should_update_weights(AgentParameters(**{**ap.__dict__, "robust": True}), 0, inner, latest, team, num_robots):
+                break
+        inner_counts.append(inner)
         return X
 
     meas.weight[:] = 1.0
@@ -1254,15 +1301,153 @@ def multi_agent_gnc(meas: Measurements, n: int, num_robots: int, r: int, X0, inn
             n_out = int((nf < w_tol).sum()); n_in = int((nf > 1 - w_tol).sum()); n_und = len(nf) - n_in - n_out
             info["history"].append(dict(mu=mu, inliers=n_in, outliers=n_out, undecided=n_und))
             info["updates"] = it + 1
+            state["weight_updates"] = it + 1
             if n_und == 0:
                 break
             mu = mu_step * mu
             X = sweeps(X, inner_sweeps)
     X = sweeps(X, inner_sweeps)
+    info["inner_iterations"] = inner_counts
     central = QuadraticProblem(construct_Q(n, d, meas), None, r, d)
     info["cost"] = 2 * central.f(X)
     info["gradnorm"] = central.rie_grad_norm(X)
     return X, info
+
+
+# --------------------------------------------------------------------------
+# Agent status, termination vote, weight-update trigger -- src/PGOAgent.cpp:399-420, 846-878, 997-1045
+# --------------------------------------------------------------------------
+
+
+@dataclass
+class AgentParameters:
+    """The fields of PGOAgentParameters these rules read, with the reference's defaults
+    (include/DPGO/PGOAgent.h:121-137)."""
+    robust: bool = False  # robustCostParams.costType != L2
+    robustOptNumWeightUpdates: int = 10
+    robustOptInnerIters: int = 30
+    robustOptMinConvergenceRatio: float = 0.8
+    maxNumIters: int = 500
+    relChangeTol: float = 5e-3
+
+
+@dataclass
+class AgentStatus:
+    """PGOAgentStatus (include/DPGO/PGOAgent.h:196-227); state: only INITIALIZED agents run the hot path."""
+    agentID: int = 0
+    state: str = "WAIT_FOR_DATA"
+    instanceNumber: int = 0
+    iterationNumber: int = 0
+    readyToTerminate: bool = False
+    relativeChange: float = 0.0
+
+
+def max_translation_distance(X, Xprev):
+    """LiftedPoseArray::maxTranslationDistance (src/manifold/Poses.cpp:86-94); tiles [n, d+1, r], the translation
+    is the last column of a pose."""
+    return float(np.sqrt(((X[:, -1, :] - Xprev[:, -1, :]) ** 2).sum(axis=1)).max())
+
+
+def local_status(agent_id: int, iteration: int, X, XPrev, success: bool, prm: AgentParameters,
+                 weight_update_count: int = 0, lc_weights=None) -> AgentStatus:
+    """The status block of PGOAgent::iterate after an optimising step (src/PGOAgent.cpp:399-420).  lc_weights: weights
+    of the agent's loop closures, private and shared (PoseGraph::statistics, src/PoseGraph.cpp:305-340: a loop closure
+    counts as converged when its weight is exactly 1 or 0; with no loop closure the ratio is 0/0 and the comparison
+    is false, as in the C++)."""
+    rel = max_translation_distance(X, XPrev)
+    ready = bool(success)
+    tol = prm.relChangeTol
+    if prm.robust and weight_update_count == 0:  # loose threshold during the initial inner iterations (:411-415)
+        tol = 5.0
+    if rel > tol:
+        ready = False
+    w = np.asarray(lc_weights if lc_weights is not None else [], dtype=np.float64)
+    if len(w) > 0:
+        ratio = float(((w == 1).sum() + (w == 0).sum()) / len(w))
+        if ratio < prm.robustOptMinConvergenceRatio:
+            ready = False
+    return AgentStatus(agent_id, "INITIALIZED", 0, iteration, ready, rel)
+
+
+def should_terminate(iteration: int, prm: AgentParameters, weight_update_count: int, team: Dict[int, AgentStatus],
+                     num_robots: int) -> bool:
+    """PGOAgent::shouldTerminate (src/PGOAgent.cpp:846-878), every robot active."""
+    if iteration >= prm.maxNumIters:
+        return True
+    if prm.robust and weight_update_count < prm.robustOptNumWeightUpdates:
+        return False
+    for rob in range(num_robots):
+        st = team.get(rob)
+        if st is None or st.state != "INITIALIZED" or not st.readyToTerminate:
+            return False
+    return True
+
+
+def should_update_weights(prm: AgentParameters, weight_update_count: int, inner_iter: int,
+                          latest_update_iteration: int, team: Dict[int, AgentStatus], num_robots: int) -> bool:
+    """PGOAgent::shouldUpdateMeasurementWeights (src/PGOAgent.cpp:997-1045)."""
+    if not prm.robust:
+        return False
+    if weight_update_count >= prm.robustOptNumWeightUpdates:
+        return False
+    if inner_iter >= prm.robustOptInnerIters:
+        return True
+    for rob in range(num_robots):
+        st = team.get(rob)
+        if st is None or st.iterationNumber < latest_update_iteration or st.state != "INITIALIZED" \
+                or not st.readyToTerminate:
+            return False
+    return True
+
+
+def rbcd_coloured_until_terminated(meas: Measurements, n: int, num_robots: int, r: int, X0,
+                                   agent_params: Optional[AgentParameters] = None,
+                                   params: Optional[ROptParameters] = None, precond: str = "jacobi",
+                                   hess_recurrence: bool = False, max_phases: int = 10000):
+    """The coloured schedule of rbcd_coloured driven by the reference's OWN stopping rule instead of a sweep count:
+    one global iteration = one colour phase (the agents of the colour call iterate(true), the others iterate(false):
+    their iteration number advances, their status does not, src/PGOAgent.cpp:376-420); after every phase the team
+    status is shared and every agent evaluates shouldTerminate (:846-878) -- all of them see the same statuses, so
+    they stop together.  Returns (X, dict(iterations, statuses, relative_changes per phase))."""
+    d = meas.d
+    ap = agent_params or AgentParameters()
+    ranges, per = partition_contiguous(meas, n, num_robots)
+    agents = []
+    for a in range(num_robots):
+        s, e = ranges[a]
+        priv = Measurements.concat([per[a]["odometry"], per[a]["private"]])
+        Qa = construct_Q(e - s, d, priv, per[a]["shared"], my_id=a)
+        sh = per[a]["shared"]
+        need = sorted({(int(sh.r2[k]), int(sh.p2[k])) if sh.r1[k] == a else (int(sh.r1[k]), int(sh.p1[k]))
+                       for k in range(sh.m)})
+        agents.append(dict(shared=sh, need=need, adj=sorted({rob for rob, _ in need}),
+                           prob=QuadraticProblem(Qa, None, r, d, precond=precond)))
+    colour = [-1] * num_robots
+    for a in range(num_robots):
+        used = {colour[q] for q in agents[a]["adj"] if colour[q] >= 0}
+        colour[a] = min(c for c in range(num_robots + 1) if c not in used)
+    ncol = max(colour) + 1
+    X = X0.copy()
+    team: Dict[int, AgentStatus] = {}
+    iteration, trace = 0, []
+    while iteration < max_phases:
+        c = iteration % ncol
+        iteration += 1
+        for a in range(num_robots):
+            if colour[a] != c:
+                continue
+            s, e = ranges[a]
+            nbr = {(rob, fr): X[ranges[rob][0] + fr] for rob, fr in agents[a]["need"]}
+            prob = agents[a]["prob"]
+            prob.G = construct_G(e - s, d, r, agents[a]["shared"], a, nbr)
+            opt = QuadraticOptimizer(prob, params or ROptParameters(), hess_recurrence=hess_recurrence)
+            XPrev = X[s:e].copy()
+            X[s:e] = opt.optimize(X[s:e])
+            team[a] = local_status(a, iteration, X[s:e], XPrev, opt.result.success, ap)
+        trace.append({a: st.relativeChange for a, st in team.items()})
+        if should_terminate(iteration, ap, 0, team, num_robots):
+            break
+    return X, dict(iterations=iteration, statuses=team, relative_changes=trace)
 
 
 # --------------------------------------------------------------------------

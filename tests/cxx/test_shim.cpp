@@ -468,6 +468,27 @@ static int run_greedy_scenario(const char* path) {
   REQUIRE(order.size() == K);
   for (unsigned k = 0; k < K; ++k) REQUIRE(order[k] == want[k]);
   REQUIRE(std::fabs(cost - want_cost) <= 1e-9 * std::fabs(want_cost));
+
+  // status and the termination vote (PGOAgent::getStatus / setNeighborStatus / shouldTerminate, src/PGOAgent.cpp:399-420,
+  // 846-878): an agent that has optimised carries its iteration number and the relative change of its last update; the
+  // vote needs every robot's status, INITIALIZED and ready
+  bool all_ready = true;
+  for (unsigned a = 0; a < robots; ++a) {
+    const PGOAgentStatus st = agents[a]->getStatus();
+    REQUIRE(st.agentID == a && st.state == PGOAgentState::INITIALIZED && st.relativeChange >= 0.0);
+    REQUIRE(st.iterationNumber <= agents[a]->iteration_number());
+    REQUIRE(st.readyToTerminate == (st.iterationNumber > 0 && st.relativeChange <= prm.relChangeTol));
+    all_ready = all_ready && st.readyToTerminate;
+  }
+  REQUIRE(!agents[0]->shouldTerminate());  // no neighbour status received yet
+  for (unsigned q = 0; q < robots; ++q)
+    for (unsigned a = 0; a < robots; ++a)
+      if (a != q) agents[q]->setNeighborStatus(agents[a]->getStatus());
+  for (unsigned q = 0; q < robots; ++q) REQUIRE(agents[q]->shouldTerminate() == all_ready);
+  const PGOAgentStatus last = agents[order.back()]->getStatus();
+  std::printf("status of robot %u: iteration %u, relative change %.3e, ready %d; team vote %d\n", order.back(),
+              last.iterationNumber, last.relativeChange, (int)last.readyToTerminate, (int)all_ready);
+  REQUIRE(last.iterationNumber == agents[order.back()]->iteration_number() && last.relativeChange > 0.0);
   return 0;
 }
 

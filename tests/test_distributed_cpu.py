@@ -13,11 +13,17 @@ import pytest
 from conftest import ROOT, to_product_measurements
 
 
-class HostAgent:
-    """CPU stand-in for DeviceAgent with the same interface (id, pack, recv_view, update, local_terms)."""
+def _status_mixin():
+    from dpgo_amd.agent import AgentStatusMixin
+    return AgentStatusMixin
+
+
+class HostAgent(_status_mixin()):
+    """CPU stand-in for DeviceAgent with the same interface (id, pack, recv_view, update, local_terms, status)."""
 
     def __init__(self, O, plan, my_id, om_local, X0_tiles, r, d):
         import torch
+        self.torch = torch
         self.O, self.plan, self.id, self.r, self.d = O, plan, my_id, r, d
         self.X = torch.tensor(np.ascontiguousarray(X0_tiles))
         self.b = d + 1
@@ -43,6 +49,10 @@ class HostAgent:
     def update(self):
         opt = self.O.QuadraticOptimizer(self._problem(), self.O.ROptParameters())
         self.X.copy_(__import__("torch").tensor(opt.optimize(self.X.numpy().copy())))
+        self.last_result = opt.result
+
+    def measure_relative_change(self, stream=None):
+        self.rel_dev[0] = self.O.max_translation_distance(self.X.numpy(), self.XPrev.numpy())
 
     def getTrajectoryInGlobalFrame(self, anchor):
         import torch
@@ -132,6 +142,96 @@ def test_two_rank_gloo_rbcd_matches_single_process_oracle(oracle, tmp_path, apr)
         assert abs(traces[0][k + 1, 0] - costs[k]) <= 1e-10 * abs(costs[k])
         assert abs(traces[0][k + 1, 1] - gns[k]) <= 1e-8 * gns[k]
     assert costs[-1] < costs[0] < 2 * central.f(X0)
+
+
+def _status_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    import dpgo_oracle as O
+    from dpgo_amd.agent import ExchangePlan, PGOAgentParameters, RBCDCluster, build_pose_graphs
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        om, n, Ttrue = O.synthetic_grid(6, 5, 4, seed=3)
+        r, d, apr = 5, 3, 2
+        X0 = O.lift(O.perturbed_truth(Ttrue, seed=4), r)
+        ranges, graphs = build_pose_graphs(to_product_measurements(om), n, world * apr, r)
+        _, per = O.partition_contiguous(om, n, world * apr)
+        plan = ExchangePlan(graphs)
+        mine = list(range(rank * apr, (rank + 1) * apr))
+        local = {a: HostAgent(O, plan, a, per[a], X0[ranges[a][0]:ranges[a][1]], r, d) for a in mine}
+        cluster = RBCDCluster(plan, local, rank, world, agents_per_rank=apr)
+        out = cluster.run_until_terminated(PGOAgentParameters(relChangeTol=2e-2, maxNumIters=60))
+        X = np.concatenate([local[a].X.numpy() for a in mine], axis=0)
+        np.savez(os.path.join(out_dir, "status%d.npz" % rank), X=X, s=ranges[mine[0]][0], e=ranges[mine[-1]][1],
+                 iterations=out["iterations"],
+                 ready=np.array([out["statuses"][a].readyToTerminate for a in range(world * apr)]),
+                 rel=np.array([out["statuses"][a].relativeChange for a in range(world * apr)]),
+                 its=np.array([out["statuses"][a].iterationNumber for a in range(world * apr)]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_gloo_termination_vote_matches_oracle(oracle, tmp_path):
+    """PGOAgent status + shouldTerminate (src/PGOAgent.cpp:399-420, 846-878) over two processes: every agent's
+    relativeChange / readyToTerminate travels to every rank (one small all-reduce per global iteration), all ranks
+    stop at the same iteration, and iteration count, statuses and iterate equal the single-process oracle driver's."""
+    import torch.multiprocessing as mp
+    O = oracle
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    mp.spawn(_status_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    om, n, Ttrue = O.synthetic_grid(6, 5, 4, seed=3)
+    X0 = O.lift(O.perturbed_truth(Ttrue, seed=4), 5)
+    Xref, info = O.rbcd_coloured_until_terminated(om, n, 4, 5, X0, O.AgentParameters(relChangeTol=2e-2, maxNumIters=60))
+    z = [np.load(os.path.join(str(tmp_path), "status%d.npz" % k)) for k in range(2)]
+    assert int(z[0]["iterations"]) == int(z[1]["iterations"]) == info["iterations"] < 60
+    X = np.zeros_like(Xref)
+    for k in range(2):
+        X[int(z[k]["s"]):int(z[k]["e"])] = z[k]["X"]
+        assert z[k]["ready"].all()
+        assert [int(v) for v in z[k]["its"]] == [info["statuses"][a].iterationNumber for a in range(4)]
+        assert np.allclose(z[k]["rel"], [info["statuses"][a].relativeChange for a in range(4)], rtol=1e-9, atol=1e-14)
+    assert np.abs(X - Xref).max() <= 1e-12
+
+
+def test_status_rules_follow_the_reference(oracle):
+    """The status / vote rules restated from src/PGOAgent.cpp:399-420, 846-878, 997-1045 on hand-made cases, oracle
+    and product (dpgo_amd.agent) side by side."""
+    from dpgo_amd import agent as A
+    O = oracle
+    X = np.zeros((3, 4, 5))
+    Xp = X.copy()
+    Xp[1, 3] = [3.0, 4.0, 0.0, 0.0, 0.0]   # translation of pose 1 moved by 5
+    Xp[2, 0] = 7.0                          # a rotation column does not count (Poses.cpp:86-94)
+    assert O.max_translation_distance(X, Xp) == 5.0
+    prm = O.AgentParameters()
+    assert O.local_status(0, 3, X, X, True, prm).readyToTerminate
+    assert not O.local_status(0, 3, X, Xp, True, prm).readyToTerminate            # 5 > 5e-3
+    assert not O.local_status(0, 3, X, X, False, prm).readyToTerminate            # failed solve
+    rob = O.AgentParameters(robust=True)
+    assert O.local_status(0, 3, X, Xp, True, rob, 0).readyToTerminate             # loose threshold 5 before update 1
+    assert not O.local_status(0, 3, X, Xp, True, rob, 1).readyToTerminate
+    assert not O.local_status(0, 3, X, X, True, rob, 1, [1, 0, 0.5, 0.5]).readyToTerminate   # ratio 0.5 < 0.8
+    assert O.local_status(0, 3, X, X, True, rob, 1, [1, 0, 1, 1, 0.5]).readyToTerminate       # ratio 0.8
+    for mod, St, Prm, term, upd in ((O, O.AgentStatus, O.AgentParameters, O.should_terminate, O.should_update_weights),
+                                    (A, A.PGOAgentStatus, A.PGOAgentParameters, A.should_terminate,
+                                     A.should_update_measurement_weights)):
+        ready = {a: St(a, "INITIALIZED", 0, 4, True, 1e-4) for a in range(3)}
+        assert term(4, Prm(), 0, ready, 3)
+        assert not term(4, Prm(), 0, {a: ready[a] for a in range(2)}, 3)           # a status is missing
+        assert term(500, Prm(), 0, {}, 3)                                          # maxNumIters
+        notyet = dict(ready)
+        notyet[1] = St(1, "INITIALIZED", 0, 4, False, 1.0)
+        assert not term(4, Prm(), 0, notyet, 3)
+        assert not term(4, Prm(robust=True), 3, ready, 3) and term(4, Prm(robust=True), 10, ready, 3)
+        assert not upd(Prm(), 0, 99, 0, ready, 3)                                  # L2: never
+        assert upd(Prm(robust=True), 0, 30, 0, {}, 3)                              # inner iterations exhausted
+        assert upd(Prm(robust=True), 0, 1, 4, ready, 3) and not upd(Prm(robust=True), 0, 1, 5, ready, 3)  # outdated
+        assert not upd(Prm(robust=True), 10, 30, 0, ready, 3) and not upd(Prm(robust=True), 0, 1, 0, notyet, 3)
 
 
 def test_exchange_plan_structure(oracle):

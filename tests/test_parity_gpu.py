@@ -1065,6 +1065,89 @@ def _inject_outliers(oracle, om, n, k, seed):
     return oracle.Measurements.concat([om, out])
 
 
+def test_agent_status_and_termination_vote_match_oracle(oracle):
+    """SURVEY 8f row 1, "status": PGOAgentStatus on the device path.  relativeChange =
+    LiftedPoseArray::maxTranslationDistance(X, XPrev) (src/manifold/Poses.cpp:86-94) from the device kernel against the
+    oracle on random iterates (3-D and 2-D; exact: a maximum, no summation order), then the coloured schedule driven by
+    PGOAgent::shouldTerminate (src/PGOAgent.cpp:846-878) on smallGrid3D / 5 agents and torus3D / 8 agents: same
+    stopping iteration, same iteration numbers and ready flags, relative changes to 1e-7, iterate to 1e-7, as the
+    oracle's driver."""
+    import torch
+    import dpgo_amd
+    from dpgo_amd import lib as L
+    from dpgo_amd.agent import (DeviceAgent, ExchangePlan, PGOAgentParameters, RBCDCluster, build_pose_graphs)
+    lib = L.load()
+    rng = np.random.default_rng(5)
+    for d, r, n in ((3, 5, 1000), (2, 3, 77), (3, 3, 1), (2, 5, 4097)):
+        A, B = rng.standard_normal((n, d + 1, r)), rng.standard_normal((n, d + 1, r))
+        B[n // 2, d] = A[n // 2, d] + 40.0 / np.sqrt(r)  # the maximum sits on one known pose
+        Ad, Bd = torch.tensor(A, device="cuda"), torch.tensor(B, device="cuda")
+        out_d = torch.zeros(1, dtype=torch.float64, device="cuda")
+        import ctypes as C
+        out_h = C.c_double(-1.0)
+        L.check(lib.dpgo_max_translation_distance_device(r, d, n, L.ptr(Ad), L.ptr(Bd), L.ptr(out_d), C.byref(out_h), None))
+        ref = oracle.max_translation_distance(A, B)
+        assert abs(ref - 40.0) < 1e-12 and abs(out_h.value - ref) <= 1e-15 * ref and float(out_d.item()) == out_h.value
+    r = 5
+    for name, robots, tol in (("smallGrid3D", 5, 5e-2), ("torus3D", 8, 1e-2)):
+        om, n = oracle.read_g2o(os.path.join(DATA, name + ".g2o"))
+        X0 = oracle.lift(oracle.chordal_initialization(om, n), r)
+        Xref, info_o = oracle.rbcd_coloured_until_terminated(
+            om, n, robots, r, X0, oracle.AgentParameters(relChangeTol=tol, maxNumIters=80),
+            hess_recurrence=device_tcg_mode(n // robots, om.d, r))
+        ranges, graphs = build_pose_graphs(to_product_measurements(om), n, robots, r)
+        plan = ExchangePlan(graphs)
+        agents = {a: DeviceAgent(graphs, plan, a, X0[ranges[a][0]:ranges[a][1]], dpgo_amd.ROptParameters(precond="jacobi"))
+                  for a in range(robots)}
+        out = RBCDCluster(plan, agents).run_until_terminated(PGOAgentParameters(relChangeTol=tol, maxNumIters=80))
+        assert out["iterations"] == info_o["iterations"] < 80, (name, out["iterations"], info_o["iterations"])
+        for a in range(robots):
+            st, so = out["statuses"][a], info_o["statuses"][a]
+            assert (st.iterationNumber, st.readyToTerminate, st.state) == (so.iterationNumber, so.readyToTerminate, so.state)
+            assert abs(st.relativeChange - so.relativeChange) <= 1e-7 * max(so.relativeChange, 1e-3)
+        X = np.concatenate([agents[a].X.cpu().numpy() for a in range(robots)], axis=0)
+        assert relerr(X, Xref) < 1e-7
+
+
+def test_distributed_gnc_with_the_reference_weight_update_trigger(oracle):
+    """DistributedGNC with agent_params: the weight updates follow PGOAgent::shouldUpdateMeasurementWeights
+    (src/PGOAgent.cpp:997-1045: every agent readyToTerminate -- relative change <= relChangeTol, 5 before the first
+    update; converged-weight ratio >= robustOptMinConvergenceRatio -- or robustOptInnerIters global iterations), not
+    a fixed sweep count.  smallGrid3D + 10 outliers, 3 agents: same number of global iterations in every block, same
+    classification history, every outlier rejected, as the oracle's driver with the same trigger."""
+    import dpgo_amd
+    from dpgo_amd.agent import DeviceAgent, ExchangePlan, PGOAgentParameters, RBCDCluster, build_pose_graphs
+    from dpgo_amd.robust import DistributedGNC, RobustCostParameters
+    r, robots, k = 5, 3, 10
+    om, n = oracle.read_g2o(os.path.join(DATA, "smallGrid3D.g2o"))
+    d = om.d
+    allm = _inject_outliers(oracle, om, n, k, seed=7)
+    X0 = oracle.lift(oracle.chordal_initialization(om, n), r)
+    ref_meas = _inject_outliers(oracle, om, n, k, seed=7)
+    ap = dict(relChangeTol=2e-2, robustOptInnerIters=12, robustOptMinConvergenceRatio=0.8)
+    Xref, info_o = oracle.multi_agent_gnc(ref_meas, n, robots, r, X0, barc=5.0, mu_step=1.4, max_updates=40,
+                                          hess_recurrence=device_tcg_mode(n // robots, d, r),
+                                          agent_params=oracle.AgentParameters(robust=True, **ap))
+    assert info_o["history"][-1]["undecided"] == 0
+    assert min(info_o["inner_iterations"]) < 12 <= max(info_o["inner_iterations"])  # both clauses of the trigger fire
+    ranges, graphs = build_pose_graphs(to_product_measurements(allm), n, robots, r)
+    plan = ExchangePlan(graphs)
+    agents = {a: DeviceAgent(graphs, plan, a, X0[ranges[a][0]:ranges[a][1]], dpgo_amd.ROptParameters(precond="jacobi"))
+              for a in range(robots)}
+    gnc = DistributedGNC(RBCDCluster(plan, agents),
+                         RobustCostParameters("GNC_TLS", GNCMaxNumIters=40, GNCBarc=5.0, GNCMuStep=1.4),
+                         agent_params=PGOAgentParameters(robust=True, **ap))
+    info = gnc.run()
+    assert info["inner_iterations"] == info_o["inner_iterations"], (info["inner_iterations"], info_o["inner_iterations"])
+    assert info["updates"] == info_o["updates"]
+    for h, ho in zip(info["history"], info_o["history"]):
+        assert (h["inliers"], h["outliers"], h["undecided"]) == (ho["inliers"], ho["outliers"], ho["undecided"])
+    assert abs(info["cost"] - info_o["cost"]) <= 1e-6 * info_o["cost"]
+    X = np.concatenate([agents[a].X.cpu().numpy() for a in range(robots)], axis=0)
+    assert relerr(X, Xref) < 1e-6
+    assert np.all(ref_meas.weight[-k:] < 1e-8) and np.all(ref_meas.weight[:om.m] > 1 - 1e-8)
+
+
 def test_distributed_gnc_matches_oracle(oracle):
     """BASELINE configs[4] (multi-agent GNC): smallGrid3D + 10 injected outlier loop closures, 3 agents on one
     GPU.  Private AND shared loop closures are re-weighted on the device (shared ones read the neighbour tile
