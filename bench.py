@@ -54,7 +54,7 @@ def parse_args():
                     help="untimed RBCD iterations from the initial guess before the benchmark state is frozen")
     ap.add_argument("--workload", default="grid100k")
     ap.add_argument("--rank", type=int, default=5, help="relaxation rank r")
-    ap.add_argument("--precond", default="auto", choices=["auto", "jacobi", "multilevel"],
+    ap.add_argument("--precond", default="auto", choices=["auto", "jacobi", "multilevel", "additive"],
                     help="tCG preconditioner: auto (library default: multilevel when the tCG budget binds, block-Jacobi "
                          "while it does not), or one of the two all the time")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -336,7 +336,7 @@ def time_to_tolerance(workload, r, precond, tol=1e-2, max_calls=12, coarse_bits=
     ag.update()  # untimed warm-up
     if coarse_bits is not None:
         ag.problem.multilevelCoarseBits(coarse_bits)
-    if precond != "jacobi":
+    if precond == "multilevel":
         ag.problem.setupMultilevel()  # the hierarchy is a one-time cost per Q (the reference factors inside its first solve)
     ag.problem.autoState("reset")     # "auto" starts where a fresh handle starts
     ag.X.copy_(torch.tensor(X0, device=ag.X.device))
@@ -699,10 +699,10 @@ def main():
         # sphere2500 (BASELINE configs[1]); then the fixed-work step rate of sphere2500
         to_tol = {}
         for wl in ([args.workload] + (["sphere2500"] if args.workload == "grid100k" else [])):
-            for pc in ("auto", "multilevel", "jacobi"):
+            for pc in ("auto", "multilevel", "additive", "jacobi"):
                 try:  # a side measurement must never cost the main line
                     to_tol["%s/%s" % (wl, pc)] = time_to_tolerance(wl, r, pc)
-                except Exception as exc:  # noqa: BLE001
+                except Exception as exc:  # noqa: BLE001  ("additive" refuses blocks beyond 256 aggregates)
                     to_tol["%s/%s" % (wl, pc)] = {"error": repr(exc)}
             try:  # opt-in storage mode (NOT the headline configuration): dense level of the hierarchy kept in fp32
                 to_tol["%s/multilevel+fp32_dense_level" % wl] = time_to_tolerance(wl, r, "multilevel", coarse_bits=32)
@@ -710,7 +710,8 @@ def main():
                 to_tol["%s/multilevel+fp32_dense_level" % wl] = {"error": repr(exc)}
         if args.workload == "grid100k":
             also = {}
-            for key, pc in (("sphere2500", "auto"), ("sphere2500_multilevel", "multilevel"), ("sphere2500_jacobi", "jacobi")):
+            for key, pc in (("sphere2500", "auto"), ("sphere2500_multilevel", "multilevel"), ("sphere2500_jacobi", "jacobi"),
+                            ("sphere2500_additive", "additive")):
                 try:
                     also[key] = secondary_single_agent("sphere2500", r, pc, args.steps, args.warmup, args.settle)
                 except Exception as exc:  # noqa: BLE001
@@ -747,8 +748,9 @@ def main():
             "data": "synthetic" if args.workload.startswith("grid") else "g2o dataset shipped in data/",
             "config": {"workload": desc, "agents": num_agents, "agents_per_gpu": apg, "r": r, "d": d,
                        "local_solver": "RTR 3x<=50 tCG, Delta0=100, tol=1e-2 (reference defaults), precond = %s" % (
-                           {"jacobi": "block-Jacobi", "multilevel": "multilevel",
-                            "auto": "auto (library default: multilevel when the tCG budget binds, else block-Jacobi)"}[
+                           {"jacobi": "block-Jacobi", "multilevel": "multilevel", "additive": "additive two-level",
+                            "auto": "auto (library default: a multilevel preconditioner when the tCG budget binds, else "
+                                    "block-Jacobi)"}[
                                args.precond]),
                        "precond_used_in_timed_steps": sorted(used_precond),
                        "same_colour_agents": "sequential (diagnostic)" if args.sequential else "concurrent",

@@ -136,6 +136,7 @@ struct dpgo_problem_s {
   std::vector<MlLevel> ml;
   std::vector<int32_t> h_rowptr, h_colidx;  // host copy of Q's block pattern (symbolic setup of the hierarchy)
   bool ml_symbolic = false, ml_ready = false, ml_user_ks = false;
+  bool ml_additive_layout = false;  // the hierarchy is the one the additive preconditioner needs (one aggregate per 4-lane-group tile)
   double ml_omega = 0.7, ml_shift = 1e-1;
   double* ml_dense = nullptr;  // inverse of the coarsest operator, row-major, leading dimension ml_lda
   float* ml_dense32 = nullptr;  // its fp32 storage (what the cycle streams when ml_coarse_bits == 32)
@@ -207,6 +208,7 @@ struct dpgo_problem_s {
   int persist_wgs = 0, persist_split = 0, persist_mt = 0;  // geometry of the current / last launch
   int persist_reserved = 0;  // resident-slot reservation held by the running solve
   bool persist_failed_once = false;
+  bool persist_add = false;  // the reservation is for the additive-preconditioner variant
   PersistCtrl* pctrl = nullptr;
   unsigned long long* pgran = nullptr;  // granule table of the in-kernel all-reduce (kGranWords 8-byte words)
   PersistCtrl* hctrl = nullptr;  // pinned
@@ -599,12 +601,15 @@ int launch_rtr_begin(dpgo_problem_s* p, double tol, double Delta0, double Dmax, 
 
 struct Counters {
   int spmm = 0;
+  bool vcycle_for_additive = false;  // an outer iteration of an "additive" solve ran the V-cycle instead
 };
 
 // ---------------------------------------------------------------------------------------------------------
 // Multilevel preconditioner: hierarchy setup (symbolic on the host once per block pattern, numeric on the device
 // for every new set of Q values) and the per-iteration launches.  DESIGN.md section 5.
 int ml_tile(int b, int split) { return (64 / (b * split)) * kWaves; }
+// tiles of the additive preconditioner's layout (4 lane groups per pose, one tile = one aggregate per workgroup)
+int additive_tile(const dpgo_problem_s* p) { return ml_tile(p->b, 4); }
 int ml_level_split(int n) { return n < 40000 ? 4 : 1; }
 
 // Aggregate sizes per coarsening.  Every k must divide the workgroup tile of its level (fused restriction); the
@@ -637,6 +642,7 @@ std::vector<int> ml_default_ks(int n, int b, int split0) {
 }
 
 void ml_free(dpgo_problem_s* p) {
+  p->ml_additive_layout = false;
   for (auto& L : p->ml) {
     free_bsr(L.A);
     free_bsr(L.AP);
@@ -845,7 +851,21 @@ int ml_numeric_setup(dpgo_problem_s* p) {
 
 // Make the hierarchy match the handle's Q (lazily, like the reference's constructPreconditioner inside the first
 // PreConditioner call, src/PoseGraph.cpp:582-586).
-int ml_ensure(dpgo_problem_s* p, double shift) {
+int ml_ensure(dpgo_problem_s* p, double shift, bool additive = false) {
+  // the additive preconditioner needs ONE aggregate per tile of its persistent layout (two levels); a hierarchy the
+  // caller set up explicitly is kept if it has that shape, the default one is replaced (and put back when the V-cycle
+  // is asked for again)
+  const int Pa = additive_tile(p);
+  const bool shape_ok = p->ml_symbolic && p->ml.size() == 2 && p->ml[0].k == Pa && p->split == 4;
+  if (additive && !shape_ok) {
+    if (p->split != 4) return fail(DPGO_ERR_UNSUPPORTED, "additive preconditioner: small-block layout only");
+    CHK(ml_symbolic_setup(p, std::vector<int>{Pa}));
+    p->ml_additive_layout = true;
+    p->ml_user_ks = false;
+  } else if (!additive && p->ml_additive_layout && !p->ml_user_ks) {
+    CHK(ml_symbolic_setup(p, ml_default_ks(p->n, p->b, p->split)));
+    p->ml_additive_layout = false;
+  }
   // level 0 smooths with the handle's shared block-Jacobi factors: a block-Jacobi solve with another shift in between
   // has overwritten them, so they are re-derived for THIS shift even when the hierarchy itself is current (no-op otherwise)
   if (p->ml_ready && p->ml_shift == shift) return build_dinv(p, shift);
@@ -1051,7 +1071,18 @@ struct PersistGeo {
 // `free_slots`: what may be reserved now.  Alone on the device: the lowest-latency layout that fits (4 lane groups per pose
 // while the tiles fit, then one pose per (d+1) lanes).  Sharing the device with other concurrently solved agents
 // (share > 1): the layout with the fewest slots, so that as many agents as possible run the kernel at once.
-PersistGeo persist_geometry(const dpgo_problem_s* p, int free_slots, int share = 1) {
+bool additive_available(const dpgo_problem_s* p) {
+  const int P = additive_tile(p);
+  return p->persist && !p->persist_failed_once && (p->n + P - 1) / P <= kPersistMax;
+}
+PersistGeo persist_geometry(const dpgo_problem_s* p, int free_slots, int share = 1, bool additive = false) {
+  if (additive) {  // fixed layout; one workgroup per CU (the rows of the coarse inverse live in its LDS)
+    const int P = additive_tile(p);
+    PersistGeo g{4, 1, (p->n + P - 1) / P, 0};
+    g.slots = g.wgs * persist_slots_per_wg(4, 1, true);
+    if (g.wgs > kPersistMax || g.slots > free_slots) return PersistGeo();
+    return g;
+  }
   static const int env_split = [] { const char* e = std::getenv("DPGO_PERSIST_SPLIT"); return e ? std::atoi(e) : 0; }();
   static const int env_mt = [] { const char* e = std::getenv("DPGO_PERSIST_MT"); return e ? std::atoi(e) : 0; }();
   const int cand[4][2] = {{4, 1}, {4, 2}, {1, 1}, {1, 2}};
@@ -1072,8 +1103,9 @@ PersistGeo persist_geometry(const dpgo_problem_s* p, int free_slots, int share =
 
 // Enqueues the persistent tCG launch of one outer iteration (no host wait).  *used = false: not launched (no geometry /
 // no free slots) -- the caller runs the two-kernel scheme.
-int launch_tcg_persistent(dpgo_problem_s* p, const double* dinv, bool* used) {
+int launch_tcg_persistent(dpgo_problem_s* p, const double* dinv, bool* used, bool additive = false) {
   *used = false;
+  if (additive && p->persist_reserved > 0 && !(p->persist_split == 4 && p->persist_mt == 1 && p->persist_add)) return DPGO_OK;
   if (p->persist_reserved == 0) {
     // Alone on the device: what is free now, first come first served.  Sharing it with other concurrently solved agents:
     // the most compact layout, at most 4/5 of the slots in use at once (a CU that holds a persistent workgroup has no
@@ -1084,11 +1116,11 @@ int launch_tcg_persistent(dpgo_problem_s* p, const double* dinv, bool* used) {
     auto& used = g_persist_used[p->device % kMaxDevices];
     PersistGeo g;
     if (p->persist_share <= 1) {
-      g = persist_geometry(p, cap - used.load(), 1);
+      g = persist_geometry(p, cap - used.load(), 1, additive);
       if (g.wgs <= 0 || !persist_reserve(p, g.slots, cap)) return DPGO_OK;
     } else {
       const int limit = cap - cap / 5;
-      g = persist_geometry(p, limit, p->persist_share);
+      g = persist_geometry(p, limit, p->persist_share, additive);
       if (g.wgs <= 0) return DPGO_OK;
       const auto t0 = std::chrono::steady_clock::now();
       while (!persist_reserve(p, g.slots, limit)) {
@@ -1099,6 +1131,7 @@ int launch_tcg_persistent(dpgo_problem_s* p, const double* dinv, bool* used) {
     p->persist_split = g.split;
     p->persist_mt = g.mt;
     p->persist_wgs = g.wgs;
+    p->persist_add = additive;
     // once per solve: the error word is sticky (a launch behind a timed-out one sees it and leaves at once), the
     // diagnostics accumulate, and the granules' epochs are salted per launch (cleared here against wrap-around)
     HIPC(hipMemsetAsync(p->pctrl, 0, sizeof(PersistCtrl), p->stream));
@@ -1114,12 +1147,24 @@ int launch_tcg_persistent(dpgo_problem_s* p, const double* dinv, bool* used) {
   const int between = env_sleep >= 0 ? std::min(255, env_sleep) : kPollSleep;
   const int poll = (first << 8) | between;
 
+  AddDev add{};
+  size_t lds = 0;
+  if (additive) {
+    auto& L0 = p->ml[0];
+    auto& C = p->ml[1];
+    add = AddDev{L0.Pb, p->ml_dense, p->ml_lda, C.n, C.r, 1.0};
+    lds = sizeof(double) * (size_t)p->b * C.n * p->b;  // (d+1) rows of the inverse
+  }
 #define PERSIST_LAUNCH(SP, MT_)                                                                                       \
   hipLaunchKernelGGL((k_tcg_persist<D, R, SP, MT_>), dim3(p->persist_wgs), dim3(kBlock), 0, p->stream, p->Q.dev(),    \
                      p->x1, p->S1, p->g1, dinv, p->eta, p->z, p->pgran, salt, p->dstate + p->cur,                     \
-                     p->dstate + (p->cur ^ 1), p->pctrl, p->n, p->hflag, p->gen, poll)
+                     p->dstate + (p->cur ^ 1), p->pctrl, p->n, p->hflag, p->gen, poll, add)
   DISPATCH(p->d, p->r, {
-    if (p->persist_split == 4 && p->persist_mt == 1) PERSIST_LAUNCH(4, 1);
+    if (additive)
+      hipLaunchKernelGGL((k_tcg_persist<D, R, 4, 1, true>), dim3(p->persist_wgs), dim3(kBlock), lds, p->stream,
+                         p->Q.dev(), p->x1, p->S1, p->g1, dinv, p->eta, p->z, p->pgran, salt, p->dstate + p->cur,
+                         p->dstate + (p->cur ^ 1), p->pctrl, p->n, p->hflag, p->gen, poll, add);
+    else if (p->persist_split == 4 && p->persist_mt == 1) PERSIST_LAUNCH(4, 1);
     else if (p->persist_split == 4) PERSIST_LAUNCH(4, 2);
     else if (p->persist_mt == 1) PERSIST_LAUNCH(1, 1);
     else PERSIST_LAUNCH(1, 2);
@@ -1150,11 +1195,15 @@ void persist_report(dpgo_problem_s* p) {
 int rtr_outer_iteration(dpgo_problem_s* p, const dpgo_ropt_params* prm, const double* dinv, Counters& cnt,
                         bool poll_at_end) {
   p->gen += 1;
-  const bool ml = prm->precond == DPGO_PRECOND_MULTILEVEL;
+  const bool add = prm->precond == DPGO_PRECOND_ADDITIVE;
+  // (additive: where the persistent kernel cannot run -- no free slots, an earlier time-out -- the V-cycle on the same
+  // two-level hierarchy takes over)
+  const bool ml = prm->precond == DPGO_PRECOND_MULTILEVEL || add;
   p->zr_from_post = ml;
-  if (p->persist && !ml && !p->persist_failed_once) {
+  if (p->persist && (!ml || add) && !p->persist_failed_once) {
     bool used = false;
-    CHK(launch_tcg_persistent(p, dinv, &used));
+    CHK(launch_tcg_persistent(p, dinv, &used, add));
+    if (add && !used) cnt.vcycle_for_additive = true;
     if (used) {  // the whole outer iteration is enqueued without a host wait; a stop test met earlier makes these exit
       CHK(launch_retract(p, p->x1, p->eta, 1.0, p->x2, p->dstate + p->cur));
       CHK(launch_grad(p, p->x2, p->g2, p->S2, nullptr, p->dstate + p->cur));
@@ -1272,8 +1321,10 @@ int run_optimize(dpgo_problem_s* p, const dpgo_ropt_params* prm, dpgo_ropt_resul
   };
   dpgo_ropt_params resolved = *prm;  // DPGO_PRECOND_AUTO -> what this handle currently runs
   if (prm->precond == DPGO_PRECOND_AUTO) p->auto_decide();
-  if (prm->precond == DPGO_PRECOND_AUTO)
-    resolved.precond = (p->auto_ml && prm->method == DPGO_METHOD_RTR) ? DPGO_PRECOND_MULTILEVEL : DPGO_PRECOND_BLOCK_JACOBI;
+  if (prm->precond == DPGO_PRECOND_AUTO)  // (the multilevel choice: the additive form wherever its persistent kernel runs)
+    resolved.precond = (p->auto_ml && prm->method == DPGO_METHOD_RTR)
+                           ? ((additive_available(p) && !p->ml_user_ks) ? DPGO_PRECOND_ADDITIVE : DPGO_PRECOND_MULTILEVEL)
+                           : DPGO_PRECOND_BLOCK_JACOBI;
   const bool is_auto = prm->precond == DPGO_PRECOND_AUTO;
   prm = &resolved;
   const double* dinv = nullptr;
@@ -1284,6 +1335,13 @@ int run_optimize(dpgo_problem_s* p, const dpgo_ropt_params* prm, dpgo_ropt_resul
     // built lazily for the current Q, like the reference's factor (src/PoseGraph.cpp:582-586)
     CHK(ml_ensure(p, prm->precond_shift));
     dinv = p->dinv;  // the smoother's block-Jacobi factors (same shift)
+  } else if (prm->precond == DPGO_PRECOND_ADDITIVE) {
+    if (prm->method != DPGO_METHOD_RTR) return fail(DPGO_ERR_UNSUPPORTED, "the additive preconditioner exists inside the tCG loop only");
+    const int P = additive_tile(p);
+    if ((p->n + P - 1) / P > kPersistMax)
+      return fail(DPGO_ERR_UNSUPPORTED, "additive preconditioner: block too large (at most 256 aggregates of " + std::to_string(P) + " poses)");
+    CHK(ml_ensure(p, prm->precond_shift, /*additive=*/true));
+    dinv = p->dinv;
   } else if (prm->precond != DPGO_PRECOND_NONE) {
     return fail(DPGO_ERR_INVALID, "unknown preconditioner");
   }
@@ -1385,7 +1443,7 @@ int run_optimize(dpgo_problem_s* p, const dpgo_ropt_params* prm, dpgo_ropt_resul
     return fail(DPGO_ERR_INVALID, "unknown method");
   }
   res->tcg_iterations = n_hess_total;
-  res->precond_used = prm->precond;
+  res->precond_used = (prm->precond == DPGO_PRECOND_ADDITIVE && cnt.vcycle_for_additive) ? DPGO_PRECOND_MULTILEVEL : prm->precond;
   if (is_auto && prm->method == DPGO_METHOD_RTR) {  // hysteresis on how much of the tCG budget the solve used
     const int budget = std::max(1, prm->RTR_iterations) * std::max(1, prm->RTR_tCG_iterations);
     // (a block without coupling never hands back: its cheap early calls end on the trust-region boundary after a few
@@ -1992,6 +2050,7 @@ int dpgo_problem_setup_multilevel(dpgo_problem_t p, int nks, const int* ks, doub
   for (size_t l = 0; same && l < v.size(); ++l) same = p->ml[l].k == v[l];
   if (!same) CHK(ml_symbolic_setup(p, v));
   p->ml_user_ks = nks > 0;
+  p->ml_additive_layout = false;
   p->ml_omega = omega;
   p->ml_shift = shift;
   CHK(ml_numeric_setup(p));
@@ -2234,6 +2293,8 @@ int dpgo_problem_precondition(dpgo_problem_t p, int precond, double shift, const
     CHK(ml_ensure(p, shift));
     CHK(launch_ml_apply(p, p->x2, p->eta, p->g2));
     return d2h(p, Z, p->g2);
+  } else if (precond == DPGO_PRECOND_ADDITIVE) {
+    return fail(DPGO_ERR_UNSUPPORTED, "the additive preconditioner exists inside the persistent tCG kernel only");
   } else if (precond != DPGO_PRECOND_NONE) {
     return fail(DPGO_ERR_INVALID, "unknown preconditioner");
   }

@@ -274,23 +274,45 @@ __device__ __forceinline__ void gather_finish(const GatherOps<D, R, SPLIT, QRES>
 // MT = tiles (of Geo::P poses) a workgroup owns: tile = rank + k * members, k < MT.  Resident slots (the host reserves
 // against 2 per CU): the (SPLIT = 4, MT = 1) variant fits two workgroups per CU (<= 256 registers) and costs one slot per
 // workgroup; the others keep up to 512 registers per lane (one workgroup per CU) and cost two.
-constexpr int persist_slots_per_wg(int split, int mt) { return (split == 4 && mt == 1) ? 1 : 2; }
-template <int D, int R, int SPLIT, int MT>
-__global__ __launch_bounds__(kBlock, 3 - persist_slots_per_wg(SPLIT, MT)) void k_tcg_persist(BsrDev Q, const double* __restrict__ X,
+constexpr int persist_slots_per_wg(int split, int mt, bool add = false) { return (split == 4 && mt == 1 && !add) ? 1 : 2; }
+
+// ADD: the preconditioner is the ADDITIVE two-level combination  z = proj_X( w Dinv r + P A_c^-1 P^T r )  on the handle's
+// two-level hierarchy with ONE aggregate per workgroup tile (k = Geo::P): block-Jacobi plus the coarse-grid correction of
+// the residual itself, so nothing inside the preconditioner applies an operator to a vector other workgroups hold -- the
+// only exchange is the restricted residual rc (n / P coarse nodes x (D+1) R doubles: an all-gather every workgroup reads
+// in full), and it rides on a reduction the iteration needs anyway.  Per iteration: phase A | all-reduce <delta, H delta> |
+// r, eta update, x1 = Dinv r, rc = P^T r | all-reduce <r, r> (rc visible) | xc = (own rows of A_c^-1, resident in LDS) rc,
+// z = proj_X(w x1 + P xc) | all-reduce <z, r> (z visible): three reductions instead of the V-cycle's five launches
+// (DESIGN.md section 5).  The oracle restates the operator (precond = "amg_additive").
+struct AddDev {
+  const double* Pb;    // prolongation blocks of level 0, [n][D+1][D+1] row-major
+  const double* Minv;  // dense inverse of the coarse operator, row-major, leading dimension lda
+  int lda, nc;         // nc coarse nodes = pose tiles
+  double* rc;          // [nc][D+1][R] restricted residual (written and gathered inside the launch)
+  double w;            // weight of the block-Jacobi term
+};
+
+template <int D, int R, int SPLIT, int MT, bool ADD = false>
+__global__ __launch_bounds__(kBlock, 3 - persist_slots_per_wg(SPLIT, MT, ADD)) void k_tcg_persist(BsrDev Q, const double* __restrict__ X,
                                                         const double* __restrict__ S, const double* __restrict__ g,
                                                         const double* __restrict__ dinv, double* __restrict__ eta, double* z,
                                                         unsigned long long* gran, unsigned salt,
                                                         const DevState* __restrict__ sin, DevState* __restrict__ sout,
                                                         PersistCtrl* ctrl, int n, unsigned long long* hflag, unsigned gen,
-                                                        int poll) {
+                                                        int poll, AddDev add) {
   using GEO = Geo<D, R, SPLIT>;
   constexpr int P = GEO::P, G = GEO::G, T = GEO::T, B = GEO::B, BB = GEO::BB;
+  static_assert(!ADD || MT == 1, "additive preconditioner: one aggregate = one tile per workgroup");
   // resident in LDS: the poses' X (projections need all rotation columns of a pose) and z (Hessian correction);
   // ex: two wave-private exchange tiles (the columns of one pose meet here)
   __shared__ __attribute__((aligned(16))) double Xs[MT][P][T], Zs[MT][P][T];
   __shared__ __attribute__((aligned(16))) double ex[2][kWaves][G][T];
   __shared__ double red[2 * 2 * kWaves * kGranVals];
   __shared__ int ok_s;
+  // additive preconditioner: P_i^T r_i of the tile's poses, the aggregate's coarse solution, its per-wave partial sums;
+  // dynamic LDS: the (D+1) rows of A_c^-1 this workgroup's aggregate needs, (D+1) x N_c doubles
+  __shared__ double ts[ADD ? P : 1][ADD ? T : 1], xc_s[ADD ? T : 1], xw_s[ADD ? kWaves : 1][ADD ? T : 1];
+  extern __shared__ double Ms[];
 
   const int rank = blockIdx.x, members = gridDim.x;
   if (threadIdx.x == 0) ok_s = 1;  // (ordered before its first use by the barriers of the first all-reduce)
@@ -362,6 +384,23 @@ __global__ __launch_bounds__(kBlock, 3 - persist_slots_per_wg(SPLIT, MT)) void k
     }
   }
   wave_sync();
+  [[maybe_unused]] double pcol[B], prow[B];  // column c / row c of the pose's prolongation block
+  [[maybe_unused]] const int Nc = add.nc * B;
+  [[maybe_unused]] const __amdgpu_buffer_rsrc_t rrc = vec_rsrc(add.rc, (size_t)(ADD ? add.nc : 0) * T * sizeof(double));
+  if constexpr (ADD) {
+#pragma unroll
+    for (int cc = 0; cc < B; ++cc) {
+      pcol[cc] = own[0] ? add.Pb[(size_t)pose[0] * BB + cc * B + L.c] : 0.0;
+      prow[cc] = own[0] ? add.Pb[(size_t)pose[0] * BB + L.c * B + cc] : 0.0;
+    }
+    if (rank < ntiles) {
+      for (int e = threadIdx.x; e < B * Nc; e += kBlock) {
+        const int row = e / Nc, j = e - row * Nc;
+        Ms[e] = add.Minv[(size_t)(rank * B + row) * add.lda + j];
+      }
+    }
+    __syncthreads();
+  }
 
   // ---- phase B: (first) r = g, eta = 0 | eta += alpha delta, r += alpha H delta;  z = proj_X(r Dinv);  partials
   auto phase_update = [&](bool first, double alpha, double (&part)[2]) {
@@ -431,6 +470,128 @@ __global__ __launch_bounds__(kBlock, 3 - persist_slots_per_wg(SPLIT, MT)) void k
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this thread's z stores have been acknowledged
   };
 
+  // ---- additive preconditioner, first half: r, eta update; x1 = Dinv r (kept in zc); rc = sum over the tile of P_i^T r_i
+  auto phase_add_restrict = [&](bool first, double alpha, double (&part)[1]) {
+    part[0] = 0.0;
+    if constexpr (ADD) {
+      if (own[0]) {
+#pragma unroll
+        for (int a = 0; a < R; ++a) {
+          if (!first) {
+            ee[0][a] = fma(alpha, dl[0][a], ee[0][a]);
+            rr[0][a] = fma(alpha, hd[0][a], rr[0][a]);
+          }
+          part[0] = fma(rr[0][a], rr[0][a], part[0]);
+        }
+        store_col<R>(&ex[0][L.wave][L.g][co], rr[0]);
+      }
+      wave_sync();  // the pose's B columns of r are in LDS
+      if (L.s == 0 && L.g < G) {
+        double t[R];
+#pragma unroll
+        for (int a = 0; a < R; ++a) t[a] = 0.0;
+        if (own[0]) {
+          jacobi_col<D, R>(&ex[0][L.wave][L.g][0], drow[0], zc[0]);  // x1 (unweighted), until z replaces it
+#pragma unroll
+          for (int cc = 0; cc < B; ++cc) {  // row c of P_i^T r_i = sum_c' P_i[c'][c] r_i[c'][:]
+#pragma unroll
+            for (int a = 0; a < R; ++a) t[a] = fma(pcol[cc], ex[0][L.wave][L.g][cc * R + a], t[a]);
+          }
+        }
+        store_col<R>(&ts[lp][co], t);  // zeros for pose slots beyond n
+      }
+      __syncthreads();
+      if ((int)threadIdx.x < T && rank < ntiles) {  // fixed order over the tile's poses; the all-gathered coarse residual
+        double sum = ts[0][threadIdx.x];
+#pragma unroll
+        for (int m = 1; m < P; ++m) sum += ts[m][threadIdx.x];
+        st_agent(add.rc + (size_t)rank * T + threadIdx.x, sum);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // acknowledged before the reduction publishes
+    }
+  };
+  // ---- second half: xc = (own rows of A_c^-1) rc, z = proj_X(w x1 + P_i xc), <z, r>
+  auto phase_add_correct = [&](double (&part)[1]) {
+    part[0] = 0.0;
+    if constexpr (ADD) {
+      double acc[B][R];
+#pragma unroll
+      for (int row = 0; row < B; ++row)
+#pragma unroll
+        for (int a = 0; a < R; ++a) acc[row][a] = 0.0;
+      for (int j = threadIdx.x; j < Nc; j += kBlock) {  // a coarse unknown's R right-hand sides: one thread each
+        double rj[R];
+        ld_col_agent<R>(rrc, j * R * 8, rj);
+#pragma unroll
+        for (int row = 0; row < B; ++row) {
+          const double m = Ms[row * Nc + j];
+#pragma unroll
+          for (int a = 0; a < R; ++a) acc[row][a] = fma(m, rj[a], acc[row][a]);
+        }
+      }
+#pragma unroll
+      for (int row = 0; row < B; ++row)
+#pragma unroll
+        for (int a = 0; a < R; ++a) {
+          const double v = wave_reduce_lane63(acc[row][a]);
+          if ((threadIdx.x & 63) == 63) xw_s[threadIdx.x >> 6][row * R + a] = v;
+        }
+      __syncthreads();
+      if ((int)threadIdx.x < T) {
+        double sum = xw_s[0][threadIdx.x];
+#pragma unroll
+        for (int w = 1; w < kWaves; ++w) sum += xw_s[w][threadIdx.x];
+        xc_s[threadIdx.x] = sum;
+      }
+      __syncthreads();
+      double xx[R];
+      if (own[0]) {
+#pragma unroll
+        for (int a = 0; a < R; ++a) {
+          double v = add.w * zc[0][a];
+#pragma unroll
+          for (int cc = 0; cc < B; ++cc) v = fma(prow[cc], xc_s[cc * R + a], v);
+          xx[a] = v;
+        }
+        store_col<R>(&ex[1][L.wave][L.g][co], xx);
+      }
+      wave_sync();
+      if (own[0]) {
+        double out[R], s[D];
+        proj_col<D, R>(&Xs[0][lp][0], &ex[1][L.wave][L.g][0], L.c, xx, out, s);
+        const size_t off = (size_t)pose[0] * T + co;
+#pragma unroll
+        for (int a = 0; a < R; ++a) {
+          part[0] = fma(out[a], rr[0][a], part[0]);
+          zc[0][a] = out[a];
+          Zs[0][lp][co + a] = out[a];
+          if constexpr (T % 2 != 0) st_agent(z + off + a, out[a]);
+        }
+      }
+      if constexpr (T % 2 == 0) {
+        wave_sync();
+        const int p0w = rank * P + L.wave * G;
+        const int npose = (n - p0w) < G ? (n - p0w) : G;
+        const int pieces = npose > 0 ? npose * (T / 2) : 0;
+        const dbl2* span = reinterpret_cast<const dbl2*>(&Zs[0][L.wave * G][0]);
+#pragma unroll
+        for (int it = 0; it < (G * (T / 2) + 63) / 64; ++it) {
+          const int pc = (int)(threadIdx.x & 63) + 64 * it;
+          if (pc < pieces) {
+            const dbl2 v = span[pc];
+            u32x4 w;
+            w.x = (unsigned)__double2loint(v.x);
+            w.y = (unsigned)__double2hiint(v.x);
+            w.z = (unsigned)__double2loint(v.y);
+            w.w = (unsigned)__double2hiint(v.y);
+            __builtin_amdgcn_raw_buffer_store_b128(w, rz, (p0w * T + 2 * pc) * 8, 0, kAuxSc1);
+          }
+        }
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+  };
+
   // ---- phase A: Hz on the own rows (one hop: Q blocks + gathered z tiles of ALL owned tiles are requested before the
   // first epilogue), direction recurrences, <delta, H delta>
   auto phase_hess = [&](bool first, double beta, double (&part)[1]) {
@@ -489,8 +650,27 @@ __global__ __launch_bounds__(kBlock, 3 - persist_slots_per_wg(SPLIT, MT)) void k
   st.e_Pd = 0.0;
   bool alive = true;
   double pr[2];
-  phase_update(true, 0.0, pr);
-  alive = chip_allreduce<2>(gran, rank, members, salt, step, pr, red, &ctrl->error, &ok_s, poll);
+  // residual update + preconditioner + the reduction(s) that carry <r,r>, <z,r>: one all-reduce with block-Jacobi / no
+  // preconditioner, two (the restricted residual becomes visible with the first) with the additive two-level one
+  unsigned long long tmid = 0;  // diagnostic: end of the update phase proper
+  auto update_and_reduce = [&](bool first, double alpha) -> bool {
+    if constexpr (ADD) {
+      double p1[1], p2[1];
+      phase_add_restrict(first, alpha, p1);
+      tmid = wall_clock64();
+      if (!chip_allreduce<1>(gran, rank, members, salt, step, p1, red, &ctrl->error, &ok_s, poll)) return false;
+      phase_add_correct(p2);
+      if (!chip_allreduce<1>(gran, rank, members, salt, step, p2, red, &ctrl->error, &ok_s, poll)) return false;
+      pr[0] = p1[0];
+      pr[1] = p2[0];
+      return true;
+    } else {
+      phase_update(first, alpha, pr);
+      tmid = wall_clock64();
+      return chip_allreduce<2>(gran, rank, members, salt, step, pr, red, &ctrl->error, &ok_s, poll);
+    }
+  };
+  alive = update_and_reduce(true, 0.0);
   if (alive) {
     st.norm_r0 = sqrt(pr[0]);
     st.z_r = pr[1];
@@ -529,10 +709,9 @@ __global__ __launch_bounds__(kBlock, 3 - persist_slots_per_wg(SPLIT, MT)) void k
       break;
     }
     st.e_Pe = e_Pe_new;
-    phase_update(false, alpha, pr);
-    const unsigned long long t3 = wall_clock64();
-    if (!(alive = chip_allreduce<2>(gran, rank, members, salt, step, pr, red, &ctrl->error, &ok_s, poll))) break;
-    const unsigned long long t4 = wall_clock64();
+    // (additive preconditioner: its second phase and reduction are reported under "all-reduce after B")
+    if (!(alive = update_and_reduce(false, alpha))) break;
+    const unsigned long long t3 = tmid, t4 = wall_clock64();
     if (!first) {
       tk[0] += t1 - t0;
       tk[1] += t2 - t1;

@@ -38,9 +38,10 @@ class ROptParameters:
     RTR_tCG_iterations: int = 50
     RTR_initial_radius: float = 100.0
     # extensions
-    # "auto" (default: the multilevel cycle when the tCG budget binds, block-Jacobi while it does not -- decided per
-    # problem handle from the solves themselves, ROPTResult.precond_used tells) | "multilevel" (aggregation-multigrid
-    # V-cycle for Q + shift I, the stand-in for the reference's exact solve) | "jacobi" (block-Jacobi) | "none"
+    # "auto" (default: a multilevel preconditioner when the tCG budget binds, block-Jacobi while it does not -- decided
+    # per problem handle, ROPTResult.precond_used tells) | "multilevel" (aggregation-multigrid V-cycle for Q + shift I, the
+    # stand-in for the reference's exact solve) | "additive" (block-Jacobi + coarse-grid correction, runs inside the
+    # persistent kernel; blocks of <= 4 096 poses in 3-D) | "jacobi" (block-Jacobi) | "none"
     precond: str = "auto"
     precond_shift: float = 1e-1  # src/PoseGraph.cpp:603
     accept_tiny_decrease: bool = True
@@ -57,8 +58,8 @@ class ROptParameters:
         c.RTR_iterations = self.RTR_iterations
         c.RTR_tCG_iterations = self.RTR_tCG_iterations
         c.RTR_initial_radius = self.RTR_initial_radius
-        c.precond = {"jacobi": L.PRECOND_BLOCK_JACOBI, "none": L.PRECOND_NONE,
-                     "multilevel": L.PRECOND_MULTILEVEL, "auto": L.PRECOND_AUTO}[self.precond]
+        c.precond = {"jacobi": L.PRECOND_BLOCK_JACOBI, "none": L.PRECOND_NONE, "multilevel": L.PRECOND_MULTILEVEL,
+                     "auto": L.PRECOND_AUTO, "additive": L.PRECOND_ADDITIVE}[self.precond]
         c.precond_shift = self.precond_shift
         c.accept_tiny_decrease = int(self.accept_tiny_decrease)
         c.tcg_poll_interval = self.tcg_poll_interval

@@ -59,6 +59,14 @@ extern "C" {
  * the optimum the trust-region boundary and the coupling, not the preconditioner, end the local solves.
  * dpgo_ropt_result::precond_used says what a call ran. */
 #define DPGO_PRECOND_AUTO 3
+/* Additive two-level preconditioner  z = proj_X( Dinv r + P A_c^-1 P^T r )  (block-Jacobi plus the coarse-grid correction
+ * of the residual; same chain prolongations and Galerkin coarse operator as the multilevel cycle, one aggregate per 16
+ * (3-D) / 20 (2-D) poses): nothing inside it applies an operator to a distributed vector, so a whole preconditioned tCG
+ * iteration runs inside the persistent kernel (three in-kernel reductions).  Available for blocks of at most 256 such
+ * aggregates (4 096 poses in 3-D); where the persistent kernel cannot run (larger blocks: DPGO_ERR_UNSUPPORTED; no free
+ * resident slots or a time-out: silently) the solve uses the multilevel V-cycle on the same hierarchy instead.  What
+ * DPGO_PRECOND_AUTO selects for such blocks when it selects a multilevel preconditioner. */
+#define DPGO_PRECOND_ADDITIVE 4
 
 /* tCG termination status; replaces ROPTLIB::tCGstatusSet in ROPTResult
  * (include/DPGO/DPGO_types.h:106). */

@@ -462,6 +462,10 @@ class QuadraticProblem:
                          preconditioner): level l+1's nodes = runs of amg_k[l] consecutive level-l
                          nodes, prolongation blocks = relative poses read off Q's odometry blocks, Galerkin operators,
                          dense inverse on the coarsest level, damped block-Jacobi pre- and post-smoothing.
+             'amg_additive' -> the ADDITIVE two-level combination on the same hierarchy (the device's "additive"
+                         preconditioner, what its persistent kernel runs on small blocks):
+                         M^-1 r = amg_add_w Dinv r + P A_c^-1 P^T r   (block-Jacobi plus the coarse-grid correction of the
+                         residual itself: no operator application inside the preconditioner), amg_add_w = 1.
     All of them are followed by the tangent projection (QuadraticProblem.cpp:68)."""
 
     def __init__(self, Q: BSR, G: Optional[np.ndarray], r: int, d: int, precond: str = "exact",
@@ -475,6 +479,8 @@ class QuadraticProblem:
         self.N = self.n * self.b
         self.Qs = Q.to_scipy().tocsr()
         self.G = np.zeros((self.n, self.b, r)) if G is None else G
+        if precond == "amg_additive":
+            self.amg_additive, self.amg_add_w = True, 1.0
         self.precond = precond
         self.shift = shift
         self._lu = None
@@ -530,7 +536,7 @@ class QuadraticProblem:
             Z = self.dinv_blocks() @ V
         elif self.precond == "none":
             Z = V.copy()
-        elif self.precond in ("amg", "amg2"):
+        elif self.precond in ("amg", "amg2", "amg_additive"):
             Z = self.amg_cycle(V)
         else:
             raise ValueError(self.precond)
@@ -584,7 +590,7 @@ class QuadraticProblem:
                 return m["AcInv"] @ rhs
             L = m["levels"][lv]
             smooth = lambda res: (L["Dinv"] @ res.reshape(L["n"], b, r)).reshape(res.shape)  # noqa: E731
-            if getattr(self, "amg_additive", False):  # experiment: additive (BPX-like) combination
+            if getattr(self, "amg_additive", False):  # additive combination (precond = "amg_additive")
                 return getattr(self, "amg_add_w", w) * smooth(rhs) + L["P"] @ cycle(lv + 1, L["P"].T @ rhs)
             x = w * smooth(rhs)
             for _ in range((self.amg_nu if lv > 0 else 1) - 1):

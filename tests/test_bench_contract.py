@@ -64,7 +64,7 @@ def test_bench_prints_one_valid_json_line():
     port = cb["single_agent_port"]
     assert port["cores"] == 1 and port["value"] > 0 and port["rel_diff_fOpt_vs_device"] < 1e-6
     tt = j["quality"]["to_tolerance"]
-    assert set(tt) == {"grid:12x10x6/auto", "grid:12x10x6/multilevel", "grid:12x10x6/jacobi",
+    assert set(tt) == {"grid:12x10x6/auto", "grid:12x10x6/multilevel", "grid:12x10x6/additive", "grid:12x10x6/jacobi",
                        "grid:12x10x6/multilevel+fp32_dense_level"}  # the last: opt-in storage mode, beside the headline
     assert rf["multilevel"]["coarse_inverse_bits"] == 64  # the headline configuration keeps everything in fp64
     assert all("products" in v for v in tt.values())

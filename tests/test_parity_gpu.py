@@ -650,6 +650,76 @@ def _persistent_case(oracle, name, r, precond, layout):
         assert abs(rg.fOpt - oo.result.fOpt) <= 1e-9 * abs(oo.result.fOpt) + 1e-14 * scale
 
 
+@pytest.mark.parametrize("name,r", [("smallGrid3D", 5), ("sphere2500", 5), ("kitti_00", 5), ("tinyGrid3D", 5),
+                                    ("sphere2500", 3), ("kitti_00", 3), ("smallGrid3D", 6)])
+def test_additive_preconditioner_matches_oracle(oracle, name, r):
+    """precond = "additive": z = proj_X(Dinv r + P A_c^-1 P^T r) on the two-level hierarchy with one aggregate per 16
+    (3-D) / 20 (2-D) poses, a whole preconditioned tCG iteration inside the persistent kernel (three in-kernel
+    reductions; the restricted residual is the only extra exchange).  Against the oracle's restatement of the operator
+    (precond = "amg_additive", same aggregates) at matched settings: same RTR / tCG iteration counts and status, iterate
+    to 1e-7, cost to 1e-9, over three calls; the kernel must really have run; the hierarchy is the oracle's."""
+    import dpgo_amd
+    om, n, d, Q, pg, prob = build_single_agent(oracle, name, r)
+    k = 16 if d == 3 else 20
+    X0 = oracle.lift(oracle.chordal_initialization(om, n), r)
+    op = oracle.QuadraticProblem(Q, None, r, d, precond="amg_additive", amg_k=[k])
+    oo = oracle.QuadraticOptimizer(op, oracle.ROptParameters(), hess_recurrence=True)
+    go = dpgo_amd.QuadraticOptimizer(prob, dpgo_amd.ROptParameters(precond="additive"))
+    Xo, Xg = X0, X0
+    for call in range(3):
+        Xo = oo.optimize(Xo)
+        Xg = matrix_to_tiles(go.optimize(tiles_to_matrix(Xg)), d)
+        rg = go.getOptResult()
+        info = prob.persistentInfo()
+        assert rg.precond_used == "additive"
+        if rg.gradNormInit >= 1e-2:  # (an iterate that already meets the tolerance leaves before any tCG launch)
+            assert info["last_members"] == -(-n // k) and info["last_split"] == 4, (rg, info)
+        assert (rg.tcg_iterations, rg.rtr_iterations, rg.tCGStatus) == (oo.result.tcg_iters, oo.result.outer_iters,
+                                                                         oracle.TCG_NAMES[oo.result.tCGStatus]), call
+        assert relerr(Xg, Xo) < 1e-7
+        Xa = np.abs(Xo).reshape(n * (d + 1), r)
+        scale = float((Xa * (abs(op.Qs) @ Xa)).sum())
+        assert abs(rg.fOpt - oo.result.fOpt) <= 1e-9 * abs(oo.result.fOpt) + 1e-14 * scale
+    assert prob.multilevelInfo()["ks"] == [k]
+    _hierarchy_check(oracle, prob, op)
+
+
+def test_additive_preconditioner_selection_and_fallbacks(oracle):
+    """auto on a small uncoupled block resolves its multilevel choice to the additive form (sphere2500: precond_used
+    "additive"); a block beyond 256 aggregates refuses "additive" explicitly and auto keeps the V-cycle there (torus3D:
+    5 000 poses = 313 aggregates); with the persistent kernel switched off "additive" runs the V-cycle on the same
+    hierarchy and still converges to the same optimum."""
+    import dpgo_amd
+    from dpgo_amd.lib import DpgoError
+    om, n, d, Q, pg, prob = build_single_agent(oracle, "sphere2500", 5)
+    X0 = oracle.lift(oracle.chordal_initialization(om, n), 5)
+    go = dpgo_amd.QuadraticOptimizer(prob, dpgo_amd.ROptParameters())
+    X = X0
+    for _ in range(8):
+        X = matrix_to_tiles(go.optimize(tiles_to_matrix(X)), d)
+        assert go.getOptResult().precond_used == "additive"
+        if go.getOptResult().gradNormOpt < 1e-2:
+            break
+    f_add = go.getOptResult().fOpt
+    assert go.getOptResult().gradNormOpt < 1e-2 and abs(2 * f_add - 1687.00581428) <= 1e-6 * 1687.0  # literature optimum
+    prob.setPersistent(False)
+    go2 = dpgo_amd.QuadraticOptimizer(prob, dpgo_amd.ROptParameters(precond="additive"))
+    X = X0
+    for _ in range(8):
+        X = matrix_to_tiles(go2.optimize(tiles_to_matrix(X)), d)
+        if go2.getOptResult().gradNormOpt < 1e-2:
+            break
+    assert prob.persistentInfo()["last_members"] == 0 and abs(go2.getOptResult().fOpt - f_add) <= 1e-7 * abs(f_add)
+    big = build_single_agent(oracle, "torus3D", 5)[-1]
+    omt, nt = oracle.read_g2o(os.path.join(DATA, "torus3D.g2o"))
+    Xt = tiles_to_matrix(oracle.lift(oracle.chordal_initialization(omt, nt), 5))
+    with pytest.raises(DpgoError):
+        dpgo_amd.QuadraticOptimizer(big, dpgo_amd.ROptParameters(precond="additive")).optimize(Xt)
+    ga = dpgo_amd.QuadraticOptimizer(big, dpgo_amd.ROptParameters())
+    ga.optimize(Xt)
+    assert ga.getOptResult().precond_used == "multilevel"
+
+
 def test_persistent_tcg_is_refused_beyond_its_capacity_and_follows_the_size_switch(oracle):
     """Blocks that need more than 2 tiles on each of 256 workgroups are refused (explicit request: error); the default
     is on by size: sphere2500 runs the persistent kernel without being asked, the single-iteration radius-shrink mode
@@ -1455,11 +1525,12 @@ def test_multilevel_preconditioner_matches_oracle(oracle, name, r, ks, bits):
 
 @pytest.mark.parametrize("name", ["sphere2500", "smallGrid3D"])
 def test_default_preconditioner_selection_matches_oracle(oracle, name):
-    """precond = "auto" (the default).  A block WITHOUT coupling to other agents starts on the multilevel cycle (the tCG
-    budget, not the trust-region boundary, ends its solves) and hands back to block-Jacobi when a solve needs a tenth
-    of the budget; a handle forced to block-Jacobi switches to multilevel after a solve that used half of it.  The
-    decision is a function of the problem: setting Q again resets it.  Whatever a call ran
-    (ROPTResult.precond_used), it matches the oracle run with that preconditioner at matched settings."""
+    """precond = "auto" (the default).  A block WITHOUT coupling to other agents starts on a multilevel preconditioner
+    (the tCG budget, not the trust-region boundary, ends its solves) and stays there; a handle forced to block-Jacobi
+    switches after a solve that used half of its budget.  The multilevel choice is the additive two-level form wherever
+    its persistent kernel runs (<= 256 aggregates), the V-cycle otherwise.  The decision is a function of the problem:
+    setting Q again resets it.  Whatever a call ran (ROPTResult.precond_used), it matches the oracle run with that
+    preconditioner at matched settings."""
     import dpgo_amd
     om, n, d, Q, pg, prob = build_single_agent(oracle, name, 5)
     r = 5
@@ -1476,12 +1547,15 @@ def test_default_preconditioner_selection_matches_oracle(oracle, name):
         used.append(rg.precond_used)
         if rg.precond_used == "multilevel" and "multilevel" not in ops:
             ops["multilevel"] = oracle.QuadraticProblem(Q, None, r, d, precond="amg", amg_k=prob.multilevelInfo()["ks"])
+        if rg.precond_used == "additive" and "additive" not in ops:
+            ops["additive"] = oracle.QuadraticProblem(Q, None, r, d, precond="amg_additive",
+                                                      amg_k=prob.multilevelInfo()["ks"])
         oo = oracle.QuadraticOptimizer(ops[rg.precond_used], oracle.ROptParameters(), hess_recurrence=True)
         Xo = oo.optimize(Xo)
         assert (rg.tcg_iterations, rg.rtr_iterations) == (oo.result.tcg_iters, oo.result.outer_iters), (call, used)
         assert relerr(Xg, Xo) < 1e-7
-    if name == "sphere2500":
-        assert used == ["jacobi", "multilevel", "multilevel"]
+    if name == "sphere2500":  # (the multilevel choice of a block this small is the additive form)
+        assert used == ["jacobi", "additive", "additive"]
     else:
         assert used[0] == "jacobi"
     # a new Q resets the decision (repeated runs reproduce)

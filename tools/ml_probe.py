@@ -47,11 +47,11 @@ for name in (sys.argv[1:] or ["sphere", "slab", "grid100k"]):
             ts.append(time.perf_counter() - t0)
         print("%-9s setup mfma=%s: %s ms  %s" % (name, mf, ["%.2f" % (1e3 * t) for t in ts], info), flush=True)
     only = os.environ.get("PROBE_ONLY")
-    for pc in ("multilevel", "jacobi", "jacobi+persistent"):
+    for pc in ("multilevel", "additive", "jacobi", "jacobi+persistent"):
         if only and pc not in only.split(","):
             continue
         try:
-            prob.setPersistent(pc.endswith("persistent"))
+            prob.setPersistent(pc.endswith("persistent") or pc == "additive")
         except dpgo_amd.DpgoError as exc:
             print("%-9s %-17s not available: %s" % (name, pc, exc), flush=True)
             continue
