@@ -34,8 +34,74 @@ class RobustCostParameters:
     TLSThreshold: float = 10.0
 
 
+def _gamma_p(a: float, x: float) -> float:
+    """Regularised lower incomplete gamma function P(a, x): series below a + 1, Lentz's continued fraction above."""
+    import math
+    if x <= 0:
+        return 0.0
+    lg = math.lgamma(a)
+    if x < a + 1:
+        ap, total, delta = a, 1.0 / a, 1.0 / a
+        for _ in range(1000):
+            ap += 1
+            delta *= x / ap
+            total += delta
+            if abs(delta) < abs(total) * 1e-17:
+                break
+        return total * math.exp(-x + a * math.log(x) - lg)
+    tiny = 1e-300
+    b = x + 1 - a
+    c, dd = 1 / tiny, 1 / b
+    h = dd
+    for k in range(1, 1000):
+        an = -k * (k - a)
+        b += 2
+        dd = an * dd + b
+        dd = tiny if abs(dd) < tiny else dd
+        c = b + an / c
+        c = tiny if abs(c) < tiny else c
+        dd = 1 / dd
+        delta = dd * c
+        h *= delta
+        if abs(delta - 1) < 1e-16:
+            break
+    return 1.0 - math.exp(-x + a * math.log(x) - lg) * h
+
+
+def chi2inv(quantile: float, dof: int) -> float:
+    """chi2inv (include/DPGO/DPGO_utils.h:146-153, src/DPGO_utils.cpp:509-512: boost's chi-squared quantile,
+    "equivalent to chi2inv in Matlab"): x with P(dof / 2, x / 2) = quantile."""
+    if not (0.0 <= quantile < 1.0) or dof <= 0:
+        raise ValueError("chi2inv: quantile in [0, 1), dof > 0")
+    if quantile == 0.0:
+        return 0.0
+    a = 0.5 * dof
+    lo, hi = 0.0, max(1.0, float(dof))
+    while _gamma_p(a, 0.5 * hi) < quantile:
+        hi *= 2
+    for _ in range(200):
+        if hi - lo <= 1e-15 * hi:
+            break
+        mid = 0.5 * (lo + hi)
+        if _gamma_p(a, 0.5 * mid) < quantile:
+            lo = mid
+        else:
+            hi = mid
+    return 0.5 * (lo + hi)
+
+
 class RobustCost:
     """src/DPGO_robust.cpp:49-134"""
+
+    @staticmethod
+    def computeErrorThresholdAtQuantile(quantile: float, dimension: int) -> float:
+        """include/DPGO/DPGO_robust.h:116-123: the GNC threshold barc for a 3-D measurement whose squared error is
+        chi-squared with 6 degrees of freedom."""
+        if dimension != 3:
+            raise ValueError("CHECK_EQ(dimension, 3) failed: quantile function currently only supports 3D problem.")
+        if not quantile > 0:
+            raise ValueError("CHECK_GT(quantile, 0) failed")
+        return chi2inv(quantile, 6) ** 0.5 if quantile < 1 else 1e5
 
     def __init__(self, params: RobustCostParameters):
         self.mParams = params

@@ -884,9 +884,63 @@ struct RobustCostParameters {
   unsigned GNCMaxNumIters = 20;
   double GNCBarc = 5.0, GNCMuStep = 1.4, GNCInitMu = 1e-4, HuberThreshold = 3.0, TLSThreshold = 10.0;
 };
+// chi2inv (include/DPGO/DPGO_utils.h:146-153, src/DPGO_utils.cpp:509-512: boost's chi-squared quantile; "equivalent to chi2inv
+// in Matlab"): x with P(dof / 2, x / 2) = quantile, P = the regularised lower incomplete gamma function (series below a + 1,
+// Lentz's continued fraction above), by bisection refined with Newton steps.
+namespace detail {
+inline double gammaP(double a, double x) {
+  if (x <= 0) return 0.0;
+  const double lg = std::lgamma(a);
+  if (x < a + 1) {
+    double ap = a, sum = 1.0 / a, del = sum;
+    for (int k = 0; k < 1000; ++k) {
+      ap += 1;
+      del *= x / ap;
+      sum += del;
+      if (std::fabs(del) < std::fabs(sum) * 1e-17) break;
+    }
+    return sum * std::exp(-x + a * std::log(x) - lg);
+  }
+  const double tiny = 1e-300;
+  double b = x + 1 - a, c = 1 / tiny, dd = 1 / b, h = dd;
+  for (int k = 1; k < 1000; ++k) {
+    const double an = -k * (k - a);
+    b += 2;
+    dd = an * dd + b;
+    if (std::fabs(dd) < tiny) dd = tiny;
+    c = b + an / c;
+    if (std::fabs(c) < tiny) c = tiny;
+    dd = 1 / dd;
+    const double del = dd * c;
+    h *= del;
+    if (std::fabs(del - 1) < 1e-16) break;
+  }
+  return 1.0 - std::exp(-x + a * std::log(x) - lg) * h;
+}
+}  // namespace detail
+inline double chi2inv(double quantile, size_t dof) {
+  if (!(quantile >= 0.0) || !(quantile < 1.0) || dof == 0) throw Error(DPGO_ERR_INVALID, "chi2inv: quantile in [0, 1), dof > 0");
+  if (quantile == 0.0) return 0.0;
+  const double a = 0.5 * (double)dof;
+  double lo = 0.0, hi = std::max(1.0, (double)dof);
+  while (detail::gammaP(a, 0.5 * hi) < quantile) hi *= 2;
+  for (int it = 0; it < 200 && hi - lo > 1e-15 * hi; ++it) {
+    const double mid = 0.5 * (lo + hi);
+    (detail::gammaP(a, 0.5 * mid) < quantile ? lo : hi) = mid;
+  }
+  return 0.5 * (lo + hi);
+}
+
 class RobustCost {
  public:
   explicit RobustCost(const RobustCostParameters& p) : params_(p), mu_(p.GNCInitMu) {}
+  // RobustCost::computeErrorThresholdAtQuantile (include/DPGO/DPGO_robust.h:116-123): the GNC threshold barc for a 3-D
+  // measurement whose squared error is chi-squared with 6 degrees of freedom
+  static double computeErrorThresholdAtQuantile(double quantile, size_t dimension) {
+    if (dimension != 3) throw Error(DPGO_ERR_INVALID, "CHECK_EQ(dimension, 3) failed: quantile function currently only supports 3D problem.");
+    if (!(quantile > 0)) throw Error(DPGO_ERR_INVALID, "CHECK_GT(quantile, 0) failed");
+    return quantile < 1 ? std::sqrt(chi2inv(quantile, 6)) : 1e5;
+  }
   double weight(double r) const {  // src/DPGO_robust.cpp:54-98
     using T = RobustCostParameters::Type;
     switch (params_.costType) {

@@ -82,15 +82,16 @@ def evaluate(Q, G, X, V=None, shift: float = 0.1):
 
 def optimize(Q, G, X0, gradnorm_tol=1e-2, RTR_iterations=3, RTR_tCG_iterations=50, RTR_initial_radius=100.0,
              method="RTR", RGD_stepsize=1e-3, RGD_use_preconditioner=True, precond="jacobi", shift=0.1,
-             accept_tiny_decrease=True, hess_recurrence=False):
-    """QuadraticOptimizer::optimize restated in C.  Returns (Xopt tiles, CResult)."""
+             accept_tiny_decrease=True, hess_recurrence=False, tiled_sums=False):
+    """QuadraticOptimizer::optimize restated in C.  Returns (Xopt tiles, CResult).  tiled_sums: every full-vector sum
+    is formed tile-wise (64 poses per partial, partials in order) -- a second summation order of the same arithmetic."""
     n, b, r = X0.shape
     rp, ci, v = _bsr(Q)
     Xc = np.ascontiguousarray(X0, dtype=np.float64)
     Gc = None if G is None else np.ascontiguousarray(G, dtype=np.float64)
     prm = CParams(0 if method == "RTR" else 1, gradnorm_tol, RGD_stepsize, int(RGD_use_preconditioner), RTR_iterations,
                   RTR_tCG_iterations, RTR_initial_radius, {"none": 0, "jacobi": 1}[precond], shift,
-                  int(accept_tiny_decrease), int(bool(hess_recurrence)))
+                  int(accept_tiny_decrease), int(bool(hess_recurrence)) | (2 if tiled_sums else 0))
     res = CResult()
     out = np.empty_like(Xc)
     rc = load().dpgo_c_optimize(n, b - 1, r, _p(rp), _p(ci), _p(v), _p(Gc), C.byref(prm), _p(Xc), _p(out), C.byref(res))

@@ -1167,6 +1167,19 @@ def multi_robot_example(meas: Measurements, n: int, num_robots: int, r: int, X0,
 # --------------------------------------------------------------------------
 
 
+def chi2inv(quantile: float, dof: int) -> float:
+    """chi2inv (src/DPGO_utils.cpp:509-512: boost::math::quantile of the chi-squared distribution; "equivalent to chi2inv
+    in Matlab", include/DPGO/DPGO_utils.h:146-153)."""
+    from scipy.stats import chi2
+    return float(chi2.ppf(quantile, dof))
+
+
+def error_threshold_at_quantile(quantile: float, dimension: int) -> float:
+    """RobustCost::computeErrorThresholdAtQuantile (include/DPGO/DPGO_robust.h:116-123)."""
+    assert dimension == 3 and quantile > 0
+    return math.sqrt(chi2inv(quantile, 6)) if quantile < 1 else 1e5
+
+
 def gnc_tls_weight(r, mu, barc):
     """RobustCost::weight for GNC_TLS (src/DPGO_robust.cpp:80-92), vectorised."""
     r = np.asarray(r, dtype=np.float64)

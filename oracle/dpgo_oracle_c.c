@@ -47,7 +47,10 @@ typedef struct {
   int precond;           /* 0 none, 1 block-Jacobi */
   double precond_shift;
   int accept_tiny_decrease;
-  int hess_recurrence;   /* 0: H applied to delta (reference arithmetic); 1: H delta' = beta H delta - H z */
+  int hess_recurrence;   /* bit 0 -- 0: H applied to delta (reference arithmetic); 1: H delta' = beta H delta - H z.
+                          * bit 1 -- every full-vector sum is formed tile-wise (partial sums over 64 poses, then the partials
+                          * in order) like the device's per-workgroup partials, instead of one running sum: a second
+                          * summation ORDER of the same arithmetic, used to measure how far two orders drift apart. */
 } CParams;
 
 typedef struct {
@@ -59,6 +62,8 @@ typedef struct {
 enum { TCG_NEGCURV = 0, TCG_EXCREGION = 1, TCG_LCON = 2, TCG_SCON = 3, TCG_MAXITER = 4 };
 
 static int g_spmm = 0;
+static int g_tiled_sums = 0;
+#define SUM_TILE 64 /* poses per partial sum in tile-wise mode */
 
 /* OUT = V Q (+ G): tile i of OUT, row c: sum_t sum_k Q_t[c][k] * V_j[k][:]   (Q symmetric: (VQ)^T = Q V^T).
  * The body is instantiated with compile-time block / rank sizes for the shapes the benchmarks use, so that the
@@ -97,6 +102,16 @@ static void spmm(const Problem* p, const double* V, const double* add, double* O
 static double dot(const Problem* p, const double* a, const double* b) {
   double s = 0.0;
   const size_t N = (size_t)p->n * p->T;
+  if (g_tiled_sums) {
+    const size_t chunk = (size_t)SUM_TILE * p->T;
+    for (size_t k0 = 0; k0 < N; k0 += chunk) {
+      double part = 0.0;
+      const size_t k1 = k0 + chunk < N ? k0 + chunk : N;
+      for (size_t k = k0; k < k1; ++k) part += a[k] * b[k];
+      s += part;
+    }
+    return s;
+  }
   for (size_t k = 0; k < N; ++k) s += a[k] * b[k];
   return s;
 }
@@ -207,6 +222,11 @@ static double cost(const Problem* p, const double* X, double* work) {
   const size_t N = (size_t)p->n * p->T;
   spmm(p, X, NULL, work);
   double s = 0.0, g = 0.0;
+  if (g_tiled_sums) {
+    s = dot(p, work, X);
+    if (p->G) g = dot(p, X, p->G);
+    return 0.5 * s + g;
+  }
   for (size_t k = 0; k < N; ++k) s += work[k] * X[k];
   if (p->G)
     for (size_t k = 0; k < N; ++k) g += X[k] * p->G[k];
@@ -356,7 +376,7 @@ static int run_rtr(const Problem* p, const CParams* prm, double* x1, double Delt
   int isstop = ngf < prm->gradnorm_tol;
   while (!isstop && it < max_iter) {
     int n_hess = 0, inner = 0;
-    status = tcg(p, x1, g1, S, Delta, prm->RTR_tCG_iterations, prm->hess_recurrence, eta, wk, &n_hess, &inner);
+    status = tcg(p, x1, g1, S, Delta, prm->RTR_tCG_iterations, prm->hess_recurrence & 1, eta, wk, &n_hess, &inner);
     res->tcg_iterations += n_hess;
     qf_retract(p, x1, eta, x2);
     const double f2 = cost(p, x2, Heta);
@@ -429,6 +449,7 @@ int dpgo_c_optimize(int n, int d, int r, const int32_t* rowptr, const int32_t* c
   memset(res, 0, sizeof(*res));
   res->tCGStatus = TCG_MAXITER;
   g_spmm = 0;
+  g_tiled_sums = (prm->hess_recurrence & 2) ? 1 : 0;
   if (prm->precond == 1 && build_dinv(&p, prm->precond_shift)) return 3;
   double* wk[11];
   for (int k = 0; k < 11; ++k) {

@@ -215,6 +215,15 @@ static int run() {
     }
     std::printf("project: ok\n");
   }
+  // ---------------- chi2inv / RobustCost::computeErrorThresholdAtQuantile (tests/testUtils.cpp:56-71 restated on table
+  // values: the reference checks CDF(chi2inv(0.95, 4)) = 0.95 by sampling)
+  REQUIRE(std::fabs(chi2inv(0.95, 4) - 9.487729036781154) < 1e-11);
+  REQUIRE(std::fabs(chi2inv(0.9, 6) - 10.644640675668422) < 1e-11);
+  REQUIRE(std::fabs(chi2inv(0.99, 6) - 16.811893829770927) < 1e-11);
+  REQUIRE(std::fabs(RobustCost::computeErrorThresholdAtQuantile(0.9, 3) - 3.2626125537164876) < 1e-12);
+  REQUIRE(RobustCost::computeErrorThresholdAtQuantile(1.0, 3) == 1e5);
+  std::printf("chi2inv: ok\n");
+
   // ---------------- rounding (PGOAgent::getTrajectoryInLocalFrame, src/PGOAgent.cpp:718-738): the triangle
   // solution rounded in the frame of pose 0 is Ttrue again; with pose 1 as the global anchor, pose 1 is identity
   {

@@ -274,6 +274,52 @@ def test_triangle_graph_known_answer(oracle):
     assert np.linalg.norm(out - Ttrue) <= 1e-4
 
 
+def test_optimization_thread_and_line_graph_known_answers(oracle):
+    """tests/testOptimizationThread.cpp:29-92 and tests/testLineGraph.cpp through the HIP path (DeviceAgent = the part of
+    PGOAgent that drives it; device chordal initialisation, device rounding).  Triangle, d = r = 3: the trajectory in
+    the local frame is Ttrue to 1e-4 after initialize() and after the optimisation loop (20 iterate() calls).  Line of
+    five poses with one random translation repeated: the graph is a tree, so the initial guess is exact -- cost and
+    gradient 0, the iterate unchanged, the rounded trajectory i * t (the reference asserts only the getters)."""
+    import torch
+    import dpgo_amd
+    from dpgo_amd.agent import DeviceAgent, ExchangePlan, build_pose_graphs
+    from dpgo_amd.initialization import chordal_initialization, odometry_initialization
+    from dpgo_amd import synthetic
+    from test_oracle import triangle_graph
+    om, Ttrue = triangle_graph(oracle)
+    pm = to_product_measurements(om)
+    T0 = chordal_initialization(pm, 3)
+    ranges, graphs = build_pose_graphs(pm, 3, 1, 3)
+    agent = DeviceAgent(graphs, ExchangePlan(graphs), 0, synthetic.lift_tiles(T0, 3), dpgo_amd.ROptParameters(precond="jacobi"))
+
+    def local(agent):
+        T = agent.getTrajectoryInLocalFrame().cpu().numpy()  # tiles [n, d+1, d]
+        return T.transpose(2, 0, 1).reshape(T.shape[2], -1)
+
+    assert np.linalg.norm(local(agent) - Ttrue) <= 1e-4       # :80
+    assert (agent.id, agent.n, agent.d, agent.r) == (0, 3, 3, 3)  # :85-88
+    for _ in range(20):
+        agent.iterate(True)
+    assert np.linalg.norm(local(agent) - Ttrue) <= 1e-4       # :92
+    rng = np.random.default_rng(3)
+    t = rng.uniform(-1, 1, 3)
+    z = np.zeros(4, dtype=np.int64)
+    oml = oracle.Measurements(3, z, np.arange(4), z.copy(), np.arange(1, 5), np.tile(np.eye(3), (4, 1, 1)),
+                              np.tile(t, (4, 1)), np.ones(4), np.ones(4), np.ones(4), np.ones(4, dtype=bool))
+    pml = to_product_measurements(oml)
+    for init in (chordal_initialization, odometry_initialization):
+        X0 = synthetic.lift_tiles(init(pml, 5), 3)
+        ranges, graphs = build_pose_graphs(pml, 5, 1, 3)
+        ag = DeviceAgent(graphs, ExchangePlan(graphs), 0, X0, dpgo_amd.ROptParameters(precond="jacobi"))
+        ag.iterate(True)
+        res = ag.last_result
+        assert (ag.id, ag.n, ag.d, ag.r) == (0, 5, 3, 3)      # what tests/testLineGraph.cpp asserts
+        assert res.fInit < 1e-14 and res.gradNormInit < 1e-8 and np.abs(ag.X.cpu().numpy() - X0).max() < 1e-9
+        T = ag.getTrajectoryInLocalFrame().cpu().numpy()
+        for i in range(5):
+            assert np.abs(T[i, :3] - np.eye(3)).max() < 1e-8 and np.abs(T[i, 3] - i * t).max() < 1e-8
+
+
 def test_prior_known_answer(oracle):
     """tests/testPGO.cpp:131-190 (testPrior): 2-pose graph + prior on pose 1; RTR 50 x 500,
     tol 1e-5 => both poses equal the prior to 1e-6."""
@@ -510,7 +556,8 @@ def test_multi_agent_rbcd_on_one_gpu_matches_oracle(oracle, name, robots, sweeps
     assert costs[-1] < costs[0]
 
 
-@pytest.mark.parametrize("storage", ["plain", "symmetric"])
+@pytest.mark.parametrize("storage", [pytest.param("plain", id="plain"),
+                                     pytest.param("symmetric", id="symmetric-fp32_dense_level-oracle_applies_the_device_inverse")])
 def test_whole_solve_at_full_size_matches_oracle(oracle, storage):
     """BASELINE.json config 4 at full size (100 000 poses, one agent): the first RBCD iterations of the bench's run --
     QuadraticOptimizer::optimize with the reference's default parameters from the perturbed-truth iterate, repeated --
@@ -520,7 +567,12 @@ def test_whole_solve_at_full_size_matches_oracle(oracle, storage):
     the steps and round-off differences between two implementations grow from call to call); per call: same RTR / tCG
     iteration counts, cost to 1e-9 (+ 1e-4 of the call's decrease), iterate to 1e-6 (1e-4 in calls that move far).
     storage = "symmetric": the same with every Q product of the tCG loop (k_tcg_hess_sym, level-0 restriction and
-    post-smoothing) on the symmetric storage that blocks beyond the Infinity Cache's size select by themselves."""
+    post-smoothing) on the symmetric storage that blocks beyond the Infinity Cache's size select by themselves -- and,
+    riding along, the opt-in fp32 storage of the dense level, for which the ORACLE IS HANDED THE DEVICE'S STORED INVERSE
+    (checked to 1e-7 against its own first: two fp64 inverses that agree to 1e-12 round to neighbouring fp32 values in a
+    few entries); that half of the comparison is therefore about the cycle, not about the inverse.
+    The tolerances are round-off sensitivity, not slack of the device path: the plain-C restatement run twice with two
+    summation orders drifts by the same amounts (tests/test_oracle.py::test_two_summation_orders_...)."""
     import torch
     import dpgo_amd
     import c_oracle as CO
