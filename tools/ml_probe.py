@@ -59,11 +59,18 @@ for name in (sys.argv[1:] or ["sphere", "slab", "grid100k"]):
         Xd = torch.tensor(X0, device="cuda", dtype=torch.float64)
         rows, tot, ms = [], 0, 0.0
         for it in range(8):
-            res = opt.optimizeDevice(Xd)
+            try:
+                res = opt.optimizeDevice(Xd)
+            except dpgo_amd.DpgoError as exc:  # e.g. "additive" beyond 256 aggregates
+                print("%-9s %-17s not available: %s" % (name, pc, exc), flush=True)
+                rows = None
+                break
             rows.append((res.tcg_iterations, float("%.3g" % res.gradNormOpt), float("%.2f" % res.elapsedMs)))
             tot += res.tcg_iterations
             ms += res.elapsedMs
             if res.gradNormOpt < 1e-2:
                 break
+        if rows is None:
+            continue
         print("%-9s %-17s products %4d  %.2f ms  (%.1f us/product)  %s %s" % (
             name, pc, tot, ms, 1e3 * ms / max(tot, 1), rows, prob.persistentInfo() if "persist" in pc else ""), flush=True)

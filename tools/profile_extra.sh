@@ -9,7 +9,7 @@ cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_rot_$TAG -o rot -- \
   python $R/tools/rotating_probe.py > $R/gpurun_out/${TAG}_rotating.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_small_$TAG -o small -- \
-  python $R/tools/ml_probe.py grid625 sphere slab > $R/gpurun_out/${TAG}_small_blocks.log 2>&1
+  python $R/tools/ml_probe.py grid625 sphere grid6250 slab > $R/gpurun_out/${TAG}_small_blocks.log 2>&1
 cd $R
 python tools/summarize_prof.py stats gpurun_out/prof_rot_$TAG gpurun_out/${TAG}_rotating_kernel_stats.csv
 python tools/summarize_prof.py stats gpurun_out/prof_small_$TAG gpurun_out/${TAG}_small_blocks_kernel_stats.csv
