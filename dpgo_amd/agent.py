@@ -373,16 +373,23 @@ class RBCDCluster:
         given list); aux = the auxiliary sequence Y (PGOAgent::getAuxSharedPoseDict).  Local pairs are
         device copies; remote pairs form ONE grouped batch of isend/irecv (ncclGroupStart/End under
         RCCL), so no ordering between ranks can deadlock."""
+        msgs = messages if messages is not None else self.plan.messages(receivers)
+        if self._exchange_batched(msgs, (receivers if messages is None else tuple(msgs), bool(aux)), aux):
+            return
         ops, staged = [], []
         sends, recvs = [], []
         dist = None
-        for a, q in (messages if messages is not None else self.plan.messages(receivers)):
+        # the library-owned communicator: all outgoing messages of this process are packed by ONE launch
+        packed = self.comm is not None and self._pack_batched(msgs, (receivers if messages is None else tuple(msgs), bool(aux)), aux)
+        for a, q in msgs:
             a_here, q_here = a in self.agents, q in self.agents
             if a_here and q_here and not self.loopback:
                 self.agents[q].recv_view(a, aux).copy_(self.agents[a].pack(q, aux))
             elif self.comm is not None:
                 if a_here:
-                    sends.append((self.owner(q), self.agents[a].pack(q, aux)))
+                    ag = self.agents[a]
+                    sends.append((self.owner(q), (ag.send_buf_aux[q] if aux else ag.send_buf[q]) if packed
+                                  else ag.pack(q, aux)))
                 if q_here:
                     recvs.append((self.owner(a), self.agents[q].recv_view(a, aux)))
             elif a_here:
@@ -406,6 +413,66 @@ class RBCDCluster:
                 w.wait()
             for view, tmp in staged:
                 view.copy_(tmp)
+
+    def _exchange_batched(self, msgs, key, aux: bool) -> bool:
+        """All messages between device agents of THIS process (no communicator in between): ONE launch for the whole
+        exchange phase (C ABI dpgo_exchange_plan_*; the plan -- iterate / index / neighbour-buffer addresses per message
+        -- is built once per phase and cached).  Returns False when the exchange needs the general path."""
+        if self.loopback or not msgs or not all(a in self.agents and q in self.agents for a, q in msgs):
+            return False
+        first = self.agents[msgs[0][0]]
+        if not hasattr(first, "send_idx") or not hasattr(first, "problem"):
+            return False  # (CPU stand-ins of the gloo tests)
+        import ctypes as C
+        cache = self.__dict__.setdefault("_xplans", {})
+        plan = cache.get(key)
+        if plan is None:
+            src, idx, cnt, dst = [], [], [], []
+            for a, q in msgs:
+                sa, rq = self.agents[a], self.agents[q]
+                src.append(L.ptr(sa.Y if aux else sa.X))
+                idx.append(L.ptr(sa.send_idx[q]))
+                cnt.append(len(sa.send_idx[q]))
+                dst.append(L.ptr(rq.recv_view(a, aux)))
+            n = len(msgs)
+            h = L._P()
+            L.check(first.problem._lib.dpgo_exchange_plan_create(
+                C.byref(h), first.r, first.d, n, (C.c_void_p * n)(*src), (C.c_void_p * n)(*idx), (C.c_int * n)(*cnt),
+                (C.c_void_p * n)(*dst), first.device.index or 0))
+            plan = cache[key] = h
+        L.check(first.problem._lib.dpgo_exchange_plan_run(plan, first.torch.cuda.current_stream().cuda_stream or None))
+        return True
+
+    def _pack_batched(self, msgs, key, aux: bool) -> bool:
+        """K11 for every message this process SENDS through the communicator, as one launch (same plan machinery as
+        _exchange_batched, the destinations are the senders' send buffers)."""
+        out = [(a, q) for a, q in msgs if a in self.agents and (self.loopback or q not in self.agents)]
+        if not out or not hasattr(self.agents[out[0][0]], "send_idx"):
+            return False
+        import ctypes as C
+        first = self.agents[out[0][0]]
+        cache = self.__dict__.setdefault("_xplans", {})
+        plan = cache.get(("pack",) + key)
+        if plan is None:
+            n = len(out)
+            src = [L.ptr(self.agents[a].Y if aux else self.agents[a].X) for a, q in out]
+            idx = [L.ptr(self.agents[a].send_idx[q]) for a, q in out]
+            cnt = [len(self.agents[a].send_idx[q]) for a, q in out]
+            dst = [L.ptr(self.agents[a].send_buf_aux[q] if aux else self.agents[a].send_buf[q]) for a, q in out]
+            h = L._P()
+            L.check(first.problem._lib.dpgo_exchange_plan_create(
+                C.byref(h), first.r, first.d, n, (C.c_void_p * n)(*src), (C.c_void_p * n)(*idx), (C.c_int * n)(*cnt),
+                (C.c_void_p * n)(*dst), first.device.index or 0))
+            plan = cache[("pack",) + key] = h
+        L.check(first.problem._lib.dpgo_exchange_plan_run(plan, first.torch.cuda.current_stream().cuda_stream or None))
+        return True
+
+    def __del__(self):
+        try:
+            for h in self.__dict__.get("_xplans", {}).values():
+                next(iter(self.agents.values())).problem._lib.dpgo_exchange_plan_destroy(h)
+        except Exception:
+            pass
 
     def _allreduce_host(self, values: np.ndarray) -> np.ndarray:
         """Sum of a small host array over the ranks (cost / gradient-norm terms).  Loop-back mode sends it through the

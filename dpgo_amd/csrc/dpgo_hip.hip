@@ -3209,6 +3209,71 @@ int dpgo_gather_tiles_device(int r, int d, const double* src_dev, const int32_t*
   return DPGO_OK;
 }
 
+struct dpgo_exchange_plan_s {
+  int device = 0, T = 0, nmsg = 0, total = 0;
+  void *src = nullptr, *idx = nullptr, *dst = nullptr, *first = nullptr;
+};
+
+int dpgo_exchange_plan_create(dpgo_exchange_plan_t* out, int r, int d, int nmsg, const double* const* src_dev,
+                              const int32_t* const* idx_dev, const int* count, double* const* dst_dev, int device) {
+  if (!out || nmsg <= 0 || !src_dev || !idx_dev || !count || !dst_dev || !supported(d, r))
+    return fail(DPGO_ERR_INVALID, "bad exchange plan arguments");
+  *out = nullptr;
+  std::vector<int32_t> first(nmsg + 1, 0);
+  for (int m = 0; m < nmsg; ++m) {
+    if (count[m] < 0 || (count[m] > 0 && (!src_dev[m] || !idx_dev[m] || !dst_dev[m]))) return fail(DPGO_ERR_INVALID, "bad message");
+    first[m + 1] = first[m] + count[m];
+  }
+  HIPC(hipSetDevice(device));
+  auto* pl = new dpgo_exchange_plan_s();
+  pl->device = device;
+  pl->T = (d + 1) * r;
+  pl->nmsg = nmsg;
+  pl->total = first[nmsg];
+  int rc = [&]() -> int {
+    HIPC(hipMalloc(&pl->src, sizeof(void*) * nmsg));
+    HIPC(hipMalloc(&pl->idx, sizeof(void*) * nmsg));
+    HIPC(hipMalloc(&pl->dst, sizeof(void*) * nmsg));
+    HIPC(hipMalloc(&pl->first, sizeof(int32_t) * (nmsg + 1)));
+    HIPC(hipMemcpy(pl->src, src_dev, sizeof(void*) * nmsg, hipMemcpyHostToDevice));
+    HIPC(hipMemcpy(pl->idx, idx_dev, sizeof(void*) * nmsg, hipMemcpyHostToDevice));
+    HIPC(hipMemcpy(pl->dst, dst_dev, sizeof(void*) * nmsg, hipMemcpyHostToDevice));
+    HIPC(hipMemcpy(pl->first, first.data(), sizeof(int32_t) * (nmsg + 1), hipMemcpyHostToDevice));
+    return DPGO_OK;
+  }();
+  if (rc != DPGO_OK) {
+    dpgo_exchange_plan_destroy(pl);
+    return rc;
+  }
+  *out = pl;
+  return DPGO_OK;
+}
+
+int dpgo_exchange_plan_run(dpgo_exchange_plan_t pl, void* stream) {
+  if (!pl) return fail(DPGO_ERR_INVALID, "null exchange plan");
+  if (pl->total == 0) return DPGO_OK;
+  HIPC(hipSetDevice(pl->device));
+  const ExchangeTable tb{(const double* const*)pl->src, (const int32_t* const*)pl->idx, (double* const*)pl->dst,
+                         (const int32_t*)pl->first, pl->nmsg};
+  const int g = std::max(1, std::min(kMaxGrid, (pl->total + kBlock / 4 - 1) / (kBlock / 4)));
+  switch (pl->T) {
+#define CASE_T(TT) case TT: hipLaunchKernelGGL((k_gather_tiles_batched<TT>), dim3(g), dim3(kBlock), 0, (hipStream_t)stream, tb); break;
+    CASE_T(6) CASE_T(9) CASE_T(12) CASE_T(15) CASE_T(16) CASE_T(20) CASE_T(24)
+#undef CASE_T
+    default: return fail(DPGO_ERR_UNSUPPORTED, "unsupported (d, r)");
+  }
+  HIPC(hipGetLastError());
+  return DPGO_OK;
+}
+
+int dpgo_exchange_plan_destroy(dpgo_exchange_plan_t pl) {
+  if (!pl) return DPGO_OK;
+  for (void* q : {pl->src, pl->idx, pl->dst, pl->first})
+    if (q) (void)hipFree(q);
+  delete pl;
+  return DPGO_OK;
+}
+
 int dpgo_max_translation_distance_device(int r, int d, int n, const double* X_dev, const double* Xprev_dev,
                                          double* out_dev, double* out_host, void* stream) {
   if (!X_dev || !Xprev_dev || !out_dev || n <= 0) return fail(DPGO_ERR_INVALID, "bad arguments");

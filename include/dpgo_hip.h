@@ -415,6 +415,17 @@ int dpgo_round_trajectory(int r, int d, int n, const double* X_host, const doubl
 int dpgo_round_trajectory_device(int r, int d, int n, const double* X_dev, const double* anchor_host, double* T_dev,
                                  void* stream);
 
+/* The public-pose exchange between agents that live in ONE process (what examples/MultiRobotExample.cpp:183-204 does by
+ * pointer calls: getSharedPoseDict -> updateNeighborPoses), as one launch per exchange phase: message m copies count[m]
+ * pose tiles  src_dev[m][idx_dev[m][k]] -> dst_dev[m][k]  (src: the sender's iterate, dst: the receiver's neighbour tile
+ * buffer at the sender's slot range).  The addresses are captured at creation and must stay valid.  (d, r) as
+ * dpgo_supported. */
+typedef struct dpgo_exchange_plan_s* dpgo_exchange_plan_t;
+int dpgo_exchange_plan_create(dpgo_exchange_plan_t* out, int r, int d, int nmsg, const double* const* src_dev,
+                              const int32_t* const* idx_dev, const int* count, double* const* dst_dev, int device);
+int dpgo_exchange_plan_run(dpgo_exchange_plan_t plan, void* stream);
+int dpgo_exchange_plan_destroy(dpgo_exchange_plan_t plan);
+
 /* Agent status (PGOAgent::iterate, src/PGOAgent.cpp:399-420): relativeChange = LiftedPoseArray::maxTranslationDistance
  * (src/manifold/Poses.cpp:86-94) of the iterate and the previous one, max_i |p_i - p_i'| over the translation columns.
  * The result is left in *out_dev (device double: e.g. a slot of the vector a termination vote all-reduces with
