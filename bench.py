@@ -532,14 +532,16 @@ def main():
     # loop launched (`in_use`: what the library's size switch selects for this block)
     in_use = agent.problem.setSpmmVariant("auto")
     hsets = max(3, nsets // 2 + 1)  # a tCG-step operand set is ~1.7x an SpMM set
-    split = 4 if n_local < 40000 else 1
     span = ((d + 1) * r) % 2 == 0
-    names = {"plain": "%s<%d,%d,%d>" % ("k_tcg_hess_span" if span else "k_tcg_hess", d, r, split),
-             "symmetric": "k_tcg_hess_sym<%d,%d>" % (d, r)}
+    names = {}
     hess = {}
     for variant in ("plain", "symmetric"):
         if agent.problem.setSpmmVariant(variant) != variant:
             continue  # (the symmetric storage needs one pose per d+1 lanes: blocks >= 40 000 poses)
+        ki = agent.problem.tcgKernelInfo()  # the instance the library launches for this block (size rules, dpgo_hip.h)
+        names[variant] = ("k_tcg_hess_sym<%d,%d,%d>" % (d, r, ki["stream_nt"]) if ki["symmetric"] else
+                          "k_tcg_hess_span<%d,%d,%d,%d>" % (d, r, ki["split"], ki["stream_nt"]) if span else
+                          "k_tcg_hess<%d,%d,%d>" % (d, r, ki["split"]))
         cold, warm_ = C.c_double(0.0), C.c_double(0.0)
         dpgo_amd.lib.check(lib.dpgo_bench_hess_rotating(agent.problem.handle, hsets + (variant == "symmetric"),
                                                         args.spmm_reps, 10, C.byref(cold)))
@@ -660,6 +662,34 @@ def main():
                                              frac=sb / (ms_spmm.value * 1e-3) / 1e9 / HBM_PEAK_GBS)),
                     spmm_symmetric=spmm_sym, spmm_storage_selected=in_use,
                     kernels=kernels, cycle_tail_us=ms_it[4] * 1e3, multilevel=ml_info)
+
+    # Blocks in the latency regime: the timed loop launched ONE kernel per solve (k_rtr_persist: the whole RTR solve, Q
+    # resident in registers, vectors in LDS, products synchronised by an in-kernel all-reduce) -- that launch is the
+    # dominant kernel of the step, and the headline figures are its: algorithmic bytes = the products it ran x the
+    # tCG-step bytes above, duration = HIP events on the solver's stream around the launch (+ its two memsets).
+    pinfo = agent.problem.persistentInfo()
+    if pinfo.get("enabled") and pinfo.get("last_members", 0) > 0:
+        from dpgo_amd.solver import bench_solve
+        bs = bench_solve(agent.optimizer, agent._snap, reps=20, warmup=3)
+        if bs["persistent"] and bs["products"] > 0:
+            solve_bytes = bs["products"] * hb
+            ach_p = solve_bytes / (bs["ms"] * 1e-3) / 1e9
+            roofline["multi_launch_kernel"] = dict(kernel=roofline["kernel"], achieved=roofline["achieved"],
+                                                   frac=roofline["frac"], avg_launch_us=roofline["avg_launch_us"],
+                                                   bytes_per_launch=hb, warm=roofline.pop("warm"),
+                                                   note="the tCG-step kernel of the multi-launch scheme (blocks beyond the "
+                                                        "persistent kernel's size); NOT what the timed loop ran")
+            roofline.update(
+                kernel="k_rtr_persist<%d,%d,%d,%d> (a whole RTR solve in one launch: %d workgroups, Q in registers, iterates "
+                       "in LDS, in-kernel all-reduces)" % (d, r, pinfo.get("last_split", 0), pinfo.get("last_tiles", 0),
+                                                           pinfo["last_members"]),
+                achieved=ach_p, frac=ach_p / HBM_PEAK_GBS, bytes_per_launch=solve_bytes, avg_launch_us=bs["ms"] * 1e3,
+                products_per_launch=bs["products"], us_per_product=bs["ms"] * 1e3 / bs["products"], traffic=None,
+                traffic_source=None,
+                protocol="HIP events on the solver's stream around one solve = one launch, %d repetitions from the "
+                         "benchmark's iterate; bytes = products x the tCG step's algorithmic bytes (SURVEY 8d) although Q "
+                         "never leaves the registers after the first read: the kernel is bound by the latency of its "
+                         "chip-wide reductions (2 per product), not by HBM" % 20)
 
     cpu = None
     jac_step = None

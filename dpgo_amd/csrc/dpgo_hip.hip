@@ -200,7 +200,14 @@ struct dpgo_problem_s {
     // 36.6 us at 100k poses with cold operands), while on cache-resident operands the fused kernels gain nothing
     // (DESIGN.md section 3).  DPGO_SPMM_SYMMETRIC=0/1 in the environment overrides.
     if (const char* e = std::getenv("DPGO_SPMM_SYMMETRIC")) return std::atoi(e) != 0;
-    return sizeof(double) * ((size_t)Q.nnzb * b * b + 8 * (size_t)n * T) + sizeof(int32_t) * (size_t)Q.nnzb > ((size_t)256 << 20);
+    return beyond_cache();
+  }
+  // what the tCG loop streams besides Q and the pose vectors (the multilevel cycle's dense inverse, A P, prolongation):
+  // set by the solve that last chose a preconditioner
+  size_t loop_extra_bytes = 0;
+  bool beyond_cache() const {
+    return sizeof(double) * ((size_t)Q.nnzb * b * b + 8 * (size_t)n * T) + sizeof(int32_t) * (size_t)Q.nnzb + loop_extra_bytes >
+           ((size_t)256 << 20);
   }
   // persistent whole-chip tCG kernel (blocks in the latency regime, block-Jacobi / no preconditioner): kernels/persist.h
   bool persist = false;      // enabled for this handle (by size; DPGO_PERSIST=0/1, dpgo_problem_set_persistent)
@@ -208,6 +215,7 @@ struct dpgo_problem_s {
   int persist_wgs = 0, persist_split = 0, persist_mt = 0;  // geometry of the current / last launch
   int persist_reserved = 0;  // resident-slot reservation held by the running solve
   bool persist_failed_once = false;
+  bool stream_nt = false;  // single-use operands of the tCG-step kernel move non-temporally (ld_stream, common.h)
   bool persist_add = false;  // the reservation is for the additive-preconditioner variant
   PersistCtrl* pctrl = nullptr;
   unsigned long long* pgran = nullptr;  // granule table of the in-kernel all-reduce (kGranWords 8-byte words)
@@ -534,9 +542,17 @@ int launch_tcg_update(dpgo_problem_s* p, const double* dinv, int first, double* 
 #define LAUNCH_TCG_HESS(p, SIN, SOUT, FIRST, HFLAG, GEN)                                                          \
   do {                                                                                                            \
     if constexpr (Span<D, R, 1>::kOk) {                                                                           \
-      if ((p)->tcg_sym)                                                                                           \
-        hipLaunchKernelGGL((k_tcg_hess_sym<D, R>), dim3((p)->grid_s()), dim3(kBlock), 0, (p)->stream,             \
+      if ((p)->tcg_sym && (p)->stream_nt)                                                                         \
+        hipLaunchKernelGGL((k_tcg_hess_sym<D, R, 1>), dim3((p)->grid_s()), dim3(kBlock), 0, (p)->stream,          \
                            (p)->sym.dev(), (p)->x1, (p)->S1, (p)->z, (p)->delta, (p)->Hd, (p)->pB(), (p)->nb_zr(), \
+                           (p)->pA(), SIN, SOUT, FIRST, (p)->n, HFLAG, GEN);                                      \
+      else if ((p)->tcg_sym)                                                                                      \
+        hipLaunchKernelGGL((k_tcg_hess_sym<D, R, 0>), dim3((p)->grid_s()), dim3(kBlock), 0, (p)->stream,          \
+                           (p)->sym.dev(), (p)->x1, (p)->S1, (p)->z, (p)->delta, (p)->Hd, (p)->pB(), (p)->nb_zr(), \
+                           (p)->pA(), SIN, SOUT, FIRST, (p)->n, HFLAG, GEN);                                      \
+      else if ((p)->stream_nt && (p)->split == 1)                                                                 \
+        hipLaunchKernelGGL((k_tcg_hess_span<D, R, 1, 1>), dim3((p)->grid_s()), dim3(kBlock), 0, (p)->stream,      \
+                           (p)->Q.dev(), (p)->x1, (p)->S1, (p)->z, (p)->delta, (p)->Hd, (p)->pB(), (p)->nb_zr(),   \
                            (p)->pA(), SIN, SOUT, FIRST, (p)->n, HFLAG, GEN);                                      \
       else                                                                                                        \
       LAUNCH_SPLIT(p, k_tcg_hess_span, (p)->grid_s(), (p)->Q.dev(), (p)->x1, (p)->S1, (p)->z, (p)->delta, (p)->Hd, \
@@ -556,6 +572,10 @@ int launch_tcg_hess(dpgo_problem_s* p, int first) {
 // which storage of Q the tCG-step kernel of the coming launches reads (Q does not change inside a solve)
 int resolve_tcg_storage(dpgo_problem_s* p) {
   p->tcg_sym = false;
+  {  // non-temporal single-use operands: when the launch is fed from HBM (same size rule as the symmetric storage)
+    const char* e = std::getenv("DPGO_STREAM_NT");
+    p->stream_nt = e ? std::atoi(e) != 0 : p->beyond_cache();
+  }
   bool span = false;
   DISPATCH(p->d, p->r, { span = Span<D, R, 1>::kOk; });
   if (!span || !p->sym_wanted()) return DPGO_OK;
@@ -1068,13 +1088,14 @@ void persist_release(dpgo_problem_s* p) {
 struct PersistGeo {
   int split = 0, mt = 0, wgs = 0, slots = 0;
 };
-// `free_slots`: what may be reserved now.  Alone on the device: the lowest-latency layout that fits (4 lane groups per pose
-// while the tiles fit, then one pose per (d+1) lanes).  Sharing the device with other concurrently solved agents
-// (share > 1): the layout with the fewest slots, so that as many agents as possible run the kernel at once.
 bool additive_available(const dpgo_problem_s* p) {
   const int P = additive_tile(p);
-  return p->persist && !p->persist_failed_once && (p->n + P - 1) / P <= kPersistMax;
+  return p->persist && !p->persist_failed_once && p->split == 4 && (p->n + P - 1) / P <= kPersistMax;
 }
+// `free_slots`: what may be reserved.  Alone on the device (share = 1): the lowest-latency layout that fits (4 lane groups
+// per pose while the tiles fit, then one pose per (d+1) lanes).  Sharing the device with `share` concurrently solved
+// agents: the lowest-latency layout of which `share` copies fit side by side; if there is none, the most compact one
+// (the solves then take turns).
 PersistGeo persist_geometry(const dpgo_problem_s* p, int free_slots, int share = 1, bool additive = false) {
   if (additive) {  // fixed layout; one workgroup per CU (the rows of the coarse inverse live in its LDS)
     const int P = additive_tile(p);
@@ -1086,7 +1107,7 @@ PersistGeo persist_geometry(const dpgo_problem_s* p, int free_slots, int share =
   static const int env_split = [] { const char* e = std::getenv("DPGO_PERSIST_SPLIT"); return e ? std::atoi(e) : 0; }();
   static const int env_mt = [] { const char* e = std::getenv("DPGO_PERSIST_MT"); return e ? std::atoi(e) : 0; }();
   const int cand[4][2] = {{4, 1}, {4, 2}, {1, 1}, {1, 2}};
-  PersistGeo best;
+  PersistGeo compact;
   for (auto& c : cand) {
     if (env_split && c[0] != env_split) continue;
     if (env_mt && c[1] != env_mt) continue;
@@ -1095,17 +1116,18 @@ PersistGeo persist_geometry(const dpgo_problem_s* p, int free_slots, int share =
     const int wgs = (tiles + c[1] - 1) / c[1];
     const int slots = wgs * persist_slots_per_wg(c[0], c[1]);
     if (wgs > kPersistMax || slots > free_slots) continue;
-    if (best.wgs == 0 || (share > 1 && slots < best.slots)) best = PersistGeo{c[0], c[1], wgs, slots};
-    if (share <= 1) break;
+    const PersistGeo g{c[0], c[1], wgs, slots};
+    if ((long long)slots * std::max(1, share) <= free_slots) return g;  // everybody fits at once
+    if (compact.wgs == 0 || slots < compact.slots) compact = g;
   }
-  return best;
+  return compact;
 }
 
-// Enqueues the persistent tCG launch of one outer iteration (no host wait).  *used = false: not launched (no geometry /
-// no free slots) -- the caller runs the two-kernel scheme.
-int launch_tcg_persistent(dpgo_problem_s* p, const double* dinv, bool* used, bool additive = false) {
+// Enqueues the persistent launch of a WHOLE solve (k_rtr_persist; no host wait).  *used = false: not launched (no geometry
+// / no free slots) -- the caller runs the multi-launch scheme.
+int launch_rtr_persistent(dpgo_problem_s* p, const dpgo_ropt_params* prm, const double* dinv, bool* used, bool additive) {
   *used = false;
-  if (additive && p->persist_reserved > 0 && !(p->persist_split == 4 && p->persist_mt == 1 && p->persist_add)) return DPGO_OK;
+  p->gen += 1;
   if (p->persist_reserved == 0) {
     // Alone on the device: what is free now, first come first served.  Sharing it with other concurrently solved agents:
     // the most compact layout, at most 4/5 of the slots in use at once (a CU that holds a persistent workgroup has no
@@ -1132,11 +1154,10 @@ int launch_tcg_persistent(dpgo_problem_s* p, const double* dinv, bool* used, boo
     p->persist_mt = g.mt;
     p->persist_wgs = g.wgs;
     p->persist_add = additive;
-    // once per solve: the error word is sticky (a launch behind a timed-out one sees it and leaves at once), the
-    // diagnostics accumulate, and the granules' epochs are salted per launch (cleared here against wrap-around)
-    HIPC(hipMemsetAsync(p->pctrl, 0, sizeof(PersistCtrl), p->stream));
-    HIPC(hipMemsetAsync(p->pgran, 0, sizeof(unsigned long long) * kGranWords, p->stream));
   }
+  // (the granules' epochs are salted per launch; the table is cleared against wrap-around of the salt)
+  HIPC(hipMemsetAsync(p->pctrl, 0, sizeof(PersistCtrl), p->stream));
+  HIPC(hipMemsetAsync(p->pgran, 0, sizeof(unsigned long long) * kGranWords, p->stream));
   const unsigned salt = ((p->gen & 0x7ffu) + 1u) << 20;  // never 0; the in-launch step counter fills the low 20 bits
   // granule sweeps of the in-kernel all-reduce: wait before the first one (a granule needs ~1 us to cross the chip and
   // the slowest of more workgroups arrives later; sweeping earlier only loads the fabric: sphere2500 11.9 -> 7.9 us per
@@ -1155,32 +1176,29 @@ int launch_tcg_persistent(dpgo_problem_s* p, const double* dinv, bool* used, boo
     add = AddDev{L0.Pb, p->ml_dense, p->ml_lda, C.n, C.r, 1.0};
     lds = sizeof(double) * (size_t)p->b * C.n * p->b;  // (d+1) rows of the inverse
   }
-#define PERSIST_LAUNCH(SP, MT_)                                                                                       \
-  hipLaunchKernelGGL((k_tcg_persist<D, R, SP, MT_>), dim3(p->persist_wgs), dim3(kBlock), 0, p->stream, p->Q.dev(),    \
-                     p->x1, p->S1, p->g1, dinv, p->eta, p->z, p->pgran, salt, p->dstate + p->cur,                     \
-                     p->dstate + (p->cur ^ 1), p->pctrl, p->n, p->hflag, p->gen, poll, add)
+  const RtrArgs ra{prm->gradnorm_tol, prm->RTR_initial_radius, 5.0 * prm->RTR_initial_radius, prm->RTR_tCG_iterations,
+                   prm->RTR_iterations, prm->accept_tiny_decrease};
+  const double* Glin = p->has_G ? p->G : nullptr;
+#define PERSIST_LAUNCH(SP, MT_, ADD_, LDS_)                                                                           \
+  hipLaunchKernelGGL((k_rtr_persist<D, R, SP, MT_, ADD_>), dim3(p->persist_wgs), dim3(kBlock), LDS_, p->stream,       \
+                     p->Q.dev(), p->x1, Glin, dinv, p->x2, p->eta, p->z, p->pgran, salt, p->dstate, p->pctrl, p->n,   \
+                     p->hflag, p->gen, poll, ra, add)
   DISPATCH(p->d, p->r, {
-    if (additive)
-      hipLaunchKernelGGL((k_tcg_persist<D, R, 4, 1, true>), dim3(p->persist_wgs), dim3(kBlock), lds, p->stream,
-                         p->Q.dev(), p->x1, p->S1, p->g1, dinv, p->eta, p->z, p->pgran, salt, p->dstate + p->cur,
-                         p->dstate + (p->cur ^ 1), p->pctrl, p->n, p->hflag, p->gen, poll, add);
-    else if (p->persist_split == 4 && p->persist_mt == 1) PERSIST_LAUNCH(4, 1);
-    else if (p->persist_split == 4) PERSIST_LAUNCH(4, 2);
-    else if (p->persist_mt == 1) PERSIST_LAUNCH(1, 1);
-    else PERSIST_LAUNCH(1, 2);
+    if (additive) PERSIST_LAUNCH(4, 1, true, lds);
+    else if (p->persist_split == 4 && p->persist_mt == 1) PERSIST_LAUNCH(4, 1, false, 0);
+    else if (p->persist_split == 4) PERSIST_LAUNCH(4, 2, false, 0);
+    else if (p->persist_mt == 1) PERSIST_LAUNCH(1, 1, false, 0);
+    else PERSIST_LAUNCH(1, 2, false, 0);
   });
 #undef PERSIST_LAUNCH
   HIPC(hipGetLastError());
-  p->cur ^= 1;
+  p->cur = 0;
   *used = true;
   return DPGO_OK;
 }
 
-void persist_report(dpgo_problem_s* p) {
+void persist_report(dpgo_problem_s* p) {  // (hctrl has been read back with the state record)
   if (!std::getenv("DPGO_PERSIST_VERBOSE")) return;
-  if (hipMemcpyAsync(p->hctrl, p->pctrl, sizeof(PersistCtrl), hipMemcpyDeviceToHost, p->stream) != hipSuccess ||
-      hipStreamSynchronize(p->stream) != hipSuccess)
-    return;
   const double it = std::max<double>(1.0, (double)p->hctrl->ticks[4]);
   std::fprintf(stderr,
                "dpgo_hip: persistent tCG: %u workgroups (%d lane groups per pose, %d tiles each)%s, %u iterations; per "
@@ -1200,25 +1218,7 @@ int rtr_outer_iteration(dpgo_problem_s* p, const dpgo_ropt_params* prm, const do
   // two-level hierarchy takes over)
   const bool ml = prm->precond == DPGO_PRECOND_MULTILEVEL || add;
   p->zr_from_post = ml;
-  if (p->persist && (!ml || add) && !p->persist_failed_once) {
-    bool used = false;
-    CHK(launch_tcg_persistent(p, dinv, &used, add));
-    if (add && !used) cnt.vcycle_for_additive = true;
-    if (used) {  // the whole outer iteration is enqueued without a host wait; a stop test met earlier makes these exit
-      CHK(launch_retract(p, p->x1, p->eta, 1.0, p->x2, p->dstate + p->cur));
-      CHK(launch_grad(p, p->x2, p->g2, p->S2, nullptr, p->dstate + p->cur));
-      cnt.spmm += 1;
-      CHK(launch_hess(p, p->x1, p->S1, p->eta, p->g1, p->Hd, p->pH(), p->dstate + p->cur, 0));
-      cnt.spmm += 1;
-      CHK(launch_rtr_update(p));
-      persist_report(p);
-      if (poll_at_end) CHK(poll_state(p));
-      else if (__atomic_load_n(p->hflag, __ATOMIC_ACQUIRE) >> 32 == p->gen &&
-               (__atomic_load_n(p->hflag, __ATOMIC_ACQUIRE) & 2ull))
-        p->saw_rtr_stop = true;  // (opportunistic: the device is usually far behind the enqueueing host)
-      return DPGO_OK;
-    }
-  }
+  if (add) cnt.vcycle_for_additive = true;
   // multilevel: the update kernel writes the pre-smoothing step of level 0 instead of the block-Jacobi z; the cycle's
   // last kernel produces z and the partial sums <r,r>, <z,r>
   auto update = [&](int first) -> int {
@@ -1307,18 +1307,6 @@ int run_optimize(dpgo_problem_s* p, const dpgo_ropt_params* prm, dpgo_ropt_resul
     dpgo_problem_s* p;
     ~SlotGuard() { persist_release(p); }
   } slot_guard{p};
-  // a persistent launch that timed out left the state record poisoned and everything behind it skipped: clear the mark,
-  // stop using the kernel on this handle, and let the caller resume from the (consistent) state with the two-kernel scheme
-  auto persist_recover = [&]() -> int {
-    if (p->hstate->rtr_stop != kPersistPoison) return 0;
-    p->persist_failed_once = true;
-    persist_release(p);
-    if (std::getenv("DPGO_PERSIST_VERBOSE"))
-      std::fprintf(stderr, "dpgo_hip: persistent tCG timed out; this handle continues with the two-kernel scheme\n");
-    p->hstate->rtr_stop = 0;
-    p->saw_rtr_stop = false;
-    return 1;
-  };
   dpgo_ropt_params resolved = *prm;  // DPGO_PRECOND_AUTO -> what this handle currently runs
   if (prm->precond == DPGO_PRECOND_AUTO) p->auto_decide();
   if (prm->precond == DPGO_PRECOND_AUTO)  // (the multilevel choice: the additive form wherever its persistent kernel runs)
@@ -1345,7 +1333,58 @@ int run_optimize(dpgo_problem_s* p, const dpgo_ropt_params* prm, dpgo_ropt_resul
   } else if (prm->precond != DPGO_PRECOND_NONE) {
     return fail(DPGO_ERR_INVALID, "unknown preconditioner");
   }
+  p->loop_extra_bytes = 0;
+  if (prm->precond == DPGO_PRECOND_MULTILEVEL && !p->ml.empty()) {
+    const size_t nd = (size_t)p->ml_lda;
+    size_t bytes = nd * nd * (size_t)(p->ml_coarse_bits / 8) / (p->ml_use_dense_sym() ? 2 : 1);
+    const auto& L0 = p->ml[0];
+    bytes += (size_t)L0.AP.nnzb * (sizeof(double) * p->b * p->b + sizeof(int32_t)) + sizeof(double) * (size_t)p->n * p->b * p->b;
+    bytes += 3 * p->vec_bytes();
+    p->loop_extra_bytes = bytes;
+  }
   CHK(resolve_tcg_storage(p));
+  // ---- blocks in the latency regime: the whole solve is ONE persistent launch (k_rtr_persist) and one read-back.  The
+  // single-iteration radius-shrink mode (:80-99) and the polling mode keep the multi-launch scheme.
+  const bool add = prm->precond == DPGO_PRECOND_ADDITIVE;
+  if (prm->method == DPGO_METHOD_RTR && prm->RTR_iterations != 1 && prm->tcg_poll_interval <= 0 && p->persist &&
+      !p->persist_failed_once && (add || prm->precond == DPGO_PRECOND_BLOCK_JACOBI || prm->precond == DPGO_PRECOND_NONE)) {
+    bool used = false;
+    CHK(launch_rtr_persistent(p, prm, dinv, &used, add));
+    if (used) {
+      HIPC(hipMemcpyAsync(p->hctrl, p->pctrl, sizeof(PersistCtrl), hipMemcpyDeviceToHost, p->stream));
+      CHK(poll_state(p));
+      persist_report(p);
+      if (p->hstate->rtr_stop != kPersistPoison) {
+        const DevState& h = *p->hstate;
+        res->fInit = h.fInit;
+        res->gradNormInit = h.gnInit;
+        res->fOpt = h.f1;
+        res->gradNormOpt = h.ngf;
+        res->tCGStatus = h.outer_iter > 0 ? h.tcg_status : DPGO_TCG_MAXITER;
+        res->rtr_iterations = h.outer_iter;
+        res->rtr_accepted = h.n_accept;
+        res->latest_step_accepted = h.accepted_last;
+        res->tcg_iterations = h.n_hess;
+        res->precond_used = prm->precond;
+        res->spmm_count = 1 + 2 * h.outer_iter + h.n_hess;
+        if (is_auto) {  // hysteresis on how much of the tCG budget the solve used (see below)
+          const int budget = std::max(1, prm->RTR_iterations) * std::max(1, prm->RTR_tCG_iterations);
+          const bool coupled = p->has_G || p->C.nnzb > 0;
+          if (!p->auto_ml && 2 * h.n_hess >= budget) p->auto_ml = true;
+          else if (p->auto_ml && coupled && 10 * h.n_hess <= budget) p->auto_ml = false;
+        }
+        res->success = 1;  // :44
+        res->elapsedMs = 1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        return DPGO_OK;
+      }
+      // a time-out (the launch's workgroups were not all resident: another process on the device): the caller's iterate is
+      // untouched; this handle stops using the kernel and the solve runs on the multi-launch scheme
+      p->persist_failed_once = true;
+      persist_release(p);
+      if (std::getenv("DPGO_PERSIST_VERBOSE"))
+        std::fprintf(stderr, "dpgo_hip: persistent solve timed out; this handle continues with the multi-launch scheme\n");
+    }
+  }
   // statistics before optimisation (:28-29) -- one fused pass: f, rgrad, S
   CHK(launch_grad(p, p->x1, p->g1, p->S1, nullptr));
   cnt.spmm += 1;
@@ -1379,10 +1418,6 @@ int run_optimize(dpgo_problem_s* p, const dpgo_ropt_params* prm, dpgo_ropt_resul
           CHK(push_state(p));
           p->saw_rtr_stop = false;
           CHK(rtr_outer_iteration(p, prm, dinv, cnt, true));
-          if (persist_recover()) {  // (push_state at the top of the loop re-installs the state)
-            shrink_tries -= 1;
-            continue;
-          }
           if (p->hstate->accepted_last) break;
           if (total_steps > 10) break;  // "Too many RTR rejections. Returning initial guess." (x1 untouched)
           radius /= 4.0;
@@ -1391,22 +1426,13 @@ int run_optimize(dpgo_problem_s* p, const dpgo_ropt_params* prm, dpgo_ropt_resul
       } else {
         const bool polling = prm->tcg_poll_interval > 0;
         p->saw_rtr_stop = false;
-        int it = 0;
-        while (true) {
-          for (; it < prm->RTR_iterations; ++it) {
-            CHK(rtr_outer_iteration(p, prm, dinv, cnt, polling));
-            if (polling ? (p->hstate->rtr_stop != 0) : p->saw_rtr_stop) break;
-            const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-            if (prm->time_bound_s > 0 && el > prm->time_bound_s) break;  // Solver.TimeBound (:78)
-          }
-          if (p->persist_reserved > 0)
-            HIPC(hipMemcpyAsync(p->hctrl, p->pctrl, sizeof(PersistCtrl), hipMemcpyDeviceToHost, p->stream));
-          CHK(poll_state(p));
-          if (!persist_recover()) break;
-          it = p->hstate->outer_iter;  // completed outer iterations; the rest runs on the two-kernel scheme
-          CHK(push_state(p));
-          p->cur = 0;
+        for (int it = 0; it < prm->RTR_iterations; ++it) {
+          CHK(rtr_outer_iteration(p, prm, dinv, cnt, polling));
+          if (polling ? (p->hstate->rtr_stop != 0) : p->saw_rtr_stop) break;
+          const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+          if (prm->time_bound_s > 0 && el > prm->time_bound_s) break;  // Solver.TimeBound (:78)
         }
+        CHK(poll_state(p));
         if (deferred) {
           res->fInit = p->hstate->fInit;
           res->gradNormInit = p->hstate->gnInit;
@@ -1551,7 +1577,7 @@ int tune_launch_caps(dpgo_problem_s* p) {
         CHK(resident_blocks(k_tcg_hess_span<D, R, 2>, &p->cap_h));
       else
         CHK(resident_blocks(k_tcg_hess_span<D, R, 1>, &p->cap_h));
-      CHK(resident_blocks(k_tcg_hess_sym<D, R>, &p->cap_hs));
+      CHK(resident_blocks(k_tcg_hess_sym<D, R, 1>, &p->cap_hs));
     } else {
       CHK(resident_blocks(k_tcg_update<D, R>, &p->cap_u));
       if (p->split == 4)
@@ -2659,6 +2685,15 @@ int dpgo_problem_set_spmm_variant(dpgo_problem_t p, int variant, int* in_use) {
   return DPGO_OK;
 }
 
+int dpgo_problem_tcg_kernel_info(dpgo_problem_t p, int* symmetric, int* split, int* stream_nt) {
+  CHK(check_ready(p));
+  CHK(resolve_tcg_storage(p));
+  if (symmetric) *symmetric = p->tcg_sym ? 1 : 0;
+  if (split) *split = p->tcg_sym ? 1 : p->split;
+  if (stream_nt) *stream_nt = (p->stream_nt && (p->tcg_sym || p->split == 1)) ? 1 : 0;
+  return DPGO_OK;
+}
+
 namespace {
 // rotating copies of the symmetric storage (values, column indices, references; the row pointers are shared)
 int bench_spmm_sym_rotating(dpgo_problem_s* p, int nsets, int reps, int warmup, double* avg_ms, double* set_bytes) {
@@ -2810,6 +2845,44 @@ int dpgo_bench_hess(dpgo_problem_t p, int reps, int warmup, double* avg_ms) {
   HIPC(hipEventDestroy(e0));
   HIPC(hipEventDestroy(e1));
   *avg_ms = (double)ms / reps;
+  return DPGO_OK;
+}
+
+int dpgo_bench_solve(dpgo_problem_t p, const dpgo_ropt_params* params, const double* X0_dev, int reps, int warmup,
+                     double* avg_ms, double* avg_products, int* persistent) {
+  CHK(check_ready(p));
+  if (reps <= 0 || !params || !X0_dev || !avg_ms) return fail(DPGO_ERR_INVALID, "bad arguments");
+  // every repetition solves from the same iterate (copied in outside the event pair)
+  hipEvent_t e0, e1;
+  HIPC(hipEventCreate(&e0));
+  HIPC(hipEventCreate(&e1));
+  double total = 0.0, products = 0.0;
+  bool all_persistent = true;
+  int rc = DPGO_OK;
+  for (int i = 0; i < warmup + reps && rc == DPGO_OK; ++i) {
+    rc = [&]() -> int {
+      HIPC(hipMemcpyAsync(p->x1, X0_dev, p->vec_bytes(), hipMemcpyDeviceToDevice, p->stream));
+      dpgo_ropt_result res;
+      HIPC(hipEventRecord(e0, p->stream));
+      CHK(run_optimize(p, params, &res));
+      HIPC(hipEventRecord(e1, p->stream));
+      HIPC(hipEventSynchronize(e1));
+      float ms = 0.f;
+      HIPC(hipEventElapsedTime(&ms, e0, e1));
+      if (i >= warmup) {
+        total += ms;
+        products += res.tcg_iterations;
+        all_persistent = all_persistent && p->hctrl && p->hctrl->members > 0 && !p->persist_failed_once;
+      }
+      return DPGO_OK;
+    }();
+  }
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  if (rc != DPGO_OK) return rc;
+  *avg_ms = total / reps;
+  if (avg_products) *avg_products = products / reps;
+  if (persistent) *persistent = all_persistent ? 1 : 0;
   return DPGO_OK;
 }
 

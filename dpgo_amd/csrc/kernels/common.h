@@ -164,6 +164,21 @@ __device__ __forceinline__ void wave_sync() {
 // (tools/stream_lab.hip: 6.1 -> 7.0 TB/s on streaming kernels); element-wise updates are done in
 // that "span layout" and only the per-pose coupling uses the lane = (pose, column) layout.
 typedef double dbl2 __attribute__((ext_vector_type(2)));
+// Operands a tCG-step kernel touches exactly once per launch (own-tile X, delta, H delta, S): with NTS = 1 they move as
+// non-temporal accesses, so that the lines the gather re-uses (Q blocks referenced from later rows, z of graph neighbours)
+// are not pushed out of the XCD's 4 MiB L2 by them.  Pays when the launch is fed from HBM (100k poses, every operand
+// rotating: symmetric storage 48.0 -> 41.2 us, plain 48.1 -> 45.8; 1M poses: 354 -> 332 us); costs when the working set
+// sits in the Infinity Cache (100k back-to-back: 33.7 -> 37.4 us), so the host selects it by size (stream_nt).
+template <int NTS, typename T>
+__device__ __forceinline__ T ld_stream(const T* p) {
+  if constexpr (NTS) return __builtin_nontemporal_load(p);
+  else return *p;
+}
+template <int NTS, typename T>
+__device__ __forceinline__ void st_stream(T* p, T v) {
+  if constexpr (NTS) __builtin_nontemporal_store(v, p);
+  else *p = v;
+}
 template <int D, int R, int SPLIT>
 struct Span {
   using GEO = Geo<D, R, SPLIT>;
@@ -331,6 +346,44 @@ __device__ __forceinline__ void jacobi_col(const double* vs /* LDS tile */, cons
     const double dk = dinv_row[k];
 #pragma unroll
     for (int a = 0; a < R; ++a) z[a] = fma(vs[k * R + a], dk, z[a]);
+  }
+}
+
+// Column c of the qf retraction of one pose (ROPTLIB Stiefel::qfRetraction: Q factor of the thin QR of the r x d block
+// with diag(R) > 0, by modified Gram-Schmidt): as = the pose's tile [col][R] in LDS holding Y + eta; lane c < D rebuilds
+// q_0 .. q_c (identical arithmetic in all lanes of the pose) and returns q_c in a; the Euclidean column (c = D) keeps a.
+template <int D, int R>
+__device__ __forceinline__ void qf_col(const double* as, int c, double (&a)[R]) {
+  if (c < D) {
+    double q[D][R];
+#pragma unroll
+    for (int k = 0; k < D; ++k) {
+      if (k <= c) {
+        double v[R];
+#pragma unroll
+        for (int t = 0; t < R; ++t) v[t] = as[k * R + t];
+#pragma unroll
+        for (int l = 0; l < D; ++l) {
+          if (l < k) {
+            double dp = 0.0;
+#pragma unroll
+            for (int t = 0; t < R; ++t) dp = fma(q[l][t], v[t], dp);
+#pragma unroll
+            for (int t = 0; t < R; ++t) v[t] = fma(-dp, q[l][t], v[t]);
+          }
+        }
+        double nn = 0.0;
+#pragma unroll
+        for (int t = 0; t < R; ++t) nn = fma(v[t], v[t], nn);
+        const double inv = 1.0 / sqrt(nn);
+#pragma unroll
+        for (int t = 0; t < R; ++t) q[k][t] = v[t] * inv;
+        if (k == c) {
+#pragma unroll
+          for (int t = 0; t < R; ++t) a[t] = q[k][t];
+        }
+      }
+    }
   }
 }
 

@@ -78,37 +78,7 @@ __global__ __launch_bounds__(kBlock) void k_retract(const double* __restrict__ X
     }
     wave_sync();
     if (ok) {
-      if (L.c < D) {
-        double q[D][R];
-#pragma unroll
-        for (int k = 0; k < D; ++k) {
-          if (k <= L.c) {
-            double v[R];
-#pragma unroll
-            for (int t = 0; t < R; ++t) v[t] = as[k * R + t];
-#pragma unroll
-            for (int l = 0; l < D; ++l) {
-              if (l < k) {
-                double dp = 0.0;
-#pragma unroll
-                for (int t = 0; t < R; ++t) dp = fma(q[l][t], v[t], dp);
-#pragma unroll
-                for (int t = 0; t < R; ++t) v[t] = fma(-dp, q[l][t], v[t]);
-              }
-            }
-            double nn = 0.0;
-#pragma unroll
-            for (int t = 0; t < R; ++t) nn = fma(v[t], v[t], nn);
-            const double inv = 1.0 / sqrt(nn);
-#pragma unroll
-            for (int t = 0; t < R; ++t) q[k][t] = v[t] * inv;
-            if (k == L.c) {
-#pragma unroll
-              for (int t = 0; t < R; ++t) a[t] = q[k][t];
-            }
-          }
-        }
-      }
+      qf_col<D, R>(as, L.c, a);
       store_col<R>(X2 + off, a);
     }
     wave_sync();

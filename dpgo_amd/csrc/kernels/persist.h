@@ -45,7 +45,7 @@ __device__ __forceinline__ void sleep_units(int n) {
   for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(1);
 }
 constexpr int kPersistMax = kBlock;        // participants (workgroups) of one launch
-constexpr int kGranVals = 2;               // partial sums per all-reduce (max)
+constexpr int kGranVals = 4;               // partial sums per all-reduce (max)
 constexpr int kGranRows = 2 * kGranVals;   // 8-byte words per participant: {epoch, low half}, {epoch, high half} per value
 // granule table: [2 buffers][kGranRows][kPersistMax] words -- a row is contiguous over the participants, so a sweep is
 // kGranRows coalesced loads per 64 participants
@@ -271,10 +271,9 @@ __device__ __forceinline__ void gather_finish(const GatherOps<D, R, SPLIT, QRES>
   }
 }
 
-// MT = tiles (of Geo::P poses) a workgroup owns: tile = rank + k * members, k < MT.  Resident slots (the host reserves
-// against 2 per CU): the (SPLIT = 4, MT = 1) variant fits two workgroups per CU (<= 256 registers) and costs one slot per
-// workgroup; the others keep up to 512 registers per lane (one workgroup per CU) and cost two.
-constexpr int persist_slots_per_wg(int split, int mt, bool add = false) { return (split == 4 && mt == 1 && !add) ? 1 : 2; }
+// MT = tiles (of Geo::P poses) a workgroup owns: tile = rank + k * members, k < MT.  Every variant keeps up to 512
+// registers per lane, i.e. one workgroup per CU; the host reserves resident slots accordingly (2 of the 2 per CU).
+constexpr int persist_slots_per_wg(int, int, bool = false) { return 2; }
 
 // ADD: the preconditioner is the ADDITIVE two-level combination  z = proj_X( w Dinv r + P A_c^-1 P^T r )  on the handle's
 // two-level hierarchy with ONE aggregate per workgroup tile (k = Geo::P): block-Jacobi plus the coarse-grid correction of
@@ -292,20 +291,36 @@ struct AddDev {
   double w;            // weight of the block-Jacobi term
 };
 
+// Trust-region parameters of a solve (src/QuadraticOptimizer.cpp:64-78)
+struct RtrArgs {
+  double tol, Delta0, Delta_max;
+  int max_inner, max_outer, accept_tiny;
+};
+
+// THE WHOLE SOLVE in one launch (QuadraticOptimizer::optimize, src/QuadraticOptimizer.cpp:26-108; ROPTLIB SolversTR::Run):
+// cost and gradient at the initial iterate, then per outer iteration the tCG loop above, the retraction, cost / gradient
+// at the trial point, the model decrease (H eta), the rho test and the radius update -- k_grad, k_rtr_begin, k_retract,
+// k_hess and k_rtr_update of the multi-launch scheme, same arithmetic, evaluated on the registers / LDS tiles the tCG
+// loop already holds.  Between workgroups travel, besides z: the trial point x2 and the step eta (write-through, gathered
+// for x2 Q and eta Q); their dot products ride on two more reductions per outer iteration.  X is read at the start and
+// written back once at the end (only then: a launch that times out leaves the caller's iterate untouched, the host reruns
+// the solve with the multi-launch scheme).  The host's part of a solve: one launch, one 200-byte read-back.
 template <int D, int R, int SPLIT, int MT, bool ADD = false>
-__global__ __launch_bounds__(kBlock, 3 - persist_slots_per_wg(SPLIT, MT, ADD)) void k_tcg_persist(BsrDev Q, const double* __restrict__ X,
-                                                        const double* __restrict__ S, const double* __restrict__ g,
-                                                        const double* __restrict__ dinv, double* __restrict__ eta, double* z,
-                                                        unsigned long long* gran, unsigned salt,
-                                                        const DevState* __restrict__ sin, DevState* __restrict__ sout,
-                                                        PersistCtrl* ctrl, int n, unsigned long long* hflag, unsigned gen,
-                                                        int poll, AddDev add) {
+__global__ __launch_bounds__(kBlock, 1) void k_rtr_persist(BsrDev Q, double* X, const double* __restrict__ Glin,
+                                                           const double* __restrict__ dinv, double* xbuf, double* ebuf,
+                                                           double* z, unsigned long long* gran, unsigned salt,
+                                                           DevState* __restrict__ sout, PersistCtrl* ctrl, int n,
+                                                           unsigned long long* hflag, unsigned gen, int poll, RtrArgs ra,
+                                                           AddDev add) {
   using GEO = Geo<D, R, SPLIT>;
   constexpr int P = GEO::P, G = GEO::G, T = GEO::T, B = GEO::B, BB = GEO::BB;
   static_assert(!ADD || MT == 1, "additive preconditioner: one aggregate = one tile per workgroup");
-  // resident in LDS: the poses' X (projections need all rotation columns of a pose) and z (Hessian correction);
-  // ex: two wave-private exchange tiles (the columns of one pose meet here)
+  // resident in LDS: the poses' X (projections need all rotation columns of a pose) and z (Hessian correction; after the
+  // tCG loop the same tiles hold the trial point x2); ex: two wave-private exchange tiles (the columns of one pose meet here)
   __shared__ __attribute__((aligned(16))) double Xs[MT][P][T], Zs[MT][P][T];
+  // Riemannian gradient at the current iterate and at the trial point (touched once per outer iteration, each lane its own
+  // column: kept out of the registers the tCG loop needs)
+  __shared__ __attribute__((aligned(16))) double G1s[MT][P][T], G2s[MT][P][T];
   __shared__ __attribute__((aligned(16))) double ex[2][kWaves][G][T];
   __shared__ double red[2 * 2 * kWaves * kGranVals];
   __shared__ int ok_s;
@@ -317,23 +332,6 @@ __global__ __launch_bounds__(kBlock, 3 - persist_slots_per_wg(SPLIT, MT, ADD)) v
   const int rank = blockIdx.x, members = gridDim.x;
   if (threadIdx.x == 0) ok_s = 1;  // (ordered before its first use by the barriers of the first all-reduce)
   DevState st;
-  load_state(st, sin);
-  if (st.rtr_stop) {
-    if (rank == 0 && threadIdx.x == 0) {
-      store_state(sout, st);
-      publish_progress(hflag, gen, st);
-    }
-    return;
-  }
-  if (__hip_atomic_load(&ctrl->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
-    // an earlier launch of this solve timed out (the word is cleared once per solve): hand the poisoned state on
-    if (rank == 0 && threadIdx.x == 0) {
-      st.rtr_stop = 3;
-      store_state(sout, st);
-      publish_progress(hflag, gen, st);
-    }
-    return;
-  }
   unsigned step = 0;
   const LaneId L = lane_id<D, SPLIT>();
   const int lp = L.wave * G + L.g;  // pose slot inside a workgroup tile
@@ -348,6 +346,9 @@ __global__ __launch_bounds__(kBlock, 3 - persist_slots_per_wg(SPLIT, MT, ADD)) v
   // the resident form of the same instance agree to 4e-14; tools/diag_layout.py)
   constexpr bool QRES = (SPLIT > 1) || (MT == 1) || (D == 2);
   const __amdgpu_buffer_rsrc_t rz = vec_rsrc(z, (size_t)n * T * sizeof(double));
+  const __amdgpu_buffer_rsrc_t rX = vec_rsrc(X, (size_t)n * T * sizeof(double));
+  const __amdgpu_buffer_rsrc_t rx2 = vec_rsrc(xbuf, (size_t)n * T * sizeof(double));
+  const __amdgpu_buffer_rsrc_t reta = vec_rsrc(ebuf, (size_t)n * T * sizeof(double));
   using GG = GatherGeo<D, SPLIT>;
   GatherOps<D, R, SPLIT, QRES> go[MT];
   int pose[MT];
@@ -369,14 +370,7 @@ __global__ __launch_bounds__(kBlock, 3 - persist_slots_per_wg(SPLIT, MT, ADD)) v
     if (own[k]) {
       const size_t off = (size_t)pose[k] * T + co;
 #pragma unroll
-      for (int a = 0; a < R; ++a) {
-        Xs[k][lp][co + a] = X[off + a];
-        rr[k][a] = g[off + a];  // r0 = g
-      }
-      if (L.c < D) {
-#pragma unroll
-        for (int a = 0; a < D; ++a) srow[k][a] = S[(size_t)pose[k] * D * D + L.c * D + a];
-      }
+      for (int a = 0; a < R; ++a) Xs[k][lp][co + a] = X[off + a];
       if (dinv) {
 #pragma unroll
         for (int a = 0; a < B; ++a) drow[k][a] = dinv[(size_t)pose[k] * BB + L.c * B + a];
@@ -641,14 +635,139 @@ __global__ __launch_bounds__(kBlock, 3 - persist_slots_per_wg(SPLIT, MT, ADD)) v
     }
   };
 
+  // ---- publish a pose tile to the other workgroups (write-through): even tile sizes leave as the wave's contiguous span
+  // of lane-linear 16-byte pieces read from its LDS copy `wave_tile` ([G][T], already written by the pose's lanes), odd
+  // ones column by column from registers
+  auto publish_tile = [&](double* gbuf, __amdgpu_buffer_rsrc_t rs, const double* wave_tile, int tile, int k,
+                          const double (&col)[R]) {
+    if constexpr (T % 2 == 0) {
+      wave_sync();
+      const int p0w = tile * P + L.wave * G;
+      const int npose = (n - p0w) < G ? (n - p0w) : G;
+      const int pieces = npose > 0 ? npose * (T / 2) : 0;
+      const dbl2* span = reinterpret_cast<const dbl2*>(wave_tile);
+#pragma unroll
+      for (int it = 0; it < (G * (T / 2) + 63) / 64; ++it) {
+        const int pc = (int)(threadIdx.x & 63) + 64 * it;
+        if (pc < pieces) {
+          const dbl2 v = span[pc];
+          u32x4 w;
+          w.x = (unsigned)__double2loint(v.x);
+          w.y = (unsigned)__double2hiint(v.x);
+          w.z = (unsigned)__double2loint(v.y);
+          w.w = (unsigned)__double2hiint(v.y);
+          __builtin_amdgcn_raw_buffer_store_b128(w, rs, (p0w * T + 2 * pc) * 8, 0, kAuxSc1);
+        }
+      }
+    } else {
+      if (own[k]) {
+        const size_t off = (size_t)pose[k] * T + co;
+#pragma unroll
+        for (int a = 0; a < R; ++a) st_agent(gbuf + off + a, col[a]);
+      }
+    }
+  };
+
+  // ---- cost and Riemannian gradient (k_grad) at the point whose tiles are in LDS (Yt) and in memory behind `ry`:
+  // partials [0] sum(YQ . Y)  [1] sum(Y . G)  [2] |rgrad|^2; rg = the gradient's own column, s = this lane's row of
+  // S = sym(Y^T EG) (ROPTLIB caches it for the Hessian)
+  auto phase_grad = [&](__amdgpu_buffer_rsrc_t ry, const double (&Yt)[MT][P][T], double (&part)[3], double (&rg)[MT][P][T],
+                        double (&sr)[MT][D]) {
+    part[0] = part[1] = part[2] = 0.0;
+#pragma unroll
+    for (int k = 0; k < MT; ++k) {
+      double eg[R];
+      {
+        double xc[GG::NB][R], qc[GG::NB][B];
+        gather_issue<D, R, SPLIT, QRES>(go[k], Q, ry, L.s, L.c, xc, qc);
+        gather_finish<D, R, SPLIT, QRES>(go[k], Q, ry, L.s, L.c, xc, qc, eg);
+      }
+      if (rank + k * members >= ntiles) continue;  // workgroup-uniform (the gather above is wave-cooperative)
+      double* xt = &ex[k & 1][L.wave][L.g][0];
+      if (own[k]) {
+        const size_t off = (size_t)pose[k] * T + co;
+#pragma unroll
+        for (int a = 0; a < R; ++a) {
+          const double xv = Yt[k][lp][co + a];
+          part[0] = fma(eg[a], xv, part[0]);
+          if (Glin) {
+            const double gv = Glin[off + a];
+            part[1] = fma(xv, gv, part[1]);
+            eg[a] += gv;
+          }
+        }
+        store_col<R>(xt + co, eg);
+      }
+      wave_sync();
+      if (own[k]) {
+        double out[R], s[D];
+        proj_col<D, R>(&Yt[k][lp][0], xt, L.c, eg, out, s);
+#pragma unroll
+        for (int a = 0; a < R; ++a) {
+          part[2] = fma(out[a], out[a], part[2]);
+          rg[k][lp][co + a] = out[a];
+        }
+#pragma unroll
+        for (int a = 0; a < D; ++a) sr[k][a] = s[a];
+      }
+    }
+    wave_sync();  // (ex is free again)
+  };
+
+  // ==== QuadraticOptimizer::optimize: statistics at the initial iterate (k_grad + k_rtr_begin)
+  bool alive = true;
+  {
+    double p3[3];
+    phase_grad(rX, Xs, p3, G1s, srow);
+    alive = chip_allreduce<3>(gran, rank, members, salt, step, p3, red, &ctrl->error, &ok_s, poll);
+    st.f1 = 0.5 * p3[0] + p3[1];
+    st.ngf = sqrt(p3[2]);
+    st.Delta = ra.Delta0;
+    st.Delta_max = ra.Delta_max;
+    st.tol = ra.tol;
+    st.f2 = st.f1;
+    st.rho = 0.0;
+    st.fInit = st.f1;
+    st.gnInit = st.ngf;
+    st.xqx = p3[0];
+    st.xg = p3[1];
+    st.outer_iter = 0;
+    st.rtr_stop = (st.ngf < ra.tol) ? 1 : 0;
+    st.accepted_last = 0;
+    st.n_accept = 0;
+    st.accept_tiny = ra.accept_tiny;
+    st.pad0 = 0;
+    st.z_r = st.d_Pd = st.e_Pd = st.e_Pe = st.norm_r0 = st.alpha = st.d_Hd = 0.0;
+    st.theta = 1.0;  // ROPTLIB RTRNewton defaults (SURVEY 8c' item 4)
+    st.kappa = 0.1;
+    st.tcg_j = 0;
+    st.tcg_done = 0;
+    st.tcg_status = TCG_MAXITER;
+    st.max_inner = ra.max_inner;
+    st.n_hess = 0;
+    st.min_inner = 0;
+  }
+  unsigned iters = 0;
+  unsigned long long tk[5] = {0, 0, 0, 0, 0};
+  bool moved = false;  // an accepted step: X has to be written back
+
+  // ==== SolversTR::Run: outer iterations
+  while (alive && !st.rtr_stop && st.outer_iter < ra.max_outer) {
   // ---- tCG_TR (ROPTLIB): the scalar logic of tcg_update_prologue / tcg_hess_prologue, evaluated redundantly (and
   // identically: same partials, same summation order) by every participant
+#pragma unroll
+  for (int k = 0; k < MT; ++k) {
+#pragma unroll
+    for (int a = 0; a < R; ++a) {
+      rr[k][a] = own[k] ? G1s[k][lp][co + a] : 0.0;  // r0 = g
+      ee[k][a] = dl[k][a] = hd[k][a] = 0.0;
+    }
+  }
   st.tcg_done = 0;
   st.tcg_j = 0;
   st.tcg_status = TCG_MAXITER;
   st.e_Pe = 0.0;
   st.e_Pd = 0.0;
-  bool alive = true;
   double pr[2];
   // residual update + preconditioner + the reduction(s) that carry <r,r>, <z,r>: one all-reduce with block-Jacobi / no
   // preconditioner, two (the restricted residual becomes visible with the first) with the additive two-level one
@@ -680,8 +799,6 @@ __global__ __launch_bounds__(kBlock, 3 - persist_slots_per_wg(SPLIT, MT, ADD)) v
   }
   double beta = 0.0;
   bool first = true;
-  unsigned iters = 0;
-  unsigned long long tk[5] = {0, 0, 0, 0, 0};
   while (alive && !st.tcg_done) {
     const unsigned long long t0 = wall_clock64();
     double dh[1];
@@ -737,30 +854,141 @@ __global__ __launch_bounds__(kBlock, 3 - persist_slots_per_wg(SPLIT, MT, ADD)) v
     }
     first = false;
   }
-  // the step eta leaves the launch (the retraction and the model decrease read it); r, delta, H delta die here
+  if (!alive) break;
+
+  // ---- retraction x2 = R_x1(eta) (k_retract: qf of Y + eta, p + eta); x2 and eta are published for the two gathers
+  // below; the x2 tiles take the place of z in LDS (z is dead until the next tCG run)
+  double p1[1] = {0.0};  // <eta, g1>
 #pragma unroll
   for (int k = 0; k < MT; ++k) {
+    if (rank + k * members >= ntiles) break;  // workgroup-uniform
+    double a2[R];
     if (own[k]) {
-      const size_t off = (size_t)pose[k] * T + co;
 #pragma unroll
-      for (int a = 0; a < R; ++a) eta[off + a] = ee[k][a];
+      for (int a = 0; a < R; ++a) {
+        a2[a] = Xs[k][lp][co + a] + ee[k][a];
+        p1[0] = fma(ee[k][a], G1s[k][lp][co + a], p1[0]);
+      }
+      store_col<R>(&ex[0][L.wave][L.g][co], a2);
+    }
+    wave_sync();
+    if (own[k]) {
+      qf_col<D, R>(&ex[0][L.wave][L.g][0], L.c, a2);
+      store_col<R>(&Zs[k][lp][co], a2);
+      store_col<R>(&ex[1][L.wave][L.g][co], ee[k]);
+    }
+    publish_tile(xbuf, rx2, &Zs[k][L.wave * G][0], rank + k * members, k, a2);
+    publish_tile(ebuf, reta, &ex[1][L.wave][0][0], rank + k * members, k, ee[k]);
+    wave_sync();  // ex of the next tile is rewritten only after this tile's reads
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // acknowledged before the reduction publishes
+  if (!(alive = chip_allreduce<1>(gran, rank, members, salt, step, p1, red, &ctrl->error, &ok_s, poll))) break;
+  const double eta_g = p1[0];
+
+  // ---- cost / gradient at the trial point, and H eta = proj_x1(eta Q - eta_rot S1) for the model decrease (k_hess)
+  double s2[MT][D], p4[4];
+  {
+    double p3[3];
+    phase_grad(rx2, Zs, p3, G2s, s2);
+    p4[0] = p3[0];
+    p4[1] = p3[1];
+    p4[2] = p3[2];
+    p4[3] = 0.0;
+  }
+#pragma unroll
+  for (int k = 0; k < MT; ++k) {
+    double h[R];
+    {
+      double xc[GG::NB][R], qc[GG::NB][B];
+      gather_issue<D, R, SPLIT, QRES>(go[k], Q, reta, L.s, L.c, xc, qc);
+      gather_finish<D, R, SPLIT, QRES>(go[k], Q, reta, L.s, L.c, xc, qc, h);
+    }
+    if (rank + k * members >= ntiles) continue;
+    if (own[k]) store_col<R>(&ex[0][L.wave][L.g][co], ee[k]);  // the pose's columns of eta
+    wave_sync();
+    if (own[k]) {
+      if (L.c < D) {
+#pragma unroll
+        for (int a = 0; a < D; ++a) {
+#pragma unroll
+          for (int q = 0; q < R; ++q) h[q] = fma(-ex[0][L.wave][L.g][a * R + q], srow[k][a], h[q]);
+        }
+      }
+      store_col<R>(&ex[1][L.wave][L.g][co], h);
+    }
+    wave_sync();
+    if (own[k]) {
+      double hz[R], s[D];
+      proj_col<D, R>(&Xs[k][lp][0], &ex[1][L.wave][L.g][0], L.c, h, hz, s);
+#pragma unroll
+      for (int a = 0; a < R; ++a) p4[3] = fma(ee[k][a], hz[a], p4[3]);
+    }
+    wave_sync();
+  }
+  if (!(alive = chip_allreduce<4>(gran, rank, members, salt, step, p4, red, &ctrl->error, &ok_s, poll))) break;
+
+  // ---- rho test, radius update, acceptance (k_rtr_update; identical in every workgroup)
+  {
+    const double f2 = 0.5 * p4[0] + p4[1];
+    const double ngf2 = sqrt(p4[2]);
+    const double eta_Heta = p4[3];
+    const double rho = (st.f1 - f2) / (-(eta_g + 0.5 * eta_Heta));
+    if (rho > 0.75) {
+      if (st.tcg_status == TCG_EXCREGION || st.tcg_status == TCG_NEGCURV) st.Delta *= 2.0;
+      if (st.Delta > st.Delta_max) st.Delta = st.Delta_max;
+    } else if (rho < 0.25) {
+      st.Delta *= 0.25;
+    }
+    const double sqeps = 1.4901161193847656e-08;  // sqrt(DBL_EPSILON)
+    bool accept = rho > 0.1;
+    if (!accept && st.accept_tiny) accept = (fabs(st.f1 - f2) / (fabs(st.f1) + 1.0) < sqeps) && (f2 < st.f1);
+    st.f2 = f2;
+    st.rho = rho;
+    st.accepted_last = accept ? 1 : 0;
+    st.outer_iter += 1;
+    if (accept) {
+      st.f1 = f2;
+      st.ngf = ngf2;
+      st.n_accept += 1;
+      st.rtr_stop = (ngf2 < st.tol) ? 1 : 0;
+      st.xqx = p4[0];
+      st.xg = p4[1];
+      moved = true;
+#pragma unroll
+      for (int k = 0; k < MT; ++k) {
+        if (own[k]) {
+#pragma unroll
+          for (int a = 0; a < R; ++a) {
+            Xs[k][lp][co + a] = Zs[k][lp][co + a];    // x1 <- x2
+            G1s[k][lp][co + a] = G2s[k][lp][co + a];  // g1 <- g2
+          }
+#pragma unroll
+          for (int a = 0; a < D; ++a) srow[k][a] = s2[k][a];  // S1 <- S2
+        }
+      }
+      wave_sync();
+    }
+  }
+  }  // outer iterations
+
+  // ==== hand the result back: the iterate (own columns; nothing was written while the solve could still fail) and
+  // the state record
+  const bool good = alive && !__hip_atomic_load(&ctrl->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (good && moved) {
+#pragma unroll
+    for (int k = 0; k < MT; ++k) {
+      if (own[k]) {
+        const size_t off = (size_t)pose[k] * T + co;
+#pragma unroll
+        for (int a = 0; a < R; ++a) X[off + a] = Xs[k][lp][co + a];
+      }
     }
   }
   if (rank == 0 && threadIdx.x == 0) {
-    // a participant that passed every all-reduce of the run saw everybody's granules of the last step, so nobody can
-    // still fail: the error flag is final here
-    if (alive && !__hip_atomic_load(&ctrl->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
-      store_state(sout, st);
-      publish_progress(hflag, gen, st);
-    } else {
-      // time-out: hand the UNCHANGED state on, poisoned, so that every kernel enqueued behind this launch exits and the
-      // host resumes from this state with the two-kernel scheme (kPersistPoison in dpgo_hip.hip)
-      DevState s0;
-      load_state(s0, sin);
-      s0.rtr_stop = 3;
-      store_state(sout, s0);
-      publish_progress(hflag, gen, s0);
-    }
+    if (!good) st.rtr_stop = 3;  // time-out: poisoned record; X is untouched and the host reruns the solve (kPersistPoison)
+    store_state(sout, st);
+    store_state(sout + 1, st);
+    publish_progress(hflag, gen, st);
     ctrl->iters += iters;  // (zeroed by the host once per solve)
     ctrl->members = (unsigned)members;
 #pragma unroll

@@ -196,7 +196,7 @@ __global__ __launch_bounds__(kBlock, DPGO_LB_HESS) void k_tcg_hess(BsrDev Q, con
 //  * the FIRST tile's global loads (row pointer, column indices, vector pieces) are issued before the scalar
 //    prologue (state record + partial-sum reduction), so the two dependent-latency chains overlap -- this is
 //    what matters for small blocks (multi-GPU strong scaling), where a kernel is a chain of ~15 memory latencies.
-template <int D, int R, int SPLIT>
+template <int D, int R, int SPLIT, int NTS = 0>
 __global__ __launch_bounds__(kBlock) void k_tcg_hess_span(BsrDev Q, const double* __restrict__ X,
                                                           const double* __restrict__ S, const double* __restrict__ z,
                                                           double* __restrict__ delta, double* __restrict__ Hd,
@@ -240,17 +240,17 @@ __global__ __launch_bounds__(kBlock) void k_tcg_hess_span(BsrDev Q, const double
     for (int it = 0; it < SPN::NIT; ++it) {
       const int pc = lane + 64 * it;
       if (2 * pc < valid) {
-        xv[it] = X2[pc];
+        xv[it] = ld_stream<NTS>(X2 + pc);
         zv[it] = z2[pc];
         if (!first) {
-          dv[it] = d2[pc];
-          hv[it] = h2[pc];
+          dv[it] = ld_stream<NTS>(d2 + pc);
+          hv[it] = ld_stream<NTS>(h2 + pc);
         }
       }
     }
     if (ok && L.c < D) {
 #pragma unroll
-      for (int a = 0; a < D; ++a) srow[a] = S[(size_t)i * D * D + L.c * D + a];
+      for (int a = 0; a < D; ++a) srow[a] = ld_stream<NTS>(S + (size_t)i * D * D + L.c * D + a);
     }
   };
   // ---- everything the prologue needs is requested before the first wait: state record (scalar loads), the
@@ -339,8 +339,8 @@ __global__ __launch_bounds__(kBlock) void k_tcg_hess_span(BsrDev Q, const double
             hn.x = fma(beta, hv[it].x, -hzv.x);
             hn.y = fma(beta, hv[it].y, -hzv.y);
           }
-          d2[pc] = dn;
-          h2[pc] = hn;
+          st_stream<NTS>(d2 + pc, dn);
+          st_stream<NTS>(h2 + pc, hn);
           part[0] = fma(dn.x, hn.x, part[0]);
           part[0] = fma(dn.y, hn.y, part[0]);
         }
@@ -360,7 +360,7 @@ __global__ __launch_bounds__(kBlock) void k_tcg_hess_span(BsrDev Q, const double
 // k_tcg_hess_span on the symmetric storage of Q (spmm_sym_pre, common.h): big blocks only (one pose per D+1 lanes).  The
 // own-tile pieces of delta / H delta are requested after the gather instead of one tile ahead and z is re-read from LDS, so
 // that the outer-product accumulators fit without losing an occupancy step.
-template <int D, int R>
+template <int D, int R, int NTS>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(DPGO_SYM_WAVES, DPGO_SYM_WAVES))) void k_tcg_hess_sym(BsrSymDev Q, const double* __restrict__ X,
                                                           const double* __restrict__ S, const double* __restrict__ z,
                                                           double* __restrict__ delta, double* __restrict__ Hd,
@@ -403,13 +403,13 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(DPGO_SYM
     for (int it = 0; it < SPN::NIT; ++it) {
       const int pc = lane + 64 * it;
       if (2 * pc < valid) {
-        xv[it] = X2[pc];
+        xv[it] = ld_stream<NTS>(X2 + pc);
         zv[it] = z2[pc];
       }
     }
     if (ok && L.c < D) {
 #pragma unroll
-      for (int a = 0; a < D; ++a) srow[a] = S[(size_t)i * D * D + L.c * D + a];
+      for (int a = 0; a < D; ++a) srow[a] = ld_stream<NTS>(S + (size_t)i * D * D + L.c * D + a);
     }
   };
   // ---- everything the prologue needs is requested before the first wait: state record (scalar loads), the
@@ -467,8 +467,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(DPGO_SYM
       for (int it = 0; it < SPN::NIT; ++it) {
         const int pc = lane + 64 * it;
         if (2 * pc < valid) {
-          dv[it] = d2[pc];
-          hv[it] = h2[pc];
+          dv[it] = ld_stream<NTS>(d2 + pc);
+          hv[it] = ld_stream<NTS>(h2 + pc);
         }
       }
     }
@@ -514,8 +514,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(DPGO_SYM
             hn.x = fma(beta, hv[it].x, -hzv.x);
             hn.y = fma(beta, hv[it].y, -hzv.y);
           }
-          d2[pc] = dn;
-          h2[pc] = hn;
+          st_stream<NTS>(d2 + pc, dn);
+          st_stream<NTS>(h2 + pc, hn);
           part[0] = fma(dn.x, hn.x, part[0]);
           part[0] = fma(dn.y, hn.y, part[0]);
         }

@@ -101,9 +101,11 @@ SIGNATURES = {
     "dpgo_problem_eval_terms_device": ([_P, _P, C.POINTER(_D), C.POINTER(_D), C.POINTER(_D)], _I),
     "dpgo_bench_spmm": ([_P, _I, _I, C.POINTER(_D)], _I),
     "dpgo_problem_set_spmm_variant": ([_P, _I, C.POINTER(_I)], _I),
+    "dpgo_problem_tcg_kernel_info": ([_P, C.POINTER(_I), C.POINTER(_I), C.POINTER(_I)], _I),
     "dpgo_bench_spmm_rotating": ([_P, _I, _I, _I, C.POINTER(_D), C.POINTER(_D)], _I),
     "dpgo_bench_hess_rotating": ([_P, _I, _I, _I, C.POINTER(_D)], _I),
     "dpgo_bench_hess": ([_P, _I, _I, C.POINTER(_D)], _I),
+    "dpgo_bench_solve": ([_P, C.POINTER(RoptParamsC), _P, _I, _I, C.POINTER(_D), C.POINTER(_D), C.POINTER(_I)], _I),
     "dpgo_bench_iteration_kernels": ([_P, _I, _I, _P], _I),
     "dpgo_manifold_project": ([_I, _I, _I, _P, _P, _I], _I),
     "dpgo_manifold_tangent_project": ([_I, _I, _I, _P, _P, _P, _I], _I),

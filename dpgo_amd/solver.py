@@ -423,6 +423,12 @@ class QuadraticProblem:
     def setPersistent(self, enable: bool = True) -> None:
         L.check(self._lib.dpgo_problem_set_persistent(self._h, int(enable)))
 
+    def tcgKernelInfo(self) -> dict:
+        """{"symmetric", "split", "stream_nt"}: the instance of the tCG-step kernel the next multi-launch solve runs."""
+        v = [C.c_int(0) for _ in range(3)]
+        L.check(self._lib.dpgo_problem_tcg_kernel_info(self._h, *[C.byref(x) for x in v]))
+        return dict(symmetric=bool(v[0].value), split=v[1].value, stream_nt=bool(v[2].value))
+
     def persistentInfo(self) -> dict:
         """{"enabled", "workgroups", "last_members", "last_iterations", "last_split", "last_tiles"}: last_members = 0
         means the last optimize call ran the two-kernel scheme; last_split = lane groups per pose, last_tiles = pose
@@ -614,6 +620,15 @@ class QuadraticOptimizer:
         L.check(p._lib.dpgo_optimize_device(p._h, C.byref(cp), L.ptr(X_dev), C.byref(cr)))
         self.result_ = ROPTResult.from_c(cr)
         return self.result_
+
+
+def bench_solve(optimizer, X0_dev, reps=20, warmup=3):
+    """HIP-event time of one whole local solve from X0_dev (C ABI dpgo_bench_solve): dict(ms, products, persistent)."""
+    p = optimizer.problem_
+    cp = optimizer.params_.to_c()
+    ms, prod, pers = C.c_double(0.0), C.c_double(0.0), C.c_int(0)
+    L.check(p._lib.dpgo_bench_solve(p._h, C.byref(cp), L.ptr(X0_dev), reps, warmup, C.byref(ms), C.byref(prod), C.byref(pers)))
+    return dict(ms=ms.value, products=prod.value, persistent=bool(pers.value))
 
 
 def _ptr_array(ptrs):

@@ -308,6 +308,12 @@ int dpgo_problem_eval_terms_device(dpgo_problem_t h, const double* X_dev, double
 #define DPGO_SPMM_PLAIN 1
 #define DPGO_SPMM_SYMMETRIC 2
 int dpgo_problem_set_spmm_variant(dpgo_problem_t h, int variant, int* in_use);
+/* Which instance of the tCG-step kernel the next solve launches (multi-launch scheme): symmetric = 1 -> k_tcg_hess_sym,
+ * else k_tcg_hess_span / k_tcg_hess with `split` lane groups per pose; stream_nt = 1 -> the instance whose single-use
+ * operands (own-tile X, delta, H delta, S) move as non-temporal accesses.  AUTO selects the symmetric storage and the
+ * non-temporal instance together when the tCG loop's working set -- Q, eight pose vectors and what the last solve's
+ * preconditioner streams -- exceeds the 256 MB Infinity Cache; DPGO_SPMM_SYMMETRIC / DPGO_STREAM_NT = 0 / 1 override. */
+int dpgo_problem_tcg_kernel_info(dpgo_problem_t h, int* symmetric, int* split, int* stream_nt);
 /* time `reps` back-to-back SpMM launches with HIP events on the handle's stream;
  * n_buffers >= 1 rotates that many (V, OUT) buffer pairs; returns average ms per launch */
 int dpgo_bench_spmm(dpgo_problem_t h, int reps, int warmup, double* avg_ms);
@@ -318,6 +324,13 @@ int dpgo_bench_spmm_rotating(dpgo_problem_t h, int nsets, int reps, int warmup, 
 /* same for the dominant kernel of a solve: the fused Q*X + Riemannian-Hessian kernel (one per tCG
  * iteration), on the solver's own buffers (iterate, cached S, search direction) */
 int dpgo_bench_hess(dpgo_problem_t h, int reps, int warmup, double* avg_ms);
+/* One whole local solve (QuadraticOptimizer::optimize, src/QuadraticOptimizer.cpp:26-48) per repetition, each from a copy
+ * of X0_dev taken outside the event pair; HIP events on the handle's stream around the solve.  For blocks in the latency
+ * regime a solve is ONE launch of k_rtr_persist (+ two memsets and a 200-byte read-back), so avg_ms is that kernel's
+ * launch duration; *persistent = 1 when every timed repetition ran that way.  avg_products = Hessian-vector products per
+ * solve. */
+int dpgo_bench_solve(dpgo_problem_t h, const dpgo_ropt_params* params, const double* X0_dev, int reps, int warmup,
+                     double* avg_ms, double* avg_products, int* persistent);
 /* As dpgo_bench_hess with every operand cycling through nsets private copies (see dpgo_bench_spmm_rotating). */
 int dpgo_bench_hess_rotating(dpgo_problem_t h, int nsets, int reps, int warmup, double* avg_ms);
 /* Average launch time of the other kernels of one preconditioned tCG iteration, each timed as `reps` back-to-back

@@ -45,11 +45,19 @@ def test_bench_prints_one_valid_json_line():
     rf = j["roofline"]
     assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12 and rf["achieved"] > 0
-    assert rf["warm"]["frac"] > 0 and rf["spmm_only"]["frac"] > 0  # frac = rotating (HBM-only), warm beside it
-    # the headline describes the kernel the timed loop launched: name, time and rate belong together
-    assert rf["spmm_storage_selected"] == "plain" and rf["kernel"].startswith("k_tcg_hess_span<3,5,4>")
+    assert rf["spmm_only"]["frac"] > 0
+    # the headline describes the kernel the timed loop launched: name, time and rate belong together.  A 720-pose block is
+    # in the latency regime: its solve is ONE launch of the persistent kernel, and the tCG-step kernel of the multi-launch
+    # scheme (frac = rotating / HBM-only, warm beside it) is reported next to it
+    assert rf["spmm_storage_selected"] == "plain" and rf["kernel"].startswith("k_rtr_persist<3,5,")
     assert abs(rf["achieved"] - rf["bytes_per_launch"] / rf["avg_launch_us"] / 1e3) < 1e-9 * rf["achieved"]
-    assert abs(rf["warm"]["achieved"] - rf["bytes_per_launch"] / rf["warm"]["avg_launch_us"] / 1e3) < 1e-9 * rf["achieved"]
+    assert rf["products_per_launch"] > 0
+    assert abs(rf["us_per_product"] - rf["avg_launch_us"] / rf["products_per_launch"]) < 1e-9 * rf["us_per_product"]
+    ml = rf["multi_launch_kernel"]
+    assert ml["kernel"].startswith("k_tcg_hess_span<3,5,4,0>") and ml["warm"]["frac"] > 0
+    assert abs(ml["achieved"] - ml["bytes_per_launch"] / ml["avg_launch_us"] / 1e3) < 1e-9 * ml["achieved"]
+    assert abs(ml["warm"]["achieved"] - ml["bytes_per_launch"] / ml["warm"]["avg_launch_us"] / 1e3) < 1e-9 * ml["achieved"]
+    assert abs(rf["bytes_per_launch"] - rf["products_per_launch"] * ml["bytes_per_launch"]) < 1e-6 * rf["bytes_per_launch"]
     assert rf["symmetric_storage"] is None  # (this small block cannot run the symmetric kernels: 4 lane groups per pose)
     assert j["products_per_step"] > 0 and j["time_to_tolerance_ms"] > 0 and j["products_to_tolerance"] > 0
     assert [k["kernel"].split()[0].rstrip(",") for k in rf["kernels"]] == ["k_tcg_update", "k_ml_restrict",

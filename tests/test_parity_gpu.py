@@ -231,6 +231,7 @@ def test_feed_modes_and_single_iteration_radius_shrink(oracle):
     om, n, d, Q, pg, prob = build_single_agent(oracle, "sphere2500", 5)
     X0 = tiles_to_matrix(oracle.lift(oracle.chordal_initialization(om, n), 5))
     outs = []
+    prob.setPersistent(False)  # the two feeds of the multi-launch scheme (a block this size otherwise solves in one launch)
     for poll in (0, 1, 8):
         opt = dpgo_amd.QuadraticOptimizer(prob, dpgo_amd.ROptParameters(precond="jacobi", tcg_poll_interval=poll))
         outs.append((opt.optimize(X0), opt.getOptResult()))
@@ -238,6 +239,14 @@ def test_feed_modes_and_single_iteration_radius_shrink(oracle):
         assert np.array_equal(X, outs[0][0])
         assert (res.tcg_iterations, res.rtr_iterations, res.fOpt) == (outs[0][1].tcg_iterations,
                                                                       outs[0][1].rtr_iterations, outs[0][1].fOpt)
+    # ... and the one-launch solve (k_rtr_persist): same algorithm, its own summation order
+    prob.setPersistent(True)
+    opt = dpgo_amd.QuadraticOptimizer(prob, dpgo_amd.ROptParameters(precond="jacobi"))
+    Xp, resp = opt.optimize(X0), opt.getOptResult()
+    assert prob.persistentInfo()["last_members"] > 0
+    assert (resp.tcg_iterations, resp.rtr_iterations) == (outs[0][1].tcg_iterations, outs[0][1].rtr_iterations)
+    assert abs(resp.fOpt - outs[0][1].fOpt) <= 1e-9 * abs(outs[0][1].fOpt)
+    assert np.max(np.abs(Xp - outs[0][0])) < 1e-7
     # single-iteration mode: a tiny initial radius is accepted at once, result equals the oracle's
     prm_o = oracle.ROptParameters(RTR_iterations=1, RTR_initial_radius=1.0)
     oo = oracle.QuadraticOptimizer(oracle.QuadraticProblem(Q, None, 5, d, precond="jacobi"), prm_o, hess_recurrence=device_tcg_mode(n, d, 5))
