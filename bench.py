@@ -608,10 +608,9 @@ def main():
         ml_info["path"] = path
         two = len(ml_info["ks"]) == 1
         nnzb_ap = None
+        graph = ml_info["ks"][0] < 0  # graph aggregates: members anywhere, summed by k_ml_agg_sum
         if path["ap"]:  # blocks of A P: the distinct aggregates the block columns of every row fall into
-            rp_, ci_, _ = agent.problem.pose_graph_.quadraticMatrix()
-            rows_ = np.repeat(np.arange(n_local, dtype=np.int64), np.diff(rp_))
-            nnzb_ap = int(np.unique(rows_ * (ml_info["sizes"][1] + 1) + np.asarray(ci_) // ml_info["ks"][0]).size)
+            nnzb_ap = int(agent.problem.multilevelGet(0, "ap_nnzb")[0])
         if path["packed_dense"]:
             nt_ = -(-Nc // 64)
             dense = dict(kernel="k_ml_coarse_prolong -> k_dense_sym_apply + k_dense_sym_finish (packed lower triangle of the "
@@ -632,9 +631,10 @@ def main():
                         bytes_per_launch=qb + 4 * vec + pbb)
         post["avg_launch_us"] = ms_it[3] * 1e3
         kernels += [
-            dict(kernel="k_ml_restrict, level 0 (r - A x1 in one pass over Q, P^T, aggregate sums%s)"
-                        % (", residual kept" if path["ap"] else ""),
-                 bytes_per_launch=qb + 2 * vec + pbb + vec // ml_info["ks"][0] + (vec if path["ap"] else 0),
+            dict(kernel="k_ml_restrict%s, level 0 (r - A x1 in one pass over Q, P^T, aggregate sums%s)"
+                        % (" -> k_ml_agg_sum" if graph else "", ", residual kept" if path["ap"] else ""),
+                 bytes_per_launch=qb + 2 * vec + pbb + vec // abs(ml_info["ks"][0]) + (vec if path["ap"] else 0)
+                 + (2 * vec if graph else 0),
                  avg_launch_us=ms_it[1] * 1e3),
             dense, post]
     for k_ in kernels:

@@ -132,6 +132,12 @@ struct dpgo_problem_s {
     // r - A (x1 + P xc) = (r - A x1) - (A P) xc
     Bsr AP;
     double* res1 = nullptr;
+    // level 0 of a two-level hierarchy with GRAPH aggregates (ml_graph_aggregates): label of every pose, members of every
+    // aggregate in discovery order, the spanning tree the prolongation is composed along, P_i^T res_i of every pose
+    bool graph = false;
+    int32_t *lab = nullptr, *agg_ptr = nullptr, *agg_mem = nullptr, *parent = nullptr, *pslot = nullptr;
+    double* tbuf = nullptr;
+    AggMap agg() const { return AggMap{graph ? lab : nullptr, k}; }
   };
   std::vector<MlLevel> ml;
   std::vector<int32_t> h_rowptr, h_colidx;  // host copy of Q's block pattern (symbolic setup of the hierarchy)
@@ -174,7 +180,7 @@ struct dpgo_problem_s {
       const char* e = std::getenv("DPGO_ML_AP");
       return e && std::atoi(e) == 0;
     }();
-    return !off && ml.size() == 2 && ml[0].AP.vals != nullptr;
+    return ml.size() == 2 && ml[0].AP.vals != nullptr && (!off || ml[0].graph);  // (graph aggregates exist in this form only)
   }
   // symmetric copy of Q for the plain SpMM on Infinity-Cache-cold blocks (k_spmm_sym): upper blocks transposed + lower references
   struct SymQ {
@@ -205,6 +211,11 @@ struct dpgo_problem_s {
   // what the tCG loop streams besides Q and the pose vectors (the multilevel cycle's dense inverse, A P, prolongation):
   // set by the solve that last chose a preconditioner
   size_t loop_extra_bytes = 0;
+  // non-temporal single-use operands: when the launch is fed from HBM (same size rule as the symmetric storage)
+  bool want_stream_nt() const {
+    const char* e = std::getenv("DPGO_STREAM_NT");
+    return e ? std::atoi(e) != 0 : beyond_cache();
+  }
   bool beyond_cache() const {
     return sizeof(double) * ((size_t)Q.nnzb * b * b + 8 * (size_t)n * T) + sizeof(int32_t) * (size_t)Q.nnzb + loop_extra_bytes >
            ((size_t)256 << 20);
@@ -480,7 +491,12 @@ int sym_ensure(dpgo_problem_s* p, bool* usable) {
 int launch_spmm_sym(dpgo_problem_s* p, const BsrSymDev& M, const double* V, const double* Gadd, double* OUT) {
   const int g = p->grid_spmm();
   DISPATCH(p->d, p->r,
-           hipLaunchKernelGGL((k_spmm_sym<D, R>), dim3(g), dim3(kBlock), 0, p->stream, M, V, Gadd, OUT, p->n));
+           {
+             if (p->want_stream_nt())
+               hipLaunchKernelGGL((k_spmm_sym<D, R, 1>), dim3(g), dim3(kBlock), 0, p->stream, M, V, Gadd, OUT, p->n);
+             else
+               hipLaunchKernelGGL((k_spmm_sym<D, R, 0>), dim3(g), dim3(kBlock), 0, p->stream, M, V, Gadd, OUT, p->n);
+           });
   HIPC(hipGetLastError());
   return DPGO_OK;
 }
@@ -497,7 +513,12 @@ int launch_spmm(dpgo_problem_s* p, const Bsr& M, const double* V, const double* 
     const int P = (64 / (p->b * p->split)) * kWaves;
     g = std::max(1, std::min(kMaxGrid, (rows + P - 1) / P));
   }
-  DISPATCH(p->d, p->r, LAUNCH_SPLIT(p, k_spmm, g, M.dev(), V, Gadd, OUT, rows));
+  DISPATCH(p->d, p->r, {
+    if (p->want_stream_nt() && p->split == 1 && &M == &p->Q)
+      hipLaunchKernelGGL((k_spmm<D, R, 1, 1>), dim3(g), dim3(kBlock), 0, p->stream, M.dev(), V, Gadd, OUT, rows);
+    else
+      LAUNCH_SPLIT(p, k_spmm, g, M.dev(), V, Gadd, OUT, rows);
+  });
   HIPC(hipGetLastError());
   return DPGO_OK;
 }
@@ -572,10 +593,7 @@ int launch_tcg_hess(dpgo_problem_s* p, int first) {
 // which storage of Q the tCG-step kernel of the coming launches reads (Q does not change inside a solve)
 int resolve_tcg_storage(dpgo_problem_s* p) {
   p->tcg_sym = false;
-  {  // non-temporal single-use operands: when the launch is fed from HBM (same size rule as the symmetric storage)
-    const char* e = std::getenv("DPGO_STREAM_NT");
-    p->stream_nt = e ? std::atoi(e) != 0 : p->beyond_cache();
-  }
+  p->stream_nt = p->want_stream_nt();
   bool span = false;
   DISPATCH(p->d, p->r, { span = Span<D, R, 1>::kOk; });
   if (!span || !p->sym_wanted()) return DPGO_OK;
@@ -636,7 +654,21 @@ int ml_level_split(int n) { return n < 40000 ? 4 : 1; }
 // coarsest operator is a dense inverse of at most kMlDense unknowns (Infinity-Cache resident), kMlDenseMax if that is
 // what it takes to get there in one coarsening; otherwise one more level.
 constexpr int kMlDense = 3200, kMlDenseMax = 6400;
+// Two-level hierarchies use GRAPH aggregates (a single negative entry -S: breadth-first-grown aggregates of at most S
+// poses, ml_graph_aggregates) whenever one coarsening with S <= kMlGraphMax reaches a dense level of about 2 500
+// unknowns: compact aggregates need 40-60 % of the Hessian-vector products that index runs of the same size need
+// (DESIGN.md section 5), and the dense level can then be small.  DPGO_ML_GRAPH=0: index runs as before.
+constexpr int kMlGraphMax = 512, kMlGraphUnknownsPerPose = 1600;
+int ml_default_graph_size(int n, int b) {
+  if (const char* e = std::getenv("DPGO_ML_GRAPH"))
+    if (std::atoi(e) == 0) return 0;
+  if (const char* e = std::getenv("DPGO_ML_GRAPH_SIZE"))  // experiments: force the size
+    if (std::atoi(e) >= 2) return std::atoi(e);
+  const long long S = std::max<long long>(4, ((long long)n * b + kMlGraphUnknownsPerPose - 1) / kMlGraphUnknownsPerPose);
+  return S <= kMlGraphMax ? (int)S : 0;
+}
 std::vector<int> ml_default_ks(int n, int b, int split0) {
+  if (const int S = ml_default_graph_size(n, b)) return std::vector<int>{-S};
   std::vector<int> ks;
   int cur = n, split = split0;
   for (int guard = 0; guard < 16; ++guard) {
@@ -666,7 +698,7 @@ void ml_free(dpgo_problem_s* p) {
   for (auto& L : p->ml) {
     free_bsr(L.A);
     free_bsr(L.AP);
-    void* ptrs[] = {L.slot_row, L.dinv, L.Pb, L.r, L.x1, L.x, L.res1};
+    void* ptrs[] = {L.slot_row, L.dinv, L.Pb, L.r, L.x1, L.x, L.res1, L.lab, L.agg_ptr, L.agg_mem, L.parent, L.pslot, L.tbuf};
     for (void* q : ptrs)
       if (q) (void)hipFree(q);
   }
@@ -686,19 +718,111 @@ void ml_free(dpgo_problem_s* p) {
 }
 
 // Symbolic setup: level sizes, block patterns of the Galerkin operators, buffers.
-int ml_symbolic_setup(dpgo_problem_s* p, const std::vector<int>& ks) {
+// Graph aggregates of at most S nodes, grown greedily: seeds in index order; a seed's aggregate takes unassigned nodes in
+// breadth-first order (queue; a node's neighbours in the order of its block row) until it holds S.  lab = aggregate of
+// every node, mem / ptr = members in discovery order, parent / pslot = the breadth-first tree (slot of block
+// (parent, node) in the pattern).  Restated in oracle/dpgo_oracle.py (amg_graph_aggregates).
+int ml_graph_aggregates(const std::vector<int32_t>& rowptr, const std::vector<int32_t>& colidx, int n, int S,
+                        std::vector<int32_t>& lab, std::vector<int32_t>& ptr, std::vector<int32_t>& mem,
+                        std::vector<int32_t>& parent, std::vector<int32_t>& pslot) {
+  lab.assign(n, -1);
+  parent.assign(n, -1);
+  pslot.assign(n, 0);
+  mem.clear();
+  mem.reserve(n);
+  ptr.assign(1, 0);
+  int na = 0;
+  for (int s = 0; s < n; ++s) {
+    if (lab[s] >= 0) continue;
+    const size_t first = mem.size();
+    lab[s] = na;
+    mem.push_back(s);
+    for (size_t head = first; head < mem.size() && (int)(mem.size() - first) < S; ++head) {
+      const int u = mem[head];
+      for (int t = rowptr[u]; t < rowptr[u + 1] && (int)(mem.size() - first) < S; ++t) {
+        const int v = colidx[t];
+        if (lab[v] >= 0) continue;
+        lab[v] = na;
+        parent[v] = u;
+        pslot[v] = t;
+        mem.push_back(v);
+      }
+    }
+    ptr.push_back((int32_t)mem.size());
+    ++na;
+  }
+  return na;
+}
+
+int ml_symbolic_setup(dpgo_problem_s* p, const std::vector<int>& ks_in) {
   ml_free(p);
   if ((int)p->h_rowptr.size() != p->n + 1) return fail(DPGO_ERR_STATE, "multilevel: Q's block pattern is not set");
   const int b = p->b, bb = b * b;
   const size_t tb = sizeof(double) * p->T;
   std::vector<int32_t> rowptr = p->h_rowptr, colidx = p->h_colidx;
   int cur = p->n;
+  // a single negative entry -S: two levels, graph aggregates of at most S poses
+  const bool graph = ks_in.size() == 1 && ks_in[0] < 0;
+  std::vector<int> ks = ks_in;
+  if (graph) ks[0] = -ks_in[0];
+  for (int k : ks)
+    if (k < 0) return fail(DPGO_ERR_INVALID, "multilevel: graph aggregates (a negative size) make a two-level hierarchy");
   p->ml.resize(ks.size() + 1);
   for (size_t l = 0; l <= ks.size(); ++l) {
     auto& L = p->ml[l];
     L.n = cur;
     L.split = (l == 0) ? p->split : ml_level_split(cur);
     L.k = (l < ks.size()) ? ks[l] : 0;
+    if (l == 0 && graph) {
+      if (L.k < 2) return fail(DPGO_ERR_INVALID, "multilevel: graph aggregates hold at least 2 poses");
+      std::vector<int32_t> lab, ptr, mem, parent, pslot;
+      const int na = ml_graph_aggregates(rowptr, colidx, cur, L.k, lab, ptr, mem, parent, pslot);
+      L.graph = true;
+      CHK(upload(&L.lab, lab.data(), lab.size(), p->stream));
+      CHK(upload(&L.agg_ptr, ptr.data(), ptr.size(), p->stream));
+      CHK(upload(&L.agg_mem, mem.data(), mem.size(), p->stream));
+      CHK(upload(&L.parent, parent.data(), parent.size(), p->stream));
+      CHK(upload(&L.pslot, pslot.data(), pslot.size(), p->stream));
+      HIPC(hipMalloc(&L.tbuf, tb * cur));
+      // pattern of A P: the aggregates the block columns of every row fall into
+      std::vector<int32_t> arow(cur + 1, 0), acol;
+      acol.reserve(colidx.size());
+      for (int i = 0; i < cur; ++i) {
+        const size_t first = acol.size();
+        for (int t = rowptr[i]; t < rowptr[i + 1]; ++t) acol.push_back(lab[colidx[t]]);
+        std::sort(acol.begin() + first, acol.end());
+        acol.erase(std::unique(acol.begin() + first, acol.end()), acol.end());
+        arow[i + 1] = (int32_t)acol.size();
+      }
+      CHK(upload_bsr(L.AP, cur, na, (int)acol.size(), b, arow.data(), acol.data(), nullptr, p->stream));
+      HIPC(hipMalloc(&L.res1, tb * cur));
+      HIPC(hipMalloc(&L.Pb, sizeof(double) * (size_t)cur * bb));
+      HIPC(hipMalloc(&L.x1, tb * cur));
+      HIPC(hipMalloc(&L.x, tb * cur));
+      // pattern of the dense level's operator: the aggregates of the block columns of every member's row
+      std::vector<int32_t> crow(na + 1, 0), ccol;
+      std::vector<int32_t> mark(na, -1);
+      for (int a = 0; a < na; ++a) {
+        const size_t first = ccol.size();
+        for (int m = ptr[a]; m < ptr[a + 1]; ++m) {
+          const int i = mem[m];
+          for (int t = rowptr[i]; t < rowptr[i + 1]; ++t) {
+            const int c = lab[colidx[t]];
+            if (mark[c] != a) {
+              mark[c] = a;
+              ccol.push_back(c);
+            }
+          }
+        }
+        std::sort(ccol.begin() + first, ccol.end());
+        crow[a + 1] = (int32_t)ccol.size();
+      }
+      HIPC(hipStreamSynchronize(p->stream));  // the host vectors go out of scope
+      rowptr.swap(crow);
+      colidx.swap(ccol);
+      cur = na;
+      continue;
+    }
     if (L.k) {
       if (L.k < 2 || ml_tile(b, L.split) % L.k)
         return fail(DPGO_ERR_INVALID, "multilevel: aggregate size must divide the workgroup tile of its level (" +
@@ -822,16 +946,21 @@ int ml_numeric_setup_d(dpgo_problem_s* p) {
     auto& L = p->ml[l];
     auto& C = p->ml[l + 1];
     const long long span = stride * L.k;
-    hipLaunchKernelGGL(k_ml_build_P<D>, dim3(flat_grid(C.n)), dim3(kBlock), 0, p->stream, p->Q.dev(), p->n, (int)stride,
-                       (int)span, L.Pb, C.n);
+    if (L.graph)
+      hipLaunchKernelGGL(k_ml_build_P_tree<D>, dim3(flat_grid(C.n)), dim3(kBlock), 0, p->stream, p->Q.dev(), L.agg_ptr,
+                         L.agg_mem, L.parent, L.pslot, L.Pb, C.n);
+    else
+      hipLaunchKernelGGL(k_ml_build_P<D>, dim3(flat_grid(C.n)), dim3(kBlock), 0, p->stream, p->Q.dev(), p->n, (int)stride,
+                         (int)span, L.Pb, C.n);
     const BsrDev A = (l == 0) ? p->Q.dev() : L.A.dev();
     hipLaunchKernelGGL(k_ml_galerkin<D>, dim3(flat_grid(C.A.nnzb)), dim3(kBlock), 0, p->stream, A,
-                       (l == 0) ? p->ml_shift : 0.0, L.Pb, L.k, L.n, C.slot_row, C.A.colidx, C.A.vals, C.A.nnzb);
+                       (l == 0) ? p->ml_shift : 0.0, L.Pb, L.agg(), L.agg_ptr, L.agg_mem, L.n, C.slot_row, C.A.colidx,
+                       C.A.vals, C.A.nnzb);
     if (C.k)  // smoother of the next level (level 0 uses the handle's block-Jacobi factors)
       hipLaunchKernelGGL(k_build_dinv<D>, dim3(flat_grid(C.n)), dim3(kBlock), 0, p->stream, C.A.dev(), 0.0, C.dinv, C.n);
     if (l == 0 && L.AP.vals)
       hipLaunchKernelGGL(k_ml_build_AP<D>, dim3(flat_grid(L.n)), dim3(kBlock), 0, p->stream, p->Q.dev(), p->ml_shift, L.Pb,
-                         L.k, L.n, L.AP.dev(), L.AP.vals);
+                         L.agg(), L.n, L.AP.dev(), L.AP.vals);
     stride = span;
   }
   HIPC(hipGetLastError());
@@ -876,7 +1005,7 @@ int ml_ensure(dpgo_problem_s* p, double shift, bool additive = false) {
   // caller set up explicitly is kept if it has that shape, the default one is replaced (and put back when the V-cycle
   // is asked for again)
   const int Pa = additive_tile(p);
-  const bool shape_ok = p->ml_symbolic && p->ml.size() == 2 && p->ml[0].k == Pa && p->split == 4;
+  const bool shape_ok = p->ml_symbolic && p->ml.size() == 2 && !p->ml[0].graph && p->ml[0].k == Pa && p->split == 4;
   if (additive && !shape_ok) {
     if (p->split != 4) return fail(DPGO_ERR_UNSUPPORTED, "additive preconditioner: small-block layout only");
     CHK(ml_symbolic_setup(p, std::vector<int>{Pa}));
@@ -956,6 +1085,38 @@ int launch_dense_sym(dpgo_problem_s* p, const dpgo_problem_s::MlLevel& C, const 
   return DPGO_OK;
 }
 
+// Level-0 restriction of the cycle: rc = P^T (r - A x1) into ml[1].r (+ the residual itself for k_ml_post_ap).  Graph
+// aggregates: the restriction kernel writes P_i^T res_i per pose, k_ml_agg_sum adds the members up.
+int launch_ml_restrict0(dpgo_problem_s* p, const double* r, const DevState* gate, int g0) {
+  auto& L = p->ml[0];
+  auto& C = p->ml[1];
+  float* rc32 = (C.k == 0 && p->ml_coarse_bits == 32) ? reinterpret_cast<float*>(C.r) : (float*)nullptr;
+  double* res_out = p->ml_use_ap() ? L.res1 : nullptr;
+  const double* dnext = C.k ? C.dinv : (const double*)nullptr;
+  if (p->tcg_sym) {  // level 0 reads Q: the symmetric copy when the tCG-step kernel does
+    DISPATCH(p->d, p->r, hipLaunchKernelGGL((k_ml_restrict<D, R, 1, BsrSymDev>), dim3(g0), dim3(kBlock), 0, p->stream,
+                                            p->sym.dev(), L.x1, r, L.Pb, p->ml_shift, L.k, C.r, rc32, dnext, p->ml_omega,
+                                            C.x1, gate, L.n, res_out, L.tbuf));
+  } else {
+    DISPATCH(p->d, p->r, LAUNCH_SPLIT(p, k_ml_restrict, g0, p->Q.dev(), L.x1, r, L.Pb, p->ml_shift, L.k, C.r, rc32, dnext,
+                                      p->ml_omega, C.x1, gate, L.n, res_out, L.tbuf));
+  }
+  if (L.graph)
+    DISPATCH(p->d, p->r, hipLaunchKernelGGL((k_ml_agg_sum<D, R>), dim3(std::min(C.n, kMaxGrid)), dim3(kBlock), 0, p->stream,
+                                            L.tbuf, L.agg_ptr, L.agg_mem, C.n, C.r, rc32, gate));
+  HIPC(hipGetLastError());
+  return DPGO_OK;
+}
+
+// Level-0 post-smoothing of a two-level hierarchy through A P (k_ml_post_ap).
+int launch_ml_post_ap(dpgo_problem_s* p, const double* Xdev, const double* r, double* z, double* pout, const DevState* gate) {
+  auto& L0 = p->ml[0];
+  DISPATCH(p->d, p->r, LAUNCH_SPLIT(p, k_ml_post_ap, p->grid_post(), L0.AP.dev(), Xdev, r, L0.res1, p->ml[1].x, L0.Pb,
+                                    L0.agg(), p->dinv, p->ml_omega, z, pout, gate, p->n));
+  HIPC(hipGetLastError());
+  return DPGO_OK;
+}
+
 // The launches of one cycle after the pre-smoothing step of level 0 (x1 = w Dinv r is in ml[0].x1):
 // z = proj_X(M^-1 r); partial sums <r,r>, <z,r> into `pout` (may be NULL).  `gate`: state record for early exit.
 int launch_ml_tail(dpgo_problem_s* p, const double* Xdev, const double* r, double* z, double* pout,
@@ -984,20 +1145,13 @@ int launch_ml_tail(dpgo_problem_s* p, const double* Xdev, const double* r, doubl
       hipLaunchKernelGGL((KERNEL<D, R, 1>), dim3(g_), dim3(kBlock), 0, p->stream, __VA_ARGS__);          \
   } while (0)
   const bool ap = p->ml_use_ap();  // two levels: the residual after pre-smoothing is kept, the dense level hands over xc
-  for (int l = 0; l + 1 < nl; ++l) {  // down
+  CHK(launch_ml_restrict0(p, r, gate, g0));
+  for (int l = 1; l + 1 < nl; ++l) {  // down
     auto& L = p->ml[l];
     auto& C = p->ml[l + 1];
-    double* res_out = (ap && l == 0) ? L.res1 : nullptr;
-    if (l == 0 && p->tcg_sym) {  // level 0 reads Q: the symmetric copy when the tCG-step kernel does
-      DISPATCH(p->d, p->r, hipLaunchKernelGGL((k_ml_restrict<D, R, 1, BsrSymDev>), dim3(g0), dim3(kBlock), 0,
-                                              p->stream, p->sym.dev(), L.x1, r, L.Pb, p->ml_shift, L.k, C.r, rc32_of(C),
-                                              C.k ? C.dinv : (const double*)nullptr, p->ml_omega, C.x1, gate, L.n,
-                                              res_out));
-    } else {
-      DISPATCH(p->d, p->r, ML_SPLIT_LAUNCH(L, k_ml_restrict, A_of(l), L.x1, r_of(l), L.Pb, l == 0 ? p->ml_shift : 0.0, L.k,
-                                           C.r, rc32_of(C), C.k ? C.dinv : (const double*)nullptr, p->ml_omega, C.x1, gate, L.n,
-                                           res_out));
-    }
+    DISPATCH(p->d, p->r, ML_SPLIT_LAUNCH(L, k_ml_restrict, A_of(l), L.x1, r_of(l), L.Pb, 0.0, L.k, C.r, rc32_of(C),
+                                         C.k ? C.dinv : (const double*)nullptr, p->ml_omega, C.x1, gate, L.n,
+                                         (double*)nullptr, (double*)nullptr));
   }
   {  // dense level (+ prolongation unless the level above does it itself)
     auto& L = p->ml[nl - 2];
@@ -1008,13 +1162,7 @@ int launch_ml_tail(dpgo_problem_s* p, const double* Xdev, const double* r, doubl
       CHK(launch_coarse_prolong(p, L, C, gate, ap ? C.x : nullptr));
   }
   g0 = p->grid_post();
-  if (ap) {
-    auto& L0 = p->ml[0];
-    DISPATCH(p->d, p->r, ML_SPLIT_LAUNCH(L0, k_ml_post_ap, L0.AP.dev(), Xdev, r, L0.res1, p->ml[1].x, L0.Pb, L0.k, p->dinv,
-                                         p->ml_omega, z, pout, gate, p->n));
-    HIPC(hipGetLastError());
-    return DPGO_OK;
-  }
+  if (ap) return launch_ml_post_ap(p, Xdev, r, z, pout, gate);
   for (int l = nl - 2; l >= 1; --l) {  // up
     auto& L = p->ml[l];
     auto& F = p->ml[l - 1];
@@ -1787,7 +1935,7 @@ int dpgo_problem_set_Q_bsr(dpgo_problem_t p, int nnzb, const int32_t* rowptr, co
     p->h_colidx.assign(colidx, colidx + nnzb);
     if (p->ml_user_ks && p->ml_symbolic) {  // keep the caller's aggregate sizes across a pattern change
       std::vector<int> ks;
-      for (size_t l = 0; l + 1 < p->ml.size(); ++l) ks.push_back(p->ml[l].k);
+      for (size_t l = 0; l + 1 < p->ml.size(); ++l) ks.push_back(p->ml[l].graph ? -p->ml[l].k : p->ml[l].k);
       CHK(ml_symbolic_setup(p, ks));
     } else {
       ml_free(p);
@@ -2073,7 +2221,7 @@ int dpgo_problem_setup_multilevel(dpgo_problem_t p, int nks, const int* ks, doub
     return fail(DPGO_ERR_INVALID, "bad multilevel arguments");
   std::vector<int> v = nks > 0 ? std::vector<int>(ks, ks + nks) : ml_default_ks(p->n, p->b, p->split);
   bool same = p->ml_symbolic && p->ml.size() == v.size() + 1;
-  for (size_t l = 0; same && l < v.size(); ++l) same = p->ml[l].k == v[l];
+  for (size_t l = 0; same && l < v.size(); ++l) same = (p->ml[l].graph ? -p->ml[l].k : p->ml[l].k) == v[l];
   if (!same) CHK(ml_symbolic_setup(p, v));
   p->ml_user_ks = nks > 0;
   p->ml_additive_layout = false;
@@ -2111,7 +2259,7 @@ int dpgo_problem_multilevel_info(dpgo_problem_t p, int* nlevels, int* sizes, int
   const int cap = nlevels ? *nlevels : 0;
   for (int l = 0; l < (int)p->ml.size() && l < cap; ++l) {
     if (sizes) sizes[l] = p->ml[l].n;
-    if (ks) ks[l] = p->ml[l].k;
+    if (ks) ks[l] = p->ml[l].graph ? -p->ml[l].k : p->ml[l].k;  // negative: graph aggregates of at most that many poses
     if (nnzb) nnzb[l] = (l == 0) ? p->Q.nnzb : p->ml[l].A.nnzb;
   }
   if (nlevels) *nlevels = (int)p->ml.size();
@@ -2139,6 +2287,14 @@ int dpgo_problem_multilevel_get(dpgo_problem_t p, int level, int what, void* out
     case DPGO_ML_A_VALUES:
       src = L.A.vals, bytes = sizeof(double) * (size_t)L.A.nnzb * bb;
       break;
+    case DPGO_ML_AGG_LABELS:
+      src = L.graph ? L.lab : nullptr, bytes = sizeof(int32_t) * (size_t)L.n;
+      break;
+    case DPGO_ML_AP_NNZB: {
+      if (!L.AP.vals) return fail(DPGO_ERR_INVALID, "this level does not hold that item");
+      *static_cast<int32_t*>(out_host) = L.AP.nnzb;
+      return DPGO_OK;
+    }
     case DPGO_ML_DENSE_INVERSE: {
       if (level + 1 != (int)p->ml.size()) return fail(DPGO_ERR_INVALID, "the dense inverse belongs to the last level");
       const int N = L.n * p->b;  // the N x N corner of the padded lda x lda array
@@ -2930,26 +3086,8 @@ int dpgo_bench_iteration_kernels(dpgo_problem_t p, int reps, int warmup, double 
   if (rc == DPGO_OK && ml) {
     const int nl = (int)p->ml.size();
     auto& L0 = p->ml[0];
-    auto& C1 = p->ml[1];
-    auto rc32_of = [&](const dpgo_problem_s::MlLevel& C) {
-      return (C.k == 0 && p->ml_coarse_bits == 32) ? reinterpret_cast<float*>(C.r) : (float*)nullptr;
-    };
     const bool ap = p->ml_use_ap();
-    double* res_out = ap ? L0.res1 : nullptr;
-    rc = timed([&]() -> int {
-      if (p->tcg_sym) {
-        DISPATCH(p->d, p->r, hipLaunchKernelGGL((k_ml_restrict<D, R, 1, BsrSymDev>), dim3(p->grid_restrict()), dim3(kBlock), 0,
-                                                p->stream, p->sym.dev(), L0.x1, p->rr, L0.Pb, p->ml_shift, L0.k, C1.r,
-                                                rc32_of(C1), C1.k ? C1.dinv : (const double*)nullptr, p->ml_omega, C1.x1,
-                                                (const DevState*)nullptr, p->n, res_out));
-      } else {
-        DISPATCH(p->d, p->r, LAUNCH_SPLIT(p, k_ml_restrict, p->grid_restrict(), p->Q.dev(), L0.x1, p->rr, L0.Pb, p->ml_shift,
-                                          L0.k, C1.r, rc32_of(C1), C1.k ? C1.dinv : (const double*)nullptr, p->ml_omega, C1.x1,
-                                          (const DevState*)nullptr, p->n, res_out));
-      }
-      HIPC(hipGetLastError());
-      return DPGO_OK;
-    }, &out_ms[1]);
+    rc = timed([&]() -> int { return launch_ml_restrict0(p, p->rr, nullptr, p->grid_restrict()); }, &out_ms[1]);
     if (rc == DPGO_OK) rc = timed([&]() -> int {
       auto& L = p->ml[nl - 2];
       auto& Cc = p->ml[nl - 1];
@@ -2958,8 +3096,7 @@ int dpgo_bench_iteration_kernels(dpgo_problem_t p, int reps, int warmup, double 
     }, &out_ms[2]);
     if (rc == DPGO_OK) rc = timed([&]() -> int {
       if (ap) {
-        DISPATCH(p->d, p->r, LAUNCH_SPLIT(p, k_ml_post_ap, p->grid_post(), L0.AP.dev(), p->x1, p->rr, L0.res1, C1.x, L0.Pb, L0.k,
-                                          p->dinv, p->ml_omega, p->z, p->pB(), (const DevState*)nullptr, p->n));
+        return launch_ml_post_ap(p, p->x1, p->rr, p->z, p->pB(), nullptr);
       } else if (p->tcg_sym) {
         DISPATCH(p->d, p->r, hipLaunchKernelGGL((k_ml_post<D, R, 1, BsrSymDev>), dim3(p->grid_post()), dim3(kBlock), 0,
                                                 p->stream, p->sym.dev(), p->x1, L0.x, p->rr, p->dinv, p->ml_omega,

@@ -397,6 +397,11 @@ __device__ __forceinline__ void store_col(double* __restrict__ p, const double (
 #pragma unroll
   for (int a = 0; a < R; ++a) p[a] = v[a];
 }
+template <int NTS, int R>
+__device__ __forceinline__ void store_col_stream(double* __restrict__ p, const double (&v)[R]) {
+#pragma unroll
+  for (int a = 0; a < R; ++a) st_stream<NTS>(p + a, v[a]);
+}
 
 // ---------------------------------------------------------------- block-SpMM core
 // acc[:] = (V*Q)[i][c][:] = sum_j sum_k V_j[:,k] * Q[i,j][c][k]      (Q symmetric)

@@ -14,6 +14,14 @@
 // k_ml_restrict x (L-1) | k_ml_coarse_prolong | k_ml_post_mid x (L-2) | k_ml_post  =  2L + 1.
 // `gate`: the solver's state record -- launches enqueued after tCG finished return at once.
 
+// Which aggregate (node of the next level) a node belongs to: runs of k consecutive nodes, or -- level 0 of a two-level
+// hierarchy with GRAPH aggregates (host: ml_graph_aggregates) -- a label per pose.
+struct AggMap {
+  const int32_t* lab;
+  int k;
+  __device__ __forceinline__ int of(int i) const { return lab ? lab[i] : i / k; }
+};
+
 // x1 = w Dinv v (stand-alone pre-smoothing step; inside the tCG loop k_tcg_update produces it)
 template <int D, int R>
 __global__ __launch_bounds__(kBlock) void k_ml_presmooth(const double* __restrict__ V, const double* __restrict__ dinv,
@@ -57,7 +65,10 @@ __global__ __launch_bounds__(kBlock) void k_ml_restrict(MAT A, const double* __r
                                                         float* __restrict__ rc32,
                                                         const double* __restrict__ dinv_next, double omega,
                                                         double* __restrict__ x1c, const DevState* __restrict__ gate,
-                                                        int n, double* __restrict__ res_out = nullptr) {
+                                                        int n, double* __restrict__ res_out = nullptr,
+                                                        double* __restrict__ tbuf = nullptr) {
+  // tbuf (graph aggregates: their members are anywhere): P_i^T res_i of every node is written out instead of summed
+  // here, k_ml_agg_sum adds the members up
   using GEO = Geo<D, R, SPLIT>;
   if (gate && (gate->tcg_done || gate->rtr_stop)) return;
   __shared__ double res_s[kWaves][GEO::G][GEO::T];  // residual tiles (per wave)
@@ -97,7 +108,15 @@ __global__ __launch_bounds__(kBlock) void k_ml_restrict(MAT A, const double* __r
           for (int a = 0; a < R; ++a) t[a] = fma(pv, res_s[L.wave][L.g][cc * R + a], t[a]);
         }
       }
-      store_col<R>(&t_s[lp][L.c * R], t);  // zeros for nodes beyond n
+      if (tbuf) {
+        if (ok) store_col<R>(tbuf + off, t);
+      } else {
+        store_col<R>(&t_s[lp][L.c * R], t);  // zeros for nodes beyond n
+      }
+    }
+    if (tbuf) {  // kernel-uniform
+      wave_sync();
+      continue;
     }
     __syncthreads();
     // Sum over the aggregate's members (all inside this tile).  Large aggregates: all threads first fold runs of 8
@@ -144,6 +163,54 @@ __global__ __launch_bounds__(kBlock) void k_ml_restrict(MAT A, const double* __r
       }
       __syncthreads();
     }
+  }
+}
+
+// Graph aggregates: rc[a] = sum over the members of aggregate a (agg_mem[agg_ptr[a] .. agg_ptr[a+1])) of t[member], in a
+// fixed order.  One workgroup per aggregate: thread (group g, element e) adds every NG-th member's element e, the partial
+// sums meet in LDS and the first T threads add them up.  rc32: the dense level stores its right-hand side in fp32.
+template <int D, int R>
+__global__ __launch_bounds__(kBlock) void k_ml_agg_sum(const double* __restrict__ t, const int32_t* __restrict__ agg_ptr,
+                                                       const int32_t* __restrict__ agg_mem, int na,
+                                                       double* __restrict__ rc, float* __restrict__ rc32,
+                                                       const DevState* __restrict__ gate) {
+  constexpr int T = (D + 1) * R, NG = kBlock / T;
+  if (gate && (gate->tcg_done || gate->rtr_stop)) return;
+  __shared__ double part[NG][T];
+  const int e = threadIdx.x % T, g = threadIdx.x / T;
+  for (int a = blockIdx.x; a < na; a += gridDim.x) {
+    const int m0 = agg_ptr[a], m1 = agg_ptr[a + 1];
+    if (g < NG) {
+      // (a member's index, then its value: two dependent loads -- U members are requested together, or a thread's dozen
+      // members cost a dozen round trips: 15 us at 100k poses)
+      constexpr int U = 8;
+      double acc = 0.0;
+      for (int mb = m0 + g; mb < m1; mb += U * NG) {
+        int idx[U];
+        double v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int m = mb + u * NG;
+          idx[u] = (m < m1) ? agg_mem[m] : -1;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] = (idx[u] >= 0) ? t[(size_t)idx[u] * T + e] : 0.0;
+#pragma unroll
+        for (int u = 0; u < U; ++u) acc += v[u];
+      }
+      part[g][e] = acc;
+    }
+    __syncthreads();
+    if (threadIdx.x < T) {
+      double acc = part[0][threadIdx.x];
+#pragma unroll
+      for (int q = 1; q < NG; ++q) acc += part[q][threadIdx.x];
+      if (rc32)
+        rc32[(size_t)a * T + threadIdx.x] = (float)acc;
+      else
+        rc[(size_t)a * T + threadIdx.x] = acc;
+    }
+    __syncthreads();
   }
 }
 
@@ -414,7 +481,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(SPLIT ==
 template <int D, int R, int SPLIT>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(SPLIT == 1 ? DPGO_POST_WAVES : 1))) void k_ml_post_ap(BsrDev AP, const double* __restrict__ X,
                                                        const double* __restrict__ r, const double* __restrict__ res1,
-                                                       const double* __restrict__ xc, const double* __restrict__ Pb, int k,
+                                                       const double* __restrict__ xc, const double* __restrict__ Pb, AggMap am,
                                                        const double* __restrict__ dinv, double omega,
                                                        double* __restrict__ Z, double* __restrict__ pout,
                                                        const DevState* __restrict__ gate, int n) {
@@ -458,7 +525,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(SPLIT ==
       jacobi_col<D, R>(vs, dr, x1c);  // x1 = w Dinv r
       jacobi_col<D, R>(zs, dr, zc);   // Dinv (r - A x)
       const double* __restrict__ pb = Pb + (size_t)i * GEO::BB + L.c * GEO::B;
-      const double* __restrict__ xa = xc + (size_t)(i / k) * GEO::T;
+      const double* __restrict__ xa = xc + (size_t)am.of(i) * GEO::T;
 #pragma unroll
       for (int a = 0; a < R; ++a) xcol[a] = omega * x1c[a];
 #pragma unroll
@@ -564,13 +631,93 @@ __global__ __launch_bounds__(kBlock) void k_ml_build_P(BsrDev Q, int n_fine, int
   }
 }
 
+// Prolongation blocks for GRAPH aggregates.  Every aggregate carries a spanning tree (the breadth-first tree the host's
+// aggregation grew it along): parent[i] = the node that discovered i (-1: the aggregate's root), pslot[i] = the slot of
+// block (parent, i) in Q.  One thread per aggregate walks its members in discovery order (a parent precedes its children)
+// and composes G(root -> i) = G(root -> parent) T(parent -> i);  Pb[i] = G^T.  T is read off the block as in k_ml_build_P;
+// the block of an edge measured the other way round (i -> parent) is the transpose -(T' Om)^T: T = T'^-1.  A block that
+// is neither (zero weight, several measurements summed) restarts the chain at the identity.
+template <int D>
+__global__ __launch_bounds__(kBlock) void k_ml_build_P_tree(BsrDev Q, const int32_t* __restrict__ agg_ptr,
+                                                            const int32_t* __restrict__ agg_mem,
+                                                            const int32_t* __restrict__ parent,
+                                                            const int32_t* __restrict__ pslot, double* Pb, int na) {
+  constexpr int B = D + 1, BB = B * B;
+  for (int a = blockIdx.x * kBlock + threadIdx.x; a < na; a += gridDim.x * kBlock) {
+    for (int m = agg_ptr[a]; m < agg_ptr[a + 1]; ++m) {
+      const int i = agg_mem[m];
+      const int par = parent[i];
+      double G[B][B];
+#pragma unroll
+      for (int p = 0; p < B; ++p)
+#pragma unroll
+        for (int q = 0; q < B; ++q) G[p][q] = (p == q) ? 1.0 : 0.0;
+      if (par >= 0) {
+        const double* blk = Q.vals + (size_t)pslot[i] * BB;
+        const double wt = -blk[D * B + D];
+        double wk = 0.0;
+#pragma unroll
+        for (int p = 0; p < D; ++p) wk = fma(blk[p * B], blk[p * B], wk);
+        wk = sqrt(wk);
+        bool fwd = true, bwd = true;
+#pragma unroll
+        for (int q = 0; q < D; ++q) {
+          fwd = fwd && (blk[D * B + q] == 0.0);
+          bwd = bwd && (blk[q * B + D] == 0.0);
+        }
+        if ((wt > 0.0) && (wk > 0.0) && (fwd || bwd)) {
+          double Tm[B][B];
+#pragma unroll
+          for (int p = 0; p < B; ++p)
+#pragma unroll
+            for (int q = 0; q < B; ++q) Tm[p][q] = (p == q) ? 1.0 : 0.0;
+#pragma unroll
+          for (int p = 0; p < D; ++p)
+#pragma unroll
+            for (int q = 0; q < D; ++q) Tm[p][q] = -blk[p * B + q] / wk;
+          if (fwd) {
+#pragma unroll
+            for (int p = 0; p < D; ++p) Tm[p][D] = -blk[p * B + D] / wt;
+          } else {  // T'^-1 = [R'^T, -R'^T t'; 0 1],  R'^T = Tm's rotation part,  t' = -blk[D][:] / wt
+#pragma unroll
+            for (int p = 0; p < D; ++p) {
+              double sv = 0.0;
+#pragma unroll
+              for (int q = 0; q < D; ++q) sv = fma(Tm[p][q], blk[D * B + q] / wt, sv);
+              Tm[p][D] = sv;
+            }
+          }
+          const double* __restrict__ Pp = Pb + (size_t)par * BB;  // G(root -> parent)^T, written earlier by this thread
+#pragma unroll
+          for (int p = 0; p < B; ++p)
+#pragma unroll
+            for (int q = 0; q < B; ++q) {
+              double sv = 0.0;
+#pragma unroll
+              for (int mm = 0; mm < B; ++mm) sv = fma(Pp[mm * B + p], Tm[mm][q], sv);
+              G[p][q] = sv;
+            }
+        }
+      }
+      double* out = Pb + (size_t)i * BB;
+#pragma unroll
+      for (int p = 0; p < B; ++p)
+#pragma unroll
+        for (int q = 0; q < B; ++q) out[p * B + q] = G[q][p];
+    }
+  }
+}
+
 // Galerkin operator, values only:  Ac[a][bc] = sum_{i in a} sum_{j in bc} P_i^T (A_ij + [i == j] shift I) P_j.
 // One thread per coarse slot (its block row in slot_row) scans the k fine rows of aggregate a: fixed summation order.
 template <int D>
-__global__ __launch_bounds__(kBlock) void k_ml_galerkin(BsrDev A, double shift, const double* __restrict__ Pb, int k,
-                                                        int n_fine, const int32_t* __restrict__ slot_row,
+__global__ __launch_bounds__(kBlock) void k_ml_galerkin(BsrDev A, double shift, const double* __restrict__ Pb, AggMap am,
+                                                        const int32_t* __restrict__ agg_ptr,
+                                                        const int32_t* __restrict__ agg_mem, int n_fine,
+                                                        const int32_t* __restrict__ slot_row,
                                                         const int32_t* __restrict__ ccol, double* __restrict__ cvals,
                                                         int cnnzb) {
+  const int k = am.k;
   constexpr int B = D + 1, BB = B * B;
   for (int s = blockIdx.x * kBlock + threadIdx.x; s < cnnzb; s += gridDim.x * kBlock) {
     const int a = slot_row[s], bc = ccol[s];
@@ -579,12 +726,15 @@ __global__ __launch_bounds__(kBlock) void k_ml_galerkin(BsrDev A, double shift, 
     for (int p = 0; p < B; ++p)
 #pragma unroll
       for (int q = 0; q < B; ++q) acc[p][q] = 0.0;
-    const int i1 = (a * k + k < n_fine) ? a * k + k : n_fine;
-    for (int i = a * k; i < i1; ++i) {
+    // members of aggregate a: a run of k nodes, or (graph aggregates) the list agg_mem[agg_ptr[a] ..)
+    const int m0 = am.lab ? agg_ptr[a] : a * k;
+    const int m1 = am.lab ? agg_ptr[a + 1] : ((a * k + k < n_fine) ? a * k + k : n_fine);
+    for (int m = m0; m < m1; ++m) {
+      const int i = am.lab ? agg_mem[m] : m;
       const double* __restrict__ Pi = Pb + (size_t)i * BB;
       for (int t = A.rowptr[i]; t < A.rowptr[i + 1]; ++t) {
         const int j = A.colidx[t];
-        if (j / k != bc) continue;
+        if (am.of(j) != bc) continue;
         const double* __restrict__ av = A.vals + (size_t)t * BB;
         const double* __restrict__ Pj = Pb + (size_t)j * BB;
         double AP[B][B];
@@ -621,7 +771,7 @@ __global__ __launch_bounds__(kBlock) void k_ml_galerkin(BsrDev A, double shift, 
 
 // A P of level 0, values only:  AP[i][a] = sum_{j in a} (Q_ij + [i == j] shift I) P_j.  One thread per block row.
 template <int D>
-__global__ __launch_bounds__(kBlock) void k_ml_build_AP(BsrDev Q, double shift, const double* __restrict__ Pb, int k,
+__global__ __launch_bounds__(kBlock) void k_ml_build_AP(BsrDev Q, double shift, const double* __restrict__ Pb, AggMap am,
                                                         int n, BsrDev AP, double* __restrict__ apvals) {
   constexpr int B = D + 1, BB = B * B;
   for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
@@ -634,7 +784,7 @@ __global__ __launch_bounds__(kBlock) void k_ml_build_AP(BsrDev Q, double shift, 
         for (int q = 0; q < B; ++q) acc[p][q] = 0.0;
       for (int t = Q.rowptr[i]; t < Q.rowptr[i + 1]; ++t) {
         const int j = Q.colidx[t];
-        if (j / k != a) continue;
+        if (am.of(j) != a) continue;
         const double* __restrict__ Aij = Q.vals + (size_t)t * BB;
         const double* __restrict__ Pj = Pb + (size_t)j * BB;
 #pragma unroll

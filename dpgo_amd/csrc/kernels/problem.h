@@ -6,7 +6,7 @@
 // OUT = V*Q (+ Gadd).  QuadraticProblem::EucGrad / EucHessianEta
 // (src/QuadraticProblem.cpp:43-54) and, with a rectangular coupling matrix, PoseGraph::constructG
 // (src/PoseGraph.cpp:493-580).
-template <int D, int R, int SPLIT>
+template <int D, int R, int SPLIT, int NTS = 0>
 __global__ __launch_bounds__(kBlock) void k_spmm(BsrDev Q, const double* __restrict__ V,
                                                  const double* __restrict__ Gadd, double* __restrict__ OUT,
                                                  int n) {
@@ -24,15 +24,15 @@ __global__ __launch_bounds__(kBlock) void k_spmm(BsrDev Q, const double* __restr
       const size_t off = (size_t)i * GEO::T + L.c * R;
       if (Gadd) {
 #pragma unroll
-        for (int a = 0; a < R; ++a) acc[a] += Gadd[off + a];
+        for (int a = 0; a < R; ++a) acc[a] += ld_stream<NTS>(Gadd + off + a);
       }
-      store_col<R>(OUT + off, acc);
+      store_col_stream<NTS, R>(OUT + off, acc);
     }
   }
 }
 
 // ================================================================ K1 on symmetric storage (common.h, spmm_sym_pre)
-template <int D, int R>
+template <int D, int R, int NTS>
 __global__ __launch_bounds__(kBlock) void k_spmm_sym(BsrSymDev Q, const double* __restrict__ V,
                                                      const double* __restrict__ Gadd, double* __restrict__ OUT, int n) {
   using GEO = Geo<D, R, 1>;
@@ -49,9 +49,9 @@ __global__ __launch_bounds__(kBlock) void k_spmm_sym(BsrSymDev Q, const double* 
       const size_t off = (size_t)i * GEO::T + L.c * R;
       if (Gadd) {
 #pragma unroll
-        for (int a = 0; a < R; ++a) out[a] += Gadd[off + a];
+        for (int a = 0; a < R; ++a) out[a] += ld_stream<NTS>(Gadd + off + a);
       }
-      store_col<R>(OUT + off, out);
+      store_col_stream<NTS, R>(OUT + off, out);
     }
   }
 }

@@ -454,7 +454,8 @@ class QuadraticProblem:
         return int(v.value)
 
     def setupMultilevel(self, ks=None, omega: float = 0.7, shift: float = 1e-1, coarse_bits=None) -> dict:
-        """Explicit setup for the current Q: ks = aggregate sizes per coarsening (None: the library's defaults),
+        """Explicit setup for the current Q: ks = aggregate sizes per coarsening (None: the library's defaults; a single
+        negative entry -S = two levels with graph aggregates of at most S poses, see dpgo_hip.h),
         coarse_bits = storage precision of the dense level (None: keep the handle's, 64 by default; 32 = opt-in).
         Returns multilevelInfo()."""
         self.refresh()
@@ -484,7 +485,8 @@ class QuadraticProblem:
         return bool(v.value)
 
     def multilevelInfo(self) -> dict:
-        """{"sizes": nodes per level, "ks": aggregate size per coarsening, "nnzb": blocks of A_l per level}."""
+        """{"sizes": nodes per level, "ks": aggregate size per coarsening (negative: graph aggregates of at most that many
+        poses), "nnzb": blocks of A_l per level}."""
         cap = 16
         nl = C.c_int(cap)
         sizes, ks, nnzb = (np.zeros(cap, dtype=np.int32) for _ in range(3))
@@ -494,7 +496,8 @@ class QuadraticProblem:
 
     def multilevelGet(self, level: int, what: str) -> np.ndarray:
         """Copy of one item of the built hierarchy: "P" (prolongation blocks of a level), "rowptr" / "colidx" / "A"
-        (Galerkin operator of a level >= 1), "inverse" (dense inverse of the last level)."""
+        (Galerkin operator of a level >= 1), "inverse" (dense inverse of the last level), "labels" (graph aggregates:
+        the aggregate of every pose), "ap_nnzb" (two levels: blocks of A P, a 1-element array)."""
         info = self.multilevelInfo()
         b = self.dimension() + 1
         n_l, nz = info["sizes"][level], info["nnzb"][level]
@@ -502,6 +505,8 @@ class QuadraticProblem:
                      "rowptr": (L.ML_A_ROWPTR, np.zeros(n_l + 1, dtype=np.int32)),
                      "colidx": (L.ML_A_COLIDX, np.zeros(nz, dtype=np.int32)),
                      "A": (L.ML_A_VALUES, np.zeros((nz, b, b))),
+                     "labels": (L.ML_AGG_LABELS, np.zeros(n_l, dtype=np.int32)),
+                     "ap_nnzb": (L.ML_AP_NNZB, np.zeros(1, dtype=np.int32)),
                      "inverse": (L.ML_DENSE_INVERSE, np.zeros((n_l * b, n_l * b)))}[what]
         L.check(self._lib.dpgo_problem_multilevel_get(self._h, int(level), code, L.ptr(out)))
         return out

@@ -196,18 +196,26 @@ int dpgo_problem_get_Q_values(dpgo_problem_t h, double* vals_host);
  * patterns of the coarse operators are the only host step, once per pattern of Q).  The hierarchy is built lazily by
  * the first solve that needs it and rebuilt (values only) after Q's values changed (set_Q_*, update_Q_values, GNC
  * re-weighting), exactly where the reference drops its factor (src/PoseGraph.cpp:352-355,582-586).
- *   dpgo_problem_setup_multilevel: explicit setup.  nks = 0: default aggregate sizes (dpgo_multilevel_default_ks);
- *     otherwise nks coarsenings with the given sizes (each must divide the workgroup tile of its level:
- *     16 nodes for levels below 40 000 nodes in 3-D, 64 above; 20 / 84 in 2-D).  omega: smoother damping (0.7);
- *     shift: the reference's 0.1.  Explicit sizes stick to the handle until the next call.
+ *   dpgo_problem_setup_multilevel: explicit setup.  nks = 0: default aggregates (dpgo_multilevel_default_ks);
+ *     otherwise nks coarsenings with the given sizes.  A positive size k: the nodes of the next level are RUNS of k
+ *     consecutive nodes, prolongation along the odometry chain (k must divide the workgroup tile of its level: 16 nodes
+ *     for levels below 40 000 nodes in 3-D, 64 above; 20 / 84 in 2-D).  A single negative size -S: two levels with
+ *     GRAPH aggregates of at most S poses -- grown breadth-first over Q's block pattern from seeds in index order,
+ *     prolongation composed along each aggregate's breadth-first tree (compact aggregates: 40-60 % of the
+ *     Hessian-vector products of index runs of the same size; the default whenever one coarsening with S <= 512
+ *     reaches a dense level of about 2 500 unknowns, i.e. up to 200 000 poses in 3-D; DPGO_ML_GRAPH=0 restores runs).
+ *     omega: smoother damping (0.7); shift: the reference's 0.1.  Explicit sizes stick to the handle until the next call.
  *   dpgo_problem_multilevel_info: *nlevels in = capacity of the arrays, out = number of levels (coarsenings + 1);
- *     sizes[l] = nodes, ks[l] = aggregate size towards level l+1 (0 on the last), nnzb[l] = blocks of A_l.
+ *     sizes[l] = nodes, ks[l] = aggregate size towards level l+1 (0 on the last; negative: graph aggregates of at most
+ *     that many nodes), nnzb[l] = blocks of A_l.
  *   dpgo_problem_multilevel_get: copy one item of a built hierarchy to the host (tests / inspection). */
 #define DPGO_ML_P_BLOCKS 0      /* level < last: n_l blocks (d+1)x(d+1), row-major                  (double) */
 #define DPGO_ML_A_ROWPTR 1      /* level >= 1: n_l + 1                                              (int32)  */
 #define DPGO_ML_A_COLIDX 2      /* level >= 1: nnzb_l                                               (int32)  */
 #define DPGO_ML_A_VALUES 3      /* level >= 1: nnzb_l blocks, row-major                             (double) */
 #define DPGO_ML_DENSE_INVERSE 4 /* last level: (n_L (d+1))^2, row-major                             (double) */
+#define DPGO_ML_AGG_LABELS 5    /* level 0 with graph aggregates: aggregate of every pose, n_0         (int32)  */
+#define DPGO_ML_AP_NNZB 6       /* level 0 of a two-level hierarchy: blocks of A P, one value          (int32)  */
 int dpgo_multilevel_default_ks(int n, int d, int* ks, int* nks); /* *nks in: capacity of ks, out: count */
 int dpgo_problem_setup_multilevel(dpgo_problem_t h, int nks, const int* ks, double omega, double shift);
 int dpgo_problem_multilevel_info(dpgo_problem_t h, int* nlevels, int* sizes, int* ks, int* nnzb);

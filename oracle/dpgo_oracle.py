@@ -29,6 +29,7 @@ here as a C-contiguous array X[n, d+1, r]: X[i, k, a] == X_ref(a, i*(d+1)+k).
 from __future__ import annotations
 
 import math
+import os
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional, Tuple
 
@@ -375,11 +376,91 @@ def project_to_rotation_group(M):
 AMG_DENSE, AMG_DENSE_MAX = 3200, 6400  # unknowns of the dense coarsest operator (82 MB / 328 MB in fp64)
 
 
+AMG_GRAPH_MAX, AMG_GRAPH_UNKNOWNS_PER_POSE = 512, 1600
+
+
+def amg_default_graph_size(n: int, b: int) -> int:
+    """Mirrors ml_default_graph_size (dpgo_amd/csrc/dpgo_hip.hip): the largest aggregate of the default two-level
+    hierarchy with GRAPH aggregates, 0 where the default is a hierarchy of index runs (more than one coarsening needed)."""
+    if os.environ.get("DPGO_ML_GRAPH", "1") == "0":
+        return 0
+    if int(os.environ.get("DPGO_ML_GRAPH_SIZE", "0")) >= 2:  # experiments: force the size
+        return int(os.environ["DPGO_ML_GRAPH_SIZE"])
+    S = max(4, -(-(n * b) // AMG_GRAPH_UNKNOWNS_PER_POSE))
+    return S if S <= AMG_GRAPH_MAX else 0
+
+
+def amg_graph_aggregates(Q: "BSR", S: int):
+    """Mirrors ml_graph_aggregates: aggregates of at most S nodes grown greedily over Q's block pattern -- seeds in index
+    order; a seed's aggregate takes unassigned nodes in breadth-first order (FIFO; a node's neighbours in the order of its
+    block row) until it holds S.  Returns (lab[n], ptr[na+1], mem[n] in discovery order, parent[n] (-1: root), pslot[n] =
+    slot of block (parent, node))."""
+    n = Q.n
+    rowptr, colidx = np.asarray(Q.rowptr), np.asarray(Q.colidx)
+    lab = -np.ones(n, dtype=np.int64)
+    parent = -np.ones(n, dtype=np.int64)
+    pslot = np.zeros(n, dtype=np.int64)
+    mem: List[int] = []
+    ptr = [0]
+    na = 0
+    for s in range(n):
+        if lab[s] >= 0:
+            continue
+        first = len(mem)
+        lab[s] = na
+        mem.append(s)
+        head = first
+        while head < len(mem) and len(mem) - first < S:
+            u = mem[head]
+            head += 1
+            for t in range(rowptr[u], rowptr[u + 1]):
+                if len(mem) - first >= S:
+                    break
+                v = colidx[t]
+                if lab[v] >= 0:
+                    continue
+                lab[v] = na
+                parent[v] = u
+                pslot[v] = t
+                mem.append(v)
+        ptr.append(len(mem))
+        na += 1
+    return lab, np.asarray(ptr, dtype=np.int64), np.asarray(mem, dtype=np.int64), parent, pslot
+
+
+def amg_tree_prolongation(Q: "BSR", d: int, mem, parent, pslot):
+    """Mirrors k_ml_build_P_tree: Pb[i] = G(root of i's aggregate -> i)^T, composed along the aggregate's breadth-first
+    tree.  The relative pose of a tree edge parent -> i is read off the block Q[parent, i]: a measurement parent -> i
+    leaves -T Om = -[w kappa R, w tau t; 0, w tau] there (last row zero but for -w tau), a measurement i -> parent its
+    transpose -(T' Om)^T (last column zero but for -w tau; T = T'^-1).  Anything else (zero weight, several measurements
+    summed): the chain restarts at the identity."""
+    b = d + 1
+    Pb = np.zeros((Q.n, b, b))
+    for i in mem:  # discovery order: a parent precedes its children
+        G = np.eye(b)
+        par = parent[i]
+        if par >= 0:
+            blk = Q.vals[pslot[i]]
+            wt = -blk[d, d]
+            wk = np.linalg.norm(blk[:d, 0])
+            fwd, bwd = bool(np.all(blk[d, :d] == 0.0)), bool(np.all(blk[:d, d] == 0.0))
+            if wt > 0 and wk > 0 and (fwd or bwd):
+                T = np.eye(b)
+                T[:d, :d] = -blk[:d, :d] / wk
+                T[:d, d] = (-blk[:d, d] / wt) if fwd else T[:d, :d] @ (blk[d, :d] / wt)
+                G = Pb[par].T @ T
+        Pb[i] = G.T
+    return Pb
+
+
 def amg_default_ks(n: int, b: int, split0: Optional[int] = None) -> List[int]:
     """Aggregate sizes (one per coarsening) of the device's multilevel preconditioner; mirrors ml_default_ks
     (dpgo_amd/csrc/dpgo_hip.hip).  Every k divides the workgroup tile of its level ((64 / (b split)) * 4 nodes, split = 4
     lane groups per node below 40 000 nodes, else 1); the coarsest operator is a dense inverse of at most AMG_DENSE
     unknowns, AMG_DENSE_MAX if that is what it takes to get there in one coarsening; otherwise one more level."""
+    S = amg_default_graph_size(n, b)
+    if S:
+        return [-S]
     lsplit = lambda m: 4 if m < 40000 else 1  # noqa: E731
     ks: List[int] = []
     cur, split = n, (split0 or lsplit(n))
@@ -554,14 +635,20 @@ class QuadraticProblem:
             elif isinstance(ks, (int, np.integer)):
                 ks = [int(ks)]
             ks = [int(k) for k in ks]
-            Pbs = amg_chain_prolongations(self.Q, self.d, ks)
+            graph = len(ks) == 1 and ks[0] < 0  # two levels, graph aggregates of at most -ks[0] poses
+            if graph:
+                lab, _, mem, parent, pslot = amg_graph_aggregates(self.Q, -ks[0])
+                Pbs = [amg_tree_prolongation(self.Q, self.d, mem, parent, pslot)]
+            else:
+                Pbs = amg_chain_prolongations(self.Q, self.d, ks)
             b = self.b
             A = (self.Qs + self.shift * sp.identity(self.N, format="csr")).tocsr()
             levels, cur = [], self.n
             for k, Pb in zip(ks, Pbs):
-                nc = (cur + k - 1) // k
+                agg = lab if graph else np.arange(cur) // k
+                nc = int(agg.max()) + 1 if graph else (cur + k - 1) // k
                 rows = (np.arange(cur)[:, None, None] * b + np.arange(b)[None, :, None]) + np.zeros((1, 1, b), dtype=np.int64)
-                cols = ((np.arange(cur) // k)[:, None, None] * b + np.arange(b)[None, None, :]) + np.zeros((1, b, 1), dtype=np.int64)
+                cols = (agg[:, None, None] * b + np.arange(b)[None, None, :]) + np.zeros((1, b, 1), dtype=np.int64)
                 P = sp.csr_matrix((Pb.ravel(), (rows.ravel(), cols.ravel())), shape=(cur * b, nc * b))
                 Ab = A.tobsr(blocksize=(b, b))
                 Ab.sort_indices()

@@ -207,6 +207,44 @@ def test_multilevel_hierarchy_rules(name, ks):
     ks = ks or O.amg_default_ks(n, b)
     odo = om.subset(np.nonzero(om.p1 + 1 == om.p2)[0])
     Qo = O.construct_Q(n, d, odo)
+    if len(ks) == 1 and ks[0] < 0:
+        # graph aggregates (the default two-level hierarchy): the prolongation composed along each aggregate's
+        # breadth-first tree (k_ml_build_P_tree) reproduces the rigid-body modes -- on the odometry chain, and on a spanning
+        # tree of the whole graph whose edges are measured in either direction
+        lab, ptr, mem, parent, pslot = O.amg_graph_aggregates(Qo, -ks[0])
+        assert sorted(mem.tolist()) == list(range(n)) and np.all(np.diff(ptr) <= -ks[0]) and np.all(np.diff(ptr) >= 1)
+        assert np.all(lab[parent[parent >= 0]] == lab[parent >= 0])
+        V = O.amg_tree_prolongation(Qo, d, mem, parent, pslot)
+        R = (Qo.to_scipy() @ V.reshape(n * b, b)).reshape(n, b, b)
+        nb_same = np.array([all(lab[Qo.colidx[t]] == lab[i] for t in range(Qo.rowptr[i], Qo.rowptr[i + 1])) for i in range(n)])
+        assert nb_same.any() and (~nb_same).any()
+        assert np.abs(R[nb_same]).max() <= 1e-7 * np.abs(Qo.vals).max()
+        assert np.abs(R[~nb_same]).max() > 1e-3 * np.abs(Qo.vals).max()  # rows at a cut see a residual
+        # spanning tree of ALL edges, every other edge reversed (measured child -> parent): one aggregate, no residual
+        Qa = O.construct_Q(n, d, om)
+        _, _, mem_a, par_a, _ = O.amg_graph_aggregates(Qa, n)
+        tree = {(int(par_a[i]), int(i)) for i in range(n) if par_a[i] >= 0}
+        sel, flip = [], []
+        for e in range(len(om.p1)):
+            a, c = int(om.p1[e]), int(om.p2[e])
+            if (a, c) in tree or (c, a) in tree:
+                tree.discard((a, c)), tree.discard((c, a))
+                sel.append(e), flip.append(len(sel) % 2 == 0)
+        tm = om.subset(np.array(sel))
+        for q, f in enumerate(flip):
+            if f:  # the same constraint measured the other way round: T^-1
+                Rm, tv = tm.R[q].copy(), tm.t[q].copy()
+                tm.R[q], tm.t[q] = Rm.T, -Rm.T @ tv
+                tm.p1[q], tm.p2[q] = tm.p2[q], tm.p1[q]
+        if len(sel) == n - 1:  # (the data set's graph is connected)
+            Qt = O.construct_Q(n, d, tm)
+            _, ptr_t, mem_t, par_t, ps_t = O.amg_graph_aggregates(Qt, n)
+            assert len(ptr_t) == 2
+            Vt = O.amg_tree_prolongation(Qt, d, mem_t, par_t, ps_t)
+            Rt = (Qt.to_scipy() @ Vt.reshape(n * b, b)).reshape(n, b, b)
+            # (the reversed edges carry their information rotated: kappa, tau isotropic, so the kernel is the same)
+            assert np.abs(Rt).max() <= 1e-7 * np.abs(Qt.vals).max()
+        return
     Pbs = O.amg_chain_prolongations(Qo, d, ks)
     # V = P_0 P_1 ... restricted to blocks: V_i = Pb_0[i] Pb_1[i // k_0] ...
     V = np.zeros((n, b, b))

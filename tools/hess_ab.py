@@ -24,6 +24,14 @@ print("%s  library %s  n %d nnzb %d  hess bytes %.1f MB" % (name, dpgo_amd.lib.L
 for variant in ("plain", "symmetric"):
     if prob.setSpmmVariant(variant) != variant:
         continue
+    sb = bench.spmm_bytes(n, nnzb, d, r)
+    ms_rot, setb, ms_w = C.c_double(0.0), C.c_double(0.0), C.c_double(0.0)
+    dpgo_amd.lib.check(lib.dpgo_bench_spmm_rotating(prob.handle, nsets * (2 if variant == "symmetric" else 1), 200, 10,
+                                                    C.byref(ms_rot), C.byref(setb)))
+    dpgo_amd.lib.check(lib.dpgo_bench_spmm(prob.handle, 200, 10, C.byref(ms_w)))
+    print("  %-9s k_spmm cold %.2f us (%.3f)   warm %.2f us (%.3f)   %s" % (
+        variant, ms_rot.value * 1e3, sb / ms_rot.value / 1e6 / 8000.0, ms_w.value * 1e3, sb / ms_w.value / 1e6 / 8000.0,
+        prob.tcgKernelInfo()), flush=True)
     for rep in range(2):
         cold, warm = C.c_double(0.0), C.c_double(0.0)
         dpgo_amd.lib.check(lib.dpgo_bench_hess_rotating(prob.handle, hsets + (variant == "symmetric"), 200, 10, C.byref(cold)))
