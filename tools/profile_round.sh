@@ -15,6 +15,7 @@ cd $R
 python tools/summarize_prof.py stats gpurun_out/prof_$TAG gpurun_out/${TAG}_bench_kernel_stats.csv
 python tools/summarize_prof.py pmc gpurun_out/${TAG}_pmc_fetch_write.json \
   FETCH_SIZE=gpurun_out/pmc_${TAG}_FETCH_SIZE WRITE_SIZE=gpurun_out/pmc_${TAG}_WRITE_SIZE
+cp gpurun_out/${TAG}_pmc_fetch_write.json profiles/  # bench.py reads roofline.traffic from the newest committed summary
 python bench.py 2>/dev/null | tail -1 > gpurun_out/${TAG}_bench.json
 rm -rf gpurun_out/prof_$TAG gpurun_out/pmc_${TAG}_FETCH_SIZE gpurun_out/pmc_${TAG}_WRITE_SIZE
 head -12 gpurun_out/${TAG}_bench_kernel_stats.csv | cut -c1-150
