@@ -136,6 +136,7 @@ struct dpgo_problem_s {
     // aggregate in discovery order, the spanning tree the prolongation is composed along, P_i^T res_i of every pose
     bool graph = false;
     int32_t *lab = nullptr, *agg_ptr = nullptr, *agg_mem = nullptr, *parent = nullptr, *pslot = nullptr;
+    int32_t* tile_perm = nullptr;  // aggregates of at most one persistent tile: pose of every (aggregate, slot), -1 = empty
     double* tbuf = nullptr;
     AggMap agg() const { return AggMap{graph ? lab : nullptr, k}; }
   };
@@ -698,7 +699,7 @@ void ml_free(dpgo_problem_s* p) {
   for (auto& L : p->ml) {
     free_bsr(L.A);
     free_bsr(L.AP);
-    void* ptrs[] = {L.slot_row, L.dinv, L.Pb, L.r, L.x1, L.x, L.res1, L.lab, L.agg_ptr, L.agg_mem, L.parent, L.pslot, L.tbuf};
+    void* ptrs[] = {L.slot_row, L.dinv, L.Pb, L.r, L.x1, L.x, L.res1, L.lab, L.agg_ptr, L.agg_mem, L.parent, L.pslot, L.tbuf, L.tile_perm};
     for (void* q : ptrs)
       if (q) (void)hipFree(q);
   }
@@ -783,6 +784,13 @@ int ml_symbolic_setup(dpgo_problem_s* p, const std::vector<int>& ks_in) {
       CHK(upload(&L.agg_mem, mem.data(), mem.size(), p->stream));
       CHK(upload(&L.parent, parent.data(), parent.size(), p->stream));
       CHK(upload(&L.pslot, pslot.data(), pslot.size(), p->stream));
+      std::vector<int32_t> tperm;
+      if (L.k == additive_tile(p)) {  // the layout of the additive preconditioner's persistent kernel: aggregate = tile
+        tperm.assign((size_t)na * L.k, -1);
+        for (int a = 0; a < na; ++a)
+          for (int m = ptr[a]; m < ptr[a + 1]; ++m) tperm[(size_t)a * L.k + (m - ptr[a])] = mem[m];
+        CHK(upload(&L.tile_perm, tperm.data(), tperm.size(), p->stream));
+      }
       HIPC(hipMalloc(&L.tbuf, tb * cur));
       // pattern of A P: the aggregates the block columns of every row fall into
       std::vector<int32_t> arow(cur + 1, 0), acol;
@@ -1005,10 +1013,19 @@ int ml_ensure(dpgo_problem_s* p, double shift, bool additive = false) {
   // caller set up explicitly is kept if it has that shape, the default one is replaced (and put back when the V-cycle
   // is asked for again)
   const int Pa = additive_tile(p);
-  const bool shape_ok = p->ml_symbolic && p->ml.size() == 2 && !p->ml[0].graph && p->ml[0].k == Pa && p->split == 4;
+  const bool shape_ok = p->ml_symbolic && p->ml.size() == 2 && p->ml[0].k == Pa && p->split == 4 &&
+                        (!p->ml[0].graph || p->ml[0].tile_perm) && p->ml[1].n <= kPersistMax;
   if (additive && !shape_ok) {
     if (p->split != 4) return fail(DPGO_ERR_UNSUPPORTED, "additive preconditioner: small-block layout only");
-    CHK(ml_symbolic_setup(p, std::vector<int>{Pa}));
+    // graph aggregates of at most one tile (about half the products of index runs) while they fit the
+    // kernel's 256 workgroups -- the greedy growth leaves fragments, so there are more of them than n / tile --, else runs
+    static const bool graph_ok = [] { const char* e = std::getenv("DPGO_ML_GRAPH"); return !e || std::atoi(e) != 0; }();
+    bool done = false;
+    if (graph_ok) {
+      CHK(ml_symbolic_setup(p, std::vector<int>{-Pa}));
+      done = p->ml[1].n <= kPersistMax;
+    }
+    if (!done) CHK(ml_symbolic_setup(p, std::vector<int>{Pa}));
     p->ml_additive_layout = true;
     p->ml_user_ks = false;
   } else if (!additive && p->ml_additive_layout && !p->ml_user_ks) {
@@ -1028,7 +1045,7 @@ int ml_ensure(dpgo_problem_s* p, double shift, bool additive = false) {
 // most of the chip idle while the dense inverse streams).
 int launch_coarse_prolong(dpgo_problem_s* p, const dpgo_problem_s::MlLevel& L, const dpgo_problem_s::MlLevel& C,
                           const DevState* gate, double* xc_out = nullptr) {
-  int nodes = C.n >= 1024 ? 2 : 1;
+  int nodes = C.n >= 512 ? 2 : 1;  // (732 nodes: 19.7 -> 17.1 us; 4 per workgroup: 18.1)
   if (const char* e = std::getenv("DPGO_COARSE_NODES")) {  // tuning knob
     const int v = std::atoi(e);
     nodes = (v == 4 || v == 2) ? v : 1;
@@ -1247,7 +1264,8 @@ bool additive_available(const dpgo_problem_s* p) {
 PersistGeo persist_geometry(const dpgo_problem_s* p, int free_slots, int share = 1, bool additive = false) {
   if (additive) {  // fixed layout; one workgroup per CU (the rows of the coarse inverse live in its LDS)
     const int P = additive_tile(p);
-    PersistGeo g{4, 1, (p->n + P - 1) / P, 0};
+    const int na = (p->ml.size() == 2 && p->ml[0].k == P) ? p->ml[1].n : (p->n + P - 1) / P;  // (after ml_ensure: the hierarchy's)
+    PersistGeo g{4, 1, na, 0};
     g.slots = g.wgs * persist_slots_per_wg(4, 1, true);
     if (g.wgs > kPersistMax || g.slots > free_slots) return PersistGeo();
     return g;
@@ -1321,7 +1339,7 @@ int launch_rtr_persistent(dpgo_problem_s* p, const dpgo_ropt_params* prm, const 
   if (additive) {
     auto& L0 = p->ml[0];
     auto& C = p->ml[1];
-    add = AddDev{L0.Pb, p->ml_dense, p->ml_lda, C.n, C.r, 1.0};
+    add = AddDev{L0.Pb, p->ml_dense, p->ml_lda, C.n, C.r, 1.0, L0.graph ? L0.tile_perm : nullptr};
     lds = sizeof(double) * (size_t)p->b * C.n * p->b;  // (d+1) rows of the inverse
   }
   const RtrArgs ra{prm->gradnorm_tol, prm->RTR_initial_radius, 5.0 * prm->RTR_initial_radius, prm->RTR_tCG_iterations,

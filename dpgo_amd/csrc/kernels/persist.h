@@ -289,6 +289,9 @@ struct AddDev {
   int lda, nc;         // nc coarse nodes = pose tiles
   double* rc;          // [nc][D+1][R] restricted residual (written and gathered inside the launch)
   double w;            // weight of the block-Jacobi term
+  // graph aggregates: pose of every (aggregate, slot), nc x tile entries, -1 = empty slot; nullptr: aggregate a = the
+  // poses [a tile, (a + 1) tile)
+  const int32_t* perm;
 };
 
 // Trust-region parameters of a solve (src/QuadraticOptimizer.cpp:64-78)
@@ -335,8 +338,10 @@ __global__ __launch_bounds__(kBlock, 1) void k_rtr_persist(BsrDev Q, double* X, 
   unsigned step = 0;
   const LaneId L = lane_id<D, SPLIT>();
   const int lp = L.wave * G + L.g;  // pose slot inside a workgroup tile
-  const int ntiles = (n + P - 1) / P;
+  // (additive preconditioner: a workgroup's tile = an aggregate; with graph aggregates its poses are anywhere)
+  const int ntiles = ADD ? add.nc : (n + P - 1) / P;
   const int co = L.c * R;
+  __shared__ int pidx_s[ADD ? P : 1];  // ADD: pose of every slot of the tile (-1: empty), for the publishing lanes
 
   // ---- resident data of the workgroup's rows (registers; X and z also in LDS)
   // block columns resident in registers (2 blocks per lane group with SPLIT = 4; with SPLIT = 1 the row's first 2 (D+1)
@@ -358,7 +363,14 @@ __global__ __launch_bounds__(kBlock, 1) void k_rtr_persist(BsrDev Q, double* X, 
   for (int k = 0; k < MT; ++k) {
     const int tile = rank + k * members;
     pose[k] = tile * P + lp;
-    okp[k] = (tile < ntiles) && (L.g < G) && (pose[k] < n);
+    if constexpr (ADD) {
+      if (add.perm) pose[k] = (tile < ntiles && L.g < G) ? add.perm[tile * P + lp] : -1;
+    }
+    okp[k] = (tile < ntiles) && (L.g < G) && (pose[k] >= 0) && (pose[k] < n);
+    if (!okp[k]) pose[k] = 0;  // (a valid row for the wave-cooperative helpers; never used)
+    if constexpr (ADD) {
+      if (L.s == 0 && L.c == 0 && L.g < G) pidx_s[lp] = okp[k] ? pose[k] : -1;
+    }
     own[k] = okp[k] && (L.s == 0);
     gather_setup<D, R, SPLIT, QRES>(go[k], Q, pose[k], L.s, L.c, okp[k]);
 #pragma unroll
@@ -464,6 +476,31 @@ __global__ __launch_bounds__(kBlock, 1) void k_rtr_persist(BsrDev Q, double* X, 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this thread's z stores have been acknowledged
   };
 
+  // ---- ADD: the wave's pose slots leave as lane-linear 16-byte write-through pieces, every pose to its own place (the
+  // poses of a graph aggregate are not contiguous)
+  [[maybe_unused]] auto publish_slots = [&](__amdgpu_buffer_rsrc_t rs, const double* wave_tile) {
+    if constexpr (ADD && T % 2 == 0) {
+      const dbl2* span = reinterpret_cast<const dbl2*>(wave_tile);
+#pragma unroll
+      for (int it = 0; it < (G * (T / 2) + 63) / 64; ++it) {
+        const int pc = (int)(threadIdx.x & 63) + 64 * it;
+        if (pc < G * (T / 2)) {
+          const int ps = pc / (T / 2), sub = pc - ps * (T / 2);
+          const int gp = pidx_s[L.wave * G + ps];
+          if (gp >= 0) {
+            const dbl2 v = span[pc];
+            u32x4 w;
+            w.x = (unsigned)__double2loint(v.x);
+            w.y = (unsigned)__double2hiint(v.x);
+            w.z = (unsigned)__double2loint(v.y);
+            w.w = (unsigned)__double2hiint(v.y);
+            __builtin_amdgcn_raw_buffer_store_b128(w, rs, (gp * T + 2 * sub) * 8, 0, kAuxSc1);
+          }
+        }
+      }
+    }
+  };
+
   // ---- additive preconditioner, first half: r, eta update; x1 = Dinv r (kept in zc); rc = sum over the tile of P_i^T r_i
   auto phase_add_restrict = [&](bool first, double alpha, double (&part)[1]) {
     part[0] = 0.0;
@@ -564,23 +601,7 @@ __global__ __launch_bounds__(kBlock, 1) void k_rtr_persist(BsrDev Q, double* X, 
       }
       if constexpr (T % 2 == 0) {
         wave_sync();
-        const int p0w = rank * P + L.wave * G;
-        const int npose = (n - p0w) < G ? (n - p0w) : G;
-        const int pieces = npose > 0 ? npose * (T / 2) : 0;
-        const dbl2* span = reinterpret_cast<const dbl2*>(&Zs[0][L.wave * G][0]);
-#pragma unroll
-        for (int it = 0; it < (G * (T / 2) + 63) / 64; ++it) {
-          const int pc = (int)(threadIdx.x & 63) + 64 * it;
-          if (pc < pieces) {
-            const dbl2 v = span[pc];
-            u32x4 w;
-            w.x = (unsigned)__double2loint(v.x);
-            w.y = (unsigned)__double2hiint(v.x);
-            w.z = (unsigned)__double2loint(v.y);
-            w.w = (unsigned)__double2hiint(v.y);
-            __builtin_amdgcn_raw_buffer_store_b128(w, rz, (p0w * T + 2 * pc) * 8, 0, kAuxSc1);
-          }
-        }
+        publish_slots(rz, &Zs[0][L.wave * G][0]);
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
@@ -640,7 +661,10 @@ __global__ __launch_bounds__(kBlock, 1) void k_rtr_persist(BsrDev Q, double* X, 
   // ones column by column from registers
   auto publish_tile = [&](double* gbuf, __amdgpu_buffer_rsrc_t rs, const double* wave_tile, int tile, int k,
                           const double (&col)[R]) {
-    if constexpr (T % 2 == 0) {
+    if constexpr (ADD && T % 2 == 0) {
+      wave_sync();
+      publish_slots(rs, wave_tile);
+    } else if constexpr (T % 2 == 0) {
       wave_sync();
       const int p0w = tile * P + L.wave * G;
       const int npose = (n - p0w) < G ? (n - p0w) : G;
