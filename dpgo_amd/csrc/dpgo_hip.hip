@@ -136,6 +136,7 @@ struct dpgo_problem_s {
     // aggregate in discovery order, the spanning tree the prolongation is composed along, P_i^T res_i of every pose
     bool graph = false;
     int32_t *lab = nullptr, *agg_ptr = nullptr, *agg_mem = nullptr, *parent = nullptr, *pslot = nullptr;
+    int32_t* mem_pos = nullptr;    // position of every pose in agg_mem (where k_ml_restrict writes its P_i^T res_i)
     int32_t* tile_perm = nullptr;  // aggregates of at most one persistent tile: pose of every (aggregate, slot), -1 = empty
     double* tbuf = nullptr;
     AggMap agg() const { return AggMap{graph ? lab : nullptr, k}; }
@@ -699,7 +700,7 @@ void ml_free(dpgo_problem_s* p) {
   for (auto& L : p->ml) {
     free_bsr(L.A);
     free_bsr(L.AP);
-    void* ptrs[] = {L.slot_row, L.dinv, L.Pb, L.r, L.x1, L.x, L.res1, L.lab, L.agg_ptr, L.agg_mem, L.parent, L.pslot, L.tbuf, L.tile_perm};
+    void* ptrs[] = {L.slot_row, L.dinv, L.Pb, L.r, L.x1, L.x, L.res1, L.lab, L.agg_ptr, L.agg_mem, L.parent, L.pslot, L.tbuf, L.tile_perm, L.mem_pos};
     for (void* q : ptrs)
       if (q) (void)hipFree(q);
   }
@@ -784,6 +785,9 @@ int ml_symbolic_setup(dpgo_problem_s* p, const std::vector<int>& ks_in) {
       CHK(upload(&L.agg_mem, mem.data(), mem.size(), p->stream));
       CHK(upload(&L.parent, parent.data(), parent.size(), p->stream));
       CHK(upload(&L.pslot, pslot.data(), pslot.size(), p->stream));
+      std::vector<int32_t> mpos(cur);
+      for (int m = 0; m < cur; ++m) mpos[mem[m]] = m;
+      CHK(upload(&L.mem_pos, mpos.data(), mpos.size(), p->stream));
       std::vector<int32_t> tperm;
       if (L.k == additive_tile(p)) {  // the layout of the additive preconditioner's persistent kernel: aggregate = tile
         tperm.assign((size_t)na * L.k, -1);
@@ -1113,14 +1117,14 @@ int launch_ml_restrict0(dpgo_problem_s* p, const double* r, const DevState* gate
   if (p->tcg_sym) {  // level 0 reads Q: the symmetric copy when the tCG-step kernel does
     DISPATCH(p->d, p->r, hipLaunchKernelGGL((k_ml_restrict<D, R, 1, BsrSymDev>), dim3(g0), dim3(kBlock), 0, p->stream,
                                             p->sym.dev(), L.x1, r, L.Pb, p->ml_shift, L.k, C.r, rc32, dnext, p->ml_omega,
-                                            C.x1, gate, L.n, res_out, L.tbuf));
+                                            C.x1, gate, L.n, res_out, L.tbuf, L.mem_pos));
   } else {
     DISPATCH(p->d, p->r, LAUNCH_SPLIT(p, k_ml_restrict, g0, p->Q.dev(), L.x1, r, L.Pb, p->ml_shift, L.k, C.r, rc32, dnext,
-                                      p->ml_omega, C.x1, gate, L.n, res_out, L.tbuf));
+                                      p->ml_omega, C.x1, gate, L.n, res_out, L.tbuf, L.mem_pos));
   }
   if (L.graph)
     DISPATCH(p->d, p->r, hipLaunchKernelGGL((k_ml_agg_sum<D, R>), dim3(std::min(C.n, kMaxGrid)), dim3(kBlock), 0, p->stream,
-                                            L.tbuf, L.agg_ptr, L.agg_mem, C.n, C.r, rc32, gate));
+                                            L.tbuf, L.agg_ptr, C.n, C.r, rc32, gate));
   HIPC(hipGetLastError());
   return DPGO_OK;
 }
@@ -1168,7 +1172,7 @@ int launch_ml_tail(dpgo_problem_s* p, const double* Xdev, const double* r, doubl
     auto& C = p->ml[l + 1];
     DISPATCH(p->d, p->r, ML_SPLIT_LAUNCH(L, k_ml_restrict, A_of(l), L.x1, r_of(l), L.Pb, 0.0, L.k, C.r, rc32_of(C),
                                          C.k ? C.dinv : (const double*)nullptr, p->ml_omega, C.x1, gate, L.n,
-                                         (double*)nullptr, (double*)nullptr));
+                                         (double*)nullptr, (double*)nullptr, (const int32_t*)nullptr));
   }
   {  // dense level (+ prolongation unless the level above does it itself)
     auto& L = p->ml[nl - 2];

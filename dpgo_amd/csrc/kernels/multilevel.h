@@ -66,9 +66,11 @@ __global__ __launch_bounds__(kBlock) void k_ml_restrict(MAT A, const double* __r
                                                         const double* __restrict__ dinv_next, double omega,
                                                         double* __restrict__ x1c, const DevState* __restrict__ gate,
                                                         int n, double* __restrict__ res_out = nullptr,
-                                                        double* __restrict__ tbuf = nullptr) {
+                                                        double* __restrict__ tbuf = nullptr,
+                                                        const int32_t* __restrict__ tpos = nullptr) {
   // tbuf (graph aggregates: their members are anywhere): P_i^T res_i of every node is written out instead of summed
-  // here, k_ml_agg_sum adds the members up
+  // here -- to position tpos[i], its place in the member list, so that k_ml_agg_sum reads every aggregate as one
+  // contiguous run
   using GEO = Geo<D, R, SPLIT>;
   if (gate && (gate->tcg_done || gate->rtr_stop)) return;
   __shared__ double res_s[kWaves][GEO::G][GEO::T];  // residual tiles (per wave)
@@ -109,7 +111,7 @@ __global__ __launch_bounds__(kBlock) void k_ml_restrict(MAT A, const double* __r
         }
       }
       if (tbuf) {
-        if (ok) store_col<R>(tbuf + off, t);
+        if (ok) store_col<R>(tbuf + (size_t)tpos[i] * GEO::T + L.c * R, t);
       } else {
         store_col<R>(&t_s[lp][L.c * R], t);  // zeros for nodes beyond n
       }
@@ -166,13 +168,13 @@ __global__ __launch_bounds__(kBlock) void k_ml_restrict(MAT A, const double* __r
   }
 }
 
-// Graph aggregates: rc[a] = sum over the members of aggregate a (agg_mem[agg_ptr[a] .. agg_ptr[a+1])) of t[member], in a
-// fixed order.  One workgroup per aggregate: thread (group g, element e) adds every NG-th member's element e, the partial
-// sums meet in LDS and the first T threads add them up.  rc32: the dense level stores its right-hand side in fp32.
+// Graph aggregates: rc[a] = sum over the members of aggregate a of t[member], in a fixed order.  k_ml_restrict wrote the
+// members' values in member-list order, so aggregate a is the contiguous run t[agg_ptr[a] .. agg_ptr[a+1]).  One workgroup
+// per aggregate: thread (group g, element e) adds every NG-th member's element e, the partial sums meet in LDS and the
+// first T threads add them up.  rc32: the dense level stores its right-hand side in fp32.
 template <int D, int R>
 __global__ __launch_bounds__(kBlock) void k_ml_agg_sum(const double* __restrict__ t, const int32_t* __restrict__ agg_ptr,
-                                                       const int32_t* __restrict__ agg_mem, int na,
-                                                       double* __restrict__ rc, float* __restrict__ rc32,
+                                                       int na, double* __restrict__ rc, float* __restrict__ rc32,
                                                        const DevState* __restrict__ gate) {
   constexpr int T = (D + 1) * R, NG = kBlock / T;
   if (gate && (gate->tcg_done || gate->rtr_stop)) return;
@@ -181,23 +183,9 @@ __global__ __launch_bounds__(kBlock) void k_ml_agg_sum(const double* __restrict_
   for (int a = blockIdx.x; a < na; a += gridDim.x) {
     const int m0 = agg_ptr[a], m1 = agg_ptr[a + 1];
     if (g < NG) {
-      // (a member's index, then its value: two dependent loads -- U members are requested together, or a thread's dozen
-      // members cost a dozen round trips: 15 us at 100k poses)
-      constexpr int U = 8;
       double acc = 0.0;
-      for (int mb = m0 + g; mb < m1; mb += U * NG) {
-        int idx[U];
-        double v[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-          const int m = mb + u * NG;
-          idx[u] = (m < m1) ? agg_mem[m] : -1;
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) v[u] = (idx[u] >= 0) ? t[(size_t)idx[u] * T + e] : 0.0;
-#pragma unroll
-        for (int u = 0; u < U; ++u) acc += v[u];
-      }
+#pragma unroll 8
+      for (int m = m0 + g; m < m1; m += NG) acc += t[(size_t)m * T + e];
       part[g][e] = acc;
     }
     __syncthreads();
