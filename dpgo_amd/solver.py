@@ -501,13 +501,14 @@ class QuadraticProblem:
         info = self.multilevelInfo()
         b = self.dimension() + 1
         n_l, nz = info["sizes"][level], info["nnzb"][level]
-        code, out = {"P": (L.ML_P_BLOCKS, np.zeros((n_l, b, b))),
-                     "rowptr": (L.ML_A_ROWPTR, np.zeros(n_l + 1, dtype=np.int32)),
-                     "colidx": (L.ML_A_COLIDX, np.zeros(nz, dtype=np.int32)),
-                     "A": (L.ML_A_VALUES, np.zeros((nz, b, b))),
-                     "labels": (L.ML_AGG_LABELS, np.zeros(n_l, dtype=np.int32)),
-                     "ap_nnzb": (L.ML_AP_NNZB, np.zeros(1, dtype=np.int32)),
-                     "inverse": (L.ML_DENSE_INVERSE, np.zeros((n_l * b, n_l * b)))}[what]
+        code, shape, dtype = {"P": (L.ML_P_BLOCKS, (n_l, b, b), np.float64),
+                              "rowptr": (L.ML_A_ROWPTR, (n_l + 1,), np.int32),
+                              "colidx": (L.ML_A_COLIDX, (nz,), np.int32),
+                              "A": (L.ML_A_VALUES, (nz, b, b), np.float64),
+                              "labels": (L.ML_AGG_LABELS, (n_l,), np.int32),
+                              "ap_nnzb": (L.ML_AP_NNZB, (1,), np.int32),
+                              "inverse": (L.ML_DENSE_INVERSE, (n_l * b, n_l * b), np.float64)}[what]
+        out = np.zeros(shape, dtype=dtype)  # (only the requested item: "inverse" of level 0 would be (n (d+1))^2)
         L.check(self._lib.dpgo_problem_multilevel_get(self._h, int(level), code, L.ptr(out)))
         return out
 
