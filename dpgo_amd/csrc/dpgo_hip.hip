@@ -3292,9 +3292,7 @@ int dpgo_chordal_initialization(int d, int n, int m, const int32_t* p1, const in
   std::vector<double> e0(hr->T, 0.0);
   for (int c = 0; c < d; ++c) e0[(size_t)c * r + c] = 1.0;
   HIPC(hipMemsetAsync(V, 0, sizeof(double) * total, hr->stream));
-  // (a copy from pageable host memory is staged by the runtime and is not ordered behind device work queued on a
-  // non-blocking stream: seen once as E0 overwritten by the memset -- zero right-hand side, zero CG iterations)
-  HIPC(hipStreamSynchronize(hr->stream));
+  HIPC(hipStreamSynchronize(hr->stream));  // (the host copy below comes from pageable memory: keep it strictly after)
   HIPC(hipMemcpyAsync(V, e0.data(), sizeof(double) * hr->T, hipMemcpyHostToDevice, hr->stream));
   HIPC(hipStreamSynchronize(hr->stream));
   CHK(launch_spmm(hr, hr->Q, V, nullptr, rhs));
@@ -3309,7 +3307,7 @@ int dpgo_chordal_initialization(int d, int n, int m, const int32_t* p1, const in
   // the identity as anchor
   hipLaunchKernelGGL(k_init_axpby, dim3(gtot), dim3(kBlock), 0, hr->stream, 1.0, w.x, 0.0, w.x, total, hr->T, r, d, 0);
   HIPC(hipMemcpyAsync(V, w.x, sizeof(double) * total, hipMemcpyDeviceToDevice, hr->stream));
-  HIPC(hipStreamSynchronize(hr->stream));  // (as above: the host copy must land AFTER the device copy)
+  HIPC(hipStreamSynchronize(hr->stream));  // (as above)
   HIPC(hipMemcpyAsync(V, e0.data(), sizeof(double) * hr->T, hipMemcpyHostToDevice, hr->stream));
   HIPC(hipStreamSynchronize(hr->stream));
   CHK(dpgo_round_trajectory_device(r, d, n, V, e0.data(), Tr, hr->stream));

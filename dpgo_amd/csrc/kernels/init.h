@@ -18,7 +18,8 @@ __device__ __forceinline__ bool init_mask(size_t e, int T, int R, int D, int mod
 __global__ __launch_bounds__(kBlock) void k_init_axpby(double a, const double* x, double b, double* y, size_t total,
                                                        int T, int R, int D, int mode) {
   for (size_t e = (size_t)blockIdx.x * kBlock + threadIdx.x; e < total; e += (size_t)gridDim.x * kBlock)
-    y[e] = init_mask(e, T, R, D, mode) ? fma(a, x[e], b * y[e]) : 0.0;
+    y[e] = init_mask(e, T, R, D, mode) ? (b == 0.0 ? a * x[e] : fma(a, x[e], b * y[e])) : 0.0;  // b = 0: y is output only
+                                                                                                // (it may be uninitialised memory: 0 * NaN)
 }
 
 // z = mask(r / diag),  diag[i][c] = A_ii[c][c]  (Jacobi)
@@ -59,5 +60,5 @@ __global__ __launch_bounds__(kBlock) void k_init_diag(BsrDev A, double* __restri
 __global__ __launch_bounds__(kBlock) void k_axpby_plain(double a, const double* __restrict__ x, double b,
                                                         double* __restrict__ y, size_t total) {
   for (size_t e = (size_t)blockIdx.x * kBlock + threadIdx.x; e < total; e += (size_t)gridDim.x * kBlock)
-    y[e] = fma(a, x[e], b * y[e]);
+    y[e] = (b == 0.0) ? a * x[e] : fma(a, x[e], b * y[e]);
 }
