@@ -1334,7 +1334,11 @@ int launch_rtr_persistent(dpgo_problem_s* p, const dpgo_ropt_params* prm, const 
   // iteration, 12.5k slab 15.3 -> 12.1), back off between sweeps.  DPGO_POLL_FIRST / DPGO_POLL_SLEEP override.
   static const int env_first = [] { const char* e = std::getenv("DPGO_POLL_FIRST"); return e ? std::atoi(e) : -1; }();
   static const int env_sleep = [] { const char* e = std::getenv("DPGO_POLL_SLEEP"); return e ? std::atoi(e) : -1; }();
-  const int first = env_first >= 0 ? std::min(255, env_first) : (p->persist_wgs <= 160 ? kPollFirstSleep : 44);
+  // (whole-solve kernel, run r4j, us per product at first = 16 / 24 / 32 / 44 / 56: sphere2500, 157 workgroups of 4 lane
+  // groups per pose, 7.3 / 6.5 / 7.0 / 7.6 / 8.3; 6 250 poses, 196 workgroups of the same layout with two tiles, 10.9 / 9.9 /
+  // 9.9 / 10.5 / 11.1; 12.5k slab, one pose per (d+1) lanes, 12.0 / 10.9 / 10.7 / 10.5 / 10.4)
+  const int first = env_first >= 0 ? std::min(255, env_first)
+                                   : (p->persist_split == 4 ? (p->persist_wgs <= 160 ? kPollFirstSleep : 30) : 44);
   const int between = env_sleep >= 0 ? std::min(255, env_sleep) : kPollSleep;
   const int poll = (first << 8) | between;
 
