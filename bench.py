@@ -666,7 +666,7 @@ def main():
     # Blocks in the latency regime: the timed loop launched ONE kernel per solve (k_rtr_persist: the whole RTR solve, Q
     # resident in registers, vectors in LDS, products synchronised by an in-kernel all-reduce) -- that launch is the
     # dominant kernel of the step, and the headline figures are its: algorithmic bytes = the products it ran x the
-    # tCG-step bytes above, duration = HIP events on the solver's stream around the launch (+ its two memsets).
+    # tCG-step bytes above, duration = HIP events on the solver's stream around the launch (+ its 80-byte memset).
     pinfo = agent.problem.persistentInfo()
     if pinfo.get("enabled") and pinfo.get("last_members", 0) > 0:
         from dpgo_amd.solver import bench_solve

@@ -232,6 +232,7 @@ struct dpgo_problem_s {
   bool persist_add = false;  // the reservation is for the additive-preconditioner variant
   PersistCtrl* pctrl = nullptr;
   unsigned long long* pgran = nullptr;  // granule table of the in-kernel all-reduce (kGranWords 8-byte words)
+  unsigned gran_cleared_at = 0;         // value of `gen` when the table was last cleared
   PersistCtrl* hctrl = nullptr;  // pinned
   double* partials = nullptr;  // 5 regions of kPartialCap*kNP
   DevState* dstate = nullptr;  // 2 slots
@@ -1325,9 +1326,13 @@ int launch_rtr_persistent(dpgo_problem_s* p, const dpgo_ropt_params* prm, const 
     p->persist_wgs = g.wgs;
     p->persist_add = additive;
   }
-  // (the granules' epochs are salted per launch; the table is cleared against wrap-around of the salt)
+  // (the granules' epochs are salted per launch, so what earlier launches left in the table never matches; the table is
+  // cleared before a salt can repeat -- every 2047 generations of this handle -- and at creation)
   HIPC(hipMemsetAsync(p->pctrl, 0, sizeof(PersistCtrl), p->stream));
-  HIPC(hipMemsetAsync(p->pgran, 0, sizeof(unsigned long long) * kGranWords, p->stream));
+  if (p->gen - p->gran_cleared_at >= 0x7ffu) {  // (the multi-launch scheme advances `gen` too: count, do not test bits)
+    HIPC(hipMemsetAsync(p->pgran, 0, sizeof(unsigned long long) * kGranWords, p->stream));
+    p->gran_cleared_at = p->gen;
+  }
   const unsigned salt = ((p->gen & 0x7ffu) + 1u) << 20;  // never 0; the in-launch step counter fills the low 20 bits
   // granule sweeps of the in-kernel all-reduce: wait before the first one (a granule needs ~1 us to cross the chip and
   // the slowest of more workgroups arrives later; sweeping earlier only loads the fabric: sphere2500 11.9 -> 7.9 us per

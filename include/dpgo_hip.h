@@ -334,7 +334,7 @@ int dpgo_bench_spmm_rotating(dpgo_problem_t h, int nsets, int reps, int warmup, 
 int dpgo_bench_hess(dpgo_problem_t h, int reps, int warmup, double* avg_ms);
 /* One whole local solve (QuadraticOptimizer::optimize, src/QuadraticOptimizer.cpp:26-48) per repetition, each from a copy
  * of X0_dev taken outside the event pair; HIP events on the handle's stream around the solve.  For blocks in the latency
- * regime a solve is ONE launch of k_rtr_persist (+ two memsets and a 200-byte read-back), so avg_ms is that kernel's
+ * regime a solve is ONE launch of k_rtr_persist (+ an 80-byte memset and a 200-byte read-back), so avg_ms is that kernel's
  * launch duration; *persistent = 1 when every timed repetition ran that way.  avg_products = Hessian-vector products per
  * solve. */
 int dpgo_bench_solve(dpgo_problem_t h, const dpgo_ropt_params* params, const double* X0_dev, int reps, int warmup,

@@ -790,6 +790,31 @@ def test_additive_preconditioner_selection_and_fallbacks(oracle):
     assert ga.getOptResult().precond_used == "multilevel"
 
 
+def test_persistent_granule_table_survives_salt_wraparound(oracle):
+    """The in-kernel all-reduce tags its granules with a per-launch salt (11 bits of the handle's generation counter) and the
+    table is cleared only before a salt can repeat: 2 200 one-launch solves on one handle -- some through the multi-launch
+    scheme in between, which advances the counter too -- all complete (no time-out, the kernel keeps running) and keep
+    returning the converged iterate's statistics."""
+    import dpgo_amd
+    om, n, d, Q, pg, prob = build_single_agent(oracle, "smallGrid3D", 5)
+    X = tiles_to_matrix(oracle.lift(oracle.chordal_initialization(om, n), 5))
+    go = dpgo_amd.QuadraticOptimizer(prob, dpgo_amd.ROptParameters(precond="jacobi"))
+    shrink = dpgo_amd.QuadraticOptimizer(prob, dpgo_amd.ROptParameters(precond="jacobi", RTR_iterations=1))  # multi-launch
+    for _ in range(12):
+        X = go.optimize(X)
+    ref = go.getOptResult()
+    assert ref.gradNormOpt < 1e-2 and prob.persistentInfo()["last_members"] > 0
+    for k in range(2200):
+        if k % 97 == 5:
+            shrink.optimize(X)
+            continue
+        X2 = go.optimize(X)
+        res = go.getOptResult()
+        assert res.success and prob.persistentInfo()["last_members"] > 0, k
+        assert abs(res.fOpt - ref.fOpt) <= 1e-12 * abs(ref.fOpt), k
+    assert prob.persistentInfo()["enabled"] == 1  # (a time-out would have switched the kernel off for this handle)
+
+
 def test_persistent_tcg_is_refused_beyond_its_capacity_and_follows_the_size_switch(oracle):
     """Blocks that need more than 2 tiles on each of 256 workgroups are refused (explicit request: error); the default
     is on by size: sphere2500 runs the persistent kernel without being asked, the single-iteration radius-shrink mode
