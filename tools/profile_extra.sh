@@ -17,3 +17,13 @@ rm -rf gpurun_out/prof_rot_$TAG gpurun_out/prof_small_$TAG
 tail -2 gpurun_out/${TAG}_rotating.log
 head -8 gpurun_out/${TAG}_rotating_kernel_stats.csv | cut -c1-140
 grep -v "^dpgo_hip" gpurun_out/${TAG}_small_blocks.log | tail -12
+# (3) the 16-agent loop-back sweep (what a rank of the 8-GPU configuration runs, eight times over): kernel stats of the
+# one-launch solves and the batched exchange
+cd /tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_loop_$TAG -o loop -- \
+  python $R/bench.py --loopback --agents-per-gpu 16 --no-cpu-baseline --no-secondary --steps 10 > $R/gpurun_out/${TAG}_loopback16.log 2>&1
+cd $R
+python tools/summarize_prof.py stats gpurun_out/prof_loop_$TAG gpurun_out/${TAG}_loopback16_kernel_stats.csv
+rm -rf gpurun_out/prof_loop_$TAG
+grep '^{' gpurun_out/${TAG}_loopback16.log | tail -1 > gpurun_out/${TAG}_loopback16_bench.json
+head -6 gpurun_out/${TAG}_loopback16_kernel_stats.csv | cut -c1-140
