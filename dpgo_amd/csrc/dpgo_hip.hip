@@ -1213,15 +1213,15 @@ int launch_ml_apply(dpgo_problem_s* p, const double* Xdev, const double* v, doub
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// Persistent tCG (kernels/persist.h): one launch runs the whole tCG_TR loop of an outer iteration.
+// One-launch solve (kernels/persist.h, k_rtr_persist): one launch runs QuadraticOptimizer::optimize whole.
 //
 // Residency.  Every workgroup of such a launch waits for all the others, so all of them must be resident at once.  The
 // grid is therefore sized against a per-device count of resident slots shared by all handles of the process (one slot =
 // one 256-thread workgroup; capacity = two per CU: every variant of the kernel is compiled for two workgroups per CU
 // -- registers, LDS --, whatever else runs), reserved for the duration of the solve.  A handle that cannot reserve runs the
-// two-kernel scheme.  Other processes are not covered: every in-kernel spin is bounded, a time-out poisons the state
-// record (rtr_stop = kPersistPoison) so that the kernels enqueued behind it exit, and run_optimize resumes from the last
-// consistent state with the two-kernel scheme.
+// multi-launch scheme.  Other processes are not covered: every in-kernel spin is bounded, a time-out poisons the state
+// record (rtr_stop = kPersistPoison) and leaves the caller's iterate untouched; run_optimize then runs the solve with the
+// multi-launch scheme.
 constexpr int kPersistPoison = 3;
 constexpr int kMaxDevices = 64;
 std::atomic<int> g_persist_used[kMaxDevices];
@@ -1789,9 +1789,9 @@ int tune_launch_caps(dpgo_problem_s* p) {
   return DPGO_OK;
 }
 
-// Persistent tCG: on by size -- every block the kernel can hold (two 64-pose tiles on each of 256 workgroups: 32 768 poses
-// in 3-D; measured per tCG iteration against the two-kernel scheme: 625 poses 7.5 / 12.6 us, sphere2500 7.3 / 14.3,
-// 6 250 11.2 / 16.7, 12.5k slab 11.4 / 19.4, 25k 18.7 / 26.5).  DPGO_PERSIST_MAX_POSES lowers the limit, DPGO_PERSIST=0/1
+// One-launch solve: on by size -- every block the kernel can hold (two 64-pose tiles on each of 256 workgroups: 32 768 poses
+// in 3-D; measured per Hessian-vector product against the multi-launch scheme: 625 poses 6.6 / 13.7 us, sphere2500 6.5 /
+// 15.4, 6 250 9.9 / 17.2, 12.5k slab 10.5 / 19.7, 25k 18.7 / 26.5).  DPGO_PERSIST_MAX_POSES lowers the limit, DPGO_PERSIST=0/1
 // overrides.
 int tune_persist(dpgo_problem_s* p) {
   static const int max_poses = [] { const char* e = std::getenv("DPGO_PERSIST_MAX_POSES"); return e ? std::atoi(e) : 1 << 30; }();

@@ -1,32 +1,35 @@
-// kernels/persist.h -- persistent whole-chip tCG kernel for blocks in the latency regime (what a GPU runs when a graph is
-// cut over many agents / GPUs: <= ~32k poses).
+// kernels/persist.h -- persistent whole-chip solve kernel for blocks in the latency regime (what a GPU runs when a graph is
+// cut over many agents / GPUs: <= ~32k poses): QuadraticOptimizer::optimize in ONE launch (k_rtr_persist).
 // Part of kernels.h (included inside namespace dpgo, in this order: common.h, problem.h, tcg.h, persist.h, multilevel.h, dense.h, manifold.h, rtr.h, agent.h, init.h).
 #pragma once
 
-// ================================================================ one launch per tCG run
-// Below a few ten thousand poses a tCG iteration of the two-kernel scheme (k_tcg_hess | k_tcg_update) is made of kernel
+// ================================================================ one launch per solve
+// Below a few ten thousand poses a tCG iteration of the multi-launch scheme (k_tcg_hess | k_tcg_update) is made of kernel
 // boundaries and prologues, not of bytes (2 500 poses 14.4 us, 12 500 poses 20.8 us per iteration
-// whatever they compute).  This kernel runs ROPTLIB's whole tCG_TR loop of one outer iteration (same
-// arithmetic, same scalar recurrences as the two-kernel scheme) in ONE launch on up to 256 workgroups:
+// whatever they compute).  k_rtr_persist (below) runs the whole solve -- ROPTLIB's SolversTR::Run with its tCG_TR loops
+// (same arithmetic, same scalar recurrences as the multi-launch scheme) -- in ONE launch on up to 256
+// workgroups.  A tCG iteration inside it:
 //   phase A: Hz = proj_X(z Q - z_rot S) on the workgroup's own rows (the gather reads the neighbours' z),
 //            delta <- beta delta - z,  H delta <- beta H delta - Hz,  partial <delta, H delta>          | all-reduce
 //   phase B: alpha / boundary test;  eta += alpha delta,  r += alpha H delta,  z = proj_X(r Dinv),
 //            partials <r,r>, <z,r>                                                                       | all-reduce
-// * Every tCG vector of the workgroup's rows (r, eta, delta, H delta, z, and X, S, Dinv, the row pointers and preloaded
-//   column indices) lives in REGISTERS for the whole launch -- one lane = one column of one pose, as everywhere; only
-//   the columns of a pose meet through a wave-private LDS tile.  The single vector that crosses workgroups is z.
+// * Every tCG vector of the workgroup's rows (r, eta, delta, H delta, z, and S, Dinv, the row's column indices and block
+//   columns of Q) lives in REGISTERS for the whole launch -- one lane = one column of one pose, as everywhere; the iterate,
+//   the trial point and the two gradients are LDS tiles; only the columns of a pose meet through a wave-private LDS tile.
+//   The vectors that cross workgroups: z per tCG iteration, the trial point and the step once per outer iteration.
 // * Placement-independent hand-off (MI355X_MICROARCH.md, "Workgroup dispatch ... visibility"; cdna_hip_programming.md
 //   Guideline 16): the 8 XCDs' L2s are not coherent and HIP promises nothing about where a workgroup runs, so z is stored
 //   WRITE-THROUGH (agent-scope relaxed atomic stores = sc1) and gathered with agent-scope loads (sc1: never served by
 //   this CU's L1 or a stale L2 line), every storing wave drains its stores (s_waitcnt vmcnt(0)) before the workgroup
 //   publishes, and the publish IS the all-reduce: each workgroup stores its K partial sums as 8-byte granules
-//   {epoch, 32-bit half} (one atomic store each, so tag and payload arrive together), ONE wave per workgroup sweeps all
-//   participants' granules until every tag carries this step's epoch, and everybody forms the sums in the same fixed
+//   {epoch, 32-bit half} (one atomic store each, so tag and payload arrive together), thread t of every workgroup sweeps
+//   participant t's granules until they carry this step's epoch, and everybody forms the sums in the same fixed
 //   order -- so every workgroup takes the same data-dependent decisions (negative curvature, boundary, kappa/theta stop).
 //   Seeing a participant's step-e granules implies its z stores of step e have reached memory.
 // * Every participant must be resident: the host sizes the grid to what the chip holds at once (and reserves those
 //   slots process-wide, so that concurrently solved agents never wait for each other's workgroups); every spin is
-//   bounded, a time-out raises PersistCtrl::error and the host reruns the outer iteration with the two-kernel scheme.
+//   bounded, a time-out raises PersistCtrl::error, the caller's iterate is left untouched and the host reruns the solve with
+//   the multi-launch scheme.
 struct PersistCtrl {
   int error;       // a spin ran out: results invalid
   unsigned iters;  // diagnostic: tCG iterations executed

@@ -431,7 +431,7 @@ class QuadraticProblem:
 
     def persistentInfo(self) -> dict:
         """{"enabled", "workgroups", "last_members", "last_iterations", "last_split", "last_tiles"}: last_members = 0
-        means the last optimize call ran the two-kernel scheme; last_split = lane groups per pose, last_tiles = pose
+        means the last optimize call ran the multi-launch scheme; last_split = lane groups per pose, last_tiles = pose
         tiles per workgroup of the last persistent launch."""
         v = [C.c_int(0) for _ in range(5)]
         L.check(self._lib.dpgo_problem_persistent_info(self._h, *[C.byref(x) for x in v]))

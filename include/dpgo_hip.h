@@ -347,15 +347,17 @@ int dpgo_bench_hess_rotating(dpgo_problem_t h, int nsets, int reps, int warmup, 
  * (all restrictions, dense level, all post-smoothing launches) as launched per iteration. */
 int dpgo_bench_iteration_kernels(dpgo_problem_t h, int reps, int warmup, double out_ms[5]);
 
-/* Persistent tCG (kernels/persist.h): for blocks in the latency regime (by default <= 16 384 poses; environment
- * DPGO_PERSIST_MAX_POSES) with the block-Jacobi / no preconditioner, the whole tCG_TR loop of an outer iteration runs as
- * ONE launch on up to 256 resident workgroups: every tCG vector of a workgroup's rows stays in registers, the only vector
- * exchanged is z (write-through stores, agent-scope gathers), and the barrier between the two phases of an iteration is
- * the all-reduce of its dot products.  On by size (DPGO_PERSIST=0/1 or set_persistent override).  A solve then enqueues
- * everything without a host wait and reads the result back once.  If a launch times out (its workgroups were not all
- * resident, e.g. because another process occupies the device) the solve resumes by itself with the two-kernel scheme and
- * the handle stops using the kernel.  info: what the LAST optimize call did (last_members = 0: the two-kernel scheme
- * ran; last_layout = 16 * lane groups per pose + tiles per workgroup). */
+/* One-launch solve (kernels/persist.h, k_rtr_persist): for blocks in the latency regime (every block the kernel can hold:
+ * <= 32 768 poses in 3-D; environment DPGO_PERSIST_MAX_POSES lowers the limit) with the block-Jacobi, additive or no
+ * preconditioner, dpgo_optimize* runs the WHOLE local solve -- initial statistics, every RTR iteration's tCG_TR loop,
+ * retraction, trial gradient, rho test -- as ONE launch on up to 256 resident workgroups: every tCG vector of a workgroup's
+ * rows stays in registers, the iterate in LDS, the only vectors exchanged are z (per tCG iteration), the trial point and the
+ * step (write-through stores, agent-scope gathers), and the barrier between two phases is the all-reduce of their dot
+ * products.  On by size (DPGO_PERSIST=0/1 or set_persistent override); RTR_iterations == 1, tcg_poll_interval > 0 and RGD
+ * keep the multi-launch scheme.  If a launch times out (its workgroups were not all resident, e.g. because another process
+ * occupies the device) the caller's iterate is untouched, the solve runs on the multi-launch scheme and the handle stops
+ * using the kernel.  info: what the LAST optimize call did (last_members = 0: the multi-launch scheme ran; last_layout =
+ * 16 * lane groups per pose + tiles per workgroup). */
 int dpgo_problem_set_persistent(dpgo_problem_t h, int enable);
 int dpgo_problem_persistent_info(dpgo_problem_t h, int* enabled, int* workgroups, int* last_members,
                                  int* last_iterations, int* last_layout);
