@@ -2246,6 +2246,20 @@ int dpgo_multilevel_default_ks(int n, int d, int* ks, int* nks) {
   return DPGO_OK;
 }
 
+int dpgo_multilevel_graph_aggregates(int n, const int32_t* rowptr, const int32_t* colidx, int max_size, int32_t* label,
+                                     int32_t* parent, int* n_aggregates) {
+  if (n <= 0 || !rowptr || !colidx || max_size < 2 || !label) return fail(DPGO_ERR_INVALID, "bad arguments");
+  const std::vector<int32_t> rp(rowptr, rowptr + n + 1), ci(colidx, colidx + rowptr[n]);
+  for (int32_t c : ci)
+    if (c < 0 || c >= n) return fail(DPGO_ERR_INVALID, "block column out of range");
+  std::vector<int32_t> lab, ptr, mem, par, pslot;
+  const int na = ml_graph_aggregates(rp, ci, n, max_size, lab, ptr, mem, par, pslot);
+  std::copy(lab.begin(), lab.end(), label);
+  if (parent) std::copy(par.begin(), par.end(), parent);
+  if (n_aggregates) *n_aggregates = na;
+  return DPGO_OK;
+}
+
 int dpgo_problem_setup_multilevel(dpgo_problem_t p, int nks, const int* ks, double omega, double shift) {
   CHK(check_ready(p));
   if (nks < 0 || nks > 8 || (nks > 0 && !ks) || !(omega > 0.0) || !(shift >= 0.0))

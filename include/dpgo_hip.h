@@ -217,6 +217,12 @@ int dpgo_problem_get_Q_values(dpgo_problem_t h, double* vals_host);
 #define DPGO_ML_AGG_LABELS 5    /* level 0 with graph aggregates: aggregate of every pose, n_0         (int32)  */
 #define DPGO_ML_AP_NNZB 6       /* level 0 of a two-level hierarchy: blocks of A P, one value          (int32)  */
 int dpgo_multilevel_default_ks(int n, int d, int* ks, int* nks); /* *nks in: capacity of ks, out: count */
+/* The host step of a graph hierarchy by itself (no device): aggregates of at most max_size nodes grown breadth-first over
+ * the block pattern (seeds in index order, FIFO, neighbours in block-row order).  label[n] = aggregate of every node,
+ * parent[n] (optional) = the node that discovered it (-1: the aggregate's root).  What dpgo_problem_setup_multilevel builds
+ * for ks = {-max_size}; exposed so that the rule can be checked without a GPU. */
+int dpgo_multilevel_graph_aggregates(int n, const int32_t* rowptr, const int32_t* colidx, int max_size, int32_t* label,
+                                     int32_t* parent, int* n_aggregates);
 int dpgo_problem_setup_multilevel(dpgo_problem_t h, int nks, const int* ks, double omega, double shift);
 int dpgo_problem_multilevel_info(dpgo_problem_t h, int* nlevels, int* sizes, int* ks, int* nnzb);
 int dpgo_problem_multilevel_get(dpgo_problem_t h, int level, int what, void* out_host);

@@ -207,6 +207,14 @@ def test_multilevel_hierarchy_rules(name, ks):
     ks = ks or O.amg_default_ks(n, b)
     odo = om.subset(np.nonzero(om.p1 + 1 == om.p2)[0])
     Qo = O.construct_Q(n, d, odo)
+    # the greedy aggregation of the library (host code, no GPU) is the oracle's, node for node, on the full graph
+    Qf = O.construct_Q(n, d, om)
+    for S in (4, 16, abs(ks[0]) if len(ks) == 1 else 7):
+        lab_o, ptr_o, _, par_o, _ = O.amg_graph_aggregates(Qf, S)
+        lab_c, par_c, na = np.zeros(n, dtype=np.int32), np.zeros(n, dtype=np.int32), C.c_int(0)
+        L.check(lib.dpgo_multilevel_graph_aggregates(n, L.ptr(L.i32(Qf.rowptr)), L.ptr(L.i32(Qf.colidx)), S, L.ptr(lab_c),
+                                                     L.ptr(par_c), C.byref(na)))
+        assert na.value == len(ptr_o) - 1 and np.array_equal(lab_c, lab_o) and np.array_equal(par_c, par_o)
     if len(ks) == 1 and ks[0] < 0:
         # graph aggregates (the default two-level hierarchy): the prolongation composed along each aggregate's
         # breadth-first tree (k_ml_build_P_tree) reproduces the rigid-body modes -- on the odometry chain, and on a spanning
