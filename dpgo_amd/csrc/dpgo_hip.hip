@@ -1534,6 +1534,11 @@ int run_optimize(dpgo_problem_s* p, const dpgo_ropt_params* prm, dpgo_ropt_resul
       CHK(poll_state(p));
       persist_report(p);
       if (p->hstate->rtr_stop != kPersistPoison) {
+        // (a participant that timed out after participant 0 had left its last reduction cannot happen unless granules
+        // that every other workgroup saw stay invisible to one for the whole spin bound; if it did, that workgroup's rows
+        // of the iterate were not written back -- never continue silently)
+        if (p->hctrl->error)
+          return fail(DPGO_ERR_HIP, "one-launch solve: a workgroup timed out after the final reduction; the iterate is incomplete");
         const DevState& h = *p->hstate;
         res->fInit = h.fInit;
         res->gradNormInit = h.gnInit;
