@@ -394,7 +394,9 @@ class QuadraticProblem {
   // Explicit setup of the multilevel preconditioner for the CURRENT Q (the analogue of
   // PoseGraph::constructPreconditioner, src/PoseGraph.cpp:598-613).  Optional: a solve with
   // ROptParameters::precond = DPGO_PRECOND_MULTILEVEL builds / refreshes it by itself.  ks: aggregate sizes per
-  // coarsening (empty = defaults).  Returns the number of levels.
+  // coarsening -- positive: index runs of that many nodes; a single negative entry -S: two levels with breadth-first-grown
+  // graph aggregates of at most S poses (what the default builds up to 200 000 poses) --, empty = defaults.  Returns the
+  // number of levels.
   int setupMultilevel(const std::vector<int>& ks = {}, double omega = 0.7, double shift = 0.1) {
     refresh();
     check(dpgo_problem_setup_multilevel(h_, (int)ks.size(), ks.empty() ? nullptr : ks.data(), omega, shift));
