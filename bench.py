@@ -48,8 +48,9 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=200,
+                    help="timed steps (default 200: > 1 s of timed region at the 100k workload's 5 ms per step)")
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--settle", type=int, default=5,
                     help="untimed RBCD iterations from the initial guess before the benchmark state is frozen")
     ap.add_argument("--workload", default="grid100k")
@@ -68,6 +69,12 @@ def parse_args():
     ap.add_argument("--loopback", action="store_true",
                     help="single GPU, several agents: every public-pose exchange and reduction travels through a 1-rank "
                          "RCCL communicator owned by the solver library (the N > 1 data path on one device)")
+    ap.add_argument("--dist", action="store_true",
+                    help="run the N > 1 code path whatever the world size: torch.distributed process group (RCCL), the "
+                         "library's communicator taken from it, barriers and all-reduces of the timing protocol, 2 agents "
+                         "per GPU.  With WORLD_SIZE = 1 (python -m torch.distributed.run --nproc-per-node 1 bench.py "
+                         "--gpus 1 --dist) the exchanges are self send / recv through the 1-rank communicator: every line "
+                         "of the multi-GPU branch executes on one device")
     return ap.parse_args()
 
 
@@ -224,7 +231,7 @@ def cpu_baseline_reference(meas_p, n, X_tiles, r, num_agents=8):
         used = {colour[q] for q in info[a]["adj"] if colour[q] >= 0}
         colour[a] = min(c for c in range(num_agents) if c not in used)
     cores = min(num_agents, os.cpu_count() or 1)
-    t_sweep, t_fact, products = 0.0, 0.0, 0
+    t_sweep, t_fact, products, per_agent = 0.0, 0.0, 0, [0] * num_agents
     with mp.get_context("fork").Pool(cores) as pool:
         for c in range(max(colour) + 1):
             ids = [a for a in range(num_agents) if colour[a] == c]
@@ -237,20 +244,21 @@ def cpu_baseline_reference(meas_p, n, X_tiles, r, num_agents=8):
             for a, (Xn, its, tf, ts) in zip(ids, out):
                 X[ranges[a][0]:ranges[a][1]] = Xn
                 products += its
+                per_agent[a] = its
             t_sweep += max(ts for _, _, _, ts in out)
             t_fact = max(t_fact, max(tf for _, _, tf, _ in out))
     central = O.QuadraticProblem(O.construct_Q(n, d, om), None, r, d, precond="none")
     return dict(value=1.0 / t_sweep, unit="it/s", cores=cores, kind="port",
                 sample="reference configuration of this workload: %d agents x %d poses, one core each, exact sparse "
                        "factor of Q_a + 0.1 I (SciPy SuperLU for CHOLMOD), RTR 3x<=50 tCG; ONE two-colour sweep "
-                       "(1 it = every agent updates once) from the benchmark's initial iterate: %.2f s + %.2f s once "
+                       "(1 it = every agent updates once) from the given iterate: %.2f s + %.2f s once "
                        "for the factorisations (inside the first solve, src/PoseGraph.cpp:582-586); NumPy/SciPy "
                        "oracle" % (num_agents, n // num_agents, t_sweep, t_fact),
                 seconds_per_sweep=t_sweep, factorisation_seconds=t_fact, tcg_iterations=products,
-                cost_2f_after=2 * central.f(X), gradnorm_after=central.rie_grad_norm(X), host_cores=os.cpu_count())
+                tcg_iterations_per_agent=per_agent, cost_2f_after=2 * central.f(X), gradnorm_after=central.rie_grad_norm(X), host_cores=os.cpu_count())
 
 
-def gpu_same_decomposition(meas, n, X0, r, num_agents, precond, device):
+def gpu_same_decomposition(meas, n, X0, r, num_agents, precond, device, reset_auto=True):
     """What cpu_baseline_reference times, on this GPU: the same `num_agents` contiguous blocks, the same initial iterate,
     ONE two-colour sweep (every agent updates once, RTR 3 x <= 50 tCG, the library's default preconditioner selection),
     agents of a colour solved concurrently.  Cost and gradient norm of the central problem after the sweep are returned
@@ -271,7 +279,7 @@ def gpu_same_decomposition(meas, n, X0, r, num_agents, precond, device):
     for _ in range(3):
         for ag in agents.values():
             ag.restore()
-            if precond == "auto":
+            if precond == "auto" and reset_auto:
                 ag.problem.autoState("reset")  # (a fresh block of a multi-agent problem starts on block-Jacobi)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -283,7 +291,9 @@ def gpu_same_decomposition(meas, n, X0, r, num_agents, precond, device):
         products = sum(ag.last_result.tcg_iterations for ag in agents.values())
     f, g = cluster.central_cost_and_gradnorm()
     return dict(value=1.0 / best, unit="it/s", seconds_per_sweep=best, agents=num_agents,
-                poses_per_agent=n // num_agents, tcg_iterations=products, cost_2f_after=2 * f, gradnorm_after=g,
+                poses_per_agent=n // num_agents, tcg_iterations=products,
+                tcg_iterations_per_agent=[agents[a].last_result.tcg_iterations for a in range(num_agents)],
+                cost_2f_after=2 * f, gradnorm_after=g,
                 preconditioners=sorted({ag.last_result.precond_used for ag in agents.values()}),
                 sample="this GPU on the reference configuration: the same %d blocks, the same initial iterate, ONE "
                        "two-colour sweep, same-colour agents solved concurrently (best of 3)" % num_agents)
@@ -373,13 +383,22 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if args.gpus > 1 and world == 1:
         raise SystemExit("launch with torch.distributed.run for --gpus > 1")
+    # the multi-GPU branch: N > 1 ranks, or forced at any world size (--dist / DPGO_BENCH_DIST=1) so that it can be
+    # executed -- and is tested -- on a single device
+    use_dist = world > 1 or args.dist or os.environ.get("DPGO_BENCH_DIST", "0") == "1"
+    if use_dist and "MASTER_ADDR" not in os.environ:  # (python bench.py --dist without a launcher)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+    loopback = args.loopback or (use_dist and world == 1)
     if dpgo_amd.device_count() < 1:
         raise SystemExit("bench.py needs a HIP device: the product path has no CPU fallback")
     dev_index = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(dev_index)
     backend = None
     comm = None
-    if world > 1:
+    if use_dist:
         # "nccl" IS RCCL on ROCm.  DPGO_DIST_BACKEND=gloo (host-staged exchange) lets the N > 1 path be exercised
         # on a single-GPU box with all ranks sharing device 0; it is also the fallback if RCCL cannot initialise.
         backend = os.environ.get("DPGO_DIST_BACKEND", "nccl")
@@ -394,7 +413,7 @@ def main():
             comm = DeviceComm.from_torch_distributed(dev_index)  # the data path's own communicator (C ABI dpgo_comm_*)
         else:
             dist.init_process_group(backend)
-    elif args.loopback:
+    elif loopback:
         from dpgo_amd.comm import DeviceComm, unique_id
         comm = DeviceComm(1, 0, unique_id(), dev_index)  # 1-rank RCCL communicator: self send / recv, all-reduce
 
@@ -404,7 +423,7 @@ def main():
     # agents: 1 for a single GPU (one agent owns the whole graph, BASELINE configs[1] style);
     # for N > 1 GPUs two agents per GPU by default -- consecutive blocks of a chain / ring partition
     # alternate colours, so every GPU hosts one agent of each colour and works in BOTH colour phases
-    apg = args.agents_per_gpu if args.agents_per_gpu > 0 else ((8 if args.loopback else 1) if world == 1 else 2)
+    apg = args.agents_per_gpu if args.agents_per_gpu > 0 else (2 if use_dist else (8 if args.loopback else 1))
     num_agents = world * apg
     ranges, graphs = build_pose_graphs(meas, n, num_agents, r)
     params = dpgo_amd.ROptParameters(precond=args.precond)  # reference defaults + block-Jacobi (or multilevel)
@@ -412,7 +431,7 @@ def main():
     my_ids = list(range(rank * apg, (rank + 1) * apg))
     agents = {a: DeviceAgent(graphs, plan, a, X0[ranges[a][0]:ranges[a][1]], params, device=dev_index)
               for a in my_ids}
-    cluster = RBCDCluster(plan, agents, rank, world, agents_per_rank=apg, comm=comm, loopback=args.loopback)
+    cluster = RBCDCluster(plan, agents, rank, world, agents_per_rank=apg, comm=comm, loopback=loopback)
     big = max(my_ids, key=lambda a: graphs[a].n())  # the agent whose kernels are profiled below
     agent = agents[big]
     nnzb_local = len(graphs[big].quadraticMatrix()[1])
@@ -420,7 +439,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -439,8 +458,8 @@ def main():
         states.append({a: ag.X.clone() for a, ag in agents.items()})
         cluster.sweep()
         work = torch.tensor([float(sum(a.last_result.tcg_iterations for a in agents.values() if a.last_result))],
-                            dtype=torch.float64, device="cpu" if (world > 1 and cluster.stage) else "cuda")
-        if world > 1:
+                            dtype=torch.float64, device="cpu" if (use_dist and cluster.stage) else "cuda")
+        if use_dist:
             dist.all_reduce(work)
         works.append(float(work.item()))
         if k < args.settle:
@@ -487,7 +506,7 @@ def main():
         used_precond |= {a.last_result.precond_used for a in agents.values() if a.last_result}
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if cluster.stage else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -549,6 +568,7 @@ def main():
         hess[variant] = dict(kernel=names[variant], cold_us=cold.value * 1e3, warm_us=warm_.value * 1e3)
     agent.problem.setSpmmVariant("auto")
     b_ = d + 1
+    qb_ = nnzb_local * (8 * b_ * b_ + 4) + 4 * (n_local + 1)  # Q with its indices
     nu_ = (nnzb_local + n_local) // 2  # stored upper blocks (diagonal + one of every off-diagonal pair)
     hb_sym_own = (nu_ * (8 * b_ * b_ + 4) + (nnzb_local - nu_) * 8 + 2 * 4 * (n_local + 1)
                   + hb - (nnzb_local * (8 * b_ * b_ + 4) + 4 * (n_local + 1)))
@@ -662,6 +682,11 @@ def main():
                                              frac=sb / (ms_spmm.value * 1e-3) / 1e9 / HBM_PEAK_GBS)),
                     spmm_symmetric=spmm_sym, spmm_storage_selected=in_use,
                     kernels=kernels, cycle_tail_us=ms_it[4] * 1e3, multilevel=ml_info)
+    # the bytes the TIMED kernel's storage really moves, whichever storage that is (the plain arrays move exactly the
+    # algorithmic bytes; the symmetric storage stores the upper blocks only)
+    own = hb_sym_own if timed == "symmetric" else hb
+    roofline.update(storage=timed, stored_bytes_per_launch=own, achieved_own_bytes=own / (ms_hrot.value * 1e-3) / 1e9,
+                    frac_own_bytes=own / (ms_hrot.value * 1e-3) / 1e9 / HBM_PEAK_GBS)
 
     # Blocks in the latency regime: the timed loop launched ONE kernel per solve (k_rtr_persist: the whole RTR solve, Q
     # resident in registers, vectors in LDS, products synchronised by an in-kernel all-reduce) -- that launch is the
@@ -679,17 +704,27 @@ def main():
                                                    bytes_per_launch=hb, warm=roofline.pop("warm"),
                                                    note="the tCG-step kernel of the multi-launch scheme (blocks beyond the "
                                                         "persistent kernel's size); NOT what the timed loop ran")
+            # HBM traffic of such a launch, modelled: Q, its indices, the block-Jacobi factors and G are read once, X is read
+            # and written once; every tCG vector lives in registers / LDS, the exchanged vectors (z, x2, eta) are
+            # write-through stores + agent-scope gathers that the Infinity Cache serves.  The kernel is bound by the latency
+            # of its chip-wide reductions, so `frac` (HBM) is small by construction; the figure comparable with the
+            # multi-launch kernel's is effective_algorithmic_GBs = products x the tCG step's algorithmic bytes / time.
+            hbm_model = qb_ + 4 * vec + 8 * b_ * b_ * n_local
+            ach_h = hbm_model / (bs["ms"] * 1e-3) / 1e9
             roofline.update(
                 kernel="k_rtr_persist<%d,%d,%d,%d> (a whole RTR solve in one launch: %d workgroups, Q in registers, iterates "
                        "in LDS, in-kernel all-reduces)" % (d, r, pinfo.get("last_split", 0), pinfo.get("last_tiles", 0),
                                                            pinfo["last_members"]),
-                achieved=ach_p, frac=ach_p / HBM_PEAK_GBS, bytes_per_launch=solve_bytes, avg_launch_us=bs["ms"] * 1e3,
+                achieved=ach_h, frac=ach_h / HBM_PEAK_GBS, bytes_per_launch=hbm_model, avg_launch_us=bs["ms"] * 1e3,
                 products_per_launch=bs["products"], us_per_product=bs["ms"] * 1e3 / bs["products"], traffic=None,
-                traffic_source=None,
-                protocol="HIP events on the solver's stream around one solve = one launch, %d repetitions from the "
-                         "benchmark's iterate; bytes = products x the tCG step's algorithmic bytes (SURVEY 8d) although Q "
-                         "never leaves the registers after the first read: the kernel is bound by the latency of its "
-                         "chip-wide reductions (2 per product), not by HBM" % 20)
+                traffic_source=None, effective_algorithmic_GBs=ach_p, effective_algorithmic_frac=ach_p / HBM_PEAK_GBS,
+                effective_algorithmic_bytes=solve_bytes, storage="registers", stored_bytes_per_launch=hbm_model,
+                achieved_own_bytes=ach_h, frac_own_bytes=ach_h / HBM_PEAK_GBS,
+                protocol="HIP events on the solver's stream around one solve = one launch (+ its commit kernel), %d "
+                         "repetitions from the benchmark's iterate; achieved / frac = MODELLED HBM bytes of the launch (Q, "
+                         "indices, factors, G, X in and out) over its time: latency-bound by its chip-wide reductions (2-3 "
+                         "per product), not by HBM; effective_algorithmic_* = products x the tCG step's algorithmic bytes "
+                         "(SURVEY 8d) over the same time, the figure comparable with multi_launch_kernel" % 20)
 
     cpu = None
     jac_step = None
@@ -713,6 +748,24 @@ def main():
                 cpu["gpu_over_cpu_same_work"] = same["value"] / cpu["value"]
             except Exception as exc:  # noqa: BLE001
                 sys.stderr.write("bench.py: gpu_same_work failed: %r\n" % (exc,))
+        if cpu is not None:
+            # the same pair from the SETTLED iterate the headline step starts from, cut into the same 8 blocks: there the tCG
+            # budget (not the trust-region boundary after a step or two) ends the local solves -- the hot loop proper
+            try:
+                X_set = np.ascontiguousarray(np.concatenate([agents[a]._snap.cpu().numpy() for a in sorted(agents)], axis=0))
+                settled_cpu = cpu_baseline_reference(meas, n, X_set, r)
+                settled_cpu["sample"] = "as cpu_baseline.sample, from the benchmark's SETTLED iterate (the state every " \
+                                        "timed step restores): " + settled_cpu["sample"]
+                try:
+                    sg = gpu_same_decomposition(meas, n, X_set, r, 8, args.precond, dev_index, reset_auto=False)
+                    sg["sample"] += "; from the settled iterate, the preconditioner selection carried over from the untimed sweep"
+                    settled_cpu["gpu_same_work"] = sg
+                    settled_cpu["gpu_over_cpu_same_work"] = sg["value"] / settled_cpu["value"]
+                except Exception as exc:  # noqa: BLE001
+                    sys.stderr.write("bench.py: gpu_same_work (settled) failed: %r\n" % (exc,))
+                cpu["settled_iterate"] = settled_cpu
+            except Exception as exc:  # noqa: BLE001
+                sys.stderr.write("bench.py: cpu_baseline (settled iterate) failed: %r\n" % (exc,))
         try:  # the device algorithm on one core, same step as the GPU's (same settled iterate)
             port = cpu_baseline(meas, n, X_state, r, args.cpu_budget_s, "jacobi")
             if cpu is None:
@@ -777,11 +830,16 @@ def main():
             "dtype": "f64",
             "data": "synthetic" if args.workload.startswith("grid") else "g2o dataset shipped in data/",
             "config": {"workload": desc, "agents": num_agents, "agents_per_gpu": apg, "r": r, "d": d,
-                       "local_solver": "RTR 3x<=50 tCG, Delta0=100, tol=1e-2 (reference defaults), precond = %s" % (
+                       "local_solver": "RTR 3x<=50 tCG, Delta0=100, tol=1e-2 (reference defaults), precond = %s; %s" % (
                            {"jacobi": "block-Jacobi", "multilevel": "multilevel", "additive": "additive two-level",
                             "auto": "auto (library default: a multilevel preconditioner when the tCG budget binds, else "
                                     "block-Jacobi)"}[
-                               args.precond]),
+                               args.precond],
+                           ("time_to_tolerance_ms = %.3f (%d Hessian-vector products from the initial guess to |rgrad| < "
+                            "1e-2, single agent, same settings)" % (tt_main["ms"], tt_main["products"]))
+                           if tt_main.get("reached") else "time_to_tolerance_ms = not measured in this run"),
+                       "time_to_tolerance_ms": tt_main.get("ms") if tt_main.get("reached") else None,
+                       "products_per_step": tcg_total / max(args.steps, 1),
                        "precond_used_in_timed_steps": sorted(used_precond),
                        "same_colour_agents": "sequential (diagnostic)" if args.sequential else "concurrent",
                        "schedule": "single agent" if num_agents == 1 else
@@ -789,7 +847,9 @@ def main():
                        "GPU solved concurrently); public-pose exchange over %s" % (
                            plan.num_colours,
                            "RCCL p2p on the solver's stream (C ABI dpgo_comm_exchange)%s" % (
-                               " through a 1-rank communicator (loop-back)" if world == 1 else "") if comm
+                               " through a 1-rank communicator (loop-back%s)" % (
+                                   "; communicator taken from the torch.distributed process group" if use_dist else "")
+                               if world == 1 else "") if comm
                            else ("device copies" if world == 1 else
                                  ("torch.distributed nccl p2p" if not cluster.stage else "gloo (host-staged)"))),
                        "dist_backend": backend,
@@ -809,7 +869,7 @@ def main():
                         "to_tolerance": to_tol},
         }
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -188,6 +188,16 @@ class DeviceAgent(AgentStatusMixin):
     restart every `restartInterval` iterations; src/PGOAgent.cpp:880-936) on the device; updateY / updateV
     are one fused kernel each (linear combination + polar projection, dpgo_axpby_project_device)."""
 
+    # buffers whose device ADDRESSES the cluster's cached exchange plans hold: re-binding any of them (a second
+    # enable_acceleration(), a caller assigning agent.X) advances buffer_generation, which the plan cache is keyed on --
+    # a stale plan would gather from / scatter into memory the allocator may already have handed to another tensor
+    _PLAN_BUFFERS = frozenset(("X", "Y", "nbr", "nbr_aux", "send_idx", "send_buf", "send_buf_aux"))
+
+    def __setattr__(self, name, value):
+        if name in DeviceAgent._PLAN_BUFFERS:
+            object.__setattr__(self, "buffer_generation", self.__dict__.get("buffer_generation", 0) + 1)
+        object.__setattr__(self, name, value)
+
     def __init__(self, graphs: Sequence[PoseGraph], plan: ExchangePlan, my_id: int, X0_tiles: np.ndarray,
                  params: Optional[ROptParameters] = None, device: int = 0):
         import torch
@@ -424,8 +434,7 @@ class RBCDCluster:
         if not hasattr(first, "send_idx") or not hasattr(first, "problem"):
             return False  # (CPU stand-ins of the gloo tests)
         import ctypes as C
-        cache = self.__dict__.setdefault("_xplans", {})
-        plan = cache.get(key)
+        plan = self._cached_plan(key)
         if plan is None:
             src, idx, cnt, dst = [], [], [], []
             for a, q in msgs:
@@ -439,9 +448,35 @@ class RBCDCluster:
             L.check(first.problem._lib.dpgo_exchange_plan_create(
                 C.byref(h), first.r, first.d, n, (C.c_void_p * n)(*src), (C.c_void_p * n)(*idx), (C.c_int * n)(*cnt),
                 (C.c_void_p * n)(*dst), first.device.index or 0))
-            plan = cache[key] = h
+            plan = self._store_plan(key, h)
         L.check(first.problem._lib.dpgo_exchange_plan_run(plan, first.torch.cuda.current_stream().cuda_stream or None))
         return True
+
+    def _buffer_generation(self) -> int:
+        return sum(getattr(ag, "buffer_generation", 0) for ag in self.agents.values())
+
+    def _cached_plan(self, key):
+        """The cached exchange plan for `key`, or None -- also when any local agent re-bound one of the buffers the plans
+        address since the plans were built (every plan is dropped then: they hold raw device addresses)."""
+        cache = self.__dict__.setdefault("_xplans", {})
+        gen = self._buffer_generation()
+        if self.__dict__.get("_xplans_gen") != gen:
+            self.invalidate_plans()
+            self._xplans_gen = gen
+        return cache.get(key)
+
+    def _store_plan(self, key, handle):
+        self._xplans[key] = handle
+        return handle
+
+    def invalidate_plans(self) -> None:
+        """Destroy the cached exchange plans (they are rebuilt from the agents' current buffers at the next exchange)."""
+        cache = self.__dict__.setdefault("_xplans", {})
+        if cache:
+            lib = next(iter(self.agents.values())).problem._lib
+            for h in cache.values():
+                lib.dpgo_exchange_plan_destroy(h)
+            cache.clear()
 
     def _pack_batched(self, msgs, key, aux: bool) -> bool:
         """K11 for every message this process SENDS through the communicator, as one launch (same plan machinery as
@@ -451,8 +486,7 @@ class RBCDCluster:
             return False
         import ctypes as C
         first = self.agents[out[0][0]]
-        cache = self.__dict__.setdefault("_xplans", {})
-        plan = cache.get(("pack",) + key)
+        plan = self._cached_plan(("pack",) + key)
         if plan is None:
             n = len(out)
             src = [L.ptr(self.agents[a].Y if aux else self.agents[a].X) for a, q in out]
@@ -463,14 +497,13 @@ class RBCDCluster:
             L.check(first.problem._lib.dpgo_exchange_plan_create(
                 C.byref(h), first.r, first.d, n, (C.c_void_p * n)(*src), (C.c_void_p * n)(*idx), (C.c_int * n)(*cnt),
                 (C.c_void_p * n)(*dst), first.device.index or 0))
-            plan = cache[("pack",) + key] = h
+            plan = self._store_plan(("pack",) + key, h)
         L.check(first.problem._lib.dpgo_exchange_plan_run(plan, first.torch.cuda.current_stream().cuda_stream or None))
         return True
 
     def __del__(self):
         try:
-            for h in self.__dict__.get("_xplans", {}).values():
-                next(iter(self.agents.values())).problem._lib.dpgo_exchange_plan_destroy(h)
+            self.invalidate_plans()
         except Exception:
             pass
 

@@ -138,13 +138,29 @@ struct dpgo_problem_s {
     int32_t *lab = nullptr, *agg_ptr = nullptr, *agg_mem = nullptr, *parent = nullptr, *pslot = nullptr;
     int32_t* mem_pos = nullptr;    // position of every pose in agg_mem (where k_ml_restrict writes its P_i^T res_i)
     int32_t* tile_perm = nullptr;  // aggregates of at most one persistent tile: pose of every (aggregate, slot), -1 = empty
+    int perm_tile = 0;             // slots per aggregate in tile_perm
+    int merge_cap = 0;             // graph aggregates: fragments merged up to this many poses (0: plain greedy growth)
     double* tbuf = nullptr;
     AggMap agg() const { return AggMap{graph ? lab : nullptr, k}; }
   };
   std::vector<MlLevel> ml;
   std::vector<int32_t> h_rowptr, h_colidx;  // host copy of Q's block pattern (symbolic setup of the hierarchy)
   bool ml_symbolic = false, ml_ready = false, ml_user_ks = false;
-  bool ml_additive_layout = false;  // the hierarchy is the one the additive preconditioner needs (one aggregate per 4-lane-group tile)
+  bool ml_additive_layout = false;  // the hierarchy is the one the additive preconditioner needs (one aggregate per workgroup tile)
+  // layout of the additive preconditioner's one-launch solve for this block pattern (additive_plan): lane groups per pose
+  // (0: the block does not fit), slots per workgroup tile = aggregate, growth size and merge bound of the graph aggregates
+  // (graph = false: index runs of `tile` poses), number of aggregates = workgroups
+  struct AddPlan {
+    int split = 0, tile = 0, S = 0, cap = 0, na = 0;
+    bool graph = true;
+  } add_plan;
+  bool add_plan_known = false;
+  // the aggregation the plan was found with (host arrays), reused by the symbolic setup that follows: growing and merging
+  // the aggregates of a 12 500-pose block is 1.4 ms of host time
+  struct AggCache {
+    int S = 0, cap = 0;
+    std::vector<int32_t> lab, ptr, mem, parent, pslot;
+  } add_agg;
   double ml_omega = 0.7, ml_shift = 1e-1;
   double* ml_dense = nullptr;  // inverse of the coarsest operator, row-major, leading dimension ml_lda
   float* ml_dense32 = nullptr;  // its fp32 storage (what the cycle streams when ml_coarse_bits == 32)
@@ -230,6 +246,7 @@ struct dpgo_problem_s {
   bool persist_failed_once = false;
   bool stream_nt = false;  // single-use operands of the tCG-step kernel move non-temporally (ld_stream, common.h)
   bool persist_add = false;  // the reservation is for the additive-preconditioner variant
+  size_t persist_lds_attr = 0;  // dynamic LDS size the additive instance's launch attribute was last raised to
   PersistCtrl* pctrl = nullptr;
   unsigned long long* pgran = nullptr;  // granule table of the in-kernel all-reduce (kGranWords 8-byte words)
   unsigned gran_cleared_at = 0;         // value of `gen` when the table was last cleared
@@ -757,17 +774,104 @@ int ml_graph_aggregates(const std::vector<int32_t>& rowptr, const std::vector<in
   return na;
 }
 
-int ml_symbolic_setup(dpgo_problem_s* p, const std::vector<int>& ks_in) {
+// The greedy growth leaves fragments (pockets between full aggregates); where an aggregate is a WORKGROUP of the one-launch
+// solve (additive preconditioner) every fragment costs a whole workgroup.  Passes over the aggregates in index order until
+// nothing changes: an aggregate of at most S / 2 nodes joins the neighbouring aggregate (one it shares a block with) it has
+// the most blocks in common with among those that still have room (sizes add up to at most `cap`; ties: the lower index).
+// Afterwards the aggregates are renumbered in the order of their smallest member and every aggregate's breadth-first tree
+// is rebuilt from that member (neighbours in block-row order).  In place; returns the number of aggregates.  Restated in
+// oracle/dpgo_oracle.py (amg_merge_small_aggregates).
+int ml_merge_small_aggregates(const std::vector<int32_t>& rowptr, const std::vector<int32_t>& colidx, int n, int S, int cap,
+                              std::vector<int32_t>& lab, std::vector<int32_t>& ptr, std::vector<int32_t>& mem,
+                              std::vector<int32_t>& parent, std::vector<int32_t>& pslot) {
+  const int na = (int)ptr.size() - 1;
+  std::vector<std::vector<int32_t>> members(na);
+  for (int a = 0; a < na; ++a) members[a].assign(mem.begin() + ptr[a], mem.begin() + ptr[a + 1]);
+  std::vector<int> cnt(na, 0);
+  std::vector<int> touched;
+  for (bool changed = true; changed;) {
+    changed = false;
+    for (int a = 0; a < na; ++a) {
+      if (members[a].empty() || 2 * (int)members[a].size() > S) continue;
+      touched.clear();
+      for (int i : members[a])
+        for (int t = rowptr[i]; t < rowptr[i + 1]; ++t) {
+          const int c = lab[colidx[t]];
+          if (c == a) continue;
+          if (cnt[c]++ == 0) touched.push_back(c);
+        }
+      std::sort(touched.begin(), touched.end());
+      int best = -1, best_n = 0;
+      for (int c : touched) {
+        if ((int)(members[c].size() + members[a].size()) <= cap && cnt[c] > best_n) best = c, best_n = cnt[c];
+        cnt[c] = 0;
+      }
+      if (best >= 0) {
+        members[best].insert(members[best].end(), members[a].begin(), members[a].end());
+        for (int i : members[a]) lab[i] = best;
+        members[a].clear();
+        changed = true;
+      }
+    }
+  }
+  std::vector<int> alive;
+  for (int a = 0; a < na; ++a)
+    if (!members[a].empty()) {
+      std::sort(members[a].begin(), members[a].end());
+      alive.push_back(a);
+    }
+  std::sort(alive.begin(), alive.end(), [&](int x, int y) { return members[x][0] < members[y][0]; });
+  std::vector<int32_t> new_lab(n, -1);
+  parent.assign(n, -1);
+  pslot.assign(n, 0);
+  mem.clear();
+  ptr.assign(1, 0);
+  for (size_t k = 0; k < alive.size(); ++k) {
+    const int a = alive[k];
+    // (a merged aggregate is connected by construction, so the search from its smallest member reaches everything; should
+    // the pattern not be symmetric, the members it misses become further roots in index order)
+    for (int root : members[a]) {
+      if (new_lab[root] >= 0) continue;
+      size_t head = mem.size();
+      new_lab[root] = (int32_t)k;
+      mem.push_back(root);
+      for (; head < mem.size(); ++head) {
+        const int u = mem[head];
+        for (int t = rowptr[u]; t < rowptr[u + 1]; ++t) {
+          const int v = colidx[t];
+          if (lab[v] != a || new_lab[v] >= 0) continue;
+          new_lab[v] = (int32_t)k;
+          parent[v] = u;
+          pslot[v] = t;
+          mem.push_back(v);
+        }
+      }
+    }
+    ptr.push_back((int32_t)mem.size());
+  }
+  lab.swap(new_lab);
+  return (int)alive.size();
+}
+
+// ks_in: aggregate sizes per coarsening; {-S}: two levels, graph aggregates of at most S poses; {-S, -cap}: the same with
+// the fragments of the greedy growth merged up to `cap` poses (ml_merge_small_aggregates).  perm_tile > 0 (graph
+// aggregates): also build the (aggregate, slot) -> pose table of the additive preconditioner's persistent layout with
+// that many slots per aggregate.
+int ml_symbolic_setup(dpgo_problem_s* p, const std::vector<int>& ks_in, int perm_tile = 0) {
   ml_free(p);
   if ((int)p->h_rowptr.size() != p->n + 1) return fail(DPGO_ERR_STATE, "multilevel: Q's block pattern is not set");
   const int b = p->b, bb = b * b;
   const size_t tb = sizeof(double) * p->T;
   std::vector<int32_t> rowptr = p->h_rowptr, colidx = p->h_colidx;
   int cur = p->n;
-  // a single negative entry -S: two levels, graph aggregates of at most S poses
-  const bool graph = ks_in.size() == 1 && ks_in[0] < 0;
+  // a single negative entry -S: two levels, graph aggregates of at most S poses; two negative entries: merged up to -ks[1]
+  const bool merged = ks_in.size() == 2 && ks_in[0] < 0 && ks_in[1] < 0;
+  const bool graph = (ks_in.size() == 1 && ks_in[0] < 0) || merged;
   std::vector<int> ks = ks_in;
+  if (merged) ks.pop_back();
   if (graph) ks[0] = -ks_in[0];
+  const int merge_cap = merged ? -ks_in[1] : 0;
+  if (merged && merge_cap < ks[0]) return fail(DPGO_ERR_INVALID, "multilevel: the merge bound is at least the growth size");
   for (int k : ks)
     if (k < 0) return fail(DPGO_ERR_INVALID, "multilevel: graph aggregates (a negative size) make a two-level hierarchy");
   p->ml.resize(ks.size() + 1);
@@ -779,8 +883,17 @@ int ml_symbolic_setup(dpgo_problem_s* p, const std::vector<int>& ks_in) {
     if (l == 0 && graph) {
       if (L.k < 2) return fail(DPGO_ERR_INVALID, "multilevel: graph aggregates hold at least 2 poses");
       std::vector<int32_t> lab, ptr, mem, parent, pslot;
-      const int na = ml_graph_aggregates(rowptr, colidx, cur, L.k, lab, ptr, mem, parent, pslot);
+      int na;
+      if (p->add_plan_known && p->add_agg.S == L.k && p->add_agg.cap == merge_cap && (int)p->add_agg.lab.size() == cur) {
+        const auto& A = p->add_agg;  // (the additive plan of this pattern was found with exactly these aggregates)
+        lab = A.lab, ptr = A.ptr, mem = A.mem, parent = A.parent, pslot = A.pslot;
+        na = (int)ptr.size() - 1;
+      } else {
+        na = ml_graph_aggregates(rowptr, colidx, cur, L.k, lab, ptr, mem, parent, pslot);
+        if (merge_cap) na = ml_merge_small_aggregates(rowptr, colidx, cur, L.k, merge_cap, lab, ptr, mem, parent, pslot);
+      }
       L.graph = true;
+      L.merge_cap = merge_cap;
       CHK(upload(&L.lab, lab.data(), lab.size(), p->stream));
       CHK(upload(&L.agg_ptr, ptr.data(), ptr.size(), p->stream));
       CHK(upload(&L.agg_mem, mem.data(), mem.size(), p->stream));
@@ -790,11 +903,15 @@ int ml_symbolic_setup(dpgo_problem_s* p, const std::vector<int>& ks_in) {
       for (int m = 0; m < cur; ++m) mpos[mem[m]] = m;
       CHK(upload(&L.mem_pos, mpos.data(), mpos.size(), p->stream));
       std::vector<int32_t> tperm;
-      if (L.k == additive_tile(p)) {  // the layout of the additive preconditioner's persistent kernel: aggregate = tile
-        tperm.assign((size_t)na * L.k, -1);
+      // the layout of the additive preconditioner's persistent kernel: aggregate = workgroup tile of `perm_tile` slots
+      if (!perm_tile && !merge_cap && L.k == additive_tile(p)) perm_tile = L.k;
+      if (perm_tile) {
+        if (std::max(L.k, merge_cap) > perm_tile) return fail(DPGO_ERR_INVALID, "multilevel: aggregates larger than the tile");
+        tperm.assign((size_t)na * perm_tile, -1);
         for (int a = 0; a < na; ++a)
-          for (int m = ptr[a]; m < ptr[a + 1]; ++m) tperm[(size_t)a * L.k + (m - ptr[a])] = mem[m];
+          for (int m = ptr[a]; m < ptr[a + 1]; ++m) tperm[(size_t)a * perm_tile + (m - ptr[a])] = mem[m];
         CHK(upload(&L.tile_perm, tperm.data(), tperm.size(), p->stream));
+        L.perm_tile = perm_tile;
       }
       HIPC(hipMalloc(&L.tbuf, tb * cur));
       // pattern of A P: the aggregates the block columns of every row fall into
@@ -959,21 +1076,33 @@ int ml_numeric_setup_d(dpgo_problem_s* p) {
     auto& L = p->ml[l];
     auto& C = p->ml[l + 1];
     const long long span = stride * L.k;
-    if (L.graph)
+    // (wave-parallel forms of the two setup kernels that walked an aggregate's members with ONE thread; DPGO_ML_SETUP_SERIAL=1
+    // restores them)
+    static const bool serial = [] { const char* e = std::getenv("DPGO_ML_SETUP_SERIAL"); return e && std::atoi(e) != 0; }();
+    auto wave_grid = [](int items) { return std::max(1, std::min(kMaxGrid, (items + kWaves - 1) / kWaves)); };
+    if (L.graph && !serial)
+      hipLaunchKernelGGL(k_ml_build_P_tree_wave<D>, dim3(wave_grid(C.n)), dim3(kBlock), 0, p->stream, p->Q.dev(), L.agg_ptr,
+                         L.agg_mem, L.parent, L.pslot, L.mem_pos, L.Pb, C.n);
+    else if (L.graph)
       hipLaunchKernelGGL(k_ml_build_P_tree<D>, dim3(flat_grid(C.n)), dim3(kBlock), 0, p->stream, p->Q.dev(), L.agg_ptr,
                          L.agg_mem, L.parent, L.pslot, L.Pb, C.n);
     else
       hipLaunchKernelGGL(k_ml_build_P<D>, dim3(flat_grid(C.n)), dim3(kBlock), 0, p->stream, p->Q.dev(), p->n, (int)stride,
                          (int)span, L.Pb, C.n);
     const BsrDev A = (l == 0) ? p->Q.dev() : L.A.dev();
-    hipLaunchKernelGGL(k_ml_galerkin<D>, dim3(flat_grid(C.A.nnzb)), dim3(kBlock), 0, p->stream, A,
-                       (l == 0) ? p->ml_shift : 0.0, L.Pb, L.agg(), L.agg_ptr, L.agg_mem, L.n, C.slot_row, C.A.colidx,
-                       C.A.vals, C.A.nnzb);
-    if (C.k)  // smoother of the next level (level 0 uses the handle's block-Jacobi factors)
-      hipLaunchKernelGGL(k_build_dinv<D>, dim3(flat_grid(C.n)), dim3(kBlock), 0, p->stream, C.A.dev(), 0.0, C.dinv, C.n);
-    if (l == 0 && L.AP.vals)
+    const bool have_ap = l == 0 && L.AP.vals;
+    if (have_ap)  // A P first: the Galerkin operator of a two-level hierarchy is its restriction
       hipLaunchKernelGGL(k_ml_build_AP<D>, dim3(flat_grid(L.n)), dim3(kBlock), 0, p->stream, p->Q.dev(), p->ml_shift, L.Pb,
                          L.agg(), L.n, L.AP.dev(), L.AP.vals);
+    if (have_ap && !serial)
+      hipLaunchKernelGGL(k_ml_galerkin_ap<D>, dim3(wave_grid(C.A.nnzb)), dim3(kBlock), 0, p->stream, L.AP.dev(), L.Pb,
+                         L.agg(), L.agg_ptr, L.agg_mem, L.n, C.slot_row, C.A.colidx, C.A.vals, C.A.nnzb);
+    else
+      hipLaunchKernelGGL(k_ml_galerkin<D>, dim3(flat_grid(C.A.nnzb)), dim3(kBlock), 0, p->stream, A,
+                         (l == 0) ? p->ml_shift : 0.0, L.Pb, L.agg(), L.agg_ptr, L.agg_mem, L.n, C.slot_row, C.A.colidx,
+                         C.A.vals, C.A.nnzb);
+    if (C.k)  // smoother of the next level (level 0 uses the handle's block-Jacobi factors)
+      hipLaunchKernelGGL(k_build_dinv<D>, dim3(flat_grid(C.n)), dim3(kBlock), 0, p->stream, C.A.dev(), 0.0, C.dinv, C.n);
     stride = span;
   }
   HIPC(hipGetLastError());
@@ -1011,26 +1140,84 @@ int ml_numeric_setup(dpgo_problem_s* p) {
   return DPGO_OK;
 }
 
+// The hierarchy's shape in the form ml_symbolic_setup takes it.
+std::vector<int> ml_current_ks(const dpgo_problem_s* p) {
+  std::vector<int> ks;
+  for (size_t l = 0; l + 1 < p->ml.size(); ++l) ks.push_back(p->ml[l].graph ? -p->ml[l].k : p->ml[l].k);
+  if (p->ml.size() == 2 && p->ml[0].graph && p->ml[0].merge_cap) ks.push_back(-p->ml[0].merge_cap);
+  return ks;
+}
+
+// Layout of the additive preconditioner inside the one-launch solve (k_rtr_persist<..., ADD>): ONE aggregate per workgroup,
+// at most kPersistMax = 256 of them.  Host only, once per block pattern:
+//   1. graph aggregates of at most one 4-lane-group tile (16 poses in 3-D), plain greedy growth, while there are <= 256
+//      (blocks up to ~3 500 poses: the lowest-latency layout);
+//   2. else one pose per (d+1) lanes (tile = 64 poses in 3-D): graph aggregates grown to S poses, fragments merged up to
+//      min(tile, 3 S / 2), with the smallest S (from ceil(n / 230) in steps of an eighth) that leaves <= 256 aggregates
+//      (12 500-pose slab: S = 55, 230 aggregates; 6 250-pose grid: S = 28, 221) -- blocks up to ~14 000 poses;
+//   3. without graph aggregates (DPGO_ML_GRAPH=0): index runs of one tile.
+const dpgo_problem_s::AddPlan& additive_plan(dpgo_problem_s* p) {
+  if (p->add_plan_known) return p->add_plan;
+  p->add_plan = dpgo_problem_s::AddPlan();
+  p->add_plan_known = true;
+  p->add_agg = dpgo_problem_s::AggCache();
+  if (p->split != 4 || (int)p->h_rowptr.size() != p->n + 1) return p->add_plan;
+  const int P4 = ml_tile(p->b, 4), P1 = ml_tile(p->b, 1), n = p->n;
+  static const bool graph_ok = [] { const char* e = std::getenv("DPGO_ML_GRAPH"); return !e || std::atoi(e) != 0; }();
+  if (graph_ok) {
+    auto& A = p->add_agg;
+    auto &lab = A.lab, &ptr = A.ptr, &mem = A.mem, &parent = A.parent, &pslot = A.pslot;
+    if ((long long)n <= (long long)kPersistMax * P4) {
+      const int na = ml_graph_aggregates(p->h_rowptr, p->h_colidx, n, P4, lab, ptr, mem, parent, pslot);
+      if (na <= kPersistMax) {
+        p->add_plan = dpgo_problem_s::AddPlan{4, P4, P4, 0, na, true};
+        A.S = P4, A.cap = 0;
+        return p->add_plan;
+      }
+    }
+    if ((long long)n <= (long long)kPersistMax * P1) {
+      for (int S = std::max(8, (n + 229) / 230); S <= P1; S += std::max(2, S / 8)) {
+        const int cap = std::min(P1, S + S / 2);
+        ml_graph_aggregates(p->h_rowptr, p->h_colidx, n, S, lab, ptr, mem, parent, pslot);
+        const int na = ml_merge_small_aggregates(p->h_rowptr, p->h_colidx, n, S, cap, lab, ptr, mem, parent, pslot);
+        if (na <= kPersistMax) {
+          p->add_plan = dpgo_problem_s::AddPlan{1, P1, S, cap, na, true};
+          A.S = S, A.cap = cap;
+          return p->add_plan;
+        }
+      }
+    }
+    p->add_agg = dpgo_problem_s::AggCache();
+  }
+  if ((n + P4 - 1) / P4 <= kPersistMax)
+    p->add_plan = dpgo_problem_s::AddPlan{4, P4, P4, 0, (n + P4 - 1) / P4, false};
+  else if ((n + P1 - 1) / P1 <= kPersistMax)
+    p->add_plan = dpgo_problem_s::AddPlan{1, P1, P1, 0, (n + P1 - 1) / P1, false};
+  return p->add_plan;
+}
+
+// lane groups per pose of the additive layout the CURRENT two-level hierarchy fits (0: none)
+int additive_split_of(const dpgo_problem_s* p) {
+  if (!p->ml_symbolic || p->ml.size() != 2 || p->split != 4 || p->ml[1].n > kPersistMax) return 0;
+  const auto& L = p->ml[0];
+  const int P4 = ml_tile(p->b, 4), P1 = ml_tile(p->b, 1);
+  const int tile = L.graph ? (L.tile_perm ? L.perm_tile : 0) : L.k;
+  return tile == P4 ? 4 : (tile == P1 ? 1 : 0);
+}
+
 // Make the hierarchy match the handle's Q (lazily, like the reference's constructPreconditioner inside the first
 // PreConditioner call, src/PoseGraph.cpp:582-586).
 int ml_ensure(dpgo_problem_s* p, double shift, bool additive = false) {
-  // the additive preconditioner needs ONE aggregate per tile of its persistent layout (two levels); a hierarchy the
-  // caller set up explicitly is kept if it has that shape, the default one is replaced (and put back when the V-cycle
-  // is asked for again)
-  const int Pa = additive_tile(p);
-  const bool shape_ok = p->ml_symbolic && p->ml.size() == 2 && p->ml[0].k == Pa && p->split == 4 &&
-                        (!p->ml[0].graph || p->ml[0].tile_perm) && p->ml[1].n <= kPersistMax;
-  if (additive && !shape_ok) {
-    if (p->split != 4) return fail(DPGO_ERR_UNSUPPORTED, "additive preconditioner: small-block layout only");
-    // graph aggregates of at most one tile (about half the products of index runs) while they fit the
-    // kernel's 256 workgroups -- the greedy growth leaves fragments, so there are more of them than n / tile --, else runs
-    static const bool graph_ok = [] { const char* e = std::getenv("DPGO_ML_GRAPH"); return !e || std::atoi(e) != 0; }();
-    bool done = false;
-    if (graph_ok) {
-      CHK(ml_symbolic_setup(p, std::vector<int>{-Pa}));
-      done = p->ml[1].n <= kPersistMax;
-    }
-    if (!done) CHK(ml_symbolic_setup(p, std::vector<int>{Pa}));
+  // the additive preconditioner needs ONE aggregate per workgroup tile of its persistent layout (two levels); a hierarchy
+  // the caller set up explicitly is kept if it has that shape, the default one is replaced by the handle's plan
+  // (additive_plan) and put back when the V-cycle is asked for again
+  if (additive && !additive_split_of(p)) {
+    const auto& plan = additive_plan(p);
+    if (!plan.split) return fail(DPGO_ERR_UNSUPPORTED, "additive preconditioner: the block does not fit 256 aggregates of one workgroup tile");
+    std::vector<int> ks{plan.graph ? -plan.S : plan.S};
+    if (plan.graph && plan.cap) ks.push_back(-plan.cap);
+    CHK(ml_symbolic_setup(p, ks, plan.graph ? plan.tile : 0));
+    if (!additive_split_of(p)) return fail(DPGO_ERR_STATE, "additive preconditioner: hierarchy does not match its plan");
     p->ml_additive_layout = true;
     p->ml_user_ks = false;
   } else if (!additive && p->ml_additive_layout && !p->ml_user_ks) {
@@ -1258,20 +1445,19 @@ void persist_release(dpgo_problem_s* p) {
 struct PersistGeo {
   int split = 0, mt = 0, wgs = 0, slots = 0;
 };
-bool additive_available(const dpgo_problem_s* p) {
-  const int P = additive_tile(p);
-  return p->persist && !p->persist_failed_once && p->split == 4 && (p->n + P - 1) / P <= kPersistMax;
+bool additive_available(dpgo_problem_s* p) {
+  return p->persist && !p->persist_failed_once && additive_plan(p).split != 0;
 }
 // `free_slots`: what may be reserved.  Alone on the device (share = 1): the lowest-latency layout that fits (4 lane groups
 // per pose while the tiles fit, then one pose per (d+1) lanes).  Sharing the device with `share` concurrently solved
 // agents: the lowest-latency layout of which `share` copies fit side by side; if there is none, the most compact one
 // (the solves then take turns).
 PersistGeo persist_geometry(const dpgo_problem_s* p, int free_slots, int share = 1, bool additive = false) {
-  if (additive) {  // fixed layout; one workgroup per CU (the rows of the coarse inverse live in its LDS)
-    const int P = additive_tile(p);
-    const int na = (p->ml.size() == 2 && p->ml[0].k == P) ? p->ml[1].n : (p->n + P - 1) / P;  // (after ml_ensure: the hierarchy's)
-    PersistGeo g{4, 1, na, 0};
-    g.slots = g.wgs * persist_slots_per_wg(4, 1, true);
+  if (additive) {  // fixed by the hierarchy (after ml_ensure); one workgroup per CU (the rows of the coarse inverse live in its LDS)
+    const int sp = additive_split_of(p);
+    if (!sp) return PersistGeo();
+    PersistGeo g{sp, 1, p->ml[1].n, 0};
+    g.slots = g.wgs * persist_slots_per_wg(sp, 1, true);
     if (g.wgs > kPersistMax || g.slots > free_slots) return PersistGeo();
     return g;
   }
@@ -1312,7 +1498,9 @@ int launch_rtr_persistent(dpgo_problem_s* p, const dpgo_ropt_params* prm, const 
       g = persist_geometry(p, cap - used.load(), 1, additive);
       if (g.wgs <= 0 || !persist_reserve(p, g.slots, cap)) return DPGO_OK;
     } else {
-      const int limit = cap - cap / 5;
+      // (the additive form's grid is fixed by its hierarchy -- one workgroup per aggregate, up to the whole chip: such solves
+      // take turns)
+      const int limit = additive ? cap : cap - cap / 5;
       g = persist_geometry(p, limit, p->persist_share, additive);
       if (g.wgs <= 0) return DPGO_OK;
       const auto t0 = std::chrono::steady_clock::now();
@@ -1358,18 +1546,33 @@ int launch_rtr_persistent(dpgo_problem_s* p, const dpgo_ropt_params* prm, const 
   const RtrArgs ra{prm->gradnorm_tol, prm->RTR_initial_radius, 5.0 * prm->RTR_initial_radius, prm->RTR_tCG_iterations,
                    prm->RTR_iterations, prm->accept_tiny_decrease};
   const double* Glin = p->has_G ? p->G : nullptr;
+  // (static + dynamic LDS of the additive instances can exceed 64 KB: the attribute is raised once per handle, layout
+  // and size)
 #define PERSIST_LAUNCH(SP, MT_, ADD_, LDS_)                                                                           \
-  hipLaunchKernelGGL((k_rtr_persist<D, R, SP, MT_, ADD_>), dim3(p->persist_wgs), dim3(kBlock), LDS_, p->stream,       \
-                     p->Q.dev(), p->x1, Glin, dinv, p->x2, p->eta, p->z, p->pgran, salt, p->dstate, p->pctrl, p->n,   \
-                     p->hflag, p->gen, poll, ra, add)
+  do {                                                                                                                \
+    if ((LDS_) > 0 && p->persist_lds_attr != (size_t)(LDS_) * 8 + SP) {                                               \
+      HIPC(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rtr_persist<D, R, SP, MT_, ADD_>),                     \
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)(LDS_)));                             \
+      p->persist_lds_attr = (size_t)(LDS_) * 8 + SP;                                                                  \
+    }                                                                                                                 \
+    hipLaunchKernelGGL((k_rtr_persist<D, R, SP, MT_, ADD_>), dim3(p->persist_wgs), dim3(kBlock), LDS_, p->stream,     \
+                       p->Q.dev(), p->x1, Glin, dinv, p->x2, p->eta, p->z, p->pgran, salt, p->dstate, p->pctrl, p->n, \
+                       p->hflag, p->gen, poll, ra, add);                                                              \
+  } while (0)
   DISPATCH(p->d, p->r, {
-    if (additive) PERSIST_LAUNCH(4, 1, true, lds);
+    if (additive && p->persist_split == 4) PERSIST_LAUNCH(4, 1, true, lds);
+    else if (additive) PERSIST_LAUNCH(1, 1, true, lds);
     else if (p->persist_split == 4 && p->persist_mt == 1) PERSIST_LAUNCH(4, 1, false, 0);
     else if (p->persist_split == 4) PERSIST_LAUNCH(4, 2, false, 0);
     else if (p->persist_mt == 1) PERSIST_LAUNCH(1, 1, false, 0);
     else PERSIST_LAUNCH(1, 2, false, 0);
   });
 #undef PERSIST_LAUNCH
+  {  // the iterate reaches the caller's X only if the launch completed on every participant (k_persist_commit)
+    const size_t count = (size_t)p->n * p->T;
+    const int grid = (int)std::min<size_t>(1024, (count + kBlock - 1) / kBlock);
+    hipLaunchKernelGGL(k_persist_commit, dim3(grid), dim3(kBlock), 0, p->stream, p->dstate, p->pctrl, p->x2, p->x1, count);
+  }
   HIPC(hipGetLastError());
   p->cur = 0;
   *used = true;
@@ -1504,9 +1707,9 @@ int run_optimize(dpgo_problem_s* p, const dpgo_ropt_params* prm, dpgo_ropt_resul
     dinv = p->dinv;  // the smoother's block-Jacobi factors (same shift)
   } else if (prm->precond == DPGO_PRECOND_ADDITIVE) {
     if (prm->method != DPGO_METHOD_RTR) return fail(DPGO_ERR_UNSUPPORTED, "the additive preconditioner exists inside the tCG loop only");
-    const int P = additive_tile(p);
-    if ((p->n + P - 1) / P > kPersistMax)
-      return fail(DPGO_ERR_UNSUPPORTED, "additive preconditioner: block too large (at most 256 aggregates of " + std::to_string(P) + " poses)");
+    if (!additive_split_of(p) && !additive_plan(p).split)
+      return fail(DPGO_ERR_UNSUPPORTED, "additive preconditioner: block too large (at most 256 aggregates of one workgroup tile, " +
+                                            std::to_string(ml_tile(p->b, 1)) + " poses)");
     CHK(ml_ensure(p, prm->precond_shift, /*additive=*/true));
     dinv = p->dinv;
   } else if (prm->precond != DPGO_PRECOND_NONE) {
@@ -1525,7 +1728,11 @@ int run_optimize(dpgo_problem_s* p, const dpgo_ropt_params* prm, dpgo_ropt_resul
   // ---- blocks in the latency regime: the whole solve is ONE persistent launch (k_rtr_persist) and one read-back.  The
   // single-iteration radius-shrink mode (:80-99) and the polling mode keep the multi-launch scheme.
   const bool add = prm->precond == DPGO_PRECOND_ADDITIVE;
-  if (prm->method == DPGO_METHOD_RTR && prm->RTR_iterations != 1 && prm->tcg_poll_interval <= 0 && p->persist &&
+  // (the in-kernel all-reduce tags its granules with salt | step, the step counter in the low 20 bits: a solve whose
+  // parameters allow more reductions than that -- at most 3 per tCG iteration + 4 per outer iteration + 1 -- keeps the
+  // multi-launch scheme)
+  const bool epochs_fit = (long long)std::max(1, prm->RTR_iterations) * (3LL * std::max(0, prm->RTR_tCG_iterations) + 4) + 1 < (1LL << 20);
+  if (prm->method == DPGO_METHOD_RTR && prm->RTR_iterations != 1 && prm->tcg_poll_interval <= 0 && p->persist && epochs_fit &&
       !p->persist_failed_once && (add || prm->precond == DPGO_PRECOND_BLOCK_JACOBI || prm->precond == DPGO_PRECOND_NONE)) {
     bool used = false;
     CHK(launch_rtr_persistent(p, prm, dinv, &used, add));
@@ -1533,12 +1740,9 @@ int run_optimize(dpgo_problem_s* p, const dpgo_ropt_params* prm, dpgo_ropt_resul
       HIPC(hipMemcpyAsync(p->hctrl, p->pctrl, sizeof(PersistCtrl), hipMemcpyDeviceToHost, p->stream));
       CHK(poll_state(p));
       persist_report(p);
-      if (p->hstate->rtr_stop != kPersistPoison) {
-        // (a participant that timed out after participant 0 had left its last reduction cannot happen unless granules
-        // that every other workgroup saw stay invisible to one for the whole spin bound; if it did, that workgroup's rows
-        // of the iterate were not written back -- never continue silently)
-        if (p->hctrl->error)
-          return fail(DPGO_ERR_HIP, "one-launch solve: a workgroup timed out after the final reduction; the iterate is incomplete");
+      // (k_persist_commit, which ran behind the solve, saw the same two words: with a poisoned record OR a raised time-out
+      // flag -- some participant gave up, however late -- the caller's iterate has not been touched)
+      if (p->hstate->rtr_stop != kPersistPoison && !p->hctrl->error) {
         const DevState& h = *p->hstate;
         res->fInit = h.fInit;
         res->gradNormInit = h.gnInit;
@@ -1969,10 +2173,10 @@ int dpgo_problem_set_Q_bsr(dpgo_problem_t p, int nnzb, const int32_t* rowptr, co
   if (!same_pattern) {
     p->h_rowptr.assign(rowptr, rowptr + p->n + 1);
     p->h_colidx.assign(colidx, colidx + nnzb);
+    p->add_plan_known = false;
     if (p->ml_user_ks && p->ml_symbolic) {  // keep the caller's aggregate sizes across a pattern change
-      std::vector<int> ks;
-      for (size_t l = 0; l + 1 < p->ml.size(); ++l) ks.push_back(p->ml[l].graph ? -p->ml[l].k : p->ml[l].k);
-      CHK(ml_symbolic_setup(p, ks));
+      const int perm_tile = p->ml[0].perm_tile;
+      CHK(ml_symbolic_setup(p, ml_current_ks(p), perm_tile));
     } else {
       ml_free(p);
     }
@@ -2265,14 +2469,49 @@ int dpgo_multilevel_graph_aggregates(int n, const int32_t* rowptr, const int32_t
   return DPGO_OK;
 }
 
+int dpgo_multilevel_merged_aggregates(int n, const int32_t* rowptr, const int32_t* colidx, int max_size, int merge_cap,
+                                      int32_t* label, int32_t* parent, int* n_aggregates) {
+  if (n <= 0 || !rowptr || !colidx || max_size < 2 || merge_cap < max_size || !label) return fail(DPGO_ERR_INVALID, "bad arguments");
+  const std::vector<int32_t> rp(rowptr, rowptr + n + 1), ci(colidx, colidx + rowptr[n]);
+  for (int32_t c : ci)
+    if (c < 0 || c >= n) return fail(DPGO_ERR_INVALID, "block column out of range");
+  std::vector<int32_t> lab, ptr, mem, par, pslot;
+  ml_graph_aggregates(rp, ci, n, max_size, lab, ptr, mem, par, pslot);
+  const int na = ml_merge_small_aggregates(rp, ci, n, max_size, merge_cap, lab, ptr, mem, par, pslot);
+  std::copy(lab.begin(), lab.end(), label);
+  if (parent) std::copy(par.begin(), par.end(), parent);
+  if (n_aggregates) *n_aggregates = na;
+  return DPGO_OK;
+}
+
+int dpgo_problem_additive_plan(dpgo_problem_t p, int* lane_groups, int* tile, int* growth, int* merge_cap, int* aggregates,
+                               int* graph) {
+  if (!p) return fail(DPGO_ERR_INVALID, "null handle");
+  if ((int)p->h_rowptr.size() != p->n + 1) return fail(DPGO_ERR_STATE, "Q's block pattern is not set");
+  const auto& plan = additive_plan(p);
+  if (lane_groups) *lane_groups = plan.split;
+  if (tile) *tile = plan.tile;
+  if (growth) *growth = plan.S;
+  if (merge_cap) *merge_cap = plan.cap;
+  if (aggregates) *aggregates = plan.na;
+  if (graph) *graph = plan.graph ? 1 : 0;
+  return DPGO_OK;
+}
+
 int dpgo_problem_setup_multilevel(dpgo_problem_t p, int nks, const int* ks, double omega, double shift) {
   CHK(check_ready(p));
   if (nks < 0 || nks > 8 || (nks > 0 && !ks) || !(omega > 0.0) || !(shift >= 0.0))
     return fail(DPGO_ERR_INVALID, "bad multilevel arguments");
   std::vector<int> v = nks > 0 ? std::vector<int>(ks, ks + nks) : ml_default_ks(p->n, p->b, p->split);
-  bool same = p->ml_symbolic && p->ml.size() == v.size() + 1;
-  for (size_t l = 0; same && l < v.size(); ++l) same = (p->ml[l].graph ? -p->ml[l].k : p->ml[l].k) == v[l];
-  if (!same) CHK(ml_symbolic_setup(p, v));
+  const bool same = p->ml_symbolic && ml_current_ks(p) == v;
+  if (!same) {
+    // graph aggregates with merged fragments that fit a workgroup tile of the one-launch solve also get that layout's
+    // (aggregate, slot) table, so that an explicit hierarchy of this shape serves precond = additive as well
+    int perm_tile = 0;
+    if (v.size() == 2 && v[0] < 0 && v[1] < 0 && p->split == 4)
+      perm_tile = -v[1] <= ml_tile(p->b, 4) ? ml_tile(p->b, 4) : (-v[1] <= ml_tile(p->b, 1) ? ml_tile(p->b, 1) : 0);
+    CHK(ml_symbolic_setup(p, v, perm_tile));
+  }
   p->ml_user_ks = nks > 0;
   p->ml_additive_layout = false;
   p->ml_omega = omega;
@@ -2310,6 +2549,8 @@ int dpgo_problem_multilevel_info(dpgo_problem_t p, int* nlevels, int* sizes, int
   for (int l = 0; l < (int)p->ml.size() && l < cap; ++l) {
     if (sizes) sizes[l] = p->ml[l].n;
     if (ks) ks[l] = p->ml[l].graph ? -p->ml[l].k : p->ml[l].k;  // negative: graph aggregates of at most that many poses
+    // (graph aggregates whose fragments were merged: the LAST level's entry, otherwise 0, carries -merge bound)
+    if (ks && l > 0 && l + 1 == (int)p->ml.size() && p->ml[0].graph && p->ml[0].merge_cap) ks[l] = -p->ml[0].merge_cap;
     if (nnzb) nnzb[l] = (l == 0) ? p->Q.nnzb : p->ml[l].A.nnzb;
   }
   if (nlevels) *nlevels = (int)p->ml.size();

@@ -696,6 +696,169 @@ __global__ __launch_bounds__(kBlock) void k_ml_build_P_tree(BsrDev Q, const int3
   }
 }
 
+// The same, one WAVE per aggregate (graph aggregates of dozens to hundreds of poses: one thread walking 250 members one
+// dependent load after the other took 1.24 ms at 100k poses, 0.37 ms on a 12 500-pose block of 230 aggregates).  The members
+// are in breadth-first discovery order, so a parent precedes its children; the wave takes them in chunks of 64 and, inside a
+// chunk, in passes: a lane computes once its parent's block is there (parent in an earlier chunk, or done in an earlier
+// pass -- ballot mask).  Every block is computed by the same arithmetic as in the one-thread kernel: identical bits.
+// mem_pos[i] = position of pose i in agg_mem.
+template <int D>
+__device__ __forceinline__ void ml_tree_block(const BsrDev& Q, const double* Pb, int i, int par, int slot, double* out) {
+  constexpr int B = D + 1, BB = B * B;
+  double G[B][B];
+#pragma unroll
+  for (int p = 0; p < B; ++p)
+#pragma unroll
+    for (int q = 0; q < B; ++q) G[p][q] = (p == q) ? 1.0 : 0.0;
+  if (par >= 0) {
+    const double* blk = Q.vals + (size_t)slot * BB;
+    const double wt = -blk[D * B + D];
+    double wk = 0.0;
+#pragma unroll
+    for (int p = 0; p < D; ++p) wk = fma(blk[p * B], blk[p * B], wk);
+    wk = sqrt(wk);
+    bool fwd = true, bwd = true;
+#pragma unroll
+    for (int q = 0; q < D; ++q) {
+      fwd = fwd && (blk[D * B + q] == 0.0);
+      bwd = bwd && (blk[q * B + D] == 0.0);
+    }
+    if ((wt > 0.0) && (wk > 0.0) && (fwd || bwd)) {
+      double Tm[B][B];
+#pragma unroll
+      for (int p = 0; p < B; ++p)
+#pragma unroll
+        for (int q = 0; q < B; ++q) Tm[p][q] = (p == q) ? 1.0 : 0.0;
+#pragma unroll
+      for (int p = 0; p < D; ++p)
+#pragma unroll
+        for (int q = 0; q < D; ++q) Tm[p][q] = -blk[p * B + q] / wk;
+      if (fwd) {
+#pragma unroll
+        for (int p = 0; p < D; ++p) Tm[p][D] = -blk[p * B + D] / wt;
+      } else {
+#pragma unroll
+        for (int p = 0; p < D; ++p) {
+          double sv = 0.0;
+#pragma unroll
+          for (int q = 0; q < D; ++q) sv = fma(Tm[p][q], blk[D * B + q] / wt, sv);
+          Tm[p][D] = sv;
+        }
+      }
+      const double* Pp = Pb + (size_t)par * BB;  // G(root -> parent)^T
+#pragma unroll
+      for (int p = 0; p < B; ++p)
+#pragma unroll
+        for (int q = 0; q < B; ++q) {
+          double sv = 0.0;
+#pragma unroll
+          for (int mm = 0; mm < B; ++mm) sv = fma(Pp[mm * B + p], Tm[mm][q], sv);
+          G[p][q] = sv;
+        }
+    }
+  }
+#pragma unroll
+  for (int p = 0; p < B; ++p)
+#pragma unroll
+    for (int q = 0; q < B; ++q) out[p * B + q] = G[q][p];
+}
+template <int D>
+__global__ __launch_bounds__(kBlock) void k_ml_build_P_tree_wave(BsrDev Q, const int32_t* __restrict__ agg_ptr,
+                                                                 const int32_t* __restrict__ agg_mem,
+                                                                 const int32_t* __restrict__ parent,
+                                                                 const int32_t* __restrict__ pslot,
+                                                                 const int32_t* __restrict__ mem_pos, double* Pb, int na) {
+  constexpr int B = D + 1, BB = B * B;
+  const int lane = threadIdx.x & 63;
+  const int wave0 = blockIdx.x * kWaves + (threadIdx.x >> 6), nwaves = gridDim.x * kWaves;
+  for (int a = wave0; a < na; a += nwaves) {
+    const int m0 = agg_ptr[a], m1 = agg_ptr[a + 1];
+    for (int c0 = m0; c0 < m1; c0 += 64) {
+      const int m = c0 + lane;
+      const bool have = m < m1;
+      const int i = have ? agg_mem[m] : 0;
+      const int par = have ? parent[i] : -1;
+      const int slot = have ? pslot[i] : 0;
+      const int pp = par >= 0 ? mem_pos[par] : -1;  // the parent's position in the member list
+      bool done = !have;
+      unsigned long long done_mask = __ballot(done);
+      for (int pass = 0; pass < 65 && done_mask != ~0ull; ++pass) {
+        const bool ready = !done && (pp < c0 || ((done_mask >> (pp - c0)) & 1ull));
+        if (ready) {
+          double out[BB];
+          ml_tree_block<D>(Q, Pb, i, par, slot, out);
+#pragma unroll
+          for (int e = 0; e < BB; ++e) Pb[(size_t)i * BB + e] = out[e];
+          done = true;
+        }
+        // the blocks just written are read by other lanes of THIS wave in the next pass / chunk
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        done_mask = __ballot(done);
+      }
+    }
+  }
+}
+
+// Galerkin operator of a TWO-level hierarchy from A P (k_ml_build_AP, which runs first):
+//   Ac[a][bc] = sum_{i in a} P_i^T (A P)[i][bc].
+// One WAVE per coarse slot: the lanes take the aggregate's members 64 apart, each looks the block column bc up in its row of
+// A P (a handful of entries) and accumulates its 4 x 4 product; the lanes' partial sums are added by the fixed DPP tree
+// (deterministic).  The one-thread-per-slot kernel below rescans every member's block row once per coarse slot of the
+// row and took 3.6 ms at 100k poses / 0.84 ms on a 12 500-pose block.
+template <int D>
+__global__ __launch_bounds__(kBlock) void k_ml_galerkin_ap(BsrDev AP, const double* __restrict__ Pb, AggMap am,
+                                                           const int32_t* __restrict__ agg_ptr,
+                                                           const int32_t* __restrict__ agg_mem, int n_fine,
+                                                           const int32_t* __restrict__ slot_row,
+                                                           const int32_t* __restrict__ ccol, double* __restrict__ cvals,
+                                                           int cnnzb) {
+  const int k = am.k;
+  constexpr int B = D + 1, BB = B * B;
+  const int lane = threadIdx.x & 63;
+  const int wave0 = blockIdx.x * kWaves + (threadIdx.x >> 6), nwaves = gridDim.x * kWaves;
+  for (int s = wave0; s < cnnzb; s += nwaves) {
+    const int a = slot_row[s], bc = ccol[s];
+    double acc[B][B];
+#pragma unroll
+    for (int p = 0; p < B; ++p)
+#pragma unroll
+      for (int q = 0; q < B; ++q) acc[p][q] = 0.0;
+    const int m0 = am.lab ? agg_ptr[a] : a * k;
+    const int m1 = am.lab ? agg_ptr[a + 1] : ((a * k + k < n_fine) ? a * k + k : n_fine);
+    for (int m = m0 + lane; m < m1; m += 64) {
+      const int i = am.lab ? agg_mem[m] : m;
+      int t = -1;
+      for (int u = AP.rowptr[i]; u < AP.rowptr[i + 1]; ++u)
+        if (AP.colidx[u] == bc) t = u;
+      if (t < 0) continue;
+      const double* __restrict__ Pi = Pb + (size_t)i * BB;
+      const double* __restrict__ av = AP.vals + (size_t)t * BB;
+#pragma unroll
+      for (int p = 0; p < B; ++p)
+#pragma unroll
+        for (int q = 0; q < B; ++q) {
+          double sv = acc[p][q];
+#pragma unroll
+          for (int mm = 0; mm < B; ++mm) sv = fma(Pi[mm * B + p], av[mm * B + q], sv);
+          acc[p][q] = sv;
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < B; ++p)
+#pragma unroll
+      for (int q = 0; q < B; ++q) acc[p][q] = wave_reduce_lane63(acc[p][q]);
+    if (lane == 63) {
+      double* __restrict__ out = cvals + (size_t)s * BB;
+#pragma unroll
+      for (int p = 0; p < B; ++p)
+#pragma unroll
+        for (int q = 0; q < B; ++q) out[p * B + q] = acc[p][q];
+    }
+  }
+}
+
 // Galerkin operator, values only:  Ac[a][bc] = sum_{i in a} sum_{j in bc} P_i^T (A_ij + [i == j] shift I) P_j.
 // One thread per coarse slot (its block row in slot_row) scans the k fine rows of aggregate a: fixed summation order.
 template <int D>

@@ -279,7 +279,8 @@ __device__ __forceinline__ void gather_finish(const GatherOps<D, R, SPLIT, QRES>
 constexpr int persist_slots_per_wg(int, int, bool = false) { return 2; }
 
 // ADD: the preconditioner is the ADDITIVE two-level combination  z = proj_X( w Dinv r + P A_c^-1 P^T r )  on the handle's
-// two-level hierarchy with ONE aggregate per workgroup tile (k = Geo::P): block-Jacobi plus the coarse-grid correction of
+// two-level hierarchy with ONE aggregate per workgroup tile (at most Geo::P poses: 16 with 4 lane groups per pose, 64 with
+// one pose per (D+1) lanes -- blocks up to ~14 000 poses in 3-D): block-Jacobi plus the coarse-grid correction of
 // the residual itself, so nothing inside the preconditioner applies an operator to a vector other workgroups hold -- the
 // only exchange is the restricted residual rc (n / P coarse nodes x (D+1) R doubles: an all-gather every workgroup reads
 // in full), and it rides on a reduction the iteration needs anyway.  Per iteration: phase A | all-reduce <delta, H delta> |
@@ -308,9 +309,10 @@ struct RtrArgs {
 // at the trial point, the model decrease (H eta), the rho test and the radius update -- k_grad, k_rtr_begin, k_retract,
 // k_hess and k_rtr_update of the multi-launch scheme, same arithmetic, evaluated on the registers / LDS tiles the tCG
 // loop already holds.  Between workgroups travel, besides z: the trial point x2 and the step eta (write-through, gathered
-// for x2 Q and eta Q); their dot products ride on two more reductions per outer iteration.  X is read at the start and
-// written back once at the end (only then: a launch that times out leaves the caller's iterate untouched, the host reruns
-// the solve with the multi-launch scheme).  The host's part of a solve: one launch, one 200-byte read-back.
+// for x2 Q and eta Q); their dot products ride on two more reductions per outer iteration.  X is read at the start; the
+// result is left in the trial-point buffer and committed to X by k_persist_commit (below) behind this kernel -- a launch
+// in which ANY participant timed out leaves the caller's iterate untouched, the host reruns the solve with the multi-launch
+// scheme.  The host's part of a solve: two launches, one 200-byte read-back.
 template <int D, int R, int SPLIT, int MT, bool ADD = false>
 __global__ __launch_bounds__(kBlock, 1) void k_rtr_persist(BsrDev Q, double* X, const double* __restrict__ Glin,
                                                            const double* __restrict__ dinv, double* xbuf, double* ebuf,
@@ -333,6 +335,7 @@ __global__ __launch_bounds__(kBlock, 1) void k_rtr_persist(BsrDev Q, double* X, 
   // additive preconditioner: P_i^T r_i of the tile's poses, the aggregate's coarse solution, its per-wave partial sums;
   // dynamic LDS: the (D+1) rows of A_c^-1 this workgroup's aggregate needs, (D+1) x N_c doubles
   __shared__ double ts[ADD ? P : 1][ADD ? T : 1], xc_s[ADD ? T : 1], xw_s[ADD ? kWaves : 1][ADD ? T : 1];
+  __shared__ double tw_s[ADD ? kWaves : 1][ADD ? T : 1];  // per-wave sums of P_i^T r_i
   extern __shared__ double Ms[];
 
   const int rank = blockIdx.x, members = gridDim.x;
@@ -534,11 +537,20 @@ __global__ __launch_bounds__(kBlock, 1) void k_rtr_persist(BsrDev Q, double* X, 
         }
         store_col<R>(&ts[lp][co], t);  // zeros for pose slots beyond n
       }
-      __syncthreads();
-      if ((int)threadIdx.x < T && rank < ntiles) {  // fixed order over the tile's poses; the all-gathered coarse residual
-        double sum = ts[0][threadIdx.x];
+      // fixed order: every wave adds up its own G pose slots, then the waves in order; the all-gathered coarse residual
+      wave_sync();
+      if ((int)(threadIdx.x & 63) < T) {
+        const int e = threadIdx.x & 63;
+        double sum = ts[L.wave * G][e];
 #pragma unroll
-        for (int m = 1; m < P; ++m) sum += ts[m][threadIdx.x];
+        for (int m = 1; m < G; ++m) sum += ts[L.wave * G + m][e];
+        tw_s[L.wave][e] = sum;
+      }
+      __syncthreads();
+      if ((int)threadIdx.x < T && rank < ntiles) {
+        double sum = tw_s[0][threadIdx.x];
+#pragma unroll
+        for (int w = 1; w < kWaves; ++w) sum += tw_s[w][threadIdx.x];
         st_agent(add.rc + (size_t)rank * T + threadIdx.x, sum);
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // acknowledged before the reduction publishes
@@ -553,14 +565,26 @@ __global__ __launch_bounds__(kBlock, 1) void k_rtr_persist(BsrDev Q, double* X, 
       for (int row = 0; row < B; ++row)
 #pragma unroll
         for (int a = 0; a < R; ++a) acc[row][a] = 0.0;
-      for (int j = threadIdx.x; j < Nc; j += kBlock) {  // a coarse unknown's R right-hand sides: one thread each
-        double rj[R];
-        ld_col_agent<R>(rrc, j * R * 8, rj);
+      // a coarse unknown's R right-hand sides: one thread each, ALL of a thread's columns requested before the first use
+      // (nc <= kPersistMax aggregates: at most NJ = D + 1 columns per thread; one memory round trip, not one per column)
+      {
+        constexpr int NJ = (kPersistMax * B + kBlock - 1) / kBlock;
+        double rj[NJ][R];
 #pragma unroll
-        for (int row = 0; row < B; ++row) {
-          const double m = Ms[row * Nc + j];
+        for (int m = 0; m < NJ; ++m) {
+          const int j = (int)threadIdx.x + m * kBlock;
+          ld_col_agent<R>(rrc, (j < Nc ? j : 0) * R * 8, rj[m]);
+        }
 #pragma unroll
-          for (int a = 0; a < R; ++a) acc[row][a] = fma(m, rj[a], acc[row][a]);
+        for (int m = 0; m < NJ; ++m) {
+          const int j = (int)threadIdx.x + m * kBlock;
+          const bool on = j < Nc;
+#pragma unroll
+          for (int row = 0; row < B; ++row) {
+            const double mv = on ? Ms[row * Nc + j] : 0.0;
+#pragma unroll
+            for (int a = 0; a < R; ++a) acc[row][a] = fma(mv, rj[m][a], acc[row][a]);
+          }
         }
       }
 #pragma unroll
@@ -998,8 +1022,10 @@ __global__ __launch_bounds__(kBlock, 1) void k_rtr_persist(BsrDev Q, double* X, 
   }
   }  // outer iterations
 
-  // ==== hand the result back: the iterate (own columns; nothing was written while the solve could still fail) and
-  // the state record
+  // ==== hand the result back: the state record, and the iterate (own columns) into the trial-point buffer -- every
+  // participant has finished gathering from it once the last reduction is through.  The CALLER'S X is written by
+  // k_persist_commit, launched behind this kernel, and only if no participant of the launch timed out: a workgroup cannot
+  // know on its own whether a slower one will still fail, so nothing here touches X.
   const bool good = alive && !__hip_atomic_load(&ctrl->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (good && moved) {
 #pragma unroll
@@ -1007,12 +1033,12 @@ __global__ __launch_bounds__(kBlock, 1) void k_rtr_persist(BsrDev Q, double* X, 
       if (own[k]) {
         const size_t off = (size_t)pose[k] * T + co;
 #pragma unroll
-        for (int a = 0; a < R; ++a) X[off + a] = Xs[k][lp][co + a];
+        for (int a = 0; a < R; ++a) xbuf[off + a] = Xs[k][lp][co + a];
       }
     }
   }
   if (rank == 0 && threadIdx.x == 0) {
-    if (!good) st.rtr_stop = 3;  // time-out: poisoned record; X is untouched and the host reruns the solve (kPersistPoison)
+    if (!good) st.rtr_stop = 3;  // time-out: poisoned record; X stays untouched and the host reruns the solve (kPersistPoison)
     store_state(sout, st);
     store_state(sout + 1, st);
     publish_progress(hflag, gen, st);
@@ -1021,4 +1047,16 @@ __global__ __launch_bounds__(kBlock, 1) void k_rtr_persist(BsrDev Q, double* X, 
 #pragma unroll
     for (int q = 0; q < 5; ++q) ctrl->ticks[q] = tk[q];
   }
+}
+
+// Second half of the hand-over of a one-launch solve (same stream, right behind k_rtr_persist): the iterate the solve left in
+// the trial-point buffer becomes the caller's X -- if and only if the launch completed on EVERY participant (state record
+// not poisoned, no time-out flag) and a step was accepted.  A late time-out of some workgroups therefore leaves X exactly as
+// the caller passed it, whatever the others had finished.
+__global__ __launch_bounds__(kBlock) void k_persist_commit(const DevState* __restrict__ st, const PersistCtrl* __restrict__ ctrl,
+                                                           const double* __restrict__ xfin, double* __restrict__ X,
+                                                           size_t count) {
+  if (st->rtr_stop == 3 || ctrl->error || st->n_accept <= 0) return;
+  // (8-byte pieces: a caller's device pointer is only promised to be aligned for doubles; at most 5 MB)
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < count; i += (size_t)gridDim.x * kBlock) X[i] = xfin[i];
 }

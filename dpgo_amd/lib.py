@@ -75,6 +75,8 @@ SIGNATURES = {
     "dpgo_problem_get_Q_values": ([_P, _P], _I),
     "dpgo_multilevel_default_ks": ([_I, _I, _P, C.POINTER(_I)], _I),
     "dpgo_multilevel_graph_aggregates": ([_I, _P, _P, _I, _P, _P, C.POINTER(_I)], _I),
+    "dpgo_multilevel_merged_aggregates": ([_I, _P, _P, _I, _I, _P, _P, C.POINTER(_I)], _I),
+    "dpgo_problem_additive_plan": ([_P] + [C.POINTER(_I)] * 6, _I),
     "dpgo_problem_setup_multilevel": ([_P, _I, _P, _D, _D], _I),
     "dpgo_problem_multilevel_info": ([_P, C.POINTER(_I), _P, _P, _P], _I),
     "dpgo_problem_multilevel_get": ([_P, _I, _I, _P], _I),

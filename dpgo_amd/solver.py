@@ -455,7 +455,8 @@ class QuadraticProblem:
 
     def setupMultilevel(self, ks=None, omega: float = 0.7, shift: float = 1e-1, coarse_bits=None) -> dict:
         """Explicit setup for the current Q: ks = aggregate sizes per coarsening (None: the library's defaults; a single
-        negative entry -S = two levels with graph aggregates of at most S poses, see dpgo_hip.h),
+        negative entry -S = two levels with graph aggregates of at most S poses, [-S, -cap] = the same with the growth's
+        fragments merged up to cap poses, see dpgo_hip.h),
         coarse_bits = storage precision of the dense level (None: keep the handle's, 64 by default; 32 = opt-in).
         Returns multilevelInfo()."""
         self.refresh()
@@ -492,7 +493,20 @@ class QuadraticProblem:
         sizes, ks, nnzb = (np.zeros(cap, dtype=np.int32) for _ in range(3))
         L.check(self._lib.dpgo_problem_multilevel_info(self._h, C.byref(nl), L.ptr(sizes), L.ptr(ks), L.ptr(nnzb)))
         n = nl.value
-        return dict(sizes=[int(v) for v in sizes[:n]], ks=[int(v) for v in ks[:n - 1]], nnzb=[int(v) for v in nnzb[:n]])
+        # (graph aggregates with merged fragments: ks = [-S, -cap], the form setupMultilevel takes)
+        kk = [int(v) for v in ks[:n - 1]] + ([int(ks[n - 1])] if n >= 2 and ks[n - 1] < 0 else [])
+        return dict(sizes=[int(v) for v in sizes[:n]], ks=kk, nnzb=[int(v) for v in nnzb[:n]])
+
+    def additivePlan(self) -> dict:
+        """Layout precond = "additive" uses for this block (dpgo_problem_additive_plan; host only): lane_groups per pose of
+        the one-launch kernel (0: the block does not fit), tile = slots per aggregate = workgroup, growth / merge_cap of
+        the graph aggregates (ks = [-growth, -merge_cap], or [-growth] when merge_cap is 0), aggregates = workgroups."""
+        v = [C.c_int(0) for _ in range(6)]
+        L.check(self._lib.dpgo_problem_additive_plan(self._h, *[C.byref(x) for x in v]))
+        keys = ("lane_groups", "tile", "growth", "merge_cap", "aggregates", "graph")
+        out = {k: int(x.value) for k, x in zip(keys, v)}
+        out["ks"] = ([-out["growth"]] + ([-out["merge_cap"]] if out["merge_cap"] else [])) if out["graph"] else [out["tile"]]
+        return out
 
     def multilevelGet(self, level: int, what: str) -> np.ndarray:
         """Copy of one item of the built hierarchy: "P" (prolongation blocks of a level), "rowptr" / "colidx" / "A"

@@ -60,12 +60,14 @@ extern "C" {
  * dpgo_ropt_result::precond_used says what a call ran. */
 #define DPGO_PRECOND_AUTO 3
 /* Additive two-level preconditioner  z = proj_X( Dinv r + P A_c^-1 P^T r )  (block-Jacobi plus the coarse-grid correction
- * of the residual; same chain prolongations and Galerkin coarse operator as the multilevel cycle, one aggregate per 16
- * (3-D) / 20 (2-D) poses): nothing inside it applies an operator to a distributed vector, so a whole preconditioned tCG
- * iteration runs inside the persistent kernel (three in-kernel reductions).  Available for blocks of at most 256 such
- * aggregates (4 096 poses in 3-D); where the persistent kernel cannot run (larger blocks: DPGO_ERR_UNSUPPORTED; no free
- * resident slots or a time-out: silently) the solve uses the multilevel V-cycle on the same hierarchy instead.  What
- * DPGO_PRECOND_AUTO selects for such blocks when it selects a multilevel preconditioner. */
+ * of the residual; same tree prolongations and Galerkin coarse operator as the multilevel cycle; ONE aggregate per
+ * workgroup of the one-launch solve: graph aggregates of at most 16 (3-D) / 20 (2-D) poses while 256 of them cover the
+ * block, beyond that -- up to ~14 000 poses in 3-D -- of at most 64 / 84 poses with the growth's fragments merged,
+ * dpgo_problem_additive_plan): nothing inside it applies an operator to a distributed vector, so a whole preconditioned
+ * tCG iteration runs inside the persistent kernel (three in-kernel reductions).  Where the persistent kernel cannot run
+ * (larger blocks: DPGO_ERR_UNSUPPORTED; no free resident slots or a time-out: silently) the solve uses the multilevel
+ * V-cycle on the same hierarchy instead.  What DPGO_PRECOND_AUTO selects for such blocks when it selects a multilevel
+ * preconditioner. */
 #define DPGO_PRECOND_ADDITIVE 4
 
 /* tCG termination status; replaces ROPTLIB::tCGstatusSet in ROPTResult
@@ -204,10 +206,12 @@ int dpgo_problem_get_Q_values(dpgo_problem_t h, double* vals_host);
  *     prolongation composed along each aggregate's breadth-first tree (compact aggregates: 40-60 % of the
  *     Hessian-vector products of index runs of the same size; the default whenever one coarsening with S <= 512
  *     reaches a dense level of about 2 500 unknowns, i.e. up to 200 000 poses in 3-D; DPGO_ML_GRAPH=0 restores runs).
+ *     Two negative sizes {-S, -cap}: the same with the fragments of the growth merged up to cap poses
+ *     (dpgo_multilevel_merged_aggregates; what the additive preconditioner builds for blocks beyond ~3 500 poses).
  *     omega: smoother damping (0.7); shift: the reference's 0.1.  Explicit sizes stick to the handle until the next call.
  *   dpgo_problem_multilevel_info: *nlevels in = capacity of the arrays, out = number of levels (coarsenings + 1);
  *     sizes[l] = nodes, ks[l] = aggregate size towards level l+1 (0 on the last; negative: graph aggregates of at most
- *     that many nodes), nnzb[l] = blocks of A_l.
+ *     that many nodes -- with merged fragments the last level's entry holds -cap instead of 0), nnzb[l] = blocks of A_l.
  *   dpgo_problem_multilevel_get: copy one item of a built hierarchy to the host (tests / inspection). */
 #define DPGO_ML_P_BLOCKS 0      /* level < last: n_l blocks (d+1)x(d+1), row-major                  (double) */
 #define DPGO_ML_A_ROWPTR 1      /* level >= 1: n_l + 1                                              (int32)  */
@@ -223,6 +227,19 @@ int dpgo_multilevel_default_ks(int n, int d, int* ks, int* nks); /* *nks in: cap
  * for ks = {-max_size}; exposed so that the rule can be checked without a GPU. */
 int dpgo_multilevel_graph_aggregates(int n, const int32_t* rowptr, const int32_t* colidx, int max_size, int32_t* label,
                                      int32_t* parent, int* n_aggregates);
+/* The same followed by the merge of the growth's fragments (what ks = {-max_size, -merge_cap} builds): an aggregate of at
+ * most max_size / 2 nodes joins the neighbouring aggregate it shares the most blocks with among those with room (sizes
+ * add up to at most merge_cap; passes in index order until nothing changes); aggregates renumbered by smallest member,
+ * breadth-first trees rebuilt from it.  Used where an aggregate is a WORKGROUP (the additive preconditioner of the
+ * one-launch solve): every fragment would cost a whole workgroup of the at most 256. */
+int dpgo_multilevel_merged_aggregates(int n, const int32_t* rowptr, const int32_t* colidx, int max_size, int merge_cap,
+                                      int32_t* label, int32_t* parent, int* n_aggregates);
+/* Layout precond = DPGO_PRECOND_ADDITIVE uses for this handle's block pattern (host only, computed once per pattern):
+ * lane_groups = lane groups per pose of the one-launch kernel (4: tiles of 16 poses in 3-D / 20 in 2-D; 1: tiles of 64 / 84;
+ * 0: the block does not fit 256 aggregates), tile = slots per aggregate, growth / merge_cap = the graph aggregates' sizes
+ * (merge_cap 0: plain greedy growth; graph 0: index runs of `tile` poses, DPGO_ML_GRAPH=0), aggregates = workgroups. */
+int dpgo_problem_additive_plan(dpgo_problem_t h, int* lane_groups, int* tile, int* growth, int* merge_cap, int* aggregates,
+                               int* graph);
 int dpgo_problem_setup_multilevel(dpgo_problem_t h, int nks, const int* ks, double omega, double shift);
 int dpgo_problem_multilevel_info(dpgo_problem_t h, int* nlevels, int* sizes, int* ks, int* nnzb);
 int dpgo_problem_multilevel_get(dpgo_problem_t h, int level, int what, void* out_host);

@@ -428,6 +428,74 @@ def amg_graph_aggregates(Q: "BSR", S: int):
     return lab, np.asarray(ptr, dtype=np.int64), np.asarray(mem, dtype=np.int64), parent, pslot
 
 
+def amg_merge_small_aggregates(Q: "BSR", S: int, lab, ptr, mem, cap: Optional[int] = None):
+    """Mirrors ml_merge_small_aggregates: the greedy growth leaves fragments (pockets between full aggregates); where an
+    aggregate is a workgroup of the one-launch solve every fragment costs a whole workgroup.  Passes over the aggregates
+    in index order until nothing changes: an aggregate of at most S / 2 nodes joins the neighbouring aggregate (one it
+    shares a block of Q with) it has the most blocks in common with among those that still have room (sizes add up to at
+    most S; ties: the lower index).  Afterwards the aggregates are renumbered in the order of their smallest member and
+    every aggregate's breadth-first tree is rebuilt from that member (neighbours in block-row order).
+    Returns (lab, ptr, mem, parent, pslot) like amg_graph_aggregates."""
+    n = Q.n
+    cap = S if cap is None else cap
+    rowptr, colidx = np.asarray(Q.rowptr), np.asarray(Q.colidx)
+    lab = np.array(lab, dtype=np.int64)
+    na = len(ptr) - 1
+    members = [list(mem[ptr[a]:ptr[a + 1]]) for a in range(na)]
+    changed = True
+    while changed:
+        changed = False
+        for a in range(na):
+            if not members[a] or 2 * len(members[a]) > S:
+                continue
+            conn: Dict[int, int] = {}
+            for i in members[a]:
+                for t in range(rowptr[i], rowptr[i + 1]):
+                    c = int(lab[colidx[t]])
+                    if c != a:
+                        conn[c] = conn.get(c, 0) + 1
+            best, best_n = -1, 0
+            for c in sorted(conn):
+                if len(members[c]) + len(members[a]) <= cap and conn[c] > best_n:
+                    best, best_n = c, conn[c]
+            if best >= 0:
+                members[best].extend(members[a])
+                for i in members[a]:
+                    lab[i] = best
+                members[a] = []
+                changed = True
+    # renumber by smallest member, rebuild the breadth-first trees
+    alive = [a for a in range(na) if members[a]]
+    alive.sort(key=lambda a: min(members[a]))
+    new_lab = -np.ones(n, dtype=np.int64)
+    parent = -np.ones(n, dtype=np.int64)
+    pslot = np.zeros(n, dtype=np.int64)
+    out_mem: List[int] = []
+    out_ptr = [0]
+    for k, a in enumerate(alive):
+        # (a merged aggregate is connected by construction, so the search from its smallest member reaches everything;
+        # should Q's pattern not be symmetric, the members it misses become further roots in index order)
+        for root in sorted(members[a]):
+            if new_lab[root] >= 0:
+                continue
+            head = len(out_mem)
+            new_lab[root] = k
+            out_mem.append(root)
+            while head < len(out_mem):
+                u = out_mem[head]
+                head += 1
+                for t in range(rowptr[u], rowptr[u + 1]):
+                    v = colidx[t]
+                    if lab[v] != a or new_lab[v] >= 0:
+                        continue
+                    new_lab[v] = k
+                    parent[v] = u
+                    pslot[v] = t
+                    out_mem.append(v)
+        out_ptr.append(len(out_mem))
+    return new_lab, np.asarray(out_ptr, dtype=np.int64), np.asarray(out_mem, dtype=np.int64), parent, pslot
+
+
 def amg_tree_prolongation(Q: "BSR", d: int, mem, parent, pslot):
     """Mirrors k_ml_build_P_tree: Pb[i] = G(root of i's aggregate -> i)^T, composed along the aggregate's breadth-first
     tree.  The relative pose of a tree edge parent -> i is read off the block Q[parent, i]: a measurement parent -> i
@@ -551,8 +619,9 @@ class QuadraticProblem:
 
     def __init__(self, Q: BSR, G: Optional[np.ndarray], r: int, d: int, precond: str = "exact",
                  shift: float = 0.1, amg_k=None, amg_omega: float = 0.7, amg_gamma: int = 1, amg_nu: int = 1,
-                 amg_coarse_bits: int = 64):
+                 amg_coarse_bits: int = 64, amg_merge: int = 0):
         self.amg_k, self.amg_omega, self._amg = amg_k, amg_omega, None
+        self.amg_merge = amg_merge  # graph aggregates: > 0 = join the fragments of the greedy growth up to this many poses (amg_merge_small_aggregates)
         self.amg_coarse_bits = amg_coarse_bits  # storage precision of the dense level (device default: 64; 32 = opt-in)
         self.amg_gamma, self.amg_nu = amg_gamma, amg_nu  # coarse-level cycle index / smoothing sweeps (experiments)
         self.Q, self.r, self.d, self.n = Q, r, d, Q.n
@@ -635,9 +704,17 @@ class QuadraticProblem:
             elif isinstance(ks, (int, np.integer)):
                 ks = [int(ks)]
             ks = [int(k) for k in ks]
-            graph = len(ks) == 1 and ks[0] < 0  # two levels, graph aggregates of at most -ks[0] poses
+            # two levels, graph aggregates of at most -ks[0] poses; [-S, -cap]: fragments merged up to cap poses
+            merged = len(ks) == 2 and ks[0] < 0 and ks[1] < 0
+            merge_cap = -ks[1] if merged else int(self.amg_merge)
+            spec = list(ks) if merged or not merge_cap else [ks[0], -merge_cap]  # (the form the device reports)
+            if merged:
+                ks = ks[:1]
+            graph = len(ks) == 1 and ks[0] < 0
             if graph:
-                lab, _, mem, parent, pslot = amg_graph_aggregates(self.Q, -ks[0])
+                lab, ptr, mem, parent, pslot = amg_graph_aggregates(self.Q, -ks[0])
+                if merge_cap:
+                    lab, ptr, mem, parent, pslot = amg_merge_small_aggregates(self.Q, -ks[0], lab, ptr, mem, merge_cap)
                 Pbs = [amg_tree_prolongation(self.Q, self.d, mem, parent, pslot)]
             else:
                 Pbs = amg_chain_prolongations(self.Q, self.d, ks)
@@ -663,7 +740,7 @@ class QuadraticProblem:
             AcInv = np.linalg.inv(Ac)
             if self.amg_coarse_bits == 32:  # the device STORES the inverse in fp32 (products stay fp64)
                 AcInv = AcInv.astype(np.float32).astype(np.float64)
-            self._amg = dict(ks=ks, levels=levels, Ac=Ac, AcInv=AcInv, nc=cur)
+            self._amg = dict(ks=spec, levels=levels, Ac=Ac, AcInv=AcInv, nc=cur)
         return self._amg
 
     def amg_cycle(self, V):
@@ -1093,12 +1170,14 @@ def perturbed_truth(Ttrue, seed: int = 2, sigma_t: float = 0.1, sigma_r: float =
 
 
 def rbcd_coloured(meas: Measurements, n: int, num_robots: int, r: int, X0, sweeps: int,
-                  params: Optional[ROptParameters] = None, precond: str = "jacobi", hess_recurrence: bool = False):
+                  params: Optional[ROptParameters] = None, precond: str = "jacobi", hess_recurrence: bool = False,
+                  amg_k=None):
     """Two-colour (greedy-coloured) parallel RBCD of SURVEY 8e on the contiguous partition of
     examples/MultiRobotExample.cpp:71-119: in every sweep each colour class updates once; an agent's
     update is PGOAgent::updateX (src/PGOAgent.cpp:938-995): G from the neighbours' current public poses
     (constructG), then QuadraticOptimizer::optimize from its current block.  Agents of one colour are not
     adjacent, so updating them one after the other equals updating them simultaneously.
+    amg_k: hierarchy of the multilevel / additive preconditioners (None: the default; a dict agent -> sizes: per agent).
     Returns (X, [central 2f after each sweep], [central gradnorm after each sweep])."""
     d = meas.d
     ranges, per = partition_contiguous(meas, n, num_robots)
@@ -1114,7 +1193,8 @@ def rbcd_coloured(meas: Measurements, n: int, num_robots: int, r: int, X0, sweep
         # one problem object per agent for the whole run (Q and the preconditioner belong to the PoseGraph's lifetime,
         # include/DPGO/PoseGraph.h:324-331); only G changes between solves
         agents.append(dict(Q=Qa, shared=sh, need=sorted(need), adj=sorted({rob for rob, _ in need}),
-                           prob=QuadraticProblem(Qa, None, r, d, precond=precond)))
+                           prob=QuadraticProblem(Qa, None, r, d, precond=precond,
+                                                 amg_k=amg_k[a] if isinstance(amg_k, dict) else amg_k)))
     colour = [-1] * num_robots
     for a in range(num_robots):
         used = {colour[q] for q in agents[a]["adj"] if colour[q] >= 0}

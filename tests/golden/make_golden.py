@@ -54,6 +54,12 @@ out["smallGrid3D_rtr_trace_jacobi"] = dict(
     fOpt=opt.result.fOpt, gradNormOpt=opt.result.gradNormOpt,
     trace=[dict(inner=t["inner"], status=t["status"], accept=bool(t["accept"]), rho=t["rho"], f2=t["f2"],
                 Delta=t["Delta"]) for t in opt.result.trace])
+# BASELINE configs[2] in the REFERENCE configuration (exact (Q_a + 0.1 I)^-1 preconditioner, RTR 3 x <= 50): torus3D cut
+# into 8 agents, 120 two-colour sweeps from the chordal initialisation (SURVEY 8e's probe: 2f = 24227.072 after sweep 119)
+om, n = O.read_g2o(os.path.join(ROOT, "data", "torus3D.g2o"))
+_, costs, gns = O.rbcd_coloured(om, n, 8, 5, O.lift(O.chordal_initialization(om, n), 5), 120, precond="exact")
+out["torus3D_8_agents_120_sweeps_exact"] = dict(
+    cost_2f={str(k): costs[k] for k in (0, 9, 49, 99, 119)}, gradnorm_after=gns[119], optimum_2f=24227.0455583823)
 with open(os.path.join(HERE, "golden_scalars.json"), "w") as fh:
     json.dump(out, fh, indent=1)
 print("wrote golden vectors")

@@ -57,9 +57,20 @@ def test_bench_prints_one_valid_json_line():
     assert ml["kernel"].startswith("k_tcg_hess_span<3,5,4,0>") and ml["warm"]["frac"] > 0
     assert abs(ml["achieved"] - ml["bytes_per_launch"] / ml["avg_launch_us"] / 1e3) < 1e-9 * ml["achieved"]
     assert abs(ml["warm"]["achieved"] - ml["bytes_per_launch"] / ml["warm"]["avg_launch_us"] / 1e3) < 1e-9 * ml["achieved"]
-    assert abs(rf["bytes_per_launch"] - rf["products_per_launch"] * ml["bytes_per_launch"]) < 1e-6 * rf["bytes_per_launch"]
+    # (one-launch solve: frac = MODELLED HBM bytes of the launch over its time -- Q and the vectors live in registers / LDS --;
+    # the figure comparable with the multi-launch kernel is effective_algorithmic_*: products x the step's bytes)
+    assert abs(rf["effective_algorithmic_bytes"] - rf["products_per_launch"] * ml["bytes_per_launch"]) < 1e-6 * rf["bytes_per_launch"] * 1e3
+    assert abs(rf["effective_algorithmic_GBs"] - rf["effective_algorithmic_bytes"] / rf["avg_launch_us"] / 1e3) < 1e-9 * rf["effective_algorithmic_GBs"]
+    assert rf["bytes_per_launch"] < ml["bytes_per_launch"] and rf["traffic"] is None
+    # the TIMED kernel's own bytes are always printed, whichever storage it reads
+    assert rf["stored_bytes_per_launch"] > 0 and rf["frac_own_bytes"] > 0 and "storage" in rf
+    assert abs(rf["frac_own_bytes"] - rf["stored_bytes_per_launch"] / rf["avg_launch_us"] / 1e3 / 8000.0) < 1e-9
     assert rf["symmetric_storage"] is None  # (this small block cannot run the symmetric kernels: 4 lane groups per pose)
     assert j["products_per_step"] > 0 and j["time_to_tolerance_ms"] > 0 and j["products_to_tolerance"] > 0
+    # ... and repeated inside `config`, which the driver's parsed record keeps
+    assert j["config"]["time_to_tolerance_ms"] == j["time_to_tolerance_ms"]
+    assert "time_to_tolerance_ms = %.3f" % j["time_to_tolerance_ms"] in j["config"]["local_solver"]
+    assert j["config"]["products_per_step"] == j["products_per_step"]
     assert [k["kernel"].split()[0].rstrip(",") for k in rf["kernels"]] == ["k_tcg_update", "k_ml_restrict",
                                                                            "k_ml_coarse_prolong", "k_ml_post"]
     assert all(k["avg_launch_us"] > 0 for k in rf["kernels"])
@@ -69,6 +80,10 @@ def test_bench_prints_one_valid_json_line():
     same = cb["gpu_same_work"]  # the like-for-like pair: same 8 blocks, same iterate, same one sweep, on the GPU
     assert same["agents"] == 8 and same["value"] > 0 and same["gradnorm_after"] > 0 and cb["gradnorm_after"] > 0
     assert abs(cb["gpu_over_cpu_same_work"] - same["value"] / cb["value"]) < 1e-9 * cb["gpu_over_cpu_same_work"]
+    assert len(same["tcg_iterations_per_agent"]) == 8 and len(cb["tcg_iterations_per_agent"]) == 8
+    st = cb["settled_iterate"]  # the same pair from the settled iterate every timed step restores
+    assert st["value"] > 0 and "SETTLED" in st["sample"] and st["gpu_same_work"]["agents"] == 8
+    assert len(st["tcg_iterations_per_agent"]) == 8 and len(st["gpu_same_work"]["tcg_iterations_per_agent"]) == 8
     port = cb["single_agent_port"]
     assert port["cores"] == 1 and port["value"] > 0 and port["rel_diff_fOpt_vs_device"] < 1e-6
     tt = j["quality"]["to_tolerance"]
@@ -90,4 +105,39 @@ def test_bench_loopback_runs_the_multi_agent_path_through_rccl():
     j = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][0])
     assert j["config"]["agents"] == 4 and "RCCL" in j["config"]["schedule"] and "loop-back" in j["config"]["schedule"]
     assert j["quality"]["exchange_ms_per_step_rank0"] > 0 and j["value"] > 0
+    assert j["quality"]["cost_2f_after_step"] < j["quality"]["cost_2f_trajectory"][0]
+
+
+def test_bench_default_steps_time_more_than_a_second():
+    """The default --steps keeps the timed region above one second at the headline workload's ~5 ms per step (the
+    driver's utilisation sampling needs that long to see the run)."""
+    sys.path.insert(0, ROOT)
+    import bench
+    old = sys.argv
+    try:
+        sys.argv = ["bench.py"]
+        a = bench.parse_args()
+    finally:
+        sys.argv = old
+    assert a.steps >= 200 and a.gpus == 1 and a.warmup >= 1
+
+
+@pytest.mark.gpu
+def test_bench_multi_gpu_branch_runs_at_world_size_one():
+    """The N > 1 branch of bench.py executed on ONE device exactly as the driver launches it for N > 1 (python -m
+    torch.distributed.run ... bench.py --gpus 1), with --dist: init_process_group("nccl") = RCCL, the library's communicator
+    taken from the process group (DeviceComm.from_torch_distributed), dist.barrier around the timed region, the
+    all-reduces of work and time, 2 agents per GPU, every exchange a grouped RCCL self send / recv timed by device events."""
+    port = 29500 + (os.getpid() % 400)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--dist", "--workload",
+           "grid:12x10x8", "--steps", "3", "--warmup", "1", "--settle", "1", "--no-cpu-baseline", "--no-secondary",
+           "--spmm-reps", "10"]
+    p = subprocess.run(cmd, capture_output=True, text=True, cwd=ROOT, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    j = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][0])
+    assert j["config"]["dist_backend"] == "nccl" and j["n_gpus"] == 1 and j["config"]["agents"] == 2
+    assert j["config"]["agents_per_gpu"] == 2 and "RCCL" in j["config"]["schedule"]
+    assert "torch.distributed process group" in j["config"]["schedule"]
+    assert j["quality"]["exchange_ms_per_step_rank0"] > 0 and j["value"] > 0 and j["steps"] == 3
     assert j["quality"]["cost_2f_after_step"] < j["quality"]["cost_2f_trajectory"][0]

@@ -215,6 +215,22 @@ def test_multilevel_hierarchy_rules(name, ks):
         L.check(lib.dpgo_multilevel_graph_aggregates(n, L.ptr(L.i32(Qf.rowptr)), L.ptr(L.i32(Qf.colidx)), S, L.ptr(lab_c),
                                                      L.ptr(par_c), C.byref(na)))
         assert na.value == len(ptr_o) - 1 and np.array_equal(lab_c, lab_o) and np.array_equal(par_c, par_o)
+    # ... and so is the merge of the growth's fragments (ks = [-S, -cap]: the additive preconditioner's aggregates beyond
+    # ~3 500 poses, where an aggregate is a workgroup): same labels and trees, no aggregate beyond the bound, every
+    # aggregate connected through its tree (one root), fewer aggregates than the plain growth leaves
+    for S, cap in ((4, 6), (16, 24), (28, 42)):
+        lab_g, ptr_g, mem_g, _, _ = O.amg_graph_aggregates(Qf, S)
+        lab_o, ptr_o, mem_o, par_o, _ = O.amg_merge_small_aggregates(Qf, S, lab_g, ptr_g, mem_g, cap)
+        lab_c, par_c, na = np.zeros(n, dtype=np.int32), np.zeros(n, dtype=np.int32), C.c_int(0)
+        L.check(lib.dpgo_multilevel_merged_aggregates(n, L.ptr(L.i32(Qf.rowptr)), L.ptr(L.i32(Qf.colidx)), S, cap,
+                                                      L.ptr(lab_c), L.ptr(par_c), C.byref(na)))
+        assert na.value == len(ptr_o) - 1 and np.array_equal(lab_c, lab_o) and np.array_equal(par_c, par_o), (S, cap)
+        sizes = np.diff(ptr_o)
+        assert sizes.max() <= cap and sizes.min() >= 1 and sorted(mem_o.tolist()) == list(range(n))
+        assert len(sizes) <= len(ptr_g) - 1
+        roots = np.bincount(lab_o[par_o < 0], minlength=len(sizes))
+        assert np.all(roots == 1), "a merged aggregate is connected: one tree"
+        assert np.all(lab_o[par_o[par_o >= 0]] == lab_o[par_o >= 0])
     if len(ks) == 1 and ks[0] < 0:
         # graph aggregates (the default two-level hierarchy): the prolongation composed along each aggregate's
         # breadth-first tree (k_ml_build_P_tree) reproduces the rigid-body modes -- on the odometry chain, and on a spanning

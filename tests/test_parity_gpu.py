@@ -200,9 +200,13 @@ def test_optimize_matches_oracle_at_matched_settings(oracle, name, r, precond):
     assert relerr(Xg, Xr) < 1e-5
 
 
-@pytest.mark.parametrize("precond", ["multilevel", "jacobi"])
-@pytest.mark.parametrize("name,ref2f", [("smallGrid3D", 1025.3980556263), ("sphere2500", 1687.0058142808),
-                                        ("torus3D", 24227.0455583823)])
+@pytest.mark.parametrize("name,ref2f,precond", [
+    ("smallGrid3D", 1025.3980556263, "multilevel"), ("sphere2500", 1687.0058142808, "multilevel"),
+    ("torus3D", 24227.0455583823, "multilevel"), ("smallGrid3D", 1025.3980556263, "jacobi"),
+    ("sphere2500", 1687.0058142808, "jacobi"), ("torus3D", 24227.0455583823, "jacobi"),
+    # kitti_00 (2-D, a 4 541-pose chain with 136 loop closures; BASELINE.md section 2: 2 f* = 125.6807087875): with the
+    # multilevel cycle and with the default selection (block-Jacobi needs tens of thousands of products on a chain)
+    ("kitti_00", 125.6807087875, "multilevel"), ("kitti_00", 125.6807087875, "auto")])
 def test_final_cost_matches_reference_configuration(oracle, name, ref2f, precond):
     """north_star: final cost matches the reference CPU solver's on the same .g2o to 1e-6 relative.
     Both sides run RTR to a tight gradient norm from the chordal initialisation; the oracle uses the
@@ -222,6 +226,39 @@ def test_final_cost_matches_reference_configuration(oracle, name, ref2f, precond
     assert abs(fg - fo) <= 1e-6 * abs(fo)
     assert abs(2 * fg - ref2f) <= 1e-6 * ref2f  # literature optimum
     assert gopt.getOptResult().gradNormOpt < 1e-3
+
+
+def test_final_cost_of_the_multi_agent_configuration_matches_reference(oracle):
+    """BASELINE configs[2] as north_star states it: torus3D cut into 8 agents, final cost against the reference
+    configuration to 1e-6 relative.  Reference side: the oracle's coloured RBCD with the EXACT (Q_a + 0.1 I)^-1
+    preconditioner, 120 two-colour sweeps from the chordal initialisation -- generated once by tests/golden/make_golden.py
+    and committed as scalars (2f = 24227.0719 after sweep 119; SURVEY 8e's probe: 24227.072, 1.1e-6 above the optimum
+    24227.0456).  Device side: the same 8 blocks and 120 sweeps with the library's DEFAULT preconditioner selection."""
+    import json
+    import dpgo_amd
+    from dpgo_amd.agent import DeviceAgent, ExchangePlan, RBCDCluster, build_pose_graphs
+    gold = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "golden_scalars.json")))
+    ref = gold["torus3D_8_agents_120_sweeps_exact"]
+    assert abs(ref["cost_2f"]["119"] - 24227.072) < 1e-3  # the figure BASELINE.md / SURVEY 8e quote
+    r, robots = 5, 8
+    om, n = oracle.read_g2o(os.path.join(DATA, "torus3D.g2o"))
+    X0 = oracle.lift(oracle.chordal_initialization(om, n), r)
+    ranges, graphs = build_pose_graphs(to_product_measurements(om), n, robots, r)
+    plan = ExchangePlan(graphs)
+    agents = {a: DeviceAgent(graphs, plan, a, X0[ranges[a][0]:ranges[a][1]], dpgo_amd.ROptParameters()) for a in range(robots)}
+    cluster = RBCDCluster(plan, agents)
+    used = set()
+    for k in range(120):
+        cluster.sweep()
+        used |= {ag.last_result.precond_used for ag in agents.values()}
+        if str(k) in ref["cost_2f"]:
+            f, g = cluster.central_cost_and_gradnorm()
+            # early sweeps: the two preconditioners take different local steps (1e-5 apart); the north_star bound applies
+            # to the final cost
+            assert abs(2 * f - ref["cost_2f"][str(k)]) <= (1e-6 if k == 119 else 1e-5) * ref["cost_2f"][str(k)], (k, 2 * f)
+    assert abs(g - ref["gradnorm_after"]) <= 0.05 * ref["gradnorm_after"]
+    assert abs(2 * f - ref["optimum_2f"]) <= 2e-6 * ref["optimum_2f"] and 2 * f > ref["optimum_2f"]
+    assert used <= {"jacobi", "additive", "multilevel"} and "jacobi" in used
 
 
 def test_feed_modes_and_single_iteration_radius_shrink(oracle):
@@ -528,12 +565,17 @@ def test_symmetric_storage_needs_big_blocks(oracle):
 @pytest.mark.parametrize("name,robots,sweeps,precond", [("smallGrid3D", 5, 4, "jacobi"), ("torus3D", 8, 10, "jacobi"),
                                                         ("smallGrid3D", 5, 4, "multilevel"),
                                                         ("torus3D", 8, 10, "multilevel"),
-                                                        ("grid:50x50x40", 8, 2, "multilevel")])
+                                                        ("grid:50x50x40", 8, 2, "multilevel"),
+                                                        ("torus3D", 8, 10, "additive"),
+                                                        ("grid:50x50x40", 8, 2, "additive")])
 def test_multi_agent_rbcd_on_one_gpu_matches_oracle(oracle, name, robots, sweeps, precond):
     """BASELINE configs[0] / configs[2] / configs[3] shape: N agents (one PGOAgent each in the reference's
     MultiRobotExample), here N DeviceAgents on one GPU exchanging public poses by device copies;
     coloured RBCD sweeps vs the oracle driver at matched settings (same preconditioner, same recurrence):
-    smallGrid3D / 5, torus3D / 8 for ten sweeps, and the 100k-pose grid cut into 8 slabs of 12 500 poses."""
+    smallGrid3D / 5, torus3D / 8 for ten sweeps, and the 100k-pose grid cut into 8 slabs of 12 500 poses.
+    "additive": the coupled blocks (G from the neighbours) solved by the one-launch kernel with the additive two-level
+    preconditioner -- torus3D's 625-pose blocks on 16-pose aggregates, the 12 500-pose slabs on merged graph aggregates of
+    at most 64 poses (one workgroup each; the oracle builds every agent's hierarchy from that agent's additivePlan)."""
     import dpgo_amd
     from dpgo_amd.agent import DeviceAgent, ExchangePlan, RBCDCluster, build_pose_graphs
     r = 5
@@ -544,12 +586,18 @@ def test_multi_agent_rbcd_on_one_gpu_matches_oracle(oracle, name, robots, sweeps
         om, n = oracle.read_g2o(os.path.join(DATA, name + ".g2o"))
         X0 = oracle.lift(oracle.chordal_initialization(om, n), r)
     d = om.d
-    Xref, costs, gns = oracle.rbcd_coloured(om, n, robots, r, X0, sweeps, hess_recurrence=device_tcg_mode(n // robots, d, r),
-                                            precond="amg" if precond == "multilevel" else precond)
     ranges, graphs = build_pose_graphs(to_product_measurements(om), n, robots, r)
     plan = ExchangePlan(graphs)
     agents = {a: DeviceAgent(graphs, plan, a, X0[ranges[a][0]:ranges[a][1]], dpgo_amd.ROptParameters(precond=precond))
               for a in range(robots)}
+    amg_k = None
+    if precond == "additive":
+        plans = {a: agents[a].problem.additivePlan() for a in range(robots)}
+        assert all(pl["lane_groups"] == (4 if name == "torus3D" else 1) and pl["graph"] for pl in plans.values()), plans
+        amg_k = {a: plans[a]["ks"] for a in range(robots)}
+    Xref, costs, gns = oracle.rbcd_coloured(om, n, robots, r, X0, sweeps, hess_recurrence=device_tcg_mode(n // robots, d, r),
+                                            precond={"multilevel": "amg", "additive": "amg_additive"}.get(precond, precond),
+                                            amg_k=amg_k)
     cluster = RBCDCluster(plan, agents)
     central = oracle.QuadraticProblem(oracle.construct_Q(n, d, om), None, r, d)
     f0, g0 = cluster.central_cost_and_gradnorm()
@@ -563,6 +611,11 @@ def test_multi_agent_rbcd_on_one_gpu_matches_oracle(oracle, name, robots, sweeps
     X = np.concatenate([agents[a].X.cpu().numpy() for a in range(robots)], axis=0)
     assert relerr(X, Xref) < 1e-7
     assert costs[-1] < costs[0]
+    if precond == "additive":  # every block's last solve ran inside the one-launch kernel on its plan's workgroups
+        for a in range(robots):
+            res, info = agents[a].optimizer.getOptResult(), agents[a].problem.persistentInfo()
+            assert res.precond_used == "additive" and info["last_members"] == plans[a]["aggregates"], (a, res, info)
+            assert agents[a].problem.multilevelInfo()["ks"] == plans[a]["ks"]
 
 
 @pytest.mark.parametrize("storage", [pytest.param("plain", id="plain"),
@@ -713,26 +766,50 @@ def _persistent_case(oracle, name, r, precond, layout):
 
 
 @pytest.mark.parametrize("name,r", [("smallGrid3D", 5), ("sphere2500", 5), ("kitti_00", 5), ("tinyGrid3D", 5),
-                                    ("sphere2500", 3), ("kitti_00", 3), ("smallGrid3D", 6)])
+                                    ("sphere2500", 3), ("kitti_00", 3), ("smallGrid3D", 6), ("torus3D", 5),
+                                    ("grid:25x25x10", 5), ("grid:50x50x5", 5), ("grid:25x25x10", 3)])
 def test_additive_preconditioner_matches_oracle(oracle, name, r):
-    """precond = "additive": z = proj_X(Dinv r + P A_c^-1 P^T r) on the two-level hierarchy with aggregates of at most 16
-    (3-D) / 20 (2-D) poses -- one per workgroup of the persistent kernel, which owns the aggregate's poses wherever their
-    indices are --, a whole preconditioned tCG iteration inside the persistent kernel (three in-kernel
-    reductions; the restricted residual is the only extra exchange).  Against the oracle's restatement of the operator
-    (precond = "amg_additive", same aggregates) at matched settings: same RTR / tCG iteration counts and status, iterate
-    to 1e-7, cost to 1e-9, over three calls; the kernel must really have run; the hierarchy is the oracle's."""
+    """precond = "additive": z = proj_X(Dinv r + P A_c^-1 P^T r) on a two-level hierarchy with ONE aggregate per workgroup
+    of the persistent kernel, which owns the aggregate's poses wherever their indices are -- graph aggregates of at most 16
+    (3-D) / 20 (2-D) poses while 256 of them cover the block, beyond that (torus3D's 5 000 poses, the 6 250-pose grid
+    block and the 12 500-pose slab of the 16- / 8-agent cuts of BASELINE configs[3]) aggregates of at most 64 poses whose
+    fragments were merged (additivePlan) --, a whole preconditioned tCG iteration inside the persistent kernel (three
+    in-kernel reductions; the restricted residual is the only extra exchange).  Against the oracle's restatement of the
+    operator (precond = "amg_additive", same aggregates) at matched settings: same RTR / tCG iteration counts and status,
+    iterate to 1e-7, cost to 1e-9, over three calls; the kernel must really have run; the hierarchy is the oracle's."""
     import dpgo_amd
-    om, n, d, Q, pg, prob = build_single_agent(oracle, name, r)
+    if name.startswith("grid:"):
+        om, n, Ttrue = oracle.synthetic_grid(*[int(v) for v in name[5:].split("x")], seed=0)
+        d = om.d
+        Q = oracle.construct_Q(n, d, om)
+        pg = dpgo_amd.PoseGraph(0, r, d)
+        pg.setMeasurements(to_product_measurements(om))
+        prob = dpgo_amd.QuadraticProblem(pg)
+        X0 = oracle.lift(oracle.perturbed_truth(Ttrue, seed=2), r)
+    else:
+        om, n, d, Q, pg, prob = build_single_agent(oracle, name, r)
+        X0 = oracle.lift(oracle.chordal_initialization(om, n), r)
+    plan = prob.additivePlan()
     k = 16 if d == 3 else 20
-    # graph aggregates of at most one tile while they fit the kernel's 256 workgroups (the greedy growth leaves fragments),
-    # else index runs: sphere2500 160 graph aggregates (157 runs), kitti_00 246 (228 runs)
-    na = len(oracle.amg_graph_aggregates(Q, k)[1]) - 1
-    ks = [-k] if na <= 256 else [k]
-    if ks[0] > 0:
-        na = -(-n // k)
-    assert ks[0] < 0
-    X0 = oracle.lift(oracle.chordal_initialization(om, n), r)
+    # sphere2500 160 aggregates, kitti_00 246: plain growth, four lane groups per pose; torus3D's 5 000 poses and the grid
+    # blocks: one pose per (d+1) lanes, merged fragments
+    assert plan["lane_groups"] == (1 if name == "torus3D" or name.startswith("grid:") else 4), plan
+    if plan["lane_groups"] == 4:
+        assert (plan["ks"], plan["tile"]) == ([-k], k), plan
+    else:
+        assert plan["tile"] == 4 * k and plan["graph"] and len(plan["ks"]) == 2, plan
+        assert -plan["ks"][1] == min(plan["tile"], plan["growth"] + plan["growth"] // 2)
+    ks = plan["ks"]
     op = oracle.QuadraticProblem(Q, None, r, d, precond="amg_additive", amg_k=ks)
+    na = op.amg_setup()["nc"]
+    assert na == plan["aggregates"] <= 256
+    if len(ks) == 2:  # the smallest growth size that fits: the one before leaves more than 256 aggregates
+        S = plan["growth"]
+        prev = [s_ for s_ in _additive_growth_sizes(n, plan["tile"]) if s_ < S]
+        if prev:
+            lab, ptr, mem, _, _ = oracle.amg_graph_aggregates(Q, prev[-1])
+            cap = min(plan["tile"], prev[-1] + prev[-1] // 2)
+            assert len(oracle.amg_merge_small_aggregates(Q, prev[-1], lab, ptr, mem, cap)[1]) - 1 > 256
     oo = oracle.QuadraticOptimizer(op, oracle.ROptParameters(), hess_recurrence=True)
     go = dpgo_amd.QuadraticOptimizer(prob, dpgo_amd.ROptParameters(precond="additive"))
     Xo, Xg = X0, X0
@@ -743,7 +820,7 @@ def test_additive_preconditioner_matches_oracle(oracle, name, r):
         info = prob.persistentInfo()
         assert rg.precond_used == "additive"
         if rg.gradNormInit >= 1e-2:  # (an iterate that already meets the tolerance leaves before any tCG launch)
-            assert info["last_members"] == na and info["last_split"] == 4, (rg, info)
+            assert info["last_members"] == na and info["last_split"] == plan["lane_groups"], (rg, info)
         assert (rg.tcg_iterations, rg.rtr_iterations, rg.tCGStatus) == (oo.result.tcg_iters, oo.result.outer_iters,
                                                                          oracle.TCG_NAMES[oo.result.tCGStatus]), call
         assert relerr(Xg, Xo) < 1e-7
@@ -754,11 +831,20 @@ def test_additive_preconditioner_matches_oracle(oracle, name, r):
     _hierarchy_check(oracle, prob, op)
 
 
+def _additive_growth_sizes(n, tile):
+    """Growth sizes additive_plan (dpgo_hip.hip) tries for a block beyond 256 aggregates of 16 poses, in order."""
+    out, S = [], max(8, (n + 229) // 230)
+    while S <= tile:
+        out.append(S)
+        S += max(2, S // 8)
+    return out
+
+
 def test_additive_preconditioner_selection_and_fallbacks(oracle):
     """auto on a small uncoupled block resolves its multilevel choice to the additive form (sphere2500: precond_used
-    "additive"); a block beyond 256 aggregates refuses "additive" explicitly and auto keeps the V-cycle there (torus3D:
-    5 000 poses = 313 aggregates); with the persistent kernel switched off "additive" runs the V-cycle on the same
-    hierarchy and still converges to the same optimum."""
+    "additive"; torus3D's 5 000 poses: the 64-pose-tile layout); a block beyond 256 aggregates of one workgroup tile
+    refuses "additive" explicitly and auto keeps the V-cycle there (an 18 000-pose grid); with the persistent kernel
+    switched off "additive" runs the V-cycle on the same hierarchy and still converges to the same optimum."""
     import dpgo_amd
     from dpgo_amd.lib import DpgoError
     om, n, d, Q, pg, prob = build_single_agent(oracle, "sphere2500", 5)
@@ -780,13 +866,22 @@ def test_additive_preconditioner_selection_and_fallbacks(oracle):
         if go2.getOptResult().gradNormOpt < 1e-2:
             break
     assert prob.persistentInfo()["last_members"] == 0 and abs(go2.getOptResult().fOpt - f_add) <= 1e-7 * abs(f_add)
-    big = build_single_agent(oracle, "torus3D", 5)[-1]
+    mid = build_single_agent(oracle, "torus3D", 5)[-1]
     omt, nt = oracle.read_g2o(os.path.join(DATA, "torus3D.g2o"))
     Xt = tiles_to_matrix(oracle.lift(oracle.chordal_initialization(omt, nt), 5))
+    gm = dpgo_amd.QuadraticOptimizer(mid, dpgo_amd.ROptParameters())
+    gm.optimize(Xt)
+    assert gm.getOptResult().precond_used == "additive" and mid.persistentInfo()["last_split"] == 1
+    omb, nb, Tb = oracle.synthetic_grid(30, 30, 20, seed=0)
+    pgb = dpgo_amd.PoseGraph(0, 5, 3)
+    pgb.setMeasurements(to_product_measurements(omb))
+    big = dpgo_amd.QuadraticProblem(pgb)
+    assert big.additivePlan()["lane_groups"] == 0
+    Xb = tiles_to_matrix(oracle.lift(oracle.perturbed_truth(Tb, seed=2), 5))
     with pytest.raises(DpgoError):
-        dpgo_amd.QuadraticOptimizer(big, dpgo_amd.ROptParameters(precond="additive")).optimize(Xt)
+        dpgo_amd.QuadraticOptimizer(big, dpgo_amd.ROptParameters(precond="additive")).optimize(Xb)
     ga = dpgo_amd.QuadraticOptimizer(big, dpgo_amd.ROptParameters())
-    ga.optimize(Xt)
+    ga.optimize(Xb)
     assert ga.getOptResult().precond_used == "multilevel"
 
 
@@ -1015,6 +1110,25 @@ def test_greedy_accelerated_schedule_matches_oracle(oracle):
     X = np.concatenate([agents[a].X.cpu().numpy() for a in range(robots)], axis=0)
     assert relerr(X, want["X"]) < 1e-7
     assert abs(got["cost"] - ref["cost"]) <= 1e-6 * ref["cost"]  # same optimum as the reference configuration
+    # Two more runs on the SAME agents and ONE cluster: enable_acceleration() re-allocates Y and the auxiliary neighbour /
+    # send buffers and the iterate is re-bound -- the cluster's cached exchange plans hold raw device addresses of the old
+    # tensors and must be rebuilt (in between the allocator is pushed to hand the freed blocks to other data).
+    import torch
+    cluster = RBCDCluster(plan, agents)
+    runs, gens, junk = [], [], []
+    for rep in range(2):
+        for a, ag in agents.items():
+            ag.X = torch.tensor(np.ascontiguousarray(X0[ranges[a][0]:ranges[a][1]]), dtype=torch.float64, device="cuda")
+            ag.iteration, ag.tcg_total = 0, 0
+            ag.enable_acceleration(robots)
+        junk.append([torch.full((3000,), float("nan"), dtype=torch.float64, device="cuda") for _ in range(64)])
+        runs.append(cluster.run_greedy(max_iters=12))
+        assert cluster._xplans, "the batched exchange ran"
+        gens.append(cluster._xplans_gen)
+    assert gens[0] != gens[1]
+    for run in runs:
+        assert run["selected"] == want["selected"][:len(run["selected"])] and len(run["selected"]) >= 12
+    assert abs(runs[0]["cost"] - runs[1]["cost"]) <= 1e-12 * abs(runs[0]["cost"])
 
 
 def test_robust_pgo_known_answer_on_device(oracle):
