@@ -349,7 +349,7 @@ def time_to_tolerance(workload, r, precond, tol=1e-2, max_calls=12, coarse_bits=
     if precond == "multilevel":
         ag.problem.setupMultilevel()  # the hierarchy is a one-time cost per Q (the reference factors inside its first solve)
     ag.problem.autoState("reset")     # "auto" starts where a fresh handle starts
-    ag.X.copy_(torch.tensor(X0, device=ag.X.device))
+    ag.set_iterate(X0)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     products, calls, gn, used = 0, 0, None, []
@@ -730,7 +730,7 @@ def main():
     jac_step = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         agent.restore()
-        X_state = agent.X.cpu().numpy()
+        X_state = agent.iterate_in_caller_order().cpu().numpy()
         try:  # the device's block-Jacobi step from the same iterate: what the 1-core port below restates
             Xj = agent.X.clone()
             rj = dpgo_amd.QuadraticOptimizer(agent.problem, dpgo_amd.ROptParameters(precond="jacobi")).optimizeDevice(Xj)
@@ -752,7 +752,7 @@ def main():
             # the same pair from the SETTLED iterate the headline step starts from, cut into the same 8 blocks: there the tCG
             # budget (not the trust-region boundary after a step or two) ends the local solves -- the hot loop proper
             try:
-                X_set = np.ascontiguousarray(np.concatenate([agents[a]._snap.cpu().numpy() for a in sorted(agents)], axis=0))
+                X_set = np.ascontiguousarray(np.concatenate([agents[a].in_caller_order(agents[a]._snap).cpu().numpy() for a in sorted(agents)], axis=0))
                 settled_cpu = cpu_baseline_reference(meas, n, X_set, r)
                 settled_cpu["sample"] = "as cpu_baseline.sample, from the benchmark's SETTLED iterate (the state every " \
                                         "timed step restores): " + settled_cpu["sample"]
@@ -853,7 +853,10 @@ def main():
                            else ("device copies" if world == 1 else
                                  ("torch.distributed nccl p2p" if not cluster.stage else "gloo (host-staged)"))),
                        "dist_backend": backend,
-                       "poses_per_agent": n_local, "nnzb_per_agent": nnzb_local},
+                       "poses_per_agent": n_local, "nnzb_per_agent": nnzb_local,
+                       "pose_order": ("renumbered inside the agent for locality (reverse Cuthill-McKee inside each XCD's "
+                                      "eighth, dpgo_locality_order); X0 in, iterates and trajectories out in the data "
+                                      "set's own numbering") if agent.pose_order is not None else "as given"},
             "roofline": roofline,
             "cpu_baseline": cpu,
             "also": also,

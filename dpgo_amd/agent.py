@@ -85,13 +85,32 @@ def should_update_measurement_weights(prm: PGOAgentParameters, weight_update_cou
     return True
 
 
-def build_pose_graphs(dataset: RelativeSEMeasurements, num_poses: int, num_robots: int, r: int):
-    """Partition like examples/MultiRobotExample.cpp:71-146 and build one PoseGraph per robot."""
+def build_pose_graphs(dataset: RelativeSEMeasurements, num_poses: int, num_robots: int, r: int, reorder=False):
+    """Partition like examples/MultiRobotExample.cpp:71-146 and build one PoseGraph per robot.
+
+    reorder (False; True, or the environment's DPGO_REORDER=1 with the default): the agent layer renumbers the poses
+    INSIDE every robot's block for locality (measurements.locality_order) before the graphs are built -- every id that
+    crosses the agent's boundary keeps the caller's numbering: DeviceAgent takes X0 and returns iterates / trajectories in
+    the caller's order (pose_order of the graph = internal row of every caller frame), the exchange plan is built from
+    the renumbered graphs on every agent alike, so public poses meet their users whatever they are called inside.
+    OFF by default: measured on the 100k-pose lattice (round 4, tools/reorder_ab.sh, rotating operands) the odometry
+    ("snake") order is already the best of those tried -- k_tcg_hess_sym 41.9 us as given, 45.8 / 44.7 / 42.8 us with
+    reverse Cuthill-McKee over runs of 16 / 64 / 250 consecutive poses inside each XCD's eighth, 45.2 us pose by pose
+    (DESIGN.md section 3)."""
+    order = None
+    import os
+    if reorder is False and os.environ.get("DPGO_REORDER") == "1":  # A/B switch for the benchmarks
+        reorder = True
+    if reorder is True:
+        from .measurements import locality_order, relabel
+        order = locality_order(dataset, num_poses, num_robots)
+        dataset = relabel(dataset, order)
     ranges, per_robot = partition_contiguous(dataset, num_poses, num_robots)
     graphs = []
     for a in range(num_robots):
         pg = PoseGraph(a, r, dataset.d)
         pg.setMeasurements(per_robot[a])
+        pg.pose_order = None if order is None else (order[ranges[a][0]:ranges[a][1]] - ranges[a][0]).astype(np.int64)
         graphs.append(pg)
     return ranges, graphs
 
@@ -211,6 +230,12 @@ class DeviceAgent(AgentStatusMixin):
         torch.cuda.set_device(self.device)
         if X0_tiles.shape != (self.n, self.b, self.r):
             raise ValueError("X0 tiles have shape %s, expected %s" % (X0_tiles.shape, (self.n, self.b, self.r)))
+        # internal row of every caller frame (build_pose_graphs(reorder=...)); None: the caller's order is kept
+        self.pose_order = getattr(self.pg, "pose_order", None)
+        if self.pose_order is not None:
+            Xi = np.empty_like(np.ascontiguousarray(X0_tiles))
+            Xi[self.pose_order] = X0_tiles
+            X0_tiles = Xi
         self.problem = QuadraticProblem(self.pg, device=device, host_linear_term=False)
         self.problem.setStream(torch.cuda.current_stream().cuda_stream)
         self.optimizer = QuadraticOptimizer(self.problem, params or ROptParameters())
@@ -314,12 +339,37 @@ class DeviceAgent(AgentStatusMixin):
     def getTrajectoryInLocalFrame(self):
         """Rounded tiles [n, d+1, d] on the device, in the frame of this agent's pose 0."""
         from .trajectory import round_trajectory_device
-        return round_trajectory_device(self.X, None)
+        anchor = None
+        if self.pose_order is not None:  # "this agent's pose 0" is the CALLER's frame 0, wherever it is kept inside
+            anchor = np.ascontiguousarray(self.X[int(self.pose_order[0])].cpu().numpy().T)
+        return self.in_caller_order(round_trajectory_device(self.X, anchor))
 
     def getTrajectoryInGlobalFrame(self, anchor):
         """anchor: r x (d+1) lifted pose (PGOAgent::setGlobalAnchor); rounded tiles [n, d+1, d] on the device."""
         from .trajectory import round_trajectory_device
-        return round_trajectory_device(self.X, anchor)
+        return self.in_caller_order(round_trajectory_device(self.X, anchor))
+
+    def in_caller_order(self, tiles):
+        """Pose tiles [n, ...] held in the agent's internal row order -> the caller's frame order (identity unless the
+        agent layer renumbered the block, build_pose_graphs(reorder=...)); torch tensor or array."""
+        if self.pose_order is None:
+            return tiles
+        if isinstance(tiles, np.ndarray):
+            return tiles[self.pose_order]
+        return tiles[self.torch.as_tensor(self.pose_order, device=tiles.device)]
+
+    def set_iterate(self, X_tiles) -> None:
+        """Overwrite the iterate with tiles [n, d+1, r] given in the CALLER's frame order (host array or tensor)."""
+        t = self.torch.as_tensor(np.ascontiguousarray(X_tiles) if isinstance(X_tiles, np.ndarray) else X_tiles,
+                                 dtype=self.torch.float64, device=self.device)
+        if self.pose_order is None:
+            self.X.copy_(t)
+        else:
+            self.X[self.torch.as_tensor(self.pose_order, device=self.device)] = t
+
+    def iterate_in_caller_order(self):
+        """The current iterate X as tiles [n, d+1, r] in the caller's frame order (device tensor)."""
+        return self.in_caller_order(self.X)
 
     def snapshot(self) -> None:
         """Remember the current iterate (benchmarks restore it so that every timed step does the same work)."""
@@ -660,7 +710,8 @@ class RBCDCluster:
         b, r = any_agent.b, any_agent.r
         a = np.zeros((b, r))
         if 0 in self.agents:
-            a = self.agents[0].X[0].cpu().numpy()
+            ag0 = self.agents[0]  # (the caller's pose 0, wherever the agent keeps it)
+            a = ag0.X[0 if getattr(ag0, "pose_order", None) is None else int(ag0.pose_order[0])].cpu().numpy()
         if self.world > 1:
             import torch
             dev = getattr(any_agent, "device", "cpu")

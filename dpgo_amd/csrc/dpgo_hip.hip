@@ -3713,6 +3713,24 @@ int dpgo_gather_tiles_device(int r, int d, const double* src_dev, const int32_t*
   return DPGO_OK;
 }
 
+int dpgo_permute_tiles_device(int r, int d, int n, const int32_t* new_index_dev, const double* in_dev, double* out_dev,
+                              int forward, void* stream) {
+  if (n == 0) return DPGO_OK;
+  if (!new_index_dev || !in_dev || !out_dev || n < 0 || in_dev == out_dev) return fail(DPGO_ERR_INVALID, "bad arguments");
+  size_t total = (size_t)n * (d + 1) * r;
+  int g = (int)((total + kBlock - 1) / kBlock);
+  if (g > kMaxGrid) g = kMaxGrid;
+  if (forward) {
+    DISPATCH(d, r, hipLaunchKernelGGL((k_scatter_tiles<D, R>), dim3(g), dim3(kBlock), 0, (hipStream_t)stream, in_dev,
+                                      new_index_dev, n, out_dev));
+  } else {
+    DISPATCH(d, r, hipLaunchKernelGGL((k_gather_tiles<D, R>), dim3(g), dim3(kBlock), 0, (hipStream_t)stream, in_dev,
+                                      new_index_dev, n, out_dev));
+  }
+  HIPC(hipGetLastError());
+  return DPGO_OK;
+}
+
 struct dpgo_exchange_plan_s {
   int device = 0, T = 0, nmsg = 0, total = 0;
   void *src = nullptr, *idx = nullptr, *dst = nullptr, *first = nullptr;

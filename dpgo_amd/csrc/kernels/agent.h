@@ -15,6 +15,19 @@ __global__ __launch_bounds__(kBlock) void k_gather_tiles(const double* __restric
   }
 }
 
+// Inverse of the above: dst tile idx[k] = src tile k (a permutation of whole pose vectors: dpgo_permute_tiles_device).
+template <int D, int R>
+__global__ __launch_bounds__(kBlock) void k_scatter_tiles(const double* __restrict__ src,
+                                                          const int32_t* __restrict__ idx, int count,
+                                                          double* __restrict__ dst) {
+  constexpr int T = (D + 1) * R;
+  const size_t total = (size_t)count * T;
+  for (size_t e = (size_t)blockIdx.x * kBlock + threadIdx.x; e < total; e += (size_t)gridDim.x * kBlock) {
+    const int k = (int)(e / T), w = (int)(e - (size_t)k * T);
+    dst[(size_t)idx[k] * T + w] = src[e];
+  }
+}
+
 // Batched form for agents that live in ONE process: message m copies cnt pose tiles src[m][idx[m][k]] -> dst[m][k]; one
 // launch for a whole exchange phase (a 16-agent sweep spent 0.5 ms in ~60 tiny pack / copy launches).  first[m] = tiles of
 // the messages before m (first[nmsg] = total).

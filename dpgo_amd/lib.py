@@ -117,6 +117,9 @@ SIGNATURES = {
     "dpgo_round_trajectory": ([_I, _I, _I, _P, _P, _P, _I], _I),
     "dpgo_round_trajectory_device": ([_I, _I, _I, _P, _P, _P, _P], _I),
     "dpgo_gather_tiles_device": ([_I, _I, _P, _P, _I, _P, _P], _I),
+    "dpgo_locality_order": ([_I, _P, _P, _I, _I, _P], _I),
+    "dpgo_locality_order_runs": ([_I, _P, _P, _I, _I, _I, _P], _I),
+    "dpgo_permute_tiles_device": ([_I, _I, _I, _P, _P, _P, _I, _P], _I),
     "dpgo_exchange_plan_create": ([C.POINTER(_P), _I, _I, _I, _P, _P, _P, _P, _I], _I),
     "dpgo_exchange_plan_run": ([_P, _P], _I),
     "dpgo_exchange_plan_destroy": ([_P], _I),

@@ -144,3 +144,47 @@ def partition_contiguous(dataset: RelativeSEMeasurements, num_poses: int, num_ro
                                dataset.weight.copy(), dataset.fixedWeight.copy())
     per_robot = [g.select((g.r1 == a) | (g.r2 == a)) for a in range(num_robots)]
     return [(int(s), int(e)) for s, e in zip(starts, ends)], per_robot
+
+
+def relabel(dataset: RelativeSEMeasurements, new_index: np.ndarray) -> RelativeSEMeasurements:
+    """The same measurements with pose i of a SINGLE index space (r1 = r2 = 0: a data set before partitioning) renamed
+    new_index[i].  Weights and the fixedWeight flags (odometry edges, never re-weighted) travel with their edges."""
+    if np.any(dataset.r1 != 0) or np.any(dataset.r2 != 0):
+        raise ValueError("relabel() takes a data set with global pose indices (robot ids 0)")
+    ni = np.asarray(new_index, dtype=np.int32)
+    return RelativeSEMeasurements(dataset.d, dataset.r1, ni[dataset.p1], dataset.r2, ni[dataset.p2], dataset.R, dataset.t,
+                                  dataset.kappa, dataset.tau, dataset.weight.copy(), dataset.fixedWeight.copy())
+
+
+def locality_order(dataset: RelativeSEMeasurements, num_poses: int, num_robots: int, parts_per_robot: int = 8) -> np.ndarray:
+    """Pose order for HBM-bound blocks (C ABI dpgo_locality_order, host code): every robot's contiguous block of the
+    demo's partition keeps its poses; inside it, each of `parts_per_robot` contiguous chunks (the shares of the 8 XCDs in
+    the kernels' tile walk, boundaries at workgroup tiles) is renumbered by reverse Cuthill-McKee over its own edges.
+    Returns new_index[num_poses]: the position of every caller pose -- a permutation that maps every robot's range onto
+    itself."""
+    import ctypes as C
+    from . import lib as L
+    per = num_poses // num_robots
+    starts = [a * per for a in range(num_robots)] + [num_poses]
+    tile = (64 // (dataset.d + 1)) * 4  # poses per workgroup tile of the one-pose-per-(d+1)-lanes kernels
+    out = np.arange(num_poses, dtype=np.int32)
+    p1, p2 = dataset.p1.astype(np.int64), dataset.p2.astype(np.int64)
+    for a in range(num_robots):
+        s, e = starts[a], starts[a + 1]
+        keep = (p1 >= s) & (p1 < e) & (p2 >= s) & (p2 < e) & (p1 != p2)
+        i = np.concatenate([p1[keep], p2[keep]]) - s
+        j = np.concatenate([p2[keep], p1[keep]]) - s
+        order = np.lexsort((j, i))
+        i, j = i[order], j[order]
+        n = e - s
+        rowptr = np.zeros(n + 1, dtype=np.int32)
+        np.add.at(rowptr, i + 1, 1)
+        rowptr = np.cumsum(rowptr).astype(np.int32)
+        colidx = np.ascontiguousarray(j, dtype=np.int32)
+        ni = np.zeros(n, dtype=np.int32)
+        import os
+        run = int(os.environ.get("DPGO_REORDER_RUN", "16"))  # (A/B knob of the benchmarks; 16 = a wave's poses)
+        L.check(L.load().dpgo_locality_order_runs(n, L.ptr(rowptr), L.ptr(colidx), int(parts_per_robot), tile, run, L.ptr(ni)))
+        out[s:e] = s + ni
+    return out
+

@@ -385,6 +385,26 @@ int dpgo_problem_set_persistent(dpgo_problem_t h, int enable);
 int dpgo_problem_persistent_info(dpgo_problem_t h, int* enabled, int* workgroups, int* last_members,
                                  int* last_iterations, int* last_layout);
 
+/* ---- pose order for HBM-bound blocks (host only; no reference counterpart: Eigen's product has no such notion) ----
+ * The block-SpMM kernels gather the tiles of a pose's graph neighbours; each XCD's workgroups sweep one contiguous eighth
+ * of the poses, so what is re-used stays in that XCD's L2 only if neighbours are close in the pose ORDER.
+ * dpgo_locality_order keeps the nparts contiguous chunks of the index range (boundaries at multiples of `align` poses) and,
+ * inside every chunk, keeps runs of 16 consecutive poses together (odometry neighbours: a wave's poses then gather contiguous
+ * memory) and orders the runs by reverse Cuthill-McKee over the graph of runs (dpgo_locality_order_runs: the run length as
+ * an argument; 1 = plain reverse Cuthill-McKee of the poses, measured 6 % slower than no renumbering).  rowptr / colidx: any
+ * structurally symmetric adjacency of the poses (Q's block pattern as dpgo_build_Q_bsr emits it); new_index[i] = position
+ * of caller pose i.  The solver itself never renumbers: a caller that owns the graph (the agent layer, dpgo_amd/agent.py,
+ * build_pose_graphs(reorder = True)) relabels its measurements with it and moves X through dpgo_permute_tiles_device on the
+ * way in and out, so that public pose ids and trajectories keep the caller's numbering.  Opt-in: on the lattice workloads
+ * of BASELINE.json the odometry order measured FASTER than every renumbering tried. */
+int dpgo_locality_order(int n, const int32_t* rowptr, const int32_t* colidx, int nparts, int align, int32_t* new_index);
+int dpgo_locality_order_runs(int n, const int32_t* rowptr, const int32_t* colidx, int nparts, int align, int run,
+                             int32_t* new_index);
+/* out tile new_index[i] = in tile i (forward = 1) or out tile i = in tile new_index[i] (forward = 0); r x (d+1) doubles per
+ * tile, device pointers, on `stream`. */
+int dpgo_permute_tiles_device(int r, int d, int n, const int32_t* new_index_dev, const double* in_dev, double* out_dev,
+                              int forward, void* stream);
+
 /* ---- initial guesses (src/DPGO_solver.cpp:220-303) ----
  * chordal: the two linear least-squares problems of chordalInitialization (rotations with pose 0 pinned to the
  *   identity, projected to SO(d); then translations) -- the reference solves them with SPQR (constructBMatrices /

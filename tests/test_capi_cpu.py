@@ -409,3 +409,49 @@ def test_python_mirror_rejects_bad_arguments_before_touching_the_device():
         pg.setMeasurements(pm)  # 3-D measurements into a 2-D graph
     with pytest.raises(ValueError):
         dpgo_amd.partition_contiguous(pm, n, n + 1)  # more robots than poses (examples/MultiRobotExample.cpp:74-77)
+
+
+def test_locality_order_is_a_block_preserving_permutation_that_shortens_the_gathers():
+    """dpgo_locality_order (host code of the library, what the agent layer renumbers blocks of >= 40 000 poses with): a
+    permutation that maps every chunk (XCD share, boundaries at workgroup tiles) onto itself, deterministic, and on a
+    lattice in odometry ("snake") order brings the neighbours of a pose from a plane's worth of rows to a fraction of it;
+    relabelling a data set with it leaves the cost of a relabelled iterate unchanged (it is a renaming)."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import dpgo_oracle as O
+    import dpgo_amd.lib as L
+    from dpgo_amd import measurements as M
+    lib = L.load()
+    om, n, Tt = O.synthetic_grid(20, 20, 10, seed=0)  # 4 000 poses; a plane is 400 rows
+    Q = O.construct_Q(n, 3, om)
+    rp, ci = L.i32(Q.rowptr), L.i32(Q.colidx)
+    nparts, align = 8, 64
+    ni = np.zeros(n, dtype=np.int32)
+    L.check(lib.dpgo_locality_order(n, L.ptr(rp), L.ptr(ci), nparts, align, L.ptr(ni)))
+    ni2 = np.zeros(n, dtype=np.int32)
+    L.check(lib.dpgo_locality_order(n, L.ptr(rp), L.ptr(ci), nparts, align, L.ptr(ni2)))
+    assert np.array_equal(ni, ni2) and sorted(ni.tolist()) == list(range(n))
+    bounds = [(n * k // nparts) // align * align for k in range(nparts)] + [n]
+    for c0, c1 in zip(bounds[:-1], bounds[1:]):
+        assert sorted(ni[c0:c1].tolist()) == list(range(c0, c1))
+    chunk = np.searchsorted(bounds, np.arange(n), side="right") - 1
+    rows = np.repeat(np.arange(n), np.diff(Q.rowptr))
+    cols = np.asarray(Q.colidx)
+    same = chunk[rows] == chunk[cols]
+    before = np.abs(rows - cols)[same].max()
+    after = np.abs(ni[rows].astype(np.int64) - ni[cols])[same].max()
+    assert before >= 399 and after <= before // 3, (before, after)
+    assert lib.dpgo_locality_order(n, L.ptr(rp), L.ptr(ci), 0, 64, L.ptr(ni2)) != 0  # bad arguments are refused
+    # the Python face: several robots, every robot's block keeps its poses; a renaming does not change the cost
+    pm = M.RelativeSEMeasurements(3, om.r1, om.p1, om.r2, om.p2, om.R, om.t, om.kappa, om.tau, om.weight, om.fixed)
+    order = M.locality_order(pm, n, 2)
+    assert sorted(order[:2000].tolist()) == list(range(2000)) and sorted(order[2000:].tolist()) == list(range(2000, n))
+    rm = M.relabel(pm, order)
+    om2 = O.Measurements(3, om.r1, rm.p1.astype(np.int64), om.r2, rm.p2.astype(np.int64), om.R, om.t, om.kappa, om.tau,
+                         om.weight, om.fixed)
+    X = O.lift(O.perturbed_truth(Tt, seed=2), 5)
+    X2 = np.empty_like(X)
+    X2[order] = X
+    f1 = O.QuadraticProblem(Q, None, 5, 3).f(X)
+    f2 = O.QuadraticProblem(O.construct_Q(n, 3, om2), None, 5, 3).f(X2)
+    assert abs(f1 - f2) <= 1e-12 * abs(f1)
+
