@@ -386,6 +386,15 @@ class DeviceAgent(AgentStatusMixin):
         self.last_result = self.optimizer.optimizeDevice(self.X)
         return self.last_result
 
+    def update_begin(self) -> None:
+        """update() in two halves (C ABI dpgo_optimize_device_begin / _end): everything of the update is enqueued on the
+        agent's stream and the host moves on; update_end() collects the result."""
+        self.optimizer.optimizeDeviceBegin(self.X, self.nbr if self.has_neighbours else None)
+
+    def update_end(self) -> ROPTResult:
+        self.last_result = self.optimizer.optimizeDeviceEnd()
+        return self.last_result
+
     def local_terms(self):
         """(sum X_a Q_a . X_a, sum X_a . G_a, |rgrad_a|^2) with the current neighbour buffer: the
         central cost is 0.5 * sum_a (xqx_a + xg_a) and the central gradnorm^2 is sum_a |rgrad_a|^2
@@ -644,6 +653,21 @@ class RBCDCluster:
         updated concurrently (C ABI dpgo_optimize_device_many: each on its own stream behind the exchange, one feeding
         host thread each), so a GPU that hosts several same-colour agents overlaps their latency-bound solves instead of
         running them one after the other."""
+        if self._stream_ordered_sweep():
+            # ONE agent per colour on this process (the multi-GPU deployment: two agents per GPU): the whole sweep --
+            # colour c's exchange, its solve, colour c+1's pack + exchange, ... -- is enqueued on one stream without a host
+            # wait in between (a one-launch solve needs no host feed); the results are read back at the end of the sweep
+            # instead of leaving the GPU idle for a host round trip per phase
+            begun = []
+            for c in range(self.plan.num_colours):
+                self.exchange(receivers=c)
+                for a in self.agents:
+                    if self.plan.colour[a] == c:
+                        self.agents[a].update_begin()
+                        begun.append(a)
+            for a in begun:
+                self.agents[a].update_end()
+            return
         for c in range(self.plan.num_colours):
             self.exchange(receivers=c)
             ids = [a for a in self.agents if self.plan.colour[a] == c]
@@ -656,6 +680,25 @@ class RBCDCluster:
             else:
                 for a in ids:
                     self.agents[a].update()
+
+    def _stream_ordered_sweep(self) -> bool:
+        """A sweep can be enqueued whole (sweep()): device agents with begin / end updates, at most one local agent per
+        colour, every exchange issued on the agents' stream (device copies or the library-owned communicator -- not the
+        torch.distributed fallback, whose waits block the host), all agents on the stream the exchanges use.
+        DPGO_ASYNC_SWEEP=0 switches it off (A/B)."""
+        cached = self.__dict__.get("_so_sweep")
+        if cached is not None:
+            return cached
+        import os
+        ok = os.environ.get("DPGO_ASYNC_SWEEP", "1") != "0" and self.plan.num_agents > 1
+        ok = ok and all(hasattr(ag, "update_begin") and hasattr(ag, "optimizer") for ag in self.agents.values())
+        per_colour: Dict[int, int] = {}
+        for a in self.agents:
+            per_colour[self.plan.colour[a]] = per_colour.get(self.plan.colour[a], 0) + 1
+        ok = ok and all(v <= 1 for v in per_colour.values())
+        ok = ok and (self.world == 1 or self.comm is not None)
+        self._so_sweep = bool(ok)
+        return self._so_sweep
 
     def block_terms(self) -> np.ndarray:
         """[num_agents, 2] array of (0.5 (xqx + xg), |rgrad_a|^2) per agent, identical on every rank."""

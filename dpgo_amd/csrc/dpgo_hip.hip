@@ -246,7 +246,19 @@ struct dpgo_problem_s {
   bool persist_failed_once = false;
   bool stream_nt = false;  // single-use operands of the tCG-step kernel move non-temporally (ld_stream, common.h)
   bool persist_add = false;  // the reservation is for the additive-preconditioner variant
+  bool persist_stream_ordered = false;  // set for the duration of a begin / end solve (see launch_rtr_persistent)
   size_t persist_lds_attr = 0;  // dynamic LDS size the additive instance's launch attribute was last raised to
+  // a solve enqueued by dpgo_optimize_device_begin and not yet collected by ..._end
+  struct Pending {
+    bool active = false;    // begin has been called
+    bool launched = false;  // the one-launch solve is in flight (else: the solve already ran, `result` holds its outcome)
+    dpgo_ropt_params resolved{};
+    bool is_auto = false;
+    const double* dinv = nullptr;
+    double* own_x1 = nullptr;
+    std::chrono::steady_clock::time_point t0;
+    dpgo_ropt_result result{};
+  } pending;
   PersistCtrl* pctrl = nullptr;
   unsigned long long* pgran = nullptr;  // granule table of the in-kernel all-reduce (kGranWords 8-byte words)
   unsigned gran_cleared_at = 0;         // value of `gen` when the table was last cleared
@@ -1485,7 +1497,17 @@ PersistGeo persist_geometry(const dpgo_problem_s* p, int free_slots, int share =
 int launch_rtr_persistent(dpgo_problem_s* p, const dpgo_ropt_params* prm, const double* dinv, bool* used, bool additive) {
   *used = false;
   p->gen += 1;
-  if (p->persist_reserved == 0) {
+  if (p->persist_stream_ordered) {
+    // dpgo_optimize_device_begin: the caller enqueues this handle's solves and everything between them on ONE stream, so
+    // no two of its one-launch solves are ever resident together -- nothing to reserve (a reservation could only be
+    // released by the collecting call, long after the kernel has left the chip)
+    const PersistGeo g = persist_geometry(p, persist_capacity(p->device), 1, additive);
+    if (g.wgs <= 0) return DPGO_OK;
+    p->persist_split = g.split;
+    p->persist_mt = g.mt;
+    p->persist_wgs = g.wgs;
+    p->persist_add = additive;
+  } else if (p->persist_reserved == 0) {
     // Alone on the device: what is free now, first come first served.  Sharing it with other concurrently solved agents:
     // the most compact layout, at most 4/5 of the slots in use at once (a CU that holds a persistent workgroup has no
     // registers left for anything else, and every agent's other kernels -- gradient, retraction, rho test -- need
@@ -1678,26 +1700,41 @@ int rtr_outer_iteration(dpgo_problem_s* p, const dpgo_ropt_params* prm, const do
   return DPGO_OK;
 }
 
-int run_optimize(dpgo_problem_s* p, const dpgo_ropt_params* prm, dpgo_ropt_result* res) {
+// phase: RUN_FULL = the whole solve, synchronously.  RUN_BEGIN = enqueue only: if the solve is a one-launch solve
+// (k_rtr_persist) the call returns with the launch, its commit kernel and the read-backs in flight (p->pending.launched);
+// otherwise the solve runs to completion right here.  RUN_END = collect what RUN_BEGIN left in flight (waits for the
+// stream, reads the state record, falls back to the multi-launch scheme after a time-out exactly as the synchronous call).
+enum { RUN_FULL = 0, RUN_BEGIN = 1, RUN_END = 2 };
+int run_optimize(dpgo_problem_s* p, const dpgo_ropt_params* prm, dpgo_ropt_result* res, int phase = RUN_FULL) {
   // X is in p->x1 on entry and on exit.  src/QuadraticOptimizer.cpp:26-48.
   auto t0 = std::chrono::steady_clock::now();
   Counters cnt;
   std::memset(res, 0, sizeof(*res));
   res->tCGStatus = DPGO_TCG_MAXITER;
-  if (p->hctrl) std::memset(p->hctrl, 0, sizeof(PersistCtrl));
+  const bool resume = phase == RUN_END;
+  if (p->hctrl && !resume) std::memset(p->hctrl, 0, sizeof(PersistCtrl));
   struct SlotGuard {  // the resident-slot reservation of the persistent kernel lives as long as the solve
     dpgo_problem_s* p;
-    ~SlotGuard() { persist_release(p); }
-  } slot_guard{p};
-  dpgo_ropt_params resolved = *prm;  // DPGO_PRECOND_AUTO -> what this handle currently runs
-  if (prm->precond == DPGO_PRECOND_AUTO) p->auto_decide();
-  if (prm->precond == DPGO_PRECOND_AUTO)  // (the multilevel choice: the additive form wherever its persistent kernel runs)
-    resolved.precond = (p->auto_ml && prm->method == DPGO_METHOD_RTR)
-                           ? ((additive_available(p) && !p->ml_user_ks) ? DPGO_PRECOND_ADDITIVE : DPGO_PRECOND_MULTILEVEL)
-                           : DPGO_PRECOND_BLOCK_JACOBI;
-  const bool is_auto = prm->precond == DPGO_PRECOND_AUTO;
+    bool armed;
+    ~SlotGuard() {
+      if (armed) persist_release(p);
+    }
+  } slot_guard{p, true};
+  dpgo_ropt_params resolved = resume ? p->pending.resolved : *prm;  // DPGO_PRECOND_AUTO -> what this handle currently runs
+  if (!resume) {
+    if (prm->precond == DPGO_PRECOND_AUTO) p->auto_decide();
+    if (prm->precond == DPGO_PRECOND_AUTO)  // (the multilevel choice: the additive form wherever its persistent kernel runs)
+      resolved.precond = (p->auto_ml && prm->method == DPGO_METHOD_RTR)
+                             ? ((additive_available(p) && !p->ml_user_ks) ? DPGO_PRECOND_ADDITIVE : DPGO_PRECOND_MULTILEVEL)
+                             : DPGO_PRECOND_BLOCK_JACOBI;
+  }
+  const bool is_auto = resume ? p->pending.is_auto : prm->precond == DPGO_PRECOND_AUTO;
+  if (resume) t0 = p->pending.t0;
   prm = &resolved;
   const double* dinv = nullptr;
+  if (resume) {
+    dinv = p->pending.dinv;
+  } else
   if (prm->precond == DPGO_PRECOND_BLOCK_JACOBI) {
     CHK(build_dinv(p, prm->precond_shift));
     dinv = p->dinv;
@@ -1715,16 +1752,18 @@ int run_optimize(dpgo_problem_s* p, const dpgo_ropt_params* prm, dpgo_ropt_resul
   } else if (prm->precond != DPGO_PRECOND_NONE) {
     return fail(DPGO_ERR_INVALID, "unknown preconditioner");
   }
-  p->loop_extra_bytes = 0;
-  if (prm->precond == DPGO_PRECOND_MULTILEVEL && !p->ml.empty()) {
-    const size_t nd = (size_t)p->ml_lda;
-    size_t bytes = nd * nd * (size_t)(p->ml_coarse_bits / 8) / (p->ml_use_dense_sym() ? 2 : 1);
-    const auto& L0 = p->ml[0];
-    bytes += (size_t)L0.AP.nnzb * (sizeof(double) * p->b * p->b + sizeof(int32_t)) + sizeof(double) * (size_t)p->n * p->b * p->b;
-    bytes += 3 * p->vec_bytes();
-    p->loop_extra_bytes = bytes;
+  if (!resume) {
+    p->loop_extra_bytes = 0;
+    if (prm->precond == DPGO_PRECOND_MULTILEVEL && !p->ml.empty()) {
+      const size_t nd = (size_t)p->ml_lda;
+      size_t bytes = nd * nd * (size_t)(p->ml_coarse_bits / 8) / (p->ml_use_dense_sym() ? 2 : 1);
+      const auto& L0 = p->ml[0];
+      bytes += (size_t)L0.AP.nnzb * (sizeof(double) * p->b * p->b + sizeof(int32_t)) + sizeof(double) * (size_t)p->n * p->b * p->b;
+      bytes += 3 * p->vec_bytes();
+      p->loop_extra_bytes = bytes;
+    }
+    CHK(resolve_tcg_storage(p));
   }
-  CHK(resolve_tcg_storage(p));
   // ---- blocks in the latency regime: the whole solve is ONE persistent launch (k_rtr_persist) and one read-back.  The
   // single-iteration radius-shrink mode (:80-99) and the polling mode keep the multi-launch scheme.
   const bool add = prm->precond == DPGO_PRECOND_ADDITIVE;
@@ -1732,13 +1771,26 @@ int run_optimize(dpgo_problem_s* p, const dpgo_ropt_params* prm, dpgo_ropt_resul
   // parameters allow more reductions than that -- at most 3 per tCG iteration + 4 per outer iteration + 1 -- keeps the
   // multi-launch scheme)
   const bool epochs_fit = (long long)std::max(1, prm->RTR_iterations) * (3LL * std::max(0, prm->RTR_tCG_iterations) + 4) + 1 < (1LL << 20);
-  if (prm->method == DPGO_METHOD_RTR && prm->RTR_iterations != 1 && prm->tcg_poll_interval <= 0 && p->persist && epochs_fit &&
-      !p->persist_failed_once && (add || prm->precond == DPGO_PRECOND_BLOCK_JACOBI || prm->precond == DPGO_PRECOND_NONE)) {
-    bool used = false;
-    CHK(launch_rtr_persistent(p, prm, dinv, &used, add));
+  if (resume || (prm->method == DPGO_METHOD_RTR && prm->RTR_iterations != 1 && prm->tcg_poll_interval <= 0 && p->persist && epochs_fit &&
+                 !p->persist_failed_once && (add || prm->precond == DPGO_PRECOND_BLOCK_JACOBI || prm->precond == DPGO_PRECOND_NONE))) {
+    bool used = resume;
+    if (!resume) CHK(launch_rtr_persistent(p, prm, dinv, &used, add));
     if (used) {
-      HIPC(hipMemcpyAsync(p->hctrl, p->pctrl, sizeof(PersistCtrl), hipMemcpyDeviceToHost, p->stream));
-      CHK(poll_state(p));
+      if (!resume) {
+        HIPC(hipMemcpyAsync(p->hctrl, p->pctrl, sizeof(PersistCtrl), hipMemcpyDeviceToHost, p->stream));
+        HIPC(hipMemcpyAsync(p->hstate, p->dstate + p->cur, sizeof(DevState), hipMemcpyDeviceToHost, p->stream));
+        if (phase == RUN_BEGIN) {  // everything of the solve is enqueued: the caller collects it with RUN_END
+          auto& pd = p->pending;
+          pd.launched = true;
+          pd.resolved = resolved;
+          pd.is_auto = is_auto;
+          pd.dinv = dinv;
+          pd.t0 = t0;
+          slot_guard.armed = false;  // (the reservation is released by the collecting call)
+          return DPGO_OK;
+        }
+      }
+      HIPC(hipStreamSynchronize(p->stream));
       persist_report(p);
       // (k_persist_commit, which ran behind the solve, saw the same two words: with a poisoned record OR a raised time-out
       // flag -- some participant gave up, however late -- the caller's iterate has not been touched)
@@ -2798,6 +2850,51 @@ int dpgo_optimize_device(dpgo_problem_t p, const dpgo_ropt_params* params, doubl
   return DPGO_OK;
 }
 
+int dpgo_optimize_device_begin(dpgo_problem_t p, const dpgo_ropt_params* params, double* X_dev,
+                               const double* nbr_tiles_dev) {
+  CHK(check_ready(p));
+  if (!params || !X_dev) return fail(DPGO_ERR_INVALID, "null pointer");
+  if (p->pending.active) return fail(DPGO_ERR_STATE, "a solve of this handle is already in flight (dpgo_optimize_device_end)");
+  if (nbr_tiles_dev) {  // PGOAgent::updateX: G from the neighbours' public poses first (same stream)
+    if (!p->C.rowptr) return fail(DPGO_ERR_STATE, "G coupling not set");
+    CHK(launch_spmm(p, p->C, nbr_tiles_dev, p->G0, p->G));
+    p->has_G = true;
+  }
+  auto& pd = p->pending;
+  pd = dpgo_problem_s::Pending();
+  pd.own_x1 = p->x1;
+  p->x1 = X_dev;
+  p->persist_stream_ordered = true;
+  dpgo_ropt_result tmp;
+  const int rc = run_optimize(p, params, &tmp, RUN_BEGIN);
+  p->persist_stream_ordered = false;
+  if (rc != DPGO_OK || !pd.launched) {  // failed, or the solve is not a one-launch solve and has run to completion
+    p->x1 = pd.own_x1;
+    if (rc != DPGO_OK) return rc;
+    pd.result = tmp;
+  }
+  pd.active = true;
+  return DPGO_OK;
+}
+
+int dpgo_optimize_device_end(dpgo_problem_t p, dpgo_ropt_result* result) {
+  if (!p || !result) return fail(DPGO_ERR_INVALID, "null pointer");
+  CHK(set_device(p));
+  auto& pd = p->pending;
+  if (!pd.active) return fail(DPGO_ERR_STATE, "no solve in flight (dpgo_optimize_device_begin)");
+  pd.active = false;
+  if (!pd.launched) {
+    *result = pd.result;
+    return DPGO_OK;
+  }
+  pd.launched = false;
+  const int rc = run_optimize(p, &pd.resolved, result, RUN_END);
+  p->x1 = pd.own_x1;
+  if (rc != DPGO_OK) return rc;
+  HIPC(hipStreamSynchronize(p->stream));
+  return DPGO_OK;
+}
+
 // ---- several agents of one process updated concurrently (same-colour agents of a parallel RBCD sweep) ----
 namespace {
 // Host threads that feed the just-in-time tCG loops of several handles at once: one worker per concurrently solved handle,
@@ -2868,11 +2965,11 @@ static int run_many(int count, const dpgo_problem_t* handles, void* after_stream
       if (handles[q] == handles[k]) return fail(DPGO_ERR_INVALID, "a handle appears twice");
   }
   std::vector<hipStream_t> prev(count);
+  for (int k = 0; k < count; ++k) prev[k] = handles[k]->stream;  // (all of them first: restored below whatever fails)
   hipEvent_t ev = nullptr;
   HIPC(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
   hipError_t e = hipEventRecord(ev, (hipStream_t)after_stream);
   for (int k = 0; k < count && e == hipSuccess; ++k) {
-    prev[k] = handles[k]->stream;
     if (prev[k] != handles[k]->own_stream) e = hipStreamSynchronize(prev[k]);  // earlier work of the handle itself
     handles[k]->stream = handles[k]->own_stream;
     handles[k]->persist_share = count;  // persistent tCG launches: prefer the layout with the fewest resident slots

@@ -642,6 +642,24 @@ class QuadraticOptimizer:
         return self.result_
 
 
+    def optimizeDeviceBegin(self, X_dev, nbr_tiles_dev=None) -> None:
+        """First half of optimizeDevice (C ABI dpgo_optimize_device_begin): G from the neighbour tile buffer (optional), then
+        the solve is ENQUEUED on the handle's stream when it is a one-launch solve (any other solve runs to completion
+        here).  X_dev belongs to the solve until optimizeDeviceEnd()."""
+        p = self.problem_
+        cp = self.params_.to_c()
+        L.check(p._lib.dpgo_optimize_device_begin(p._h, C.byref(cp), L.ptr(X_dev),
+                                                  L.ptr(nbr_tiles_dev) if nbr_tiles_dev is not None else None))
+
+    def optimizeDeviceEnd(self) -> ROPTResult:
+        """Second half: waits for the handle's stream and returns the result of the solve optimizeDeviceBegin enqueued."""
+        p = self.problem_
+        cr = L.RoptResultC()
+        L.check(p._lib.dpgo_optimize_device_end(p._h, C.byref(cr)))
+        self.result_ = ROPTResult.from_c(cr)
+        return self.result_
+
+
 def bench_solve(optimizer, X0_dev, reps=20, warmup=3):
     """HIP-event time of one whole local solve from X0_dev (C ABI dpgo_bench_solve): dict(ms, products, persistent)."""
     p = optimizer.problem_

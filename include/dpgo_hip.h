@@ -301,6 +301,19 @@ int dpgo_optimize(dpgo_problem_t h, const dpgo_ropt_params* params, const double
                   dpgo_ropt_result* result);
 int dpgo_optimize_device(dpgo_problem_t h, const dpgo_ropt_params* params, double* X_dev,
                          dpgo_ropt_result* result);
+/* The same solve in two halves, for callers that enqueue a whole sweep without waiting (RBCDCluster.sweep when a process
+ * hosts one agent per colour: colour c's solve, colour c+1's pack + exchange and its solve are all stream-ordered; the
+ * host reads the results back at the end of the sweep instead of idling the GPU between phases).
+ *   begin: G from the neighbour tile buffer (nbr_tiles_dev may be NULL), then -- if the solve is a one-launch solve
+ *     (k_rtr_persist) -- the launch, its commit kernel and the read-backs are enqueued on the handle's stream and the call
+ *     returns; any other solve runs to completion inside begin.  X_dev belongs to the solve until `end`.  The caller keeps
+ *     everything it enqueues between begin and end on that same stream (one-launch solves of different handles must not be
+ *     resident together; the resident-slot accounting of the synchronous calls is not used here).
+ *   end: waits for the stream, fills `result`; after a time-out of the launch the solve is re-run with the multi-launch
+ *     scheme exactly as dpgo_optimize_device does.  One solve in flight per handle (DPGO_ERR_STATE otherwise). */
+int dpgo_optimize_device_begin(dpgo_problem_t h, const dpgo_ropt_params* params, double* X_dev,
+                               const double* nbr_tiles_dev);
+int dpgo_optimize_device_end(dpgo_problem_t h, dpgo_ropt_result* result);
 
 /* Several agents hosted by one process / GPU updated CONCURRENTLY: the agents of one colour class of a parallel RBCD
  * sweep (examples/MultiRobotExample.cpp:170-255 updates its robots one after the other inside one process; the reference's

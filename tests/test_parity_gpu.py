@@ -1058,6 +1058,54 @@ def test_concurrent_same_colour_agents_match_sequential_updates(oracle):
         assert runs[1][0][-1][0] < runs[1][0][0][0]
 
 
+def test_stream_ordered_sweep_matches_phase_by_phase(oracle):
+    """A process that hosts ONE agent per colour (two agents per GPU, the multi-GPU deployment) enqueues a whole sweep --
+    exchange, solve, next colour's pack + exchange, solve -- on one stream through dpgo_optimize_device_begin / _end and
+    reads the results back at the end (RBCDCluster.sweep): the iterates and results are those of the phase-by-phase sweep
+    bit for bit (same kernels in the same order), for one-launch solves (2 x 6 250-pose blocks, block-Jacobi and the
+    additive form via "auto") and for solves that cannot be enqueued (multilevel V-cycle: begin runs them to completion).
+    The two halves refuse to be called out of order."""
+    import dpgo_amd
+    from dpgo_amd.agent import DeviceAgent, ExchangePlan, RBCDCluster, build_pose_graphs
+    from dpgo_amd.lib import DpgoError
+    r, robots = 5, 2
+    om, n, Ttrue = oracle.synthetic_grid(25, 25, 20, seed=0)
+    X0 = oracle.lift(oracle.perturbed_truth(Ttrue, seed=2), r)
+    for precond in ("jacobi", "auto", "multilevel"):
+        out = {}
+        for ordered in (True, False):
+            ranges, graphs = build_pose_graphs(to_product_measurements(om), n, robots, r)
+            plan = ExchangePlan(graphs)
+            agents = {a: DeviceAgent(graphs, plan, a, X0[ranges[a][0]:ranges[a][1]], dpgo_amd.ROptParameters(precond=precond))
+                      for a in range(robots)}
+            cluster = RBCDCluster(plan, agents)
+            assert cluster._stream_ordered_sweep() is True
+            if not ordered:
+                cluster._so_sweep = False
+            hist = []
+            for _ in range(4):
+                cluster.sweep()
+                hist.append([(ag.last_result.tcg_iterations, ag.last_result.rtr_iterations, ag.last_result.precond_used,
+                              ag.last_result.fOpt, ag.last_result.gradNormOpt) for ag in agents.values()])
+            out[ordered] = (hist, [agents[a].X.cpu().numpy() for a in range(robots)], cluster.central_cost_and_gradnorm())
+            if ordered and precond == "jacobi":
+                ag = agents[0]
+                with pytest.raises(DpgoError):
+                    ag.optimizer.optimizeDeviceEnd()  # nothing in flight
+                ag.update_begin()
+                with pytest.raises(DpgoError):
+                    ag.update_begin()  # one solve per handle
+                ag.update_end()
+                assert ag.problem.persistentInfo()["last_members"] > 0  # it WAS a one-launch solve
+        assert out[True][0] == out[False][0], precond
+        for Xa, Xb in zip(out[True][1], out[False][1]):
+            assert np.array_equal(Xa, Xb), precond
+        assert out[True][2] == out[False][2]
+        if precond == "auto":  # coupled blocks: block-Jacobi first, the additive form once the budget binds
+            used = [h[2] for sweep in out[True][0] for h in sweep]
+            assert "jacobi" in used and set(used) <= {"jacobi", "additive"}
+
+
 def test_external_stream_ordering_is_deterministic(oracle):
     """Regression: work of a handle bound to torch's current stream (the NULL / default stream) is ordered
     with torch ops on that stream -- restoring an iterate with tensor.copy_ and solving again gives the
@@ -1682,7 +1730,9 @@ def test_distributed_gnc_kitti_reference_schedule(oracle):
     last = info["history"][-1]
     assert (last["inliers"], last["outliers"], last["undecided"]) == (136, k, 0), info["history"]
     assert abs(info["updates"] - info_o["updates"]) <= 2, (info["updates"], info_o["updates"])
-    assert abs(info["muInit"] - info_o["muInit"]) <= 1e-2 * info_o["muInit"]
+    # (mu_0 = barc^2 / (2 max residual^2 - barc^2) after two unconverged sweeps: the two preconditioners leave the worst
+    # outlier's residual 1-2 % apart)
+    assert abs(info["muInit"] - info_o["muInit"]) <= 0.1 * info_o["muInit"]
     # every edge's final weight, gathered from the agents that hold it: the oracle's classification, edge for edge
     per = n // robots
     rob = np.minimum(np.arange(n) // per, robots - 1)
