@@ -69,6 +69,11 @@ def parse_args():
     ap.add_argument("--loopback", action="store_true",
                     help="single GPU, several agents: every public-pose exchange and reduction travels through a 1-rank "
                          "RCCL communicator owned by the solver library (the N > 1 data path on one device)")
+    ap.add_argument("--transport", default="rccl", choices=["rccl", "ipc"],
+                    help="N > 1: how the public poses travel.  rccl (default): grouped ncclSend / ncclRecv on the solver's "
+                         "stream.  ipc: the peer-store transport of dpgo_amd/ipc.py -- receivers' neighbour buffers mapped "
+                         "through hipIpc handles, senders' pack kernel writes straight into them; processes of one node, gloo "
+                         "for rendezvous and reductions (works with several ranks on ONE device, which RCCL refuses)")
     ap.add_argument("--dist", action="store_true",
                     help="run the N > 1 code path whatever the world size: torch.distributed process group (RCCL), the "
                          "library's communicator taken from it, barriers and all-reduces of the timing protocol, 2 agents "
@@ -401,7 +406,9 @@ def main():
     if use_dist:
         # "nccl" IS RCCL on ROCm.  DPGO_DIST_BACKEND=gloo (host-staged exchange) lets the N > 1 path be exercised
         # on a single-GPU box with all ranks sharing device 0; it is also the fallback if RCCL cannot initialise.
-        backend = os.environ.get("DPGO_DIST_BACKEND", "nccl")
+        backend = "gloo" if args.transport == "ipc" else os.environ.get("DPGO_DIST_BACKEND", "nccl")
+        if args.transport == "ipc" and world == 1:
+            raise SystemExit("--transport ipc needs at least two processes (torch.distributed.run --nproc-per-node 2)")
         if backend == "nccl":
             # no silent degradation: if RCCL cannot initialise the run FAILS (non-zero exit) -- a host-staged number
             # must never stand in for the xGMI one
@@ -432,6 +439,8 @@ def main():
     agents = {a: DeviceAgent(graphs, plan, a, X0[ranges[a][0]:ranges[a][1]], params, device=dev_index)
               for a in my_ids}
     cluster = RBCDCluster(plan, agents, rank, world, agents_per_rank=apg, comm=comm, loopback=loopback)
+    if use_dist and args.transport == "ipc":
+        cluster.enable_peer_store()
     big = max(my_ids, key=lambda a: graphs[a].n())  # the agent whose kernels are profiled below
     agent = agents[big]
     nnzb_local = len(graphs[big].quadraticMatrix()[1])
@@ -851,8 +860,10 @@ def main():
                                    "; communicator taken from the torch.distributed process group" if use_dist else "")
                                if world == 1 else "") if comm
                            else ("device copies" if world == 1 else
-                                 ("torch.distributed nccl p2p" if not cluster.stage else "gloo (host-staged)"))),
-                       "dist_backend": backend,
+                                 ("peer store: senders' pack kernels write into the receivers' hipIpc-mapped neighbour "
+                                  "buffers, gloo barriers (dpgo_amd/ipc.py)" if cluster.peer_store is not None else
+                                  ("torch.distributed nccl p2p" if not cluster.stage else "gloo (host-staged)")))),
+                       "dist_backend": backend, "transport": (args.transport if use_dist else None),
                        "poses_per_agent": n_local, "nnzb_per_agent": nnzb_local,
                        "pose_order": ("renumbered inside the agent for locality (reverse Cuthill-McKee inside each XCD's "
                                       "eighth, dpgo_locality_order); X0 in, iterates and trajectories out in the data "

@@ -431,6 +431,14 @@ class RBCDCluster:
             if stage_through_host is None:
                 stage_through_host = dist.get_backend() == "gloo"
         self.stage = bool(stage_through_host) and comm is None
+        self.peer_store = None  # dpgo_amd.ipc.IpcPeerStore (enable_peer_store): processes of one node, mapped buffers
+
+    def enable_peer_store(self) -> None:
+        """Carry the public-pose exchange by the peer-store transport (dpgo_amd/ipc.py): collective over the default
+        process group (gloo suffices).  Reductions and the anchor broadcast keep their transport."""
+        from .ipc import IpcPeerStore
+        self.peer_store = IpcPeerStore(self)
+        self.__dict__.pop("_so_sweep", None)
 
     def owner(self, agent_id: int) -> int:
         """Rank hosting an agent: consecutive ids share a rank (agents_per_rank = 2 puts one agent of
@@ -443,6 +451,9 @@ class RBCDCluster:
         device copies; remote pairs form ONE grouped batch of isend/irecv (ncclGroupStart/End under
         RCCL), so no ordering between ranks can deadlock."""
         msgs = messages if messages is not None else self.plan.messages(receivers)
+        if getattr(self, "peer_store", None) is not None:  # senders write straight into the receivers' mapped buffers
+            self.peer_store.exchange(msgs, receivers if messages is None else tuple(msgs), bool(aux))
+            return
         if self._exchange_batched(msgs, (receivers if messages is None else tuple(msgs), bool(aux)), aux):
             return
         ops, staged = [], []
@@ -696,7 +707,7 @@ class RBCDCluster:
         for a in self.agents:
             per_colour[self.plan.colour[a]] = per_colour.get(self.plan.colour[a], 0) + 1
         ok = ok and all(v <= 1 for v in per_colour.values())
-        ok = ok and (self.world == 1 or self.comm is not None)
+        ok = ok and (self.world == 1 or self.comm is not None) and self.peer_store is None
         self._so_sweep = bool(ok)
         return self._so_sweep
 

@@ -1106,6 +1106,27 @@ def test_stream_ordered_sweep_matches_phase_by_phase(oracle):
             assert "jacobi" in used and set(used) <= {"jacobi", "additive"}
 
 
+@pytest.mark.parametrize("workload,sweeps", [("smallGrid3D", 6), ("grid:20x20x10", 3)])
+def test_two_processes_exchange_through_mapped_buffers_on_one_gpu(workload, sweeps):
+    """A genuinely multi-PROCESS device exchange on one GPU (RCCL refuses two ranks on one device; IPC does not): two
+    processes on device 0, two agents each (one per colour), gloo for the rendezvous and the small reductions, the
+    receivers' neighbour tile buffers mapped into the senders through hipIpc handles and the senders' batched pack
+    kernel (k_gather_tiles_batched) writing straight into them (dpgo_amd/ipc.py; SURVEY section 5's peer-store
+    alternative).  The iterates after the sweeps are those of the same four agents in ONE process, bit for bit."""
+    port = 29500 + (os.getpid() % 400) + (17 if workload.startswith("grid") else 0)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(os.path.dirname(os.path.abspath(__file__)), "ipc_worker.py"), workload,
+           str(sweeps)]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+    assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-3000:])
+    line = [ln for ln in p.stdout.splitlines() if ln.startswith("IPC_RESULT")]
+    assert len(line) == 1, p.stdout[-2000:]
+    kv = dict(tok.split("=", 1) for tok in line[0].split()[1:])
+    assert kv["bit_identical"] == "1" and kv["costs_equal"] == "1" and kv["iterations_equal"] == "1", line[0]
+    assert kv["decrease"] == "1" and float(kv["exchange_ms_per_sweep"]) > 0.0
+
+
 def test_external_stream_ordering_is_deterministic(oracle):
     """Regression: work of a handle bound to torch's current stream (the NULL / default stream) is ordered
     with torch ops on that stream -- restoring an iterate with tensor.copy_ and solving again gives the
