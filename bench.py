@@ -623,8 +623,11 @@ def main():
     vec = 8 * r * b_ * n_local
     ms_it = (C.c_double * 5)()
     dpgo_amd.lib.check(lib.dpgo_bench_iteration_kernels(agent.problem.handle, args.spmm_reps, 10, ms_it))
+    # (block-Jacobi mode reads X for the tangent projection of z: 8 pose vectors; the multilevel pre-smoothing step is not
+    # projected: 7 -- the probe runs the mode the hierarchy state selects, dpgo_bench_iteration_kernels)
+    upd_vecs = 8 if args.precond == "jacobi" else 7
     kernels = [dict(kernel="k_tcg_update (eta, r updates, pre-smoothing / block-Jacobi, <r,r>)",
-                    bytes_per_launch=8 * vec + 8 * b_ * b_ * n_local, avg_launch_us=ms_it[0] * 1e3)]
+                    bytes_per_launch=upd_vecs * vec + 8 * b_ * b_ * n_local, avg_launch_us=ms_it[0] * 1e3)]
     ml_info = None
     if args.precond != "jacobi":
         ml_info = agent.problem.setupMultilevel()  # (auto may not have built it yet)

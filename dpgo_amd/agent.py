@@ -54,13 +54,16 @@ class PGOAgentStatus:
 
 
 def should_terminate(iteration: int, prm: PGOAgentParameters, weight_update_count: int,
-                     team: Dict[int, PGOAgentStatus], num_robots: int) -> bool:
-    """PGOAgent::shouldTerminate (src/PGOAgent.cpp:846-878), every robot active."""
+                     team: Dict[int, PGOAgentStatus], num_robots: int, inactive=()) -> bool:
+    """PGOAgent::shouldTerminate (src/PGOAgent.cpp:846-878); robots in `inactive` (PGOAgent::setRobotActive(id, false),
+    :1173-1184) have no vote (:861-862)."""
     if iteration >= prm.maxNumIters:
         return True
     if prm.robust and weight_update_count < prm.robustOptNumWeightUpdates:
         return False
     for rob in range(num_robots):
+        if rob in inactive:
+            continue
         st = team.get(rob)
         if st is None or st.state != "INITIALIZED" or not st.readyToTerminate:
             return False
@@ -69,8 +72,8 @@ def should_terminate(iteration: int, prm: PGOAgentParameters, weight_update_coun
 
 def should_update_measurement_weights(prm: PGOAgentParameters, weight_update_count: int, inner_iter: int,
                                       latest_update_iteration: int, team: Dict[int, PGOAgentStatus],
-                                      num_robots: int) -> bool:
-    """PGOAgent::shouldUpdateMeasurementWeights (src/PGOAgent.cpp:997-1045)."""
+                                      num_robots: int, inactive=()) -> bool:
+    """PGOAgent::shouldUpdateMeasurementWeights (src/PGOAgent.cpp:997-1045); inactive robots are skipped (:1016-1017)."""
     if not prm.robust:
         return False
     if weight_update_count >= prm.robustOptNumWeightUpdates:
@@ -78,6 +81,8 @@ def should_update_measurement_weights(prm: PGOAgentParameters, weight_update_cou
     if inner_iter >= prm.robustOptInnerIters:
         return True
     for rob in range(num_robots):
+        if rob in inactive:
+            continue
         st = team.get(rob)
         if st is None or st.iterationNumber < latest_update_iteration or st.state != "INITIALIZED" \
                 or not st.readyToTerminate:
@@ -386,6 +391,24 @@ class DeviceAgent(AgentStatusMixin):
         self.last_result = self.optimizer.optimizeDevice(self.X)
         return self.last_result
 
+    def setRobotActive(self, robot_id: int, active: bool = True) -> None:
+        """PGOAgent::setRobotActive (src/PGOAgent.cpp:1173-1184): the team's activity flags; for a NEIGHBOUR the shared
+        edges with it leave (or re-enter) this agent's Q and G -- PoseGraph::setNeighborActive drops the data matrices,
+        here: Q's values and the coupling blocks are rebuilt and re-uploaded (same block pattern: the hierarchy of the
+        preconditioner is refreshed lazily, values only)."""
+        self.__dict__.setdefault("team_inactive", set())
+        (self.team_inactive.discard if active else self.team_inactive.add)(int(robot_id))
+        if self.pg.hasNeighbor(robot_id):
+            before = self.pg.q_version
+            self.pg.setNeighborActive(robot_id, active)
+            if self.pg.q_version != before:
+                self.problem.refresh()
+                if self.has_neighbours:
+                    self.problem.setCouplingFromPoseGraph()
+
+    def isRobotActive(self, robot_id: int) -> bool:
+        return int(robot_id) not in self.__dict__.get("team_inactive", set())
+
     def update_begin(self) -> None:
         """update() in two halves (C ABI dpgo_optimize_device_begin / _end): everything of the update is enqueued on the
         agent's stream and the host moves on; update_end() collects the result."""
@@ -432,6 +455,20 @@ class RBCDCluster:
                 stage_through_host = dist.get_backend() == "gloo"
         self.stage = bool(stage_through_host) and comm is None
         self.peer_store = None  # dpgo_amd.ipc.IpcPeerStore (enable_peer_store): processes of one node, mapped buffers
+
+    def set_robot_active(self, robot_id: int, active: bool = True) -> None:
+        """The driver's part of PGOAgent::setRobotActive: every local agent is told (its neighbours drop / restore the
+        shared edges), the inactive agent stops updating, and the termination / weight-update votes skip it
+        (src/PGOAgent.cpp:861-862, 1016-1017)."""
+        self.__dict__.setdefault("inactive", set())
+        (self.inactive.discard if active else self.inactive.add)(int(robot_id))
+        for ag in self.agents.values():
+            if hasattr(ag, "setRobotActive"):
+                ag.setRobotActive(robot_id, active)
+
+    def _active_ids(self, c: int):
+        off = self.__dict__.get("inactive", ())
+        return [a for a in self.agents if self.plan.colour[a] == c and a not in off]
 
     def enable_peer_store(self) -> None:
         """Carry the public-pose exchange by the peer-store transport (dpgo_amd/ipc.py): collective over the default
@@ -604,7 +641,7 @@ class RBCDCluster:
         iteration number, XPrev is saved before and the agents' relative changes are measured on the device after the
         solves, read back together (one small copy per phase) and turned into PGOAgentStatus records."""
         self.exchange(receivers=c)
-        ids = [a for a in self.agents if self.plan.colour[a] == c]
+        ids = self._active_ids(c)
         tracked = [a for a in ids if getattr(self.agents[a], "track_status", False)] if iteration is not None else []
         for a in tracked:
             self.agents[a].XPrev.copy_(self.agents[a].X)
@@ -655,7 +692,7 @@ class RBCDCluster:
             self.phase(c, iteration)
             team = self.team_status()
             trace.append({a: st.relativeChange for a, st in team.items()})
-            if should_terminate(iteration, prm, 0, team, self.plan.num_agents):
+            if should_terminate(iteration, prm, 0, team, self.plan.num_agents, self.__dict__.get("inactive", ())):
                 break
         return dict(iterations=iteration, statuses=team, relative_changes=trace)
 
@@ -672,16 +709,15 @@ class RBCDCluster:
             begun = []
             for c in range(self.plan.num_colours):
                 self.exchange(receivers=c)
-                for a in self.agents:
-                    if self.plan.colour[a] == c:
-                        self.agents[a].update_begin()
-                        begun.append(a)
+                for a in self._active_ids(c):
+                    self.agents[a].update_begin()
+                    begun.append(a)
             for a in begun:
                 self.agents[a].update_end()
             return
         for c in range(self.plan.num_colours):
             self.exchange(receivers=c)
-            ids = [a for a in self.agents if self.plan.colour[a] == c]
+            ids = self._active_ids(c)
             if self.concurrent and len(ids) > 1 and all(hasattr(self.agents[a], "optimizer") for a in ids):
                 ags = [self.agents[a] for a in ids]
                 res = optimize_device_many([g.optimizer for g in ags], [g.X for g in ags],

@@ -113,6 +113,8 @@ class PoseGraph:
         self._meas: Optional[RelativeSEMeasurements] = None
         self.neighbor_poses_: Dict[Tuple[int, int], np.ndarray] = {}
         self.priors_: Dict[int, np.ndarray] = {}
+        self.neighbor_active_: Dict[int, bool] = {}  # neighbour robot -> active (src/PoseGraph.cpp:192-207)
+        self.use_inactive_neighbors_ = False          # :632
         self._Q = None
         self._G = None
         self._coupling = None
@@ -151,7 +153,52 @@ class PoseGraph:
         self.n_ = n
         self.neighbor_poses_ = {}
         self.priors_ = {}
+        self.neighbor_active_ = {int(q): True for q in set(m.r1.tolist()) | set(m.r2.tolist()) if q != self.id_}
         self.clearDataMatrices()
+
+    # ---- neighbour activity (src/PoseGraph.cpp:188-207, 252-303, 632-634) ----
+    def hasNeighbor(self, robot_id: int) -> bool:
+        return int(robot_id) in self.neighbor_active_
+
+    def isNeighborActive(self, neighbor_id: int) -> bool:
+        return self.neighbor_active_.get(int(neighbor_id), False)
+
+    def setNeighborActive(self, neighbor_id: int, active: bool) -> None:
+        """PoseGraph::setNeighborActive: the shared edges with an inactive neighbour leave Q and G (constructQ /
+        constructG skip them, :418-430, :520-532) -- the data matrices are dropped when the flag changes."""
+        if not self.hasNeighbor(neighbor_id):
+            return
+        if self.neighbor_active_[int(neighbor_id)] != bool(active):
+            self.clearDataMatrices()
+        self.neighbor_active_[int(neighbor_id)] = bool(active)
+
+    def useInactiveNeighbors(self, use: bool = True) -> None:
+        """PoseGraph::useInactiveNeighbors (:632-634): keep an inactive neighbour's edges whose pose is still known."""
+        self.use_inactive_neighbors_ = bool(use)
+        self.clearDataMatrices()
+
+    def activeNeighborIDs(self):
+        return sorted(q for q, act in self.neighbor_active_.items() if act)
+
+    def activeNeighborPublicPoseIDs(self):
+        return [pid for pid in self.neighborPoseIDs() if self.isNeighborActive(pid[0])]
+
+    def _effective_weights(self) -> np.ndarray:
+        """The measurement weights the data matrices are built with: an edge with an inactive neighbour contributes
+        nothing (unless use_inactive_neighbors_ and its pose is known) -- carried as weight 0, which adds exact zeros
+        where the reference skips the edge (Omega = w diag(kappa.., tau))."""
+        m = self._meas
+        w = m.weight
+        if all(self.neighbor_active_.values()):
+            return w
+        w = w.copy()
+        for e in range(len(m)):
+            if m.r1[e] == m.r2[e]:
+                continue
+            nb = (int(m.r2[e]), int(m.p2[e])) if m.r1[e] == self.id_ else (int(m.r1[e]), int(m.p1[e]))
+            if not self.isNeighborActive(nb[0]) and not (self.use_inactive_neighbors_ and nb in self.neighbor_poses_):
+                w[e] = 0.0
+        return w
 
     def measurements(self) -> RelativeSEMeasurements:
         return self._meas
@@ -199,14 +246,15 @@ class PoseGraph:
 
     def _edge_arrays(self):
         m = self._meas
+        self._w_eff = np.ascontiguousarray(self._effective_weights(), dtype=np.float64)  # (kept alive for the C call)
         return (len(m), L.ptr(m.r1), L.ptr(m.p1), L.ptr(m.r2), L.ptr(m.p2), L.ptr(m.R), L.ptr(m.t),
-                L.ptr(m.kappa), L.ptr(m.tau), L.ptr(m.weight))
+                L.ptr(m.kappa), L.ptr(m.tau), L.ptr(self._w_eff))
 
     def quadraticMatrix(self):
         """PoseGraph::quadraticMatrix (:345-350) -> (rowptr, colidx, vals[nnzb, b, b]) block-CSR,
-        built by dpgo_build_Q_bsr (constructQ, :381-491).  Every neighbour is treated as active;
-        the reference's missing-pose check (:418-424) is enforced where the poses are actually
-        consumed, in linearMatrix()."""
+        built by dpgo_build_Q_bsr (constructQ, :381-491).  Shared edges with an inactive neighbour
+        (setNeighborActive) are left out (:425-430); the reference's missing-pose check for ACTIVE
+        neighbours (:418-424) is enforced where the poses are actually consumed, in linearMatrix()."""
         if self._Q is None:
             if self._meas is None or self.n_ == 0:
                 raise RuntimeError("PoseGraph has no measurements")
@@ -270,6 +318,8 @@ class PoseGraph:
                 for t in range(rowptr[i], rowptr[i + 1]):
                     pid = slots[colidx[t]]
                     if pid not in self.neighbor_poses_:
+                        if not self.isNeighborActive(pid[0]):
+                            continue  # (its coupling blocks are zero: the edge is out of the problem, :525-530)
                         raise LookupError("Missing active neighbor pose %s" % (pid,))
                     Xn = np.asarray(self.neighbor_poses_[pid], dtype=np.float64)  # r x b
                     G[:, i * b:(i + 1) * b] += Xn @ vals[t].T  # out[a,c] = sum_k X[a,k] blk[c][k]

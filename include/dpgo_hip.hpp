@@ -26,6 +26,7 @@
 #include <cmath>
 #include <cstdint>
 #include <map>
+#include <set>
 #include <memory>
 #include <cstring>
 #include <stdexcept>
@@ -170,7 +171,32 @@ class PoseGraph {
     }
     neighbor_poses_.clear();
     priors_.clear();
+    neighbor_active_.clear();
+    for (const auto& m : meas_)
+      if (m.r1 != m.r2) neighbor_active_[(unsigned)(m.r1 == id_ ? m.r2 : m.r1)] = true;
     clearDataMatrices();
+  }
+  // Neighbour activity (src/PoseGraph.cpp:188-207, 252-264, 632-634): the shared edges with an INACTIVE neighbour are
+  // skipped by constructQ / constructG (:425-430, :527-532) unless useInactiveNeighbors is set and the pose is known.
+  bool hasNeighbor(unsigned robot_id) const { return neighbor_active_.count(robot_id) != 0; }
+  bool isNeighborActive(unsigned neighbor_id) const {
+    auto it = neighbor_active_.find(neighbor_id);
+    return it != neighbor_active_.end() && it->second;
+  }
+  void setNeighborActive(unsigned neighbor_id, bool active) {
+    if (!hasNeighbor(neighbor_id)) return;
+    if (neighbor_active_[neighbor_id] != active) clearDataMatrices();
+    neighbor_active_[neighbor_id] = active;
+  }
+  void useInactiveNeighbors(bool use = true) {
+    use_inactive_neighbors_ = use;
+    clearDataMatrices();
+  }
+  std::set<unsigned> activeNeighborIDs() const {
+    std::set<unsigned> out;
+    for (const auto& kv : neighbor_active_)
+      if (kv.second) out.insert(kv.first);
+    return out;
   }
   void setPrior(unsigned index, const Matrix& Xi) {  // :176-181
     if (index >= n_ || Xi.rows() != r_ || Xi.cols() != d_ + 1) throw Error(DPGO_ERR_INVALID, "bad prior");
@@ -286,6 +312,7 @@ class PoseGraph {
         const bool outgoing = m.r1 == id_;
         const PoseID nid = outgoing ? PoseID(m.r2, m.p2) : PoseID(m.r1, m.p1);
         auto it = neighbor_poses_.find(nid);
+        if (!isNeighborActive(nid.first) && (!use_inactive_neighbors_ || it == neighbor_poses_.end())) continue;  // :527-532
         if (it == neighbor_poses_.end()) throw Error(DPGO_ERR_STATE, "Missing active neighbor pose");
         const Matrix& Xn = it->second;  // r x (d+1)
         double T[4][4] = {}, om[4];
@@ -332,7 +359,14 @@ class PoseGraph {
       for (unsigned p = 0; p < d_; ++p) s.t.push_back(m.t(p, 0));
       s.kappa.push_back(m.kappa);
       s.tau.push_back(m.tau);
-      s.w.push_back(m.weight);
+      // an edge with an inactive neighbour is out of the data matrices (unless useInactiveNeighbors and its pose is known):
+      // carried as weight 0, which adds exact zeros where the reference skips the edge (Omega = w diag(kappa.., tau))
+      double w = m.weight;
+      if (m.r1 != m.r2) {
+        const PoseID nid = m.r1 == id_ ? PoseID((unsigned)m.r2, (unsigned)m.p2) : PoseID((unsigned)m.r1, (unsigned)m.p1);
+        if (!isNeighborActive(nid.first) && !(use_inactive_neighbors_ && neighbor_poses_.count(nid))) w = 0.0;
+      }
+      s.w.push_back(w);
     }
     return s;
   }
@@ -340,6 +374,8 @@ class PoseGraph {
   std::vector<RelativeSEMeasurement> meas_;
   std::map<PoseID, Matrix> neighbor_poses_;
   std::map<unsigned, Matrix> priors_;
+  std::map<unsigned, bool> neighbor_active_;
+  bool use_inactive_neighbors_ = false;
   Bsr Q_;
   Matrix G_;
   bool has_Q_ = false, has_G_ = false;
@@ -667,10 +703,26 @@ class PGOAgent {
   // PGOAgent::getStatus / setNeighborStatus (PGOAgent.h:300-310, src/PGOAgent.cpp:604-610) and shouldTerminate (:846-878)
   PGOAgentStatus getStatus() const { return status_; }
   void setNeighborStatus(const PGOAgentStatus& status) { team_[status.agentID] = status; }
+  // PGOAgent::isRobotActive / setRobotActive (src/PGOAgent.cpp:1167-1184): for a NEIGHBOUR the shared edges with it leave
+  // (or re-enter) Q and G -- the pose graph drops its data matrices and the device handle is refreshed (values only)
+  bool isRobotActive(unsigned robot_id) const { return robot_id < prm_.numRobots && !inactive_.count(robot_id); }
+  void setRobotActive(unsigned robot_id, bool active = true) {
+    if (robot_id >= prm_.numRobots) return;
+    if (active) inactive_.erase(robot_id); else inactive_.insert(robot_id);
+    if (pg_ && pg_->hasNeighbor(robot_id)) {
+      const unsigned long before = pg_->qVersion();
+      pg_->setNeighborActive(robot_id, active);
+      if (pg_->qVersion() != before && problem_) {
+        problem_->refresh();                   // Q's values (same block pattern)
+        problem_->setCouplingFromPoseGraph();  // the coupling blocks of G (same slot order)
+      }
+    }
+  }
   bool shouldTerminate() {
     if (iteration_number() >= prm_.maxNumIters) return true;
     team_[id_] = status_;
     for (unsigned robot = 0; robot < prm_.numRobots; ++robot) {
+      if (!isRobotActive(robot)) continue;  // :861-862
       auto it = team_.find(robot);
       if (it == team_.end()) return false;
       if (it->second.state != PGOAgentState::INITIALIZED) return false;
@@ -856,6 +908,7 @@ class PGOAgent {
   double* rel_ = nullptr;  // device scalar: relativeChange of the last optimising iterate
   PGOAgentStatus status_;
   std::map<unsigned, PGOAgentStatus> team_;
+  std::set<unsigned> inactive_;  // robots switched off by setRobotActive(id, false)
   int32_t* pub_idx_ = nullptr;
   std::vector<double> nbr_h_, nbr_aux_h_;
   bool nbr_dirty_ = false, aux_dirty_ = false;

@@ -237,6 +237,22 @@ def bsr_from_block_triplets(n, b, bi, bj, blocks) -> BSR:
     return BSR(n, b, rowptr, cols, vals)
 
 
+def active_shared_edges(shared: Optional[Measurements], my_id: int, inactive=None, use_inactive: bool = False,
+                        neighbor_poses=None) -> Optional[Measurements]:
+    """The shared edges constructQ / constructG use (src/PoseGraph.cpp:418-430, 442-454, 520-532, 545-557): an edge with
+    an INACTIVE neighbour (PoseGraph::setNeighborActive, set by PGOAgent::setRobotActive, src/PGOAgent.cpp:1173-1184) is
+    skipped unless use_inactive_neighbors_ is set and its pose is available."""
+    if shared is None or not shared.m or not inactive:
+        return shared
+    keep = []
+    for e in range(shared.m):
+        nb = (int(shared.r2[e]), int(shared.p2[e])) if shared.r1[e] == my_id else (int(shared.r1[e]), int(shared.p1[e]))
+        if nb[0] in inactive and not (use_inactive and neighbor_poses is not None and nb in neighbor_poses):
+            continue
+        keep.append(e)
+    return shared.subset(np.array(keep, dtype=np.int64))
+
+
 def construct_Q(n: int, d: int, private: Measurements, shared: Optional[Measurements] = None,
                 my_id: int = 0, priors: Optional[Dict[int, np.ndarray]] = None,
                 prior_kappa: float = 10000.0, prior_tau: float = 100.0) -> BSR:
@@ -1171,13 +1187,16 @@ def perturbed_truth(Ttrue, seed: int = 2, sigma_t: float = 0.1, sigma_r: float =
 
 def rbcd_coloured(meas: Measurements, n: int, num_robots: int, r: int, X0, sweeps: int,
                   params: Optional[ROptParameters] = None, precond: str = "jacobi", hess_recurrence: bool = False,
-                  amg_k=None):
+                  amg_k=None, inactive=()):
     """Two-colour (greedy-coloured) parallel RBCD of SURVEY 8e on the contiguous partition of
     examples/MultiRobotExample.cpp:71-119: in every sweep each colour class updates once; an agent's
     update is PGOAgent::updateX (src/PGOAgent.cpp:938-995): G from the neighbours' current public poses
     (constructG), then QuadraticOptimizer::optimize from its current block.  Agents of one colour are not
     adjacent, so updating them one after the other equals updating them simultaneously.
     amg_k: hierarchy of the multilevel / additive preconditioners (None: the default; a dict agent -> sizes: per agent).
+    inactive: robots switched off by PGOAgent::setRobotActive(id, false) (src/PGOAgent.cpp:1173-1184): they do not
+    update, and their neighbours' data matrices leave the shared edges with them out (active_shared_edges); the
+    colouring is that of the full team.
     Returns (X, [central 2f after each sweep], [central gradnorm after each sweep])."""
     d = meas.d
     ranges, per = partition_contiguous(meas, n, num_robots)
@@ -1185,14 +1204,16 @@ def rbcd_coloured(meas: Measurements, n: int, num_robots: int, r: int, X0, sweep
     for a in range(num_robots):
         s, e = ranges[a]
         priv = Measurements.concat([per[a]["odometry"], per[a]["private"]])
-        Qa = construct_Q(e - s, d, priv, per[a]["shared"], my_id=a)
-        sh = per[a]["shared"]
+        full = per[a]["shared"]
+        sh = active_shared_edges(full, a, set(inactive))
+        Qa = construct_Q(e - s, d, priv, sh, my_id=a)
         need = set()
         for k in range(sh.m):
             need.add((int(sh.r2[k]), int(sh.p2[k])) if sh.r1[k] == a else (int(sh.r1[k]), int(sh.p1[k])))
+        team_adj = sorted({int(full.r2[k]) if full.r1[k] == a else int(full.r1[k]) for k in range(full.m)})
         # one problem object per agent for the whole run (Q and the preconditioner belong to the PoseGraph's lifetime,
         # include/DPGO/PoseGraph.h:324-331); only G changes between solves
-        agents.append(dict(Q=Qa, shared=sh, need=sorted(need), adj=sorted({rob for rob, _ in need}),
+        agents.append(dict(Q=Qa, shared=sh, need=sorted(need), adj=team_adj,
                            prob=QuadraticProblem(Qa, None, r, d, precond=precond,
                                                  amg_k=amg_k[a] if isinstance(amg_k, dict) else amg_k)))
     colour = [-1] * num_robots
@@ -1208,7 +1229,7 @@ def rbcd_coloured(meas: Measurements, n: int, num_robots: int, r: int, X0, sweep
     for _ in range(sweeps):
         for c in range(max(colour) + 1):
             for a in range(num_robots):
-                if colour[a] != c:
+                if colour[a] != c or a in inactive:
                     continue
                 s, e = ranges[a]
                 nbr = {(rob, fr): X[ranges[rob][0] + fr] for rob, fr in agents[a]["need"]}
@@ -1556,13 +1577,16 @@ def local_status(agent_id: int, iteration: int, X, XPrev, success: bool, prm: Ag
 
 
 def should_terminate(iteration: int, prm: AgentParameters, weight_update_count: int, team: Dict[int, AgentStatus],
-                     num_robots: int) -> bool:
-    """PGOAgent::shouldTerminate (src/PGOAgent.cpp:846-878), every robot active."""
+                     num_robots: int, inactive=()) -> bool:
+    """PGOAgent::shouldTerminate (src/PGOAgent.cpp:846-878); robots in `inactive` (PGOAgent::setRobotActive(id, false),
+    :1173-1184) have no vote (:861-862)."""
     if iteration >= prm.maxNumIters:
         return True
     if prm.robust and weight_update_count < prm.robustOptNumWeightUpdates:
         return False
     for rob in range(num_robots):
+        if rob in inactive:
+            continue
         st = team.get(rob)
         if st is None or st.state != "INITIALIZED" or not st.readyToTerminate:
             return False
@@ -1570,8 +1594,8 @@ def should_terminate(iteration: int, prm: AgentParameters, weight_update_count: 
 
 
 def should_update_weights(prm: AgentParameters, weight_update_count: int, inner_iter: int,
-                          latest_update_iteration: int, team: Dict[int, AgentStatus], num_robots: int) -> bool:
-    """PGOAgent::shouldUpdateMeasurementWeights (src/PGOAgent.cpp:997-1045)."""
+                          latest_update_iteration: int, team: Dict[int, AgentStatus], num_robots: int, inactive=()) -> bool:
+    """PGOAgent::shouldUpdateMeasurementWeights (src/PGOAgent.cpp:997-1045); inactive robots are skipped (:1016-1017)."""
     if not prm.robust:
         return False
     if weight_update_count >= prm.robustOptNumWeightUpdates:
@@ -1579,6 +1603,8 @@ def should_update_weights(prm: AgentParameters, weight_update_count: int, inner_
     if inner_iter >= prm.robustOptInnerIters:
         return True
     for rob in range(num_robots):
+        if rob in inactive:
+            continue
         st = team.get(rob)
         if st is None or st.iterationNumber < latest_update_iteration or st.state != "INITIALIZED" \
                 or not st.readyToTerminate:

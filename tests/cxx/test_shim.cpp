@@ -501,7 +501,57 @@ static int run_greedy_scenario(const char* path) {
   return 0;
 }
 
+// Host-only: PoseGraph::setNeighborActive / useInactiveNeighbors (src/PoseGraph.cpp:199-207, 632-634) -- the shared edges
+// with an inactive neighbour leave Q and G (:425-430, :527-532); needs no device.
+static int check_inactive_neighbours() {
+  Matrix I3 = Matrix::Identity(3, 3), t = Matrix::Zero(3, 1);
+  t(0, 0) = 1.0;
+  std::vector<RelativeSEMeasurement> ms = {RelativeSEMeasurement(1, 1, 0, 1, I3, t, 2.0, 3.0),   // odometry of robot 1
+                                           RelativeSEMeasurement(0, 1, 4, 0, I3, t, 5.0, 7.0),   // incoming from robot 0
+                                           RelativeSEMeasurement(1, 2, 1, 6, I3, t, 11.0, 13.0)};  // outgoing to robot 2
+  PoseGraph pg(1, 3, 3), without(1, 3, 3);
+  pg.setMeasurements(ms);
+  without.setMeasurements({ms[0], ms[1]});
+  REQUIRE(pg.hasNeighbor(0) && pg.hasNeighbor(2) && !pg.hasNeighbor(3) && pg.isNeighborActive(2));
+  const auto full = pg.quadraticMatrix().vals;
+  const unsigned long v0 = pg.qVersion();
+  pg.setNeighborActive(3, false);  // not a neighbour: ignored
+  pg.setNeighborActive(2, true);   // unchanged: nothing dropped
+  REQUIRE(pg.qVersion() == v0);
+  pg.setNeighborActive(2, false);
+  REQUIRE(pg.qVersion() > v0 && !pg.isNeighborActive(2) && pg.activeNeighborIDs() == std::set<unsigned>({0}));
+  const auto& q1 = pg.quadraticMatrix().vals;
+  const auto& q2 = without.quadraticMatrix().vals;
+  REQUIRE(q1.size() == q2.size() && q1.size() == full.size());
+  double dmax = 0.0, dfull = 0.0;
+  for (size_t k = 0; k < q1.size(); ++k) {
+    dmax = std::max(dmax, std::fabs(q1[k] - q2[k]));
+    dfull = std::max(dfull, std::fabs(q1[k] - full[k]));
+  }
+  REQUIRE(dmax == 0.0 && dfull > 1.0);
+  Matrix X0(3, 4);
+  for (unsigned a = 0; a < 3; ++a) X0(a, a) = 1.0;
+  pg.setNeighborPoses({{PoseGraph::PoseID(0, 4), X0}});  // robot 2's pose is NOT required any more
+  without.setNeighborPoses({{PoseGraph::PoseID(0, 4), X0}});
+  const Matrix &G1 = pg.linearMatrix(), &G2 = without.linearMatrix();
+  for (size_t k = 0; k < (size_t)G1.rows() * G1.cols(); ++k) REQUIRE(G1.data()[k] == G2.data()[k]);
+  pg.setNeighborActive(2, true);
+  pg.setNeighborPoses({{PoseGraph::PoseID(0, 4), X0}});
+  bool threw = false;
+  try {
+    pg.linearMatrix();
+  } catch (const Error&) {
+    threw = true;  // "Missing active neighbor pose" (:523-526)
+  }
+  REQUIRE(threw);
+  const auto& q3 = pg.quadraticMatrix().vals;
+  for (size_t k = 0; k < q3.size(); ++k) REQUIRE(q3[k] == full[k]);
+  std::printf("inactive neighbours: ok\n");
+  return 0;
+}
+
 int main(int argc, char** argv) {
+  if (check_inactive_neighbours() != 0) return 1;
   int count = 0;
   if (dpgo_device_count(&count) != DPGO_OK || count < 1) {
     // still exercise the failure path: creation must fail with DPGO_ERR_HIP, never fall back

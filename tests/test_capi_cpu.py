@@ -139,6 +139,75 @@ def test_partition_and_coupling_match_oracle(oracle):
         assert np.abs(Gt - Ga).max() <= 1e-12 * np.abs(Ga).max()
 
 
+def test_inactive_neighbours_leave_the_data_matrices(oracle):
+    """PoseGraph::setNeighborActive (src/PoseGraph.cpp:199-207) as PGOAgent::setRobotActive drives it (:1173-1184): the
+    shared edges with an inactive neighbour are skipped by constructQ / constructG (:425-430, :527-532) -- unless
+    useInactiveNeighbors is set and the pose is known --, the data matrices are dropped when the flag changes, the missing-
+    pose check applies to ACTIVE neighbours only.  Product host code against the oracle's restatement."""
+    import dpgo_amd
+    path = os.path.join(DATA, "smallGrid3D.g2o")
+    om, n = oracle.read_g2o(path)
+    pm, _ = dpgo_amd.read_g2o_file(path)
+    ranges, per = oracle.partition_contiguous(om, n, 5)
+    _, per_p = dpgo_amd.partition_contiguous(pm, n, 5)
+    r, d, a = 5, 3, 2
+    X = oracle.polar_project(np.random.default_rng(1).standard_normal((n, d + 1, r)), d)
+    s, e = ranges[a]
+    pg = dpgo_amd.PoseGraph(a, r, d)
+    pg.setMeasurements(per_p[a])
+    nbrs = sorted({rob for rob, _ in pg.neighborPoseIDs()})
+    assert nbrs == [1, 3] and pg.activeNeighborIDs() == nbrs and pg.hasNeighbor(1) and not pg.hasNeighbor(4)
+    v0 = pg.q_version
+    pg.setNeighborActive(4, False)  # not a neighbour: ignored (:200-202)
+    pg.setNeighborActive(1, True)   # unchanged: nothing dropped
+    assert pg.q_version == v0
+    pg.setNeighborActive(3, False)
+    assert pg.q_version > v0 and not pg.isNeighborActive(3) and pg.activeNeighborIDs() == [1]
+    assert all(rob == 1 for rob, _ in pg.activeNeighborPublicPoseIDs())
+    priv = oracle.Measurements.concat([per[a]["odometry"], per[a]["private"]])
+    sh = oracle.active_shared_edges(per[a]["shared"], a, {3})
+    assert 0 < sh.m < per[a]["shared"].m
+    Qa = oracle.construct_Q(e - s, d, priv, sh, my_id=a)
+    rp, ci, v = pg.quadraticMatrix()
+    assert np.array_equal(rp, Qa.rowptr) and np.array_equal(ci, Qa.colidx)
+    assert np.abs(v - Qa.vals).max() <= 1e-12 * np.abs(Qa.vals).max()
+    Qfull = oracle.construct_Q(e - s, d, priv, per[a]["shared"], my_id=a)
+    assert np.abs(v - Qfull.vals).max() > 1e-3 * np.abs(Qfull.vals).max()  # the edges really left
+    # G: only the ACTIVE neighbour's poses are required
+    act = {pid: X[ranges[pid[0]][0] + pid[1]] for pid in pg.neighborPoseIDs() if pid[0] == 1}
+    pg.setNeighborPoses({k: t.T for k, t in act.items()})
+    Gt = np.ascontiguousarray(pg.linearMatrix().T).reshape(e - s, d + 1, r)
+    Ga = oracle.construct_G(e - s, d, r, sh, a, act)
+    assert np.abs(Gt - Ga).max() <= 1e-12 * np.abs(Ga).max()
+    # useInactiveNeighbors: an inactive neighbour's edge whose pose is known stays in the problem
+    every = {pid: X[ranges[pid[0]][0] + pid[1]] for pid in pg.neighborPoseIDs()}
+    pg.useInactiveNeighbors(True)
+    pg.setNeighborPoses({k: t.T for k, t in every.items()})
+    rp2, ci2, v2 = pg.quadraticMatrix()
+    assert np.abs(v2 - Qfull.vals).max() <= 1e-12 * np.abs(Qfull.vals).max()
+    Gfull = oracle.construct_G(e - s, d, r, per[a]["shared"], a, every)
+    assert np.abs(np.ascontiguousarray(pg.linearMatrix().T).reshape(e - s, d + 1, r) - Gfull).max() <= 1e-12 * np.abs(Gfull).max()
+    # back to active: the full matrices again, and the missing-pose check with them
+    pg.useInactiveNeighbors(False)
+    pg.setNeighborActive(3, True)
+    pg.setNeighborPoses({k: t.T for k, t in act.items()})
+    assert np.abs(pg.quadraticMatrix()[2] - Qfull.vals).max() <= 1e-12 * np.abs(Qfull.vals).max()
+    with pytest.raises(LookupError):
+        pg.linearMatrix()
+    # the votes skip inactive robots (src/PGOAgent.cpp:861-862, 1016-1017), product rules = oracle rules
+    from dpgo_amd.agent import PGOAgentParameters, PGOAgentStatus, should_terminate, should_update_measurement_weights
+    prm, oprm = PGOAgentParameters(), oracle.AgentParameters()
+    team = {q: PGOAgentStatus(q, "INITIALIZED", 0, 7, q != 3, 0.0) for q in range(5)}
+    oteam = {q: oracle.AgentStatus(q, "INITIALIZED", 0, 7, q != 3, 0.0) for q in range(5)}
+    for off in ((), (3,), (2,)):
+        assert should_terminate(7, prm, 0, team, 5, off) == oracle.should_terminate(7, oprm, 0, oteam, 5, off) == (off == (3,))
+    from dataclasses import replace
+    rprm, orprm = replace(prm, robust=True), oracle.AgentParameters(**{**oprm.__dict__, "robust": True})
+    for off in ((), (3,)):
+        assert should_update_measurement_weights(rprm, 0, 1, 0, team, 5, off) == \
+            oracle.should_update_weights(orprm, 0, 1, 0, oteam, 5, off) == (off == (3,))
+
+
 def test_duplicate_and_irrelevant_edges(oracle):
     """PoseGraph::addMeasurement drops irrelevant edges (src/PoseGraph.cpp:68-71) and duplicates (:83-88)."""
     import dpgo_amd

@@ -25,6 +25,7 @@ def test_cxx_shim_compiles_and_refuses_without_device(tmp_path):
         pytest.skip("a GPU is present (covered by the gpu test)")
     p = subprocess.run([exe], capture_output=True, text=True)
     assert p.returncode == 77, p.stdout + p.stderr  # DPGO_ERR_HIP, no CPU fallback
+    assert "inactive neighbours: ok" in p.stdout  # (host-only part: PoseGraph::setNeighborActive)
 
 
 def _write_greedy_scenario(path):
@@ -73,7 +74,7 @@ def test_cxx_shim_reference_known_answers(tmp_path):
     want = _write_greedy_scenario(scenario)
     p = subprocess.run([exe, scenario], capture_output=True, text=True)
     assert p.returncode == 0, p.stdout + p.stderr
-    assert "lifted variable: ok" in p.stdout
+    assert "lifted variable: ok" in p.stdout and "inactive neighbours: ok" in p.stdout
     assert "greedy: %d iterations" % want["iterations"] in p.stdout  # same selection sequence as the Python driver
     assert "triangle" in p.stdout and "prior" in p.stdout and "project: ok" in p.stdout
     assert "rounding" in p.stdout and "robust: inlier" in p.stdout and "robust: outlier" in p.stdout

@@ -1127,6 +1127,39 @@ def test_two_processes_exchange_through_mapped_buffers_on_one_gpu(workload, swee
     assert kv["decrease"] == "1" and float(kv["exchange_ms_per_sweep"]) > 0.0
 
 
+def test_inactive_robot_leaves_the_team(oracle):
+    """PGOAgent::setRobotActive(id, false) (src/PGOAgent.cpp:1173-1184) on the device path: robot 3 of smallGrid3D / 5 is
+    switched off after two sweeps -- it stops updating, its neighbours (2 and 4) rebuild Q and the coupling blocks
+    without the shared edges (values only, on the device), the sweeps go on -- and switched on again; every stage against
+    the oracle's coloured RBCD with the same activity sets (same iterates to 1e-7, same cost)."""
+    import dpgo_amd
+    from dpgo_amd.agent import DeviceAgent, ExchangePlan, RBCDCluster, build_pose_graphs
+    r, robots = 5, 5
+    om, n = oracle.read_g2o(os.path.join(DATA, "smallGrid3D.g2o"))
+    X0 = oracle.lift(oracle.chordal_initialization(om, n), r)
+    ranges, graphs = build_pose_graphs(to_product_measurements(om), n, robots, r)
+    plan = ExchangePlan(graphs)
+    agents = {a: DeviceAgent(graphs, plan, a, X0[ranges[a][0]:ranges[a][1]], dpgo_amd.ROptParameters(precond="jacobi"))
+              for a in range(robots)}
+    cluster = RBCDCluster(plan, agents)
+    mode = device_tcg_mode(n // robots, om.d, r)
+    Xo = X0
+    for inactive, sweeps in (((), 2), ((3,), 3), ((), 2)):
+        cluster.set_robot_active(3, 3 not in inactive)
+        assert agents[2].pg.isNeighborActive(3) == (3 not in inactive) and agents[0].isRobotActive(3) == (3 not in inactive)
+        Xo, costs, gns = oracle.rbcd_coloured(om, n, robots, r, Xo, sweeps, hess_recurrence=mode, precond="jacobi",
+                                              inactive=inactive)
+        before = agents[3].X.clone()
+        for _ in range(sweeps):
+            cluster.sweep()
+        X = np.concatenate([agents[a].X.cpu().numpy() for a in range(robots)], axis=0)
+        assert relerr(X, Xo) < 1e-7, inactive
+        if inactive:
+            assert bool((agents[3].X == before).all())  # the inactive robot did not move
+        f, g = cluster.central_cost_and_gradnorm()
+        assert abs(2 * f - costs[-1]) <= 1e-9 * abs(costs[-1])
+
+
 def test_external_stream_ordering_is_deterministic(oracle):
     """Regression: work of a handle bound to torch's current stream (the NULL / default stream) is ordered
     with torch ops on that stream -- restoring an iterate with tensor.copy_ and solving again gives the
