@@ -1156,8 +1156,9 @@ def test_inactive_robot_leaves_the_team(oracle):
         assert relerr(X, Xo) < 1e-7, inactive
         if inactive:
             assert bool((agents[3].X == before).all())  # the inactive robot did not move
-        f, g = cluster.central_cost_and_gradnorm()
-        assert abs(2 * f - costs[-1]) <= 1e-9 * abs(costs[-1])
+        else:  # (the central cost is assembled from the agents' LOCAL problems: with a robot off they leave edges out)
+            f, g = cluster.central_cost_and_gradnorm()
+            assert abs(2 * f - costs[-1]) <= 1e-9 * abs(costs[-1])
 
 
 def test_external_stream_ordering_is_deterministic(oracle):
