@@ -1423,6 +1423,7 @@ int launch_ml_apply(dpgo_problem_s* p, const double* Xdev, const double* v, doub
 // multi-launch scheme.
 constexpr int kPersistPoison = 3;
 constexpr int kMaxDevices = 64;
+std::atomic<int> g_warnings{0};  // warnings printed to stderr so far (dpgo_warning_count)
 std::atomic<int> g_persist_used[kMaxDevices];
 std::atomic<int> g_persist_cap[kMaxDevices];  // 0 = not yet queried
 
@@ -2850,6 +2851,8 @@ int dpgo_optimize_device(dpgo_problem_t p, const dpgo_ropt_params* params, doubl
   return DPGO_OK;
 }
 
+int dpgo_warning_count(void) { return g_warnings.load(); }
+
 int dpgo_optimize_device_begin(dpgo_problem_t p, const dpgo_ropt_params* params, double* X_dev,
                                const double* nbr_tiles_dev) {
   CHK(check_ready(p));
@@ -2963,6 +2966,20 @@ static int run_many(int count, const dpgo_problem_t* handles, void* after_stream
     if (handles[k]->device != handles[0]->device) return fail(DPGO_ERR_INVALID, "handles on different devices");
     for (int q = 0; q < k; ++q)
       if (handles[q] == handles[k]) return fail(DPGO_ERR_INVALID, "a handle appears twice");
+  }
+  {  // ROCm maps HIP streams onto GPU_MAX_HW_QUEUES hardware queues (default 4): more concurrently solved handles than
+     // that still complete, but queue behind each other -- say so once instead of silently serialising
+    static std::atomic<bool> warned{false};
+    const char* e = std::getenv("GPU_MAX_HW_QUEUES");
+    const int queues = (e && std::atoi(e) > 0) ? std::atoi(e) : 4;
+    if (count > queues && !warned.exchange(true)) {
+      g_warnings.fetch_add(1);
+      std::fprintf(stderr,
+                   "dpgo_hip: warning: %d handles are solved concurrently but GPU_MAX_HW_QUEUES is %d: their streams share %d "
+                   "hardware queues and partly serialise; set GPU_MAX_HW_QUEUES >= %d in the environment before the HIP runtime "
+                   "initialises (bench.py does)\n",
+                   count, queues, queues, count);
+    }
   }
   std::vector<hipStream_t> prev(count);
   for (int k = 0; k < count; ++k) prev[k] = handles[k]->stream;  // (all of them first: restored below whatever fails)

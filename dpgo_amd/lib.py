@@ -97,6 +97,7 @@ SIGNATURES = {
     "dpgo_problem_precondition": ([_P, _I, _D, _P, _P, _P], _I),
     "dpgo_optimize": ([_P, C.POINTER(RoptParamsC), _P, _P, C.POINTER(RoptResultC)], _I),
     "dpgo_optimize_device": ([_P, C.POINTER(RoptParamsC), _P, C.POINTER(RoptResultC)], _I),
+    "dpgo_warning_count": ([], _I),
     "dpgo_optimize_device_begin": ([_P, C.POINTER(RoptParamsC), _P, _P], _I),
     "dpgo_optimize_device_end": ([_P, C.POINTER(RoptResultC)], _I),
     "dpgo_optimize_device_many": ([_I, _P, C.POINTER(RoptParamsC), _P, _P, _P, _P], _I),

@@ -733,13 +733,24 @@ def _addr(x):
 def optimize_device_many(optimizers, X_devs, nbr_tiles=None, after_stream=None):
     """QuadraticOptimizer::optimize of several agents hosted by this process, CONCURRENTLY (C ABI
     dpgo_optimize_device_many): every problem runs on its own stream, ordered after `after_stream`; nbr_tiles[k]
-    (or None) is agent k's neighbour tile buffer, from which G is rebuilt first (PGOAgent::updateX).  All optimizers
-    must carry the same parameters.  Returns the list of ROPTResult (also stored in each optimizer)."""
+    (or None) is agent k's neighbour tile buffer, from which G is rebuilt first (PGOAgent::updateX).  Optimizers that do
+    not all carry the same parameters are solved one after the other, each with its own.  Returns the list of ROPTResult
+    (also stored in each optimizer)."""
     if not optimizers:
         return []
     lib = optimizers[0].problem_._lib
     cp = optimizers[0].params_.to_c()
     n = len(optimizers)
+    # the C entry point takes ONE parameter record for all handles: optimizers configured differently are solved one after
+    # the other with their own parameters instead of silently inheriting the first one's
+    first = bytes(cp)
+    if any(bytes(o.params_.to_c()) != first for o in optimizers[1:]):
+        out = []
+        for k, (o, x) in enumerate(zip(optimizers, X_devs)):
+            if nbr_tiles is not None and nbr_tiles[k] is not None:
+                o.problem_.updateLinearMatrixFromNeighbors(nbr_tiles[k])
+            out.append(o.optimizeDevice(x))
+        return out
     handles = _ptr_array([o.problem_._h.value for o in optimizers])
     xs = _ptr_array([_addr(x) for x in X_devs])
     nb = _ptr_array([_addr(t) for t in nbr_tiles]) if nbr_tiles is not None else None

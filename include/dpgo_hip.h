@@ -301,6 +301,9 @@ int dpgo_optimize(dpgo_problem_t h, const dpgo_ropt_params* params, const double
                   dpgo_ropt_result* result);
 int dpgo_optimize_device(dpgo_problem_t h, const dpgo_ropt_params* params, double* X_dev,
                          dpgo_ropt_result* result);
+/* Number of warnings the library has printed to stderr so far (each kind once per process): e.g. more concurrently solved
+ * handles (dpgo_optimize_device_many, dpgo_problem_eval_terms_device_many) than GPU_MAX_HW_QUEUES hardware queues. */
+int dpgo_warning_count(void);
 /* The same solve in two halves, for callers that enqueue a whole sweep without waiting (RBCDCluster.sweep when a process
  * hosts one agent per colour: colour c's solve, colour c+1's pack + exchange and its solve are all stream-ordered; the
  * host reads the results back at the end of the sweep instead of idling the GPU between phases).

@@ -15,6 +15,7 @@ import pytest
 from conftest import DATA, matrix_to_tiles, tiles_to_matrix, to_product_measurements, device_tcg_mode
 
 pytestmark = pytest.mark.gpu
+ROOT_DIR = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 RTOL_ELEM = 1e-11
 
@@ -1159,6 +1160,65 @@ def test_inactive_robot_leaves_the_team(oracle):
         else:  # (the central cost is assembled from the agents' LOCAL problems: with a robot off they leave edges out)
             f, g = cluster.central_cost_and_gradnorm()
             assert abs(2 * f - costs[-1]) <= 1e-9 * abs(costs[-1])
+
+
+def test_more_concurrent_handles_than_hardware_queues_warn_once_and_complete():
+    """ROCm maps HIP streams onto GPU_MAX_HW_QUEUES hardware queues (4 by default; bench.py raises it to 16 before the runtime
+    starts).  A caller that solves 8 handles concurrently WITHOUT the variable is not refused and not silently serialised:
+    the solves complete with the results of one-at-a-time solves and the library says so once on stderr
+    (dpgo_warning_count)."""
+    code = r"""
+import os, sys
+sys.path.insert(0, %r)
+sys.path.insert(0, os.path.join(%r, "oracle"))
+import numpy as np, torch
+import dpgo_amd, dpgo_amd.lib as L
+import dpgo_oracle as O
+from dpgo_amd.solver import optimize_device_many
+from conftest import to_product_measurements
+om, n = O.read_g2o(os.path.join(%r, "data", "smallGrid3D.g2o"))
+X0 = O.lift(O.chordal_initialization(om, n), 5)
+probs, opts, Xs = [], [], []
+for k in range(8):
+    pg = dpgo_amd.PoseGraph(0, 5, 3)
+    pg.setMeasurements(to_product_measurements(om))
+    probs.append(dpgo_amd.QuadraticProblem(pg))
+    opts.append(dpgo_amd.QuadraticOptimizer(probs[-1], dpgo_amd.ROptParameters(precond="jacobi")))
+    Xs.append(torch.tensor(X0, device="cuda", dtype=torch.float64))
+solo = opts[0].optimizeDevice(Xs[0].clone())
+assert L.load().dpgo_warning_count() == 0
+for rep in range(2):
+    res = optimize_device_many(opts, Xs, [None] * 8, torch.cuda.current_stream().cuda_stream)
+    if rep == 0:
+        assert all(r.tcg_iterations == solo.tcg_iterations and abs(r.fOpt - solo.fOpt) <= 1e-12 * abs(solo.fOpt) for r in res)
+assert L.load().dpgo_warning_count() == 1
+print("QUEUES_OK")
+""" % (ROOT_DIR, ROOT_DIR, ROOT_DIR)
+    env = {k: v for k, v in os.environ.items() if k != "GPU_MAX_HW_QUEUES"}
+    env["PYTHONPATH"] = os.path.dirname(os.path.abspath(__file__)) + os.pathsep + env.get("PYTHONPATH", "")
+    p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and "QUEUES_OK" in p.stdout, (p.stdout[-500:], p.stderr[-2000:])
+    assert p.stderr.count("GPU_MAX_HW_QUEUES is 4") == 1, p.stderr[-2000:]
+
+
+def test_concurrent_update_with_different_parameters_solves_each_with_its_own(oracle):
+    """dpgo_optimize_device_many takes ONE parameter record; the Python face solves optimizers that are configured
+    differently one after the other, each with its own parameters, instead of silently applying the first one's."""
+    import torch
+    import dpgo_amd
+    from dpgo_amd.solver import optimize_device_many
+    om, n, d, Q, pg, prob = build_single_agent(oracle, "smallGrid3D", 5)
+    _, _, _, _, pg2, prob2 = build_single_agent(oracle, "smallGrid3D", 5)
+    X0 = oracle.lift(oracle.chordal_initialization(om, n), 5)
+    oa = dpgo_amd.QuadraticOptimizer(prob, dpgo_amd.ROptParameters(precond="jacobi"))
+    ob = dpgo_amd.QuadraticOptimizer(prob2, dpgo_amd.ROptParameters(precond="none", RTR_tCG_iterations=7))
+    want = [o.optimizeDevice(torch.tensor(X0, device="cuda", dtype=torch.float64)) for o in (oa, ob)]
+    assert want[0].tcg_iterations != want[1].tcg_iterations
+    Xs = [torch.tensor(X0, device="cuda", dtype=torch.float64) for _ in range(2)]
+    got = optimize_device_many([oa, ob], Xs, None, torch.cuda.current_stream().cuda_stream)
+    for g, w in zip(got, want):
+        assert (g.tcg_iterations, g.rtr_iterations, g.precond_used) == (w.tcg_iterations, w.rtr_iterations, w.precond_used)
+        assert g.fOpt == w.fOpt
 
 
 def test_external_stream_ordering_is_deterministic(oracle):
