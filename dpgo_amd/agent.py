@@ -707,11 +707,19 @@ class RBCDCluster:
             # wait in between (a one-launch solve needs no host feed); the results are read back at the end of the sweep
             # instead of leaving the GPU idle for a host round trip per phase
             begun = []
-            for c in range(self.plan.num_colours):
-                self.exchange(receivers=c)
-                for a in self._active_ids(c):
-                    self.agents[a].update_begin()
-                    begun.append(a)
+            try:
+                for c in range(self.plan.num_colours):
+                    self.exchange(receivers=c)
+                    for a in self._active_ids(c):
+                        self.agents[a].update_begin()
+                        begun.append(a)
+            except Exception:
+                for a in begun:  # never leave a solve in flight behind an error: the handles would refuse the next begin
+                    try:
+                        self.agents[a].update_end()
+                    except Exception:
+                        pass
+                raise
             for a in begun:
                 self.agents[a].update_end()
             return

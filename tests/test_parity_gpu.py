@@ -806,7 +806,7 @@ def test_additive_preconditioner_matches_oracle(oracle, name, r):
     if plan["lane_groups"] == 4:
         assert (plan["ks"], plan["tile"]) == ([-k], k), plan
     else:
-        assert plan["tile"] == 4 * k and plan["graph"] and len(plan["ks"]) == 2, plan
+        assert plan["tile"] == (64 // (d + 1)) * 4 and plan["graph"] and len(plan["ks"]) == 2, plan  # 64 poses; 84 in 2-D
         assert -plan["ks"][1] == min(plan["tile"], plan["growth"] + plan["growth"] // 2)
     ks = plan["ks"]
     op = oracle.QuadraticProblem(Q, None, r, d, precond="amg_additive", amg_k=ks)
