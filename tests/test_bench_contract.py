@@ -141,3 +141,25 @@ def test_bench_multi_gpu_branch_runs_at_world_size_one():
     assert "torch.distributed process group" in j["config"]["schedule"]
     assert j["quality"]["exchange_ms_per_step_rank0"] > 0 and j["value"] > 0 and j["steps"] == 3
     assert j["quality"]["cost_2f_after_step"] < j["quality"]["cost_2f_trajectory"][0]
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_on_one_gpu_through_the_peer_store():
+    """bench.py with TWO ranks (torch.distributed.run --nproc-per-node 2, both on device 0) and --transport ipc: gloo process
+    group, 2 agents per rank, the public poses written by the senders' pack kernels straight into the receivers'
+    hipIpc-mapped neighbour buffers (dpgo_amd/ipc.py), barrier + max-over-ranks timing, rank 0 prints the line."""
+    port = 29500 + ((os.getpid() + 211) % 400)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--transport", "ipc",
+           "--workload", "grid:12x10x8", "--steps", "3", "--warmup", "1", "--settle", "1", "--no-cpu-baseline",
+           "--no-secondary", "--spmm-reps", "10"]
+    p = subprocess.run(cmd, capture_output=True, text=True, cwd=ROOT, timeout=900,
+                       env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1  # rank 0 only
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["config"]["agents"] == 4 and j["config"]["agents_per_gpu"] == 2
+    assert j["config"]["dist_backend"] == "gloo" and j["config"]["transport"] == "ipc" and "peer store" in j["config"]["schedule"]
+    assert j["quality"]["exchange_ms_per_step_rank0"] > 0 and j["value"] > 0 and j["scaling"] == "strong"
+    assert j["quality"]["cost_2f_after_step"] < j["quality"]["cost_2f_trajectory"][0]
