@@ -440,6 +440,18 @@ class QuadraticProblem {
     check(dpgo_problem_multilevel_info(h_, &nl, nullptr, nullptr, nullptr));
     return nl;
   }
+  // Layout precond = DPGO_PRECOND_ADDITIVE (and AUTO, in the one-launch regime) uses for this block: lane groups per pose of
+  // the kernel (0: the block does not fit 256 aggregates of one workgroup tile), slots per aggregate, growth size and merge
+  // bound of the graph aggregates, number of aggregates = workgroups (dpgo_problem_additive_plan; host only).
+  struct AdditivePlan {
+    int lane_groups = 0, tile = 0, growth = 0, merge_cap = 0, aggregates = 0, graph = 0;
+  };
+  AdditivePlan additivePlan() {
+    refresh();
+    AdditivePlan a;
+    check(dpgo_problem_additive_plan(h_, &a.lane_groups, &a.tile, &a.growth, &a.merge_cap, &a.aggregates, &a.graph));
+    return a;
+  }
   // Storage of the dense coarsest level (64 bits by default, 32 = opt-in) and of Q for its products (DPGO_SPMM_*; the
   // default picks the half-size symmetric storage for blocks that no longer fit the Infinity Cache).  See dpgo_hip.h.
   int multilevelCoarseBits(int bits = -1) {
@@ -516,6 +528,24 @@ class QuadraticOptimizer {
     dpgo_ropt_params c = params_.to_c();
     dpgo_ropt_result res;
     check(dpgo_optimize_device(problem_->handle(), &c, X_dev, &res));
+    result_ = ROPTResult(res.success != 0, res.fInit, res.gradNormInit, res.fOpt, res.gradNormOpt, res.elapsedMs);
+    result_.tCGStatus = res.tCGStatus;
+    result_.tcgIterations = res.tcg_iterations;
+    result_.precondUsed = res.precond_used;
+    result_.rtrIterations = res.rtr_iterations;
+    return result_;
+  }
+  // The same in two halves (dpgo_optimize_device_begin / _end): `begin` enqueues the solve on the handle's stream when it is a
+  // one-launch solve (G is rebuilt from the neighbour tile buffer first when one is given) and returns; `end` waits and
+  // returns the result.  For callers that enqueue a whole sweep -- exchange, solve, next exchange, next solve -- without a
+  // host wait in between (dpgo_amd/agent.py, RBCDCluster.sweep).
+  void optimizeDeviceBegin(double* X_dev, const double* nbr_tiles_dev = nullptr) {
+    dpgo_ropt_params c = params_.to_c();
+    check(dpgo_optimize_device_begin(problem_->handle(), &c, X_dev, nbr_tiles_dev));
+  }
+  ROPTResult optimizeDeviceEnd() {
+    dpgo_ropt_result res;
+    check(dpgo_optimize_device_end(problem_->handle(), &res));
     result_ = ROPTResult(res.success != 0, res.fInit, res.gradNormInit, res.fOpt, res.gradNormOpt, res.elapsedMs);
     result_.tCGStatus = res.tCGStatus;
     result_.tcgIterations = res.tcg_iterations;

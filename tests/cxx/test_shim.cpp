@@ -344,6 +344,47 @@ static int run() {
     REQUIRE(dm <= 1e-5);
   }
 
+  // ---------------- the solve in two halves (dpgo_optimize_device_begin / _end) and the additive plan through the mirror:
+  // same result as the one-call device solve, the halves refuse to be called out of order
+  {
+    const auto plan = problem.additivePlan();
+    REQUIRE(plan.lane_groups == 4 && plan.tile == 16 && plan.aggregates == 1 && plan.graph == 1);  // 3 poses: one aggregate
+    ROptParameters pm;
+    pm.precond = DPGO_PRECOND_BLOCK_JACOBI;
+    QuadraticOptimizer oa(&problem, pm);
+    const size_t bytes = sizeof(double) * T0.rows() * T0.cols();
+    double *Xa = nullptr, *Xb = nullptr;
+    check(dpgo_device_malloc((void**)&Xa, bytes, 0));
+    check(dpgo_device_malloc((void**)&Xb, bytes, 0));
+    check(dpgo_device_memcpy(Xa, T0.data(), bytes, DPGO_COPY_H2D, nullptr));
+    check(dpgo_device_memcpy(Xb, T0.data(), bytes, DPGO_COPY_H2D, nullptr));
+    const ROPTResult whole = oa.optimizeDevice(Xa);
+    bool threw = false;
+    try {
+      oa.optimizeDeviceEnd();
+    } catch (const Error&) {
+      threw = true;  // nothing in flight
+    }
+    REQUIRE(threw);
+    oa.optimizeDeviceBegin(Xb);
+    threw = false;
+    try {
+      oa.optimizeDeviceBegin(Xb);
+    } catch (const Error&) {
+      threw = true;  // one solve per handle
+    }
+    REQUIRE(threw);
+    const ROPTResult halves = oa.optimizeDeviceEnd();
+    REQUIRE(halves.success && halves.fOpt == whole.fOpt && halves.tcgIterations == whole.tcgIterations);
+    Matrix A(T0.rows(), T0.cols()), Bm(T0.rows(), T0.cols());
+    check(dpgo_device_memcpy(A.data(), Xa, bytes, DPGO_COPY_D2H, nullptr));
+    check(dpgo_device_memcpy(Bm.data(), Xb, bytes, DPGO_COPY_D2H, nullptr));
+    for (size_t q = 0; q < A.rows() * A.cols(); ++q) REQUIRE(A.data()[q] == Bm.data()[q]);
+    check(dpgo_device_free(Xa));
+    check(dpgo_device_free(Xb));
+    std::printf("begin/end: ok\n");
+  }
+
   // ---------------- LiftedSEVariable / LiftedSEVector (tests/testEigenMap.cpp:12-36: the flat storage is the matrix)
   {
     LiftedSEVariable var(5, 3, 7);

@@ -79,3 +79,4 @@ def test_cxx_shim_reference_known_answers(tmp_path):
     assert "triangle" in p.stdout and "prior" in p.stdout and "project: ok" in p.stdout
     assert "rounding" in p.stdout and "robust: inlier" in p.stdout and "robust: outlier" in p.stdout
     assert "precond 1:" in p.stdout and "precond 2:" in p.stdout  # block-Jacobi and multilevel
+    assert "begin/end: ok" in p.stdout  # the solve in two halves + the additive plan through the mirror
