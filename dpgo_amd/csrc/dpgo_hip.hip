@@ -1658,7 +1658,10 @@ int rtr_outer_iteration(dpgo_problem_s* p, const dpgo_ropt_params* prm, const do
   } else {
     // just-in-time feed: stay kAhead iterations ahead of the progress word the device publishes into
     // host-coherent memory; no synchronisation, no copy, at most kAhead wasted (early-exit) iterations
-    const int kAhead = ml ? 2 : 4;  // a multilevel iteration is 5+ launches: waste fewer of them after tCG stops
+    // a multilevel iteration is 5+ launches: waste fewer of them after tCG stops.  (2 is the minimum: iteration j's count
+    // is published by the prologue of iteration j+1's Hessian-step kernel, so one iteration ahead never sees progress --
+    // tried in round 4, the watchdog fires.)
+    const int kAhead = ml ? 2 : 4;
     int enq = 0, last_j = -1;
     auto t_progress = std::chrono::steady_clock::now();
     while (true) {
