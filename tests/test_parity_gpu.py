@@ -1521,6 +1521,12 @@ def test_single_pose_and_two_pose_graphs(oracle):
     opt = dpgo_amd.QuadraticOptimizer(prob, dpgo_amd.ROptParameters(precond="jacobi", gradnorm_tol=1e-9, RTR_iterations=30))
     Xg = matrix_to_tiles(opt.optimize(tiles_to_matrix(X0)), 3)
     assert opt.getOptResult().fOpt < 1e-12  # one edge can be satisfied exactly
+    # ... with every preconditioner (n = 2: one aggregate, a 4 x 4 dense level; the additive form's plan is one workgroup)
+    assert prob.additivePlan()["aggregates"] == 1 and prob.additivePlan()["lane_groups"] == 4
+    for pc in ("none", "multilevel", "additive", "auto"):
+        o2 = dpgo_amd.QuadraticOptimizer(prob, dpgo_amd.ROptParameters(precond=pc, gradnorm_tol=1e-9, RTR_iterations=30))
+        o2.optimize(tiles_to_matrix(X0))
+        assert o2.getOptResult().fOpt < 1e-12 and o2.getOptResult().gradNormOpt < 1e-6, pc
     # single-pose agent: robot 1 owns one pose, linked to robot 0 by one shared edge
     shared = oracle.Measurements(3, z, np.array([1]), np.ones(1, dtype=np.int64), np.array([0]), Rm,
                                  np.array([[1.0, 2.0, 3.0]]), np.array([10.0]), np.array([4.0]), np.ones(1),
@@ -1537,6 +1543,15 @@ def test_single_pose_and_two_pose_graphs(oracle):
     Xa = X0[:1]
     assert abs(prob1.f(tiles_to_matrix(Xa)) - pa.f(Xa)) <= 1e-12 * abs(pa.f(Xa))
     assert relerr(matrix_to_tiles(prob1.RieGrad(tiles_to_matrix(Xa)), 3), pa.rie_grad(Xa)) < RTOL_ELEM
+    # the one-pose block solved with every preconditioner: the same optimum as the oracle's (block-Jacobi is exact on it)
+    oo = oracle.QuadraticOptimizer(oracle.QuadraticProblem(Qa, Ga, 5, 3, precond="jacobi"),
+                                   oracle.ROptParameters(gradnorm_tol=1e-9, RTR_iterations=30))
+    oo.optimize(Xa)
+    for pc in ("jacobi", "none", "multilevel", "additive", "auto"):
+        o1 = dpgo_amd.QuadraticOptimizer(prob1, dpgo_amd.ROptParameters(precond=pc, gradnorm_tol=1e-9, RTR_iterations=30))
+        o1.optimize(tiles_to_matrix(Xa))
+        assert abs(o1.getOptResult().fOpt - oo.result.fOpt) <= 1e-9 * max(abs(oo.result.fOpt), 1.0), pc
+        assert o1.getOptResult().gradNormOpt < 1e-6, pc
 
 
 def _inject_outliers(oracle, om, n, k, seed):
