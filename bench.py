@@ -665,8 +665,10 @@ def main():
         kernels += [
             dict(kernel="k_ml_restrict%s, level 0 (r - A x1 in one pass over Q, P^T, aggregate sums%s)"
                         % (" -> k_ml_agg_sum" if graph else "", ", residual kept" if path["ap"] else ""),
+                 # (graph aggregates: one partial sum per run of same-aggregate poses inside a wave's chunk is written by
+                 # the restriction and read by k_ml_agg_sum -- a pose-sized tile each)
                  bytes_per_launch=qb + 2 * vec + pbb + vec // abs(ml_info["ks"][0]) + (vec if path["ap"] else 0)
-                 + (2 * vec if graph else 0),
+                 + (2 * 8 * r * b_ * int(agent.problem.multilevelGet(0, "restrict_partials")[0]) if graph else 0),
                  avg_launch_us=ms_it[1] * 1e3),
             dense, post]
     for k_ in kernels:

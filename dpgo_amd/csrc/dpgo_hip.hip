@@ -136,7 +136,12 @@ struct dpgo_problem_s {
     // aggregate in discovery order, the spanning tree the prolongation is composed along, P_i^T res_i of every pose
     bool graph = false;
     int32_t *lab = nullptr, *agg_ptr = nullptr, *agg_mem = nullptr, *parent = nullptr, *pslot = nullptr;
-    int32_t* mem_pos = nullptr;    // position of every pose in agg_mem (where k_ml_restrict writes its P_i^T res_i)
+    int32_t* mem_pos = nullptr;    // position of every pose in agg_mem (k_ml_build_P_tree_wave)
+    // restriction of graph aggregates: inside the G consecutive poses a wave of k_ml_restrict owns, every RUN of poses with
+    // the same aggregate is added up in the wave and leaves ONE partial sum; seg_info[i] = slot * 32 + length for the first
+    // pose of a run (-1 otherwise), slots ordered by aggregate, seg_ptr[a] .. seg_ptr[a+1] = the partial sums of aggregate a
+    int32_t *seg_info = nullptr, *seg_ptr = nullptr;
+    int nseg = 0;  // partial sums per restriction
     int32_t* tile_perm = nullptr;  // aggregates of at most one persistent tile: pose of every (aggregate, slot), -1 = empty
     int perm_tile = 0;             // slots per aggregate in tile_perm
     int merge_cap = 0;             // graph aggregates: fragments merged up to this many poses (0: plain greedy growth)
@@ -730,7 +735,8 @@ void ml_free(dpgo_problem_s* p) {
   for (auto& L : p->ml) {
     free_bsr(L.A);
     free_bsr(L.AP);
-    void* ptrs[] = {L.slot_row, L.dinv, L.Pb, L.r, L.x1, L.x, L.res1, L.lab, L.agg_ptr, L.agg_mem, L.parent, L.pslot, L.tbuf, L.tile_perm, L.mem_pos};
+    void* ptrs[] = {L.slot_row, L.dinv, L.Pb, L.r, L.x1, L.x, L.res1, L.lab, L.agg_ptr, L.agg_mem, L.parent, L.pslot, L.tbuf, L.tile_perm, L.mem_pos,
+                    L.seg_info, L.seg_ptr};
     for (void* q : ptrs)
       if (q) (void)hipFree(q);
   }
@@ -914,6 +920,27 @@ int ml_symbolic_setup(dpgo_problem_s* p, const std::vector<int>& ks_in, int perm
       std::vector<int32_t> mpos(cur);
       for (int m = 0; m < cur; ++m) mpos[mem[m]] = m;
       CHK(upload(&L.mem_pos, mpos.data(), mpos.size(), p->stream));
+      std::vector<int32_t> seg_info(cur, -1), seg_ptr(na + 1, 0);
+      {  // runs of equal labels inside the level-0 kernels' wave chunks (G consecutive poses)
+        const int G = 64 / (b * L.split);
+        std::vector<std::pair<int32_t, int32_t>> runs;  // (aggregate, first pose), in pose order
+        for (int i = 0; i < cur;) {
+          int j = i + 1;
+          while (j < cur && j % G != 0 && lab[j] == lab[i]) ++j;
+          runs.emplace_back(lab[i], i);
+          seg_info[i] = j - i;  // (length for now)
+          i = j;
+        }
+        std::stable_sort(runs.begin(), runs.end(), [](const auto& x, const auto& y) { return x.first < y.first; });
+        for (size_t q = 0; q < runs.size(); ++q) {
+          seg_info[runs[q].second] += (int32_t)q * 32;
+          seg_ptr[runs[q].first + 1] += 1;
+        }
+        for (int a = 0; a < na; ++a) seg_ptr[a + 1] += seg_ptr[a];
+        L.nseg = (int)runs.size();
+      }
+      CHK(upload(&L.seg_info, seg_info.data(), seg_info.size(), p->stream));
+      CHK(upload(&L.seg_ptr, seg_ptr.data(), seg_ptr.size(), p->stream));
       std::vector<int32_t> tperm;
       // the layout of the additive preconditioner's persistent kernel: aggregate = workgroup tile of `perm_tile` slots
       if (!perm_tile && !merge_cap && L.k == additive_tile(p)) perm_tile = L.k;
@@ -1307,7 +1334,8 @@ int launch_dense_sym(dpgo_problem_s* p, const dpgo_problem_s::MlLevel& C, const 
 }
 
 // Level-0 restriction of the cycle: rc = P^T (r - A x1) into ml[1].r (+ the residual itself for k_ml_post_ap).  Graph
-// aggregates: the restriction kernel writes P_i^T res_i per pose, k_ml_agg_sum adds the members up.
+// aggregates: the restriction kernel adds P_i^T res_i up over every run of same-aggregate poses inside a wave's chunk and
+// writes one partial sum per run, k_ml_agg_sum adds an aggregate's partial sums up.
 int launch_ml_restrict0(dpgo_problem_s* p, const double* r, const DevState* gate, int g0) {
   auto& L = p->ml[0];
   auto& C = p->ml[1];
@@ -1317,14 +1345,14 @@ int launch_ml_restrict0(dpgo_problem_s* p, const double* r, const DevState* gate
   if (p->tcg_sym) {  // level 0 reads Q: the symmetric copy when the tCG-step kernel does
     DISPATCH(p->d, p->r, hipLaunchKernelGGL((k_ml_restrict<D, R, 1, BsrSymDev>), dim3(g0), dim3(kBlock), 0, p->stream,
                                             p->sym.dev(), L.x1, r, L.Pb, p->ml_shift, L.k, C.r, rc32, dnext, p->ml_omega,
-                                            C.x1, gate, L.n, res_out, L.tbuf, L.mem_pos));
+                                            C.x1, gate, L.n, res_out, L.tbuf, L.seg_info));
   } else {
     DISPATCH(p->d, p->r, LAUNCH_SPLIT(p, k_ml_restrict, g0, p->Q.dev(), L.x1, r, L.Pb, p->ml_shift, L.k, C.r, rc32, dnext,
-                                      p->ml_omega, C.x1, gate, L.n, res_out, L.tbuf, L.mem_pos));
+                                      p->ml_omega, C.x1, gate, L.n, res_out, L.tbuf, L.seg_info));
   }
   if (L.graph)
     DISPATCH(p->d, p->r, hipLaunchKernelGGL((k_ml_agg_sum<D, R>), dim3(std::min(C.n, kMaxGrid)), dim3(kBlock), 0, p->stream,
-                                            L.tbuf, L.agg_ptr, C.n, C.r, rc32, gate));
+                                            L.tbuf, L.seg_ptr, C.n, C.r, rc32, gate));
   HIPC(hipGetLastError());
   return DPGO_OK;
 }
@@ -2640,6 +2668,11 @@ int dpgo_problem_multilevel_get(dpgo_problem_t p, int level, int what, void* out
     case DPGO_ML_AP_NNZB: {
       if (!L.AP.vals) return fail(DPGO_ERR_INVALID, "this level does not hold that item");
       *static_cast<int32_t*>(out_host) = L.AP.nnzb;
+      return DPGO_OK;
+    }
+    case DPGO_ML_RESTRICT_PARTIALS: {
+      if (!L.graph) return fail(DPGO_ERR_INVALID, "this level does not hold that item");
+      *static_cast<int32_t*>(out_host) = L.nseg;
       return DPGO_OK;
     }
     case DPGO_ML_DENSE_INVERSE: {

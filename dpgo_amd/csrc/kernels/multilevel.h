@@ -68,9 +68,9 @@ __global__ __launch_bounds__(kBlock) void k_ml_restrict(MAT A, const double* __r
                                                         int n, double* __restrict__ res_out = nullptr,
                                                         double* __restrict__ tbuf = nullptr,
                                                         const int32_t* __restrict__ tpos = nullptr) {
-  // tbuf (graph aggregates: their members are anywhere): P_i^T res_i of every node is written out instead of summed
-  // here -- to position tpos[i], its place in the member list, so that k_ml_agg_sum reads every aggregate as one
-  // contiguous run
+  // tbuf (graph aggregates: their members are anywhere): partial sums of P_i^T res_i over runs of same-aggregate nodes
+  // are written out instead of the aggregate's sum -- to the slots tpos encodes, ordered by aggregate, so that
+  // k_ml_agg_sum reads every aggregate's partial sums as one contiguous run
   using GEO = Geo<D, R, SPLIT>;
   if (gate && (gate->tcg_done || gate->rtr_stop)) return;
   __shared__ double res_s[kWaves][GEO::G][GEO::T];  // residual tiles (per wave)
@@ -110,14 +110,29 @@ __global__ __launch_bounds__(kBlock) void k_ml_restrict(MAT A, const double* __r
           for (int a = 0; a < R; ++a) t[a] = fma(pv, res_s[L.wave][L.g][cc * R + a], t[a]);
         }
       }
-      if (tbuf) {
-        if (ok) store_col<R>(tbuf + (size_t)tpos[i] * GEO::T + L.c * R, t);
-      } else {
-        store_col<R>(&t_s[lp][L.c * R], t);  // zeros for nodes beyond n
-      }
+      store_col<R>(&t_s[lp][L.c * R], t);  // zeros for nodes beyond n (rows lp of a wave are private to it)
     }
-    if (tbuf) {  // kernel-uniform
+    if (tbuf) {  // kernel-uniform: graph aggregates
+      // inside the wave's G consecutive nodes every RUN of nodes of one aggregate is added up here (fixed order) and
+      // leaves ONE partial sum: tpos[i] = slot * 32 + length for the first node of a run, -1 otherwise (host:
+      // ml_symbolic_setup).  Consecutive poses mostly share an aggregate, so k_ml_agg_sum reads a fraction of what one
+      // value per node was (100k poses: 16 MB written + 16 MB read per cycle before).
       wave_sync();
+      if (ok) {
+        const int info = tpos[i];
+        if (info >= 0) {
+          const int len = info & 31;
+          double acc[R];
+#pragma unroll
+          for (int a = 0; a < R; ++a) acc[a] = t_s[lp][L.c * R + a];
+          for (int m = 1; m < len; ++m) {
+#pragma unroll
+            for (int a = 0; a < R; ++a) acc[a] += t_s[lp + m][L.c * R + a];
+          }
+          store_col<R>(tbuf + (size_t)(info >> 5) * GEO::T + L.c * R, acc);
+        }
+      }
+      wave_sync();  // (the wave's rows of t_s are rewritten by its next tile)
       continue;
     }
     __syncthreads();
@@ -168,8 +183,8 @@ __global__ __launch_bounds__(kBlock) void k_ml_restrict(MAT A, const double* __r
   }
 }
 
-// Graph aggregates: rc[a] = sum over the members of aggregate a of t[member], in a fixed order.  k_ml_restrict wrote the
-// members' values in member-list order, so aggregate a is the contiguous run t[agg_ptr[a] .. agg_ptr[a+1]).  One workgroup
+// Graph aggregates: rc[a] = sum of aggregate a's partial sums, in a fixed order.  k_ml_restrict wrote them ordered by
+// aggregate, so aggregate a is the contiguous run t[agg_ptr[a] .. agg_ptr[a+1]) (agg_ptr = the host's seg_ptr).  One workgroup
 // per aggregate: thread (group g, element e) adds every NG-th member's element e, the partial sums meet in LDS and the
 // first T threads add them up.  rc32: the dense level stores its right-hand side in fp32.
 template <int D, int R>

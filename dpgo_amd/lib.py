@@ -20,6 +20,7 @@ METHOD_RTR, METHOD_RGD = 0, 1
 PRECOND_NONE, PRECOND_BLOCK_JACOBI, PRECOND_MULTILEVEL, PRECOND_AUTO, PRECOND_ADDITIVE = 0, 1, 2, 3, 4
 PRECOND_NAMES = ["none", "jacobi", "multilevel", "auto", "additive"]
 ML_P_BLOCKS, ML_A_ROWPTR, ML_A_COLIDX, ML_A_VALUES, ML_DENSE_INVERSE, ML_AGG_LABELS, ML_AP_NNZB = 0, 1, 2, 3, 4, 5, 6
+ML_RESTRICT_PARTIALS = 7
 TCG_STATUS = ["NEGCURVTURE", "EXCREGION", "LCON", "SCON", "MAXITER"]
 
 

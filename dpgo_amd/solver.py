@@ -561,7 +561,8 @@ class QuadraticProblem:
     def multilevelGet(self, level: int, what: str) -> np.ndarray:
         """Copy of one item of the built hierarchy: "P" (prolongation blocks of a level), "rowptr" / "colidx" / "A"
         (Galerkin operator of a level >= 1), "inverse" (dense inverse of the last level), "labels" (graph aggregates:
-        the aggregate of every pose), "ap_nnzb" (two levels: blocks of A P, a 1-element array)."""
+        the aggregate of every pose), "ap_nnzb" (two levels: blocks of A P, a 1-element array), "restrict_partials" (graph
+        aggregates: partial sums one restriction writes, a 1-element array)."""
         info = self.multilevelInfo()
         b = self.dimension() + 1
         n_l, nz = info["sizes"][level], info["nnzb"][level]
@@ -571,6 +572,7 @@ class QuadraticProblem:
                               "A": (L.ML_A_VALUES, (nz, b, b), np.float64),
                               "labels": (L.ML_AGG_LABELS, (n_l,), np.int32),
                               "ap_nnzb": (L.ML_AP_NNZB, (1,), np.int32),
+                              "restrict_partials": (L.ML_RESTRICT_PARTIALS, (1,), np.int32),
                               "inverse": (L.ML_DENSE_INVERSE, (n_l * b, n_l * b), np.float64)}[what]
         out = np.zeros(shape, dtype=dtype)  # (only the requested item: "inverse" of level 0 would be (n (d+1))^2)
         L.check(self._lib.dpgo_problem_multilevel_get(self._h, int(level), code, L.ptr(out)))

@@ -220,6 +220,8 @@ int dpgo_problem_get_Q_values(dpgo_problem_t h, double* vals_host);
 #define DPGO_ML_DENSE_INVERSE 4 /* last level: (n_L (d+1))^2, row-major                             (double) */
 #define DPGO_ML_AGG_LABELS 5    /* level 0 with graph aggregates: aggregate of every pose, n_0         (int32)  */
 #define DPGO_ML_AP_NNZB 6       /* level 0 of a two-level hierarchy: blocks of A P, one value          (int32)  */
+#define DPGO_ML_RESTRICT_PARTIALS 7 /* level 0 with graph aggregates: partial sums one restriction writes -- one per run of
+                                     * same-aggregate poses inside a wave's chunk of consecutive poses, one value (int32) */
 int dpgo_multilevel_default_ks(int n, int d, int* ks, int* nks); /* *nks in: capacity of ks, out: count */
 /* The host step of a graph hierarchy by itself (no device): aggregates of at most max_size nodes grown breadth-first over
  * the block pattern (seeds in index order, FIFO, neighbours in block-row order).  label[n] = aggregate of every node,
