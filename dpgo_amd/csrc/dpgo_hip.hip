@@ -1449,7 +1449,6 @@ int launch_ml_apply(dpgo_problem_s* p, const double* Xdev, const double* v, doub
 // multi-launch scheme.  Other processes are not covered: every in-kernel spin is bounded, a time-out poisons the state
 // record (rtr_stop = kPersistPoison) and leaves the caller's iterate untouched; run_optimize then runs the solve with the
 // multi-launch scheme.
-constexpr int kPersistPoison = 3;
 constexpr int kMaxDevices = 64;
 std::atomic<int> g_warnings{0};  // warnings printed to stderr so far (dpgo_warning_count)
 std::atomic<int> g_persist_used[kMaxDevices];

@@ -41,6 +41,7 @@ struct PersistCtrl {
 };
 
 constexpr unsigned kSpinLimit = 1u << 21;  // polls (with s_sleep) before a spin gives up: ~0.5 s
+constexpr int kPersistPoison = 3;          // DevState::rtr_stop of a launch in which a participant timed out
 // s_sleep units (64 clocks each) before the first granule sweep of a reduction and between sweeps; packed into one
 // kernel argument (first << 8 | between) so that they can be tuned at run time (DPGO_POLL_FIRST / DPGO_POLL_SLEEP)
 constexpr int kPollFirstSleep = 24, kPollSleep = 3;
@@ -1038,7 +1039,7 @@ __global__ __launch_bounds__(kBlock, 1) void k_rtr_persist(BsrDev Q, double* X, 
     }
   }
   if (rank == 0 && threadIdx.x == 0) {
-    if (!good) st.rtr_stop = 3;  // time-out: poisoned record; X stays untouched and the host reruns the solve (kPersistPoison)
+    if (!good) st.rtr_stop = kPersistPoison;  // time-out: X stays untouched and the host reruns the solve
     store_state(sout, st);
     store_state(sout + 1, st);
     publish_progress(hflag, gen, st);
@@ -1056,7 +1057,7 @@ __global__ __launch_bounds__(kBlock, 1) void k_rtr_persist(BsrDev Q, double* X, 
 __global__ __launch_bounds__(kBlock) void k_persist_commit(const DevState* __restrict__ st, const PersistCtrl* __restrict__ ctrl,
                                                            const double* __restrict__ xfin, double* __restrict__ X,
                                                            size_t count) {
-  if (st->rtr_stop == 3 || ctrl->error || st->n_accept <= 0) return;
+  if (st->rtr_stop == kPersistPoison || ctrl->error || st->n_accept <= 0) return;
   // (8-byte pieces: a caller's device pointer is only promised to be aligned for doubles; at most 5 MB)
   for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < count; i += (size_t)gridDim.x * kBlock) X[i] = xfin[i];
 }

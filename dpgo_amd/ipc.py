@@ -39,9 +39,14 @@ class IpcPeerStore:
     def _share(self, aux: bool) -> None:
         from torch.multiprocessing.reductions import reduce_tensor
         mine = {}
+        self._keep = [t for t in self._keep if getattr(t, "_dpgo_aux", None) != aux]  # (re-share: drop the old exports)
         for a, ag in self.cluster.agents.items():
             t = ag.nbr_aux if aux else ag.nbr
             mine[a] = reduce_tensor(t)  # (rebuild function, arguments incl. the hipIpcMemHandle of the allocation)
+            try:
+                t._dpgo_aux = aux
+            except Exception:
+                pass
             self._keep.append(t)
         everyone = [None] * self.world
         self.dist.all_gather_object(everyone, mine)
