@@ -638,7 +638,7 @@ def main():
         ml_info["coarse_inverse_bits"] = cbits
         path = agent.problem.multilevelPath()
         ml_info["path"] = path
-        two = len(ml_info["ks"]) == 1
+        two = len(ml_info["sizes"]) == 2
         nnzb_ap = None
         graph = ml_info["ks"][0] < 0  # graph aggregates: members anywhere, summed by k_ml_agg_sum
         if path["ap"]:  # blocks of A P: the distinct aggregates the block columns of every row fall into

@@ -704,8 +704,23 @@ int ml_default_graph_size(int n, int b) {
   const long long S = std::max<long long>(4, ((long long)n * b + kMlGraphUnknownsPerPose - 1) / kMlGraphUnknownsPerPose);
   return S <= kMlGraphMax ? (int)S : 0;
 }
+// Blocks whose plain greedy growth would use aggregates of >= kMlMergeFrom poses (n (d+1) >= ~100 000 unknowns: >= 25 600
+// poses in 3-D) grow them to S = ceil(n (d+1) / 2 200) instead and MERGE the growth's fragments up to 3 S / 2
+// (ml_merge_small_aggregates): the aggregates come out uniform (mean ~ S instead of ~0.55 S with a tail of fragments), the
+// same coarse-space quality needs a quarter fewer of them -- 100k poses: 546 aggregates / 70 products to |rgrad| < 1e-2
+// against 732 / 77, a dense level of 38 MB instead of 69 MB; 25k: 536 / 87 against 589 / 93 (oracle, round 4).  Smaller
+// blocks keep the plain growth (same product counts either way; their hierarchies are what the committed vectors pin).
+constexpr int kMlMergeFrom = 64, kMlMergedUnknownsPerPose = 2200;
 std::vector<int> ml_default_ks(int n, int b, int split0) {
-  if (const int S = ml_default_graph_size(n, b)) return std::vector<int>{-S};
+  if (const int S = ml_default_graph_size(n, b)) {
+    const bool forced = std::getenv("DPGO_ML_GRAPH_SIZE") != nullptr;
+    if (!forced && S >= kMlMergeFrom) {
+      const int Sm = (int)(((long long)n * b + kMlMergedUnknownsPerPose - 1) / kMlMergedUnknownsPerPose);
+      const int cap = Sm + Sm / 2;
+      if (cap <= kMlGraphMax) return std::vector<int>{-Sm, -cap};
+    }
+    return std::vector<int>{-S};
+  }
   std::vector<int> ks;
   int cur = n, split = split0;
   for (int guard = 0; guard < 16; ++guard) {

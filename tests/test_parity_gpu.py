@@ -656,8 +656,9 @@ def test_whole_solve_at_full_size_matches_oracle(oracle, storage):
         if precond == "multilevel":
             bits = 32 if storage == "symmetric" else 64  # the opt-in fp32 storage of the dense level rides along
             info = prob.setupMultilevel(coarse_bits=bits)
-            # (the default: two levels, graph aggregates of at most 250 poses, a dense level of about 2 500 unknowns)
-            assert info["ks"] == [-250] and info["sizes"][0] == 100000 and 400 <= info["sizes"][1] <= 900
+            # (the default: two levels, graph aggregates grown to 182 poses with the fragments merged up to 273: 546 of them,
+            # a dense level of about 2 200 unknowns)
+            assert info["ks"] == [-182, -273] and info["sizes"][0] == 100000 and 400 <= info["sizes"][1] <= 900
             op = oracle.QuadraticProblem(Q, None, r, d, precond="amg", amg_k=info["ks"], amg_coarse_bits=bits)
             if bits == 32:  # both sides run with the SAME stored inverse (see _hierarchy_check)
                 inv = prob.multilevelGet(1, "inverse")

@@ -7,7 +7,8 @@ waste whole workgroups.  Compares, for a size bound S,
               to `cap` poses -- the workgroup's tile),
 by the number of aggregates and by Hessian-vector products until |rgrad| < 1e-2.
 
-usage: python tools/balanced_aggregates_experiment.py 50x50x5|sphere|torus 16,32,55:64  (S or S:cap)
+usage: python tools/balanced_aggregates_experiment.py 50x50x5|sphere|torus 16,32,55:64 [vcycle]  (S or S:cap; vcycle: the
+       V(1,1) cycle instead of the additive form)
 """
 import os
 import sys
@@ -35,7 +36,8 @@ def main():
         S, cap = (int(v) for v in (spec.split(":") if ":" in spec else (spec, "0")))
         for mode in (("merged",) if cap else ("greedy",)):
             t0 = time.time()
-            op = O.QuadraticProblem(Q, None, r, d, precond="amg_additive", amg_k=[-S], amg_merge=cap)
+            pc = "amg" if len(sys.argv) > 3 and sys.argv[3] == "vcycle" else "amg_additive"
+            op = O.QuadraticProblem(Q, None, r, d, precond=pc, amg_k=[-S], amg_merge=cap)
             opt = O.QuadraticOptimizer(op, O.ROptParameters())
             X, total, rows = X0.copy(), 0, []
             for _ in range(12):
