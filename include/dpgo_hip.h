@@ -207,7 +207,9 @@ int dpgo_problem_get_Q_values(dpgo_problem_t h, double* vals_host);
  *     Hessian-vector products of index runs of the same size; the default whenever one coarsening with S <= 512
  *     reaches a dense level of about 2 500 unknowns, i.e. up to 200 000 poses in 3-D; DPGO_ML_GRAPH=0 restores runs).
  *     Two negative sizes {-S, -cap}: the same with the fragments of the growth merged up to cap poses
- *     (dpgo_multilevel_merged_aggregates; what the additive preconditioner builds for blocks beyond ~3 500 poses).
+ *     (dpgo_multilevel_merged_aggregates; what the additive preconditioner builds for blocks beyond ~3 500 poses, and the
+ *     DEFAULT of blocks of >= ~100 000 unknowns -- 25 600 poses in 3-D --: S = ceil(n (d+1) / 2 200), cap = 3 S / 2; the
+ *     uniform aggregates need a quarter fewer of them for the same convergence, dpgo_multilevel_default_ks tells).
  *     omega: smoother damping (0.7); shift: the reference's 0.1.  Explicit sizes stick to the handle until the next call.
  *   dpgo_problem_multilevel_info: *nlevels in = capacity of the arrays, out = number of levels (coarsenings + 1);
  *     sizes[l] = nodes, ks[l] = aggregate size towards level l+1 (0 on the last; negative: graph aggregates of at most
