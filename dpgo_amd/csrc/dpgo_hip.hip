@@ -1289,27 +1289,38 @@ int ml_ensure(dpgo_problem_s* p, double shift, bool additive = false) {
 // Dense level + prolongation.  Large coarsest levels: two nodes per workgroup (halves the right-hand-side loads per
 // matrix byte); balanced rounds: every workgroup takes the same number of node groups (a ragged last round would leave
 // most of the chip idle while the dense inverse streams).
+int persist_capacity(int device);  // (two resident slots per CU; below)
 int launch_coarse_prolong(dpgo_problem_s* p, const dpgo_problem_s::MlLevel& L, const dpgo_problem_s::MlLevel& C,
                           const DevState* gate, double* xc_out = nullptr) {
-  int nodes = C.n >= 512 ? 2 : 1;  // (732 nodes: 19.7 -> 17.1 us; 4 per workgroup: 18.1)
+  const bool f32 = p->ml_coarse_bits == 32;
+  // nodes per workgroup (the right-hand side is read once per workgroup): 732 nodes: 1 -> 2: 19.7 -> 17.1 us, 4: 18.1;
+  // three (fp64 storage) where that brings the level down to one workgroup per CU in one round: 546 nodes: 2 -> 3:
+  // 273 -> 182 workgroups, 10.5 -> 9.7 us
+  const int cus = persist_capacity(p->device) / 2;
+  int nodes = C.n >= 512 ? 2 : 1;
+  if (nodes == 2 && !f32 && (C.n + 1) / 2 > cus && (C.n + 2) / 3 <= cus) nodes = 3;
   if (const char* e = std::getenv("DPGO_COARSE_NODES")) {  // tuning knob
     const int v = std::atoi(e);
-    nodes = (v == 4 || v == 2) ? v : 1;
+    nodes = (v == 4 || v == 2 || (v == 3 && !f32)) ? v : 1;
   }
   const int groups = (C.n + nodes - 1) / nodes;
   int cap = kMaxGrid;
   if (const char* e = std::getenv("DPGO_COARSE_GRID")) cap = std::max(1, std::atoi(e));  // tuning knob
   const int rounds = (groups + cap - 1) / cap;
   const int gc = std::max(1, (groups + rounds - 1) / rounds);
-  const bool f32 = p->ml_coarse_bits == 32;
+  // non-temporal loads of the inverse only when it would sweep the Infinity Cache (kernel comment)
+  int hint = (size_t)p->ml_lda * p->ml_lda * (f32 ? 4 : 8) > ((size_t)128 << 20);
+  if (const char* e = std::getenv("DPGO_COARSE_NT")) hint = std::atoi(e) != 0;  // tuning knob
 #define COARSE_LAUNCH(NODES, MT, MPTR)                                                                               \
   hipLaunchKernelGGL((k_ml_coarse_prolong<D, R, NODES, MT>), dim3(gc), dim3(kBlock), 0, p->stream, MPTR, p->ml_lda,   \
-                     reinterpret_cast<const MT*>(C.r), L.x1, L.Pb, L.k, L.x, gate, L.n, C.n, xc_out)
+                     reinterpret_cast<const MT*>(C.r), L.x1, L.Pb, L.k, L.x, gate, L.n, C.n, xc_out, hint)
   DISPATCH(p->d, p->r, {
     if (nodes == 4 && f32)
       COARSE_LAUNCH(4, float, p->ml_dense32);
     else if (nodes == 4)
       COARSE_LAUNCH(4, double, p->ml_dense);
+    else if (nodes == 3)
+      COARSE_LAUNCH(3, double, p->ml_dense);
     else if (nodes == 2 && f32)
       COARSE_LAUNCH(2, float, p->ml_dense32);
     else if (nodes == 2)

@@ -234,13 +234,19 @@ __global__ __launch_bounds__(kBlock) void k_ml_agg_sum(const double* __restrict_
 #ifndef DPGO_COARSE_UNROLL
 #define DPGO_COARSE_UNROLL 1  // streaming steps whose loads are in flight together (measured: 1 -> 49.4, 2 -> 56.6 us)
 #endif
+// stream_hint: the matrix is read ONCE per cycle by exactly one workgroup.  A big inverse (round 2: 313 MB) is streamed
+// with non-temporal loads so that it does not push Q and the tCG vectors out of the 256 MB Infinity Cache; a small one
+// (100k poses with merged aggregates: 38 MB) is better left to stay there: 13.2 -> 10.5 us, same box.  (Requesting
+// several steps' loads together, by hand, made this kernel slower at every depth tried -- 2 / 3 / 5 steps: 13.7 / 17.3 /
+// 19.1 us against 13.2 --: it runs at the rate its source delivers, not at a latency.)
 template <int D, int R, int NODES, class MT>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(DPGO_COARSE_WAVES, DPGO_COARSE_WAVES))) void k_ml_coarse_prolong(const MT* __restrict__ M, int lda,
                                                               const MT* __restrict__ rc,
                                                               const double* __restrict__ x1,
                                                               const double* __restrict__ Pb, int k,
                                                               double* __restrict__ x, const DevState* __restrict__ gate,
-                                                              int n, int nc, double* __restrict__ xc_out = nullptr) {
+                                                              int n, int nc, double* __restrict__ xc_out = nullptr,
+                                                              int stream_hint = 1) {
   constexpr int B = D + 1, T = B * R, BB = B * B, NR = NODES * B;
   constexpr int CPL = 16 / (int)sizeof(MT);  // columns per lane and step
   struct alignas(16) Pack {
@@ -271,38 +277,48 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(DPGO_COA
       struct alignas(16) RPack {
         MT v[CPL * R];
       };
+      auto stream_rows = [&](auto nt) {
 #pragma unroll DPGO_COARSE_UNROLL
-      for (int j = wave * 64 + lane; j < npack; j += kBlock) {
-        Pack mv[NR];
+        for (int j = wave * 64 + lane; j < npack; j += kBlock) {
+          Pack mv[NR];
 #pragma unroll
-        for (int c = 0; c < NR; ++c) {  // streamed once per cycle by exactly one workgroup: non-temporal, so that the
-                                        // inverse does not push Q and the tCG vectors out of the Infinity Cache
-          const dbl2 raw = __builtin_nontemporal_load(reinterpret_cast<const dbl2*>(m + (size_t)c * lda + CPL * j));
-          __builtin_memcpy(&mv[c], &raw, 16);
-        }
-        RPack rp;  // rc of column CPL j + cc in [cc R, (cc + 1) R)
-        if (CPL * j + CPL <= N) {
-          dbl2 raw[R];
+          for (int c = 0; c < NR; ++c) {
+            const dbl2* src = reinterpret_cast<const dbl2*>(m + (size_t)c * lda + CPL * j);
+            dbl2 raw;
+            if constexpr (decltype(nt)::value)
+              raw = __builtin_nontemporal_load(src);
+            else
+              raw = *src;
+            __builtin_memcpy(&mv[c], &raw, 16);
+          }
+          RPack rp;  // rc of column CPL j + cc in [cc R, (cc + 1) R)
+          if (CPL * j + CPL <= N) {
+            dbl2 raw[R];
 #pragma unroll
-          for (int q = 0; q < R; ++q) raw[q] = rc2[(size_t)j * R + q];
-          __builtin_memcpy(&rp, raw, sizeof(rp));
-        } else {
+            for (int q = 0; q < R; ++q) raw[q] = rc2[(size_t)j * R + q];
+            __builtin_memcpy(&rp, raw, sizeof(rp));
+          } else {
 #pragma unroll
-          for (int e = 0; e < CPL * R; ++e)
-            rp.v[e] = (CPL * j + e / R < N) ? rc[(size_t)(CPL * j) * R + e] : (MT)0;
-        }
-        double rv[CPL * R];
+            for (int e = 0; e < CPL * R; ++e)
+              rp.v[e] = (CPL * j + e / R < N) ? rc[(size_t)(CPL * j) * R + e] : (MT)0;
+          }
+          double rv[CPL * R];
 #pragma unroll
-        for (int e = 0; e < CPL * R; ++e) rv[e] = (double)rp.v[e];
+          for (int e = 0; e < CPL * R; ++e) rv[e] = (double)rp.v[e];
 #pragma unroll
-        for (int c = 0; c < NR; ++c) {
+          for (int c = 0; c < NR; ++c) {
 #pragma unroll
-          for (int q = 0; q < R; ++q) {
+            for (int q = 0; q < R; ++q) {
 #pragma unroll
-            for (int cc = 0; cc < CPL; ++cc) acc[c][q] = fma((double)mv[c].v[cc], rv[cc * R + q], acc[c][q]);
+              for (int cc = 0; cc < CPL; ++cc) acc[c][q] = fma((double)mv[c].v[cc], rv[cc * R + q], acc[c][q]);
+            }
           }
         }
-      }
+      };
+      if (stream_hint)
+        stream_rows(std::true_type{});
+      else
+        stream_rows(std::false_type{});
 #pragma unroll
       for (int nd = 0; nd < NODES; ++nd) {
 #pragma unroll
