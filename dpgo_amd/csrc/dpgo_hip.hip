@@ -1295,7 +1295,7 @@ int launch_coarse_prolong(dpgo_problem_s* p, const dpgo_problem_s::MlLevel& L, c
   const bool f32 = p->ml_coarse_bits == 32;
   // nodes per workgroup (the right-hand side is read once per workgroup): 732 nodes: 1 -> 2: 19.7 -> 17.1 us, 4: 18.1;
   // three (fp64 storage) where that brings the level down to one workgroup per CU in one round: 546 nodes: 2 -> 3:
-  // 273 -> 182 workgroups, 10.5 -> 9.7 us
+  // 273 -> 182 workgroups, 13.2 -> 11.6 us, the 100k bench step 4.45 -> 4.33 ms
   const int cus = persist_capacity(p->device) / 2;
   int nodes = C.n >= 512 ? 2 : 1;
   if (nodes == 2 && !f32 && (C.n + 1) / 2 > cus && (C.n + 2) / 3 <= cus) nodes = 3;
@@ -1308,8 +1308,8 @@ int launch_coarse_prolong(dpgo_problem_s* p, const dpgo_problem_s::MlLevel& L, c
   if (const char* e = std::getenv("DPGO_COARSE_GRID")) cap = std::max(1, std::atoi(e));  // tuning knob
   const int rounds = (groups + cap - 1) / cap;
   const int gc = std::max(1, (groups + rounds - 1) / rounds);
-  // non-temporal loads of the inverse only when it would sweep the Infinity Cache (kernel comment)
-  int hint = (size_t)p->ml_lda * p->ml_lda * (f32 ? 4 : 8) > ((size_t)128 << 20);
+  // non-temporal loads of the inverse whenever the loop's working set does not fit the Infinity Cache (kernel comment)
+  int hint = p->beyond_cache();
   if (const char* e = std::getenv("DPGO_COARSE_NT")) hint = std::atoi(e) != 0;  // tuning knob
 #define COARSE_LAUNCH(NODES, MT, MPTR)                                                                               \
   hipLaunchKernelGGL((k_ml_coarse_prolong<D, R, NODES, MT>), dim3(gc), dim3(kBlock), 0, p->stream, MPTR, p->ml_lda,   \

@@ -234,11 +234,12 @@ __global__ __launch_bounds__(kBlock) void k_ml_agg_sum(const double* __restrict_
 #ifndef DPGO_COARSE_UNROLL
 #define DPGO_COARSE_UNROLL 1  // streaming steps whose loads are in flight together (measured: 1 -> 49.4, 2 -> 56.6 us)
 #endif
-// stream_hint: the matrix is read ONCE per cycle by exactly one workgroup.  A big inverse (round 2: 313 MB) is streamed
-// with non-temporal loads so that it does not push Q and the tCG vectors out of the 256 MB Infinity Cache; a small one
-// (100k poses with merged aggregates: 38 MB) is better left to stay there: 13.2 -> 10.5 us, same box.  (Requesting
-// several steps' loads together, by hand, made this kernel slower at every depth tried -- 2 / 3 / 5 steps: 13.7 / 17.3 /
-// 19.1 us against 13.2 --: it runs at the rate its source delivers, not at a latency.)
+// stream_hint: the matrix is read ONCE per cycle by exactly one workgroup.  When the loop's working set exceeds the 256 MB
+// Infinity Cache the inverse is streamed with non-temporal loads so that it does not push Q and the tCG vectors out -- also
+// a small one: at 100k poses with merged aggregates (38 MB) plain loads make THIS kernel faster (13.2 -> 10.5 us) and the
+// loop slower (bench step 4.39 -> 4.48 ms, same box).  (Requesting several steps' loads together, by hand, made the kernel
+// slower at every depth tried -- 2 / 3 / 5 steps: 13.7 / 17.3 / 19.1 us against 13.2 --: it runs at the rate its source
+// delivers, not at a latency.)
 template <int D, int R, int NODES, class MT>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(DPGO_COARSE_WAVES, DPGO_COARSE_WAVES))) void k_ml_coarse_prolong(const MT* __restrict__ M, int lda,
                                                               const MT* __restrict__ rc,
