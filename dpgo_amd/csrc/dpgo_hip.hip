@@ -1362,19 +1362,29 @@ int launch_dense_sym(dpgo_problem_s* p, const dpgo_problem_s::MlLevel& C, const 
 // Level-0 restriction of the cycle: rc = P^T (r - A x1) into ml[1].r (+ the residual itself for k_ml_post_ap).  Graph
 // aggregates: the restriction kernel adds P_i^T res_i up over every run of same-aggregate poses inside a wave's chunk and
 // writes one partial sum per run, k_ml_agg_sum adds an aggregate's partial sums up.
-int launch_ml_restrict0(dpgo_problem_s* p, const double* r, const DevState* gate, int g0) {
+int launch_ml_restrict0(dpgo_problem_s* p, const double* r, const DevState* gate, int g0, bool stop_check = false) {
   auto& L = p->ml[0];
   auto& C = p->ml[1];
+  // inside the tCG loop (not after its first update): tCG's residual test one kernel early (TcgStopCheck, multilevel.h);
+  // the <r,r> partial sums are the ones k_tcg_update wrote, one per workgroup of ITS grid
+  TcgStopCheck stop;
+  if (stop_check && gate) {
+    stop.state = const_cast<DevState*>(gate);
+    stop.pin = p->pB();
+    stop.nb = p->grid();
+    stop.hflag = p->hflag;
+    stop.gen = p->gen;
+  }
   float* rc32 = (C.k == 0 && p->ml_coarse_bits == 32) ? reinterpret_cast<float*>(C.r) : (float*)nullptr;
   double* res_out = p->ml_use_ap() ? L.res1 : nullptr;
   const double* dnext = C.k ? C.dinv : (const double*)nullptr;
   if (p->tcg_sym) {  // level 0 reads Q: the symmetric copy when the tCG-step kernel does
     DISPATCH(p->d, p->r, hipLaunchKernelGGL((k_ml_restrict<D, R, 1, BsrSymDev>), dim3(g0), dim3(kBlock), 0, p->stream,
                                             p->sym.dev(), L.x1, r, L.Pb, p->ml_shift, L.k, C.r, rc32, dnext, p->ml_omega,
-                                            C.x1, gate, L.n, res_out, L.tbuf, L.seg_info));
+                                            C.x1, gate, L.n, res_out, L.tbuf, L.seg_info, stop));
   } else {
     DISPATCH(p->d, p->r, LAUNCH_SPLIT(p, k_ml_restrict, g0, p->Q.dev(), L.x1, r, L.Pb, p->ml_shift, L.k, C.r, rc32, dnext,
-                                      p->ml_omega, C.x1, gate, L.n, res_out, L.tbuf, L.seg_info));
+                                      p->ml_omega, C.x1, gate, L.n, res_out, L.tbuf, L.seg_info, stop));
   }
   if (L.graph)
     DISPATCH(p->d, p->r, hipLaunchKernelGGL((k_ml_agg_sum<D, R>), dim3(std::min(C.n, kMaxGrid)), dim3(kBlock), 0, p->stream,
@@ -1395,7 +1405,7 @@ int launch_ml_post_ap(dpgo_problem_s* p, const double* Xdev, const double* r, do
 // The launches of one cycle after the pre-smoothing step of level 0 (x1 = w Dinv r is in ml[0].x1):
 // z = proj_X(M^-1 r); partial sums <r,r>, <z,r> into `pout` (may be NULL).  `gate`: state record for early exit.
 int launch_ml_tail(dpgo_problem_s* p, const double* Xdev, const double* r, double* z, double* pout,
-                   const DevState* gate) {
+                   const DevState* gate, bool stop_check = false) {
   const int nl = (int)p->ml.size();
   // the dense level reads its right-hand side in the precision its inverse is stored in (same buffer)
   auto rc32_of = [&](const dpgo_problem_s::MlLevel& C) {
@@ -1420,7 +1430,7 @@ int launch_ml_tail(dpgo_problem_s* p, const double* Xdev, const double* r, doubl
       hipLaunchKernelGGL((KERNEL<D, R, 1>), dim3(g_), dim3(kBlock), 0, p->stream, __VA_ARGS__);          \
   } while (0)
   const bool ap = p->ml_use_ap();  // two levels: the residual after pre-smoothing is kept, the dense level hands over xc
-  CHK(launch_ml_restrict0(p, r, gate, g0));
+  CHK(launch_ml_restrict0(p, r, gate, g0, stop_check));
   for (int l = 1; l + 1 < nl; ++l) {  // down
     auto& L = p->ml[l];
     auto& C = p->ml[l + 1];
@@ -1682,7 +1692,8 @@ int rtr_outer_iteration(dpgo_problem_s* p, const dpgo_ropt_params* prm, const do
   auto update = [&](int first) -> int {
     if (ml) {
       CHK(launch_tcg_update(p, dinv, first, p->ml[0].x1, p->ml_omega));
-      return launch_ml_tail(p, p->x1, p->rr, p->z, p->pB(), p->dstate + p->cur);
+      static const bool early_stop = [] { const char* e = std::getenv("DPGO_ML_EARLY_STOP"); return !e || std::atoi(e) != 0; }();
+      return launch_ml_tail(p, p->x1, p->rr, p->z, p->pB(), p->dstate + p->cur, early_stop && !first);
     }
     return launch_tcg_update(p, dinv, first);
   };
@@ -1714,7 +1725,8 @@ int rtr_outer_iteration(dpgo_problem_s* p, const dpgo_ropt_params* prm, const do
     // a multilevel iteration is 5+ launches: waste fewer of them after tCG stops.  (2 is the minimum: iteration j's count
     // is published by the prologue of iteration j+1's Hessian-step kernel, so one iteration ahead never sees progress --
     // tried in round 4, the watchdog fires.)
-    const int kAhead = ml ? 2 : 4;
+    int kAhead = ml ? 2 : 4;
+    if (const char* e = std::getenv("DPGO_TCG_AHEAD")) kAhead = std::max(2, std::atoi(e));  // tuning knob (>= 2, see above)
     int enq = 0, last_j = -1;
     auto t_progress = std::chrono::steady_clock::now();
     while (true) {

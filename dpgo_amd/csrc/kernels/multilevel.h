@@ -58,16 +58,30 @@ __global__ __launch_bounds__(kBlock) void k_ml_presmooth(const double* __restric
 // workgroup tiles: GEO::P % k == 0).  With `dinv_next` (the next level is not the dense one) the pre-smoothing step of
 // level l+1, x1c = w Dinv_{l+1} rc, rides in the epilogue.  `rc32` (the next level is the dense one and its inverse is
 // stored in fp32): rc is written in fp32 instead.  `res_out`: the residual r - A x1 itself is kept (k_ml_post_ap).
+// `stop` (inside the tCG loop, level 0): the LAST workgroup -- the one with the fewest tiles -- also evaluates tCG's
+// residual test |r| <= |r0| min(|r0|^theta, kappa) from the <r,r> partial sums k_tcg_update just wrote, i.e. one kernel
+// earlier than the Hessian-step kernel's prologue would (tcg_hess_prologue: same test, same state fields).  When it
+// holds it raises tcg_done in the state record the rest of the cycle and the next Hessian-step kernel are gated on and
+// publishes it to the host: the final iteration of a converged tCG run no longer pays for a dense solve and a
+// post-smoothing pass whose result nobody reads, and the host stops enqueuing one iteration sooner.
+struct TcgStopCheck {
+  DevState* state = nullptr;  // the record `gate` points to; NULL: no check
+  const double* pin = nullptr;
+  int nb = 0;
+  unsigned long long* hflag = nullptr;
+  unsigned gen = 0;
+};
 template <int D, int R, int SPLIT, class MAT = BsrDev>
 __global__ __launch_bounds__(kBlock) void k_ml_restrict(MAT A, const double* __restrict__ x1,
                                                         const double* __restrict__ r, const double* __restrict__ Pb,
                                                         double shift, int k, double* __restrict__ rc,
                                                         float* __restrict__ rc32,
                                                         const double* __restrict__ dinv_next, double omega,
-                                                        double* __restrict__ x1c, const DevState* __restrict__ gate,
+                                                        double* __restrict__ x1c, const DevState* gate,
                                                         int n, double* __restrict__ res_out = nullptr,
                                                         double* __restrict__ tbuf = nullptr,
-                                                        const int32_t* __restrict__ tpos = nullptr) {
+                                                        const int32_t* __restrict__ tpos = nullptr,
+                                                        TcgStopCheck stop = TcgStopCheck()) {
   // tbuf (graph aggregates: their members are anywhere): partial sums of P_i^T res_i over runs of same-aggregate nodes
   // are written out instead of the aggregate's sum -- to the slots tpos encodes, ordered by aggregate, so that
   // k_ml_agg_sum reads every aggregate's partial sums as one contiguous run
@@ -78,6 +92,26 @@ __global__ __launch_bounds__(kBlock) void k_ml_restrict(MAT A, const double* __r
   const LaneId L = lane_id<D, SPLIT>();
   const int ntiles = (n + GEO::P - 1) / GEO::P;
   const TileIter ti_ = tile_iter(ntiles);
+  if (stop.state && blockIdx.x == gridDim.x - 1) {  // workgroup-uniform
+    double rr_sum[1];
+    load_partials<1>(stop.pin, stop.nb, rr_sum, &t_s[0][0]);
+    if (threadIdx.x == 0) {
+      const DevState* st = stop.state;
+      const double norm_r = sqrt(rr_sum[0]), nr0 = st->norm_r0, theta = st->theta, kappa = st->kappa;
+      const double pw = (theta == 1.0) ? nr0 : pow(nr0, theta);
+      const int j = st->tcg_j;
+      if (j >= st->min_inner && norm_r <= nr0 * (pw < kappa ? pw : kappa)) {
+        stop.state->tcg_status = (kappa < pw) ? TCG_LCON : TCG_SCON;
+        stop.state->tcg_done = 1;
+        if (stop.hflag) {
+          const unsigned long long w = ((unsigned long long)stop.gen << 32) |
+                                       ((unsigned long long)((unsigned)j & 0xFFFFFFu) << 8) | 1ull;
+          __hip_atomic_store(stop.hflag, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+      }
+    }
+    __syncthreads();  // (t_s is reused by the tiles below)
+  }
   for (int tile = ti_.first; tile < ti_.last; tile += ti_.step) {
     const int lp = L.wave * GEO::G + L.g;  // node slot inside the workgroup tile
     const int i = tile * GEO::P + lp;
