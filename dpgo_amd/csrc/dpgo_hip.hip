@@ -560,18 +560,35 @@ int launch_spmm(dpgo_problem_s* p, const Bsr& M, const double* V, const double* 
   return DPGO_OK;
 }
 
+bool outer_sym_enabled() {  // tuning knob: DPGO_OUTER_SYM=0 keeps the outer iteration on the plain copy of Q
+  static const bool on = [] { const char* e = std::getenv("DPGO_OUTER_SYM"); return !e || std::atoi(e) != 0; }();
+  return on;
+}
+// `sym`: inside a solve whose tCG-step kernel reads the symmetric copy of Q (p->tcg_sym, valid for the duration of the
+// solve) the gradient and the rho-test Hessian read it too: 7 us less per launch at 100k poses with cold operands, and the
+// outer iteration no longer streams the 91 MB of the plain copy through the Infinity Cache the tCG loop lives in.
 int launch_grad(dpgo_problem_s* p, const double* X, double* RG, double* S, double* EG,
-                const DevState* st = nullptr) {
+                const DevState* st = nullptr, bool sym = false) {
   const double* Gm = p->has_G ? p->G : nullptr;
-  DISPATCH(p->d, p->r, LAUNCH_SPLIT(p, k_grad, p->grid_s(), p->Q.dev(), X, Gm, RG, S, EG, p->pE(), st, p->n));
+  if (sym && p->split == 1) {
+    DISPATCH(p->d, p->r, hipLaunchKernelGGL((k_grad<D, R, 1, BsrSymDev>), dim3(p->grid_s()), dim3(kBlock), 0, p->stream,
+                                            p->sym.dev(), X, Gm, RG, S, EG, p->pE(), st, p->n));
+  } else {
+    DISPATCH(p->d, p->r, LAUNCH_SPLIT(p, k_grad, p->grid_s(), p->Q.dev(), X, Gm, RG, S, EG, p->pE(), st, p->n));
+  }
   HIPC(hipGetLastError());
   return DPGO_OK;
 }
 
 int launch_hess(dpgo_problem_s* p, const double* X, const double* S, const double* V, const double* Gdot,
-                double* HV, double* partials, const DevState* st, int check_tcg) {
-  DISPATCH(p->d, p->r,
-           LAUNCH_SPLIT(p, k_hess, p->grid_s(), p->Q.dev(), X, S, V, Gdot, HV, partials, st, check_tcg, p->n));
+                double* HV, double* partials, const DevState* st, int check_tcg, bool sym = false) {
+  if (sym && p->split == 1) {
+    DISPATCH(p->d, p->r, hipLaunchKernelGGL((k_hess<D, R, 1, BsrSymDev>), dim3(p->grid_s()), dim3(kBlock), 0, p->stream,
+                                            p->sym.dev(), X, S, V, Gdot, HV, partials, st, check_tcg, p->n));
+  } else {
+    DISPATCH(p->d, p->r,
+             LAUNCH_SPLIT(p, k_hess, p->grid_s(), p->Q.dev(), X, S, V, Gdot, HV, partials, st, check_tcg, p->n));
+  }
   HIPC(hipGetLastError());
   return DPGO_OK;
 }
@@ -1760,9 +1777,9 @@ int rtr_outer_iteration(dpgo_problem_s* p, const dpgo_ropt_params* prm, const do
   if (!done) CHK(launch_tcg_hess(p, 0));  // max_inner iterations enqueued, not (yet known to be) finished: last prologue
   if (p->saw_rtr_stop) return DPGO_OK;  // the previous outer iteration already met the stop test
   CHK(launch_retract(p, p->x1, p->eta, 1.0, p->x2, p->dstate + p->cur));
-  CHK(launch_grad(p, p->x2, p->g2, p->S2, nullptr, p->dstate + p->cur));
+  CHK(launch_grad(p, p->x2, p->g2, p->S2, nullptr, p->dstate + p->cur, p->tcg_sym && outer_sym_enabled()));
   cnt.spmm += 1;
-  CHK(launch_hess(p, p->x1, p->S1, p->eta, p->g1, p->Hd, p->pH(), p->dstate + p->cur, 0));
+  CHK(launch_hess(p, p->x1, p->S1, p->eta, p->g1, p->Hd, p->pH(), p->dstate + p->cur, 0, p->tcg_sym && outer_sym_enabled()));
   cnt.spmm += 1;
   CHK(launch_rtr_update(p));
   if (poll_at_end) CHK(poll_state(p));
@@ -1895,7 +1912,7 @@ int run_optimize(dpgo_problem_s* p, const dpgo_ropt_params* prm, dpgo_ropt_resul
     }
   }
   // statistics before optimisation (:28-29) -- one fused pass: f, rgrad, S
-  CHK(launch_grad(p, p->x1, p->g1, p->S1, nullptr));
+  CHK(launch_grad(p, p->x1, p->g1, p->S1, nullptr, nullptr, prm->method == DPGO_METHOD_RTR && p->tcg_sym && outer_sym_enabled()));
   cnt.spmm += 1;
   CHK(launch_rtr_begin(p, prm->gradnorm_tol, prm->RTR_initial_radius, 5.0 * prm->RTR_initial_radius,
                        prm->RTR_tCG_iterations, prm->accept_tiny_decrease));

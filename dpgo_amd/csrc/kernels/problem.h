@@ -89,8 +89,8 @@ __global__ __launch_bounds__(kBlock) void k_sym_check(const double* __restrict__
 // EG = XQ + G (:43-47), S = sym(Y^T EG_rot) (cached for the Hessian, ROPTLIB EucGradToGrad),
 // RG = proj_X(EG) (:71-79) and |RG|^2 (:81-83).
 // partials: [0] sum(XQ.X)  [1] sum(X.G)  [2] |RG|^2
-template <int D, int R, int SPLIT>
-__global__ __launch_bounds__(kBlock) void k_grad(BsrDev Q, const double* __restrict__ X,
+template <int D, int R, int SPLIT, class MAT = BsrDev>
+__global__ __launch_bounds__(kBlock) void k_grad(MAT Q, const double* __restrict__ X,
                                                  const double* __restrict__ Gm, double* __restrict__ RG,
                                                  double* __restrict__ S, double* __restrict__ EGout,
                                                  double* __restrict__ partials, const DevState* __restrict__ st,
@@ -111,7 +111,7 @@ __global__ __launch_bounds__(kBlock) void k_grad(BsrDev Q, const double* __restr
     const size_t off = (size_t)i * GEO::T + L.c * R;
     double* ys = ok ? &sm[L.wave][0][L.g][0] : nullptr;
     double* ws = ok ? &sm[L.wave][1][L.g][0] : nullptr;
-    spmm_col<D, R, SPLIT>(Q.rowptr, Q.colidx, Q.vals, X, i, L.s, L.c, okp, eg);
+    q_gather<D, R, SPLIT>(Q, X, i, L.s, L.c, okp, eg);  // (plain or symmetric storage of Q, common.h)
     if (ok) {
       load_col<R>(X + off, x);
 #pragma unroll
@@ -150,8 +150,8 @@ __global__ __launch_bounds__(kBlock) void k_grad(BsrDev Q, const double* __restr
 // src/QuadraticProblem.cpp:49-54, + ROPTLIB Stiefel::EucHvToHv + ProductManifold::Projection).
 // partials: [0] <V,HV>   [1] <V,Gdot> (if Gdot != null; used for the RTR model decrease)
 // When `st` is given the kernel is a tCG step and exits early once tCG has finished.
-template <int D, int R, int SPLIT>
-__global__ __launch_bounds__(kBlock) void k_hess(BsrDev Q, const double* __restrict__ X,
+template <int D, int R, int SPLIT, class MAT = BsrDev>
+__global__ __launch_bounds__(kBlock) void k_hess(MAT Q, const double* __restrict__ X,
                                                  const double* __restrict__ S, const double* __restrict__ V,
                                                  const double* __restrict__ Gdot, double* __restrict__ HV,
                                                  double* __restrict__ partials, const DevState* __restrict__ st,
@@ -176,7 +176,7 @@ __global__ __launch_bounds__(kBlock) void k_hess(BsrDev Q, const double* __restr
     double* ys = ok ? &sm[L.wave][0][L.g][0] : nullptr;
     double* vs = ok ? &sm[L.wave][1][L.g][0] : nullptr;
     double* hs = ok ? &sm[L.wave][2][L.g][0] : nullptr;
-    spmm_col<D, R, SPLIT>(Q.rowptr, Q.colidx, Q.vals, V, i, L.s, L.c, okp, h);
+    q_gather<D, R, SPLIT>(Q, V, i, L.s, L.c, okp, h);
     if (ok) {
       load_col<R>(X + off, x);
       load_col<R>(V + off, v);
