@@ -2201,3 +2201,43 @@ def test_multilevel_on_random_graphs_with_broken_chains(oracle, d, r, n, hub_edg
     # are compared to 2 % only; what pins the arithmetic is the 1e-9 on the operator above)
     if rg.tcg_iterations == oo.result.tcg_iters:
         assert abs(rg.fOpt - oo.result.fOpt) <= 2e-2 * abs(oo.result.fOpt)
+
+
+def _early_stop_case(name, r):
+    """Helper of test_early_residual_test_changes_nothing (own process: the knob is read once): three multi-launch
+    multilevel solves, prints a digest of the iterate and the solver's counters."""
+    import hashlib
+    import json
+
+    import dpgo_oracle as oracle
+    import dpgo_amd
+    om, n, d, Q, pg, prob = build_single_agent(oracle, name, r)
+    prob.setPersistent(False)
+    X = tiles_to_matrix(oracle.lift(oracle.chordal_initialization(om, n), r))
+    go = dpgo_amd.QuadraticOptimizer(prob, dpgo_amd.ROptParameters(precond="multilevel"))
+    rows = []
+    for call in range(3):
+        X = go.optimize(X)
+        rg = go.getOptResult()
+        rows.append([rg.tcg_iterations, rg.rtr_iterations, rg.tCGStatus, repr(rg.fOpt), repr(rg.gradNormOpt)])
+    print("DIGEST " + json.dumps([hashlib.sha256(np.ascontiguousarray(X).tobytes()).hexdigest(), rows]))
+
+
+@pytest.mark.parametrize("name,r", [("sphere2500", 5), ("kitti_00", 3)])
+def test_early_residual_test_changes_nothing(name, r):
+    """Multilevel tCG evaluates the residual test in the restriction kernel, one kernel before the Hessian-step kernel's
+    prologue would (TcgStopCheck, kernels/multilevel.h): a converged run skips the V-cycle on its final residual.  Nothing
+    of the solve may depend on it: the iterate after three solves is BIT-identical with the test left where it was
+    (DPGO_ML_EARLY_STOP=0), and so are the counters, the status and the cost."""
+    out = {}
+    for flag in ("0", "1"):
+        env = dict(os.environ, DPGO_ML_EARLY_STOP=flag)
+        code = ("import sys; sys.path.insert(0, %r); import conftest, test_parity_gpu as t; t._early_stop_case(%r, %d)" %
+                (os.path.dirname(os.path.abspath(__file__)), name, r))
+        p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, p.stderr[-3000:]
+        lines = [ln for ln in p.stdout.splitlines() if ln.startswith("DIGEST ")]
+        assert lines, p.stdout[-2000:]
+        out[flag] = lines[-1]
+    assert out["0"] == out["1"]
+    assert any(st in out["1"] for st in ("LCON", "SCON")), out["1"]  # (a run that ended on the residual test is in the sample)
