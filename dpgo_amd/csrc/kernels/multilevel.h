@@ -63,7 +63,8 @@ __global__ __launch_bounds__(kBlock) void k_ml_presmooth(const double* __restric
 // earlier than the Hessian-step kernel's prologue would (tcg_hess_prologue: same test, same state fields).  When it
 // holds it raises tcg_done in the state record the rest of the cycle and the next Hessian-step kernel are gated on and
 // publishes it to the host: the final iteration of a converged tCG run no longer pays for a dense solve and a
-// post-smoothing pass whose result nobody reads, and the host stops enqueuing one iteration sooner.
+// post-smoothing pass whose result nobody reads, and the host learns one cycle sooner that it can enqueue the outer
+// iteration's launches (what it had already enqueued of the next tCG iteration exits in its prologues, as before).
 struct TcgStopCheck {
   DevState* state = nullptr;  // the record `gate` points to; NULL: no check
   const double* pin = nullptr;
