@@ -20,11 +20,14 @@ storage): `frac` is its HBM-only figure (every operand cycling through > 256 MB 
 the back-to-back one the Infinity-Cache-resident loop sees; the other storage's figures stand beside it
 (`symmetric_storage` / `plain_storage`, with the fraction on the bytes that storage really moves);
 `roofline.kernels` lists the other kernels of one preconditioned tCG iteration.  `products_per_step` and
-`time_to_tolerance_ms` are top-level: "it/s" alone does not say how much a step does.  `cpu_baseline` (rank 0, N = 1
-only) = the reference configuration of the workload on the host cores (the graph cut into 8 agents, one core each,
-exact sparse factor of Q_a + 0.1 I, ONE two-colour sweep from the initial iterate) and, in `gpu_same_work`, this GPU
-running exactly that: same 8 blocks, same initial iterate, same one sweep, cost and gradient norm after it printed for
-both; beside it the 1-core C port of the device algorithm on the timed single-agent step.
+`time_to_tolerance_ms` are top-level: "it/s" alone does not say how much a step does; `hierarchy_setup_ms` is the
+once-per-Q cost of the preconditioner those solves ran (`time_to_tolerance_incl_setup_ms` = both).  `cpu_baseline` (rank
+0, N = 1 only) = the reference configuration of the workload on the host cores (the graph cut into 8 agents, one core
+each, exact sparse factor of Q_a + 0.1 I, ONE two-colour sweep from the SETTLED iterate every timed step restores;
+`factorisation_seconds` beside it) and, in `gpu_same_work`, this GPU running exactly that: same 8 blocks, same iterate,
+same one sweep, the preconditioner selection in its steady state, cost and gradient norm after it printed for both,
+`hierarchy_setup_ms` per block; the same pair from the initial iterate under `initial_iterate`; beside it the 1-core C
+port of the device algorithm on the timed single-agent step.
 """
 import argparse
 import json
@@ -56,8 +59,8 @@ def parse_args():
     ap.add_argument("--workload", default="grid100k")
     ap.add_argument("--rank", type=int, default=5, help="relaxation rank r")
     ap.add_argument("--precond", default="auto", choices=["auto", "jacobi", "multilevel", "additive"],
-                    help="tCG preconditioner: auto (library default: multilevel when the tCG budget binds, block-Jacobi "
-                         "while it does not), or one of the two all the time")
+                    help="tCG preconditioner: auto (library default, include/dpgo_hip.h DPGO_PRECOND_AUTO), or one of "
+                         "the others all the time")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the sphere2500 side measurement (`also` field)")
     ap.add_argument("--cpu-budget-s", type=float, default=25.0)
@@ -280,6 +283,19 @@ def gpu_same_decomposition(meas, n, X0, r, num_agents, precond, device, reset_au
     for ag in agents.values():
         ag.snapshot()
     cluster.sweep()  # untimed: first-use setup (block-Jacobi factors, launch caches)
+    selection_sweeps = 0
+    if precond == "auto" and not reset_auto:  # the selection's steady state from this iterate (as in main(); untimed)
+        def sel_state():
+            return [(ag.problem.autoState(), ag.problem.autoInfo()["state"], ag.problem.autoInfo()["backoff"]) for ag in agents.values()]
+        calm, prev = 0, sel_state()
+        while calm < 2 and selection_sweeps < 40:
+            for ag in agents.values():
+                ag.restore()
+            cluster.sweep()
+            selection_sweeps += 1
+            cur = sel_state()
+            calm = calm + 1 if cur == prev else 0
+            prev = cur
     best, products = None, 0
     for _ in range(3):
         for ag in agents.values():
@@ -295,7 +311,29 @@ def gpu_same_decomposition(meas, n, X0, r, num_agents, precond, device, reset_au
             best = el
         products = sum(ag.last_result.tcg_iterations for ag in agents.values())
     f, g = cluster.central_cost_and_gradnorm()
+    # the once-per-Q cost of the blocks' preconditioner (the pair of cpu_baseline.factorisation_seconds): the hierarchy of
+    # the additive one-launch solve -- what `auto` builds for a coupled block of this size once block-Jacobi has cost as
+    # much -- timed on a fresh handle of every block: first call = block pattern (host) + values (device), second = values
+    setup = None
+    try:
+        setup = dict(first_ms=[], values_only_ms=[], aggregates=[])
+        for a in range(num_agents):
+            pr = dpgo_amd.QuadraticProblem(graphs[a], device=device, host_linear_term=False)
+            pl = pr.additivePlan()
+            ks = pl["ks"] if pl["lane_groups"] else None
+            for key in ("first_ms", "values_only_ms"):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                info = pr.setupMultilevel(ks)
+                setup[key].append(1e3 * (time.perf_counter() - t0))
+            setup["aggregates"].append(info["sizes"][-1])
+            del pr
+        setup["what"] = ("additive two-level hierarchy (merged graph aggregates, one per workgroup)" if ks is not None
+                         else "default multilevel hierarchy")
+    except Exception as exc:  # noqa: BLE001
+        setup = {"error": repr(exc)}
     return dict(value=1.0 / best, unit="it/s", seconds_per_sweep=best, agents=num_agents,
+                hierarchy_setup_ms=setup, selection_sweeps=selection_sweeps, auto_rule=[agents[a].problem.autoInfo() for a in range(num_agents)] if precond == "auto" else None,
                 poses_per_agent=n // num_agents, tcg_iterations=products,
                 tcg_iterations_per_agent=[agents[a].last_result.tcg_iterations for a in range(num_agents)],
                 cost_2f_after=2 * f, gradnorm_after=g,
@@ -334,9 +372,18 @@ def secondary_single_agent(workload, r, precond, steps, warmup, settle):
         tcg += res.tcg_iterations
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
-    return dict(workload=desc, precond=precond, it_per_s=steps / el, ms_per_step=1e3 * el / steps,
-                tcg_iterations_per_step=tcg / steps, settle_iterations=k, gradnorm_before_step=gns[k],
-                gradnorm_after_step=res.gradNormOpt)
+    ph = ag.problem.persistentPhases()  # (the last timed solve: in-kernel split of a one-launch solve, zeros otherwise)
+    return dict(workload=desc, precond=precond, precond_used=res.precond_used, it_per_s=steps / el,
+                ms_per_step=1e3 * el / steps, tcg_iterations_per_step=tcg / steps,
+                us_per_product=1e6 * el / max(tcg, 1), settle_iterations=k, gradnorm_before_step=gns[k],
+                gradnorm_after_step=res.gradNormOpt,
+                in_kernel_us_per_iteration=(dict(hessian_phase=ph["hessian"], all_reduce_after_hessian=ph["reduce_after_hessian"],
+                                                 update_phase=ph["update"], reductions_after_update=ph["reduce_after_update"],
+                                                 total=ph["hessian"] + ph["reduce_after_hessian"] + ph["update"] + ph["reduce_after_update"],
+                                                 note="participant 0 of the one-launch solve, 100 MHz wall clock, iterations after the "
+                                                      "first; us_per_product above = wall time of the whole step (launch, "
+                                                      "outer iterations, read-back) over its products")
+                                            if ph["iterations"] > 0 else None))
 
 
 def time_to_tolerance(workload, r, precond, tol=1e-2, max_calls=12, coarse_bits=None):
@@ -368,8 +415,34 @@ def time_to_tolerance(workload, r, precond, tol=1e-2, max_calls=12, coarse_bits=
             break
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
+    # the once-per-Q cost the loop above does not contain (the reference factors inside its first timed solve,
+    # src/PoseGraph.cpp:582-586): the hierarchy of the preconditioner the calls ran, built on a FRESH handle -- block
+    # pattern on the host + values on the device (first_ms), values only (what a change of Q's values costs)
+    setup_first = setup_values = None
+    ml_used = [u for u in used if u in ("multilevel", "additive")]
+    if ml_used:
+        try:
+            pr = dpgo_amd.QuadraticProblem(graphs[0], host_linear_term=False)
+            ks = None
+            if ml_used[0] == "additive":
+                pl = pr.additivePlan()
+                ks = pl["ks"] if pl["lane_groups"] else None
+            if coarse_bits is not None:
+                pr.multilevelCoarseBits(coarse_bits)
+            ts = []
+            for _ in range(2):
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                pr.setupMultilevel(ks)
+                ts.append(1e3 * (time.perf_counter() - t1))
+            setup_first, setup_values = ts
+            del pr
+        except Exception as exc:  # noqa: BLE001
+            sys.stderr.write("bench.py: hierarchy set-up timing failed: %r\n" % (exc,))
     return dict(products=products, rbcd_iterations=calls, ms=1e3 * el, gradnorm=gn, reached=bool(gn < tol),
-                us_per_product=1e6 * el / max(products, 1), preconditioners=used)
+                us_per_product=1e6 * el / max(products, 1), preconditioners=used,
+                hierarchy_setup_ms=setup_first, hierarchy_values_only_ms=setup_values,
+                ms_incl_setup=(1e3 * el + setup_first) if setup_first is not None else 1e3 * el)
 
 
 def main():
@@ -481,6 +554,27 @@ def main():
     del states
     for a in agents.values():
         a.snapshot()
+    # Steady state of the preconditioner selection (untimed): `auto` decides per handle from the solves themselves (coupled
+    # blocks: the cost rule of dpgo_hip.h pays the hierarchy once the block-Jacobi solves have cost as much) -- sweeps from
+    # the benchmark's iterate until no agent's selection state changed in two consecutive sweeps, so that the timed steps
+    # run what a long RBCD run runs and contain no set-up.
+    selection_sweeps = 0
+    if args.precond == "auto" and num_agents > 1:
+        def sel_state():
+            return [(ag.problem.autoState(), ag.problem.autoInfo()["state"], ag.problem.autoInfo()["backoff"]) for ag in agents.values()]
+        calm, prev = 0, sel_state()
+        while calm < 2 and selection_sweeps < 40:
+            for a in agents.values():
+                a.restore()
+            cluster.sweep()
+            selection_sweeps += 1
+            cur = sel_state()
+            changed = torch.tensor([0.0 if cur == prev else 1.0], dtype=torch.float64,
+                                   device="cpu" if (use_dist and cluster.stage) else "cuda")
+            if use_dist:  # every rank runs the same number of sweeps (they contain the exchanges)
+                dist.all_reduce(changed, op=dist.ReduceOp.MAX)
+            calm = calm + 1 if float(changed.item()) == 0.0 else 0
+            prev = cur
 
     # device time of the public-pose exchanges, from event pairs on the stream they are enqueued on -- no host wait is
     # added to the path being timed (pack kernel -> RCCL batch / device copies -> consumed by the coupling SpMM)
@@ -678,7 +772,8 @@ def main():
                     kernel="%s (one tCG step: Q*z block-SpMM + Riemannian-Hessian epilogue + in-place direction / "
                            "H-direction recurrences)" % kname,
                     achieved=ach_rot, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach_rot / HBM_PEAK_GBS, traffic=traffic,
-                    traffic_source=traffic_src, bytes_per_launch=hb, avg_launch_us=ms_hrot.value * 1e3,
+                    traffic_source=traffic_src, traffic_live=False,  # (a constant of the committed PMC summary, not of this run)
+                    bytes_per_launch=hb, avg_launch_us=ms_hrot.value * 1e3,
                     protocol="HIP events over %d launches of the kernel the timed loop launches (storage selected: %s), "
                              "every operand rotating through %d private sets (> 256 MB in total): HBM-only rate"
                              % (args.spmm_reps, timed, hsets),
@@ -772,12 +867,16 @@ def main():
                                         "timed step restores): " + settled_cpu["sample"]
                 try:
                     sg = gpu_same_decomposition(meas, n, X_set, r, 8, args.precond, dev_index, reset_auto=False)
-                    sg["sample"] += "; from the settled iterate, the preconditioner selection carried over from the untimed sweep"
+                    sg["sample"] += "; from the settled iterate, the preconditioner selection in its steady state"
                     settled_cpu["gpu_same_work"] = sg
                     settled_cpu["gpu_over_cpu_same_work"] = sg["value"] / settled_cpu["value"]
                 except Exception as exc:  # noqa: BLE001
                     sys.stderr.write("bench.py: gpu_same_work (settled) failed: %r\n" % (exc,))
-                cpu["settled_iterate"] = settled_cpu
+                # the SETTLED pair is cpu_baseline.value (the hot loop proper: the tCG loop, not the launch overhead of a
+                # handful of boundary-limited products, is what both sides spend their time in); the pair from the initial
+                # iterate stays under its own key
+                settled_cpu["initial_iterate"] = cpu
+                cpu = settled_cpu
             except Exception as exc:  # noqa: BLE001
                 sys.stderr.write("bench.py: cpu_baseline (settled iterate) failed: %r\n" % (exc,))
         try:  # the device algorithm on one core, same step as the GPU's (same settled iterate)
@@ -838,6 +937,12 @@ def main():
             "gradnorm_after_step": g1,
             "time_to_tolerance_ms": tt_main.get("ms") if tt_main.get("reached") else None,
             "products_to_tolerance": tt_main.get("products") if tt_main.get("reached") else None,
+            # the once-per-Q cost (the reference's factorisation sits inside its first timed solve,
+            # src/PoseGraph.cpp:582-586; cpu_baseline.factorisation_seconds is its pair): the hierarchy of the
+            # preconditioner the solves above ran, on a fresh handle -- block pattern on the host + values on the device
+            "hierarchy_setup_ms": tt_main.get("hierarchy_setup_ms"),
+            "hierarchy_values_only_ms": tt_main.get("hierarchy_values_only_ms"),
+            "time_to_tolerance_incl_setup_ms": tt_main.get("ms_incl_setup") if tt_main.get("reached") else None,
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
@@ -846,15 +951,19 @@ def main():
             "config": {"workload": desc, "agents": num_agents, "agents_per_gpu": apg, "r": r, "d": d,
                        "local_solver": "RTR 3x<=50 tCG, Delta0=100, tol=1e-2 (reference defaults), precond = %s; %s" % (
                            {"jacobi": "block-Jacobi", "multilevel": "multilevel", "additive": "additive two-level",
-                            "auto": "auto (library default: a multilevel preconditioner when the tCG budget binds, else "
-                                    "block-Jacobi)"}[
+                            "auto": "auto (library default: multilevel on a block without coupling; a coupled block "
+                                    "starts on block-Jacobi and moves to the additive two-level one-launch solve once "
+                                    "block-Jacobi has cost one hierarchy set-up, while that is cheaper -- dpgo_hip.h)"}[
                                args.precond],
                            ("time_to_tolerance_ms = %.3f (%d Hessian-vector products from the initial guess to |rgrad| < "
                             "1e-2, single agent, same settings)" % (tt_main["ms"], tt_main["products"]))
                            if tt_main.get("reached") else "time_to_tolerance_ms = not measured in this run"),
                        "time_to_tolerance_ms": tt_main.get("ms") if tt_main.get("reached") else None,
+                       "hierarchy_setup_ms": tt_main.get("hierarchy_setup_ms"),
+                       "time_to_tolerance_incl_setup_ms": tt_main.get("ms_incl_setup") if tt_main.get("reached") else None,
                        "products_per_step": tcg_total / max(args.steps, 1),
                        "precond_used_in_timed_steps": sorted(used_precond),
+                       "selection_sweeps_before_timing": selection_sweeps,
                        "same_colour_agents": "sequential (diagnostic)" if args.sequential else "concurrent",
                        "schedule": "single agent" if num_agents == 1 else
                        "%d-colour parallel RBCD; 1 step = 1 sweep (every agent updates once; same-colour agents of a "

@@ -191,10 +191,23 @@ struct dpgo_problem_s {
   // to other agents -- there the tCG budget, not the trust-region boundary, ends the local solves --, block-Jacobi
   // for a block of a multi-agent problem; then hysteresis on the share of the tCG budget each solve used.
   bool auto_ml = false, auto_decided = false;
+  // The cost rule of a COUPLED block the additive one-launch solve can hold (dpgo_hip.h, DPGO_PRECOND_AUTO): Q -- and with it
+  // the hierarchy -- is constant across RBCD sweeps, so the set-up is paid once; everything is counted in units of a tenth of
+  // a block-Jacobi product (kAutoUnits*), a function of the solves' product counts only, so that repeated runs reproduce.
+  struct AutoCost {
+    long long jac_units = 0;  // block-Jacobi work since Q last changed (or since the last hand-back)
+    int ref = 0;              // products of the block-Jacobi solve the additive form is measured against
+    int state = 0;            // 0 block-Jacobi, 1 additive on trial (its first solve), 2 additive
+    int backoff = 0;          // hand-backs so far: the next trial waits for 2^backoff set-ups' worth of block-Jacobi work
+    int switches = 0;         // block-Jacobi -> additive transitions since Q last changed
+    int last_used = -1, last_products = 0;  // the last auto solve, as the rule saw it
+    int uj = 10, ua = 18;     // unit costs of a block-Jacobi / an additive product the rule last used (auto_units_*)
+  } auto_cost;
   void auto_decide() {
     if (!auto_decided) {
       auto_ml = !(has_G || C.nnzb > 0);
       auto_decided = true;
+      auto_cost = AutoCost();
     }
   }
   // two-level hierarchies: level-0 post-smoothing through A P and the coarse solution (k_ml_post_ap); DPGO_ML_AP=0 disables
@@ -1247,14 +1260,31 @@ const dpgo_problem_s::AddPlan& additive_plan(dpgo_problem_s* p) {
       }
     }
     if ((long long)n <= (long long)kPersistMax * P1) {
-      for (int S = std::max(8, (n + 229) / 230); S <= P1; S += std::max(2, S / 8)) {
+      // A handle that is solved next to other handles of the device (dpgo_optimize_device_many: persist_share > 1 when the
+      // plan is first asked for) aims at HALF the chip -- every aggregate is a workgroup that owns a CU for the whole solve,
+      // so two such solves run side by side instead of taking turns; the product count is a weak function of the aggregate
+      // size, the time of an iteration is not a function of how full the tiles are.
+      const int want = (p->persist_share > 1 && (long long)n * 10 <= (long long)(kPersistMax / 2) * P1 * 8) ? kPersistMax / 2 : kPersistMax;
+      for (int S = std::max(8, (n + (want * 9) / 10 - 1) / ((want * 9) / 10)); S <= P1; S += std::max(2, S / 8)) {
         const int cap = std::min(P1, S + S / 2);
         ml_graph_aggregates(p->h_rowptr, p->h_colidx, n, S, lab, ptr, mem, parent, pslot);
         const int na = ml_merge_small_aggregates(p->h_rowptr, p->h_colidx, n, S, cap, lab, ptr, mem, parent, pslot);
-        if (na <= kPersistMax) {
+        if (na <= want) {
           p->add_plan = dpgo_problem_s::AddPlan{1, P1, S, cap, na, true};
           A.S = S, A.cap = cap;
           return p->add_plan;
+        }
+      }
+      if (want < kPersistMax) {  // (no growth size reaches half the chip: the whole-chip plan)
+        for (int S = std::max(8, (n + 229) / 230); S <= P1; S += std::max(2, S / 8)) {
+          const int cap = std::min(P1, S + S / 2);
+          ml_graph_aggregates(p->h_rowptr, p->h_colidx, n, S, lab, ptr, mem, parent, pslot);
+          const int na = ml_merge_small_aggregates(p->h_rowptr, p->h_colidx, n, S, cap, lab, ptr, mem, parent, pslot);
+          if (na <= kPersistMax) {
+            p->add_plan = dpgo_problem_s::AddPlan{1, P1, S, cap, na, true};
+            A.S = S, A.cap = cap;
+            return p->add_plan;
+          }
         }
       }
     }
@@ -1786,6 +1816,96 @@ int rtr_outer_iteration(dpgo_problem_s* p, const dpgo_ropt_params* prm, const do
   return DPGO_OK;
 }
 
+// DPGO_PRECOND_AUTO after a solve: what the next one runs (dpgo_hip.h).  `used` = the preconditioner the solve resolved to,
+// `products` = its Hessian-vector products.
+//   * a block without coupling to other agents never hands back (its cheap early calls end on the trust-region boundary
+//     after a few products whatever the preconditioner, and the switch back and forth cost the 100k grid 37.6 against
+//     29.3 ms);
+//   * a coupled block the additive one-launch solve cannot hold: hysteresis on the share of the tCG budget a solve used
+//     (the V-cycle is ~3x a block-Jacobi iteration: it pays when the budget binds);
+//   * a coupled block the additive solve CAN hold (<= ~14 000 poses): the cost rule.  Q is constant across RBCD sweeps, so
+//     the hierarchy is paid once: when the block-Jacobi solves since the last change of Q have cost as much as one set-up
+//     (kAutoSetupUnits: 2.8-3.0 ms against 9.9-10.6 us per block-Jacobi product on 6 250 / 12 500 poses), the next solve
+//     runs additive on trial; it stays while its products x the additive unit cost (19 us) stay below the reference
+//     block-Jacobi solve's x the block-Jacobi unit cost, and hands back otherwise (the hierarchy is kept: the next trial
+//     is free but waits twice as long).
+//     The unit costs are those of a solve that has the device to itself.  A handle solved NEXT TO others of the device
+//     (dpgo_optimize_device_many, persist_share > 1) is charged for the part of the chip its launch blocks instead: the
+//     additive form owns one CU per aggregate (up to the whole chip: such solves take turns), block-Jacobi's compact
+//     layout a quarter to a half of it, so there a product costs [us] x max(resident slots / slots in use at once, 1 / share)
+//     x share -- the same figure as alone whenever every concurrently solved handle fits at once.
+constexpr int kAutoUnitsJacobi = 10, kAutoUnitsAdditive = 18, kAutoSetupUnits = 2800, kAutoMinProducts = 6;
+int auto_units_jacobi(dpgo_problem_s* p) {
+  const int share = std::max(1, p->persist_share);
+  if (share == 1 || !p->persist) return kAutoUnitsJacobi;
+  const int cap = persist_capacity(p->device), limit = cap - cap / 5;  // (what launch_rtr_persistent lets such solves use)
+  const PersistGeo g = persist_geometry(p, limit, share, false);
+  if (g.wgs <= 0) return kAutoUnitsJacobi;
+  const double part = std::max((double)g.slots / limit, 1.0 / share);
+  return std::max(1, (int)std::lround(kAutoUnitsJacobi * (g.mt == 2 ? 1.25 : 1.0) * part * share));
+}
+int auto_units_additive(dpgo_problem_s* p) {  // (after additive_available(p): the plan exists)
+  const int share = std::max(1, p->persist_share);
+  if (share == 1) return kAutoUnitsAdditive;
+  const int cap = persist_capacity(p->device);
+  const double part = std::max((double)(p->add_plan.na * persist_slots_per_wg(p->add_plan.split, 1, true)) / cap, 1.0 / share);
+  return std::max(1, (int)std::lround(kAutoUnitsAdditive * part * share));
+}
+void auto_update(dpgo_problem_s* p, const dpgo_ropt_params* prm, int used, int products) {
+  const int budget = std::max(1, prm->RTR_iterations) * std::max(1, prm->RTR_tCG_iterations);
+  const bool coupled = p->has_G || p->C.nnzb > 0;
+  auto& a = p->auto_cost;
+  a.last_used = used;
+  a.last_products = products;
+  if (!coupled) {
+    if (!p->auto_ml && 2 * products >= budget) p->auto_ml = true;
+    return;
+  }
+  static const bool cost_rule = [] { const char* e = std::getenv("DPGO_AUTO_COST_RULE"); return !e || std::atoi(e) != 0; }();
+  if (!p->auto_ml) {  // the solve ran block-Jacobi
+    a.state = 0;
+    a.uj = auto_units_jacobi(p);
+    a.jac_units += (long long)kAutoUnitsJacobi * products;  // (the set-up is wall time: paid back in solo units)
+    const bool binds = 2 * products >= budget;
+    const bool paid = cost_rule && products >= kAutoMinProducts && a.jac_units >= ((long long)kAutoSetupUnits << a.backoff);
+    if (binds || paid) {
+      // (the plan -- host aggregation, once per block pattern -- is only looked for when the rule wants it)
+      const bool add = cost_rule && !p->ml_user_ks && additive_available(p);
+      if (add) a.ua = auto_units_additive(p);
+      // a trial that cannot win is not run: even at kAutoMinProducts the additive solve would cost more than this one did
+      const bool hopeless = add && !binds && (long long)a.ua * kAutoMinProducts >= (long long)a.uj * products;
+      if (hopeless) {
+        a.jac_units = 0;
+        a.backoff = std::min(a.backoff + 1, 6);
+      } else if (binds || add) {
+        p->auto_ml = true;
+        if (add) {
+          a.state = 1;
+          a.ref = products;
+          a.switches += 1;
+        }
+      }
+    }
+    return;
+  }
+  if (a.state == 0) {  // a multilevel choice outside the cost rule (V-cycle blocks, dpgo_problem_auto_state): budget hysteresis
+    if (10 * products <= budget) p->auto_ml = false;
+    return;
+  }
+  a.ua = auto_units_additive(p);
+  // on trial: strictly cheaper than the reference solve; once accepted: handed back only when 15 % dearer (the two are
+  // within a few per cent of each other on interior blocks of a chain partition -- no flapping)
+  const long long cost = (long long)a.ua * products * 100, ref = (long long)a.uj * a.ref * (a.state == 2 ? 115 : 100);
+  if (cost < ref) {
+    a.state = 2;
+  } else {  // no cheaper than block-Jacobi on this block in this phase of the run: hand back, try again later
+    p->auto_ml = false;
+    a.state = 0;
+    a.jac_units = 0;
+    a.backoff = std::min(a.backoff + 1, 6);
+  }
+}
+
 // phase: RUN_FULL = the whole solve, synchronously.  RUN_BEGIN = enqueue only: if the solve is a one-launch solve
 // (k_rtr_persist) the call returns with the launch, its commit kernel and the read-backs in flight (p->pending.launched);
 // otherwise the solve runs to completion right here.  RUN_END = collect what RUN_BEGIN left in flight (waits for the
@@ -1893,12 +2013,7 @@ int run_optimize(dpgo_problem_s* p, const dpgo_ropt_params* prm, dpgo_ropt_resul
         res->tcg_iterations = h.n_hess;
         res->precond_used = prm->precond;
         res->spmm_count = 1 + 2 * h.outer_iter + h.n_hess;
-        if (is_auto) {  // hysteresis on how much of the tCG budget the solve used (see below)
-          const int budget = std::max(1, prm->RTR_iterations) * std::max(1, prm->RTR_tCG_iterations);
-          const bool coupled = p->has_G || p->C.nnzb > 0;
-          if (!p->auto_ml && 2 * h.n_hess >= budget) p->auto_ml = true;
-          else if (p->auto_ml && coupled && 10 * h.n_hess <= budget) p->auto_ml = false;
-        }
+        if (is_auto) auto_update(p, prm, prm->precond, h.n_hess);
         res->success = 1;  // :44
         res->elapsedMs = 1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         return DPGO_OK;
@@ -1996,14 +2111,7 @@ int run_optimize(dpgo_problem_s* p, const dpgo_ropt_params* prm, dpgo_ropt_resul
   }
   res->tcg_iterations = n_hess_total;
   res->precond_used = (prm->precond == DPGO_PRECOND_ADDITIVE && cnt.vcycle_for_additive) ? DPGO_PRECOND_MULTILEVEL : prm->precond;
-  if (is_auto && prm->method == DPGO_METHOD_RTR) {  // hysteresis on how much of the tCG budget the solve used
-    const int budget = std::max(1, prm->RTR_iterations) * std::max(1, prm->RTR_tCG_iterations);
-    // (a block without coupling never hands back: its cheap early calls end on the trust-region boundary after a few
-    // products whatever the preconditioner, and the switch back and forth cost the 100k grid 37.6 against 29.3 ms)
-    const bool coupled = p->has_G || p->C.nnzb > 0;
-    if (!p->auto_ml && 2 * n_hess_total >= budget) p->auto_ml = true;
-    else if (p->auto_ml && coupled && 10 * n_hess_total <= budget) p->auto_ml = false;
-  }
+  if (is_auto && prm->method == DPGO_METHOD_RTR) auto_update(p, prm, res->precond_used, n_hess_total);
   res->spmm_count = cnt.spmm + n_hess_total;
   res->success = 1;  // :44 (set unconditionally after a solve)
   res->elapsedMs = 1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
@@ -2751,11 +2859,34 @@ int dpgo_problem_auto_state(dpgo_problem_t p, int* use_multilevel) {
   if (*use_multilevel >= 0) {
     p->auto_ml = *use_multilevel != 0;
     p->auto_decided = true;
+    p->auto_cost = dpgo_problem_s::AutoCost();  // (a choice made from outside is followed by the budget hysteresis)
   } else {
     if (*use_multilevel == -2) p->auto_decided = false;  // back to the decision a fresh handle takes for this problem
     p->auto_decide();
   }
   *use_multilevel = p->auto_ml ? 1 : 0;
+  return DPGO_OK;
+}
+
+int dpgo_problem_auto_info(dpgo_problem_t p, int* state, long long* jacobi_units, int* reference_products, int* switches,
+                           int* backoff, int* units_jacobi, int* units_additive) {
+  if (!p) return fail(DPGO_ERR_INVALID, "null handle");
+  const auto& a = p->auto_cost;
+  if (units_jacobi) *units_jacobi = a.uj;
+  if (units_additive) *units_additive = a.ua;
+  if (state) *state = a.state;
+  if (jacobi_units) *jacobi_units = a.jac_units;
+  if (reference_products) *reference_products = a.ref;
+  if (switches) *switches = a.switches;
+  if (backoff) *backoff = a.backoff;
+  return DPGO_OK;
+}
+
+int dpgo_auto_rule_constants(int* units_jacobi, int* units_additive, int* setup_units, int* min_products) {
+  if (units_jacobi) *units_jacobi = kAutoUnitsJacobi;
+  if (units_additive) *units_additive = kAutoUnitsAdditive;
+  if (setup_units) *setup_units = kAutoSetupUnits;
+  if (min_products) *min_products = kAutoMinProducts;
   return DPGO_OK;
 }
 
@@ -3195,6 +3326,15 @@ int dpgo_problem_persistent_info(dpgo_problem_t p, int* enabled, int* workgroups
   if (last_members) *last_members = p->hctrl ? (int)p->hctrl->members : 0;
   if (last_iterations) *last_iterations = p->hctrl ? (int)p->hctrl->iters : 0;
   if (last_layout) *last_layout = (p->hctrl && p->hctrl->members) ? p->persist_split * 16 + p->persist_mt : 0;
+  return DPGO_OK;
+}
+
+int dpgo_problem_persistent_phases(dpgo_problem_t p, double us_per_iteration[4], int* iterations) {
+  if (!p || !us_per_iteration) return fail(DPGO_ERR_INVALID, "null handle / pointer");
+  const double it = p->hctrl ? (double)p->hctrl->ticks[4] : 0.0;
+  for (int k = 0; k < 4; ++k)  // (100 MHz wall-clock ticks of participant 0, summed over the iterations after the first)
+    us_per_iteration[k] = (p->hctrl && it > 0.0 && p->hctrl->members) ? 0.01 * (double)p->hctrl->ticks[k] / it : 0.0;
+  if (iterations) *iterations = (p->hctrl && p->hctrl->members) ? (int)p->hctrl->iters : 0;
   return DPGO_OK;
 }
 

@@ -85,6 +85,8 @@ SIGNATURES = {
     "dpgo_problem_multilevel_path": ([_P, C.POINTER(_I)], _I),
     "dpgo_problem_multilevel_coarse_bits": ([_P, C.POINTER(_I)], _I),
     "dpgo_problem_auto_state": ([_P, C.POINTER(_I)], _I),
+    "dpgo_problem_auto_info": ([_P, C.POINTER(_I), C.POINTER(C.c_longlong)] + [C.POINTER(_I)] * 5, _I),
+    "dpgo_auto_rule_constants": ([C.POINTER(_I)] * 4, _I),
     "dpgo_problem_set_G": ([_P, _P], _I),
     "dpgo_problem_set_G_device": ([_P, _P], _I),
     "dpgo_problem_set_G_coupling": ([_P, _I, _I, _P, _P, _P, _P], _I),
@@ -131,6 +133,7 @@ SIGNATURES = {
     "dpgo_axpby_project_device": ([_I, _I, _I, _D, _P, _D, _P, _D, _P, _I, _P, _P], _I),
     "dpgo_problem_set_persistent": ([_P, _I], _I),
     "dpgo_problem_persistent_info": ([_P, C.POINTER(_I), C.POINTER(_I), C.POINTER(_I), C.POINTER(_I), C.POINTER(_I)], _I),
+    "dpgo_problem_persistent_phases": ([_P, _P, C.POINTER(_I)], _I),
     "dpgo_chordal_initialization": ([_I, _I, _I, _P, _P, _P, _P, _P, _P, _D, _I, _P, _P, _I], _I),
     "dpgo_odometry_initialization": ([_I, _I, _I, _P, _P, _P, _P, _P], _I),
     "dpgo_device_malloc": ([C.POINTER(_P), C.c_size_t, _I], _I),

@@ -489,6 +489,14 @@ class QuadraticProblem:
         out["last_split"], out["last_tiles"] = v[4].value // 16, v[4].value % 16
         return out
 
+    def persistentPhases(self) -> dict:
+        """In-kernel phase split of the last one-launch solve, us per tCG iteration on participant 0
+        (dpgo_problem_persistent_phases): hessian, reduce_after_hessian, update, reduce_after_update; iterations."""
+        v = (C.c_double * 4)()
+        it = C.c_int(0)
+        L.check(self._lib.dpgo_problem_persistent_phases(self._h, v, C.byref(it)))
+        return dict(hessian=v[0], reduce_after_hessian=v[1], update=v[2], reduce_after_update=v[3], iterations=it.value)
+
     # ---- multilevel preconditioner (built on the device; lazily by the first solve, like
     # PoseGraph::constructPreconditioner inside the first PreConditioner call, src/PoseGraph.cpp:582-586) ----
     def multilevelPath(self) -> dict:
@@ -534,6 +542,23 @@ class QuadraticProblem:
         v = C.c_int(-1 if use_multilevel is None else (-2 if use_multilevel == "reset" else int(bool(use_multilevel))))
         L.check(self._lib.dpgo_problem_auto_state(self._h, C.byref(v)))
         return bool(v.value)
+
+    def autoInfo(self) -> dict:
+        """Where the cost rule of precond = "auto" stands on this handle (dpgo_problem_auto_info): state ("jacobi" /
+        "trial" / "additive"), jacobi_units counted since Q last changed (or the last hand-back), reference_products,
+        switches, backoff, the unit costs the rule last charged on this handle (units_jacobi / units_additive: scaled by the
+        part of the chip a launch blocks when the handle is solved next to others) and the rule's constants
+        (dpgo_auto_rule_constants)."""
+        st, ref, sw, bo, uj, ua = (C.c_int(0) for _ in range(6))
+        units = C.c_longlong(0)
+        L.check(self._lib.dpgo_problem_auto_info(self._h, C.byref(st), C.byref(units), C.byref(ref), C.byref(sw), C.byref(bo),
+                                                 C.byref(uj), C.byref(ua)))
+        k = [C.c_int(0) for _ in range(4)]
+        L.check(self._lib.dpgo_auto_rule_constants(*[C.byref(x) for x in k]))
+        return dict(state=("jacobi", "trial", "additive")[st.value], jacobi_units=int(units.value),
+                    reference_products=ref.value, switches=sw.value, backoff=bo.value,
+                    units_jacobi=uj.value, units_additive=ua.value, units_jacobi_alone=k[0].value,
+                    units_additive_alone=k[1].value, setup_units=k[2].value, min_products=k[3].value)
 
     def multilevelInfo(self) -> dict:
         """{"sizes": nodes per level, "ks": aggregate size per coarsening (negative: graph aggregates of at most that many

@@ -51,13 +51,25 @@ extern "C" {
 #define DPGO_PRECOND_NONE 0
 #define DPGO_PRECOND_BLOCK_JACOBI 1
 #define DPGO_PRECOND_MULTILEVEL 2 /* aggregation-multigrid V-cycle for Q + shift I (built on the device) */
-/* DEFAULT.  The multilevel cycle whenever it pays, block-Jacobi otherwise, decided per handle from the solves themselves:
- * a block-Jacobi solve that used >= half of its tCG budget (RTR_iterations x RTR_tCG_iterations Hessian-vector products)
- * makes the next solves multilevel; a multilevel solve that needed <= a tenth of the budget hands back to block-Jacobi.
- * Rationale: a multilevel iteration costs ~3.3x a block-Jacobi one and needs 4-7x fewer of them
- * when the tCG budget binds (single-agent solves, the locally dominated end phase) -- but in multi-agent RBCD far from
- * the optimum the trust-region boundary and the coupling, not the preconditioner, end the local solves.
- * dpgo_ropt_result::precond_used says what a call ran. */
+/* DEFAULT.  A multilevel preconditioner whenever it pays, block-Jacobi otherwise, decided per handle from the solves
+ * themselves (a function of their product counts only, so repeated runs reproduce; every change of Q starts over):
+ *  - a block WITHOUT coupling to other agents runs multilevel from its first solve and never hands back;
+ *  - a coupled block the additive one-launch solve can hold (dpgo_problem_additive_plan: up to ~14 000 poses in 3-D)
+ *    follows a COST RULE, in units of a tenth of a block-Jacobi product (dpgo_auto_rule_constants): Q -- hence the
+ *    hierarchy -- is constant across RBCD sweeps, so its set-up (2 800 units = 280 block-Jacobi products: 2.8-3.0 ms
+ *    against 10 us) is paid once.  When the block-Jacobi solves since Q last changed have cost as much as one set-up
+ *    (and the last one ran >= 6 products), or one of them used >= half its tCG budget, the next solve runs additive on
+ *    trial; it stays additive while its products x 18 stay below the reference block-Jacobi solve's x 10 (19 us against
+ *    10.6 us per product), and hands back otherwise -- the hierarchy is kept, the next trial waits for twice the work.
+ *    Handles solved next to others of one device are charged for the part of the chip their launch blocks
+ *    (dpgo_problem_auto_info): there the additive form -- one CU per aggregate -- has to need ~3x fewer products;
+ *  - any other coupled block: a block-Jacobi solve that used >= half of its tCG budget (RTR_iterations x
+ *    RTR_tCG_iterations products) makes the next solves multilevel (the V-cycle: ~3x a block-Jacobi iteration, 4-7x fewer of
+ *    them when the budget binds); a multilevel solve that needed <= a tenth of the budget hands back.
+ * In multi-agent RBCD far from the optimum the trust-region boundary and the coupling, not the preconditioner, end the
+ * local solves: there the trial fails and block-Jacobi stays.  dpgo_ropt_result::precond_used says
+ * what a call ran, dpgo_problem_auto_info where the rule stands.  DPGO_AUTO_COST_RULE=0 in the environment: budget
+ * hysteresis only (the rule of earlier versions). */
 #define DPGO_PRECOND_AUTO 3
 /* Additive two-level preconditioner  z = proj_X( Dinv r + P A_c^-1 P^T r )  (block-Jacobi plus the coarse-grid correction
  * of the residual; same tree prolongations and Galerkin coarse operator as the multilevel cycle; ONE aggregate per
@@ -263,6 +275,18 @@ int dpgo_problem_multilevel_coarse_bits(dpgo_problem_t h, int* bits);
  * decision a fresh handle takes for the current problem (multilevel for a block without coupling to other agents,
  * block-Jacobi for a block of a multi-agent problem; every change of Q does the same). */
 int dpgo_problem_auto_state(dpgo_problem_t h, int* use_multilevel);
+/* Where the cost rule of DPGO_PRECOND_AUTO stands on this handle (any pointer may be NULL): state 0 = block-Jacobi,
+ * 1 = the additive form on trial (its first solve is next or just ran), 2 = additive; jacobi_units = block-Jacobi work
+ * counted since Q last changed or since the last hand-back; reference_products = products of the block-Jacobi solve the
+ * additive form is measured against; switches = block-Jacobi -> additive transitions since Q last changed; backoff =
+ * hand-backs so far (incl. trials not run because they could not win); units_jacobi / units_additive = the unit costs the
+ * rule last charged a product of either kind on THIS handle: the constants below for a solve that has the device to
+ * itself; for a handle solved next to others of the device (dpgo_optimize_device_many) scaled by the part of the chip the
+ * launch blocks (the additive form owns one CU per aggregate, so such solves take turns).  dpgo_auto_rule_constants: the rule's units per block-Jacobi / additive product, the set-up cost in
+ * the same units and the fewest products of a solve that can trigger a trial (host only). */
+int dpgo_problem_auto_info(dpgo_problem_t h, int* state, long long* jacobi_units, int* reference_products, int* switches,
+                           int* backoff, int* units_jacobi, int* units_additive);
+int dpgo_auto_rule_constants(int* units_jacobi, int* units_additive, int* setup_units, int* min_products);
 /* In-place blocked Gauss-Jordan inverse of a dense SPD matrix on the device (the kernel pair that inverts the coarsest
  * operator; exposed for tests).  N <= 16384, row-major host arrays; use_mfma: fp64 matrix cores for the rank-64
  * updates (v_mfma_f64_16x16x4_f64) or plain FMAs. */
@@ -404,6 +428,11 @@ int dpgo_bench_iteration_kernels(dpgo_problem_t h, int reps, int warmup, double 
 int dpgo_problem_set_persistent(dpgo_problem_t h, int enable);
 int dpgo_problem_persistent_info(dpgo_problem_t h, int* enabled, int* workgroups, int* last_members,
                                  int* last_iterations, int* last_layout);
+/* The in-kernel phase split of the LAST one-launch solve, microseconds per tCG iteration on participant 0 (100 MHz wall
+ * clock, iterations after the first): [0] Hessian phase, [1] the all-reduce behind it, [2] update phase (with the additive
+ * form: + restriction), [3] the reduction(s) behind it (additive: coarse solve, correction, projection and two reductions);
+ * all 0 when the last call ran the multi-launch scheme.  *iterations (optional) = tCG iterations of that launch. */
+int dpgo_problem_persistent_phases(dpgo_problem_t h, double us_per_iteration[4], int* iterations);
 
 /* ---- pose order for HBM-bound blocks (host only; no reference counterpart: Eigen's product has no such notion) ----
  * The block-SpMM kernels gather the tiles of a pose's graph neighbours; each XCD's workgroups sweep one contiguous eighth

@@ -1193,7 +1193,7 @@ def perturbed_truth(Ttrue, seed: int = 2, sigma_t: float = 0.1, sigma_r: float =
 
 def rbcd_coloured(meas: Measurements, n: int, num_robots: int, r: int, X0, sweeps: int,
                   params: Optional[ROptParameters] = None, precond: str = "jacobi", hess_recurrence: bool = False,
-                  amg_k=None, inactive=()):
+                  amg_k=None, inactive=(), schedule=None, counts=None):
     """Two-colour (greedy-coloured) parallel RBCD of SURVEY 8e on the contiguous partition of
     examples/MultiRobotExample.cpp:71-119: in every sweep each colour class updates once; an agent's
     update is PGOAgent::updateX (src/PGOAgent.cpp:938-995): G from the neighbours' current public poses
@@ -1203,6 +1203,10 @@ def rbcd_coloured(meas: Measurements, n: int, num_robots: int, r: int, X0, sweep
     inactive: robots switched off by PGOAgent::setRobotActive(id, false) (src/PGOAgent.cpp:1173-1184): they do not
     update, and their neighbours' data matrices leave the shared edges with them out (active_shared_edges); the
     colouring is that of the full team.
+    schedule: {(agent, sweep): preconditioner name} -- solves whose preconditioner differs from `precond` (the device's
+    default selection switches a coupled block from block-Jacobi to the additive form in the middle of a run; the test
+    tells the oracle which solve ran what, ROPTResult::precond_used).  counts: a list that receives (sweep, agent,
+    Hessian-vector products) of every solve.
     Returns (X, [central 2f after each sweep], [central gradnorm after each sweep])."""
     d = meas.d
     ranges, per = partition_contiguous(meas, n, num_robots)
@@ -1232,7 +1236,7 @@ def rbcd_coloured(meas: Measurements, n: int, num_robots: int, r: int, X0, sweep
     central = QuadraticProblem(construct_Q(n, d, meas), None, r, d)
     X = X0.copy()
     costs, gns = [], []
-    for _ in range(sweeps):
+    for sweep in range(sweeps):
         for c in range(max(colour) + 1):
             for a in range(num_robots):
                 if colour[a] != c or a in inactive:
@@ -1240,12 +1244,60 @@ def rbcd_coloured(meas: Measurements, n: int, num_robots: int, r: int, X0, sweep
                 s, e = ranges[a]
                 nbr = {(rob, fr): X[ranges[rob][0] + fr] for rob, fr in agents[a]["need"]}
                 prob = agents[a]["prob"]
+                want = (schedule or {}).get((a, sweep), precond)
+                if want != precond:  # one problem object per (agent, preconditioner): its hierarchy is built once
+                    alt = agents[a].setdefault("alt", {})
+                    if want not in alt:
+                        alt[want] = QuadraticProblem(agents[a]["Q"], None, r, d, precond=want,
+                                                     amg_k=amg_k[a] if isinstance(amg_k, dict) else amg_k)
+                    prob = alt[want]
                 prob.G = construct_G(e - s, d, r, agents[a]["shared"], a, nbr)
                 opt = QuadraticOptimizer(prob, params or ROptParameters(), hess_recurrence=hess_recurrence)
                 X[s:e] = opt.optimize(X[s:e])
+                if counts is not None:
+                    counts.append((sweep, a, opt.result.tcg_iters))
         costs.append(2 * central.f(X))
         gns.append(central.rie_grad_norm(X))
     return X, costs, gns
+
+
+class AutoCostRule:
+    """Restatement of the device's default preconditioner selection (precond = "auto", include/dpgo_hip.h
+    DPGO_PRECOND_AUTO; dpgo_amd/csrc: auto_update) for a COUPLED block the additive one-launch solve can hold -- the
+    device's stand-in for "the factor of Q + 0.1 I is there whenever PreConditioner is called"
+    (src/QuadraticProblem.cpp:56-69, src/PoseGraph.cpp:582-613).  Units: a tenth of a block-Jacobi product of a solve that
+    has the device to itself (units_jacobi_alone, in which the set-up is paid back); units_jacobi / units_additive are what
+    a product of either kind is charged on this handle (the same when it is solved alone; scaled by the part of the chip a
+    launch blocks when it shares the device).  next() = what the next solve runs; record(products) = the solve just
+    finished."""
+
+    def __init__(self, budget=150, units_jacobi=10, units_additive=18, setup_units=2800, min_products=6,
+                 units_jacobi_alone=10):
+        self.budget, self.uj, self.ua, self.setup, self.minp = budget, units_jacobi, units_additive, setup_units, min_products
+        self.uj0 = units_jacobi_alone
+        self.ml, self.state, self.units, self.ref, self.backoff, self.switches = False, 0, 0, 0, 0, 0
+
+    def next(self) -> str:
+        return "additive" if self.ml else "jacobi"
+
+    def record(self, products: int) -> None:
+        if not self.ml:
+            self.state = 0
+            self.units += self.uj0 * products
+            binds = 2 * products >= self.budget
+            paid = products >= self.minp and self.units >= (self.setup << self.backoff)
+            if binds or paid:
+                if not binds and self.ua * self.minp >= self.uj * products:  # a trial that cannot win is not run
+                    self.units, self.backoff = 0, min(self.backoff + 1, 6)
+                    return
+                self.ml, self.state, self.ref = True, 1, products
+                self.switches += 1
+            return
+        if self.ua * products * 100 < self.uj * self.ref * (115 if self.state == 2 else 100):
+            self.state = 2
+        else:
+            self.ml, self.state, self.units = False, 0, 0
+            self.backoff = min(self.backoff + 1, 6)
 
 
 # --------------------------------------------------------------------------

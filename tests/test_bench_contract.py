@@ -74,16 +74,26 @@ def test_bench_prints_one_valid_json_line():
     assert [k["kernel"].split()[0].rstrip(",") for k in rf["kernels"]] == ["k_tcg_update", "k_ml_restrict",
                                                                            "k_ml_coarse_prolong", "k_ml_post"]
     assert all(k["avg_launch_us"] > 0 for k in rf["kernels"])
+    # the once-per-Q cost of the preconditioner beside the time to tolerance (the reference factors inside its first solve)
+    assert j["hierarchy_setup_ms"] > 0 and j["hierarchy_values_only_ms"] > 0
+    assert abs(j["time_to_tolerance_incl_setup_ms"] - (j["time_to_tolerance_ms"] + j["hierarchy_setup_ms"])) < 1e-9
+    assert j["config"]["hierarchy_setup_ms"] == j["hierarchy_setup_ms"]
+    assert j["config"]["time_to_tolerance_incl_setup_ms"] == j["time_to_tolerance_incl_setup_ms"]
+    assert rf["traffic_live"] is False
     cb = j["cpu_baseline"]  # reference configuration (exact factor, one core per agent) + the 1-core port beside it
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and cb["unit"] == "it/s"
-    assert "exact sparse factor" in cb["sample"]
+    # cpu_baseline.value is the pair from the SETTLED iterate every timed step restores ...
+    assert "exact sparse factor" in cb["sample"] and "SETTLED" in cb["sample"] and cb["factorisation_seconds"] > 0
     same = cb["gpu_same_work"]  # the like-for-like pair: same 8 blocks, same iterate, same one sweep, on the GPU
     assert same["agents"] == 8 and same["value"] > 0 and same["gradnorm_after"] > 0 and cb["gradnorm_after"] > 0
     assert abs(cb["gpu_over_cpu_same_work"] - same["value"] / cb["value"]) < 1e-9 * cb["gpu_over_cpu_same_work"]
     assert len(same["tcg_iterations_per_agent"]) == 8 and len(cb["tcg_iterations_per_agent"]) == 8
-    st = cb["settled_iterate"]  # the same pair from the settled iterate every timed step restores
-    assert st["value"] > 0 and "SETTLED" in st["sample"] and st["gpu_same_work"]["agents"] == 8
-    assert len(st["tcg_iterations_per_agent"]) == 8 and len(st["gpu_same_work"]["tcg_iterations_per_agent"]) == 8
+    hs = same["hierarchy_setup_ms"]  # the GPU side's once-per-Q cost, per block
+    assert len(hs["first_ms"]) == 8 and min(hs["first_ms"]) > 0 and min(hs["values_only_ms"]) > 0
+    assert len(same["auto_rule"]) == 8 and all(a["state"] in ("jacobi", "trial", "additive") for a in same["auto_rule"])
+    ini = cb["initial_iterate"]  # ... the pair from the benchmark's initial iterate under its own key
+    assert ini["value"] > 0 and "SETTLED" not in ini["sample"] and ini["gpu_same_work"]["agents"] == 8
+    assert len(ini["tcg_iterations_per_agent"]) == 8 and len(ini["gpu_same_work"]["tcg_iterations_per_agent"]) == 8
     port = cb["single_agent_port"]
     assert port["cores"] == 1 and port["value"] > 0 and port["rel_diff_fOpt_vs_device"] < 1e-6
     tt = j["quality"]["to_tolerance"]
@@ -91,6 +101,21 @@ def test_bench_prints_one_valid_json_line():
                        "grid:12x10x6/multilevel+fp32_dense_level"}  # the last: opt-in storage mode, beside the headline
     assert rf["multilevel"]["coarse_inverse_bits"] == 64  # the headline configuration keeps everything in fp64
     assert all("products" in v for v in tt.values())
+
+
+@pytest.mark.gpu
+def test_bench_secondary_workload_reports_per_product_cost_and_in_kernel_split():
+    """`also.sphere2500` of the headline line (BASELINE's metric is quoted on sphere2500 as well): the fixed-work step rate,
+    microseconds per Hessian-vector product and, for a one-launch solve, the in-kernel phase split of participant 0."""
+    sys.path.insert(0, ROOT)
+    import bench
+    e = bench.secondary_single_agent("sphere2500", 5, "auto", 3, 1, 2)
+    assert e["it_per_s"] > 0 and e["tcg_iterations_per_step"] > 0 and e["precond_used"] in ("additive", "multilevel", "jacobi")
+    assert abs(e["us_per_product"] - 1e3 * e["ms_per_step"] / e["tcg_iterations_per_step"]) < 1e-6 * e["us_per_product"]
+    ph = e["in_kernel_us_per_iteration"]  # sphere2500 is a one-launch solve
+    assert ph is not None and ph["hessian_phase"] > 0 and ph["total"] < e["us_per_product"] * 1.5
+    assert abs(ph["total"] - (ph["hessian_phase"] + ph["all_reduce_after_hessian"] + ph["update_phase"]
+                              + ph["reductions_after_update"])) < 1e-9
 
 
 @pytest.mark.gpu
@@ -106,6 +131,9 @@ def test_bench_loopback_runs_the_multi_agent_path_through_rccl():
     assert j["config"]["agents"] == 4 and "RCCL" in j["config"]["schedule"] and "loop-back" in j["config"]["schedule"]
     assert j["quality"]["exchange_ms_per_step_rank0"] > 0 and j["value"] > 0
     assert j["quality"]["cost_2f_after_step"] < j["quality"]["cost_2f_trajectory"][0]
+    # coupled blocks under `auto`: the selection is brought to its steady state before the timed steps
+    assert j["config"]["selection_sweeps_before_timing"] >= 2
+    assert set(j["config"]["precond_used_in_timed_steps"]) <= {"jacobi", "additive", "multilevel"}
 
 
 def test_bench_default_steps_time_more_than_a_second():

@@ -622,6 +622,79 @@ def test_multi_agent_rbcd_on_one_gpu_matches_oracle(oracle, name, robots, sweeps
             assert agents[a].problem.multilevelInfo()["ks"] == plans[a]["ks"]
 
 
+@pytest.mark.parametrize("name,robots,settle,sweeps", [("torus3D", 8, 0, 12), ("grid:50x50x40", 8, 4, 13)])
+def test_auto_cost_rule_switches_coupled_blocks_to_additive(oracle, name, robots, settle, sweeps):
+    """precond = "auto" on COUPLED blocks the additive one-launch solve can hold (include/dpgo_hip.h, DPGO_PRECOND_AUTO):
+    every agent starts on block-Jacobi; once its block-Jacobi solves since Q last changed have cost as much as one
+    hierarchy set-up (280 products' worth) the next solve runs the additive form on trial, and stays there while it is
+    cheaper than the block-Jacobi solve it is measured against.  The run goes THROUGH the switch -- torus3D / 8 from the
+    chordal guess, the 100k grid as 8 slabs of 12 500 poses from an iterate a few sweeps in (far from the optimum the
+    slabs' solves end on the trust-region boundary after a handful of products and the rule rightly never fires) -- and
+    is compared sweep by sweep with the oracle, which is TOLD which solve ran which preconditioner (precond_used) and
+    builds every agent's hierarchy from that agent's additivePlan; the oracle's own restatement of the rule
+    (AutoCostRule), fed with the oracle's product counts, must predict the device's choices."""
+    import dpgo_amd
+    from dpgo_amd.agent import DeviceAgent, ExchangePlan, RBCDCluster, build_pose_graphs
+    r = 5
+    if name.startswith("grid:"):
+        om, n, Ttrue = oracle.synthetic_grid(*[int(v) for v in name[5:].split("x")], seed=0)
+        X0 = oracle.lift(oracle.perturbed_truth(Ttrue, seed=2), r)
+    else:
+        om, n = oracle.read_g2o(os.path.join(DATA, name + ".g2o"))
+        X0 = oracle.lift(oracle.chordal_initialization(om, n), r)
+    d = om.d
+    ranges, graphs = build_pose_graphs(to_product_measurements(om), n, robots, r)
+    plan = ExchangePlan(graphs)
+    agents = {a: DeviceAgent(graphs, plan, a, X0[ranges[a][0]:ranges[a][1]], dpgo_amd.ROptParameters())
+              for a in range(robots)}
+    assert all(ag.optimizer.params_.precond == "auto" for ag in agents.values())
+    cluster = RBCDCluster(plan, agents)
+    for _ in range(settle):  # (untimed part of the run: whatever it selects; the comparison starts from a fresh rule)
+        cluster.sweep()
+    for ag in agents.values():
+        ag.problem.autoState("reset")
+        assert ag.problem.autoState() is False and ag.problem.autoInfo()["state"] == "jacobi"
+    Xstart = np.concatenate([agents[a].X.cpu().numpy() for a in range(robots)], axis=0)
+    used, products, dev = {}, {}, []
+    for k in range(sweeps):
+        cluster.sweep()
+        for a in range(robots):
+            res = agents[a].last_result
+            used[(a, k)], products[(a, k)] = res.precond_used, res.tcg_iterations
+        f, g = cluster.central_cost_and_gradnorm()
+        dev.append((2 * f, g))
+    assert set(used.values()) <= {"jacobi", "additive"}, used
+    switched = [a for a in range(robots) if any(used[(a, k)] == "additive" for k in range(sweeps))]
+    assert switched, products  # the run reaches the switch
+    plans = {a: agents[a].problem.additivePlan() for a in range(robots)}
+    counts = []
+    names = {"jacobi": "jacobi", "additive": "amg_additive"}
+    Xref, costs, gns = oracle.rbcd_coloured(om, n, robots, r, Xstart, sweeps, hess_recurrence=device_tcg_mode(n // robots, d, r),
+                                            precond="jacobi", amg_k={a: plans[a]["ks"] for a in range(robots)},
+                                            schedule={key: names[v] for key, v in used.items()}, counts=counts)
+    for k in range(sweeps):
+        assert abs(dev[k][0] - costs[k]) <= 1e-9 * abs(costs[k]), k
+        assert abs(dev[k][1] - gns[k]) <= 1e-6 * gns[k], k
+    assert {(a, k): it for k, a, it in counts} == products
+    X = np.concatenate([agents[a].X.cpu().numpy() for a in range(robots)], axis=0)
+    assert relerr(X, Xref) < 1e-7
+    for a in range(robots):  # the device followed the rule (this agent's unit costs: four same-colour agents share the device)
+        info = agents[a].problem.autoInfo()
+        rule = oracle.AutoCostRule(budget=150, units_jacobi=info["units_jacobi"], units_additive=info["units_additive"],
+                                   setup_units=info["setup_units"], min_products=info["min_products"],
+                                   units_jacobi_alone=info["units_jacobi_alone"])
+        for k in range(sweeps):
+            assert used[(a, k)] == rule.next(), (a, k, [products[(a, q)] for q in range(sweeps)])
+            rule.record(products[(a, k)])
+        got = agents[a].problem.autoInfo()
+        assert (got["state"] != "jacobi") == (rule.next() == "additive") and got["switches"] == rule.switches, (a, got)
+    for a in switched:  # an additive solve ran inside the one-launch kernel, on its plan's workgroups, hierarchy kept across G
+        last = max(k for k in range(sweeps) if used[(a, k)] == "additive")
+        assert agents[a].problem.multilevelInfo()["ks"] == plans[a]["ks"], a
+        if last == sweeps - 1:
+            assert agents[a].problem.persistentInfo()["last_members"] == plans[a]["aggregates"]
+
+
 @pytest.mark.parametrize("storage", [pytest.param("plain", id="plain"),
                                      pytest.param("symmetric", id="symmetric-fp32_dense_level-oracle_applies_the_device_inverse")])
 def test_whole_solve_at_full_size_matches_oracle(oracle, storage):
