@@ -285,17 +285,19 @@ def gpu_same_decomposition(meas, n, X0, r, num_agents, precond, device, reset_au
     cluster.sweep()  # untimed: first-use setup (block-Jacobi factors, launch caches)
     selection_sweeps = 0
     if precond == "auto" and not reset_auto:  # the selection's steady state from this iterate (as in main(); untimed)
-        def sel_state():
-            return [(ag.problem.autoState(), ag.problem.autoInfo()["state"], ag.problem.autoInfo()["backoff"]) for ag in agents.values()]
-        calm, prev = 0, sel_state()
-        while calm < 2 and selection_sweeps < 40:
+        def undecided():  # (as in main(): agents of the cost rule that have not been through a trial yet)
+            n_open = 0
+            for ag in agents.values():
+                info = ag.problem.autoInfo()
+                small = ag.problem.additivePlan()["lane_groups"] != 0 and ag.has_neighbours
+                if small and (info["state"] == "trial" or (info["state"] == "jacobi" and info["backoff"] == 0)):
+                    n_open += 1
+            return n_open
+        while undecided() and selection_sweeps < 40:
             for ag in agents.values():
                 ag.restore()
             cluster.sweep()
             selection_sweeps += 1
-            cur = sel_state()
-            calm = calm + 1 if cur == prev else 0
-            prev = cur
     best, products = None, 0
     for _ in range(3):
         for ag in agents.values():
@@ -560,21 +562,28 @@ def main():
     # run what a long RBCD run runs and contain no set-up.
     selection_sweeps = 0
     if args.precond == "auto" and num_agents > 1:
-        def sel_state():
-            return [(ag.problem.autoState(), ag.problem.autoInfo()["state"], ag.problem.autoInfo()["backoff"]) for ag in agents.values()]
-        calm, prev = 0, sel_state()
-        while calm < 2 and selection_sweeps < 40:
+        def undecided():
+            # an agent still on block-Jacobi that has never been through a trial (nor skipped a hopeless one) will switch
+            # once its block-Jacobi work has paid one set-up: not a steady state yet; blocks outside the cost rule
+            # (no coupling, or too large for the additive form: they follow the tCG-budget hysteresis) are steady at once
+            n_open = 0
+            for ag in agents.values():
+                info = ag.problem.autoInfo()
+                small = ag.problem.additivePlan()["lane_groups"] != 0 and ag.has_neighbours
+                if small and (info["state"] == "trial" or (info["state"] == "jacobi" and info["backoff"] == 0)):
+                    n_open += 1
+            return n_open
+        while selection_sweeps < 40:
+            open_ = torch.tensor([float(undecided())], dtype=torch.float64,
+                                 device="cpu" if (use_dist and cluster.stage) else "cuda")
+            if use_dist:  # every rank runs the same number of sweeps (they contain the exchanges)
+                dist.all_reduce(open_, op=dist.ReduceOp.MAX)
+            if float(open_.item()) == 0.0:
+                break
             for a in agents.values():
                 a.restore()
             cluster.sweep()
             selection_sweeps += 1
-            cur = sel_state()
-            changed = torch.tensor([0.0 if cur == prev else 1.0], dtype=torch.float64,
-                                   device="cpu" if (use_dist and cluster.stage) else "cuda")
-            if use_dist:  # every rank runs the same number of sweeps (they contain the exchanges)
-                dist.all_reduce(changed, op=dist.ReduceOp.MAX)
-            calm = calm + 1 if float(changed.item()) == 0.0 else 0
-            prev = cur
 
     # device time of the public-pose exchanges, from event pairs on the stream they are enqueued on -- no host wait is
     # added to the path being timed (pack kernel -> RCCL batch / device copies -> consumed by the coupling SpMM)

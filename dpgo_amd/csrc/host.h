@@ -1,0 +1,492 @@
+// host.h -- what the translation units of libdpgo_hip.so share: error reporting, the (d, r) dispatch macros, the problem
+// handle (struct dpgo_problem_s: device buffers, hierarchy, solver state of one PoseGraph) and the declarations of the
+// host-side helpers each unit defines.
+//   problem.hip     handle lifecycle, Q / G upload, symmetric storage, QuadraticProblem evaluations (k_spmm, k_grad, k_hess ...)
+//   multilevel.hip  hierarchy set-up (symbolic on the host, numeric on the device) and the V-cycle's launches
+//   solve.hip       QuadraticOptimizer::optimize: tCG launches, the one-launch solve, RTR outer loop, preconditioner
+//                   selection (DPGO_PRECOND_AUTO), concurrent / begin-end solves
+//   agents.hip      GNC re-weighting, initial guesses, manifold operations, public-pose exchange plans
+//   bench_probes.hip  kernel timing probes used by bench.py
+#pragma once
+#include "kernels.h"
+
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
+#include <thread>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "../../include/dpgo_hip.h"
+
+using namespace dpgo;
+
+namespace dpgo_host {
+
+
+inline thread_local std::string g_err;
+
+inline int fail(int code, const std::string& msg) {
+  g_err = msg;
+  return code;
+}
+
+#define HIPC(expr)                                                                              \
+  do {                                                                                          \
+    hipError_t e_ = (expr);                                                                     \
+    if (e_ != hipSuccess)                                                                       \
+      return fail(DPGO_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_) + " (" + __FILE__ + \
+                                    ":" + std::to_string(__LINE__) + ")");                      \
+  } while (0)
+
+#define CHK(expr)                \
+  do {                           \
+    int rc_ = (expr);            \
+    if (rc_ != DPGO_OK) return rc_; \
+  } while (0)
+
+// (d, r) pairs with compiled kernels
+#define DPGO_FOR_DR(M) M(2, 2) M(2, 3) M(2, 4) M(2, 5) M(3, 3) M(3, 4) M(3, 5) M(3, 6)
+
+inline bool supported(int d, int r) {
+#define M(dd, rr) \
+  if (d == dd && r == rr) return true;
+  DPGO_FOR_DR(M)
+#undef M
+  return false;
+}
+
+// DISPATCH(d, r, body): body sees constexpr int D, R
+#define DPGO_CASE(dd, rr, ...)   \
+  case (dd) * 16 + (rr): {       \
+    constexpr int D = dd, R = rr; \
+    __VA_ARGS__;                 \
+  } break;
+#define DISPATCH(d, r, ...)                                                                         \
+  switch ((d) * 16 + (r)) {                                                                         \
+    DPGO_CASE(2, 2, __VA_ARGS__) DPGO_CASE(2, 3, __VA_ARGS__) DPGO_CASE(2, 4, __VA_ARGS__)          \
+    DPGO_CASE(2, 5, __VA_ARGS__) DPGO_CASE(3, 3, __VA_ARGS__) DPGO_CASE(3, 4, __VA_ARGS__)          \
+    DPGO_CASE(3, 5, __VA_ARGS__) DPGO_CASE(3, 6, __VA_ARGS__)                                       \
+    default:                                                                                        \
+      return fail(DPGO_ERR_UNSUPPORTED, "unsupported (d, r)");                                      \
+  }
+
+// launch a <D, R, SPLIT> kernel with the handle's split factor
+#define LAUNCH_SPLIT(p, KERNEL, GRID, ...)                                                            \
+  do {                                                                                                \
+    if ((p)->split == 4)                                                                              \
+      hipLaunchKernelGGL((KERNEL<D, R, 4>), dim3(GRID), dim3(kBlock), 0, (p)->stream, __VA_ARGS__);   \
+    else if ((p)->split == 2)                                                                         \
+      hipLaunchKernelGGL((KERNEL<D, R, 2>), dim3(GRID), dim3(kBlock), 0, (p)->stream, __VA_ARGS__);   \
+    else                                                                                              \
+      hipLaunchKernelGGL((KERNEL<D, R, 1>), dim3(GRID), dim3(kBlock), 0, (p)->stream, __VA_ARGS__);   \
+  } while (0)
+
+struct Bsr {
+  int nrows = 0, ncols = 0, nnzb = 0;
+  int32_t* rowptr = nullptr;
+  int32_t* colidx = nullptr;
+  double* vals = nullptr;
+  BsrDev dev() const { return BsrDev{rowptr, colidx, vals}; }
+};
+
+inline int free_bsr(Bsr& m) {
+  if (m.rowptr) HIPC(hipFree(m.rowptr));
+  if (m.colidx) HIPC(hipFree(m.colidx));
+  if (m.vals) HIPC(hipFree(m.vals));
+  m = Bsr();
+  return DPGO_OK;
+}
+
+
+}  // namespace dpgo_host
+using namespace dpgo_host;
+
+struct dpgo_problem_s {
+  int r = 0, d = 0, n = 0, b = 0, T = 0;
+  int device = 0;
+  hipStream_t own_stream = nullptr;
+  hipStream_t stream = nullptr;
+  Bsr Q;
+  Bsr C;  // inter-agent coupling (rectangular), for G
+  double* G0 = nullptr;
+  double* G = nullptr;
+  bool has_G = false;
+  double* dinv = nullptr;
+  double dinv_shift = -1.0;
+  // work vectors
+  double *x1 = nullptr, *x2 = nullptr, *g1 = nullptr, *g2 = nullptr, *eta = nullptr, *delta = nullptr,
+         *Hd = nullptr, *rr = nullptr, *z = nullptr, *S1 = nullptr, *S2 = nullptr;
+  // multilevel (aggregation multigrid) preconditioner: levels[0] = the pose level ... levels.back() = the dense level
+  struct MlLevel {
+    int n = 0;      // nodes
+    int k = 0;      // aggregate size towards the next level (0 on the dense level)
+    int split = 1;  // lane groups per node of this level's SpMM-family kernels
+    Bsr A;          // level >= 1: Galerkin operator (level 0: Q + shift I, never formed)
+    int32_t* slot_row = nullptr;  // level >= 1: block row of every slot of A
+    double *dinv = nullptr, *Pb = nullptr;            // smoother factors; prolongation blocks towards level + 1
+    double *r = nullptr, *x1 = nullptr, *x = nullptr;  // restricted residual, pre-smoothed iterate, corrected iterate
+    // level 0 of a two-level hierarchy: AP = (Q + shift I) P (block rows = poses, block columns = level-1 nodes) and the
+    // residual after pre-smoothing, so that the post-smoothing kernel gathers from the SMALL coarse vector:
+    // r - A (x1 + P xc) = (r - A x1) - (A P) xc
+    Bsr AP;
+    double* res1 = nullptr;
+    // level 0 of a two-level hierarchy with GRAPH aggregates (ml_graph_aggregates): label of every pose, members of every
+    // aggregate in discovery order, the spanning tree the prolongation is composed along, P_i^T res_i of every pose
+    bool graph = false;
+    int32_t *lab = nullptr, *agg_ptr = nullptr, *agg_mem = nullptr, *parent = nullptr, *pslot = nullptr;
+    int32_t* mem_pos = nullptr;    // position of every pose in agg_mem (k_ml_build_P_tree_wave)
+    // restriction of graph aggregates: inside the G consecutive poses a wave of k_ml_restrict owns, every RUN of poses with
+    // the same aggregate is added up in the wave and leaves ONE partial sum; seg_info[i] = slot * 32 + length for the first
+    // pose of a run (-1 otherwise), slots ordered by aggregate, seg_ptr[a] .. seg_ptr[a+1] = the partial sums of aggregate a
+    int32_t *seg_info = nullptr, *seg_ptr = nullptr;
+    int nseg = 0;  // partial sums per restriction
+    int32_t* tile_perm = nullptr;  // aggregates of at most one persistent tile: pose of every (aggregate, slot), -1 = empty
+    int perm_tile = 0;             // slots per aggregate in tile_perm
+    int merge_cap = 0;             // graph aggregates: fragments merged up to this many poses (0: plain greedy growth)
+    double* tbuf = nullptr;
+    AggMap agg() const { return AggMap{graph ? lab : nullptr, k}; }
+  };
+  std::vector<MlLevel> ml;
+  std::vector<int32_t> h_rowptr, h_colidx;  // host copy of Q's block pattern (symbolic setup of the hierarchy)
+  bool ml_symbolic = false, ml_ready = false, ml_user_ks = false;
+  bool ml_additive_layout = false;  // the hierarchy is the one the additive preconditioner needs (one aggregate per workgroup tile)
+  // layout of the additive preconditioner's one-launch solve for this block pattern (additive_plan): lane groups per pose
+  // (0: the block does not fit), slots per workgroup tile = aggregate, growth size and merge bound of the graph aggregates
+  // (graph = false: index runs of `tile` poses), number of aggregates = workgroups
+  struct AddPlan {
+    int split = 0, tile = 0, S = 0, cap = 0, na = 0;
+    bool graph = true;
+  } add_plan;
+  bool add_plan_known = false;
+  // the aggregation the plan was found with (host arrays), reused by the symbolic setup that follows: growing and merging
+  // the aggregates of a 12 500-pose block is 1.4 ms of host time
+  struct AggCache {
+    int S = 0, cap = 0;
+    std::vector<int32_t> lab, ptr, mem, parent, pslot;
+  } add_agg;
+  double ml_omega = 0.7, ml_shift = 1e-1;
+  double* ml_dense = nullptr;  // inverse of the coarsest operator, row-major, leading dimension ml_lda
+  float* ml_dense32 = nullptr;  // its fp32 storage (what the cycle streams when ml_coarse_bits == 32)
+  // lower block triangle of the (exactly symmetric) inverse, packed 64 x 64 tiles: what a two-level cycle streams in 64-bit
+  // mode (k_dense_sym_apply: half the bytes); chunk table, partial-sum buffers
+  double *ml_packed = nullptr, *ml_pd = nullptr, *ml_pt = nullptr;
+  DenseChunk* ml_chunks = nullptr;
+  int* ml_chunk_first = nullptr;
+  int ml_nchunks = 0;
+  bool ml_use_dense_sym() const {
+    static const int env = [] {
+      const char* e = std::getenv("DPGO_ML_DENSE_SYM");
+      return e ? std::atoi(e) : -1;
+    }();
+    if (!ml_use_ap() || ml_coarse_bits != 64 || !ml_packed || env == 0) return false;
+    return env == 1 || ml_lda >= 3072;  // below, the row-streaming kernel (one launch, cache-resident inverse) is as fast
+  }
+  int ml_coarse_bits = 64;  // 32: opt-in (dpgo_problem_multilevel_coarse_bits)
+  int ml_lda = 0;
+  double *ml_W = nullptr, *ml_Rx = nullptr;  // Gauss-Jordan panels (setup only)
+  // DPGO_PRECOND_AUTO: the multilevel cycle is currently selected.  Decided afresh at the first "auto" use after every
+  // change of Q (a function of the problem only, so repeated runs reproduce): multilevel for a block without coupling
+  // to other agents -- there the tCG budget, not the trust-region boundary, ends the local solves --, block-Jacobi
+  // for a block of a multi-agent problem; then hysteresis on the share of the tCG budget each solve used.
+  bool auto_ml = false, auto_decided = false;
+  // The cost rule of a COUPLED block the additive one-launch solve can hold (dpgo_hip.h, DPGO_PRECOND_AUTO): Q -- and with it
+  // the hierarchy -- is constant across RBCD sweeps, so the set-up is paid once; everything is counted in units of a tenth of
+  // a block-Jacobi product (kAutoUnits*), a function of the solves' product counts only, so that repeated runs reproduce.
+  struct AutoCost {
+    long long jac_units = 0;  // block-Jacobi work since Q last changed (or since the last hand-back)
+    int ref = 0;              // products of the block-Jacobi solve the additive form is measured against
+    int state = 0;            // 0 block-Jacobi, 1 additive on trial (its first solve), 2 additive
+    int backoff = 0;          // hand-backs so far: the next trial waits for 2^backoff set-ups' worth of block-Jacobi work
+    int switches = 0;         // block-Jacobi -> additive transitions since Q last changed
+    int last_used = -1, last_products = 0;  // the last auto solve, as the rule saw it
+    int uj = 10, ua = 18;     // unit costs of a block-Jacobi / an additive product the rule last used (auto_units_*)
+  } auto_cost;
+  void auto_decide() {
+    if (!auto_decided) {
+      auto_ml = !(has_G || C.nnzb > 0);
+      auto_decided = true;
+      auto_cost = AutoCost();
+    }
+  }
+  // two-level hierarchies: level-0 post-smoothing through A P and the coarse solution (k_ml_post_ap); DPGO_ML_AP=0 disables
+  bool ml_use_ap() const {
+    static const bool off = [] {
+      const char* e = std::getenv("DPGO_ML_AP");
+      return e && std::atoi(e) == 0;
+    }();
+    return ml.size() == 2 && ml[0].AP.vals != nullptr && (!off || ml[0].graph);  // (graph aggregates exist in this form only)
+  }
+  // symmetric copy of Q for the plain SpMM on Infinity-Cache-cold blocks (k_spmm_sym): upper blocks transposed + lower references
+  struct SymQ {
+    int nu = 0, nl = 0;
+    int32_t *urow = nullptr, *ucol = nullptr, *usrc = nullptr, *lrow = nullptr, *lcol = nullptr, *lslot = nullptr,
+            *lsrc = nullptr;
+    double* uvalsT = nullptr;
+    int* flag = nullptr;       // device: set by k_sym_check when a lower block is not the transpose of its upper one
+    bool symbolic = false;     // pattern arrays belong to the current block pattern
+    bool pattern_ok = false;   // the pattern is structurally symmetric
+    bool ready = false;        // uvalsT holds the current values and they passed the symmetry check
+    bool values_ok = false;
+    BsrSymDev dev() const { return BsrSymDev{urow, ucol, uvalsT, lrow, lcol, lslot}; }
+  } sym;
+  int spmm_variant = DPGO_SPMM_AUTO;
+  bool tcg_sym = false;  // the fused tCG-step kernel reads the symmetric copy (resolved before a solve / a kernel probe)
+  int cap_hs = kMaxGrid; // launch cap of k_tcg_hess_sym
+  bool sym_wanted() const {
+    if (spmm_variant == DPGO_SPMM_PLAIN || split != 1) return false;
+    if (spmm_variant == DPGO_SPMM_SYMMETRIC) return true;
+    // AUTO: when the tCG loop's working set (Q and eight pose vectors) no longer fits the 256 MB Infinity Cache, i.e. when
+    // Q's bytes come from HBM: there the half-size storage wins (k_tcg_hess 45.5 against 49.4 us, plain product 28.4 against
+    // 36.6 us at 100k poses with cold operands), while on cache-resident operands the fused kernels gain nothing
+    // (DESIGN.md section 3).  DPGO_SPMM_SYMMETRIC=0/1 in the environment overrides.
+    if (const char* e = std::getenv("DPGO_SPMM_SYMMETRIC")) return std::atoi(e) != 0;
+    return beyond_cache();
+  }
+  // what the tCG loop streams besides Q and the pose vectors (the multilevel cycle's dense inverse, A P, prolongation):
+  // set by the solve that last chose a preconditioner
+  size_t loop_extra_bytes = 0;
+  // non-temporal single-use operands: when the launch is fed from HBM (same size rule as the symmetric storage)
+  bool want_stream_nt() const {
+    const char* e = std::getenv("DPGO_STREAM_NT");
+    return e ? std::atoi(e) != 0 : beyond_cache();
+  }
+  bool beyond_cache() const {
+    return sizeof(double) * ((size_t)Q.nnzb * b * b + 8 * (size_t)n * T) + sizeof(int32_t) * (size_t)Q.nnzb + loop_extra_bytes >
+           ((size_t)256 << 20);
+  }
+  // persistent whole-chip tCG kernel (blocks in the latency regime, block-Jacobi / no preconditioner): kernels/persist.h
+  bool persist = false;      // enabled for this handle (by size; DPGO_PERSIST=0/1, dpgo_problem_set_persistent)
+  int persist_share = 1;     // agents solved concurrently on this device (> 1: the most compact layout is preferred)
+  int persist_wgs = 0, persist_split = 0, persist_mt = 0;  // geometry of the current / last launch
+  int persist_reserved = 0;  // resident-slot reservation held by the running solve
+  bool persist_failed_once = false;
+  bool stream_nt = false;  // single-use operands of the tCG-step kernel move non-temporally (ld_stream, common.h)
+  bool persist_add = false;  // the reservation is for the additive-preconditioner variant
+  bool persist_stream_ordered = false;  // set for the duration of a begin / end solve (see launch_rtr_persistent)
+  size_t persist_lds_attr = 0;  // dynamic LDS size the additive instance's launch attribute was last raised to
+  // a solve enqueued by dpgo_optimize_device_begin and not yet collected by ..._end
+  struct Pending {
+    bool active = false;    // begin has been called
+    bool launched = false;  // the one-launch solve is in flight (else: the solve already ran, `result` holds its outcome)
+    dpgo_ropt_params resolved{};
+    bool is_auto = false;
+    const double* dinv = nullptr;
+    double* own_x1 = nullptr;
+    std::chrono::steady_clock::time_point t0;
+    dpgo_ropt_result result{};
+  } pending;
+  PersistCtrl* pctrl = nullptr;
+  unsigned long long* pgran = nullptr;  // granule table of the in-kernel all-reduce (kGranWords 8-byte words)
+  unsigned gran_cleared_at = 0;         // value of `gen` when the table was last cleared
+  PersistCtrl* hctrl = nullptr;  // pinned
+  double* partials = nullptr;  // 5 regions of kPartialCap*kNP
+  DevState* dstate = nullptr;  // 2 slots
+  DevState* hstate = nullptr;  // pinned
+  unsigned long long* hflag = nullptr;  // pinned, host-coherent: device-published tCG progress word
+  unsigned gen = 0;
+  bool saw_rtr_stop = false;  // set from the progress word in just-in-time mode
+  // re-weightable edges (GNC)
+  int em = 0;
+  int32_t *e_p1 = nullptr, *e_p2 = nullptr, *c_ptr = nullptr, *c_edge = nullptr;
+  double *e_R = nullptr, *e_t = nullptr, *e_kappa = nullptr, *e_tau = nullptr, *e_w = nullptr, *e_rsq = nullptr,
+         *q_base = nullptr;
+  uint8_t *e_fixed = nullptr, *c_kind = nullptr, *e_role = nullptr;
+  int32_t* e_slot = nullptr;
+  // contributions of shared re-weightable edges to the coupling matrix C
+  int32_t *g_ptr = nullptr, *g_edge = nullptr;
+  uint8_t* g_kind = nullptr;
+  double* c_base = nullptr;
+  int n_shared_edges = 0;
+  int* e_counts = nullptr;
+  EdgeDev edges() const {
+    return EdgeDev{e_p1, e_p2, e_R, e_t, e_kappa, e_tau, e_fixed, e_role, e_slot, e_w, e_rsq, em};
+  }
+  int cur = 0;
+  size_t vec_bytes() const { return (size_t)n * T * sizeof(double); }
+  double* pE() const { return partials; }
+  double* pA() const { return partials + 1 * kPartialCap * kNP; }
+  double* pB() const { return partials + 2 * kPartialCap * kNP; }
+  double* pH() const { return partials + 3 * kPartialCap * kNP; }
+  int grid() const {
+    const int P = (64 / b) * kWaves;
+    int tiles = (n + P - 1) / P;
+    if (tiles < 1) tiles = 1;
+    return tiles < cap_u ? tiles : cap_u;
+  }
+  int cap_u = kMaxGrid, cap_h = kMaxGrid;  // launch caps of the streaming / SpMM kernel families
+  // entries of partial region B (<r,r>, <z,r>) that k_tcg_hess has to sum: written by k_tcg_update (its grid) or,
+  // with the fused multilevel cycle, by k_ml_post (SpMM-family grid)
+  bool zr_from_post = false;
+  int nb_zr() const { return zr_from_post ? grid_post() : grid(); }
+  int split = 1;  // lane groups per pose in the SpMM kernels (latency layout for small blocks)
+  int grid_s() const {  // SpMM kernels (k_spmm, k_grad, k_hess, k_tcg_hess)
+    const int P = (64 / (b * split)) * kWaves;
+    int tiles = (n + P - 1) / P;
+    if (tiles < 1) tiles = 1;
+    const int cap = tcg_sym ? cap_hs : cap_h;
+    return tiles < cap ? tiles : cap;
+  }
+  // level-0 restriction / post-smoothing of the multilevel cycle: their own resident-slot counts (lighter kernels than
+  // k_tcg_hess: with 4 instead of 3 waves per SIMD the 1 563 tiles of the 100k block take 2 rounds instead of 3)
+  int cap_restrict = kMaxGrid, cap_post = kMaxGrid;
+  int grid_tiles(int cap) const {
+    const int P = (64 / (b * split)) * kWaves;
+    int tiles = (n + P - 1) / P;
+    if (tiles < 1) tiles = 1;
+    return tiles < cap ? tiles : cap;
+  }
+  int grid_restrict() const { return grid_tiles(cap_restrict); }
+  int grid_post() const { return grid_tiles(cap_post); }
+  int grid_spmm() const {  // plain k_spmm: no partial sums, higher occupancy than the fused tCG kernel
+    const int P = (64 / (b * split)) * kWaves;
+    int tiles = (n + P - 1) / P;
+    if (tiles < 1) tiles = 1;
+    return tiles < kMaxGrid ? tiles : kMaxGrid;
+  }
+  int grid_flat() const {  // elementwise kernels
+    size_t total = (size_t)n * T;
+    size_t g = (total + kBlock - 1) / kBlock;
+    if (g < 1) g = 1;
+    return g < (size_t)kMaxGrid ? (int)g : kMaxGrid;
+  }
+};
+
+namespace dpgo_host {
+
+struct Counters {
+  int spmm = 0;
+  bool vcycle_for_additive = false;  // an outer iteration of an "additive" solve ran the V-cycle instead
+};
+
+template <class Tp>
+inline int upload(Tp** dst, const Tp* src, size_t count, hipStream_t s) {
+  HIPC(hipMalloc(dst, sizeof(Tp) * (count > 0 ? count : 1)));
+  if (count > 0) HIPC(hipMemcpyAsync(*dst, src, sizeof(Tp) * count, hipMemcpyHostToDevice, s));
+  return DPGO_OK;
+}
+
+struct TmpDev {
+  std::vector<void*> ptrs;
+  ~TmpDev() {
+    for (auto q : ptrs) (void)hipFree(q);
+  }
+  int alloc(double** out, size_t bytes) {
+    HIPC(hipMalloc(out, bytes));
+    ptrs.push_back(*out);
+    return DPGO_OK;
+  }
+};
+
+template <typename T>
+inline int sym_upload(T** dst, const std::vector<T>& v, hipStream_t stream) {
+  HIPC(hipMalloc(dst, sizeof(T) * std::max<size_t>(1, v.size())));
+  if (!v.empty()) HIPC(hipMemcpyAsync(*dst, v.data(), sizeof(T) * v.size(), hipMemcpyHostToDevice, stream));
+  return DPGO_OK;
+}
+
+struct PersistGeo {
+  int split = 0, mt = 0, wgs = 0, slots = 0;
+};
+
+enum { RUN_FULL = 0, RUN_BEGIN = 1, RUN_END = 2 };  // run_optimize phases (solve.hip)
+
+// ---- problem.hip
+int set_device(dpgo_problem_s* p);
+int upload_bsr(Bsr& m, int nrows, int ncols, int nnzb, int b, const int32_t* rowptr, const int32_t* colidx,
+               const double* vals, hipStream_t s);
+int validate_bsr(int nrows, int ncols, int nnzb, const int32_t* rowptr, const int32_t* colidx, bool need_diag);
+int build_dinv(dpgo_problem_s* p, double shift);
+int poll_state(dpgo_problem_s* p);
+int push_state(dpgo_problem_s* p);
+void sym_free(dpgo_problem_s* p);
+int sym_symbolic_setup(dpgo_problem_s* p);
+int sym_ensure(dpgo_problem_s* p, bool* usable);
+int launch_spmm_sym(dpgo_problem_s* p, const BsrSymDev& M, const double* V, const double* Gadd, double* OUT);
+int launch_spmm(dpgo_problem_s* p, const Bsr& M, const double* V, const double* Gadd, double* OUT, int nrows = -1);
+bool outer_sym_enabled();
+int launch_grad(dpgo_problem_s* p, const double* X, double* RG, double* S, double* EG,
+                const DevState* st = nullptr, bool sym = false);
+int launch_hess(dpgo_problem_s* p, const double* X, const double* S, const double* V, const double* Gdot,
+                double* HV, double* partials, const DevState* st, int check_tcg, bool sym = false);
+int launch_retract(dpgo_problem_s* p, const double* X, const double* eta, double scale, double* X2,
+                   const DevState* st);
+int launch_rtr_update(dpgo_problem_s* p);
+int launch_precond(dpgo_problem_s* p, const double* X, const double* V, const double* dinv, double* Z);
+int launch_rtr_begin(dpgo_problem_s* p, double tol, double Delta0, double Dmax, int max_inner, int tiny);
+int check_ready(dpgo_problem_s* p);
+int h2d(dpgo_problem_s* p, double* dst, const double* src);
+int d2h(dpgo_problem_s* p, double* dst, const double* src);
+
+// ---- multilevel.hip
+int ml_tile(int b, int split);
+int additive_tile(const dpgo_problem_s* p);
+int ml_level_split(int n);
+int ml_default_graph_size(int n, int b);
+std::vector<int> ml_default_ks(int n, int b, int split0);
+void ml_free(dpgo_problem_s* p);
+int ml_graph_aggregates(const std::vector<int32_t>& rowptr, const std::vector<int32_t>& colidx, int n, int S,
+                        std::vector<int32_t>& lab, std::vector<int32_t>& ptr, std::vector<int32_t>& mem,
+                        std::vector<int32_t>& parent, std::vector<int32_t>& pslot);
+int ml_merge_small_aggregates(const std::vector<int32_t>& rowptr, const std::vector<int32_t>& colidx, int n, int S, int cap,
+                              std::vector<int32_t>& lab, std::vector<int32_t>& ptr, std::vector<int32_t>& mem,
+                              std::vector<int32_t>& parent, std::vector<int32_t>& pslot);
+int ml_symbolic_setup(dpgo_problem_s* p, const std::vector<int>& ks_in, int perm_tile = 0);
+int flat_grid(size_t items);
+bool gj_use_mfma();
+int dense_spd_inverse(hipStream_t s, double* M, int lda, double* W, double* Rx, bool mfma);
+int ml_numeric_setup(dpgo_problem_s* p);
+std::vector<int> ml_current_ks(const dpgo_problem_s* p);
+const dpgo_problem_s::AddPlan& additive_plan(dpgo_problem_s* p);
+int additive_split_of(const dpgo_problem_s* p);
+int ml_ensure(dpgo_problem_s* p, double shift, bool additive = false);
+int persist_capacity(int device);  // (two resident slots per CU; below)
+int launch_coarse_prolong(dpgo_problem_s* p, const dpgo_problem_s::MlLevel& L, const dpgo_problem_s::MlLevel& C,
+                          const DevState* gate, double* xc_out = nullptr);
+int launch_dense_sym(dpgo_problem_s* p, const dpgo_problem_s::MlLevel& C, const DevState* gate);
+int launch_ml_restrict0(dpgo_problem_s* p, const double* r, const DevState* gate, int g0, bool stop_check = false);
+int launch_ml_post_ap(dpgo_problem_s* p, const double* Xdev, const double* r, double* z, double* pout, const DevState* gate);
+int launch_ml_tail(dpgo_problem_s* p, const double* Xdev, const double* r, double* z, double* pout,
+                   const DevState* gate, bool stop_check = false);
+int launch_ml_apply(dpgo_problem_s* p, const double* Xdev, const double* v, double* z);
+
+// ---- solve.hip
+int launch_tcg_update(dpgo_problem_s* p, const double* dinv, int first, double* z_out = nullptr,
+                      double ml_omega = 0.0);
+int launch_tcg_hess(dpgo_problem_s* p, int first);
+int launch_tcg_hess_with(dpgo_problem_s* p, const DevState* sin, DevState* sout, int first, unsigned long long* hflag,
+                         unsigned gen);
+int resolve_tcg_storage(dpgo_problem_s* p);
+int persist_capacity(int device);
+bool persist_reserve(dpgo_problem_s* p, int slots, int limit);
+void persist_release(dpgo_problem_s* p);
+bool additive_available(dpgo_problem_s* p);
+PersistGeo persist_geometry(const dpgo_problem_s* p, int free_slots, int share = 1, bool additive = false);
+int launch_rtr_persistent(dpgo_problem_s* p, const dpgo_ropt_params* prm, const double* dinv, bool* used, bool additive);
+void persist_report(dpgo_problem_s* p);
+int rtr_outer_iteration(dpgo_problem_s* p, const dpgo_ropt_params* prm, const double* dinv, Counters& cnt,
+                        bool poll_at_end);
+int auto_units_jacobi(dpgo_problem_s* p);
+int auto_units_additive(dpgo_problem_s* p);
+void auto_update(dpgo_problem_s* p, const dpgo_ropt_params* prm, int used, int products);
+int run_optimize(dpgo_problem_s* p, const dpgo_ropt_params* prm, dpgo_ropt_result* res, int phase = RUN_FULL);
+int tune_launch_caps(dpgo_problem_s* p);
+int tune_persist(dpgo_problem_s* p);
+
+// ---- agents.hip
+int free_edges(dpgo_problem_s* p);
+int rebuild_vals(dpgo_problem_s* p, int nnzb, const int32_t* cptr, const int32_t* cedge, const uint8_t* ckind,
+                 const double* base, double sign, double* out);
+int rebuild_Q_from_weights(dpgo_problem_s* p, const double* base, double sign, double* out);
+int rebuild_C_from_weights(dpgo_problem_s* p, const double* base, double sign, double* out);
+int refresh_after_weights(dpgo_problem_s* p);
+
+}  // namespace dpgo_host

@@ -67,7 +67,7 @@ __device__ __forceinline__ void lds_gj_invert(double (*Ds)[kNB + 1]) {
   __syncthreads();
 }
 
-__global__ __launch_bounds__(kBlock) void k_sweep_panel(const double* __restrict__ M, int lda, int kb,
+static __global__ __launch_bounds__(kBlock) void k_sweep_panel(const double* __restrict__ M, int lda, int kb,
                                                         double* __restrict__ W, double* __restrict__ Rx) {
   __shared__ double Ds[kNB][kNB + 1];
   __shared__ double As[kNB][kNB + 1];  // A_kj, row-major
@@ -213,7 +213,7 @@ __global__ __launch_bounds__(kBlock) void k_sweep_update(double* __restrict__ M,
 }
 
 // A^-1 = -(swept lower triangle), mirrored into the full array (exactly symmetric)
-__global__ __launch_bounds__(kBlock) void k_sweep_finish(double* __restrict__ M, int lda) {
+static __global__ __launch_bounds__(kBlock) void k_sweep_finish(double* __restrict__ M, int lda) {
   const int tj = blockIdx.x, ti = blockIdx.y;
   if (tj > ti) return;
   __shared__ double Ts[kNB][kNB + 1];
@@ -240,13 +240,13 @@ __global__ __launch_bounds__(kBlock) void k_sweep_finish(double* __restrict__ M,
 }
 
 // unit diagonal on the padding rows N .. lda-1 of a zero-filled lda x lda array
-__global__ __launch_bounds__(kBlock) void k_dense_pad_identity(double* __restrict__ M, int lda, int N) {
+static __global__ __launch_bounds__(kBlock) void k_dense_pad_identity(double* __restrict__ M, int lda, int N) {
   for (int i = N + blockIdx.x * kBlock + threadIdx.x; i < lda; i += gridDim.x * kBlock) M[(size_t)i * lda + i] = 1.0;
 }
 
 // fp32 storage of the finished inverse; the fp64 array keeps the SAME (rounded) values, so that what the caller can read
 // back (dpgo_problem_multilevel_get) is exactly what the cycle applies
-__global__ __launch_bounds__(kBlock) void k_dense_round_f32(double* __restrict__ M, float* __restrict__ M32, size_t total) {
+static __global__ __launch_bounds__(kBlock) void k_dense_round_f32(double* __restrict__ M, float* __restrict__ M32, size_t total) {
   for (size_t e = (size_t)blockIdx.x * kBlock + threadIdx.x; e < total; e += (size_t)gridDim.x * kBlock) {
     const float v = (float)M[e];
     M32[e] = v;
@@ -267,7 +267,7 @@ struct DenseChunk {
   int I, J0, cnt, pad;
 };
 
-__global__ __launch_bounds__(kBlock) void k_dense_pack_lower(const double* __restrict__ M, int lda,
+static __global__ __launch_bounds__(kBlock) void k_dense_pack_lower(const double* __restrict__ M, int lda,
                                                              double* __restrict__ packed) {
   const int tj = blockIdx.x, ti = blockIdx.y;
   if (tj > ti) return;

@@ -15,7 +15,7 @@ __device__ __forceinline__ bool init_mask(size_t e, int T, int R, int D, int mod
 }
 
 // y = mask(a x + b y)   (y may alias x)
-__global__ __launch_bounds__(kBlock) void k_init_axpby(double a, const double* x, double b, double* y, size_t total,
+static __global__ __launch_bounds__(kBlock) void k_init_axpby(double a, const double* x, double b, double* y, size_t total,
                                                        int T, int R, int D, int mode) {
   for (size_t e = (size_t)blockIdx.x * kBlock + threadIdx.x; e < total; e += (size_t)gridDim.x * kBlock)
     y[e] = init_mask(e, T, R, D, mode) ? (b == 0.0 ? a * x[e] : fma(a, x[e], b * y[e])) : 0.0;  // b = 0: y is output only
@@ -23,7 +23,7 @@ __global__ __launch_bounds__(kBlock) void k_init_axpby(double a, const double* x
 }
 
 // z = mask(r / diag),  diag[i][c] = A_ii[c][c]  (Jacobi)
-__global__ __launch_bounds__(kBlock) void k_init_jacobi(const double* __restrict__ r, const double* __restrict__ diag,
+static __global__ __launch_bounds__(kBlock) void k_init_jacobi(const double* __restrict__ r, const double* __restrict__ diag,
                                                         double* __restrict__ z, size_t total, int T, int R, int D,
                                                         int mode) {
   for (size_t e = (size_t)blockIdx.x * kBlock + threadIdx.x; e < total; e += (size_t)gridDim.x * kBlock) {
@@ -33,7 +33,7 @@ __global__ __launch_bounds__(kBlock) void k_init_jacobi(const double* __restrict
 }
 
 // per-workgroup partial sums of <x, y> (fixed order; the host adds the partials in index order)
-__global__ __launch_bounds__(kBlock) void k_init_dot(const double* __restrict__ x, const double* __restrict__ y,
+static __global__ __launch_bounds__(kBlock) void k_init_dot(const double* __restrict__ x, const double* __restrict__ y,
                                                      double* __restrict__ partial, size_t total) {
   __shared__ double red[kWaves * kNP];
   double v[1] = {0.0};
@@ -57,7 +57,7 @@ __global__ __launch_bounds__(kBlock) void k_init_diag(BsrDev A, double* __restri
 }
 
 // y = a x + b y, no mask
-__global__ __launch_bounds__(kBlock) void k_axpby_plain(double a, const double* __restrict__ x, double b,
+static __global__ __launch_bounds__(kBlock) void k_axpby_plain(double a, const double* __restrict__ x, double b,
                                                         double* __restrict__ y, size_t total) {
   for (size_t e = (size_t)blockIdx.x * kBlock + threadIdx.x; e < total; e += (size_t)gridDim.x * kBlock)
     y[e] = (b == 0.0) ? a * x[e] : fma(a, x[e], b * y[e]);

@@ -1054,7 +1054,7 @@ __global__ __launch_bounds__(kBlock, 1) void k_rtr_persist(BsrDev Q, double* X, 
 // the trial-point buffer becomes the caller's X -- if and only if the launch completed on EVERY participant (state record
 // not poisoned, no time-out flag) and a step was accepted.  A late time-out of some workgroups therefore leaves X exactly as
 // the caller passed it, whatever the others had finished.
-__global__ __launch_bounds__(kBlock) void k_persist_commit(const DevState* __restrict__ st, const PersistCtrl* __restrict__ ctrl,
+static __global__ __launch_bounds__(kBlock) void k_persist_commit(const DevState* __restrict__ st, const PersistCtrl* __restrict__ ctrl,
                                                            const double* __restrict__ xfin, double* __restrict__ X,
                                                            size_t count) {
   if (st->rtr_stop == kPersistPoison || ctrl->error || st->n_accept <= 0) return;

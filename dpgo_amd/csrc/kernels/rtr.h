@@ -62,7 +62,7 @@ __global__ __launch_bounds__(kBlock) void k_rtr_update(double* __restrict__ x1, 
 }
 
 // RTR start: f1, |g1| from k_grad partials at x1; initial radius; stop test.
-__global__ void k_rtr_begin(const double* __restrict__ pe, int nb_e, DevState* __restrict__ s0, double tol,
+static __global__ void k_rtr_begin(const double* __restrict__ pe, int nb_e, DevState* __restrict__ s0, double tol,
                             double Delta0, double Delta_max, int max_inner, int accept_tiny) {
   __shared__ double red[kWaves * kNP];
   double e3[3];

@@ -397,7 +397,7 @@ AMG_MERGE_FROM, AMG_MERGED_UNKNOWNS_PER_POSE = 64, 2200  # mirrors kMlMergeFrom 
 
 
 def amg_default_graph_size(n: int, b: int) -> int:
-    """Mirrors ml_default_graph_size (dpgo_amd/csrc/dpgo_hip.hip): the largest aggregate of the default two-level
+    """Mirrors ml_default_graph_size (dpgo_amd/csrc/multilevel.hip): the largest aggregate of the default two-level
     hierarchy with GRAPH aggregates, 0 where the default is a hierarchy of index runs (more than one coarsening needed)."""
     if os.environ.get("DPGO_ML_GRAPH", "1") == "0":
         return 0
@@ -540,7 +540,7 @@ def amg_tree_prolongation(Q: "BSR", d: int, mem, parent, pslot):
 
 def amg_default_ks(n: int, b: int, split0: Optional[int] = None) -> List[int]:
     """Aggregate sizes (one per coarsening) of the device's multilevel preconditioner; mirrors ml_default_ks
-    (dpgo_amd/csrc/dpgo_hip.hip).  Every k divides the workgroup tile of its level ((64 / (b split)) * 4 nodes, split = 4
+    (dpgo_amd/csrc/multilevel.hip).  Every k divides the workgroup tile of its level ((64 / (b split)) * 4 nodes, split = 4
     lane groups per node below 40 000 nodes, else 1); the coarsest operator is a dense inverse of at most AMG_DENSE
     unknowns, AMG_DENSE_MAX if that is what it takes to get there in one coarsening; otherwise one more level."""
     S = amg_default_graph_size(n, b)

@@ -920,7 +920,7 @@ def test_additive_preconditioner_matches_oracle(oracle, name, r):
 
 
 def _additive_growth_sizes(n, tile):
-    """Growth sizes additive_plan (dpgo_hip.hip) tries for a block beyond 256 aggregates of 16 poses, in order."""
+    """Growth sizes additive_plan (csrc/multilevel.hip) tries for a block beyond 256 aggregates of 16 poses, in order."""
     out, S = [], max(8, (n + 229) // 230)
     while S <= tile:
         out.append(S)
