@@ -289,7 +289,7 @@ def gpu_same_decomposition(meas, n, X0, r, num_agents, precond, device, reset_au
             n_open = 0
             for ag in agents.values():
                 info = ag.problem.autoInfo()
-                small = ag.problem.additivePlan()["lane_groups"] != 0 and ag.has_neighbours
+                small = ag.n * (ag.d + 1) <= 65536 and ag.has_neighbours  # (256 aggregates of one 64-lane-group tile)
                 if small and (info["state"] == "trial" or (info["state"] == "jacobi" and info["backoff"] == 0)):
                     n_open += 1
             return n_open
@@ -569,7 +569,7 @@ def main():
             n_open = 0
             for ag in agents.values():
                 info = ag.problem.autoInfo()
-                small = ag.problem.additivePlan()["lane_groups"] != 0 and ag.has_neighbours
+                small = ag.n * (ag.d + 1) <= 65536 and ag.has_neighbours  # (256 aggregates of one 64-lane-group tile)
                 if small and (info["state"] == "trial" or (info["state"] == "jacobi" and info["backoff"] == 0)):
                     n_open += 1
             return n_open
