@@ -242,7 +242,8 @@ class DeviceAgent(AgentStatusMixin):
             Xi[self.pose_order] = X0_tiles
             X0_tiles = Xi
         self.problem = QuadraticProblem(self.pg, device=device, host_linear_term=False)
-        self.problem.setStream(torch.cuda.current_stream().cuda_stream)
+        self.stream_id = torch.cuda.current_stream().cuda_stream  # the stream the handle's work is enqueued on
+        self.problem.setStream(self.stream_id)
         self.optimizer = QuadraticOptimizer(self.problem, params or ROptParameters())
         self.X = torch.tensor(np.ascontiguousarray(X0_tiles), dtype=torch.float64, device=self.device)
         self.has_neighbours = len(plan.slots[my_id]) > 0
@@ -277,7 +278,7 @@ class DeviceAgent(AgentStatusMixin):
         m = self.pg.measurements()
         idx = self.problem.reweightable_index
         w, _ = self.problem.getEdgeWeights()
-        lc = ~((m.r1[idx] == m.r2[idx]) & (m.p1[idx] + 1 == m.p2[idx]))
+        lc = ~self.pg.odometry_mask()[idx]
         return np.asarray(w)[lc]
 
     def measure_relative_change(self, stream=None) -> None:
@@ -398,12 +399,20 @@ class DeviceAgent(AgentStatusMixin):
         preconditioner is refreshed lazily, values only)."""
         self.__dict__.setdefault("team_inactive", set())
         (self.team_inactive.discard if active else self.team_inactive.add)(int(robot_id))
-        if self.pg.hasNeighbor(robot_id):
+        if self.pg.hasNeighbor(robot_id) and self.pg.isNeighborActive(robot_id) != bool(active):
+            # robust mode: the GNC weights live on the device; the host copy refresh() rebuilds Q from must carry them
+            # (with the flags as they were: the edges that are out right now keep the weight they come back with)
+            self.problem.pullEdgeWeights()
             before = self.pg.q_version
             self.pg.setNeighborActive(robot_id, active)
             if self.pg.q_version != before:
+                # refresh() uploads Q and re-registers the re-weightable edges (effective weights, inactive ones fixed); with
+                # shared edges registered it has uploaded the coupling blocks as well -- uploading them again would drop
+                # the edge lists that index them
                 self.problem.refresh()
-                if self.has_neighbours:
+                shared_registered = (getattr(self.problem, "reweightable_index", None) is not None
+                                     and getattr(self.problem, "_reweight_shared", False))
+                if self.has_neighbours and not shared_registered:
                     self.problem.setCouplingFromPoseGraph()
 
     def isRobotActive(self, robot_id: int) -> bool:
@@ -475,7 +484,7 @@ class RBCDCluster:
         process group (gloo suffices).  Reductions and the anchor broadcast keep their transport."""
         from .ipc import IpcPeerStore
         self.peer_store = IpcPeerStore(self)
-        self.__dict__.pop("_so_sweep", None)
+        self.__dict__.pop("_so_sig", None)
 
     def owner(self, agent_id: int) -> int:
         """Rank hosting an agent: consecutive ids share a rank (agents_per_rank = 2 puts one agent of
@@ -720,8 +729,23 @@ class RBCDCluster:
                     except Exception:
                         pass
                 raise
+            fell_back = None
             for a in begun:
-                self.agents[a].update_end()
+                ag = self.agents[a]
+                was_on = ag.problem.persistentInfo()["enabled"]
+                ag.update_end()
+                if fell_back is None and was_on and not ag.problem.persistentInfo()["enabled"]:
+                    fell_back = a  # its one-launch solve timed out and was re-run with the multi-launch scheme in update_end
+            if fell_back is not None:
+                # ... AFTER the later colours had exchanged and solved against its old poses: for those colours this sweep
+                # was a Jacobi-style update, without RBCD's descent guarantee.  Say so, and redo them in order.
+                import warnings
+                warnings.warn("dpgo_amd: agent %d's one-launch solve fell back inside a stream-ordered sweep; the colours "
+                              "behind it are exchanged and solved again" % fell_back)
+                for c in range(self.plan.colour[fell_back] + 1, self.plan.num_colours):
+                    self.exchange(receivers=c)
+                    for a in self._active_ids(c):
+                        self.agents[a].update()
             return
         for c in range(self.plan.num_colours):
             self.exchange(receivers=c)
@@ -741,9 +765,15 @@ class RBCDCluster:
         colour, every exchange issued on the agents' stream (device copies or the library-owned communicator -- not the
         torch.distributed fallback, whose waits block the host), all agents on the stream the exchanges use.
         DPGO_ASYNC_SWEEP=0 switches it off (A/B)."""
-        cached = self.__dict__.get("_so_sweep")
-        if cached is not None:
-            return cached
+        # (decided afresh whenever the set of agents, their streams or the current stream change: a handle on another
+        # stream than the one the exchanges are enqueued on would not be ordered behind them)
+        if not self.agents or not all(hasattr(ag, "update_begin") for ag in self.agents.values()):
+            return False  # (CPU stand-ins of the gloo tests: nothing to enqueue)
+        cur = self._main_stream()
+        sig = (tuple(sorted(self.agents)), tuple(getattr(ag, "stream_id", None) for _, ag in sorted(self.agents.items())),
+               cur, self.peer_store is None, self.comm is None)
+        if self.__dict__.get("_so_sig") == sig:
+            return self._so_sweep
         import os
         ok = os.environ.get("DPGO_ASYNC_SWEEP", "1") != "0" and self.plan.num_agents > 1
         ok = ok and all(hasattr(ag, "update_begin") and hasattr(ag, "optimizer") for ag in self.agents.values())
@@ -752,7 +782,8 @@ class RBCDCluster:
             per_colour[self.plan.colour[a]] = per_colour.get(self.plan.colour[a], 0) + 1
         ok = ok and all(v <= 1 for v in per_colour.values())
         ok = ok and (self.world == 1 or self.comm is not None) and self.peer_store is None
-        self._so_sweep = bool(ok)
+        ok = ok and all(getattr(ag, "stream_id", None) == cur for ag in self.agents.values())
+        self._so_sweep, self._so_sig = bool(ok), sig
         return self._so_sweep
 
     def block_terms(self) -> np.ndarray:

@@ -107,6 +107,71 @@ inline int free_bsr(Bsr& m) {
 }
 
 
+
+// Every tuning / A-B switch of the library in ONE place: read from the environment once (first use; dpgo_options_reload
+// reads again), printed by dpgo_describe_options / dpgo_problem_describe.  -1 (or 0 where noted) = not set: the size rules
+// decide.  The kernel-selecting ones are exercised by tests/test_parity_gpu.py::test_kernel_selecting_switches_*.
+//        field              variable                  unset  meaning
+#define DPGO_OPTIONS(X)                                                                                                  \
+  X(split,             "DPGO_SPLIT",              0,  "lane groups per pose of the SpMM-family kernels: 1, 2, 4 (0: by size)")       \
+  X(spmm_symmetric,    "DPGO_SPMM_SYMMETRIC",    -1,  "symmetric storage of Q for blocks beyond the Infinity Cache: 0 / 1")          \
+  X(stream_nt,         "DPGO_STREAM_NT",         -1,  "non-temporal single-use operands in the tCG-step kernels: 0 / 1")             \
+  X(outer_sym,         "DPGO_OUTER_SYM",          1,  "outer RTR iteration (k_grad / k_hess) reads the symmetric copy when tCG does") \
+  X(iter_graph,        "DPGO_ITER_GRAPH",         1,  "steady tCG iterations replayed from an instantiated hipGraph")                \
+  X(tcg_ahead,         "DPGO_TCG_AHEAD",          0,  "iterations the just-in-time feed stays ahead (0: 2 multilevel / 4 otherwise)") \
+  X(grid_update,       "DPGO_GRID_UPDATE",        0,  "launch cap of k_tcg_update (0: resident count)")                              \
+  X(grid_hess,         "DPGO_GRID_HESS",          0,  "launch cap of k_tcg_hess (0: resident count)")                                \
+  X(grid_hess_sym,     "DPGO_GRID_HESS_SYM",      0,  "launch cap of k_tcg_hess_sym (0: resident count)")                            \
+  X(grid_ml,           "DPGO_GRID_ML",            0,  "launch cap of the level-0 restriction / post-smoothing (0: resident count)")  \
+  X(persist,           "DPGO_PERSIST",           -1,  "one-launch solve (k_rtr_persist) off / on whatever the size: 0 / 1")          \
+  X(persist_max_poses, "DPGO_PERSIST_MAX_POSES",  0,  "largest block the one-launch solve takes (0: every block it can hold)")       \
+  X(persist_split,     "DPGO_PERSIST_SPLIT",      0,  "lane groups per pose of the one-launch solve: 1, 4 (0: by size)")             \
+  X(persist_mt,        "DPGO_PERSIST_MT",         0,  "tiles per workgroup of the one-launch solve: 1, 2 (0: by size)")              \
+  X(poll_first,        "DPGO_POLL_FIRST",        -1,  "s_sleep units before the first sweep of the in-kernel all-reduce")            \
+  X(poll_sleep,        "DPGO_POLL_SLEEP",        -1,  "s_sleep units between sweeps of the in-kernel all-reduce")                    \
+  X(persist_verbose,   "DPGO_PERSIST_VERBOSE",    0,  "per-solve phase report of the one-launch solve on stderr")                    \
+  X(auto_cost_rule,    "DPGO_AUTO_COST_RULE",     1,  "DPGO_PRECOND_AUTO on coupled blocks: cost rule (0: tCG-budget hysteresis only)") \
+  X(ml_graph,          "DPGO_ML_GRAPH",           1,  "graph aggregates in the default hierarchy (0: index runs)")                   \
+  X(ml_graph_size,     "DPGO_ML_GRAPH_SIZE",      0,  "growth size of the default graph aggregates (0: by size)")                    \
+  X(ml_ap,             "DPGO_ML_AP",              1,  "two-level post-smoothing through A P (0: gather through Q; index runs only)") \
+  X(ml_dense_sym,      "DPGO_ML_DENSE_SYM",      -1,  "dense level from the packed lower triangle on the matrix cores: 0 / 1")       \
+  X(ml_early_stop,     "DPGO_ML_EARLY_STOP",      1,  "tCG's residual test in the restriction kernel, one kernel early")             \
+  X(ml_setup_serial,   "DPGO_ML_SETUP_SERIAL",    0,  "one-thread-per-aggregate set-up kernels of round 3")                          \
+  X(gj_mfma,           "DPGO_GJ_MFMA",            1,  "rank-64 updates of the dense inverse on the fp64 matrix cores")               \
+  X(dense_chunk,       "DPGO_DENSE_CHUNK",        0,  "tiles per workgroup of k_dense_sym_apply (0: default)")                       \
+  X(coarse_nodes,      "DPGO_COARSE_NODES",       0,  "nodes per workgroup of k_ml_coarse_prolong: 1-4 (0: by size)")                \
+  X(coarse_grid,       "DPGO_COARSE_GRID",        0,  "launch cap of k_ml_coarse_prolong (0: default)")                              \
+  X(coarse_nt,         "DPGO_COARSE_NT",         -1,  "non-temporal loads of the dense inverse: 0 / 1")
+struct Options {
+#define X(field, var, unset, text) int field = unset;
+  DPGO_OPTIONS(X)
+#undef X
+};
+inline Options& options_storage() {
+  static Options o;
+  return o;
+}
+inline void options_read(Options& o) {
+  o = Options();
+#define X(field, var, unset, text) \
+  if (const char* e_ = std::getenv(var)) o.field = (*e_ == 0) ? 1 : std::atoi(e_);
+  DPGO_OPTIONS(X)
+#undef X
+}
+inline const Options& options() {
+  static const bool once = (options_read(options_storage()), true);
+  (void)once;
+  return options_storage();
+}
+inline std::string options_describe() {
+  const Options& o = options();
+  std::string s;
+#define X(field, var, unset, text) s += std::string(var) + "=" + std::to_string(o.field) + (o.field == (unset) ? "" : " [set]") + "  # " + text + "\n";
+  DPGO_OPTIONS(X)
+#undef X
+  return s;
+}
+
 }  // namespace dpgo_host
 using namespace dpgo_host;
 
@@ -183,10 +248,7 @@ struct dpgo_problem_s {
   int* ml_chunk_first = nullptr;
   int ml_nchunks = 0;
   bool ml_use_dense_sym() const {
-    static const int env = [] {
-      const char* e = std::getenv("DPGO_ML_DENSE_SYM");
-      return e ? std::atoi(e) : -1;
-    }();
+    const int env = options().ml_dense_sym;
     if (!ml_use_ap() || ml_coarse_bits != 64 || !ml_packed || env == 0) return false;
     return env == 1 || ml_lda >= 3072;  // below, the row-streaming kernel (one launch, cache-resident inverse) is as fast
   }
@@ -219,10 +281,7 @@ struct dpgo_problem_s {
   }
   // two-level hierarchies: level-0 post-smoothing through A P and the coarse solution (k_ml_post_ap); DPGO_ML_AP=0 disables
   bool ml_use_ap() const {
-    static const bool off = [] {
-      const char* e = std::getenv("DPGO_ML_AP");
-      return e && std::atoi(e) == 0;
-    }();
+    const bool off = options().ml_ap == 0;
     return ml.size() == 2 && ml[0].AP.vals != nullptr && (!off || ml[0].graph);  // (graph aggregates exist in this form only)
   }
   // symmetric copy of Q for the plain SpMM on Infinity-Cache-cold blocks (k_spmm_sym): upper blocks transposed + lower references
@@ -248,7 +307,7 @@ struct dpgo_problem_s {
     // Q's bytes come from HBM: there the half-size storage wins (k_tcg_hess 45.5 against 49.4 us, plain product 28.4 against
     // 36.6 us at 100k poses with cold operands), while on cache-resident operands the fused kernels gain nothing
     // (DESIGN.md section 3).  DPGO_SPMM_SYMMETRIC=0/1 in the environment overrides.
-    if (const char* e = std::getenv("DPGO_SPMM_SYMMETRIC")) return std::atoi(e) != 0;
+    if (options().spmm_symmetric >= 0) return options().spmm_symmetric != 0;
     return beyond_cache();
   }
   // what the tCG loop streams besides Q and the pose vectors (the multilevel cycle's dense inverse, A P, prolongation):
@@ -256,8 +315,7 @@ struct dpgo_problem_s {
   size_t loop_extra_bytes = 0;
   // non-temporal single-use operands: when the launch is fed from HBM (same size rule as the symmetric storage)
   bool want_stream_nt() const {
-    const char* e = std::getenv("DPGO_STREAM_NT");
-    return e ? std::atoi(e) != 0 : beyond_cache();
+    return options().stream_nt >= 0 ? options().stream_nt != 0 : beyond_cache();
   }
   bool beyond_cache() const {
     return sizeof(double) * ((size_t)Q.nnzb * b * b + 8 * (size_t)n * T) + sizeof(int32_t) * (size_t)Q.nnzb + loop_extra_bytes >
@@ -272,7 +330,6 @@ struct dpgo_problem_s {
   bool stream_nt = false;  // single-use operands of the tCG-step kernel move non-temporally (ld_stream, common.h)
   bool persist_add = false;  // the reservation is for the additive-preconditioner variant
   bool persist_stream_ordered = false;  // set for the duration of a begin / end solve (see launch_rtr_persistent)
-  size_t persist_lds_attr = 0;  // dynamic LDS size the additive instance's launch attribute was last raised to
   // a solve enqueued by dpgo_optimize_device_begin and not yet collected by ..._end
   struct Pending {
     bool active = false;    // begin has been called
@@ -294,6 +351,18 @@ struct dpgo_problem_s {
   unsigned long long* hflag = nullptr;  // pinned, host-coherent: device-published tCG progress word
   unsigned gen = 0;
   bool saw_rtr_stop = false;  // set from the progress word in just-in-time mode
+  // One STEADY tCG iteration (j >= 1: Hessian step, update, and the V-cycle's launches when that is the preconditioner)
+  // of the multi-launch scheme as an instantiated hipGraph, replayed by the just-in-time feed instead of 2-6 stream
+  // launches (tools/launch_lab.hip: the boundary between two dependent kernels is 3.4 us on a stream, 1.6 us inside a
+  // graph).  One per parity of the state slot the iteration starts from; `key` = hash of everything the launches read
+  // from the handle (iter_graph_key, solve.hip): a graph is re-captured when it no longer matches.
+  struct IterGraph {
+    hipGraphExec_t exec = nullptr;
+    unsigned long long key = 0;
+  } iter_graph[2];
+  bool capturing = false;          // launches are being recorded: they pass generation 0 (kernels/common.h, state_gen)
+  bool iter_graph_failed = false;  // capture / instantiation / launch failed once: this handle keeps plain launches
+  unsigned launch_gen() const { return capturing ? 0u : gen; }
   // re-weightable edges (GNC)
   int em = 0;
   int32_t *e_p1 = nullptr, *e_p2 = nullptr, *c_ptr = nullptr, *c_edge = nullptr;

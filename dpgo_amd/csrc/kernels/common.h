@@ -41,6 +41,15 @@ __device__ __forceinline__ void publish_progress(unsigned long long* hflag, unsi
   }
 }
 
+// The generation a tCG run's progress words carry.  Launches that are replayed from an instantiated hipGraph (one steady
+// tCG iteration, solve.hip) cannot take it as a kernel argument -- it changes with every outer iteration -- so the record
+// carries it: a launch with gen != 0 (every direct launch; the first launches of a tCG run always are) writes it into
+// the record, a launch with gen == 0 reads it from there.
+__device__ __forceinline__ unsigned state_gen(DevState& st, unsigned gen) {
+  if (gen) st.pad0 = (int)gen;
+  return (unsigned)st.pad0;
+}
+
 // Field-wise state copies: copying the whole struct by value (read, modify, write back) is lowered through
 // scratch memory (120 B/lane measured with -Rpass-analysis=kernel-resource-usage), i.e. extra memory
 // round trips on the critical path of every solver kernel.  Field by field it is scalar loads into SGPRs.

@@ -105,7 +105,8 @@ __global__ __launch_bounds__(kBlock) void k_ml_restrict(MAT A, const double* __r
         stop.state->tcg_status = (kappa < pw) ? TCG_LCON : TCG_SCON;
         stop.state->tcg_done = 1;
         if (stop.hflag) {
-          const unsigned long long w = ((unsigned long long)stop.gen << 32) |
+          const unsigned g_ = stop.gen ? stop.gen : (unsigned)st->pad0;  // (0: a replayed launch, see state_gen)
+          const unsigned long long w = ((unsigned long long)g_ << 32) |
                                        ((unsigned long long)((unsigned)j & 0xFFFFFFu) << 8) | 1ull;
           __hip_atomic_store(stop.hflag, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }

@@ -105,6 +105,7 @@ __global__ __launch_bounds__(kBlock, DPGO_LB_HESS) void k_tcg_hess(BsrDev Q, con
   __shared__ double red[kWaves * kNP];
   DevState st;
   load_state(st, sin);
+  gen = state_gen(st, gen);
   if (st.rtr_stop || st.tcg_done) {
     if (blockIdx.x == 0 && threadIdx.x == 0) {
       store_state(sout, st);
@@ -261,6 +262,7 @@ __global__ __launch_bounds__(kBlock) void k_tcg_hess_span(BsrDev Q, const double
   DPGO_STAMP(0, 0);
   DevState st;
   load_state(st, sin);
+  gen = state_gen(st, gen);
   [[maybe_unused]] PartialRaw<2> praw;
   if constexpr (SPLIT > 1) partials_issue<2>(pin, nb_in, praw);
   int tile = ti_.first;
@@ -420,6 +422,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(DPGO_SYM
   DPGO_STAMP(0, 0);
   DevState st;
   load_state(st, sin);
+  gen = state_gen(st, gen);
   [[maybe_unused]] PartialRaw<2> praw;
   int tile = ti_.first;
   bool have = tile < ti_.last;
@@ -601,6 +604,7 @@ __global__ __launch_bounds__(kBlock) void k_tcg_update_span(const double* __rest
   // state record and partial sums are requested before the first tile (see k_tcg_hess_span)
   DevState st;
   load_state(st, sin);
+  gen = state_gen(st, gen);
   PartialRaw<1> praw;
   partials_issue<1>(pin, nb_in, praw);
   int tile = ti_.first;
@@ -730,6 +734,7 @@ __global__ __launch_bounds__(kBlock, DPGO_LB_UPDATE) void k_tcg_update(const dou
   __shared__ double red[kWaves * kNP];
   DevState st;
   load_state(st, sin);
+  gen = state_gen(st, gen);
   if (st.rtr_stop || (!first && st.tcg_done)) {
     if (blockIdx.x == 0 && threadIdx.x == 0) {
       store_state(sout, st);

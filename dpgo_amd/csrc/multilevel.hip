@@ -21,10 +21,8 @@ constexpr int kMlDense = 3200, kMlDenseMax = 6400;
 // (DESIGN.md section 5), and the dense level can then be small.  DPGO_ML_GRAPH=0: index runs as before.
 constexpr int kMlGraphMax = 512, kMlGraphUnknownsPerPose = 1600;
 int ml_default_graph_size(int n, int b) {
-  if (const char* e = std::getenv("DPGO_ML_GRAPH"))
-    if (std::atoi(e) == 0) return 0;
-  if (const char* e = std::getenv("DPGO_ML_GRAPH_SIZE"))  // experiments: force the size
-    if (std::atoi(e) >= 2) return std::atoi(e);
+  if (options().ml_graph == 0) return 0;
+  if (options().ml_graph_size >= 2) return options().ml_graph_size;  // experiments: force the size
   const long long S = std::max<long long>(4, ((long long)n * b + kMlGraphUnknownsPerPose - 1) / kMlGraphUnknownsPerPose);
   return S <= kMlGraphMax ? (int)S : 0;
 }
@@ -37,7 +35,7 @@ int ml_default_graph_size(int n, int b) {
 constexpr int kMlMergeFrom = 64, kMlMergedUnknownsPerPose = 2200;
 std::vector<int> ml_default_ks(int n, int b, int split0) {
   if (const int S = ml_default_graph_size(n, b)) {
-    const bool forced = std::getenv("DPGO_ML_GRAPH_SIZE") != nullptr;
+    const bool forced = options().ml_graph_size >= 2;
     if (!forced && S >= kMlMergeFrom) {
       const int Sm = (int)(((long long)n * b + kMlMergedUnknownsPerPose - 1) / kMlMergedUnknownsPerPose);
       const int cap = Sm + Sm / 2;
@@ -397,7 +395,7 @@ int ml_symbolic_setup(dpgo_problem_s* p, const std::vector<int>& ks_in, int perm
   if (p->ml.size() == 2) {  // two levels: the packed lower triangle and the bookkeeping of k_dense_sym_apply
     const int nT = p->ml_lda / kNB;
     int chunk = kDenseChunk;
-    if (const char* e = std::getenv("DPGO_DENSE_CHUNK")) chunk = std::max(1, std::atoi(e));  // tuning knob
+    if (options().dense_chunk > 0) chunk = options().dense_chunk;  // tuning knob
     std::vector<DenseChunk> chunks;
     std::vector<int> first(nT + 1, 0);
     for (int I = 0; I < nT; ++I) {
@@ -427,8 +425,7 @@ int flat_grid(size_t items) {
 }
 
 bool gj_use_mfma() {
-  if (const char* e = std::getenv("DPGO_GJ_MFMA")) return std::atoi(e) != 0;
-  return true;
+  return options().gj_mfma != 0;
 }
 
 // In-place inverse of the dense SPD lda x lda array M (lda a multiple of 64); W, Rx: lda x 64 panels.
@@ -456,7 +453,7 @@ int ml_numeric_setup_d(dpgo_problem_s* p) {
     const long long span = stride * L.k;
     // (wave-parallel forms of the two setup kernels that walked an aggregate's members with ONE thread; DPGO_ML_SETUP_SERIAL=1
     // restores them)
-    static const bool serial = [] { const char* e = std::getenv("DPGO_ML_SETUP_SERIAL"); return e && std::atoi(e) != 0; }();
+    const bool serial = options().ml_setup_serial != 0;
     auto wave_grid = [](int items) { return std::max(1, std::min(kMaxGrid, (items + kWaves - 1) / kWaves)); };
     if (L.graph && !serial)
       hipLaunchKernelGGL(k_ml_build_P_tree_wave<D>, dim3(wave_grid(C.n)), dim3(kBlock), 0, p->stream, p->Q.dev(), L.agg_ptr,
@@ -541,7 +538,7 @@ const dpgo_problem_s::AddPlan& additive_plan(dpgo_problem_s* p) {
   p->add_agg = dpgo_problem_s::AggCache();
   if (p->split != 4 || (int)p->h_rowptr.size() != p->n + 1) return p->add_plan;
   const int P4 = ml_tile(p->b, 4), P1 = ml_tile(p->b, 1), n = p->n;
-  static const bool graph_ok = [] { const char* e = std::getenv("DPGO_ML_GRAPH"); return !e || std::atoi(e) != 0; }();
+  const bool graph_ok = options().ml_graph != 0;
   if (graph_ok) {
     auto& A = p->add_agg;
     auto &lab = A.lab, &ptr = A.ptr, &mem = A.mem, &parent = A.parent, &pslot = A.pslot;
@@ -640,18 +637,16 @@ int launch_coarse_prolong(dpgo_problem_s* p, const dpgo_problem_s::MlLevel& L, c
   const int cus = persist_capacity(p->device) / 2;
   int nodes = C.n >= 512 ? 2 : 1;
   if (nodes == 2 && !f32 && (C.n + 1) / 2 > cus && (C.n + 2) / 3 <= cus) nodes = 3;
-  if (const char* e = std::getenv("DPGO_COARSE_NODES")) {  // tuning knob
-    const int v = std::atoi(e);
+  if (const int v = options().coarse_nodes)  // tuning knob
     nodes = (v == 4 || v == 2 || (v == 3 && !f32)) ? v : 1;
-  }
   const int groups = (C.n + nodes - 1) / nodes;
   int cap = kMaxGrid;
-  if (const char* e = std::getenv("DPGO_COARSE_GRID")) cap = std::max(1, std::atoi(e));  // tuning knob
+  if (options().coarse_grid > 0) cap = options().coarse_grid;  // tuning knob
   const int rounds = (groups + cap - 1) / cap;
   const int gc = std::max(1, (groups + rounds - 1) / rounds);
   // non-temporal loads of the inverse whenever the loop's working set does not fit the Infinity Cache (kernel comment)
   int hint = p->beyond_cache();
-  if (const char* e = std::getenv("DPGO_COARSE_NT")) hint = std::atoi(e) != 0;  // tuning knob
+  if (options().coarse_nt >= 0) hint = options().coarse_nt != 0;  // tuning knob
 #define COARSE_LAUNCH(NODES, MT, MPTR)                                                                               \
   hipLaunchKernelGGL((k_ml_coarse_prolong<D, R, NODES, MT>), dim3(gc), dim3(kBlock), 0, p->stream, MPTR, p->ml_lda,   \
                      reinterpret_cast<const MT*>(C.r), L.x1, L.Pb, L.k, L.x, gate, L.n, C.n, xc_out, hint)
@@ -714,7 +709,7 @@ int launch_ml_restrict0(dpgo_problem_s* p, const double* r, const DevState* gate
     stop.pin = p->pB();
     stop.nb = p->grid();
     stop.hflag = p->hflag;
-    stop.gen = p->gen;
+    stop.gen = p->launch_gen();
   }
   float* rc32 = (C.k == 0 && p->ml_coarse_bits == 32) ? reinterpret_cast<float*>(C.r) : (float*)nullptr;
   double* res_out = p->ml_use_ap() ? L.res1 : nullptr;
@@ -824,10 +819,8 @@ extern "C" {
 int dpgo_multilevel_default_ks(int n, int d, int* ks, int* nks) {
   if (n <= 0 || d < 2 || d > 3 || !nks) return fail(DPGO_ERR_INVALID, "bad arguments");
   int split = (n < 40000) ? 4 : 1;
-  if (const char* e = std::getenv("DPGO_SPLIT")) {
-    const int v = std::atoi(e);
+  if (const int v = options().split)
     if (v == 1 || v == 2 || v == 4) split = v;
-  }
   const std::vector<int> v = ml_default_ks(n, d + 1, split);
   if (ks)
     for (size_t l = 0; l < v.size() && (int)l < *nks; ++l) ks[l] = v[l];

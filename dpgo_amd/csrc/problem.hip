@@ -199,8 +199,7 @@ int launch_spmm(dpgo_problem_s* p, const Bsr& M, const double* V, const double* 
 }
 
 bool outer_sym_enabled() {  // tuning knob: DPGO_OUTER_SYM=0 keeps the outer iteration on the plain copy of Q
-  static const bool on = [] { const char* e = std::getenv("DPGO_OUTER_SYM"); return !e || std::atoi(e) != 0; }();
-  return on;
+  return options().outer_sym != 0;
 }
 // `sym`: inside a solve whose tCG-step kernel reads the symmetric copy of Q (p->tcg_sym, valid for the duration of the
 // solve) the gradient and the rho-test Hessian read it too: 7 us less per launch at 100k poses with cold operands, and the
@@ -341,10 +340,8 @@ int dpgo_problem_create(dpgo_problem_t* out, int r, int d, int n, int device) {
   p->device = device;
   // small blocks are latency-bound: spread each row over 4 lane groups
   p->split = (n < 40000) ? 4 : 1;
-  if (const char* e = std::getenv("DPGO_SPLIT")) {
-    const int v = std::atoi(e);
+  if (const int v = options().split)
     if (v == 1 || v == 2 || v == 4) p->split = v;
-  }
   int rc = [&]() -> int {
     HIPC(hipSetDevice(device));
     CHK(tune_launch_caps(p));
@@ -382,6 +379,46 @@ int dpgo_problem_create(dpgo_problem_t* out, int r, int d, int n, int device) {
 }
 
 
+// ---- the library's switches and what a handle currently runs (plain text, for logs and tests) ----
+static int copy_text(const std::string& s, char* out, int capacity) {
+  if (!out || capacity <= 0) return fail(DPGO_ERR_INVALID, "null / empty output buffer");
+  const size_t k = std::min(s.size(), (size_t)capacity - 1);
+  std::memcpy(out, s.data(), k);
+  out[k] = 0;
+  return DPGO_OK;
+}
+int dpgo_describe_options(char* out, int capacity) { return copy_text(options_describe(), out, capacity); }
+int dpgo_options_reload(void) {
+  (void)options();
+  options_read(options_storage());
+  return DPGO_OK;
+}
+int dpgo_problem_describe(dpgo_problem_t p, char* out, int capacity) {
+  if (!p) return fail(DPGO_ERR_INVALID, "null handle");
+  std::string s = "dpgo_hip problem: d=" + std::to_string(p->d) + " r=" + std::to_string(p->r) + " n=" + std::to_string(p->n) +
+                  " nnzb=" + std::to_string(p->Q.nnzb) + " device=" + std::to_string(p->device) + "\n";
+  s += "  lane groups per pose " + std::to_string(p->split) + "; launch caps update/hess/hess_sym/restrict/post " +
+       std::to_string(p->cap_u) + "/" + std::to_string(p->cap_h) + "/" + std::to_string(p->cap_hs) + "/" +
+       std::to_string(p->cap_restrict) + "/" + std::to_string(p->cap_post) + "\n";
+  s += std::string("  tCG-step storage: ") + (p->tcg_sym ? "symmetric" : "plain") + (p->stream_nt ? ", non-temporal single-use operands" : "") +
+       "; coupling " + ((p->has_G || p->C.nnzb > 0) ? "yes" : "no") + "\n";
+  s += std::string("  one-launch solve: ") + ((p->persist && !p->persist_failed_once) ? "on" : "off") + ", last geometry " +
+       std::to_string(p->persist_wgs) + " workgroups x " + std::to_string(p->persist_split) + " lane groups x " +
+       std::to_string(p->persist_mt) + " tiles" + (p->persist_add ? " (additive)" : "") + "\n";
+  s += std::string("  auto: ") + (p->auto_decided ? (p->auto_ml ? "multilevel" : "block-Jacobi") : "undecided") + ", cost-rule state " +
+       std::to_string(p->auto_cost.state) + ", block-Jacobi units " + std::to_string(p->auto_cost.jac_units) + ", switches " +
+       std::to_string(p->auto_cost.switches) + ", hand-backs " + std::to_string(p->auto_cost.backoff) + "\n";
+  s += "  hierarchy:";
+  if (!p->ml_symbolic) s += " none";
+  for (size_t l = 0; l < p->ml.size(); ++l)
+    s += " [" + std::to_string(p->ml[l].n) + " nodes" + (p->ml[l].k ? ", k=" + std::to_string(p->ml[l].graph ? -p->ml[l].k : p->ml[l].k) : ", dense") + "]";
+  s += std::string(p->ml_ready ? " built" : " not built") + ", dense level fp" + std::to_string(p->ml_coarse_bits) +
+       (p->ml_additive_layout ? ", additive layout" : "") + "\n";
+  s += std::string("  iteration graphs: ") + (p->iter_graph_failed ? "unavailable" : (p->iter_graph[0].exec || p->iter_graph[1].exec ? "captured" : "none yet")) + "\n";
+  s += "options:\n" + options_describe();
+  return copy_text(s, out, capacity);
+}
+
 int dpgo_problem_destroy(dpgo_problem_t p) {
   if (!p) return DPGO_OK;
   (void)hipSetDevice(p->device);
@@ -401,6 +438,8 @@ int dpgo_problem_destroy(dpgo_problem_t p) {
   if (p->pctrl) (void)hipFree(p->pctrl);
   if (p->pgran) (void)hipFree(p->pgran);
   if (p->hctrl) (void)hipHostFree(p->hctrl);
+  for (auto& g : p->iter_graph)
+    if (g.exec) (void)hipGraphExecDestroy(g.exec);
   if (p->own_stream) (void)hipStreamDestroy(p->own_stream);
   delete p;
   return DPGO_OK;

@@ -11,11 +11,11 @@ int launch_tcg_update(dpgo_problem_s* p, const double* dinv, int first, double* 
     if constexpr (Span<D, R, 1>::kOk)
       hipLaunchKernelGGL((k_tcg_update_span<D, R>), dim3(g), dim3(kBlock), 0, p->stream, p->x1, p->g1, dinv, p->delta,
                          p->Hd, p->eta, p->rr, zt, p->pA(), p->grid_s(), p->pB(), p->dstate + p->cur,
-                         p->dstate + (p->cur ^ 1), first, p->n, p->hflag, p->gen, ml_omega);
+                         p->dstate + (p->cur ^ 1), first, p->n, p->hflag, p->launch_gen(), ml_omega);
     else
       hipLaunchKernelGGL((k_tcg_update<D, R>), dim3(g), dim3(kBlock), 0, p->stream, p->x1, p->g1, dinv, p->delta,
                          p->Hd, p->eta, p->rr, zt, p->pA(), p->grid_s(), p->pB(), p->dstate + p->cur,
-                         p->dstate + (p->cur ^ 1), first, p->n, p->hflag, p->gen, ml_omega);
+                         p->dstate + (p->cur ^ 1), first, p->n, p->hflag, p->launch_gen(), ml_omega);
   });
   HIPC(hipGetLastError());
   p->cur ^= 1;
@@ -54,7 +54,7 @@ int launch_tcg_hess_with(dpgo_problem_s* p, const DevState* sin, DevState* sout,
   return DPGO_OK;
 }
 int launch_tcg_hess(dpgo_problem_s* p, int first) {
-  CHK(launch_tcg_hess_with(p, p->dstate + p->cur, p->dstate + (p->cur ^ 1), first, p->hflag, p->gen));
+  CHK(launch_tcg_hess_with(p, p->dstate + p->cur, p->dstate + (p->cur ^ 1), first, p->hflag, p->launch_gen()));
   p->cur ^= 1;
   return DPGO_OK;
 }
@@ -131,8 +131,7 @@ PersistGeo persist_geometry(const dpgo_problem_s* p, int free_slots, int share, 
     if (g.wgs > kPersistMax || g.slots > free_slots) return PersistGeo();
     return g;
   }
-  static const int env_split = [] { const char* e = std::getenv("DPGO_PERSIST_SPLIT"); return e ? std::atoi(e) : 0; }();
-  static const int env_mt = [] { const char* e = std::getenv("DPGO_PERSIST_MT"); return e ? std::atoi(e) : 0; }();
+  const int env_split = options().persist_split, env_mt = options().persist_mt;
   const int cand[4][2] = {{4, 1}, {4, 2}, {1, 1}, {1, 2}};
   PersistGeo compact;
   for (auto& c : cand) {
@@ -205,8 +204,7 @@ int launch_rtr_persistent(dpgo_problem_s* p, const dpgo_ropt_params* prm, const 
   // granule sweeps of the in-kernel all-reduce: wait before the first one (a granule needs ~1 us to cross the chip and
   // the slowest of more workgroups arrives later; sweeping earlier only loads the fabric: sphere2500 11.9 -> 7.9 us per
   // iteration, 12.5k slab 15.3 -> 12.1), back off between sweeps.  DPGO_POLL_FIRST / DPGO_POLL_SLEEP override.
-  static const int env_first = [] { const char* e = std::getenv("DPGO_POLL_FIRST"); return e ? std::atoi(e) : -1; }();
-  static const int env_sleep = [] { const char* e = std::getenv("DPGO_POLL_SLEEP"); return e ? std::atoi(e) : -1; }();
+  const int env_first = options().poll_first, env_sleep = options().poll_sleep;
   // (whole-solve kernel, run r4j, us per product at first = 16 / 24 / 32 / 44 / 56: sphere2500, 157 workgroups of 4 lane
   // groups per pose, 7.3 / 6.5 / 7.0 / 7.6 / 8.3; 6 250 poses, 196 workgroups of the same layout with two tiles, 10.9 / 9.9 /
   // 9.9 / 10.5 / 11.1; 12.5k slab, one pose per (d+1) lanes, 12.0 / 10.9 / 10.7 / 10.5 / 10.4)
@@ -226,14 +224,19 @@ int launch_rtr_persistent(dpgo_problem_s* p, const dpgo_ropt_params* prm, const 
   const RtrArgs ra{prm->gradnorm_tol, prm->RTR_initial_radius, 5.0 * prm->RTR_initial_radius, prm->RTR_tCG_iterations,
                    prm->RTR_iterations, prm->accept_tiny_decrease};
   const double* Glin = p->has_G ? p->G : nullptr;
-  // (static + dynamic LDS of the additive instances can exceed 64 KB: the attribute is raised once per handle, layout
-  // and size)
+  // (static + dynamic LDS of the additive instances can exceed 64 KB: the launch attribute is raised to the largest size
+  // any handle of the process has asked of that instantiation on that device)
 #define PERSIST_LAUNCH(SP, MT_, ADD_, LDS_)                                                                           \
   do {                                                                                                                \
-    if ((LDS_) > 0 && p->persist_lds_attr != (size_t)(LDS_) * 8 + SP) {                                               \
-      HIPC(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rtr_persist<D, R, SP, MT_, ADD_>),                     \
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)(LDS_)));                             \
-      p->persist_lds_attr = (size_t)(LDS_) * 8 + SP;                                                                  \
+    if ((LDS_) > 0) { /* the attribute belongs to the instantiation and the device: only ever raised */              \
+      static std::atomic<int> hw_[kMaxDevices];                                                                       \
+      auto& h_ = hw_[p->device % kMaxDevices];                                                                        \
+      if ((int)(LDS_) > h_.load()) {                                                                                  \
+        HIPC(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rtr_persist<D, R, SP, MT_, ADD_>),                   \
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)(LDS_)));                           \
+        int cur_ = h_.load();                                                                                         \
+        while (cur_ < (int)(LDS_) && !h_.compare_exchange_weak(cur_, (int)(LDS_))) {}                                 \
+      }                                                                                                               \
     }                                                                                                                 \
     hipLaunchKernelGGL((k_rtr_persist<D, R, SP, MT_, ADD_>), dim3(p->persist_wgs), dim3(kBlock), LDS_, p->stream,     \
                        p->Q.dev(), p->x1, Glin, dinv, p->x2, p->eta, p->z, p->pgran, salt, p->dstate, p->pctrl, p->n, \
@@ -260,7 +263,7 @@ int launch_rtr_persistent(dpgo_problem_s* p, const dpgo_ropt_params* prm, const 
 }
 
 void persist_report(dpgo_problem_s* p) {  // (hctrl has been read back with the state record)
-  if (!std::getenv("DPGO_PERSIST_VERBOSE")) return;
+  if (!options().persist_verbose) return;
   const double it = std::max<double>(1.0, (double)p->hctrl->ticks[4]);
   std::fprintf(stderr,
                "dpgo_hip: persistent tCG: %u workgroups (%d lane groups per pose, %d tiles each)%s, %u iterations; per "
@@ -268,6 +271,55 @@ void persist_report(dpgo_problem_s* p) {  // (hctrl has been read back with the 
                p->hctrl->members, p->persist_split, p->persist_mt, p->hctrl->error ? " TIMED OUT" : "", p->hctrl->iters,
                0.01 * (double)p->hctrl->ticks[0] / it, 0.01 * (double)p->hctrl->ticks[1] / it,
                0.01 * (double)p->hctrl->ticks[2] / it, 0.01 * (double)p->hctrl->ticks[3] / it);
+}
+
+// ---- one steady tCG iteration as an instantiated hipGraph (dpgo_problem_s::IterGraph) ----
+// Everything the launches of an iteration read from the handle, hashed: a captured graph is valid exactly while this
+// value is unchanged (a buffer that was freed and came back at the same address with the same sizes is the same launch).
+struct KeyHash {
+  unsigned long long h = 1469598103934665603ull;
+  void add(const void* ptr) { mix((unsigned long long)(uintptr_t)ptr); }
+  void add(long long v) { mix((unsigned long long)v); }
+  void add(double v) {
+    unsigned long long u;
+    std::memcpy(&u, &v, sizeof(u));
+    mix(u);
+  }
+  void mix(unsigned long long v) {
+    for (int k = 0; k < 8; ++k) {
+      h ^= (v >> (8 * k)) & 0xffull;
+      h *= 1099511628211ull;
+    }
+  }
+};
+void key_bsr(KeyHash& k, const Bsr& m) {
+  k.add((long long)m.nrows), k.add((long long)m.ncols), k.add((long long)m.nnzb);
+  k.add(m.rowptr), k.add(m.colidx), k.add(m.vals);
+}
+unsigned long long iter_graph_key(const dpgo_problem_s* p, const double* dinv, bool ml, bool early_stop) {
+  KeyHash k;
+  k.add((long long)p->d), k.add((long long)p->r), k.add((long long)p->n), k.add((long long)p->split), k.add((long long)p->cur);
+  k.add((long long)p->tcg_sym), k.add((long long)p->stream_nt), k.add((long long)ml), k.add((long long)early_stop);
+  k.add((long long)p->grid()), k.add((long long)p->grid_s()), k.add((long long)p->grid_restrict()), k.add((long long)p->grid_post());
+  k.add((long long)p->zr_from_post), k.add((long long)p->nb_zr()), k.add((long long)p->device);
+  key_bsr(k, p->Q);
+  const auto& y = p->sym;
+  k.add(y.urow), k.add(y.ucol), k.add(y.uvalsT), k.add(y.lrow), k.add(y.lcol), k.add(y.lslot);
+  const void* vecs[] = {p->x1, p->g1, p->S1, p->z, p->delta, p->Hd, p->eta, p->rr, dinv, p->dinv, p->partials, p->dstate, p->hflag};
+  for (auto v : vecs) k.add(v);
+  if (!ml) return k.h;
+  k.add(p->ml_omega), k.add(p->ml_shift), k.add((long long)p->ml_coarse_bits), k.add((long long)p->ml_lda);
+  k.add((long long)p->ml_use_ap()), k.add((long long)p->ml_use_dense_sym()), k.add((long long)p->beyond_cache());
+  k.add(p->ml_dense), k.add(p->ml_dense32), k.add(p->ml_packed), k.add(p->ml_pd), k.add(p->ml_pt), k.add(p->ml_chunks);
+  k.add(p->ml_chunk_first), k.add((long long)p->ml_nchunks), k.add((long long)p->ml.size());
+  for (const auto& L : p->ml) {
+    k.add((long long)L.n), k.add((long long)L.k), k.add((long long)L.split), k.add((long long)L.graph), k.add((long long)L.nseg);
+    key_bsr(k, L.A), key_bsr(k, L.AP);
+    const void* ptrs[] = {L.slot_row, L.dinv, L.Pb, L.r, L.x1, L.x, L.res1, L.lab, L.agg_ptr, L.agg_mem, L.parent, L.pslot,
+                          L.mem_pos, L.seg_info, L.seg_ptr, L.tile_perm, L.tbuf};
+    for (auto v : ptrs) k.add(v);
+  }
+  return k.h;
 }
 
 // One ROPTLIB SolversTR::Run outer iteration: tCG + retraction + rho test.  State stays on the device; the host
@@ -286,14 +338,65 @@ int rtr_outer_iteration(dpgo_problem_s* p, const dpgo_ropt_params* prm, const do
   auto update = [&](int first) -> int {
     if (ml) {
       CHK(launch_tcg_update(p, dinv, first, p->ml[0].x1, p->ml_omega));
-      static const bool early_stop = [] { const char* e = std::getenv("DPGO_ML_EARLY_STOP"); return !e || std::atoi(e) != 0; }();
+      const bool early_stop = options().ml_early_stop != 0;
       return launch_ml_tail(p, p->x1, p->rr, p->z, p->pB(), p->dstate + p->cur, early_stop && !first);
     }
     return launch_tcg_update(p, dinv, first);
   };
   CHK(update(1));
   const int max_inner = prm->RTR_tCG_iterations;
+  // Steady iterations (j >= 1) of the just-in-time feed are replayed from an instantiated hipGraph: the launches of one
+  // iteration recorded once (stream capture on the handle's private stream -- the caller's may be the legacy default
+  // stream, which cannot be captured --, generation 0 = "the one in the state record") and launched into the handle's
+  // stream.  Same kernels, same arguments, same order: bit-identical iterates.  DPGO_ITER_GRAPH=0 keeps plain launches.
+  const bool graph_wanted = options().iter_graph != 0, early_stop_ = options().ml_early_stop != 0;
+  const bool use_graph = graph_wanted && !p->iter_graph_failed && prm->tcg_poll_interval <= 0 && max_inner > 1 && p->own_stream;
+  auto replay = [&]() -> int {  // one steady iteration; DPGO_OK with *launched = false: the caller launches directly
+    auto& g = p->iter_graph[p->cur & 1];
+    const unsigned long long key = iter_graph_key(p, dinv, ml, early_stop_);
+    if (!g.exec || g.key != key) {
+      if (g.exec) (void)hipGraphExecDestroy(g.exec);
+      g.exec = nullptr;
+      hipStream_t own = p->own_stream, keep = p->stream;
+      const int cur0 = p->cur;
+      if (keep == own) HIPC(hipStreamSynchronize(own));  // (recording starts on an idle stream)
+      if (hipStreamBeginCapture(own, hipStreamCaptureModeThreadLocal) != hipSuccess) {
+        (void)hipGetLastError();
+        p->iter_graph_failed = true;
+        return DPGO_ERR_UNSUPPORTED;
+      }
+      p->stream = own;
+      p->capturing = true;
+      int rc = launch_tcg_hess(p, 0);
+      if (rc == DPGO_OK) rc = update(0);
+      p->capturing = false;
+      p->stream = keep;
+      p->cur = cur0;
+      hipGraph_t graph = nullptr;
+      const hipError_t e1 = hipStreamEndCapture(own, &graph);
+      hipError_t e2 = hipSuccess;
+      if (rc == DPGO_OK && e1 == hipSuccess && graph) e2 = hipGraphInstantiate(&g.exec, graph, nullptr, nullptr, 0);
+      if (graph) (void)hipGraphDestroy(graph);
+      if (rc != DPGO_OK || e1 != hipSuccess || e2 != hipSuccess || !g.exec) {
+        (void)hipGetLastError();
+        g.exec = nullptr;
+        p->iter_graph_failed = true;
+        return DPGO_ERR_UNSUPPORTED;
+      }
+      g.key = key;
+    }
+    if (hipGraphLaunch(g.exec, p->stream) != hipSuccess) {
+      (void)hipGetLastError();
+      p->iter_graph_failed = true;
+      return DPGO_ERR_UNSUPPORTED;
+    }
+    return DPGO_OK;
+  };
   auto step = [&](int j) -> int {
+    if (j >= 1 && use_graph && !p->iter_graph_failed) {
+      if (replay() == DPGO_OK) return DPGO_OK;  // (otherwise: nothing of this iteration has been enqueued)
+      if (options().persist_verbose) std::fprintf(stderr, "dpgo_hip: hipGraph replay of a tCG iteration unavailable; plain launches\n");
+    }
     CHK(launch_tcg_hess(p, j == 0 ? 1 : 0));
     return update(0);
   };
@@ -320,7 +423,7 @@ int rtr_outer_iteration(dpgo_problem_s* p, const dpgo_ropt_params* prm, const do
     // is published by the prologue of iteration j+1's Hessian-step kernel, so one iteration ahead never sees progress --
     // tried in round 4, the watchdog fires.)
     int kAhead = ml ? 2 : 4;
-    if (const char* e = std::getenv("DPGO_TCG_AHEAD")) kAhead = std::max(2, std::atoi(e));  // tuning knob (>= 2, see above)
+    if (options().tcg_ahead > 0) kAhead = std::max(2, options().tcg_ahead);  // tuning knob (>= 2, see above)
     int enq = 0, last_j = -1;
     auto t_progress = std::chrono::steady_clock::now();
     while (true) {
@@ -408,7 +511,7 @@ void auto_update(dpgo_problem_s* p, const dpgo_ropt_params* prm, int used, int p
     if (!p->auto_ml && 2 * products >= budget) p->auto_ml = true;
     return;
   }
-  static const bool cost_rule = [] { const char* e = std::getenv("DPGO_AUTO_COST_RULE"); return !e || std::atoi(e) != 0; }();
+  const bool cost_rule = options().auto_cost_rule != 0;
   if (!p->auto_ml) {  // the solve ran block-Jacobi
     a.state = 0;
     a.uj = auto_units_jacobi(p);
@@ -568,7 +671,7 @@ int run_optimize(dpgo_problem_s* p, const dpgo_ropt_params* prm, dpgo_ropt_resul
       // untouched; this handle stops using the kernel and the solve runs on the multi-launch scheme
       p->persist_failed_once = true;
       persist_release(p);
-      if (std::getenv("DPGO_PERSIST_VERBOSE"))
+      if (options().persist_verbose)
         std::fprintf(stderr, "dpgo_hip: persistent solve timed out; this handle continues with the multi-launch scheme\n");
     }
   }
@@ -711,13 +814,11 @@ int tune_launch_caps(dpgo_problem_s* p) {
       CHK(resident_blocks(k_ml_post_ap<D, R, 1>, &p->cap_post));
     }
   });
-  if (const char* e = std::getenv("DPGO_GRID_ML")) {
-    p->cap_restrict = p->cap_post = std::max(1, std::min(kPartialCap, std::atoi(e)));
-  }
+  if (options().grid_ml > 0) p->cap_restrict = p->cap_post = std::min(kPartialCap, options().grid_ml);
   // tuning knobs (any value up to the partial-sum capacity is valid)
-  if (const char* e = std::getenv("DPGO_GRID_UPDATE")) p->cap_u = std::max(1, std::min(kPartialCap, std::atoi(e)));
-  if (const char* e = std::getenv("DPGO_GRID_HESS")) p->cap_h = std::max(1, std::min(kPartialCap, std::atoi(e)));
-  if (const char* e = std::getenv("DPGO_GRID_HESS_SYM")) p->cap_hs = std::max(1, std::min(kPartialCap, std::atoi(e)));
+  if (options().grid_update > 0) p->cap_u = std::min(kPartialCap, options().grid_update);
+  if (options().grid_hess > 0) p->cap_h = std::min(kPartialCap, options().grid_hess);
+  if (options().grid_hess_sym > 0) p->cap_hs = std::min(kPartialCap, options().grid_hess_sym);
   return DPGO_OK;
 }
 
@@ -726,10 +827,10 @@ int tune_launch_caps(dpgo_problem_s* p) {
 // 15.4, 6 250 9.9 / 17.2, 12.5k slab 10.5 / 19.7, 25k 18.7 / 26.5).  DPGO_PERSIST_MAX_POSES lowers the limit, DPGO_PERSIST=0/1
 // overrides.
 int tune_persist(dpgo_problem_s* p) {
-  static const int max_poses = [] { const char* e = std::getenv("DPGO_PERSIST_MAX_POSES"); return e ? std::atoi(e) : 1 << 30; }();
+  const int max_poses = options().persist_max_poses > 0 ? options().persist_max_poses : 1 << 30;
   const bool fits = persist_geometry(p, persist_capacity(p->device)).wgs > 0;
   bool on = fits && p->n <= max_poses;
-  if (const char* e = std::getenv("DPGO_PERSIST")) on = fits && std::atoi(e) != 0;
+  if (options().persist >= 0) on = fits && options().persist != 0;
   p->persist = on;
   return DPGO_OK;
 }

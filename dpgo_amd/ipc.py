@@ -74,18 +74,24 @@ class IpcPeerStore:
         torch, dist = self.torch, self.dist
         c = self.cluster
         gen = c._buffer_generation()
-        if self._shared_gen.get(aux) != gen:
-            # first (auxiliary) exchange, or an agent re-bound one of its buffers: export / open again -- collective: the
-            # agents of every rank are re-initialised by the same driver calls, so every rank takes this branch together
+        out = [(a, q) for a, q in msgs if a in c.agents]
+        torch.cuda.current_stream().synchronize()
+        # first (auxiliary) exchange, or an agent of SOME rank re-bound one of its buffers: export / open again.  _share is
+        # collective, the buffer generation is a local count -- so the decision is agreed on: the maximum over the ranks
+        # of "mine changed" rides on the reduction that is the barrier before the launch (nobody still reads the buffers)
+        flag = torch.tensor([1.0 if self._shared_gen.get(aux) != gen else 0.0],
+                            device="cuda" if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        if float(flag.item()) > 0.0:
+            for key_ in [k for k in self._remote if k[1] == aux]:  # (stale mappings of this kind of buffer)
+                del self._remote[key_]
             self._share(aux)
+            self._plan_gen = None  # remote addresses may have changed whatever the local generation says
         if self.__dict__.get("_plan_gen") != gen:  # the plans hold raw device addresses
             for h in self._plans.values():
                 self._destroy(h)
             self._plans.clear()
             self._plan_gen = gen
-        out = [(a, q) for a, q in msgs if a in c.agents]
-        torch.cuda.current_stream().synchronize()
-        dist.barrier()
         if out:
             first = c.agents[out[0][0]]
             pkey = (key, aux)

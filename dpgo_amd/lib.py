@@ -59,6 +59,9 @@ SIGNATURES = {
     "dpgo_device_count": ([C.POINTER(C.c_int)], _I),
     "dpgo_ropt_params_default": ([C.POINTER(RoptParamsC)], None),
     "dpgo_supported": ([_I, _I], _I),
+    "dpgo_describe_options": ([C.c_char_p, _I], _I),
+    "dpgo_options_reload": ([], _I),
+    "dpgo_problem_describe": ([_P, C.c_char_p, _I], _I),
     "dpgo_problem_create": ([C.POINTER(_P), _I, _I, _I, _I], _I),
     "dpgo_problem_destroy": ([_P], _I),
     "dpgo_problem_set_stream": ([_P, _P], _I),
@@ -199,6 +202,13 @@ def ptr(a) -> Optional[int]:
     if hasattr(a, "data_ptr"):
         return a.data_ptr()
     raise TypeError("cannot take the address of %r" % type(a))
+
+
+def describe_options() -> str:
+    """The library's DPGO_* switches as it read them (dpgo_describe_options)."""
+    buf = C.create_string_buffer(16384)
+    check(load().dpgo_describe_options(buf, len(buf)))
+    return buf.value.decode("utf-8", "replace")
 
 
 def device_count() -> int:

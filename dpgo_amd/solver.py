@@ -200,6 +200,23 @@ class PoseGraph:
                 w[e] = 0.0
         return w
 
+    def odometry_mask(self, m: Optional[RelativeSEMeasurements] = None) -> np.ndarray:
+        """Which of the measurements (default: all of this graph's) are odometry -- consecutive poses of this robot in
+        the CALLER's numbering (PoseGraph::addOdometry keeps exactly those apart, src/PoseGraph.cpp:61-77).  A graph
+        whose poses the agent layer renumbered for locality (build_pose_graphs(reorder=True): pose_order = internal row
+        of every caller frame) tests the caller's ids, so that a loop closure landing on consecutive internal rows
+        stays a loop closure."""
+        m = self._meas if m is None else m
+        same = m.r1 == m.r2
+        order = getattr(self, "pose_order", None)
+        if order is None:
+            return same & (m.p1 + 1 == m.p2)
+        caller = np.empty(len(order), dtype=np.int64)
+        caller[np.asarray(order, dtype=np.int64)] = np.arange(len(order))
+        p1 = np.where(same, caller[np.minimum(m.p1, len(order) - 1)], 0)
+        p2 = np.where(same, caller[np.minimum(m.p2, len(order) - 1)], 0)
+        return same & (p1 + 1 == p2)
+
     def measurements(self) -> RelativeSEMeasurements:
         return self._meas
 
@@ -536,6 +553,13 @@ class QuadraticProblem:
         L.check(self._lib.dpgo_problem_set_spmm_variant(self._h, names[variant], C.byref(v)))
         return "symmetric" if v.value == 2 else "plain"
 
+    def describe(self) -> str:
+        """What this handle currently runs (layout, storage, one-launch solve, preconditioner selection, hierarchy) and the
+        library's switches (dpgo_problem_describe)."""
+        buf = C.create_string_buffer(32768)
+        L.check(self._lib.dpgo_problem_describe(self._h, buf, len(buf)))
+        return buf.value.decode("utf-8", "replace")
+
     def autoState(self, use_multilevel=None) -> bool:
         """What precond = "auto" currently runs on this handle (True: the multilevel cycle); a bool argument sets it,
         "reset" returns to the decision a fresh handle takes for this problem."""
@@ -630,9 +654,15 @@ class QuadraticProblem:
                     role[e], slot[e] = 2, slot_index[(int(m.r1[e]), int(m.p1[e]))]
         fixed = np.asarray(m.fixedWeight, dtype=bool)
         if include_shared:
-            fixed = fixed | ((m.r1 == m.r2) & (m.p1 + 1 == m.p2))
+            fixed = fixed | pg.odometry_mask(m)
+        # what Q and the coupling blocks were built with: the shared edges with an INACTIVE neighbour are out (weight 0,
+        # PoseGraph::constructQ / constructG skip them; PGOAgent::updateMeasurementWeights only walks
+        # activeLoopClosures(), src/PGOAgent.cpp:1104-1118) -- registered with that weight and never re-weighted, so
+        # that the device's base Q - sum(w contrib) and every later re-weighting leave them out as well
+        w_eff = np.asarray(pg._effective_weights(), dtype=np.float64)[sel]
+        fixed = fixed | (w_eff != np.asarray(m.weight, dtype=np.float64))
         fixed = np.ascontiguousarray(fixed, dtype=np.uint8)
-        w = np.ascontiguousarray(m.weight, dtype=np.float64)
+        w = np.ascontiguousarray(w_eff, dtype=np.float64)
         L.check(self._lib.dpgo_problem_set_reweightable_edges_ex(
             self._h, len(m), L.ptr(m.p1), L.ptr(m.p2), L.ptr(role), L.ptr(slot), L.ptr(m.R), L.ptr(m.t),
             L.ptr(m.kappa), L.ptr(m.tau), L.ptr(w), L.ptr(fixed)))
@@ -649,6 +679,19 @@ class QuadraticProblem:
             self._h, L.ptr(X_dev), L.ptr(nbr_tiles_dev) if nbr_tiles_dev is not None else None, float(mu),
             float(barc), float(w_tol), int(update), C.byref(counts), C.byref(mx)))
         return tuple(counts), mx.value
+
+    def pullEdgeWeights(self) -> None:
+        """Write the device's current GNC weights of the registered edges back into the pose graph's measurements (the
+        host copy is what refresh() rebuilds Q from after a neighbour (de)activation); edges that are out because their
+        neighbour is inactive keep the host weight they will come back with."""
+        idx = getattr(self, "reweightable_index", None)
+        if idx is None or len(idx) == 0:
+            return
+        pg = self.pose_graph_
+        w, _ = self.getEdgeWeights()
+        m = pg.measurements()
+        live = np.asarray(pg._effective_weights())[idx] == np.asarray(m.weight)[idx]
+        m.weight[idx[live]] = np.asarray(w)[live]
 
     def setEdgeWeights(self, w: np.ndarray) -> None:
         w = np.ascontiguousarray(w, dtype=np.float64)

@@ -135,6 +135,13 @@ void dpgo_ropt_params_default(dpgo_ropt_params* p);
 /* 1 if the (d, r) pair has compiled kernels */
 int dpgo_supported(int d, int r);
 
+/* Every tuning / A-B switch the library reads from the environment (DPGO_*; read once at first use), one
+ * "NAME=value  # meaning" line each ("[set]" marks the ones the environment overrides); dpgo_options_reload reads the
+ * environment again (tools).  dpgo_problem_describe: what a handle currently runs -- layout, storage, one-launch solve,
+ * preconditioner selection, hierarchy -- followed by the same list.  Text is truncated to capacity - 1 characters. */
+int dpgo_describe_options(char* out, int capacity);
+int dpgo_options_reload(void);
+
 /* ---- problem lifecycle: replaces QuadraticProblem(shared_ptr<PoseGraph>)
  * (include/DPGO/QuadraticProblem.h:39) + the data PoseGraph caches for it
  * (Q_, G_, precon_: include/DPGO/PoseGraph.h:324-331).  The handle owns device copies of
@@ -143,6 +150,7 @@ int dpgo_supported(int d, int r);
  * iteration, src/PGOAgent.cpp:968-969, which is free on the CPU but not on a device). */
 int dpgo_problem_create(dpgo_problem_t* out, int r, int d, int n, int device);
 int dpgo_problem_destroy(dpgo_problem_t h);
+int dpgo_problem_describe(dpgo_problem_t h, char* out, int capacity);
 /* Run this handle's work on an external HIP stream, e.g. torch's current stream, so that it is ordered
  * with the caller's own device work.  hip_stream = NULL selects the device's DEFAULT (null) stream --
  * which is what torch.cuda.current_stream().cuda_stream is unless the caller switched streams.

@@ -622,7 +622,7 @@ def test_multi_agent_rbcd_on_one_gpu_matches_oracle(oracle, name, robots, sweeps
             assert agents[a].problem.multilevelInfo()["ks"] == plans[a]["ks"]
 
 
-@pytest.mark.parametrize("name,robots,settle,sweeps", [("torus3D", 8, 0, 12), ("grid:50x50x40", 8, 4, 13)])
+@pytest.mark.parametrize("name,robots,settle,sweeps", [("torus3D", 8, 0, 12), ("grid:50x50x40", 8, 4, 11)])
 def test_auto_cost_rule_switches_coupled_blocks_to_additive(oracle, name, robots, settle, sweeps):
     """precond = "auto" on COUPLED blocks the additive one-launch solve can hold (include/dpgo_hip.h, DPGO_PRECOND_AUTO):
     every agent starts on block-Jacobi; once its block-Jacobi solves since Q last changed have cost as much as one
@@ -1244,6 +1244,76 @@ def test_inactive_robot_leaves_the_team(oracle):
         else:  # (the central cost is assembled from the agents' LOCAL problems: with a robot off they leave edges out)
             f, g = cluster.central_cost_and_gradnorm()
             assert abs(2 * f - costs[-1]) <= 1e-9 * abs(costs[-1])
+
+
+def test_inactive_neighbour_in_robust_mode_keeps_the_device_weights(oracle):
+    """PGOAgent::setRobotActive in robust (GNC) mode -- ADVICE r4: the GNC weights live on the device, the host copy of
+    the measurements is what Q is rebuilt from when a neighbour is switched off.  smallGrid3D / 5 with every loop closure
+    registered as re-weightable: after a re-weighting that leaves weights strictly between 0 and 1, robot 3 is switched
+    off and on again.  At every stage agent 2's device weights and Q values are those of the reference's data matrices
+    (constructQ over the ACTIVE edges with the current weights, src/PoseGraph.cpp:381-491): the edges with robot 3 leave
+    with weight 0, are not re-weighted while it is off (PGOAgent::updateMeasurementWeights walks activeLoopClosures()
+    only, src/PGOAgent.cpp:1104-1118), and come back with the weights they left with; all other weights survive both
+    switches."""
+    import dpgo_amd
+    from dpgo_amd.agent import DeviceAgent, ExchangePlan, RBCDCluster, build_pose_graphs
+    r, robots, me, off = 5, 5, 2, 3
+    om, n = oracle.read_g2o(os.path.join(DATA, "smallGrid3D.g2o"))
+    d = om.d
+    X0 = oracle.lift(oracle.chordal_initialization(om, n), r)
+    ranges, graphs = build_pose_graphs(to_product_measurements(om), n, robots, r)
+    plan = ExchangePlan(graphs)
+    agents = {a: DeviceAgent(graphs, plan, a, X0[ranges[a][0]:ranges[a][1]], dpgo_amd.ROptParameters(precond="jacobi"))
+              for a in range(robots)}
+    cluster = RBCDCluster(plan, agents)
+    for ag in agents.values():
+        ag.problem.setReweightableEdges(include_shared=True)
+    cluster.sweep()
+    cluster.exchange(None)
+    ag = agents[me]
+    pg, prob = ag.pg, ag.problem
+    idx = prob.reweightable_index
+    m = pg.measurements()
+    with_off = np.array([(m.r1[e] != m.r2[e]) and off in (int(m.r1[e]), int(m.r2[e])) for e in idx])
+    assert with_off.any()
+
+    def q_reference():  # Q of agent `me` from its host measurements as the reference's constructQ builds it
+        pg._Q = None    # (the cached matrix predates the weights written back)
+        _, _, vals = pg.quadraticMatrix()
+        return np.asarray(vals).copy()
+
+    def q_device():
+        out = np.zeros_like(q_reference())
+        dpgo_amd.lib.check(prob._lib.dpgo_problem_get_Q_values(prob.handle, dpgo_amd.lib.ptr(out)))
+        return out
+
+    # a re-weighting with a small mu: weights strictly inside (0, 1) exist afterwards
+    mu = 0.05  # (GNC-TLS: residuals between mu / (mu + 1) barc^2 and (mu + 1) / mu barc^2 get intermediate weights)
+    prob.gncReweightDevice(ag.X, ag.nbr, mu, 5.0, update=True)
+    w1, _ = prob.getEdgeWeights()
+    lc = ~pg.odometry_mask()[idx]
+    assert np.all(w1[~lc] == 1.0) and (np.unique(np.round(w1[lc], 12)).size > 1 or np.any((w1[lc] > 0) & (w1[lc] < 1)))
+    # --- robot 3 off: its edges leave (weight 0), everything else keeps the DEVICE weights
+    cluster.set_robot_active(off, False)
+    w2, _ = prob.getEdgeWeights()
+    assert np.all(w2[with_off] == 0.0) and np.array_equal(w2[~with_off], w1[~with_off])
+    assert np.array_equal(np.asarray(m.weight)[idx][~with_off], w1[~with_off])  # the host copy followed
+    assert relerr(q_device(), q_reference()) < 1e-13
+    # ... a re-weighting while it is off leaves those edges out
+    prob.gncReweightDevice(ag.X, ag.nbr, 1.4 * mu, 5.0, update=True)
+    w3, _ = prob.getEdgeWeights()
+    assert np.all(w3[with_off] == 0.0)
+    prob.pullEdgeWeights()
+    assert relerr(q_device(), q_reference()) < 1e-13
+    lam = np.linalg.eigvalsh(oracle.BSR(pg.n(), d + 1, *[np.asarray(v) for v in pg.quadraticMatrix()]).to_scipy().toarray())
+    assert lam.min() > -1e-9 * lam.max()  # Q stays positive semidefinite
+    # --- back on: the edges return with the weights they left with, the others with the latest ones
+    cluster.set_robot_active(off, True)
+    w4, _ = prob.getEdgeWeights()
+    assert np.array_equal(w4[with_off], w1[with_off]) and np.array_equal(w4[~with_off], w3[~with_off])
+    assert relerr(q_device(), q_reference()) < 1e-13
+    cluster.sweep()  # the solves still run on the rebuilt matrices
+    assert agents[me].last_result.success
 
 
 def test_more_concurrent_handles_than_hardware_queues_warn_once_and_complete():
@@ -2274,6 +2344,101 @@ def test_multilevel_on_random_graphs_with_broken_chains(oracle, d, r, n, hub_edg
     # are compared to 2 % only; what pins the arithmetic is the 1e-9 on the operator above)
     if rg.tcg_iterations == oo.result.tcg_iters:
         assert abs(rg.fOpt - oo.result.fOpt) <= 2e-2 * abs(oo.result.fOpt)
+
+
+SWITCH_SETS = [
+    ({}, "baseline"),
+    ({"DPGO_ML_EARLY_STOP": "0"}, "bitwise"),      # tCG's residual test back in the Hessian-step kernel's prologue
+    ({"DPGO_ITER_GRAPH": "0"}, "bitwise"),         # steady tCG iterations as plain stream launches instead of a hipGraph
+    ({"DPGO_SPMM_SYMMETRIC": "1"}, "oracle"),      # symmetric storage of Q: k_tcg_hess_sym, level-0 restriction / post-smoothing
+    ({"DPGO_SPMM_SYMMETRIC": "1", "DPGO_OUTER_SYM": "0", "DPGO_STREAM_NT": "1"}, "oracle"),  # outer iteration on the plain copy
+    ({"DPGO_SPMM_SYMMETRIC": "0", "DPGO_STREAM_NT": "1"}, "oracle"),  # plain storage with non-temporal single-use operands
+    ({"DPGO_ML_GRAPH": "0"}, "oracle"),            # index-run hierarchy (k_ml_post_ap on runs, in-workgroup restriction sums)
+    ({"DPGO_ML_GRAPH": "0", "DPGO_ML_AP": "0"}, "oracle"),  # ... post-smoothing gathers through Q (k_ml_post)
+    ({"DPGO_ML_SETUP_SERIAL": "1", "DPGO_GJ_MFMA": "0"}, "oracle"),  # round-3 set-up kernels, FMA rank-64 updates
+    ({"DPGO_ML_DENSE_SYM": "1"}, "oracle"),        # dense level from the packed lower triangle on the matrix cores
+    ({"DPGO_COARSE_NODES": "1", "DPGO_COARSE_NT": "1"}, "oracle"),  # one node per workgroup, non-temporal inverse
+]
+
+
+@pytest.mark.parametrize("workload", ["smallGrid3D", "grid:40x40x25"])
+def test_kernel_selecting_switches_match_oracle(oracle, workload):
+    """Every environment switch that selects a different KERNEL or storage on the multi-launch multilevel path
+    (csrc/host.h, DPGO_OPTIONS; the tested configuration used to be the default one only), flipped one set at a time on
+    smallGrid3D and on a 40 000-pose grid (the smallest block that can run the symmetric storage): two
+    QuadraticOptimizer::optimize calls with the multilevel preconditioner against the oracle told the device's
+    hierarchy, each call from the oracle's iterate -- same tCG / RTR counts, cost 1e-9 (+ 1e-4 of the call's decrease),
+    iterate 1e-6.  Switches that must not change a single bit (where the residual test sits, how the launches are
+    enqueued) are also compared bitwise with the default run.  The library reads its switches once; the test reloads
+    them (dpgo_options_reload) and builds a fresh handle per set.  DPGO_ASYNC_SWEEP lives in the Python agent layer:
+    test_stream_ordered_sweep_matches_phase_by_phase."""
+    import hashlib
+    import torch
+    import dpgo_amd
+    r = 5
+    if workload.startswith("grid:"):
+        om, n, Ttrue = oracle.synthetic_grid(*[int(v) for v in workload[5:].split("x")], seed=0)
+        X0 = oracle.lift(oracle.perturbed_truth(Ttrue, seed=2), r)
+    else:
+        om, n = oracle.read_g2o(os.path.join(DATA, workload + ".g2o"))
+        X0 = oracle.lift(oracle.chordal_initialization(om, n), r)
+    d = om.d
+    Q = oracle.construct_Q(n, d, om)
+    lib = dpgo_amd.lib.load()
+    names = sorted({k for sw, _ in SWITCH_SETS for k in sw})
+    saved = {k: os.environ.get(k) for k in names}
+    want = {}      # hierarchy -> [(tcg, rtr, fOpt, Xo)] of the oracle's calls
+    digests = {}
+    try:
+        for sw, mode in SWITCH_SETS:
+            for k in names:
+                os.environ.pop(k, None)
+            os.environ.update(sw)
+            dpgo_amd.lib.check(lib.dpgo_options_reload())
+            text = dpgo_amd.lib.describe_options()
+            assert all(("%s=%s [set]" % kv) in text for kv in sw.items()), (sw, text)
+            pg = dpgo_amd.PoseGraph(0, r, d)
+            pg.setMeasurements(to_product_measurements(om))
+            prob = dpgo_amd.QuadraticProblem(pg)
+            prob.setPersistent(False)
+            opt = dpgo_amd.QuadraticOptimizer(prob, dpgo_amd.ROptParameters(precond="multilevel"))
+            ks = tuple(prob.setupMultilevel()["ks"])
+            if ks not in want:
+                op = oracle.QuadraticProblem(Q, None, r, d, precond="amg", amg_k=list(ks))
+                rows, Xo = [], X0
+                for call in range(2):
+                    oo = oracle.QuadraticOptimizer(op, oracle.ROptParameters(), hess_recurrence=True)
+                    Xn = oo.optimize(Xo)
+                    rows.append((oo.result.tcg_iters, oo.result.outer_iters, oo.result.fOpt, Xo, Xn))
+                    Xo = Xn
+                want[ks] = rows
+            Xd = torch.tensor(X0, device="cuda", dtype=torch.float64)
+            h = hashlib.sha256()
+            for call, (tcg, rtr, fopt, Xin, Xout) in enumerate(want[ks]):
+                Xd.copy_(torch.tensor(Xin))
+                res = opt.optimizeDevice(Xd)
+                assert res.precond_used == "multilevel" and prob.persistentInfo()["last_members"] == 0, (sw, res)
+                assert (res.tcg_iterations, res.rtr_iterations) == (tcg, rtr), (sw, call)
+                dec = abs(res.fInit - res.fOpt)
+                assert abs(res.fOpt - fopt) <= 1e-9 * abs(fopt) + 1e-4 * dec, (sw, call)
+                assert relerr(Xd.cpu().numpy(), Xout) < 1e-6, (sw, call)
+                h.update(Xd.cpu().numpy().tobytes())
+                h.update(repr((res.tcg_iterations, res.rtr_iterations, res.tCGStatus, res.fOpt, res.gradNormOpt)).encode())
+            digests[tuple(sorted(sw.items()))] = (mode, h.hexdigest())
+            if "DPGO_SPMM_SYMMETRIC" in sw and n >= 40000:
+                assert prob.tcgKernelInfo()["symmetric"] == int(sw["DPGO_SPMM_SYMMETRIC"]), sw
+            del opt, prob
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+        lib.dpgo_options_reload()
+    base = digests[()][1]
+    for key, (mode, dig) in digests.items():
+        if mode == "bitwise":
+            assert dig == base, key
 
 
 def _early_stop_case(name, r):

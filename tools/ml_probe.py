@@ -39,6 +39,7 @@ for name in (sys.argv[1:] or ["sphere", "slab", "grid100k"]):
     prob = dpgo_amd.QuadraticProblem(pg)
     for mf in (("0", "1") if os.environ.get("PROBE_SETUP") else ()):
         os.environ["DPGO_GJ_MFMA"] = mf
+        dpgo_amd.lib.load().dpgo_options_reload()  # (the library reads its switches once)
         ts = []
         for rep in range(3):
             torch.cuda.synchronize()
