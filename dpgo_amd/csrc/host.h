@@ -117,7 +117,7 @@ inline int free_bsr(Bsr& m) {
   X(spmm_symmetric,    "DPGO_SPMM_SYMMETRIC",    -1,  "symmetric storage of Q for blocks beyond the Infinity Cache: 0 / 1")          \
   X(stream_nt,         "DPGO_STREAM_NT",         -1,  "non-temporal single-use operands in the tCG-step kernels: 0 / 1")             \
   X(outer_sym,         "DPGO_OUTER_SYM",          1,  "outer RTR iteration (k_grad / k_hess) reads the symmetric copy when tCG does") \
-  X(iter_graph,        "DPGO_ITER_GRAPH",         1,  "steady tCG iterations replayed from an instantiated hipGraph")                \
+  X(iter_graph,        "DPGO_ITER_GRAPH",         0,  "steady tCG iterations replayed from an instantiated hipGraph (measured slower)") \
   X(tcg_ahead,         "DPGO_TCG_AHEAD",          0,  "iterations the just-in-time feed stays ahead (0: 2 multilevel / 4 otherwise)") \
   X(grid_update,       "DPGO_GRID_UPDATE",        0,  "launch cap of k_tcg_update (0: resident count)")                              \
   X(grid_hess,         "DPGO_GRID_HESS",          0,  "launch cap of k_tcg_hess (0: resident count)")                                \
@@ -136,6 +136,7 @@ inline int free_bsr(Bsr& m) {
   X(ml_ap,             "DPGO_ML_AP",              1,  "two-level post-smoothing through A P (0: gather through Q; index runs only)") \
   X(ml_dense_sym,      "DPGO_ML_DENSE_SYM",      -1,  "dense level from the packed lower triangle on the matrix cores: 0 / 1")       \
   X(ml_early_stop,     "DPGO_ML_EARLY_STOP",      1,  "tCG's residual test in the restriction kernel, one kernel early")             \
+  X(ml_operator_bits,  "DPGO_ML_OPERATOR_BITS",   0,  "level-0 operator copies of the cycle on HBM-bound blocks: 32 / 64 (0: 64)")   \
   X(ml_setup_serial,   "DPGO_ML_SETUP_SERIAL",    0,  "one-thread-per-aggregate set-up kernels of round 3")                          \
   X(gj_mfma,           "DPGO_GJ_MFMA",            1,  "rank-64 updates of the dense inverse on the fp64 matrix cores")               \
   X(dense_chunk,       "DPGO_DENSE_CHUNK",        0,  "tiles per workgroup of k_dense_sym_apply (0: default)")                       \
@@ -218,6 +219,7 @@ struct dpgo_problem_s {
     int perm_tile = 0;             // slots per aggregate in tile_perm
     int merge_cap = 0;             // graph aggregates: fragments merged up to this many poses (0: plain greedy growth)
     double* tbuf = nullptr;
+    float *Pb32 = nullptr, *AP32 = nullptr;  // fp32 copies of Pb and of A P's values (level 0, ml_operator_bits == 32)
     AggMap agg() const { return AggMap{graph ? lab : nullptr, k}; }
   };
   std::vector<MlLevel> ml;
@@ -253,6 +255,14 @@ struct dpgo_problem_s {
     return env == 1 || ml_lda >= 3072;  // below, the row-streaming kernel (one launch, cache-resident inverse) is as fast
   }
   int ml_coarse_bits = 64;  // 32: opt-in (dpgo_problem_multilevel_coarse_bits)
+  // Storage precision of the OPERATOR COPIES the V-cycle streams on level 0 of an HBM-bound block (symmetric storage, two
+  // levels): Q's values in the restriction's residual r - A x1, the values of A P in the post-smoothing, the prolongation
+  // blocks in both -- 32: fp32 copies beside the fp64 originals (the Hessian step, the set-up and every product and sum
+  // stay fp64; the cycle is a preconditioner).  ml_ops32_ready: the copies hold the current values.
+  int ml_operator_bits = 64;
+  bool ml_ops32_ready = false;
+  bool ml_ops32_wanted() const { return ml_operator_bits == 32 && tcg_sym && split == 1 && ml_use_ap() && sym.uvalsT != nullptr; }
+  bool ml_ops32_active() const { return ml_ops32_wanted() && ml_ops32_ready; }
   int ml_lda = 0;
   double *ml_W = nullptr, *ml_Rx = nullptr;  // Gauss-Jordan panels (setup only)
   // DPGO_PRECOND_AUTO: the multilevel cycle is currently selected.  Decided afresh at the first "auto" use after every
@@ -290,12 +300,14 @@ struct dpgo_problem_s {
     int32_t *urow = nullptr, *ucol = nullptr, *usrc = nullptr, *lrow = nullptr, *lcol = nullptr, *lslot = nullptr,
             *lsrc = nullptr;
     double* uvalsT = nullptr;
+    float* uvalsT32 = nullptr;  // fp32 copy of the values (the cycle's level-0 restriction, ml_operator_bits == 32)
     int* flag = nullptr;       // device: set by k_sym_check when a lower block is not the transpose of its upper one
     bool symbolic = false;     // pattern arrays belong to the current block pattern
     bool pattern_ok = false;   // the pattern is structurally symmetric
     bool ready = false;        // uvalsT holds the current values and they passed the symmetry check
     bool values_ok = false;
     BsrSymDev dev() const { return BsrSymDev{urow, ucol, uvalsT, lrow, lcol, lslot}; }
+    BsrSymDev32 dev32() const { return BsrSymDev32{urow, ucol, uvalsT32, lrow, lcol, lslot}; }
   } sym;
   int spmm_variant = DPGO_SPMM_AUTO;
   bool tcg_sym = false;  // the fused tCG-step kernel reads the symmetric copy (resolved before a solve / a kernel probe)
@@ -517,6 +529,7 @@ std::vector<int> ml_current_ks(const dpgo_problem_s* p);
 const dpgo_problem_s::AddPlan& additive_plan(dpgo_problem_s* p);
 int additive_split_of(const dpgo_problem_s* p);
 int ml_ensure(dpgo_problem_s* p, double shift, bool additive = false);
+int ml_ops32_ensure(dpgo_problem_s* p);
 int persist_capacity(int device);  // (two resident slots per CU; below)
 int launch_coarse_prolong(dpgo_problem_s* p, const dpgo_problem_s::MlLevel& L, const dpgo_problem_s::MlLevel& C,
                           const DevState* gate, double* xc_out = nullptr);

@@ -455,9 +455,11 @@ __device__ __forceinline__ double ld_tile(const double* __restrict__ p) {
     return *p;
   }
 }
-template <int D, int R, int SPLIT, int NT = 0>
+// VT: storage type of the block values (double; float for the reduced-precision operator copies of the multilevel cycle --
+// every product and sum stays fp64)
+template <int D, int R, int SPLIT, int NT = 0, class VT = double>
 __device__ __forceinline__ void spmm_col_pre(const RowIdx& ri, const int32_t* __restrict__ colidx,
-                                             const double* __restrict__ vals, const double* __restrict__ V, int s,
+                                             const VT* __restrict__ vals, const double* __restrict__ V, int s,
                                              int c, double (&acc)[R]) {
   constexpr int B = D + 1, T = B * R, BB = B * B, LPP = B * SPLIT;
   constexpr int NJ = (SPLIT == 1) ? 2 : 1;   // preloaded indices per lane
@@ -482,18 +484,18 @@ __device__ __forceinline__ void spmm_col_pre(const RowIdx& ri, const int32_t* __
       const bool okA = kA < deg && kA < NPRE, okB = kB < deg && kB < NPRE;
       double qa[B], qb[B], xa[T], xb[T];
       if (okA) {
-        const double* __restrict__ q = vals + (size_t)(t0 + kA) * BB + c * B;
+        const VT* __restrict__ q = vals + (size_t)(t0 + kA) * BB + c * B;
         const double* __restrict__ x = V + (size_t)jA * T;
 #pragma unroll
-        for (int kk = 0; kk < B; ++kk) qa[kk] = q[kk];
+        for (int kk = 0; kk < B; ++kk) qa[kk] = (double)q[kk];
 #pragma unroll
         for (int e = 0; e < T; ++e) xa[e] = ld_tile<NT>(x + e);
       }
       if (okB) {
-        const double* __restrict__ q = vals + (size_t)(t0 + kB) * BB + c * B;
+        const VT* __restrict__ q = vals + (size_t)(t0 + kB) * BB + c * B;
         const double* __restrict__ x = V + (size_t)jB * T;
 #pragma unroll
-        for (int kk = 0; kk < B; ++kk) qb[kk] = q[kk];
+        for (int kk = 0; kk < B; ++kk) qb[kk] = (double)q[kk];
 #pragma unroll
         for (int e = 0; e < T; ++e) xb[e] = ld_tile<NT>(x + e);
       }
@@ -518,11 +520,11 @@ __device__ __forceinline__ void spmm_col_pre(const RowIdx& ri, const int32_t* __
     const int src = (k < LPP) ? k : k - LPP;
     const int j = __shfl((NJ == 2 && k >= LPP) ? jb : ja, gbase + (src < LPP ? src : 0));
     if (k < deg && k < NPRE) {
-      const double* __restrict__ q = vals + (size_t)(t0 + k) * BB + c * B;
+      const VT* __restrict__ q = vals + (size_t)(t0 + k) * BB + c * B;
       const double* __restrict__ x = V + (size_t)j * T;
       double qk[B];
 #pragma unroll
-      for (int kk = 0; kk < B; ++kk) qk[kk] = q[kk];
+      for (int kk = 0; kk < B; ++kk) qk[kk] = (double)q[kk];
 #pragma unroll
       for (int kk = 0; kk < B; ++kk) {
 #pragma unroll
@@ -532,11 +534,11 @@ __device__ __forceinline__ void spmm_col_pre(const RowIdx& ri, const int32_t* __
   }
   for (int t = t0 + NPRE + s; t < t1; t += SPLIT) {  // rows with more than NPRE blocks
     const int j = colidx[t];
-    const double* __restrict__ q = vals + (size_t)t * BB + c * B;
+    const VT* __restrict__ q = vals + (size_t)t * BB + c * B;
     const double* __restrict__ x = V + (size_t)j * T;
     double qk[B];
 #pragma unroll
-    for (int kk = 0; kk < B; ++kk) qk[kk] = q[kk];
+    for (int kk = 0; kk < B; ++kk) qk[kk] = (double)q[kk];
 #pragma unroll
     for (int kk = 0; kk < B; ++kk) {
 #pragma unroll
@@ -552,20 +554,23 @@ __device__ __forceinline__ void spmm_col_pre(const RowIdx& ri, const int32_t* __
   }
 }
 
-template <int D, int R, int SPLIT, int NT = 0>
+template <int D, int R, int SPLIT, int NT = 0, class VT = double>
 __device__ __forceinline__ void spmm_col(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colidx,
-                                         const double* __restrict__ vals, const double* __restrict__ V,
+                                         const VT* __restrict__ vals, const double* __restrict__ V,
                                          int i, int s, int c, bool ok, double (&acc)[R]) {
   const RowIdx ri = row_idx_load<D, SPLIT>(rowptr, colidx, i, s, c, ok);
   spmm_col_pre<D, R, SPLIT, NT>(ri, colidx, vals, V, s, c, acc);
 }
 
 // ---------------------------------------------------------------- kernel arguments
-struct BsrDev {
+template <class VT>
+struct BsrDevT {
   const int32_t* rowptr;
   const int32_t* colidx;
-  const double* vals;
+  const VT* vals;
 };
+using BsrDev = BsrDevT<double>;
+using BsrDev32 = BsrDevT<float>;  // fp32 copy of the values (A P of the multilevel cycle, opt-in)
 
 // ---------------------------------------------------------------- reduce-scatter over the lanes of a pose
 // Every lane (pose, column c) holds a (D+1) x R partial acc[cc][a]; afterwards out[a] = sum over the pose's lanes of their
@@ -606,19 +611,22 @@ __device__ __forceinline__ void pose_reduce_scatter(const double (&acc)[D + 1][R
 // leaves row c of (Q V)_i in lane c.  The first (D+1) upper and lower column indices of a row are preloaded by the pose's
 // lanes and broadcast by shuffles.  One pose per (D+1) lanes (SPLIT = 1) only.  100k-pose grid, plain product: 28.4 us
 // against 36.6 us with Infinity-Cache-cold operands, 22.9 against 24.4 us warm (profiles/).
-struct BsrSymDev {
+template <class VT>
+struct BsrSymDevT {
   const int32_t* urow;   // [n + 1] upper blocks (j >= i) of every block row
   const int32_t* ucol;
-  const double* uvalsT;  // transposed blocks: uvalsT[u][p][q] = Q[i, j][q][p]
+  const VT* uvalsT;      // transposed blocks: uvalsT[u][p][q] = Q[i, j][q][p]
   const int32_t* lrow;   // [n + 1] lower references (j < i)
   const int32_t* lcol;
   const int32_t* lslot;  // upper slot of block (j, i)
 };
+using BsrSymDev = BsrSymDevT<double>;
+using BsrSymDev32 = BsrSymDevT<float>;  // fp32 copy of the values (level-0 restriction of the multilevel cycle, opt-in)
 struct SymIdx {
   int u0, du, l0, dl, ju, jl, sl;
 };
-template <int D>
-__device__ __forceinline__ SymIdx sym_idx_load(const BsrSymDev& Q, int i, int c, bool ok) {
+template <int D, class VT>
+__device__ __forceinline__ SymIdx sym_idx_load(const BsrSymDevT<VT>& Q, int i, int c, bool ok) {
   SymIdx si;
   si.u0 = ok ? Q.urow[i] : 0;
   si.du = (ok ? Q.urow[i + 1] : 0) - si.u0;
@@ -630,8 +638,8 @@ __device__ __forceinline__ SymIdx sym_idx_load(const BsrSymDev& Q, int i, int c,
   return si;
 }
 // wave-cooperative (all 64 lanes); out = row c of (Q V)_i for the lane (g, c) of pose i
-template <int D, int R>
-__device__ __forceinline__ void spmm_sym_pre(const SymIdx& si, const BsrSymDev& Q, const double* __restrict__ V, int c,
+template <int D, int R, class VT>
+__device__ __forceinline__ void spmm_sym_pre(const SymIdx& si, const BsrSymDevT<VT>& Q, const double* __restrict__ V, int c,
                                              double (&out)[R]) {
   constexpr int B = D + 1, T = B * R, BB = B * B;
   const int lane = threadIdx.x & 63, gbase = lane - c;
@@ -662,14 +670,14 @@ __device__ __forceinline__ void spmm_sym_pre(const SymIdx& si, const BsrSymDev& 
     if (k < du) {
       double q[B];
 #pragma unroll
-      for (int pp = 0; pp < B; ++pp) q[pp] = Q.uvalsT[(size_t)(u0 + k) * BB + c * B + pp];
+      for (int pp = 0; pp < B; ++pp) q[pp] = (double)Q.uvalsT[(size_t)(u0 + k) * BB + c * B + pp];
       fma_block(q, j);
     }
   }
   for (int t = u0 + B; t < u0 + du; ++t) {
     double q[B];
 #pragma unroll
-    for (int pp = 0; pp < B; ++pp) q[pp] = Q.uvalsT[(size_t)t * BB + c * B + pp];
+    for (int pp = 0; pp < B; ++pp) q[pp] = (double)Q.uvalsT[(size_t)t * BB + c * B + pp];
     fma_block(q, Q.ucol[t]);
   }
   for (int k = 0; k < ll; ++k) {  // lower references: column c of Q[i,j] = row c of Q[j,i] = strided in its storage
@@ -678,7 +686,7 @@ __device__ __forceinline__ void spmm_sym_pre(const SymIdx& si, const BsrSymDev& 
     if (k < dl) {
       double q[B];
 #pragma unroll
-      for (int pp = 0; pp < B; ++pp) q[pp] = Q.uvalsT[(size_t)sb * BB + pp * B + c];
+      for (int pp = 0; pp < B; ++pp) q[pp] = (double)Q.uvalsT[(size_t)sb * BB + pp * B + c];
       fma_block(q, j);
     }
   }
@@ -686,20 +694,20 @@ __device__ __forceinline__ void spmm_sym_pre(const SymIdx& si, const BsrSymDev& 
     double q[B];
     const size_t sb = (size_t)Q.lslot[t];
 #pragma unroll
-    for (int pp = 0; pp < B; ++pp) q[pp] = Q.uvalsT[sb * BB + pp * B + c];
+    for (int pp = 0; pp < B; ++pp) q[pp] = (double)Q.uvalsT[sb * BB + pp * B + c];
     fma_block(q, Q.lcol[t]);
   }
   pose_reduce_scatter<D, R>(acc, c, out);
 }
 
 // storage-generic row gather: h = row c of (A V)_i for the lane (g, s, c) of node i
-template <int D, int R, int SPLIT>
-__device__ __forceinline__ void q_gather(const BsrDev& A, const double* __restrict__ V, int i, int s, int c, bool okp,
+template <int D, int R, int SPLIT, class VT>
+__device__ __forceinline__ void q_gather(const BsrDevT<VT>& A, const double* __restrict__ V, int i, int s, int c, bool okp,
                                          double (&h)[R]) {
   spmm_col<D, R, SPLIT>(A.rowptr, A.colidx, A.vals, V, i, s, c, okp, h);
 }
-template <int D, int R, int SPLIT>
-__device__ __forceinline__ void q_gather(const BsrSymDev& A, const double* __restrict__ V, int i, int s, int c, bool okp,
+template <int D, int R, int SPLIT, class VT>
+__device__ __forceinline__ void q_gather(const BsrSymDevT<VT>& A, const double* __restrict__ V, int i, int s, int c, bool okp,
                                          double (&h)[R]) {
   static_assert(SPLIT == 1, "symmetric storage: one node per D+1 lanes");
   const SymIdx si = sym_idx_load<D>(A, i, c, okp);

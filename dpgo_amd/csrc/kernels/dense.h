@@ -239,6 +239,11 @@ static __global__ __launch_bounds__(kBlock) void k_sweep_finish(double* __restri
   }
 }
 
+// out[i] = (float)in[i]: the fp32 operator copies of the multilevel cycle (A P, prolongation blocks, symmetric Q)
+static __global__ __launch_bounds__(kBlock) void k_copy_f32(const double* __restrict__ in, float* __restrict__ out, size_t total) {
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (size_t)gridDim.x * kBlock) out[i] = (float)in[i];
+}
+
 // unit diagonal on the padding rows N .. lda-1 of a zero-filled lda x lda array
 static __global__ __launch_bounds__(kBlock) void k_dense_pad_identity(double* __restrict__ M, int lda, int N) {
   for (int i = N + blockIdx.x * kBlock + threadIdx.x; i < lda; i += gridDim.x * kBlock) M[(size_t)i * lda + i] = 1.0;

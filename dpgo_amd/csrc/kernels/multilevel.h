@@ -72,9 +72,10 @@ struct TcgStopCheck {
   unsigned long long* hflag = nullptr;
   unsigned gen = 0;
 };
-template <int D, int R, int SPLIT, class MAT = BsrDev>
+// PT: storage type of the prolongation blocks (float with the fp32 operator copies of the cycle, like MAT's values)
+template <int D, int R, int SPLIT, class MAT = BsrDev, class PT = double>
 __global__ __launch_bounds__(kBlock) void k_ml_restrict(MAT A, const double* __restrict__ x1,
-                                                        const double* __restrict__ r, const double* __restrict__ Pb,
+                                                        const double* __restrict__ r, const PT* __restrict__ Pb,
                                                         double shift, int k, double* __restrict__ rc,
                                                         float* __restrict__ rc32,
                                                         const double* __restrict__ dinv_next, double omega,
@@ -138,10 +139,10 @@ __global__ __launch_bounds__(kBlock) void k_ml_restrict(MAT A, const double* __r
 #pragma unroll
       for (int a = 0; a < R; ++a) t[a] = 0.0;
       if (ok) {  // row c of P_i^T res_i = sum_c' P_i[c'][c] res_i[c'][:]
-        const double* __restrict__ pb = Pb + (size_t)i * GEO::BB;
+        const PT* __restrict__ pb = Pb + (size_t)i * GEO::BB;
 #pragma unroll
         for (int cc = 0; cc < GEO::B; ++cc) {
-          const double pv = pb[cc * GEO::B + L.c];
+          const double pv = (double)pb[cc * GEO::B + L.c];
 #pragma unroll
           for (int a = 0; a < R; ++a) t[a] = fma(pv, res_s[L.wave][L.g][cc * R + a], t[a]);
         }
@@ -534,10 +535,11 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(SPLIT ==
 // AP has about half of Q's blocks and its gather reads the coarse solution (a few hundred KB: L2-resident) instead of a 16 MB
 // pose vector; x1 = w Dinv r is recomputed from r (read anyway for <r,r>, <z,r>), the prolongation x1 + P xc happens here and
 // not in the dense kernel.  Same operator as k_ml_post up to summation order.
-template <int D, int R, int SPLIT>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(SPLIT == 1 ? DPGO_POST_WAVES : 1))) void k_ml_post_ap(BsrDev AP, const double* __restrict__ X,
+// VT: storage type of A P's values and of the prolongation blocks (float: the opt-in fp32 operator copies of the cycle)
+template <int D, int R, int SPLIT, class VT = double>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(SPLIT == 1 ? DPGO_POST_WAVES : 1))) void k_ml_post_ap(BsrDevT<VT> AP, const double* __restrict__ X,
                                                        const double* __restrict__ r, const double* __restrict__ res1,
-                                                       const double* __restrict__ xc, const double* __restrict__ Pb, AggMap am,
+                                                       const double* __restrict__ xc, const VT* __restrict__ Pb, AggMap am,
                                                        const double* __restrict__ dinv, double omega,
                                                        double* __restrict__ Z, double* __restrict__ pout,
                                                        const DevState* __restrict__ gate, int n) {
@@ -580,13 +582,13 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(SPLIT ==
       double x1c[R], zc[R];
       jacobi_col<D, R>(vs, dr, x1c);  // x1 = w Dinv r
       jacobi_col<D, R>(zs, dr, zc);   // Dinv (r - A x)
-      const double* __restrict__ pb = Pb + (size_t)i * GEO::BB + L.c * GEO::B;
+      const VT* __restrict__ pb = Pb + (size_t)i * GEO::BB + L.c * GEO::B;
       const double* __restrict__ xa = xc + (size_t)am.of(i) * GEO::T;
 #pragma unroll
       for (int a = 0; a < R; ++a) xcol[a] = omega * x1c[a];
 #pragma unroll
       for (int cc = 0; cc < GEO::B; ++cc) {
-        const double pv = pb[cc];
+        const double pv = (double)pb[cc];
 #pragma unroll
         for (int a = 0; a < R; ++a) xcol[a] = fma(pv, xa[cc * R + a], xcol[a]);
       }

@@ -73,7 +73,7 @@ void ml_free(dpgo_problem_s* p) {
     free_bsr(L.A);
     free_bsr(L.AP);
     void* ptrs[] = {L.slot_row, L.dinv, L.Pb, L.r, L.x1, L.x, L.res1, L.lab, L.agg_ptr, L.agg_mem, L.parent, L.pslot, L.tbuf, L.tile_perm, L.mem_pos,
-                    L.seg_info, L.seg_ptr};
+                    L.seg_info, L.seg_ptr, L.Pb32, L.AP32};
     for (void* q : ptrs)
       if (q) (void)hipFree(q);
   }
@@ -90,6 +90,7 @@ void ml_free(dpgo_problem_s* p) {
   p->ml_nchunks = 0;
   p->ml_lda = 0;
   p->ml_symbolic = p->ml_ready = false;
+  p->ml_ops32_ready = false;
 }
 
 // Symbolic setup: level sizes, block patterns of the Galerkin operators, buffers.
@@ -512,6 +513,7 @@ int ml_numeric_setup(dpgo_problem_s* p) {
   else
     CHK(ml_numeric_setup_d<3>(p));
   p->ml_ready = true;
+  p->ml_ops32_ready = false;  // (the fp32 copies of A P and the prolongation follow at the next solve that streams them)
   return DPGO_OK;
 }
 
@@ -624,6 +626,28 @@ int ml_ensure(dpgo_problem_s* p, double shift, bool additive) {
   return ml_numeric_setup(p);
 }
 
+// The fp32 operator copies of the cycle (dpgo_problem_s::ml_operator_bits): (re)built from the fp64 originals whenever those
+// changed -- after the hierarchy's numeric set-up, after the symmetric copy of Q was refreshed -- by the first solve that
+// wants them (call after resolve_tcg_storage and ml_ensure; never inside a recorded iteration).
+int ml_ops32_ensure(dpgo_problem_s* p) {
+  if (!p->ml_ops32_wanted() || p->ml_ops32_ready) return DPGO_OK;
+  auto& L0 = p->ml[0];
+  const size_t bb = (size_t)p->b * p->b;
+  const size_t nu = (size_t)p->sym.nu * bb, nap = (size_t)L0.AP.nnzb * bb, npb = (size_t)L0.n * bb;
+  if (!p->sym.uvalsT32) HIPC(hipMalloc(&p->sym.uvalsT32, sizeof(float) * nu));
+  if (!L0.AP32) HIPC(hipMalloc(&L0.AP32, sizeof(float) * nap));
+  if (!L0.Pb32) HIPC(hipMalloc(&L0.Pb32, sizeof(float) * npb));
+  auto copy = [&](const double* in, float* out, size_t total) {
+    hipLaunchKernelGGL(k_copy_f32, dim3(flat_grid(total)), dim3(kBlock), 0, p->stream, in, out, total);
+  };
+  copy(p->sym.uvalsT, p->sym.uvalsT32, nu);
+  copy(L0.AP.vals, L0.AP32, nap);
+  copy(L0.Pb, L0.Pb32, npb);
+  HIPC(hipGetLastError());
+  p->ml_ops32_ready = true;
+  return DPGO_OK;
+}
+
 // Dense level + prolongation.  Large coarsest levels: two nodes per workgroup (halves the right-hand-side loads per
 // matrix byte); balanced rounds: every workgroup takes the same number of node groups (a ragged last round would leave
 // most of the chip idle while the dense inverse streams).
@@ -714,7 +738,11 @@ int launch_ml_restrict0(dpgo_problem_s* p, const double* r, const DevState* gate
   float* rc32 = (C.k == 0 && p->ml_coarse_bits == 32) ? reinterpret_cast<float*>(C.r) : (float*)nullptr;
   double* res_out = p->ml_use_ap() ? L.res1 : nullptr;
   const double* dnext = C.k ? C.dinv : (const double*)nullptr;
-  if (p->tcg_sym) {  // level 0 reads Q: the symmetric copy when the tCG-step kernel does
+  if (p->ml_ops32_active()) {  // ... its fp32 copy (and the prolongation's) when the handle opted in
+    DISPATCH(p->d, p->r, hipLaunchKernelGGL((k_ml_restrict<D, R, 1, BsrSymDev32, float>), dim3(g0), dim3(kBlock), 0, p->stream,
+                                            p->sym.dev32(), L.x1, r, L.Pb32, p->ml_shift, L.k, C.r, rc32, dnext, p->ml_omega,
+                                            C.x1, gate, L.n, res_out, L.tbuf, L.seg_info, stop));
+  } else if (p->tcg_sym) {  // level 0 reads Q: the symmetric copy when the tCG-step kernel does
     DISPATCH(p->d, p->r, hipLaunchKernelGGL((k_ml_restrict<D, R, 1, BsrSymDev>), dim3(g0), dim3(kBlock), 0, p->stream,
                                             p->sym.dev(), L.x1, r, L.Pb, p->ml_shift, L.k, C.r, rc32, dnext, p->ml_omega,
                                             C.x1, gate, L.n, res_out, L.tbuf, L.seg_info, stop));
@@ -732,6 +760,14 @@ int launch_ml_restrict0(dpgo_problem_s* p, const double* r, const DevState* gate
 // Level-0 post-smoothing of a two-level hierarchy through A P (k_ml_post_ap).
 int launch_ml_post_ap(dpgo_problem_s* p, const double* Xdev, const double* r, double* z, double* pout, const DevState* gate) {
   auto& L0 = p->ml[0];
+  if (p->ml_ops32_active()) {
+    const BsrDev32 ap32{L0.AP.rowptr, L0.AP.colidx, L0.AP32};
+    DISPATCH(p->d, p->r, hipLaunchKernelGGL((k_ml_post_ap<D, R, 1, float>), dim3(p->grid_post()), dim3(kBlock), 0, p->stream,
+                                            ap32, Xdev, r, L0.res1, p->ml[1].x, L0.Pb32, L0.agg(), p->dinv, p->ml_omega, z, pout,
+                                            gate, p->n));
+    HIPC(hipGetLastError());
+    return DPGO_OK;
+  }
   DISPATCH(p->d, p->r, LAUNCH_SPLIT(p, k_ml_post_ap, p->grid_post(), L0.AP.dev(), Xdev, r, L0.res1, p->ml[1].x, L0.Pb,
                                     L0.agg(), p->dinv, p->ml_omega, z, pout, gate, p->n));
   HIPC(hipGetLastError());
@@ -921,6 +957,17 @@ int dpgo_problem_multilevel_coarse_bits(dpgo_problem_t p, int* bits) {
   return DPGO_OK;
 }
 
+
+int dpgo_problem_multilevel_operator_bits(dpgo_problem_t p, int* bits, int* active) {
+  if (!p || !bits) return fail(DPGO_ERR_INVALID, "null handle / pointer");
+  if (*bits >= 0) {
+    if (*bits != 32 && *bits != 64) return fail(DPGO_ERR_INVALID, "the cycle's operator copies are stored in 32 or 64 bits");
+    p->ml_operator_bits = *bits;
+  }
+  *bits = p->ml_operator_bits;
+  if (active) *active = p->ml_ops32_active() ? 1 : 0;  // (what the last solve's cycle streamed)
+  return DPGO_OK;
+}
 
 int dpgo_problem_multilevel_info(dpgo_problem_t p, int* nlevels, int* sizes, int* ks, int* nnzb) {
   if (!p) return fail(DPGO_ERR_INVALID, "null handle");

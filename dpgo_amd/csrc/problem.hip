@@ -73,7 +73,7 @@ int push_state(dpgo_problem_s* p) {
 // ---- symmetric copy of Q (plain SpMM on cold blocks) ----
 void sym_free(dpgo_problem_s* p) {
   auto& S = p->sym;
-  void* ptrs[] = {S.urow, S.ucol, S.usrc, S.lrow, S.lcol, S.lslot, S.lsrc, S.uvalsT, S.flag};
+  void* ptrs[] = {S.urow, S.ucol, S.usrc, S.lrow, S.lcol, S.lslot, S.lsrc, S.uvalsT, S.flag, S.uvalsT32};
   for (void* q : ptrs)
     if (q) (void)hipFree(q);
   S = dpgo_problem_s::SymQ();
@@ -157,6 +157,7 @@ int sym_ensure(dpgo_problem_s* p, bool* usable) {
     HIPC(hipStreamSynchronize(p->stream));
     S.values_ok = (bad == 0);
     S.ready = true;
+    p->ml_ops32_ready = false;  // (the fp32 copy of these values is rebuilt by the next solve that streams it)
   }
   *usable = S.values_ok;
   return DPGO_OK;
@@ -342,6 +343,7 @@ int dpgo_problem_create(dpgo_problem_t* out, int r, int d, int n, int device) {
   p->split = (n < 40000) ? 4 : 1;
   if (const int v = options().split)
     if (v == 1 || v == 2 || v == 4) p->split = v;
+  if (options().ml_operator_bits == 32) p->ml_operator_bits = 32;
   int rc = [&]() -> int {
     HIPC(hipSetDevice(device));
     CHK(tune_launch_caps(p));
@@ -413,7 +415,8 @@ int dpgo_problem_describe(dpgo_problem_t p, char* out, int capacity) {
   for (size_t l = 0; l < p->ml.size(); ++l)
     s += " [" + std::to_string(p->ml[l].n) + " nodes" + (p->ml[l].k ? ", k=" + std::to_string(p->ml[l].graph ? -p->ml[l].k : p->ml[l].k) : ", dense") + "]";
   s += std::string(p->ml_ready ? " built" : " not built") + ", dense level fp" + std::to_string(p->ml_coarse_bits) +
-       (p->ml_additive_layout ? ", additive layout" : "") + "\n";
+       (p->ml_additive_layout ? ", additive layout" : "") + ", level-0 operator copies of the cycle fp" +
+       std::to_string(p->ml_operator_bits) + (p->ml_ops32_active() ? " (in use)" : "") + "\n";
   s += std::string("  iteration graphs: ") + (p->iter_graph_failed ? "unavailable" : (p->iter_graph[0].exec || p->iter_graph[1].exec ? "captured" : "none yet")) + "\n";
   s += "options:\n" + options_describe();
   return copy_text(s, out, capacity);
@@ -716,6 +719,7 @@ int dpgo_problem_precondition(dpgo_problem_t p, int precond, double shift, const
     dinv = p->dinv;
   } else if (precond == DPGO_PRECOND_MULTILEVEL) {
     CHK(ml_ensure(p, shift));
+    CHK(ml_ops32_ensure(p));
     CHK(launch_ml_apply(p, p->x2, p->eta, p->g2));
     return d2h(p, Z, p->g2);
   } else if (precond == DPGO_PRECOND_ADDITIVE) {

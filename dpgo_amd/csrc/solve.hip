@@ -312,11 +312,12 @@ unsigned long long iter_graph_key(const dpgo_problem_s* p, const double* dinv, b
   k.add((long long)p->ml_use_ap()), k.add((long long)p->ml_use_dense_sym()), k.add((long long)p->beyond_cache());
   k.add(p->ml_dense), k.add(p->ml_dense32), k.add(p->ml_packed), k.add(p->ml_pd), k.add(p->ml_pt), k.add(p->ml_chunks);
   k.add(p->ml_chunk_first), k.add((long long)p->ml_nchunks), k.add((long long)p->ml.size());
+  k.add((long long)p->ml_ops32_active()), k.add(p->sym.uvalsT32);
   for (const auto& L : p->ml) {
     k.add((long long)L.n), k.add((long long)L.k), k.add((long long)L.split), k.add((long long)L.graph), k.add((long long)L.nseg);
     key_bsr(k, L.A), key_bsr(k, L.AP);
     const void* ptrs[] = {L.slot_row, L.dinv, L.Pb, L.r, L.x1, L.x, L.res1, L.lab, L.agg_ptr, L.agg_mem, L.parent, L.pslot,
-                          L.mem_pos, L.seg_info, L.seg_ptr, L.tile_perm, L.tbuf};
+                          L.mem_pos, L.seg_info, L.seg_ptr, L.tile_perm, L.tbuf, L.Pb32, L.AP32};
     for (auto v : ptrs) k.add(v);
   }
   return k.h;
@@ -348,7 +349,11 @@ int rtr_outer_iteration(dpgo_problem_s* p, const dpgo_ropt_params* prm, const do
   // Steady iterations (j >= 1) of the just-in-time feed are replayed from an instantiated hipGraph: the launches of one
   // iteration recorded once (stream capture on the handle's private stream -- the caller's may be the legacy default
   // stream, which cannot be captured --, generation 0 = "the one in the state record") and launched into the handle's
-  // stream.  Same kernels, same arguments, same order: bit-identical iterates.  DPGO_ITER_GRAPH=0 keeps plain launches.
+  // stream.  Same kernels, same arguments, same order: bit-identical iterates.  OPT-IN (DPGO_ITER_GRAPH=1): measured on the
+  // 100k-pose grid (round 5, two interleaved repetitions) a replayed iteration is SLOWER than its six stream launches --
+  // 158.2 / 157.1 against 150.6 / 152.0 us per product -- although the boundary between two kernels INSIDE one graph is half
+  // a stream boundary (tools/launch_lab.hip: 1.6 against 3.4 us): every hipGraphLaunch of this six-node graph costs more
+  // than the five boundaries it shortens.
   const bool graph_wanted = options().iter_graph != 0, early_stop_ = options().ml_early_stop != 0;
   const bool use_graph = graph_wanted && !p->iter_graph_failed && prm->tcg_poll_interval <= 0 && max_inner > 1 && p->own_stream;
   auto replay = [&]() -> int {  // one steady iteration; DPGO_OK with *launched = false: the caller launches directly
@@ -618,6 +623,7 @@ int run_optimize(dpgo_problem_s* p, const dpgo_ropt_params* prm, dpgo_ropt_resul
       p->loop_extra_bytes = bytes;
     }
     CHK(resolve_tcg_storage(p));
+    if (prm->precond == DPGO_PRECOND_MULTILEVEL) CHK(ml_ops32_ensure(p));  // (opt-in fp32 operator copies of the cycle)
   }
   // ---- blocks in the latency regime: the whole solve is ONE persistent launch (k_rtr_persist) and one read-back.  The
   // single-iteration radius-shrink mode (:80-99) and the polling mode keep the multi-launch scheme.

@@ -87,6 +87,7 @@ SIGNATURES = {
     "dpgo_dense_spd_inverse": ([_I, _P, _P, _I, _I], _I),
     "dpgo_problem_multilevel_path": ([_P, C.POINTER(_I)], _I),
     "dpgo_problem_multilevel_coarse_bits": ([_P, C.POINTER(_I)], _I),
+    "dpgo_problem_multilevel_operator_bits": ([_P, C.POINTER(_I), C.POINTER(_I)], _I),
     "dpgo_problem_auto_state": ([_P, C.POINTER(_I)], _I),
     "dpgo_problem_auto_info": ([_P, C.POINTER(_I), C.POINTER(C.c_longlong)] + [C.POINTER(_I)] * 5, _I),
     "dpgo_auto_rule_constants": ([C.POINTER(_I)] * 4, _I),

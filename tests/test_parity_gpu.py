@@ -2349,7 +2349,8 @@ def test_multilevel_on_random_graphs_with_broken_chains(oracle, d, r, n, hub_edg
 SWITCH_SETS = [
     ({}, "baseline"),
     ({"DPGO_ML_EARLY_STOP": "0"}, "bitwise"),      # tCG's residual test back in the Hessian-step kernel's prologue
-    ({"DPGO_ITER_GRAPH": "0"}, "bitwise"),         # steady tCG iterations as plain stream launches instead of a hipGraph
+    ({"DPGO_ITER_GRAPH": "1"}, "bitwise"),         # steady tCG iterations replayed from an instantiated hipGraph
+    ({"DPGO_SPMM_SYMMETRIC": "1", "DPGO_ML_OPERATOR_BITS": "32"}, "oracle32"),  # fp32 operator copies of the cycle (sym. storage)
     ({"DPGO_SPMM_SYMMETRIC": "1"}, "oracle"),      # symmetric storage of Q: k_tcg_hess_sym, level-0 restriction / post-smoothing
     ({"DPGO_SPMM_SYMMETRIC": "1", "DPGO_OUTER_SYM": "0", "DPGO_STREAM_NT": "1"}, "oracle"),  # outer iteration on the plain copy
     ({"DPGO_SPMM_SYMMETRIC": "0", "DPGO_STREAM_NT": "1"}, "oracle"),  # plain storage with non-temporal single-use operands
@@ -2403,8 +2404,12 @@ def test_kernel_selecting_switches_match_oracle(oracle, workload):
             prob.setPersistent(False)
             opt = dpgo_amd.QuadraticOptimizer(prob, dpgo_amd.ROptParameters(precond="multilevel"))
             ks = tuple(prob.setupMultilevel()["ks"])
+            # (the fp32 operator copies exist on blocks that run the symmetric storage: there the oracle is told)
+            obits = 32 if (mode == "oracle32" and n >= 40000) else 64
+            ks = ks + ((obits,) if obits == 32 else ())
             if ks not in want:
-                op = oracle.QuadraticProblem(Q, None, r, d, precond="amg", amg_k=list(ks))
+                op = oracle.QuadraticProblem(Q, None, r, d, precond="amg", amg_k=list(ks[:-1] if obits == 32 else ks),
+                                             amg_operator_bits=obits)
                 rows, Xo = [], X0
                 for call in range(2):
                     oo = oracle.QuadraticOptimizer(op, oracle.ROptParameters(), hess_recurrence=True)
@@ -2427,6 +2432,7 @@ def test_kernel_selecting_switches_match_oracle(oracle, workload):
             digests[tuple(sorted(sw.items()))] = (mode, h.hexdigest())
             if "DPGO_SPMM_SYMMETRIC" in sw and n >= 40000:
                 assert prob.tcgKernelInfo()["symmetric"] == int(sw["DPGO_SPMM_SYMMETRIC"]), sw
+            assert prob.multilevelOperatorBits() == dict(bits=32 if mode == "oracle32" else 64, active=(obits == 32)), sw
             del opt, prob
     finally:
         for k, v in saved.items():
