@@ -98,11 +98,11 @@ def make_workload(name, r):
         X0 = synthetic.lift_tiles(synthetic.perturbed_truth(Ttrue, seed=2), r)
         return meas, n, X0, "synthetic 3-D grid %dx%dx%d (%d poses, %d edges), init = perturbed truth" % (
             nx, ny, nz, n, len(meas))
-    if name == "sphere2500":
+    if name in ("sphere2500", "torus3D"):
         from dpgo_amd.initialization import chordal_initialization
-        meas, n = dpgo_amd.read_g2o_file(os.path.join(ROOT, "data", "sphere2500.g2o"))
+        meas, n = dpgo_amd.read_g2o_file(os.path.join(ROOT, "data", name + ".g2o"))
         X0 = synthetic.lift_tiles(chordal_initialization(meas, n), r)
-        return meas, n, X0, "sphere2500.g2o (2500 poses, 4949 edges), chordal init"
+        return meas, n, X0, "%s.g2o (%d poses, %d edges), chordal init" % (name, n, len(meas))
     raise SystemExit("unknown workload %r" % name)
 
 
@@ -388,7 +388,7 @@ def secondary_single_agent(workload, r, precond, steps, warmup, settle):
                                             if ph["iterations"] > 0 else None))
 
 
-def time_to_tolerance(workload, r, precond, tol=1e-2, max_calls=12, coarse_bits=None):
+def time_to_tolerance(workload, r, precond, tol=1e-2, max_calls=12, coarse_bits=None, operator_bits=None):
     """Products-to-tolerance and time-to-gradnorm: QuadraticOptimizer::optimize (reference defaults) called from the
     initial guess until |rgrad| < tol (the local solver's own tolerance), single agent, single GPU."""
     import torch
@@ -400,6 +400,8 @@ def time_to_tolerance(workload, r, precond, tol=1e-2, max_calls=12, coarse_bits=
     ag.update()  # untimed warm-up
     if coarse_bits is not None:
         ag.problem.multilevelCoarseBits(coarse_bits)
+    if operator_bits is not None:
+        ag.problem.multilevelOperatorBits(operator_bits)
     if precond == "multilevel":
         ag.problem.setupMultilevel()  # the hierarchy is a one-time cost per Q (the reference factors inside its first solve)
     ag.problem.autoState("reset")     # "auto" starts where a fresh handle starts
@@ -443,6 +445,7 @@ def time_to_tolerance(workload, r, precond, tol=1e-2, max_calls=12, coarse_bits=
             sys.stderr.write("bench.py: hierarchy set-up timing failed: %r\n" % (exc,))
     return dict(products=products, rbcd_iterations=calls, ms=1e3 * el, gradnorm=gn, reached=bool(gn < tol),
                 us_per_product=1e6 * el / max(products, 1), preconditioners=used,
+                cycle_operator_copy_bits=(32 if ag.problem.multilevelOperatorBits()["active"] else 64) if ml_used else None,
                 hierarchy_setup_ms=setup_first, hierarchy_values_only_ms=setup_values,
                 ms_incl_setup=(1e3 * el + setup_first) if setup_first is not None else 1e3 * el)
 
@@ -739,6 +742,11 @@ def main():
         Nc = ml_info["sizes"][-1] * b_
         cbits = agent.problem.multilevelCoarseBits()
         ml_info["coarse_inverse_bits"] = cbits
+        # storage of the level-0 operator copies the cycle streams (symmetric Q in the restriction, A P in the
+        # post-smoothing, prolongation blocks): fp32 copies by default on blocks that run the symmetric storage; every
+        # product and sum is fp64.  bytes_per_launch of those two kernels below stay the ALGORITHMIC (fp64) bytes.
+        ob = agent.problem.multilevelOperatorBits()
+        ml_info["cycle_operator_copy_bits"] = 32 if ob["active"] else 64
         path = agent.problem.multilevelPath()
         ml_info["path"] = path
         two = len(ml_info["sizes"]) == 2
@@ -903,7 +911,7 @@ def main():
         # products-to-tolerance and time-to-gradnorm on this workload with both preconditioners, and the same for
         # sphere2500 (BASELINE configs[1]); then the fixed-work step rate of sphere2500
         to_tol = {}
-        for wl in ([args.workload] + (["sphere2500"] if args.workload == "grid100k" else [])):
+        for wl in ([args.workload] + (["sphere2500", "torus3D"] if args.workload == "grid100k" else [])):
             for pc in ("auto", "multilevel", "additive", "jacobi"):
                 try:  # a side measurement must never cost the main line
                     to_tol["%s/%s" % (wl, pc)] = time_to_tolerance(wl, r, pc)
@@ -913,6 +921,10 @@ def main():
                 to_tol["%s/multilevel+fp32_dense_level" % wl] = time_to_tolerance(wl, r, "multilevel", coarse_bits=32)
             except Exception as exc:  # noqa: BLE001
                 to_tol["%s/multilevel+fp32_dense_level" % wl] = {"error": repr(exc)}
+            try:  # the cycle streaming the fp64 originals of its level-0 operators instead of the default fp32 copies
+                to_tol["%s/multilevel+fp64_cycle_operators" % wl] = time_to_tolerance(wl, r, "multilevel", operator_bits=64)
+            except Exception as exc:  # noqa: BLE001
+                to_tol["%s/multilevel+fp64_cycle_operators" % wl] = {"error": repr(exc)}
         if args.workload == "grid100k":
             also = {}
             for key, pc in (("sphere2500", "auto"), ("sphere2500_multilevel", "multilevel"), ("sphere2500_jacobi", "jacobi"),
@@ -968,6 +980,10 @@ def main():
                             "1e-2, single agent, same settings)" % (tt_main["ms"], tt_main["products"]))
                            if tt_main.get("reached") else "time_to_tolerance_ms = not measured in this run"),
                        "time_to_tolerance_ms": tt_main.get("ms") if tt_main.get("reached") else None,
+                       "cycle_storage": ("all vectors, the Hessian step, smoother factors and dense level fp64; the "
+                                         "multilevel cycle streams fp%d copies of its level-0 operators (symmetric Q, A P, "
+                                         "prolongation blocks), fp64 arithmetic" % ml_info["cycle_operator_copy_bits"])
+                       if ml_info else None,
                        "hierarchy_setup_ms": tt_main.get("hierarchy_setup_ms"),
                        "time_to_tolerance_incl_setup_ms": tt_main.get("ms_incl_setup") if tt_main.get("reached") else None,
                        "products_per_step": tcg_total / max(args.steps, 1),

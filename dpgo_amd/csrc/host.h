@@ -136,7 +136,7 @@ inline int free_bsr(Bsr& m) {
   X(ml_ap,             "DPGO_ML_AP",              1,  "two-level post-smoothing through A P (0: gather through Q; index runs only)") \
   X(ml_dense_sym,      "DPGO_ML_DENSE_SYM",      -1,  "dense level from the packed lower triangle on the matrix cores: 0 / 1")       \
   X(ml_early_stop,     "DPGO_ML_EARLY_STOP",      1,  "tCG's residual test in the restriction kernel, one kernel early")             \
-  X(ml_operator_bits,  "DPGO_ML_OPERATOR_BITS",   0,  "level-0 operator copies of the cycle on HBM-bound blocks: 32 / 64 (0: 64)")   \
+  X(ml_operator_bits,  "DPGO_ML_OPERATOR_BITS",   0,  "level-0 operator copies of the cycle on HBM-bound blocks: 32 / 64 (0: 32)")   \
   X(ml_setup_serial,   "DPGO_ML_SETUP_SERIAL",    0,  "one-thread-per-aggregate set-up kernels of round 3")                          \
   X(gj_mfma,           "DPGO_GJ_MFMA",            1,  "rank-64 updates of the dense inverse on the fp64 matrix cores")               \
   X(dense_chunk,       "DPGO_DENSE_CHUNK",        0,  "tiles per workgroup of k_dense_sym_apply (0: default)")                       \
@@ -258,8 +258,10 @@ struct dpgo_problem_s {
   // Storage precision of the OPERATOR COPIES the V-cycle streams on level 0 of an HBM-bound block (symmetric storage, two
   // levels): Q's values in the restriction's residual r - A x1, the values of A P in the post-smoothing, the prolongation
   // blocks in both -- 32: fp32 copies beside the fp64 originals (the Hessian step, the set-up and every product and sum
-  // stay fp64; the cycle is a preconditioner).  ml_ops32_ready: the copies hold the current values.
-  int ml_operator_bits = 64;
+  // stay fp64; the cycle is a preconditioner).  DEFAULT since round 5 (100k poses: restriction 34.1 -> 29.2 us, post-smoothing
+  // 25.7 -> 23.9 us, 152 -> 148 us per product, same product counts; 64 restores the fp64 originals).  ml_ops32_ready: the
+  // copies hold the current values.
+  int ml_operator_bits = 32;
   bool ml_ops32_ready = false;
   bool ml_ops32_wanted() const { return ml_operator_bits == 32 && tcg_sym && split == 1 && ml_use_ap() && sym.uvalsT != nullptr; }
   bool ml_ops32_active() const { return ml_ops32_wanted() && ml_ops32_ready; }

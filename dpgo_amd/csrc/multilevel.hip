@@ -30,9 +30,13 @@ int ml_default_graph_size(int n, int b) {
 // poses in 3-D) grow them to S = ceil(n (d+1) / 2 200) instead and MERGE the growth's fragments up to 3 S / 2
 // (ml_merge_small_aggregates): the aggregates come out uniform (mean ~ S instead of ~0.55 S with a tail of fragments), the
 // same coarse-space quality needs a quarter fewer of them -- 100k poses: 546 aggregates / 70 products to |rgrad| < 1e-2
-// against 732 / 77, a dense level of 38 MB instead of 69 MB; 25k: 536 / 87 against 589 / 93 (oracle, round 4).  Smaller
-// blocks keep the plain growth (same product counts either way; their hierarchies are what the committed vectors pin).
-constexpr int kMlMergeFrom = 64, kMlMergedUnknownsPerPose = 2200;
+// against 732 / 77, a dense level of 38 MB instead of 69 MB; 25k: 536 / 87 against 589 / 93 (oracle, round 4).  Round 5:
+// from a plain growth size of 12 on (n (d+1) > ~17 600 unknowns: >= 4 400 poses in 3-D) -- torus3D 38 -> 35 products
+// (exact factor: 22; S = 6 / cap 9: 29 with 814 aggregates, S = 4 / cap 6: 28 with 1 215 aggregates = a dense level of 4 860
+// unknowns, 189 MB, whose stream costs what the ten products save), 6 250-pose grid 50 -> 42, 12 500-pose slab 140 -> ~105
+// (oracle, tools/balanced_aggregates_experiment.py ... vcycle).  Smaller blocks keep the plain growth (sphere2500: 364 aggregates / 32 products against 417 / 49 merged;
+// their hierarchies are what the committed vectors pin).
+constexpr int kMlMergeFrom = 12, kMlMergedUnknownsPerPose = 2200;
 std::vector<int> ml_default_ks(int n, int b, int split0) {
   if (const int S = ml_default_graph_size(n, b)) {
     const bool forced = options().ml_graph_size >= 2;

@@ -343,7 +343,7 @@ int dpgo_problem_create(dpgo_problem_t* out, int r, int d, int n, int device) {
   p->split = (n < 40000) ? 4 : 1;
   if (const int v = options().split)
     if (v == 1 || v == 2 || v == 4) p->split = v;
-  if (options().ml_operator_bits == 32) p->ml_operator_bits = 32;
+  if (options().ml_operator_bits == 64) p->ml_operator_bits = 64;
   int rc = [&]() -> int {
     HIPC(hipSetDevice(device));
     CHK(tune_launch_caps(p));

@@ -393,7 +393,7 @@ AMG_DENSE, AMG_DENSE_MAX = 3200, 6400  # unknowns of the dense coarsest operator
 
 
 AMG_GRAPH_MAX, AMG_GRAPH_UNKNOWNS_PER_POSE = 512, 1600
-AMG_MERGE_FROM, AMG_MERGED_UNKNOWNS_PER_POSE = 64, 2200  # mirrors kMlMergeFrom / kMlMergedUnknownsPerPose
+AMG_MERGE_FROM, AMG_MERGED_UNKNOWNS_PER_POSE = 12, 2200  # mirrors kMlMergeFrom / kMlMergedUnknownsPerPose
 
 
 def amg_default_graph_size(n: int, b: int) -> int:
@@ -545,7 +545,7 @@ def amg_default_ks(n: int, b: int, split0: Optional[int] = None) -> List[int]:
     unknowns, AMG_DENSE_MAX if that is what it takes to get there in one coarsening; otherwise one more level."""
     S = amg_default_graph_size(n, b)
     if S:
-        # (blocks of >= ~100 000 unknowns: aggregates grown to ceil(n b / 2 200) poses, fragments merged up to 3/2 of that)
+        # (blocks beyond ~17 600 unknowns: aggregates grown to ceil(n b / 2 200) poses, fragments merged up to 3/2 of that)
         if S >= AMG_MERGE_FROM and "DPGO_ML_GRAPH_SIZE" not in os.environ:
             Sm = -(-(n * b) // AMG_MERGED_UNKNOWNS_PER_POSE)
             if Sm + Sm // 2 <= AMG_GRAPH_MAX:

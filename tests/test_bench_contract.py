@@ -98,8 +98,11 @@ def test_bench_prints_one_valid_json_line():
     assert port["cores"] == 1 and port["value"] > 0 and port["rel_diff_fOpt_vs_device"] < 1e-6
     tt = j["quality"]["to_tolerance"]
     assert set(tt) == {"grid:12x10x6/auto", "grid:12x10x6/multilevel", "grid:12x10x6/additive", "grid:12x10x6/jacobi",
-                       "grid:12x10x6/multilevel+fp32_dense_level"}  # the last: opt-in storage mode, beside the headline
-    assert rf["multilevel"]["coarse_inverse_bits"] == 64  # the headline configuration keeps everything in fp64
+                       "grid:12x10x6/multilevel+fp32_dense_level",   # opt-in storage mode, beside the headline
+                       "grid:12x10x6/multilevel+fp64_cycle_operators"}  # (the default's fp32 operator copies switched off)
+    assert rf["multilevel"]["coarse_inverse_bits"] == 64  # the dense level of the headline configuration is fp64
+    # the cycle's operator copies: fp32 only where the symmetric storage runs (blocks beyond the Infinity Cache), named in config
+    assert rf["multilevel"]["cycle_operator_copy_bits"] == 64 and "fp64 copies" in j["config"]["cycle_storage"]
     assert all("products" in v for v in tt.values())
 
 

@@ -732,7 +732,11 @@ def test_whole_solve_at_full_size_matches_oracle(oracle, storage):
             # (the default: two levels, graph aggregates grown to 182 poses with the fragments merged up to 273: 546 of them,
             # a dense level of about 2 200 unknowns)
             assert info["ks"] == [-182, -273] and info["sizes"][0] == 100000 and 400 <= info["sizes"][1] <= 900
-            op = oracle.QuadraticProblem(Q, None, r, d, precond="amg", amg_k=info["ks"], amg_coarse_bits=bits)
+            # (on the symmetric storage the cycle streams fp32 copies of its level-0 operators by default: mirrored)
+            obits = prob.multilevelOperatorBits()["bits"] if storage == "symmetric" else 64
+            assert obits == (32 if storage == "symmetric" else 64)
+            op = oracle.QuadraticProblem(Q, None, r, d, precond="amg", amg_k=info["ks"], amg_coarse_bits=bits,
+                                         amg_operator_bits=obits)
             if bits == 32:  # both sides run with the SAME stored inverse (see _hierarchy_check)
                 inv = prob.multilevelGet(1, "inverse")
                 assert relerr(inv, op.amg_setup()["AcInv"]) < 1e-7
@@ -757,6 +761,8 @@ def test_whole_solve_at_full_size_matches_oracle(oracle, storage):
             # 150 CG steps on 400 000 unknowns leave 1.5e-7 between two summation orders in the iterate
             assert relerr(Xd.cpu().numpy(), Xo) < (1e-6 if dec < 1e-4 * abs(want[2]) else 1e-4), (precond, it)
             total += res.tcg_iterations
+        if precond == "multilevel":
+            assert prob.multilevelOperatorBits()["active"] == (storage == "symmetric")
         assert total > 40  # the calls reach the regime in which the tCG budget is actually used
 
 
@@ -2350,7 +2356,7 @@ SWITCH_SETS = [
     ({}, "baseline"),
     ({"DPGO_ML_EARLY_STOP": "0"}, "bitwise"),      # tCG's residual test back in the Hessian-step kernel's prologue
     ({"DPGO_ITER_GRAPH": "1"}, "bitwise"),         # steady tCG iterations replayed from an instantiated hipGraph
-    ({"DPGO_SPMM_SYMMETRIC": "1", "DPGO_ML_OPERATOR_BITS": "32"}, "oracle32"),  # fp32 operator copies of the cycle (sym. storage)
+    ({"DPGO_SPMM_SYMMETRIC": "1", "DPGO_ML_OPERATOR_BITS": "64"}, "oracle"),  # the cycle streams the fp64 operators (sym. storage)
     ({"DPGO_SPMM_SYMMETRIC": "1"}, "oracle"),      # symmetric storage of Q: k_tcg_hess_sym, level-0 restriction / post-smoothing
     ({"DPGO_SPMM_SYMMETRIC": "1", "DPGO_OUTER_SYM": "0", "DPGO_STREAM_NT": "1"}, "oracle"),  # outer iteration on the plain copy
     ({"DPGO_SPMM_SYMMETRIC": "0", "DPGO_STREAM_NT": "1"}, "oracle"),  # plain storage with non-temporal single-use operands
@@ -2404,8 +2410,10 @@ def test_kernel_selecting_switches_match_oracle(oracle, workload):
             prob.setPersistent(False)
             opt = dpgo_amd.QuadraticOptimizer(prob, dpgo_amd.ROptParameters(precond="multilevel"))
             ks = tuple(prob.setupMultilevel()["ks"])
-            # (the fp32 operator copies exist on blocks that run the symmetric storage: there the oracle is told)
-            obits = 32 if (mode == "oracle32" and n >= 40000) else 64
+            # (the cycle of a block that runs the symmetric storage streams fp32 copies of its level-0 operators unless told
+            # otherwise: the oracle mirrors the storage, amg_operator_bits)
+            want_bits = 64 if sw.get("DPGO_ML_OPERATOR_BITS") == "64" else 32
+            obits = want_bits if (sw.get("DPGO_SPMM_SYMMETRIC") == "1" and n >= 40000) else 64
             ks = ks + ((obits,) if obits == 32 else ())
             if ks not in want:
                 op = oracle.QuadraticProblem(Q, None, r, d, precond="amg", amg_k=list(ks[:-1] if obits == 32 else ks),
@@ -2432,7 +2440,7 @@ def test_kernel_selecting_switches_match_oracle(oracle, workload):
             digests[tuple(sorted(sw.items()))] = (mode, h.hexdigest())
             if "DPGO_SPMM_SYMMETRIC" in sw and n >= 40000:
                 assert prob.tcgKernelInfo()["symmetric"] == int(sw["DPGO_SPMM_SYMMETRIC"]), sw
-            assert prob.multilevelOperatorBits() == dict(bits=32 if mode == "oracle32" else 64, active=(obits == 32)), sw
+            assert prob.multilevelOperatorBits() == dict(bits=want_bits, active=(obits == 32)), sw
             del opt, prob
     finally:
         for k, v in saved.items():
