@@ -160,7 +160,7 @@ int bench_spmm_sym_rotating(dpgo_problem_s* p, int nsets, int reps, int warmup, 
   }
   auto launch = [&](int i) {
     const Set& st = sets[i % nsets];
-    return launch_spmm_sym(p, BsrSymDev{S.urow, st.uc, st.v, S.lrow, st.lc, st.ls}, st.x, nullptr, st.o);
+    return launch_spmm_sym(p, BsrSymDev{S.urow, st.uc, st.v, S.lrow, st.lc, st.ls, S.tord}, st.x, nullptr, st.o);
   };
   hipEvent_t e0, e1;
   (void)hipEventCreate(&e0);

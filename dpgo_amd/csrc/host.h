@@ -117,6 +117,7 @@ inline int free_bsr(Bsr& m) {
   X(spmm_symmetric,    "DPGO_SPMM_SYMMETRIC",    -1,  "symmetric storage of Q for blocks beyond the Infinity Cache: 0 / 1")          \
   X(stream_nt,         "DPGO_STREAM_NT",         -1,  "non-temporal single-use operands in the tCG-step kernels: 0 / 1")             \
   X(outer_sym,         "DPGO_OUTER_SYM",          1,  "outer RTR iteration (k_grad / k_hess) reads the symmetric copy when tCG does") \
+  X(tile_walk,         "DPGO_TILE_WALK",          1,  "symmetric-storage kernels walk each XCD's tiles breadth-first over the tile graph (0: index order)") \
   X(iter_graph,        "DPGO_ITER_GRAPH",         0,  "steady tCG iterations replayed from an instantiated hipGraph (measured slower)") \
   X(tcg_ahead,         "DPGO_TCG_AHEAD",          0,  "iterations the just-in-time feed stays ahead (0: 2 multilevel / 4 otherwise)") \
   X(grid_update,       "DPGO_GRID_UPDATE",        0,  "launch cap of k_tcg_update (0: resident count)")                              \
@@ -303,13 +304,14 @@ struct dpgo_problem_s {
             *lsrc = nullptr;
     double* uvalsT = nullptr;
     float* uvalsT32 = nullptr;  // fp32 copy of the values (the cycle's level-0 restriction, ml_operator_bits == 32)
+    int32_t* tord = nullptr;    // walk over the workgroup tiles (BsrSymDevT::tord; NULL: index order)
     int* flag = nullptr;       // device: set by k_sym_check when a lower block is not the transpose of its upper one
     bool symbolic = false;     // pattern arrays belong to the current block pattern
     bool pattern_ok = false;   // the pattern is structurally symmetric
     bool ready = false;        // uvalsT holds the current values and they passed the symmetry check
     bool values_ok = false;
-    BsrSymDev dev() const { return BsrSymDev{urow, ucol, uvalsT, lrow, lcol, lslot}; }
-    BsrSymDev32 dev32() const { return BsrSymDev32{urow, ucol, uvalsT32, lrow, lcol, lslot}; }
+    BsrSymDev dev() const { return BsrSymDev{urow, ucol, uvalsT, lrow, lcol, lslot, tord}; }
+    BsrSymDev32 dev32() const { return BsrSymDev32{urow, ucol, uvalsT32, lrow, lcol, lslot, tord}; }
   } sym;
   int spmm_variant = DPGO_SPMM_AUTO;
   bool tcg_sym = false;  // the fused tCG-step kernel reads the symmetric copy (resolved before a solve / a kernel probe)

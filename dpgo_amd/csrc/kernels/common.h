@@ -619,7 +619,17 @@ struct BsrSymDevT {
   const int32_t* lrow;   // [n + 1] lower references (j < i)
   const int32_t* lcol;
   const int32_t* lslot;  // upper slot of block (j, i)
+  // The WALK over the workgroup tiles (NULL: index order): tord[k] = the tile processed k-th, a permutation INSIDE each XCD's
+  // contiguous eighth (tile_iter): breadth-first over the tile graph, so that the tiles one XCD processes at the same time
+  // are graph neighbours -- a row's lower references and the z tiles it gathers are then in flight in the same L2 instead
+  // of being fetched once per round (host: sym_symbolic_setup; the pose order, i.e. the data layout, is untouched).
+  const int32_t* tord;
 };
+// the k-th tile of a kernel's walk over storage A
+template <class VT>
+__device__ __forceinline__ int tile_of(const BsrDevT<VT>&, int k) { return k; }
+template <class VT>
+__device__ __forceinline__ int tile_of(const BsrSymDevT<VT>& A, int k) { return A.tord ? A.tord[k] : k; }
 using BsrSymDev = BsrSymDevT<double>;
 using BsrSymDev32 = BsrSymDevT<float>;  // fp32 copy of the values (level-0 restriction of the multilevel cycle, opt-in)
 struct SymIdx {

@@ -115,7 +115,8 @@ __global__ __launch_bounds__(kBlock) void k_ml_restrict(MAT A, const double* __r
     }
     __syncthreads();  // (t_s is reused by the tiles below)
   }
-  for (int tile = ti_.first; tile < ti_.last; tile += ti_.step) {
+  for (int tk = ti_.first; tk < ti_.last; tk += ti_.step) {
+    const int tile = tile_of(A, tk);
     const int lp = L.wave * GEO::G + L.g;  // node slot inside the workgroup tile
     const int i = tile * GEO::P + lp;
     const bool okp = (L.g < GEO::G) && (i < n);
@@ -487,7 +488,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(SPLIT ==
   const int ntiles = (n + GEO::P - 1) / GEO::P;
   const TileIter ti_ = tile_iter(ntiles);
   double part[2] = {0.0, 0.0};
-  for (int tile = ti_.first; tile < ti_.last; tile += ti_.step) {
+  for (int tk = ti_.first; tk < ti_.last; tk += ti_.step) {
+    const int tile = tile_of(Q, tk);
     const int i = tile * GEO::P + L.wave * GEO::G + L.g;
     const bool okp = (L.g < GEO::G) && (i < n);
     const bool ok = okp && (L.s == 0);

@@ -39,7 +39,8 @@ __global__ __launch_bounds__(kBlock) void k_spmm_sym(BsrSymDev Q, const double* 
   const LaneId L = lane_id<D, 1>();
   const int ntiles = (n + GEO::P - 1) / GEO::P;
   const TileIter ti_ = tile_iter(ntiles);
-  for (int tile = ti_.first; tile < ti_.last; tile += ti_.step) {
+  for (int tk = ti_.first; tk < ti_.last; tk += ti_.step) {
+    const int tile = tile_of(Q, tk);
     const int i = tile * GEO::P + L.wave * GEO::G + L.g;
     const bool ok = (L.g < GEO::G) && (i < n);
     const SymIdx si = sym_idx_load<D>(Q, i, L.c, ok);
@@ -103,7 +104,8 @@ __global__ __launch_bounds__(kBlock) void k_grad(MAT Q, const double* __restrict
   const int ntiles = (n + GEO::P - 1) / GEO::P;
   double part[3] = {0.0, 0.0, 0.0};
   const TileIter ti_ = tile_iter(ntiles);
-  for (int tile = ti_.first; tile < ti_.last; tile += ti_.step) {
+  for (int tk = ti_.first; tk < ti_.last; tk += ti_.step) {
+    const int tile = tile_of(Q, tk);
     const int i = tile * GEO::P + L.wave * GEO::G + L.g;
     const bool okp = (L.g < GEO::G) && (i < n);
     const bool ok = okp && (L.s == 0);
@@ -167,7 +169,8 @@ __global__ __launch_bounds__(kBlock) void k_hess(MAT Q, const double* __restrict
   const int ntiles = (n + GEO::P - 1) / GEO::P;
   double part[2] = {0.0, 0.0};
   const TileIter ti_ = tile_iter(ntiles);
-  for (int tile = ti_.first; tile < ti_.last; tile += ti_.step) {
+  for (int tk = ti_.first; tk < ti_.last; tk += ti_.step) {
+    const int tile = tile_of(Q, tk);
     const int i = tile * GEO::P + L.wave * GEO::G + L.g;
     const bool okp = (L.g < GEO::G) && (i < n);
     const bool ok = okp && (L.s == 0);

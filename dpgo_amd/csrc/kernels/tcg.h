@@ -390,7 +390,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(DPGO_SYM
   double srow[D];
   int p0 = 0, valid = 0, i = 0;
   bool okp = false, ok = false;
-  auto prefetch = [&](int tile) {
+  auto prefetch = [&](int tk) {
+    const int tile = tile_of(Q, tk);  // (the walk over the tiles: BsrSymDevT::tord)
     p0 = tile * GEO::P + L.wave * GEO::G;
     const int npose = (n - p0) < GEO::G ? (n - p0) : GEO::G;
     valid = npose > 0 ? npose * GEO::T : 0;

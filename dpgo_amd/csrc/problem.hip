@@ -73,7 +73,7 @@ int push_state(dpgo_problem_s* p) {
 // ---- symmetric copy of Q (plain SpMM on cold blocks) ----
 void sym_free(dpgo_problem_s* p) {
   auto& S = p->sym;
-  void* ptrs[] = {S.urow, S.ucol, S.usrc, S.lrow, S.lcol, S.lslot, S.lsrc, S.uvalsT, S.flag, S.uvalsT32};
+  void* ptrs[] = {S.urow, S.ucol, S.usrc, S.lrow, S.lcol, S.lslot, S.lsrc, S.uvalsT, S.flag, S.uvalsT32, S.tord};
   for (void* q : ptrs)
     if (q) (void)hipFree(q);
   S = dpgo_problem_s::SymQ();
@@ -127,6 +127,55 @@ int sym_symbolic_setup(dpgo_problem_s* p) {
   CHK(sym_upload(&S.lsrc, lsrc, p->stream));
   HIPC(hipMalloc(&S.uvalsT, sizeof(double) * (size_t)std::max(1, S.nu) * p->b * p->b));
   HIPC(hipMalloc(&S.flag, sizeof(int)));
+  if (options().tile_walk != 0) {
+    // The walk over the workgroup tiles of the symmetric-storage kernels (BsrSymDevT::tord).  tile_iter gives XCD x the
+    // contiguous eighth [T x / 8, T (x + 1) / 8) of the T tiles and its workgroups walk it with a stride of their count, so
+    // the tiles one XCD has in flight together are ~96 CONSECUTIVE positions of its eighth.  In index order those are 2.5
+    // lattice layers of the 100k grid: the z-neighbours (+-2 500 poses = 39 tiles) of 40 % of the rows belong to another
+    // round -- their z tiles and the upper blocks their lower references point to are fetched again (PMC: 1.18x the
+    // stored bytes, rounds 2-4).  Breadth-first order over the tile graph inside each eighth makes consecutive positions
+    // graph neighbours (on the lattice: all layers of a strip of rows before the next strip); the pose order -- the data
+    // layout, the odometry runs the span loads rely on -- is untouched (round 4's pose renumbering lost exactly there).
+    const int P = (64 / p->b) * kWaves, T = (n + P - 1) / P;
+    if (T >= 16) {
+      std::vector<std::vector<int32_t>> adj(T);
+      for (int i = 0; i < n; ++i) {
+        const int ti = i / P;
+        for (int t = rp[i]; t < rp[i + 1]; ++t) {
+          const int tj = ci[t] / P;
+          if (tj != ti && (adj[ti].empty() || adj[ti].back() != tj)) adj[ti].push_back(tj);
+        }
+      }
+      for (auto& a : adj) {
+        std::sort(a.begin(), a.end());
+        a.erase(std::unique(a.begin(), a.end()), a.end());
+      }
+      std::vector<int32_t> order;
+      order.reserve(T);
+      std::vector<char> seen(T, 0);
+      for (int x = 0; x < 8; ++x) {
+        const int lo = (int)(((long long)T * x) >> 3), hi = (int)(((long long)T * (x + 1)) >> 3);
+        for (int seed = lo; seed < hi; ++seed) {  // (components in index order; one on a connected share)
+          if (seen[seed]) continue;
+          size_t head = order.size();
+          order.push_back(seed);
+          seen[seed] = 1;
+          while (head < order.size()) {
+            const int u = order[head++];
+            for (int v : adj[u])
+              if (v >= lo && v < hi && !seen[v]) {
+                seen[v] = 1;
+                order.push_back(v);
+              }
+          }
+        }
+      }
+      if ((int)order.size() == T) {
+        CHK(sym_upload(&S.tord, order, p->stream));
+        HIPC(hipStreamSynchronize(p->stream));  // (`order` goes out of scope)
+      }
+    }
+  }
   HIPC(hipStreamSynchronize(p->stream));  // the host vectors go out of scope
   S.pattern_ok = true;
   return DPGO_OK;

@@ -2359,6 +2359,7 @@ SWITCH_SETS = [
     ({"DPGO_SPMM_SYMMETRIC": "1", "DPGO_ML_OPERATOR_BITS": "64"}, "oracle"),  # the cycle streams the fp64 operators (sym. storage)
     ({"DPGO_SPMM_SYMMETRIC": "1"}, "oracle"),      # symmetric storage of Q: k_tcg_hess_sym, level-0 restriction / post-smoothing
     ({"DPGO_SPMM_SYMMETRIC": "1", "DPGO_OUTER_SYM": "0", "DPGO_STREAM_NT": "1"}, "oracle"),  # outer iteration on the plain copy
+    ({"DPGO_SPMM_SYMMETRIC": "1", "DPGO_TILE_WALK": "0"}, "oracle"),  # symmetric-storage kernels walk their tiles in index order
     ({"DPGO_SPMM_SYMMETRIC": "0", "DPGO_STREAM_NT": "1"}, "oracle"),  # plain storage with non-temporal single-use operands
     ({"DPGO_ML_GRAPH": "0"}, "oracle"),            # index-run hierarchy (k_ml_post_ap on runs, in-workgroup restriction sums)
     ({"DPGO_ML_GRAPH": "0", "DPGO_ML_AP": "0"}, "oracle"),  # ... post-smoothing gathers through Q (k_ml_post)
