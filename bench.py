@@ -627,6 +627,8 @@ def main():
         elapsed = float(t.item())
     exchange_ms = sum(e0.elapsed_time(e1) for e0, e1 in ex_events)
     cluster.exchange = _exchange
+    # (what the timed steps' cycles streamed: asked NOW -- the probes below set the hierarchy up again)
+    ops_active = bool(agent.problem.multilevelOperatorBits()["active"])
     f1, g1 = cluster.central_cost_and_gradnorm()
 
     # ---- dominant-kernel roofline, measured live with HIP events on the solver's stream ----
@@ -745,8 +747,7 @@ def main():
         # storage of the level-0 operator copies the cycle streams (symmetric Q in the restriction, A P in the
         # post-smoothing, prolongation blocks): fp32 copies by default on blocks that run the symmetric storage; every
         # product and sum is fp64.  bytes_per_launch of those two kernels below stay the ALGORITHMIC (fp64) bytes.
-        ob = agent.problem.multilevelOperatorBits()
-        ml_info["cycle_operator_copy_bits"] = 32 if ob["active"] else 64
+        ml_info["cycle_operator_copy_bits"] = 32 if ops_active else 64
         path = agent.problem.multilevelPath()
         ml_info["path"] = path
         two = len(ml_info["sizes"]) == 2
