@@ -524,3 +524,66 @@ def test_locality_order_is_a_block_preserving_permutation_that_shortens_the_gath
     f2 = O.QuadraticProblem(O.construct_Q(n, 3, om2), None, 5, 3).f(X2)
     assert abs(f1 - f2) <= 1e-12 * abs(f1)
 
+
+
+def test_switches_are_one_table_read_once_and_the_auto_rule_is_restated(oracle):
+    """Host-only pieces of round 5.  (1) Every DPGO_* switch lives in one table (csrc/host.h, DPGO_OPTIONS):
+    dpgo_describe_options lists them with their values, the environment is read once and again on
+    dpgo_options_reload.  (2) The constants of DPGO_PRECOND_AUTO's cost rule (dpgo_auto_rule_constants) are the ones
+    the oracle's restatement (AutoCostRule) defaults to, and the restatement behaves as documented: block-Jacobi until
+    one set-up is paid, one additive solve on trial, hand-back with a doubled wait when it is no cheaper, 15 % of
+    hysteresis once accepted, no trial that cannot win."""
+    import ctypes as C
+    import dpgo_amd.lib as L
+    lib = L.load()
+    text = L.describe_options()
+    rows = dict(ln.split("  # ")[0].split("=", 1) for ln in text.strip().splitlines())
+    for name in ("DPGO_SPLIT", "DPGO_SPMM_SYMMETRIC", "DPGO_ITER_GRAPH", "DPGO_ML_OPERATOR_BITS", "DPGO_TILE_WALK",
+                 "DPGO_AUTO_COST_RULE", "DPGO_ML_EARLY_STOP", "DPGO_OUTER_SYM", "DPGO_ML_GRAPH", "DPGO_PERSIST"):
+        assert name in rows, name
+    assert len(rows) >= 30 and all("[set]" not in v for k, v in rows.items() if k not in os.environ)
+    old = os.environ.get("DPGO_TCG_AHEAD")
+    try:
+        os.environ["DPGO_TCG_AHEAD"] = "7"
+        assert "DPGO_TCG_AHEAD=7 [set]" not in L.describe_options()  # read once ...
+        L.check(lib.dpgo_options_reload())
+        assert "DPGO_TCG_AHEAD=7 [set]" in L.describe_options()     # ... until told to look again
+    finally:
+        if old is None:
+            os.environ.pop("DPGO_TCG_AHEAD", None)
+        else:
+            os.environ["DPGO_TCG_AHEAD"] = old
+        lib.dpgo_options_reload()
+    k = [C.c_int(0) for _ in range(4)]
+    L.check(lib.dpgo_auto_rule_constants(*[C.byref(x) for x in k]))
+    uj, ua, setup, minp = (x.value for x in k)
+    r = oracle.AutoCostRule()
+    assert (r.uj, r.ua, r.setup, r.minp, r.uj0) == (uj, ua, setup, minp, uj) == (10, 18, 2800, 6, 10)
+    # 36 products per block-Jacobi solve: the set-up is paid after 8 solves (8 x 360 = 2 880 units)
+    seq = []
+    for _ in range(8):
+        seq.append(r.next())
+        r.record(36)
+    assert seq == ["jacobi"] * 8 and r.next() == "additive" and r.state == 1 and r.ref == 36
+    r.record(20)  # 20 x 18 = 360 >= 36 x 10: no cheaper -> handed back, the next trial waits for two set-ups
+    assert r.next() == "jacobi" and r.backoff == 1 and r.units == 0
+    for _ in range(16):
+        r.record(36)
+    assert r.next() == "additive"
+    r.record(19)  # 342 < 360: accepted
+    assert r.state == 2 and r.next() == "additive"
+    r.record(22)  # 396 < 1.15 x 360 = 414: stays (hysteresis)
+    assert r.next() == "additive"
+    r.record(24)  # 432 >= 414: handed back
+    assert r.next() == "jacobi" and r.backoff == 2
+    # a handle that shares the device is charged for the part of the chip its launch blocks: a trial that cannot win is skipped
+    s = oracle.AutoCostRule(units_jacobi=24, units_additive=65)
+    for _ in range(8):
+        s.record(36)
+    assert s.next() == "additive" and s.switches == 1  # (65 x 6 = 390 < 24 x 36 = 864: the trial can win, so it runs)
+    s.record(20)                                       # 65 x 20 = 1 300 >= 864: it did not
+    assert s.next() == "jacobi" and s.backoff == 1
+    t = oracle.AutoCostRule(units_jacobi=24, units_additive=65)
+    for _ in range(19):
+        t.record(15)                                   # 19 x 150 = 2 850 units: paid -- but 65 x 6 >= 24 x 15 = 360
+    assert t.next() == "jacobi" and t.backoff == 1 and t.switches == 0 and t.units == 0
