@@ -458,6 +458,34 @@ class QuadraticProblem {
     check(dpgo_problem_multilevel_coarse_bits(h_, &bits));
     return bits;
   }
+  // Storage of the level-0 operator copies the V-cycle streams on HBM-bound blocks (32 bits by default, 64 = the fp64
+  // originals; dpgo_problem_multilevel_operator_bits).  *active: the last solve's cycle streamed the fp32 copies.
+  int multilevelOperatorBits(int bits = -1, bool* active = nullptr) {
+    int act = 0;
+    check(dpgo_problem_multilevel_operator_bits(h_, &bits, &act));
+    if (active) *active = act != 0;
+    return bits;
+  }
+  // Where the cost rule of DPGO_PRECOND_AUTO stands on this handle (dpgo_problem_auto_info): what a coupled block the
+  // additive one-launch solve can hold is running and why.
+  struct AutoInfo {
+    int state = 0;  // 0 block-Jacobi, 1 additive on trial, 2 additive
+    long long jacobi_units = 0;
+    int reference_products = 0, switches = 0, backoff = 0, units_jacobi = 0, units_additive = 0;
+  };
+  AutoInfo autoInfo() {
+    AutoInfo a;
+    check(dpgo_problem_auto_info(h_, &a.state, &a.jacobi_units, &a.reference_products, &a.switches, &a.backoff,
+                                 &a.units_jacobi, &a.units_additive));
+    return a;
+  }
+  // What this handle currently runs and the library's DPGO_* switches, as text (dpgo_problem_describe).
+  std::string describe() {
+    std::string out(32768, '\0');
+    check(dpgo_problem_describe(h_, &out[0], (int)out.size()));
+    out.resize(std::strlen(out.c_str()));
+    return out;
+  }
   int multilevelPath() {  // DPGO_ML_PATH_* flags of the kernels a cycle of the current hierarchy runs
     int flags = 0;
     check(dpgo_problem_multilevel_path(h_, &flags));

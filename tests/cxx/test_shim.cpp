@@ -322,6 +322,10 @@ static int run() {
   for (int pc : {DPGO_PRECOND_BLOCK_JACOBI, DPGO_PRECOND_MULTILEVEL}) {
     if (pc == DPGO_PRECOND_MULTILEVEL) {
       REQUIRE(problem.multilevelCoarseBits() == 64);  // storage defaults: full precision, plain block-CSR on a small block
+      bool ops32 = true;
+      REQUIRE(problem.multilevelOperatorBits(-1, &ops32) == 32 && !ops32);  // (fp32 operator copies: HBM-bound blocks only)
+      REQUIRE(problem.autoInfo().state == 0 && problem.autoInfo().switches == 0);
+      REQUIRE(problem.describe().find("DPGO_TILE_WALK=") != std::string::npos);
       REQUIRE(problem.setSpmmVariant(DPGO_SPMM_SYMMETRIC) == DPGO_SPMM_PLAIN);  // needs blocks of >= 40 000 poses
       REQUIRE(problem.setSpmmVariant(DPGO_SPMM_AUTO) == DPGO_SPMM_PLAIN);
       REQUIRE(problem.setupMultilevel({2}) == 2);
