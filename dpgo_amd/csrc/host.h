@@ -138,6 +138,7 @@ inline int free_bsr(Bsr& m) {
   X(ml_dense_sym,      "DPGO_ML_DENSE_SYM",      -1,  "dense level from the packed lower triangle on the matrix cores: 0 / 1")       \
   X(ml_early_stop,     "DPGO_ML_EARLY_STOP",      1,  "tCG's residual test in the restriction kernel, one kernel early")             \
   X(ml_operator_bits,  "DPGO_ML_OPERATOR_BITS",   0,  "level-0 operator copies of the cycle on HBM-bound blocks: 32 / 64 (0: 32)")   \
+  X(ml_vector_bits,    "DPGO_ML_VECTOR_BITS",     0,  "cycle-internal vectors (pre-smoothed iterate, kept residual) beside fp32 operator copies: 32 / 64 (0: 32)") \
   X(ml_setup_serial,   "DPGO_ML_SETUP_SERIAL",    0,  "one-thread-per-aggregate set-up kernels of round 3")                          \
   X(gj_mfma,           "DPGO_GJ_MFMA",            1,  "rank-64 updates of the dense inverse on the fp64 matrix cores")               \
   X(dense_chunk,       "DPGO_DENSE_CHUNK",        0,  "tiles per workgroup of k_dense_sym_apply (0: default)")                       \
@@ -221,6 +222,9 @@ struct dpgo_problem_s {
     int merge_cap = 0;             // graph aggregates: fragments merged up to this many poses (0: plain greedy growth)
     double* tbuf = nullptr;
     float *Pb32 = nullptr, *AP32 = nullptr;  // fp32 copies of Pb and of A P's values (level 0, ml_operator_bits == 32)
+    float *x1f = nullptr, *res1f = nullptr;  // ... and the cycle-internal vectors of level 0 in that storage: the
+                                             // pre-smoothed iterate (k_tcg_update -> k_ml_restrict), the kept residual
+                                             // (k_ml_restrict -> k_ml_post_ap)
     AggMap agg() const { return AggMap{graph ? lab : nullptr, k}; }
   };
   std::vector<MlLevel> ml;
@@ -259,13 +263,16 @@ struct dpgo_problem_s {
   // Storage precision of the OPERATOR COPIES the V-cycle streams on level 0 of an HBM-bound block (symmetric storage, two
   // levels): Q's values in the restriction's residual r - A x1, the values of A P in the post-smoothing, the prolongation
   // blocks in both -- 32: fp32 copies beside the fp64 originals (the Hessian step, the set-up and every product and sum
-  // stay fp64; the cycle is a preconditioner).  DEFAULT since round 5 (100k poses: restriction 34.1 -> 29.2 us, post-smoothing
+  // stay fp64; the cycle is a preconditioner) -- and, with them, the two vectors that live INSIDE a cycle: the
+  // pre-smoothed iterate x1 and the kept residual res1 (written once, read once per application).  DEFAULT since round 5 (100k poses: restriction 34.1 -> 29.2 us, post-smoothing
   // 25.7 -> 23.9 us, 152 -> 148 us per product, same product counts; 64 restores the fp64 originals).  ml_ops32_ready: the
   // copies hold the current values.
   int ml_operator_bits = 32;
   bool ml_ops32_ready = false;
+  bool ml_ops32_suspend = false;  // set around a stand-alone application of the cycle (its pre-smoothing kernel writes fp64)
   bool ml_ops32_wanted() const { return ml_operator_bits == 32 && tcg_sym && split == 1 && ml_use_ap() && sym.uvalsT != nullptr; }
-  bool ml_ops32_active() const { return ml_ops32_wanted() && ml_ops32_ready; }
+  bool ml_ops32_active() const { return !ml_ops32_suspend && ml_ops32_wanted() && ml_ops32_ready; }
+  bool ml_vec32_active() const { return ml_ops32_active() && options().ml_vector_bits != 64; }  // (x1 / res1 in fp32 too)
   int ml_lda = 0;
   double *ml_W = nullptr, *ml_Rx = nullptr;  // Gauss-Jordan panels (setup only)
   // DPGO_PRECOND_AUTO: the multilevel cycle is currently selected.  Decided afresh at the first "auto" use after every

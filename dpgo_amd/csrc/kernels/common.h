@@ -406,6 +406,16 @@ __device__ __forceinline__ void store_col(double* __restrict__ p, const double (
 #pragma unroll
   for (int a = 0; a < R; ++a) p[a] = v[a];
 }
+template <int R, class XT>
+__device__ __forceinline__ void load_col_t(const XT* __restrict__ p, double (&v)[R]) {
+#pragma unroll
+  for (int a = 0; a < R; ++a) v[a] = (double)p[a];
+}
+template <int R, class XT>
+__device__ __forceinline__ void store_col_t(XT* __restrict__ p, const double (&v)[R]) {
+#pragma unroll
+  for (int a = 0; a < R; ++a) p[a] = (XT)v[a];
+}
 template <int NTS, int R>
 __device__ __forceinline__ void store_col_stream(double* __restrict__ p, const double (&v)[R]) {
 #pragma unroll
@@ -648,8 +658,9 @@ __device__ __forceinline__ SymIdx sym_idx_load(const BsrSymDevT<VT>& Q, int i, i
   return si;
 }
 // wave-cooperative (all 64 lanes); out = row c of (Q V)_i for the lane (g, c) of pose i
-template <int D, int R, class VT>
-__device__ __forceinline__ void spmm_sym_pre(const SymIdx& si, const BsrSymDevT<VT>& Q, const double* __restrict__ V, int c,
+// XT: storage type of the gathered vector (double; float for the cycle-internal vectors kept in fp32)
+template <int D, int R, class VT, class XT = double>
+__device__ __forceinline__ void spmm_sym_pre(const SymIdx& si, const BsrSymDevT<VT>& Q, const XT* __restrict__ V, int c,
                                              double (&out)[R]) {
   constexpr int B = D + 1, T = B * R, BB = B * B;
   const int lane = threadIdx.x & 63, gbase = lane - c;
@@ -669,7 +680,7 @@ __device__ __forceinline__ void spmm_sym_pre(const SymIdx& si, const BsrSymDevT<
   auto fma_block = [&](const double (&q)[B], int j) {
     double xc[R];
 #pragma unroll
-    for (int a = 0; a < R; ++a) xc[a] = V[(size_t)j * T + c * R + a];
+    for (int a = 0; a < R; ++a) xc[a] = (double)V[(size_t)j * T + c * R + a];
 #pragma unroll
     for (int cc = 0; cc < B; ++cc)
 #pragma unroll
@@ -716,8 +727,8 @@ __device__ __forceinline__ void q_gather(const BsrDevT<VT>& A, const double* __r
                                          double (&h)[R]) {
   spmm_col<D, R, SPLIT>(A.rowptr, A.colidx, A.vals, V, i, s, c, okp, h);
 }
-template <int D, int R, int SPLIT, class VT>
-__device__ __forceinline__ void q_gather(const BsrSymDevT<VT>& A, const double* __restrict__ V, int i, int s, int c, bool okp,
+template <int D, int R, int SPLIT, class VT, class XT>
+__device__ __forceinline__ void q_gather(const BsrSymDevT<VT>& A, const XT* __restrict__ V, int i, int s, int c, bool okp,
                                          double (&h)[R]) {
   static_assert(SPLIT == 1, "symmetric storage: one node per D+1 lanes");
   const SymIdx si = sym_idx_load<D>(A, i, c, okp);

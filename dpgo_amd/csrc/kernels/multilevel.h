@@ -72,15 +72,16 @@ struct TcgStopCheck {
   unsigned long long* hflag = nullptr;
   unsigned gen = 0;
 };
-// PT: storage type of the prolongation blocks (float with the fp32 operator copies of the cycle, like MAT's values)
-template <int D, int R, int SPLIT, class MAT = BsrDev, class PT = double>
-__global__ __launch_bounds__(kBlock) void k_ml_restrict(MAT A, const double* __restrict__ x1,
+// PT: storage type of the prolongation blocks (float with the fp32 operator copies of the cycle, like MAT's values);
+// XT: storage type of the cycle-internal vectors x1 (read: own tile + gather) and res_out (written) -- float with them
+template <int D, int R, int SPLIT, class MAT = BsrDev, class PT = double, class XT = double>
+__global__ __launch_bounds__(kBlock) void k_ml_restrict(MAT A, const XT* __restrict__ x1,
                                                         const double* __restrict__ r, const PT* __restrict__ Pb,
                                                         double shift, int k, double* __restrict__ rc,
                                                         float* __restrict__ rc32,
                                                         const double* __restrict__ dinv_next, double omega,
                                                         double* __restrict__ x1c, const DevState* gate,
-                                                        int n, double* __restrict__ res_out = nullptr,
+                                                        int n, XT* __restrict__ res_out = nullptr,
                                                         double* __restrict__ tbuf = nullptr,
                                                         const int32_t* __restrict__ tpos = nullptr,
                                                         TcgStopCheck stop = TcgStopCheck()) {
@@ -127,12 +128,12 @@ __global__ __launch_bounds__(kBlock) void k_ml_restrict(MAT A, const double* __r
     q_gather<D, R, SPLIT>(A, x1, i, L.s, L.c, okp, h);
     if (ok) {
       double xr[R], rr[R];
-      load_col<R>(x1 + off, xr);
+      load_col_t<R>(x1 + off, xr);
       load_col<R>(r + off, rr);
 #pragma unroll
       for (int a = 0; a < R; ++a) h[a] = rr[a] - h[a] - shift * xr[a];
       store_col<R>(&res_s[L.wave][L.g][L.c * R], h);
-      if (res_out) store_col<R>(res_out + off, h);  // kept for k_ml_post_ap
+      if (res_out) store_col_t<R>(res_out + off, h);  // kept for k_ml_post_ap (in its storage type; P^T res uses h itself)
     }
     wave_sync();
     if (L.s == 0 && L.g < GEO::G) {
@@ -537,10 +538,10 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(SPLIT ==
 // AP has about half of Q's blocks and its gather reads the coarse solution (a few hundred KB: L2-resident) instead of a 16 MB
 // pose vector; x1 = w Dinv r is recomputed from r (read anyway for <r,r>, <z,r>), the prolongation x1 + P xc happens here and
 // not in the dense kernel.  Same operator as k_ml_post up to summation order.
-// VT: storage type of A P's values and of the prolongation blocks (float: the opt-in fp32 operator copies of the cycle)
-template <int D, int R, int SPLIT, class VT = double>
+// VT: storage type of A P's values and of the prolongation blocks, RT: of the kept residual res1 (float: the fp32 copies of the cycle)
+template <int D, int R, int SPLIT, class VT = double, class RT = VT>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(SPLIT == 1 ? DPGO_POST_WAVES : 1))) void k_ml_post_ap(BsrDevT<VT> AP, const double* __restrict__ X,
-                                                       const double* __restrict__ r, const double* __restrict__ res1,
+                                                       const double* __restrict__ r, const RT* __restrict__ res1,
                                                        const double* __restrict__ xc, const VT* __restrict__ Pb, AggMap am,
                                                        const double* __restrict__ dinv, double omega,
                                                        double* __restrict__ Z, double* __restrict__ pout,
@@ -567,7 +568,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(SPLIT ==
       double x[R], rs[R];
       load_col<R>(X + off, x);
       load_col<R>(r + off, rr);
-      load_col<R>(res1 + off, rs);
+      load_col_t<R>(res1 + off, rs);
 #pragma unroll
       for (int q = 0; q < GEO::B; ++q) dr[q] = dinv[(size_t)i * GEO::BB + L.c * GEO::B + q];
 #pragma unroll

@@ -546,8 +546,9 @@ __global__ __launch_bounds__(kBlock) void k_tcg_update_span(const double* __rest
                                                             double* __restrict__ pout, const DevState* __restrict__ sin,
                                                             DevState* __restrict__ sout, int first, int n,
                                                             unsigned long long* hflag, unsigned gen,
-                                                            double ml_omega) {
-  // ml_omega > 0 (fused multilevel preconditioner): z receives the pre-smoothing step w Dinv r, unprojected
+                                                            double ml_omega, float* __restrict__ z32 = nullptr) {
+  // ml_omega > 0 (fused multilevel preconditioner): z receives the pre-smoothing step w Dinv r, unprojected -- into z32
+  // instead, rounded to fp32, when the cycle keeps its internal vectors in that storage (kernel-uniform)
   using GEO = Geo<D, R>;
   using SPN = Span<D, R, 1>;
   __shared__ __attribute__((aligned(16))) double sm[kWaves][4][GEO::G][GEO::T];
@@ -696,11 +697,23 @@ __global__ __launch_bounds__(kBlock) void k_tcg_update_span(const double* __rest
         store_col<R>(os + L.g * GEO::T + L.c * R, out);
       }
       wave_sync();
-      dbl2* z2 = reinterpret_cast<dbl2*>(z + base);
+      if (z32) {
+        float2* zf = reinterpret_cast<float2*>(z32 + base);
 #pragma unroll
-      for (int it = 0; it < SPN::NIT; ++it) {
-        const int pc = lane + 64 * it;
-        if (2 * pc < valid) z2[pc] = reinterpret_cast<const dbl2*>(os)[pc];
+        for (int it = 0; it < SPN::NIT; ++it) {
+          const int pc = lane + 64 * it;
+          if (2 * pc < valid) {
+            const dbl2 v = reinterpret_cast<const dbl2*>(os)[pc];
+            zf[pc] = make_float2((float)v.x, (float)v.y);
+          }
+        }
+      } else {
+        dbl2* z2 = reinterpret_cast<dbl2*>(z + base);
+#pragma unroll
+        for (int it = 0; it < SPN::NIT; ++it) {
+          const int pc = lane + 64 * it;
+          if (2 * pc < valid) z2[pc] = reinterpret_cast<const dbl2*>(os)[pc];
+        }
       }
       wave_sync();
     }

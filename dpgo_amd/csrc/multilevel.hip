@@ -77,7 +77,7 @@ void ml_free(dpgo_problem_s* p) {
     free_bsr(L.A);
     free_bsr(L.AP);
     void* ptrs[] = {L.slot_row, L.dinv, L.Pb, L.r, L.x1, L.x, L.res1, L.lab, L.agg_ptr, L.agg_mem, L.parent, L.pslot, L.tbuf, L.tile_perm, L.mem_pos,
-                    L.seg_info, L.seg_ptr, L.Pb32, L.AP32};
+                    L.seg_info, L.seg_ptr, L.Pb32, L.AP32, L.x1f, L.res1f};
     for (void* q : ptrs)
       if (q) (void)hipFree(q);
   }
@@ -641,6 +641,8 @@ int ml_ops32_ensure(dpgo_problem_s* p) {
   if (!p->sym.uvalsT32) HIPC(hipMalloc(&p->sym.uvalsT32, sizeof(float) * nu));
   if (!L0.AP32) HIPC(hipMalloc(&L0.AP32, sizeof(float) * nap));
   if (!L0.Pb32) HIPC(hipMalloc(&L0.Pb32, sizeof(float) * npb));
+  if (!L0.x1f) HIPC(hipMalloc(&L0.x1f, sizeof(float) * (size_t)L0.n * p->T));
+  if (!L0.res1f) HIPC(hipMalloc(&L0.res1f, sizeof(float) * (size_t)L0.n * p->T));
   auto copy = [&](const double* in, float* out, size_t total) {
     hipLaunchKernelGGL(k_copy_f32, dim3(flat_grid(total)), dim3(kBlock), 0, p->stream, in, out, total);
   };
@@ -742,10 +744,14 @@ int launch_ml_restrict0(dpgo_problem_s* p, const double* r, const DevState* gate
   float* rc32 = (C.k == 0 && p->ml_coarse_bits == 32) ? reinterpret_cast<float*>(C.r) : (float*)nullptr;
   double* res_out = p->ml_use_ap() ? L.res1 : nullptr;
   const double* dnext = C.k ? C.dinv : (const double*)nullptr;
-  if (p->ml_ops32_active()) {  // ... its fp32 copy (and the prolongation's) when the handle opted in
-    DISPATCH(p->d, p->r, hipLaunchKernelGGL((k_ml_restrict<D, R, 1, BsrSymDev32, float>), dim3(g0), dim3(kBlock), 0, p->stream,
-                                            p->sym.dev32(), L.x1, r, L.Pb32, p->ml_shift, L.k, C.r, rc32, dnext, p->ml_omega,
-                                            C.x1, gate, L.n, res_out, L.tbuf, L.seg_info, stop));
+  if (p->ml_vec32_active()) {  // ... its fp32 copy (and the prolongation's), the cycle's internal vectors in fp32 as well
+    DISPATCH(p->d, p->r, hipLaunchKernelGGL((k_ml_restrict<D, R, 1, BsrSymDev32, float, float>), dim3(g0), dim3(kBlock), 0,
+                                            p->stream, p->sym.dev32(), L.x1f, r, L.Pb32, p->ml_shift, L.k, C.r, rc32, dnext,
+                                            p->ml_omega, C.x1, gate, L.n, L.res1f, L.tbuf, L.seg_info, stop));
+  } else if (p->ml_ops32_active()) {  // (A/B: fp32 operator copies, fp64 vectors -- DPGO_ML_VECTOR_BITS=64)
+    DISPATCH(p->d, p->r, hipLaunchKernelGGL((k_ml_restrict<D, R, 1, BsrSymDev32, float, double>), dim3(g0), dim3(kBlock), 0,
+                                            p->stream, p->sym.dev32(), L.x1, r, L.Pb32, p->ml_shift, L.k, C.r, rc32, dnext,
+                                            p->ml_omega, C.x1, gate, L.n, res_out, L.tbuf, L.seg_info, stop));
   } else if (p->tcg_sym) {  // level 0 reads Q: the symmetric copy when the tCG-step kernel does
     DISPATCH(p->d, p->r, hipLaunchKernelGGL((k_ml_restrict<D, R, 1, BsrSymDev>), dim3(g0), dim3(kBlock), 0, p->stream,
                                             p->sym.dev(), L.x1, r, L.Pb, p->ml_shift, L.k, C.r, rc32, dnext, p->ml_omega,
@@ -766,9 +772,15 @@ int launch_ml_post_ap(dpgo_problem_s* p, const double* Xdev, const double* r, do
   auto& L0 = p->ml[0];
   if (p->ml_ops32_active()) {
     const BsrDev32 ap32{L0.AP.rowptr, L0.AP.colidx, L0.AP32};
-    DISPATCH(p->d, p->r, hipLaunchKernelGGL((k_ml_post_ap<D, R, 1, float>), dim3(p->grid_post()), dim3(kBlock), 0, p->stream,
-                                            ap32, Xdev, r, L0.res1, p->ml[1].x, L0.Pb32, L0.agg(), p->dinv, p->ml_omega, z, pout,
-                                            gate, p->n));
+    if (p->ml_vec32_active()) {
+      DISPATCH(p->d, p->r, hipLaunchKernelGGL((k_ml_post_ap<D, R, 1, float, float>), dim3(p->grid_post()), dim3(kBlock), 0,
+                                              p->stream, ap32, Xdev, r, L0.res1f, p->ml[1].x, L0.Pb32, L0.agg(), p->dinv,
+                                              p->ml_omega, z, pout, gate, p->n));
+    } else {
+      DISPATCH(p->d, p->r, hipLaunchKernelGGL((k_ml_post_ap<D, R, 1, float, double>), dim3(p->grid_post()), dim3(kBlock), 0,
+                                              p->stream, ap32, Xdev, r, L0.res1, p->ml[1].x, L0.Pb32, L0.agg(), p->dinv,
+                                              p->ml_omega, z, pout, gate, p->n));
+    }
     HIPC(hipGetLastError());
     return DPGO_OK;
   }
@@ -848,7 +860,11 @@ int launch_ml_apply(dpgo_problem_s* p, const double* Xdev, const double* v, doub
   DISPATCH(p->d, p->r, hipLaunchKernelGGL((k_ml_presmooth<D, R>), dim3(p->grid()), dim3(kBlock), 0, p->stream, v, p->dinv,
                                           p->ml_omega, p->ml[0].x1, (const DevState*)nullptr, p->n));
   HIPC(hipGetLastError());
-  return launch_ml_tail(p, Xdev, v, z, nullptr, nullptr);
+  // (outside the tCG loop the cycle reads the fp64 originals: its pre-smoothed iterate was written in fp64 just above)
+  p->ml_ops32_suspend = true;
+  const int rc = launch_ml_tail(p, Xdev, v, z, nullptr, nullptr);
+  p->ml_ops32_suspend = false;
+  return rc;
 }
 
 }  // namespace dpgo_host

@@ -7,11 +7,13 @@ int launch_tcg_update(dpgo_problem_s* p, const double* dinv, int first, double* 
                       double ml_omega) {
   const int g = p->grid();
   double* zt = z_out ? z_out : p->z;
+  // (the pre-smoothed iterate of a cycle that keeps its internal vectors in fp32 goes to that buffer instead)
+  float* z32 = (ml_omega > 0.0 && !p->ml.empty() && z_out == p->ml[0].x1 && p->ml_vec32_active()) ? p->ml[0].x1f : nullptr;
   DISPATCH(p->d, p->r, {
     if constexpr (Span<D, R, 1>::kOk)
       hipLaunchKernelGGL((k_tcg_update_span<D, R>), dim3(g), dim3(kBlock), 0, p->stream, p->x1, p->g1, dinv, p->delta,
                          p->Hd, p->eta, p->rr, zt, p->pA(), p->grid_s(), p->pB(), p->dstate + p->cur,
-                         p->dstate + (p->cur ^ 1), first, p->n, p->hflag, p->launch_gen(), ml_omega);
+                         p->dstate + (p->cur ^ 1), first, p->n, p->hflag, p->launch_gen(), ml_omega, z32);
     else
       hipLaunchKernelGGL((k_tcg_update<D, R>), dim3(g), dim3(kBlock), 0, p->stream, p->x1, p->g1, dinv, p->delta,
                          p->Hd, p->eta, p->rr, zt, p->pA(), p->grid_s(), p->pB(), p->dstate + p->cur,
@@ -312,12 +314,12 @@ unsigned long long iter_graph_key(const dpgo_problem_s* p, const double* dinv, b
   k.add((long long)p->ml_use_ap()), k.add((long long)p->ml_use_dense_sym()), k.add((long long)p->beyond_cache());
   k.add(p->ml_dense), k.add(p->ml_dense32), k.add(p->ml_packed), k.add(p->ml_pd), k.add(p->ml_pt), k.add(p->ml_chunks);
   k.add(p->ml_chunk_first), k.add((long long)p->ml_nchunks), k.add((long long)p->ml.size());
-  k.add((long long)p->ml_ops32_active()), k.add(p->sym.uvalsT32);
+  k.add((long long)p->ml_ops32_active()), k.add((long long)p->ml_vec32_active()), k.add(p->sym.uvalsT32);
   for (const auto& L : p->ml) {
     k.add((long long)L.n), k.add((long long)L.k), k.add((long long)L.split), k.add((long long)L.graph), k.add((long long)L.nseg);
     key_bsr(k, L.A), key_bsr(k, L.AP);
     const void* ptrs[] = {L.slot_row, L.dinv, L.Pb, L.r, L.x1, L.x, L.res1, L.lab, L.agg_ptr, L.agg_mem, L.parent, L.pslot,
-                          L.mem_pos, L.seg_info, L.seg_ptr, L.tile_perm, L.tbuf, L.Pb32, L.AP32};
+                          L.mem_pos, L.seg_info, L.seg_ptr, L.tile_perm, L.tbuf, L.Pb32, L.AP32, L.x1f, L.res1f};
     for (auto v : ptrs) k.add(v);
   }
   return k.h;

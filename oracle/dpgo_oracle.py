@@ -641,12 +641,16 @@ class QuadraticProblem:
 
     def __init__(self, Q: BSR, G: Optional[np.ndarray], r: int, d: int, precond: str = "exact",
                  shift: float = 0.1, amg_k=None, amg_omega: float = 0.7, amg_gamma: int = 1, amg_nu: int = 1,
-                 amg_coarse_bits: int = 64, amg_merge: int = 0, amg_operator_bits: int = 64):
+                 amg_coarse_bits: int = 64, amg_merge: int = 0, amg_operator_bits: int = 64,
+                 amg_vector_bits: Optional[int] = None):
         self.amg_k, self.amg_omega, self._amg = amg_k, amg_omega, None
         # storage precision of the level-0 OPERATOR COPIES the device's cycle streams on HBM-bound blocks (device default
         # 64; 32 = opt-in, dpgo_problem_multilevel_operator_bits): Q's values in the residual r - A x1, the values of A P
         # in the post-smoothing, the prolongation blocks in both -- two-level hierarchies only (amg_cycle)
         self.amg_operator_bits = amg_operator_bits
+        # ... and of the two vectors that live inside such a cycle (pre-smoothed iterate, kept residual): the operator
+        # copies' precision unless told otherwise (the device's A/B switch DPGO_ML_VECTOR_BITS)
+        self.amg_vector_bits = amg_operator_bits if amg_vector_bits is None else amg_vector_bits
         self.amg_merge = amg_merge  # graph aggregates: > 0 = join the fragments of the greedy growth up to this many poses (amg_merge_small_aggregates)
         self.amg_coarse_bits = amg_coarse_bits  # storage precision of the dense level (device default: 64; 32 = opt-in)
         self.amg_gamma, self.amg_nu = amg_gamma, amg_nu  # coarse-level cycle index / smoothing sweeps (experiments)
@@ -773,12 +777,15 @@ class QuadraticProblem:
         m = self.amg_setup()
         w, b, r = self.amg_omega, self.b, self.r
         if self.amg_operator_bits == 32 and len(m["levels"]) == 1 and not getattr(self, "amg_additive", False):
-            # The device's two-level cycle in the form its kernels evaluate it (k_ml_restrict, k_ml_post_ap):
+            # The device's two-level cycle in the form its kernels evaluate it (k_tcg_update, k_ml_restrict, k_ml_post_ap):
             #   x1 = w Dinv r;  res1 = r - Q x1 - shift x1;  rc = P^T res1;  xc = Ac^-1 rc;
             #   z = (x1 + P xc) + w Dinv (res1 - (A P) xc)
             # with Q, P and A P read from fp32 COPIES (each rounded from its fp64 original; A P is the fp64 product
-            # rounded, not the product of the rounded factors), everything else -- Dinv, the dense level, every product and
-            # sum -- in fp64.  With fp64 copies this is the generic cycle below up to summation order.
+            # rounded, not the product of the rounded factors) and the two vectors that live inside the cycle STORED in
+            # fp32: the x1 the restriction reads (own rows and gathers) is the rounded one -- the post-smoothing
+            # recomputes x1 from r in fp64 --, the res1 the post-smoothing reads is the rounded one -- P^T res1 uses the
+            # fp64 value the restriction still holds.  Everything else -- Dinv, the dense level, every product and sum --
+            # in fp64.  With fp64 storage this is the generic cycle below up to summation order.
             L = m["levels"][0]
             if "ops32" not in m:
                 f32 = lambda M: M.astype(np.float32).astype(np.float64)  # noqa: E731
@@ -792,13 +799,15 @@ class QuadraticProblem:
             Q32, P32, AP32 = m["ops32"]
             smooth = lambda res: (L["Dinv"] @ res.reshape(L["n"], b, r)).reshape(res.shape)  # noqa: E731
             rhs = V.reshape(self.N, self.r)
+            f32 = (lambda M: M.astype(np.float32).astype(np.float64)) if self.amg_vector_bits == 32 else (lambda M: M)  # noqa: E731
             x1 = w * smooth(rhs)
-            res1 = rhs - Q32 @ x1 - self.shift * x1
+            x1s = f32(x1)
+            res1 = rhs - Q32 @ x1s - self.shift * x1s
             rc = P32.T @ res1
             if self.amg_coarse_bits == 32:
                 rc = rc.astype(np.float32).astype(np.float64)
             xc = m["AcInv"] @ rc
-            z = (x1 + P32 @ xc) + w * smooth(res1 - AP32 @ xc)
+            z = (x1 + P32 @ xc) + w * smooth(f32(res1) - AP32 @ xc)
             return z.reshape(V.shape)
 
         def cycle(lv, rhs):

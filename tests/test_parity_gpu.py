@@ -2357,6 +2357,7 @@ SWITCH_SETS = [
     ({"DPGO_ML_EARLY_STOP": "0"}, "bitwise"),      # tCG's residual test back in the Hessian-step kernel's prologue
     ({"DPGO_ITER_GRAPH": "1"}, "bitwise"),         # steady tCG iterations replayed from an instantiated hipGraph
     ({"DPGO_SPMM_SYMMETRIC": "1", "DPGO_ML_OPERATOR_BITS": "64"}, "oracle"),  # the cycle streams the fp64 operators (sym. storage)
+    ({"DPGO_SPMM_SYMMETRIC": "1", "DPGO_ML_VECTOR_BITS": "64"}, "oracle"),    # fp32 operator copies, fp64 vectors inside the cycle
     ({"DPGO_SPMM_SYMMETRIC": "1"}, "oracle"),      # symmetric storage of Q: k_tcg_hess_sym, level-0 restriction / post-smoothing
     ({"DPGO_SPMM_SYMMETRIC": "1", "DPGO_OUTER_SYM": "0", "DPGO_STREAM_NT": "1"}, "oracle"),  # outer iteration on the plain copy
     ({"DPGO_SPMM_SYMMETRIC": "1", "DPGO_TILE_WALK": "0"}, "oracle"),  # symmetric-storage kernels walk their tiles in index order
@@ -2415,10 +2416,12 @@ def test_kernel_selecting_switches_match_oracle(oracle, workload):
             # otherwise: the oracle mirrors the storage, amg_operator_bits)
             want_bits = 64 if sw.get("DPGO_ML_OPERATOR_BITS") == "64" else 32
             obits = want_bits if (sw.get("DPGO_SPMM_SYMMETRIC") == "1" and n >= 40000) else 64
-            ks = ks + ((obits,) if obits == 32 else ())
+            vbits = 64 if sw.get("DPGO_ML_VECTOR_BITS") == "64" else obits
+            hier = list(ks)
+            ks = ks + ((obits, vbits) if obits == 32 else ())
             if ks not in want:
-                op = oracle.QuadraticProblem(Q, None, r, d, precond="amg", amg_k=list(ks[:-1] if obits == 32 else ks),
-                                             amg_operator_bits=obits)
+                op = oracle.QuadraticProblem(Q, None, r, d, precond="amg", amg_k=hier, amg_operator_bits=obits,
+                                             amg_vector_bits=vbits)
                 rows, Xo = [], X0
                 for call in range(2):
                     oo = oracle.QuadraticOptimizer(op, oracle.ROptParameters(), hess_recurrence=True)
