@@ -282,10 +282,13 @@ int dpgo_problem_multilevel_coarse_bits(dpgo_problem_t h, int* bits);
 /* Storage precision of the OPERATOR COPIES the V-cycle streams on level 0 of an HBM-bound block (symmetric storage of Q,
  * two-level hierarchy; ignored elsewhere): *bits = 32 (default) or 64 -- fp32 copies of Q's values for the restriction's
  * residual r - A x1, of A P's values for the post-smoothing and of the prolongation blocks for both, beside the fp64
- * originals: the cycle streams ~70 MB less per application at 100 000 poses.  The cycle is a preconditioner: the tCG
- * vectors, the Hessian step, the hierarchy's set-up, the smoother's factors, the dense level and every product and sum
- * stay fp64; the optimum does not depend on it, the products to the tolerance are the same (100 000-pose grid: 70 either
- * way, 152 -> 148 us each); 64 (or DPGO_ML_OPERATOR_BITS=64) streams the fp64 originals.  A negative input only queries; *active (optional) = 1 if the last
+ * originals -- and the two vectors that live INSIDE a cycle (the pre-smoothed iterate the update kernel hands to the
+ * restriction, the residual the restriction keeps for the post-smoothing) are stored in fp32 as well: the cycle streams
+ * ~100 MB less per application at 100 000 poses and its gathers fetch half-size tiles.  The cycle is a preconditioner:
+ * the tCG vectors, the Hessian step, the hierarchy's set-up, the smoother's factors, the dense level and every product and
+ * sum stay fp64; the optimum does not depend on it, the products to the tolerance are the same (100 000-pose grid: 70
+ * either way, 152 -> 138 us each); 64 (or DPGO_ML_OPERATOR_BITS=64) streams the fp64 originals (DPGO_ML_VECTOR_BITS=64: fp32
+ * operator copies, fp64 vectors -- the A/B of the two halves).  A negative input only queries; *active (optional) = 1 if the last
  * solve's cycle streamed the fp32 copies.  The oracle mirrors the storage (amg_operator_bits). */
 int dpgo_problem_multilevel_operator_bits(dpgo_problem_t h, int* bits, int* active);
 /* State of DPGO_PRECOND_AUTO on this handle: *use_multilevel in/out; 0 / 1 set it, -1 only queries, -2 returns to the
