@@ -981,9 +981,12 @@ def main():
                             "1e-2, single agent, same settings)" % (tt_main["ms"], tt_main["products"]))
                            if tt_main.get("reached") else "time_to_tolerance_ms = not measured in this run"),
                        "time_to_tolerance_ms": tt_main.get("ms") if tt_main.get("reached") else None,
-                       "cycle_storage": ("all vectors, the Hessian step, smoother factors and dense level fp64; the "
+                       "cycle_storage": ("tCG vectors, the Hessian step, smoother factors and dense level fp64; the "
                                          "multilevel cycle streams fp%d copies of its level-0 operators (symmetric Q, A P, "
-                                         "prolongation blocks), fp64 arithmetic" % ml_info["cycle_operator_copy_bits"])
+                                         "prolongation blocks) and keeps its two internal vectors (pre-smoothed iterate, "
+                                         "kept residual) in fp%d; fp64 arithmetic throughout" % (
+                                             ml_info["cycle_operator_copy_bits"],
+                                             64 if os.environ.get("DPGO_ML_VECTOR_BITS") == "64" else ml_info["cycle_operator_copy_bits"]))
                        if ml_info else None,
                        "hierarchy_setup_ms": tt_main.get("hierarchy_setup_ms"),
                        "time_to_tolerance_incl_setup_ms": tt_main.get("ms_incl_setup") if tt_main.get("reached") else None,
