@@ -1004,7 +1004,9 @@ def main():
                                if world == 1 else "") if comm
                            else ("device copies" if world == 1 else
                                  ("peer store: senders' pack kernels write into the receivers' hipIpc-mapped neighbour "
-                                  "buffers, gloo barriers (dpgo_amd/ipc.py)" if cluster.peer_store is not None else
+                                  "buffers, ordered %s (dpgo_amd/ipc.py)" % (
+                                      "on the device by epoch words both sides map" if cluster.peer_store.device_ordered
+                                      else "by two host barriers per exchange") if cluster.peer_store is not None else
                                   ("torch.distributed nccl p2p" if not cluster.stage else "gloo (host-staged)")))),
                        "dist_backend": backend, "transport": (args.transport if use_dist else None),
                        "poses_per_agent": n_local, "nnzb_per_agent": nnzb_local,

@@ -601,6 +601,38 @@ int dpgo_exchange_plan_run(dpgo_exchange_plan_t pl, void* stream) {
 }
 
 
+// ---- ordering words of the peer-store transport (kernels/agent.h: k_flags_write / k_flags_wait) ----
+static int flag_table(int n, unsigned long long* const* words_dev, const unsigned long long* values, int first, FlagTable* t) {
+  t->n = std::min(kFlagCap, n - first);
+  for (int k = 0; k < t->n; ++k) {
+    if (!words_dev[first + k]) return fail(DPGO_ERR_INVALID, "null ordering word");
+    t->p[k] = words_dev[first + k];
+    t->v[k] = values[first + k];
+  }
+  return DPGO_OK;
+}
+int dpgo_flags_write_device(int n, unsigned long long* const* words_dev, const unsigned long long* values, void* stream) {
+  if (n < 0 || (n > 0 && (!words_dev || !values))) return fail(DPGO_ERR_INVALID, "bad ordering-word arguments");
+  for (int first = 0; first < n; first += kFlagCap) {
+    FlagTable t;
+    CHK(flag_table(n, words_dev, values, first, &t));
+    hipLaunchKernelGGL(k_flags_write, dim3(1), dim3(64), 0, (hipStream_t)stream, t);
+  }
+  HIPC(hipGetLastError());
+  return DPGO_OK;
+}
+int dpgo_flags_wait_device(int n, unsigned long long* const* words_dev, const unsigned long long* values, int timeout_ms,
+                           void* stream) {
+  if (n < 0 || (n > 0 && (!words_dev || !values)) || timeout_ms <= 0) return fail(DPGO_ERR_INVALID, "bad ordering-word arguments");
+  for (int first = 0; first < n; first += kFlagCap) {
+    FlagTable t;
+    CHK(flag_table(n, words_dev, values, first, &t));
+    hipLaunchKernelGGL(k_flags_wait, dim3(1), dim3(64), 0, (hipStream_t)stream, t, (long long)timeout_ms * 100000LL);
+  }
+  HIPC(hipGetLastError());
+  return DPGO_OK;
+}
+
 int dpgo_exchange_plan_destroy(dpgo_exchange_plan_t pl) {
   if (!pl) return DPGO_OK;
   for (void* q : {pl->src, pl->idx, pl->dst, pl->first})

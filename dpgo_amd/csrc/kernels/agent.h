@@ -28,6 +28,33 @@ __global__ __launch_bounds__(kBlock) void k_scatter_tiles(const double* __restri
   }
 }
 
+// Ordering words of the peer-store transport (dpgo_amd/ipc.py): 64-bit epochs in device memory that TWO PROCESSES map
+// (hipIpc).  A producer's stream writes a word AFTER the kernel that produced the data (stream order: that kernel's
+// end-of-kernel release has made its stores visible device-wide); a consumer's stream runs k_flags_wait BEFORE the kernel
+// that reads the data (whose start-of-kernel acquire then sees it).  System-scope atomics (sc0 sc1: write-through stores,
+// cache-bypassing loads), so the words themselves need no kernel boundary.  The wait is bounded: a word that does not
+// arrive within `timeout_ticks` (100 MHz wall clock) traps -- a loud failure of that process instead of a hung GPU.
+constexpr int kFlagCap = 32;
+struct FlagTable {
+  unsigned long long* p[kFlagCap];
+  unsigned long long v[kFlagCap];
+  int n;
+};
+static __global__ void k_flags_write(FlagTable t) {
+  const int i = threadIdx.x;
+  if (i < t.n) __hip_atomic_store(t.p[i], t.v[i], __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+static __global__ void k_flags_wait(FlagTable t, long long timeout_ticks) {
+  const int i = threadIdx.x;
+  if (i < t.n) {
+    const long long t0 = wall_clock64();
+    while (__hip_atomic_load(t.p[i], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < t.v[i]) {
+      __builtin_amdgcn_s_sleep(16);
+      if (wall_clock64() - t0 > timeout_ticks) __builtin_trap();
+    }
+  }
+}
+
 // Batched form for agents that live in ONE process: message m copies cnt pose tiles src[m][idx[m][k]] -> dst[m][k]; one
 // launch for a whole exchange phase (a 16-agent sweep spent 0.5 ms in ~60 tiny pack / copy launches).  first[m] = tiles of
 // the messages before m (first[nmsg] = total).

@@ -4,17 +4,27 @@ send / receive): every agent's neighbour tile buffer is mapped into the address 
 batched launch of the exchange plan, k_gather_tiles_batched -- writes the public poses STRAIGHT into the receiver's
 buffer: no staging buffer, no communicator kernel, one launch per exchange phase and process.
 
-What it needs from the launcher: a torch.distributed process group for the rendezvous (the IPC handles travel over it
-once) and for the two host barriers that order an exchange against the solves around it (gloo is enough: RCCL refuses two
-ranks on one device, IPC does not -- this is the transport with which the multi-process data path runs on ONE GPU).  The
-processes may sit on the same device or on different devices of one node (peer access).  RCCL stays the default transport
-of bench.py and of the multi-node case; `bench.py --transport ipc` prints this transport's exchange time beside it.
+Ordering (round 5): ON THE DEVICE.  Every process also shares a small array of 64-bit epoch words; per message a -> q there
+is a `ready` word in q's process (the tiles of epoch e have landed) and an `ack` word in a's process (q has consumed epoch
+e).  An exchange enqueues, on the stream everything else of the sweep is enqueued on and without a host wait:
+    acknowledge what arrived earlier  ->  wait for the acks of what is about to be overwritten  ->  pack kernel (writes into
+    the receivers' buffers)  ->  publish `ready`  ->  wait for the `ready` words of the incoming messages
+(C ABI dpgo_flags_write_device / dpgo_flags_wait_device: system-scope atomics; the data itself is ordered by kernel
+boundaries on either side; a wait is bounded and traps instead of hanging).  Round 4 ordered an exchange with two HOST
+barriers (2.0 ms of an 8.97 ms sweep at 4 x 25 000 poses); DPGO_IPC_HOST_BARRIERS=1 keeps that scheme for A/B runs.
+
+What it needs from the launcher: a torch.distributed process group for the rendezvous (the IPC handles travel over it once;
+gloo is enough: RCCL refuses two ranks on one device, IPC does not -- this is the transport with which the multi-process
+data path runs on ONE GPU).  The processes may sit on the same device or on different devices of one node (peer access).
+RCCL stays the default transport of bench.py and of the multi-node case; `bench.py --transport ipc` prints this transport's
+exchange time beside it.
 
 Reference counterpart: the in-process pointer calls of examples/MultiRobotExample.cpp:183-204 (setNeighborPoses with the
 sender's PoseDict) -- a peer store is the closest device analogue of handing the neighbour a pointer."""
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Dict, List, Tuple
 
 from . import lib as L
@@ -23,19 +33,42 @@ from . import lib as L
 class IpcPeerStore:
     """Collective constructor (every rank of the default process group calls it with its RBCDCluster)."""
 
+    WAIT_TIMEOUT_MS = 20000  # a peer that never publishes: the waiting kernel traps after this long
+
     def __init__(self, cluster):
         import torch
         import torch.distributed as dist
         self.torch, self.dist = torch, dist
         self.cluster = cluster
         self.rank, self.world = dist.get_rank(), dist.get_world_size()
+        self.device_ordered = os.environ.get("DPGO_IPC_HOST_BARRIERS", "0") != "1"
         self._remote: Dict[Tuple[int, bool], object] = {}  # (agent id, aux) -> tensor aliasing that agent's buffer
         self._plans: Dict[tuple, object] = {}
         self._shared_gen: Dict[bool, int] = {}
         self._keep: List[object] = []
+        # ordering words: [aux][ready / ack][message], message = index into the plan's full message list; every process
+        # holds the whole (tiny) array, a word is WRITTEN by exactly one peer and READ by its owner
+        self._msgs = list(cluster.plan.messages(None))
+        self._mid = {m: k for k, m in enumerate(self._msgs)}
+        nm = max(1, len(self._msgs))
+        dev = next(iter(cluster.agents.values())).device
+        self._words = torch.zeros(2 * 2 * nm, dtype=torch.int64, device=dev)
+        self._nm = nm
+        self._epoch: Dict[Tuple[int, int, bool], int] = {}     # (a, q, aux) -> epochs sent / expected so far
+        self._acked: Dict[Tuple[int, int, bool], int] = {}     # (a, q, aux) -> last epoch this process acknowledged
+        self._peer_words: Dict[int, object] = {}               # rank -> tensor aliasing that rank's words
+        self._share_words()
         self._share(False)
 
     # ---- rendezvous: export every local agent's neighbour buffer, open everybody else's ----
+    def _share_words(self) -> None:
+        from torch.multiprocessing.reductions import reduce_tensor
+        everyone = [None] * self.world
+        self.dist.all_gather_object(everyone, reduce_tensor(self._words))
+        for r, (rebuild, args) in enumerate(everyone):
+            if r != self.rank:
+                self._peer_words[r] = rebuild(*args)
+
     def _share(self, aux: bool) -> None:
         from torch.multiprocessing.reductions import reduce_tensor
         mine = {}
@@ -68,9 +101,99 @@ class IpcPeerStore:
             return (ag.nbr_aux if aux else ag.nbr)[lo:hi]
         return self._remote[(q, aux)][lo:hi]
 
+    # ---- ordering words ----
+    def _word(self, owner_rank: int, aux: bool, which: int, msg) -> int:
+        """Device address (in THIS process's address space) of a word that lives in `owner_rank`'s array."""
+        t = self._words if owner_rank == self.rank else self._peer_words[owner_rank]
+        return t.data_ptr() + 8 * ((2 * int(aux) + which) * self._nm + self._mid[msg])
+
+    def _flags(self, fn, entries, stream, *extra) -> None:
+        if not entries:
+            return
+        n = len(entries)
+        ptrs = (C.c_void_p * n)(*[p for p, _ in entries])
+        vals = (C.c_ulonglong * n)(*[v for _, v in entries])
+        L.check(fn(n, ptrs, vals, *extra, stream))
+
+    def _plan(self, out, key, aux: bool):
+        c = self.cluster
+        gen = c._buffer_generation()
+        if self.__dict__.get("_plan_gen") != gen:  # the plans hold raw device addresses
+            for h in self._plans.values():
+                self._destroy(h)
+            self._plans.clear()
+            self._plan_gen = gen
+        pkey = (key, aux)
+        plan = self._plans.get(pkey)
+        if plan is None:
+            first = c.agents[out[0][0]]
+            n = len(out)
+            src = [L.ptr(c.agents[a].Y if aux else c.agents[a].X) for a, q in out]
+            idx = [L.ptr(c.agents[a].send_idx[q]) for a, q in out]
+            cnt = [len(c.agents[a].send_idx[q]) for a, q in out]
+            dst = [L.ptr(self._dst(q, a, aux)) for a, q in out]
+            h = L._P()
+            L.check(first.problem._lib.dpgo_exchange_plan_create(
+                C.byref(h), first.r, first.d, n, (C.c_void_p * n)(*src), (C.c_void_p * n)(*idx), (C.c_int * n)(*cnt),
+                (C.c_void_p * n)(*dst), first.device.index or 0))
+            plan = self._plans[pkey] = h
+        return plan
+
     def exchange(self, msgs, key, aux: bool) -> None:
-        """All messages of one exchange phase whose SENDER lives here, as one launch; two host barriers order it against
-        the receivers' solves (before: nobody still reads the buffers; after: everything has landed)."""
+        """All messages of one exchange phase whose SENDER lives here, as one launch, ordered against the receivers' solves
+        on the device (see the module text); DPGO_IPC_HOST_BARRIERS=1: by two host barriers as in round 4."""
+        if not self.device_ordered:
+            return self._exchange_host_barriers(msgs, key, aux)
+        torch = self.torch
+        c = self.cluster
+        gen = c._buffer_generation()
+        if aux not in self._shared_gen:
+            # the first exchange of this kind of buffer: every rank reaches it at the same point of the same driver code
+            self._share(aux)
+        elif self._shared_gen[aux] != gen:
+            # re-sharing is collective and this scheme has no host rendezvous per exchange to agree on it
+            raise RuntimeError("dpgo_amd.ipc: an agent re-bound a buffer the peers have mapped; call "
+                               "cluster.peer_store.reshare() on EVERY rank before the next exchange")
+        lib = next(iter(c.agents.values())).problem._lib
+        stream = torch.cuda.current_stream().cuda_stream or None
+        own = c.owner
+        out = [(a, q) for a, q in msgs if a in c.agents]
+        remote_out = [(a, q) for a, q in out if q not in c.agents]
+        remote_in = [(a, q) for a, q in msgs if q in c.agents and a not in c.agents]
+        # 1. acknowledge everything that arrived in earlier exchanges: every kernel that read it is ahead on this stream
+        acks = []
+        for (a, q, x), e in self._epoch.items():
+            if q in c.agents and a not in c.agents and self._acked.get((a, q, x), 0) < e:
+                acks.append((self._word(own(a), x, 1, (a, q)), e))
+                self._acked[(a, q, x)] = e
+        self._flags(lib.dpgo_flags_write_device, acks, stream)
+        # 2. the receivers have consumed what this exchange overwrites
+        self._flags(lib.dpgo_flags_wait_device, [(self._word(self.rank, aux, 1, m), self._epoch.get((m[0], m[1], aux), 0))
+                                                 for m in remote_out if self._epoch.get((m[0], m[1], aux), 0) > 0],
+                    stream, self.WAIT_TIMEOUT_MS)
+        # 3. the tiles
+        if out:
+            L.check(lib.dpgo_exchange_plan_run(self._plan(out, key, aux), stream))
+        # 4. publish, 5. wait for what this process receives
+        for m in remote_out + remote_in:
+            k = (m[0], m[1], aux)
+            self._epoch[k] = self._epoch.get(k, 0) + 1
+        self._flags(lib.dpgo_flags_write_device, [(self._word(own(m[1]), aux, 0, m), self._epoch[(m[0], m[1], aux)])
+                                                  for m in remote_out], stream)
+        self._flags(lib.dpgo_flags_wait_device, [(self._word(self.rank, aux, 0, m), self._epoch[(m[0], m[1], aux)])
+                                                 for m in remote_in], stream, self.WAIT_TIMEOUT_MS)
+
+    def reshare(self) -> None:
+        """Collective: export / open every buffer again after an agent re-bound one (agent.X = ..., a second
+        enable_acceleration()).  All in-flight work is drained first."""
+        self.torch.cuda.synchronize()
+        self.dist.barrier()
+        self._remote.clear()
+        for aux in list(self._shared_gen):
+            self._share(aux)
+        self._plan_gen = None
+
+    def _exchange_host_barriers(self, msgs, key, aux: bool) -> None:
         torch, dist = self.torch, self.dist
         c = self.cluster
         gen = c._buffer_generation()
@@ -87,32 +210,17 @@ class IpcPeerStore:
                 del self._remote[key_]
             self._share(aux)
             self._plan_gen = None  # remote addresses may have changed whatever the local generation says
-        if self.__dict__.get("_plan_gen") != gen:  # the plans hold raw device addresses
-            for h in self._plans.values():
-                self._destroy(h)
-            self._plans.clear()
-            self._plan_gen = gen
         if out:
             first = c.agents[out[0][0]]
-            pkey = (key, aux)
-            plan = self._plans.get(pkey)
-            if plan is None:
-                n = len(out)
-                src = [L.ptr(c.agents[a].Y if aux else c.agents[a].X) for a, q in out]
-                idx = [L.ptr(c.agents[a].send_idx[q]) for a, q in out]
-                cnt = [len(c.agents[a].send_idx[q]) for a, q in out]
-                dst = [L.ptr(self._dst(q, a, aux)) for a, q in out]
-                h = L._P()
-                L.check(first.problem._lib.dpgo_exchange_plan_create(
-                    C.byref(h), first.r, first.d, n, (C.c_void_p * n)(*src), (C.c_void_p * n)(*idx), (C.c_int * n)(*cnt),
-                    (C.c_void_p * n)(*dst), first.device.index or 0))
-                plan = self._plans[pkey] = h
-            L.check(first.problem._lib.dpgo_exchange_plan_run(plan, torch.cuda.current_stream().cuda_stream or None))
+            L.check(first.problem._lib.dpgo_exchange_plan_run(self._plan(out, key, aux),
+                                                             torch.cuda.current_stream().cuda_stream or None))
             torch.cuda.current_stream().synchronize()
         dist.barrier()
 
     def close(self) -> None:
+        self.torch.cuda.synchronize()
         for h in self._plans.values():
             self._destroy(h)
         self._plans.clear()
         self._remote.clear()
+        self._peer_words.clear()

@@ -560,6 +560,15 @@ int dpgo_exchange_plan_create(dpgo_exchange_plan_t* out, int r, int d, int nmsg,
                               const int32_t* const* idx_dev, const int* count, double* const* dst_dev, int device);
 int dpgo_exchange_plan_run(dpgo_exchange_plan_t plan, void* stream);
 int dpgo_exchange_plan_destroy(dpgo_exchange_plan_t plan);
+/* Device-side ordering of an exchange between PROCESSES that map each other's buffers (dpgo_amd/ipc.py, the peer-store
+ * transport; no reference counterpart -- the demo driver's agents share one address space): 64-bit epoch words in device
+ * memory both sides map.  write: words_dev[k] <- values[k] (system-scope release store), enqueued BEHIND the kernel that
+ * produced the data.  wait: the stream stalls until every word >= its value (system-scope acquire loads), enqueued IN
+ * FRONT of the kernel that consumes the data; a word that does not arrive within timeout_ms traps the waiting kernel (the
+ * process fails loudly; nothing hangs).  Host arrays of device pointers / values; any n. */
+int dpgo_flags_write_device(int n, unsigned long long* const* words_dev, const unsigned long long* values, void* stream);
+int dpgo_flags_wait_device(int n, unsigned long long* const* words_dev, const unsigned long long* values, int timeout_ms,
+                           void* stream);
 
 /* Agent status (PGOAgent::iterate, src/PGOAgent.cpp:399-420): relativeChange = LiftedPoseArray::maxTranslationDistance
  * (src/manifold/Poses.cpp:86-94) of the iterate and the previous one, max_i |p_i - p_i'| over the translation columns.
