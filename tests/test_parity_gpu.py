@@ -2304,8 +2304,10 @@ def test_dense_spd_inverse(N, mfma):
 def test_multilevel_on_random_graphs_with_broken_chains(oracle, d, r, n, hub_edges, drop):
     """precond = "multilevel" away from the benchmark datasets: a hub row, ragged sizes (n not a multiple of k), both
     tile parities, and odometry chains with missing links (the prolongation restarts at the identity there).  One
-    application matches the oracle's cycle to 1e-8; the solve is a descent with the same iteration counts as the
-    oracle (+-1 tCG step on these badly scaled problems) and ends at the same cost.  (Far from the optimum the
+    application matches the oracle's cycle to 1e-8 -- THAT is the parity claim of this test.  The whole solve is only
+    smoke-tested here: a descent with the same iteration counts as the oracle (+-1 tCG step on these badly scaled
+    problems), costs compared to 2 % when the counts agree (one step more or less before the trust-region boundary is
+    another, equally valid step; whole-solve parity lives in the tests on the data sets).  (Far from the optimum the
     trust-region boundary, measured in the preconditioner's norm, decides the step: no claim is made here about which
     preconditioner gets further in three outer iterations.)"""
     import dpgo_amd
