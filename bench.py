@@ -628,7 +628,8 @@ def main():
     exchange_ms = sum(e0.elapsed_time(e1) for e0, e1 in ex_events)
     cluster.exchange = _exchange
     # (what the timed steps' cycles streamed: asked NOW -- the probes below set the hierarchy up again)
-    ops_active = bool(agent.problem.multilevelOperatorBits()["active"])
+    ops_state = agent.problem.multilevelOperatorBits()
+    ops_active = bool(ops_state["active"])
     f1, g1 = cluster.central_cost_and_gradnorm()
 
     # ---- dominant-kernel roofline, measured live with HIP events on the solver's stream ----
@@ -742,7 +743,7 @@ def main():
         qb = nnzb_local * (8 * b_ * b_ + 4) + 4 * (n_local + 1)
         pbb = 8 * b_ * b_ * n_local
         Nc = ml_info["sizes"][-1] * b_
-        cbits = agent.problem.multilevelCoarseBits()
+        cbits = 32 if ops_state["dense"] else agent.problem.multilevelCoarseBits()  # (what the timed steps streamed)
         ml_info["coarse_inverse_bits"] = cbits
         # storage of the level-0 operator copies the cycle streams (symmetric Q in the restriction, A P in the
         # post-smoothing, prolongation blocks): fp32 copies by default on blocks that run the symmetric storage; every
@@ -983,10 +984,11 @@ def main():
                        "time_to_tolerance_ms": tt_main.get("ms") if tt_main.get("reached") else None,
                        "cycle_storage": ("tCG vectors, the Hessian step, smoother factors and dense level fp64; the "
                                          "multilevel cycle streams fp%d copies of its level-0 operators (symmetric Q, A P, "
-                                         "prolongation blocks) and keeps its two internal vectors (pre-smoothed iterate, "
-                                         "kept residual) in fp%d; fp64 arithmetic throughout" % (
-                                             ml_info["cycle_operator_copy_bits"],
-                                             64 if os.environ.get("DPGO_ML_VECTOR_BITS") == "64" else ml_info["cycle_operator_copy_bits"]))
+                                         "prolongation blocks), keeps its two internal vectors (pre-smoothed iterate, "
+                                         "kept residual) in fp%d and its dense level (inverse, restricted residual) in "
+                                         "fp%d; fp64 arithmetic throughout" % (
+                                             ml_info["cycle_operator_copy_bits"], 32 if ops_state["vectors"] else 64,
+                                             ml_info["coarse_inverse_bits"]))
                        if ml_info else None,
                        "hierarchy_setup_ms": tt_main.get("hierarchy_setup_ms"),
                        "time_to_tolerance_incl_setup_ms": tt_main.get("ms_incl_setup") if tt_main.get("reached") else None,

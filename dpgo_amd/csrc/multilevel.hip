@@ -499,10 +499,16 @@ int ml_numeric_setup_d(dpgo_problem_s* p) {
     hipLaunchKernelGGL(k_dense_pack_lower, dim3(nT, nT), dim3(kBlock), 0, p->stream, p->ml_dense, lda, p->ml_packed);
     HIPC(hipGetLastError());
   }
-  if (p->ml_coarse_bits == 32) {
+  {  // the fp32 storage of the inverse: what the cycle streams when the dense level is kept in fp32 -- by request
+     // (ml_coarse_bits == 32: the fp64 array then keeps the SAME rounded values, so that what dpgo_problem_multilevel_get
+     // returns is what the cycle applies) or together with the rest of the cycle's storage (coarse32_active: the fp64
+     // array stays exact, the cycle applies its rounding)
     const size_t total = (size_t)lda * (lda + 8);
-    hipLaunchKernelGGL(k_dense_round_f32, dim3(flat_grid(total)), dim3(kBlock), 0, p->stream, p->ml_dense, p->ml_dense32,
-                       total);
+    if (p->ml_coarse_bits == 32)
+      hipLaunchKernelGGL(k_dense_round_f32, dim3(flat_grid(total)), dim3(kBlock), 0, p->stream, p->ml_dense, p->ml_dense32,
+                         total);
+    else
+      hipLaunchKernelGGL(k_copy_f32, dim3(flat_grid(total)), dim3(kBlock), 0, p->stream, p->ml_dense, p->ml_dense32, total);
     HIPC(hipGetLastError());
   }
   return DPGO_OK;
@@ -660,7 +666,7 @@ int ml_ops32_ensure(dpgo_problem_s* p) {
 int persist_capacity(int device);  // (two resident slots per CU; below)
 int launch_coarse_prolong(dpgo_problem_s* p, const dpgo_problem_s::MlLevel& L, const dpgo_problem_s::MlLevel& C,
                           const DevState* gate, double* xc_out) {
-  const bool f32 = p->ml_coarse_bits == 32;
+  const bool f32 = p->coarse32_active();
   // nodes per workgroup (the right-hand side is read once per workgroup): 732 nodes: 1 -> 2: 19.7 -> 17.1 us, 4: 18.1;
   // three (fp64 storage) where that brings the level down to one workgroup per CU in one round: 546 nodes: 2 -> 3:
   // 273 -> 182 workgroups, 13.2 -> 11.6 us, the 100k bench step 4.45 -> 4.33 ms
@@ -741,7 +747,7 @@ int launch_ml_restrict0(dpgo_problem_s* p, const double* r, const DevState* gate
     stop.hflag = p->hflag;
     stop.gen = p->launch_gen();
   }
-  float* rc32 = (C.k == 0 && p->ml_coarse_bits == 32) ? reinterpret_cast<float*>(C.r) : (float*)nullptr;
+  float* rc32 = (C.k == 0 && p->coarse32_active()) ? reinterpret_cast<float*>(C.r) : (float*)nullptr;
   double* res_out = p->ml_use_ap() ? L.res1 : nullptr;
   const double* dnext = C.k ? C.dinv : (const double*)nullptr;
   if (p->ml_vec32_active()) {  // ... its fp32 copy (and the prolongation's), the cycle's internal vectors in fp32 as well
@@ -797,7 +803,7 @@ int launch_ml_tail(dpgo_problem_s* p, const double* Xdev, const double* r, doubl
   const int nl = (int)p->ml.size();
   // the dense level reads its right-hand side in the precision its inverse is stored in (same buffer)
   auto rc32_of = [&](const dpgo_problem_s::MlLevel& C) {
-    return (C.k == 0 && p->ml_coarse_bits == 32) ? reinterpret_cast<float*>(C.r) : (float*)nullptr;
+    return (C.k == 0 && p->coarse32_active()) ? reinterpret_cast<float*>(C.r) : (float*)nullptr;
   };
   auto A_of = [&](int l) { return l == 0 ? p->Q.dev() : p->ml[l].A.dev(); };
   auto r_of = [&](int l) { return l == 0 ? r : (const double*)p->ml[l].r; };
@@ -985,7 +991,8 @@ int dpgo_problem_multilevel_operator_bits(dpgo_problem_t p, int* bits, int* acti
     p->ml_operator_bits = *bits;
   }
   *bits = p->ml_operator_bits;
-  if (active) *active = p->ml_ops32_active() ? 1 : 0;  // (what the last solve's cycle streamed)
+  // (what the last solve's cycle streamed: 1 operator copies, 2 the cycle's internal vectors, 4 the dense level -- in fp32)
+  if (active) *active = (p->ml_ops32_active() ? 1 : 0) | (p->ml_vec32_active() ? 2 : 0) | (p->coarse32_active() ? 4 : 0);
   return DPGO_OK;
 }
 

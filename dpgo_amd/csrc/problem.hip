@@ -463,7 +463,7 @@ int dpgo_problem_describe(dpgo_problem_t p, char* out, int capacity) {
   if (!p->ml_symbolic) s += " none";
   for (size_t l = 0; l < p->ml.size(); ++l)
     s += " [" + std::to_string(p->ml[l].n) + " nodes" + (p->ml[l].k ? ", k=" + std::to_string(p->ml[l].graph ? -p->ml[l].k : p->ml[l].k) : ", dense") + "]";
-  s += std::string(p->ml_ready ? " built" : " not built") + ", dense level fp" + std::to_string(p->ml_coarse_bits) +
+  s += std::string(p->ml_ready ? " built" : " not built") + ", dense level fp" + std::to_string(p->coarse32_active() ? 32 : 64) +
        (p->ml_additive_layout ? ", additive layout" : "") + ", level-0 operator copies of the cycle fp" +
        std::to_string(p->ml_operator_bits) + (p->ml_ops32_active() ? " (in use)" : "") + "\n";
   s += std::string("  iteration graphs: ") + (p->iter_graph_failed ? "unavailable" : (p->iter_graph[0].exec || p->iter_graph[1].exec ? "captured" : "none yet")) + "\n";

@@ -314,7 +314,8 @@ unsigned long long iter_graph_key(const dpgo_problem_s* p, const double* dinv, b
   k.add((long long)p->ml_use_ap()), k.add((long long)p->ml_use_dense_sym()), k.add((long long)p->beyond_cache());
   k.add(p->ml_dense), k.add(p->ml_dense32), k.add(p->ml_packed), k.add(p->ml_pd), k.add(p->ml_pt), k.add(p->ml_chunks);
   k.add(p->ml_chunk_first), k.add((long long)p->ml_nchunks), k.add((long long)p->ml.size());
-  k.add((long long)p->ml_ops32_active()), k.add((long long)p->ml_vec32_active()), k.add(p->sym.uvalsT32);
+  k.add((long long)p->ml_ops32_active()), k.add((long long)p->ml_vec32_active()), k.add((long long)p->coarse32_active());
+  k.add(p->sym.uvalsT32);
   for (const auto& L : p->ml) {
     k.add((long long)L.n), k.add((long long)L.k), k.add((long long)L.split), k.add((long long)L.graph), k.add((long long)L.nseg);
     key_bsr(k, L.A), key_bsr(k, L.AP);

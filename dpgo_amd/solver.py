@@ -530,11 +530,11 @@ class QuadraticProblem:
 
     def multilevelOperatorBits(self, bits=None) -> dict:
         """Storage precision (32 or 64 bits) of the level-0 operator copies the V-cycle streams on HBM-bound blocks
-        (dpgo_problem_multilevel_operator_bits); an argument sets it.  {"bits", "active"}: active = the last solve's
-        cycle streamed the fp32 copies."""
+        (dpgo_problem_multilevel_operator_bits); an argument sets it.  {"bits", "active", "vectors", "dense"}: what the
+        last solve's cycle streamed in fp32 -- the operator copies, its two internal vectors, the dense level."""
         v, act = C.c_int(-1 if bits is None else int(bits)), C.c_int(0)
         L.check(self._lib.dpgo_problem_multilevel_operator_bits(self._h, C.byref(v), C.byref(act)))
-        return dict(bits=int(v.value), active=bool(act.value))
+        return dict(bits=int(v.value), active=bool(act.value & 1), vectors=bool(act.value & 2), dense=bool(act.value & 4))
 
     def setupMultilevel(self, ks=None, omega: float = 0.7, shift: float = 1e-1, coarse_bits=None) -> dict:
         """Explicit setup for the current Q: ks = aggregate sizes per coarsening (None: the library's defaults; a single

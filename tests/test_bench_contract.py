@@ -103,6 +103,7 @@ def test_bench_prints_one_valid_json_line():
     assert rf["multilevel"]["coarse_inverse_bits"] == 64  # the dense level of the headline configuration is fp64
     # the cycle's operator copies: fp32 only where the symmetric storage runs (blocks beyond the Infinity Cache), named in config
     assert rf["multilevel"]["cycle_operator_copy_bits"] == 64 and "fp64 copies" in j["config"]["cycle_storage"]
+    assert "dense level (inverse, restricted residual) in fp64" in j["config"]["cycle_storage"]
     assert all("products" in v for v in tt.values())
 
 

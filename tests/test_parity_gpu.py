@@ -762,7 +762,8 @@ def test_whole_solve_at_full_size_matches_oracle(oracle, storage):
             assert relerr(Xd.cpu().numpy(), Xo) < (1e-6 if dec < 1e-4 * abs(want[2]) else 1e-4), (precond, it)
             total += res.tcg_iterations
         if precond == "multilevel":
-            assert prob.multilevelOperatorBits()["active"] == (storage == "symmetric")
+            ob = prob.multilevelOperatorBits()
+            assert ob["active"] == ob["vectors"] == (storage == "symmetric") and ob["dense"] == (bits == 32)
         assert total > 40  # the calls reach the regime in which the tCG budget is actually used
 
 
@@ -2421,9 +2422,10 @@ def test_kernel_selecting_switches_match_oracle(oracle, workload):
             vbits = 64 if sw.get("DPGO_ML_VECTOR_BITS") == "64" else obits
             hier = list(ks)
             ks = ks + ((obits, vbits) if obits == 32 else ())
+            cbits = 32 if (obits == 32 and vbits == 32) else 64  # (the dense level follows the cycle's vectors)
             if ks not in want:
                 op = oracle.QuadraticProblem(Q, None, r, d, precond="amg", amg_k=hier, amg_operator_bits=obits,
-                                             amg_vector_bits=vbits)
+                                             amg_vector_bits=vbits, amg_coarse_bits=cbits)
                 rows, Xo = [], X0
                 for call in range(2):
                     oo = oracle.QuadraticOptimizer(op, oracle.ROptParameters(), hess_recurrence=True)
@@ -2446,7 +2448,8 @@ def test_kernel_selecting_switches_match_oracle(oracle, workload):
             digests[tuple(sorted(sw.items()))] = (mode, h.hexdigest())
             if "DPGO_SPMM_SYMMETRIC" in sw and n >= 40000:
                 assert prob.tcgKernelInfo()["symmetric"] == int(sw["DPGO_SPMM_SYMMETRIC"]), sw
-            assert prob.multilevelOperatorBits() == dict(bits=want_bits, active=(obits == 32)), sw
+            assert prob.multilevelOperatorBits() == dict(bits=want_bits, active=(obits == 32), vectors=(obits == 32 and vbits == 32),
+                                                         dense=(cbits == 32)), sw
             del opt, prob
     finally:
         for k, v in saved.items():
