@@ -139,7 +139,7 @@ inline int free_bsr(Bsr& m) {
   X(ml_early_stop,     "DPGO_ML_EARLY_STOP",      1,  "tCG's residual test in the restriction kernel, one kernel early")             \
   X(ml_operator_bits,  "DPGO_ML_OPERATOR_BITS",   0,  "level-0 operator copies of the cycle on HBM-bound blocks: 32 / 64 (0: 32)")   \
   X(ml_vector_bits,    "DPGO_ML_VECTOR_BITS",     0,  "cycle-internal vectors (pre-smoothed iterate, kept residual) beside fp32 operator copies: 32 / 64 (0: 32)") \
-  X(ml_dense_bits,     "DPGO_ML_DENSE_BITS",      0,  "dense level beside fp32 cycle vectors: 32 / 64 (0: 32)")                       \
+  X(ml_dense_bits,     "DPGO_ML_DENSE_BITS",      0,  "dense level beside fp32 cycle vectors: 32 / 64 (0: 64 -- fp32 measured neutral)") \
   X(ml_setup_serial,   "DPGO_ML_SETUP_SERIAL",    0,  "one-thread-per-aggregate set-up kernels of round 3")                          \
   X(gj_mfma,           "DPGO_GJ_MFMA",            1,  "rank-64 updates of the dense inverse on the fp64 matrix cores")               \
   X(dense_chunk,       "DPGO_DENSE_CHUNK",        0,  "tiles per workgroup of k_dense_sym_apply (0: default)")                       \
@@ -275,10 +275,12 @@ struct dpgo_problem_s {
   bool ml_ops32_active() const { return !ml_ops32_suspend && ml_ops32_wanted() && ml_ops32_ready; }
   bool ml_vec32_active() const { return ml_ops32_active() && options().ml_vector_bits != 64; }  // (x1 / res1 in fp32 too)
   // the dense level (the inverse of the coarsest operator and the restricted residual it multiplies) streamed in fp32: by
-  // request (ml_coarse_bits == 32) or with the rest of the cycle's storage on HBM-bound blocks -- unless the level runs on
-  // the packed-triangle matrix-core kernels, which exist in fp64 only
+  // request per handle (ml_coarse_bits == 32) or, with the rest of the cycle's fp32 storage, by DPGO_ML_DENSE_BITS=32 --
+  // unless the level runs on the packed-triangle matrix-core kernels, which exist in fp64 only.  NOT the default: at 100k
+  // poses the dense kernel itself gets faster (11.8 -> 9.3 us), the loop does not (136.0 against 135.6 us per product, three
+  // interleaved pairs: the 19 MB it frees in the Infinity Cache change nothing the other kernels notice).
   bool coarse32_active() const {
-    return ml_coarse_bits == 32 || (ml_vec32_active() && !ml_use_dense_sym() && options().ml_dense_bits != 64);
+    return ml_coarse_bits == 32 || (ml_vec32_active() && !ml_use_dense_sym() && options().ml_dense_bits == 32);
   }
   int ml_lda = 0;
   double *ml_W = nullptr, *ml_Rx = nullptr;  // Gauss-Jordan panels (setup only)

@@ -288,9 +288,9 @@ int dpgo_problem_multilevel_coarse_bits(dpgo_problem_t h, int* bits);
  * the tCG vectors, the Hessian step, the hierarchy's set-up, the smoother's factors, the dense level and every product and
  * sum stay fp64; the optimum does not depend on it, the products to the tolerance are the same (100 000-pose grid: 70
  * either way, 152 -> 138 us each); 64 (or DPGO_ML_OPERATOR_BITS=64) streams the fp64 originals (DPGO_ML_VECTOR_BITS=64: fp32
- * operator copies, fp64 vectors -- the A/B of the two halves).  With the vectors the DENSE LEVEL goes to fp32 storage as
- * well (the inverse of the coarsest operator and the restricted residual it multiplies; what
- * dpgo_problem_multilevel_coarse_bits(32) requests by itself) unless it runs on the packed-triangle matrix-core kernels.
+ * operator copies, fp64 vectors -- the A/B of the two halves).  The DENSE LEVEL (the inverse of the coarsest operator and
+ * the restricted residual it multiplies) stays fp64 unless dpgo_problem_multilevel_coarse_bits(32) or DPGO_ML_DENSE_BITS=32
+ * asks otherwise (measured neutral for the loop at 100 000 poses).
  * *active is a mask: 1 = operator copies, 2 = internal vectors, 4 = dense level streamed in fp32 by the last solve.  A negative input only queries; *active (optional) = 1 if the last
  * solve's cycle streamed the fp32 copies.  The oracle mirrors the storage (amg_operator_bits). */
 int dpgo_problem_multilevel_operator_bits(dpgo_problem_t h, int* bits, int* active);

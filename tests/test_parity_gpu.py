@@ -2361,6 +2361,7 @@ SWITCH_SETS = [
     ({"DPGO_ITER_GRAPH": "1"}, "bitwise"),         # steady tCG iterations replayed from an instantiated hipGraph
     ({"DPGO_SPMM_SYMMETRIC": "1", "DPGO_ML_OPERATOR_BITS": "64"}, "oracle"),  # the cycle streams the fp64 operators (sym. storage)
     ({"DPGO_SPMM_SYMMETRIC": "1", "DPGO_ML_VECTOR_BITS": "64"}, "oracle"),    # fp32 operator copies, fp64 vectors inside the cycle
+    ({"DPGO_SPMM_SYMMETRIC": "1", "DPGO_ML_DENSE_BITS": "32"}, "oracle"),     # ... and the dense level in fp32 as well
     ({"DPGO_SPMM_SYMMETRIC": "1"}, "oracle"),      # symmetric storage of Q: k_tcg_hess_sym, level-0 restriction / post-smoothing
     ({"DPGO_SPMM_SYMMETRIC": "1", "DPGO_OUTER_SYM": "0", "DPGO_STREAM_NT": "1"}, "oracle"),  # outer iteration on the plain copy
     ({"DPGO_SPMM_SYMMETRIC": "1", "DPGO_TILE_WALK": "0"}, "oracle"),  # symmetric-storage kernels walk their tiles in index order
@@ -2421,8 +2422,8 @@ def test_kernel_selecting_switches_match_oracle(oracle, workload):
             obits = want_bits if (sw.get("DPGO_SPMM_SYMMETRIC") == "1" and n >= 40000) else 64
             vbits = 64 if sw.get("DPGO_ML_VECTOR_BITS") == "64" else obits
             hier = list(ks)
-            ks = ks + ((obits, vbits) if obits == 32 else ())
-            cbits = 32 if (obits == 32 and vbits == 32) else 64  # (the dense level follows the cycle's vectors)
+            cbits = 32 if (obits == 32 and vbits == 32 and sw.get("DPGO_ML_DENSE_BITS") == "32") else 64
+            ks = ks + ((obits, vbits, cbits) if obits == 32 else ())
             if ks not in want:
                 op = oracle.QuadraticProblem(Q, None, r, d, precond="amg", amg_k=hier, amg_operator_bits=obits,
                                              amg_vector_bits=vbits, amg_coarse_bits=cbits)
