@@ -1054,9 +1054,24 @@ __global__ __launch_bounds__(kBlock, 1) void k_rtr_persist(BsrDev Q, double* X, 
 // the trial-point buffer becomes the caller's X -- if and only if the launch completed on EVERY participant (state record
 // not poisoned, no time-out flag) and a step was accepted.  A late time-out of some workgroups therefore leaves X exactly as
 // the caller passed it, whatever the others had finished.
+// It also REPORTS: workgroup 0 writes the state record and the control block into the handle's host-coherent pinned copies
+// (hst, hct: NULL = not wanted), which the host reads after synchronising the stream -- two copy commands (and their
+// boundaries) less behind every one-launch solve.
 static __global__ __launch_bounds__(kBlock) void k_persist_commit(const DevState* __restrict__ st, const PersistCtrl* __restrict__ ctrl,
                                                            const double* __restrict__ xfin, double* __restrict__ X,
-                                                           size_t count) {
+                                                           size_t count, DevState* hst = nullptr, PersistCtrl* hct = nullptr) {
+  if (blockIdx.x == 0 && threadIdx.x == 0 && hst && hct) {
+#define X(f) hst->f = st->f;
+    DPGO_STATE_FIELDS(X)
+#undef X
+    hct->error = ctrl->error;
+    hct->iters = ctrl->iters;
+    hct->members = ctrl->members;
+    hct->pad = ctrl->pad;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) hct->ticks[q] = ctrl->ticks[q];
+    __threadfence_system();
+  }
   if (st->rtr_stop == kPersistPoison || ctrl->error || st->n_accept <= 0) return;
   // (8-byte pieces: a caller's device pointer is only promised to be aligned for doubles; at most 5 MB)
   for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < count; i += (size_t)gridDim.x * kBlock) X[i] = xfin[i];

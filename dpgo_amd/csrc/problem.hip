@@ -410,11 +410,12 @@ int dpgo_problem_create(dpgo_problem_t* out, int r, int d, int n, int device) {
     HIPC(hipMalloc(&p->partials, sizeof(double) * 5 * kPartialCap * kNP));
     HIPC(hipMemsetAsync(p->partials, 0, sizeof(double) * 5 * kPartialCap * kNP, p->stream));
     HIPC(hipMalloc(&p->dstate, sizeof(DevState) * 2));
-    HIPC(hipHostMalloc(&p->hstate, sizeof(DevState)));
+    // (host-coherent, device-visible: the one-launch solve's commit kernel writes its report straight into them)
+    HIPC(hipHostMalloc(&p->hstate, sizeof(DevState), hipHostMallocCoherent | hipHostMallocMapped));
     HIPC(hipMalloc(&p->pctrl, sizeof(PersistCtrl)));
     HIPC(hipMalloc(&p->pgran, sizeof(unsigned long long) * kGranWords));
     HIPC(hipMemsetAsync(p->pgran, 0, sizeof(unsigned long long) * kGranWords, p->stream));
-    HIPC(hipHostMalloc(&p->hctrl, sizeof(PersistCtrl)));
+    HIPC(hipHostMalloc(&p->hctrl, sizeof(PersistCtrl), hipHostMallocCoherent | hipHostMallocMapped));
     CHK(tune_persist(p));
     HIPC(hipHostMalloc(&p->hflag, 64, hipHostMallocCoherent | hipHostMallocMapped));
     *p->hflag = 0ull;

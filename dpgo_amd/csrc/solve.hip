@@ -256,7 +256,10 @@ int launch_rtr_persistent(dpgo_problem_s* p, const dpgo_ropt_params* prm, const 
   {  // the iterate reaches the caller's X only if the launch completed on every participant (k_persist_commit)
     const size_t count = (size_t)p->n * p->T;
     const int grid = (int)std::min<size_t>(1024, (count + kBlock - 1) / kBlock);
-    hipLaunchKernelGGL(k_persist_commit, dim3(grid), dim3(kBlock), 0, p->stream, p->dstate, p->pctrl, p->x2, p->x1, count);
+    // (p->cur = 0 below: dstate[0] is the record the solve leaves; the commit kernel also writes it and the control block
+    // into the host-coherent copies the caller reads after synchronising)
+    hipLaunchKernelGGL(k_persist_commit, dim3(grid), dim3(kBlock), 0, p->stream, p->dstate, p->pctrl, p->x2, p->x1, count,
+                       p->hstate, p->hctrl);
   }
   HIPC(hipGetLastError());
   p->cur = 0;
@@ -641,8 +644,7 @@ int run_optimize(dpgo_problem_s* p, const dpgo_ropt_params* prm, dpgo_ropt_resul
     if (!resume) CHK(launch_rtr_persistent(p, prm, dinv, &used, add));
     if (used) {
       if (!resume) {
-        HIPC(hipMemcpyAsync(p->hctrl, p->pctrl, sizeof(PersistCtrl), hipMemcpyDeviceToHost, p->stream));
-        HIPC(hipMemcpyAsync(p->hstate, p->dstate + p->cur, sizeof(DevState), hipMemcpyDeviceToHost, p->stream));
+        // (no read-back commands: k_persist_commit has written the state record and the control block into hstate / hctrl)
         if (phase == RUN_BEGIN) {  // everything of the solve is enqueued: the caller collects it with RUN_END
           auto& pd = p->pending;
           pd.launched = true;
