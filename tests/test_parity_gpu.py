@@ -798,6 +798,22 @@ def test_symmetric_storage_solve_2d_matches_oracle(oracle):
             dec = abs(res.fInit - res.fOpt)
             assert abs(res.fOpt - ro.fOpt) <= 1e-9 * abs(ro.fOpt) + 1e-4 * dec, (storage, it)
             assert relerr(Xd.cpu().numpy(), Xw) < 1e-5, (storage, it)
+    # ... and the multilevel cycle on the symmetric storage in 2-D (three lanes per pose, 12-double tiles): its fp32 storage
+    # (operator copies and internal vectors, the default there) against the fp64 originals -- the same solve to round-off
+    # of the preconditioner: same counts, cost to 1e-8, iterate to 1e-6
+    assert prob.setSpmmVariant("symmetric") == "symmetric"
+    outs = {}
+    for bits in (32, 64):
+        prob.multilevelOperatorBits(bits)
+        opt = dpgo_amd.QuadraticOptimizer(prob, dpgo_amd.ROptParameters(precond="multilevel"))
+        Xd = torch.tensor(X0, device="cuda", dtype=torch.float64)
+        res = opt.optimizeDevice(Xd)
+        ob = prob.multilevelOperatorBits()
+        assert res.precond_used == "multilevel" and ob["active"] == ob["vectors"] == (bits == 32), (bits, ob)
+        outs[bits] = (res, Xd.cpu().numpy())
+    (r32, X32), (r64, X64) = outs[32], outs[64]
+    assert (r32.tcg_iterations, r32.rtr_iterations, r32.tCGStatus) == (r64.tcg_iterations, r64.rtr_iterations, r64.tCGStatus)
+    assert r32.fOpt < r32.fInit and abs(r32.fOpt - r64.fOpt) <= 1e-8 * abs(r64.fOpt) and relerr(X32, X64) < 1e-6
 
 
 @pytest.mark.parametrize("name,r,precond,layout", [
