@@ -131,8 +131,17 @@ __device__ __forceinline__ TileIter tile_iter(int ntiles) {
 #ifndef DPGO_LB_HESS
 #define DPGO_LB_HESS 1
 #endif
+#ifndef DPGO_HESS_BATCH
+#define DPGO_HESS_BATCH 4  // blocks whose loads the gather of k_tcg_hess_sym issues before the first FMA (spmm_sym_pre's NB)
+#endif
+#ifndef DPGO_RESTRICT_WAVES
+#define DPGO_RESTRICT_WAVES 4  // waves per SIMD k_ml_restrict (one pose per D+1 lanes) is compiled for
+#endif
+#ifndef DPGO_GATHER_BATCH
+#define DPGO_GATHER_BATCH 1  // the same for the other kernels on the symmetric storage (q_gather: restriction, one-launch solve)
+#endif
 #ifndef DPGO_SYM_WAVES
-#define DPGO_SYM_WAVES 3  // waves per SIMD k_tcg_hess_sym is compiled for (<= 168 VGPRs)
+#define DPGO_SYM_WAVES 2  // waves per SIMD k_tcg_hess_sym is compiled for (<= 256 VGPRs; 3 with DPGO_HESS_BATCH=1)
 #endif
 #ifndef DPGO_LB_UPDATE
 #define DPGO_LB_UPDATE 1
@@ -140,7 +149,20 @@ __device__ __forceinline__ TileIter tile_iter(int ntiles) {
 // Optional in-kernel timeline (diagnostic builds only, -DDPGO_TIMELINE): workgroup 0 / lane 0 stamps the 100 MHz
 // wall clock at phase boundaries of the two tCG kernels into a global array read back by dpgo_debug_timeline.
 #ifdef DPGO_TIMELINE
-__device__ long long g_timeline[2][16];
+static __device__ long long g_timeline[2][16];
+// k_tcg_hess_sym, per tile: wave 0 of the first / middle / last workgroup stamps entry [0], prologue done [1], end [2] and,
+// for its t-th tile, slots 4 + 6 t + I (I: 0 top of the loop, 1 LDS staged, 2 gather done, 3 own pieces requested + sync,
+// 4 projected, 5 stored + next tile requested)
+static __device__ long long g_tl_tiles[3][64];
+#define DPGO_TL_TILES_DECL                                                                                              \
+  const int tlw_ = blockIdx.x == 0 ? 0 : (blockIdx.x == gridDim.x / 2 ? 1 : (blockIdx.x == gridDim.x - 1 ? 2 : -1)); \
+  int tlt_ = 0;                                                                                                         \
+  const long long tle_ = wall_clock64()
+#define DPGO_STAMP_ENTRY do { if (tlw_ >= 0 && threadIdx.x == 0) g_tl_tiles[tlw_][0] = tle_; } while (0)  // (launches that run)
+#define DPGO_STAMP_AT(SLOT) do { if (tlw_ >= 0 && threadIdx.x == 0 && (SLOT) < 64) g_tl_tiles[tlw_][SLOT] = wall_clock64(); } while (0)
+#define DPGO_STAMP_TILE(I) DPGO_STAMP_AT(4 + 6 * tlt_ + (I))
+#define DPGO_TILE_NEXT ++tlt_
+#define DPGO_TL_USE(X) asm volatile("" ::"v"(X))  // (a stamp behind it is not scheduled ahead of X's producers)
 #define DPGO_TL_DECL long long tl_[8] = {0, 0, 0, 0, 0, 0, 0, 0}
 #define DPGO_STAMP(K, I) tl_[I] = wall_clock64()
 #define DPGO_COMMIT(K)                                     \
@@ -150,6 +172,12 @@ __device__ long long g_timeline[2][16];
   } while (0)
 #else
 #define DPGO_TL_DECL do { } while (0)
+#define DPGO_TL_TILES_DECL do { } while (0)
+#define DPGO_STAMP_AT(SLOT) do { } while (0)
+#define DPGO_STAMP_ENTRY do { } while (0)
+#define DPGO_STAMP_TILE(I) do { } while (0)
+#define DPGO_TILE_NEXT do { } while (0)
+#define DPGO_TL_USE(X) do { } while (0)
 #define DPGO_STAMP(K, I) do { } while (0)
 #define DPGO_COMMIT(K) do { } while (0)
 #endif
@@ -659,7 +687,8 @@ __device__ __forceinline__ SymIdx sym_idx_load(const BsrSymDevT<VT>& Q, int i, i
 }
 // wave-cooperative (all 64 lanes); out = row c of (Q V)_i for the lane (g, c) of pose i
 // XT: storage type of the gathered vector (double; float for the cycle-internal vectors kept in fp32)
-template <int D, int R, class VT, class XT = double>
+// NB: blocks whose loads are in flight together (registers: NB (D+1+R) doubles)
+template <int D, int R, int NB_ = 1, class VT, class XT = double>
 __device__ __forceinline__ void spmm_sym_pre(const SymIdx& si, const BsrSymDevT<VT>& Q, const XT* __restrict__ V, int c,
                                              double (&out)[R]) {
   constexpr int B = D + 1, T = B * R, BB = B * B;
@@ -686,13 +715,32 @@ __device__ __forceinline__ void spmm_sym_pre(const SymIdx& si, const BsrSymDevT<
 #pragma unroll
       for (int a = 0; a < R; ++a) acc[cc][a] = fma(xc[a], q[cc], acc[cc][a]);
   };
-  for (int k = 0; k < lu; ++k) {  // upper blocks: column c of Q[i,j] = row c of the transposed storage
-    const int j = __shfl(si.ju, gbase + k);
-    if (k < du) {
-      double q[B];
+  // The first B upper blocks and lower references: all addresses are known up front (u0 + k, and the preloaded j / slot),
+  // so the loads of NB blocks are issued back to back before the first FMA -- one memory round trip per NB blocks instead of
+  // one per block (the accumulation order is unchanged: results are bit-identical for every NB).
+  constexpr int NB = NB_ < B ? NB_ : B;
+  for (int k0 = 0; k0 < lu; k0 += NB) {  // upper blocks: column c of Q[i,j] = row c of the transposed storage
+    double q[NB][B], xc[NB][R];
 #pragma unroll
-      for (int pp = 0; pp < B; ++pp) q[pp] = (double)Q.uvalsT[(size_t)(u0 + k) * BB + c * B + pp];
-      fma_block(q, j);
+    for (int b = 0; b < NB; ++b) {
+      const int k = k0 + b;
+      const int j = __shfl(si.ju, gbase + (k < B ? k : 0));
+      if (k < B && k < du) {
+#pragma unroll
+        for (int pp = 0; pp < B; ++pp) q[b][pp] = (double)Q.uvalsT[(size_t)(u0 + k) * BB + c * B + pp];
+#pragma unroll
+        for (int a = 0; a < R; ++a) xc[b][a] = (double)V[(size_t)j * T + c * R + a];
+      }
+    }
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      const int k = k0 + b;
+      if (k < B && k < du) {
+#pragma unroll
+        for (int cc = 0; cc < B; ++cc)
+#pragma unroll
+          for (int a = 0; a < R; ++a) acc[cc][a] = fma(xc[b][a], q[b][cc], acc[cc][a]);
+      }
     }
   }
   for (int t = u0 + B; t < u0 + du; ++t) {
@@ -701,14 +749,29 @@ __device__ __forceinline__ void spmm_sym_pre(const SymIdx& si, const BsrSymDevT<
     for (int pp = 0; pp < B; ++pp) q[pp] = (double)Q.uvalsT[(size_t)t * BB + c * B + pp];
     fma_block(q, Q.ucol[t]);
   }
-  for (int k = 0; k < ll; ++k) {  // lower references: column c of Q[i,j] = row c of Q[j,i] = strided in its storage
-    const int j = __shfl(si.jl, gbase + k);
-    const int sb = __shfl(si.sl, gbase + k);
-    if (k < dl) {
-      double q[B];
+  for (int k0 = 0; k0 < ll; k0 += NB) {  // lower references: column c of Q[i,j] = row c of Q[j,i] = strided in its storage
+    double q[NB][B], xc[NB][R];
 #pragma unroll
-      for (int pp = 0; pp < B; ++pp) q[pp] = (double)Q.uvalsT[(size_t)sb * BB + pp * B + c];
-      fma_block(q, j);
+    for (int b = 0; b < NB; ++b) {
+      const int k = k0 + b;
+      const int j = __shfl(si.jl, gbase + (k < B ? k : 0));
+      const int sb = __shfl(si.sl, gbase + (k < B ? k : 0));
+      if (k < B && k < dl) {
+#pragma unroll
+        for (int pp = 0; pp < B; ++pp) q[b][pp] = (double)Q.uvalsT[(size_t)sb * BB + pp * B + c];
+#pragma unroll
+        for (int a = 0; a < R; ++a) xc[b][a] = (double)V[(size_t)j * T + c * R + a];
+      }
+    }
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      const int k = k0 + b;
+      if (k < B && k < dl) {
+#pragma unroll
+        for (int cc = 0; cc < B; ++cc)
+#pragma unroll
+          for (int a = 0; a < R; ++a) acc[cc][a] = fma(xc[b][a], q[b][cc], acc[cc][a]);
+      }
     }
   }
   for (int t = l0 + B; t < l0 + dl; ++t) {
@@ -732,6 +795,6 @@ __device__ __forceinline__ void q_gather(const BsrSymDevT<VT>& A, const XT* __re
                                          double (&h)[R]) {
   static_assert(SPLIT == 1, "symmetric storage: one node per D+1 lanes");
   const SymIdx si = sym_idx_load<D>(A, i, c, okp);
-  spmm_sym_pre<D, R>(si, A, V, c, h);
+  spmm_sym_pre<D, R, DPGO_GATHER_BATCH>(si, A, V, c, h);
 }
 

@@ -72,10 +72,17 @@ struct TcgStopCheck {
   unsigned long long* hflag = nullptr;
   unsigned gen = 0;
 };
+// Waves per SIMD the restriction is compiled for.  One pose per D+1 lanes: 4 (<= 128 VGPRs), because the grid is sized
+// for 4 resident workgroups per CU (1 024: the 1 563 tiles of the 100k block in two rounds) and the symmetric-storage
+// variants came out at 130 VGPRs = 3 per CU, i.e. a quarter of the grid waited for a slot.
+template <int D, int R, int SPLIT>
+struct RestrictWaves {
+  static constexpr int kMin = (SPLIT == 1 && D == 3 && R <= 5) ? DPGO_RESTRICT_WAVES : 1;  // (121 .. 130 VGPRs without)
+};
 // PT: storage type of the prolongation blocks (float with the fp32 operator copies of the cycle, like MAT's values);
 // XT: storage type of the cycle-internal vectors x1 (read: own tile + gather) and res_out (written) -- float with them
 template <int D, int R, int SPLIT, class MAT = BsrDev, class PT = double, class XT = double>
-__global__ __launch_bounds__(kBlock) void k_ml_restrict(MAT A, const XT* __restrict__ x1,
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(RestrictWaves<D, R, SPLIT>::kMin, 8))) void k_ml_restrict(MAT A, const XT* __restrict__ x1,
                                                         const double* __restrict__ r, const PT* __restrict__ Pb,
                                                         double shift, int k, double* __restrict__ rc,
                                                         float* __restrict__ rc32,

@@ -360,8 +360,14 @@ __global__ __launch_bounds__(kBlock) void k_tcg_hess_span(BsrDev Q, const double
 }
 
 // k_tcg_hess_span on the symmetric storage of Q (spmm_sym_pre, common.h): big blocks only (one pose per D+1 lanes).  The
-// own-tile pieces of delta / H delta are requested after the gather instead of one tile ahead and z is re-read from LDS, so
-// that the outer-product accumulators fit without losing an occupancy step.
+// own-tile pieces of delta / H delta are requested after the gather instead of one tile ahead and z is re-read from LDS
+// (registers).  The gather keeps the loads of DPGO_HESS_BATCH blocks in flight per wave, which costs the third wave per SIMD
+// (217 VGPRs) and still wins: 2 waves x 4 blocks in flight against 3 x 1 (39.7 -> 37.3 us).  In-kernel timeline of a tile
+// (tools/timeline_tiles.py, profiles/r05_v4_timeline_tiles.txt): ~8 us, of which the gather's two round trips 3 us and the
+// epilogue behind it 4 us.  Tried on top and measured neutral, i.e. the launch is bound by what the memory system
+// delivers to 512 resident workgroups, not by one wave's chain of round trips: delta / H delta requested in front of the
+// gather (37.4..37.7 us), a three-stage pipeline over the tiles (row extents two tiles ahead, indices + own X, z, S one tile
+// ahead: tile 7 us, launch 37.4..38.0 us), the previous kernel's partial sums requested in front of the first tile.
 template <int D, int R, int NTS>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(DPGO_SYM_WAVES, DPGO_SYM_WAVES))) void k_tcg_hess_sym(BsrSymDev Q, const double* __restrict__ X,
                                                           const double* __restrict__ S, const double* __restrict__ z,
@@ -420,6 +426,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(DPGO_SYM
   // occupancy step), then the first tile.  A small-block launch is a chain of dependent memory round trips
   // (rocprof: 9.4 us for 2500 poses); this takes two of them off the chain.
   DPGO_TL_DECL;
+  DPGO_TL_TILES_DECL;
   DPGO_STAMP(0, 0);
   DevState st;
   load_state(st, sin);
@@ -446,9 +453,12 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(DPGO_SYM
   }
   if (!go) return;
   DPGO_STAMP(0, 2);
+  DPGO_STAMP_ENTRY;
+  DPGO_STAMP_AT(1);
 
   double part[1] = {0.0};
   while (have) {
+    DPGO_STAMP_TILE(0);
 #pragma unroll
     for (int it = 0; it < SPN::NIT; ++it) {
       const int pc = lane + 64 * it;
@@ -458,8 +468,11 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(DPGO_SYM
       }
     }
     DPGO_STAMP(0, 3);
+    DPGO_STAMP_TILE(1);
     double h[R];
-    spmm_sym_pre<D, R>(si, Q, z, L.c, h);
+    spmm_sym_pre<D, R, DPGO_HESS_BATCH>(si, Q, z, L.c, h);
+    DPGO_TL_USE(h[0]);
+    DPGO_STAMP_TILE(2);
     // delta, H delta of the own tile: requested after the gather (its accumulators need the registers), consumed after
     // the projection
     dbl2 dv[SPN::NIT], hv[SPN::NIT];
@@ -478,6 +491,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(DPGO_SYM
     }
     wave_sync();
     DPGO_STAMP(0, 4);
+    DPGO_STAMP_TILE(3);
     if (ok) {
       if (L.c < D) {
         const double* vt = vs + L.g * GEO::T;
@@ -496,6 +510,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(DPGO_SYM
       store_col<R>(os + L.g * GEO::T + L.c * R, hz);
     }
     wave_sync();
+    DPGO_STAMP_TILE(4);
     {
       const size_t base = (size_t)p0 * GEO::T;
       dbl2* d2 = reinterpret_cast<dbl2*>(delta + base);
@@ -530,9 +545,12 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(DPGO_SYM
     tile += ti_.step;
     have = tile < ti_.last;
     if (have) prefetch(tile);
+    DPGO_STAMP_TILE(5);
+    DPGO_TILE_NEXT;
   }
   store_partials<1>(part, pout, red);
   DPGO_STAMP(0, 6);
+  DPGO_STAMP_AT(2);
   DPGO_COMMIT(0);
 }
 

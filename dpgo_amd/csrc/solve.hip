@@ -821,8 +821,22 @@ int tune_launch_caps(dpgo_problem_s* p) {
       CHK(resident_blocks(k_ml_restrict<D, R, 2, BsrDev>, &p->cap_restrict));
       CHK(resident_blocks(k_ml_post_ap<D, R, 2>, &p->cap_post));
     } else {
+      // one pose per D+1 lanes: the smallest count over the variants a cycle may launch (plain / symmetric storage, fp64 /
+      // fp32 copies) -- a grid sized for a variant with more resident workgroups than the launched one leaves part of it
+      // waiting for a slot
+      int c = 0;
       CHK(resident_blocks(k_ml_restrict<D, R, 1, BsrDev>, &p->cap_restrict));
+      CHK(resident_blocks(k_ml_restrict<D, R, 1, BsrSymDev, double, double>, &c));
+      p->cap_restrict = std::min(p->cap_restrict, c);
+      CHK(resident_blocks(k_ml_restrict<D, R, 1, BsrSymDev32, float, float>, &c));
+      p->cap_restrict = std::min(p->cap_restrict, c);
+      CHK(resident_blocks(k_ml_restrict<D, R, 1, BsrSymDev32, float, double>, &c));
+      p->cap_restrict = std::min(p->cap_restrict, c);
       CHK(resident_blocks(k_ml_post_ap<D, R, 1>, &p->cap_post));
+      CHK(resident_blocks(k_ml_post_ap<D, R, 1, float, float>, &c));
+      p->cap_post = std::min(p->cap_post, c);
+      CHK(resident_blocks(k_ml_post_ap<D, R, 1, float, double>, &c));
+      p->cap_post = std::min(p->cap_post, c);
     }
   });
   if (options().grid_ml > 0) p->cap_restrict = p->cap_post = std::min(kPartialCap, options().grid_ml);
@@ -1133,6 +1147,11 @@ int dpgo_problem_eval_terms_device_many(int count, const dpgo_problem_t* handles
 int dpgo_debug_timeline(long long* out /* [2][16] */) {
   HIPC(hipDeviceSynchronize());
   HIPC(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_timeline), sizeof(long long) * 32));
+  return DPGO_OK;
+}
+int dpgo_debug_timeline_tiles(long long* out /* [3][64] */) {
+  HIPC(hipDeviceSynchronize());
+  HIPC(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_tl_tiles), sizeof(long long) * 3 * 64));
   return DPGO_OK;
 }
 #endif
