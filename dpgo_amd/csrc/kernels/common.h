@@ -150,17 +150,24 @@ __device__ __forceinline__ TileIter tile_iter(int ntiles) {
 // wall clock at phase boundaries of the two tCG kernels into a global array read back by dpgo_debug_timeline.
 #ifdef DPGO_TIMELINE
 static __device__ long long g_timeline[2][16];
-// k_tcg_hess_sym, per tile: wave 0 of the first / middle / last workgroup stamps entry [0], prologue done [1], end [2] and,
-// for its t-th tile, slots 4 + 6 t + I (I: 0 top of the loop, 1 LDS staged, 2 gather done, 3 own pieces requested + sync,
-// 4 projected, 5 stored + next tile requested)
+// Per tile: wave 0 of the first / middle / last workgroup stamps entry [0], prologue done [1], end [2] and, for its t-th
+// tile, slots 4 + 6 t + I.  k_tcg_hess_sym (g_tl_tiles; I: 0 top of the loop, 1 LDS staged, 2 gather done, 3 own pieces
+// requested + sync, 4 projected, 5 stored + next tile requested), k_ml_restrict (g_tl_restrict; I: 0 top, 1 gather done,
+// 2 residual staged, 3 P^T res staged, 4 run sums written, 5 tile done), k_ml_post_ap (g_tl_post; I: 0 top, 1 gather done,
+// 2 own rows staged, 3 smoothed + prolonged, 4 staged again, 5 projected + stored).
 static __device__ long long g_tl_tiles[3][64];
+static __device__ long long g_tl_restrict[3][64];
+static __device__ long long g_tl_post[3][64];
 #define DPGO_TL_TILES_DECL                                                                                              \
   const int tlw_ = blockIdx.x == 0 ? 0 : (blockIdx.x == gridDim.x / 2 ? 1 : (blockIdx.x == gridDim.x - 1 ? 2 : -1)); \
   int tlt_ = 0;                                                                                                         \
   const long long tle_ = wall_clock64()
-#define DPGO_STAMP_ENTRY do { if (tlw_ >= 0 && threadIdx.x == 0) g_tl_tiles[tlw_][0] = tle_; } while (0)  // (launches that run)
-#define DPGO_STAMP_AT(SLOT) do { if (tlw_ >= 0 && threadIdx.x == 0 && (SLOT) < 64) g_tl_tiles[tlw_][SLOT] = wall_clock64(); } while (0)
-#define DPGO_STAMP_TILE(I) DPGO_STAMP_AT(4 + 6 * tlt_ + (I))
+#define DPGO_STAMP_ENTRY_IN(ARR) do { if (tlw_ >= 0 && threadIdx.x == 0) ARR[tlw_][0] = tle_; } while (0)  // (launches that run)
+#define DPGO_STAMP_AT_IN(ARR, SLOT) do { if (tlw_ >= 0 && threadIdx.x == 0 && (SLOT) < 64) ARR[tlw_][SLOT] = wall_clock64(); } while (0)
+#define DPGO_STAMP_TILE_IN(ARR, I) DPGO_STAMP_AT_IN(ARR, 4 + 6 * tlt_ + (I))
+#define DPGO_STAMP_ENTRY DPGO_STAMP_ENTRY_IN(g_tl_tiles)
+#define DPGO_STAMP_AT(SLOT) DPGO_STAMP_AT_IN(g_tl_tiles, SLOT)
+#define DPGO_STAMP_TILE(I) DPGO_STAMP_TILE_IN(g_tl_tiles, I)
 #define DPGO_TILE_NEXT ++tlt_
 #define DPGO_TL_USE(X) asm volatile("" ::"v"(X))  // (a stamp behind it is not scheduled ahead of X's producers)
 #define DPGO_TL_DECL long long tl_[8] = {0, 0, 0, 0, 0, 0, 0, 0}
@@ -175,6 +182,9 @@ static __device__ long long g_tl_tiles[3][64];
 #define DPGO_TL_TILES_DECL do { } while (0)
 #define DPGO_STAMP_AT(SLOT) do { } while (0)
 #define DPGO_STAMP_ENTRY do { } while (0)
+#define DPGO_STAMP_ENTRY_IN(ARR) do { } while (0)
+#define DPGO_STAMP_AT_IN(ARR, SLOT) do { } while (0)
+#define DPGO_STAMP_TILE_IN(ARR, I) do { } while (0)
 #define DPGO_STAMP_TILE(I) do { } while (0)
 #define DPGO_TILE_NEXT do { } while (0)
 #define DPGO_TL_USE(X) do { } while (0)

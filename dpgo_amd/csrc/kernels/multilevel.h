@@ -96,7 +96,9 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(Restrict
   // are written out instead of the aggregate's sum -- to the slots tpos encodes, ordered by aggregate, so that
   // k_ml_agg_sum reads every aggregate's partial sums as one contiguous run
   using GEO = Geo<D, R, SPLIT>;
+  DPGO_TL_TILES_DECL;
   if (gate && (gate->tcg_done || gate->rtr_stop)) return;
+  DPGO_STAMP_ENTRY_IN(g_tl_restrict);
   __shared__ double res_s[kWaves][GEO::G][GEO::T];  // residual tiles (per wave)
   __shared__ double t_s[GEO::P][GEO::T];            // P_i^T res_i of every node of the workgroup tile
   const LaneId L = lane_id<D, SPLIT>();
@@ -123,7 +125,9 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(Restrict
     }
     __syncthreads();  // (t_s is reused by the tiles below)
   }
+  DPGO_STAMP_AT_IN(g_tl_restrict, 1);
   for (int tk = ti_.first; tk < ti_.last; tk += ti_.step) {
+    DPGO_STAMP_TILE_IN(g_tl_restrict, 0);
     const int tile = tile_of(A, tk);
     const int lp = L.wave * GEO::G + L.g;  // node slot inside the workgroup tile
     const int i = tile * GEO::P + lp;
@@ -131,8 +135,13 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(Restrict
     const bool ok = okp && (L.s == 0);
     const size_t off = (size_t)i * GEO::T + L.c * R;
     // (loading the own rows BEFORE the gather was tried and is slower: 35.3 -> 44.3 us at 100k poses)
+    // (the small ones -- the pose's column of P, its slot in the run sums -- in front of it: each its own round trip behind
+    // the gather in the in-kernel timeline, 0.3 and 0.5 us shorter per tile when hoisted, and the gather that much longer:
+    // launch 17.8 -> 18.5 us.  The cycle's kernels move their time between phases, not off the launch.)
     double h[R];
     q_gather<D, R, SPLIT>(A, x1, i, L.s, L.c, okp, h);
+    DPGO_TL_USE(h[0]);
+    DPGO_STAMP_TILE_IN(g_tl_restrict, 1);
     if (ok) {
       double xr[R], rr[R];
       load_col_t<R>(x1 + off, xr);
@@ -143,6 +152,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(Restrict
       if (res_out) store_col_t<R>(res_out + off, h);  // kept for k_ml_post_ap (in its storage type; P^T res uses h itself)
     }
     wave_sync();
+    DPGO_STAMP_TILE_IN(g_tl_restrict, 2);
     if (L.s == 0 && L.g < GEO::G) {
       double t[R];
 #pragma unroll
@@ -158,6 +168,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(Restrict
       }
       store_col<R>(&t_s[lp][L.c * R], t);  // zeros for nodes beyond n (rows lp of a wave are private to it)
     }
+    DPGO_STAMP_TILE_IN(g_tl_restrict, 3);
     if (tbuf) {  // kernel-uniform: graph aggregates
       // inside the wave's G consecutive nodes every RUN of nodes of one aggregate is added up here (fixed order) and
       // leaves ONE partial sum: tpos[i] = slot * 32 + length for the first node of a run, -1 otherwise (host:
@@ -179,6 +190,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(Restrict
         }
       }
       wave_sync();  // (the wave's rows of t_s are rewritten by its next tile)
+      DPGO_STAMP_TILE_IN(g_tl_restrict, 4);
+      DPGO_TILE_NEXT;
       continue;
     }
     __syncthreads();
@@ -554,7 +567,9 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(SPLIT ==
                                                        double* __restrict__ Z, double* __restrict__ pout,
                                                        const DevState* __restrict__ gate, int n) {
   using GEO = Geo<D, R, SPLIT>;
+  DPGO_TL_TILES_DECL;
   if (gate && (gate->tcg_done || gate->rtr_stop)) return;
+  DPGO_STAMP_ENTRY_IN(g_tl_post);
   __shared__ double sm[kWaves][3][GEO::G][GEO::T];
   __shared__ double red[kWaves * kNP];
   const LaneId L = lane_id<D, SPLIT>();
@@ -562,6 +577,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(SPLIT ==
   const TileIter ti_ = tile_iter(ntiles);
   double part[2] = {0.0, 0.0};
   for (int tile = ti_.first; tile < ti_.last; tile += ti_.step) {
+    DPGO_STAMP_TILE_IN(g_tl_post, 0);
     const int i = tile * GEO::P + L.wave * GEO::G + L.g;
     const bool okp = (L.g < GEO::G) && (i < n);
     const bool ok = okp && (L.s == 0);
@@ -570,7 +586,12 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(SPLIT ==
     double* vs = ok ? &sm[L.wave][1][L.g][0] : nullptr;
     double* zs = ok ? &sm[L.wave][2][L.g][0] : nullptr;
     double h[R], rr[R], xcol[R], z[R], dr[GEO::B];
+    // (the aggregate's label and the pose's row of P requested HERE, in front of the gather, take 2.5 us out of the
+    // smoothing + prolongation phase of a tile -- the label is a round trip of its own in front of the coarse tile's -- and
+    // the gather grows by as much: launch 21.2 .. 22.7 -> 20.6 .. 22.4 us, cycle tail 59.1 -> 60.0 us; not kept)
     spmm_col<D, R, SPLIT>(AP.rowptr, AP.colidx, AP.vals, xc, i, L.s, L.c, okp, h);
+    DPGO_TL_USE(h[0]);
+    DPGO_STAMP_TILE_IN(g_tl_post, 1);
     if (ok) {
       double x[R], rs[R];
       load_col<R>(X + off, x);
@@ -588,6 +609,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(SPLIT ==
       store_col<R>(zs + L.c * R, h);
     }
     wave_sync();
+    DPGO_STAMP_TILE_IN(g_tl_post, 2);
     if (ok) {
       double x1c[R], zc[R];
       jacobi_col<D, R>(vs, dr, x1c);  // x1 = w Dinv r
@@ -604,10 +626,13 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(SPLIT ==
       }
 #pragma unroll
       for (int a = 0; a < R; ++a) z[a] = fma(omega, zc[a], xcol[a]);
+      DPGO_TL_USE(z[0]);
     }
+    DPGO_STAMP_TILE_IN(g_tl_post, 3);
     wave_sync();  // every lane of the pose has read vs / zs before zs is overwritten
     if (ok) store_col<R>(zs + L.c * R, z);
     wave_sync();
+    DPGO_STAMP_TILE_IN(g_tl_post, 4);
     if (ok) {
       double out[R], sdummy[D];
       proj_col<D, R>(ys, zs, L.c, z, out, sdummy);
@@ -616,8 +641,11 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(SPLIT ==
       for (int a = 0; a < R; ++a) part[1] = fma(out[a], rr[a], part[1]);
     }
     wave_sync();
+    DPGO_STAMP_TILE_IN(g_tl_post, 5);
+    DPGO_TILE_NEXT;
   }
   if (pout) store_partials<2>(part, pout, red);
+  DPGO_STAMP_AT_IN(g_tl_post, 2);
 }
 
 // ================================================================ on-device setup of the hierarchy

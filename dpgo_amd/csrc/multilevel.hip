@@ -1084,5 +1084,13 @@ int dpgo_dense_spd_inverse(int N, const double* A_host, double* Ainv_host, int d
   HIPC(hipMemcpy2D(Ainv_host, sizeof(double) * N, M, sizeof(double) * lda, sizeof(double) * N, N, hipMemcpyDeviceToHost));
   return DPGO_OK;
 }
+#ifdef DPGO_TIMELINE
+int dpgo_debug_timeline_cycle(long long* out /* [2][3][64]: restriction, post-smoothing */) {
+  HIPC(hipDeviceSynchronize());
+  HIPC(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_tl_restrict), sizeof(long long) * 3 * 64));
+  HIPC(hipMemcpyFromSymbol(out + 3 * 64, HIP_SYMBOL(g_tl_post), sizeof(long long) * 3 * 64));
+  return DPGO_OK;
+}
+#endif
 
 }  // extern "C"
