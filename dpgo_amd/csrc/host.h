@@ -131,6 +131,7 @@ inline int free_bsr(Bsr& m) {
   X(poll_first,        "DPGO_POLL_FIRST",        -1,  "s_sleep units before the first sweep of the in-kernel all-reduce")            \
   X(poll_sleep,        "DPGO_POLL_SLEEP",        -1,  "s_sleep units between sweeps of the in-kernel all-reduce")                    \
   X(persist_verbose,   "DPGO_PERSIST_VERBOSE",    0,  "per-solve phase report of the one-launch solve on stderr")                    \
+  X(setup_timing,      "DPGO_SETUP_TIMING",       0,  "section times of the hierarchy's symbolic set-up on stderr")                  \
   X(auto_cost_rule,    "DPGO_AUTO_COST_RULE",     1,  "DPGO_PRECOND_AUTO on coupled blocks: cost rule (0: tCG-budget hysteresis only)") \
   X(ml_graph,          "DPGO_ML_GRAPH",           1,  "graph aggregates in the default hierarchy (0: index runs)")                   \
   X(ml_graph_size,     "DPGO_ML_GRAPH_SIZE",      0,  "growth size of the default graph aggregates (0: by size)")                    \

@@ -174,41 +174,72 @@ int ml_merge_small_aggregates(const std::vector<int32_t>& rowptr, const std::vec
       }
     }
   }
+  // Members of the surviving aggregates in index order (one counting pass over the poses instead of a sort per aggregate),
+  // `grew` = absorbed at least one other aggregate.
+  std::vector<char> grew(na, 0);
+  for (int a = 0; a < na; ++a)
+    if (!members[a].empty() && (int)members[a].size() != ptr[a + 1] - ptr[a]) grew[a] = 1;
+  std::vector<int32_t> first_member(na, -1);
+  for (int i = n - 1; i >= 0; --i) first_member[lab[i]] = i;
   std::vector<int> alive;
   for (int a = 0; a < na; ++a)
-    if (!members[a].empty()) {
-      std::sort(members[a].begin(), members[a].end());
-      alive.push_back(a);
-    }
-  std::sort(alive.begin(), alive.end(), [&](int x, int y) { return members[x][0] < members[y][0]; });
-  std::vector<int32_t> new_lab(n, -1);
+    if (!members[a].empty()) alive.push_back(a);
+  std::sort(alive.begin(), alive.end(), [&](int x, int y) { return first_member[x] < first_member[y]; });
+  std::vector<int32_t> sorted_mem, sorted_ptr(na + 1, 0);
+  {  // only the aggregates that grew need their members sorted (the roots of the search below)
+    for (int a = 0; a < na; ++a) sorted_ptr[a + 1] = sorted_ptr[a] + (grew[a] ? (int32_t)members[a].size() : 0);
+    sorted_mem.resize(sorted_ptr[na]);
+    std::vector<int32_t> fill(sorted_ptr.begin(), sorted_ptr.end() - 1);
+    for (int i = 0; i < n; ++i)
+      if (grew[lab[i]]) sorted_mem[fill[lab[i]]++] = i;
+  }
+  std::vector<int32_t> new_lab(n, -1), new_mem;
+  std::vector<int32_t> old_parent, old_pslot;
+  old_parent.swap(parent);
+  old_pslot.swap(pslot);
   parent.assign(n, -1);
   pslot.assign(n, 0);
-  mem.clear();
-  ptr.assign(1, 0);
+  new_mem.reserve(n);
+  std::vector<int32_t> new_ptr(1, 0);
   for (size_t k = 0; k < alive.size(); ++k) {
     const int a = alive[k];
+    if (!grew[a]) {
+      // untouched by the merge: the growth's own search started from the aggregate's smallest member (seeds are taken in
+      // index order) and claimed exactly these poses in exactly the order the search below would -- keep its tree
+      for (int m = ptr[a]; m < ptr[a + 1]; ++m) {
+        const int v = mem[m];
+        new_lab[v] = (int32_t)k;
+        parent[v] = old_parent[v];
+        pslot[v] = old_pslot[v];
+        new_mem.push_back(v);
+      }
+      new_ptr.push_back((int32_t)new_mem.size());
+      continue;
+    }
     // (a merged aggregate is connected by construction, so the search from its smallest member reaches everything; should
     // the pattern not be symmetric, the members it misses become further roots in index order)
-    for (int root : members[a]) {
+    for (int q = sorted_ptr[a]; q < sorted_ptr[a + 1]; ++q) {
+      const int root = sorted_mem[q];
       if (new_lab[root] >= 0) continue;
-      size_t head = mem.size();
+      size_t head = new_mem.size();
       new_lab[root] = (int32_t)k;
-      mem.push_back(root);
-      for (; head < mem.size(); ++head) {
-        const int u = mem[head];
+      new_mem.push_back(root);
+      for (; head < new_mem.size(); ++head) {
+        const int u = new_mem[head];
         for (int t = rowptr[u]; t < rowptr[u + 1]; ++t) {
           const int v = colidx[t];
           if (lab[v] != a || new_lab[v] >= 0) continue;
           new_lab[v] = (int32_t)k;
           parent[v] = u;
           pslot[v] = t;
-          mem.push_back(v);
+          new_mem.push_back(v);
         }
       }
     }
-    ptr.push_back((int32_t)mem.size());
+    new_ptr.push_back((int32_t)new_mem.size());
   }
+  mem.swap(new_mem);
+  ptr.swap(new_ptr);
   lab.swap(new_lab);
   return (int)alive.size();
 }
@@ -218,7 +249,18 @@ int ml_merge_small_aggregates(const std::vector<int32_t>& rowptr, const std::vec
 // aggregates): also build the (aggregate, slot) -> pose table of the additive preconditioner's persistent layout with
 // that many slots per aggregate.
 int ml_symbolic_setup(dpgo_problem_s* p, const std::vector<int>& ks_in, int perm_tile) {
+  // DPGO_SETUP_TIMING=1: host section times on stderr (where the once-per-pattern cost of the hierarchy goes)
+  const bool timing = options().setup_timing != 0;
+  auto t_last = std::chrono::steady_clock::now();
+  const auto t_first = t_last;
+  auto lap = [&](const char* what) {
+    if (!timing) return;
+    const auto t = std::chrono::steady_clock::now();
+    std::fprintf(stderr, "dpgo_hip: symbolic set-up: %-44s %7.3f ms\n", what, 1e3 * std::chrono::duration<double>(t - t_last).count());
+    t_last = t;
+  };
   ml_free(p);
+  lap("previous hierarchy freed");
   if ((int)p->h_rowptr.size() != p->n + 1) return fail(DPGO_ERR_STATE, "multilevel: Q's block pattern is not set");
   const int b = p->b, bb = b * b;
   const size_t tb = sizeof(double) * p->T;
@@ -250,7 +292,9 @@ int ml_symbolic_setup(dpgo_problem_s* p, const std::vector<int>& ks_in, int perm
         na = (int)ptr.size() - 1;
       } else {
         na = ml_graph_aggregates(rowptr, colidx, cur, L.k, lab, ptr, mem, parent, pslot);
+        lap("greedy growth of the aggregates");
         if (merge_cap) na = ml_merge_small_aggregates(rowptr, colidx, cur, L.k, merge_cap, lab, ptr, mem, parent, pslot);
+        lap("merge of the growth's fragments");
       }
       L.graph = true;
       L.merge_cap = merge_cap;
@@ -262,6 +306,7 @@ int ml_symbolic_setup(dpgo_problem_s* p, const std::vector<int>& ks_in, int perm
       std::vector<int32_t> mpos(cur);
       for (int m = 0; m < cur; ++m) mpos[mem[m]] = m;
       CHK(upload(&L.mem_pos, mpos.data(), mpos.size(), p->stream));
+      lap("labels, members, trees uploaded");
       std::vector<int32_t> seg_info(cur, -1), seg_ptr(na + 1, 0);
       {  // runs of equal labels inside the level-0 kernels' wave chunks (G consecutive poses)
         const int G = 64 / (b * L.split);
@@ -294,7 +339,9 @@ int ml_symbolic_setup(dpgo_problem_s* p, const std::vector<int>& ks_in, int perm
         CHK(upload(&L.tile_perm, tperm.data(), tperm.size(), p->stream));
         L.perm_tile = perm_tile;
       }
+      lap("run table, tile table");
       HIPC(hipMalloc(&L.tbuf, tb * cur));
+      lap("run-sum buffer allocated");
       // pattern of A P: the aggregates the block columns of every row fall into
       std::vector<int32_t> arow(cur + 1, 0), acol;
       acol.reserve(colidx.size());
@@ -305,11 +352,14 @@ int ml_symbolic_setup(dpgo_problem_s* p, const std::vector<int>& ks_in, int perm
         acol.erase(std::unique(acol.begin() + first, acol.end()), acol.end());
         arow[i + 1] = (int32_t)acol.size();
       }
+      lap("pattern of A P");
       CHK(upload_bsr(L.AP, cur, na, (int)acol.size(), b, arow.data(), acol.data(), nullptr, p->stream));
+      lap("A P allocated, pattern uploaded");
       HIPC(hipMalloc(&L.res1, tb * cur));
       HIPC(hipMalloc(&L.Pb, sizeof(double) * (size_t)cur * bb));
       HIPC(hipMalloc(&L.x1, tb * cur));
       HIPC(hipMalloc(&L.x, tb * cur));
+      lap("level-0 vectors allocated");
       // pattern of the dense level's operator: the aggregates of the block columns of every member's row
       std::vector<int32_t> crow(na + 1, 0), ccol;
       std::vector<int32_t> mark(na, -1);
@@ -328,7 +378,9 @@ int ml_symbolic_setup(dpgo_problem_s* p, const std::vector<int>& ks_in, int perm
         std::sort(ccol.begin() + first, ccol.end());
         crow[a + 1] = (int32_t)ccol.size();
       }
+      lap("pattern of the dense level's operator");
       HIPC(hipStreamSynchronize(p->stream));  // the host vectors go out of scope
+      lap("stream synchronised");
       rowptr.swap(crow);
       colidx.swap(ccol);
       cur = na;
@@ -419,6 +471,10 @@ int ml_symbolic_setup(dpgo_problem_s* p, const std::vector<int>& ks_in, int perm
   HIPC(hipMalloc(&p->ml_W, sizeof(double) * (size_t)p->ml_lda * kNB));
   HIPC(hipMalloc(&p->ml_Rx, sizeof(double) * (size_t)p->ml_lda * kNB));
   HIPC(hipStreamSynchronize(p->stream));
+  lap("coarser levels, dense level allocated");
+  if (timing)
+    std::fprintf(stderr, "dpgo_hip: symbolic set-up: %-44s %7.3f ms\n", "total",
+                 1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t_first).count());
   p->ml_symbolic = true;
   return DPGO_OK;
 }
