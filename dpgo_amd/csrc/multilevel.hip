@@ -244,6 +244,48 @@ int ml_merge_small_aggregates(const std::vector<int32_t>& rowptr, const std::vec
   return (int)alive.size();
 }
 
+// Pattern of A P for labelled aggregates: row i holds the sorted, distinct labels of its block columns.  (Inserting into
+// the sorted row instead of sort + unique was measured: no gain, the labels' gather is what it costs.)
+void ml_ap_pattern(const std::vector<int32_t>& rowptr, const std::vector<int32_t>& colidx, const std::vector<int32_t>& lab,
+                   int n, std::vector<int32_t>& arow, std::vector<int32_t>& acol) {
+  arow.assign(n + 1, 0);
+  acol.clear();
+  acol.reserve(colidx.size());
+  for (int i = 0; i < n; ++i) {
+    const size_t first = acol.size();
+    for (int t = rowptr[i]; t < rowptr[i + 1]; ++t) acol.push_back(lab[colidx[t]]);
+    std::sort(acol.begin() + first, acol.end());
+    acol.erase(std::unique(acol.begin() + first, acol.end()), acol.end());
+    arow[i + 1] = (int32_t)acol.size();
+  }
+}
+
+// Runs of equal labels inside chunks of G consecutive poses (what one wave of the level-0 kernels adds up before it
+// writes): seg_info[first pose of a run] = 32 * slot + length (-1 elsewhere), the slots ordered by aggregate and, inside
+// an aggregate, by pose (a counting sort over the runs), seg_ptr = the aggregates' slot ranges.  Returns the run count.
+int ml_run_table(const std::vector<int32_t>& lab, int n, int na, int G, std::vector<int32_t>& seg_info,
+                 std::vector<int32_t>& seg_ptr) {
+  seg_info.assign(n, -1);
+  seg_ptr.assign(na + 1, 0);
+  int nruns = 0;
+  for (int i = 0; i < n;) {
+    int j = i + 1;
+    while (j < n && j % G != 0 && lab[j] == lab[i]) ++j;
+    seg_info[i] = j - i;  // (length for now)
+    seg_ptr[lab[i] + 1] += 1;
+    ++nruns;
+    i = j;
+  }
+  for (int a = 0; a < na; ++a) seg_ptr[a + 1] += seg_ptr[a];
+  std::vector<int32_t> next(seg_ptr.begin(), seg_ptr.end() - 1);
+  for (int i = 0; i < n;) {
+    const int len = seg_info[i];
+    seg_info[i] = len + 32 * next[lab[i]]++;
+    i += len;
+  }
+  return nruns;
+}
+
 // ks_in: aggregate sizes per coarsening; {-S}: two levels, graph aggregates of at most S poses; {-S, -cap}: the same with
 // the fragments of the greedy growth merged up to `cap` poses (ml_merge_small_aggregates).  perm_tile > 0 (graph
 // aggregates): also build the (aggregate, slot) -> pose table of the additive preconditioner's persistent layout with
@@ -307,25 +349,8 @@ int ml_symbolic_setup(dpgo_problem_s* p, const std::vector<int>& ks_in, int perm
       for (int m = 0; m < cur; ++m) mpos[mem[m]] = m;
       CHK(upload(&L.mem_pos, mpos.data(), mpos.size(), p->stream));
       lap("labels, members, trees uploaded");
-      std::vector<int32_t> seg_info(cur, -1), seg_ptr(na + 1, 0);
-      {  // runs of equal labels inside the level-0 kernels' wave chunks (G consecutive poses)
-        const int G = 64 / (b * L.split);
-        std::vector<std::pair<int32_t, int32_t>> runs;  // (aggregate, first pose), in pose order
-        for (int i = 0; i < cur;) {
-          int j = i + 1;
-          while (j < cur && j % G != 0 && lab[j] == lab[i]) ++j;
-          runs.emplace_back(lab[i], i);
-          seg_info[i] = j - i;  // (length for now)
-          i = j;
-        }
-        std::stable_sort(runs.begin(), runs.end(), [](const auto& x, const auto& y) { return x.first < y.first; });
-        for (size_t q = 0; q < runs.size(); ++q) {
-          seg_info[runs[q].second] += (int32_t)q * 32;
-          seg_ptr[runs[q].first + 1] += 1;
-        }
-        for (int a = 0; a < na; ++a) seg_ptr[a + 1] += seg_ptr[a];
-        L.nseg = (int)runs.size();
-      }
+      std::vector<int32_t> seg_info, seg_ptr;
+      L.nseg = ml_run_table(lab, cur, na, 64 / (b * L.split), seg_info, seg_ptr);
       CHK(upload(&L.seg_info, seg_info.data(), seg_info.size(), p->stream));
       CHK(upload(&L.seg_ptr, seg_ptr.data(), seg_ptr.size(), p->stream));
       std::vector<int32_t> tperm;
@@ -343,15 +368,8 @@ int ml_symbolic_setup(dpgo_problem_s* p, const std::vector<int>& ks_in, int perm
       HIPC(hipMalloc(&L.tbuf, tb * cur));
       lap("run-sum buffer allocated");
       // pattern of A P: the aggregates the block columns of every row fall into
-      std::vector<int32_t> arow(cur + 1, 0), acol;
-      acol.reserve(colidx.size());
-      for (int i = 0; i < cur; ++i) {
-        const size_t first = acol.size();
-        for (int t = rowptr[i]; t < rowptr[i + 1]; ++t) acol.push_back(lab[colidx[t]]);
-        std::sort(acol.begin() + first, acol.end());
-        acol.erase(std::unique(acol.begin() + first, acol.end()), acol.end());
-        arow[i + 1] = (int32_t)acol.size();
-      }
+      std::vector<int32_t> arow, acol;
+      ml_ap_pattern(rowptr, colidx, lab, cur, arow, acol);
       lap("pattern of A P");
       CHK(upload_bsr(L.AP, cur, na, (int)acol.size(), b, arow.data(), acol.data(), nullptr, p->stream));
       lap("A P allocated, pattern uploaded");
