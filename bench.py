@@ -121,6 +121,130 @@ def hess_bytes(n, nnzb, d, r):
     return nnzb * (8 * b * b + 4) + 4 * (n + 1) + v + (v + 8 * d * d * n) + 2 * v + 2 * v
 
 
+def pmc_bytes(pmc, prefix):
+    """HBM-side bytes per launch of the kernel whose name starts with `prefix`, from a committed rocprofv3 PMC summary
+    (profiles/r*_pmc_fetch_write.json: separate FETCH_SIZE and WRITE_SIZE passes of this same command, KB): FETCH_SIZE x 2
+    (the gfx950 correction, calibrated on k_retract / k_rtr_update whose byte counts are exact) + WRITE_SIZE; "max" = the
+    full (non-early-exit) launches.  Several instantiations under one prefix: the one launched most often.  Returns
+    (bytes, key) or (None, None)."""
+    if not pmc:
+        return None, None
+    fs, ws = pmc.get("FETCH_SIZE_KB", {}), pmc.get("WRITE_SIZE_KB", {})
+    keys = [k for k in fs if k.startswith(prefix) and k in ws]
+    if not keys:
+        return None, None
+    key = max(keys, key=lambda k: fs[k].get("calls", 0))
+    return (2.0 * fs[key]["max"] + ws[key]["max"]) * 1024.0, key
+
+
+def kitti_with_outliers(k=25, seed=11):
+    """BASELINE configs[4]'s input: kitti_00.g2o (2-D, 4 541 poses) + k injected outlier loop closures (random rotation,
+    translation in [-5, 5]^2, 300-600 poses apart, the median precisions of the data set's loop closures) -- the generator of
+    tests/test_parity_gpu.py::_kitti_with_outliers on the product's own measurement type."""
+    import dpgo_amd
+    from dpgo_amd.measurements import RelativeSEMeasurements
+    om, n = dpgo_amd.read_g2o_file(os.path.join(ROOT, "data", "kitti_00.g2o"))
+    rng = np.random.default_rng(seed)
+    taken = set(zip(om.p1.tolist(), om.p2.tolist()))
+    p1, p2 = [], []
+    while len(p1) < k:
+        a = int(rng.integers(0, n - 600))
+        b = int(a + rng.integers(300, 600))
+        if (a, b) not in taken:
+            taken.add((a, b))
+            p1.append(a)
+            p2.append(b)
+    th = rng.uniform(-np.pi, np.pi, k)
+    Rk = np.stack([np.array([[np.cos(a), -np.sin(a)], [np.sin(a), np.cos(a)]]) for a in th])
+    lc = np.nonzero(~om.fixedWeight)[0]
+    z = np.zeros(k, dtype=np.int64)
+    out = RelativeSEMeasurements(2, z, np.array(p1), z.copy(), np.array(p2), Rk, rng.uniform(-5, 5, (k, 2)),
+                                 np.full(k, np.median(om.kappa[lc])), np.full(k, np.median(om.tau[lc])), np.ones(k),
+                                 np.zeros(k, dtype=bool))
+    return om, RelativeSEMeasurements.concatenate([om, out]), n
+
+
+def kitti_gnc_gpu(r, device, robots=4, k=25, inner_sweeps=2):
+    """BASELINE configs[4] timed: kitti_00 + 25 outliers cut into 4 agents on this GPU, GNC-TLS with the reference's
+    schedule (include/DPGO/DPGO_robust.h:49-53: barc 5, mu x 1.4), 2 coloured sweeps between weight updates.  A weight
+    update (PGOAgent::updateMeasurementWeights, src/PGOAgent.cpp:1104-1142) = public-pose exchange + residuals and weights
+    (k_edge_weights) + Q values, coupling blocks and preconditioner values rebuilt on the device (k_rebuild_Q; the block
+    pattern is fixed) + the two scalar reductions; timed between device synchronisations.  The run is done twice from the
+    same initial iterate: the first contains every first-use set-up, the second is what is reported."""
+    import torch
+    import dpgo_amd
+    from dpgo_amd import synthetic
+    from dpgo_amd.agent import DeviceAgent, ExchangePlan, RBCDCluster, build_pose_graphs
+    from dpgo_amd.initialization import chordal_initialization
+    from dpgo_amd.robust import DistributedGNC, RobustCostParameters
+    om, meas, n = kitti_with_outliers(k)
+    X0 = synthetic.lift_tiles(chordal_initialization(om, n), r)
+    ranges, graphs = build_pose_graphs(meas, n, robots, r)
+    plan = ExchangePlan(graphs)
+    agents = {a: DeviceAgent(graphs, plan, a, X0[ranges[a][0]:ranges[a][1]], dpgo_amd.ROptParameters(), device=device)
+              for a in range(robots)}
+    cluster = RBCDCluster(plan, agents)
+    gnc = DistributedGNC(cluster, RobustCostParameters("GNC_TLS", GNCMaxNumIters=80, GNCBarc=5.0, GNCMuStep=1.4),
+                         inner_sweeps=inner_sweeps)
+    t_rw, t_sw = [], []
+    rw, sw = gnc._reweight_all, gnc._sweeps
+
+    def timed(fn, sink):
+        def wrapped(*a, **kw):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            out = fn(*a, **kw)
+            torch.cuda.synchronize()
+            sink.append(time.perf_counter() - t0)
+            return out
+        return wrapped
+
+    gnc._reweight_all, gnc._sweeps = timed(rw, t_rw), timed(sw, t_sw)
+    runs = []
+    for _ in range(2):
+        for a, ag in agents.items():
+            ag.set_iterate(X0[ranges[a][0]:ranges[a][1]])
+        del t_rw[:], t_sw[:]
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        info = gnc.run()
+        torch.cuda.synchronize()
+        runs.append(dict(total_ms=1e3 * (time.perf_counter() - t0), updates=info["updates"],
+                         # (the first _reweight_all only evaluates the residuals for mu_0: update=False)
+                         ms_per_weight_update=1e3 * float(np.median(t_rw[1:])) if len(t_rw) > 1 else None,
+                         ms_per_inner_block=1e3 * float(np.median(t_sw)), inner_blocks=len(t_sw),
+                         cost_2f=info["cost"], gradnorm=info["gradnorm"], last=info["history"][-1] if info["history"] else None))
+    first, rep = runs
+    rep = dict(rep)
+    rep.update(workload="kitti_00.g2o + %d outlier loop closures, %d agents, r = %d, GNC-TLS barc 5, mu x 1.4, %d sweeps "
+                        "between weight updates" % (k, robots, r, inner_sweeps),
+               ms_per_gnc_outer_iteration=(rep["ms_per_weight_update"] or 0.0) + rep["ms_per_inner_block"],
+               first_run_total_ms=first["total_ms"],
+               preconditioners=sorted({ag.last_result.precond_used for ag in agents.values() if ag.last_result}))
+    return rep
+
+
+def kitti_gnc_cpu(r, budget_updates=6, robots=4, k=25, inner_sweeps=2):
+    """The same schedule on the host with the oracle (reference configuration: exact (Q_a + 0.1 I)^-1), bounded to
+    `budget_updates` weight updates; seconds per GNC outer iteration (weight update + inner sweeps) = total / updates."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import dpgo_oracle as O
+    om_p, meas_p, n = kitti_with_outliers(k)
+
+    def conv(m):
+        return O.Measurements(m.d, m.r1.astype(np.int64), m.p1.astype(np.int64), m.r2.astype(np.int64),
+                              m.p2.astype(np.int64), m.R, m.t, m.kappa, m.tau, m.weight.copy(), m.fixedWeight.copy())
+    X0 = O.lift(O.chordal_initialization(conv(om_p), n), r)
+    t0 = time.perf_counter()
+    _, info = O.multi_agent_gnc(conv(meas_p), n, robots, r, X0, inner_sweeps=inner_sweeps, barc=5.0, mu_step=1.4,
+                                max_updates=budget_updates, precond="exact")
+    el = time.perf_counter() - t0
+    blocks = info["updates"] + 1  # (the block before mu_0 and one after every update but possibly the last)
+    return dict(seconds=el, updates=info["updates"], seconds_per_gnc_outer_iteration=el / max(blocks, 1),
+                sample="oracle, %d agents sequentially on one core, exact sparse factor, first %d weight updates of the "
+                       "schedule" % (robots, info["updates"]))
+
+
 def cpu_baseline(meas_p, n, X_state, r, budget_s, precond="jacobi"):
     """CPU restatement ("port") timed on the SAME step the GPU is timed on: one RBCD iteration (RTR 3 x <=50 tCG,
     block-Jacobi, H-direction recurrence) from the settled iterate, one thread like the reference (ENABLE_OPENMP
@@ -450,6 +574,122 @@ def time_to_tolerance(workload, r, precond, tol=1e-2, max_calls=12, coarse_bits=
                 ms_incl_setup=(1e3 * el + setup_first) if setup_first is not None else 1e3 * el)
 
 
+LINE_LIMIT = 6144  # bytes: the driver's record keeps the last 8 KB of stdout
+
+
+def _rnd(v, sig=5):
+    """Floats rounded to `sig` significant digits (the last line is a summary; bench_detail.json keeps full precision)."""
+    if isinstance(v, float):
+        return float("%.*g" % (sig, v)) if v == v and abs(v) != float("inf") else None
+    if isinstance(v, dict):
+        return {k: _rnd(x, sig) for k, x in v.items()}
+    if isinstance(v, (list, tuple)):
+        return [_rnd(x, sig) for x in v]
+    return v
+
+
+def compact_line(out):
+    """The driver's line from the full record `out`: headline keys, `config` in a few short strings, `roofline` (headline
+    kernel + its PMC traffic + the fraction on the bytes it streams + the SpMM north_star names + one entry per kernel of
+    the iteration + the whole iteration), `cpu_baseline` (the reference-configuration pair) and BASELINE configs[4]'s
+    timing.  Guaranteed <= LINE_LIMIT bytes: optional groups are dropped from the end of the priority list until it fits."""
+    rf, cb, cfg = out.get("roofline") or {}, out.get("cpu_baseline") or None, out.get("config") or {}
+    q = out.get("quality") or {}
+    head = {k: out.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step",
+                                    "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "products_per_step",
+                                    "gradnorm_before_step", "gradnorm_after_step", "time_to_tolerance_ms",
+                                    "products_to_tolerance", "hierarchy_setup_ms", "hierarchy_values_only_ms",
+                                    "time_to_tolerance_incl_setup_ms")}
+    head["us_per_product"] = q.get("us_per_tcg_iteration_rank0")
+    ml = rf.get("multilevel") or {}
+    config = {"workload": cfg.get("workload"), "agents": cfg.get("agents"), "agents_per_gpu": cfg.get("agents_per_gpu"),
+              "r": cfg.get("r"), "d": cfg.get("d"),
+              "local_solver": "RTR 3x<=50 tCG, Delta0=100, tol=1e-2 (reference defaults), precond=%s, ran %s" % (
+                  cfg.get("precond"), "+".join(cfg.get("precond_used_in_timed_steps") or [])),
+              "cycle_storage": cfg.get("cycle_storage_short"), "schedule": (cfg.get("schedule") or "")[:120],
+              "transport": cfg.get("transport"), "exchange_ms_per_step": q.get("exchange_ms_per_step_rank0"),
+              "poses_per_agent": cfg.get("poses_per_agent"), "nnzb_per_agent": cfg.get("nnzb_per_agent")}
+    roof = {k: rf.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "traffic_live",
+                                   "bytes_per_launch", "avg_launch_us", "storage")}
+    roof["kernel"] = (rf.get("kernel") or "").split(" (")[0]
+    roof["what"] = "one tCG step (Q*z block-SpMM + Riemannian-Hessian epilogue + recurrences); achieved/frac: ALGORITHMIC " \
+                   "bytes (full fp64 Q, SURVEY 8d) / rotating-operand time; frac_own_bytes: the bytes this storage streams"
+    roof["streamed_bytes"] = rf.get("stored_bytes_per_launch")
+    roof["frac_own_bytes"] = rf.get("frac_own_bytes")
+    if rf.get("traffic") and rf.get("avg_launch_us"):
+        roof["frac_traffic"] = rf["traffic"] / rf["avg_launch_us"] / 1e3 / HBM_PEAK_GBS
+    if rf.get("warm"):
+        roof["warm_us"], roof["warm_frac"] = rf["warm"].get("avg_launch_us"), rf["warm"].get("frac")
+    for key in ("products_per_launch", "us_per_product", "effective_algorithmic_frac"):  # (one-launch solves)
+        if rf.get(key) is not None:
+            roof[key] = rf[key]
+    sp = rf.get("spmm_symmetric") if rf.get("spmm_storage_selected") == "symmetric" and rf.get("spmm_symmetric") else rf.get("spmm_only")
+    if sp:
+        roof["spmm"] = {"kernel": (sp.get("kernel") or "").split(" (")[0], "bytes_per_launch": sp.get("bytes_per_launch"),
+                        "avg_launch_us": sp.get("avg_launch_us"), "frac": sp.get("frac"),
+                        "frac_own_bytes": sp.get("frac_own_bytes", sp.get("frac")), "traffic": sp.get("traffic")}
+    roof["kernels"] = [{"kernel": k.get("kernel"), "us": k.get("avg_launch_us"), "streamed_bytes": k.get("streamed_bytes"),
+                        "algorithmic_bytes_fp64": k.get("algorithmic_bytes_fp64"), "achieved": k.get("achieved"),
+                        "frac": k.get("frac"), "traffic": k.get("traffic"), "frac_traffic": k.get("frac_traffic")}
+                       for k in (rf.get("kernels") or [])]
+    it = rf.get("iteration")
+    roof["iteration"] = {k: it.get(k) for k in ("launches", "bytes", "traffic", "us_per_product", "achieved", "frac",
+                                                "frac_traffic", "kernel_us_sum")} if it else None
+    if ml:
+        roof["hierarchy"] = {"sizes": ml.get("sizes"), "ks": ml.get("ks"), "coarse_inverse_bits": ml.get("coarse_inverse_bits"),
+                             "cycle_operator_copy_bits": ml.get("cycle_operator_copy_bits")}
+    cpu = None
+    if cb:
+        g = cb.get("gpu_same_work") or {}
+        hs = (g.get("hierarchy_setup_ms") or {})
+        cpu = {k: cb.get(k) for k in ("value", "unit", "cores", "kind", "seconds_per_sweep", "factorisation_seconds",
+                                      "tcg_iterations", "host_cores", "gradnorm_after")}
+        cpu["sample"] = (cb.get("sample_short") or cb.get("sample") or "")[:200]
+        if g:
+            cpu["gpu_same_work"] = {"seconds_per_sweep": g.get("seconds_per_sweep"), "tcg_iterations": g.get("tcg_iterations"),
+                                    "preconditioners": g.get("preconditioners"), "gradnorm_after": g.get("gradnorm_after"),
+                                    "hierarchy_setup_ms_max": max(hs["first_ms"]) if hs.get("first_ms") else None}
+    kit = out.get("kitti_gnc")
+    kitti = None
+    if kit and "error" not in kit:
+        kitti = {k: kit.get(k) for k in ("ms_per_weight_update", "ms_per_inner_block", "ms_per_gnc_outer_iteration", "updates",
+                                         "total_ms", "first_run_total_ms", "cost_2f", "preconditioners")}
+        kitti["workload"] = "kitti_00 + 25 outliers, 4 agents, GNC-TLS barc 5, mu x1.4, 2 sweeps per update"
+        if kit.get("cpu"):
+            kitti["cpu_seconds_per_gnc_outer_iteration"] = kit["cpu"].get("seconds_per_gnc_outer_iteration")
+            kitti["cpu_sample"] = (kit["cpu"].get("sample") or "")[:120]
+    elif kit:
+        kitti = {"error": str(kit.get("error"))[:160]}
+    tt = {}
+    for key, v in (q.get("to_tolerance") or {}).items():
+        if isinstance(v, dict) and "products" in v and key.split("/")[-1] in ("auto", "jacobi"):
+            tt[key] = [v.get("products"), v.get("ms"), v.get("reached")]
+    also = {}
+    for key, v in (out.get("also") or {}).items():
+        if isinstance(v, dict) and "it_per_s" in v and key == "sphere2500":
+            also[key] = {"it_per_s": v["it_per_s"], "us_per_product": v.get("us_per_product"), "precond_used": v.get("precond_used"),
+                         "in_kernel_us_per_iteration": (v.get("in_kernel_us_per_iteration") or {}).get("total")}
+    line = dict(head)
+    line.update(config=config, roofline=roof, cpu_baseline=cpu, kitti_gnc=kitti,
+                to_tolerance_products_ms_reached=tt or None, also=also or None,
+                detail="full record: bench_detail.json and the stdout line prefixed 'DETAIL '")
+    line = _rnd(line)
+    text = json.dumps(line, separators=(",", ":"))
+    for drop in ("also", "to_tolerance_products_ms_reached", ("roofline", "hierarchy"), ("roofline", "what"),
+                 ("config", "schedule"), ("roofline", "traffic_source"), ("cpu_baseline", "sample"), "kitti_gnc"):
+        if len(text) <= LINE_LIMIT:
+            break
+        if isinstance(drop, tuple):
+            if isinstance(line.get(drop[0]), dict):
+                line[drop[0]].pop(drop[1], None)
+        else:
+            line.pop(drop, None)
+        text = json.dumps(line, separators=(",", ":"))
+    if len(text) > LINE_LIMIT:
+        raise RuntimeError("bench line is %d bytes (> %d)" % (len(text), LINE_LIMIT))
+    return text
+
+
 def main():
     args = parse_args()
     if args.sequential:
@@ -713,17 +953,15 @@ def main():
     traffic = None
     traffic_src = None
     import glob
+    pmc = None
     pmc_files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_fetch_write.json")))
     if world == 1 and args.workload == "grid100k" and r == 5 and pmc_files:
         # HBM-side bytes per launch from rocprofv3 PMC passes of this same command (separate FETCH_SIZE and
-        # WRITE_SIZE passes, tools/profile_round.sh): FETCH_SIZE x 2 (gfx950 correction, calibrated on
-        # k_retract / k_rtr_update whose byte counts are exact) + WRITE_SIZE, KB -> bytes; "max" = the full
-        # (non-early-exit) launches.  The newest committed summary is used -- a constant of the committed profile, not
-        # a measurement of this run (traffic_source says which file).
+        # WRITE_SIZE passes, tools/profile_round.sh; pmc_bytes() above).  The newest committed summary is used -- a
+        # constant of the committed profile, not a measurement of this run (traffic_source says which file).
         pmc = json.load(open(pmc_files[-1]))
-        key = kname.replace(",", ", ")
-        if key in pmc.get("FETCH_SIZE_KB", {}) and key in pmc.get("WRITE_SIZE_KB", {}):
-            traffic = (2.0 * pmc["FETCH_SIZE_KB"][key]["max"] + pmc["WRITE_SIZE_KB"][key]["max"]) * 1024.0
+        traffic, key = pmc_bytes(pmc, kname.split("<")[0] + "<")
+        if traffic is not None:
             traffic_src = "%s [%s]" % (os.path.relpath(pmc_files[-1], ROOT), key)
     # HBM figure first (SURVEY 8d protocol: every operand of the launch cycles through > 256 MB of private copies, so
     # the 256 MB Infinity Cache cannot serve it); `warm` = back-to-back launches on the solver's own buffers, which is
@@ -732,22 +970,33 @@ def main():
     vec = 8 * r * b_ * n_local
     ms_it = (C.c_double * 5)()
     dpgo_amd.lib.check(lib.dpgo_bench_iteration_kernels(agent.problem.handle, args.spmm_reps, 10, ms_it))
+    # Every kernel of one preconditioned tCG iteration gets TWO byte counts: `algorithmic_bytes_fp64` (every operand at
+    # 8 bytes, the full Q: comparable across storages) and `streamed_bytes` (what THIS configuration's launch moves: upper
+    # blocks only on the symmetric storage, fp32 operator copies and cycle vectors at 4 bytes).  achieved / frac are on
+    # the streamed bytes; `traffic` = the committed PMC summary's HBM-side bytes of that kernel (pmc_bytes()).
     # (block-Jacobi mode reads X for the tangent projection of z: 8 pose vectors; the multilevel pre-smoothing step is not
     # projected: 7 -- the probe runs the mode the hierarchy state selects, dpgo_bench_iteration_kernels)
+    vb = 4 if ops_active else 8             # bytes per stored value of the cycle's level-0 operator copies
+    xb = 4 if ops_state["vectors"] else 8   # bytes per entry of the two cycle-internal vectors
+    pbb = 8 * b_ * b_ * n_local             # one (d+1)^2 block per pose, fp64 (smoother factors; prolongation at vb)
     upd_vecs = 8 if args.precond == "jacobi" else 7
-    kernels = [dict(kernel="k_tcg_update (eta, r updates, pre-smoothing / block-Jacobi, <r,r>)",
-                    bytes_per_launch=upd_vecs * vec + 8 * b_ * b_ * n_local, avg_launch_us=ms_it[0] * 1e3)]
+    kernels = [dict(kernel="k_tcg_update_span" if span else "k_tcg_update", pmc_prefix="k_tcg_update",
+                    what="eta, r updates, pre-smoothing / block-Jacobi, <r,r>",
+                    algorithmic_bytes_fp64=upd_vecs * vec + pbb,
+                    # (multilevel mode: reads eta, delta, H delta, r and the smoother factors, writes eta, r and the
+                    # pre-smoothed iterate -- in the cycle's vector storage)
+                    streamed_bytes=(upd_vecs * vec + pbb) if args.precond == "jacobi" else (6 * vec + pbb + vec * xb // 8),
+                    avg_launch_us=ms_it[0] * 1e3)]
     ml_info = None
     if args.precond != "jacobi":
         ml_info = agent.problem.setupMultilevel()  # (auto may not have built it yet)
         qb = nnzb_local * (8 * b_ * b_ + 4) + 4 * (n_local + 1)
-        pbb = 8 * b_ * b_ * n_local
         Nc = ml_info["sizes"][-1] * b_
         cbits = 32 if ops_state["dense"] else agent.problem.multilevelCoarseBits()  # (what the timed steps streamed)
         ml_info["coarse_inverse_bits"] = cbits
         # storage of the level-0 operator copies the cycle streams (symmetric Q in the restriction, A P in the
         # post-smoothing, prolongation blocks): fp32 copies by default on blocks that run the symmetric storage; every
-        # product and sum is fp64.  bytes_per_launch of those two kernels below stay the ALGORITHMIC (fp64) bytes.
+        # product and sum is fp64.
         ml_info["cycle_operator_copy_bits"] = 32 if ops_active else 64
         path = agent.problem.multilevelPath()
         ml_info["path"] = path
@@ -758,35 +1007,62 @@ def main():
             nnzb_ap = int(agent.problem.multilevelGet(0, "ap_nnzb")[0])
         if path["packed_dense"]:
             nt_ = -(-Nc // 64)
-            dense = dict(kernel="k_ml_coarse_prolong -> k_dense_sym_apply + k_dense_sym_finish (packed lower triangle of the "
-                                "inverse of %d unknowns, fp64, matrix cores)" % Nc,
-                         bytes_per_launch=8 * 64 * 64 * nt_ * (nt_ + 1) // 2 + 2 * 8 * r * Nc + 2 * 8 * r * 64 * nt_ * nt_ // 2)
+            db = 8 * 64 * 64 * nt_ * (nt_ + 1) // 2 + 2 * 8 * r * Nc + 2 * 8 * r * 64 * nt_ * nt_ // 2
+            dense = dict(kernel="k_dense_sym_apply", pmc_prefix="k_dense_sym_apply",
+                         what="k_ml_coarse_prolong -> k_dense_sym_apply + k_dense_sym_finish (packed lower triangle of the "
+                              "inverse of %d unknowns, fp64, matrix cores)" % Nc,
+                         algorithmic_bytes_fp64=db, streamed_bytes=db)
         else:
-            dense = dict(kernel="k_ml_coarse_prolong (dense inverse of %d unknowns stored in fp%d, fp64 arithmetic%s)"
-                                % (Nc, cbits, "" if path["ap"] else ", + prolongation"),
-                         bytes_per_launch=(cbits // 8) * Nc * Nc + 8 * r * Nc
-                         + (2 * vec + pbb if two and not path["ap"] else 0))
+            tail_ = (2 * vec + pbb if two and not path["ap"] else 0)
+            dense = dict(kernel="k_ml_coarse_prolong", pmc_prefix="k_ml_coarse_prolong",
+                         what="dense inverse of %d unknowns stored in fp%d, fp64 arithmetic%s"
+                              % (Nc, cbits, "" if path["ap"] else ", + prolongation"),
+                         algorithmic_bytes_fp64=8 * Nc * Nc + 8 * r * Nc + 8 * r * Nc * (1 if path["ap"] else 0) + tail_,
+                         streamed_bytes=(cbits // 8) * Nc * Nc + (cbits // 8) * r * Nc + 8 * r * Nc * (1 if path["ap"] else 0) + tail_)
         dense["avg_launch_us"] = ms_it[2] * 1e3
         if path["ap"]:
-            post = dict(kernel="k_ml_post -> k_ml_post_ap (post-smoothing through A P and the coarse solution, prolongation, "
-                               "projection, <r,r>, <z,r>)",
-                        bytes_per_launch=nnzb_ap * (8 * b_ * b_ + 4) + 4 * (n_local + 1) + 4 * vec + 2 * pbb)
+            post = dict(kernel="k_ml_post_ap", pmc_prefix="k_ml_post_ap",
+                        what="post-smoothing through A P and the coarse solution, prolongation, projection, <r,r>, <z,r>",
+                        algorithmic_bytes_fp64=nnzb_ap * (8 * b_ * b_ + 4) + 4 * (n_local + 1) + 4 * vec + 2 * pbb,
+                        # A P and the prolongation blocks at vb, the kept residual at xb; X, r, smoother factors, the
+                        # aggregate labels and the output z in fp64 / int32; the coarse solution once
+                        streamed_bytes=nnzb_ap * (vb * b_ * b_ + 4) + 4 * (n_local + 1) + 3 * vec + vec * xb // 8
+                        + pbb + pbb * vb // 8 + 4 * n_local + 8 * r * Nc)
         else:
-            post = dict(kernel="k_ml_post (post-smoothing in the SpMM epilogue, projection, <r,r>, <z,r>)",
-                        bytes_per_launch=qb + 4 * vec + pbb)
+            post = dict(kernel="k_ml_post", pmc_prefix="k_ml_post<",
+                        what="post-smoothing in the SpMM epilogue, projection, <r,r>, <z,r>",
+                        algorithmic_bytes_fp64=qb + 4 * vec + pbb, streamed_bytes=qb + 4 * vec + pbb)
         post["avg_launch_us"] = ms_it[3] * 1e3
+        partials = int(agent.problem.multilevelGet(0, "restrict_partials")[0]) if graph else 0
+        if timed == "symmetric":  # the restriction walks the symmetric storage (values at vb)
+            q_stream = nu_ * (vb * b_ * b_ + 4) + (nnzb_local - nu_) * 8 + 2 * 4 * (n_local + 1)
+        else:
+            q_stream = qb
         kernels += [
-            dict(kernel="k_ml_restrict%s, level 0 (r - A x1 in one pass over Q, P^T, aggregate sums%s)"
-                        % (" -> k_ml_agg_sum" if graph else "", ", residual kept" if path["ap"] else ""),
+            dict(kernel="k_ml_restrict" + (" + k_ml_agg_sum" if graph else ""), pmc_prefix="k_ml_restrict",
+                 pmc_prefix2="k_ml_agg_sum" if graph else None,
+                 what="level 0: r - A x1 in one pass over Q, P^T, aggregate sums%s" % (", residual kept" if path["ap"] else ""),
                  # (graph aggregates: one partial sum per run of same-aggregate poses inside a wave's chunk is written by
                  # the restriction and read by k_ml_agg_sum -- a pose-sized tile each)
-                 bytes_per_launch=qb + 2 * vec + pbb + vec // abs(ml_info["ks"][0]) + (vec if path["ap"] else 0)
-                 + (2 * 8 * r * b_ * int(agent.problem.multilevelGet(0, "restrict_partials")[0]) if graph else 0),
+                 algorithmic_bytes_fp64=qb + 2 * vec + pbb + vec // abs(ml_info["ks"][0]) + (vec if path["ap"] else 0)
+                 + 2 * 8 * r * b_ * partials,
+                 # Q (this storage) + the pre-smoothed iterate (own tiles; its gathered tiles are re-reads) and the kept
+                 # residual at xb + r in fp64 + prolongation blocks at vb + run table + partial sums out and in + rc
+                 streamed_bytes=q_stream + vec * xb // 8 + vec + pbb * vb // 8 + (vec * xb // 8 if path["ap"] else 0)
+                 + (4 * n_local if graph else 0) + 2 * 8 * r * b_ * partials + (cbits // 8) * r * Nc,
                  avg_launch_us=ms_it[1] * 1e3),
             dense, post]
     for k_ in kernels:
-        k_["achieved"] = k_["bytes_per_launch"] / max(k_["avg_launch_us"], 1e-9) / 1e3
+        k_["achieved"] = k_["streamed_bytes"] / max(k_["avg_launch_us"], 1e-9) / 1e3
         k_["frac"] = k_["achieved"] / HBM_PEAK_GBS
+        k_["frac_fp64_equivalent"] = k_["algorithmic_bytes_fp64"] / max(k_["avg_launch_us"], 1e-9) / 1e3 / HBM_PEAK_GBS
+        t_, key_ = pmc_bytes(pmc, k_.pop("pmc_prefix"))
+        p2_ = k_.pop("pmc_prefix2", None)
+        if t_ is not None and p2_:
+            t2_, _ = pmc_bytes(pmc, p2_)
+            t_ += t2_ or 0.0
+        k_["traffic"] = t_
+        k_["frac_traffic"] = (t_ / max(k_["avg_launch_us"], 1e-9) / 1e3 / HBM_PEAK_GBS) if t_ is not None else None
     roofline = dict(bound="hbm",
                     kernel="%s (one tCG step: Q*z block-SpMM + Riemannian-Hessian epilogue + in-place direction / "
                            "H-direction recurrences)" % kname,
@@ -813,8 +1089,26 @@ def main():
     # the bytes the TIMED kernel's storage really moves, whichever storage that is (the plain arrays move exactly the
     # algorithmic bytes; the symmetric storage stores the upper blocks only)
     own = hb_sym_own if timed == "symmetric" else hb
+    for e_, pre_ in ((roofline["spmm_only"], "k_spmm<"), (spmm_sym, "k_spmm_sym<")):
+        if e_ is not None:
+            e_["traffic"], _ = pmc_bytes(pmc, pre_)
     roofline.update(storage=timed, stored_bytes_per_launch=own, achieved_own_bytes=own / (ms_hrot.value * 1e-3) / 1e9,
                     frac_own_bytes=own / (ms_hrot.value * 1e-3) / 1e9 / HBM_PEAK_GBS)
+    # One whole preconditioned tCG iteration of the TIMED loop: the bytes its launches stream (the Hessian-step kernel's own
+    # bytes + the kernels above) over the loop's wall time per product (outer-iteration kernels and launch gaps included),
+    # and the same with the committed PMC bytes.
+    us_pp = 1e6 * elapsed / max(tcg_total, 1)
+    it_bytes = own + sum(k_["streamed_bytes"] for k_ in kernels)
+    it_traffic = (traffic + sum(k_["traffic"] for k_ in kernels)) if (traffic is not None and all(
+        k_["traffic"] is not None for k_ in kernels)) else None
+    roofline["iteration"] = dict(
+        launches=1 + len(kernels) + sum(1 for k_ in kernels if " + " in k_["kernel"]),
+        bytes=it_bytes, algorithmic_bytes_fp64=hb + sum(k_["algorithmic_bytes_fp64"] for k_ in kernels),
+        traffic=it_traffic, us_per_product=us_pp, achieved=it_bytes / us_pp / 1e3, frac=it_bytes / us_pp / 1e3 / HBM_PEAK_GBS,
+        frac_traffic=(it_traffic / us_pp / 1e3 / HBM_PEAK_GBS) if it_traffic is not None else None,
+        kernel_us_sum=ms_hess.value * 1e3 + sum(k_["avg_launch_us"] for k_ in kernels),
+        note="bytes = streamed bytes of the iteration's launches (Hessian step on its own storage + roofline.kernels); "
+             "us_per_product = timed loop's wall time / its Hessian-vector products")
 
     # Blocks in the latency regime: the timed loop launched ONE kernel per solve (k_rtr_persist: the whole RTR solve, Q
     # resident in registers, vectors in LDS, products synchronised by an in-kernel all-reduce) -- that launch is the
@@ -839,6 +1133,7 @@ def main():
             # multi-launch kernel's is effective_algorithmic_GBs = products x the tCG step's algorithmic bytes / time.
             hbm_model = qb_ + 4 * vec + 8 * b_ * b_ * n_local
             ach_h = hbm_model / (bs["ms"] * 1e-3) / 1e9
+            roofline["iteration"] = None  # (one launch per solve: products_per_launch / us_per_product below)
             roofline.update(
                 kernel="k_rtr_persist<%d,%d,%d,%d> (a whole RTR solve in one launch: %d workgroups, Q in registers, iterates "
                        "in LDS, in-kernel all-reduces)" % (d, r, pinfo.get("last_split", 0), pinfo.get("last_tiles", 0),
@@ -882,6 +1177,9 @@ def main():
             try:
                 X_set = np.ascontiguousarray(np.concatenate([agents[a].in_caller_order(agents[a]._snap).cpu().numpy() for a in sorted(agents)], axis=0))
                 settled_cpu = cpu_baseline_reference(meas, n, X_set, r)
+                settled_cpu["sample_short"] = ("reference configuration: 8 agents x %d poses, one core each, exact sparse factor "
+                                               "of Q_a+0.1I (SciPy SuperLU for CHOLMOD), RTR 3x<=50 tCG, ONE two-colour sweep from "
+                                               "the SETTLED iterate" % (n // 8))
                 settled_cpu["sample"] = "as cpu_baseline.sample, from the benchmark's SETTLED iterate (the state every " \
                                         "timed step restores): " + settled_cpu["sample"]
                 try:
@@ -935,6 +1233,18 @@ def main():
                     also[key] = secondary_single_agent("sphere2500", r, pc, args.steps, args.warmup, args.settle)
                 except Exception as exc:  # noqa: BLE001
                     also[key] = {"error": repr(exc)}
+
+    kitti = None
+    if rank == 0 and world == 1 and not args.no_secondary and args.workload == "grid100k":
+        try:  # BASELINE configs[4]: the re-weighted rebuild of Q each GNC outer iteration, timed
+            kitti = kitti_gnc_gpu(r, dev_index)
+            if not args.no_cpu_baseline:
+                try:
+                    kitti["cpu"] = kitti_gnc_cpu(r, budget_updates=10)
+                except Exception as exc:  # noqa: BLE001
+                    sys.stderr.write("bench.py: kitti_gnc CPU pair failed: %r\n" % (exc,))
+        except Exception as exc:  # noqa: BLE001
+            kitti = {"error": repr(exc)}
 
     if rank == 0:
         if cpu and cpu.get("single_agent_port", cpu).get("fOpt") is not None:
@@ -990,6 +1300,11 @@ def main():
                                              ml_info["cycle_operator_copy_bits"], 32 if ops_state["vectors"] else 64,
                                              ml_info["coarse_inverse_bits"]))
                        if ml_info else None,
+                       "cycle_storage_short": ("cycle operators fp%d, cycle vectors fp%d, dense level fp%d; tCG vectors, Hessian "
+                                               "step and all arithmetic fp64" % (
+                                                   ml_info["cycle_operator_copy_bits"], 32 if ops_state["vectors"] else 64,
+                                                   ml_info["coarse_inverse_bits"])) if ml_info else None,
+                       "precond": args.precond,
                        "hierarchy_setup_ms": tt_main.get("hierarchy_setup_ms"),
                        "time_to_tolerance_incl_setup_ms": tt_main.get("ms_incl_setup") if tt_main.get("reached") else None,
                        "products_per_step": tcg_total / max(args.steps, 1),
@@ -1018,6 +1333,7 @@ def main():
             "roofline": roofline,
             "cpu_baseline": cpu,
             "also": also,
+            "kitti_gnc": kitti,
             "quality": {"settle_iterations": settled,
                         "cost_2f_trajectory": [c for c, _ in trajectory],
                         "gradnorm_trajectory": [g for _, g in trajectory],
@@ -1029,7 +1345,16 @@ def main():
                                            "host synchronisation inside the timed loop)",
                         "to_tolerance": to_tol},
         }
-        print(json.dumps(out))
+        # Everything measured goes to bench_detail.json and to an EARLIER stdout line prefixed "DETAIL "; the LAST stdout
+        # line is the driver's: one JSON object of at most 6 KB (compact_line).
+        try:
+            with open(os.path.join(ROOT, "bench_detail.json"), "w") as fh:
+                json.dump(out, fh, indent=1)
+        except OSError as exc:
+            sys.stderr.write("bench.py: bench_detail.json not written: %r\n" % (exc,))
+        print("DETAIL " + json.dumps(out))
+        print(compact_line(out))
+        sys.stdout.flush()
     if use_dist:
         dist.destroy_process_group()
 

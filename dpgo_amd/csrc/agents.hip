@@ -621,16 +621,28 @@ int dpgo_flags_write_device(int n, unsigned long long* const* words_dev, const u
   HIPC(hipGetLastError());
   return DPGO_OK;
 }
-int dpgo_flags_wait_device(int n, unsigned long long* const* words_dev, const unsigned long long* values, int timeout_ms,
-                           void* stream) {
-  if (n < 0 || (n > 0 && (!words_dev || !values)) || timeout_ms <= 0) return fail(DPGO_ERR_INVALID, "bad ordering-word arguments");
+namespace {
+int flags_wait(int n, unsigned long long* const* words_dev, const unsigned long long* values, long long timeout_ms,
+               unsigned long long* err_word, void* stream) {
   for (int first = 0; first < n; first += kFlagCap) {
     FlagTable t;
     CHK(flag_table(n, words_dev, values, first, &t));
-    hipLaunchKernelGGL(k_flags_wait, dim3(1), dim3(64), 0, (hipStream_t)stream, t, (long long)timeout_ms * 100000LL);
+    hipLaunchKernelGGL(k_flags_wait, dim3(1), dim3(64), 0, (hipStream_t)stream, t, timeout_ms * 100000LL, err_word);
   }
   HIPC(hipGetLastError());
   return DPGO_OK;
+}
+}  // namespace
+int dpgo_flags_wait_device(int n, unsigned long long* const* words_dev, const unsigned long long* values, int timeout_ms,
+                           void* stream) {
+  if (n < 0 || (n > 0 && (!words_dev || !values)) || timeout_ms <= 0) return fail(DPGO_ERR_INVALID, "bad ordering-word arguments");
+  return flags_wait(n, words_dev, values, timeout_ms, nullptr, stream);
+}
+int dpgo_flags_wait_device_checked(int n, unsigned long long* const* words_dev, const unsigned long long* values,
+                                   long long timeout_ms, unsigned long long* err_word, void* stream) {
+  if (n < 0 || (n > 0 && (!words_dev || !values)) || timeout_ms < 0 || (timeout_ms > 0 && !err_word))
+    return fail(DPGO_ERR_INVALID, "bad ordering-word arguments");
+  return flags_wait(n, words_dev, values, timeout_ms, err_word, stream);
 }
 
 int dpgo_exchange_plan_destroy(dpgo_exchange_plan_t pl) {

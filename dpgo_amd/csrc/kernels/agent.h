@@ -32,8 +32,8 @@ __global__ __launch_bounds__(kBlock) void k_scatter_tiles(const double* __restri
 // (hipIpc).  A producer's stream writes a word AFTER the kernel that produced the data (stream order: that kernel's
 // end-of-kernel release has made its stores visible device-wide); a consumer's stream runs k_flags_wait BEFORE the kernel
 // that reads the data (whose start-of-kernel acquire then sees it).  System-scope atomics (sc0 sc1: write-through stores,
-// cache-bypassing loads), so the words themselves need no kernel boundary.  The wait is bounded: a word that does not
-// arrive within `timeout_ticks` (100 MHz wall clock) traps -- a loud failure of that process instead of a hung GPU.
+// cache-bypassing loads), so the words themselves need no kernel boundary.  The wait can be bounded (`timeout_ticks` of the
+// 100 MHz wall clock): a word that does not arrive in time is reported through an error word the host polls, or traps.
 constexpr int kFlagCap = 32;
 struct FlagTable {
   unsigned long long* p[kFlagCap];
@@ -44,13 +44,20 @@ static __global__ void k_flags_write(FlagTable t) {
   const int i = threadIdx.x;
   if (i < t.n) __hip_atomic_store(t.p[i], t.v[i], __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
-static __global__ void k_flags_wait(FlagTable t, long long timeout_ticks) {
+// timeout_ticks <= 0: no limit.  err (host-coherent memory, may be NULL): a word that times out is REPORTED there (1 + its
+// index, system-scope store) and the kernel returns -- the host reads the word at its next exchange and raises; without an
+// error word the kernel traps (the process's HIP context is lost: the round-5 behaviour, kept for dpgo_flags_wait_device).
+static __global__ void k_flags_wait(FlagTable t, long long timeout_ticks, unsigned long long* err) {
   const int i = threadIdx.x;
   if (i < t.n) {
     const long long t0 = wall_clock64();
     while (__hip_atomic_load(t.p[i], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < t.v[i]) {
       __builtin_amdgcn_s_sleep(16);
-      if (wall_clock64() - t0 > timeout_ticks) __builtin_trap();
+      if (timeout_ticks > 0 && wall_clock64() - t0 > timeout_ticks) {
+        if (!err) __builtin_trap();
+        __hip_atomic_store(err, (unsigned long long)(i + 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        break;
+      }
     }
   }
 }

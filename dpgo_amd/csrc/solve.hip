@@ -14,10 +14,14 @@ int launch_tcg_update(dpgo_problem_s* p, const double* dinv, int first, double* 
       hipLaunchKernelGGL((k_tcg_update_span<D, R>), dim3(g), dim3(kBlock), 0, p->stream, p->x1, p->g1, dinv, p->delta,
                          p->Hd, p->eta, p->rr, zt, p->pA(), p->grid_s(), p->pB(), p->dstate + p->cur,
                          p->dstate + (p->cur ^ 1), first, p->n, p->hflag, p->launch_gen(), ml_omega, z32);
-    else
+    else {
+      // (odd tile size: the generic kernel has no fp32 output -- resolve_tcg_storage keeps such blocks off the symmetric
+      // storage, hence off the cycle's fp32 vectors; a state that says otherwise is refused instead of dropping z32)
+      if (z32) return fail(DPGO_ERR_STATE, "fp32 cycle vectors need the span kernels (even pose tile size)");
       hipLaunchKernelGGL((k_tcg_update<D, R>), dim3(g), dim3(kBlock), 0, p->stream, p->x1, p->g1, dinv, p->delta,
                          p->Hd, p->eta, p->rr, zt, p->pA(), p->grid_s(), p->pB(), p->dstate + p->cur,
                          p->dstate + (p->cur ^ 1), first, p->n, p->hflag, p->launch_gen(), ml_omega);
+    }
   });
   HIPC(hipGetLastError());
   p->cur ^= 1;
@@ -309,7 +313,7 @@ unsigned long long iter_graph_key(const dpgo_problem_s* p, const double* dinv, b
   k.add((long long)p->zr_from_post), k.add((long long)p->nb_zr()), k.add((long long)p->device);
   key_bsr(k, p->Q);
   const auto& y = p->sym;
-  k.add(y.urow), k.add(y.ucol), k.add(y.uvalsT), k.add(y.lrow), k.add(y.lcol), k.add(y.lslot);
+  k.add(y.urow), k.add(y.ucol), k.add(y.uvalsT), k.add(y.lrow), k.add(y.lcol), k.add(y.lslot), k.add(y.tord);
   const void* vecs[] = {p->x1, p->g1, p->S1, p->z, p->delta, p->Hd, p->eta, p->rr, dinv, p->dinv, p->partials, p->dstate, p->hflag};
   for (auto v : vecs) k.add(v);
   if (!ml) return k.h;

@@ -9,8 +9,14 @@ is a `ready` word in q's process (the tiles of epoch e have landed) and an `ack`
 e).  An exchange enqueues, on the stream everything else of the sweep is enqueued on and without a host wait:
     acknowledge what arrived earlier  ->  wait for the acks of what is about to be overwritten  ->  pack kernel (writes into
     the receivers' buffers)  ->  publish `ready`  ->  wait for the `ready` words of the incoming messages
-(C ABI dpgo_flags_write_device / dpgo_flags_wait_device: system-scope atomics; the data itself is ordered by kernel
-boundaries on either side; a wait is bounded and traps instead of hanging).  Round 4 ordered an exchange with two HOST
+(C ABI dpgo_flags_write_device / dpgo_flags_wait_device_checked: system-scope atomics; the data itself is ordered by kernel
+boundaries on either side).  A wait has NO time limit by default -- a late peer (a host-side Q rebuild, a checkpoint, a
+debugger, a long local solve) delays the stream exactly as round 4's host barriers delayed the host; DPGO_IPC_WAIT_TIMEOUT_MS
+(or the constructor's wait_timeout_ms) bounds it, and a word that has not arrived by then is reported through an error word
+in pinned host memory: the NEXT exchange() / check() / close() of that process raises RuntimeError (what was read in between
+is stale); nothing traps, the HIP context survives.  Any kernel that reads agent.nbr / nbr_aux must be enqueued BEFORE the
+next exchange() call (which acknowledges the epoch and so lets the sender overwrite the buffer), on the stream exchange() runs
+on -- readers on an agent's own stream are ordered in front of the acknowledgement by an event.  Round 4 ordered an exchange with two HOST
 barriers (2.0 ms of an 8.97 ms sweep at 4 x 25 000 poses); DPGO_IPC_HOST_BARRIERS=1 keeps that scheme for A/B runs.
 
 What it needs from the launcher: a torch.distributed process group for the rendezvous (the IPC handles travel over it once;
@@ -33,15 +39,22 @@ from . import lib as L
 class IpcPeerStore:
     """Collective constructor (every rank of the default process group calls it with its RBCDCluster)."""
 
-    WAIT_TIMEOUT_MS = 20000  # a peer that never publishes: the waiting kernel traps after this long
+    WAIT_TIMEOUT_MS = 0  # default limit of a device-side wait, milliseconds; 0 = none (DPGO_IPC_WAIT_TIMEOUT_MS overrides)
 
-    def __init__(self, cluster):
+    def __init__(self, cluster, wait_timeout_ms=None):
         import torch
         import torch.distributed as dist
         self.torch, self.dist = torch, dist
         self.cluster = cluster
         self.rank, self.world = dist.get_rank(), dist.get_world_size()
         self.device_ordered = os.environ.get("DPGO_IPC_HOST_BARRIERS", "0") != "1"
+        if wait_timeout_ms is None:
+            wait_timeout_ms = int(os.environ.get("DPGO_IPC_WAIT_TIMEOUT_MS", str(self.WAIT_TIMEOUT_MS)))
+        if wait_timeout_ms < 0:
+            raise ValueError("wait_timeout_ms >= 0 (0 = no limit)")
+        self.wait_timeout_ms = int(wait_timeout_ms)
+        # the word a timed-out wait reports into: pinned host memory (device-visible; read here without a stream sync)
+        self._err = torch.zeros(1, dtype=torch.int64).pin_memory()
         self._remote: Dict[Tuple[int, bool], object] = {}  # (agent id, aux) -> tensor aliasing that agent's buffer
         self._plans: Dict[tuple, object] = {}
         self._shared_gen: Dict[bool, int] = {}
@@ -51,7 +64,9 @@ class IpcPeerStore:
         self._msgs = list(cluster.plan.messages(None))
         self._mid = {m: k for k, m in enumerate(self._msgs)}
         nm = max(1, len(self._msgs))
-        dev = next(iter(cluster.agents.values())).device
+        # (a rank that hosts no agent still takes part in the collective rendezvous below)
+        dev = (next(iter(cluster.agents.values())).device if cluster.agents
+               else torch.device("cuda", torch.cuda.current_device()))
         self._words = torch.zeros(2 * 2 * nm, dtype=torch.int64, device=dev)
         self._nm = nm
         self._epoch: Dict[Tuple[int, int, bool], int] = {}     # (a, q, aux) -> epochs sent / expected so far
@@ -91,7 +106,27 @@ class IpcPeerStore:
         self._shared_gen[aux] = self.cluster._buffer_generation()
 
     def _destroy(self, handle) -> None:
-        next(iter(self.cluster.agents.values())).problem._lib.dpgo_exchange_plan_destroy(handle)
+        L.load().dpgo_exchange_plan_destroy(handle)
+
+    def check(self) -> None:
+        """Raises if a device-side wait of this process timed out (wait_timeout_ms > 0 only).  Reads pinned host memory: no
+        stream synchronisation."""
+        code = int(self._err[0].item())
+        if code:
+            raise RuntimeError("dpgo_amd.ipc: a device-side wait for a peer's ordering word timed out after %d ms (word %d "
+                               "of its batch); the neighbour tiles read since then are stale.  Raise "
+                               "DPGO_IPC_WAIT_TIMEOUT_MS (0 = no limit) or use DPGO_IPC_HOST_BARRIERS=1"
+                               % (self.wait_timeout_ms, code - 1))
+
+    def _wait(self, lib, entries, stream) -> None:
+        if not entries:
+            return
+        n = len(entries)
+        ptrs = (C.c_void_p * n)(*[p for p, _ in entries])
+        vals = (C.c_ulonglong * n)(*[v for _, v in entries])
+        L.check(lib.dpgo_flags_wait_device_checked(n, ptrs, vals, self.wait_timeout_ms,
+                                                   C.c_void_p(self._err.data_ptr()) if self.wait_timeout_ms > 0 else None,
+                                                   stream))
 
     def _dst(self, q: int, a: int, aux: bool):
         """The slots of agent q's neighbour buffer that agent a fills -- local tensor or the mapped remote one."""
@@ -154,8 +189,21 @@ class IpcPeerStore:
             # re-sharing is collective and this scheme has no host rendezvous per exchange to agree on it
             raise RuntimeError("dpgo_amd.ipc: an agent re-bound a buffer the peers have mapped; call "
                                "cluster.peer_store.reshare() on EVERY rank before the next exchange")
-        lib = next(iter(c.agents.values())).problem._lib
-        stream = torch.cuda.current_stream().cuda_stream or None
+        self.check()
+        unknown = [m for m in msgs if m not in self._mid]
+        if unknown:
+            raise ValueError("dpgo_amd.ipc: exchange(messages=...) entries outside the exchange plan: %r" % (unknown[:4],))
+        lib = L.load()
+        cur = torch.cuda.current_stream()
+        stream = cur.cuda_stream or None
+        # readers of the neighbour buffers enqueued on an agent's OWN stream (it differs from this one only in hand-written
+        # drivers) must be ahead of the acknowledgement below: this stream waits for an event recorded on theirs
+        for ag in c.agents.values():
+            sid = getattr(ag, "stream_id", None)
+            if sid is not None and sid != cur.cuda_stream:
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.ExternalStream(sid, device=ag.device) if sid else torch.cuda.default_stream(ag.device))
+                cur.wait_event(ev)
         own = c.owner
         out = [(a, q) for a, q in msgs if a in c.agents]
         remote_out = [(a, q) for a, q in out if q not in c.agents]
@@ -168,9 +216,8 @@ class IpcPeerStore:
                 self._acked[(a, q, x)] = e
         self._flags(lib.dpgo_flags_write_device, acks, stream)
         # 2. the receivers have consumed what this exchange overwrites
-        self._flags(lib.dpgo_flags_wait_device, [(self._word(self.rank, aux, 1, m), self._epoch.get((m[0], m[1], aux), 0))
-                                                 for m in remote_out if self._epoch.get((m[0], m[1], aux), 0) > 0],
-                    stream, self.WAIT_TIMEOUT_MS)
+        self._wait(lib, [(self._word(self.rank, aux, 1, m), self._epoch.get((m[0], m[1], aux), 0))
+                         for m in remote_out if self._epoch.get((m[0], m[1], aux), 0) > 0], stream)
         # 3. the tiles
         if out:
             L.check(lib.dpgo_exchange_plan_run(self._plan(out, key, aux), stream))
@@ -180,8 +227,7 @@ class IpcPeerStore:
             self._epoch[k] = self._epoch.get(k, 0) + 1
         self._flags(lib.dpgo_flags_write_device, [(self._word(own(m[1]), aux, 0, m), self._epoch[(m[0], m[1], aux)])
                                                   for m in remote_out], stream)
-        self._flags(lib.dpgo_flags_wait_device, [(self._word(self.rank, aux, 0, m), self._epoch[(m[0], m[1], aux)])
-                                                 for m in remote_in], stream, self.WAIT_TIMEOUT_MS)
+        self._wait(lib, [(self._word(self.rank, aux, 0, m), self._epoch[(m[0], m[1], aux)]) for m in remote_in], stream)
 
     def reshare(self) -> None:
         """Collective: export / open every buffer again after an agent re-bound one (agent.X = ..., a second
@@ -219,6 +265,12 @@ class IpcPeerStore:
 
     def close(self) -> None:
         self.torch.cuda.synchronize()
+        try:
+            self.check()
+        finally:
+            self._close()
+
+    def _close(self) -> None:
         for h in self._plans.values():
             self._destroy(h)
         self._plans.clear()

@@ -135,6 +135,7 @@ SIGNATURES = {
     "dpgo_exchange_plan_destroy": ([_P], _I),
     "dpgo_flags_write_device": ([_I, _P, _P, _P], _I),
     "dpgo_flags_wait_device": ([_I, _P, _P, _I, _P], _I),
+    "dpgo_flags_wait_device_checked": ([_I, _P, _P, C.c_longlong, _P, _P], _I),
     "dpgo_max_translation_distance_device": ([_I, _I, _I, _P, _P, _P, C.POINTER(_D), _P], _I),
     "dpgo_axpby_project_device": ([_I, _I, _I, _D, _P, _D, _P, _D, _P, _I, _P, _P], _I),
     "dpgo_problem_set_persistent": ([_P, _I], _I),

@@ -572,6 +572,13 @@ int dpgo_exchange_plan_destroy(dpgo_exchange_plan_t plan);
 int dpgo_flags_write_device(int n, unsigned long long* const* words_dev, const unsigned long long* values, void* stream);
 int dpgo_flags_wait_device(int n, unsigned long long* const* words_dev, const unsigned long long* values, int timeout_ms,
                            void* stream);
+/* The same wait without the trap (what dpgo_amd/ipc.py enqueues): timeout_ms = 0 waits without a limit -- a late peer (a host
+ * side Q rebuild, a checkpoint, a debugger) only delays the stream, as the host barriers of round 4 did; timeout_ms > 0: a
+ * word that has not arrived by then is REPORTED -- 1 + its index stored (system scope) into *err_word, which must be memory
+ * the host can read without synchronising the stream (pinned host memory) -- and the kernel returns, so that the host can
+ * raise an error at its next exchange instead of losing its HIP context. */
+int dpgo_flags_wait_device_checked(int n, unsigned long long* const* words_dev, const unsigned long long* values,
+                                   long long timeout_ms, unsigned long long* err_word, void* stream);
 
 /* Agent status (PGOAgent::iterate, src/PGOAgent.cpp:399-420): relativeChange = LiftedPoseArray::maxTranslationDistance
  * (src/manifold/Poses.cpp:86-94) of the iterate and the previous one, max_i |p_i - p_i'| over the translation columns.

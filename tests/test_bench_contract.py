@@ -10,6 +10,23 @@ from conftest import ROOT
 
 REQUIRED = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
             "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"}
+LINE_LIMIT = 6144  # the driver's record keeps the last 8 KB of stdout: the LAST line must fit with room to spare
+
+
+def records(stdout):
+    """(driver line, full record): the LAST stdout line is the driver's JSON object (<= 6 KB); everything measured is in
+    the earlier line prefixed 'DETAIL ' (and in bench_detail.json)."""
+    lines = stdout.splitlines()
+    driver = [ln for ln in lines if ln.startswith("{")]
+    detail = [ln for ln in lines if ln.startswith("DETAIL {")]
+    assert len(driver) == 1 and len(detail) == 1 and lines[-1] == driver[0]
+    assert len(driver[0].encode()) < LINE_LIMIT, len(driver[0])
+    line, full = json.loads(driver[0]), json.loads(detail[0][len("DETAIL "):])
+    assert REQUIRED <= set(line) and REQUIRED <= set(full)
+    for k in ("metric", "unit", "n_gpus", "steps", "warmup", "higher_is_better", "scaling", "vs_baseline", "dtype", "data"):
+        assert line[k] == full[k]
+    assert abs(line["value"] - full["value"]) <= 1e-4 * full["value"]  # (the line rounds to 5 significant digits)
+    return line, full
 
 
 def test_algorithmic_byte_formulas_match_the_survey():
@@ -20,6 +37,32 @@ def test_algorithmic_byte_formulas_match_the_survey():
     assert bench.spmm_bytes(2500, 12398, 3, 5) == 2446540  # sphere2500: 2.44 MB
     assert bench.hess_bytes(100000, 687000, 3, 5) == 687000 * 132 + 4 * 100001 + 100000 * (6 * 160 + 72)
     assert bench.HBM_PEAK_GBS == 8000.0
+
+
+def test_compact_line_of_a_committed_full_record_fits_the_drivers_record():
+    """bench.compact_line on the largest full record committed so far (round 5's 24 KB line, which the driver could not
+    parse): below 6 KB, the contract's keys present, floats rounded to 5 significant digits."""
+    import glob
+    sys.path.insert(0, ROOT)
+    import bench
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r0[56]_v*_bench.json")))
+    assert files
+    for f in files:
+        full = json.load(open(f))
+        if "quality" not in full:
+            continue  # (already a compact line)
+        text = bench.compact_line(full)
+        assert len(text.encode()) < LINE_LIMIT and "\n" not in text
+        line = json.loads(text)
+        assert REQUIRED <= set(line) and line["roofline"]["frac"] > 0
+        assert (line["cpu_baseline"] is None) == (full["cpu_baseline"] is None)
+        assert abs(line["value"] - full["value"]) <= 1e-4 * full["value"]
+    # a pathological record (long strings everywhere) still fits: optional groups are dropped
+    full = json.load(open(files[-1]))
+    if "quality" in full:
+        full["config"]["workload"] = "w" * 300
+        full["also"] = {"sphere2500": {"it_per_s": 1.0, "us_per_product": 1.0, "precond_used": "x" * 3000}}
+        assert len(bench.compact_line(full).encode()) < LINE_LIMIT
 
 
 def test_entry_points_exist():
@@ -34,10 +77,26 @@ def test_bench_prints_one_valid_json_line():
                         "--warmup", "1", "--settle", "2", "--cpu-budget-s", "3", "--spmm-reps", "20"],
                        capture_output=True, text=True, cwd=ROOT, timeout=600)
     assert p.returncode == 0, p.stderr[-2000:]
-    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1
-    j = json.loads(lines[0])
-    assert REQUIRED <= set(j)
+    line, j = records(p.stdout)
+    assert os.path.exists(os.path.join(ROOT, "bench_detail.json"))
+    # ---- the driver's line: headline keys, roofline of the timed kernel, the reference-configuration pair
+    assert line["metric"] == "rbcd_iterations_per_sec" and line["n_gpus"] == 1 and line["dtype"] == "f64"
+    lrf, lcb = line["roofline"], line["cpu_baseline"]
+    assert lrf["bound"] == "hbm" and lrf["peak"] == 8000.0 and lrf["unit"] == "GB/s" and lrf["achieved"] > 0
+    assert abs(lrf["frac"] - lrf["achieved"] / lrf["peak"]) < 1e-4 and lrf["kernel"].startswith("k_rtr_persist<3,5,")
+    assert lrf["frac_own_bytes"] > 0 and lrf["streamed_bytes"] > 0 and lrf["traffic"] is None
+    names = [k["kernel"].split()[0] for k in lrf["kernels"]]
+    assert names[:2] == ["k_tcg_update_span", "k_ml_restrict"] and names[2] in ("k_ml_coarse_prolong", "k_dense_sym_apply")
+    assert names[3] in ("k_ml_post", "k_ml_post_ap") and len(names) == 4
+    assert all(k["us"] > 0 and k["streamed_bytes"] > 0 and k["algorithmic_bytes_fp64"] >= k["streamed_bytes"] and
+               abs(k["frac"] - k["streamed_bytes"] / k["us"] / 1e3 / 8000.0) < 1e-3 * k["frac"] for k in lrf["kernels"])
+    assert lcb["kind"] == "port" and lcb["cores"] >= 1 and lcb["value"] > 0 and lcb["unit"] == "it/s" and len(lcb["sample"]) <= 200
+    assert lcb["seconds_per_sweep"] > 0 and lcb["factorisation_seconds"] > 0 and lcb["tcg_iterations"] > 0 and lcb["host_cores"] >= 1
+    assert lcb["gpu_same_work"]["seconds_per_sweep"] > 0 and lcb["gpu_same_work"]["preconditioners"]
+    assert "gpu_over_cpu_same_work" not in lcb
+    assert "workload" in line["config"] and "model" not in line["config"] and line["products_per_step"] > 0
+    assert line["time_to_tolerance_ms"] > 0 and line["hierarchy_setup_ms"] > 0 and line["us_per_product"] > 0
+    # ---- the full record
     assert j["metric"] == "rbcd_iterations_per_sec" and j["unit"] == "it/s" and j["higher_is_better"] is True
     assert j["n_gpus"] == 1 and j["steps"] == 2 and j["warmup"] == 1 and j["dtype"] == "f64" and j["vs_baseline"] is None
     assert j["value"] > 0 and abs(j["value"] - 1e3 / j["ms_per_step"]) < 1e-6 * j["value"]
@@ -71,8 +130,10 @@ def test_bench_prints_one_valid_json_line():
     assert j["config"]["time_to_tolerance_ms"] == j["time_to_tolerance_ms"]
     assert "time_to_tolerance_ms = %.3f" % j["time_to_tolerance_ms"] in j["config"]["local_solver"]
     assert j["config"]["products_per_step"] == j["products_per_step"]
-    assert [k["kernel"].split()[0].rstrip(",") for k in rf["kernels"]] == ["k_tcg_update", "k_ml_restrict",
-                                                                           "k_ml_coarse_prolong", "k_ml_post"]
+    assert [k["kernel"].split()[0] for k in rf["kernels"]] == names
+    # fp64 everywhere on this small block: the streamed bytes ARE the algorithmic bytes, up to the symmetric storage
+    assert all(k["streamed_bytes"] <= k["algorithmic_bytes_fp64"] and k["frac"] <= k["frac_fp64_equivalent"] + 1e-12
+               for k in rf["kernels"])
     assert all(k["avg_launch_us"] > 0 for k in rf["kernels"])
     # the once-per-Q cost of the preconditioner beside the time to tolerance (the reference factors inside its first solve)
     assert j["hierarchy_setup_ms"] > 0 and j["hierarchy_values_only_ms"] > 0
@@ -108,6 +169,48 @@ def test_bench_prints_one_valid_json_line():
 
 
 @pytest.mark.gpu
+def test_bench_default_invocation_fits_the_drivers_record():
+    """The driver's own command (python bench.py --gpus 1 --steps 20 --warmup 5: the 100k-pose grid): the LAST stdout line
+    is one JSON object below 6 KB carrying `roofline` (headline kernel, PMC traffic, streamed-byte fractions of every kernel
+    of the iteration, the whole iteration) and `cpu_baseline`; BASELINE configs[4] (kitti_00 GNC) has its numbers; the
+    default (fp32 cycle storage) and the fp64-cycle run need the same number of products to the tolerance."""
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "5"],
+                       capture_output=True, text=True, cwd=ROOT, timeout=1200)
+    assert p.returncode == 0, p.stderr[-3000:]
+    line, full = records(p.stdout)
+    assert "100000 poses" in line["config"]["workload"] and line["config"]["agents"] == 1
+    rf = line["roofline"]
+    assert rf["kernel"].startswith("k_tcg_hess_sym<3,5,") and rf["storage"] == "symmetric" and 0.3 < rf["frac"] < 1.0
+    assert rf["streamed_bytes"] < rf["bytes_per_launch"] and rf["frac_own_bytes"] < rf["frac"]
+    assert rf["traffic"] > 0 and rf["traffic_live"] is False and rf["spmm"]["kernel"].startswith("k_spmm_sym<")
+    assert rf["spmm"]["frac"] >= 0.30  # north_star: >= 30 % of the HBM roofline on the Q*X SpMM at 100k poses
+    assert len(rf["kernels"]) == 4
+    for k in rf["kernels"]:
+        assert abs(k["frac"] - k["streamed_bytes"] / k["us"] / 1e3 / 8000.0) < 1e-3 * k["frac"]
+        assert k["streamed_bytes"] <= k["algorithmic_bytes_fp64"] and k["traffic"] > 0
+        assert abs(k["frac_traffic"] - k["traffic"] / k["us"] / 1e3 / 8000.0) < 1e-3 * k["frac_traffic"]
+    it = rf["iteration"]
+    assert it["launches"] == 6 and abs(it["us_per_product"] - line["us_per_product"]) < 1e-3 * it["us_per_product"]
+    assert abs(it["frac"] - it["bytes"] / it["us_per_product"] / 1e3 / 8000.0) < 1e-3 * it["frac"]
+    assert it["bytes"] == rf["streamed_bytes"] + sum(k["streamed_bytes"] for k in rf["kernels"])
+    cb = line["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["value"] > 0 and cb["cores"] >= 1 and len(cb["sample"]) <= 200
+    assert cb["gpu_same_work"]["seconds_per_sweep"] > 0 and "gpu_over_cpu_same_work" not in cb
+    kg = line["kitti_gnc"]  # BASELINE configs[4]: weight update (re-weighted Q rebuild) and GNC outer iteration, timed
+    assert kg["ms_per_weight_update"] > 0 and kg["ms_per_inner_block"] > 0 and kg["updates"] >= 30
+    assert abs(kg["ms_per_gnc_outer_iteration"] - (kg["ms_per_weight_update"] + kg["ms_per_inner_block"])) < 1e-3 * kg["ms_per_gnc_outer_iteration"]
+    assert kg["total_ms"] > 0 and kg["cpu_seconds_per_gnc_outer_iteration"] > 0
+    fk = full["kitti_gnc"]
+    assert (fk["last"]["inliers"], fk["last"]["outliers"], fk["last"]["undecided"]) == (136, 25, 0)
+    # the mixed-precision default against its fp64-cycle twin: same products to the tolerance
+    tt = full["quality"]["to_tolerance"]
+    a, b = tt["grid100k/multilevel"], tt["grid100k/multilevel+fp64_cycle_operators"]
+    assert a["reached"] and b["reached"] and a["cycle_operator_copy_bits"] == 32 and b["cycle_operator_copy_bits"] == 64
+    assert abs(a["products"] - b["products"]) <= 2, (a["products"], b["products"])
+    assert abs(a["gradnorm"] - b["gradnorm"]) <= 1e-3 * b["gradnorm"]
+
+
+@pytest.mark.gpu
 def test_bench_secondary_workload_reports_per_product_cost_and_in_kernel_split():
     """`also.sphere2500` of the headline line (BASELINE's metric is quoted on sphere2500 as well): the fixed-work step rate,
     microseconds per Hessian-vector product and, for a one-launch solve, the in-kernel phase split of participant 0."""
@@ -131,7 +234,8 @@ def test_bench_loopback_runs_the_multi_agent_path_through_rccl():
                         "--no-secondary", "--spmm-reps", "10"],
                        capture_output=True, text=True, cwd=ROOT, timeout=600)
     assert p.returncode == 0, p.stderr[-2000:]
-    j = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][0])
+    line, j = records(p.stdout)
+    assert line["roofline"] is not None and line["cpu_baseline"] is None and line["config"]["agents"] == j["config"]["agents"]
     assert j["config"]["agents"] == 4 and "RCCL" in j["config"]["schedule"] and "loop-back" in j["config"]["schedule"]
     assert j["quality"]["exchange_ms_per_step_rank0"] > 0 and j["value"] > 0
     assert j["quality"]["cost_2f_after_step"] < j["quality"]["cost_2f_trajectory"][0]
@@ -167,7 +271,8 @@ def test_bench_multi_gpu_branch_runs_at_world_size_one():
            "--spmm-reps", "10"]
     p = subprocess.run(cmd, capture_output=True, text=True, cwd=ROOT, timeout=900)
     assert p.returncode == 0, p.stderr[-3000:]
-    j = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][0])
+    line, j = records(p.stdout)
+    assert line["roofline"] is not None and line["cpu_baseline"] is None and line["config"]["agents"] == j["config"]["agents"]
     assert j["config"]["dist_backend"] == "nccl" and j["n_gpus"] == 1 and j["config"]["agents"] == 2
     assert j["config"]["agents_per_gpu"] == 2 and "RCCL" in j["config"]["schedule"]
     assert "torch.distributed process group" in j["config"]["schedule"]
@@ -188,9 +293,8 @@ def test_bench_two_ranks_on_one_gpu_through_the_peer_store():
     p = subprocess.run(cmd, capture_output=True, text=True, cwd=ROOT, timeout=900,
                        env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
     assert p.returncode == 0, p.stderr[-3000:]
-    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1  # rank 0 only
-    j = json.loads(lines[0])
+    line, j = records(p.stdout)  # (one driver line: rank 0 only)
+    assert line["n_gpus"] == 2 and line["config"]["transport"] == "ipc"
     assert j["n_gpus"] == 2 and j["config"]["agents"] == 4 and j["config"]["agents_per_gpu"] == 2
     assert j["config"]["dist_backend"] == "gloo" and j["config"]["transport"] == "ipc" and "peer store" in j["config"]["schedule"]
     assert j["quality"]["exchange_ms_per_step_rank0"] > 0 and j["value"] > 0 and j["scaling"] == "strong"

@@ -767,6 +767,50 @@ def test_whole_solve_at_full_size_matches_oracle(oracle, storage):
         assert total > 40  # the calls reach the regime in which the tCG budget is actually used
 
 
+def test_mixed_precision_default_reaches_the_reference_cost(oracle):
+    """The bridge from the DEFAULT configuration of HBM-bound blocks -- the multilevel cycle streaming fp32 copies of its
+    level-0 operators and keeping its two internal vectors in fp32 -- to the reference's exact fp64 operator, on a block
+    where that storage is active: the synthetic 40 x 40 x 25 grid (40 000 poses, BASELINE configs[3]'s generator), single
+    agent, symmetric storage, RTR to |rgrad| < 1e-4 from the perturbed-truth iterate.  Reference side: the oracle with the
+    EXACT (Q + 0.1 I)^-1 preconditioner (src/QuadraticProblem.cpp:56-69) -- its sparse factor of the 160 000-unknown 3-D
+    operator takes minutes, so the run is a committed fixture (tests/golden/make_golden_grid40k.py ->
+    golden_scalars.json["grid40x40x25_exact"]).  Asserted: final cost within 1e-6 relative on all three pairs (default /
+    fp64 cycle / reference), the two device runs within 2 products and one outer iteration of each other."""
+    import json
+    import torch
+    import dpgo_amd
+    gold = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "golden_scalars.json")))
+    ref = gold["grid40x40x25_exact"]
+    assert ref["precond"] == "exact" and ref["gradNormOpt"] < 1e-4 and ref["n"] == 40000
+    meas, n, Ttrue = oracle.synthetic_grid(40, 40, 25, seed=ref["seed_graph"])
+    d, r = 3, ref["r"]
+    X0 = oracle.lift(oracle.perturbed_truth(Ttrue, seed=ref["seed_iterate"]), r)
+    pg = dpgo_amd.PoseGraph(0, r, d)
+    pg.setMeasurements(to_product_measurements(meas))
+    prob = dpgo_amd.QuadraticProblem(pg)
+    assert abs(prob.f(tiles_to_matrix(X0)) - ref["fInit"]) <= 1e-12 * abs(ref["fInit"])  # the same problem, the same start
+    assert prob.setSpmmVariant("symmetric") == "symmetric"
+    prm = dpgo_amd.ROptParameters(precond="multilevel", gradnorm_tol=1e-4, RTR_iterations=60, RTR_tCG_iterations=500,
+                                  time_bound_s=120.0)
+    out = {}
+    for bits in (32, 64):
+        prob.multilevelOperatorBits(bits)
+        opt = dpgo_amd.QuadraticOptimizer(prob, prm)
+        Xd = torch.tensor(X0, device="cuda", dtype=torch.float64)
+        res = opt.optimizeDevice(Xd)
+        ob = prob.multilevelOperatorBits()
+        assert ob["active"] == ob["vectors"] == (bits == 32), ob  # what the solve's cycles really streamed
+        assert res.gradNormOpt < 1e-4
+        out[bits] = res
+    f32, f64, fo = out[32].fOpt, out[64].fOpt, ref["fOpt"]
+    assert abs(f32 - fo) <= 1e-6 * abs(fo), (f32, fo)
+    assert abs(f64 - fo) <= 1e-6 * abs(fo), (f64, fo)
+    assert abs(f32 - f64) <= 1e-6 * abs(fo), (f32, f64)
+    assert abs(out[32].tcg_iterations - out[64].tcg_iterations) <= 2, (out[32].tcg_iterations, out[64].tcg_iterations)
+    assert abs(out[32].rtr_iterations - out[64].rtr_iterations) <= 1
+    prob.multilevelOperatorBits(32)
+
+
 def test_symmetric_storage_solve_2d_matches_oracle(oracle):
     """k_tcg_hess_sym for SE(2) (three lanes per pose: shuffle reduction instead of the quad butterfly): 50 000-pose
     lattice, r = 4, block-Jacobi, two calls against the plain-C restatement; and the same calls on the plain storage."""

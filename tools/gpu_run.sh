@@ -24,10 +24,14 @@ run_task() {
       local name=$1; shift
       timeout 1200 python bench.py "$@" > "$OUT/$name.out" 2> "$OUT/$name.err"
       grep '^{' "$OUT/$name.out" | tail -1 > "$OUT/$name.json"
-      python - "$OUT/$name.json" <<'PY'
+      grep '^DETAIL {' "$OUT/$name.out" | tail -1 | cut -c8- > "$OUT/${name}_detail.json"
+      python - "$OUT/$name.json" "$OUT/${name}_detail.json" <<'PY'
 import json, sys
 try:
-    j = json.load(open(sys.argv[1]))
+    line = open(sys.argv[1]).read()
+    json.loads(line)
+    j = json.load(open(sys.argv[2]))
+    print("bench line: %d bytes" % len(line.strip()))
 except Exception as e:
     print("bench: no JSON line (%r)" % (e,)); sys.exit(0)
 rf, q = j.get("roofline") or {}, j.get("quality") or {}

@@ -16,7 +16,8 @@ python tools/summarize_prof.py stats gpurun_out/prof_$TAG gpurun_out/${TAG}_benc
 python tools/summarize_prof.py pmc gpurun_out/${TAG}_pmc_fetch_write.json \
   FETCH_SIZE=gpurun_out/pmc_${TAG}_FETCH_SIZE WRITE_SIZE=gpurun_out/pmc_${TAG}_WRITE_SIZE
 cp gpurun_out/${TAG}_pmc_fetch_write.json profiles/  # bench.py reads roofline.traffic from the newest committed summary
-python bench.py 2>/dev/null | tail -1 > gpurun_out/${TAG}_bench.json
+python bench.py 2>/dev/null | tail -1 > gpurun_out/${TAG}_bench.json   # the driver's line (<= 6 KB)
+cp bench_detail.json gpurun_out/${TAG}_bench_detail.json                 # everything measured (the DETAIL line)
 rm -rf gpurun_out/prof_$TAG gpurun_out/pmc_${TAG}_FETCH_SIZE gpurun_out/pmc_${TAG}_WRITE_SIZE
 head -12 gpurun_out/${TAG}_bench_kernel_stats.csv | cut -c1-150
 python -c "
