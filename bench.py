@@ -980,13 +980,15 @@ def main():
     xb = 4 if ops_state["vectors"] else 8   # bytes per entry of the two cycle-internal vectors
     pbb = 8 * b_ * b_ * n_local             # one (d+1)^2 block per pose, fp64 (smoother factors; prolongation at vb)
     upd_vecs = 8 if args.precond == "jacobi" else 7
+
+    def update_bytes(xb_):
+        # block-Jacobi mode: 8 pose vectors + the factors; multilevel mode: reads eta, delta, H delta, r and the smoother
+        # factors, writes eta, r and the pre-smoothed iterate (in the cycle's vector storage)
+        return (upd_vecs * vec + pbb) if args.precond == "jacobi" else (6 * vec + pbb + vec * xb_ // 8)
+
     kernels = [dict(kernel="k_tcg_update_span" if span else "k_tcg_update", pmc_prefix="k_tcg_update",
                     what="eta, r updates, pre-smoothing / block-Jacobi, <r,r>",
-                    algorithmic_bytes_fp64=upd_vecs * vec + pbb,
-                    # (multilevel mode: reads eta, delta, H delta, r and the smoother factors, writes eta, r and the
-                    # pre-smoothed iterate -- in the cycle's vector storage)
-                    streamed_bytes=(upd_vecs * vec + pbb) if args.precond == "jacobi" else (6 * vec + pbb + vec * xb // 8),
-                    avg_launch_us=ms_it[0] * 1e3)]
+                    algorithmic_bytes_fp64=update_bytes(8), streamed_bytes=update_bytes(xb), avg_launch_us=ms_it[0] * 1e3)]
     ml_info = None
     if args.precond != "jacobi":
         ml_info = agent.problem.setupMultilevel()  # (auto may not have built it yet)
@@ -1005,52 +1007,57 @@ def main():
         graph = ml_info["ks"][0] < 0  # graph aggregates: members anywhere, summed by k_ml_agg_sum
         if path["ap"]:  # blocks of A P: the distinct aggregates the block columns of every row fall into
             nnzb_ap = int(agent.problem.multilevelGet(0, "ap_nnzb")[0])
+        partials = int(agent.problem.multilevelGet(0, "restrict_partials")[0]) if graph else 0
+
+        # The byte model of a cycle kernel is ONE function of the storage: (vb_, xb_, cb_) = bytes per operator value /
+        # cycle-vector entry / dense-level entry, sym_ = Q walked on the symmetric storage.  streamed_bytes = the model at
+        # this configuration's storage, algorithmic_bytes_fp64 = the same model at 8 / 8 / 8 bytes and the full Q.
+        def dense_bytes(cb_):
+            if path["packed_dense"]:
+                nt_ = -(-Nc // 64)
+                return 8 * 64 * 64 * nt_ * (nt_ + 1) // 2 + 2 * 8 * r * Nc + 2 * 8 * r * 64 * nt_ * nt_ // 2
+            # the inverse and the restricted residual it multiplies at cb_; the coarse solution out (A P path) in fp64;
+            # without A P the prolongation happens here (x1, P in; x out)
+            return cb_ * Nc * Nc + cb_ * r * Nc + (8 * r * Nc if path["ap"] else 0) + (2 * vec + pbb if two and not path["ap"] else 0)
+
+        def post_bytes(vb_, xb_):
+            if path["ap"]:
+                # A P and the prolongation blocks at vb_, the kept residual at xb_; X, r, smoother factors, the aggregate
+                # labels and the output z in fp64 / int32; the coarse solution once
+                return (nnzb_ap * (vb_ * b_ * b_ + 4) + 4 * (n_local + 1) + 3 * vec + vec * xb_ // 8 + pbb + pbb * vb_ // 8
+                        + 4 * n_local + 8 * r * Nc)
+            return qb + 4 * vec + pbb
+
+        def restrict_bytes(vb_, xb_, cb_, sym_):
+            # Q (this storage) + the pre-smoothed iterate (own tiles; its gathered tiles are re-reads) and the kept residual
+            # at xb_ + r in fp64 + prolongation blocks at vb_ + run table + partial sums out and in (graph aggregates: one
+            # per run of same-aggregate poses inside a wave's chunk) + the restricted residual at cb_
+            q_ = (nu_ * (vb_ * b_ * b_ + 4) + (nnzb_local - nu_) * 8 + 2 * 4 * (n_local + 1)) if sym_ else qb
+            return (q_ + vec * xb_ // 8 + vec + pbb * vb_ // 8 + (vec * xb_ // 8 if path["ap"] else 0)
+                    + (4 * n_local if graph else 0) + 2 * 8 * r * b_ * partials + cb_ * r * Nc)
+
         if path["packed_dense"]:
-            nt_ = -(-Nc // 64)
-            db = 8 * 64 * 64 * nt_ * (nt_ + 1) // 2 + 2 * 8 * r * Nc + 2 * 8 * r * 64 * nt_ * nt_ // 2
             dense = dict(kernel="k_dense_sym_apply", pmc_prefix="k_dense_sym_apply",
                          what="k_ml_coarse_prolong -> k_dense_sym_apply + k_dense_sym_finish (packed lower triangle of the "
-                              "inverse of %d unknowns, fp64, matrix cores)" % Nc,
-                         algorithmic_bytes_fp64=db, streamed_bytes=db)
+                              "inverse of %d unknowns, fp64, matrix cores)" % Nc)
         else:
-            tail_ = (2 * vec + pbb if two and not path["ap"] else 0)
             dense = dict(kernel="k_ml_coarse_prolong", pmc_prefix="k_ml_coarse_prolong",
                          what="dense inverse of %d unknowns stored in fp%d, fp64 arithmetic%s"
-                              % (Nc, cbits, "" if path["ap"] else ", + prolongation"),
-                         algorithmic_bytes_fp64=8 * Nc * Nc + 8 * r * Nc + 8 * r * Nc * (1 if path["ap"] else 0) + tail_,
-                         streamed_bytes=(cbits // 8) * Nc * Nc + (cbits // 8) * r * Nc + 8 * r * Nc * (1 if path["ap"] else 0) + tail_)
-        dense["avg_launch_us"] = ms_it[2] * 1e3
+                              % (Nc, cbits, "" if path["ap"] else ", + prolongation"))
+        dense.update(algorithmic_bytes_fp64=dense_bytes(8), streamed_bytes=dense_bytes(cbits // 8), avg_launch_us=ms_it[2] * 1e3)
         if path["ap"]:
             post = dict(kernel="k_ml_post_ap", pmc_prefix="k_ml_post_ap",
-                        what="post-smoothing through A P and the coarse solution, prolongation, projection, <r,r>, <z,r>",
-                        algorithmic_bytes_fp64=nnzb_ap * (8 * b_ * b_ + 4) + 4 * (n_local + 1) + 4 * vec + 2 * pbb,
-                        # A P and the prolongation blocks at vb, the kept residual at xb; X, r, smoother factors, the
-                        # aggregate labels and the output z in fp64 / int32; the coarse solution once
-                        streamed_bytes=nnzb_ap * (vb * b_ * b_ + 4) + 4 * (n_local + 1) + 3 * vec + vec * xb // 8
-                        + pbb + pbb * vb // 8 + 4 * n_local + 8 * r * Nc)
+                        what="post-smoothing through A P and the coarse solution, prolongation, projection, <r,r>, <z,r>")
         else:
             post = dict(kernel="k_ml_post", pmc_prefix="k_ml_post<",
-                        what="post-smoothing in the SpMM epilogue, projection, <r,r>, <z,r>",
-                        algorithmic_bytes_fp64=qb + 4 * vec + pbb, streamed_bytes=qb + 4 * vec + pbb)
-        post["avg_launch_us"] = ms_it[3] * 1e3
-        partials = int(agent.problem.multilevelGet(0, "restrict_partials")[0]) if graph else 0
-        if timed == "symmetric":  # the restriction walks the symmetric storage (values at vb)
-            q_stream = nu_ * (vb * b_ * b_ + 4) + (nnzb_local - nu_) * 8 + 2 * 4 * (n_local + 1)
-        else:
-            q_stream = qb
+                        what="post-smoothing in the SpMM epilogue, projection, <r,r>, <z,r>")
+        post.update(algorithmic_bytes_fp64=post_bytes(8, 8), streamed_bytes=post_bytes(vb, xb), avg_launch_us=ms_it[3] * 1e3)
         kernels += [
             dict(kernel="k_ml_restrict" + (" + k_ml_agg_sum" if graph else ""), pmc_prefix="k_ml_restrict",
                  pmc_prefix2="k_ml_agg_sum" if graph else None,
                  what="level 0: r - A x1 in one pass over Q, P^T, aggregate sums%s" % (", residual kept" if path["ap"] else ""),
-                 # (graph aggregates: one partial sum per run of same-aggregate poses inside a wave's chunk is written by
-                 # the restriction and read by k_ml_agg_sum -- a pose-sized tile each)
-                 algorithmic_bytes_fp64=qb + 2 * vec + pbb + vec // abs(ml_info["ks"][0]) + (vec if path["ap"] else 0)
-                 + 2 * 8 * r * b_ * partials,
-                 # Q (this storage) + the pre-smoothed iterate (own tiles; its gathered tiles are re-reads) and the kept
-                 # residual at xb + r in fp64 + prolongation blocks at vb + run table + partial sums out and in + rc
-                 streamed_bytes=q_stream + vec * xb // 8 + vec + pbb * vb // 8 + (vec * xb // 8 if path["ap"] else 0)
-                 + (4 * n_local if graph else 0) + 2 * 8 * r * b_ * partials + (cbits // 8) * r * Nc,
-                 avg_launch_us=ms_it[1] * 1e3),
+                 algorithmic_bytes_fp64=restrict_bytes(8, 8, 8, False),
+                 streamed_bytes=restrict_bytes(vb, xb, cbits // 8, timed == "symmetric"), avg_launch_us=ms_it[1] * 1e3),
             dense, post]
     for k_ in kernels:
         k_["achieved"] = k_["streamed_bytes"] / max(k_["avg_launch_us"], 1e-9) / 1e3

@@ -15,6 +15,7 @@
 #include <chrono>
 #include <condition_variable>
 #include <functional>
+#include <memory>
 #include <mutex>
 #include <thread>
 #include <cmath>
@@ -132,9 +133,11 @@ inline int free_bsr(Bsr& m) {
   X(poll_sleep,        "DPGO_POLL_SLEEP",        -1,  "s_sleep units between sweeps of the in-kernel all-reduce")                    \
   X(persist_verbose,   "DPGO_PERSIST_VERBOSE",    0,  "per-solve phase report of the one-launch solve on stderr")                    \
   X(setup_timing,      "DPGO_SETUP_TIMING",       0,  "section times of the hierarchy's symbolic set-up on stderr")                  \
+  X(setup_threads,     "DPGO_SETUP_THREADS",      0,  "host threads of the hierarchy's symbolic set-up (0: min(8, cores); 1: serial)") \
   X(auto_cost_rule,    "DPGO_AUTO_COST_RULE",     1,  "DPGO_PRECOND_AUTO on coupled blocks: cost rule (0: tCG-budget hysteresis only)") \
   X(ml_graph,          "DPGO_ML_GRAPH",           1,  "graph aggregates in the default hierarchy (0: index runs)")                   \
   X(ml_graph_size,     "DPGO_ML_GRAPH_SIZE",      0,  "growth size of the default graph aggregates (0: by size)")                    \
+  X(ml_growth_chunks,  "DPGO_ML_GROWTH_CHUNKS",   0,  "index ranges the graph aggregates grow and merge in (0: 8 from 65 536 poses, else 1)") \
   X(ml_ap,             "DPGO_ML_AP",              1,  "two-level post-smoothing through A P (0: gather through Q; index runs only)") \
   X(ml_dense_sym,      "DPGO_ML_DENSE_SYM",      -1,  "dense level from the packed lower triangle on the matrix cores: 0 / 1")       \
   X(ml_early_stop,     "DPGO_ML_EARLY_STOP",      1,  "tCG's residual test in the restriction kernel, one kernel early")             \
@@ -476,6 +479,96 @@ inline int upload(Tp** dst, const Tp* src, size_t count, hipStream_t s) {
   return DPGO_OK;
 }
 
+// Host worker threads of the set-up code (the hierarchy's symbolic set-up): created once per process and kept -- in a
+// process that has the HIP runtime and an ML framework loaded pthread_create costs 0.2-0.4 ms (static TLS of every loaded
+// library), more than the sections it would run.  A batch = fn(0 .. count-1); whoever waits for a batch executes its items
+// too, so batches may be started from inside items (nested sections) without a deadlock.
+class TaskPool {
+ public:
+  struct Batch {
+    std::function<void(int)> fn;
+    int count = 0;
+    std::atomic<int> next{0}, done{0};
+  };
+  using Job = std::shared_ptr<Batch>;
+  static TaskPool& get() {
+    static TaskPool* pool = new TaskPool();  // never destroyed: the workers are detached
+    return *pool;
+  }
+  // starts fn(0 .. count-1) on the workers; the caller goes on and later calls wait()
+  Job submit(int count, std::function<void(int)> fn, int max_threads) {
+    Job b = std::make_shared<Batch>();
+    b->fn = std::move(fn);
+    b->count = count;
+    const int helpers = std::max(0, std::min(count, max_threads - 1));
+    if (helpers > 0) {
+      {
+        std::lock_guard<std::mutex> lk(mu_);
+        while ((int)nworkers_ < std::min(kMaxWorkers, std::max(helpers, (int)nworkers_))) {
+          std::thread([this] { loop(); }).detach();
+          ++nworkers_;
+        }
+        for (int k = 0; k < helpers; ++k) queue_.push_back(b);
+      }
+      cv_.notify_all();
+    }
+    return b;
+  }
+  // executes what is left of the batch, then waits for the items other threads are still running
+  void wait(const Job& b) {
+    if (!b) return;
+    help(*b);
+    while (b->done.load(std::memory_order_acquire) < b->count) std::this_thread::yield();
+  }
+  void run(int count, const std::function<void(int)>& fn, int max_threads) {
+    if (count <= 0) return;
+    if (count == 1 || max_threads <= 1) {
+      for (int k = 0; k < count; ++k) fn(k);
+      return;
+    }
+    wait(submit(count, fn, max_threads));
+  }
+  // creates the workers ahead of their first use, from a helper thread (the caller pays one pthread_create)
+  void warm(int threads) {
+    bool expected = false;
+    if (threads <= 1 || !warmed_.compare_exchange_strong(expected, true)) return;
+    std::thread([this, threads] { wait(submit(threads - 1, [](int) {}, threads)); }).detach();
+  }
+
+ private:
+  static constexpr int kMaxWorkers = 15;
+  static void help(Batch& b) {
+    for (;;) {
+      const int k = b.next.fetch_add(1, std::memory_order_relaxed);
+      if (k >= b.count) return;
+      b.fn(k);
+      b.done.fetch_add(1, std::memory_order_release);
+    }
+  }
+  void loop() {
+    for (;;) {
+      Job b;
+      {
+        std::unique_lock<std::mutex> lk(mu_);
+        cv_.wait(lk, [this] { return !queue_.empty(); });
+        b = std::move(queue_.front());
+        queue_.erase(queue_.begin());
+      }
+      help(*b);
+    }
+  }
+  std::mutex mu_;
+  std::condition_variable cv_;
+  std::vector<Job> queue_;
+  unsigned nworkers_ = 0;
+  std::atomic<bool> warmed_{false};
+};
+// waits for a job when the scope is left, whichever way
+struct JobGuard {
+  TaskPool::Job job;
+  ~JobGuard() { TaskPool::get().wait(job); }
+};
+
 struct TmpDev {
   std::vector<void*> ptrs;
   ~TmpDev() {
@@ -542,6 +635,7 @@ int ml_merge_small_aggregates(const std::vector<int32_t>& rowptr, const std::vec
                               std::vector<int32_t>& lab, std::vector<int32_t>& ptr, std::vector<int32_t>& mem,
                               std::vector<int32_t>& parent, std::vector<int32_t>& pslot);
 int ml_symbolic_setup(dpgo_problem_s* p, const std::vector<int>& ks_in, int perm_tile = 0);
+int setup_threads();  // host threads of the symbolic set-up (DPGO_SETUP_THREADS)
 int flat_grid(size_t items);
 bool gj_use_mfma();
 int dense_spd_inverse(hipStream_t s, double* M, int lda, double* W, double* Rx, bool mfma);

@@ -97,22 +97,27 @@ void ml_free(dpgo_problem_s* p) {
   p->ml_ops32_ready = false;
 }
 
-// Symbolic setup: level sizes, block patterns of the Galerkin operators, buffers.
-// Graph aggregates of at most S nodes, grown greedily: seeds in index order; a seed's aggregate takes unassigned nodes in
-// breadth-first order (queue; a node's neighbours in the order of its block row) until it holds S.  lab = aggregate of
-// every node, mem / ptr = members in discovery order, parent / pslot = the breadth-first tree (slot of block
-// (parent, node) in the pattern).  Restated in oracle/dpgo_oracle.py (amg_graph_aggregates).
-int ml_graph_aggregates(const std::vector<int32_t>& rowptr, const std::vector<int32_t>& colidx, int n, int S,
-                        std::vector<int32_t>& lab, std::vector<int32_t>& ptr, std::vector<int32_t>& mem,
-                        std::vector<int32_t>& parent, std::vector<int32_t>& pslot) {
-  lab.assign(n, -1);
-  parent.assign(n, -1);
-  pslot.assign(n, 0);
+// Large blocks grow (and merge) their aggregates independently inside `chunks` contiguous index ranges -- [n c / chunks,
+// n (c + 1) / chunks): a seed's search does not leave its range, a fragment joins a neighbour of its own range -- one host
+// thread each; the ranges' aggregates are numbered one range after the other.  This is the RULE (restated in the oracle:
+// amg_growth_chunks / the lo, hi arguments of amg_graph_aggregates and amg_merge_small_aggregates), not a schedule: the
+// result does not depend on the number of threads that execute it.  100k poses: growth + merge 3.7 -> 0.6 ms.
+int ml_growth_chunks(int n) {
+  const int forced = options().ml_growth_chunks;
+  if (forced > 0) return std::max(1, std::min(forced, std::max(1, n / 64)));
+  return n >= 65536 ? 8 : 1;
+}
+namespace {
+// growth inside [lo, hi): lab (aggregate ids local to the range, from 0), parent, pslot written at the range's indices;
+// mem / ptr local to the range
+int grow_range(const std::vector<int32_t>& rowptr, const std::vector<int32_t>& colidx, int lo, int hi, int S,
+               std::vector<int32_t>& lab, std::vector<int32_t>& ptr, std::vector<int32_t>& mem,
+               std::vector<int32_t>& parent, std::vector<int32_t>& pslot) {
   mem.clear();
-  mem.reserve(n);
+  mem.reserve(hi - lo);
   ptr.assign(1, 0);
   int na = 0;
-  for (int s = 0; s < n; ++s) {
+  for (int s = lo; s < hi; ++s) {
     if (lab[s] >= 0) continue;
     const size_t first = mem.size();
     lab[s] = na;
@@ -121,7 +126,7 @@ int ml_graph_aggregates(const std::vector<int32_t>& rowptr, const std::vector<in
       const int u = mem[head];
       for (int t = rowptr[u]; t < rowptr[u + 1] && (int)(mem.size() - first) < S; ++t) {
         const int v = colidx[t];
-        if (lab[v] >= 0) continue;
+        if (v < lo || v >= hi || lab[v] >= 0) continue;
         lab[v] = na;
         parent[v] = u;
         pslot[v] = t;
@@ -134,17 +139,12 @@ int ml_graph_aggregates(const std::vector<int32_t>& rowptr, const std::vector<in
   return na;
 }
 
-// The greedy growth leaves fragments (pockets between full aggregates); where an aggregate is a WORKGROUP of the one-launch
-// solve (additive preconditioner) every fragment costs a whole workgroup.  Passes over the aggregates in index order until
-// nothing changes: an aggregate of at most S / 2 nodes joins the neighbouring aggregate (one it shares a block with) it has
-// the most blocks in common with among those that still have room (sizes add up to at most `cap`; ties: the lower index).
-// Afterwards the aggregates are renumbered in the order of their smallest member and every aggregate's breadth-first tree
-// is rebuilt from that member (neighbours in block-row order).  In place; returns the number of aggregates.  Restated in
-// oracle/dpgo_oracle.py (amg_merge_small_aggregates).
-int ml_merge_small_aggregates(const std::vector<int32_t>& rowptr, const std::vector<int32_t>& colidx, int n, int S, int cap,
-                              std::vector<int32_t>& lab, std::vector<int32_t>& ptr, std::vector<int32_t>& mem,
-                              std::vector<int32_t>& parent, std::vector<int32_t>& pslot) {
+// merge inside [lo, hi) (lab: ids local to the range); in place; returns the number of aggregates of the range
+int merge_range(const std::vector<int32_t>& rowptr, const std::vector<int32_t>& colidx, int lo, int hi, int S, int cap,
+                std::vector<int32_t>& lab, std::vector<int32_t>& ptr, std::vector<int32_t>& mem,
+                std::vector<int32_t>& parent, std::vector<int32_t>& pslot) {
   const int na = (int)ptr.size() - 1;
+  const int n = hi - lo;
   std::vector<std::vector<int32_t>> members(na);
   for (int a = 0; a < na; ++a) members[a].assign(mem.begin() + ptr[a], mem.begin() + ptr[a + 1]);
   std::vector<int> cnt(na, 0);
@@ -156,7 +156,9 @@ int ml_merge_small_aggregates(const std::vector<int32_t>& rowptr, const std::vec
       touched.clear();
       for (int i : members[a])
         for (int t = rowptr[i]; t < rowptr[i + 1]; ++t) {
-          const int c = lab[colidx[t]];
+          const int v = colidx[t];
+          if (v < lo || v >= hi) continue;
+          const int c = lab[v];
           if (c == a) continue;
           if (cnt[c]++ == 0) touched.push_back(c);
         }
@@ -180,7 +182,7 @@ int ml_merge_small_aggregates(const std::vector<int32_t>& rowptr, const std::vec
   for (int a = 0; a < na; ++a)
     if (!members[a].empty() && (int)members[a].size() != ptr[a + 1] - ptr[a]) grew[a] = 1;
   std::vector<int32_t> first_member(na, -1);
-  for (int i = n - 1; i >= 0; --i) first_member[lab[i]] = i;
+  for (int i = hi - 1; i >= lo; --i) first_member[lab[i]] = i;
   std::vector<int> alive;
   for (int a = 0; a < na; ++a)
     if (!members[a].empty()) alive.push_back(a);
@@ -190,15 +192,13 @@ int ml_merge_small_aggregates(const std::vector<int32_t>& rowptr, const std::vec
     for (int a = 0; a < na; ++a) sorted_ptr[a + 1] = sorted_ptr[a] + (grew[a] ? (int32_t)members[a].size() : 0);
     sorted_mem.resize(sorted_ptr[na]);
     std::vector<int32_t> fill(sorted_ptr.begin(), sorted_ptr.end() - 1);
-    for (int i = 0; i < n; ++i)
+    for (int i = lo; i < hi; ++i)
       if (grew[lab[i]]) sorted_mem[fill[lab[i]]++] = i;
   }
-  std::vector<int32_t> new_lab(n, -1), new_mem;
-  std::vector<int32_t> old_parent, old_pslot;
-  old_parent.swap(parent);
-  old_pslot.swap(pslot);
-  parent.assign(n, -1);
-  pslot.assign(n, 0);
+  std::vector<int32_t> new_lab(n, -1), new_mem;  // (new_lab indexed by pose - lo)
+  std::vector<int32_t> old_parent(parent.begin() + lo, parent.begin() + hi), old_pslot(pslot.begin() + lo, pslot.begin() + hi);
+  std::fill(parent.begin() + lo, parent.begin() + hi, -1);
+  std::fill(pslot.begin() + lo, pslot.begin() + hi, 0);
   new_mem.reserve(n);
   std::vector<int32_t> new_ptr(1, 0);
   for (size_t k = 0; k < alive.size(); ++k) {
@@ -208,9 +208,9 @@ int ml_merge_small_aggregates(const std::vector<int32_t>& rowptr, const std::vec
       // index order) and claimed exactly these poses in exactly the order the search below would -- keep its tree
       for (int m = ptr[a]; m < ptr[a + 1]; ++m) {
         const int v = mem[m];
-        new_lab[v] = (int32_t)k;
-        parent[v] = old_parent[v];
-        pslot[v] = old_pslot[v];
+        new_lab[v - lo] = (int32_t)k;
+        parent[v] = old_parent[v - lo];
+        pslot[v] = old_pslot[v - lo];
         new_mem.push_back(v);
       }
       new_ptr.push_back((int32_t)new_mem.size());
@@ -220,16 +220,16 @@ int ml_merge_small_aggregates(const std::vector<int32_t>& rowptr, const std::vec
     // the pattern not be symmetric, the members it misses become further roots in index order)
     for (int q = sorted_ptr[a]; q < sorted_ptr[a + 1]; ++q) {
       const int root = sorted_mem[q];
-      if (new_lab[root] >= 0) continue;
+      if (new_lab[root - lo] >= 0) continue;
       size_t head = new_mem.size();
-      new_lab[root] = (int32_t)k;
+      new_lab[root - lo] = (int32_t)k;
       new_mem.push_back(root);
       for (; head < new_mem.size(); ++head) {
         const int u = new_mem[head];
         for (int t = rowptr[u]; t < rowptr[u + 1]; ++t) {
           const int v = colidx[t];
-          if (lab[v] != a || new_lab[v] >= 0) continue;
-          new_lab[v] = (int32_t)k;
+          if (v < lo || v >= hi || lab[v] != a || new_lab[v - lo] >= 0) continue;
+          new_lab[v - lo] = (int32_t)k;
           parent[v] = u;
           pslot[v] = t;
           new_mem.push_back(v);
@@ -240,24 +240,194 @@ int ml_merge_small_aggregates(const std::vector<int32_t>& rowptr, const std::vec
   }
   mem.swap(new_mem);
   ptr.swap(new_ptr);
-  lab.swap(new_lab);
+  std::copy(new_lab.begin(), new_lab.end(), lab.begin() + lo);
   return (int)alive.size();
+}
+}  // namespace
+
+template <class F>
+void parallel_ranges(int n, int chunks, F&& fn);
+int setup_threads();
+
+// Symbolic setup: level sizes, block patterns of the Galerkin operators, buffers.
+// Graph aggregates of at most S nodes, grown greedily: seeds in index order; a seed's aggregate takes unassigned nodes in
+// breadth-first order (queue; a node's neighbours in the order of its block row) until it holds S.  lab = aggregate of
+// every node, mem / ptr = members in discovery order, parent / pslot = the breadth-first tree (slot of block
+// (parent, node) in the pattern).  cap > 0: followed by the merge of the fragments (below), both inside the index ranges of
+// ml_growth_chunks.  Restated in oracle/dpgo_oracle.py (amg_graph_aggregates, amg_merge_small_aggregates).
+//
+// The merge: the greedy growth leaves fragments (pockets between full aggregates); where an aggregate is a WORKGROUP of the
+// one-launch solve (additive preconditioner) every fragment costs a whole workgroup.  Passes over the aggregates in index
+// order until nothing changes: an aggregate of at most S / 2 nodes joins the neighbouring aggregate (one it shares a block
+// with) it has the most blocks in common with among those that still have room (sizes add up to at most `cap`; ties: the
+// lower index).  Afterwards the aggregates are renumbered in the order of their smallest member and every aggregate's
+// breadth-first tree is rebuilt from that member (neighbours in block-row order).
+int ml_grow_and_merge(const std::vector<int32_t>& rowptr, const std::vector<int32_t>& colidx, int n, int S, int cap,
+                      bool do_grow, std::vector<int32_t>& lab, std::vector<int32_t>& ptr, std::vector<int32_t>& mem,
+                      std::vector<int32_t>& parent, std::vector<int32_t>& pslot, int chunks) {
+  chunks = std::max(1, std::min(chunks, std::max(1, n)));
+  if (do_grow) {
+    lab.assign(n, -1);
+    parent.assign(n, -1);
+    pslot.assign(n, 0);
+  }
+  struct Part {
+    std::vector<int32_t> ptr, mem;
+    int na = 0;
+  };
+  std::vector<Part> parts(chunks);
+  auto bound = [&](int c) { return (int)((long long)n * c / chunks); };
+  if (!do_grow) {
+    // the caller's aggregates (ml_graph_aggregates' output: numbered range after range, none across a range boundary) are
+    // split by range, ids local to the range; anything else is merged as ONE range
+    const int na_in = (int)ptr.size() - 1;
+    std::vector<int> first_agg(chunks + 1, na_in);
+    bool split_ok = chunks > 1;
+    if (split_ok) {
+      int c = 0;
+      first_agg[0] = 0;
+      for (int a = 0; a < na_in && split_ok; ++a) {
+        if (ptr[a + 1] <= ptr[a]) { split_ok = false; break; }
+        int lo_m = n, hi_m = -1;
+        for (int m = ptr[a]; m < ptr[a + 1]; ++m) lo_m = std::min(lo_m, (int)mem[m]), hi_m = std::max(hi_m, (int)mem[m]);
+        while (c + 1 < chunks && lo_m >= bound(c + 1)) first_agg[++c] = a;
+        if (lo_m < bound(c) || hi_m >= bound(c + 1)) split_ok = false;
+      }
+      while (c + 1 < chunks) first_agg[++c] = na_in;
+      first_agg[chunks] = na_in;
+    }
+    if (!split_ok) {
+      chunks = 1;
+      parts.resize(1);
+      parts[0].ptr = ptr;
+      parts[0].mem = mem;
+      parts[0].na = na_in;
+    } else {
+      for (int c = 0; c < chunks; ++c) {
+        const int a0 = first_agg[c], a1 = first_agg[c + 1];
+        Part& P = parts[c];
+        P.na = a1 - a0;
+        P.ptr.assign(1, 0);
+        for (int a = a0; a < a1; ++a) P.ptr.push_back(ptr[a + 1] - ptr[a0]);
+        P.mem.assign(mem.begin() + ptr[a0], mem.begin() + ptr[a1]);
+        if (a0 > 0)
+          for (int i = bound(c); i < bound(c + 1); ++i) lab[i] -= a0;
+      }
+    }
+  }
+  const bool timing_ = options().setup_timing > 1;
+  const auto tA = std::chrono::steady_clock::now();
+  std::vector<double> tch(chunks, 0.0);
+  parallel_ranges(chunks, std::min(chunks, setup_threads()), [&](int, int c0, int c1) {
+    for (int c = c0; c < c1; ++c) {
+      const auto t0 = std::chrono::steady_clock::now();
+      Part& P = parts[c];
+      const int lo = bound(c), hi = bound(c + 1);
+      if (do_grow) P.na = grow_range(rowptr, colidx, lo, hi, S, lab, P.ptr, P.mem, parent, pslot);
+      if (cap > 0) P.na = merge_range(rowptr, colidx, lo, hi, S, cap, lab, P.ptr, P.mem, parent, pslot);
+      tch[c] = 1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    }
+  });
+  const auto tB = std::chrono::steady_clock::now();
+  // the ranges' aggregates one after the other
+  std::vector<int> agg_off(chunks + 1, 0);
+  std::vector<size_t> mem_off(chunks + 1, 0);
+  for (int c = 0; c < chunks; ++c) agg_off[c + 1] = agg_off[c] + parts[c].na, mem_off[c + 1] = mem_off[c] + parts[c].mem.size();
+  const int na = agg_off[chunks];
+  mem.resize(mem_off[chunks]);
+  ptr.assign((size_t)na + 1, 0);
+  parallel_ranges(chunks, std::min(chunks, setup_threads()), [&](int, int c0, int c1) {
+    for (int c = c0; c < c1; ++c) {
+      const Part& P = parts[c];
+      if (agg_off[c] > 0)
+        for (int i = bound(c); i < bound(c + 1); ++i) lab[i] += agg_off[c];
+      for (int a = 0; a < P.na; ++a) ptr[(size_t)agg_off[c] + a + 1] = (int32_t)(mem_off[c] + P.ptr[a + 1]);
+      if (!P.mem.empty()) std::memcpy(mem.data() + mem_off[c], P.mem.data(), sizeof(int32_t) * P.mem.size());
+    }
+  });
+  if (timing_) {
+    std::fprintf(stderr, "dpgo_hip: grow / merge (%d ranges): parallel section %.3f ms, join %.3f ms; per range:", chunks,
+                 1e3 * std::chrono::duration<double>(tB - tA).count(),
+                 1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - tB).count());
+    for (double t : tch) std::fprintf(stderr, " %.3f", t);
+    std::fprintf(stderr, "\n");
+  }
+  return na;
+}
+int ml_graph_aggregates(const std::vector<int32_t>& rowptr, const std::vector<int32_t>& colidx, int n, int S,
+                        std::vector<int32_t>& lab, std::vector<int32_t>& ptr, std::vector<int32_t>& mem,
+                        std::vector<int32_t>& parent, std::vector<int32_t>& pslot) {
+  return ml_grow_and_merge(rowptr, colidx, n, S, 0, true, lab, ptr, mem, parent, pslot, ml_growth_chunks(n));
+}
+int ml_merge_small_aggregates(const std::vector<int32_t>& rowptr, const std::vector<int32_t>& colidx, int n, int S, int cap,
+                              std::vector<int32_t>& lab, std::vector<int32_t>& ptr, std::vector<int32_t>& mem,
+                              std::vector<int32_t>& parent, std::vector<int32_t>& pslot) {
+  return ml_grow_and_merge(rowptr, colidx, n, S, cap, false, lab, ptr, mem, parent, pslot, ml_growth_chunks(n));
+}
+
+// Host threads of the symbolic set-up (DPGO_SETUP_THREADS; the results do not depend on the count: every parallel section
+// below works on disjoint row ranges and is joined in range order).
+int setup_threads() {
+  const int want = options().setup_threads;
+  if (want > 0) return std::min(want, 64);
+  const unsigned hw = std::thread::hardware_concurrency();
+  return (int)std::max(1u, std::min(8u, hw ? hw : 1u));
+}
+// fn(chunk, begin, end) over `chunks` contiguous ranges of [0, n) on the process's worker threads (TaskPool, host.h)
+template <class F>
+void parallel_ranges(int n, int chunks, F&& fn) {
+  chunks = std::max(1, std::min(chunks, n > 0 ? n : 1));
+  TaskPool::get().run(chunks, [&](int c) {
+    fn(c, (int)((long long)n * c / chunks), (int)((long long)n * (c + 1) / chunks));
+  }, setup_threads());
+}
+// rows [lo, hi) of a row-wise pattern built by `row(i, out)` (appends row i's sorted columns) into per-range pieces, joined
+// in range order: rowptr / colidx identical to the serial loop
+template <class F>
+void pattern_by_ranges(int n, int threads, int grain, size_t reserve_hint, F&& row, std::vector<int32_t>& rowptr_out,
+                       std::vector<int32_t>& col_out) {
+  const int chunks = std::max(1, std::min(threads, n / grain + 1));
+  std::vector<std::vector<int32_t>> cols(chunks), cnt(chunks);
+  parallel_ranges(n, chunks, [&](int c, int lo, int hi) {
+    auto& cc = cols[c];
+    auto& nn = cnt[c];
+    cc.reserve(reserve_hint / chunks + 16);
+    nn.resize(hi - lo);
+    for (int i = lo; i < hi; ++i) {
+      const size_t first = cc.size();
+      row(c, i, cc);
+      nn[i - lo] = (int32_t)(cc.size() - first);
+    }
+  });
+  rowptr_out.assign(n + 1, 0);
+  size_t total = 0;
+  for (auto& cc : cols) total += cc.size();
+  col_out.resize(total);
+  std::vector<size_t> base(chunks + 1, 0);
+  for (int c = 0; c < chunks; ++c) base[c + 1] = base[c] + cols[c].size();
+  parallel_ranges(chunks, chunks, [&](int, int c0, int c1) {
+    for (int c = c0; c < c1; ++c) {
+      const int lo = (int)((long long)n * c / chunks);
+      if (!cols[c].empty()) std::memcpy(col_out.data() + base[c], cols[c].data(), sizeof(int32_t) * cols[c].size());
+      size_t at = base[c];
+      for (size_t k = 0; k < cnt[c].size(); ++k) {
+        at += cnt[c][k];
+        rowptr_out[lo + k + 1] = (int32_t)at;
+      }
+    }
+  });
 }
 
 // Pattern of A P for labelled aggregates: row i holds the sorted, distinct labels of its block columns.  (Inserting into
-// the sorted row instead of sort + unique was measured: no gain, the labels' gather is what it costs.)
+// the sorted row instead of sort + unique was measured: no gain, the labels' gather is what it costs.)  Row ranges in parallel.
 void ml_ap_pattern(const std::vector<int32_t>& rowptr, const std::vector<int32_t>& colidx, const std::vector<int32_t>& lab,
                    int n, std::vector<int32_t>& arow, std::vector<int32_t>& acol) {
-  arow.assign(n + 1, 0);
-  acol.clear();
-  acol.reserve(colidx.size());
-  for (int i = 0; i < n; ++i) {
-    const size_t first = acol.size();
-    for (int t = rowptr[i]; t < rowptr[i + 1]; ++t) acol.push_back(lab[colidx[t]]);
-    std::sort(acol.begin() + first, acol.end());
-    acol.erase(std::unique(acol.begin() + first, acol.end()), acol.end());
-    arow[i + 1] = (int32_t)acol.size();
-  }
+  pattern_by_ranges(n, setup_threads(), 1024, colidx.size(), [&](int, int i, std::vector<int32_t>& out) {
+    const size_t first = out.size();
+    for (int t = rowptr[i]; t < rowptr[i + 1]; ++t) out.push_back(lab[colidx[t]]);
+    std::sort(out.begin() + first, out.end());
+    out.erase(std::unique(out.begin() + first, out.end()), out.end());
+  }, arow, acol);
 }
 
 // Runs of equal labels inside chunks of G consecutive poses (what one wave of the level-0 kernels adds up before it
@@ -328,6 +498,19 @@ int ml_symbolic_setup(dpgo_problem_s* p, const std::vector<int>& ks_in, int perm
       if (L.k < 2) return fail(DPGO_ERR_INVALID, "multilevel: graph aggregates hold at least 2 poses");
       std::vector<int32_t> lab, ptr, mem, parent, pslot;
       int na;
+      // the level-0 buffers whose sizes are known up front are allocated by a helper thread while the aggregates grow
+      hipError_t alloc_err = hipSuccess;
+      const int dev_ = p->device;
+      const int nthreads = setup_threads();
+      JobGuard alloc_job{TaskPool::get().submit(1, [&, dev_](int) {
+        hipError_t e = hipSetDevice(dev_);
+        if (e == hipSuccess) e = hipMalloc(&L.tbuf, tb * cur);
+        if (e == hipSuccess) e = hipMalloc(&L.res1, tb * cur);
+        if (e == hipSuccess) e = hipMalloc(&L.Pb, sizeof(double) * (size_t)cur * bb);
+        if (e == hipSuccess) e = hipMalloc(&L.x1, tb * cur);
+        if (e == hipSuccess) e = hipMalloc(&L.x, tb * cur);
+        alloc_err = e;
+      }, nthreads)};
       if (p->add_plan_known && p->add_agg.S == L.k && p->add_agg.cap == merge_cap && (int)p->add_agg.lab.size() == cur) {
         const auto& A = p->add_agg;  // (the additive plan of this pattern was found with exactly these aggregates)
         lab = A.lab, ptr = A.ptr, mem = A.mem, parent = A.parent, pslot = A.pslot;
@@ -340,6 +523,34 @@ int ml_symbolic_setup(dpgo_problem_s* p, const std::vector<int>& ks_in, int perm
       }
       L.graph = true;
       L.merge_cap = merge_cap;
+      // the patterns that follow from the labels -- A P (rows in parallel) and the dense level's operator (aggregates in
+      // parallel) -- are built by worker threads while this one uploads the labels and builds the run and tile tables
+      std::vector<int32_t> arow, acol, crow, ccol;
+      JobGuard pattern_job{TaskPool::get().submit(2, [&](int which) {
+        if (which == 0) {  // pattern of A P: the aggregates every row's block columns fall into
+          ml_ap_pattern(rowptr, colidx, lab, cur, arow, acol);
+          return;
+        }
+        // pattern of the dense level's operator: the aggregates of the block columns of every member's row
+        const int chunks = std::max(1, std::min(std::max(1, nthreads / 2), na / 16 + 1));
+        std::vector<std::vector<int32_t>> marks(chunks);
+        pattern_by_ranges(na, chunks, 16, colidx.size() / 8, [&](int c, int a, std::vector<int32_t>& out) {
+          auto& mark = marks[c];
+          if (mark.empty()) mark.assign(na, -1);
+          const size_t first = out.size();
+          for (int m = ptr[a]; m < ptr[a + 1]; ++m) {
+            const int i = mem[m];
+            for (int t = rowptr[i]; t < rowptr[i + 1]; ++t) {
+              const int cl = lab[colidx[t]];
+              if (mark[cl] != a) {
+                mark[cl] = a;
+                out.push_back(cl);
+              }
+            }
+          }
+          std::sort(out.begin() + first, out.end());
+        }, crow, ccol);
+      }, nthreads)};
       CHK(upload(&L.lab, lab.data(), lab.size(), p->stream));
       CHK(upload(&L.agg_ptr, ptr.data(), ptr.size(), p->stream));
       CHK(upload(&L.agg_mem, mem.data(), mem.size(), p->stream));
@@ -365,38 +576,13 @@ int ml_symbolic_setup(dpgo_problem_s* p, const std::vector<int>& ks_in, int perm
         L.perm_tile = perm_tile;
       }
       lap("run table, tile table");
-      HIPC(hipMalloc(&L.tbuf, tb * cur));
-      lap("run-sum buffer allocated");
-      // pattern of A P: the aggregates the block columns of every row fall into
-      std::vector<int32_t> arow, acol;
-      ml_ap_pattern(rowptr, colidx, lab, cur, arow, acol);
-      lap("pattern of A P");
+      TaskPool::get().wait(pattern_job.job);
+      lap("patterns of A P and of the dense level joined");
       CHK(upload_bsr(L.AP, cur, na, (int)acol.size(), b, arow.data(), acol.data(), nullptr, p->stream));
       lap("A P allocated, pattern uploaded");
-      HIPC(hipMalloc(&L.res1, tb * cur));
-      HIPC(hipMalloc(&L.Pb, sizeof(double) * (size_t)cur * bb));
-      HIPC(hipMalloc(&L.x1, tb * cur));
-      HIPC(hipMalloc(&L.x, tb * cur));
-      lap("level-0 vectors allocated");
-      // pattern of the dense level's operator: the aggregates of the block columns of every member's row
-      std::vector<int32_t> crow(na + 1, 0), ccol;
-      std::vector<int32_t> mark(na, -1);
-      for (int a = 0; a < na; ++a) {
-        const size_t first = ccol.size();
-        for (int m = ptr[a]; m < ptr[a + 1]; ++m) {
-          const int i = mem[m];
-          for (int t = rowptr[i]; t < rowptr[i + 1]; ++t) {
-            const int c = lab[colidx[t]];
-            if (mark[c] != a) {
-              mark[c] = a;
-              ccol.push_back(c);
-            }
-          }
-        }
-        std::sort(ccol.begin() + first, ccol.end());
-        crow[a + 1] = (int32_t)ccol.size();
-      }
-      lap("pattern of the dense level's operator");
+      TaskPool::get().wait(alloc_job.job);
+      if (alloc_err != hipSuccess) return fail(DPGO_ERR_HIP, std::string("hipMalloc (level-0 buffers): ") + hipGetErrorString(alloc_err));
+      lap("level-0 vectors joined");
       HIPC(hipStreamSynchronize(p->stream));  // the host vectors go out of scope
       lap("stream synchronised");
       rowptr.swap(crow);

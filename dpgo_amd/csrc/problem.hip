@@ -381,6 +381,7 @@ int dpgo_problem_create(dpgo_problem_t* out, int r, int d, int n, int device) {
   CHK(dpgo_device_count(&cnt));
   if (cnt <= 0) return fail(DPGO_ERR_HIP, "no HIP device (this library has no CPU fallback)");
   if (device < 0 || device >= cnt) return fail(DPGO_ERR_INVALID, "device index out of range");
+  TaskPool::get().warm(setup_threads());  // (the set-up code's worker threads exist before their first use)
   auto* p = new dpgo_problem_s();
   p->r = r;
   p->d = d;

@@ -407,20 +407,25 @@ def amg_default_graph_size(n: int, b: int) -> int:
     return S if S <= AMG_GRAPH_MAX else 0
 
 
-def amg_graph_aggregates(Q: "BSR", S: int):
-    """Mirrors ml_graph_aggregates: aggregates of at most S nodes grown greedily over Q's block pattern -- seeds in index
-    order; a seed's aggregate takes unassigned nodes in breadth-first order (FIFO; a node's neighbours in the order of its
-    block row) until it holds S.  Returns (lab[n], ptr[na+1], mem[n] in discovery order, parent[n] (-1: root), pslot[n] =
-    slot of block (parent, node))."""
-    n = Q.n
-    rowptr, colidx = np.asarray(Q.rowptr), np.asarray(Q.colidx)
-    lab = -np.ones(n, dtype=np.int64)
-    parent = -np.ones(n, dtype=np.int64)
-    pslot = np.zeros(n, dtype=np.int64)
+AMG_GROWTH_CHUNKS_FROM = 65536  # poses from which the aggregates grow and merge inside 8 index ranges (ml_growth_chunks)
+
+
+def amg_growth_chunks(n: int) -> int:
+    """Mirrors ml_growth_chunks (dpgo_amd/csrc/multilevel.hip): the number of contiguous index ranges
+    [n c / chunks, n (c + 1) / chunks) inside which large blocks grow and merge their aggregates independently (the device
+    library gives every range a host thread; DPGO_ML_GROWTH_CHUNKS overrides the count on both sides)."""
+    forced = int(os.environ.get("DPGO_ML_GROWTH_CHUNKS", "0") or 0)
+    if forced > 0:
+        return max(1, min(forced, max(1, n // 64)))
+    return 8 if n >= AMG_GROWTH_CHUNKS_FROM else 1
+
+
+def _amg_grow_range(rowptr, colidx, lo: int, hi: int, S: int, lab, parent, pslot):
+    """Growth inside [lo, hi) (grow_range): aggregate ids local to the range; returns (ptr, mem) of the range."""
     mem: List[int] = []
     ptr = [0]
     na = 0
-    for s in range(n):
+    for s in range(lo, hi):
         if lab[s] >= 0:
             continue
         first = len(mem)
@@ -434,7 +439,7 @@ def amg_graph_aggregates(Q: "BSR", S: int):
                 if len(mem) - first >= S:
                     break
                 v = colidx[t]
-                if lab[v] >= 0:
+                if v < lo or v >= hi or lab[v] >= 0:
                     continue
                 lab[v] = na
                 parent[v] = u
@@ -442,23 +447,38 @@ def amg_graph_aggregates(Q: "BSR", S: int):
                 mem.append(v)
         ptr.append(len(mem))
         na += 1
+    return ptr, mem
+
+
+def amg_graph_aggregates(Q: "BSR", S: int, chunks: Optional[int] = None):
+    """Mirrors ml_graph_aggregates: aggregates of at most S nodes grown greedily over Q's block pattern -- seeds in index
+    order; a seed's aggregate takes unassigned nodes in breadth-first order (FIFO; a node's neighbours in the order of its
+    block row) until it holds S -- independently inside each of amg_growth_chunks(n) contiguous index ranges (a search
+    does not leave its range), the ranges' aggregates numbered one range after the other.  Returns (lab[n], ptr[na+1],
+    mem[n] in discovery order, parent[n] (-1: root), pslot[n] = slot of block (parent, node))."""
+    n = Q.n
+    chunks = amg_growth_chunks(n) if chunks is None else max(1, min(int(chunks), max(1, n)))
+    rowptr, colidx = np.asarray(Q.rowptr), np.asarray(Q.colidx)
+    lab = -np.ones(n, dtype=np.int64)
+    parent = -np.ones(n, dtype=np.int64)
+    pslot = np.zeros(n, dtype=np.int64)
+    mem: List[int] = []
+    ptr = [0]
+    na = 0
+    for c in range(chunks):
+        lo, hi = n * c // chunks, n * (c + 1) // chunks
+        ptr_c, mem_c = _amg_grow_range(rowptr, colidx, lo, hi, S, lab, parent, pslot)
+        lab[lo:hi] += na
+        ptr.extend(len(mem) + q for q in ptr_c[1:])
+        mem.extend(mem_c)
+        na += len(ptr_c) - 1
     return lab, np.asarray(ptr, dtype=np.int64), np.asarray(mem, dtype=np.int64), parent, pslot
 
 
-def amg_merge_small_aggregates(Q: "BSR", S: int, lab, ptr, mem, cap: Optional[int] = None):
-    """Mirrors ml_merge_small_aggregates: the greedy growth leaves fragments (pockets between full aggregates); where an
-    aggregate is a workgroup of the one-launch solve every fragment costs a whole workgroup.  Passes over the aggregates
-    in index order until nothing changes: an aggregate of at most S / 2 nodes joins the neighbouring aggregate (one it
-    shares a block of Q with) it has the most blocks in common with among those that still have room (sizes add up to at
-    most S; ties: the lower index).  Afterwards the aggregates are renumbered in the order of their smallest member and
-    every aggregate's breadth-first tree is rebuilt from that member (neighbours in block-row order).
-    Returns (lab, ptr, mem, parent, pslot) like amg_graph_aggregates."""
-    n = Q.n
-    cap = S if cap is None else cap
-    rowptr, colidx = np.asarray(Q.rowptr), np.asarray(Q.colidx)
-    lab = np.array(lab, dtype=np.int64)
-    na = len(ptr) - 1
-    members = [list(mem[ptr[a]:ptr[a + 1]]) for a in range(na)]
+def _amg_merge_range(rowptr, colidx, lo: int, hi: int, S: int, cap: int, lab, members, new_lab, parent, pslot):
+    """merge_range: `members` = the range's aggregates (lists of poses), lab = their ids local to the range at the range's
+    indices.  Writes new_lab (ids local to the range), parent, pslot at the range's indices; returns (ptr, mem) of the range."""
+    na = len(members)
     changed = True
     while changed:
         changed = False
@@ -468,7 +488,10 @@ def amg_merge_small_aggregates(Q: "BSR", S: int, lab, ptr, mem, cap: Optional[in
             conn: Dict[int, int] = {}
             for i in members[a]:
                 for t in range(rowptr[i], rowptr[i + 1]):
-                    c = int(lab[colidx[t]])
+                    v = colidx[t]
+                    if v < lo or v >= hi:
+                        continue
+                    c = int(lab[v])
                     if c != a:
                         conn[c] = conn.get(c, 0) + 1
             best, best_n = -1, 0
@@ -484,9 +507,6 @@ def amg_merge_small_aggregates(Q: "BSR", S: int, lab, ptr, mem, cap: Optional[in
     # renumber by smallest member, rebuild the breadth-first trees
     alive = [a for a in range(na) if members[a]]
     alive.sort(key=lambda a: min(members[a]))
-    new_lab = -np.ones(n, dtype=np.int64)
-    parent = -np.ones(n, dtype=np.int64)
-    pslot = np.zeros(n, dtype=np.int64)
     out_mem: List[int] = []
     out_ptr = [0]
     for k, a in enumerate(alive):
@@ -503,13 +523,71 @@ def amg_merge_small_aggregates(Q: "BSR", S: int, lab, ptr, mem, cap: Optional[in
                 head += 1
                 for t in range(rowptr[u], rowptr[u + 1]):
                     v = colidx[t]
-                    if lab[v] != a or new_lab[v] >= 0:
+                    if v < lo or v >= hi or lab[v] != a or new_lab[v] >= 0:
                         continue
                     new_lab[v] = k
                     parent[v] = u
                     pslot[v] = t
                     out_mem.append(v)
         out_ptr.append(len(out_mem))
+    return out_ptr, out_mem
+
+
+def amg_merge_small_aggregates(Q: "BSR", S: int, lab, ptr, mem, cap: Optional[int] = None, chunks: Optional[int] = None):
+    """Mirrors ml_merge_small_aggregates: the greedy growth leaves fragments (pockets between full aggregates); where an
+    aggregate is a workgroup of the one-launch solve every fragment costs a whole workgroup.  Passes over the aggregates
+    in index order until nothing changes: an aggregate of at most S / 2 nodes joins the neighbouring aggregate (one it
+    shares a block of Q with) it has the most blocks in common with among those that still have room (sizes add up to at
+    most `cap`; ties: the lower index).  Afterwards the aggregates are renumbered in the order of their smallest member and
+    every aggregate's breadth-first tree is rebuilt from that member (neighbours in block-row order).  Like the growth,
+    independently inside each of amg_growth_chunks(n) index ranges (aggregates that do not sit inside one range -- not the
+    growth's output -- are merged as one range).  Returns (lab, ptr, mem, parent, pslot) like amg_graph_aggregates."""
+    n = Q.n
+    cap = S if cap is None else cap
+    chunks = amg_growth_chunks(n) if chunks is None else max(1, min(int(chunks), max(1, n)))
+    rowptr, colidx = np.asarray(Q.rowptr), np.asarray(Q.colidx)
+    lab = np.array(lab, dtype=np.int64)
+    na = len(ptr) - 1
+    members = [[int(v) for v in mem[ptr[a]:ptr[a + 1]]] for a in range(na)]
+    bound = lambda c: n * c // chunks  # noqa: E731
+    # the aggregates of every range (numbered range after range by the growth)
+    first_agg = [0] * (chunks + 1)
+    ok = chunks > 1
+    if ok:
+        c = 0
+        for a in range(na):
+            if not members[a]:
+                ok = False
+                break
+            lo_m, hi_m = min(members[a]), max(members[a])
+            while c + 1 < chunks and lo_m >= bound(c + 1):
+                c += 1
+                first_agg[c] = a
+            if lo_m < bound(c) or hi_m >= bound(c + 1):
+                ok = False
+                break
+        while c + 1 < chunks:
+            c += 1
+            first_agg[c] = na
+        first_agg[chunks] = na
+    if not ok:
+        chunks, first_agg = 1, [0, na]
+        bound = lambda c: n * c  # noqa: E731
+    new_lab = -np.ones(n, dtype=np.int64)
+    parent = -np.ones(n, dtype=np.int64)
+    pslot = np.zeros(n, dtype=np.int64)
+    out_mem: List[int] = []
+    out_ptr = [0]
+    total = 0
+    for c in range(chunks):
+        lo, hi = bound(c), bound(c + 1)
+        a0, a1 = first_agg[c], first_agg[c + 1]
+        lab[lo:hi] -= a0
+        ptr_c, mem_c = _amg_merge_range(rowptr, colidx, lo, hi, S, cap, lab, members[a0:a1], new_lab, parent, pslot)
+        new_lab[lo:hi] += total
+        out_ptr.extend(len(out_mem) + q for q in ptr_c[1:])
+        out_mem.extend(mem_c)
+        total += len(ptr_c) - 1
     return new_lab, np.asarray(out_ptr, dtype=np.int64), np.asarray(out_mem, dtype=np.int64), parent, pslot
 
 

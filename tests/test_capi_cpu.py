@@ -254,6 +254,91 @@ def test_trajectory_csv_round_trip(tmp_path):
     assert len(lines) == len(meas) + 1
 
 
+def test_aggregates_grow_and_merge_inside_index_ranges():
+    """Large blocks (>= 65 536 poses) grow and merge their graph aggregates independently inside 8 contiguous index ranges
+    (ml_growth_chunks; one host thread per range in the library): the rule is the oracle's (amg_growth_chunks and the range
+    arguments of its growth / merge), node for node, and does not depend on the number of threads that execute it.  Checked
+    on a 20 x 20 x 12 grid with the range count forced on both sides (DPGO_ML_GROWTH_CHUNKS = 5: ranges that do not fall on
+    layer boundaries), on the default rule's threshold, and once at 65 536 nodes of a chain (8 ranges by size)."""
+    import ctypes as C
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import dpgo_oracle as O
+    import dpgo_amd.lib as L
+    lib = L.load()
+    assert O.amg_growth_chunks(65535) == 1 and O.amg_growth_chunks(65536) == 8 and O.amg_growth_chunks(1000000) == 8
+
+    def device_side(Q, S, cap):
+        n = Q.n
+        rp, ci = L.i32(Q.rowptr), L.i32(Q.colidx)  # (kept alive across the calls)
+        lab_c, par_c, na = np.zeros(n, dtype=np.int32), np.zeros(n, dtype=np.int32), C.c_int(0)
+        L.check(lib.dpgo_multilevel_graph_aggregates(n, L.ptr(rp), L.ptr(ci), S, L.ptr(lab_c), L.ptr(par_c), C.byref(na)))
+        lab_m, par_m, nm = np.zeros(n, dtype=np.int32), np.zeros(n, dtype=np.int32), C.c_int(0)
+        L.check(lib.dpgo_multilevel_merged_aggregates(n, L.ptr(rp), L.ptr(ci), S, cap, L.ptr(lab_m), L.ptr(par_m),
+                                                      C.byref(nm)))
+        return (lab_c, par_c, na.value), (lab_m, par_m, nm.value)
+
+    meas, n, _ = O.synthetic_grid(20, 20, 12, seed=0)
+    Q = O.construct_Q(n, 3, meas)
+    keep = {k: os.environ.get(k) for k in ("DPGO_ML_GROWTH_CHUNKS", "DPGO_SETUP_THREADS")}
+    try:
+        results = {}
+        for chunks in (1, 5):
+            for threads in (1, 3, 8):
+                os.environ["DPGO_ML_GROWTH_CHUNKS"], os.environ["DPGO_SETUP_THREADS"] = str(chunks), str(threads)
+                L.check(lib.dpgo_options_reload())
+                assert O.amg_growth_chunks(n) == chunks
+                S, cap = 30, 45
+                (lab_c, par_c, na), (lab_m, par_m, nm) = device_side(Q, S, cap)
+                lab_o, ptr_o, mem_o, par_o, _ = O.amg_graph_aggregates(Q, S)
+                assert na == len(ptr_o) - 1 and np.array_equal(lab_c, lab_o) and np.array_equal(par_c, par_o), (chunks, threads)
+                lab_q, ptr_q, mem_q, par_q, _ = O.amg_merge_small_aggregates(Q, S, lab_o, ptr_o, mem_o, cap)
+                assert nm == len(ptr_q) - 1 and np.array_equal(lab_m, lab_q) and np.array_equal(par_m, par_q), (chunks, threads)
+                results.setdefault(chunks, []).append((lab_m.copy(), par_m.copy()))
+                if chunks > 1:  # no aggregate across a range boundary; ids ascend range after range; trees stay inside
+                    rng_of = np.minimum(np.arange(n) * chunks // n, chunks - 1)
+                    for c in range(chunks):  # (the boundaries are n c / chunks rounded down)
+                        lo, hi = n * c // chunks, n * (c + 1) // chunks
+                        rng_of[lo:hi] = c
+                    first = np.array([rng_of[mem_q[ptr_q[a]]] for a in range(nm)])
+                    assert np.all(np.diff(first) >= 0)
+                    assert np.all(rng_of == first[lab_q])
+                    assert np.all(rng_of[par_q[par_q >= 0]] == rng_of[par_q >= 0])
+                    sizes = np.diff(ptr_q)
+                    assert sizes.max() <= cap and sizes.min() >= 1 and sorted(mem_q.tolist()) == list(range(n))
+        for chunks, runs in results.items():  # the thread count changes nothing
+            assert all(np.array_equal(runs[0][0], r[0]) and np.array_equal(runs[0][1], r[1]) for r in runs[1:])
+        assert not np.array_equal(results[1][0][0], results[5][0][0])  # (the rule itself does change the aggregates)
+        # the default rule at its threshold: a 65 536-node chain, 8 ranges
+        del os.environ["DPGO_ML_GROWTH_CHUNKS"]
+        os.environ["DPGO_SETUP_THREADS"] = "0"
+        L.check(lib.dpgo_options_reload())
+        nn = 65536
+        rowptr = np.zeros(nn + 1, dtype=np.int64)
+        cols = []
+        for i in range(nn):
+            row = [j for j in (i - 1, i, i + 1) if 0 <= j < nn]
+            cols.extend(row)
+            rowptr[i + 1] = len(cols)
+
+        class Pattern:
+            n, rowptr, colidx = nn, None, None
+        Pq = Pattern()
+        Pq.rowptr, Pq.colidx = rowptr, np.array(cols, dtype=np.int64)
+        (lab_c, par_c, na), (lab_m, par_m, nm) = device_side(Pq, 100, 150)
+        lab_o, ptr_o, mem_o, par_o, _ = O.amg_graph_aggregates(Pq, 100)
+        assert np.array_equal(lab_c, lab_o) and np.array_equal(par_c, par_o)
+        assert na == 8 * 82 and np.all(lab_o[np.arange(1, 8) * 8192] != lab_o[np.arange(1, 8) * 8192 - 1])  # 8192 = 81 x 100 + 92
+        lab_q, ptr_q, _, par_q, _ = O.amg_merge_small_aggregates(Pq, 100, lab_o, ptr_o, mem_o, 150)
+        assert nm == len(ptr_q) - 1 and np.array_equal(lab_m, lab_q) and np.array_equal(par_m, par_q)
+    finally:
+        for k, v in keep.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+        lib.dpgo_options_reload()
+
+
 @pytest.mark.parametrize("name,ks", [("smallGrid3D", None), ("kitti_00", None), ("sphere2500", [4, 8])])
 def test_multilevel_hierarchy_rules(name, ks):
     """Host-side rules of precond = "multilevel": the library's default aggregate sizes (dpgo_multilevel_default_ks, no
