@@ -1359,11 +1359,26 @@ def main():
                 json.dump(out, fh, indent=1)
         except OSError as exc:
             sys.stderr.write("bench.py: bench_detail.json not written: %r\n" % (exc,))
-        print("DETAIL " + json.dumps(out))
-        print(compact_line(out))
-        sys.stdout.flush()
+        final = ("DETAIL " + json.dumps(out), compact_line(out))
+    else:
+        final = None
+    # The driver's line must be the LAST thing on stdout.  Libraries underneath print through C stdio (RCCL's version / path
+    # banner), which is block-buffered on a pipe and would otherwise be flushed at process exit, BEHIND the line: every rank
+    # flushes its C and Python buffers, the ranks meet, the process group is taken down, and only then rank 0 prints.
+    import ctypes
+    libc = ctypes.CDLL(None)
+    sys.stdout.flush()
+    libc.fflush(None)
     if use_dist:
+        barrier()
         dist.destroy_process_group()
+        libc.fflush(None)
+    if final is not None:
+        if use_dist and world > 1:
+            time.sleep(0.2)  # (the other ranks' last flushes travel through the launcher's pipes)
+        print(final[0])
+        print(final[1])
+        sys.stdout.flush()
 
 
 if __name__ == "__main__":

@@ -16,6 +16,8 @@
 #include <condition_variable>
 #include <functional>
 #include <memory>
+#include <pthread.h>
+#include <sched.h>
 #include <mutex>
 #include <thread>
 #include <cmath>
@@ -134,6 +136,7 @@ inline int free_bsr(Bsr& m) {
   X(persist_verbose,   "DPGO_PERSIST_VERBOSE",    0,  "per-solve phase report of the one-launch solve on stderr")                    \
   X(setup_timing,      "DPGO_SETUP_TIMING",       0,  "section times of the hierarchy's symbolic set-up on stderr")                  \
   X(setup_threads,     "DPGO_SETUP_THREADS",      0,  "host threads of the hierarchy's symbolic set-up (0: min(8, cores); 1: serial)") \
+  X(setup_pin,         "DPGO_SETUP_PIN",          1,  "set-up worker threads placed in the CPU group of the thread that first used them") \
   X(auto_cost_rule,    "DPGO_AUTO_COST_RULE",     1,  "DPGO_PRECOND_AUTO on coupled blocks: cost rule (0: tCG-budget hysteresis only)") \
   X(ml_graph,          "DPGO_ML_GRAPH",           1,  "graph aggregates in the default hierarchy (0: index runs)")                   \
   X(ml_graph_size,     "DPGO_ML_GRAPH_SIZE",      0,  "growth size of the default graph aggregates (0: by size)")                    \
@@ -505,7 +508,11 @@ class TaskPool {
       {
         std::lock_guard<std::mutex> lk(mu_);
         while ((int)nworkers_ < std::min(kMaxWorkers, std::max(helpers, (int)nworkers_))) {
-          std::thread([this] { loop(); }).detach();
+          const int id = (int)nworkers_;
+          std::thread([this, id] {
+            pin(id);
+            loop();
+          }).detach();
           ++nworkers_;
         }
         for (int k = 0; k < helpers; ++k) queue_.push_back(b);
@@ -537,6 +544,26 @@ class TaskPool {
 
  private:
   static constexpr int kMaxWorkers = 15;
+  // Workers next to the thread that created the pool (DPGO_SETUP_PIN=0: wherever the scheduler puts them): the sections
+  // they run share arrays of a few MB that thread has just written -- on a multi-socket host a worker on another socket
+  // (or another L3 slice) reads them across the fabric.  Heuristic: the aligned group of 8 consecutive CPU numbers around
+  // the creator's CPU (one core complex on current server parts), restricted to the process's affinity mask; a worker may
+  // run on any CPU of the group.  Purely a placement hint: failures are ignored.
+  int home_cpu_ = -1;
+  void pin(int) {
+    if (!pin_enabled() || home_cpu_ < 0) return;
+    cpu_set_t allowed, want;
+    CPU_ZERO(&allowed);
+    CPU_ZERO(&want);
+    if (sched_getaffinity(0, sizeof(allowed), &allowed) != 0) return;
+    const int lo = home_cpu_ & ~7;
+    int cnt = 0;
+    for (int c = lo; c < lo + 8; ++c)
+      if (c < CPU_SETSIZE && CPU_ISSET(c, &allowed)) CPU_SET(c, &want), ++cnt;
+    if (cnt >= 2) (void)pthread_setaffinity_np(pthread_self(), sizeof(want), &want);
+  }
+  static bool pin_enabled() { return options().setup_pin != 0; }
+  TaskPool() { home_cpu_ = sched_getcpu(); }
   static void help(Batch& b) {
     for (;;) {
       const int k = b.next.fetch_add(1, std::memory_order_relaxed);

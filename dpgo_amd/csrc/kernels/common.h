@@ -140,6 +140,15 @@ __device__ __forceinline__ TileIter tile_iter(int ntiles) {
 #ifndef DPGO_GATHER_BATCH
 #define DPGO_GATHER_BATCH 1  // the same for the other kernels on the symmetric storage (q_gather: restriction, one-launch solve)
 #endif
+#ifndef DPGO_CYCLE_SPAN
+// own-tile rows of the cycle's level-0 kernels (restriction, post-smoothing) as lane-linear span pieces through the wave's LDS
+// tiles, like the tCG kernels (1) or per-lane column loads / stores (0).  Built, parity-green and measured in round 6
+// (profiles/r06_ab_results.txt, three interleaved pairs at 100k poses): restriction 23.9 -> 28.8 us, post-smoothing
+// 22.8 -> 32.9 us, 132.8 -> 155.5 us per product -- the extra LDS round trip and wave barrier per tile sit on the tile's
+// dependent chain behind the gather, and the post-smoothing kernel spills 19 instead of 10 VGPRs at its 4 waves per SIMD.
+// Negative: off.
+#define DPGO_CYCLE_SPAN 0
+#endif
 #ifndef DPGO_SYM_WAVES
 #define DPGO_SYM_WAVES 2  // waves per SIMD k_tcg_hess_sym is compiled for (<= 256 VGPRs; 3 with DPGO_HESS_BATCH=1)
 #endif
@@ -234,6 +243,47 @@ struct Span {
   static constexpr int NPC = SP / 2;          // 16-byte pieces
   static constexpr int NIT = (NPC + 63) / 64; // pieces per lane
 };
+
+// Own-tile span moves between global memory and a wave's LDS tile (layout [pose][column][R] = the memory layout): pieces of
+// two entries, lane-linear (16-byte accesses for fp64, 8-byte for the fp32 storage of the cycle's vectors -- converted on the
+// way, the LDS tile is always fp64).  `valid` = entries of the span that exist (ragged last tile).  Wave-cooperative.
+template <int D, int R, int NTS = 0, class XT>
+__device__ __forceinline__ void span_to_lds(const XT* __restrict__ src, double* __restrict__ lds, int valid) {
+  using SPN = Span<D, R, 1>;
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int it = 0; it < SPN::NIT; ++it) {
+    const int pc = lane + 64 * it;
+    if (2 * pc < valid) {
+      dbl2 v;
+      if constexpr (sizeof(XT) == 8) {
+        v = ld_stream<NTS>(reinterpret_cast<const dbl2*>(src) + pc);
+      } else {
+        const float2 f = ld_stream<NTS>(reinterpret_cast<const float2*>(src) + pc);
+        v.x = (double)f.x;
+        v.y = (double)f.y;
+      }
+      reinterpret_cast<dbl2*>(lds)[pc] = v;
+    }
+  }
+}
+template <int D, int R, int NTS = 0, class XT>
+__device__ __forceinline__ void span_from_lds(XT* __restrict__ dst, const double* __restrict__ lds, int valid) {
+  using SPN = Span<D, R, 1>;
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int it = 0; it < SPN::NIT; ++it) {
+    const int pc = lane + 64 * it;
+    if (2 * pc < valid) {
+      const dbl2 v = reinterpret_cast<const dbl2*>(lds)[pc];
+      if constexpr (sizeof(XT) == 8) {
+        st_stream<NTS>(reinterpret_cast<dbl2*>(dst) + pc, v);
+      } else {
+        st_stream<NTS>(reinterpret_cast<float2*>(dst) + pc, make_float2((float)v.x, (float)v.y));
+      }
+    }
+  }
+}
 
 // ---------------------------------------------------------------- reductions
 __device__ __forceinline__ double wave_allreduce(double v) {

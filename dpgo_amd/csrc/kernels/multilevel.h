@@ -142,16 +142,39 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(Restrict
     q_gather<D, R, SPLIT>(A, x1, i, L.s, L.c, okp, h);
     DPGO_TL_USE(h[0]);
     DPGO_STAMP_TILE_IN(g_tl_restrict, 1);
-    if (ok) {
-      double xr[R], rr[R];
-      load_col_t<R>(x1 + off, xr);
-      load_col<R>(r + off, rr);
+    if constexpr (SPLIT == 1 && Span<D, R, 1>::kOk && DPGO_CYCLE_SPAN) {
+      // (opt-in, measured slower: see DPGO_CYCLE_SPAN in common.h) the own rows of r and x1 and the kept residual move as
+      // lane-linear pieces of the wave's span: r is staged in the wave's residual tile, x1 in its rows of t_s (free until
+      // the P^T products below); same arithmetic
+      const int p0 = tile * GEO::P + L.wave * GEO::G;
+      const int npose = (n - p0) < GEO::G ? (n - p0) : GEO::G;
+      const int valid = npose > 0 ? npose * GEO::T : 0;
+      const size_t base = (size_t)p0 * GEO::T;
+      double* rw = &res_s[L.wave][0][0];
+      span_to_lds<D, R>(r + base, rw, valid);
+      span_to_lds<D, R>(x1 + base, &t_s[L.wave * GEO::G][0], valid);
+      wave_sync();
+      if (ok) {
+        const double* rr = &res_s[L.wave][L.g][L.c * R];
+        const double* xr = &t_s[lp][L.c * R];
 #pragma unroll
-      for (int a = 0; a < R; ++a) h[a] = rr[a] - h[a] - shift * xr[a];
-      store_col<R>(&res_s[L.wave][L.g][L.c * R], h);
-      if (res_out) store_col_t<R>(res_out + off, h);  // kept for k_ml_post_ap (in its storage type; P^T res uses h itself)
+        for (int a = 0; a < R; ++a) h[a] = rr[a] - h[a] - shift * xr[a];
+        store_col<R>(&res_s[L.wave][L.g][L.c * R], h);  // (a lane reads and writes its own column only)
+      }
+      wave_sync();
+      if (res_out) span_from_lds<D, R>(res_out + base, rw, valid);  // kept for k_ml_post_ap, in its storage type
+    } else {
+      if (ok) {
+        double xr[R], rr[R];
+        load_col_t<R>(x1 + off, xr);
+        load_col<R>(r + off, rr);
+#pragma unroll
+        for (int a = 0; a < R; ++a) h[a] = rr[a] - h[a] - shift * xr[a];
+        store_col<R>(&res_s[L.wave][L.g][L.c * R], h);
+        if (res_out) store_col_t<R>(res_out + off, h);  // kept for k_ml_post_ap (in its storage type; P^T res uses h itself)
+      }
+      wave_sync();
     }
-    wave_sync();
     DPGO_STAMP_TILE_IN(g_tl_restrict, 2);
     if (L.s == 0 && L.g < GEO::G) {
       double t[R];
@@ -592,7 +615,34 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(SPLIT ==
     spmm_col<D, R, SPLIT>(AP.rowptr, AP.colidx, AP.vals, xc, i, L.s, L.c, okp, h);
     DPGO_TL_USE(h[0]);
     DPGO_STAMP_TILE_IN(g_tl_post, 1);
-    if (ok) {
+    constexpr bool kSpan = (SPLIT == 1) && Span<D, R, 1>::kOk && DPGO_CYCLE_SPAN;
+    [[maybe_unused]] int valid = 0;
+    [[maybe_unused]] size_t base = 0;
+    if constexpr (kSpan) {
+      // (opt-in, measured slower: see DPGO_CYCLE_SPAN in common.h) own rows of X, r and the kept residual as lane-linear
+      // pieces of the wave's span, staged in the three tiles; the output leaves the same way (below); same arithmetic
+      const int p0 = tile * GEO::P + L.wave * GEO::G;
+      const int npose = (n - p0) < GEO::G ? (n - p0) : GEO::G;
+      valid = npose > 0 ? npose * GEO::T : 0;
+      base = (size_t)p0 * GEO::T;
+      span_to_lds<D, R>(X + base, &sm[L.wave][0][0][0], valid);
+      span_to_lds<D, R>(r + base, &sm[L.wave][1][0][0], valid);
+      span_to_lds<D, R>(res1 + base, &sm[L.wave][2][0][0], valid);
+      if (ok) {
+#pragma unroll
+        for (int q = 0; q < GEO::B; ++q) dr[q] = dinv[(size_t)i * GEO::BB + L.c * GEO::B + q];
+      }
+      wave_sync();
+      if (ok) {
+#pragma unroll
+        for (int a = 0; a < R; ++a) {
+          rr[a] = vs[L.c * R + a];
+          h[a] = zs[L.c * R + a] - h[a];  // r - A x
+          part[0] = fma(rr[a], rr[a], part[0]);
+        }
+        store_col<R>(zs + L.c * R, h);  // (a lane reads and writes its own column only)
+      }
+    } else if (ok) {
       double x[R], rs[R];
       load_col<R>(X + off, x);
       load_col<R>(r + off, rr);
@@ -636,11 +686,18 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(SPLIT ==
     if (ok) {
       double out[R], sdummy[D];
       proj_col<D, R>(ys, zs, L.c, z, out, sdummy);
-      store_col<R>(Z + off, out);
+      if constexpr (kSpan)
+        store_col<R>(vs + L.c * R, out);  // (the r tile is free: its last readers were the smoothing steps above)
+      else
+        store_col<R>(Z + off, out);
 #pragma unroll
       for (int a = 0; a < R; ++a) part[1] = fma(out[a], rr[a], part[1]);
     }
     wave_sync();
+    if constexpr (kSpan) {
+      span_from_lds<D, R>(Z + base, &sm[L.wave][1][0][0], valid);
+      wave_sync();
+    }
     DPGO_STAMP_TILE_IN(g_tl_post, 5);
     DPGO_TILE_NEXT;
   }

@@ -91,7 +91,7 @@ def test_bench_prints_one_valid_json_line():
     assert all(k["us"] > 0 and k["streamed_bytes"] > 0 and k["algorithmic_bytes_fp64"] >= k["streamed_bytes"] and
                abs(k["frac"] - k["streamed_bytes"] / k["us"] / 1e3 / 8000.0) < 1e-3 * k["frac"] for k in lrf["kernels"])
     assert lcb["kind"] == "port" and lcb["cores"] >= 1 and lcb["value"] > 0 and lcb["unit"] == "it/s" and len(lcb["sample"]) <= 200
-    assert lcb["seconds_per_sweep"] > 0 and lcb["factorisation_seconds"] > 0 and lcb["tcg_iterations"] > 0 and lcb["host_cores"] >= 1
+    assert lcb["seconds_per_sweep"] > 0 and lcb["factorisation_seconds"] > 0 and lcb["tcg_iterations"] >= 0 and lcb["host_cores"] >= 1
     assert lcb["gpu_same_work"]["seconds_per_sweep"] > 0 and lcb["gpu_same_work"]["preconditioners"]
     assert "gpu_over_cpu_same_work" not in lcb
     assert "workload" in line["config"] and "model" not in line["config"] and line["products_per_step"] > 0
