@@ -134,6 +134,7 @@ inline int free_bsr(Bsr& m) {
   X(poll_first,        "DPGO_POLL_FIRST",        -1,  "s_sleep units before the first sweep of the in-kernel all-reduce")            \
   X(poll_sleep,        "DPGO_POLL_SLEEP",        -1,  "s_sleep units between sweeps of the in-kernel all-reduce")                    \
   X(persist_verbose,   "DPGO_PERSIST_VERBOSE",    0,  "per-solve phase report of the one-launch solve on stderr")                    \
+  X(hess_dma,          "DPGO_HESS_DMA",           0,  "k_tcg_hess_sym's own tiles by LDS-DMA: 1 = double-buffered, 2 waves / SIMD, 4 blocks in flight; 2 = 3 waves, 2 blocks") \
   X(setup_timing,      "DPGO_SETUP_TIMING",       0,  "section times of the hierarchy's symbolic set-up on stderr")                  \
   X(setup_threads,     "DPGO_SETUP_THREADS",      0,  "host threads of the hierarchy's symbolic set-up (0: min(8, cores); 1: serial)") \
   X(setup_pin,         "DPGO_SETUP_PIN",          1,  "set-up worker threads placed in the CPU group of the thread that first used them") \

@@ -554,6 +554,189 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(DPGO_SYM
   DPGO_COMMIT(0);
 }
 
+// k_tcg_hess_sym with the own-tile streams moved by LDS-DMA (global_load_lds_dwordx4: 1 KiB per wave instruction, straight
+// into the wave's LDS tiles, no staging registers) -- VERDICT r5 item 3a.  X and z of the NEXT tile are requested at the top
+// of the current tile (double-buffered tiles), delta / H delta of the current tile in front of the gather; the h / proj(h)
+// tiles share one buffer.  Seven tiles per wave (70 KB per workgroup: two workgroups per CU, as the register version).
+// Same arithmetic in the same order as k_tcg_hess_sym: bit-identical results.  WAVES: waves per SIMD it is compiled for,
+// HB: blocks whose loads the gather keeps in flight.  DPGO_HESS_DMA selects it (solve.hip); measurements in DESIGN.md.
+// NT = 1: non-temporal (aux = 2), for operands a launch touches once -- as ld_stream<1> of the register version
+template <int D, int R, int NT = 0>
+__device__ __forceinline__ void span_dma(const double* __restrict__ src, double* lds_tile, int valid) {
+  using SPN = Span<D, R, 1>;
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int it = 0; it < SPN::NIT; ++it) {
+    const int pc = lane + 64 * it;
+    if (2 * pc < valid) {
+      if constexpr (NT)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(reinterpret_cast<const dbl2*>(src) + pc),
+                                         (__attribute__((address_space(3))) void*)(lds_tile + 128 * it), 16, 0, 2);
+      else
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(reinterpret_cast<const dbl2*>(src) + pc),
+                                         (__attribute__((address_space(3))) void*)(lds_tile + 128 * it), 16, 0, 0);
+    }
+  }
+}
+template <int D, int R, int NTS, int WAVES, int HB, int DBUF>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void k_tcg_hess_sym_dma(
+    BsrSymDev Q, const double* __restrict__ X, const double* __restrict__ S, const double* __restrict__ z,
+    double* __restrict__ delta, double* __restrict__ Hd, const double* __restrict__ pin, int nb_in,
+    double* __restrict__ pout, const DevState* __restrict__ sin, DevState* __restrict__ sout, int first, int n,
+    unsigned long long* hflag, unsigned gen) {
+  using GEO = Geo<D, R, 1>;
+  using SPN = Span<D, R, 1>;
+  // DBUF = 1: X[2], z[2], delta, H delta, h / proj(h) -- the next tile's X, z land while this tile is worked on (70 KB per
+  // workgroup: 2 per CU); DBUF = 0: one X and one z tile, requested when the previous tile is done with them (51 KB: 3 per CU)
+  constexpr int NX = DBUF ? 2 : 1, NT = 2 * NX + 3;
+  __shared__ __attribute__((aligned(16))) double sm[kWaves][NT][GEO::G][GEO::T];
+  __shared__ double red[kWaves * kNP];
+  const LaneId L = lane_id<D, 1>();
+  const int lane = threadIdx.x & 63;
+  const int ntiles = (n + GEO::P - 1) / GEO::P;
+  const TileIter ti_ = tile_iter(ntiles);
+  auto tile_ptr = [&](int k) { return &sm[L.wave][k][0][0]; };
+  double* ds = tile_ptr(2 * NX);
+  double* es = tile_ptr(2 * NX + 1);
+  double* hs = tile_ptr(2 * NX + 2);
+
+  auto span_of = [&](int tile, int& p0, int& valid) {
+    p0 = tile * GEO::P + L.wave * GEO::G;
+    const int npose = (n - p0) < GEO::G ? (n - p0) : GEO::G;
+    valid = npose > 0 ? npose * GEO::T : 0;
+  };
+  // ---- per-tile register state: row extents / preloaded indices and the S rows (requested one tile ahead, as before)
+  SymIdx si;
+  double srow[D];
+  int p0 = 0, valid = 0, i = 0;
+  bool okp = false, ok = false;
+  auto prefetch_idx = [&](int tile) {
+    span_of(tile, p0, valid);
+    i = p0 + L.g;
+    okp = (L.g < GEO::G) && (i < n);
+    ok = okp;
+    si = sym_idx_load<D>(Q, i, L.c, okp);
+    if (ok && L.c < D) {
+#pragma unroll
+      for (int a = 0; a < D; ++a) srow[a] = ld_stream<NTS>(S + (size_t)i * D * D + L.c * D + a);
+    }
+  };
+  auto dma_xz = [&](int tile, int buf) {
+    int q0, v;
+    span_of(tile, q0, v);
+    const size_t base = (size_t)q0 * GEO::T;
+    span_dma<D, R, NTS>(X + base, tile_ptr(buf), v);
+    span_dma<D, R>(z + base, tile_ptr(NX + buf), v);  // (z is gathered by the neighbours' rows: kept in L2)
+  };
+  DevState st;
+  load_state(st, sin);
+  gen = state_gen(st, gen);
+  int tk = ti_.first;
+  bool have = tk < ti_.last;
+  int tile = have ? tile_of(Q, tk) : 0;
+  int buf = 0;
+  if (have) {
+    dma_xz(tile, 0);
+    prefetch_idx(tile);
+  }
+  // ---- scalar prologue
+  if (st.rtr_stop || st.tcg_done) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+      store_state(sout, st);
+      publish_progress(hflag, gen, st);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (no DMA may land in LDS a later workgroup owns)
+    return;
+  }
+  double beta;
+  const bool go = tcg_hess_prologue(st, pin, nb_in, first, red, beta, nullptr);
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    store_state(sout, st);
+    publish_progress(hflag, gen, st);
+  }
+  if (!go) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    return;
+  }
+
+  double part[1] = {0.0};
+  while (have) {
+    const int tk2 = tk + ti_.step;
+    const bool have2 = tk2 < ti_.last;
+    const int tile2 = have2 ? tile_of(Q, tk2) : 0;
+    const size_t base = (size_t)p0 * GEO::T;
+    if (DBUF && have2) dma_xz(tile2, buf ^ 1);  // the next tile's X, z: in flight during this tile's gather and epilogue
+    if (!first) {
+      span_dma<D, R, NTS>(delta + base, ds, valid);
+      span_dma<D, R, NTS>(Hd + base, es, valid);
+    }
+    double* ys = tile_ptr(buf);
+    double* vs = tile_ptr(NX + buf);
+    double h[R];
+    spmm_sym_pre<D, R, HB>(si, Q, z, L.c, h);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every DMA piece of this wave has landed
+    wave_sync();
+    if (ok) {
+      if (L.c < D) {
+        const double* vt = vs + L.g * GEO::T;
+#pragma unroll
+        for (int a = 0; a < D; ++a) {
+#pragma unroll
+          for (int k = 0; k < R; ++k) h[k] = fma(-vt[a * R + k], srow[a], h[k]);
+        }
+      }
+      store_col<R>(hs + L.g * GEO::T + L.c * R, h);
+    }
+    wave_sync();
+    double hz[R];
+    if (ok) {
+      double sdummy[D];
+      proj_col<D, R>(ys + L.g * GEO::T, hs + L.g * GEO::T, L.c, h, hz, sdummy);
+    }
+    wave_sync();  // every lane of a pose has read the h tile before proj(h) replaces it
+    if (ok) store_col<R>(hs + L.g * GEO::T + L.c * R, hz);
+    wave_sync();
+    {
+      dbl2* d2 = reinterpret_cast<dbl2*>(delta + base);
+      dbl2* h2 = reinterpret_cast<dbl2*>(Hd + base);
+#pragma unroll
+      for (int it = 0; it < SPN::NIT; ++it) {
+        const int pc = lane + 64 * it;
+        if (2 * pc < valid) {
+          const dbl2 hzv = reinterpret_cast<const dbl2*>(hs)[pc];
+          const dbl2 zl = reinterpret_cast<const dbl2*>(vs)[pc];
+          dbl2 dn, hn;
+          if (first) {
+            dn.x = -zl.x;
+            dn.y = -zl.y;
+            hn.x = -hzv.x;
+            hn.y = -hzv.y;
+          } else {
+            const dbl2 dv = reinterpret_cast<const dbl2*>(ds)[pc];
+            const dbl2 hv = reinterpret_cast<const dbl2*>(es)[pc];
+            dn.x = fma(beta, dv.x, -zl.x);
+            dn.y = fma(beta, dv.y, -zl.y);
+            hn.x = fma(beta, hv.x, -hzv.x);
+            hn.y = fma(beta, hv.y, -hzv.y);
+          }
+          st_stream<NTS>(d2 + pc, dn);
+          st_stream<NTS>(h2 + pc, hn);
+          part[0] = fma(dn.x, hn.x, part[0]);
+          part[0] = fma(dn.y, hn.y, part[0]);
+        }
+      }
+    }
+    wave_sync();
+    tk = tk2;
+    have = have2;
+    tile = tile2;
+    if (DBUF) buf ^= 1;
+    if (!DBUF && have) dma_xz(tile, 0);  // (the wave is done with its X / z tiles: wave_sync above)
+    if (have) prefetch_idx(tile);
+  }
+  store_partials<1>(part, pout, red);
+}
+
 template <int D, int R>
 __global__ __launch_bounds__(kBlock) void k_tcg_update_span(const double* __restrict__ X, const double* __restrict__ g,
                                                             const double* __restrict__ dinv,

@@ -694,6 +694,13 @@ bool gj_use_mfma() {
 }
 
 // In-place inverse of the dense SPD lda x lda array M (lda a multiple of 64); W, Rx: lda x 64 panels.
+// (Round 6, both measured at 2 184 unknowns = 35 block steps and NOT kept: a look-ahead schedule -- the tiles of block row /
+// column kb + 1 first, the rest of the rank-64 update in one launch with the next panel, W / Rx double-buffered, bitwise the
+// same result -- 2.80 ms against 2.65 ms: the panel's latency-bound pivot loop runs slower beside 600 update workgroups than
+// the launch it saves; the 64 x 64 pivot block by four block steps of 16 pivots -- one wavefront inverting the 16 x 16 block
+// with wave barriers only, rank-16 updates on 4 x 4 register tiles, reciprocal by v_rcp_f64 + two Newton steps -- 2.96 ms:
+// a pivot's dependent chain (LDS line, reciprocal, quad shuffle, LDS write, barrier) costs the same 0.7 us in a wavefront as
+// in a workgroup.)
 int dense_spd_inverse(hipStream_t s, double* M, int lda, double* W, double* Rx, bool mfma) {
   const int nt = lda / kNB;
   for (int kb = 0; kb < nt; ++kb) {

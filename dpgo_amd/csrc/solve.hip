@@ -33,7 +33,15 @@ int launch_tcg_update(dpgo_problem_s* p, const double* dinv, int first, double* 
 #define LAUNCH_TCG_HESS(p, SIN, SOUT, FIRST, HFLAG, GEN)                                                          \
   do {                                                                                                            \
     if constexpr (Span<D, R, 1>::kOk) {                                                                           \
-      if ((p)->tcg_sym && (p)->stream_nt)                                                                         \
+      if ((p)->tcg_sym && options().hess_dma == 1)                                                                \
+        hipLaunchKernelGGL((k_tcg_hess_sym_dma<D, R, 1, 2, 4, 1>), dim3((p)->grid_s()), dim3(kBlock), 0,          \
+                           (p)->stream, (p)->sym.dev(), (p)->x1, (p)->S1, (p)->z, (p)->delta, (p)->Hd, (p)->pB(), \
+                           (p)->nb_zr(), (p)->pA(), SIN, SOUT, FIRST, (p)->n, HFLAG, GEN);                         \
+      else if ((p)->tcg_sym && options().hess_dma == 2)                                                           \
+        hipLaunchKernelGGL((k_tcg_hess_sym_dma<D, R, 1, 3, 2, 0>), dim3((p)->grid_s()), dim3(kBlock), 0,          \
+                           (p)->stream, (p)->sym.dev(), (p)->x1, (p)->S1, (p)->z, (p)->delta, (p)->Hd, (p)->pB(), \
+                           (p)->nb_zr(), (p)->pA(), SIN, SOUT, FIRST, (p)->n, HFLAG, GEN);                         \
+      else if ((p)->tcg_sym && (p)->stream_nt)                                                                    \
         hipLaunchKernelGGL((k_tcg_hess_sym<D, R, 1>), dim3((p)->grid_s()), dim3(kBlock), 0, (p)->stream,          \
                            (p)->sym.dev(), (p)->x1, (p)->S1, (p)->z, (p)->delta, (p)->Hd, (p)->pB(), (p)->nb_zr(), \
                            (p)->pA(), SIN, SOUT, FIRST, (p)->n, HFLAG, GEN);                                      \
@@ -806,7 +814,12 @@ int tune_launch_caps(dpgo_problem_s* p) {
         CHK(resident_blocks(k_tcg_hess_span<D, R, 2>, &p->cap_h));
       else
         CHK(resident_blocks(k_tcg_hess_span<D, R, 1>, &p->cap_h));
-      CHK(resident_blocks(k_tcg_hess_sym<D, R, 1>, &p->cap_hs));
+      if (options().hess_dma == 1)
+        CHK(resident_blocks((k_tcg_hess_sym_dma<D, R, 1, 2, 4, 1>), &p->cap_hs));
+      else if (options().hess_dma == 2)
+        CHK(resident_blocks((k_tcg_hess_sym_dma<D, R, 1, 3, 2, 0>), &p->cap_hs));
+      else
+        CHK(resident_blocks(k_tcg_hess_sym<D, R, 1>, &p->cap_hs));
     } else {
       CHK(resident_blocks(k_tcg_update<D, R>, &p->cap_u));
       if (p->split == 4)

@@ -2426,6 +2426,8 @@ SWITCH_SETS = [
     ({"DPGO_SPMM_SYMMETRIC": "1", "DPGO_ML_DENSE_BITS": "32"}, "oracle"),     # ... and the dense level in fp32 as well
     ({"DPGO_SPMM_SYMMETRIC": "1"}, "oracle"),      # symmetric storage of Q: k_tcg_hess_sym, level-0 restriction / post-smoothing
     ({"DPGO_SPMM_SYMMETRIC": "1", "DPGO_OUTER_SYM": "0", "DPGO_STREAM_NT": "1"}, "oracle"),  # outer iteration on the plain copy
+    ({"DPGO_SPMM_SYMMETRIC": "1", "DPGO_STREAM_NT": "1", "DPGO_HESS_DMA": "1"}, "oracle"),  # k_tcg_hess_sym_dma: own tiles by LDS-DMA, double-buffered
+    ({"DPGO_SPMM_SYMMETRIC": "1", "DPGO_STREAM_NT": "1", "DPGO_HESS_DMA": "2"}, "oracle"),  # ... single-buffered, 3 waves per SIMD, 2 blocks in flight
     ({"DPGO_SPMM_SYMMETRIC": "1", "DPGO_TILE_WALK": "0"}, "oracle"),  # symmetric-storage kernels walk their tiles in index order
     ({"DPGO_SPMM_SYMMETRIC": "0", "DPGO_STREAM_NT": "1"}, "oracle"),  # plain storage with non-temporal single-use operands
     ({"DPGO_ML_GRAPH": "0"}, "oracle"),            # index-run hierarchy (k_ml_post_ap on runs, in-workgroup restriction sums)
