@@ -27,3 +27,13 @@ python tools/summarize_prof.py stats gpurun_out/prof_loop_$TAG gpurun_out/${TAG}
 rm -rf gpurun_out/prof_loop_$TAG
 grep '^{' gpurun_out/${TAG}_loopback16.log | tail -1 > gpurun_out/${TAG}_loopback16_bench.json
 head -6 gpurun_out/${TAG}_loopback16_kernel_stats.csv | cut -c1-140
+# (4) BASELINE configs[4]: kitti_00 GNC (4 agents, reference schedule) -- kernel stats of the weight updates (k_edge_weights,
+# k_rebuild_Q, hierarchy values) and of the one-launch solves between them
+cd /tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_kitti_$TAG -o kitti -- \
+  python $R/tools/r6/kitti_gnc_probe.py > $R/gpurun_out/${TAG}_kitti_gnc.log 2>&1
+cd $R
+python tools/summarize_prof.py stats gpurun_out/prof_kitti_$TAG gpurun_out/${TAG}_kitti_gnc_kernel_stats.csv
+rm -rf gpurun_out/prof_kitti_$TAG
+grep '^{' gpurun_out/${TAG}_kitti_gnc.log | tail -1 > gpurun_out/${TAG}_kitti_gnc.json
+head -8 gpurun_out/${TAG}_kitti_gnc_kernel_stats.csv | cut -c1-140
