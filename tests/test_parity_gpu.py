@@ -2430,6 +2430,9 @@ SWITCH_SETS = [
     ({"DPGO_SPMM_SYMMETRIC": "1", "DPGO_STREAM_NT": "1", "DPGO_HESS_DMA": "2"}, "oracle"),  # ... single-buffered, 3 waves per SIMD, 2 blocks in flight
     ({"DPGO_SPMM_SYMMETRIC": "1", "DPGO_TILE_WALK": "0"}, "oracle"),  # symmetric-storage kernels walk their tiles in index order
     ({"DPGO_SPMM_SYMMETRIC": "0", "DPGO_STREAM_NT": "1"}, "oracle"),  # plain storage with non-temporal single-use operands
+    ({"DPGO_SETUP_THREADS": "1"}, "bitwise"),      # the hierarchy's symbolic set-up on the calling thread alone
+    ({"DPGO_SETUP_THREADS": "5", "DPGO_SETUP_PIN": "0"}, "bitwise"),  # ... on five unpinned threads
+    ({"DPGO_ML_GROWTH_CHUNKS": "4"}, "oracle"),    # aggregates grown and merged inside 4 index ranges (the oracle reads the same variable)
     ({"DPGO_ML_GRAPH": "0"}, "oracle"),            # index-run hierarchy (k_ml_post_ap on runs, in-workgroup restriction sums)
     ({"DPGO_ML_GRAPH": "0", "DPGO_ML_AP": "0"}, "oracle"),  # ... post-smoothing gathers through Q (k_ml_post)
     ({"DPGO_ML_SETUP_SERIAL": "1", "DPGO_GJ_MFMA": "0"}, "oracle"),  # round-3 set-up kernels, FMA rank-64 updates
@@ -2488,6 +2491,8 @@ def test_kernel_selecting_switches_match_oracle(oracle, workload):
             hier = list(ks)
             cbits = 32 if (obits == 32 and vbits == 32 and sw.get("DPGO_ML_DENSE_BITS") == "32") else 64
             ks = ks + ((obits, vbits, cbits) if obits == 32 else ())
+            if "DPGO_ML_GROWTH_CHUNKS" in sw:  # (another aggregation rule under the same sizes: its own oracle rows)
+                ks = ks + ("ranges", sw["DPGO_ML_GROWTH_CHUNKS"])
             if ks not in want:
                 op = oracle.QuadraticProblem(Q, None, r, d, precond="amg", amg_k=hier, amg_operator_bits=obits,
                                              amg_vector_bits=vbits, amg_coarse_bits=cbits)
