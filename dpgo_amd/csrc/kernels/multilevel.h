@@ -165,11 +165,13 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(Restrict
       if (res_out) span_from_lds<D, R>(res_out + base, rw, valid);  // kept for k_ml_post_ap, in its storage type
     } else {
       if (ok) {
-        double xr[R], rr[R];
-        load_col_t<R>(x1 + off, xr);
+        XT xr[R];  // (kept in its storage type until used: five registers instead of ten for the fp32 cycle vectors)
+        double rr[R];
+#pragma unroll
+        for (int a = 0; a < R; ++a) xr[a] = x1[off + a];
         load_col<R>(r + off, rr);
 #pragma unroll
-        for (int a = 0; a < R; ++a) h[a] = rr[a] - h[a] - shift * xr[a];
+        for (int a = 0; a < R; ++a) h[a] = rr[a] - h[a] - shift * (double)xr[a];
         store_col<R>(&res_s[L.wave][L.g][L.c * R], h);
         if (res_out) store_col_t<R>(res_out + off, h);  // kept for k_ml_post_ap (in its storage type; P^T res uses h itself)
       }
@@ -242,11 +244,16 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(Restrict
 #pragma unroll
         for (int a = 0; a < R; ++a) acc[a] += t_s[lp + m][L.c * R + a];
       }
+      // (the lane's column offset is made opaque HERE: otherwise the two store addresses are formed once in front of the
+      // tile loop and, at 4 waves per SIMD, spilled -- 16 bytes of scratch written per thread and launch also when the
+      // graph-aggregate path above never comes here)
+      int cr = L.c * R;
+      asm volatile("" : "+v"(cr));
       if (rc32) {  // the dense level reads its right-hand side in the precision its inverse is stored in
 #pragma unroll
-        for (int a = 0; a < R; ++a) rc32[(size_t)(i / k) * GEO::T + L.c * R + a] = (float)acc[a];
+        for (int a = 0; a < R; ++a) rc32[(size_t)(i / k) * GEO::T + cr + a] = (float)acc[a];
       } else {
-        store_col<R>(rc + (size_t)(i / k) * GEO::T + L.c * R, acc);
+        store_col<R>(rc + (size_t)(i / k) * GEO::T + cr, acc);
       }
     }
     __syncthreads();
@@ -513,6 +520,9 @@ __global__ __launch_bounds__(kBlock) void k_ml_post_mid(BsrDev A, const double* 
   }
 }
 
+#ifndef DPGO_POST_RR_LDS
+#define DPGO_POST_RR_LDS 1  // k_ml_post_ap: r for <z, r> re-read from LDS (0: kept in registers)
+#endif
 #ifndef DPGO_POST_WAVES
 #define DPGO_POST_WAVES 4  // waves per SIMD the level-0 post-smoothing kernels are compiled for (<= 128 VGPRs, see grid_post())
 #endif
@@ -686,12 +696,19 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(SPLIT ==
     if (ok) {
       double out[R], sdummy[D];
       proj_col<D, R>(ys, zs, L.c, z, out, sdummy);
+      // <z, r>: r re-read from the wave's tile instead of kept in registers across the smoothing steps (the kernel is
+      // compiled for 4 waves per SIMD = 128 VGPRs and spilled 10 of them: ~15 MB of scratch traffic per launch)
+      if constexpr (DPGO_POST_RR_LDS) {
+#pragma unroll
+        for (int a = 0; a < R; ++a) part[1] = fma(out[a], vs[L.c * R + a], part[1]);
+      } else {
+#pragma unroll
+        for (int a = 0; a < R; ++a) part[1] = fma(out[a], rr[a], part[1]);
+      }
       if constexpr (kSpan)
         store_col<R>(vs + L.c * R, out);  // (the r tile is free: its last readers were the smoothing steps above)
       else
         store_col<R>(Z + off, out);
-#pragma unroll
-      for (int a = 0; a < R; ++a) part[1] = fma(out[a], rr[a], part[1]);
     }
     wave_sync();
     if constexpr (kSpan) {
