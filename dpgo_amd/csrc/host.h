@@ -432,6 +432,13 @@ struct dpgo_problem_s {
     return tiles < cap_u ? tiles : cap_u;
   }
   int cap_u = kMaxGrid, cap_h = kMaxGrid;  // launch caps of the streaming / SpMM kernel families
+  // k_tcg_update_span's multilevel-mode instance (no iterate, no projection: 143 VGPRs = 3 waves per SIMD) has its own cap
+  int cap_u_ml = kMaxGrid;
+  int grid_u(bool ml_mode) const {
+    const int P = (64 / b) * kWaves;
+    const int tiles = std::max(1, (n + P - 1) / P);
+    return std::min(tiles, ml_mode ? cap_u_ml : cap_u);
+  }
   // entries of partial region B (<r,r>, <z,r>) that k_tcg_hess has to sum: written by k_tcg_update (its grid) or,
   // with the fused multilevel cycle, by k_ml_post (SpMM-family grid)
   bool zr_from_post = false;

@@ -737,8 +737,20 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(WAVES, W
   store_partials<1>(part, pout, red);
 }
 
-template <int D, int R>
-__global__ __launch_bounds__(kBlock) void k_tcg_update_span(const double* __restrict__ X, const double* __restrict__ g,
+#ifndef DPGO_UPDATE_WAVES
+#define DPGO_UPDATE_WAVES 0  // waves per SIMD k_tcg_update_span is compiled for (0: the compiler's choice -- 203 VGPRs = 2 waves)
+#endif
+// ML = 1: the launch is known to be in multilevel mode (ml_omega > 0: z receives the unprojected pre-smoothing step, the
+// iterate is not read) -- the instance the 100k loop launches: without the iterate's pieces and the projection it fits
+// DPGO_UPDATE_WAVES_ML waves per SIMD.  ML = 0: the mode is the runtime argument (block-Jacobi / no preconditioner / either).
+#ifndef DPGO_UPDATE_WAVES_ML
+#define DPGO_UPDATE_WAVES_ML 3
+#endif
+template <int D, int R, int ML = 0>
+__global__ __launch_bounds__(kBlock)
+    __attribute__((amdgpu_waves_per_eu(ML ? DPGO_UPDATE_WAVES_ML : (DPGO_UPDATE_WAVES ? DPGO_UPDATE_WAVES : 1),
+                                       ML ? DPGO_UPDATE_WAVES_ML : (DPGO_UPDATE_WAVES ? DPGO_UPDATE_WAVES : 8))))
+void k_tcg_update_span(const double* __restrict__ X, const double* __restrict__ g,
                                                             const double* __restrict__ dinv,
                                                             const double* __restrict__ delta,
                                                             const double* __restrict__ Hd, double* __restrict__ eta,
@@ -763,6 +775,7 @@ __global__ __launch_bounds__(kBlock) void k_tcg_update_span(const double* __rest
   double* zs = &sm[L.wave][2][0][0];
   double* os = &sm[L.wave][3][0][0];
 
+  const bool ml_mode = ML ? true : (ml_omega > 0.0);  // (ML: compile-time)
   dbl2 xv[SPN::NIT], ev[SPN::NIT], dv[SPN::NIT], hv[SPN::NIT], rv[SPN::NIT];
   double drow[GEO::B];
   int p0 = 0, valid = 0, i = 0;
@@ -786,7 +799,7 @@ __global__ __launch_bounds__(kBlock) void k_tcg_update_span(const double* __rest
       if (2 * pc < valid) {
         // (the iterate is only needed by the tangent projection of the block-Jacobi / unpreconditioned z; the multilevel
         // pre-smoothing step x1 = w Dinv r is not projected: 16 MB less per launch at 100k poses)
-        if (!(ml_omega > 0.0)) xv[it] = X2[pc];
+        if (!ml_mode) xv[it] = X2[pc];
         if (first) {
           rv[it] = g2[pc];
         } else {
@@ -850,7 +863,7 @@ __global__ __launch_bounds__(kBlock) void k_tcg_update_span(const double* __rest
       for (int it = 0; it < SPN::NIT; ++it) {
         const int pc = lane + 64 * it;
         if (2 * pc < valid) {
-          if (!(ml_omega > 0.0)) reinterpret_cast<dbl2*>(ys)[pc] = xv[it];
+          if (!ml_mode) reinterpret_cast<dbl2*>(ys)[pc] = xv[it];
           dbl2 rr = rv[it];
           if (mode == 2) {
             dbl2 zero;
@@ -886,7 +899,7 @@ __global__ __launch_bounds__(kBlock) void k_tcg_update_span(const double* __rest
       wave_sync();
       if (ok) {
         double out[R], sdummy[D];
-        if (ml_omega > 0.0) {
+        if (ml_mode) {
 #pragma unroll
           for (int a = 0; a < R; ++a) out[a] = ml_omega * zz[a];
         } else {

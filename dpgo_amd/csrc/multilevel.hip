@@ -1010,7 +1010,7 @@ int launch_ml_restrict0(dpgo_problem_s* p, const double* r, const DevState* gate
   if (stop_check && gate) {
     stop.state = const_cast<DevState*>(gate);
     stop.pin = p->pB();
-    stop.nb = p->grid();
+    stop.nb = p->grid_u(true);  // (k_tcg_update_span's multilevel-mode instance wrote them)
     stop.hflag = p->hflag;
     stop.gen = p->launch_gen();
   }

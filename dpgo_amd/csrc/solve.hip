@@ -5,16 +5,22 @@ namespace dpgo_host {
 
 int launch_tcg_update(dpgo_problem_s* p, const double* dinv, int first, double* z_out,
                       double ml_omega) {
-  const int g = p->grid();
+  const bool ml_mode = ml_omega > 0.0;
+  const int g = p->grid_u(ml_mode);
   double* zt = z_out ? z_out : p->z;
   // (the pre-smoothed iterate of a cycle that keeps its internal vectors in fp32 goes to that buffer instead)
   float* z32 = (ml_omega > 0.0 && !p->ml.empty() && z_out == p->ml[0].x1 && p->ml_vec32_active()) ? p->ml[0].x1f : nullptr;
   DISPATCH(p->d, p->r, {
-    if constexpr (Span<D, R, 1>::kOk)
-      hipLaunchKernelGGL((k_tcg_update_span<D, R>), dim3(g), dim3(kBlock), 0, p->stream, p->x1, p->g1, dinv, p->delta,
-                         p->Hd, p->eta, p->rr, zt, p->pA(), p->grid_s(), p->pB(), p->dstate + p->cur,
-                         p->dstate + (p->cur ^ 1), first, p->n, p->hflag, p->launch_gen(), ml_omega, z32);
-    else {
+    if constexpr (Span<D, R, 1>::kOk) {
+      if (ml_mode)  // (the instance compiled for the multilevel mode: 3 waves per SIMD)
+        hipLaunchKernelGGL((k_tcg_update_span<D, R, 1>), dim3(g), dim3(kBlock), 0, p->stream, p->x1, p->g1, dinv, p->delta,
+                           p->Hd, p->eta, p->rr, zt, p->pA(), p->grid_s(), p->pB(), p->dstate + p->cur,
+                           p->dstate + (p->cur ^ 1), first, p->n, p->hflag, p->launch_gen(), ml_omega, z32);
+      else
+        hipLaunchKernelGGL((k_tcg_update_span<D, R, 0>), dim3(g), dim3(kBlock), 0, p->stream, p->x1, p->g1, dinv, p->delta,
+                           p->Hd, p->eta, p->rr, zt, p->pA(), p->grid_s(), p->pB(), p->dstate + p->cur,
+                           p->dstate + (p->cur ^ 1), first, p->n, p->hflag, p->launch_gen(), ml_omega, z32);
+    } else {
       // (odd tile size: the generic kernel has no fp32 output -- resolve_tcg_storage keeps such blocks off the symmetric
       // storage, hence off the cycle's fp32 vectors; a state that says otherwise is refused instead of dropping z32)
       if (z32) return fail(DPGO_ERR_STATE, "fp32 cycle vectors need the span kernels (even pose tile size)");
@@ -317,7 +323,7 @@ unsigned long long iter_graph_key(const dpgo_problem_s* p, const double* dinv, b
   KeyHash k;
   k.add((long long)p->d), k.add((long long)p->r), k.add((long long)p->n), k.add((long long)p->split), k.add((long long)p->cur);
   k.add((long long)p->tcg_sym), k.add((long long)p->stream_nt), k.add((long long)ml), k.add((long long)early_stop);
-  k.add((long long)p->grid()), k.add((long long)p->grid_s()), k.add((long long)p->grid_restrict()), k.add((long long)p->grid_post());
+  k.add((long long)p->grid()), k.add((long long)p->grid_u(true)), k.add((long long)p->grid_s()), k.add((long long)p->grid_restrict()), k.add((long long)p->grid_post());
   k.add((long long)p->zr_from_post), k.add((long long)p->nb_zr()), k.add((long long)p->device);
   key_bsr(k, p->Q);
   const auto& y = p->sym;
@@ -807,7 +813,8 @@ int resident_blocks(K kernel, int* out) {
 int tune_launch_caps(dpgo_problem_s* p) {
   DISPATCH(p->d, p->r, {
     if constexpr (Span<D, R, 1>::kOk) {
-      CHK(resident_blocks(k_tcg_update_span<D, R>, &p->cap_u));
+      CHK(resident_blocks((k_tcg_update_span<D, R, 0>), &p->cap_u));
+      CHK(resident_blocks((k_tcg_update_span<D, R, 1>), &p->cap_u_ml));
       if (p->split == 4)
         CHK(resident_blocks(k_tcg_hess_span<D, R, 4>, &p->cap_h));
       else if (p->split == 2)
@@ -822,6 +829,7 @@ int tune_launch_caps(dpgo_problem_s* p) {
         CHK(resident_blocks(k_tcg_hess_sym<D, R, 1>, &p->cap_hs));
     } else {
       CHK(resident_blocks(k_tcg_update<D, R>, &p->cap_u));
+      p->cap_u_ml = p->cap_u;  // (one kernel for both modes)
       if (p->split == 4)
         CHK(resident_blocks(k_tcg_hess<D, R, 4>, &p->cap_h));
       else if (p->split == 2)
@@ -858,7 +866,7 @@ int tune_launch_caps(dpgo_problem_s* p) {
   });
   if (options().grid_ml > 0) p->cap_restrict = p->cap_post = std::min(kPartialCap, options().grid_ml);
   // tuning knobs (any value up to the partial-sum capacity is valid)
-  if (options().grid_update > 0) p->cap_u = std::min(kPartialCap, options().grid_update);
+  if (options().grid_update > 0) p->cap_u = p->cap_u_ml = std::min(kPartialCap, options().grid_update);
   if (options().grid_hess > 0) p->cap_h = std::min(kPartialCap, options().grid_hess);
   if (options().grid_hess_sym > 0) p->cap_hs = std::min(kPartialCap, options().grid_hess_sym);
   return DPGO_OK;
