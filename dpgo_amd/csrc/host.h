@@ -126,6 +126,7 @@ inline int free_bsr(Bsr& m) {
   X(grid_update,       "DPGO_GRID_UPDATE",        0,  "launch cap of k_tcg_update (0: resident count)")                              \
   X(grid_hess,         "DPGO_GRID_HESS",          0,  "launch cap of k_tcg_hess (0: resident count)")                                \
   X(grid_hess_sym,     "DPGO_GRID_HESS_SYM",      0,  "launch cap of k_tcg_hess_sym (0: resident count)")                            \
+  X(grid_spmm_sym,     "DPGO_GRID_SPMM_SYM",      0,  "launch cap of k_spmm_sym (0: resident count, at most 1024)")                  \
   X(grid_ml,           "DPGO_GRID_ML",            0,  "launch cap of the level-0 restriction / post-smoothing (0: resident count)")  \
   X(persist,           "DPGO_PERSIST",           -1,  "one-launch solve (k_rtr_persist) off / on whatever the size: 0 / 1")          \
   X(persist_max_poses, "DPGO_PERSIST_MAX_POSES",  0,  "largest block the one-launch solve takes (0: every block it can hold)")       \
@@ -462,6 +463,12 @@ struct dpgo_problem_s {
   }
   int grid_restrict() const { return grid_tiles(cap_restrict); }
   int grid_post() const { return grid_tiles(cap_post); }
+  int cap_spmm_sym = kMaxGrid;  // launch cap of k_spmm_sym (resident count of the compiled kernel)
+  int grid_spmm_sym() const {
+    const int P = (64 / b) * kWaves;
+    const int tiles = std::max(1, (n + P - 1) / P);
+    return std::min(tiles, cap_spmm_sym);
+  }
   int grid_spmm() const {  // plain k_spmm: no partial sums, higher occupancy than the fused tCG kernel
     const int P = (64 / (b * split)) * kWaves;
     int tiles = (n + P - 1) / P;

@@ -32,10 +32,22 @@ __global__ __launch_bounds__(kBlock) void k_spmm(BsrDev Q, const double* __restr
 }
 
 // ================================================================ K1 on symmetric storage (common.h, spmm_sym_pre)
+// DPGO_SPMM_SYM_BATCH: blocks whose loads the gather keeps in flight (as DPGO_HESS_BATCH for the tCG-step kernel);
+// DPGO_SPMM_SYM_SPAN: the product leaves through the wave's LDS tile as lane-linear 16-byte pieces (even tile sizes) instead
+// of five 8-byte stores per lane at a 40-byte stride -- non-temporal 8-byte stores reach HBM as partial lines (PMC: 20.6 MB
+// written for 16 MB of output).
+#ifndef DPGO_SPMM_SYM_BATCH
+#define DPGO_SPMM_SYM_BATCH 4
+#endif
+#ifndef DPGO_SPMM_SYM_SPAN
+#define DPGO_SPMM_SYM_SPAN 1
+#endif
 template <int D, int R, int NTS>
 __global__ __launch_bounds__(kBlock) void k_spmm_sym(BsrSymDev Q, const double* __restrict__ V,
                                                      const double* __restrict__ Gadd, double* __restrict__ OUT, int n) {
   using GEO = Geo<D, R, 1>;
+  constexpr bool kSpanOut = Span<D, R, 1>::kOk && DPGO_SPMM_SYM_SPAN;
+  __shared__ __attribute__((aligned(16))) double os[kSpanOut ? kWaves : 1][kSpanOut ? GEO::G : 1][kSpanOut ? GEO::T : 1];
   const LaneId L = lane_id<D, 1>();
   const int ntiles = (n + GEO::P - 1) / GEO::P;
   const TileIter ti_ = tile_iter(ntiles);
@@ -45,13 +57,21 @@ __global__ __launch_bounds__(kBlock) void k_spmm_sym(BsrSymDev Q, const double* 
     const bool ok = (L.g < GEO::G) && (i < n);
     const SymIdx si = sym_idx_load<D>(Q, i, L.c, ok);
     double out[R];
-    spmm_sym_pre<D, R>(si, Q, V, L.c, out);
-    if (ok) {
-      const size_t off = (size_t)i * GEO::T + L.c * R;
-      if (Gadd) {
+    spmm_sym_pre<D, R, DPGO_SPMM_SYM_BATCH>(si, Q, V, L.c, out);
+    const size_t off = (size_t)i * GEO::T + L.c * R;
+    if (ok && Gadd) {
 #pragma unroll
-        for (int a = 0; a < R; ++a) out[a] += ld_stream<NTS>(Gadd + off + a);
-      }
+      for (int a = 0; a < R; ++a) out[a] += ld_stream<NTS>(Gadd + off + a);
+    }
+    if constexpr (kSpanOut) {
+      const int p0 = tile * GEO::P + L.wave * GEO::G;
+      const int npose = (n - p0) < GEO::G ? (n - p0) : GEO::G;
+      const int valid = npose > 0 ? npose * GEO::T : 0;
+      if (ok) store_col<R>(&os[L.wave][L.g][L.c * R], out);
+      wave_sync();
+      span_from_lds<D, R, NTS>(OUT + (size_t)p0 * GEO::T, &os[L.wave][0][0], valid);
+      wave_sync();  // (the tile is rewritten by the wave's next row block)
+    } else if (ok) {
       store_col_stream<NTS, R>(OUT + off, out);
     }
   }

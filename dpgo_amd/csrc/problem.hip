@@ -214,7 +214,7 @@ int sym_ensure(dpgo_problem_s* p, bool* usable) {
 
 // ---- kernel launch helpers (templated on D, R through DISPATCH) ----
 int launch_spmm_sym(dpgo_problem_s* p, const BsrSymDev& M, const double* V, const double* Gadd, double* OUT) {
-  const int g = p->grid_spmm();
+  const int g = p->grid_spmm_sym();
   DISPATCH(p->d, p->r,
            {
              if (p->want_stream_nt())

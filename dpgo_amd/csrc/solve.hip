@@ -869,6 +869,12 @@ int tune_launch_caps(dpgo_problem_s* p) {
   if (options().grid_update > 0) p->cap_u = p->cap_u_ml = std::min(kPartialCap, options().grid_update);
   if (options().grid_hess > 0) p->cap_h = std::min(kPartialCap, options().grid_hess);
   if (options().grid_hess_sym > 0) p->cap_hs = std::min(kPartialCap, options().grid_hess_sym);
+  DISPATCH(p->d, p->r, {
+    int c = kMaxGrid;
+    CHK(resident_blocks((k_spmm_sym<D, R, 1>), &c));
+    p->cap_spmm_sym = std::min(kMaxGrid, c);
+  });
+  if (options().grid_spmm_sym > 0) p->cap_spmm_sym = std::min(4096, options().grid_spmm_sym);
   return DPGO_OK;
 }
 
