@@ -126,6 +126,7 @@ inline int free_bsr(Bsr& m) {
   X(grid_update,       "DPGO_GRID_UPDATE",        0,  "launch cap of k_tcg_update (0: resident count)")                              \
   X(grid_hess,         "DPGO_GRID_HESS",          0,  "launch cap of k_tcg_hess (0: resident count)")                                \
   X(grid_hess_sym,     "DPGO_GRID_HESS_SYM",      0,  "launch cap of k_tcg_hess_sym (0: resident count)")                            \
+  X(grid_outer_sym,    "DPGO_GRID_OUTER_SYM",     0,  "launch cap of k_grad / k_hess on the symmetric storage (0: resident count)")  \
   X(grid_spmm_sym,     "DPGO_GRID_SPMM_SYM",      0,  "launch cap of k_spmm_sym (0: resident count, at most 1024)")                  \
   X(grid_ml,           "DPGO_GRID_ML",            0,  "launch cap of the level-0 restriction / post-smoothing (0: resident count)")  \
   X(persist,           "DPGO_PERSIST",           -1,  "one-launch solve (k_rtr_persist) off / on whatever the size: 0 / 1")          \
@@ -463,6 +464,16 @@ struct dpgo_problem_s {
   }
   int grid_restrict() const { return grid_tiles(cap_restrict); }
   int grid_post() const { return grid_tiles(cap_post); }
+  // the outer iteration's kernels on the symmetric storage (k_grad, k_hess: 110-114 VGPRs = 4 waves per SIMD) have their own
+  // cap -- grid_s() is sized for the tCG-step kernel's 2 waves per SIMD -- and whoever sums their partials is told the
+  // grid of the launch that wrote them
+  int cap_outer_sym = kMaxGrid;
+  int nb_grad = 0, nb_hess = 0;
+  int grid_outer_sym() const {
+    const int P = (64 / b) * kWaves;
+    const int tiles = std::max(1, (n + P - 1) / P);
+    return std::min(tiles, cap_outer_sym);
+  }
   int cap_spmm_sym = kMaxGrid;  // launch cap of k_spmm_sym (resident count of the compiled kernel)
   int grid_spmm_sym() const {
     const int P = (64 / b) * kWaves;

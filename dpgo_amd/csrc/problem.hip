@@ -258,10 +258,12 @@ int launch_grad(dpgo_problem_s* p, const double* X, double* RG, double* S, doubl
                 const DevState* st, bool sym) {
   const double* Gm = p->has_G ? p->G : nullptr;
   if (sym && p->split == 1) {
-    DISPATCH(p->d, p->r, hipLaunchKernelGGL((k_grad<D, R, 1, BsrSymDev>), dim3(p->grid_s()), dim3(kBlock), 0, p->stream,
+    p->nb_grad = p->grid_outer_sym();
+    DISPATCH(p->d, p->r, hipLaunchKernelGGL((k_grad<D, R, 1, BsrSymDev>), dim3(p->nb_grad), dim3(kBlock), 0, p->stream,
                                             p->sym.dev(), X, Gm, RG, S, EG, p->pE(), st, p->n));
   } else {
-    DISPATCH(p->d, p->r, LAUNCH_SPLIT(p, k_grad, p->grid_s(), p->Q.dev(), X, Gm, RG, S, EG, p->pE(), st, p->n));
+    p->nb_grad = p->grid_s();
+    DISPATCH(p->d, p->r, LAUNCH_SPLIT(p, k_grad, p->nb_grad, p->Q.dev(), X, Gm, RG, S, EG, p->pE(), st, p->n));
   }
   HIPC(hipGetLastError());
   return DPGO_OK;
@@ -270,11 +272,13 @@ int launch_grad(dpgo_problem_s* p, const double* X, double* RG, double* S, doubl
 int launch_hess(dpgo_problem_s* p, const double* X, const double* S, const double* V, const double* Gdot,
                 double* HV, double* partials, const DevState* st, int check_tcg, bool sym) {
   if (sym && p->split == 1) {
-    DISPATCH(p->d, p->r, hipLaunchKernelGGL((k_hess<D, R, 1, BsrSymDev>), dim3(p->grid_s()), dim3(kBlock), 0, p->stream,
+    p->nb_hess = p->grid_outer_sym();
+    DISPATCH(p->d, p->r, hipLaunchKernelGGL((k_hess<D, R, 1, BsrSymDev>), dim3(p->nb_hess), dim3(kBlock), 0, p->stream,
                                             p->sym.dev(), X, S, V, Gdot, HV, partials, st, check_tcg, p->n));
   } else {
+    p->nb_hess = p->grid_s();
     DISPATCH(p->d, p->r,
-             LAUNCH_SPLIT(p, k_hess, p->grid_s(), p->Q.dev(), X, S, V, Gdot, HV, partials, st, check_tcg, p->n));
+             LAUNCH_SPLIT(p, k_hess, p->nb_hess, p->Q.dev(), X, S, V, Gdot, HV, partials, st, check_tcg, p->n));
   }
   HIPC(hipGetLastError());
   return DPGO_OK;
@@ -289,10 +293,11 @@ int launch_retract(dpgo_problem_s* p, const double* X, const double* eta, double
 }
 
 int launch_rtr_update(dpgo_problem_s* p) {
-  const int g = p->grid_s();
+  // (the partial sums of the last k_grad / k_hess launch: their grids, launch_grad / launch_hess)
+  const int ge = p->nb_grad > 0 ? p->nb_grad : p->grid_s(), gh = p->nb_hess > 0 ? p->nb_hess : p->grid_s();
   DISPATCH(p->d, p->r,
            hipLaunchKernelGGL((k_rtr_update<D, R>), dim3(p->grid_flat()), dim3(kBlock), 0, p->stream, p->x1, p->x2,
-                              p->g1, p->g2, p->S1, p->S2, p->pE(), g, p->pH(), g, p->dstate + p->cur,
+                              p->g1, p->g2, p->S1, p->S2, p->pE(), ge, p->pH(), gh, p->dstate + p->cur,
                               p->dstate + (p->cur ^ 1), p->n));
   HIPC(hipGetLastError());
   p->cur ^= 1;
@@ -307,7 +312,7 @@ int launch_precond(dpgo_problem_s* p, const double* X, const double* V, const do
 }
 
 int launch_rtr_begin(dpgo_problem_s* p, double tol, double Delta0, double Dmax, int max_inner, int tiny) {
-  hipLaunchKernelGGL(k_rtr_begin, dim3(1), dim3(kBlock), 0, p->stream, p->pE(), p->grid_s(), p->dstate, tol, Delta0,
+  hipLaunchKernelGGL(k_rtr_begin, dim3(1), dim3(kBlock), 0, p->stream, p->pE(), p->nb_grad > 0 ? p->nb_grad : p->grid_s(), p->dstate, tol, Delta0,
                      Dmax, max_inner, tiny);
   HIPC(hipGetLastError());
   p->cur = 0;

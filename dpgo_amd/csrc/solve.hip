@@ -873,7 +873,12 @@ int tune_launch_caps(dpgo_problem_s* p) {
     int c = kMaxGrid;
     CHK(resident_blocks((k_spmm_sym<D, R, 1>), &c));
     p->cap_spmm_sym = std::min(kMaxGrid, c);
+    int cg = kMaxGrid, ch = kMaxGrid;
+    CHK(resident_blocks((k_grad<D, R, 1, BsrSymDev>), &cg));
+    CHK(resident_blocks((k_hess<D, R, 1, BsrSymDev>), &ch));
+    p->cap_outer_sym = std::min(kPartialCap, std::min(cg, ch));
   });
+  if (options().grid_outer_sym > 0) p->cap_outer_sym = std::min(kPartialCap, options().grid_outer_sym);
   if (options().grid_spmm_sym > 0) p->cap_spmm_sym = std::min(4096, options().grid_spmm_sym);
   return DPGO_OK;
 }
