@@ -126,6 +126,7 @@ inline int free_bsr(Bsr& m) {
   X(grid_update,       "DPGO_GRID_UPDATE",        0,  "launch cap of k_tcg_update (0: resident count)")                              \
   X(grid_hess,         "DPGO_GRID_HESS",          0,  "launch cap of k_tcg_hess (0: resident count)")                                \
   X(grid_hess_sym,     "DPGO_GRID_HESS_SYM",      0,  "launch cap of k_tcg_hess_sym (0: resident count)")                            \
+  X(grid_retract,      "DPGO_GRID_RETRACT",       0,  "launch cap of k_retract (0: 1024)")                                           \
   X(grid_outer_sym,    "DPGO_GRID_OUTER_SYM",     0,  "launch cap of k_grad / k_hess on the symmetric storage (0: resident count)")  \
   X(grid_spmm_sym,     "DPGO_GRID_SPMM_SYM",      0,  "launch cap of k_spmm_sym (0: resident count, at most 1024)")                  \
   X(grid_ml,           "DPGO_GRID_ML",            0,  "launch cap of the level-0 restriction / post-smoothing (0: resident count)")  \
