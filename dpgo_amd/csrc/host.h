@@ -136,6 +136,7 @@ inline int free_bsr(Bsr& m) {
   X(persist_mt,        "DPGO_PERSIST_MT",         0,  "tiles per workgroup of the one-launch solve: 1, 2 (0: by size)")              \
   X(poll_first,        "DPGO_POLL_FIRST",        -1,  "s_sleep units before the first sweep of the in-kernel all-reduce")            \
   X(poll_sleep,        "DPGO_POLL_SLEEP",        -1,  "s_sleep units between sweeps of the in-kernel all-reduce")                    \
+  X(poll_first_pay,    "DPGO_POLL_FIRST_PAY",    -1,  "the same before the first sweep of a reduction that carries a payload")       \
   X(persist_verbose,   "DPGO_PERSIST_VERBOSE",    0,  "per-solve phase report of the one-launch solve on stderr")                    \
   X(hess_dma,          "DPGO_HESS_DMA",           0,  "k_tcg_hess_sym's own tiles by LDS-DMA: 1 = double-buffered, 2 waves / SIMD, 4 blocks in flight; 2 = 3 waves, 2 blocks") \
   X(setup_timing,      "DPGO_SETUP_TIMING",       0,  "section times of the hierarchy's symbolic set-up on stderr")                  \

@@ -318,6 +318,47 @@ __device__ __forceinline__ double wave_reduce_lane63(double v) {
   return s;
 }
 
+// Wave sums of N values at once (N a multiple of 4; the callers pad with zeros): a reduce-scatter over the four rows of
+// the wavefront instead of N full reductions.  gfx950's v_permlane32_swap / v_permlane16_swap exchange half of one
+// register with the other half of a second one, so a PAIR of values is folded over the two halves of the wave (then over
+// the two rows of each half) by two swaps and one addition: N values -> N/2 -> N/4, each now the sum over all four rows of
+// ONE of the original values, which one depending on the lane's row; five DPP row shifts finish every survivor inside
+// its row.  N = 20: 15 pair steps + 5 row reductions, about a quarter of the instructions of 20 x wave_reduce_lane63.
+// Result: lane 15 of row q (lane 16 q + 15) holds in out[j] the wave sum of v[4 j + kRowValue[q]].  Fixed tree.
+__device__ __forceinline__ void swap_fold32(double x, double y, double& s) {  // s: lanes 0..31 sum x's halves, 32..63 y's
+  const auto lo = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(x), (unsigned)__double2loint(y), false, false);
+  const auto hi = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(x), (unsigned)__double2hiint(y), false, false);
+  s = __hiloint2double((int)hi[0], (int)lo[0]) + __hiloint2double((int)hi[1], (int)lo[1]);
+}
+__device__ __forceinline__ void swap_fold16(double x, double y, double& s) {  // s: even rows sum x's row pair, odd rows y's
+  const auto lo = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(x), (unsigned)__double2loint(y), false, false);
+  const auto hi = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(x), (unsigned)__double2hiint(y), false, false);
+  s = __hiloint2double((int)hi[0], (int)lo[0]) + __hiloint2double((int)hi[1], (int)lo[1]);
+}
+__device__ __forceinline__ int wave_rows_value(int lane) {  // kRowValue[row of the lane]: rows 0..3 -> 0, 2, 1, 3
+  const int q = lane >> 4;
+  return ((q & 1) << 1) | (q >> 1);
+}
+template <int N>
+__device__ __forceinline__ void wave_reduce_rows(const double (&v)[N], double (&out)[N / 4]) {
+  static_assert(N % 4 == 0, "pad to a multiple of 4");
+  double w[N / 2];
+#pragma unroll
+  for (int i = 0; i < N / 2; ++i) swap_fold32(v[2 * i], v[2 * i + 1], w[i]);  // half h holds value 2 i + h
+#pragma unroll
+  for (int j = 0; j < N / 4; ++j) {
+    double s;
+    swap_fold16(w[2 * j], w[2 * j + 1], s);  // row parity p holds w[2 j + p]: value 4 j + 2 p + h
+    double t = s;
+    t += dpp_shifted<0x111, 0xf, 0xf>(s);  // row_shr:1
+    t += dpp_shifted<0x112, 0xf, 0xf>(s);  // row_shr:2
+    t += dpp_shifted<0x113, 0xf, 0xf>(s);  // row_shr:3
+    t += dpp_shifted<0x114, 0xf, 0xe>(t);  // row_shr:4, banks 1..3
+    t += dpp_shifted<0x118, 0xf, 0xc>(t);  // row_shr:8, banks 2..3 -> lane 15 of the row holds the sum
+    out[j] = t;
+  }
+}
+
 template <int K>
 __device__ __forceinline__ void block_allreduce(double (&v)[K], double* red /* >= kWaves*K */) {
 #if DPGO_DPP_REDUCE

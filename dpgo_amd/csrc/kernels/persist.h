@@ -45,12 +45,17 @@ constexpr int kPersistPoison = 3;          // DevState::rtr_stop of a launch in 
 // s_sleep units (64 clocks each) before the first granule sweep of a reduction and between sweeps; packed into one
 // kernel argument (first << 8 | between) so that they can be tuned at run time (DPGO_POLL_FIRST / DPGO_POLL_SLEEP)
 constexpr int kPollFirstSleep = 24, kPollSleep = 3;
+constexpr int kPollFirstPaySleep = 0;  // before the first sweep of a reduction with a payload (0: as a plain one); bits 16..23
 __device__ __forceinline__ void sleep_units(int n) {
   for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(1);
 }
 constexpr int kPersistMax = kBlock;        // participants (workgroups) of one launch
 constexpr int kGranVals = 4;               // partial sums per all-reduce (max)
-constexpr int kGranRows = 2 * kGranVals;   // 8-byte words per participant: {epoch, low half}, {epoch, high half} per value
+// A reduction can also CARRY a payload: up to kGranPay doubles per participant that are not summed but handed, participant
+// t's to thread t of every workgroup (an all-gather riding on the all-reduce: same granules, same sweep, same epoch -- the
+// additive preconditioner's restricted vectors, (D+1) R <= 24 doubles per aggregate).
+constexpr int kGranPay = 24;
+constexpr int kGranRows = 2 * (kGranVals + kGranPay);  // 8-byte words per participant: {epoch, low half}, {epoch, high half} per value
 // granule table: [2 buffers][kGranRows][kPersistMax] words -- a row is contiguous over the participants, so a sweep is
 // kGranRows coalesced loads per 64 participants
 constexpr size_t kGranWords = (size_t)2 * kGranRows * kPersistMax;
@@ -95,10 +100,14 @@ __device__ __forceinline__ void ld_col_agent(__amdgpu_buffer_rsrc_t rz, int byte
 // partial sums, out = the sums over the launch (identical bits in every thread of every workgroup).  PRECONDITION: every
 // thread has executed `s_waitcnt vmcnt(0)` after its last store that other workgroups read (the first barrier below then
 // orders the whole workgroup's stores before the publish).  red: 2 x (2 * kWaves * kGranVals) doubles.  *ok_s: 1 at kernel start.
-template <int K>
+// PAY > 0: `pay_ws` = the workgroup's payload as per-wave partial sums in LDS, [kWaves][PAY] (written by every wave BEFORE
+// the call; the waves are added in order behind the first barrier), `got` = out: participant threadIdx.x's payload
+// (threads >= members: zeros).
+template <int K, int PAY = 0>
 __device__ __forceinline__ bool chip_allreduce(unsigned long long* gran, int rank, int members, unsigned salt, unsigned& step,
-                                               double (&part)[K], double* red, int* error, int* ok_s, int poll) {
-  static_assert(K <= kGranVals, "granule rows");
+                                               double (&part)[K], double* red, int* error, int* ok_s, int poll,
+                                               const double* pay_ws = nullptr, double* got = nullptr) {
+  static_assert(K <= kGranVals && PAY <= kGranPay, "granule rows");
   step += 1;
   const unsigned long long epoch = (unsigned long long)(salt | step);  // never 0; unique per launch and step
   unsigned long long* buf = gran + (size_t)(step & 1u) * kGranRows * kPersistMax;
@@ -122,35 +131,66 @@ __device__ __forceinline__ bool chip_allreduce(unsigned long long* gran, int ran
     const unsigned long long w = (epoch << 32) | (half ? (bits >> 32) : (bits & 0xffffffffull));
     __hip_atomic_store(buf + (size_t)threadIdx.x * kPersistMax + rank, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
+  if constexpr (PAY > 0) {  // the payload's granules: rows 2 kGranVals .. of the table
+    const int g = (int)threadIdx.x - 2 * K;
+    if (g >= 0 && g < 2 * PAY) {
+      const int e = g >> 1, half = g & 1;
+      double sum = pay_ws[e];
+#pragma unroll
+      for (int w = 1; w < kWaves; ++w) sum += pay_ws[w * PAY + e];
+      const unsigned long long bits = (unsigned long long)__double_as_longlong(sum);
+      const unsigned long long w = (epoch << 32) | (half ? (bits >> 32) : (bits & 0xffffffffull));
+      __hip_atomic_store(buf + (size_t)(2 * kGranVals + g) * kPersistMax + rank, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
   // thread t sweeps participant t's granules (one pass = 2K loads in flight, a row of the table per load instruction)
   double v[K];
 #pragma unroll
   for (int k = 0; k < K; ++k) v[k] = 0.0;
+  if constexpr (PAY > 0) {
+#pragma unroll
+    for (int e = 0; e < PAY; ++e) got[e] = 0.0;
+  }
   if ((int)threadIdx.x < members) {
     const int t = threadIdx.x;
-    bool got = false;
+    bool got_all = false;
     // a granule needs ~1 us to cross the chip: polls before that only load the fabric the granules travel on (sweeping
     // at once made the reduction 1 us SLOWER at 196 workgroups), so the first sweep waits and the later ones back off
-    sleep_units(poll >> 8);
+    sleep_units((PAY > 0 && ((poll >> 16) & 0xff)) ? ((poll >> 16) & 0xff) : ((poll >> 8) & 0xff));
     for (unsigned it = 0; it < kSpinLimit; ++it) {
       unsigned long long w[2 * K];
+      [[maybe_unused]] unsigned long long wp[PAY > 0 ? 2 * PAY : 1];
 #pragma unroll
       for (int j = 0; j < 2 * K; ++j)
         w[j] = __hip_atomic_load(buf + (size_t)j * kPersistMax + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if constexpr (PAY > 0) {
+#pragma unroll
+        for (int j = 0; j < 2 * PAY; ++j)
+          wp[j] = __hip_atomic_load(buf + (size_t)(2 * kGranVals + j) * kPersistMax + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
       bool all = true;
 #pragma unroll
       for (int j = 0; j < 2 * K; ++j) all = all && ((w[j] >> 32) == epoch);
+      if constexpr (PAY > 0) {
+#pragma unroll
+        for (int j = 0; j < 2 * PAY; ++j) all = all && ((wp[j] >> 32) == epoch);
+      }
       if (all) {
 #pragma unroll
         for (int k = 0; k < K; ++k)
           v[k] = __longlong_as_double((long long)((w[2 * k] & 0xffffffffull) | (w[2 * k + 1] << 32)));
-        got = true;
+        if constexpr (PAY > 0) {
+#pragma unroll
+          for (int e = 0; e < PAY; ++e)
+            got[e] = __longlong_as_double((long long)((wp[2 * e] & 0xffffffffull) | (wp[2 * e + 1] << 32)));
+        }
+        got_all = true;
         break;
       }
       if ((it & 255u) == 255u && __hip_atomic_load(error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
       sleep_units(poll & 0xff);
     }
-    if (!got) {
+    if (!got_all) {
       __hip_atomic_store(error, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       *ok_s = 0;  // sticky: the launch is abandoned
     }
@@ -284,10 +324,23 @@ constexpr int persist_slots_per_wg(int, int, bool = false) { return 2; }
 // one pose per (D+1) lanes -- blocks up to ~14 000 poses in 3-D): block-Jacobi plus the coarse-grid correction of
 // the residual itself, so nothing inside the preconditioner applies an operator to a vector other workgroups hold -- the
 // only exchange is the restricted residual rc (n / P coarse nodes x (D+1) R doubles: an all-gather every workgroup reads
-// in full), and it rides on a reduction the iteration needs anyway.  Per iteration: phase A | all-reduce <delta, H delta> |
-// r, eta update, x1 = Dinv r, rc = P^T r | all-reduce <r, r> (rc visible) | xc = (own rows of A_c^-1, resident in LDS) rc,
-// z = proj_X(w x1 + P xc) | all-reduce <z, r> (z visible): three reductions instead of the V-cycle's five launches
-// (DESIGN.md section 5).  The oracle restates the operator (precond = "amg_additive").
+// in full), and it rides on a reduction the iteration needs anyway.  Per iteration (round 2-5 form, DPGO_ADD_PAYLOAD=0):
+// phase A | all-reduce <delta, H delta> | r, eta update, x1 = Dinv r, rc = P^T r | all-reduce <r, r> (rc visible) |
+// xc = (own rows of A_c^-1, resident in LDS) rc, z = proj_X(w x1 + P xc) | all-reduce <z, r> (z visible): three reductions
+// instead of the V-cycle's five launches.  The oracle restates the operator (precond = "amg_additive").
+//
+// Round 6 (DPGO_ADD_PAYLOAD=1, the default): TWO reductions per iteration, as block-Jacobi.  The restriction is linear and
+// tCG's residual is a recurrence, r <- r + alpha H delta, so rc <- rc + alpha P^T(H delta): the restriction of H delta is
+// formed in phase A -- BEFORE alpha is known -- and travels as the PAYLOAD of the <delta, H delta> reduction
+// (chip_allreduce<K, PAY>: an all-gather on the same granules and the same sweep); thread t of every workgroup keeps
+// aggregate t's rows of rc in registers for the whole tCG run and adds alpha times what it swept.  Phase B then runs
+// straight through -- r, eta, x1, rc, xc, z -- and <r, r>, <z, r> leave in ONE reduction.  Only the first residual of a
+// tCG run (r0 = g) is restricted directly (payload of its <r, r> reduction).  Same operator; rc differs from P^T r by the
+// rounding of the recurrence, as r itself does from g + H eta.
+#ifndef DPGO_ADD_PAYLOAD
+#define DPGO_ADD_PAYLOAD 1
+#endif
+constexpr bool kAddPayload = DPGO_ADD_PAYLOAD != 0;
 struct AddDev {
   const double* Pb;    // prolongation blocks of level 0, [n][D+1][D+1] row-major
   const double* Minv;  // dense inverse of the coarse operator, row-major, leading dimension lda
@@ -398,6 +451,9 @@ __global__ __launch_bounds__(kBlock, 1) void k_rtr_persist(BsrDev Q, double* X, 
   }
   wave_sync();
   [[maybe_unused]] double pcol[B], prow[B];  // column c / row c of the pose's prolongation block
+  // (payload form) aggregate threadIdx.x's (D+1) x R entries of the restricted residual, kept for a whole tCG run, and of
+  // the restricted H delta the last Hessian-step reduction carried
+  [[maybe_unused]] double rct[ADD ? T : 1], hct[ADD ? T : 1];
   [[maybe_unused]] const int Nc = add.nc * B;
   [[maybe_unused]] const __amdgpu_buffer_rsrc_t rrc = vec_rsrc(add.rc, (size_t)(ADD ? add.nc : 0) * T * sizeof(double));
   if constexpr (ADD) {
@@ -509,7 +565,35 @@ __global__ __launch_bounds__(kBlock, 1) void k_rtr_persist(BsrDev Q, double* X, 
   };
 
   // ---- additive preconditioner, first half: r, eta update; x1 = Dinv r (kept in zc); rc = sum over the tile of P_i^T r_i
-  auto phase_add_restrict = [&](bool first, double alpha, double (&part)[1]) {
+  // (payload form: `with_rc` = the restriction is wanted -- the first residual of a tCG run; it is left as per-wave sums in
+  // tw_s for the reduction that carries it)
+  // P_i^T v_i of the wave's poses (their B columns of v in `tile`), summed over the wave's G pose slots in a fixed order
+  [[maybe_unused]] auto restrict_to_waves = [&](const double (*tile)[T]) {
+    if constexpr (ADD) {
+      if (L.s == 0 && L.g < G) {
+        double t[R];
+#pragma unroll
+        for (int a = 0; a < R; ++a) t[a] = 0.0;
+        if (own[0]) {
+#pragma unroll
+          for (int cc = 0; cc < B; ++cc) {  // row c of P_i^T v_i = sum_c' P_i[c'][c] v_i[c'][:]
+#pragma unroll
+            for (int a = 0; a < R; ++a) t[a] = fma(pcol[cc], tile[L.g][cc * R + a], t[a]);
+          }
+        }
+        store_col<R>(&ts[lp][co], t);  // zeros for pose slots beyond n
+      }
+      wave_sync();
+      if ((int)(threadIdx.x & 63) < T) {
+        const int e = threadIdx.x & 63;
+        double sum = ts[L.wave * G][e];
+#pragma unroll
+        for (int m = 1; m < G; ++m) sum += ts[L.wave * G + m][e];
+        tw_s[L.wave][e] = sum;
+      }
+    }
+  };
+  auto phase_add_restrict = [&](bool first, double alpha, double (&part)[1], bool with_rc = true) {
     part[0] = 0.0;
     if constexpr (ADD) {
       if (own[0]) {
@@ -524,29 +608,13 @@ __global__ __launch_bounds__(kBlock, 1) void k_rtr_persist(BsrDev Q, double* X, 
         store_col<R>(&ex[0][L.wave][L.g][co], rr[0]);
       }
       wave_sync();  // the pose's B columns of r are in LDS
-      if (L.s == 0 && L.g < G) {
-        double t[R];
-#pragma unroll
-        for (int a = 0; a < R; ++a) t[a] = 0.0;
-        if (own[0]) {
-          jacobi_col<D, R>(&ex[0][L.wave][L.g][0], drow[0], zc[0]);  // x1 (unweighted), until z replaces it
-#pragma unroll
-          for (int cc = 0; cc < B; ++cc) {  // row c of P_i^T r_i = sum_c' P_i[c'][c] r_i[c'][:]
-#pragma unroll
-            for (int a = 0; a < R; ++a) t[a] = fma(pcol[cc], ex[0][L.wave][L.g][cc * R + a], t[a]);
-          }
-        }
-        store_col<R>(&ts[lp][co], t);  // zeros for pose slots beyond n
+      if (own[0]) jacobi_col<D, R>(&ex[0][L.wave][L.g][0], drow[0], zc[0]);  // x1 (unweighted), until z replaces it
+      if constexpr (kAddPayload) {
+        if (with_rc) restrict_to_waves(ex[0][L.wave]);
+        return;
       }
       // fixed order: every wave adds up its own G pose slots, then the waves in order; the all-gathered coarse residual
-      wave_sync();
-      if ((int)(threadIdx.x & 63) < T) {
-        const int e = threadIdx.x & 63;
-        double sum = ts[L.wave * G][e];
-#pragma unroll
-        for (int m = 1; m < G; ++m) sum += ts[L.wave * G + m][e];
-        tw_s[L.wave][e] = sum;
-      }
+      restrict_to_waves(ex[0][L.wave]);
       __syncthreads();
       if ((int)threadIdx.x < T && rank < ntiles) {
         double sum = tw_s[0][threadIdx.x];
@@ -568,7 +636,20 @@ __global__ __launch_bounds__(kBlock, 1) void k_rtr_persist(BsrDev Q, double* X, 
         for (int a = 0; a < R; ++a) acc[row][a] = 0.0;
       // a coarse unknown's R right-hand sides: one thread each, ALL of a thread's columns requested before the first use
       // (nc <= kPersistMax aggregates: at most NJ = D + 1 columns per thread; one memory round trip, not one per column)
-      {
+      if constexpr (kAddPayload) {
+        // thread t holds aggregate t's B coarse unknowns (rct): B columns of the workgroup's rows of the inverse each
+        const int t = threadIdx.x;
+        const bool on = t < add.nc;
+#pragma unroll
+        for (int b = 0; b < B; ++b) {
+#pragma unroll
+          for (int row = 0; row < B; ++row) {
+            const double mv = on ? Ms[row * Nc + (on ? t : 0) * B + b] : 0.0;
+#pragma unroll
+            for (int a = 0; a < R; ++a) acc[row][a] = fma(mv, rct[b * R + a], acc[row][a]);
+          }
+        }
+      } else {
         constexpr int NJ = (kPersistMax * B + kBlock - 1) / kBlock;
         double rj[NJ][R];
 #pragma unroll
@@ -588,13 +669,27 @@ __global__ __launch_bounds__(kBlock, 1) void k_rtr_persist(BsrDev Q, double* X, 
           }
         }
       }
+      if constexpr (kAddPayload) {  // the T wave sums as one reduce-scatter over the wave's rows (common.h)
+        constexpr int TP = (T + 3) / 4 * 4;
+        double flat[TP], rs[TP / 4];
 #pragma unroll
-      for (int row = 0; row < B; ++row)
+        for (int e = 0; e < TP; ++e) flat[e] = e < T ? acc[e / R][e % R] : 0.0;
+        wave_reduce_rows<TP>(flat, rs);
+        if ((threadIdx.x & 15) == 15) {
+          const int q = wave_rows_value(threadIdx.x & 63);
 #pragma unroll
-        for (int a = 0; a < R; ++a) {
-          const double v = wave_reduce_lane63(acc[row][a]);
-          if ((threadIdx.x & 63) == 63) xw_s[threadIdx.x >> 6][row * R + a] = v;
+          for (int j = 0; j < TP / 4; ++j)
+            if (4 * j + q < T) xw_s[threadIdx.x >> 6][4 * j + q] = rs[j];
         }
+      } else {
+#pragma unroll
+        for (int row = 0; row < B; ++row)
+#pragma unroll
+          for (int a = 0; a < R; ++a) {
+            const double v = wave_reduce_lane63(acc[row][a]);
+            if ((threadIdx.x & 63) == 63) xw_s[threadIdx.x >> 6][row * R + a] = v;
+          }
+      }
       __syncthreads();
       if ((int)threadIdx.x < T) {
         double sum = xw_s[0][threadIdx.x];
@@ -681,6 +776,11 @@ __global__ __launch_bounds__(kBlock, 1) void k_rtr_persist(BsrDev Q, double* X, 
           part[0] = fma(dn, hn, part[0]);
         }
       }
+    }
+    if constexpr (ADD && kAddPayload) {  // P^T (H delta) of the tile rides on the reduction of <delta, H delta>
+      if (own[0]) store_col<R>(&ex[1][L.wave][L.g][co], hd[0]);
+      wave_sync();
+      restrict_to_waves(ex[1][L.wave]);
     }
   };
 
@@ -825,7 +925,28 @@ __global__ __launch_bounds__(kBlock, 1) void k_rtr_persist(BsrDev Q, double* X, 
   // preconditioner, two (the restricted residual becomes visible with the first) with the additive two-level one
   unsigned long long tmid = 0;  // diagnostic: end of the update phase proper
   auto update_and_reduce = [&](bool first, double alpha) -> bool {
-    if constexpr (ADD) {
+    if constexpr (ADD && kAddPayload) {
+      double p1[1], p2[1];
+      if (first) {  // r0 = g: restricted directly, all-gathered with <r, r>
+        phase_add_restrict(true, alpha, p1, true);
+        tmid = wall_clock64();
+        if (!chip_allreduce<1, T>(gran, rank, members, salt, step, p1, red, &ctrl->error, &ok_s, poll, &tw_s[0][0], rct))
+          return false;
+        phase_add_correct(p2);
+        if (!chip_allreduce<1>(gran, rank, members, salt, step, p2, red, &ctrl->error, &ok_s, poll)) return false;
+        pr[0] = p1[0];
+        pr[1] = p2[0];
+        return true;
+      }
+      phase_add_restrict(false, alpha, p1, false);
+#pragma unroll
+      for (int e = 0; e < T; ++e) rct[e] = fma(alpha, hct[e], rct[e]);  // rc <- rc + alpha P^T (H delta)
+      phase_add_correct(p2);
+      pr[0] = p1[0];
+      pr[1] = p2[0];
+      tmid = wall_clock64();
+      return chip_allreduce<2>(gran, rank, members, salt, step, pr, red, &ctrl->error, &ok_s, poll);
+    } else if constexpr (ADD) {
       double p1[1], p2[1];
       phase_add_restrict(first, alpha, p1);
       tmid = wall_clock64();
@@ -856,7 +977,11 @@ __global__ __launch_bounds__(kBlock, 1) void k_rtr_persist(BsrDev Q, double* X, 
     double dh[1];
     phase_hess(first, beta, dh);
     const unsigned long long t1 = wall_clock64();
-    if (!(alive = chip_allreduce<1>(gran, rank, members, salt, step, dh, red, &ctrl->error, &ok_s, poll))) break;
+    if constexpr (ADD && kAddPayload)
+      alive = chip_allreduce<1, T>(gran, rank, members, salt, step, dh, red, &ctrl->error, &ok_s, poll, &tw_s[0][0], hct);
+    else
+      alive = chip_allreduce<1>(gran, rank, members, salt, step, dh, red, &ctrl->error, &ok_s, poll);
+    if (!alive) break;
     const unsigned long long t2 = wall_clock64();
     const double d_Hd = dh[0];
     const double alpha = st.z_r / d_Hd;

@@ -231,7 +231,11 @@ int launch_rtr_persistent(dpgo_problem_s* p, const dpgo_ropt_params* prm, const 
   const int first = env_first >= 0 ? std::min(255, env_first)
                                    : (p->persist_split == 4 ? (p->persist_wgs <= 160 ? kPollFirstSleep : 30) : 44);
   const int between = env_sleep >= 0 ? std::min(255, env_sleep) : kPollSleep;
-  const int poll = (first << 8) | between;
+  // (a reduction that also carries the additive preconditioner's payload -- 2 (d+1) r more granules per participant --
+  // completes later: its first sweep waits longer; 0 in the argument = as the plain one)
+  const int env_first_pay = options().poll_first_pay;
+  const int first_pay = env_first_pay >= 0 ? std::min(255, env_first_pay) : kPollFirstPaySleep;
+  const int poll = (first_pay << 16) | (first << 8) | between;
 
   AddDev add{};
   size_t lds = 0;
@@ -513,7 +517,9 @@ int rtr_outer_iteration(dpgo_problem_s* p, const dpgo_ropt_params* prm, const do
 //     additive form owns one CU per aggregate (up to the whole chip: such solves take turns), block-Jacobi's compact
 //     layout a quarter to a half of it, so there a product costs [us] x max(resident slots / slots in use at once, 1 / share)
 //     x share -- the same figure as alone whenever every concurrently solved handle fits at once.
-constexpr int kAutoUnitsJacobi = 10, kAutoUnitsAdditive = 18, kAutoSetupUnits = 2800, kAutoMinProducts = 6;
+// (round 6: an additive iteration is two chip-wide reductions, as a block-Jacobi one -- 13.0 against 9.5 us on a 12 500-pose
+// slab, 9.1 against 6.6 on sphere2500; it was 15.7 / 10.6 with three: 18 units)
+constexpr int kAutoUnitsJacobi = 10, kAutoUnitsAdditive = 14, kAutoSetupUnits = 2800, kAutoMinProducts = 6;
 int auto_units_jacobi(dpgo_problem_s* p) {
   const int share = std::max(1, p->persist_share);
   if (share == 1 || !p->persist) return kAutoUnitsJacobi;
