@@ -234,6 +234,9 @@ struct GatherOps {
   using GG = GatherGeo<D, SPLIT>;
   int t0, deg;
   int j[GG::NB];  // gathered pose of block m (own pose / pose 0 when the block is absent)
+  // the same pose as a slot of the workgroup's OWN LDS tiles ((tile index) P + slot), -1 = another workgroup's: its
+  // z is read from the tile this workgroup wrote itself instead of crossing the chip (DPGO_PERSIST_LOCAL; set by the kernel)
+  int loc[GG::NB];
   double q[QRES ? GG::NB : 1][GG::B];
 };
 template <int D, int R, int SPLIT, bool QRES>
@@ -247,22 +250,30 @@ __device__ __forceinline__ void gather_setup(GatherOps<D, R, SPLIT, QRES>& go, c
     const int blk = s + m * SPLIT;
     const bool on = blk < go.deg && blk < GG::NPRE;
     go.j[m] = on ? Q.colidx[go.t0 + blk] : (okp ? i : 0);
+    go.loc[m] = -1;
     if constexpr (QRES) {
 #pragma unroll
       for (int cc = 0; cc < B; ++cc) go.q[m][cc] = on ? Q.vals[(size_t)(go.t0 + blk) * BB + cc * B + c] : 0.0;
     }
   }
 }
+// own_tiles (LDS, [tiles][P][T] of the gathered vector, complete and ordered by a workgroup barrier; nullptr: none): the
+// columns of poses this workgroup owns come from there
 template <int D, int R, int SPLIT, bool QRES>
 __device__ __forceinline__ void gather_issue(const GatherOps<D, R, SPLIT, QRES>& go, const BsrDev& Q,
                                              __amdgpu_buffer_rsrc_t rz, int s, int c,
                                              double (&xc)[GatherGeo<D, SPLIT>::NB][R],
-                                             double (&qc)[GatherGeo<D, SPLIT>::NB][D + 1]) {
+                                             double (&qc)[GatherGeo<D, SPLIT>::NB][D + 1],
+                                             const double* own_tiles = nullptr) {
   using GG = GatherGeo<D, SPLIT>;
   constexpr int B = GG::B, BB = B * B, T = B * R;
 #pragma unroll
   for (int m = 0; m < GG::NB; ++m) {
-    ld_col_agent<R>(rz, (go.j[m] * T + c * R) * 8, xc[m]);
+    if (own_tiles && go.loc[m] >= 0) {
+      load_col<R>(own_tiles + go.loc[m] * T + c * R, xc[m]);
+    } else {
+      ld_col_agent<R>(rz, (go.j[m] * T + c * R) * 8, xc[m]);
+    }
     if constexpr (QRES) {
 #pragma unroll
       for (int cc = 0; cc < B; ++cc) qc[m][cc] = go.q[m][cc];
@@ -350,7 +361,19 @@ struct AddDev {
   // graph aggregates: pose of every (aggregate, slot), nc x tile entries, -1 = empty slot; nullptr: aggregate a = the
   // poses [a tile, (a + 1) tile)
   const int32_t* perm;
+  // graph aggregates: aggregate of every pose, its position in the member list, the member list's row pointer (a pose's
+  // slot in its aggregate's tile = mem_pos - agg_ptr[aggregate]); nullptr with index runs
+  const int32_t *lab, *mem_pos, *agg_ptr;
 };
+#ifndef DPGO_PERSIST_LOCAL
+#define DPGO_PERSIST_LOCAL 1  // tCG's gather reads the poses of the workgroup's own tiles from LDS (0: everything from memory)
+#endif
+// Used by the layouts with one pose per (D+1) lanes (64-pose tiles: on a 12 500-pose slab three quarters of a graph
+// aggregate's neighbours, 3 of 7 of an index tile's, are the workgroup's own -- Hessian phase 3.8 -> 2.25 us additive,
+// 3.2 -> 1.9 block-Jacobi).  With 4 lane groups per pose (16-pose tiles) few neighbours are local and the test costs what
+// it saves (torus3D block-Jacobi 10.0 -> 10.3 us per iteration): off.
+template <int SPLIT>
+constexpr bool persist_local() { return DPGO_PERSIST_LOCAL != 0 && SPLIT == 1; }
 
 // Trust-region parameters of a solve (src/QuadraticOptimizer.cpp:64-78)
 struct RtrArgs {
@@ -433,6 +456,25 @@ __global__ __launch_bounds__(kBlock, 1) void k_rtr_persist(BsrDev Q, double* X, 
     }
     own[k] = okp[k] && (L.s == 0);
     gather_setup<D, R, SPLIT, QRES>(go[k], Q, pose[k], L.s, L.c, okp[k]);
+    if constexpr (persist_local<SPLIT>()) {
+#pragma unroll
+      for (int m = 0; m < GG::NB; ++m) {
+        const int j = go[k].j[m];
+        int lc = -1;
+        if constexpr (ADD) {
+          if (add.lab) {
+            if (add.lab[j] == rank) lc = add.mem_pos[j] - add.agg_ptr[rank];
+          } else if (j / P == rank) {
+            lc = j - rank * P;
+          }
+        } else {
+#pragma unroll
+          for (int kk = 0; kk < MT; ++kk)
+            if (j / P == rank + kk * members) lc = kk * P + (j - (rank + kk * members) * P);
+        }
+        go[k].loc[m] = lc;
+      }
+    }
 #pragma unroll
     for (int a = 0; a < R; ++a) rr[k][a] = ee[k][a] = dl[k][a] = hd[k][a] = zc[k][a] = 0.0;
 #pragma unroll
@@ -735,17 +777,19 @@ __global__ __launch_bounds__(kBlock, 1) void k_rtr_persist(BsrDev Q, double* X, 
   auto phase_hess = [&](bool first, double beta, double (&part)[1]) {
     part[0] = 0.0;
     double h[MT][R];
+    // (z of the workgroup's own poses: the LDS tiles the update phase wrote, ordered by the barriers of its reduction)
+    const double* own_z = persist_local<SPLIT>() ? &Zs[0][0][0] : nullptr;
     if constexpr (SPLIT > 1) {  // few loads per tile: all tiles' requests go out before the first reduction
       double xc[MT][GG::NB][R], qc[MT][GG::NB][B];
 #pragma unroll
-      for (int k = 0; k < MT; ++k) gather_issue<D, R, SPLIT, QRES>(go[k], Q, rz, L.s, L.c, xc[k], qc[k]);
+      for (int k = 0; k < MT; ++k) gather_issue<D, R, SPLIT, QRES>(go[k], Q, rz, L.s, L.c, xc[k], qc[k], own_z);
 #pragma unroll
       for (int k = 0; k < MT; ++k) gather_finish<D, R, SPLIT, QRES>(go[k], Q, rz, L.s, L.c, xc[k], qc[k], h[k]);
     } else {  // one pose per (D+1) lanes: a tile's 2 (D+1) R + 2 (D+1)^2 loads fill the register budget; tile after tile
 #pragma unroll
       for (int k = 0; k < MT; ++k) {
         double xc[GG::NB][R], qc[GG::NB][B];
-        gather_issue<D, R, SPLIT, QRES>(go[k], Q, rz, L.s, L.c, xc, qc);
+        gather_issue<D, R, SPLIT, QRES>(go[k], Q, rz, L.s, L.c, xc, qc, own_z);
         gather_finish<D, R, SPLIT, QRES>(go[k], Q, rz, L.s, L.c, xc, qc, h[k]);
       }
     }

@@ -242,7 +242,8 @@ int launch_rtr_persistent(dpgo_problem_s* p, const dpgo_ropt_params* prm, const 
   if (additive) {
     auto& L0 = p->ml[0];
     auto& C = p->ml[1];
-    add = AddDev{L0.Pb, p->ml_dense, p->ml_lda, C.n, C.r, 1.0, L0.graph ? L0.tile_perm : nullptr};
+    add = AddDev{L0.Pb, p->ml_dense, p->ml_lda, C.n, C.r, 1.0, L0.graph ? L0.tile_perm : nullptr,
+                 L0.graph ? L0.lab : nullptr, L0.graph ? L0.mem_pos : nullptr, L0.graph ? L0.agg_ptr : nullptr};
     lds = sizeof(double) * (size_t)p->b * C.n * p->b;  // (d+1) rows of the inverse
   }
   const RtrArgs ra{prm->gradnorm_tol, prm->RTR_initial_radius, 5.0 * prm->RTR_initial_radius, prm->RTR_tCG_iterations,
