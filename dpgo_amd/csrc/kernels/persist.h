@@ -56,8 +56,8 @@ constexpr int kGranVals = 4;               // partial sums per all-reduce (max)
 // additive preconditioner's restricted vectors, (D+1) R <= 24 doubles per aggregate).
 constexpr int kGranPay = 24;
 constexpr int kGranRows = 2 * (kGranVals + kGranPay);  // 8-byte words per participant: {epoch, low half}, {epoch, high half} per value
-// granule table: [2 buffers][kGranRows][kPersistMax] words -- a row is contiguous over the participants, so a sweep is
-// kGranRows coalesced loads per 64 participants
+// granule table: [2 buffers][kGranVals + kGranPay values][kPersistMax participants] cells of 2 words (chip_allreduce) -- a
+// row is contiguous over the participants, so a sweep is one coalesced 16-byte load per value and 64 participants
 constexpr size_t kGranWords = (size_t)2 * kGranRows * kPersistMax;
 
 __device__ __forceinline__ double ld_agent(const double* p) {
@@ -111,6 +111,13 @@ __device__ __forceinline__ bool chip_allreduce(unsigned long long* gran, int ran
   step += 1;
   const unsigned long long epoch = (unsigned long long)(salt | step);  // never 0; unique per launch and step
   unsigned long long* buf = gran + (size_t)(step & 1u) * kGranRows * kPersistMax;
+  // Table of one buffer: CELLS of 16 bytes, cell (value v, participant t) at word 2 (v kPersistMax + t) = the value's two
+  // granules {epoch, low half}, {epoch, high half} side by side.  Each granule is still ONE 8-byte store (tag and payload
+  // arrive together, whatever happens to the pair); the sweep reads a cell with one 16-byte load -- half the load
+  // instructions, and 8-byte accesses move at 0.54-0.70x the rate of 16-byte ones (MI355X_MICROARCH.md) -- and checks
+  // both tags.  Values 0 .. kGranVals-1: the partial sums; kGranVals ..: the payload.
+  [[maybe_unused]] const __amdgpu_buffer_rsrc_t rg =
+      __builtin_amdgcn_make_buffer_rsrc(buf, 0, (int)(kGranRows * kPersistMax * sizeof(unsigned long long)), 0x00020000);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   // two sets of scratch alternate: a wave that runs ahead into the next reduction must not overwrite sums a slower wave
   // of this one still reads (only wave-level barriers separate the two)
@@ -129,9 +136,9 @@ __device__ __forceinline__ bool chip_allreduce(unsigned long long* gran, int ran
     for (int w = 1; w < kWaves; ++w) sum += red[w * K + k];
     const unsigned long long bits = (unsigned long long)__double_as_longlong(sum);
     const unsigned long long w = (epoch << 32) | (half ? (bits >> 32) : (bits & 0xffffffffull));
-    __hip_atomic_store(buf + (size_t)threadIdx.x * kPersistMax + rank, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(buf + ((size_t)k * kPersistMax + rank) * 2 + half, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
-  if constexpr (PAY > 0) {  // the payload's granules: rows 2 kGranVals .. of the table
+  if constexpr (PAY > 0) {  // the payload's granules: values kGranVals .. of the table
     const int g = (int)threadIdx.x - 2 * K;
     if (g >= 0 && g < 2 * PAY) {
       const int e = g >> 1, half = g & 1;
@@ -140,10 +147,10 @@ __device__ __forceinline__ bool chip_allreduce(unsigned long long* gran, int ran
       for (int w = 1; w < kWaves; ++w) sum += pay_ws[w * PAY + e];
       const unsigned long long bits = (unsigned long long)__double_as_longlong(sum);
       const unsigned long long w = (epoch << 32) | (half ? (bits >> 32) : (bits & 0xffffffffull));
-      __hip_atomic_store(buf + (size_t)(2 * kGranVals + g) * kPersistMax + rank, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(buf + ((size_t)(kGranVals + e) * kPersistMax + rank) * 2 + half, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
-  // thread t sweeps participant t's granules (one pass = 2K loads in flight, a row of the table per load instruction)
+  // thread t sweeps participant t's cells (one pass = K (+ PAY) 16-byte loads in flight, a row of the table per load instruction)
   double v[K];
 #pragma unroll
   for (int k = 0; k < K; ++k) v[k] = 0.0;
@@ -158,31 +165,29 @@ __device__ __forceinline__ bool chip_allreduce(unsigned long long* gran, int ran
     // at once made the reduction 1 us SLOWER at 196 workgroups), so the first sweep waits and the later ones back off
     sleep_units((PAY > 0 && ((poll >> 16) & 0xff)) ? ((poll >> 16) & 0xff) : ((poll >> 8) & 0xff));
     for (unsigned it = 0; it < kSpinLimit; ++it) {
-      unsigned long long w[2 * K];
-      [[maybe_unused]] unsigned long long wp[PAY > 0 ? 2 * PAY : 1];
+      u32x4 c[K];
+      [[maybe_unused]] u32x4 cp[PAY > 0 ? PAY : 1];
 #pragma unroll
-      for (int j = 0; j < 2 * K; ++j)
-        w[j] = __hip_atomic_load(buf + (size_t)j * kPersistMax + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      for (int k = 0; k < K; ++k) c[k] = __builtin_amdgcn_raw_buffer_load_b128(rg, (k * kPersistMax + t) * 16, 0, kAuxSc1);
       if constexpr (PAY > 0) {
 #pragma unroll
-        for (int j = 0; j < 2 * PAY; ++j)
-          wp[j] = __hip_atomic_load(buf + (size_t)(2 * kGranVals + j) * kPersistMax + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int e = 0; e < PAY; ++e)
+          cp[e] = __builtin_amdgcn_raw_buffer_load_b128(rg, ((kGranVals + e) * kPersistMax + t) * 16, 0, kAuxSc1);
       }
+      const unsigned ep = (unsigned)epoch;
       bool all = true;
 #pragma unroll
-      for (int j = 0; j < 2 * K; ++j) all = all && ((w[j] >> 32) == epoch);
+      for (int k = 0; k < K; ++k) all = all && (c[k].y == ep) && (c[k].w == ep);
       if constexpr (PAY > 0) {
 #pragma unroll
-        for (int j = 0; j < 2 * PAY; ++j) all = all && ((wp[j] >> 32) == epoch);
+        for (int e = 0; e < PAY; ++e) all = all && (cp[e].y == ep) && (cp[e].w == ep);
       }
       if (all) {
 #pragma unroll
-        for (int k = 0; k < K; ++k)
-          v[k] = __longlong_as_double((long long)((w[2 * k] & 0xffffffffull) | (w[2 * k + 1] << 32)));
+        for (int k = 0; k < K; ++k) v[k] = __hiloint2double((int)c[k].z, (int)c[k].x);
         if constexpr (PAY > 0) {
 #pragma unroll
-          for (int e = 0; e < PAY; ++e)
-            got[e] = __longlong_as_double((long long)((wp[2 * e] & 0xffffffffull) | (wp[2 * e + 1] << 32)));
+          for (int e = 0; e < PAY; ++e) got[e] = __hiloint2double((int)cp[e].z, (int)cp[e].x);
         }
         got_all = true;
         break;
