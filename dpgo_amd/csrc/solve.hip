@@ -518,9 +518,9 @@ int rtr_outer_iteration(dpgo_problem_s* p, const dpgo_ropt_params* prm, const do
 //     additive form owns one CU per aggregate (up to the whole chip: such solves take turns), block-Jacobi's compact
 //     layout a quarter to a half of it, so there a product costs [us] x max(resident slots / slots in use at once, 1 / share)
 //     x share -- the same figure as alone whenever every concurrently solved handle fits at once.
-// (round 6: an additive iteration is two chip-wide reductions, as a block-Jacobi one -- 13.0 against 9.5 us on a 12 500-pose
-// slab, 9.1 against 6.6 on sphere2500; it was 15.7 / 10.6 with three: 18 units)
-constexpr int kAutoUnitsJacobi = 10, kAutoUnitsAdditive = 14, kAutoSetupUnits = 2800, kAutoMinProducts = 6;
+// (round 6: an additive iteration is two chip-wide reductions, as a block-Jacobi one -- 11.0 against 9.6 us on a 12 500-pose
+// slab, 8.7 against 6.6 on sphere2500; it was 15.7 / 10.6 with three: 18 units)
+constexpr int kAutoUnitsJacobi = 10, kAutoUnitsAdditive = 13, kAutoSetupUnits = 2800, kAutoMinProducts = 6;
 int auto_units_jacobi(dpgo_problem_s* p) {
   const int share = std::max(1, p->persist_share);
   if (share == 1 || !p->persist) return kAutoUnitsJacobi;

@@ -59,8 +59,8 @@ extern "C" {
  *    hierarchy -- is constant across RBCD sweeps, so its set-up (2 800 units = 280 block-Jacobi products: 2.8-3.0 ms
  *    against 10 us) is paid once.  When the block-Jacobi solves since Q last changed have cost as much as one set-up
  *    (and the last one ran >= 6 products), or one of them used >= half its tCG budget, the next solve runs additive on
- *    trial; it stays additive while its products x 14 stay below the reference block-Jacobi solve's x 10 (round 6: 11.7 us
- *    against 8.8 us per in-kernel iteration on a 12 500-pose slab, 9.1 against 6.6 on sphere2500; 18 units before the
+ *    trial; it stays additive while its products x 13 stay below the reference block-Jacobi solve's x 10 (round 6: 11.0 us
+ *    against 9.6 us per in-kernel iteration on a 12 500-pose slab, 8.7 against 6.6 on sphere2500; 18 units before the
  *    additive iteration lost its third reduction), and hands back otherwise -- the hierarchy is kept, the next trial waits
  *    for twice the work.
  *    Handles solved next to others of one device are charged for the part of the chip their launch blocks

@@ -1390,7 +1390,7 @@ class AutoCostRule:
     launch blocks when it shares the device).  next() = what the next solve runs; record(products) = the solve just
     finished."""
 
-    def __init__(self, budget=150, units_jacobi=10, units_additive=14, setup_units=2800, min_products=6,
+    def __init__(self, budget=150, units_jacobi=10, units_additive=13, setup_units=2800, min_products=6,
                  units_jacobi_alone=10):
         self.budget, self.uj, self.ua, self.setup, self.minp = budget, units_jacobi, units_additive, setup_units, min_products
         self.uj0 = units_jacobi_alone

@@ -643,23 +643,23 @@ def test_switches_are_one_table_read_once_and_the_auto_rule_is_restated(oracle):
     L.check(lib.dpgo_auto_rule_constants(*[C.byref(x) for x in k]))
     uj, ua, setup, minp = (x.value for x in k)
     r = oracle.AutoCostRule()
-    assert (r.uj, r.ua, r.setup, r.minp, r.uj0) == (uj, ua, setup, minp, uj) == (10, 14, 2800, 6, 10)
+    assert (r.uj, r.ua, r.setup, r.minp, r.uj0) == (uj, ua, setup, minp, uj) == (10, 13, 2800, 6, 10)
     # 36 products per block-Jacobi solve: the set-up is paid after 8 solves (8 x 360 = 2 880 units)
     seq = []
     for _ in range(8):
         seq.append(r.next())
         r.record(36)
     assert seq == ["jacobi"] * 8 and r.next() == "additive" and r.state == 1 and r.ref == 36
-    r.record(26)  # 26 x 14 = 364 >= 36 x 10: no cheaper -> handed back, the next trial waits for two set-ups
+    r.record(28)  # 28 x 13 = 364 >= 36 x 10: no cheaper -> handed back, the next trial waits for two set-ups
     assert r.next() == "jacobi" and r.backoff == 1 and r.units == 0
     for _ in range(16):
         r.record(36)
     assert r.next() == "additive"
-    r.record(25)  # 350 < 360: accepted
+    r.record(27)  # 351 < 360: accepted
     assert r.state == 2 and r.next() == "additive"
-    r.record(29)  # 406 < 1.15 x 360 = 414: stays (hysteresis)
+    r.record(31)  # 403 < 1.15 x 360 = 414: stays (hysteresis)
     assert r.next() == "additive"
-    r.record(30)  # 420 >= 414: handed back
+    r.record(32)  # 416 >= 414: handed back
     assert r.next() == "jacobi" and r.backoff == 2
     # a handle that shares the device is charged for the part of the chip its launch blocks: a trial that cannot win is skipped
     s = oracle.AutoCostRule(units_jacobi=24, units_additive=65)
