@@ -229,7 +229,11 @@ int launch_rtr_persistent(dpgo_problem_s* p, const dpgo_ropt_params* prm, const 
   // groups per pose, 7.3 / 6.5 / 7.0 / 7.6 / 8.3; 6 250 poses, 196 workgroups of the same layout with two tiles, 10.9 / 9.9 /
   // 9.9 / 10.5 / 11.1; 12.5k slab, one pose per (d+1) lanes, 12.0 / 10.9 / 10.7 / 10.5 / 10.4)
   const int first = env_first >= 0 ? std::min(255, env_first)
-                                   : (p->persist_split == 4 ? (p->persist_wgs <= 160 ? kPollFirstSleep : 30) : 44);
+                                   : (p->persist_split == 4 ? (p->persist_wgs <= 160 ? kPollFirstSleep : 30) : 32);
+  // (one pose per (d+1) lanes: 44 until round 6; with the phases that round shortened -- own tiles from LDS, 16-byte cells --
+  // the sweep over 12 / 20 / 28 / 36 / 44 / 52 has its best at 28-36: slab additive 17.1 / 15.7 / 14.6 / 14.7 / 15.0 / 15.3,
+  // block-Jacobi 10.5 / 9.9 / 9.6 / 9.6 / 9.7 / 9.7, torus3D additive 17.1 / 15.5 / 15.0 / 14.8 / 15.2 / 15.7 us per product;
+  // tools/r6/poll_first_sweep.sh)
   const int between = env_sleep >= 0 ? std::min(255, env_sleep) : kPollSleep;
   // (a reduction that also carries the additive preconditioner's payload -- 2 (d+1) r more granules per participant --
   // completes later: its first sweep waits longer; 0 in the argument = as the plain one)
