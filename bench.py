@@ -648,6 +648,8 @@ def compact_line(out):
         if g:
             cpu["gpu_same_work"] = {"seconds_per_sweep": g.get("seconds_per_sweep"), "tcg_iterations": g.get("tcg_iterations"),
                                     "preconditioners": g.get("preconditioners"), "gradnorm_after": g.get("gradnorm_after"),
+                                    # (one timing per block on a fresh handle: the median is the figure, the max shows outliers)
+                                    "hierarchy_setup_ms_median": sorted(hs["first_ms"])[len(hs["first_ms"]) // 2] if hs.get("first_ms") else None,
                                     "hierarchy_setup_ms_max": max(hs["first_ms"]) if hs.get("first_ms") else None}
     kit = out.get("kitti_gnc")
     kitti = None

@@ -391,3 +391,92 @@ int dpgo_bench_iteration_kernels(dpgo_problem_t p, int reps, int warmup, double 
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------------------------------------
+// Test probe of the one-launch solve's communication primitives (kernels/persist.h, kernels/common.h), without a solve
+// around them: `steps` chip-wide reductions of K = 2 partial sums, each carrying a payload of PAY doubles per workgroup
+// (chip_allreduce<2, PAY>), and the wavefront reduce-scatter the additive preconditioner's coarse solve uses
+// (wave_reduce_rows).  tests/test_parity_gpu.py::test_in_kernel_reduction_primitives.
+namespace dpgo {
+template <int PAY>
+__global__ __launch_bounds__(kBlock, 1) void k_probe_allreduce(unsigned long long* gran, unsigned salt, int steps,
+                                                               const double* __restrict__ in, const double* __restrict__ pay_in,
+                                                               double* __restrict__ sums, double* __restrict__ pay_out,
+                                                               double* __restrict__ rows_out, int* error, int poll) {
+  constexpr int TP = (PAY + 3) / 4 * 4;
+  __shared__ double red[2 * 2 * kWaves * kGranVals];
+  __shared__ double tw_s[kWaves][PAY];
+  __shared__ int ok_s;
+  const int rank = blockIdx.x, members = gridDim.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (threadIdx.x == 0) ok_s = 1;
+  unsigned step = 0;
+  for (int s = 0; s < steps; ++s) {
+    double part[2], got[PAY];
+    part[0] = in[((size_t)rank * kBlock + threadIdx.x) * 2 + 0] * (s + 1);
+    part[1] = in[((size_t)rank * kBlock + threadIdx.x) * 2 + 1] - s;
+    if (lane < PAY) tw_s[wave][lane] = pay_in[((size_t)rank * kWaves + wave) * PAY + lane] + s;
+    if (!chip_allreduce<2, PAY>(gran, rank, members, salt, step, part, red, error, &ok_s, poll, &tw_s[0][0], got)) return;
+    if (threadIdx.x == 0) {
+      sums[((size_t)rank * steps + s) * 2 + 0] = part[0];
+      sums[((size_t)rank * steps + s) * 2 + 1] = part[1];
+    }
+    if ((int)threadIdx.x < members) {
+#pragma unroll
+      for (int e = 0; e < PAY; ++e) pay_out[(((size_t)rank * steps + s) * members + threadIdx.x) * PAY + e] = got[e];
+    }
+    __syncthreads();  // (tw_s is rewritten by the next step)
+  }
+  // reduce-scatter of PAY values over every wavefront: value e of thread t = in[t][0] * (e + 1) + in[t][1]
+  double v[TP], rs[TP / 4];
+#pragma unroll
+  for (int e = 0; e < TP; ++e)
+    v[e] = e < PAY ? in[((size_t)rank * kBlock + threadIdx.x) * 2] * (e + 1) + in[((size_t)rank * kBlock + threadIdx.x) * 2 + 1] : 0.0;
+  wave_reduce_rows<TP>(v, rs);
+  if ((threadIdx.x & 15) == 15) {
+    const int q = wave_rows_value(lane);
+#pragma unroll
+    for (int j = 0; j < TP / 4; ++j)
+      if (4 * j + q < PAY) rows_out[((size_t)rank * kWaves + wave) * PAY + 4 * j + q] = rs[j];
+  }
+}
+}  // namespace dpgo
+
+extern "C" int dpgo_debug_reduction_primitives(int workgroups, int pay, int steps, const double* in_dev, const double* pay_in_dev,
+                                               double* sums_dev, double* pay_out_dev, double* rows_out_dev) {
+  using namespace dpgo;
+  if (workgroups < 1 || workgroups > kPersistMax || steps < 1 || !in_dev || !pay_in_dev || !sums_dev || !pay_out_dev || !rows_out_dev)
+    return fail(DPGO_ERR_INVALID, "bad arguments");
+  int device = 0, cus = 0;
+  HIPC(hipGetDevice(&device));
+  HIPC(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device));
+  if (workgroups > cus) return fail(DPGO_ERR_INVALID, "more workgroups than the device holds at once");
+  unsigned long long* gran = nullptr;
+  int* error = nullptr;
+  HIPC(hipMalloc(&gran, sizeof(unsigned long long) * kGranWords));
+  HIPC(hipMalloc(&error, sizeof(int)));
+  HIPC(hipMemset(gran, 0, sizeof(unsigned long long) * kGranWords));
+  HIPC(hipMemset(error, 0, sizeof(int)));
+  const unsigned salt = 5u << 20;
+  const int poll = (kPollFirstSleep << 8) | kPollSleep;
+  switch (pay) {
+#define CASE_(P)                                                                                                         \
+  case P:                                                                                                                \
+    hipLaunchKernelGGL((k_probe_allreduce<P>), dim3(workgroups), dim3(kBlock), 0, nullptr, gran, salt, steps, in_dev,   \
+                       pay_in_dev, sums_dev, pay_out_dev, rows_out_dev, error, poll);                                    \
+    break;
+    CASE_(6) CASE_(9) CASE_(15) CASE_(20) CASE_(24)
+#undef CASE_
+    default:
+      (void)hipFree(gran);
+      (void)hipFree(error);
+      return fail(DPGO_ERR_UNSUPPORTED, "payload size: one of 6, 9, 15, 20, 24");
+  }
+  HIPC(hipGetLastError());
+  HIPC(hipDeviceSynchronize());
+  int herr = 0;
+  HIPC(hipMemcpy(&herr, error, sizeof(int), hipMemcpyDeviceToHost));
+  (void)hipFree(gran);
+  (void)hipFree(error);
+  if (herr) return fail(DPGO_ERR_HIP, "a reduction timed out");
+  return DPGO_OK;
+}

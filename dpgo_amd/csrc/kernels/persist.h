@@ -13,6 +13,10 @@
 //            delta <- beta delta - z,  H delta <- beta H delta - Hz,  partial <delta, H delta>          | all-reduce
 //   phase B: alpha / boundary test;  eta += alpha delta,  r += alpha H delta,  z = proj_X(r Dinv),
 //            partials <r,r>, <z,r>                                                                       | all-reduce
+//   (the additive two-level preconditioner, ADD below, keeps this shape since round 6: the restriction of H delta rides
+//    on the first reduction as a payload, the coarse solve and the prolongation sit in phase B)
+// * The gather of phase A takes the poses of the workgroup's OWN tiles from the LDS tiles phase B wrote (layouts with
+//   64-pose tiles, persist_local) and crosses the chip only for the others.
 // * Every tCG vector of the workgroup's rows (r, eta, delta, H delta, z, and S, Dinv, the row's column indices and block
 //   columns of Q) lives in REGISTERS for the whole launch -- one lane = one column of one pose, as everywhere; the iterate,
 //   the trial point and the two gradients are LDS tiles; only the columns of a pose meet through a wave-private LDS tile.

@@ -158,6 +158,7 @@ SIGNATURES = {
                           C.POINTER(_I), _P, _P, _P], _I),
     "dpgo_build_G_coupling": ([_I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
                                C.POINTER(_I), _P, _P, _P], _I),
+    "dpgo_debug_reduction_primitives": ([_I, _I, _I, _P, _P, _P, _P, _P], _I),
 }
 
 _lib: Optional[C.CDLL] = None

@@ -439,6 +439,17 @@ int dpgo_bench_hess_rotating(dpgo_problem_t h, int nsets, int reps, int warmup, 
  * (all restrictions, dense level, all post-smoothing launches) as launched per iteration. */
 int dpgo_bench_iteration_kernels(dpgo_problem_t h, int reps, int warmup, double out_ms[5]);
 
+/* Test probe (no reference counterpart): the communication primitives of the one-launch solve alone.  `workgroups`
+ * (<= the device's CUs, <= 256) run `steps` chip-wide reductions of two partial sums per thread -- in_dev
+ * [workgroups][256][2]: step s reduces in[..][0] * (s + 1) and in[..][1] - s -- each carrying a payload of `pay`
+ * (6, 9, 15, 20 or 24) doubles per workgroup, the per-wave parts pay_in_dev [workgroups][4][pay] (+ s) added in wave
+ * order.  sums_dev [workgroups][steps][2]: what every workgroup's thread 0 holds afterwards (identical bits in all of
+ * them); pay_out_dev [workgroups][steps][workgroups][pay]: participant t's payload as thread t of every workgroup
+ * received it; rows_out_dev [workgroups][4][pay]: the wavefront sums of value e = in[t][0] (e + 1) + in[t][1] over the 64
+ * lanes of each wave by the reduce-scatter wave_reduce_rows.  Synchronous, default stream. */
+int dpgo_debug_reduction_primitives(int workgroups, int pay, int steps, const double* in_dev, const double* pay_in_dev,
+                                    double* sums_dev, double* pay_out_dev, double* rows_out_dev);
+
 /* One-launch solve (kernels/persist.h, k_rtr_persist): for blocks in the latency regime (every block the kernel can hold:
  * <= 32 768 poses in 3-D; environment DPGO_PERSIST_MAX_POSES lowers the limit) with the block-Jacobi, additive or no
  * preconditioner, dpgo_optimize* runs the WHOLE local solve -- initial statistics, every RTR iteration's tCG_TR loop,

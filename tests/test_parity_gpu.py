@@ -139,6 +139,46 @@ def test_manifold_ops_match_oracle(oracle, d, r, n):
     assert np.abs(Yr @ np.swapaxes(Yr, 1, 2) - np.eye(d)).max() <= 1e-12
 
 
+@pytest.mark.parametrize("workgroups,pay", [(196, 20), (157, 20), (64, 9), (256, 24), (40, 15), (7, 6)])
+def test_in_kernel_reduction_primitives(workgroups, pay):
+    """The communication primitives of the one-launch solve on their own (dpgo_debug_reduction_primitives; no reference
+    counterpart: they stand in for ROPTLIB's serial dot products inside tCG_TR).  chip_allreduce<2, PAY>: three chip-wide
+    reductions of two sums over 256 threads x `workgroups`, each carrying a payload of PAY = (d+1) r doubles per workgroup
+    -- the all-gather the additive preconditioner's restricted vectors ride on (round 6): every workgroup ends with the
+    SAME bits, the sums agree with numpy, and thread t of every workgroup holds participant t's payload exactly (the
+    per-wave parts added in wave order).  wave_reduce_rows: the reduce-scatter of PAY values over a wavefront
+    (v_permlane32_swap / v_permlane16_swap pair folds + DPP row shifts) against numpy, every value in its place."""
+    import torch
+    import dpgo_amd.lib as L
+    lib = L.load()
+    if workgroups > torch.cuda.get_device_properties(0).multi_processor_count:
+        pytest.skip("needs %d compute units" % workgroups)
+    rng = np.random.default_rng(workgroups * 100 + pay)
+    steps = 3
+    a = rng.standard_normal((workgroups, 256, 2))
+    pw = rng.standard_normal((workgroups, 4, pay))
+    dev = lambda x: torch.from_numpy(np.ascontiguousarray(x)).cuda()  # noqa: E731
+    a_d, pw_d = dev(a), dev(pw)
+    sums = torch.zeros((workgroups, steps, 2), dtype=torch.float64, device="cuda")
+    pout = torch.zeros((workgroups, steps, workgroups, pay), dtype=torch.float64, device="cuda")
+    rows = torch.zeros((workgroups, 4, pay), dtype=torch.float64, device="cuda")
+    torch.cuda.synchronize()
+    L.check(lib.dpgo_debug_reduction_primitives(workgroups, pay, steps, L.ptr(a_d), L.ptr(pw_d), L.ptr(sums), L.ptr(pout),
+                                                 L.ptr(rows)))
+    sums, pout, rows = sums.cpu().numpy(), pout.cpu().numpy(), rows.cpu().numpy()
+    for s in range(steps):
+        want = np.array([(a[:, :, 0] * (s + 1)).sum(), (a[:, :, 1] - s).sum()])
+        assert np.abs(sums[0, s] - want).max() <= 1e-11 * (np.abs(a).sum() + steps * a[:, :, 0].size)
+        assert (sums[:, s] == sums[0, s]).all()  # identical bits in every workgroup
+        p = pw + s
+        gathered = ((p[:, 0] + p[:, 1]) + p[:, 2]) + p[:, 3]  # the waves in order
+        assert (pout[:, s] == gathered[None]).all()
+    e = np.arange(1, pay + 1)[None, None, :]
+    v = a[:, :, 0:1] * e + a[:, :, 1:2]                       # [workgroups][256][pay]
+    want_rows = v.reshape(workgroups, 4, 64, pay).sum(axis=2)
+    assert np.abs(rows - want_rows).max() <= 1e-12 * np.abs(v).reshape(workgroups, 4, 64, pay).sum(axis=2).max()
+
+
 def test_polar_projection_of_rank_deficient_blocks_is_finite(oracle):
     """LiftedSEManifold::project on blocks without full column rank (a zero block, a rank-1 block, a block with two
     parallel columns): the reference's JacobiSVD U V^T (src/DPGO_utils.cpp:480-486) stays finite there; so does the
