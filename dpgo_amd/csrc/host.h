@@ -386,6 +386,7 @@ struct dpgo_problem_s {
     dpgo_ropt_result result{};
   } pending;
   PersistCtrl* pctrl = nullptr;
+  bool pctrl_dirty = true;  // the control block has to be cleared in front of the next one-launch solve (creation, after a time-out)
   unsigned long long* pgran = nullptr;  // granule table of the in-kernel all-reduce (kGranWords 8-byte words)
   unsigned gran_cleared_at = 0;         // value of `gen` when the table was last cleared
   PersistCtrl* hctrl = nullptr;  // pinned

@@ -1221,7 +1221,7 @@ __global__ __launch_bounds__(kBlock, 1) void k_rtr_persist(BsrDev Q, double* X, 
     store_state(sout, st);
     store_state(sout + 1, st);
     publish_progress(hflag, gen, st);
-    ctrl->iters += iters;  // (zeroed by the host once per solve)
+    ctrl->iters = iters;
     ctrl->members = (unsigned)members;
 #pragma unroll
     for (int q = 0; q < 5; ++q) ctrl->ticks[q] = tk[q];

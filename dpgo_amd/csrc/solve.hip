@@ -215,7 +215,12 @@ int launch_rtr_persistent(dpgo_problem_s* p, const dpgo_ropt_params* prm, const 
   }
   // (the granules' epochs are salted per launch, so what earlier launches left in the table never matches; the table is
   // cleared before a salt can repeat -- every 2047 generations of this handle -- and at creation)
-  HIPC(hipMemsetAsync(p->pctrl, 0, sizeof(PersistCtrl), p->stream));
+  // (the control block: every field but `error` is assigned by the launch, and `error` is zero unless a launch of this
+  // handle timed out -- cleared at creation and behind such a launch only, not by a fill kernel in front of every solve)
+  if (p->pctrl_dirty) {
+    HIPC(hipMemsetAsync(p->pctrl, 0, sizeof(PersistCtrl), p->stream));
+    p->pctrl_dirty = false;
+  }
   if (p->gen - p->gran_cleared_at >= 0x7ffu) {  // (the multi-launch scheme advances `gen` too: count, do not test bits)
     HIPC(hipMemsetAsync(p->pgran, 0, sizeof(unsigned long long) * kGranWords, p->stream));
     p->gran_cleared_at = p->gen;
@@ -710,6 +715,7 @@ int run_optimize(dpgo_problem_s* p, const dpgo_ropt_params* prm, dpgo_ropt_resul
       // a time-out (the launch's workgroups were not all resident: another process on the device): the caller's iterate is
       // untouched; this handle stops using the kernel and the solve runs on the multi-launch scheme
       p->persist_failed_once = true;
+      p->pctrl_dirty = true;
       persist_release(p);
       if (options().persist_verbose)
         std::fprintf(stderr, "dpgo_hip: persistent solve timed out; this handle continues with the multi-launch scheme\n");
