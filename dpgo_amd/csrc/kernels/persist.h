@@ -425,6 +425,7 @@ __global__ __launch_bounds__(kBlock, 1) void k_rtr_persist(BsrDev Q, double* X, 
   extern __shared__ double Ms[];
 
   const int rank = blockIdx.x, members = gridDim.x;
+  const unsigned long long t_entry = wall_clock64();  // (diagnostic timeline, PersistCtrl::ticks[5..7])
   if (threadIdx.x == 0) ok_s = 1;  // (ordered before its first use by the barriers of the first all-reduce)
   DevState st;
   unsigned step = 0;
@@ -953,7 +954,10 @@ __global__ __launch_bounds__(kBlock, 1) void k_rtr_persist(BsrDev Q, double* X, 
     st.min_inner = 0;
   }
   unsigned iters = 0;
-  unsigned long long tk[5] = {0, 0, 0, 0, 0};
+  // [5] kernel entry -> initial statistics reduced  [6] first updates (r0 = g, z0) of the outer iterations, summed
+  // [7] retraction, trial point, H eta, rho test of the outer iterations, summed
+  unsigned long long tk[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  tk[5] = wall_clock64() - t_entry;
   bool moved = false;  // an accepted step: X has to be written back
 
   // ==== SolversTR::Run: outer iterations
@@ -1015,7 +1019,11 @@ __global__ __launch_bounds__(kBlock, 1) void k_rtr_persist(BsrDev Q, double* X, 
       return chip_allreduce<2>(gran, rank, members, salt, step, pr, red, &ctrl->error, &ok_s, poll);
     }
   };
-  alive = update_and_reduce(true, 0.0);
+  {
+    const unsigned long long tu = wall_clock64();
+    alive = update_and_reduce(true, 0.0);
+    tk[6] += wall_clock64() - tu;
+  }
   if (alive) {
     st.norm_r0 = sqrt(pr[0]);
     st.z_r = pr[1];
@@ -1088,6 +1096,7 @@ __global__ __launch_bounds__(kBlock, 1) void k_rtr_persist(BsrDev Q, double* X, 
 
   // ---- retraction x2 = R_x1(eta) (k_retract: qf of Y + eta, p + eta); x2 and eta are published for the two gathers
   // below; the x2 tiles take the place of z in LDS (z is dead until the next tCG run)
+  const unsigned long long t_tail = wall_clock64();
   double p1[1] = {0.0};  // <eta, g1>
 #pragma unroll
   for (int k = 0; k < MT; ++k) {
@@ -1199,6 +1208,7 @@ __global__ __launch_bounds__(kBlock, 1) void k_rtr_persist(BsrDev Q, double* X, 
       wave_sync();
     }
   }
+  tk[7] += wall_clock64() - t_tail;
   }  // outer iterations
 
   // ==== hand the result back: the state record, and the iterate (own columns) into the trial-point buffer -- every
@@ -1224,7 +1234,7 @@ __global__ __launch_bounds__(kBlock, 1) void k_rtr_persist(BsrDev Q, double* X, 
     ctrl->iters = iters;
     ctrl->members = (unsigned)members;
 #pragma unroll
-    for (int q = 0; q < 5; ++q) ctrl->ticks[q] = tk[q];
+    for (int q = 0; q < 8; ++q) ctrl->ticks[q] = tk[q];
   }
 }
 

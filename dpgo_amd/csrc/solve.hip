@@ -304,10 +304,12 @@ void persist_report(dpgo_problem_s* p) {  // (hctrl has been read back with the 
   const double it = std::max<double>(1.0, (double)p->hctrl->ticks[4]);
   std::fprintf(stderr,
                "dpgo_hip: persistent tCG: %u workgroups (%d lane groups per pose, %d tiles each)%s, %u iterations; per "
-               "iteration (us): Hessian phase %.2f, all-reduce %.2f, update phase %.2f, all-reduce %.2f\n",
+               "iteration (us): Hessian phase %.2f, all-reduce %.2f, update phase %.2f, all-reduce %.2f; per solve (us): "
+               "set-up + initial statistics %.1f, first updates %.1f, retraction / trial point / rho test %.1f\n",
                p->hctrl->members, p->persist_split, p->persist_mt, p->hctrl->error ? " TIMED OUT" : "", p->hctrl->iters,
                0.01 * (double)p->hctrl->ticks[0] / it, 0.01 * (double)p->hctrl->ticks[1] / it,
-               0.01 * (double)p->hctrl->ticks[2] / it, 0.01 * (double)p->hctrl->ticks[3] / it);
+               0.01 * (double)p->hctrl->ticks[2] / it, 0.01 * (double)p->hctrl->ticks[3] / it,
+               0.01 * (double)p->hctrl->ticks[5], 0.01 * (double)p->hctrl->ticks[6], 0.01 * (double)p->hctrl->ticks[7]);
 }
 
 // ---- one steady tCG iteration as an instantiated hipGraph (dpgo_problem_s::IterGraph) ----
