@@ -415,6 +415,9 @@ __global__ __launch_bounds__(kBlock, 1) void k_rtr_persist(BsrDev Q, double* X, 
   // Riemannian gradient at the current iterate and at the trial point (touched once per outer iteration, each lane its own
   // column: kept out of the registers the tCG loop needs)
   __shared__ __attribute__((aligned(16))) double G1s[MT][P][T], G2s[MT][P][T];
+  // (own-tile gathers, persist_local: the step eta of the workgroup's poses, for the H eta gather of the rho test)
+  constexpr bool kLoc = persist_local<SPLIT>();
+  __shared__ __attribute__((aligned(16))) double Es[kLoc ? MT : 1][kLoc ? P : 1][kLoc ? T : 1];
   __shared__ __attribute__((aligned(16))) double ex[2][kWaves][G][T];
   __shared__ double red[2 * 2 * kWaves * kGranVals];
   __shared__ int ok_s;
@@ -877,15 +880,18 @@ __global__ __launch_bounds__(kBlock, 1) void k_rtr_persist(BsrDev Q, double* X, 
   // ---- cost and Riemannian gradient (k_grad) at the point whose tiles are in LDS (Yt) and in memory behind `ry`:
   // partials [0] sum(YQ . Y)  [1] sum(Y . G)  [2] |rgrad|^2; rg = the gradient's own column, s = this lane's row of
   // S = sym(Y^T EG) (ROPTLIB caches it for the Hessian)
+  // (the point's tiles Yt are complete and ordered by a workgroup barrier when this runs: the gather takes the
+  // workgroup's own poses from them, as tCG's does)
   auto phase_grad = [&](__amdgpu_buffer_rsrc_t ry, const double (&Yt)[MT][P][T], double (&part)[3], double (&rg)[MT][P][T],
                         double (&sr)[MT][D]) {
     part[0] = part[1] = part[2] = 0.0;
+    const double* own_y = kLoc ? &Yt[0][0][0] : nullptr;
 #pragma unroll
     for (int k = 0; k < MT; ++k) {
       double eg[R];
       {
         double xc[GG::NB][R], qc[GG::NB][B];
-        gather_issue<D, R, SPLIT, QRES>(go[k], Q, ry, L.s, L.c, xc, qc);
+        gather_issue<D, R, SPLIT, QRES>(go[k], Q, ry, L.s, L.c, xc, qc, own_y);
         gather_finish<D, R, SPLIT, QRES>(go[k], Q, ry, L.s, L.c, xc, qc, eg);
       }
       if (rank + k * members >= ntiles) continue;  // workgroup-uniform (the gather above is wave-cooperative)
@@ -924,6 +930,7 @@ __global__ __launch_bounds__(kBlock, 1) void k_rtr_persist(BsrDev Q, double* X, 
   bool alive = true;
   {
     double p3[3];
+    if constexpr (kLoc) __syncthreads();  // (the X tiles of all waves are in LDS: the gather below reads other waves' rows)
     phase_grad(rX, Xs, p3, G1s, srow);
     alive = chip_allreduce<3>(gran, rank, members, salt, step, p3, red, &ctrl->error, &ok_s, poll);
     st.f1 = 0.5 * p3[0] + p3[1];
@@ -1115,6 +1122,7 @@ __global__ __launch_bounds__(kBlock, 1) void k_rtr_persist(BsrDev Q, double* X, 
       qf_col<D, R>(&ex[0][L.wave][L.g][0], L.c, a2);
       store_col<R>(&Zs[k][lp][co], a2);
       store_col<R>(&ex[1][L.wave][L.g][co], ee[k]);
+      if constexpr (kLoc) store_col<R>(&Es[k][lp][co], ee[k]);
     }
     publish_tile(xbuf, rx2, &Zs[k][L.wave * G][0], rank + k * members, k, a2);
     publish_tile(ebuf, reta, &ex[1][L.wave][0][0], rank + k * members, k, ee[k]);
@@ -1139,7 +1147,7 @@ __global__ __launch_bounds__(kBlock, 1) void k_rtr_persist(BsrDev Q, double* X, 
     double h[R];
     {
       double xc[GG::NB][R], qc[GG::NB][B];
-      gather_issue<D, R, SPLIT, QRES>(go[k], Q, reta, L.s, L.c, xc, qc);
+      gather_issue<D, R, SPLIT, QRES>(go[k], Q, reta, L.s, L.c, xc, qc, kLoc ? &Es[0][0][0] : nullptr);
       gather_finish<D, R, SPLIT, QRES>(go[k], Q, reta, L.s, L.c, xc, qc, h);
     }
     if (rank + k * members >= ntiles) continue;
