@@ -475,8 +475,9 @@ __global__ __launch_bounds__(kBlock, 1) void k_rtr_persist(BsrDev Q, double* X, 
         const int j = go[k].j[m];
         int lc = -1;
         if constexpr (ADD) {
-          if (add.lab) {
-            if (add.lab[j] == rank) lc = add.mem_pos[j] - add.agg_ptr[rank];
+          if (add.lab) {  // (both lookups issued together: one round trip)
+            const int la = add.lab[j], mp = add.mem_pos[j];
+            if (la == rank) lc = mp - add.agg_ptr[rank];
           } else if (j / P == rank) {
             lc = j - rank * P;
           }
@@ -518,10 +519,24 @@ __global__ __launch_bounds__(kBlock, 1) void k_rtr_persist(BsrDev Q, double* X, 
       prow[cc] = own[0] ? add.Pb[(size_t)pose[0] * BB + L.c * B + cc] : 0.0;
     }
     if (rank < ntiles) {
-      for (int e = threadIdx.x; e < B * Nc; e += kBlock) {
-        const int row = e / Nc, j = e - row * Nc;
-        Ms[e] = add.Minv[(size_t)(rank * B + row) * add.lda + j];
-      }
+      // (all of a thread's loads in flight together -- Nc <= kPersistMax (D+1): at most D+1 per row -- instead of one
+      // dependent round trip per element: the additive form's set-up was 9 us longer than block-Jacobi's)
+      constexpr int NJ = (kPersistMax * B + kBlock - 1) / kBlock;
+      double mv[B][NJ];
+#pragma unroll
+      for (int row = 0; row < B; ++row)
+#pragma unroll
+        for (int q = 0; q < NJ; ++q) {
+          const int j = (int)threadIdx.x + q * kBlock;
+          mv[row][q] = j < Nc ? add.Minv[(size_t)(rank * B + row) * add.lda + j] : 0.0;
+        }
+#pragma unroll
+      for (int row = 0; row < B; ++row)
+#pragma unroll
+        for (int q = 0; q < NJ; ++q) {
+          const int j = (int)threadIdx.x + q * kBlock;
+          if (j < Nc) Ms[row * Nc + j] = mv[row][q];
+        }
     }
     __syncthreads();
   }
