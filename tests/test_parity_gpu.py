@@ -179,6 +179,59 @@ def test_in_kernel_reduction_primitives(workgroups, pay):
     assert np.abs(rows - want_rows).max() <= 1e-12 * np.abs(v).reshape(workgroups, 4, 64, pay).sum(axis=2).max()
 
 
+@pytest.mark.parametrize("name,precond", [("sphere2500", "additive"), ("grid:25x25x10", "additive"), ("grid:25x25x10", "jacobi")])
+def test_one_launch_solve_does_not_depend_on_timing(oracle, name, precond):
+    """The in-kernel reductions of the one-launch solve add their operands in a fixed order whatever arrives first
+    (kernels/persist.h, chip_allreduce: thread t sweeps participant t, fixed trees) -- also the one that carries the
+    additive preconditioner's payload, and the gathers that take the workgroup's own tiles from LDS read what the memory
+    copy holds.  So WHEN a sweep looks must not change a bit: three optimize calls with the polling knobs at their
+    defaults, polling at once (DPGO_POLL_FIRST = DPGO_POLL_FIRST_PAY = 0, DPGO_POLL_SLEEP = 0) and late (90 / 120 / 7)
+    leave bitwise the same iterates and result records.  (What ROPTLIB guarantees trivially with serial dot products.)"""
+    import hashlib
+    import torch
+    import dpgo_amd
+    r = 5
+    if name.startswith("grid:"):
+        om, n, Ttrue = oracle.synthetic_grid(*[int(v) for v in name[5:].split("x")], seed=0)
+        X0 = oracle.lift(oracle.perturbed_truth(Ttrue, seed=2), r)
+    else:
+        om, n = oracle.read_g2o(os.path.join(DATA, name + ".g2o"))
+        X0 = oracle.lift(oracle.chordal_initialization(om, n), r)
+    d = om.d
+    lib = dpgo_amd.lib.load()
+    knobs = ("DPGO_POLL_FIRST", "DPGO_POLL_FIRST_PAY", "DPGO_POLL_SLEEP")
+    saved = {k: os.environ.get(k) for k in knobs}
+    digests = []
+    try:
+        for sw in ({}, {"DPGO_POLL_FIRST": "0", "DPGO_POLL_FIRST_PAY": "0", "DPGO_POLL_SLEEP": "0"},
+                   {"DPGO_POLL_FIRST": "90", "DPGO_POLL_FIRST_PAY": "120", "DPGO_POLL_SLEEP": "7"}):
+            for k in knobs:
+                os.environ.pop(k, None)
+            os.environ.update(sw)
+            dpgo_amd.lib.check(lib.dpgo_options_reload())
+            pg = dpgo_amd.PoseGraph(0, r, d)
+            pg.setMeasurements(to_product_measurements(om))
+            prob = dpgo_amd.QuadraticProblem(pg)
+            opt = dpgo_amd.QuadraticOptimizer(prob, dpgo_amd.ROptParameters(precond=precond))
+            Xd = torch.tensor(X0, device="cuda", dtype=torch.float64)
+            h = hashlib.sha256()
+            for call in range(3):
+                res = opt.optimizeDevice(Xd)
+                assert res.precond_used == precond and prob.persistentInfo()["last_members"] > 0, (sw, res)
+                h.update(Xd.cpu().numpy().tobytes())
+                h.update(repr((res.tcg_iterations, res.rtr_iterations, res.tCGStatus, res.fOpt, res.gradNormOpt)).encode())
+            digests.append(h.hexdigest())
+            del opt, prob
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+        lib.dpgo_options_reload()
+    assert digests[0] == digests[1] == digests[2], digests
+
+
 def test_polar_projection_of_rank_deficient_blocks_is_finite(oracle):
     """LiftedSEManifold::project on blocks without full column rank (a zero block, a rank-1 block, a block with two
     parallel columns): the reference's JacobiSVD U V^T (src/DPGO_utils.cpp:480-486) stays finite there; so does the
