@@ -539,7 +539,12 @@ int auto_units_jacobi(dpgo_problem_s* p) {
   const PersistGeo g = persist_geometry(p, limit, share, false);
   if (g.wgs <= 0) return kAutoUnitsJacobi;
   const double part = std::max((double)g.slots / limit, 1.0 / share);
-  return std::max(1, (int)std::lround(kAutoUnitsJacobi * (g.mt == 2 ? 1.25 : 1.0) * part * share));
+  // (two tiles per workgroup cost 1.25x per product with 4 lane groups per pose; with one pose per (d+1) lanes -- the
+  // 12 500-pose slabs -- that variant keeps 512 registers and spills: measured under sharing 22 us per product against
+  // 9.4 alone, i.e. two such solves side by side gain nothing over one after the other: 2.1x.  Round 6, loop-back sweeps
+  // 8 x 12 500: forced block-Jacobi 3.81 ms, forced additive 3.05 ms, the rule with 1.25x here 3.72 ms -- a mix.)
+  const double two_tiles = g.mt == 2 ? (g.split == 1 ? 2.1 : 1.25) : 1.0;
+  return std::max(1, (int)std::lround(kAutoUnitsJacobi * two_tiles * part * share));
 }
 int auto_units_additive(dpgo_problem_s* p) {  // (after additive_available(p): the plan exists)
   const int share = std::max(1, p->persist_share);
