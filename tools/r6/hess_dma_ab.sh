@@ -1,7 +1,7 @@
 #!/bin/bash
-# A/B of the LDS-DMA variants of the symmetric-storage tCG-step kernel (DPGO_HESS_DMA = 0 / 1 / 2, one library, one box):
+# A/B of the LDS-DMA variants of the symmetric-storage tCG-step kernel (DPGO_HESS_DMA = 0 / 1 / 2 / 3: MODES="0 1 3"; one library, one box):
 # rotating-operand launch time, back-to-back launch time, loop time per product.  usage: bash tools/r6/hess_dma_ab.sh [reps]
-for rep in $(seq 1 ${1:-3}); do for mode in 0 1 2; do
+for rep in $(seq 1 ${1:-3}); do for mode in ${MODES:-0 1 2}; do
 DPGO_HESS_DMA=$mode timeout 300 python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-secondary 2>/dev/null | grep '^DETAIL {' | tail -1 | cut -c8- > /tmp/b.json
 python - <<PY
 import json
